@@ -1,0 +1,255 @@
+/*
+ * teloscan.h — C-ABI of libteloscan.so: the MI355X (gfx950) implementation of
+ * Teloscope's telomeric-motif scan path.
+ *
+ * This is the drop-in boundary.  The reference has no plugin registry; the seam
+ * is two C++ member functions,
+ *
+ *     SegmentData Teloscope::scanSegment(std::string&, uint64_t absPos, bool tipsOnly);
+ *                                                   (include/teloscope.h:260, src/teloscope.cpp:537)
+ *     bool        ReadTelomereFilter::matches(std::string);
+ *                                                   (include/read-filter.h:16, src/read-filter.cpp:37)
+ *
+ * and every entry point below names the reference interface it replaces.
+ * Plain pointers and sizes only; no C++ or torch types.  All functions that
+ * return int return TS_OK (0) or a negative ts_status; ts_last_error() gives
+ * the text.  The library never calls exit().
+ *
+ * There is no CPU fallback: if no HIP device is usable, ts_create() fails
+ * with TS_ERR_NO_DEVICE.
+ */
+#ifndef TELOSCAN_H
+#define TELOSCAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TELOSCAN_ABI_VERSION 1
+
+typedef enum ts_status {
+    TS_OK               =  0,
+    TS_ERR_INVALID_ARG  = -1,
+    TS_ERR_NO_DEVICE    = -2,   /* no usable HIP device (no CPU fallback exists) */
+    TS_ERR_HIP          = -3,   /* a HIP runtime call failed */
+    TS_ERR_ALLOC        = -4,
+    TS_ERR_UNSUPPORTED  = -5,   /* parameter set outside what the kernels implement */
+    TS_ERR_STATE        = -6
+} ts_status;
+
+/* ScaffoldType, include/tools.h:13-19 (same enumerator order). */
+typedef enum ts_scaffold_type {
+    TS_T2T = 0, TS_GAPPED_T2T, TS_MISASSEMBLY, TS_GAPPED_MISASSEMBLY,
+    TS_INCOMPLETE, TS_GAPPED_INCOMPLETE, TS_NONE, TS_GAPPED_NONE,
+    TS_DISCORDANT, TS_GAPPED_DISCORDANT
+} ts_scaffold_type;
+
+/* One expanded search pattern = one element of UserInputTeloscope::patternInfo
+ * plus the isCanonical flag the Teloscope ctor derives (include/teloscope.h:241-247). */
+typedef struct ts_pattern {
+    char    seq[64];        /* NUL-terminated, A/C/G/T only */
+    uint8_t len;
+    uint8_t is_forward;
+    uint8_t is_canonical;
+    uint8_t reserved;
+} ts_pattern;
+
+/* The fields of UserInputTeloscope (include/input.h:15-64) the scan path reads. */
+typedef struct ts_params {
+    uint32_t struct_size;        /* = sizeof(ts_params), for ABI growth */
+    uint32_t window_size;        /* -w, default 1000 */
+    uint32_t step;               /* -s, default 1000, must be <= window_size */
+    uint32_t terminal_limit;     /* -t, default 50000 */
+    uint16_t max_match_dist;     /* -k, default 50 */
+    uint16_t min_block_len;      /* -l, default 300 */
+    uint16_t max_block_dist;     /* -d, default 500 */
+    uint16_t min_block_counts;   /* default 2 */
+    float    min_block_density;  /* -y, default 0.5 */
+    uint16_t canonical_size;     /* strlen(canonical) */
+    uint8_t  out_gc;             /* -g : nucleotide counts + gc_content are produced */
+    uint8_t  out_entropy;        /* -e : nucleotide counts + shannon_entropy */
+    uint8_t  out_matches;        /* -m */
+    uint8_t  out_its;            /* -i */
+    uint8_t  fold_case;          /* 1: a/c/g/t match like A/C/G/T (what every reference
+                                       caller gets by calling unmaskSequence first);
+                                    0: strict scanSegment semantics (lower case = non-ACGT) */
+    uint8_t  reserved0;
+    int32_t  device;             /* HIP device ordinal, -1 = current device */
+    uint32_t reserved1;
+} ts_params;
+
+/* MatchInfo, include/teloscope.h:89-95 (matchSeq is seq.substr(position-absPos, match_size)). */
+#define TS_MATCH_FORWARD   0x1u
+#define TS_MATCH_CANONICAL 0x2u
+#define TS_MATCH_TERMINAL  0x4u   /* isTerminal of src/teloscope.cpp:451-459 */
+typedef struct ts_match {
+    uint64_t position;
+    uint16_t match_size;
+    uint8_t  flags;
+    uint8_t  reserved[5];
+} ts_match;
+
+/* WindowData, include/teloscope.h:119-137, without the fields no writer reads. */
+typedef struct ts_window {
+    uint64_t window_start;           /* absolute (absPos + window offset) */
+    uint32_t current_window_size;
+    uint32_t nucleotide_counts[4];   /* A C G T; zero unless out_gc || out_entropy */
+    float    gc_content;             /* getGCContent, include/teloscope.h:211 (if out_gc) */
+    float    shannon_entropy;        /* getShannonEntropy, include/teloscope.h:199 (if out_entropy) */
+    uint32_t canonical_covered;
+    uint32_t non_canonical_covered;
+    uint32_t fwd_covered;
+    uint32_t rev_covered;
+    uint32_t reserved;
+} ts_window;
+
+/* TelomereBlock, include/teloscope.h:103-117. */
+typedef struct ts_block {
+    uint64_t start;
+    uint32_t block_len;
+    uint32_t block_counts;
+    uint32_t forward_count;
+    uint32_t reverse_count;
+    uint32_t canonical_count;
+    uint32_t non_canonical_count;
+    uint32_t total_covered;
+    uint32_t fwd_covered;
+    uint32_t can_covered;
+    uint8_t  has_valid_or;
+    uint8_t  is_longest;
+    char     block_label;
+    uint8_t  reserved;
+} ts_block;
+
+/* One scanSegment() call: (sequence, absPos, tipsOnly). */
+typedef struct ts_segment_in {
+    const char *seq;        /* borrowed for the duration of the call; need not be NUL-terminated */
+    uint64_t    len;
+    uint64_t    abs_pos;
+    uint8_t     tips_only;
+    uint8_t     reserved[7];
+} ts_segment_in;
+
+/* SegmentData, include/teloscope.h:139-148.  `matches` holds what the
+ * reference pushes to allMatches (full scan) or to fwdMatches+revMatches
+ * (tips-only), in the reference's push order; the other reference vectors are
+ * subsequences selected by flags:
+ *   canonicalMatches     = flags & CANONICAL                  (full scan only)
+ *   nonCanonicalMatches  = !(flags & CANONICAL) && TERMINAL   (full scan only)
+ *   fwdMatches / revMatches = flags & FORWARD / not
+ * Arrays are owned by the library until ts_free_segments(). */
+typedef struct ts_segment_out {
+    ts_window *windows;             uint64_t n_windows;
+    ts_match  *matches;             uint64_t n_matches;
+    ts_block  *terminal_blocks;     uint64_t n_terminal_blocks;
+    ts_block  *interstitial_blocks; uint64_t n_interstitial_blocks;
+} ts_segment_out;
+
+typedef struct ts_ctx   ts_ctx;
+typedef struct ts_batch ts_batch;
+
+int         ts_abi_version(void);
+const char *ts_last_error(const ts_ctx *ctx);      /* ctx may be NULL: last create error */
+int         ts_device_count(void);                 /* usable HIP devices, 0 if none */
+
+/* ---- pattern preparation: expandPatternsWithOrientation, src/tools.cpp:201-283,
+ *      plus the canonical-orientation rule of src/main.cpp:287-296. ---------------- */
+/* canonical_in: the -c argument (upper-cased by the callee). Writes the
+ * lexicographically smaller of (canonical, revcomp) to fwd_out, the other to rev_out
+ * (each >= 64 bytes). */
+int ts_canonical_orientation(const char *canonical_in, char *fwd_out, char *rev_out);
+/* raw_csv: comma-separated -p list (IUPAC allowed). On success *out is a malloc'd
+ * array of *n_out patterns sorted like the reference's patternInfo; free with
+ * ts_free_patterns(). */
+int  ts_expand_patterns(const char *raw_csv, int edit_distance, const char *canonical_fwd,
+                        ts_pattern **out, size_t *n_out);
+void ts_free_patterns(ts_pattern *p);
+
+/* ---- context: the Teloscope object (ctor include/teloscope.h:241-247). Builds the
+ *      k-mer match tables on the device.  Thread-safe for concurrent scan/filter calls
+ *      (calls are serialised on an internal mutex; results are independent of call order). */
+ts_ctx *ts_create(const ts_params *params, const ts_pattern *patterns, size_t n_patterns);
+void    ts_destroy(ts_ctx *ctx);
+/* 1 if (window, step, patterns) are handled by the tiled uniform-k kernel, 0 if by the
+ * general kernel. */
+int     ts_uses_fast_path(const ts_ctx *ctx);
+
+/* ---- Teloscope::scanSegment, batched (src/teloscope.cpp:537-658).  out[i] receives the
+ *      SegmentData of segs[i]; a one-element call equals one scanSegment() call.  Host
+ *      buffers in, host results out (H2D, kernels, D2H and host block calling inside). */
+int  ts_scan_segments(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out);
+void ts_free_segments(ts_segment_out *out, size_t n_segs);
+
+/* ---- ReadTelomereFilter (src/read-filter.cpp:10-45).  ts_create_read_filter applies
+ *      makeReadFilterInput's overrides (min_block_len 42 unless min_block_len_set,
+ *      terminal_limit UINT32_MAX/2, all genome-wide outputs off); ts_filter_reads is
+ *      matches() over a batch: trailing '\r' stripped, case folded, pass[i] = 1 iff the
+ *      read has a terminal block. */
+ts_ctx *ts_create_read_filter(const ts_params *params, int min_block_len_set,
+                              const ts_pattern *patterns, size_t n_patterns);
+int     ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens,
+                        size_t n_reads, uint8_t *pass);
+
+/* ---- Teloscope::labelTerminalBlocks (src/teloscope.cpp:259-383): the step walkPath runs
+ *      on the concatenated terminal blocks of a path (src/input.cpp:1031).  Sorts blocks in
+ *      place, sets is_longest, writes the granular label (needs 2*n+1 bytes). */
+int ts_label_terminal_blocks(ts_block *blocks, size_t n, uint16_t gaps, uint64_t path_size,
+                             uint32_t terminal_limit, char *label_out, int *scaffold_type_out);
+
+/* ---- window float metrics (include/teloscope.h:199-214), evaluated on the host from
+ *      the integer counts exactly as the reference does. */
+float ts_gc_content(const uint32_t counts[4], uint32_t window_size);
+float ts_shannon_entropy(const uint32_t counts[4], uint32_t window_size);
+
+/* ---- device-resident batches: the same scan with inputs and outputs kept in HBM.
+ *      Used by bench.py and the multi-GPU driver; ts_scan_segments is built on it. ----- */
+typedef struct ts_batch_info {
+    uint64_t n_segments;
+    uint64_t total_bases;
+    uint64_t input_bytes;       /* size of the device input buffer the batch expects */
+    uint64_t n_windows;         /* window records produced */
+    uint64_t n_tiles;
+    uint64_t match_capacity;    /* match records the device buffer can hold */
+    uint64_t n_matches;         /* valid after ts_batch_sync() */
+    uint64_t algorithmic_bytes; /* 1 B/base + 32 B/window + 4 B/match (after sync) */
+    double   last_kernel_ms;    /* HIP-event time of the last scan (after sync) */
+} ts_batch_info;
+
+/* Plans a batch of n_segs segments of the given lengths (all tips_only or all full scan).
+ * match_capacity 0 = default (bases/4). */
+ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t *abs_pos,
+                          size_t n_segs, int tips_only, uint64_t match_capacity);
+void      ts_batch_destroy(ts_batch *b);
+/* Byte offset of segment i inside the device input buffer (16-byte aligned). */
+uint64_t  ts_batch_segment_offset(const ts_batch *b, size_t i);
+/* Device pointer of the batch's own input buffer (input_bytes long). */
+void     *ts_batch_input_ptr(ts_batch *b);
+/* Copies one segment's bases host -> device input buffer. */
+int       ts_batch_upload(ts_batch *b, size_t i, const char *seq);
+/* Enqueues the scan on `stream` (a hipStream_t, NULL = default stream), reading bases from
+ * d_input (NULL = the batch's own input buffer). Asynchronous. */
+int       ts_batch_scan(ts_batch *b, const void *d_input, void *stream);
+/* Waits for the last scan, reads back counters; grows the match buffer and rescans if it
+ * overflowed. */
+int       ts_batch_sync(ts_batch *b);
+int       ts_batch_get_info(const ts_batch *b, ts_batch_info *info);
+/* Device pointers to the raw result buffers (valid after sync): window records
+ * (8 x uint32 each: A,C,G,T, canonical/nonCanonical/fwd/rev covered) and packed 32-bit
+ * match records ((tile-relative position << 2) | fwd << 1 | canonical). */
+const void *ts_batch_windows_ptr(const ts_batch *b);
+const void *ts_batch_matches_ptr(const ts_batch *b);
+/* D2H + host post-processing (absolute positions, terminal flags, block calling):
+ * fills out[0..n_segments). Free with ts_free_segments(). */
+int       ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out *out);
+/* Per-segment summary (n_windows, n_matches, n_canonical, n_forward as 4 x uint64 per
+ * segment) written to a device buffer of 32*n_segments bytes: the "hit buffer" ranks
+ * gather over RCCL. */
+int       ts_batch_segment_summary(ts_batch *b, void *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TELOSCAN_H */

@@ -1,0 +1,36 @@
+testFiles/mirror_merge.fa 
+embedded
+
++++ Path Summary Report +++
+pos	header	telomeres	labels	gaps	type	granular
+1	chr_mirror_merge	1	p	0	incomplete	P
+
++++ Assembly Summary Report +++
+Total paths:	1
+Total gaps:	0
+Scaffold N50:	2700
+Contig N50:	2700
+Total telomeres:	1
+
++++ Telomere Statistics +++
+Mean length:	700
+Median length:	700
+Min length:	700
+Max length:	700
+
++++ Chromosome Telomere Counts+++
+Two telomeres:	0
+One telomere:	1
+Zero telomeres:	0
+
++++ Chromosome Telomere/Gap Completeness+++
+T2T:	0
+Gapped T2T:	0
+Misassembled:	0
+Gapped misassembled:	0
+Incomplete:	1
+Gapped incomplete:	0
+No telomeres:	0
+Gapped no telomeres:	0
+Discordant:	0
+Gapped discordant:	0

@@ -1,0 +1,39 @@
+testFiles/mirror_merge.fa -f testFiles/mirror_merge.fa -r -o testFiles/tmp
+embedded
+
++++ Path Summary Report +++
+pos	header	telomeres	labels	gaps	type	granular	its	canonical	windows
+1	chr_mirror_merge	1	p	0	incomplete	P	0	100	3
+
++++ Assembly Summary Report +++
+Total paths:	1
+Total gaps:	0
+Scaffold N50:	2700
+Contig N50:	2700
+Total telomeres:	1
+Total ITS blocks:	0
+Total canonical matches:	100
+Total windows analyzed:	3
+
++++ Telomere Statistics +++
+Mean length:	700
+Median length:	700
+Min length:	700
+Max length:	700
+
++++ Chromosome Telomere Counts+++
+Two telomeres:	0
+One telomere:	1
+Zero telomeres:	0
+
++++ Chromosome Telomere/Gap Completeness+++
+T2T:	0
+Gapped T2T:	0
+Misassembled:	0
+Gapped misassembled:	0
+Incomplete:	1
+Gapped incomplete:	0
+No telomeres:	0
+Gapped no telomeres:	0
+Discordant:	0
+Gapped discordant:	0

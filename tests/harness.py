@@ -1,0 +1,400 @@
+"""Backend-agnostic test harness: drives either the CPU oracle or the HIP product
+through the same caller logic the reference wraps around its scan path, so that
+the reference's own `.tst` manifests (stdout of the CLI) can be checked.
+
+What is restated here (test infrastructure, host/python only):
+  * option parsing of the flags the manifests use       (src/main.cpp:186-660)
+  * FASTA -> path components (segments / N-gaps)        (gfalibs behaviour, pinned by
+                                                         testFiles/expected/*_gaps.bed)
+  * Teloscope::walkPath                                 (src/input.cpp:942-1041)
+  * Path/Assembly summary printing                      (src/teloscope.cpp:687-694,815-857,959-1055)
+  * FASTQ 4-line record reader of --fastq-subset        (src/input.cpp:96-149,737-832)
+
+The scan itself (scanSegment, block calling, labelTerminalBlocks, read filter) is
+delegated to a backend object: tests.backends.OracleBackend or ProductBackend.
+"""
+import gzip
+import os
+import shlex
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SCAFFOLD_NAMES = ["t2t", "gapped_t2t", "misassembly", "gapped_misassembly", "incomplete",
+                  "gapped_incomplete", "none", "gapped_none", "discordant", "gapped_discordant"]
+
+
+# ----------------------------------------------------------------------------- CLI
+class Options:
+    """UserInputTeloscope as main() leaves it (include/input.h:15-64)."""
+
+    def __init__(self):
+        self.input = None
+        self.canonical_fwd = "CCCTAA"
+        self.canonical_rev = "TTAGGG"
+        self.canonical_size = 6
+        self.raw_patterns = None
+        self.window_size = 1000
+        self.step = 1000
+        self.terminal_limit = 50000
+        self.edit_distance = 1
+        self.max_match_dist = 50
+        self.min_block_len = 300
+        self.min_block_len_set = False
+        self.max_block_dist = 500
+        self.min_block_counts = 2
+        self.min_block_density = np.float32(0.5)
+        self.out_win_repeats = False
+        self.out_gc = False
+        self.out_entropy = False
+        self.out_matches = False
+        self.out_its = False
+        self.ultra_fast = True
+        self.manual_curation = False
+        self.fastq_subset = False
+        self.stdin_redirect = None
+
+    def params(self):
+        """fields shared by tso_params / ts_params"""
+        return dict(window_size=self.window_size, step=self.step,
+                    terminal_limit=self.terminal_limit, max_match_dist=self.max_match_dist,
+                    min_block_len=self.min_block_len, max_block_dist=self.max_block_dist,
+                    min_block_counts=self.min_block_counts,
+                    min_block_density=float(self.min_block_density),
+                    canonical_size=self.canonical_size, out_gc=int(self.out_gc),
+                    out_entropy=int(self.out_entropy), out_matches=int(self.out_matches))
+
+
+def _revcom(s):
+    return s.translate(str.maketrans("ACGTacgt", "TGCAtgca"))[::-1]
+
+
+def parse_cli(command):
+    """getopt_long loop of src/main.cpp:186-565 for the options used by the manifests."""
+    o = Options()
+    toks = shlex.split(command.replace("<", " < "))
+    i = 0
+    needs_arg = {"-f", "-o", "-j", "-p", "-s", "-w", "-c", "-t", "-k", "-d", "-l", "-y", "-x"}
+    while i < len(toks):
+        t = toks[i]
+        if t == "<":
+            o.stdin_redirect = toks[i + 1]
+            i += 2
+            continue
+        if t in needs_arg:
+            a = toks[i + 1]
+            i += 2
+            if t == "-f":
+                o.input = a
+            elif t == "-c":
+                c = a.upper()
+                rc = _revcom(c)
+                o.canonical_size = len(c)
+                if c <= rc:                       # lex-smaller = Fwd (src/main.cpp:287-296)
+                    o.canonical_fwd, o.canonical_rev = c, rc
+                else:
+                    o.canonical_fwd, o.canonical_rev = rc, c
+            elif t == "-p":
+                o.raw_patterns = [p.upper() for p in a.split(",") if p]
+            elif t == "-w":
+                o.window_size = int(a)
+            elif t == "-s":
+                o.step = int(a)
+            elif t == "-t":
+                o.terminal_limit = int(a)
+            elif t == "-k":
+                o.max_match_dist = int(a)
+            elif t == "-d":
+                o.max_block_dist = int(a)
+            elif t == "-l":
+                o.min_block_len = int(a)
+                o.min_block_len_set = True
+            elif t == "-y":
+                o.min_block_density = np.float32(a)
+            elif t == "-x":
+                o.edit_distance = int(a)
+            continue
+        i += 1
+        if t == "--fastq-subset":
+            o.fastq_subset = True
+        elif t in ("-r", "-g", "-e", "-m", "-i", "-a"):
+            o.ultra_fast = False
+            if t == "-r":
+                o.out_win_repeats = True
+            elif t == "-g":
+                o.out_gc = True
+            elif t == "-e":
+                o.out_entropy = True
+            elif t == "-m":
+                o.out_matches = True
+            elif t == "-i":
+                o.out_its = True
+        elif t == "-u":
+            if o.out_win_repeats or o.out_gc or o.out_entropy or o.out_its or o.out_matches:
+                o.ultra_fast = False
+            else:
+                o.ultra_fast = True
+        elif t == "-n":
+            o.manual_curation = True
+        elif t.startswith("-"):
+            pass                                   # --cmd, --verbose ...
+        elif o.input is None:
+            o.input = t                            # first positional
+    if o.raw_patterns is None or not o.raw_patterns:
+        o.raw_patterns = [o.canonical_fwd, o.canonical_rev]   # src/main.cpp:626-633
+    return o
+
+
+# --------------------------------------------------------------------------- FASTA
+def _open(path):
+    return gzip.open(path, "rt") if path.endswith(".gz") else open(path, "rt")
+
+
+def read_fasta(path):
+    """-> [(header_token, sequence)] ; header = first whitespace-delimited token."""
+    out, name, chunks = [], None, []
+    with _open(path) as fh:
+        for line in fh:
+            line = line.rstrip("\r\n")
+            if line.startswith(">"):
+                if name is not None:
+                    out.append((name, "".join(chunks)))
+                name = line[1:].split()[0] if len(line) > 1 else ""
+                chunks = []
+            elif name is not None:
+                chunks.append(line)
+    if name is not None:
+        out.append((name, "".join(chunks)))
+    return out
+
+
+def path_components(seq):
+    """Split a record into segments and gaps the way gfalibs builds a path: every run of
+    N/n (also X/x) is a gap component, the rest are '+' segments.  Returns
+    [('S', start, str) | ('G', start, length)]."""
+    comps = []
+    b = np.frombuffer(seq.encode(), dtype=np.uint8)
+    if len(b) == 0:
+        return comps
+    isgap = (b == ord("N")) | (b == ord("n")) | (b == ord("X")) | (b == ord("x"))
+    edges = np.flatnonzero(np.diff(isgap.astype(np.int8))) + 1
+    starts = np.concatenate(([0], edges))
+    ends = np.concatenate((edges, [len(b)]))
+    for s, e in zip(starts, ends):
+        if isgap[s]:
+            comps.append(("G", int(s), int(e - s)))
+        else:
+            comps.append(("S", int(s), seq[s:e]))
+    return comps
+
+
+# ------------------------------------------------------------------------ walkPath
+def walk_path(backend, opts, seq_pos, header, seq):
+    """Teloscope::walkPath, src/input.cpp:942-1041."""
+    pd = dict(seq_pos=seq_pos, header=header.replace("\r", ""), path_size=len(seq), gaps=[],
+              windows=[], terminal_blocks=[], interstitial_blocks=[],
+              canonical_matches=[], non_canonical_matches=[])
+    abs_pos = 0
+    for comp in path_components(seq):
+        if comp[0] == "S":
+            s = comp[2].upper()                    # unmaskSequence
+            r = backend.scan_segment(s, abs_pos, opts.ultra_fast)
+            for k in ("windows", "terminal_blocks", "interstitial_blocks",
+                      "canonical_matches", "non_canonical_matches"):
+                pd[k].append(r[k])
+            abs_pos += len(s)
+        else:
+            pd["gaps"].append((abs_pos, comp[2]))
+            abs_pos += comp[2]
+    for k in ("windows", "terminal_blocks", "interstitial_blocks",
+              "canonical_matches", "non_canonical_matches"):
+        pd[k] = np.concatenate(pd[k]) if pd[k] else None
+    tb = pd["terminal_blocks"]
+    if tb is None:
+        tb = backend.empty_blocks()
+    tb, label, stype = backend.label_terminal_blocks(tb, len(pd["gaps"]) & 0xFFFF, pd["path_size"],
+                                                     opts.terminal_limit)
+    pd["terminal_blocks"], pd["terminal_label"], pd["scaffold_type"] = tb, label, stype
+    return pd
+
+
+def _n(a):
+    return 0 if a is None else len(a)
+
+
+def _fmt_float(x):
+    """operator<<(float) at default precision 6"""
+    return "%g" % float(np.float32(x))
+
+
+def _n50(lengths):
+    """Teloscope::computeN50, include/teloscope.h:224-235"""
+    if not lengths:
+        return 0
+    ls = sorted(lengths, reverse=True)
+    total, cum = sum(ls), 0
+    for v in ls:
+        cum += v
+        if cum * 2 >= total:
+            return v
+    return ls[-1]
+
+
+def _stats(values):
+    """getStats, src/tools.cpp:23-51 (float32 accumulation)"""
+    v = [np.float32(x) for x in values]
+    s = np.float32(0.0)
+    for x in v:
+        s = np.float32(s + x)
+    mean = np.float32(s / np.float32(len(v)))
+    srt = sorted(v)
+    mid = len(v) // 2
+    if len(v) % 2 == 0:
+        med = np.float32((srt[mid] + srt[mid - 1]) / np.float32(2))
+    else:
+        med = srt[mid]
+    return mean, med, min(v), max(v)
+
+
+def run_assembly(backend, opts, fasta_path):
+    """Input::read + handleBEDFile/printSummary: returns the CLI's stdout as a string."""
+    recs = read_fasta(fasta_path)
+    paths = [walk_path(backend, opts, i, h, s) for i, (h, s) in enumerate(recs)]
+    return format_report(paths, opts), paths
+
+
+def format_report(paths, opts):
+    out = ["", "+++ Path Summary Report +++"]
+    if not opts.ultra_fast:
+        out.append("pos\theader\ttelomeres\tlabels\tgaps\ttype\tgranular\tits\tcanonical\twindows")
+    else:
+        out.append("pos\theader\ttelomeres\tlabels\tgaps\ttype\tgranular")
+    tot_telo = tot_gaps = tot_its = tot_can = tot_win = 0
+    lengths = []
+    counts = [0] * 10
+    scaf_lens, contig_lens = [], []
+    for pd in paths:
+        longest, labels = 0, ""
+        for b in pd["terminal_blocks"]:
+            if b["is_longest"]:
+                longest += 1
+                labels += b["block_label"].decode()
+                lengths.append(float(b["block_len"]))
+        line = "%d\t%s\t%d\t%s\t%d\t%s\t%s" % (
+            pd["seq_pos"] + 1, pd["header"], longest, labels if labels else "none",
+            len(pd["gaps"]) & 0xFFFF, SCAFFOLD_NAMES[pd["scaffold_type"]], pd["terminal_label"])
+        tot_telo += longest
+        tot_gaps += len(pd["gaps"]) & 0xFFFF
+        if not opts.ultra_fast:
+            line += "\t%d\t%d\t%d" % (_n(pd["interstitial_blocks"]), _n(pd["canonical_matches"]),
+                                      _n(pd["windows"]))
+            tot_win += _n(pd["windows"])
+            tot_its += _n(pd["interstitial_blocks"])
+            tot_can += _n(pd["canonical_matches"])
+        out.append(line)
+        counts[pd["scaffold_type"]] += 1
+        scaf_lens.append(pd["path_size"])
+        prev_end = 0
+        for gs, gl in sorted(pd["gaps"]):
+            if gs > prev_end:
+                contig_lens.append(gs - prev_end)
+            prev_end = gs + gl
+        if pd["path_size"] > prev_end:
+            contig_lens.append(pd["path_size"] - prev_end)
+
+    out += ["", "+++ Assembly Summary Report +++", "Total paths:\t%d" % len(paths),
+            "Total gaps:\t%d" % tot_gaps, "Scaffold N50:\t%d" % _n50(scaf_lens),
+            "Contig N50:\t%d" % _n50(contig_lens), "Total telomeres:\t%d" % tot_telo]
+    if not opts.ultra_fast:
+        out += ["Total ITS blocks:\t%d" % tot_its, "Total canonical matches:\t%d" % tot_can,
+                "Total windows analyzed:\t%d" % tot_win]
+    out += ["", "+++ Telomere Statistics +++"]
+    if tot_telo > 0:
+        mean, med, mn, mx = _stats(lengths)
+        out += ["Mean length:\t" + _fmt_float(mean), "Median length:\t" + _fmt_float(med),
+                "Min length:\t" + _fmt_float(mn), "Max length:\t" + _fmt_float(mx)]
+    else:
+        out.append("No telomeres found for statistics.")
+    T = counts
+    out += ["", "+++ Chromosome Telomere Counts+++",
+            "Two telomeres:\t%d" % (T[0] + T[1] + T[2] + T[3]),
+            "One telomere:\t%d" % (T[4] + T[5]), "Zero telomeres:\t%d" % (T[6] + T[7]),
+            "", "+++ Chromosome Telomere/Gap Completeness+++",
+            "T2T:\t%d" % T[0], "Gapped T2T:\t%d" % T[1], "Misassembled:\t%d" % T[2],
+            "Gapped misassembled:\t%d" % T[3], "Incomplete:\t%d" % T[4],
+            "Gapped incomplete:\t%d" % T[5], "No telomeres:\t%d" % T[6],
+            "Gapped no telomeres:\t%d" % T[7], "Discordant:\t%d" % T[8],
+            "Gapped discordant:\t%d" % T[9]]
+    return "\n".join(out) + "\n"
+
+
+# --------------------------------------------------------------------------- FASTQ
+def read_fastq_records(data):
+    """4-line reader of src/input.cpp:113-138: blank lines between records are skipped,
+    line terminators are kept verbatim in the echoed record, the sequence handed to the
+    filter is the second line without its '\\n' (a trailing '\\r' is the filter's job).
+    Returns [(raw_record_bytes, sequence_bytes)] or raises ValueError on a malformed file."""
+    if not data:
+        raise ValueError("FASTQ input is empty")
+    if data[:1] != b"@":
+        raise ValueError("FASTQ input must start with '@'")
+    lines = data.split(b"\n")
+    if lines and lines[-1] == b"":          # std::getline yields no line after a final '\n'
+        lines.pop()
+
+    def logical_len(l):
+        return len(l) - 1 if l.endswith(b"\r") else len(l)
+
+    recs, i, n = [], 0, len(lines)
+    while i < n:
+        if logical_len(lines[i]) == 0:      # blank line (or lone '\r') before a header
+            i += 1
+            continue
+        if i + 3 >= n:
+            raise ValueError("truncated FASTQ record")
+        h, s, p, q = lines[i:i + 4]
+        if not h.startswith(b"@"):
+            raise ValueError("expected header line starting with '@'")
+        if not p.startswith(b"+"):
+            raise ValueError("expected separator line starting with '+'")
+        if logical_len(s) != logical_len(q):
+            raise ValueError("sequence and quality length differ")
+        recs.append((b"\n".join((h, s, p, q)) + b"\n", s))
+        i += 4
+    return recs
+
+
+def run_fastq_subset(read_filter, data):
+    """Input::readFastqSubset: returns (stdout bytes, kept, total)."""
+    recs = read_fastq_records(data)
+    passes = read_filter.filter([s for _, s in recs])
+    out = b"".join(r for (r, _), ok in zip(recs, passes) if ok)
+    return out, int(sum(passes)), len(recs)
+
+
+# ------------------------------------------------------------------------ manifests
+def load_manifest(path):
+    with open(path) as fh:
+        lines = fh.read().split("\n")
+    command = lines[0]
+    rest = lines[1:]
+    first = next((j for j, l in enumerate(rest) if l.strip()), None)
+    if first is None:
+        return dict(command=command, mode="empty")
+    if rest[first].startswith("expect_") or rest[first].startswith("gfa_"):
+        directives = []
+        for l in rest[first:]:
+            if l.strip():
+                k, _, v = l.partition(" ")
+                directives.append((k, v))
+        return dict(command=command, mode="directive", directives=directives)
+    if rest[first] == "embedded":
+        body = rest[first + 1:]
+        return dict(command=command, mode="embedded", expected="\n".join(body))
+    return dict(command=command, mode="file", expected_path=rest[first].strip())
+
+
+def golden_path(rel):
+    """testFiles/x -> tests/golden/testFiles/x"""
+    return os.path.join(GOLDEN, rel)
