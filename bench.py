@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py — Gbases/s scanned by the HIP telomeric-motif scan on MI355X.
+
+Workload (BASELINE.json configs[1]): synthetic 3.0 Gb human-scale assembly, 200 contigs
+(log-uniform 1-250 Mb), telomeric arrays + TVRs at contig ends, planted ITS blocks, 0.1 %
+soft-masked bases; flags -c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -x 1 -w 1000 -s 500
+-r -g -e -m -i  (124 patterns, k = 6).  One "step" = one full scan of the resident batch:
+window records (8 x u32 per window) and the packed match stream are produced in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--gbases G]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scans its own
+3.0 Gb shard of contigs (weak scaling, contigs are independent units) and the per-segment
+hit summaries are gathered to rank 0 over RCCL inside the timed step.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (imported before libteloscan so both share one HIP runtime)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FLAGS = "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -x 1 -w 1000 -s 500 -r -g -e -m -i"
+
+
+def contig_lengths(total, n, seed):
+    rng = np.random.default_rng(seed)
+    raw = np.exp(rng.uniform(np.log(1e6), np.log(250e6), size=n))
+    lens = np.maximum((raw * (total / raw.sum())).astype(np.int64), 20000)
+    lens[-1] += total - lens.sum()
+    return [int(x) for x in lens]
+
+
+def fill_synthetic(buf, offsets, lens, seed, dev):
+    """Random ACGT + telomeres/TVRs at both ends of every contig + ITS blocks + soft-masking,
+    generated on the device (model of src/get-mock-chr.cpp:96-136)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    chunk = 1 << 28
+    for a in range(0, buf.numel(), chunk):
+        b = min(buf.numel(), a + chunk)
+        idx = torch.randint(0, 4, (b - a,), dtype=torch.uint8, device=dev, generator=g)
+        buf[a:b] = lut[idx.long()]
+        m = torch.rand(b - a, device=dev, generator=g) < 0.001          # 0.1 % lower case
+        buf[a:b] |= (m.to(torch.uint8) << 5)
+        del idx, m
+    rng = np.random.default_rng(seed + 1)
+
+    def tract(unit, reps, rate):
+        t = np.tile(np.frombuffer(unit, dtype=np.uint8), reps).copy()
+        k = rng.random(len(t)) < rate
+        t[k] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(k.sum()))]
+        return torch.from_numpy(t).to(dev)
+
+    for off, n in zip(offsets, lens):
+        p = torch.cat([tract(b"CCCTAA", 2000, 0.0), tract(b"CCCTAA", 100, 1.0 / 6)])
+        q = torch.cat([tract(b"TTAGGG", 100, 1.0 / 6), tract(b"TTAGGG", 2000, 0.0)])
+        if len(p) + len(q) < n:
+            buf[off:off + len(p)] = p
+            buf[off + n - len(q):off + n] = q
+    n_its = 50
+    for _ in range(n_its):
+        ci = int(rng.integers(0, len(lens)))
+        ln = int(rng.integers(200, 2000)) // 6
+        unit = b"TTAGGG" if rng.random() < 0.5 else b"CCCTAA"
+        at = int(rng.integers(20000, max(20001, lens[ci] - 20000 - 6 * ln)))
+        t = tract(unit, ln, 0.02)
+        buf[offsets[ci] + at:offsets[ci] + at + len(t)] = t
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gbases", type=float, default=3.0, help="bases per GPU (Gb); 3.0 = BASELINE config")
+    ap.add_argument("--contigs", type=int, default=200)
+    ap.add_argument("--cpu-sample-mb", type=float, default=384.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from tests import harness as H
+    from tests.backends import _user_input
+
+    opts = H.parse_cli("x.fa " + FLAGS)
+    ui = _user_input(opts)
+    ui.device = local_rank
+    tel = ta.Teloscope(ui)
+    L = K.lib()
+
+    total = int(args.gbases * 1e9)
+    lens = contig_lengths(total, args.contigs, 42 + rank)
+    n = len(lens)
+    lens_c = (C.c_uint64 * n)(*lens)
+    batch = L.ts_batch_create(tel._ctx.ptr, lens_c, None, n, 0, 0)
+    if not batch:
+        raise RuntimeError(tel._ctx.error())
+    info = K.BatchInfo()
+    L.ts_batch_get_info(batch, C.byref(info))
+    offsets = [int(L.ts_batch_segment_offset(batch, i)) for i in range(n)]
+
+    buf = torch.zeros(int(info.input_bytes), dtype=torch.uint8, device=dev)
+    fill_synthetic(buf, offsets, lens, 42 + rank, dev)
+    summary = torch.zeros(n * 4, dtype=torch.int64, device=dev)
+    gathered = [torch.zeros_like(summary) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    dptr = C.c_void_p(buf.data_ptr())
+
+    def step():
+        rc = L.ts_batch_scan(batch, dptr, sptr)
+        if rc != 0:
+            raise RuntimeError(tel._ctx.error())
+        if world > 1:
+            rc = L.ts_batch_segment_summary(batch, C.c_void_p(summary.data_ptr()), sptr)
+            if rc != 0:
+                raise RuntimeError(tel._ctx.error())
+            dist.gather(summary, gathered, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    if L.ts_batch_sync(batch) != 0:          # also grows the match buffer if it overflowed
+        raise RuntimeError(tel._ctx.error())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1) / args.steps
+
+    if L.ts_batch_sync(batch) != 0:
+        raise RuntimeError(tel._ctx.error())
+    L.ts_batch_get_info(batch, C.byref(info))
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = tmax / args.steps * 1e3
+        value = world * total / (tmax / args.steps) / 1e9
+        alg_bytes = int(info.algorithmic_bytes)
+        kern_ms = float(info.last_kernel_ms)           # HIP events around the last scan, on its stream
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Gbases/s scanned (whole node), 3 Gb FASTA TTAGGG w=1000 s=500",
+            "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic %.2f Gb / %d contigs per GPU, %s, 124 patterns k=6"
+                                   % (args.gbases, n, FLAGS),
+                       "bases_per_gpu": total, "windows": int(info.n_windows),
+                       "matches": int(info.n_matches), "tiles": int(info.n_tiles),
+                       "timed_region": "resident ASCII in HBM -> window records + packed match stream in HBM"
+                                       + (" + RCCL gather of per-segment hit summaries" if world > 1 else ""),
+                       "device_ms_per_step_events": round(dev_ms, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "ts_scan_tiles", "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes": alg_bytes},
+        }
+        if not args.no_cpu_baseline:
+            from tests.backends import OracleBackend
+            nb = int(min(args.cpu_sample_mb * 1e6, lens[0]))
+            host = buf[offsets[0]:offsets[0] + nb].cpu().numpy().tobytes().upper()
+            ob = OracleBackend(opts)
+            c0 = time.perf_counter()
+            _, nw, nm = ob.oracle.bench_scan(host)
+            cpu_s = time.perf_counter() - c0
+            out["cpu_baseline"] = {
+                "value": round(nb / cpu_s / 1e9, 5), "unit": "Gbases/s", "cores": 1, "kind": "port",
+                "sample": "first %.0f Mb of contig 0 of the same synthetic assembly, same flags, "
+                          "scan stage only (oracle/teloscope_oracle.c: trie walk + carry loop), "
+                          "%d windows, %d matches, %.1f s" % (nb / 1e6, nw, nm, cpu_s)}
+        print(json.dumps(out))
+    L.ts_batch_destroy(batch)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+"""ctypes binding of libteloscan.so (the C-ABI declared in include/teloscan.h).
+
+The library is the product; this module only maps its structs and entry points.  It fails
+loudly (ImportError) when the shared object is missing — there is no Python or CPU
+fallback for the scan path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libteloscan.so")
+
+TS_OK = 0
+TS_ERR_INVALID_ARG, TS_ERR_NO_DEVICE, TS_ERR_HIP, TS_ERR_ALLOC, TS_ERR_UNSUPPORTED, TS_ERR_STATE = \
+    -1, -2, -3, -4, -5, -6
+MATCH_FORWARD, MATCH_CANONICAL, MATCH_TERMINAL = 1, 2, 4
+
+
+class Pattern(C.Structure):
+    _fields_ = [("seq", C.c_char * 64), ("len", C.c_uint8), ("is_forward", C.c_uint8),
+                ("is_canonical", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class Params(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("window_size", C.c_uint32), ("step", C.c_uint32),
+                ("terminal_limit", C.c_uint32), ("max_match_dist", C.c_uint16),
+                ("min_block_len", C.c_uint16), ("max_block_dist", C.c_uint16),
+                ("min_block_counts", C.c_uint16), ("min_block_density", C.c_float),
+                ("canonical_size", C.c_uint16), ("out_gc", C.c_uint8), ("out_entropy", C.c_uint8),
+                ("out_matches", C.c_uint8), ("out_its", C.c_uint8), ("fold_case", C.c_uint8),
+                ("reserved0", C.c_uint8), ("device", C.c_int32), ("reserved1", C.c_uint32)]
+
+
+class Match(C.Structure):
+    _fields_ = [("position", C.c_uint64), ("match_size", C.c_uint16), ("flags", C.c_uint8),
+                ("reserved", C.c_uint8 * 5)]
+
+
+class Window(C.Structure):
+    _fields_ = [("window_start", C.c_uint64), ("current_window_size", C.c_uint32),
+                ("nucleotide_counts", C.c_uint32 * 4), ("gc_content", C.c_float),
+                ("shannon_entropy", C.c_float), ("canonical_covered", C.c_uint32),
+                ("non_canonical_covered", C.c_uint32), ("fwd_covered", C.c_uint32),
+                ("rev_covered", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Block(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("block_len", C.c_uint32), ("block_counts", C.c_uint32),
+                ("forward_count", C.c_uint32), ("reverse_count", C.c_uint32),
+                ("canonical_count", C.c_uint32), ("non_canonical_count", C.c_uint32),
+                ("total_covered", C.c_uint32), ("fwd_covered", C.c_uint32),
+                ("can_covered", C.c_uint32), ("has_valid_or", C.c_uint8),
+                ("is_longest", C.c_uint8), ("block_label", C.c_char), ("reserved", C.c_uint8)]
+
+
+class SegmentIn(C.Structure):
+    _fields_ = [("seq", C.c_char_p), ("len", C.c_uint64), ("abs_pos", C.c_uint64),
+                ("tips_only", C.c_uint8), ("reserved", C.c_uint8 * 7)]
+
+
+class SegmentOut(C.Structure):
+    _fields_ = [("windows", C.POINTER(Window)), ("n_windows", C.c_uint64),
+                ("matches", C.POINTER(Match)), ("n_matches", C.c_uint64),
+                ("terminal_blocks", C.POINTER(Block)), ("n_terminal_blocks", C.c_uint64),
+                ("interstitial_blocks", C.POINTER(Block)), ("n_interstitial_blocks", C.c_uint64)]
+
+
+class BatchInfo(C.Structure):
+    _fields_ = [("n_segments", C.c_uint64), ("total_bases", C.c_uint64), ("input_bytes", C.c_uint64),
+                ("n_windows", C.c_uint64), ("n_tiles", C.c_uint64), ("match_capacity", C.c_uint64),
+                ("n_matches", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
+                ("last_kernel_ms", C.c_double)]
+
+
+MATCH_DT = np.dtype(Match)
+WINDOW_DT = np.dtype(Window)
+BLOCK_DT = np.dtype(Block)
+
+# every symbol include/teloscan.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "ts_abi_version", "ts_last_error", "ts_device_count", "ts_canonical_orientation",
+    "ts_expand_patterns", "ts_free_patterns", "ts_create", "ts_destroy", "ts_uses_fast_path",
+    "ts_scan_segments", "ts_free_segments", "ts_create_read_filter", "ts_filter_reads",
+    "ts_label_terminal_blocks", "ts_gc_content", "ts_shannon_entropy", "ts_batch_create",
+    "ts_batch_destroy", "ts_batch_segment_offset", "ts_batch_input_ptr", "ts_batch_upload",
+    "ts_batch_scan", "ts_batch_sync", "ts_batch_get_info", "ts_batch_windows_ptr",
+    "ts_batch_matches_ptr", "ts_batch_download", "ts_batch_segment_summary",
+]
+
+
+def build(force=False):
+    """Compiles libteloscan.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    inc = os.path.join(os.path.dirname(_HERE), "include", "teloscan.h")
+    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir)
+            if f.endswith((".hip", ".cpp", ".h", ".hpp"))] + [inc]
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", src_dir])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libteloscan.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C teloscope_amd/csrc`; teloscope_amd has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.ts_abi_version.restype = C.c_int
+    L.ts_last_error.restype = C.c_char_p
+    L.ts_last_error.argtypes = [C.c_void_p]
+    L.ts_device_count.restype = C.c_int
+    L.ts_canonical_orientation.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.ts_expand_patterns.argtypes = [C.c_char_p, C.c_int, C.c_char_p,
+                                     C.POINTER(C.POINTER(Pattern)), C.POINTER(C.c_size_t)]
+    L.ts_free_patterns.argtypes = [C.POINTER(Pattern)]
+    L.ts_create.restype = C.c_void_p
+    L.ts_create.argtypes = [C.POINTER(Params), C.POINTER(Pattern), C.c_size_t]
+    L.ts_create_read_filter.restype = C.c_void_p
+    L.ts_create_read_filter.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(Pattern), C.c_size_t]
+    L.ts_destroy.argtypes = [C.c_void_p]
+    L.ts_uses_fast_path.argtypes = [C.c_void_p]
+    L.ts_scan_segments.argtypes = [C.c_void_p, C.POINTER(SegmentIn), C.c_size_t, C.POINTER(SegmentOut)]
+    L.ts_free_segments.argtypes = [C.POINTER(SegmentOut), C.c_size_t]
+    L.ts_filter_reads.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+                                  C.c_size_t, C.POINTER(C.c_uint8)]
+    L.ts_label_terminal_blocks.argtypes = [C.POINTER(Block), C.c_size_t, C.c_uint16, C.c_uint64,
+                                           C.c_uint32, C.c_char_p, C.POINTER(C.c_int)]
+    L.ts_gc_content.restype = C.c_float
+    L.ts_gc_content.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
+    L.ts_shannon_entropy.restype = C.c_float
+    L.ts_shannon_entropy.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
+    L.ts_batch_create.restype = C.c_void_p
+    L.ts_batch_create.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                  C.c_size_t, C.c_int, C.c_uint64]
+    L.ts_batch_destroy.argtypes = [C.c_void_p]
+    L.ts_batch_segment_offset.restype = C.c_uint64
+    L.ts_batch_segment_offset.argtypes = [C.c_void_p, C.c_size_t]
+    L.ts_batch_input_ptr.restype = C.c_void_p
+    L.ts_batch_input_ptr.argtypes = [C.c_void_p]
+    L.ts_batch_upload.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p]
+    L.ts_batch_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ts_batch_sync.argtypes = [C.c_void_p]
+    L.ts_batch_get_info.argtypes = [C.c_void_p, C.POINTER(BatchInfo)]
+    L.ts_batch_windows_ptr.restype = C.c_void_p
+    L.ts_batch_windows_ptr.argtypes = [C.c_void_p]
+    L.ts_batch_matches_ptr.restype = C.c_void_p
+    L.ts_batch_matches_ptr.argtypes = [C.c_void_p]
+    L.ts_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SegmentOut)]
+    L.ts_batch_segment_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+class TeloscanError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libteloscan error %d: %s" % (code, msg))
+        self.code = code
+
+
+def copy_array(ptr, n, dt):
+    if n == 0:
+        return np.zeros(0, dtype=dt)
+    buf = C.string_at(C.cast(ptr, C.c_void_p), n * dt.itemsize)
+    return np.frombuffer(buf, dtype=dt).copy()

@@ -1,0 +1,745 @@
+// capi.cpp — the C-ABI of libteloscan (include/teloscan.h): contexts, device-resident
+// batches, the batched scanSegment / ReadTelomereFilter entry points and their host
+// post-processing.  There is no CPU scan path in this library: without a HIP device
+// ts_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "host.hpp"
+#include "ts_internal.h"
+
+int ts_k_occupancy(uint32_t lds_bytes);
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, need ? need : 16);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace
+
+struct ts_ctx {
+    ts_params params{};
+    std::vector<ts::Pattern> patterns;
+    ts::BlockParams bp{};
+    uint32_t k = 0;                 // uniform pattern length (0 = mixed)
+    uint32_t longest = 0;
+    bool fast_ok = false;           // table-driven tiled kernel usable for the pattern set
+    std::string why_not;            // reason when a scan mode is unsupported
+    int device = 0;
+    int num_cu = 0;
+    uint32_t table_rows = 0;
+    DevBuf d_table;
+    mutable std::mutex mtx;
+    mutable std::string error;
+    bool read_filter = false;
+
+    int fail(int code, const std::string &msg) const { error = msg; return code; }
+};
+
+namespace {
+
+struct Region {                     // one scanned interval of a segment
+    uint64_t start, len;            // relative to the segment
+    uint32_t first_tile, n_tiles;
+    uint64_t tile_bases;            // owned bases per tile
+};
+
+struct SegPlan {
+    uint64_t len = 0, abs_pos = 0;
+    uint64_t in_off = 0;            // byte offset in the device input buffer
+    uint64_t win_base = 0, n_windows = 0;
+    uint32_t first_tile = 0, n_tiles = 0;
+    std::vector<Region> regions;
+};
+
+}  // namespace
+
+struct ts_batch {
+    ts_ctx *ctx = nullptr;
+    bool tips = false;
+    std::vector<SegPlan> segs;
+    std::vector<TsTile> tiles;
+    TsScanParams kp{};
+    uint32_t grid = 0, lds_bytes = 0;
+    uint64_t total_bases = 0, input_bytes = 0, n_windows = 0, match_cap = 0;
+    uint64_t n_matches = 0;
+    double last_ms = 0.0;
+    bool scanned = false, synced = false;
+    const void *last_input = nullptr;
+    void *last_stream = nullptr;
+    DevBuf d_in, d_tiles, d_windows, d_matches, d_state, d_prefix, d_stats, d_small, d_segtab;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return (ctx)->fail(TS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+constexpr uint32_t kMaxLds = 160u * 1024u;
+constexpr uint32_t kTargetTileBases = 32768;
+constexpr uint32_t kMaxBlocksPerTile = 448;
+
+// Chooses the tile geometry for a full-window scan; false if it cannot fit in LDS.
+bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, std::string &why) {
+    const ts_params &P = c->params;
+    const uint32_t k = c->k;
+    kp.k = k;
+    kp.table_rows = c->table_rows;
+    kp.fold_mask = P.fold_case ? 0xDFDFDFDFu : 0xFFFFFFFFu;
+    if (tips) {
+        kp.s = kp.w = kTargetTileBases;      // one pseudo block per tile, no window records
+        kp.q = 0; kp.r = 0; kp.qq = 0; kp.hh = kp.s - k;
+        kp.straddle_fix = 0; kp.windows_on = 0; kp.nuc_on = 0;
+        wpt = 1;
+    } else {
+        const uint32_t s = P.step, w = P.window_size;
+        kp.s = s; kp.w = w;
+        kp.q = w / s; kp.r = w % s;
+        kp.qq = (w - k) / s; kp.hh = (w - k) % s;
+        kp.straddle_fix = (w == s) ? 1u : 0u;
+        kp.windows_on = 1;
+        kp.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u;
+        wpt = std::max<uint32_t>(1, std::min<uint32_t>(kTargetTileBases / s, kMaxBlocksPerTile));
+    }
+    for (;;) {
+        const uint64_t span = (uint64_t)(wpt + kp.q) * kp.s;
+        if (span > (1u << 22)) { why = "window too large for one tile"; return false; }
+        kp.nch = (uint32_t)ceil_div(15 + span + 16 + 16 + 16, TS_CHUNK);
+        kp.max_blocks = wpt + kp.q + 1;
+        const int lds = ts_k_lds_bytes(&kp);
+        if ((uint32_t)lds <= kMaxLds) return true;
+        if (wpt == 1) { why = "window/step geometry does not fit the 160 KB LDS tile"; return false; }
+        wpt = std::max<uint32_t>(1, wpt / 2);
+    }
+}
+
+void add_region_tiles(ts_batch *b, SegPlan &sp, uint32_t seg_index, uint64_t start, uint64_t len,
+                      uint64_t tile_bases, uint64_t windows_per_tile, bool windows) {
+    Region rg{start, len, (uint32_t)b->tiles.size(), 0, tile_bases};
+    const uint64_t nt = ceil_div(len, tile_bases);
+    for (uint64_t j = 0; j < nt; ++j) {
+        TsTile t{};
+        const uint64_t u0 = j * tile_bases;
+        const uint64_t rem = len - u0;
+        t.in_off = sp.in_off + start + u0;
+        t.nrel = (uint32_t)std::min<uint64_t>(rem, 1u << 30);
+        if (windows) {
+            const uint64_t wins_left = sp.n_windows - j * windows_per_tile;
+            t.nwin = (uint32_t)std::min<uint64_t>(wins_left, windows_per_tile);
+            t.win_out = sp.win_base + j * windows_per_tile;
+        } else {
+            t.nwin = 1;
+            t.win_out = 0;
+        }
+        t.own_len = (uint32_t)std::min<uint64_t>(rem, tile_bases);
+        t.seg = seg_index;
+        b->tiles.push_back(t);
+    }
+    rg.n_tiles = (uint32_t)nt;
+    sp.regions.push_back(rg);
+}
+
+int batch_alloc_outputs(ts_batch *b) {
+    ts_ctx *c = b->ctx;
+    const size_t nt = b->tiles.size();
+    HIP_TRY(c, b->d_tiles.ensure(nt * sizeof(TsTile)));
+    HIP_TRY(c, b->d_windows.ensure(std::max<uint64_t>(b->n_windows, 1) * 32));
+    HIP_TRY(c, b->d_matches.ensure(std::max<uint64_t>(b->match_cap, 1) * 4));
+    HIP_TRY(c, b->d_state.ensure((nt + 1) * 8));
+    HIP_TRY(c, b->d_prefix.ensure((nt + 1) * 8));
+    HIP_TRY(c, b->d_stats.ensure((nt + 1) * 8));
+    HIP_TRY(c, b->d_small.ensure(64));
+    if (nt) HIP_TRY(c, hipMemcpy(b->d_tiles.p, b->tiles.data(), nt * sizeof(TsTile), hipMemcpyHostToDevice));
+    return TS_OK;
+}
+
+}  // namespace
+
+// =========================================================================== misc entry points
+extern "C" {
+
+int ts_abi_version(void) { return TELOSCAN_ABI_VERSION; }
+
+const char *ts_last_error(const ts_ctx *ctx) {
+    return ctx ? ctx->error.c_str() : g_create_error.c_str();
+}
+
+int ts_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ts_canonical_orientation(const char *canonical_in, char *fwd_out, char *rev_out) {
+    if (!canonical_in || !fwd_out || !rev_out || std::strlen(canonical_in) > 62) return TS_ERR_INVALID_ARG;
+    std::string f, r;
+    ts::canonical_orientation(canonical_in, f, r);
+    std::strcpy(fwd_out, f.c_str());
+    std::strcpy(rev_out, r.c_str());
+    return TS_OK;
+}
+
+int ts_expand_patterns(const char *raw_csv, int edit_distance, const char *canonical_fwd,
+                       ts_pattern **out, size_t *n_out) {
+    if (!raw_csv || !canonical_fwd || !out || !n_out || edit_distance < 0 || edit_distance > 2)
+        return TS_ERR_INVALID_ARG;
+    std::vector<ts::Pattern> v = ts::expand_patterns(raw_csv, edit_distance, canonical_fwd);
+    ts_pattern *arr = (ts_pattern *)std::calloc(v.size() ? v.size() : 1, sizeof(ts_pattern));
+    if (!arr) return TS_ERR_ALLOC;
+    for (size_t i = 0; i < v.size(); ++i) {
+        std::strncpy(arr[i].seq, v[i].seq.c_str(), 63);
+        arr[i].len = (uint8_t)v[i].seq.size();
+        arr[i].is_forward = v[i].is_forward;
+        arr[i].is_canonical = v[i].is_canonical;
+    }
+    *out = arr;
+    *n_out = v.size();
+    return TS_OK;
+}
+
+void ts_free_patterns(ts_pattern *p) { std::free(p); }
+
+float ts_gc_content(const uint32_t counts[4], uint32_t window_size) { return ts::gc_content(counts, window_size); }
+float ts_shannon_entropy(const uint32_t counts[4], uint32_t window_size) { return ts::shannon_entropy(counts, window_size); }
+
+int ts_label_terminal_blocks(ts_block *blocks, size_t n, uint16_t gaps, uint64_t path_size,
+                             uint32_t terminal_limit, char *label_out, int *scaffold_type_out) {
+    if ((n && !blocks) || !label_out || !scaffold_type_out) return TS_ERR_INVALID_ARG;
+    std::string label;
+    *scaffold_type_out = ts::label_terminal_blocks(blocks, n, gaps, path_size, terminal_limit, label);
+    std::memcpy(label_out, label.c_str(), label.size() + 1);
+    return TS_OK;
+}
+
+// =========================================================================== context
+static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, size_t n_patterns,
+                           bool read_filter, int min_block_len_set) {
+    g_create_error.clear();
+    if (!params || params->struct_size != sizeof(ts_params) || (n_patterns && !patterns)) {
+        g_create_error = "ts_create: bad arguments (struct_size mismatch?)";
+        return nullptr;
+    }
+    if (params->step == 0 || params->window_size == 0 || params->step > params->window_size) {
+        g_create_error = "ts_create: need 0 < step <= window_size";
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = "ts_create: no usable HIP device (libteloscan has no CPU fallback)";
+        return nullptr;
+    }
+    ts_ctx *c = new ts_ctx();
+    c->params = *params;
+    c->read_filter = read_filter;
+    if (read_filter) {                                   // makeReadFilterInput, src/read-filter.cpp:10-30
+        if (!min_block_len_set) c->params.min_block_len = 42;
+        c->params.terminal_limit = std::numeric_limits<uint32_t>::max() / 2;
+        c->params.out_gc = c->params.out_entropy = c->params.out_matches = c->params.out_its = 0;
+        c->params.fold_case = 1;
+    }
+    int dev = params->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev || hipSetDevice(dev) != hipSuccess) {
+        g_create_error = "ts_create: cannot select HIP device";
+        delete c;
+        return nullptr;
+    }
+    c->device = dev;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (c->num_cu <= 0) c->num_cu = 256;
+
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+    for (size_t i = 0; i < n_patterns; ++i) {
+        ts::Pattern p;
+        p.seq.assign(patterns[i].seq, patterns[i].len);
+        p.is_forward = patterns[i].is_forward;
+        p.is_canonical = patterns[i].is_canonical;
+        kmin = std::min<uint32_t>(kmin, patterns[i].len);
+        kmax = std::max<uint32_t>(kmax, patterns[i].len);
+        c->patterns.push_back(std::move(p));
+    }
+    c->longest = kmax;
+    c->bp.terminal_limit = c->params.terminal_limit;
+    c->bp.max_match_dist = c->params.max_match_dist;
+    c->bp.min_block_len = c->params.min_block_len;
+    c->bp.max_block_dist = c->params.max_block_dist;
+    c->bp.min_block_counts = c->params.min_block_counts;
+    c->bp.min_block_density = c->params.min_block_density;
+    c->bp.first_pattern_len = n_patterns ? patterns[0].len : 0;
+
+    if (n_patterns == 0) {
+        c->why_not = "empty pattern set";
+    } else if (kmin != kmax) {
+        c->why_not = "mixed-length pattern sets need the general kernel (not built yet)";
+    } else {
+        std::vector<uint32_t> table;
+        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows)) {
+            c->why_not = "pattern length outside 3..9 or non-ACGT pattern";
+        } else {
+            c->k = kmin;
+            if (c->d_table.ensure(table.size() * 4) != hipSuccess ||
+                hipMemcpy(c->d_table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                g_create_error = "ts_create: cannot upload match table";
+                delete c;
+                return nullptr;
+            }
+            c->fast_ok = true;
+        }
+    }
+    return c;
+}
+
+ts_ctx *ts_create(const ts_params *params, const ts_pattern *patterns, size_t n_patterns) {
+    return create_impl(params, patterns, n_patterns, false, 1);
+}
+
+ts_ctx *ts_create_read_filter(const ts_params *params, int min_block_len_set,
+                              const ts_pattern *patterns, size_t n_patterns) {
+    return create_impl(params, patterns, n_patterns, true, min_block_len_set);
+}
+
+void ts_destroy(ts_ctx *ctx) {
+    if (!ctx) return;
+    ctx->d_table.release();
+    delete ctx;
+}
+
+// The tiled kernel implements the closed form of the reference's carry loop, valid when
+// w == s or longest <= min(s, w - s); outside it the reference's uint32
+// arithmetic wraps and only a literal emulation reproduces it.
+static bool full_scan_supported(const ts_ctx *c, std::string &why) {
+    if (!c->fast_ok) { why = c->why_not; return false; }
+    const uint32_t s = c->params.step, w = c->params.window_size, ov = w - s, L = c->longest;
+    if (L > w) { why = "pattern longer than window"; return false; }
+    if (ov != 0 && L > std::min(s, ov)) {
+        why = "longest pattern exceeds min(step, window-step): reference start-index arithmetic wraps";
+        return false;
+    }
+    return true;
+}
+
+int ts_uses_fast_path(const ts_ctx *ctx) {
+    std::string why;
+    return ctx && full_scan_supported(ctx, why) ? 1 : 0;
+}
+
+// =========================================================================== batches
+ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t *abs_pos,
+                          size_t n_segs, int tips_only, uint64_t match_capacity) {
+    if (!ctx) return nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    if (n_segs && !seg_lens) { ctx->fail(TS_ERR_INVALID_ARG, "ts_batch_create: null seg_lens"); return nullptr; }
+    std::string why;
+    if (tips_only ? !ctx->fast_ok : !full_scan_supported(ctx, why)) {
+        ctx->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: " + (tips_only ? ctx->why_not : why));
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->fail(TS_ERR_HIP, "hipSetDevice failed"); return nullptr; }
+
+    ts_batch *b = new ts_batch();
+    b->ctx = ctx;
+    b->tips = tips_only != 0;
+    uint32_t wpt = 1;
+    if (!plan_geometry(ctx, b->tips, b->kp, wpt, why)) {
+        ctx->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: " + why);
+        delete b;
+        return nullptr;
+    }
+    const uint64_t tile_bases = (uint64_t)wpt * b->kp.s;
+    const uint32_t tl = ctx->params.terminal_limit;
+
+    uint64_t off = 0, wins = 0;
+    b->segs.resize(n_segs);
+    for (size_t i = 0; i < n_segs; ++i) {
+        SegPlan &sp = b->segs[i];
+        sp.len = seg_lens[i];
+        sp.abs_pos = abs_pos ? abs_pos[i] : 0;
+        sp.in_off = off;
+        off += (sp.len + 15) & ~15ull;
+        sp.first_tile = (uint32_t)b->tiles.size();
+        if (b->tips) {
+            const uint32_t twice = 2u * tl;             // uint32 product, as src/teloscope.cpp:576
+            if (sp.len > twice) {
+                add_region_tiles(b, sp, (uint32_t)i, 0, tl, tile_bases, 1, false);
+                add_region_tiles(b, sp, (uint32_t)i, sp.len - tl, tl, tile_bases, 1, false);
+            } else if (sp.len > 0) {
+                add_region_tiles(b, sp, (uint32_t)i, 0, sp.len, tile_bases, 1, false);
+            }
+        } else {
+            sp.win_base = wins;
+            sp.n_windows = ceil_div(sp.len, ctx->params.step);
+            wins += sp.n_windows;
+            if (sp.len > 0) add_region_tiles(b, sp, (uint32_t)i, 0, sp.len, tile_bases, wpt, true);
+        }
+        sp.n_tiles = (uint32_t)b->tiles.size() - sp.first_tile;
+        b->total_bases += sp.len;
+    }
+    b->input_bytes = off + TS_IN_PAD;
+    b->n_windows = wins;
+    b->match_cap = match_capacity ? match_capacity : b->total_bases / 4 + 4096;
+    if (b->tiles.size() >= 0x7FFFFFFFull) {
+        ctx->fail(TS_ERR_UNSUPPORTED, "too many tiles in one batch");
+        delete b;
+        return nullptr;
+    }
+
+    b->lds_bytes = (uint32_t)ts_k_lds_bytes(&b->kp);
+    if (ts_k_prepare(b->lds_bytes) != 0) {
+        ctx->fail(TS_ERR_HIP, "cannot raise dynamic LDS limit");
+        delete b;
+        return nullptr;
+    }
+    const int occ = ts_k_occupancy(b->lds_bytes);
+    b->grid = (uint32_t)std::min<uint64_t>(std::max<size_t>(b->tiles.size(), 1), (uint64_t)ctx->num_cu * occ);
+
+    if (batch_alloc_outputs(b) != TS_OK || hipEventCreate(&b->ev0) != hipSuccess ||
+        hipEventCreate(&b->ev1) != hipSuccess) {
+        if (ctx->error.empty()) ctx->fail(TS_ERR_HIP, "batch allocation failed");
+        ts_batch_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+
+void ts_batch_destroy(ts_batch *b) {
+    if (!b) return;
+    b->d_in.release(); b->d_tiles.release(); b->d_windows.release(); b->d_matches.release();
+    b->d_state.release(); b->d_prefix.release(); b->d_stats.release(); b->d_small.release();
+    b->d_segtab.release();
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    delete b;
+}
+
+uint64_t ts_batch_segment_offset(const ts_batch *b, size_t i) {
+    return (b && i < b->segs.size()) ? b->segs[i].in_off : 0;
+}
+
+void *ts_batch_input_ptr(ts_batch *b) {
+    if (!b) return nullptr;
+    if (!b->d_in.p) {
+        if (b->d_in.ensure(b->input_bytes) != hipSuccess) return nullptr;
+        (void)hipMemset(b->d_in.p, 0, b->input_bytes);
+    }
+    return b->d_in.p;
+}
+
+int ts_batch_upload(ts_batch *b, size_t i, const char *seq) {
+    if (!b || i >= b->segs.size() || (!seq && b->segs[i].len)) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    if (!ts_batch_input_ptr(b)) return c->fail(TS_ERR_ALLOC, "cannot allocate device input buffer");
+    if (b->segs[i].len)
+        HIP_TRY(c, hipMemcpy((char *)b->d_in.p + b->segs[i].in_off, seq, b->segs[i].len, hipMemcpyHostToDevice));
+    return TS_OK;
+}
+
+int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
+    if (!b) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    if (!d_input) d_input = ts_batch_input_ptr(b);
+    if (!d_input) return c->fail(TS_ERR_ALLOC, "no device input buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nt = b->tiles.size();
+    b->last_input = d_input;
+    b->last_stream = stream;
+    b->scanned = true;
+    b->synced = false;
+
+    TsScanParams &kp = b->kp;
+    kp.in = (const uint8_t *)d_input;
+    kp.tiles = (const TsTile *)b->d_tiles.p;
+    kp.table = (const uint32_t *)c->d_table.p;
+    kp.windows_out = (uint32_t *)b->d_windows.p;
+    kp.matches_out = (uint32_t *)b->d_matches.p;
+    kp.state = (unsigned long long *)b->d_state.p;
+    kp.tile_prefix = (unsigned long long *)b->d_prefix.p;
+    kp.tile_stats = (uint32_t *)b->d_stats.p;
+    kp.ticket = (uint32_t *)b->d_small.p;
+    kp.error_flag = (uint32_t *)b->d_small.p + 1;
+    kp.match_cap = b->match_cap;
+    kp.ntiles = (uint32_t)nt;
+
+    HIP_TRY(c, hipMemsetAsync(b->d_state.p, 0, (nt + 1) * 8, st));
+    HIP_TRY(c, hipMemsetAsync(b->d_small.p, 0, 64, st));
+    HIP_TRY(c, hipEventRecord(b->ev0, st));
+    if (nt) {
+        int e = ts_k_launch_scan(&kp, b->grid, b->lds_bytes, stream);
+        if (e != 0) return c->fail(TS_ERR_HIP, std::string("scan kernel launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    HIP_TRY(c, hipEventRecord(b->ev1, st));
+    return TS_OK;
+}
+
+int ts_batch_sync(ts_batch *b) {
+    if (!b) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    if (!b->scanned) return c->fail(TS_ERR_STATE, "ts_batch_sync before ts_batch_scan");
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        HIP_TRY(c, hipEventSynchronize(b->ev1));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, b->ev0, b->ev1));
+        b->last_ms = ms;
+        const size_t nt = b->tiles.size();
+        uint32_t small[2] = {0, 0};
+        HIP_TRY(c, hipMemcpy(small, b->d_small.p, 8, hipMemcpyDeviceToHost));
+        if (small[1]) return c->fail(TS_ERR_HIP, "look-back spin timed out inside the scan kernel");
+        unsigned long long last = 0;
+        if (nt) HIP_TRY(c, hipMemcpy(&last, (char *)b->d_state.p + (nt - 1) * 8, 8, hipMemcpyDeviceToHost));
+        b->n_matches = last & ((1ull << 62) - 1ull);
+        if (b->n_matches <= b->match_cap) { b->synced = true; return TS_OK; }
+        // the match buffer overflowed: grow it to the exact size and rescan
+        b->match_cap = b->n_matches + 1024;
+        HIP_TRY(c, b->d_matches.ensure(b->match_cap * 4));
+        int rc = ts_batch_scan(b, b->last_input, b->last_stream);
+        if (rc != TS_OK) return rc;
+    }
+    return c->fail(TS_ERR_STATE, "match buffer kept overflowing");
+}
+
+int ts_batch_get_info(const ts_batch *b, ts_batch_info *info) {
+    if (!b || !info) return TS_ERR_INVALID_ARG;
+    info->n_segments = b->segs.size();
+    info->total_bases = b->total_bases;
+    info->input_bytes = b->input_bytes;
+    info->n_windows = b->n_windows;
+    info->n_tiles = b->tiles.size();
+    info->match_capacity = b->match_cap;
+    info->n_matches = b->synced ? b->n_matches : 0;
+    info->algorithmic_bytes = b->total_bases + 32ull * b->n_windows + 4ull * info->n_matches;
+    info->last_kernel_ms = b->last_ms;
+    return TS_OK;
+}
+
+const void *ts_batch_windows_ptr(const ts_batch *b) { return b ? b->d_windows.p : nullptr; }
+const void *ts_batch_matches_ptr(const ts_batch *b) { return b ? b->d_matches.p : nullptr; }
+
+int ts_batch_segment_summary(ts_batch *b, void *d_out, void *stream) {
+    if (!b || !d_out) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    const size_t ns = b->segs.size();
+    if (!b->d_segtab.p) {
+        std::vector<uint32_t> first(ns + 1);
+        std::vector<uint64_t> nwin(ns);
+        for (size_t i = 0; i < ns; ++i) { first[i] = b->segs[i].first_tile; nwin[i] = b->segs[i].n_windows; }
+        first[ns] = (uint32_t)b->tiles.size();
+        const size_t bytes_first = ((ns + 1) * 4 + 15) & ~15ull;
+        HIP_TRY(c, b->d_segtab.ensure(bytes_first + ns * 8 + 16));
+        HIP_TRY(c, hipMemcpy(b->d_segtab.p, first.data(), (ns + 1) * 4, hipMemcpyHostToDevice));
+        if (ns) HIP_TRY(c, hipMemcpy((char *)b->d_segtab.p + bytes_first, nwin.data(), ns * 8, hipMemcpyHostToDevice));
+    }
+    const size_t bytes_first = ((ns + 1) * 4 + 15) & ~15ull;
+    int e = ts_k_launch_summary((const TsTile *)b->d_tiles.p, (const unsigned long long *)b->d_prefix.p,
+                                (const unsigned long long *)b->d_state.p, (const uint32_t *)b->d_stats.p,
+                                (const uint32_t *)b->d_segtab.p,
+                                (const uint64_t *)((char *)b->d_segtab.p + bytes_first), (uint32_t)ns,
+                                (uint32_t)b->tiles.size(), (unsigned long long *)d_out, stream);
+    if (e != 0) return c->fail(TS_ERR_HIP, "summary kernel launch failed");
+    return TS_OK;
+}
+
+// --------------------------------------------------------------- download + host post-processing
+int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out *out) {
+    (void)host_seqs;
+    if (!b || !out) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    if (!b->synced) { int rc = ts_batch_sync(b); if (rc != TS_OK) return rc; }
+    const ts_params &P = c->params;
+    const size_t nt = b->tiles.size(), ns = b->segs.size();
+
+    std::vector<uint32_t> wins(b->n_windows * 8);
+    std::vector<uint32_t> recs(b->n_matches);
+    std::vector<unsigned long long> prefix(nt + 1);
+    if (b->n_windows) HIP_TRY(c, hipMemcpy(wins.data(), b->d_windows.p, b->n_windows * 32, hipMemcpyDeviceToHost));
+    if (b->n_matches) HIP_TRY(c, hipMemcpy(recs.data(), b->d_matches.p, b->n_matches * 4, hipMemcpyDeviceToHost));
+    if (nt) HIP_TRY(c, hipMemcpy(prefix.data(), b->d_prefix.p, nt * 8, hipMemcpyDeviceToHost));
+    prefix[nt] = b->n_matches;
+
+    const uint16_t klen = (uint16_t)c->k;
+    for (size_t si = 0; si < ns; ++si) {
+        const SegPlan &sp = b->segs[si];
+        ts_segment_out &o = out[si];
+        std::memset(&o, 0, sizeof o);
+
+        // windows (float metrics on the host from the integer counts, as the reference does)
+        if (!b->tips && sp.n_windows) {
+            o.windows = (ts_window *)std::calloc(sp.n_windows, sizeof(ts_window));
+            if (!o.windows) return c->fail(TS_ERR_ALLOC, "out of host memory");
+            o.n_windows = sp.n_windows;
+            const bool nuc = P.out_gc || P.out_entropy;
+            for (uint64_t kwin = 0; kwin < sp.n_windows; ++kwin) {
+                const uint32_t *r = &wins[(sp.win_base + kwin) * 8];
+                ts_window &w = o.windows[kwin];
+                const uint64_t ws = kwin * P.step;
+                w.window_start = sp.abs_pos + ws;
+                w.current_window_size = (uint32_t)std::min<uint64_t>(P.window_size, sp.len - ws);
+                if (nuc) for (int i = 0; i < 4; ++i) w.nucleotide_counts[i] = r[i];
+                if (P.out_gc) w.gc_content = ts::gc_content(w.nucleotide_counts, w.current_window_size);
+                if (P.out_entropy) w.shannon_entropy = ts::shannon_entropy(w.nucleotide_counts, w.current_window_size);
+                w.canonical_covered = r[4];
+                w.non_canonical_covered = r[5];
+                w.fwd_covered = r[6];
+                w.rev_covered = r[7];
+            }
+        }
+
+        // matches: tile-relative packed records -> absolute MatchInfo
+        const uint64_t m0 = sp.n_tiles ? prefix[sp.first_tile] : 0;
+        const uint64_t m1 = sp.n_tiles ? prefix[sp.first_tile + sp.n_tiles] : 0;
+        const uint64_t nm = m1 - m0;
+        if (nm) {
+            o.matches = (ts_match *)std::malloc(nm * sizeof(ts_match));
+            if (!o.matches) return c->fail(TS_ERR_ALLOC, "out of host memory");
+            o.n_matches = nm;
+        }
+        const uint64_t term_end = sp.len > P.terminal_limit ? sp.len - P.terminal_limit : 0;
+        uint64_t w_i = 0;
+        for (const Region &rg : sp.regions) {
+            for (uint32_t t = 0; t < rg.n_tiles; ++t) {
+                const uint32_t ti = rg.first_tile + t;
+                const uint64_t tile_rel = rg.start + (uint64_t)t * rg.tile_bases;   // segment-relative
+                for (uint64_t ri = prefix[ti]; ri < prefix[ti + 1]; ++ri) {
+                    const uint32_t rec = recs[ri];
+                    const uint64_t rel = tile_rel + (rec >> 2);
+                    ts_match &m = o.matches[w_i++];
+                    m.position = sp.abs_pos + rel;
+                    m.match_size = klen;
+                    uint8_t fl = 0;
+                    if (rec & 2u) fl |= TS_MATCH_FORWARD;
+                    if (rec & 1u) fl |= TS_MATCH_CANONICAL;
+                    if (rel <= P.terminal_limit || rel >= term_end) fl |= TS_MATCH_TERMINAL;   // src/teloscope.cpp:451-459
+                    m.flags = fl;
+                    std::memset(m.reserved, 0, sizeof m.reserved);
+                }
+            }
+        }
+
+        // block calling (src/teloscope.cpp:642-657)
+        std::vector<uint32_t> fwd_idx, rev_idx;
+        fwd_idx.reserve(nm / 2 + 1); rev_idx.reserve(nm / 2 + 1);
+        for (uint64_t i = 0; i < nm; ++i)
+            ((o.matches[i].flags & TS_MATCH_FORWARD) ? fwd_idx : rev_idx).push_back((uint32_t)i);
+        if (nm > 0xFFFFFFFFull) return c->fail(TS_ERR_UNSUPPORTED, "more than 2^32 matches in one segment");
+        std::vector<ts_block> term, its;
+        uint64_t fwd_boundary = sp.abs_pos, rev_boundary = sp.abs_pos + sp.len;
+        if (fwd_idx.size() >= 2)
+            fwd_boundary = ts::terminal_blocks(c->bp, o.matches, fwd_idx.data(), fwd_idx.size(), term, sp.len, sp.abs_pos, true);
+        if (rev_idx.size() >= 2)
+            rev_boundary = ts::terminal_blocks(c->bp, o.matches, rev_idx.data(), rev_idx.size(), term, sp.len, sp.abs_pos, false);
+        if (!b->tips && fwd_boundary < rev_boundary && nm >= 2)
+            ts::interstitial_blocks(c->bp, o.matches, nm, its, fwd_boundary, rev_boundary);
+        auto copy_blocks = [&](const std::vector<ts_block> &v, ts_block *&dst, uint64_t &n) -> bool {
+            n = v.size();
+            dst = nullptr;
+            if (v.empty()) return true;
+            dst = (ts_block *)std::malloc(v.size() * sizeof(ts_block));
+            if (!dst) return false;
+            std::memcpy(dst, v.data(), v.size() * sizeof(ts_block));
+            return true;
+        };
+        if (!copy_blocks(term, o.terminal_blocks, o.n_terminal_blocks) ||
+            !copy_blocks(its, o.interstitial_blocks, o.n_interstitial_blocks))
+            return c->fail(TS_ERR_ALLOC, "out of host memory");
+    }
+    return TS_OK;
+}
+
+void ts_free_segments(ts_segment_out *out, size_t n_segs) {
+    if (!out) return;
+    for (size_t i = 0; i < n_segs; ++i) {
+        std::free(out[i].windows);
+        std::free(out[i].matches);
+        std::free(out[i].terminal_blocks);
+        std::free(out[i].interstitial_blocks);
+        std::memset(&out[i], 0, sizeof out[i]);
+    }
+}
+
+// =========================================================================== scanSegment, batched
+static int scan_group(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<size_t> &which,
+                      bool tips, ts_segment_out *out) {
+    if (which.empty()) return TS_OK;
+    std::vector<uint64_t> lens(which.size()), abs(which.size());
+    for (size_t i = 0; i < which.size(); ++i) { lens[i] = segs[which[i]].len; abs[i] = segs[which[i]].abs_pos; }
+    ts_batch *b = ts_batch_create(ctx, lens.data(), abs.data(), which.size(), tips, 0);
+    if (!b) return ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP;
+    int rc = TS_OK;
+    for (size_t i = 0; i < which.size() && rc == TS_OK; ++i) rc = ts_batch_upload(b, i, segs[which[i]].seq);
+    if (rc == TS_OK) rc = ts_batch_scan(b, nullptr, nullptr);
+    if (rc == TS_OK) rc = ts_batch_sync(b);
+    std::vector<ts_segment_out> tmp(which.size());
+    if (rc == TS_OK) rc = ts_batch_download(b, nullptr, tmp.data());
+    if (rc == TS_OK)
+        for (size_t i = 0; i < which.size(); ++i) out[which[i]] = tmp[i];
+    else
+        ts_free_segments(tmp.data(), tmp.size());
+    ts_batch_destroy(b);
+    return rc;
+}
+
+int ts_scan_segments(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out) {
+    if (!ctx || (n_segs && (!segs || !out))) return TS_ERR_INVALID_ARG;
+    for (size_t i = 0; i < n_segs; ++i) {
+        std::memset(&out[i], 0, sizeof out[i]);
+        if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
+    }
+    std::vector<size_t> full, tips;
+    for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
+    int rc = scan_group(ctx, segs, full, false, out);
+    if (rc == TS_OK) rc = scan_group(ctx, segs, tips, true, out);
+    if (rc != TS_OK) ts_free_segments(out, n_segs);
+    return rc;
+}
+
+// =========================================================================== ReadTelomereFilter
+int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, size_t n_reads,
+                    uint8_t *pass) {
+    if (!ctx || (n_reads && (!seqs || !lens || !pass))) return TS_ERR_INVALID_ARG;
+    if (!ctx->read_filter) return ctx->fail(TS_ERR_STATE, "context was not made by ts_create_read_filter");
+    std::vector<ts_segment_in> in(n_reads);
+    for (size_t i = 0; i < n_reads; ++i) {
+        uint64_t n = lens[i];
+        if (n && seqs[i][n - 1] == '\r') --n;             // src/read-filter.cpp:38-40
+        in[i].seq = seqs[i];
+        in[i].len = n;
+        in[i].abs_pos = 0;
+        in[i].tips_only = 1;
+    }
+    std::vector<ts_segment_out> out(n_reads);
+    int rc = ts_scan_segments(ctx, in.data(), n_reads, out.data());
+    if (rc != TS_OK) return rc;
+    for (size_t i = 0; i < n_reads; ++i) pass[i] = out[i].n_terminal_blocks != 0;
+    ts_free_segments(out.data(), n_reads);
+    return TS_OK;
+}
+
+}  // extern "C"

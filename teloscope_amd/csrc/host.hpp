@@ -1,0 +1,51 @@
+// host.hpp — internal C++17 interfaces of libteloscan's host side.
+#ifndef TS_HOST_HPP
+#define TS_HOST_HPP
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/teloscan.h"
+
+namespace ts {
+
+struct Pattern {
+    std::string seq;
+    bool is_forward = false;
+    bool is_canonical = false;
+};
+
+// patterns.cpp
+std::string rev_com(const std::string &s);
+void unmask(std::string &s);
+void canonical_orientation(const std::string &canonical_in, std::string &fwd, std::string &rev);
+std::vector<Pattern> expand_patterns(const std::string &raw_csv, int edit_distance,
+                                     const std::string &canonical_fwd);
+int  base_code(char c);
+bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
+                       uint32_t &rows);
+
+// blocks.cpp — block calling on the match stream (src/teloscope.cpp:29-383)
+struct BlockParams {
+    uint32_t terminal_limit;
+    uint16_t max_match_dist, min_block_len, max_block_dist, min_block_counts;
+    float    min_block_density;
+    uint16_t first_pattern_len;     // userInput.patterns.front().size()
+};
+
+// Matches are passed as parallel views over ts_match records; `idx` selects a subsequence
+// (fwdMatches / revMatches) without copying, nullptr = all.
+uint64_t terminal_blocks(const BlockParams &bp, const ts_match *m, const uint32_t *idx, size_t n,
+                         std::vector<ts_block> &out, uint64_t seg_size, uint64_t abs_pos, bool from_start);
+void interstitial_blocks(const BlockParams &bp, const ts_match *m, size_t n, std::vector<ts_block> &out,
+                         uint64_t fwd_boundary, uint64_t rev_boundary);
+int  label_terminal_blocks(ts_block *blocks, size_t n, uint16_t gaps, uint64_t path_size,
+                           uint32_t terminal_limit, std::string &label);
+
+float gc_content(const uint32_t counts[4], uint32_t window_size);
+float shannon_entropy(const uint32_t counts[4], uint32_t window_size);
+
+}  // namespace ts
+
+#endif

@@ -1,0 +1,195 @@
+// patterns.cpp — host-side pattern preparation of libteloscan (C++17).
+//
+// Product restatement of the reference's pattern expansion
+// (expandPatternsWithOrientation, src/tools.cpp:201-283; getCombinations :73-85;
+// getEditVariants :88-128; the canonical orientation rule src/main.cpp:287-296) and of
+// the gfalibs helpers it leans on (revCom, unmaskSequence).  It defines WHICH k-mers the
+// kernels match, so it is part of the path even though it runs once per context.
+#include "host.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace ts {
+
+std::string rev_com(const std::string &s) {
+    std::string r(s.rbegin(), s.rend());
+    for (char &c : r) {
+        switch (c) {
+            case 'A': c = 'T'; break; case 'T': c = 'A'; break;
+            case 'C': c = 'G'; break; case 'G': c = 'C'; break;
+            case 'a': c = 't'; break; case 't': c = 'a'; break;
+            case 'c': c = 'g'; break; case 'g': c = 'c'; break;
+            default: break;
+        }
+    }
+    return r;
+}
+
+void unmask(std::string &s) {
+    for (char &c : s)
+        if (c >= 'a' && c <= 'z') c = static_cast<char>(c - 'a' + 'A');
+}
+
+namespace {
+
+const char *iupac(char c) {
+    switch (c) {
+        case 'A': return "A";   case 'C': return "C";   case 'G': return "G";   case 'T': return "T";
+        case 'R': return "AG";  case 'Y': return "CT";  case 'M': return "AC";  case 'K': return "GT";
+        case 'S': return "CG";  case 'W': return "AT";  case 'H': return "ACT"; case 'B': return "CGT";
+        case 'V': return "ACG"; case 'D': return "AGT"; case 'N': return "ACGT";
+        default:  return "";
+    }
+}
+
+void combos(const std::string &pat, std::string &cur, size_t idx, std::vector<std::string> &out) {
+    if (idx == pat.size()) { out.push_back(cur); return; }
+    for (const char *m = iupac(pat[idx]); *m; ++m) {
+        cur[idx] = *m;
+        combos(pat, cur, idx + 1, out);
+    }
+}
+
+void edits(const std::string &pat, int max_dist, std::vector<std::string> &out) {
+    if (max_dist <= 0) return;
+    static const char nts[4] = {'A', 'C', 'G', 'T'};
+    const size_t first = out.size();
+    for (size_t i = 0; i < pat.size(); ++i) {
+        const char o = pat[i];
+        if (o != 'A' && o != 'C' && o != 'G' && o != 'T') continue;
+        for (char n : nts) {
+            if (n == o) continue;
+            out.push_back(pat);
+            out.back()[i] = n;
+        }
+    }
+    if (max_dist >= 2) {
+        const size_t d1 = out.size();
+        for (size_t v = first; v < d1; ++v) {
+            const std::string base = out[v];
+            edits(base, 1, out);
+        }
+    }
+}
+
+unsigned best_offset_distance(const std::string &shorter, const std::string &longer) {
+    unsigned best = 255;
+    for (size_t off = 0; off + shorter.size() <= longer.size(); ++off) {
+        unsigned d = 0;
+        for (size_t i = 0; i < shorter.size(); ++i) d += shorter[i] != longer[off + i];
+        best = std::min<unsigned>(best, d & 0xFFu);
+    }
+    return best;
+}
+
+bool closer_to_fwd(const std::string &pat, const std::string &can_fwd, const std::string &can_rev) {
+    if (pat.size() == can_fwd.size()) {
+        unsigned df = 0, dr = 0;
+        for (size_t i = 0; i < pat.size(); ++i) {
+            df += pat[i] != can_fwd[i];
+            dr += pat[i] != can_rev[i];
+        }
+        return (df & 0xFFu) <= (dr & 0xFFu);
+    }
+    const bool pat_short = pat.size() < can_fwd.size();
+    const std::string &shorter = pat_short ? pat : can_fwd;
+    const std::string longer = pat_short ? can_fwd : pat;
+    const std::string longer_rev = pat_short ? can_rev : rev_com(pat);
+    return best_offset_distance(shorter, longer) <= best_offset_distance(shorter, longer_rev);
+}
+
+}  // namespace
+
+void canonical_orientation(const std::string &canonical_in, std::string &fwd, std::string &rev) {
+    std::string c = canonical_in;
+    unmask(c);
+    const std::string rc = rev_com(c);
+    if (c <= rc) { fwd = c; rev = rc; } else { fwd = rc; rev = c; }
+}
+
+std::vector<Pattern> expand_patterns(const std::string &raw_csv, int edit_distance,
+                                     const std::string &canonical_fwd) {
+    const std::string can_rev = rev_com(canonical_fwd);
+    std::vector<std::pair<std::string, bool>> all;
+
+    size_t pos = 0;
+    while (pos <= raw_csv.size()) {
+        size_t comma = raw_csv.find(',', pos);
+        if (comma == std::string::npos) comma = raw_csv.size();
+        std::string seed = raw_csv.substr(pos, comma - pos);
+        pos = comma + 1;
+        if (seed.empty() || seed.size() > 62) continue;
+        unmask(seed);
+
+        std::vector<std::string> cs;
+        std::string cur = seed;
+        combos(seed, cur, 0, cs);
+        for (const std::string &combo : cs) {
+            const bool seed_fwd = closer_to_fwd(combo, canonical_fwd, can_rev);
+            std::vector<std::string> vars{combo};
+            edits(combo, edit_distance, vars);
+            for (const std::string &v : vars) {
+                all.emplace_back(v, seed_fwd);
+                all.emplace_back(rev_com(v), !seed_fwd);
+            }
+        }
+    }
+
+    // Same call sequence as the reference on the same element order, so that equal strings
+    // with different orientation resolve the way its libstdc++ build resolves them.
+    std::sort(all.begin(), all.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    all.erase(std::unique(all.begin(), all.end(),
+                          [](const auto &a, const auto &b) { return a.first == b.first; }),
+              all.end());
+
+    std::vector<Pattern> out;
+    out.reserve(all.size());
+    for (const auto &pr : all) {
+        Pattern p;
+        p.seq = pr.first;
+        p.is_forward = pr.second;
+        p.is_canonical = (pr.first == canonical_fwd || pr.first == can_rev);
+        out.push_back(std::move(p));
+    }
+    return out;
+}
+
+// 2-bit code used by the kernels' SWAR decode: (ascii >> 1) & 3  ->  A0 C1 T2 G3
+int base_code(char c) {
+    switch (c) {
+        case 'A': return 0; case 'C': return 1; case 'T': return 2; case 'G': return 3;
+        default: return -1;
+    }
+}
+
+// Match table for uniform-length pattern sets: for k-mer index x (base i at bits 2i..2i+1)
+// row x>>5 holds, for each of 16 replicas, the dwords {M, F, C, 0}; bit x&31 of M says
+// "x is a pattern", of F "forward-oriented", of C "canonical".  The 16 replicas give every
+// lane of a ds_read_b128 lane group its own 4 banks.
+bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
+                       uint32_t &rows) {
+    if (k < 3 || k > 9) return false;
+    const uint64_t entries = 1ull << (2 * k);
+    rows = static_cast<uint32_t>(entries / 32);
+    table.assign(static_cast<size_t>(rows) * 64, 0u);
+    for (const Pattern &p : pats) {
+        if (p.seq.size() != k) return false;
+        uint32_t x = 0;
+        for (uint32_t i = 0; i < k; ++i) {
+            const int c = base_code(p.seq[i]);
+            if (c < 0) return false;
+            x |= static_cast<uint32_t>(c) << (2 * i);
+        }
+        const uint32_t row = x >> 5, bit = 1u << (x & 31u);
+        for (uint32_t rep = 0; rep < 16; ++rep) {
+            uint32_t *e = &table[static_cast<size_t>(row) * 64 + rep * 4];
+            e[0] |= bit;
+            if (p.is_forward) e[1] |= bit;
+            if (p.is_canonical) e[2] |= bit;
+        }
+    }
+    return true;
+}
+
+}  // namespace ts

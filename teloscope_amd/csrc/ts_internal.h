@@ -1,0 +1,79 @@
+// ts_internal.h — structures shared by the host side of libteloscan and its HIP kernels.
+#ifndef TS_INTERNAL_H
+#define TS_INTERNAL_H
+
+#include <stdint.h>
+
+// Geometry of the tiled uniform-k scan kernel (kernels.hip: ts_scan_tiles).
+//
+// A segment (or tips-only region) is cut into tiles.  A tile OWNS `nwin` consecutive
+// windows (window k covers [k*s, k*s+w)) = the `nwin*s` bases where those windows start,
+// and additionally reads a halo so that every owned window and every k-mer that starts
+// in an owned base is complete.  Positions inside a tile are "plane coordinates":
+// byte offset from the 16-byte-aligned address at or below the tile's first owned base.
+
+#define TS_WG_THREADS   512            // 8 wavefronts per workgroup
+#define TS_WAVES        (TS_WG_THREADS / 64)
+#define TS_CHUNK        1008           // positions a wave resolves per iteration (63 lanes x 16)
+#define TS_BLK_STRIDE   16             // u32 accumulators per step-block in LDS
+#define TS_IN_PAD       4096           // bytes of zero padding after the last segment in the input buffer
+
+// lookback state word: [63:62] status, [61:0] value
+#define TS_ST_INVALID 0ull
+#define TS_ST_AGG     1ull
+#define TS_ST_INCL    2ull
+
+struct TsTile {                 // 32 bytes
+    uint64_t in_off;            // byte offset (input buffer) of the tile's first owned base
+    uint64_t win_out;           // index of the first owned window record
+    uint32_t nrel;              // bases from the first owned base to the end of the segment/region (clamped)
+    uint32_t nwin;              // owned windows (tips mode: 1 pseudo block, no record written)
+    uint32_t own_len;           // owned bases = min(nrel, nwin*s)
+    uint32_t seg;               // segment index (host bookkeeping / summary kernel)
+};
+
+struct TsScanParams {
+    const uint8_t  *in;
+    const TsTile   *tiles;
+    const uint32_t *table;      // replicated match table: rows x 16 replicas x {M,F,C,0}
+    uint32_t       *windows_out;    // 8 x u32 per window
+    uint32_t       *matches_out;    // packed records
+    unsigned long long *state;      // lookback words, one per tile (zeroed before launch)
+    unsigned long long *tile_prefix;// exclusive match prefix per tile
+    uint32_t       *tile_stats;     // per tile: {canonical, forward} pushed-match counts
+    uint32_t       *ticket;         // tile dispenser (zeroed before launch)
+    uint32_t       *error_flag;     // set to 1 if a lookback spin timed out
+    uint64_t        match_cap;
+    uint32_t        ntiles;
+    uint32_t        table_rows;     // 4^k / 32
+    uint32_t        k;              // pattern length
+    uint32_t        s, w;           // step and window (tips mode: s = w = tile size)
+    uint32_t        q, r;           // w = q*s + r
+    uint32_t        qq, hh;         // w - k = qq*s + hh
+    uint32_t        nch;            // chunks of TS_CHUNK positions per tile
+    uint32_t        max_blocks;     // LDS accumulator rows
+    uint32_t        fold_mask;      // 0xDFDFDFDF (fold case) or 0xFFFFFFFF
+    uint32_t        straddle_fix;   // 1: w == s, drop matches that straddle a window end
+    uint32_t        windows_on;     // 0 in tips-only mode
+    uint32_t        nuc_on;         // nucleotide counts wanted (-g / -e)
+};
+
+struct TsLaunchInfo {
+    uint32_t grid;
+    uint32_t lds_bytes;
+};
+
+#ifdef __cplusplus
+extern "C++" {
+// Implemented in kernels.hip (compiled by hipcc).  All return a hipError_t as int.
+int  ts_k_lds_bytes(const TsScanParams *p);
+int  ts_k_prepare(uint32_t lds_bytes);                       // raises the dynamic-LDS limit once
+int  ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, void *stream);
+int  ts_k_launch_summary(const TsTile *tiles, const unsigned long long *tile_prefix,
+                         const unsigned long long *state, const uint32_t *tile_stats,
+                         const uint32_t *seg_first_tile, const uint64_t *seg_nwin,
+                         uint32_t nseg, uint32_t ntiles, unsigned long long *out, void *stream);
+}
+#endif
+
+#endif

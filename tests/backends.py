@@ -35,3 +35,97 @@ class OracleReadFilter:
 
     def filter(self, seqs):
         return [self.oracle.read_filter_matches(s) for s in seqs]
+
+
+def _user_input(opts):
+    import teloscope_amd as ta
+    ui = ta.UserInputTeloscope(
+        canonicalFwd=opts.canonical_fwd, canonicalRev=opts.canonical_rev,
+        canonicalSize=opts.canonical_size, rawPatterns=list(opts.raw_patterns),
+        windowSize=opts.window_size, step=opts.step, terminalLimit=opts.terminal_limit,
+        editDistance=opts.edit_distance, maxMatchDist=opts.max_match_dist,
+        minBlockLen=opts.min_block_len, minBlockLenSet=opts.min_block_len_set,
+        maxBlockDist=opts.max_block_dist, minBlockCounts=opts.min_block_counts,
+        minBlockDensity=float(opts.min_block_density), outGC=opts.out_gc,
+        outEntropy=opts.out_entropy, outMatches=opts.out_matches, outITS=opts.out_its,
+        outWinRepeats=opts.out_win_repeats, ultraFastMode=opts.ultra_fast)
+    ui.patternInfo = ta.expandPatternsWithOrientation(ui.rawPatterns, ui.editDistance, ui.canonicalFwd)
+    return ui
+
+
+class ProductBackend:
+    """libteloscan.so (HIP, gfx950) through teloscope_amd: the thing under test."""
+
+    def __init__(self, opts):
+        import teloscope_amd as ta
+        self.ta = ta
+        self.ui = _user_input(opts)
+        self.patterns = [(p, f, p in (opts.canonical_fwd, opts.canonical_rev)) for p, f in self.ui.patternInfo]
+        self.teloscope = ta.Teloscope(self.ui)
+
+    def scan_segment(self, seq, abs_pos, tips_only):
+        return segment_as_dict(self.teloscope.scanSegment(seq, abs_pos, tips_only))
+
+    def scan_segments(self, segs):
+        return [segment_as_dict(s) for s in self.teloscope.scanSegments(segs)]
+
+    def empty_blocks(self):
+        from teloscope_amd import _capi
+        return np.zeros(0, dtype=_capi.BLOCK_DT)
+
+    def label_terminal_blocks(self, blocks, gaps, path_size, terminal_limit):
+        return self.ta.Teloscope.labelTerminalBlocks(blocks, gaps, path_size, terminal_limit)
+
+
+class ProductReadFilter:
+    def __init__(self, opts):
+        import teloscope_amd as ta
+        self.rf = ta.ReadTelomereFilter(_user_input(opts))
+
+    def filter(self, seqs):
+        return self.rf.matchesBatch(seqs)
+
+
+def segment_as_dict(sd):
+    return dict(windows=sd.windows, terminal_blocks=sd.terminalBlocks,
+                interstitial_blocks=sd.interstitialBlocks, canonical_matches=sd.canonicalMatches,
+                non_canonical_matches=sd.nonCanonicalMatches, fwd_matches=sd.fwdMatches,
+                rev_matches=sd.revMatches, all_matches=sd.allMatches)
+
+
+MATCH_FIELDS = ("position", "match_size")
+WINDOW_FIELDS = ("window_start", "current_window_size", "nucleotide_counts", "canonical_covered",
+                 "non_canonical_covered", "fwd_covered", "rev_covered")
+BLOCK_FIELDS = ("start", "block_len", "block_counts", "forward_count", "reverse_count",
+                "canonical_count", "non_canonical_count", "total_covered", "fwd_covered",
+                "can_covered", "has_valid_or", "block_label")
+
+
+def assert_segment_equal(got, exp, tips_only, float_fields=True, ctx=""):
+    """Bit-exact comparison of a product SegmentData (dict) with the oracle's."""
+    def cmp_matches(name):
+        g, e = got[name], exp[name]
+        assert len(g) == len(e), "%s %s: %d vs %d matches" % (ctx, name, len(g), len(e))
+        for f in MATCH_FIELDS:
+            assert np.array_equal(g[f], e[f]), "%s %s.%s differs" % (ctx, name, f)
+        gf = (g["flags"] & 1) != 0
+        gc = (g["flags"] & 2) != 0
+        assert np.array_equal(gf, e["is_forward"] != 0), "%s %s.is_forward differs" % (ctx, name)
+        assert np.array_equal(gc, e["is_canonical"] != 0), "%s %s.is_canonical differs" % (ctx, name)
+
+    for name in ("fwd_matches", "rev_matches", "all_matches", "canonical_matches", "non_canonical_matches"):
+        cmp_matches(name)
+    gw, ew = got["windows"], exp["windows"]
+    assert len(gw) == len(ew), "%s windows: %d vs %d" % (ctx, len(gw), len(ew))
+    for f in WINDOW_FIELDS:
+        assert np.array_equal(gw[f], ew[f]), "%s windows.%s differs" % (ctx, f)
+    if float_fields and len(gw):
+        # float32 metrics are evaluated on the host from identical integers: expected bit-equal,
+        # north_star tolerance is 1e-6
+        assert np.max(np.abs(gw["gc_content"].astype(np.float64) - ew["gc_content"])) <= 1e-6, ctx
+        assert np.max(np.abs(gw["shannon_entropy"].astype(np.float64) - ew["shannon_entropy"])) <= 1e-6, ctx
+    for name in ("terminal_blocks", "interstitial_blocks"):
+        g, e = got[name], exp[name]
+        assert len(g) == len(e), "%s %s: %d vs %d" % (ctx, name, len(g), len(e))
+        for f in BLOCK_FIELDS:
+            assert np.array_equal(g[f], e[f]), "%s %s.%s differs" % (ctx, name, f)

@@ -1,0 +1,130 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/teloscan.h
+declares, its host-only entry points (pattern expansion, labelling, float metrics) agree with
+the oracle, and — without a GPU — context creation fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import harness as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import teloscope_amd
+    return teloscope_amd
+
+
+def test_header_symbols_exported(ta):
+    from teloscope_amd import _capi
+    hdr = open(os.path.join(ROOT, "include", "teloscan.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)          # declarations only, not comments
+    declared = set(re.findall(r"\b(ts_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_capi.SYMBOLS)
+    lib = C.CDLL(_capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert lib.ts_abi_version() == 1
+
+
+def test_struct_sizes_match_header(ta, tmp_path):
+    """ctypes mirrors vs the C compiler's view of include/teloscan.h."""
+    import subprocess
+    from teloscope_amd import _capi as K
+    names = ["ts_params", "ts_match", "ts_window", "ts_block", "ts_pattern", "ts_segment_in",
+             "ts_segment_out", "ts_batch_info"]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "teloscan.h"\nint main(void){' +
+                   "".join('printf("%%zu\\n", sizeof(%s));' % n for n in names) + "return 0;}")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    mirrors = [K.Params, K.Match, K.Window, K.Block, K.Pattern, K.SegmentIn, K.SegmentOut, K.BatchInfo]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+PATTERN_CASES = [
+    (["CCCTAA", "TTAGGG"], 1, "CCCTAA", 38),
+    (["CCCTAA", "TTAGGG"], 0, "CCCTAA", 2),
+    (["CCCTAA", "TTAGGG"], 2, "CCCTAA", 308),
+    (["TTAGGG", "TCAGGG", "TGAGGG", "TTGGGG"], 1, "CCCTAA", 124),
+    (["CCCTAAA", "TTTAGGG"], 1, "CCCTAAA", 44),
+    (["TTAGGN"], 0, "CCCTAA", None),
+    (["TTRGGG", "CCCTAA"], 1, "CCCTAA", None),
+    (["TTAGG", "TTAGGG"], 1, "CCCTAA", None),
+]
+
+
+@pytest.mark.parametrize("raw,ed,can,count", PATTERN_CASES)
+def test_pattern_expansion_matches_oracle(ta, oracle_lib, raw, ed, can, count):
+    """expandPatternsWithOrientation (src/tools.cpp:201-283): product C++ vs oracle C, and the
+    pattern counts the reference prints ("Scanning N telomeric variants")."""
+    got = ta.expandPatternsWithOrientation(raw, ed, can)
+    exp = oracle_lib.expand_patterns(raw, ed, can)
+    assert [(p, f) for p, f, _, _ in exp] == got
+    assert not any(a for _, _, _, a in exp)
+    if count is not None:
+        assert len(got) == count
+
+
+def test_canonical_orientation(ta):
+    assert ta.canonicalOrientation("TTAGGG") == ("CCCTAA", "TTAGGG")
+    assert ta.canonicalOrientation("ccctaaa") == ("CCCTAAA", "TTTAGGG")
+
+
+def test_float_metrics_match_oracle(ta, oracle_lib):
+    rng = np.random.default_rng(7)
+    for _ in range(2000):
+        size = int(rng.integers(1, 5000))
+        c = rng.multinomial(int(rng.integers(0, size + 1)), [0.3, 0.2, 0.2, 0.3])
+        a = ta.getGCContent(c, size), ta.getShannonEntropy(c, size)
+        b = oracle_lib.gc_content(c, size), oracle_lib.shannon_entropy(c, size)
+        assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+
+
+def test_label_terminal_blocks_matches_oracle(ta, oracle_lib):
+    from teloscope_amd import _capi as K
+    rng = np.random.default_rng(11)
+    for _ in range(500):
+        n = int(rng.integers(0, 6))
+        path_size = int(rng.integers(100, 200000))
+        blocks = np.zeros(n, dtype=K.BLOCK_DT)
+        ob = np.zeros(n, dtype=oracle_lib.BLOCK_DT)
+        for i in range(n):
+            start = int(rng.integers(0, path_size))
+            vals = dict(start=start, block_len=int(rng.integers(1, 5000)),
+                        can_covered=int(rng.integers(1, 4000)), has_valid_or=int(rng.integers(0, 2)),
+                        block_label=(b"p", b"q")[int(rng.integers(0, 2))])
+            for k, v in vals.items():
+                blocks[i][k] = v
+                ob[i][k] = v
+        gaps = int(rng.integers(0, 2))
+        tl = int(rng.choice([100, 50000]))
+        gb, glabel, gtype = ta.Teloscope.labelTerminalBlocks(blocks, gaps, path_size, tl)
+        eb, elabel, etype = oracle_lib.label_terminal_blocks(ob, gaps, path_size, tl)
+        assert (glabel, gtype) == (elabel, etype)
+        assert np.array_equal(gb["is_longest"], eb["is_longest"])
+        assert np.array_equal(gb["start"], eb["start"])
+
+
+def test_no_cpu_fallback(ta):
+    """Without a HIP device the product refuses to run (no silent CPU path)."""
+    from teloscope_amd import _capi as K
+    if K.lib().ts_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(ta.TeloscanError) as ei:
+        ta.Teloscope(ta.UserInputTeloscope())
+    assert ei.value.code == K.TS_ERR_NO_DEVICE
+
+
+def test_product_does_not_reference_oracle():
+    """teloscope_amd/ must never import, link or load anything from oracle/."""
+    for dp, _, files in os.walk(os.path.join(ROOT, "teloscope_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle" not in txt.lower().replace("no cpu", ""), os.path.join(dp, f)

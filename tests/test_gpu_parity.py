@@ -1,0 +1,213 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle, on a real MI355X.
+
+  * every legacy `.tst` manifest: the CLI stdout the reference expects, produced from the
+    GPU scan, plus segment-level bit-exact equality with the oracle (windows, all five match
+    lists, terminal and interstitial blocks);
+  * FASTQ-subset manifests and read-filter known answers;
+  * seeded random assemblies over the window/step/pattern grid incl. the BASELINE flag sets,
+    with N runs, IUPAC codes, soft-masked bases and lengths straddling w, s, t, 2t and the tile;
+  * size-independent properties at multi-megabase scale.
+"""
+import glob
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from tests import harness as H
+from tests import seqgen
+from tests.backends import (OracleBackend, OracleReadFilter, ProductBackend, ProductReadFilter,
+                            assert_segment_equal)
+from tests.test_oracle_read_filter_kats import KATS, RANDOM_OPTION_SETS, random_read_set
+
+pytestmark = pytest.mark.gpu
+
+MANIFESTS = sorted(glob.glob(os.path.join(H.GOLDEN, "validateFiles", "*.tst")))
+LEGACY = [m for m in MANIFESTS if H.load_manifest(m)["mode"] == "embedded"]
+FASTQ = [m for m in MANIFESTS if os.path.basename(m).startswith("fastq_subset")]
+
+
+class BothBackends:
+    """Runs the product and checks every scanSegment result against the oracle on the fly."""
+
+    def __init__(self, opts):
+        self.prod = ProductBackend(opts)
+        self.orac = OracleBackend(opts)
+        assert [(p, f) for p, f, _ in self.prod.patterns] == [(p, f) for p, f, _, _ in self.orac.patterns]
+
+    def scan_segment(self, seq, abs_pos, tips_only):
+        g = self.prod.scan_segment(seq, abs_pos, tips_only)
+        e = self.orac.scan_segment(seq, abs_pos, tips_only)
+        assert_segment_equal(g, e, tips_only, ctx="abs_pos=%d len=%d tips=%s" % (abs_pos, len(seq), tips_only))
+        return g
+
+    def empty_blocks(self):
+        return self.prod.empty_blocks()
+
+    def label_terminal_blocks(self, *a):
+        return self.prod.label_terminal_blocks(*a)
+
+
+@pytest.mark.parametrize("path", LEGACY, ids=[os.path.basename(p) for p in LEGACY])
+def test_legacy_manifest_on_gpu(path):
+    m = H.load_manifest(path)
+    opts = H.parse_cli(m["command"])
+    stdout, _ = H.run_assembly(BothBackends(opts), opts, H.golden_path(opts.input))
+    assert stdout.split("\n") == m["expected"].split("\n")
+
+
+@pytest.mark.parametrize("path", FASTQ, ids=[os.path.basename(p) for p in FASTQ])
+def test_fastq_manifest_on_gpu(path):
+    m = H.load_manifest(path)
+    d = {}
+    for k, v in m["directives"]:
+        d.setdefault(k, []).append(v)
+    opts = H.parse_cli(m["command"])
+    src = H.golden_path(opts.input or opts.stdin_redirect)
+    data = gzip.open(src, "rb").read() if src.endswith(".gz") else open(src, "rb").read()
+    try:
+        out, kept, total = H.run_fastq_subset(ProductReadFilter(opts), data)
+        code = 0
+    except ValueError:
+        code = 1
+    assert code == int(d["expect_exit"][0])
+    if code == 0:
+        so = d.get("expect_stdout", ["ignore"])[0]
+        if " -o " in m["command"]:
+            so = "testFiles/expected/fastq_subset.fq"
+        if so != "ignore":
+            assert out == open(H.golden_path(so), "rb").read()
+        for sub in d.get("expect_stderr_substr", []):
+            if sub.startswith("FASTQ subset: kept"):
+                assert sub == "FASTQ subset: kept %d of %d reads." % (kept, total)
+
+
+@pytest.mark.parametrize("case", range(len(KATS)))
+def test_read_filter_kat_on_gpu(case):
+    cli, seqs, expected = KATS[case]
+    opts = H.parse_cli("--fastq-subset " + cli)
+    got = [n for n, ok in zip(seqs, ProductReadFilter(opts).filter([s.encode() for s in seqs.values()])) if ok]
+    assert got == expected
+
+
+@pytest.mark.parametrize("cli", RANDOM_OPTION_SETS)
+def test_read_filter_random_reads_on_gpu(cli):
+    """the 240 seeded reads of scripts/test_bam_subset.py:384-404, product vs oracle"""
+    seqs = [s.encode() for s in random_read_set().values()]
+    opts = H.parse_cli("--fastq-subset " + cli)
+    assert ProductReadFilter(opts).filter(seqs) == OracleReadFilter(opts).filter(seqs)
+
+
+GRID = [
+    # cli, note
+    "-r -g -e -m -i",                                           # default w = s = 1000 (straddle loss)
+    "-w 1000 -s 500 -r -g -e -m -i",
+    "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -m -i",   # BASELINE cfg 2/3
+    "-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i",                # BASELINE cfg 5 (k = 7)
+    "-w 500 -s 250 -r -g -e -i",
+    "-w 200 -s 200 -r -g",
+    "-w 1000 -s 100 -g -e -i",                                  # q = 10
+    "-w 1000 -s 300 -r -g -e -i",                               # w not a multiple of s
+    "-w 777 -s 333 -r -g -e -m -i -t 700",
+    "-w 64 -s 16 -g -i -t 100",
+    "-x 0 -w 1000 -s 500 -g -e -i",
+    "-x 2 -w 1000 -s 500 -r -i -k 20 -d 100",
+    "-p TTAGGN -x 0 -w 300 -s 150 -g -i",
+    "-c TTAGG -w 100 -s 50 -g -e -i -l 50",                     # k = 5
+    "-c TTTTAGGG -x 1 -w 1000 -s 1000 -r -g -e -i",             # k = 8
+    "-c TTTTTAGGG -x 1 -w 400 -s 200 -r -g",                    # k = 9
+    "",                                                         # ultra-fast (tips only), t = 50000
+    "-t 300",
+    "-t 1000 -l 60 -k 10 -d 30 -y 0.8",
+    "-c CCCTAAA -t 2500",
+]
+LENGTHS = [1, 5, 6, 7, 15, 16, 17, 63, 100, 250, 499, 500, 501, 999, 1000, 1001, 1999, 2000, 2001,
+           4095, 32499, 32500, 32501, 33007, 65000, 70001, 99999, 100000, 100001, 131072, 250003]
+
+
+@pytest.mark.parametrize("cli", GRID)
+def test_random_segments_match_oracle(cli):
+    opts = H.parse_cli("x.fa " + cli)
+    prod, orac = ProductBackend(opts), OracleBackend(opts)
+    rng = np.random.default_rng(abs(hash(cli)) % (2 ** 32) if False else len(cli) * 7919 + 13)
+    unit_f, unit_r = opts.canonical_fwd, opts.canonical_rev
+    segs = []
+    for i, n in enumerate(LENGTHS):
+        s = seqgen.chromosome(rng, n, unit_f, unit_r, telo_repeats=min(150, max(1, n // 40)),
+                              tvr_rate=0.03, n_its=3, iupac=(n // 5000) * (i % 2),
+                              lower=0.0, n_runs=0)
+        segs.append((s, int(rng.integers(0, 10 ** 7)), opts.ultra_fast))
+    segs.append((b"", 5, opts.ultra_fast))
+    # one call, many segments: result order = input order
+    got = prod.scan_segments(segs)
+    for (s, ap, tips), g in zip(segs, got):
+        e = orac.scan_segment(s, ap, tips)
+        assert_segment_equal(g, e, tips, ctx="cli=%r len=%d" % (cli, len(s)))
+
+
+def test_non_acgt_and_case_handling():
+    """IUPAC codes / N inside a segment kill every k-mer that touches them; lower case follows
+    fold_case (default: folded, like unmaskSequence + scanSegment; 0: strict scanSegment)."""
+    import teloscope_amd as ta
+    opts = H.parse_cli("x.fa -w 1000 -s 500 -r -g -e -m -i")
+    rng = np.random.default_rng(5)
+    s = bytearray(seqgen.chromosome(rng, 40000, n_its=4, iupac=40, lower=0.05, n_runs=6))
+    prod, orac = ProductBackend(opts), OracleBackend(opts)
+    g = prod.scan_segment(bytes(s), 123, False)
+    assert_segment_equal(g, orac.scan_segment(bytes(s).upper(), 123, False), False, ctx="folded")
+    # strict: lower-case letters are non-ACGT, exactly what scanSegment does with them
+    ui = prod.ui
+    ui.foldCase = False
+    strict = ta.Teloscope(ui)
+    from tests.backends import segment_as_dict
+    g2 = segment_as_dict(strict.scanSegment(bytes(s), 123, False))
+    assert_segment_equal(g2, orac.scan_segment(bytes(s), 123, False), False, ctx="strict")
+
+
+def test_unsupported_parameter_sets_fail_loudly():
+    """Parameter sets the tiled kernel does not implement return TS_ERR_UNSUPPORTED; they are
+    never routed to a CPU path."""
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    for cli in ("-w 10 -s 5 -g", "-p TTAGGG,TTAGG -w 1000 -s 500 -g", "-w 1000 -s 997 -r"):
+        opts = H.parse_cli("x.fa " + cli)
+        be = ProductBackend(opts)
+        with pytest.raises(ta.TeloscanError) as ei:
+            be.scan_segment(b"ACGT" * 100, 0, False)
+        assert ei.value.code == K.TS_ERR_UNSUPPORTED
+
+
+def test_real_chromosome_matches_oracle():
+    """testFiles/bTaeGut7_chr33_mat.fa.gz (4.2 Mb zebra finch chr33), BASELINE flag set."""
+    opts = H.parse_cli("x -c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -m -i")
+    recs = H.read_fasta(H.golden_path("testFiles/bTaeGut7_chr33_mat.fa.gz"))
+    both = BothBackends(opts)
+    for i, (h, s) in enumerate(recs):
+        H.walk_path(both, opts, i, h, s)
+
+
+def test_large_scan_properties():
+    """64 Mb in 5 segments at the BASELINE geometry: window count, exact nucleotide totals
+    (checksum of checksums against numpy), sorted match stream, covered = k x count, and
+    full equality with the oracle on a 3 Mb slice."""
+    opts = H.parse_cli("x -c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 1000 -r -g -e -m -i")
+    prod, orac = ProductBackend(opts), OracleBackend(opts)
+    rng = np.random.default_rng(99)
+    lens = [20_000_003, 3_000_000, 25_000_000, 999, 16_000_001]
+    segs = [(seqgen.chromosome(rng, n, telo_repeats=500, n_its=20), 1000 * i, False) for i, n in enumerate(lens)]
+    got = prod.scan_segments(segs)
+    for (s, ap, _), g, n in zip(segs, got, lens):
+        w = g["windows"]
+        assert len(w) == -(-n // 1000)
+        arr = np.frombuffer(s, dtype=np.uint8)
+        tot = [int((arr == c).sum()) for c in b"ACGT"]
+        assert w["nucleotide_counts"].sum(axis=0).tolist() == tot          # w == s: windows tile the segment
+        assert int(w["current_window_size"].sum()) == n
+        pos = g["all_matches"]["position"]
+        assert np.all(np.diff(pos.astype(np.int64)) > 0)
+        assert pos.min() >= ap and pos.max() + 6 <= ap + n
+        f = (g["all_matches"]["flags"] & 1) != 0
+        assert int(w["fwd_covered"].sum()) == 6 * int(f.sum())
+        assert int(w["rev_covered"].sum()) == 6 * int((~f).sum())
+    assert_segment_equal(got[1], orac.scan_segment(segs[1][0], segs[1][1], False), False, ctx="3Mb slice")
