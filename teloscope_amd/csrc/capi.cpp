@@ -48,7 +48,7 @@ struct ts_ctx {
     std::string why_not;            // reason when a scan mode is unsupported
     int device = 0;
     int num_cu = 0;
-    uint32_t table_rows = 0;
+    uint32_t table_rows = 0, table_replicas = 16;
     DevBuf d_table;
     mutable std::mutex mtx;
     mutable std::string error;
@@ -113,6 +113,8 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     const uint32_t k = c->k;
     kp.k = k;
     kp.table_rows = c->table_rows;
+    kp.row_stride = c->table_replicas * 16u;
+    kp.rep_mask = c->table_replicas - 1u;
     kp.fold_mask = P.fold_case ? 0xDFDFDFDFu : 0xFFFFFFFFu;
     if (tips) {
         kp.s = kp.w = kTargetTileBases;      // one pseudo block per tile, no window records
@@ -302,7 +304,7 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
         c->why_not = "mixed-length pattern sets need the general kernel (not built yet)";
     } else {
         std::vector<uint32_t> table;
-        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows)) {
+        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows, c->table_replicas)) {
             c->why_not = "pattern length outside 3..9 or non-ACGT pattern";
         } else {
             c->k = kmin;

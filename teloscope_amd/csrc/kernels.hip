@@ -90,7 +90,7 @@ __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15
 
 __host__ __device__ inline uint32_t lds_layout(const TsScanParams &P, uint32_t off[8]) {
     uint32_t o = 0;
-    off[0] = o; o += P.table_rows * 256u;
+    off[0] = o; o += P.table_rows * P.row_stride;
     off[1] = o; o += align16(P.nch * 63u * 4u + 16u);
     const uint32_t pb = align16(P.nch * 63u * 2u + 16u);
     off[2] = o; o += pb;
@@ -129,13 +129,13 @@ void ts_scan_tiles(const TsScanParams P) {
     {
         const uint4 *src = (const uint4 *)P.table;
         uint4 *dst = (uint4 *)L.table;
-        const uint32_t n16 = P.table_rows * 16u;
+        const uint32_t n16 = P.table_rows * (P.row_stride >> 4);
         for (uint32_t i = tid; i < n16; i += TS_WG_THREADS) dst[i] = src[i];
     }
 
     const uint32_t k = P.k;
     const uint32_t rowbits = 2u * k - 5u;
-    const uint32_t repoff = (lane & 15u) * 16u;
+    const uint32_t repoff = (lane & P.rep_mask) * 16u;
     const unsigned char *tab_bytes = (const unsigned char *)L.table;
 
     for (;;) {
@@ -215,7 +215,7 @@ void ts_scan_tiles(const TsScanParams P) {
                 for (int j = 0; j < 16; ++j) {
                     const uint32_t tmp = (j == 0) ? w2 : __builtin_amdgcn_alignbit(nxt, w2, 2 * j);
                     const uint32_t row = __builtin_amdgcn_ubfe(tmp, 5, rowbits);
-                    const uint4 ent = *(const uint4 *)(tab_bytes + row * 256u + repoff);
+                    const uint4 ent = *(const uint4 *)(tab_bytes + row * P.row_stride + repoff);
                     asm volatile("" ::"v"(ent.w));   // keep all 16 bytes live: ds_read_b128 (4 LDS cycles), not b96 (8)
                     aM = __builtin_amdgcn_alignbit(ent.x >> (tmp & 31u), aM, 1);
                     aF = __builtin_amdgcn_alignbit(ent.y >> (tmp & 31u), aF, 1);

@@ -165,14 +165,16 @@ int base_code(char c) {
 
 // Match table for uniform-length pattern sets: for k-mer index x (base i at bits 2i..2i+1)
 // row x>>5 holds, for each of 16 replicas, the dwords {M, F, C, 0}; bit x&31 of M says
-// "x is a pattern", of F "forward-oriented", of C "canonical".  The 16 replicas give every
-// lane of a ds_read_b128 lane group its own 4 banks.
+// "x is a pattern", of F "forward-oriented", of C "canonical".  16 replicas give every
+// lane of a ds_read_b128 lane group its own 4 banks (conflict-free); k >= 8 has to trade
+// replicas for LDS capacity (4^k/32 rows): 4 replicas at k = 8, 1 at k = 9.
 bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
-                       uint32_t &rows) {
+                       uint32_t &rows, uint32_t &replicas) {
     if (k < 3 || k > 9) return false;
     const uint64_t entries = 1ull << (2 * k);
     rows = static_cast<uint32_t>(entries / 32);
-    table.assign(static_cast<size_t>(rows) * 64, 0u);
+    replicas = k <= 7 ? 16u : (k == 8 ? 4u : 1u);
+    table.assign(static_cast<size_t>(rows) * replicas * 4, 0u);
     for (const Pattern &p : pats) {
         if (p.seq.size() != k) return false;
         uint32_t x = 0;
@@ -182,8 +184,8 @@ bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector
             x |= static_cast<uint32_t>(c) << (2 * i);
         }
         const uint32_t row = x >> 5, bit = 1u << (x & 31u);
-        for (uint32_t rep = 0; rep < 16; ++rep) {
-            uint32_t *e = &table[static_cast<size_t>(row) * 64 + rep * 4];
+        for (uint32_t rep = 0; rep < replicas; ++rep) {
+            uint32_t *e = &table[(static_cast<size_t>(row) * replicas + rep) * 4];
             e[0] |= bit;
             if (p.is_forward) e[1] |= bit;
             if (p.is_canonical) e[2] |= bit;

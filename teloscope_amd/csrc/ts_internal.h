@@ -35,7 +35,7 @@ struct TsTile {                 // 32 bytes
 struct TsScanParams {
     const uint8_t  *in;
     const TsTile   *tiles;
-    const uint32_t *table;      // replicated match table: rows x 16 replicas x {M,F,C,0}
+    const uint32_t *table;      // replicated match table: rows x replicas x {M,F,C,0}
     uint32_t       *windows_out;    // 8 x u32 per window
     uint32_t       *matches_out;    // packed records
     unsigned long long *state;      // lookback words, one per tile (zeroed before launch)
@@ -46,6 +46,8 @@ struct TsScanParams {
     uint64_t        match_cap;
     uint32_t        ntiles;
     uint32_t        table_rows;     // 4^k / 32
+    uint32_t        row_stride;     // bytes per table row = replicas * 16
+    uint32_t        rep_mask;       // replicas - 1 (replica = lane & rep_mask)
     uint32_t        k;              // pattern length
     uint32_t        s, w;           // step and window (tips mode: s = w = tile size)
     uint32_t        q, r;           // w = q*s + r
