@@ -237,8 +237,10 @@ int       ts_batch_scan(ts_batch *b, const void *d_input, void *stream);
 int       ts_batch_sync(ts_batch *b);
 int       ts_batch_get_info(const ts_batch *b, ts_batch_info *info);
 /* Device pointers to the raw result buffers (valid after sync): window records
- * (8 x uint32 each: A,C,G,T, canonical/nonCanonical/fwd/rev covered) and packed 32-bit
- * match records ((tile-relative position << 2) | fwd << 1 | canonical). */
+ * (8 x uint32 each: A,C,G,T, canonical/nonCanonical/fwd/rev covered) and the dense stream of
+ * packed 32-bit match records ((tile-relative position << 2) | fwd << 1 | canonical).  Records
+ * of one tile are contiguous and position-ordered; tiles are placed in completion order and
+ * located through the batch's tile directory (ts_batch_download does that). */
 const void *ts_batch_windows_ptr(const ts_batch *b);
 const void *ts_batch_matches_ptr(const ts_batch *b);
 /* D2H + host post-processing (absolute positions, terminal flags, block calling):

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libteloscan.so")
+LIB_PATH = os.environ.get("TELOSCAN_LIB") or os.path.join(_HERE, "libteloscan.so")
 
 TS_OK = 0
 TS_ERR_INVALID_ARG, TS_ERR_NO_DEVICE, TS_ERR_HIP, TS_ERR_ALLOC, TS_ERR_UNSUPPORTED, TS_ERR_STATE = \

@@ -88,7 +88,7 @@ struct ts_batch {
     bool scanned = false, synced = false;
     const void *last_input = nullptr;
     void *last_stream = nullptr;
-    DevBuf d_in, d_tiles, d_windows, d_matches, d_state, d_prefix, d_stats, d_small, d_segtab;
+    DevBuf d_in, d_tiles, d_windows, d_matches, d_tile_off, d_stats, d_small, d_segtab;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -104,7 +104,6 @@ namespace {
 uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 constexpr uint32_t kMaxLds = 160u * 1024u;
-constexpr uint32_t kTargetTileBases = 32768;
 constexpr uint32_t kMaxBlocksPerTile = 448;
 
 // Chooses the tile geometry for a full-window scan; false if it cannot fit in LDS.
@@ -113,14 +112,24 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     const uint32_t k = c->k;
     kp.k = k;
     kp.table_rows = c->table_rows;
-    kp.row_stride = c->table_replicas * 16u;
+    kp.row_shift = c->table_replicas == 16 ? 8u : (c->table_replicas == 4 ? 6u : 4u);
     kp.rep_mask = c->table_replicas - 1u;
     kp.fold_mask = P.fold_case ? 0xDFDFDFDFu : 0xFFFFFFFFu;
     if (tips) {
-        kp.s = kp.w = kTargetTileBases;      // one pseudo block per tile, no window records
-        kp.q = 0; kp.r = 0; kp.qq = 0; kp.hh = kp.s - k;
+        // one pseudo block per tile, no window records; the tile size is ours to choose
+        kp.q = 0; kp.r = 0; kp.qq = 0;
         kp.straddle_fix = 0; kp.windows_on = 0; kp.nuc_on = 0;
         wpt = 1;
+        for (uint32_t tb = 32u * TS_CHUNK - 64u; tb >= 2048u; tb = (tb / 2u) & ~15u) {
+            kp.s = kp.w = tb;
+            kp.hh = tb - k;
+            kp.s_inv = (uint32_t)(((1ull << 32) + tb - 1) / tb);
+            kp.nch = (uint32_t)ceil_div(15 + (uint64_t)tb + 16 + 16 + 16, TS_CHUNK);
+            kp.max_blocks = 2;
+            if ((uint32_t)ts_k_lds_bytes(&kp) <= kMaxLds) return true;
+        }
+        why = "match table leaves no room for a tile in LDS";
+        return false;
     } else {
         const uint32_t s = P.step, w = P.window_size;
         kp.s = s; kp.w = w;
@@ -129,8 +138,12 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
         kp.straddle_fix = (w == s) ? 1u : 0u;
         kp.windows_on = 1;
         kp.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u;
-        wpt = std::max<uint32_t>(1, std::min<uint32_t>(kTargetTileBases / s, kMaxBlocksPerTile));
+        // whole number of 8-wave rounds: (15 + span + 48) <= 32 chunks of 1008 positions
+        const uint32_t span_max = 32u * TS_CHUNK - 63u;
+        const uint32_t nblk = span_max / s;
+        wpt = nblk > kp.q ? std::min<uint32_t>(nblk - kp.q, kMaxBlocksPerTile) : 1u;
     }
+    kp.s_inv = (uint32_t)(((1ull << 32) + kp.s - 1) / kp.s);
     for (;;) {
         const uint64_t span = (uint64_t)(wpt + kp.q) * kp.s;
         if (span > (1u << 22)) { why = "window too large for one tile"; return false; }
@@ -175,10 +188,9 @@ int batch_alloc_outputs(ts_batch *b) {
     HIP_TRY(c, b->d_tiles.ensure(nt * sizeof(TsTile)));
     HIP_TRY(c, b->d_windows.ensure(std::max<uint64_t>(b->n_windows, 1) * 32));
     HIP_TRY(c, b->d_matches.ensure(std::max<uint64_t>(b->match_cap, 1) * 4));
-    HIP_TRY(c, b->d_state.ensure((nt + 1) * 8));
-    HIP_TRY(c, b->d_prefix.ensure((nt + 1) * 8));
-    HIP_TRY(c, b->d_stats.ensure((nt + 1) * 8));
-    HIP_TRY(c, b->d_small.ensure(64));
+    HIP_TRY(c, b->d_tile_off.ensure((nt + 1) * 8));
+    HIP_TRY(c, b->d_stats.ensure((nt + 1) * 16));
+    HIP_TRY(c, b->d_small.ensure(256));
     if (nt) HIP_TRY(c, hipMemcpy(b->d_tiles.p, b->tiles.data(), nt * sizeof(TsTile), hipMemcpyHostToDevice));
     return TS_OK;
 }
@@ -435,7 +447,7 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
 void ts_batch_destroy(ts_batch *b) {
     if (!b) return;
     b->d_in.release(); b->d_tiles.release(); b->d_windows.release(); b->d_matches.release();
-    b->d_state.release(); b->d_prefix.release(); b->d_stats.release(); b->d_small.release();
+    b->d_tile_off.release(); b->d_stats.release(); b->d_small.release();
     b->d_segtab.release();
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -483,16 +495,19 @@ int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
     kp.table = (const uint32_t *)c->d_table.p;
     kp.windows_out = (uint32_t *)b->d_windows.p;
     kp.matches_out = (uint32_t *)b->d_matches.p;
-    kp.state = (unsigned long long *)b->d_state.p;
-    kp.tile_prefix = (unsigned long long *)b->d_prefix.p;
+    kp.tile_off = (unsigned long long *)b->d_tile_off.p;
     kp.tile_stats = (uint32_t *)b->d_stats.p;
     kp.ticket = (uint32_t *)b->d_small.p;
-    kp.error_flag = (uint32_t *)b->d_small.p + 1;
+    kp.cursor = (unsigned long long *)((char *)b->d_small.p + 8);
+#ifdef TS_PHASE_TIMERS
+    kp.phase_cycles = (unsigned long long *)((char *)b->d_small.p + 64);
+#else
+    kp.phase_cycles = nullptr;
+#endif
     kp.match_cap = b->match_cap;
     kp.ntiles = (uint32_t)nt;
 
-    HIP_TRY(c, hipMemsetAsync(b->d_state.p, 0, (nt + 1) * 8, st));
-    HIP_TRY(c, hipMemsetAsync(b->d_small.p, 0, 64, st));
+    HIP_TRY(c, hipMemsetAsync(b->d_small.p, 0, 256, st));
     HIP_TRY(c, hipEventRecord(b->ev0, st));
     if (nt) {
         int e = ts_k_launch_scan(&kp, b->grid, b->lds_bytes, stream);
@@ -511,13 +526,22 @@ int ts_batch_sync(ts_batch *b) {
         float ms = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&ms, b->ev0, b->ev1));
         b->last_ms = ms;
-        const size_t nt = b->tiles.size();
-        uint32_t small[2] = {0, 0};
-        HIP_TRY(c, hipMemcpy(small, b->d_small.p, 8, hipMemcpyDeviceToHost));
-        if (small[1]) return c->fail(TS_ERR_HIP, "look-back spin timed out inside the scan kernel");
-        unsigned long long last = 0;
-        if (nt) HIP_TRY(c, hipMemcpy(&last, (char *)b->d_state.p + (nt - 1) * 8, 8, hipMemcpyDeviceToHost));
-        b->n_matches = last & ((1ull << 62) - 1ull);
+        unsigned long long total = 0;
+        HIP_TRY(c, hipMemcpy(&total, (char *)b->d_small.p + 8, 8, hipMemcpyDeviceToHost));
+        b->n_matches = total;
+#ifdef TS_PHASE_TIMERS
+        {
+            unsigned long long pc[10];
+            static const char *names[7] = {"phase1", "straddle_fix", "emitA+reserve", "phase2a", "windows", "emitB", "-"};
+            if (hipMemcpy(pc, (char *)b->d_small.p + 64, 80, hipMemcpyDeviceToHost) == hipSuccess) {
+
+                unsigned long long tot = 0;
+                for (int i = 0; i < 7; ++i) tot += pc[i];
+                for (int i = 0; i < 7; ++i)
+                    std::fprintf(stderr, "[phase] %-16s %12llu ticks  %5.1f %%\n", names[i], pc[i], tot ? 100.0 * pc[i] / tot : 0.0);
+            }
+        }
+#endif
         if (b->n_matches <= b->match_cap) { b->synced = true; return TS_OK; }
         // the match buffer overflowed: grow it to the exact size and rescan
         b->match_cap = b->n_matches + 1024;
@@ -560,11 +584,9 @@ int ts_batch_segment_summary(ts_batch *b, void *d_out, void *stream) {
         if (ns) HIP_TRY(c, hipMemcpy((char *)b->d_segtab.p + bytes_first, nwin.data(), ns * 8, hipMemcpyHostToDevice));
     }
     const size_t bytes_first = ((ns + 1) * 4 + 15) & ~15ull;
-    int e = ts_k_launch_summary((const TsTile *)b->d_tiles.p, (const unsigned long long *)b->d_prefix.p,
-                                (const unsigned long long *)b->d_state.p, (const uint32_t *)b->d_stats.p,
-                                (const uint32_t *)b->d_segtab.p,
+    int e = ts_k_launch_summary((const uint32_t *)b->d_stats.p, (const uint32_t *)b->d_segtab.p,
                                 (const uint64_t *)((char *)b->d_segtab.p + bytes_first), (uint32_t)ns,
-                                (uint32_t)b->tiles.size(), (unsigned long long *)d_out, stream);
+                                (unsigned long long *)d_out, stream);
     if (e != 0) return c->fail(TS_ERR_HIP, "summary kernel launch failed");
     return TS_OK;
 }
@@ -580,11 +602,13 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
 
     std::vector<uint32_t> wins(b->n_windows * 8);
     std::vector<uint32_t> recs(b->n_matches);
-    std::vector<unsigned long long> prefix(nt + 1);
+    // tile directory: records of tile t are recs[tile_off[t] .. +tile_stats[4t]), in position order
+    std::vector<unsigned long long> tile_off(nt + 1);
+    std::vector<uint32_t> tile_stats(4 * (nt + 1));
     if (b->n_windows) HIP_TRY(c, hipMemcpy(wins.data(), b->d_windows.p, b->n_windows * 32, hipMemcpyDeviceToHost));
     if (b->n_matches) HIP_TRY(c, hipMemcpy(recs.data(), b->d_matches.p, b->n_matches * 4, hipMemcpyDeviceToHost));
-    if (nt) HIP_TRY(c, hipMemcpy(prefix.data(), b->d_prefix.p, nt * 8, hipMemcpyDeviceToHost));
-    prefix[nt] = b->n_matches;
+    if (nt) HIP_TRY(c, hipMemcpy(tile_off.data(), b->d_tile_off.p, nt * 8, hipMemcpyDeviceToHost));
+    if (nt) HIP_TRY(c, hipMemcpy(tile_stats.data(), b->d_stats.p, nt * 16, hipMemcpyDeviceToHost));
 
     const uint16_t klen = (uint16_t)c->k;
     for (size_t si = 0; si < ns; ++si) {
@@ -615,9 +639,8 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
         }
 
         // matches: tile-relative packed records -> absolute MatchInfo
-        const uint64_t m0 = sp.n_tiles ? prefix[sp.first_tile] : 0;
-        const uint64_t m1 = sp.n_tiles ? prefix[sp.first_tile + sp.n_tiles] : 0;
-        const uint64_t nm = m1 - m0;
+        uint64_t nm = 0;
+        for (uint32_t t = 0; t < sp.n_tiles; ++t) nm += tile_stats[4ull * (sp.first_tile + t)];
         if (nm) {
             o.matches = (ts_match *)std::malloc(nm * sizeof(ts_match));
             if (!o.matches) return c->fail(TS_ERR_ALLOC, "out of host memory");
@@ -629,7 +652,9 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
             for (uint32_t t = 0; t < rg.n_tiles; ++t) {
                 const uint32_t ti = rg.first_tile + t;
                 const uint64_t tile_rel = rg.start + (uint64_t)t * rg.tile_bases;   // segment-relative
-                for (uint64_t ri = prefix[ti]; ri < prefix[ti + 1]; ++ri) {
+                const uint64_t r0 = tile_off[ti], r1 = r0 + tile_stats[4ull * ti];
+                if (r1 > recs.size()) return c->fail(TS_ERR_STATE, "tile directory out of range");
+                for (uint64_t ri = r0; ri < r1; ++ri) {
                     const uint32_t rec = recs[ri];
                     const uint64_t rel = tile_rel + (rec >> 2);
                     ts_match &m = o.matches[w_i++];

@@ -18,11 +18,6 @@
 #define TS_BLK_STRIDE   16             // u32 accumulators per step-block in LDS
 #define TS_IN_PAD       4096           // bytes of zero padding after the last segment in the input buffer
 
-// lookback state word: [63:62] status, [61:0] value
-#define TS_ST_INVALID 0ull
-#define TS_ST_AGG     1ull
-#define TS_ST_INCL    2ull
-
 struct TsTile {                 // 32 bytes
     uint64_t in_off;            // byte offset (input buffer) of the tile's first owned base
     uint64_t win_out;           // index of the first owned window record
@@ -38,18 +33,19 @@ struct TsScanParams {
     const uint32_t *table;      // replicated match table: rows x replicas x {M,F,C,0}
     uint32_t       *windows_out;    // 8 x u32 per window
     uint32_t       *matches_out;    // packed records
-    unsigned long long *state;      // lookback words, one per tile (zeroed before launch)
-    unsigned long long *tile_prefix;// exclusive match prefix per tile
-    uint32_t       *tile_stats;     // per tile: {canonical, forward} pushed-match counts
+    unsigned long long *cursor;     // next free match record (zeroed before launch)
+    unsigned long long *tile_off;   // tile directory: first record of each tile
+    uint32_t       *tile_stats;     // tile directory: {matches, canonical, forward, 0} per tile
     uint32_t       *ticket;         // tile dispenser (zeroed before launch)
-    uint32_t       *error_flag;     // set to 1 if a lookback spin timed out
+    unsigned long long *phase_cycles;// diagnostic build only (TS_PHASE_TIMERS), else null
     uint64_t        match_cap;
     uint32_t        ntiles;
     uint32_t        table_rows;     // 4^k / 32
-    uint32_t        row_stride;     // bytes per table row = replicas * 16
+    uint32_t        row_shift;      // log2(bytes per table row) = log2(replicas * 16)
     uint32_t        rep_mask;       // replicas - 1 (replica = lane & rep_mask)
     uint32_t        k;              // pattern length
     uint32_t        s, w;           // step and window (tips mode: s = w = tile size)
+    uint32_t        s_inv;          // ceil(2^32 / s) for multiply-high division by s
     uint32_t        q, r;           // w = q*s + r
     uint32_t        qq, hh;         // w - k = qq*s + hh
     uint32_t        nch;            // chunks of TS_CHUNK positions per tile
@@ -71,10 +67,8 @@ extern "C++" {
 int  ts_k_lds_bytes(const TsScanParams *p);
 int  ts_k_prepare(uint32_t lds_bytes);                       // raises the dynamic-LDS limit once
 int  ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, void *stream);
-int  ts_k_launch_summary(const TsTile *tiles, const unsigned long long *tile_prefix,
-                         const unsigned long long *state, const uint32_t *tile_stats,
-                         const uint32_t *seg_first_tile, const uint64_t *seg_nwin,
-                         uint32_t nseg, uint32_t ntiles, unsigned long long *out, void *stream);
+int  ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_tile,
+                         const uint64_t *seg_nwin, uint32_t nseg, unsigned long long *out, void *stream);
 }
 #endif
 
