@@ -16,8 +16,6 @@
 #include "host.hpp"
 #include "ts_internal.h"
 
-int ts_k_occupancy(uint32_t lds_bytes);
-
 namespace {
 
 thread_local std::string g_create_error;
@@ -88,7 +86,9 @@ struct ts_batch {
     bool scanned = false, synced = false;
     const void *last_input = nullptr;
     void *last_stream = nullptr;
-    DevBuf d_in, d_tiles, d_windows, d_matches, d_tile_off, d_stats, d_small, d_segtab;
+    DevBuf d_in, d_tiles, d_windows, d_matches, d_tile_off, d_stats, d_fill, d_segtab, d_dense, d_dense_base;
+    uint32_t total_waves = 0, region_cap = 0;
+    std::vector<uint32_t> wave_fill;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -105,31 +105,23 @@ uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 constexpr uint32_t kMaxLds = 160u * 1024u;
 constexpr uint32_t kMaxBlocksPerTile = 448;
+constexpr uint32_t kPreferredChunks = 8;       // ~8 k positions per wave tile
 
-// Chooses the tile geometry for a full-window scan; false if it cannot fit in LDS.
+// Chooses waves per workgroup, chunks per tile and windows per tile so that the match table plus
+// one LDS slice per wave fit in 160 KB; false if even one wave cannot hold one window.
 bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, std::string &why) {
     const ts_params &P = c->params;
     const uint32_t k = c->k;
     kp.k = k;
     kp.table_rows = c->table_rows;
-    kp.row_shift = c->table_replicas == 16 ? 8u : (c->table_replicas == 4 ? 6u : 4u);
+    kp.row_shift = c->table_replicas == 16 ? 8u : (c->table_replicas == 8 ? 7u : (c->table_replicas == 4 ? 6u :
+                   (c->table_replicas == 2 ? 5u : 4u)));
     kp.rep_mask = c->table_replicas - 1u;
     kp.fold_mask = P.fold_case ? 0xDFDFDFDFu : 0xFFFFFFFFu;
+    const uint32_t table_bytes = kp.table_rows << kp.row_shift;
     if (tips) {
-        // one pseudo block per tile, no window records; the tile size is ours to choose
         kp.q = 0; kp.r = 0; kp.qq = 0;
         kp.straddle_fix = 0; kp.windows_on = 0; kp.nuc_on = 0;
-        wpt = 1;
-        for (uint32_t tb = 32u * TS_CHUNK - 64u; tb >= 2048u; tb = (tb / 2u) & ~15u) {
-            kp.s = kp.w = tb;
-            kp.hh = tb - k;
-            kp.s_inv = (uint32_t)(((1ull << 32) + tb - 1) / tb);
-            kp.nch = (uint32_t)ceil_div(15 + (uint64_t)tb + 16 + 16 + 16, TS_CHUNK);
-            kp.max_blocks = 2;
-            if ((uint32_t)ts_k_lds_bytes(&kp) <= kMaxLds) return true;
-        }
-        why = "match table leaves no room for a tile in LDS";
-        return false;
     } else {
         const uint32_t s = P.step, w = P.window_size;
         kp.s = s; kp.w = w;
@@ -138,22 +130,35 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
         kp.straddle_fix = (w == s) ? 1u : 0u;
         kp.windows_on = 1;
         kp.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u;
-        // whole number of 8-wave rounds: (15 + span + 48) <= 32 chunks of 1008 positions
-        const uint32_t span_max = 32u * TS_CHUNK - 63u;
-        const uint32_t nblk = span_max / s;
-        wpt = nblk > kp.q ? std::min<uint32_t>(nblk - kp.q, kMaxBlocksPerTile) : 1u;
+        kp.s_inv = (uint32_t)(((1ull << 32) + s - 1) / s);
     }
-    kp.s_inv = (uint32_t)(((1ull << 32) + kp.s - 1) / kp.s);
-    for (;;) {
-        const uint64_t span = (uint64_t)(wpt + kp.q) * kp.s;
-        if (span > (1u << 22)) { why = "window too large for one tile"; return false; }
-        kp.nch = (uint32_t)ceil_div(15 + span + 16 + 16 + 16, TS_CHUNK);
-        kp.max_blocks = wpt + kp.q + 1;
-        const int lds = ts_k_lds_bytes(&kp);
-        if ((uint32_t)lds <= kMaxLds) return true;
-        if (wpt == 1) { why = "window/step geometry does not fit the 160 KB LDS tile"; return false; }
-        wpt = std::max<uint32_t>(1, wpt / 2);
+    for (uint32_t waves = 16; waves >= 1; waves >>= 1) {
+        kp.waves_per_wg = waves;
+        // smallest tile that holds one window, then grow towards the preferred size
+        uint32_t nch_min = 1;
+        if (!tips) nch_min = (uint32_t)ceil_div((uint64_t)(1 + kp.q) * kp.s + 63, TS_CHUNK);
+        for (uint32_t nch = std::max(nch_min, kPreferredChunks);; --nch) {
+            kp.nch = nch;
+            const uint32_t span_max = nch * TS_CHUNK - 63u;
+            if (tips) {
+                const uint32_t tb = span_max & ~15u;            // one pseudo block per tile
+                kp.s = kp.w = tb;
+                kp.hh = tb - k;
+                kp.s_inv = (uint32_t)(((1ull << 32) + tb - 1) / tb);
+                kp.max_blocks = 2;
+                wpt = 1;
+            } else {
+                const uint32_t nblk = span_max / kp.s;
+                wpt = nblk > kp.q ? std::min<uint32_t>(nblk - kp.q, kMaxBlocksPerTile) : 0u;
+                kp.max_blocks = wpt + kp.q + 1;
+            }
+            if (wpt >= 1 && (uint32_t)ts_k_lds_bytes(&kp) <= kMaxLds) return true;
+            if (nch <= nch_min) break;
+        }
+        (void)table_bytes;
     }
+    why = "window/step geometry does not fit the 160 KB LDS of a CU";
+    return false;
 }
 
 void add_region_tiles(ts_batch *b, SegPlan &sp, uint32_t seg_index, uint64_t start, uint64_t len,
@@ -187,10 +192,10 @@ int batch_alloc_outputs(ts_batch *b) {
     const size_t nt = b->tiles.size();
     HIP_TRY(c, b->d_tiles.ensure(nt * sizeof(TsTile)));
     HIP_TRY(c, b->d_windows.ensure(std::max<uint64_t>(b->n_windows, 1) * 32));
-    HIP_TRY(c, b->d_matches.ensure(std::max<uint64_t>(b->match_cap, 1) * 4));
+    HIP_TRY(c, b->d_matches.ensure((uint64_t)b->region_cap * b->total_waves * 4));
     HIP_TRY(c, b->d_tile_off.ensure((nt + 1) * 8));
     HIP_TRY(c, b->d_stats.ensure((nt + 1) * 16));
-    HIP_TRY(c, b->d_small.ensure(256));
+    HIP_TRY(c, b->d_fill.ensure((size_t)b->total_waves * 4 + 16));
     if (nt) HIP_TRY(c, hipMemcpy(b->d_tiles.p, b->tiles.data(), nt * sizeof(TsTile), hipMemcpyHostToDevice));
     return TS_OK;
 }
@@ -432,8 +437,19 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
         delete b;
         return nullptr;
     }
-    const int occ = ts_k_occupancy(b->lds_bytes);
-    b->grid = (uint32_t)std::min<uint64_t>(std::max<size_t>(b->tiles.size(), 1), (uint64_t)ctx->num_cu * occ);
+    // one persistent workgroup per CU; tiles are dealt round-robin to its waves
+    const uint32_t wpw = b->kp.waves_per_wg;
+    b->grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(b->tiles.size(), wpw), 1), (uint64_t)ctx->num_cu);
+    b->total_waves = b->grid * wpw;
+    // every wave appends to its own region of the match buffer; small batches get the worst case
+    // (every base a match), large ones bases/4 spread evenly, grown on overflow by ts_batch_sync
+    const uint64_t tiles_per_wave = ceil_div(std::max<size_t>(b->tiles.size(), 1), b->total_waves);
+    const uint64_t worst = tiles_per_wave * tile_bases;
+    uint64_t cap = ceil_div(b->match_cap, b->total_waves);
+    if (b->total_bases <= (64ull << 20) && !match_capacity) cap = worst;
+    cap = std::min<uint64_t>(std::max<uint64_t>(cap, 256), worst);
+    b->region_cap = (uint32_t)((cap + 3) & ~3ull);
+    b->match_cap = (uint64_t)b->region_cap * b->total_waves;
 
     if (batch_alloc_outputs(b) != TS_OK || hipEventCreate(&b->ev0) != hipSuccess ||
         hipEventCreate(&b->ev1) != hipSuccess) {
@@ -447,7 +463,7 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
 void ts_batch_destroy(ts_batch *b) {
     if (!b) return;
     b->d_in.release(); b->d_tiles.release(); b->d_windows.release(); b->d_matches.release();
-    b->d_tile_off.release(); b->d_stats.release(); b->d_small.release();
+    b->d_tile_off.release(); b->d_stats.release(); b->d_fill.release(); b->d_dense.release(); b->d_dense_base.release();
     b->d_segtab.release();
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -497,19 +513,12 @@ int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
     kp.matches_out = (uint32_t *)b->d_matches.p;
     kp.tile_off = (unsigned long long *)b->d_tile_off.p;
     kp.tile_stats = (uint32_t *)b->d_stats.p;
-    kp.ticket = (uint32_t *)b->d_small.p;
-    kp.cursor = (unsigned long long *)((char *)b->d_small.p + 8);
-#ifdef TS_PHASE_TIMERS
-    kp.phase_cycles = (unsigned long long *)((char *)b->d_small.p + 64);
-#else
-    kp.phase_cycles = nullptr;
-#endif
-    kp.match_cap = b->match_cap;
+    kp.wave_fill = (uint32_t *)b->d_fill.p;
+    kp.region_cap = b->region_cap;
     kp.ntiles = (uint32_t)nt;
 
-    HIP_TRY(c, hipMemsetAsync(b->d_small.p, 0, 256, st));
     HIP_TRY(c, hipEventRecord(b->ev0, st));
-    if (nt) {
+    {
         int e = ts_k_launch_scan(&kp, b->grid, b->lds_bytes, stream);
         if (e != 0) return c->fail(TS_ERR_HIP, std::string("scan kernel launch: ") + hipGetErrorString((hipError_t)e));
     }
@@ -526,25 +535,16 @@ int ts_batch_sync(ts_batch *b) {
         float ms = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&ms, b->ev0, b->ev1));
         b->last_ms = ms;
-        unsigned long long total = 0;
-        HIP_TRY(c, hipMemcpy(&total, (char *)b->d_small.p + 8, 8, hipMemcpyDeviceToHost));
+        b->wave_fill.assign(b->total_waves, 0u);
+        HIP_TRY(c, hipMemcpy(b->wave_fill.data(), b->d_fill.p, (size_t)b->total_waves * 4, hipMemcpyDeviceToHost));
+        uint64_t total = 0;
+        uint32_t worst = 0;
+        for (uint32_t f : b->wave_fill) { total += f; worst = std::max(worst, f); }
         b->n_matches = total;
-#ifdef TS_PHASE_TIMERS
-        {
-            unsigned long long pc[10];
-            static const char *names[7] = {"phase1", "straddle_fix", "emitA+reserve", "phase2a", "windows", "emitB", "-"};
-            if (hipMemcpy(pc, (char *)b->d_small.p + 64, 80, hipMemcpyDeviceToHost) == hipSuccess) {
-
-                unsigned long long tot = 0;
-                for (int i = 0; i < 7; ++i) tot += pc[i];
-                for (int i = 0; i < 7; ++i)
-                    std::fprintf(stderr, "[phase] %-16s %12llu ticks  %5.1f %%\n", names[i], pc[i], tot ? 100.0 * pc[i] / tot : 0.0);
-            }
-        }
-#endif
-        if (b->n_matches <= b->match_cap) { b->synced = true; return TS_OK; }
-        // the match buffer overflowed: grow it to the exact size and rescan
-        b->match_cap = b->n_matches + 1024;
+        if (worst <= b->region_cap) { b->synced = true; return TS_OK; }
+        // a wave's region overflowed: size the regions for the fullest wave and rescan
+        b->region_cap = (uint32_t)(((uint64_t)worst + worst / 8 + 64 + 3) & ~3ull);
+        b->match_cap = (uint64_t)b->region_cap * b->total_waves;
         HIP_TRY(c, b->d_matches.ensure(b->match_cap * 4));
         int rc = ts_batch_scan(b, b->last_input, b->last_stream);
         if (rc != TS_OK) return rc;
@@ -606,9 +606,26 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
     std::vector<unsigned long long> tile_off(nt + 1);
     std::vector<uint32_t> tile_stats(4 * (nt + 1));
     if (b->n_windows) HIP_TRY(c, hipMemcpy(wins.data(), b->d_windows.p, b->n_windows * 32, hipMemcpyDeviceToHost));
-    if (b->n_matches) HIP_TRY(c, hipMemcpy(recs.data(), b->d_matches.p, b->n_matches * 4, hipMemcpyDeviceToHost));
+    // pack the per-wave regions into one dense stream on the device, then one D2H copy
+    std::vector<unsigned long long> dense_base(b->total_waves + 1, 0);
+    for (uint32_t w = 0; w < b->total_waves; ++w) dense_base[w + 1] = dense_base[w] + b->wave_fill[w];
+    if (b->n_matches) {
+        HIP_TRY(c, b->d_dense.ensure(b->n_matches * 4));
+        HIP_TRY(c, b->d_dense_base.ensure((size_t)(b->total_waves + 1) * 8));
+        HIP_TRY(c, hipMemcpy(b->d_dense_base.p, dense_base.data(), (size_t)(b->total_waves + 1) * 8, hipMemcpyHostToDevice));
+        int e = ts_k_launch_compact((const uint32_t *)b->d_matches.p, (const uint32_t *)b->d_fill.p,
+                                    (const unsigned long long *)b->d_dense_base.p, b->region_cap,
+                                    b->total_waves, (uint32_t *)b->d_dense.p, nullptr);
+        if (e != 0) return c->fail(TS_ERR_HIP, "compaction kernel launch failed");
+        HIP_TRY(c, hipMemcpy(recs.data(), b->d_dense.p, b->n_matches * 4, hipMemcpyDeviceToHost));
+    }
     if (nt) HIP_TRY(c, hipMemcpy(tile_off.data(), b->d_tile_off.p, nt * 8, hipMemcpyDeviceToHost));
     if (nt) HIP_TRY(c, hipMemcpy(tile_stats.data(), b->d_stats.p, nt * 16, hipMemcpyDeviceToHost));
+    // region offset -> dense offset (tile t was scanned by wave t mod total_waves)
+    for (size_t t = 0; t < nt; ++t) {
+        const uint32_t w = (uint32_t)(t % b->total_waves);
+        tile_off[t] = tile_off[t] - (unsigned long long)w * b->region_cap + dense_base[w];
+    }
 
     const uint16_t klen = (uint16_t)c->k;
     for (size_t si = 0; si < ns; ++si) {

@@ -5,20 +5,22 @@
 // kernel.  Integer/byte work bounded by HBM (1 B/base in, 32 B/window + 4 B/match out);
 // no MFMA on purpose.
 //
-// Per tile (see ts_internal.h):
-//   phase 1  every wavefront resolves 1008 positions per iteration: one coalesced 16 B/lane
-//            load, SWAR ASCII -> 2-bit codes (v_perm / v_sad_u8 / v_dot4), rolling k-mer per
-//            position, ONE conflict-free ds_read_b128 from a 16x-replicated bit table in LDS
-//            giving {match, forward, canonical}; results are kept as bit planes in LDS.
-//   phase 2  per-step-block partial sums by range popcounts over the planes (LDS atomics),
-//            windows assembled from ceil(w/s)+1 block partials -> 8 x u32 per window.
-//   emit     each tile reserves room for its matches with one atomic add on a global cursor
-//            (issued early, consumed late) and every wave compacts its matches to packed
-//            32-bit records; the per-tile directory {offset, count} makes the dense stream
-//            addressable in position order.  No workgroup ever waits on another one.
-// Every per-tile global round trip (tile ticket, tile descriptor, record offset) is issued
-// at least one phase before its result is needed: on a CU that is streaming, a dependent
-// global access costs microseconds.
+// Execution model: ONE WAVEFRONT PER TILE.  A tile is a run of consecutive windows of one
+// segment (~8 k bases plus the w-s halo); a wave scans its tile start to finish out of its own
+// slice of LDS, and the waves of a workgroup share nothing but the read-only match table.
+// After the table is loaded there is no workgroup barrier, no global atomic and no wait on
+// another wave anywhere: tiles are dealt round-robin, and every wave appends its packed
+// match records to its own region of the output (a per-tile directory {offset, count} makes
+// the stream addressable in position order).  Latency is hidden by the 16 waves per CU.
+//
+// Per tile:
+//   phase 1  1008 positions per iteration: one coalesced 16 B/lane load, SWAR ASCII -> 2-bit
+//            codes (v_perm / v_sad_u8 / v_dot4), rolling k-mer per position, ONE ds_read_b128
+//            from the replicated bit table in LDS giving {match, forward, canonical}; results
+//            are kept as bit planes in the wave's LDS slice.
+//   phase 2  per-step-block partial sums by range popcounts over the planes; windows are
+//            assembled from ceil(w/s)+1 block partials -> 8 x u32 per window, coalesced.
+//   emit     prefix-sum (DPP) compaction of the match plane into packed 32-bit records.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -78,101 +80,71 @@ __device__ __forceinline__ void plane_clear(uint32_t *p, uint32_t lo, uint32_t h
     }
 }
 
-struct Lds {
-    uint32_t *codes;            // 2-bit codes, 16 bases per dword
-    uint16_t *pV, *pM, *pF, *pC;   // validity / match / forward / canonical planes (16 positions per halfword)
-    uint32_t *blk;              // per step-block accumulators
-    uint32_t *misc;
-};
-
 __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
-__host__ __device__ inline uint32_t lds_layout(const TsScanParams &P, uint32_t off[8]) {
+// LDS: [match table][wave 0 slice][wave 1 slice]...; a slice = codes | V | M | F | C | blk
+struct SliceLayout { uint32_t codes, pV, pM, pF, pC, blk, bytes; };
+
+__host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
+    SliceLayout s;
     uint32_t o = 0;
-    off[0] = o; o += P.table_rows << P.row_shift;
-    off[1] = o; o += align16(P.nch * 63u * 4u + 16u);
+    s.codes = o; o += align16(P.nch * 63u * 4u + 16u);
     const uint32_t pb = align16(P.nch * 63u * 2u + 16u);
-    for (int i = 2; i <= 5; ++i) { off[i] = o; o += pb; }          // V, M, F, C
-    off[6] = o; o += align16(P.max_blocks * TS_BLK_STRIDE * 4u);
-    off[7] = o; o += 256u;
-    return o;
+    s.pV = o; o += pb;
+    s.pM = o; o += pb;
+    s.pF = o; o += pb;
+    s.pC = o; o += pb;
+    s.blk = o; o += align16(P.max_blocks * TS_BLK_COUNTERS * 4u);
+    s.bytes = o;
+    return s;
 }
 
-// Diagnostic build only (-DTS_PHASE_TIMERS): per-phase cycle shares, summed over tiles, from
-// s_memtime stamps taken by thread 0 (never in the product build; stamps perturb timing).
-#ifdef TS_PHASE_TIMERS
-#define TS_STAMP(i) do { if (tid == 0) { __builtin_amdgcn_sched_barrier(0); stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#else
-#define TS_STAMP(i) do { } while (0)
-#endif
-
-// misc[] slots
-enum { MI_TILE = 0, MI_INVALID = 1, MI_OFF_LO = 2, MI_OFF_HI = 3, MI_TOT = 4 /* [8] */, MI_CAN = 12,
-       MI_FWD = 20, MI_DESC = 32 /* TsTile of the next tile, 8 dwords */ };
+__host__ __device__ inline uint32_t lds_total(const TsScanParams &P) {
+    return (P.table_rows << P.row_shift) + P.waves_per_wg * slice_layout(P).bytes;
+}
 
 // ---------------------------------------------------------------------------------------
-// 2 workgroups per CU (LDS-limited) = 4 waves per SIMD: cap the allocation at 128 VGPRs
-__global__ __launch_bounds__(TS_WG_THREADS, 4)
+// 16 waves per CU = 4 per SIMD: at most 128 VGPRs
+__global__ __launch_bounds__(TS_MAX_WG_THREADS, 4)
 void ts_scan_tiles(const TsScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint32_t off[8];
-    lds_layout(P, off);
-    Lds L;
-    L.codes = (uint32_t *)(lds_raw + off[1]);
-    L.pV = (uint16_t *)(lds_raw + off[2]);
-    L.pM = (uint16_t *)(lds_raw + off[3]);
-    L.pF = (uint16_t *)(lds_raw + off[4]);
-    L.pC = (uint16_t *)(lds_raw + off[5]);
-    L.blk = (uint32_t *)(lds_raw + off[6]);
-    L.misc = (uint32_t *)(lds_raw + off[7]);
-
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    const uint32_t wave = tid >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 
-    // the replicated bit table stays in LDS for the lifetime of this (persistent) workgroup
+    // the replicated bit table is loaded once and stays for the lifetime of the workgroup
+    const uint32_t table_bytes = P.table_rows << P.row_shift;
     {
         const uint4 *src = (const uint4 *)P.table;
-        uint4 *dst = (uint4 *)(lds_raw + off[0]);
-        const uint32_t n16 = (P.table_rows << P.row_shift) >> 4;
-        for (uint32_t i = tid; i < n16; i += TS_WG_THREADS) dst[i] = src[i];
+        uint4 *dst = (uint4 *)lds_raw;
+        const uint32_t n16 = table_bytes >> 4;
+        for (uint32_t i = tid; i < n16; i += blockDim.x) dst[i] = src[i];
     }
+    __syncthreads();                              // the only workgroup barrier in the kernel
+
+    const SliceLayout SL = slice_layout(P);
+    unsigned char *slice = lds_raw + table_bytes + wave * SL.bytes;
+    uint32_t *codes = (uint32_t *)(slice + SL.codes);
+    uint16_t *pV = (uint16_t *)(slice + SL.pV);
+    uint16_t *pM = (uint16_t *)(slice + SL.pM);
+    uint16_t *pF = (uint16_t *)(slice + SL.pF);
+    uint16_t *pC = (uint16_t *)(slice + SL.pC);
+    uint32_t *blk = (uint32_t *)(slice + SL.blk);
+    const uint32_t NB = P.max_blocks;             // blk[counter * NB + block]
 
     const uint32_t k = P.k;
     const uint32_t rowbits = 2u * k - 5u;
     const uint32_t repoff = (lane & P.rep_mask) * 16u;
-    // LDS byte address of the table (the dynamic-LDS base is where the table lives)
-    const uint32_t tab_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(lds_raw + off[0]);
+    // LDS byte address of the table (it sits at the dynamic-LDS base)
+    const uint32_t tab_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw;
 
-    // Tile tickets and descriptors are fetched one tile ahead; misc[MI_TILE] / misc[MI_DESC]
-    // always describe the tile the next iteration scans.
-    if (tid == 0) L.misc[MI_TILE] = atomicAdd(P.ticket, 1u);
-    __syncthreads();
-    if (tid < 8u) {
-        const uint32_t t0 = L.misc[MI_TILE];
-        if (t0 < P.ntiles) L.misc[MI_DESC + tid] = ((const uint32_t *)&P.tiles[t0])[tid];
-    }
+    const uint32_t total_waves = gridDim.x * P.waves_per_wg;
+    const uint32_t gw = blockIdx.x * P.waves_per_wg + wave;
+    const u64 region_base = (u64)gw * P.region_cap;
+    uint32_t cursor = 0;                          // records this wave has produced so far
 
-    for (;;) {
-        __syncthreads();                         // previous iteration fully retired (and table visible)
-        const uint32_t tile = L.misc[MI_TILE];
-        if (tile >= P.ntiles) break;
-        TsTile T;
-        {
-            const uint32_t *d = &L.misc[MI_DESC];
-            T.in_off = ((u64)d[1] << 32) | d[0];
-            T.win_out = ((u64)d[3] << 32) | d[2];
-            T.nrel = d[4]; T.nwin = d[5]; T.own_len = d[6]; T.seg = d[7];
-        }
-        if (tid == 0) L.misc[MI_INVALID] = 0;
-        __syncthreads();                         // everyone has read the ticket before it is replaced
-        uint32_t next_tile = 0;
-        if (tid == 0) next_tile = atomicAdd(P.ticket, 1u);     // consumed after phase 1
-
-#ifdef TS_PHASE_TIMERS
-        u64 stamps[7];
-#endif
-        TS_STAMP(0);
+    for (uint32_t tile = gw; tile < P.ntiles; tile += total_waves) {
+        const TsTile T = P.tiles[tile];           // wave-uniform: scalar loads
         const uint32_t sh = (uint32_t)(T.in_off & 15ull);
         const unsigned char *src = P.in + (T.in_off - sh);
         const uint32_t nblk = T.nwin + P.q;                       // step blocks whose partials are needed
@@ -182,18 +154,17 @@ void ts_scan_tiles(const TsScanParams P) {
         uint32_t need = sh + (T.nrel < span + 16u ? T.nrel : span + 16u);
         uint32_t nch = (need + 16u + TS_CHUNK - 1u) / TS_CHUNK;
         if (nch > P.nch) nch = P.nch;
+        bool has_invalid = false;
 
-        for (uint32_t i = tid; i < P.max_blocks * TS_BLK_STRIDE; i += TS_WG_THREADS) L.blk[i] = 0;
+        if (P.windows_on)
+            for (uint32_t i = lane; i < NB * TS_BLK_COUNTERS; i += 64u) blk[i] = 0;
 
         // ------------------------------------------------------------------ phase 1
         {
-            uint32_t c = wave;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < nch) v = *(const uint4 *)(src + (size_t)c * TS_CHUNK + lane * 16u);
-            while (c < nch) {
-                const uint32_t cn = c + TS_WAVES;
+            uint4 v = *(const uint4 *)(src + lane * 16u);
+            for (uint32_t c = 0; c < nch; ++c) {
                 uint4 vn = make_uint4(0, 0, 0, 0);
-                if (cn < nch) vn = *(const uint4 *)(src + (size_t)cn * TS_CHUNK + lane * 16u);
+                if (c + 1u < nch) vn = *(const uint4 *)(src + (size_t)(c + 1u) * TS_CHUNK + lane * 16u);
 
                 // ASCII -> 2-bit codes (A0 C1 T2 G3) and a validity check, 4 bases per dword
                 const uint32_t x[4] = {v.x, v.y, v.z, v.w};
@@ -230,7 +201,7 @@ void ts_scan_tiles(const TsScanParams P) {
                     w2 = __builtin_amdgcn_udot4(t[2], 0x40100401u, w2 << 8, false);
                     w2 = __builtin_amdgcn_udot4(t[1], 0x40100401u, w2 << 8, false);
                     w2 = __builtin_amdgcn_udot4(t[0], 0x40100401u, w2 << 8, false);
-                    if (lane == 0) L.misc[MI_INVALID] = 1;
+                    has_invalid = true;
                 }
 
                 // next lane's 16 bases (DPP wave_shl:1, lane i <- lane i+1; lane 63's value is unused)
@@ -283,81 +254,36 @@ void ts_scan_tiles(const TsScanParams P) {
 
                 if (lane < 63u) {
                     const uint32_t h = c * 63u + lane;
-                    L.codes[h] = w2;
-                    L.pM[h] = (uint16_t)M16;
-                    L.pF[h] = (uint16_t)F16;
-                    L.pC[h] = (uint16_t)C16;
-                    L.pV[h] = (uint16_t)(~inv16);
+                    codes[h] = w2;
+                    pM[h] = (uint16_t)M16;
+                    pF[h] = (uint16_t)F16;
+                    pC[h] = (uint16_t)C16;
+                    pV[h] = (uint16_t)(~inv16);
                 }
-                c = cn;
                 v = vn;
             }
         }
-        if (tid == 0) L.misc[MI_TILE] = next_tile;
-        __syncthreads();
-        TS_STAMP(1);
-        // descriptor of the next tile: loaded now, parked in LDS after phase 2a
-        uint32_t next_desc = 0;
-        const uint32_t nt_id = L.misc[MI_TILE];
-        if (tid < 8u && nt_id < P.ntiles) next_desc = ((const uint32_t *)&P.tiles[nt_id])[tid];
+        __builtin_amdgcn_wave_barrier();          // planes written above are read by other lanes below
 
         // -------------------------------------------- w == s: matches may not straddle a window end
         if (P.straddle_fix && k > 1u) {
-            for (uint32_t b = tid; b < nblk; b += TS_WG_THREADS) {
+            for (uint32_t b = lane; b < nblk; b += 64u) {
                 const uint32_t hi = sh + (b + 1u) * P.s;
                 if (hi <= nch * TS_CHUNK) {
                     const uint32_t lo = hi - (k - 1u);
-                    plane_clear((uint32_t *)L.pM, lo, hi);
-                    plane_clear((uint32_t *)L.pF, lo, hi);
-                    plane_clear((uint32_t *)L.pC, lo, hi);
+                    plane_clear((uint32_t *)pM, lo, hi);
+                    plane_clear((uint32_t *)pF, lo, hi);
+                    plane_clear((uint32_t *)pC, lo, hi);
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
-        TS_STAMP(2);
-
-        // ------------------------------------------------- emit step A: owned match totals per wave
-        const uint32_t own_end = sh + T.own_len;                  // plane coord
-        const uint32_t h_hi = (own_end + 15u) >> 4;
-        const uint32_t per = (((h_hi + TS_WAVES - 1u) / TS_WAVES) + 63u) & ~63u;
-        const uint32_t hw0 = wave * per;
-        const uint32_t hw1 = (hw0 + per < h_hi) ? hw0 + per : h_hi;
-        {
-            uint32_t cm = 0, cc = 0, cf = 0;
-            for (uint32_t h = hw0 + lane; h < hw1; h += 64u) {
-                const uint32_t hb = h << 4;
-                const uint32_t lo = hb > sh ? 0u : sh - hb;
-                const uint32_t hi = (hb + 16u <= own_end) ? 16u : own_end - hb;
-                const uint32_t m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                const uint32_t M = L.pM[h] & m;
-                cm += __popc(M);
-                cc += __popc(M & L.pC[h]);
-                cf += __popc(M & L.pF[h]);
-            }
-            cm = wave_sum(cm); cc = wave_sum(cc); cf = wave_sum(cf);
-            if (lane == 0) { L.misc[MI_TOT + wave] = cm; L.misc[MI_CAN + wave] = cc; L.misc[MI_FWD + wave] = cf; }
-        }
-        __syncthreads();
-
-        // ------------------- reserve room for this tile's records: one atomic add, consumed later
-        uint32_t agg = 0;
-#pragma unroll
-        for (int i = 0; i < TS_WAVES; ++i) agg += L.misc[MI_TOT + i];
-        u64 rec_off = 0;
-        if (tid == 0) {
-            rec_off = atomicAdd(P.cursor, (u64)agg);
-            uint32_t tc = 0, tf = 0;
-            for (int i = 0; i < TS_WAVES; ++i) { tc += L.misc[MI_CAN + i]; tf += L.misc[MI_FWD + i]; }
-            *(uint4 *)&P.tile_stats[4u * tile] = make_uint4(agg, tc, tf, 0u);
-        }
-        TS_STAMP(3);
 
         // ------------------------------------------------------------------ phase 2a
-        const bool has_invalid = L.misc[MI_INVALID] != 0;
         if (P.windows_on) {
             const uint32_t ngran = (sh + count_lim + 63u) >> 6;
-            const u64 *gM = (const u64 *)L.pM, *gF = (const u64 *)L.pF, *gC = (const u64 *)L.pC;
-            for (uint32_t g = tid; g < ngran; g += TS_WG_THREADS) {
+            const u64 *gM = (const u64 *)pM, *gF = (const u64 *)pF, *gC = (const u64 *)pC;
+            for (uint32_t g = lane; g < ngran; g += 64u) {
                 const uint32_t gx = g << 6;
                 const uint32_t x_lo = gx > sh ? gx : sh;
                 const uint32_t x_hi = (gx + 64u < sh + count_lim) ? gx + 64u : sh + count_lim;
@@ -380,11 +306,11 @@ void ts_scan_tiles(const TsScanParams P) {
                             const u64 m = mask64(u + sh - gx, eu + sh - gx);
                             const uint32_t nm = __popcll(M & m);
                             if (nm) {
-                                uint32_t *a = &L.blk[b * TS_BLK_STRIDE + (head ? 8u : 11u)];
+                                uint32_t *a = &blk[(head ? 8u : 11u) * NB + b];
                                 const uint32_t nf = __popcll(F & m), nc = __popcll(C & m);
                                 atomicAdd(&a[0], nm);
-                                if (nc) atomicAdd(&a[1], nc);
-                                if (nf) atomicAdd(&a[2], nf);
+                                if (nc) atomicAdd(&a[NB], nc);
+                                if (nf) atomicAdd(&a[2u * NB], nf);
                             }
                             o += eu - u; u = eu;
                             if (o >= P.s) { o = 0; ++b; }
@@ -400,7 +326,7 @@ void ts_scan_tiles(const TsScanParams P) {
                         const uint32_t xa = u + sh, xb = eu + sh;
                         uint32_t n1 = 0, n2 = 0, n3 = 0, nt = 0;
                         if (xb - xa == 64u && !has_invalid) {           // whole granule, all bases valid
-                            const uint4 cd4 = *(const uint4 *)&L.codes[g << 2];
+                            const uint4 cd4 = *(const uint4 *)&codes[g << 2];
                             const uint32_t cd[4] = {cd4.x, cd4.y, cd4.z, cd4.w};
 #pragma unroll
                             for (int tq = 0; tq < 4; ++tq) {
@@ -420,8 +346,8 @@ void ts_scan_tiles(const TsScanParams P) {
                                     const uint32_t nb2 = (hi - lo) * 2u;
                                     uint32_t sel = (nb2 >= 32u ? ~0u : ((1u << nb2) - 1u)) << ((lo - base) * 2u);
                                     sel &= 0x55555555u;
-                                    if (has_invalid) sel &= spread16(L.pV[d]);
-                                    const uint32_t cd = L.codes[d];
+                                    if (has_invalid) sel &= spread16(pV[d]);
+                                    const uint32_t cd = codes[d];
                                     const uint32_t l0 = cd & sel, h0 = (cd >> 1) & sel;
                                     n3 += __popc(l0 & h0);
                                     n1 += __popc(l0 & ~h0);
@@ -430,93 +356,91 @@ void ts_scan_tiles(const TsScanParams P) {
                                 }
                             }
                         }
-                        uint32_t *a = &L.blk[b * TS_BLK_STRIDE + (head ? 0u : 4u)];
+                        uint32_t *a = &blk[(head ? 0u : 4u) * NB + b];
                         const uint32_t n0 = nt - n1 - n2 - n3;
                         if (n0) atomicAdd(&a[0], n0);
-                        if (n1) atomicAdd(&a[1], n1);
-                        if (n2) atomicAdd(&a[2], n2);
-                        if (n3) atomicAdd(&a[3], n3);
+                        if (n1) atomicAdd(&a[NB], n1);
+                        if (n2) atomicAdd(&a[2u * NB], n2);
+                        if (n3) atomicAdd(&a[3u * NB], n3);
                         o += eu - u; u = eu;
                         if (o >= P.s) { o = 0; ++b; }
                     }
                 }
             }
         }
-        TS_STAMP(4);
-        if (tid < 8u) L.misc[MI_DESC + tid] = next_desc;
-        if (tid == 0) {
-            L.misc[MI_OFF_LO] = (uint32_t)rec_off;
-            L.misc[MI_OFF_HI] = (uint32_t)(rec_off >> 32);
-            P.tile_off[tile] = rec_off;
-        }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
 
-        // --------------------------------------------------------------- phase 2b: window records
+        // ------------------------------------------------- phase 2b: window records, 8 x u32 each
         if (P.windows_on) {
-            for (uint32_t i = tid; i < T.nwin; i += TS_WG_THREADS) {
-                uint32_t n[4] = {0, 0, 0, 0}, m[3] = {0, 0, 0};
-                for (uint32_t j = 0; j < P.q; ++j) {
-                    const uint32_t *a = &L.blk[(i + j) * TS_BLK_STRIDE];
-#pragma unroll
-                    for (int cidx = 0; cidx < 4; ++cidx) n[cidx] += a[cidx] + a[4 + cidx];
+            const uint32_t nitems = T.nwin * 8u;
+            uint32_t *wout = P.windows_out + T.win_out * 8ull;
+            for (uint32_t it = lane; it < nitems; it += 64u) {
+                const uint32_t i = it >> 3, f = it & 7u;
+                uint32_t val;
+                if (f < 4u) {                                       // A C G T  (codes: A0 C1 T2 G3)
+                    const uint32_t c = (f == 2u) ? 3u : (f == 3u ? 2u : f);
+                    const uint32_t *hd = &blk[c * NB], *rs = &blk[(4u + c) * NB];
+                    val = 0;
+                    for (uint32_t j = 0; j < P.q; ++j) val += hd[i + j] + rs[i + j];
+                    if (P.r) val += hd[i + P.q];
+                } else {                                            // covered bases = k x count
+                    const uint32_t *mh = &blk[8u * NB], *mr = &blk[11u * NB];
+                    const uint32_t sel = (f & 2u) ? 2u * NB : NB;   // canonical (f=4,5) or forward (f=6,7)
+                    uint32_t mm = 0, ms = 0;
+                    for (uint32_t j = 0; j < P.qq; ++j) {
+                        mm += mh[i + j] + mr[i + j];
+                        ms += mh[sel + i + j] + mr[sel + i + j];
+                    }
+                    mm += mh[i + P.qq];
+                    ms += mh[sel + i + P.qq];
+                    val = ((f & 1u) ? (mm - ms) : ms) * k;
                 }
-                if (P.r) {
-                    const uint32_t *a = &L.blk[(i + P.q) * TS_BLK_STRIDE];
-#pragma unroll
-                    for (int cidx = 0; cidx < 4; ++cidx) n[cidx] += a[cidx];
-                }
-                for (uint32_t j = 0; j < P.qq; ++j) {
-                    const uint32_t *a = &L.blk[(i + j) * TS_BLK_STRIDE];
-#pragma unroll
-                    for (int cidx = 0; cidx < 3; ++cidx) m[cidx] += a[8 + cidx] + a[11 + cidx];
-                }
-                {
-                    const uint32_t *a = &L.blk[(i + P.qq) * TS_BLK_STRIDE];
-#pragma unroll
-                    for (int cidx = 0; cidx < 3; ++cidx) m[cidx] += a[8 + cidx];
-                }
-                uint4 *dst = (uint4 *)(P.windows_out + (T.win_out + i) * 8ull);
-                dst[0] = make_uint4(n[0], n[1], n[3], n[2]);                // A C G T
-                dst[1] = make_uint4(m[1] * k, (m[0] - m[1]) * k, m[2] * k, (m[0] - m[2]) * k);
+                wout[it] = val;
             }
         }
-        TS_STAMP(5);
 
-        // ------------------------------------------------------- emit step B: packed records
+        // ------------------------------------------------------- emit: packed match records
         {
-            u64 obase = ((u64)L.misc[MI_OFF_HI] << 32) | (u64)L.misc[MI_OFF_LO];
-            for (uint32_t i = 0; i < wave; ++i) obase += L.misc[MI_TOT + i];
-            for (uint32_t h0 = hw0; h0 < hw1; h0 += 64u) {
+            const uint32_t own_end = sh + T.own_len;              // plane coord
+            const uint32_t h_hi = (own_end + 15u) >> 4;
+            const u64 obase0 = region_base + cursor;
+            uint32_t done = 0, ccan = 0, cfwd = 0;
+            for (uint32_t h0 = 0; h0 < h_hi; h0 += 64u) {
                 const uint32_t h = h0 + lane;
                 uint32_t M = 0, F = 0, C = 0;
-                if (h < hw1) {
+                if (h < h_hi) {
                     const uint32_t hb = h << 4;
                     const uint32_t lo = hb > sh ? 0u : sh - hb;
                     const uint32_t hi = (hb + 16u <= own_end) ? 16u : own_end - hb;
                     const uint32_t m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                    M = L.pM[h] & m; F = L.pF[h]; C = L.pC[h];
+                    M = pM[h] & m; F = pF[h]; C = pC[h];
                 }
                 const uint32_t cnt = __popc(M);
+                ccan += __popc(M & C);
+                cfwd += __popc(M & F);
                 const uint32_t incl = wave_scan_incl(cnt);
-                u64 o = obase + (u64)(incl - cnt);
-                const uint32_t ubase = (h << 4) - sh;                 // tile-relative position of bit 0
+                uint32_t o = cursor + done + (incl - cnt);         // index inside this wave's region
+                const uint32_t ubase = (h << 4) - sh;               // tile-relative position of bit 0
                 while (M) {
                     const uint32_t j = (uint32_t)__builtin_ctz(M);
                     M &= M - 1u;
                     const uint32_t rec = ((ubase + j) << 2) | (((F >> j) & 1u) << 1) | ((C >> j) & 1u);
-                    if (o < P.match_cap) P.matches_out[o] = rec;
+                    if (o < P.region_cap) P.matches_out[region_base + o] = rec;
                     ++o;
                 }
-                obase += (u64)(uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                done += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
+            ccan = wave_sum(ccan);
+            cfwd = wave_sum(cfwd);
+            if (lane == 0) {
+                P.tile_off[tile] = obase0;
+                *(uint4 *)&P.tile_stats[4ull * tile] = make_uint4(done, ccan, cfwd, 0u);
+            }
+            cursor += done;
         }
-#ifdef TS_PHASE_TIMERS
-        __syncthreads();
-        TS_STAMP(6);
-        if (tid == 0 && P.phase_cycles)
-            for (int i = 0; i < 6; ++i) atomicAdd(&P.phase_cycles[i], stamps[i + 1] - stamps[i]);
-#endif
+        __builtin_amdgcn_wave_barrier();          // next tile overwrites the planes
     }
+    if (lane == 0) P.wave_fill[gw] = cursor;      // records needed by this wave (may exceed region_cap)
 }
 
 // Per-segment hit summary {windows, matches, canonical, forward}: the buffer ranks gather.
@@ -535,27 +459,28 @@ __global__ void ts_segment_summary(const uint32_t *tile_stats, const uint32_t *s
     out[4ull * sidx + 3] = nf;
 }
 
+// Packs the per-wave record regions into one dense stream (used before a D2H copy).
+__global__ void ts_compact_regions(const uint32_t *regions, const uint32_t *wave_fill, const u64 *wave_dense_base,
+                                   uint32_t region_cap, uint32_t nwaves, uint32_t *dense) {
+    const uint32_t w = blockIdx.x;
+    if (w >= nwaves) return;
+    const uint32_t n = wave_fill[w] < region_cap ? wave_fill[w] : region_cap;
+    const uint32_t *src = regions + (u64)w * region_cap;
+    uint32_t *dst = dense + wave_dense_base[w];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
 }  // namespace
 
-int ts_k_lds_bytes(const TsScanParams *p) {
-    uint32_t off[8];
-    return (int)lds_layout(*p, off);
-}
+int ts_k_lds_bytes(const TsScanParams *p) { return (int)lds_total(*p); }
 
 int ts_k_prepare(uint32_t lds_bytes) {
     return (int)hipFuncSetAttribute((const void *)ts_scan_tiles,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
-int ts_k_occupancy(uint32_t lds_bytes) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ts_scan_tiles, TS_WG_THREADS, lds_bytes) != hipSuccess)
-        return 1;
-    return nb < 1 ? 1 : nb;
-}
-
 int ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, void *stream) {
-    hipLaunchKernelGGL(ts_scan_tiles, dim3(grid), dim3(TS_WG_THREADS), lds_bytes, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(ts_scan_tiles, dim3(grid), dim3(p->waves_per_wg * 64u), lds_bytes, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 
@@ -564,5 +489,13 @@ int ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_ti
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(ts_segment_summary, dim3((nseg + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
                        tile_stats, seg_first_tile, seg_nwin, nseg, out);
+    return (int)hipGetLastError();
+}
+
+int ts_k_launch_compact(const uint32_t *regions, const uint32_t *wave_fill, const unsigned long long *wave_dense_base,
+                        uint32_t region_cap, uint32_t nwaves, uint32_t *dense, void *stream) {
+    if (nwaves == 0) return 0;
+    hipLaunchKernelGGL(ts_compact_regions, dim3(nwaves), dim3(256), 0, (hipStream_t)stream,
+                       regions, wave_fill, wave_dense_base, region_cap, nwaves, dense);
     return (int)hipGetLastError();
 }

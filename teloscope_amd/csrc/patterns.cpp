@@ -166,14 +166,14 @@ int base_code(char c) {
 // Match table for uniform-length pattern sets: for k-mer index x (base i at bits 2i..2i+1)
 // row x>>5 holds, for each of 16 replicas, the dwords {M, F, C, 0}; bit x&31 of M says
 // "x is a pattern", of F "forward-oriented", of C "canonical".  16 replicas give every
-// lane of a ds_read_b128 lane group its own 4 banks (conflict-free); k >= 8 has to trade
-// replicas for LDS capacity (4^k/32 rows): 4 replicas at k = 8, 1 at k = 9.
+// lane of a ds_read_b128 lane group its own 4 banks (conflict-free); k >= 7 has to trade
+// replicas for LDS capacity (4^k/32 rows): 8 replicas at k = 7, 2 at k = 8, 1 at k = 9.
 bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
                        uint32_t &rows, uint32_t &replicas) {
     if (k < 3 || k > 9) return false;
     const uint64_t entries = 1ull << (2 * k);
     rows = static_cast<uint32_t>(entries / 32);
-    replicas = k <= 7 ? 16u : (k == 8 ? 4u : 1u);
+    replicas = k <= 6 ? 16u : (k == 7 ? 8u : (k == 8 ? 2u : 1u));       // table <= 64 KB up to k = 8
     table.assign(static_cast<size_t>(rows) * replicas * 4, 0u);
     for (const Pattern &p : pats) {
         if (p.seq.size() != k) return false;

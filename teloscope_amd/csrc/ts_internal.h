@@ -6,16 +6,15 @@
 
 // Geometry of the tiled uniform-k scan kernel (kernels.hip: ts_scan_tiles).
 //
-// A segment (or tips-only region) is cut into tiles.  A tile OWNS `nwin` consecutive
-// windows (window k covers [k*s, k*s+w)) = the `nwin*s` bases where those windows start,
-// and additionally reads a halo so that every owned window and every k-mer that starts
-// in an owned base is complete.  Positions inside a tile are "plane coordinates":
+// A segment (or tips-only region) is cut into tiles; ONE WAVEFRONT scans one tile.  A tile OWNS
+// `nwin` consecutive windows (window k covers [k*s, k*s+w)) = the `nwin*s` bases where those
+// windows start, and additionally reads a halo so that every owned window and every k-mer
+// that starts in an owned base is complete.  Positions inside a tile are "plane coordinates":
 // byte offset from the 16-byte-aligned address at or below the tile's first owned base.
 
-#define TS_WG_THREADS   512            // 8 wavefronts per workgroup
-#define TS_WAVES        (TS_WG_THREADS / 64)
+#define TS_MAX_WG_THREADS 1024         // up to 16 wavefronts per workgroup, one workgroup per CU
 #define TS_CHUNK        1008           // positions a wave resolves per iteration (63 lanes x 16)
-#define TS_BLK_STRIDE   16             // u32 accumulators per step-block in LDS
+#define TS_BLK_COUNTERS 14             // per step-block: nuc head[4] rest[4], match head[3] rest[3]
 #define TS_IN_PAD       4096           // bytes of zero padding after the last segment in the input buffer
 
 struct TsTile {                 // 32 bytes
@@ -32,14 +31,13 @@ struct TsScanParams {
     const TsTile   *tiles;
     const uint32_t *table;      // replicated match table: rows x replicas x {M,F,C,0}
     uint32_t       *windows_out;    // 8 x u32 per window
-    uint32_t       *matches_out;    // packed records
-    unsigned long long *cursor;     // next free match record (zeroed before launch)
-    unsigned long long *tile_off;   // tile directory: first record of each tile
+    uint32_t       *matches_out;    // packed records, one region of region_cap records per wave
+    unsigned long long *tile_off;   // tile directory: first record of each tile (index into matches_out)
     uint32_t       *tile_stats;     // tile directory: {matches, canonical, forward, 0} per tile
-    uint32_t       *ticket;         // tile dispenser (zeroed before launch)
-    unsigned long long *phase_cycles;// diagnostic build only (TS_PHASE_TIMERS), else null
-    uint64_t        match_cap;
+    uint32_t       *wave_fill;      // per wave: records it needed (> region_cap means overflow)
+    uint32_t        region_cap;     // records per wave region
     uint32_t        ntiles;
+    uint32_t        waves_per_wg;
     uint32_t        table_rows;     // 4^k / 32
     uint32_t        row_shift;      // log2(bytes per table row) = log2(replicas * 16)
     uint32_t        rep_mask;       // replicas - 1 (replica = lane & rep_mask)
@@ -49,7 +47,7 @@ struct TsScanParams {
     uint32_t        q, r;           // w = q*s + r
     uint32_t        qq, hh;         // w - k = qq*s + hh
     uint32_t        nch;            // chunks of TS_CHUNK positions per tile
-    uint32_t        max_blocks;     // LDS accumulator rows
+    uint32_t        max_blocks;     // rows of the LDS block accumulators
     uint32_t        fold_mask;      // 0xDFDFDFDF (fold case) or 0xFFFFFFFF
     uint32_t        straddle_fix;   // 1: w == s, drop matches that straddle a window end
     uint32_t        windows_on;     // 0 in tips-only mode
@@ -65,10 +63,13 @@ struct TsLaunchInfo {
 extern "C++" {
 // Implemented in kernels.hip (compiled by hipcc).  All return a hipError_t as int.
 int  ts_k_lds_bytes(const TsScanParams *p);
-int  ts_k_prepare(uint32_t lds_bytes);                       // raises the dynamic-LDS limit once
+int  ts_k_prepare(uint32_t lds_bytes);                       // raises the dynamic-LDS limit
 int  ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, void *stream);
 int  ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_tile,
                          const uint64_t *seg_nwin, uint32_t nseg, unsigned long long *out, void *stream);
+int  ts_k_launch_compact(const uint32_t *regions, const uint32_t *wave_fill,
+                         const unsigned long long *wave_dense_base, uint32_t region_cap,
+                         uint32_t nwaves, uint32_t *dense, void *stream);
 }
 #endif
 
