@@ -192,18 +192,30 @@ def main():
                          "algorithmic_bytes": alg_bytes},
         }
         if not args.no_cpu_baseline:
+            # bounded sample of the same workload on ONE host core through the oracle port
             from tests.backends import OracleBackend
-            nb = int(min(args.cpu_sample_mb * 1e6, lens[0]))
-            host = buf[offsets[0]:offsets[0] + nb].cpu().numpy().tobytes().upper()
             ob = OracleBackend(opts)
-            c0 = time.perf_counter()
-            _, nw, nm = ob.oracle.bench_scan(host)
-            cpu_s = time.perf_counter() - c0
+            want = int(args.cpu_sample_mb * 1e6)
+            order = sorted(range(n), key=lambda i: -lens[i])
+            took, cpu_s, nw_t, nm_t, used = 0, 0.0, 0, 0, 0
+            for ci in order:
+                if took >= want:
+                    break
+                nb = int(min(want - took, lens[ci]))
+                host = buf[offsets[ci]:offsets[ci] + nb].cpu().numpy().tobytes().upper()
+                c0 = time.perf_counter()
+                _, nw, nm = ob.oracle.bench_scan(host)
+                cpu_s += time.perf_counter() - c0
+                took += nb
+                nw_t += nw
+                nm_t += nm
+                used += 1
+                del host
             out["cpu_baseline"] = {
-                "value": round(nb / cpu_s / 1e9, 5), "unit": "Gbases/s", "cores": 1, "kind": "port",
-                "sample": "first %.0f Mb of contig 0 of the same synthetic assembly, same flags, "
-                          "scan stage only (oracle/teloscope_oracle.c: trie walk + carry loop), "
-                          "%d windows, %d matches, %.1f s" % (nb / 1e6, nw, nm, cpu_s)}
+                "value": round(took / cpu_s / 1e9, 5), "unit": "Gbases/s", "cores": 1, "kind": "port",
+                "sample": "first %.0f Mb of the %d largest contigs of the same synthetic assembly, same flags, "
+                          "scan stage only incl. block calling (oracle/teloscope_oracle.c: trie walk + carry "
+                          "loop), %d windows, %d matches, %.1f s" % (took / 1e6, used, nw_t, nm_t, cpu_s)}
         print(json.dumps(out))
     L.ts_batch_destroy(batch)
     if world > 1:

@@ -211,3 +211,60 @@ def test_large_scan_properties():
         assert int(w["fwd_covered"].sum()) == 6 * int(f.sum())
         assert int(w["rev_covered"].sum()) == 6 * int((~f).sum())
     assert_segment_equal(got[1], orac.scan_segment(segs[1][0], segs[1][1], False), False, ctx="3Mb slice")
+
+
+def _hip():
+    import ctypes as C
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            return C.CDLL(name)
+        except OSError:
+            continue
+    pytest.skip("libamdhip64 not loadable")
+
+
+def test_batch_api_summary_and_overflow_rescan():
+    """Device-resident batch API: a deliberately tiny match capacity forces the overflow ->
+    grow -> rescan path; the per-segment summary kernel (the buffer ranks gather) must agree
+    with the downloaded results and with the oracle."""
+    import ctypes as C
+    from teloscope_amd import _capi as K
+    opts = H.parse_cli("x -w 1000 -s 500 -r -g -e -m -i")
+    prod, orac = ProductBackend(opts), OracleBackend(opts)
+    L = K.lib()
+    rng = np.random.default_rng(4)
+    seqs = [seqgen.chromosome(rng, n, telo_repeats=400, n_its=6) for n in (300_000, 50_000, 1, 0, 1_000_000)]
+    n = len(seqs)
+    lens = (C.c_uint64 * n)(*[len(s) for s in seqs])
+    absp = (C.c_uint64 * n)(*[1000 * i for i in range(n)])
+    ctx = prod.teloscope._ctx.ptr
+    b = L.ts_batch_create(ctx, lens, absp, n, 0, 64)            # 64 records: certain to overflow
+    assert b, L.ts_last_error(ctx)
+    for i, s in enumerate(seqs):
+        assert L.ts_batch_upload(b, i, s) == 0
+    assert L.ts_batch_scan(b, None, None) == 0
+    assert L.ts_batch_sync(b) == 0, L.ts_last_error(ctx)
+    info = K.BatchInfo()
+    L.ts_batch_get_info(b, C.byref(info))
+    out = (K.SegmentOut * n)()
+    assert L.ts_batch_download(b, None, out) == 0, L.ts_last_error(ctx)
+    hip = _hip()
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), C.c_size_t(32 * n)) == 0
+    assert L.ts_batch_segment_summary(b, dptr, None) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    summ = np.zeros((n, 4), dtype=np.uint64)
+    assert hip.hipMemcpy(summ.ctypes.data_as(C.c_void_p), dptr, C.c_size_t(32 * n), 2) == 0
+    hip.hipFree(dptr)
+    total = 0
+    for i, s in enumerate(seqs):
+        e = orac.scan_segment(s, 1000 * i, False)
+        m = e["all_matches"]
+        assert summ[i].tolist() == [len(e["windows"]), len(m), int(m["is_canonical"].sum()),
+                                    int(m["is_forward"].sum())]
+        assert out[i].n_matches == len(m) and out[i].n_windows == len(e["windows"])
+        total += len(m)
+    assert info.n_matches == total
+    assert info.algorithmic_bytes == sum(len(s) for s in seqs) + 32 * info.n_windows + 4 * total
+    L.ts_free_segments(out, n)
+    L.ts_batch_destroy(b)
