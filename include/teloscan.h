@@ -36,7 +36,7 @@ typedef enum ts_status {
     TS_ERR_NO_DEVICE    = -2,   /* no usable HIP device (no CPU fallback exists) */
     TS_ERR_HIP          = -3,   /* a HIP runtime call failed */
     TS_ERR_ALLOC        = -4,
-    TS_ERR_UNSUPPORTED  = -5,   /* parameter set outside what the kernels implement */
+    TS_ERR_UNSUPPORTED  = -5,   /* parameter set no device path implements (pattern > 32 bases, > 8 lengths, ...) */
     TS_ERR_STATE        = -6
 } ts_status;
 
@@ -173,8 +173,9 @@ void ts_free_patterns(ts_pattern *p);
  *      (calls are serialised on an internal mutex; results are independent of call order). */
 ts_ctx *ts_create(const ts_params *params, const ts_pattern *patterns, size_t n_patterns);
 void    ts_destroy(ts_ctx *ctx);
-/* 1 if (window, step, patterns) are handled by the tiled uniform-k kernel, 0 if by the
- * general kernel. */
+/* 1 if full scans with this (window, step, patterns) run on the tiled uniform-k kernel,
+ * 0 if on the general kernels (mixed-length sets, k > 9, or a longest pattern exceeding
+ * min(step, window-step), where the reference's start-index arithmetic wraps). */
 int     ts_uses_fast_path(const ts_ctx *ctx);
 
 /* ---- Teloscope::scanSegment, batched (src/teloscope.cpp:537-658).  out[i] receives the

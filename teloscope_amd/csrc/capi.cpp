@@ -47,6 +47,10 @@ struct ts_ctx {
     int device = 0;
     int num_cu = 0;
     uint32_t table_rows = 0, table_replicas = 16;
+    // general kernels (generic.hip): sorted 2-bit codes per pattern length
+    bool generic_ok = false;
+    TsGenericPatterns gpat{};
+    DevBuf d_gcodes, d_gflags;
     DevBuf d_table;
     mutable std::mutex mtx;
     mutable std::string error;
@@ -315,10 +319,49 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
     c->bp.min_block_density = c->params.min_block_density;
     c->bp.first_pattern_len = n_patterns ? patterns[0].len : 0;
 
+    // tables of the general kernels: usable for any set with <= 8 distinct lengths <= 32
+    if (n_patterns) {
+        std::vector<uint32_t> lens;
+        for (const ts::Pattern &p : c->patterns) lens.push_back((uint32_t)p.seq.size());
+        std::sort(lens.begin(), lens.end());
+        lens.erase(std::unique(lens.begin(), lens.end()), lens.end());
+        bool ok = lens.size() <= 8 && lens.back() <= 32 && lens.front() >= 1;
+        std::vector<unsigned long long> codes;
+        std::vector<uint8_t> flags;
+        if (ok) {
+            c->gpat.nlen = (uint32_t)lens.size();
+            for (size_t li = 0; li < lens.size() && ok; ++li) {
+                c->gpat.len[li] = lens[li];
+                c->gpat.first[li] = (uint32_t)codes.size();
+                std::vector<std::pair<unsigned long long, uint8_t>> v;
+                for (const ts::Pattern &p : c->patterns) {
+                    if (p.seq.size() != lens[li]) continue;
+                    unsigned long long code = 0;
+                    for (size_t i = 0; i < p.seq.size(); ++i) {
+                        const int b = ts::base_code(p.seq[i]);
+                        if (b < 0) { ok = false; break; }
+                        code |= (unsigned long long)b << (2 * i);
+                    }
+                    v.emplace_back(code, (uint8_t)((p.is_forward ? 1 : 0) | (p.is_canonical ? 2 : 0)));
+                }
+                std::sort(v.begin(), v.end());
+                for (const auto &e : v) { codes.push_back(e.first); flags.push_back(e.second); }
+            }
+            c->gpat.first[lens.size()] = (uint32_t)codes.size();
+        }
+        if (ok && c->d_gcodes.ensure(codes.size() * 8) == hipSuccess && c->d_gflags.ensure(flags.size() + 16) == hipSuccess &&
+            hipMemcpy(c->d_gcodes.p, codes.data(), codes.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(c->d_gflags.p, flags.data(), flags.size(), hipMemcpyHostToDevice) == hipSuccess) {
+            c->gpat.codes = (const unsigned long long *)c->d_gcodes.p;
+            c->gpat.flags = (const uint8_t *)c->d_gflags.p;
+            c->generic_ok = true;
+        }
+    }
+
     if (n_patterns == 0) {
         c->why_not = "empty pattern set";
     } else if (kmin != kmax) {
-        c->why_not = "mixed-length pattern sets need the general kernel (not built yet)";
+        c->why_not = "mixed-length pattern set";
     } else {
         std::vector<uint32_t> table;
         if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows, c->table_replicas)) {
@@ -349,6 +392,8 @@ ts_ctx *ts_create_read_filter(const ts_params *params, int min_block_len_set,
 void ts_destroy(ts_ctx *ctx) {
     if (!ctx) return;
     ctx->d_table.release();
+    ctx->d_gcodes.release();
+    ctx->d_gflags.release();
     delete ctx;
 }
 
@@ -591,13 +636,81 @@ int ts_batch_segment_summary(ts_batch *b, void *d_out, void *stream) {
     return TS_OK;
 }
 
+// --------------------------------------------------------------- shared host post-processing
+// Turns one segment's raw results into SegmentData: window records (float metrics evaluated on
+// the host from the integer counts, as the reference does), terminal flags, block calling
+// (src/teloscope.cpp:642-657).  `matches` arrive with absolute positions and FORWARD/CANONICAL set.
+static int finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos,
+                            const uint32_t *win_raw, uint64_t n_windows, std::vector<ts_match> &matches,
+                            ts_segment_out &o) {
+    const ts_params &P = c->params;
+    std::memset(&o, 0, sizeof o);
+    if (!tips && n_windows) {
+        o.windows = (ts_window *)std::calloc(n_windows, sizeof(ts_window));
+        if (!o.windows) return c->fail(TS_ERR_ALLOC, "out of host memory");
+        o.n_windows = n_windows;
+        const bool nuc = P.out_gc || P.out_entropy;
+        for (uint64_t kwin = 0; kwin < n_windows; ++kwin) {
+            const uint32_t *r = &win_raw[kwin * 8];
+            ts_window &w = o.windows[kwin];
+            const uint64_t ws = kwin * P.step;
+            w.window_start = abs_pos + ws;
+            w.current_window_size = (uint32_t)std::min<uint64_t>(P.window_size, seg_len - ws);
+            if (nuc) for (int i = 0; i < 4; ++i) w.nucleotide_counts[i] = r[i];
+            if (P.out_gc) w.gc_content = ts::gc_content(w.nucleotide_counts, w.current_window_size);
+            if (P.out_entropy) w.shannon_entropy = ts::shannon_entropy(w.nucleotide_counts, w.current_window_size);
+            w.canonical_covered = r[4];
+            w.non_canonical_covered = r[5];
+            w.fwd_covered = r[6];
+            w.rev_covered = r[7];
+        }
+    }
+    const uint64_t nm = matches.size();
+    if (nm > 0xFFFFFFFFull) return c->fail(TS_ERR_UNSUPPORTED, "more than 2^32 matches in one segment");
+    const uint64_t term_end = seg_len > P.terminal_limit ? seg_len - P.terminal_limit : 0;
+    for (ts_match &m : matches) {                                   // isTerminal, src/teloscope.cpp:451-459
+        const uint64_t rel = m.position - abs_pos;
+        if (rel <= P.terminal_limit || rel >= term_end) m.flags |= TS_MATCH_TERMINAL;
+    }
+    if (nm) {
+        o.matches = (ts_match *)std::malloc(nm * sizeof(ts_match));
+        if (!o.matches) return c->fail(TS_ERR_ALLOC, "out of host memory");
+        std::memcpy(o.matches, matches.data(), nm * sizeof(ts_match));
+        o.n_matches = nm;
+    }
+    std::vector<uint32_t> fwd_idx, rev_idx;
+    fwd_idx.reserve(nm / 2 + 1); rev_idx.reserve(nm / 2 + 1);
+    for (uint64_t i = 0; i < nm; ++i)
+        ((o.matches[i].flags & TS_MATCH_FORWARD) ? fwd_idx : rev_idx).push_back((uint32_t)i);
+    std::vector<ts_block> term, its;
+    uint64_t fwd_boundary = abs_pos, rev_boundary = abs_pos + seg_len;
+    if (fwd_idx.size() >= 2)
+        fwd_boundary = ts::terminal_blocks(c->bp, o.matches, fwd_idx.data(), fwd_idx.size(), term, seg_len, abs_pos, true);
+    if (rev_idx.size() >= 2)
+        rev_boundary = ts::terminal_blocks(c->bp, o.matches, rev_idx.data(), rev_idx.size(), term, seg_len, abs_pos, false);
+    if (!tips && fwd_boundary < rev_boundary && nm >= 2)
+        ts::interstitial_blocks(c->bp, o.matches, nm, its, fwd_boundary, rev_boundary);
+    auto copy_blocks = [&](const std::vector<ts_block> &v, ts_block *&dst, uint64_t &n) -> bool {
+        n = v.size();
+        dst = nullptr;
+        if (v.empty()) return true;
+        dst = (ts_block *)std::malloc(v.size() * sizeof(ts_block));
+        if (!dst) return false;
+        std::memcpy(dst, v.data(), v.size() * sizeof(ts_block));
+        return true;
+    };
+    if (!copy_blocks(term, o.terminal_blocks, o.n_terminal_blocks) ||
+        !copy_blocks(its, o.interstitial_blocks, o.n_interstitial_blocks))
+        return c->fail(TS_ERR_ALLOC, "out of host memory");
+    return TS_OK;
+}
+
 // --------------------------------------------------------------- download + host post-processing
 int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out *out) {
     (void)host_seqs;
     if (!b || !out) return TS_ERR_INVALID_ARG;
     ts_ctx *c = b->ctx;
     if (!b->synced) { int rc = ts_batch_sync(b); if (rc != TS_OK) return rc; }
-    const ts_params &P = c->params;
     const size_t nt = b->tiles.size(), ns = b->segs.size();
 
     std::vector<uint32_t> wins(b->n_windows * 8);
@@ -628,43 +741,14 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
     }
 
     const uint16_t klen = (uint16_t)c->k;
+    std::vector<ts_match> matches;
     for (size_t si = 0; si < ns; ++si) {
         const SegPlan &sp = b->segs[si];
-        ts_segment_out &o = out[si];
-        std::memset(&o, 0, sizeof o);
-
-        // windows (float metrics on the host from the integer counts, as the reference does)
-        if (!b->tips && sp.n_windows) {
-            o.windows = (ts_window *)std::calloc(sp.n_windows, sizeof(ts_window));
-            if (!o.windows) return c->fail(TS_ERR_ALLOC, "out of host memory");
-            o.n_windows = sp.n_windows;
-            const bool nuc = P.out_gc || P.out_entropy;
-            for (uint64_t kwin = 0; kwin < sp.n_windows; ++kwin) {
-                const uint32_t *r = &wins[(sp.win_base + kwin) * 8];
-                ts_window &w = o.windows[kwin];
-                const uint64_t ws = kwin * P.step;
-                w.window_start = sp.abs_pos + ws;
-                w.current_window_size = (uint32_t)std::min<uint64_t>(P.window_size, sp.len - ws);
-                if (nuc) for (int i = 0; i < 4; ++i) w.nucleotide_counts[i] = r[i];
-                if (P.out_gc) w.gc_content = ts::gc_content(w.nucleotide_counts, w.current_window_size);
-                if (P.out_entropy) w.shannon_entropy = ts::shannon_entropy(w.nucleotide_counts, w.current_window_size);
-                w.canonical_covered = r[4];
-                w.non_canonical_covered = r[5];
-                w.fwd_covered = r[6];
-                w.rev_covered = r[7];
-            }
-        }
-
-        // matches: tile-relative packed records -> absolute MatchInfo
+        // matches: tile-relative packed records -> absolute MatchInfo, tiles in position order
         uint64_t nm = 0;
         for (uint32_t t = 0; t < sp.n_tiles; ++t) nm += tile_stats[4ull * (sp.first_tile + t)];
-        if (nm) {
-            o.matches = (ts_match *)std::malloc(nm * sizeof(ts_match));
-            if (!o.matches) return c->fail(TS_ERR_ALLOC, "out of host memory");
-            o.n_matches = nm;
-        }
-        const uint64_t term_end = sp.len > P.terminal_limit ? sp.len - P.terminal_limit : 0;
-        uint64_t w_i = 0;
+        matches.clear();
+        matches.reserve(nm);
         for (const Region &rg : sp.regions) {
             for (uint32_t t = 0; t < rg.n_tiles; ++t) {
                 const uint32_t ti = rg.first_tile + t;
@@ -673,46 +757,18 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
                 if (r1 > recs.size()) return c->fail(TS_ERR_STATE, "tile directory out of range");
                 for (uint64_t ri = r0; ri < r1; ++ri) {
                     const uint32_t rec = recs[ri];
-                    const uint64_t rel = tile_rel + (rec >> 2);
-                    ts_match &m = o.matches[w_i++];
-                    m.position = sp.abs_pos + rel;
+                    ts_match m{};
+                    m.position = sp.abs_pos + tile_rel + (rec >> 2);
                     m.match_size = klen;
-                    uint8_t fl = 0;
-                    if (rec & 2u) fl |= TS_MATCH_FORWARD;
-                    if (rec & 1u) fl |= TS_MATCH_CANONICAL;
-                    if (rel <= P.terminal_limit || rel >= term_end) fl |= TS_MATCH_TERMINAL;   // src/teloscope.cpp:451-459
-                    m.flags = fl;
-                    std::memset(m.reserved, 0, sizeof m.reserved);
+                    m.flags = (uint8_t)(((rec & 2u) ? TS_MATCH_FORWARD : 0u) | ((rec & 1u) ? TS_MATCH_CANONICAL : 0u));
+                    matches.push_back(m);
                 }
             }
         }
-
-        // block calling (src/teloscope.cpp:642-657)
-        std::vector<uint32_t> fwd_idx, rev_idx;
-        fwd_idx.reserve(nm / 2 + 1); rev_idx.reserve(nm / 2 + 1);
-        for (uint64_t i = 0; i < nm; ++i)
-            ((o.matches[i].flags & TS_MATCH_FORWARD) ? fwd_idx : rev_idx).push_back((uint32_t)i);
-        if (nm > 0xFFFFFFFFull) return c->fail(TS_ERR_UNSUPPORTED, "more than 2^32 matches in one segment");
-        std::vector<ts_block> term, its;
-        uint64_t fwd_boundary = sp.abs_pos, rev_boundary = sp.abs_pos + sp.len;
-        if (fwd_idx.size() >= 2)
-            fwd_boundary = ts::terminal_blocks(c->bp, o.matches, fwd_idx.data(), fwd_idx.size(), term, sp.len, sp.abs_pos, true);
-        if (rev_idx.size() >= 2)
-            rev_boundary = ts::terminal_blocks(c->bp, o.matches, rev_idx.data(), rev_idx.size(), term, sp.len, sp.abs_pos, false);
-        if (!b->tips && fwd_boundary < rev_boundary && nm >= 2)
-            ts::interstitial_blocks(c->bp, o.matches, nm, its, fwd_boundary, rev_boundary);
-        auto copy_blocks = [&](const std::vector<ts_block> &v, ts_block *&dst, uint64_t &n) -> bool {
-            n = v.size();
-            dst = nullptr;
-            if (v.empty()) return true;
-            dst = (ts_block *)std::malloc(v.size() * sizeof(ts_block));
-            if (!dst) return false;
-            std::memcpy(dst, v.data(), v.size() * sizeof(ts_block));
-            return true;
-        };
-        if (!copy_blocks(term, o.terminal_blocks, o.n_terminal_blocks) ||
-            !copy_blocks(its, o.interstitial_blocks, o.n_interstitial_blocks))
-            return c->fail(TS_ERR_ALLOC, "out of host memory");
+        int rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos,
+                                  sp.n_windows ? &wins[sp.win_base * 8] : nullptr, b->tips ? 0 : sp.n_windows,
+                                  matches, out[si]);
+        if (rc != TS_OK) return rc;
     }
     return TS_OK;
 }
@@ -726,6 +782,105 @@ void ts_free_segments(ts_segment_out *out, size_t n_segs) {
         std::free(out[i].interstitial_blocks);
         std::memset(&out[i], 0, sizeof out[i]);
     }
+}
+
+// =========================================================================== general path
+// For parameter sets outside the tiled kernel's closed form (mixed-length pattern sets, pattern
+// lengths > 9, or a longest pattern exceeding min(step, window-step) where the reference's
+// uint32 start index wraps): ts_generic_match + ts_generic_windows (generic.hip) on the device,
+// then only ordering work on the host.  One segment at a time; this is the slow exact path.
+static int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<size_t> &which,
+                              bool tips, ts_segment_out *out) {
+    if (which.empty()) return TS_OK;
+    if (!c->generic_ok)
+        return c->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: more than 8 pattern lengths, a pattern longer "
+                                           "than 32 or a non-ACGT pattern");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const ts_params &P = c->params;
+    const uint32_t s = P.step, w = P.window_size, ov = w - s, L = c->longest;
+    DevBuf d_seq, d_mask, d_win;
+    std::vector<uint32_t> mask, wins;
+    std::vector<ts_match> matches;
+    struct Hit { uint64_t k, p; uint16_t len; uint8_t flags; };
+    std::vector<Hit> hits;
+    int rc = TS_OK;
+    for (size_t wi = 0; wi < which.size() && rc == TS_OK; ++wi) {
+        const ts_segment_in &sg = segs[which[wi]];
+        const uint64_t N = sg.len;
+        matches.clear();
+        uint64_t nwin = 0;
+        // regions exactly as scanSegment picks them (src/teloscope.cpp:576-583; uint32 product)
+        std::vector<std::pair<uint64_t, uint64_t>> regions;
+        if (tips) {
+            const uint32_t twice = 2u * P.terminal_limit;
+            if (N > twice) { regions.emplace_back(0, P.terminal_limit); regions.emplace_back(N - P.terminal_limit, P.terminal_limit); }
+            else if (N) regions.emplace_back(0, N);
+        } else if (N) {
+            regions.emplace_back(0, N);
+            nwin = ceil_div(N, s);
+        }
+        for (const auto &rg : regions) {
+            const uint64_t r0 = rg.first, n = rg.second;
+            if (d_seq.ensure(n + 16) != hipSuccess || d_mask.ensure(n * 4 + 16) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "device allocation failed"); break; }
+            if (hipMemcpy(d_seq.p, sg.seq + r0, n, hipMemcpyHostToDevice) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "H2D copy failed"); break; }
+            if (ts_k_launch_generic_match((const unsigned char *)d_seq.p, n, &c->gpat, P.fold_case, (uint32_t *)d_mask.p, nullptr) != 0) { rc = c->fail(TS_ERR_HIP, "generic match kernel launch failed"); break; }
+            if (!tips) {
+                TsGenericGeom Q{};
+                Q.n = N; Q.s = s; Q.w = w; Q.longest = L; Q.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u; Q.fold = P.fold_case;
+                if (d_win.ensure(nwin * 32 + 16) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "device allocation failed"); break; }
+                if (ts_k_launch_generic_windows((const unsigned char *)d_seq.p, (const uint32_t *)d_mask.p, &c->gpat, &Q, nwin, (uint32_t *)d_win.p, nullptr) != 0) { rc = c->fail(TS_ERR_HIP, "generic window kernel launch failed"); break; }
+                wins.resize(nwin * 8);
+                if (hipMemcpy(wins.data(), d_win.p, nwin * 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "D2H copy failed"); break; }
+            }
+            mask.resize(n);
+            if (hipMemcpy(mask.data(), d_mask.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "D2H copy failed"); break; }
+
+            // enumerate matches in (position, length) order; in full-scan mode keep those some
+            // window's own scan pushes (src/teloscope.cpp:485) and order them by that window
+            hits.clear();
+            const uint32_t t1 = s - L, t2 = ov - L;                     // uint32 wrap, src/teloscope.cpp:413-415
+            const uint32_t start_index = t1 < t2 ? t1 : t2;
+            for (uint64_t p = 0; p < n; ++p) {
+                const uint32_t m = mask[p];
+                if (!m) continue;
+                for (uint32_t li = 0; li < c->gpat.nlen; ++li) {
+                    const uint32_t b = (m >> (3 * li)) & 7u;
+                    if (!(b & 1u)) continue;
+                    const uint32_t len = c->gpat.len[li];
+                    const uint8_t fl = (uint8_t)(((b & 2u) ? TS_MATCH_FORWARD : 0u) | ((b & 4u) ? TS_MATCH_CANONICAL : 0u));
+                    uint64_t k = 0;
+                    if (!tips) {
+                        const uint64_t e = p + len - 1;
+                        if (ov == 0) {
+                            k = p / s;
+                            const uint64_t cws = std::min<uint64_t>(w, N - k * s);
+                            if ((p - k * s) + len > cws) continue;      // crosses its only window's end
+                        } else if (e < std::min<uint64_t>(w, N)) {
+                            k = 0;                                      // window 0 scans everything it holds
+                        } else {
+                            k = (e - ov) / s;                           // the one window with j >= overlap
+                            if (p < k * s || (p - k * s) < start_index) continue;
+                        }
+                    }
+                    hits.push_back(Hit{k, r0 + p, (uint16_t)len, fl});
+                }
+            }
+            if (!tips)
+                std::stable_sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.k < b.k; });
+            for (const Hit &h : hits) {
+                ts_match m{};
+                m.position = sg.abs_pos + h.p;
+                m.match_size = h.len;
+                m.flags = h.flags;
+                matches.push_back(m);
+            }
+        }
+        if (rc != TS_OK) break;
+        rc = finalize_segment(c, tips, N, sg.abs_pos, wins.data(), nwin, matches, out[which[wi]]);
+    }
+    d_seq.release(); d_mask.release(); d_win.release();
+    return rc;
 }
 
 // =========================================================================== scanSegment, batched
@@ -758,8 +913,11 @@ int ts_scan_segments(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_s
     }
     std::vector<size_t> full, tips;
     for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
-    int rc = scan_group(ctx, segs, full, false, out);
-    if (rc == TS_OK) rc = scan_group(ctx, segs, tips, true, out);
+    std::string why;
+    int rc = full_scan_supported(ctx, why) ? scan_group(ctx, segs, full, false, out)
+                                           : scan_group_generic(ctx, segs, full, false, out);
+    if (rc == TS_OK) rc = ctx->fast_ok ? scan_group(ctx, segs, tips, true, out)
+                                       : scan_group_generic(ctx, segs, tips, true, out);
     if (rc != TS_OK) ts_free_segments(out, n_segs);
     return rc;
 }

@@ -52,6 +52,16 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v), 63);
 }
 
+// sixteen 2-bit codes (one per byte of t[0..3], values 0..3) -> one dword, base i at bits 2i..2i+1;
+// four independent v_dot4_u32_u8 (weights 1,4,16,64) and three v_lshl_or, no dependent dot chain
+__device__ __forceinline__ uint32_t pack16(const uint32_t t[4]) {
+    const uint32_t b0 = __builtin_amdgcn_udot4(t[0], 0x40100401u, 0u, false);
+    const uint32_t b1 = __builtin_amdgcn_udot4(t[1], 0x40100401u, 0u, false);
+    const uint32_t b2 = __builtin_amdgcn_udot4(t[2], 0x40100401u, 0u, false);
+    const uint32_t b3 = __builtin_amdgcn_udot4(t[3], 0x40100401u, 0u, false);
+    return (b0 | (b1 << 8)) | ((b2 | (b3 << 8)) << 16);
+}
+
 // spread the 16 bits of v to the even bit positions of a dword
 __device__ __forceinline__ uint32_t spread16(uint32_t x) {
     x = (x | (x << 8)) & 0x00FF00FFu;
@@ -160,107 +170,112 @@ void ts_scan_tiles(const TsScanParams P) {
             for (uint32_t i = lane; i < NB * TS_BLK_COUNTERS; i += 64u) blk[i] = 0;
 
         // ------------------------------------------------------------------ phase 1
-        {
-            uint4 v = *(const uint4 *)(src + lane * 16u);
-            for (uint32_t c = 0; c < nch; ++c) {
-                uint4 vn = make_uint4(0, 0, 0, 0);
-                if (c + 1u < nch) vn = *(const uint4 *)(src + (size_t)(c + 1u) * TS_CHUNK + lane * 16u);
+        // Chunk c+1's 16 B/lane load is in flight while chunk c is resolved; the loop is unrolled
+        // by two with alternating registers so the loaded value is never copied (a copy would
+        // make the compiler wait for the load it was meant to overlap).
+        auto resolve_chunk = [&](const uint32_t c, const uint4 v) {
+            // ASCII -> 2-bit codes (A0 C1 T2 G3) and a validity check, 4 bases per dword
+            const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+            uint32_t t[4], e[4], sad = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                t[i] = (x[i] >> 1) & 0x07070707u;
+                e[i] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x47544341u, t[i]);
+                sad = __builtin_amdgcn_sad_u8(x[i] & P.fold_mask, e[i], sad);
+            }
+            uint32_t w2 = pack16(t);
 
-                // ASCII -> 2-bit codes (A0 C1 T2 G3) and a validity check, 4 bases per dword
-                const uint32_t x[4] = {v.x, v.y, v.z, v.w};
-                uint32_t t[4], e[4], sad = 0;
+            const uint32_t pos0 = c * TS_CHUNK + lane * 16u;     // plane coord of this lane's first base
+            uint32_t inv16 = 0;
+            const bool slow = __any(sad != 0) || (c * TS_CHUNK + 1024u > xend);
+            if (slow) {                                           // wave-uniform, rare
+                uint32_t b4[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    t[i] = (x[i] >> 1) & 0x07070707u;
-                    e[i] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x47544341u, t[i]);
-                    sad = __builtin_amdgcn_sad_u8(x[i] & P.fold_mask, e[i], sad);
+                    const uint32_t d = (x[i] & P.fold_mask) ^ e[i];
+                    const uint32_t nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;
+                    b4[i] = __builtin_amdgcn_udot4(nz, 0x08040201u, 0u, false);
+                    t[i] &= 0x03030303u;
                 }
-                uint32_t w2 = __builtin_amdgcn_udot4(t[3], 0x40100401u, 0u, false);
-                w2 = __builtin_amdgcn_udot4(t[2], 0x40100401u, w2 << 8, false);
-                w2 = __builtin_amdgcn_udot4(t[1], 0x40100401u, w2 << 8, false);
-                w2 = __builtin_amdgcn_udot4(t[0], 0x40100401u, w2 << 8, false);
+                inv16 = b4[0] | (b4[1] << 4) | (b4[2] << 8) | (b4[3] << 12);
+                if (pos0 + 16u > xend) {
+                    const uint32_t nv = xend > pos0 ? xend - pos0 : 0u;
+                    inv16 |= (0xFFFFu << nv) & 0xFFFFu;
+                }
+                w2 = pack16(t);
+                has_invalid = true;
+            }
 
-                const uint32_t pos0 = c * TS_CHUNK + lane * 16u;     // plane coord of this lane's first base
-                uint32_t inv16 = 0;
-                const bool slow = __any(sad != 0) || (c * TS_CHUNK + 1024u > xend);
-                if (slow) {                                           // wave-uniform, rare
-                    uint32_t b4[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t d = (x[i] & P.fold_mask) ^ e[i];
-                        const uint32_t nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;
-                        b4[i] = __builtin_amdgcn_udot4(nz, 0x08040201u, 0u, false);
-                        t[i] &= 0x03030303u;
-                    }
-                    inv16 = b4[0] | (b4[1] << 4) | (b4[2] << 8) | (b4[3] << 12);
-                    if (pos0 + 16u > xend) {
-                        const uint32_t nv = xend > pos0 ? xend - pos0 : 0u;
-                        inv16 |= (0xFFFFu << nv) & 0xFFFFu;
-                    }
-                    w2 = __builtin_amdgcn_udot4(t[3], 0x40100401u, 0u, false);
-                    w2 = __builtin_amdgcn_udot4(t[2], 0x40100401u, w2 << 8, false);
-                    w2 = __builtin_amdgcn_udot4(t[1], 0x40100401u, w2 << 8, false);
-                    w2 = __builtin_amdgcn_udot4(t[0], 0x40100401u, w2 << 8, false);
-                    has_invalid = true;
-                }
+            // next lane's 16 bases (DPP wave_shl:1, lane i <- lane i+1; lane 63's value is unused)
+            const uint32_t nxt = (uint32_t)__builtin_amdgcn_mov_dpp((int)w2, 0x130, 0xf, 0xf, false);
 
-                // next lane's 16 bases (DPP wave_shl:1, lane i <- lane i+1; lane 63's value is unused)
-                const uint32_t nxt = (uint32_t)__builtin_amdgcn_mov_dpp((int)w2, 0x130, 0xf, 0xf, false);
+            // one table probe per position: row = k-mer >> 5, bit = k-mer & 31.  All sixteen
+            // ds_read_b128 are issued back to back (inline asm: hipcc would narrow them to b96 and
+            // serialise them on a register-reuse wait), then consumed in two halves behind counted
+            // lgkmcnt waits, so LDS latency is paid once per chunk instead of once per probe.
+            uint32_t tmp[16];
+            u32x4 ent[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                tmp[j] = (j == 0) ? w2 : __builtin_amdgcn_alignbit(nxt, w2, 2 * j);
+                const uint32_t row = __builtin_amdgcn_ubfe(tmp[j], 5, rowbits);
+                const uint32_t addr = tab_base + (row << P.row_shift) + repoff;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(ent[j]) : "v"(addr));
+            }
+            uint32_t aM = 0, aF = 0, aC = 0;
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // every probe's full 16-byte destination stays allocated until its wait has passed
+            // (the unused 4th dword must not be handed to another value while the read is in flight)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(ent[j]));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                aM = __builtin_amdgcn_alignbit(ent[j].x >> (tmp[j] & 31u), aM, 1);
+                aF = __builtin_amdgcn_alignbit(ent[j].y >> (tmp[j] & 31u), aF, 1);
+                aC = __builtin_amdgcn_alignbit(ent[j].z >> (tmp[j] & 31u), aC, 1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 8; j < 16; ++j) asm volatile("" ::"v"(ent[j]));
+#pragma unroll
+            for (int j = 8; j < 16; ++j) {
+                aM = __builtin_amdgcn_alignbit(ent[j].x >> (tmp[j] & 31u), aM, 1);
+                aF = __builtin_amdgcn_alignbit(ent[j].y >> (tmp[j] & 31u), aF, 1);
+                aC = __builtin_amdgcn_alignbit(ent[j].z >> (tmp[j] & 31u), aC, 1);
+            }
+            uint32_t M16 = aM >> 16, F16 = aF >> 16, C16 = aC >> 16;
 
-                // one table probe per position: row = k-mer >> 5, bit = k-mer & 31.  All sixteen
-                // ds_read_b128 are issued back to back (inline asm: hipcc would narrow them to b96 and
-                // serialise them on a register-reuse wait), then consumed in two halves behind counted
-                // lgkmcnt waits, so LDS latency is paid once per chunk instead of once per probe.
-                uint32_t tmp[16];
-                u32x4 ent[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    tmp[j] = (j == 0) ? w2 : __builtin_amdgcn_alignbit(nxt, w2, 2 * j);
-                    const uint32_t row = __builtin_amdgcn_ubfe(tmp[j], 5, rowbits);
-                    const uint32_t addr = tab_base + (row << P.row_shift) + repoff;
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(ent[j]) : "v"(addr));
-                }
-                uint32_t aM = 0, aF = 0, aC = 0;
-                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                // every probe's full 16-byte destination stays allocated until its wait has passed
-                // (the unused 4th dword must not be handed to another value while the read is in flight)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(ent[j]));
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    aM = __builtin_amdgcn_alignbit(ent[j].x >> (tmp[j] & 31u), aM, 1);
-                    aF = __builtin_amdgcn_alignbit(ent[j].y >> (tmp[j] & 31u), aF, 1);
-                    aC = __builtin_amdgcn_alignbit(ent[j].z >> (tmp[j] & 31u), aC, 1);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 8; j < 16; ++j) asm volatile("" ::"v"(ent[j]));
-#pragma unroll
-                for (int j = 8; j < 16; ++j) {
-                    aM = __builtin_amdgcn_alignbit(ent[j].x >> (tmp[j] & 31u), aM, 1);
-                    aF = __builtin_amdgcn_alignbit(ent[j].y >> (tmp[j] & 31u), aF, 1);
-                    aC = __builtin_amdgcn_alignbit(ent[j].z >> (tmp[j] & 31u), aC, 1);
-                }
-                uint32_t M16 = aM >> 16, F16 = aF >> 16, C16 = aC >> 16;
+            if (slow) {                                           // k-mers touching an invalid base
+                const uint32_t inv32 = inv16 | ((uint32_t)__builtin_amdgcn_mov_dpp((int)inv16, 0x130, 0xf, 0xf, false) << 16);
+                uint32_t kb = 0;
+                for (uint32_t i = 0; i < k; ++i) kb |= inv32 >> i;
+                M16 &= ~kb; F16 &= ~kb; C16 &= ~kb;
+            }
 
-                if (slow) {                                           // k-mers touching an invalid base
-                    const uint32_t inv32 = inv16 | ((uint32_t)__builtin_amdgcn_mov_dpp((int)inv16, 0x130, 0xf, 0xf, false) << 16);
-                    uint32_t kb = 0;
-                    for (uint32_t i = 0; i < k; ++i) kb |= inv32 >> i;
-                    M16 &= ~kb; F16 &= ~kb; C16 &= ~kb;
-                }
-
-                if (lane < 63u) {
-                    const uint32_t h = c * 63u + lane;
-                    codes[h] = w2;
-                    pM[h] = (uint16_t)M16;
-                    pF[h] = (uint16_t)F16;
-                    pC[h] = (uint16_t)C16;
-                    pV[h] = (uint16_t)(~inv16);
-                }
-                v = vn;
+            if (lane < 63u) {
+                const uint32_t h = c * 63u + lane;
+                codes[h] = w2;
+                pM[h] = (uint16_t)M16;
+                pF[h] = (uint16_t)F16;
+                pC[h] = (uint16_t)C16;
+                pV[h] = (uint16_t)(~inv16);
+            }
+        };
+        {
+            // loads are unconditional (the last one re-reads the final chunk) so that the wait
+            // before each resolve is a counted vmcnt(1), never vmcnt(0)
+            const uint32_t last = nch - 1u;
+            uint4 va = *(const uint4 *)(src + lane * 16u), vb;
+            for (uint32_t c = 0; c < nch; c += 2u) {
+                const uint32_t c1 = c + 1u < last ? c + 1u : last;
+                vb = *(const uint4 *)(src + (size_t)c1 * TS_CHUNK + lane * 16u);
+                resolve_chunk(c, va);
+                if (c + 1u >= nch) break;
+                const uint32_t c2 = c + 2u < last ? c + 2u : last;
+                va = *(const uint4 *)(src + (size_t)c2 * TS_CHUNK + lane * 16u);
+                resolve_chunk(c + 1u, vb);
             }
         }
         __builtin_amdgcn_wave_barrier();          // planes written above are read by other lanes below

@@ -54,6 +54,21 @@ struct TsScanParams {
     uint32_t        nuc_on;         // nucleotide counts wanted (-g / -e)
 };
 
+// ---- general kernels (generic.hip) ----
+struct TsGenericPatterns {
+    const unsigned long long *codes;    // per length: ascending 2-bit codes (base i at bits 2i..2i+1)
+    const uint8_t *flags;               // bit0 forward, bit1 canonical (parallel to codes)
+    uint32_t nlen;                      // distinct pattern lengths, ascending
+    uint32_t len[8];
+    uint32_t first[9];                  // codes[first[i] .. first[i+1]) have length len[i]
+};
+
+struct TsGenericGeom {
+    unsigned long long n;               // segment length
+    uint32_t s, w, longest;
+    uint32_t nuc_on, fold;
+};
+
 struct TsLaunchInfo {
     uint32_t grid;
     uint32_t lds_bytes;
@@ -67,6 +82,10 @@ int  ts_k_prepare(uint32_t lds_bytes);                       // raises the dynam
 int  ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, void *stream);
 int  ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_tile,
                          const uint64_t *seg_nwin, uint32_t nseg, unsigned long long *out, void *stream);
+int  ts_k_launch_generic_match(const unsigned char *seq, unsigned long long n, const TsGenericPatterns *G,
+                               uint32_t fold, uint32_t *mask, void *stream);
+int  ts_k_launch_generic_windows(const unsigned char *seq, const uint32_t *mask, const TsGenericPatterns *G,
+                                 const TsGenericGeom *Q, unsigned long long nwin, uint32_t *out, void *stream);
 int  ts_k_launch_compact(const uint32_t *regions, const uint32_t *wave_fill,
                          const unsigned long long *wave_dense_base, uint32_t region_cap,
                          uint32_t nwaves, uint32_t *dense, void *stream);

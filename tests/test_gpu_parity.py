@@ -165,12 +165,44 @@ def test_non_acgt_and_case_handling():
     assert_segment_equal(g2, orac.scan_segment(bytes(s), 123, False), False, ctx="strict")
 
 
+GENERIC_GRID = [
+    # parameter sets outside the tiled kernel's closed form -> general kernels (generic.hip)
+    "-w 10 -s 5 -g -i",                                   # L > step and L > overlap: both start indices wrap
+    "-w 1000 -s 997 -r -g -e -i",                         # L > overlap only
+    "-w 12 -s 8 -g -e -m -i -t 50",                       # L > overlap, tiny windows
+    "-w 1000 -s 998 -r -g",
+    "-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i",      # mixed lengths 5/6 (several matches per position)
+    "-p TTAGGG,TTAGG,TTTAGGGTTTAGGG -x 1 -w 500 -s 500 -g -i",
+    "-p TTAGGG,TTAGG -t 400",                             # mixed lengths, tips only
+    "-c TTTAGGGTTTAGGG -x 1 -w 1000 -s 500 -r -g -i",     # k = 14 (no LDS table)
+    "-c TTAGGGTTAGGG -x 0",                               # k = 12, tips only
+]
+
+
+@pytest.mark.parametrize("cli", GENERIC_GRID)
+def test_general_kernels_match_oracle(cli):
+    opts = H.parse_cli("x.fa " + cli)
+    prod, orac = ProductBackend(opts), OracleBackend(opts)
+    assert not prod.teloscope.usesFastPath() or opts.ultra_fast
+    rng = np.random.default_rng(len(cli) * 31 + 7)
+    segs = []
+    for i, n in enumerate([1, 4, 5, 9, 10, 11, 23, 100, 997, 998, 1000, 1994, 2001, 5000, 33333, 70001]):
+        s = seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev,
+                              telo_repeats=min(100, max(1, n // 40)), tvr_rate=0.05, n_its=3,
+                              iupac=(n // 3000) * (i % 2))
+        segs.append((s, int(rng.integers(0, 10 ** 6)), opts.ultra_fast))
+    got = prod.scan_segments(segs)
+    for (s, ap, tips), g in zip(segs, got):
+        assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="cli=%r len=%d" % (cli, len(s)))
+
+
 def test_unsupported_parameter_sets_fail_loudly():
-    """Parameter sets the tiled kernel does not implement return TS_ERR_UNSUPPORTED; they are
-    never routed to a CPU path."""
+    """What even the general kernels do not take (a pattern longer than 32, more than 8 distinct
+    lengths) returns TS_ERR_UNSUPPORTED; nothing is ever routed to a CPU path."""
     import teloscope_amd as ta
     from teloscope_amd import _capi as K
-    for cli in ("-w 10 -s 5 -g", "-p TTAGGG,TTAGG -w 1000 -s 500 -g", "-w 1000 -s 997 -r"):
+    for cli in ("-p " + "TTAGGG" * 6 + " -x 0 -w 1000 -s 500 -g",
+                "-x 0 -p " + ",".join("TTAGGG"[:3] + "A" * i for i in range(9)) + " -w 1000 -s 500 -g"):
         opts = H.parse_cli("x.fa " + cli)
         be = ProductBackend(opts)
         with pytest.raises(ta.TeloscanError) as ei:
