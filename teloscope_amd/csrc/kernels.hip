@@ -415,27 +415,31 @@ void ts_scan_tiles(const TsScanParams P) {
         }
 
         // ------------------------------------------------------- emit: packed match records
+        // 32 positions per lane and iteration (plane dwords): the per-match loop runs for the
+        // fullest lane, so wider lanes waste fewer of its iterations.
         {
             const uint32_t own_end = sh + T.own_len;              // plane coord
-            const uint32_t h_hi = (own_end + 15u) >> 4;
+            const uint32_t w_hi = (own_end + 31u) >> 5;
+            const uint32_t *wM = (const uint32_t *)pM, *wF = (const uint32_t *)pF, *wC = (const uint32_t *)pC;
             const u64 obase0 = region_base + cursor;
             uint32_t done = 0, ccan = 0, cfwd = 0;
-            for (uint32_t h0 = 0; h0 < h_hi; h0 += 64u) {
+            for (uint32_t h0 = 0; h0 < w_hi; h0 += 64u) {
                 const uint32_t h = h0 + lane;
                 uint32_t M = 0, F = 0, C = 0;
-                if (h < h_hi) {
-                    const uint32_t hb = h << 4;
+                if (h < w_hi) {
+                    const uint32_t hb = h << 5;
                     const uint32_t lo = hb > sh ? 0u : sh - hb;
-                    const uint32_t hi = (hb + 16u <= own_end) ? 16u : own_end - hb;
-                    const uint32_t m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                    M = pM[h] & m; F = pF[h]; C = pC[h];
+                    const uint32_t hi = (hb + 32u <= own_end) ? 32u : own_end - hb;
+                    uint32_t m = hi >= 32u ? ~0u : ((1u << hi) - 1u);
+                    m &= ~0u << lo;
+                    M = wM[h] & m; F = wF[h]; C = wC[h];
                 }
                 const uint32_t cnt = __popc(M);
                 ccan += __popc(M & C);
                 cfwd += __popc(M & F);
                 const uint32_t incl = wave_scan_incl(cnt);
                 uint32_t o = cursor + done + (incl - cnt);         // index inside this wave's region
-                const uint32_t ubase = (h << 4) - sh;               // tile-relative position of bit 0
+                const uint32_t ubase = (h << 5) - sh;               // tile-relative position of bit 0
                 while (M) {
                     const uint32_t j = (uint32_t)__builtin_ctz(M);
                     M &= M - 1u;
