@@ -46,7 +46,7 @@ struct ts_ctx {
     std::string why_not;            // reason when a scan mode is unsupported
     int device = 0;
     int num_cu = 0;
-    uint32_t table_rows = 0, table_replicas = 16;
+    uint32_t table_rows = 0, table_replicas = 8, fc_bytes = 0;
     // general kernels (generic.hip): sorted 2-bit codes per pattern length
     bool generic_ok = false;
     TsGenericPatterns gpat{};
@@ -118,11 +118,10 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     const uint32_t k = c->k;
     kp.k = k;
     kp.table_rows = c->table_rows;
-    kp.row_shift = c->table_replicas == 16 ? 8u : (c->table_replicas == 8 ? 7u : (c->table_replicas == 4 ? 6u :
-                   (c->table_replicas == 2 ? 5u : 4u)));
+    kp.row_shift = c->table_replicas == 8 ? 5u : (c->table_replicas == 2 ? 3u : 2u);      // replicas * 4 bytes
+    kp.fc_bytes = c->fc_bytes;
     kp.rep_mask = c->table_replicas - 1u;
     kp.fold_mask = P.fold_case ? 0xDFDFDFDFu : 0xFFFFFFFFu;
-    const uint32_t table_bytes = kp.table_rows << kp.row_shift;
     if (tips) {
         kp.q = 0; kp.r = 0; kp.qq = 0;
         kp.straddle_fix = 0; kp.windows_on = 0; kp.nuc_on = 0;
@@ -159,7 +158,6 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
             if (wpt >= 1 && (uint32_t)ts_k_lds_bytes(&kp) <= kMaxLds) return true;
             if (nch <= nch_min) break;
         }
-        (void)table_bytes;
     }
     why = "window/step geometry does not fit the 160 KB LDS of a CU";
     return false;
@@ -364,8 +362,8 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
         c->why_not = "mixed-length pattern set";
     } else {
         std::vector<uint32_t> table;
-        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows, c->table_replicas)) {
-            c->why_not = "pattern length outside 3..9 or non-ACGT pattern";
+        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows, c->table_replicas, c->fc_bytes)) {
+            c->why_not = "pattern length outside 3..8 or non-ACGT pattern";
         } else {
             c->k = kmin;
             if (c->d_table.ensure(table.size() * 4) != hipSuccess ||

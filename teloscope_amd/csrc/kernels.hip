@@ -15,9 +15,10 @@
 //
 // Per tile:
 //   phase 1  1008 positions per iteration: one coalesced 16 B/lane load, SWAR ASCII -> 2-bit
-//            codes (v_perm / v_sad_u8 / v_dot4), rolling k-mer per position, ONE ds_read_b128
-//            from the replicated bit table in LDS giving {match, forward, canonical}; results
-//            are kept as bit planes in the wave's LDS slice.
+//            codes (v_perm / v_sad_u8 / v_dot4), ONE ds_read_b32 per TWO positions from the
+//            replicated pair table in LDS ((k+1)-mer -> match bits of both positions), forward /
+//            canonical flags resolved only at matched positions; results are kept as bit planes
+//            in the wave's LDS slice.
 //   phase 2  per-step-block partial sums by range popcounts over the planes; windows are
 //            assembled from ceil(w/s)+1 block partials -> 8 x u32 per window, coalesced.
 //   emit     prefix-sum (DPP) compaction of the match plane into packed 32-bit records.
@@ -110,7 +111,7 @@ __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
 }
 
 __host__ __device__ inline uint32_t lds_total(const TsScanParams &P) {
-    return (P.table_rows << P.row_shift) + P.waves_per_wg * slice_layout(P).bytes;
+    return (P.table_rows << P.row_shift) + P.fc_bytes + P.waves_per_wg * slice_layout(P).bytes;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -123,7 +124,7 @@ void ts_scan_tiles(const TsScanParams P) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 
     // the replicated bit table is loaded once and stays for the lifetime of the workgroup
-    const uint32_t table_bytes = P.table_rows << P.row_shift;
+    const uint32_t table_bytes = (P.table_rows << P.row_shift) + P.fc_bytes;      // pair table + flag table
     {
         const uint4 *src = (const uint4 *)P.table;
         uint4 *dst = (uint4 *)lds_raw;
@@ -143,8 +144,10 @@ void ts_scan_tiles(const TsScanParams P) {
     const uint32_t NB = P.max_blocks;             // blk[counter * NB + block]
 
     const uint32_t k = P.k;
-    const uint32_t rowbits = 2u * k - 5u;
-    const uint32_t repoff = (lane & P.rep_mask) * 16u;
+    const uint32_t rowbits = 2u * (k + 1u) - 4u;      // pair table: 4^(k+1) entries, 16 per dword
+    const uint32_t repoff = (lane & P.rep_mask) * 4u;
+    const uint32_t kmask = (1u << (2u * k)) - 1u;
+    const uint32_t *fc_table = (const uint32_t *)(lds_raw + (P.table_rows << P.row_shift));
     // LDS byte address of the table (it sits at the dynamic-LDS base)
     const uint32_t tab_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw;
 
@@ -209,49 +212,45 @@ void ts_scan_tiles(const TsScanParams P) {
             // next lane's 16 bases (DPP wave_shl:1, lane i <- lane i+1; lane 63's value is unused)
             const uint32_t nxt = (uint32_t)__builtin_amdgcn_mov_dpp((int)w2, 0x130, 0xf, 0xf, false);
 
-            // one table probe per position: row = k-mer >> 5, bit = k-mer & 31.  All sixteen
-            // ds_read_b128 are issued back to back (inline asm: hipcc would narrow them to b96 and
-            // serialise them on a register-reuse wait), then consumed in two halves behind counted
-            // lgkmcnt waits, so LDS latency is paid once per chunk instead of once per probe.
-            uint32_t tmp[16];
-            u32x4 ent[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                tmp[j] = (j == 0) ? w2 : __builtin_amdgcn_alignbit(nxt, w2, 2 * j);
-                const uint32_t row = __builtin_amdgcn_ubfe(tmp[j], 5, rowbits);
-                const uint32_t addr = tab_base + (row << P.row_shift) + repoff;
-                asm volatile("ds_read_b128 %0, %1" : "=v"(ent[j]) : "v"(addr));
-            }
-            uint32_t aM = 0, aF = 0, aC = 0;
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            // every probe's full 16-byte destination stays allocated until its wait has passed
-            // (the unused 4th dword must not be handed to another value while the read is in flight)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(ent[j]));
+            // ONE table probe per TWO positions: the pair table is indexed by the (k+1)-mer that
+            // starts at an even position and holds {match at p, match at p+1} (16 entries per dword:
+            // row = index >> 4, bit = 2 * (index & 15)).  All eight ds_read_b32 are issued back to
+            // back (inline asm) and consumed behind one counted wait.
+            uint32_t tmp[8], ent[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                aM = __builtin_amdgcn_alignbit(ent[j].x >> (tmp[j] & 31u), aM, 1);
-                aF = __builtin_amdgcn_alignbit(ent[j].y >> (tmp[j] & 31u), aF, 1);
-                aC = __builtin_amdgcn_alignbit(ent[j].z >> (tmp[j] & 31u), aC, 1);
+                tmp[j] = (j == 0) ? w2 : __builtin_amdgcn_alignbit(nxt, w2, 4 * j);
+                const uint32_t row = __builtin_amdgcn_ubfe(tmp[j], 4, rowbits);
+                const uint32_t addr = tab_base + (row << P.row_shift) + repoff;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(ent[j]) : "v"(addr));
             }
+            uint32_t aM = 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 8; j < 16; ++j) asm volatile("" ::"v"(ent[j]));
-#pragma unroll
-            for (int j = 8; j < 16; ++j) {
-                aM = __builtin_amdgcn_alignbit(ent[j].x >> (tmp[j] & 31u), aM, 1);
-                aF = __builtin_amdgcn_alignbit(ent[j].y >> (tmp[j] & 31u), aF, 1);
-                aC = __builtin_amdgcn_alignbit(ent[j].z >> (tmp[j] & 31u), aC, 1);
-            }
-            uint32_t M16 = aM >> 16, F16 = aF >> 16, C16 = aC >> 16;
+            for (int j = 0; j < 8; ++j)
+                aM = __builtin_amdgcn_alignbit(ent[j] >> ((tmp[j] << 1) & 31u), aM, 2);
+            uint32_t M16 = aM >> 16;
 
             if (slow) {                                           // k-mers touching an invalid base
                 const uint32_t inv32 = inv16 | ((uint32_t)__builtin_amdgcn_mov_dpp((int)inv16, 0x130, 0xf, 0xf, false) << 16);
                 uint32_t kb = 0;
                 for (uint32_t i = 0; i < k; ++i) kb |= inv32 >> i;
-                M16 &= ~kb; F16 &= ~kb; C16 &= ~kb;
+                M16 &= ~kb;
+            }
+
+            // forward / canonical flags only where something matched (a few per cent of positions):
+            // 2 bits per k-mer in an unreplicated LDS table, one pass per set bit of the fullest lane
+            uint32_t F16 = 0, C16 = 0;
+            for (uint32_t m = M16; __any(m != 0);) {
+                if (m) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    const uint32_t idx = __builtin_amdgcn_alignbit(nxt, w2, 2u * j) & kmask;
+                    const uint32_t fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
+                    F16 |= (fc & 1u) << j;
+                    C16 |= (fc >> 1) << j;
+                }
             }
 
             if (lane < 63u) {

@@ -163,18 +163,17 @@ int base_code(char c) {
     }
 }
 
-// Match table for uniform-length pattern sets: for k-mer index x (base i at bits 2i..2i+1)
-// row x>>5 holds, for each of 16 replicas, the dwords {M, F, C, 0}; bit x&31 of M says
-// "x is a pattern", of F "forward-oriented", of C "canonical".  16 replicas give every
-// lane of a ds_read_b128 lane group its own 4 banks (conflict-free); k >= 7 has to trade
-// replicas for LDS capacity (4^k/32 rows): 8 replicas at k = 7, 2 at k = 8, 1 at k = 9.
+// Match tables for uniform-length pattern sets (k-mer index x: base i at bits 2i..2i+1).
+//  * pair table: indexed by the (k+1)-mer y = bases p..p+k; entry = 2 bits {x(p) is a pattern,
+//    x(p+1) is a pattern}, 16 entries per dword (row = y >> 4), each row replicated R times so
+//    that the lanes of a ds_read_b32 group spread over the LDS banks (R = 8 / 2 / 1 for k <= 6 / 7 / 8);
+//  * flag table: 2 bits per k-mer {forward, canonical}, looked up only at matched positions.
+// Layout in `table`: [rows x R dwords][4^k / 16 dwords].
 bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
-                       uint32_t &rows, uint32_t &replicas) {
-    if (k < 3 || k > 9) return false;
-    const uint64_t entries = 1ull << (2 * k);
-    rows = static_cast<uint32_t>(entries / 32);
-    replicas = k <= 6 ? 16u : (k == 7 ? 8u : (k == 8 ? 2u : 1u));       // table <= 64 KB up to k = 8
-    table.assign(static_cast<size_t>(rows) * replicas * 4, 0u);
+                       uint32_t &rows, uint32_t &replicas, uint32_t &fc_bytes) {
+    if (k < 3 || k > 8) return false;
+    const uint64_t nk = 1ull << (2 * k);
+    std::vector<uint8_t> m(nk, 0), fl(nk, 0);
     for (const Pattern &p : pats) {
         if (p.seq.size() != k) return false;
         uint32_t x = 0;
@@ -183,14 +182,24 @@ bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector
             if (c < 0) return false;
             x |= static_cast<uint32_t>(c) << (2 * i);
         }
-        const uint32_t row = x >> 5, bit = 1u << (x & 31u);
-        for (uint32_t rep = 0; rep < replicas; ++rep) {
-            uint32_t *e = &table[(static_cast<size_t>(row) * replicas + rep) * 4];
-            e[0] |= bit;
-            if (p.is_forward) e[1] |= bit;
-            if (p.is_canonical) e[2] |= bit;
-        }
+        m[x] = 1;
+        fl[x] = static_cast<uint8_t>((p.is_forward ? 1 : 0) | (p.is_canonical ? 2 : 0));
     }
+    const uint64_t npairs = nk * 4;                                   // (k+1)-mers
+    rows = static_cast<uint32_t>(npairs / 16);
+    replicas = k <= 6 ? 8u : (k == 7 ? 2u : 1u);
+    const size_t fc_words = static_cast<size_t>(std::max<uint64_t>(nk / 16, 4));
+    fc_bytes = static_cast<uint32_t>(fc_words * 4);
+    table.assign(static_cast<size_t>(rows) * replicas + fc_words, 0u);
+    const uint32_t kmask = static_cast<uint32_t>(nk - 1);
+    for (uint64_t y = 0; y < npairs; ++y) {
+        const uint32_t bits = (m[y & kmask] ? 1u : 0u) | (m[(y >> 2) & kmask] ? 2u : 0u);
+        if (!bits) continue;
+        for (uint32_t rep = 0; rep < replicas; ++rep)
+            table[(y >> 4) * replicas + rep] |= bits << (2 * (y & 15));
+    }
+    uint32_t *fc = &table[static_cast<size_t>(rows) * replicas];
+    for (uint64_t x = 0; x < nk; ++x) fc[x >> 4] |= static_cast<uint32_t>(fl[x]) << (2 * (x & 15));
     return true;
 }
 

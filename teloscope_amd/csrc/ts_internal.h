@@ -29,7 +29,7 @@ struct TsTile {                 // 32 bytes
 struct TsScanParams {
     const uint8_t  *in;
     const TsTile   *tiles;
-    const uint32_t *table;      // replicated match table: rows x replicas x {M,F,C,0}
+    const uint32_t *table;      // pair table (rows x replicas dwords) followed by the flag table (fc_bytes)
     uint32_t       *windows_out;    // 8 x u32 per window
     uint32_t       *matches_out;    // packed records, one region of region_cap records per wave
     unsigned long long *tile_off;   // tile directory: first record of each tile (index into matches_out)
@@ -38,8 +38,9 @@ struct TsScanParams {
     uint32_t        region_cap;     // records per wave region
     uint32_t        ntiles;
     uint32_t        waves_per_wg;
-    uint32_t        table_rows;     // 4^k / 32
-    uint32_t        row_shift;      // log2(bytes per table row) = log2(replicas * 16)
+    uint32_t        table_rows;     // 4^(k+1) / 16
+    uint32_t        fc_bytes;       // flag table: 2 bits per k-mer, 4^k / 4 bytes (16-byte multiple)
+    uint32_t        row_shift;      // log2(bytes per table row) = log2(replicas * 4)
     uint32_t        rep_mask;       // replicas - 1 (replica = lane & rep_mask)
     uint32_t        k;              // pattern length
     uint32_t        s, w;           // step and window (tips mode: s = w = tile size)
