@@ -47,6 +47,7 @@ struct ts_ctx {
     int device = 0;
     int num_cu = 0;
     uint32_t table_rows = 0, table_replicas = 8, fc_bytes = 0;
+    bool fc_byte_table = true;
     // general kernels (generic.hip): sorted 2-bit codes per pattern length
     bool generic_ok = false;
     TsGenericPatterns gpat{};
@@ -120,6 +121,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     kp.table_rows = c->table_rows;
     kp.row_shift = c->table_replicas == 8 ? 5u : (c->table_replicas == 2 ? 3u : 2u);      // replicas * 4 bytes
     kp.fc_bytes = c->fc_bytes;
+    kp.fc_byte_table = c->fc_byte_table ? 1u : 0u;
     kp.rep_mask = c->table_replicas - 1u;
     kp.fold_mask = P.fold_case ? 0xDFDFDFDFu : 0xFFFFFFFFu;
     if (tips) {
@@ -362,7 +364,7 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
         c->why_not = "mixed-length pattern set";
     } else {
         std::vector<uint32_t> table;
-        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows, c->table_replicas, c->fc_bytes)) {
+        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows, c->table_replicas, c->fc_bytes, c->fc_byte_table)) {
             c->why_not = "pattern length outside 3..8 or non-ACGT pattern";
         } else {
             c->k = kmin;

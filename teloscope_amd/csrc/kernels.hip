@@ -116,6 +116,7 @@ __host__ __device__ inline uint32_t lds_total(const TsScanParams &P) {
 
 // ---------------------------------------------------------------------------------------
 // 16 waves per CU = 4 per SIMD: at most 128 VGPRs
+template <bool FC_BYTES>
 __global__ __launch_bounds__(TS_MAX_WG_THREADS, 4)
 void ts_scan_tiles(const TsScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -148,6 +149,7 @@ void ts_scan_tiles(const TsScanParams P) {
     const uint32_t repoff = (lane & P.rep_mask) * 4u;
     const uint32_t kmask = (1u << (2u * k)) - 1u;
     const uint32_t *fc_table = (const uint32_t *)(lds_raw + (P.table_rows << P.row_shift));
+    const unsigned char *fc_bytes = (const unsigned char *)fc_table;
     // LDS byte address of the table (it sits at the dynamic-LDS base)
     const uint32_t tab_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw;
 
@@ -240,18 +242,21 @@ void ts_scan_tiles(const TsScanParams P) {
             }
 
             // forward / canonical flags only where something matched (a few per cent of positions):
-            // 2 bits per k-mer in an unreplicated LDS table, one pass per set bit of the fullest lane
+            // one pass per set bit of the fullest lane, branch-free per lane (bit 16 is a sentinel
+            // that keeps ctz defined for lanes that have run out of matches; its writes land in
+            // bit 16 of F16/C16 and are masked off).  Flag table: one byte per k-mer, or 2 bits.
             uint32_t F16 = 0, C16 = 0;
-            for (uint32_t m = M16; __any(m != 0);) {
-                if (m) {
-                    const uint32_t j = (uint32_t)__builtin_ctz(m);
-                    m &= m - 1u;
-                    const uint32_t idx = __builtin_amdgcn_alignbit(nxt, w2, 2u * j) & kmask;
-                    const uint32_t fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
-                    F16 |= (fc & 1u) << j;
-                    C16 |= (fc >> 1) << j;
-                }
+            for (uint32_t m = M16 | 0x10000u; __any((m & 0xFFFFu) != 0u);) {
+                const uint32_t j = (uint32_t)__builtin_ctz(m);
+                const uint32_t idx = __builtin_amdgcn_alignbit(nxt, w2, 2u * j) & kmask;
+                uint32_t fc;
+                if (FC_BYTES) fc = fc_bytes[idx];
+                else fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
+                m = (m & (m - 1u)) | 0x10000u;
+                F16 |= (fc & 1u) << j;
+                C16 |= (fc >> 1) << j;
             }
+            F16 &= 0xFFFFu; C16 &= 0xFFFFu;
 
             if (lane < 63u) {
                 const uint32_t h = c * 63u + lane;
@@ -493,12 +498,18 @@ __global__ void ts_compact_regions(const uint32_t *regions, const uint32_t *wave
 int ts_k_lds_bytes(const TsScanParams *p) { return (int)lds_total(*p); }
 
 int ts_k_prepare(uint32_t lds_bytes) {
-    return (int)hipFuncSetAttribute((const void *)ts_scan_tiles,
+    int e = (int)hipFuncSetAttribute((const void *)ts_scan_tiles<true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e) return e;
+    return (int)hipFuncSetAttribute((const void *)ts_scan_tiles<false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
 int ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, void *stream) {
-    hipLaunchKernelGGL(ts_scan_tiles, dim3(grid), dim3(p->waves_per_wg * 64u), lds_bytes, (hipStream_t)stream, *p);
+    if (p->fc_byte_table)
+        hipLaunchKernelGGL(ts_scan_tiles<true>, dim3(grid), dim3(p->waves_per_wg * 64u), lds_bytes, (hipStream_t)stream, *p);
+    else
+        hipLaunchKernelGGL(ts_scan_tiles<false>, dim3(grid), dim3(p->waves_per_wg * 64u), lds_bytes, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 

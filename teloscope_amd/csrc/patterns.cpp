@@ -167,10 +167,11 @@ int base_code(char c) {
 //  * pair table: indexed by the (k+1)-mer y = bases p..p+k; entry = 2 bits {x(p) is a pattern,
 //    x(p+1) is a pattern}, 16 entries per dword (row = y >> 4), each row replicated R times so
 //    that the lanes of a ds_read_b32 group spread over the LDS banks (R = 8 / 2 / 1 for k <= 6 / 7 / 8);
-//  * flag table: 2 bits per k-mer {forward, canonical}, looked up only at matched positions.
-// Layout in `table`: [rows x R dwords][4^k / 16 dwords].
+//  * flag table: {forward, canonical} per k-mer, looked up only at matched positions: one byte
+//    per k-mer for k <= 7 (cheapest lookup), 2 bits per k-mer at k = 8 (LDS capacity).
+// Layout in `table`: [rows x R dwords][flag table].
 bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
-                       uint32_t &rows, uint32_t &replicas, uint32_t &fc_bytes) {
+                       uint32_t &rows, uint32_t &replicas, uint32_t &fc_bytes, bool &fc_byte_table) {
     if (k < 3 || k > 8) return false;
     const uint64_t nk = 1ull << (2 * k);
     std::vector<uint8_t> m(nk, 0), fl(nk, 0);
@@ -188,7 +189,8 @@ bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector
     const uint64_t npairs = nk * 4;                                   // (k+1)-mers
     rows = static_cast<uint32_t>(npairs / 16);
     replicas = k <= 6 ? 8u : (k == 7 ? 2u : 1u);
-    const size_t fc_words = static_cast<size_t>(std::max<uint64_t>(nk / 16, 4));
+    fc_byte_table = k <= 7;
+    const size_t fc_words = static_cast<size_t>(std::max<uint64_t>(fc_byte_table ? nk / 4 : nk / 16, 4));
     fc_bytes = static_cast<uint32_t>(fc_words * 4);
     table.assign(static_cast<size_t>(rows) * replicas + fc_words, 0u);
     const uint32_t kmask = static_cast<uint32_t>(nk - 1);
@@ -199,7 +201,10 @@ bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector
             table[(y >> 4) * replicas + rep] |= bits << (2 * (y & 15));
     }
     uint32_t *fc = &table[static_cast<size_t>(rows) * replicas];
-    for (uint64_t x = 0; x < nk; ++x) fc[x >> 4] |= static_cast<uint32_t>(fl[x]) << (2 * (x & 15));
+    for (uint64_t x = 0; x < nk; ++x) {
+        if (fc_byte_table) fc[x >> 2] |= static_cast<uint32_t>(fl[x]) << (8 * (x & 3));
+        else fc[x >> 4] |= static_cast<uint32_t>(fl[x]) << (2 * (x & 15));
+    }
     return true;
 }
 

@@ -39,7 +39,8 @@ struct TsScanParams {
     uint32_t        ntiles;
     uint32_t        waves_per_wg;
     uint32_t        table_rows;     // 4^(k+1) / 16
-    uint32_t        fc_bytes;       // flag table: 2 bits per k-mer, 4^k / 4 bytes (16-byte multiple)
+    uint32_t        fc_bytes;       // flag table size in bytes (16-byte multiple)
+    uint32_t        fc_byte_table;  // 1: one byte {forward, canonical} per k-mer; 0: 2 bits per k-mer
     uint32_t        row_shift;      // log2(bytes per table row) = log2(replicas * 4)
     uint32_t        rep_mask;       // replicas - 1 (replica = lane & rep_mask)
     uint32_t        k;              // pattern length
