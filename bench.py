@@ -92,11 +92,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("TS_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse N > 1 on one GPU
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import teloscope_amd as ta
     from teloscope_amd import _capi as K
@@ -105,7 +110,7 @@ def main():
 
     opts = H.parse_cli("x.fa " + FLAGS)
     ui = _user_input(opts)
-    ui.device = local_rank
+    ui.device = dev_index
     tel = ta.Teloscope(ui)
     L = K.lib()
 
@@ -123,7 +128,9 @@ def main():
     buf = torch.zeros(int(info.input_bytes), dtype=torch.uint8, device=dev)
     fill_synthetic(buf, offsets, lens, 42 + rank, dev)
     summary = torch.zeros(n * 4, dtype=torch.int64, device=dev)
-    gathered = [torch.zeros_like(summary) for _ in range(world)] if (world > 1 and rank == 0) else None
+    xdev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = [torch.zeros(n * 4, dtype=torch.int64, device=xdev) for _ in range(world)] \
+        if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream()
     sptr = C.c_void_p(stream.cuda_stream)
     dptr = C.c_void_p(buf.data_ptr())
@@ -136,7 +143,7 @@ def main():
             rc = L.ts_batch_segment_summary(batch, C.c_void_p(summary.data_ptr()), sptr)
             if rc != 0:
                 raise RuntimeError(tel._ctx.error())
-            dist.gather(summary, gathered, dst=0)
+            dist.gather(summary if backend == "nccl" else summary.cpu(), gathered, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -163,7 +170,7 @@ def main():
         raise RuntimeError(tel._ctx.error())
     L.ts_batch_get_info(batch, C.byref(info))
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())

@@ -927,21 +927,70 @@ int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
                     uint8_t *pass) {
     if (!ctx || (n_reads && (!seqs || !lens || !pass))) return TS_ERR_INVALID_ARG;
     if (!ctx->read_filter) return ctx->fail(TS_ERR_STATE, "context was not made by ts_create_read_filter");
-    std::vector<ts_segment_in> in(n_reads);
+    if (n_reads == 0) return TS_OK;
+    std::vector<uint64_t> rl(n_reads);
     for (size_t i = 0; i < n_reads; ++i) {
         uint64_t n = lens[i];
         if (n && seqs[i][n - 1] == '\r') --n;             // src/read-filter.cpp:38-40
-        in[i].seq = seqs[i];
-        in[i].len = n;
-        in[i].abs_pos = 0;
-        in[i].tips_only = 1;
+        rl[i] = n;
     }
-    std::vector<ts_segment_out> out(n_reads);
-    int rc = ts_scan_segments(ctx, in.data(), n_reads, out.data());
-    if (rc != TS_OK) return rc;
-    for (size_t i = 0; i < n_reads; ++i) pass[i] = out[i].n_terminal_blocks != 0;
-    ts_free_segments(out.data(), n_reads);
-    return TS_OK;
+    if (!ctx->fast_ok) {
+        // mixed-length pattern sets: general kernels + host block predicate
+        std::vector<ts_segment_in> in(n_reads);
+        for (size_t i = 0; i < n_reads; ++i) { in[i].seq = seqs[i]; in[i].len = rl[i]; in[i].abs_pos = 0; in[i].tips_only = 1; }
+        std::vector<ts_segment_out> out(n_reads);
+        int rc = ts_scan_segments(ctx, in.data(), n_reads, out.data());
+        if (rc != TS_OK) return rc;
+        for (size_t i = 0; i < n_reads; ++i) pass[i] = out[i].n_terminal_blocks != 0;
+        ts_free_segments(out.data(), n_reads);
+        return TS_OK;
+    }
+    // tiled path: whole-read tips scan, then the terminal-block predicate on the device; only one
+    // byte per read comes back
+    ts_batch *b = ts_batch_create(ctx, rl.data(), nullptr, n_reads, 1, 0);
+    if (!b) return ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP;
+    int rc = TS_OK;
+    for (size_t i = 0; i < n_reads && rc == TS_OK; ++i) rc = ts_batch_upload(b, i, seqs[i]);
+    if (rc == TS_OK) rc = ts_batch_scan(b, nullptr, nullptr);
+    if (rc == TS_OK) rc = ts_batch_sync(b);
+    if (rc == TS_OK) {
+        ts_ctx *c = ctx;
+        auto run = [&]() -> int {
+            const size_t ns = n_reads;
+            std::vector<uint32_t> first(ns + 1);
+            std::vector<unsigned long long> inoff(ns), slen(ns);
+            for (size_t i = 0; i < ns; ++i) { first[i] = b->segs[i].first_tile; inoff[i] = b->segs[i].in_off; slen[i] = b->segs[i].len; }
+            first[ns] = (uint32_t)b->tiles.size();
+            DevBuf d_first, d_inoff, d_len, d_pass;
+            HIP_TRY(c, d_first.ensure((ns + 1) * 4));
+            HIP_TRY(c, d_inoff.ensure(ns * 8));
+            HIP_TRY(c, d_len.ensure(ns * 8));
+            HIP_TRY(c, d_pass.ensure(ns + 16));
+            HIP_TRY(c, hipMemcpy(d_first.p, first.data(), (ns + 1) * 4, hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(d_inoff.p, inoff.data(), ns * 8, hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(d_len.p, slen.data(), ns * 8, hipMemcpyHostToDevice));
+            TsPredParams Q{};
+            Q.terminal_limit = c->params.terminal_limit;
+            Q.max_match_dist = c->params.max_match_dist;
+            Q.min_block_len = c->params.min_block_len;
+            Q.max_block_dist = c->params.max_block_dist;
+            Q.min_block_counts = c->params.min_block_counts;
+            Q.min_block_density = c->params.min_block_density;
+            Q.k = c->k;
+            int e = ts_k_launch_predicate((const TsTile *)b->d_tiles.p, (const unsigned long long *)b->d_tile_off.p,
+                                          (const uint32_t *)b->d_stats.p, (const uint32_t *)b->d_matches.p,
+                                          (const uint32_t *)d_first.p, (const unsigned long long *)d_inoff.p,
+                                          (const unsigned long long *)d_len.p, (uint32_t)ns, &Q,
+                                          (unsigned char *)d_pass.p, nullptr);
+            if (e != 0) return c->fail(TS_ERR_HIP, "predicate kernel launch failed");
+            HIP_TRY(c, hipMemcpy(pass, d_pass.p, ns, hipMemcpyDeviceToHost));
+            d_first.release(); d_inoff.release(); d_len.release(); d_pass.release();
+            return TS_OK;
+        };
+        rc = run();
+    }
+    ts_batch_destroy(b);
+    return rc;
 }
 
 }  // extern "C"

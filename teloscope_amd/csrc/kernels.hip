@@ -482,6 +482,110 @@ __global__ void ts_segment_summary(const uint32_t *tile_stats, const uint32_t *s
     out[4ull * sidx + 3] = nf;
 }
 
+// ---------------------------------------------------------------------------------------
+// ts_terminal_predicate: "does this segment have a terminal telomere block?" decided on the
+// device from the packed match stream — Teloscope::getTerminalBlocks (src/teloscope.cpp:29-176)
+// for both orientations, reduced to whether outBlocks would be non-empty.  One thread per
+// segment walks its tiles' records (ascending for the forward list, descending for the reverse
+// list) through the same two-phase state machine: chain matches <= -k apart into sub-blocks,
+// keep those with >= minBlockCounts matches, a canonical match and canonical density >= -y,
+// merge kept sub-blocks <= -d apart, pass if a merged block is >= -l long.  This is what turns
+// ReadTelomereFilter::matches (src/read-filter.cpp:37-45) into one byte per read off the device.
+struct PredState {
+    bool in_block, have_cur, pass;
+    u64 bstart, bend, prev;                 // running sub-block
+    uint32_t counts, canon, can_cov;
+    u64 cstart, clen;                       // running merged block
+};
+
+__device__ __forceinline__ void pred_close_sub(PredState &st, const TsPredParams &Q, bool from_start) {
+    const float need = Q.min_block_density * (float)(st.bend - st.bstart);
+    if (st.counts >= Q.min_block_counts && st.canon > 0u && (float)st.can_cov >= need) {
+        const u64 sstart = st.bstart, slen = (uint32_t)(st.bend - st.bstart);
+        if (!st.have_cur) {
+            st.cstart = sstart; st.clen = slen; st.have_cur = true;
+        } else {
+            const u64 gap = from_start ? sstart - (st.cstart + st.clen) : st.cstart - (sstart + slen);
+            if (gap <= Q.max_block_dist) {
+                if (from_start) st.clen = (uint32_t)((sstart + slen) - st.cstart);
+                else { st.clen = (uint32_t)((st.cstart + st.clen) - sstart); st.cstart = sstart; }
+            } else {
+                if (st.clen >= Q.min_block_len) st.pass = true;
+                st.cstart = sstart; st.clen = slen;
+            }
+        }
+    }
+    st.in_block = false;
+}
+
+// returns false when the walk must stop (a match outside the terminal zone while no chain is open)
+__device__ __forceinline__ bool pred_feed(PredState &st, const TsPredParams &Q, bool from_start, u64 pos,
+                                          bool canonical, u64 seg_len) {
+    if (st.in_block) {
+        const u64 gap = from_start ? pos - st.prev : st.prev - pos;
+        if (gap <= Q.max_match_dist) {
+            if (from_start) st.bend = pos + Q.k; else st.bstart = pos;
+            st.counts++; st.canon += canonical; st.can_cov += canonical ? Q.k : 0u;
+            st.prev = pos;
+            return true;
+        }
+        pred_close_sub(st, Q, from_start);
+    }
+    const bool in_zone = seg_len <= Q.terminal_limit ? true
+                       : (from_start ? pos < Q.terminal_limit : pos >= seg_len - Q.terminal_limit);
+    if (!in_zone) return false;
+    st.bstart = pos; st.bend = pos + Q.k; st.prev = pos;
+    st.counts = 1; st.canon = canonical; st.can_cov = canonical ? Q.k : 0u;
+    st.in_block = true;
+    return true;
+}
+
+__global__ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                                      const uint32_t *matches, const uint32_t *seg_first_tile,
+                                      const u64 *seg_in_off, const u64 *seg_len, uint32_t nseg,
+                                      const TsPredParams Q, unsigned char *pass) {
+    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= nseg) return;
+    const uint32_t t0 = seg_first_tile[si], t1 = seg_first_tile[si + 1];
+    const u64 n = seg_len[si], base = seg_in_off[si];
+    u64 total = 0, nfwd = 0;
+    for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
+    bool ok = false;
+    if (nfwd >= 2) {                                        // forward list, from the segment start
+        PredState st = {};
+        bool go = true;
+        for (uint32_t t = t0; t < t1 && go && !st.pass; ++t) {
+            const u64 rel0 = tiles[t].in_off - base;
+            const uint32_t *r = matches + tile_off[t];
+            const uint32_t cnt = tile_stats[4u * t];
+            for (uint32_t i = 0; i < cnt && go; ++i) {
+                const uint32_t rec = r[i];
+                if (rec & 2u) go = pred_feed(st, Q, true, rel0 + (rec >> 2), rec & 1u, n);
+            }
+        }
+        if (st.in_block) pred_close_sub(st, Q, true);
+        if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
+        ok = st.pass;
+    }
+    if (!ok && total - nfwd >= 2) {                         // reverse list, from the segment end
+        PredState st = {};
+        bool go = true;
+        for (uint32_t t = t1; t > t0 && go && !st.pass; --t) {
+            const u64 rel0 = tiles[t - 1].in_off - base;
+            const uint32_t *r = matches + tile_off[t - 1];
+            const uint32_t cnt = tile_stats[4u * (t - 1)];
+            for (uint32_t i = cnt; i > 0 && go; --i) {
+                const uint32_t rec = r[i - 1];
+                if (!(rec & 2u)) go = pred_feed(st, Q, false, rel0 + (rec >> 2), rec & 1u, n);
+            }
+        }
+        if (st.in_block) pred_close_sub(st, Q, false);
+        if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
+        ok = st.pass;
+    }
+    pass[si] = ok ? 1 : 0;
+}
+
 // Packs the per-wave record regions into one dense stream (used before a D2H copy).
 __global__ void ts_compact_regions(const uint32_t *regions, const uint32_t *wave_fill, const u64 *wave_dense_base,
                                    uint32_t region_cap, uint32_t nwaves, uint32_t *dense) {
@@ -518,6 +622,16 @@ int ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_ti
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(ts_segment_summary, dim3((nseg + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
                        tile_stats, seg_first_tile, seg_nwin, nseg, out);
+    return (int)hipGetLastError();
+}
+
+int ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,
+                          const uint32_t *matches, const uint32_t *seg_first_tile,
+                          const unsigned long long *seg_in_off, const unsigned long long *seg_len, uint32_t nseg,
+                          const TsPredParams *Q, unsigned char *pass, void *stream) {
+    if (nseg == 0) return 0;
+    hipLaunchKernelGGL(ts_terminal_predicate, dim3((nseg + 63u) / 64u), dim3(64), 0, (hipStream_t)stream,
+                       tiles, tile_off, tile_stats, matches, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass);
     return (int)hipGetLastError();
 }
 

@@ -56,6 +56,14 @@ struct TsScanParams {
     uint32_t        nuc_on;         // nucleotide counts wanted (-g / -e)
 };
 
+// parameters of getTerminalBlocks for the device-side predicate (kernels.hip: ts_terminal_predicate)
+struct TsPredParams {
+    uint32_t terminal_limit;
+    uint32_t max_match_dist, min_block_len, max_block_dist, min_block_counts;
+    float    min_block_density;
+    uint32_t k;                         // match length (uniform)
+};
+
 // ---- general kernels (generic.hip) ----
 struct TsGenericPatterns {
     const unsigned long long *codes;    // per length: ascending 2-bit codes (base i at bits 2i..2i+1)
@@ -88,6 +96,10 @@ int  ts_k_launch_generic_match(const unsigned char *seq, unsigned long long n, c
                                uint32_t fold, uint32_t *mask, void *stream);
 int  ts_k_launch_generic_windows(const unsigned char *seq, const uint32_t *mask, const TsGenericPatterns *G,
                                  const TsGenericGeom *Q, unsigned long long nwin, uint32_t *out, void *stream);
+int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,
+                           const uint32_t *matches, const uint32_t *seg_first_tile,
+                           const unsigned long long *seg_in_off, const unsigned long long *seg_len,
+                           uint32_t nseg, const TsPredParams *Q, unsigned char *pass, void *stream);
 int  ts_k_launch_compact(const uint32_t *regions, const uint32_t *wave_fill,
                          const unsigned long long *wave_dense_base, uint32_t region_cap,
                          uint32_t nwaves, uint32_t *dense, void *stream);

@@ -300,3 +300,39 @@ def test_batch_api_summary_and_overflow_rescan():
     assert info.algorithmic_bytes == sum(len(s) for s in seqs) + 32 * info.n_windows + 4 * total
     L.ts_free_segments(out, n)
     L.ts_batch_destroy(b)
+
+
+@pytest.mark.parametrize("cli", ["-l 42", "-x 0 -l 18 -y 0.8 -k 10 -d 10", "-c CCCTAAA -l 60 -k 20 -d 200 -y 0.6"])
+def test_read_filter_device_predicate_long_reads(cli):
+    """HiFi-like reads (1-40 kb, several tiles each) with terminal / internal telomeric tracts,
+    1 % substitutions, N's and soft-masking: pass bits from the on-device terminal-block predicate
+    must equal ReadTelomereFilter::matches as restated by the oracle, in input order."""
+    opts = H.parse_cli("--fastq-subset " + cli)
+    rng = np.random.default_rng(43)
+    unit = opts.canonical_rev
+    reads = []
+    for i in range(1500):
+        n = int(np.clip(rng.normal(15000, 8000), 50, 40000))
+        s = bytearray(seqgen.random_dna(rng, n).tobytes())
+        kind = i % 5
+        if kind in (0, 1):                                     # tract at an end / in the middle
+            ln = int(rng.integers(1, 120)) * len(unit)
+            u = unit if rng.random() < 0.5 else opts.canonical_fwd
+            t = seqgen.mutate(rng, seqgen.repeat_array(u, ln // len(u)), 0.01).tobytes()
+            at = 0 if kind == 0 else int(rng.integers(0, max(1, n - len(t))))
+            if rng.random() < 0.5 and kind == 0:
+                at = max(0, n - len(t))
+            s[at:at + len(t)] = t[:max(0, n - at)]
+        if i % 7 == 0:
+            for _ in range(3):
+                at = int(rng.integers(0, n))
+                s[at:at + int(rng.integers(1, 5))] = b"N" * 4
+        if i % 9 == 0:
+            s = bytearray(bytes(s).lower())
+        if i % 11 == 0:
+            s += b"\r"
+        reads.append(bytes(s[:40001]))
+    got = ProductReadFilter(opts).filter(reads)
+    exp = OracleReadFilter(opts).filter(reads)
+    assert got == exp
+    assert 0 < sum(got) < len(got)
