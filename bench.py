@@ -76,8 +76,84 @@ def fill_synthetic(buf, offsets, lens, seed, dev):
         buf[offsets[ci] + at:offsets[ci] + at + len(t)] = t
 
 
+def verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev):
+    """Size-independent parity properties at the full bench size, with an INDEPENDENT computation
+    in torch (rolling 2-bit k-mer code + table lookup, nothing shared with the HIP kernels):
+      * per contig: matches / canonical / forward counts == ts_batch_segment_summary;
+      * per contig: A,C,G,T totals == sum of the even-indexed windows' nucleotide counts
+        (w = 2s: the even windows tile the contig exactly).
+    Returns a dict for the bench line; raises on any mismatch."""
+    n = len(lens)
+    k = len(ui.patternInfo[0][0])
+    code_of = {"A": 0, "C": 1, "T": 2, "G": 3}
+    tbl = torch.zeros(3, 4 ** k, dtype=torch.bool)
+    for pat, fwd in ui.patternInfo:
+        x = sum(code_of[ch] << (2 * i) for i, ch in enumerate(pat))
+        tbl[0, x] = True
+        tbl[1, x] = bool(fwd)
+        tbl[2, x] = pat in (ui.canonicalFwd, ui.canonicalRev)
+    tbl = tbl.to(dev)
+    lut = torch.full((256,), 4, dtype=torch.int32)
+    for ch, c in code_of.items():
+        lut[ord(ch)] = c
+        lut[ord(ch.lower())] = c
+    lut = lut.to(dev)
+    summ = torch.zeros(n * 4, dtype=torch.int64, device=dev)
+    if L.ts_batch_segment_summary(batch, C.c_void_p(summ.data_ptr()), None) != 0:
+        raise RuntimeError(tel._ctx.error())
+    torch.cuda.synchronize()
+    summ = summ.view(n, 4).cpu().numpy()
+    info = __import__("teloscope_amd")._capi.BatchInfo()
+    L.ts_batch_get_info(batch, C.byref(info))
+    wins = torch.empty(int(info.n_windows) * 8, dtype=torch.int32, device=dev)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    wp = L.ts_batch_windows_ptr(batch)
+    assert hip.hipMemcpy(C.c_void_p(wins.data_ptr()), C.c_void_p(wp), C.c_size_t(wins.numel() * 4), 3) == 0
+    wins = wins.view(-1, 8)
+    step, window = ui.step, ui.windowSize
+    assert window == 2 * step
+    wbase = 0
+    chunk = 1 << 27
+    for ci in range(n):
+        nb, off = lens[ci], offsets[ci]
+        cnt = torch.zeros(3, dtype=torch.int64, device=dev)
+        nuc = torch.zeros(4, dtype=torch.int64, device=dev)
+        for a in range(0, nb, chunk):
+            b = min(nb, a + chunk + k - 1)
+            c = lut[buf[off + a:off + b].long()]
+            own = min(nb, a + chunk) - a
+            nuc += torch.bincount(c[:own], minlength=5)[:4]
+            m = b - a - k + 1
+            if m > 0:
+                code = torch.zeros(m, dtype=torch.int32, device=dev)
+                bad = torch.zeros(m, dtype=torch.bool, device=dev)
+                for i in range(k):
+                    ci_ = c[i:i + m]
+                    code += (ci_ & 3) << (2 * i)
+                    bad |= ci_ == 4
+                take = min(m, own)
+                code, bad = code[:take].long(), bad[:take]
+                for f in range(3):
+                    cnt[f] += (tbl[f][code] & ~bad).sum()
+            del c
+        nwin = -(-nb // step)
+        w = wins[wbase:wbase + nwin]
+        wbase += nwin
+        got_nuc = w[0::2, [0, 1, 3, 2]].sum(dim=0, dtype=torch.int64)      # records are A C G T; codes A C T G
+        assert summ[ci].tolist() == [nwin, int(cnt[0]), int(cnt[2]), int(cnt[1])], \
+            ("match counts differ on contig %d" % ci, summ[ci].tolist(), cnt.tolist())
+        assert got_nuc.tolist() == nuc.tolist(), ("nucleotide totals differ on contig %d" % ci)
+        cov = w[:, 4:8].sum(dim=0, dtype=torch.int64)                       # covered bases, each match in <= 2 windows
+        assert int(cov[0] + cov[1]) == int(cov[2] + cov[3])
+    return {"contigs_checked": n, "matches_checked": int(summ[:, 1].sum()),
+            "properties": "per-contig match/canonical/forward counts vs independent torch k-mer lookup; "
+                          "A/C/G/T totals vs even-window sums"}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--verify", action="store_true", help="untimed full-size parity properties (torch)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -223,6 +299,8 @@ def main():
                 "sample": "first %.0f Mb of the %d largest contigs of the same synthetic assembly, same flags, "
                           "scan stage only incl. block calling (oracle/teloscope_oracle.c: trie walk + carry "
                           "loop), %d windows, %d matches, %.1f s" % (took / 1e6, used, nw_t, nm_t, cpu_s)}
+        if args.verify:
+            out["verify"] = verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev)
         print(json.dumps(out))
     L.ts_batch_destroy(batch)
     if world > 1:

@@ -488,8 +488,13 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
     b->total_waves = b->grid * wpw;
     // every wave appends to its own region of the match buffer; small batches get the worst case
     // (every base a match), large ones bases/4 spread evenly, grown on overflow by ts_batch_sync
-    const uint64_t tiles_per_wave = ceil_div(std::max<size_t>(b->tiles.size(), 1), b->total_waves);
-    const uint64_t worst = tiles_per_wave * tile_bases;
+    // (worst case for wave w = the owned bases of the tiles it is dealt: t = w, w + waves, ...)
+    uint64_t worst = 256;
+    {
+        std::vector<uint64_t> per_wave(b->total_waves, 0);
+        for (size_t t = 0; t < b->tiles.size(); ++t) per_wave[t % b->total_waves] += b->tiles[t].own_len;
+        for (uint64_t v : per_wave) worst = std::max(worst, v);
+    }
     uint64_t cap = ceil_div(b->match_cap, b->total_waves);
     if (b->total_bases <= (64ull << 20) && !match_capacity) cap = worst;
     cap = std::min<uint64_t>(std::max<uint64_t>(cap, 256), worst);
@@ -883,6 +888,19 @@ static int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::v
     return rc;
 }
 
+// Stages all segments of a batch in one host buffer laid out like the device buffer and uploads
+// it with a single copy (one hipMemcpy per read would cost ~10 us each).
+static int batch_upload_all(ts_batch *b, const std::vector<const char *> &seqs) {
+    ts_ctx *c = b->ctx;
+    if (!ts_batch_input_ptr(b)) return c->fail(TS_ERR_ALLOC, "cannot allocate device input buffer");
+    std::vector<char> stage;
+    try { stage.assign(b->input_bytes, 0); } catch (...) { return c->fail(TS_ERR_ALLOC, "out of host memory"); }
+    for (size_t i = 0; i < b->segs.size(); ++i)
+        if (b->segs[i].len) std::memcpy(stage.data() + b->segs[i].in_off, seqs[i], b->segs[i].len);
+    HIP_TRY(c, hipMemcpy(b->d_in.p, stage.data(), b->input_bytes, hipMemcpyHostToDevice));
+    return TS_OK;
+}
+
 // =========================================================================== scanSegment, batched
 static int scan_group(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<size_t> &which,
                       bool tips, ts_segment_out *out) {
@@ -891,8 +909,9 @@ static int scan_group(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<
     for (size_t i = 0; i < which.size(); ++i) { lens[i] = segs[which[i]].len; abs[i] = segs[which[i]].abs_pos; }
     ts_batch *b = ts_batch_create(ctx, lens.data(), abs.data(), which.size(), tips, 0);
     if (!b) return ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP;
-    int rc = TS_OK;
-    for (size_t i = 0; i < which.size() && rc == TS_OK; ++i) rc = ts_batch_upload(b, i, segs[which[i]].seq);
+    std::vector<const char *> ptrs(which.size());
+    for (size_t i = 0; i < which.size(); ++i) ptrs[i] = segs[which[i]].seq;
+    int rc = batch_upload_all(b, ptrs);
     if (rc == TS_OK) rc = ts_batch_scan(b, nullptr, nullptr);
     if (rc == TS_OK) rc = ts_batch_sync(b);
     std::vector<ts_segment_out> tmp(which.size());
@@ -949,8 +968,7 @@ int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
     // byte per read comes back
     ts_batch *b = ts_batch_create(ctx, rl.data(), nullptr, n_reads, 1, 0);
     if (!b) return ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP;
-    int rc = TS_OK;
-    for (size_t i = 0; i < n_reads && rc == TS_OK; ++i) rc = ts_batch_upload(b, i, seqs[i]);
+    int rc = batch_upload_all(b, std::vector<const char *>(seqs, seqs + n_reads));
     if (rc == TS_OK) rc = ts_batch_scan(b, nullptr, nullptr);
     if (rc == TS_OK) rc = ts_batch_sync(b);
     if (rc == TS_OK) {

@@ -469,17 +469,32 @@ void ts_scan_tiles(const TsScanParams P) {
 // Per-segment hit summary {windows, matches, canonical, forward}: the buffer ranks gather.
 __global__ void ts_segment_summary(const uint32_t *tile_stats, const uint32_t *seg_first_tile,
                                    const uint64_t *seg_nwin, uint32_t nseg, u64 *out) {
-    const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    // one workgroup per segment (a 250 Mb contig has ~35 k tiles): strided partial sums, LDS reduce
+    __shared__ u64 part[3][256];
+    const uint32_t sidx = blockIdx.x;
     if (sidx >= nseg) return;
     const uint32_t t0 = seg_first_tile[sidx], t1 = seg_first_tile[sidx + 1];
     u64 nm = 0, nc = 0, nf = 0;
-    for (uint32_t t = t0; t < t1; ++t) {
-        nm += tile_stats[4u * t]; nc += tile_stats[4u * t + 1u]; nf += tile_stats[4u * t + 2u];
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+        const uint4 st = *(const uint4 *)&tile_stats[4ull * t];
+        nm += st.x; nc += st.y; nf += st.z;
     }
-    out[4ull * sidx + 0] = seg_nwin[sidx];
-    out[4ull * sidx + 1] = nm;
-    out[4ull * sidx + 2] = nc;
-    out[4ull * sidx + 3] = nf;
+    part[0][threadIdx.x] = nm; part[1][threadIdx.x] = nc; part[2][threadIdx.x] = nf;
+    __syncthreads();
+    for (uint32_t o = 128; o >= 1; o >>= 1) {
+        if (threadIdx.x < o) {
+            part[0][threadIdx.x] += part[0][threadIdx.x + o];
+            part[1][threadIdx.x] += part[1][threadIdx.x + o];
+            part[2][threadIdx.x] += part[2][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[4ull * sidx + 0] = seg_nwin[sidx];
+        out[4ull * sidx + 1] = part[0][0];
+        out[4ull * sidx + 2] = part[1][0];
+        out[4ull * sidx + 3] = part[2][0];
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -620,7 +635,7 @@ int ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, v
 int ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_tile, const uint64_t *seg_nwin,
                         uint32_t nseg, unsigned long long *out, void *stream) {
     if (nseg == 0) return 0;
-    hipLaunchKernelGGL(ts_segment_summary, dim3((nseg + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(ts_segment_summary, dim3(nseg), dim3(256), 0, (hipStream_t)stream,
                        tile_stats, seg_first_tile, seg_nwin, nseg, out);
     return (int)hipGetLastError();
 }

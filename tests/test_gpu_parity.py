@@ -336,3 +336,20 @@ def test_read_filter_device_predicate_long_reads(cli):
     exp = OracleReadFilter(opts).filter(reads)
     assert got == exp
     assert 0 < sum(got) < len(got)
+
+
+def test_bench_full_size_properties_small():
+    """bench.py --verify at 0.2 Gb (the same untimed check the round-end profile runs at 3 Gb):
+    per-contig match / canonical / forward counts against an independent torch k-mer lookup and
+    A/C/G/T totals against even-window sums."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gbases", "0.2", "--contigs", "12",
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--verify"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["verify"]["contigs_checked"] == 12 and out["verify"]["matches_checked"] > 1_000_000
