@@ -154,6 +154,7 @@ def verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--verify", action="store_true", help="untimed full-size parity properties (torch)")
+    ap.add_argument("--blocks", action="store_true", help="also time device block calling (untimed in value)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -301,6 +302,18 @@ def main():
                           "loop), %d windows, %d matches, %.1f s" % (took / 1e6, used, nw_t, nm_t, cpu_s)}
         if args.verify:
             out["verify"] = verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev)
+        if args.blocks:
+            seg_out = (K.SegmentOut * n)()
+            b0 = time.perf_counter()
+            rc = L.ts_batch_download_blocks(batch, seg_out)
+            bdt = time.perf_counter() - b0
+            if rc != 0:
+                raise RuntimeError(tel._ctx.error())
+            out["device_block_calling"] = {
+                "wall_ms_incl_alloc_d2h_windows": round(bdt * 1e3, 2),
+                "terminal_blocks": int(sum(seg_out[i].n_terminal_blocks for i in range(n))),
+                "interstitial_blocks": int(sum(seg_out[i].n_interstitial_blocks for i in range(n)))}
+            L.ts_free_segments(seg_out, n)
         print(json.dumps(out))
     L.ts_batch_destroy(batch)
     if world > 1:

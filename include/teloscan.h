@@ -247,6 +247,12 @@ const void *ts_batch_matches_ptr(const ts_batch *b);
 /* D2H + host post-processing (absolute positions, terminal flags, block calling):
  * fills out[0..n_segments). Free with ts_free_segments(). */
 int       ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out *out);
+/* Block calling ON THE DEVICE (getTerminalBlocks / getInterstitialBlocks, src/teloscope.cpp:29-256)
+ * from the resident match stream, for a synced batch: fills out[i].terminal_blocks /
+ * interstitial_blocks (and windows for a full scan) exactly as ts_batch_download would, but
+ * leaves out[i].matches empty — only the blocks (a few per segment) cross PCIe.  Free with
+ * ts_free_segments(). */
+int       ts_batch_download_blocks(ts_batch *b, ts_segment_out *out);
 /* Per-segment summary (n_windows, n_matches, n_canonical, n_forward as 4 x uint64 per
  * segment) written to a device buffer of 32*n_segments bytes: the "hit buffer" ranks
  * gather over RCCL. */

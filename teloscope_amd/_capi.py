@@ -87,7 +87,7 @@ SYMBOLS = [
     "ts_label_terminal_blocks", "ts_gc_content", "ts_shannon_entropy", "ts_batch_create",
     "ts_batch_destroy", "ts_batch_segment_offset", "ts_batch_input_ptr", "ts_batch_upload",
     "ts_batch_scan", "ts_batch_sync", "ts_batch_get_info", "ts_batch_windows_ptr",
-    "ts_batch_matches_ptr", "ts_batch_download", "ts_batch_segment_summary",
+    "ts_batch_matches_ptr", "ts_batch_download", "ts_batch_download_blocks", "ts_batch_segment_summary",
 ]
 
 
@@ -157,6 +157,7 @@ def lib():
     L.ts_batch_matches_ptr.restype = C.c_void_p
     L.ts_batch_matches_ptr.argtypes = [C.c_void_p]
     L.ts_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SegmentOut)]
+    L.ts_batch_download_blocks.argtypes = [C.c_void_p, C.POINTER(SegmentOut)]
     L.ts_batch_segment_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L

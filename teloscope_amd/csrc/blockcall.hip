@@ -1,0 +1,248 @@
+// blockcall.hip — telomere block calling on the device, from the packed match stream (gfx950).
+//
+// Device form of Teloscope::getTerminalBlocks (src/teloscope.cpp:29-176) and
+// getInterstitialBlocks (:179-256), the O(matches) step that follows the scan inside
+// scanSegment (:642-657).  With it only blocks (a few per segment) have to leave the GPU instead
+// of the whole match stream.
+//
+//   ts_terminal_blocks      one thread per segment: the reference's two-phase walk (chain matches
+//                           <= -k apart inside the terminal zone, keep dense canonical sub-blocks,
+//                           merge sub-blocks <= -d apart, keep >= -l) over the forward list from
+//                           the start and the reverse list from the end; emits the blocks and the
+//                           two boundaries that fence the interstitial search.
+//   ts_interstitial_blocks  one thread per match record, sparse: an interstitial block needs >= 4
+//                           canonical matches, and canonical matches are ~2 % of the stream, so
+//                           only the FIRST canonical match of a chain ("leader") walks its chain
+//                           (matches <= -k apart inside [fwdBoundary, revBoundary)) and evaluates
+//                           the reference's filters; every other thread returns after a few loads.
+//
+// Records are addressed through the tile directory {tile_off, tile_stats}; tiles of one segment
+// are consecutive and position-ordered, so prev/next step across tile boundaries.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ts_internal.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+struct Cursor { uint32_t t, i; };            // record i of tile t
+
+struct SegView {
+    const TsTile *tiles;
+    const u64 *tile_off;
+    const uint32_t *tile_stats;
+    const uint32_t *matches;
+    uint32_t t0, t1;                         // tiles of the segment
+    u64 base;                                // in_off of the segment
+
+    __device__ uint32_t count(uint32_t t) const { return tile_stats[4u * t]; }
+    __device__ uint32_t rec(Cursor c) const { return matches[tile_off[c.t] + c.i]; }
+    __device__ u64 pos(Cursor c, uint32_t r) const { return tiles[c.t].in_off - base + (r >> 2); }
+    __device__ bool next(Cursor &c) const {
+        if (c.i + 1u < count(c.t)) { ++c.i; return true; }
+        for (uint32_t t = c.t + 1u; t < t1; ++t)
+            if (count(t)) { c.t = t; c.i = 0; return true; }
+        return false;
+    }
+    __device__ bool prev(Cursor &c) const {
+        if (c.i > 0u) { --c.i; return true; }
+        for (uint32_t t = c.t; t > t0; --t)
+            if (count(t - 1u)) { c.t = t - 1u; c.i = count(t - 1u) - 1u; return true; }
+        return false;
+    }
+    __device__ bool first(Cursor &c) const {
+        for (uint32_t t = t0; t < t1; ++t)
+            if (count(t)) { c.t = t; c.i = 0; return true; }
+        return false;
+    }
+    __device__ bool last(Cursor &c) const {
+        for (uint32_t t = t1; t > t0; --t)
+            if (count(t - 1u)) { c.t = t - 1u; c.i = count(t - 1u) - 1u; return true; }
+        return false;
+    }
+};
+
+struct Chain {                               // running chain of matches (startNewBlock / extend)
+    u64 start, end, prev;
+    uint32_t counts, fwd, canon, cov, fwd_cov, can_cov;
+    __device__ void begin(u64 p, uint32_t r, uint32_t k) {
+        start = p; end = p + k; prev = p; counts = 1;
+        fwd = (r >> 1) & 1u; canon = r & 1u; cov = k; fwd_cov = fwd * k; can_cov = canon * k;
+    }
+    __device__ void add(u64 p, uint32_t r, uint32_t k) {
+        ++counts; const uint32_t f = (r >> 1) & 1u, c = r & 1u;
+        fwd += f; canon += c; cov += k; fwd_cov += f * k; can_cov += c * k; prev = p;
+    }
+    __device__ void to_block(TsDevBlock &b) const {
+        b.start = start; b.block_len = (uint32_t)(end - start); b.block_counts = counts;
+        b.forward_count = fwd; b.reverse_count = counts - fwd; b.canonical_count = canon;
+        b.non_canonical_count = counts - canon; b.total_covered = cov; b.fwd_covered = fwd_cov;
+        b.can_covered = can_cov; b.has_valid_or = 1; b.is_longest = 0; b.block_label = 0; b.reserved = 0;
+    }
+};
+
+__device__ void emit_block(const TsBlockCallParams &Q, TsDevBlock &b, uint32_t seg, uint32_t kind, uint32_t seq,
+                           u64 abs_pos) {
+    const uint32_t slot = atomicAdd(Q.n_blocks, 1u);
+    if (slot >= Q.block_cap) return;                       // overflow: the host sees n_blocks > cap
+    b.start += abs_pos;
+    b.seg = seg; b.kind = kind; b.seq = seq; b.pad = 0;
+    Q.blocks[slot] = b;
+}
+
+// one direction of getTerminalBlocks for one segment; returns the boundary
+__device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, uint32_t seg, u64 n, u64 abs_pos,
+                                  bool from_start, uint32_t &seq) {
+    u64 boundary = from_start ? 0 : n;                     // segment-relative
+    Cursor c;
+    if (!(from_start ? V.first(c) : V.last(c))) return boundary;
+    Chain ch; bool open = false;
+    TsDevBlock cur; bool have_cur = false;
+    auto close_block = [&]() {
+        if (cur.block_len >= Q.min_block_len) {
+            cur.block_label = from_start ? 'p' : 'q';
+            const u64 rel_start = cur.start, rel_end = rel_start + cur.block_len;
+            const u64 left = rel_start, right = rel_end <= n ? n - rel_end : 0;
+            cur.has_valid_or = from_start ? (left <= right) : (left >= right);
+            boundary = from_start ? cur.start + cur.block_len : cur.start;
+            TsDevBlock out = cur;
+            emit_block(Q, out, seg, from_start ? 0u : 1u, seq++, abs_pos);
+        }
+    };
+    auto close_sub = [&]() {
+        const float need = Q.min_block_density * (float)(ch.end - ch.start);
+        if (ch.counts >= Q.min_block_counts && ch.canon > 0u && (float)ch.can_cov >= need) {
+            TsDevBlock sb; ch.to_block(sb);
+            if (!have_cur) { cur = sb; have_cur = true; }
+            else {
+                const u64 gap = from_start ? sb.start - (cur.start + cur.block_len)
+                                           : cur.start - (sb.start + sb.block_len);
+                if (gap <= Q.max_block_dist) {
+                    if (from_start) cur.block_len = (uint32_t)((sb.start + sb.block_len) - cur.start);
+                    else { cur.block_len = (uint32_t)((cur.start + cur.block_len) - sb.start); cur.start = sb.start; }
+                    cur.block_counts += sb.block_counts; cur.forward_count += sb.forward_count;
+                    cur.reverse_count += sb.reverse_count; cur.canonical_count += sb.canonical_count;
+                    cur.non_canonical_count += sb.non_canonical_count; cur.total_covered += sb.total_covered;
+                    cur.fwd_covered += sb.fwd_covered; cur.can_covered += sb.can_covered;
+                } else { close_block(); cur = sb; }
+            }
+        }
+        open = false;
+    };
+    bool more = true;
+    while (more) {
+        const uint32_t r = V.rec(c);
+        if ((((r >> 1) & 1u) != 0u) == from_start) {      // forward list from the start, reverse from the end
+            const u64 p = V.pos(c, r);
+            bool handled = false;
+            if (open) {
+                const u64 gap = from_start ? p - ch.prev : ch.prev - p;
+                if (gap <= Q.max_match_dist) {
+                    if (from_start) ch.end = p + Q.k; else ch.start = p;
+                    ch.add(p, r, Q.k);
+                    handled = true;
+                } else close_sub();
+            }
+            if (!handled) {
+                const bool in_zone = n <= Q.terminal_limit ? true
+                                   : (from_start ? p < Q.terminal_limit : p >= n - Q.terminal_limit);
+                if (!in_zone) break;
+                ch.begin(p, r, Q.k); open = true;
+            }
+        }
+        more = from_start ? V.next(c) : V.prev(c);
+    }
+    if (open) close_sub();
+    if (have_cur) close_block();
+    return boundary;
+}
+
+__global__ void ts_terminal_blocks(const TsBlockCallParams Q, const uint32_t *seg_first_tile, const u64 *seg_in_off,
+                                   const u64 *seg_len, const u64 *seg_abs, uint32_t nseg, u64 *bounds) {
+    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= nseg) return;
+    SegView V{Q.tiles, Q.tile_off, Q.tile_stats, Q.matches, seg_first_tile[si], seg_first_tile[si + 1], seg_in_off[si]};
+    const u64 n = seg_len[si];
+    u64 total = 0, nfwd = 0;
+    for (uint32_t t = V.t0; t < V.t1; ++t) { total += V.tile_stats[4u * t]; nfwd += V.tile_stats[4u * t + 2u]; }
+    uint32_t seq = 0;
+    u64 fb = 0, rb = n;
+    if (nfwd >= 2) fb = terminal_direction(Q, V, si, n, seg_abs[si], true, seq);
+    if (total - nfwd >= 2) rb = terminal_direction(Q, V, si, n, seg_abs[si], false, seq);
+    bounds[2ull * si] = fb;
+    bounds[2ull * si + 1] = (total >= 2 && fb < rb) ? rb : 0;   // rb = 0 disables the interstitial search
+}
+
+// computeBlockLabel, include/teloscope.h:217-222
+__device__ char its_label(uint32_t fwd_count, uint32_t counts) {
+    const float ratio = ((float)fwd_count * 100.0f) / (float)counts;
+    if (ratio > 66.6f) return 'p';
+    if (ratio < 33.3f) return 'q';
+    return 'b';
+}
+
+__global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t *seg_first_tile,
+                                       const u64 *seg_in_off, const u64 *seg_abs, const u64 *bounds,
+                                       uint32_t ntiles) {
+    // one wave per tile, lanes over its records
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t si = Q.tiles[tile].seg;
+    const u64 fb = bounds[2ull * si], rb = bounds[2ull * si + 1];
+    if (rb == 0) return;
+    SegView V{Q.tiles, Q.tile_off, Q.tile_stats, Q.matches, seg_first_tile[si], seg_first_tile[si + 1], seg_in_off[si]};
+    const uint32_t cnt = V.count(tile);
+    for (uint32_t i = lane; i < cnt; i += 64u) {
+        Cursor c{tile, i};
+        const uint32_t r = V.rec(c);
+        if (!(r & 1u)) continue;                           // only canonical matches can lead a block
+        const u64 p = V.pos(c, r);
+        if (p < fb || p >= rb) continue;
+        // walk left: not the leader if an earlier canonical match is in the same chain
+        Cursor s = c; u64 sp = p; bool leader = true;
+        for (Cursor q = c;;) {
+            if (!V.prev(q)) break;
+            const uint32_t rq = V.rec(q);
+            const u64 pq = V.pos(q, rq);
+            if (pq < fb || sp - pq > Q.max_match_dist) break;
+            if (rq & 1u) { leader = false; break; }
+            s = q; sp = pq;
+        }
+        if (!leader) continue;
+        // s is the chain's first match: walk the whole chain
+        Chain ch;
+        ch.begin(sp, V.rec(s), Q.k);
+        for (Cursor q = s; V.next(q);) {
+            const uint32_t rq = V.rec(q);
+            const u64 pq = V.pos(q, rq);
+            if (pq >= rb || pq - ch.prev > Q.max_match_dist) break;
+            ch.end = pq + Q.k;
+            ch.add(pq, rq, Q.k);
+        }
+        const uint32_t blen = (uint32_t)(ch.end - ch.start);
+        const char lab = its_label(ch.fwd, ch.counts);
+        if (blen >= Q.its_min_len && ch.canon >= 4u && !(lab == 'b' && ch.fwd < 2u && (ch.counts - ch.fwd) < 2u)) {
+            TsDevBlock b; ch.to_block(b);
+            b.block_label = lab;
+            emit_block(Q, b, si, 2u, 0u, seg_abs[si]);
+        }
+    }
+}
+
+}  // namespace
+
+int ts_k_launch_block_call(const TsBlockCallParams *Q, const uint32_t *seg_first_tile,
+                           const unsigned long long *seg_in_off, const unsigned long long *seg_len,
+                           const unsigned long long *seg_abs, uint32_t nseg, uint32_t ntiles,
+                           unsigned long long *bounds, int with_its, void *stream) {
+    if (nseg == 0) return 0;
+    hipLaunchKernelGGL(ts_terminal_blocks, dim3((nseg + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, *Q,
+                       seg_first_tile, seg_in_off, seg_len, seg_abs, nseg, bounds);
+    if (with_its && ntiles)
+        hipLaunchKernelGGL(ts_interstitial_blocks, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *Q,
+                           seg_first_tile, seg_in_off, seg_abs, bounds, ntiles);
+    return (int)hipGetLastError();
+}

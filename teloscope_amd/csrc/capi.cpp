@@ -778,6 +778,105 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
     return TS_OK;
 }
 
+// --------------------------------------------------------------- device block calling (row f1)
+int ts_batch_download_blocks(ts_batch *b, ts_segment_out *out) {
+    if (!b || !out) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    if (!b->synced) { int rc = ts_batch_sync(b); if (rc != TS_OK) return rc; }
+    const ts_params &P = c->params;
+    const size_t ns = b->segs.size(), nt = b->tiles.size();
+    for (size_t i = 0; i < ns; ++i) std::memset(&out[i], 0, sizeof out[i]);
+    if (ns == 0) return TS_OK;
+
+    std::vector<uint32_t> first(ns + 1);
+    std::vector<unsigned long long> inoff(ns), slen(ns), sabs(ns);
+    for (size_t i = 0; i < ns; ++i) {
+        first[i] = b->segs[i].first_tile; inoff[i] = b->segs[i].in_off;
+        slen[i] = b->segs[i].len; sabs[i] = b->segs[i].abs_pos;
+    }
+    first[ns] = (uint32_t)nt;
+    DevBuf d_first, d_inoff, d_len, d_abs, d_bounds, d_blocks, d_count;
+    auto release = [&]() { d_first.release(); d_inoff.release(); d_len.release(); d_abs.release();
+                           d_bounds.release(); d_blocks.release(); d_count.release(); };
+    std::vector<TsDevBlock> blocks;
+    uint32_t cap = (uint32_t)std::min<uint64_t>(64ull * ns + 4096 + b->n_matches / 256, 1u << 26);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (d_first.ensure((ns + 1) * 4) != hipSuccess || d_inoff.ensure(ns * 8) != hipSuccess ||
+            d_len.ensure(ns * 8) != hipSuccess || d_abs.ensure(ns * 8) != hipSuccess ||
+            d_bounds.ensure(ns * 16) != hipSuccess || d_blocks.ensure((size_t)cap * sizeof(TsDevBlock)) != hipSuccess ||
+            d_count.ensure(16) != hipSuccess) { release(); return c->fail(TS_ERR_ALLOC, "device allocation failed"); }
+        if (hipMemcpy(d_first.p, first.data(), (ns + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_inoff.p, inoff.data(), ns * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_len.p, slen.data(), ns * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_abs.p, sabs.data(), ns * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(d_count.p, 0, 16) != hipSuccess) { release(); return c->fail(TS_ERR_HIP, "H2D copy failed"); }
+        TsBlockCallParams Q{};
+        Q.tiles = (const TsTile *)b->d_tiles.p;
+        Q.tile_off = (const unsigned long long *)b->d_tile_off.p;
+        Q.tile_stats = (const uint32_t *)b->d_stats.p;
+        Q.matches = (const uint32_t *)b->d_matches.p;
+        Q.blocks = (TsDevBlock *)d_blocks.p;
+        Q.n_blocks = (uint32_t *)d_count.p;
+        Q.block_cap = cap;
+        Q.terminal_limit = P.terminal_limit; Q.max_match_dist = P.max_match_dist;
+        Q.min_block_len = P.min_block_len; Q.max_block_dist = P.max_block_dist;
+        Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;
+        Q.k = c->k; Q.its_min_len = (uint32_t)(uint16_t)(2 * c->bp.first_pattern_len);
+        if (ts_k_launch_block_call(&Q, (const uint32_t *)d_first.p, (const unsigned long long *)d_inoff.p,
+                                   (const unsigned long long *)d_len.p, (const unsigned long long *)d_abs.p,
+                                   (uint32_t)ns, (uint32_t)nt, (unsigned long long *)d_bounds.p, b->tips ? 0 : 1,
+                                   nullptr) != 0) { release(); return c->fail(TS_ERR_HIP, "block-calling kernel launch failed"); }
+        uint32_t nb = 0;
+        if (hipMemcpy(&nb, d_count.p, 4, hipMemcpyDeviceToHost) != hipSuccess) { release(); return c->fail(TS_ERR_HIP, "D2H copy failed"); }
+        if (nb > cap) { cap = nb + 1024; continue; }            // rare: more blocks than provisioned, rerun
+        blocks.resize(nb);
+        if (nb && hipMemcpy(blocks.data(), d_blocks.p, (size_t)nb * sizeof(TsDevBlock), hipMemcpyDeviceToHost) != hipSuccess) {
+            release(); return c->fail(TS_ERR_HIP, "D2H copy failed");
+        }
+        break;
+    }
+    release();
+
+    // order: terminal blocks in push order (forward walk, then reverse walk); interstitial by start
+    std::sort(blocks.begin(), blocks.end(), [](const TsDevBlock &x, const TsDevBlock &y) {
+        if (x.seg != y.seg) return x.seg < y.seg;
+        const uint32_t kx = x.kind == 2 ? 1 : 0, ky = y.kind == 2 ? 1 : 0;
+        if (kx != ky) return kx < ky;
+        return kx ? x.start < y.start : x.seq < y.seq;
+    });
+    std::vector<uint32_t> wins;
+    if (!b->tips && b->n_windows) {
+        wins.resize(b->n_windows * 8);
+        HIP_TRY(c, hipMemcpy(wins.data(), b->d_windows.p, b->n_windows * 32, hipMemcpyDeviceToHost));
+    }
+    size_t bi = 0;
+    std::vector<ts_match> none;
+    for (size_t si = 0; si < ns; ++si) {
+        const SegPlan &sp = b->segs[si];
+        int rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos, sp.n_windows ? &wins[sp.win_base * 8] : nullptr,
+                                  b->tips ? 0 : sp.n_windows, none, out[si]);       // windows only
+        if (rc != TS_OK) return rc;
+        std::vector<ts_block> term, its;
+        for (; bi < blocks.size() && blocks[bi].seg == si; ++bi) {
+            ts_block t{};
+            std::memcpy(&t, &blocks[bi], sizeof(ts_block));
+            (blocks[bi].kind == 2 ? its : term).push_back(t);
+        }
+        auto put = [&](const std::vector<ts_block> &v, ts_block *&dst, uint64_t &n) -> bool {
+            n = v.size(); dst = nullptr;
+            if (v.empty()) return true;
+            dst = (ts_block *)std::malloc(v.size() * sizeof(ts_block));
+            if (!dst) return false;
+            std::memcpy(dst, v.data(), v.size() * sizeof(ts_block));
+            return true;
+        };
+        if (!put(term, out[si].terminal_blocks, out[si].n_terminal_blocks) ||
+            !put(its, out[si].interstitial_blocks, out[si].n_interstitial_blocks))
+            return c->fail(TS_ERR_ALLOC, "out of host memory");
+    }
+    return TS_OK;
+}
+
 void ts_free_segments(ts_segment_out *out, size_t n_segs) {
     if (!out) return;
     for (size_t i = 0; i < n_segs; ++i) {

@@ -64,6 +64,34 @@ struct TsPredParams {
     uint32_t k;                         // match length (uniform)
 };
 
+// ---- device block calling (blockcall.hip) ----
+struct TsDevBlock {                     // ts_block (include/teloscan.h) + bookkeeping, 64 bytes
+    unsigned long long start;
+    uint32_t block_len, block_counts, forward_count, reverse_count, canonical_count, non_canonical_count;
+    uint32_t total_covered, fwd_covered, can_covered;
+    uint8_t  has_valid_or, is_longest;
+    char     block_label;
+    uint8_t  reserved;
+    uint32_t seg;                       // segment index
+    uint32_t kind;                      // 0/1 terminal (forward / reverse walk), 2 interstitial
+    uint32_t seq;                       // push order among the segment's terminal blocks
+    uint32_t pad;
+};
+
+struct TsBlockCallParams {
+    const TsTile *tiles;
+    const unsigned long long *tile_off;
+    const uint32_t *tile_stats;
+    const uint32_t *matches;
+    TsDevBlock *blocks;
+    uint32_t *n_blocks;                 // atomic counter; > block_cap means overflow
+    uint32_t block_cap;
+    uint32_t terminal_limit, max_match_dist, min_block_len, max_block_dist, min_block_counts;
+    float    min_block_density;
+    uint32_t k;                         // match length (uniform)
+    uint32_t its_min_len;               // 2 * patterns.front().size()
+};
+
 // ---- general kernels (generic.hip) ----
 struct TsGenericPatterns {
     const unsigned long long *codes;    // per length: ascending 2-bit codes (base i at bits 2i..2i+1)
@@ -100,6 +128,10 @@ int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_o
                            const uint32_t *matches, const uint32_t *seg_first_tile,
                            const unsigned long long *seg_in_off, const unsigned long long *seg_len,
                            uint32_t nseg, const TsPredParams *Q, unsigned char *pass, void *stream);
+int  ts_k_launch_block_call(const TsBlockCallParams *Q, const uint32_t *seg_first_tile,
+                            const unsigned long long *seg_in_off, const unsigned long long *seg_len,
+                            const unsigned long long *seg_abs, uint32_t nseg, uint32_t ntiles,
+                            unsigned long long *bounds, int with_its, void *stream);
 int  ts_k_launch_compact(const uint32_t *regions, const uint32_t *wave_fill,
                          const unsigned long long *wave_dense_base, uint32_t region_cap,
                          uint32_t nwaves, uint32_t *dense, void *stream);

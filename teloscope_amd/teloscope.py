@@ -178,6 +178,37 @@ class Teloscope:
         K.lib().ts_free_segments(out, n)
         return res
 
+    def scanSegmentsBlocksOnly(self, segments, tipsOnly=False):
+        """Device-resident variant: scan + block calling ON THE DEVICE (ts_batch_download_blocks);
+        returns SegmentData whose match vectors are empty (windows and blocks only).
+        segments = [(sequence, absPos)], all full-scan or all tips-only."""
+        n = len(segments)
+        seqs = [s.encode() if isinstance(s, str) else bytes(s) for s, _ in segments]
+        lens = (C.c_uint64 * max(1, n))(*[len(s) for s in seqs])
+        absp = (C.c_uint64 * max(1, n))(*[int(a) for _, a in segments])
+        L = K.lib()
+        b = L.ts_batch_create(self._ctx.ptr, lens, absp, n, int(bool(tipsOnly)), 0)
+        if not b:
+            raise K.TeloscanError(K.TS_ERR_UNSUPPORTED, self._ctx.error())
+        try:
+            for i, s in enumerate(seqs):
+                rc = L.ts_batch_upload(b, i, s)
+                if rc != K.TS_OK:
+                    raise K.TeloscanError(rc, self._ctx.error())
+            for fn in (lambda: L.ts_batch_scan(b, None, None), lambda: L.ts_batch_sync(b)):
+                rc = fn()
+                if rc != K.TS_OK:
+                    raise K.TeloscanError(rc, self._ctx.error())
+            out = (K.SegmentOut * max(1, n))()
+            rc = L.ts_batch_download_blocks(b, out)
+            if rc != K.TS_OK:
+                raise K.TeloscanError(rc, self._ctx.error())
+            res = [SegmentData(out[i], bool(tipsOnly)) for i in range(n)]
+            L.ts_free_segments(out, n)
+            return res
+        finally:
+            L.ts_batch_destroy(b)
+
     def scanSegment(self, sequence, absPos=0, tipsOnly=False):
         """SegmentData Teloscope::scanSegment(std::string&, uint64_t absPos, bool tipsOnly)."""
         return self.scanSegments([(sequence, absPos, tipsOnly)])[0]

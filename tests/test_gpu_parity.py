@@ -353,3 +353,41 @@ def test_bench_full_size_properties_small():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["verify"]["contigs_checked"] == 12 and out["verify"]["matches_checked"] > 1_000_000
+
+
+BLOCKCALL_GRID = ["-r -g -e -m -i", "-w 1000 -s 500 -r -g -e -m -i",
+                  "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -m -i",
+                  "-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i", "-x 2 -w 1000 -s 500 -r -i -k 20 -d 100",
+                  "-w 1000 -s 500 -i -t 700 -l 60 -k 10 -d 30 -y 0.8", "", "-t 300", "-t 1000 -l 60 -k 10 -d 30 -y 0.8"]
+
+
+@pytest.mark.parametrize("cli", BLOCKCALL_GRID)
+def test_device_block_calling_matches_oracle(cli):
+    """getTerminalBlocks / getInterstitialBlocks on the device (ts_batch_download_blocks): blocks
+    and windows equal the oracle's, with no match record leaving the GPU."""
+    from tests.backends import BLOCK_FIELDS, WINDOW_FIELDS
+    opts = H.parse_cli("x.fa " + cli)
+    prod, orac = ProductBackend(opts), OracleBackend(opts)
+    rng = np.random.default_rng(len(cli) * 131 + 5)
+    segs = []
+    for i, n in enumerate([7, 600, 1999, 8000, 8001, 16500, 70001, 250003, 1_000_000]):
+        s = seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev,
+                              telo_repeats=min(400, max(1, n // 30)), tvr_rate=0.04, n_its=8,
+                              iupac=(n // 5000) * (i % 2))
+        if i % 3 == 0 and n > 3000:                          # an inverted telomere and a mid-contig tract
+            s = s[:n // 2] + seqgen.repeat_array(opts.canonical_fwd, 40).tobytes() + s[n // 2 + 240:]
+        segs.append((s, int(rng.integers(0, 10 ** 6))))
+    got = prod.teloscope.scanSegmentsBlocksOnly(segs, tipsOnly=opts.ultra_fast)
+    n_its = 0
+    for (s, ap), g in zip(segs, got):
+        e = orac.scan_segment(s, ap, opts.ultra_fast)
+        for name, gb in (("terminal_blocks", g.terminalBlocks), ("interstitial_blocks", g.interstitialBlocks)):
+            assert len(gb) == len(e[name]), "%s %s count len=%d" % (cli, name, len(s))
+            for f in BLOCK_FIELDS:
+                assert np.array_equal(gb[f], e[name][f]), "%s %s.%s len=%d" % (cli, name, f, len(s))
+        for f in WINDOW_FIELDS:
+            assert np.array_equal(g.windows[f], e["windows"][f])
+        assert len(g.allMatches) == 0
+        n_its += len(e["interstitial_blocks"])
+    if not opts.ultra_fast:
+        assert n_its > 0
