@@ -161,12 +161,17 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
 
 __global__ void ts_terminal_blocks(const TsBlockCallParams Q, const uint32_t *seg_first_tile, const u64 *seg_in_off,
                                    const u64 *seg_len, const u64 *seg_abs, uint32_t nseg, u64 *bounds) {
-    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per segment: the lanes add up the segment's tile counts (a 250 Mb contig has ~35 k
+    // tiles), lane 0 then walks the two ends
+    const uint32_t si = blockIdx.x;
     if (si >= nseg) return;
+    const uint32_t lane = threadIdx.x & 63u;
     SegView V{Q.tiles, Q.tile_off, Q.tile_stats, Q.matches, seg_first_tile[si], seg_first_tile[si + 1], seg_in_off[si]};
     const u64 n = seg_len[si];
     u64 total = 0, nfwd = 0;
-    for (uint32_t t = V.t0; t < V.t1; ++t) { total += V.tile_stats[4u * t]; nfwd += V.tile_stats[4u * t + 2u]; }
+    for (uint32_t t = V.t0 + lane; t < V.t1; t += 64u) { total += V.tile_stats[4u * t]; nfwd += V.tile_stats[4u * t + 2u]; }
+    for (int o = 32; o >= 1; o >>= 1) { total += __shfl_xor(total, o); nfwd += __shfl_xor(nfwd, o); }
+    if (lane != 0) return;
     uint32_t seq = 0;
     u64 fb = 0, rb = n;
     if (nfwd >= 2) fb = terminal_direction(Q, V, si, n, seg_abs[si], true, seq);
@@ -239,7 +244,7 @@ int ts_k_launch_block_call(const TsBlockCallParams *Q, const uint32_t *seg_first
                            const unsigned long long *seg_abs, uint32_t nseg, uint32_t ntiles,
                            unsigned long long *bounds, int with_its, void *stream) {
     if (nseg == 0) return 0;
-    hipLaunchKernelGGL(ts_terminal_blocks, dim3((nseg + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, *Q,
+    hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(64), 0, (hipStream_t)stream, *Q,
                        seg_first_tile, seg_in_off, seg_len, seg_abs, nseg, bounds);
     if (with_its && ntiles)
         hipLaunchKernelGGL(ts_interstitial_blocks, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *Q,
