@@ -546,6 +546,7 @@ int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
     if (!b) return TS_ERR_INVALID_ARG;
     ts_ctx *c = b->ctx;
     std::lock_guard<std::mutex> lk(c->mtx);
+    HIP_TRY(c, hipSetDevice(c->device));
     if (!d_input) d_input = ts_batch_input_ptr(b);
     if (!d_input) return c->fail(TS_ERR_ALLOC, "no device input buffer");
     hipStream_t st = (hipStream_t)stream;
@@ -580,6 +581,7 @@ int ts_batch_sync(ts_batch *b) {
     if (!b) return TS_ERR_INVALID_ARG;
     ts_ctx *c = b->ctx;
     if (!b->scanned) return c->fail(TS_ERR_STATE, "ts_batch_sync before ts_batch_scan");
+    HIP_TRY(c, hipSetDevice(c->device));
     for (int attempt = 0; attempt < 3; ++attempt) {
         HIP_TRY(c, hipEventSynchronize(b->ev1));
         float ms = 0.f;

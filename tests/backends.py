@@ -6,11 +6,15 @@ import numpy as np
 class OracleBackend:
     """oracle/teloscope_oracle.c through ctypes (the checker)."""
 
-    def __init__(self, opts):
+    def __init__(self, opts, patterns=None):
+        """patterns: optional explicit [(seq, is_forward, is_canonical)] (what the Teloscope ctor is
+        given); default = the oracle's own expandPatternsWithOrientation."""
         from oracle import pyoracle as po
         self.po = po
         self.opts = opts
-        self.patterns = po.expand_patterns(opts.raw_patterns, opts.edit_distance, opts.canonical_fwd)
+        self.patterns = patterns if patterns is not None else \
+            po.expand_patterns(opts.raw_patterns, opts.edit_distance, opts.canonical_fwd)
+        self.ambiguous = any(len(p) > 3 and p[3] for p in self.patterns)
         self.oracle = po.Oracle(opts.params(), self.patterns)
 
     def scan_segment(self, seq, abs_pos, tips_only):

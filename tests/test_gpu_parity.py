@@ -391,3 +391,44 @@ def test_device_block_calling_matches_oracle(cli):
         n_its += len(e["interstitial_blocks"])
     if not opts.ultra_fast:
         assert n_its > 0
+
+
+def test_fuzz_parameters_and_degenerate_segments():
+    """Seeded fuzz over the parameter space (canonical motif, edit distance, window/step, block
+    thresholds, scan mode) with degenerate segments mixed in (empty, shorter than k, all N, all one
+    base, IUPAC only, lower case only): whichever device path the library picks must equal the oracle."""
+    rng = np.random.default_rng(2024)
+    motifs = ["TTAGGG", "TTAGG", "CCCTAAA", "TTTTAGGG", "TTAGGGG", "TCAGG"]
+    for it in range(16):
+        c = motifs[int(rng.integers(0, len(motifs)))]
+        w = int(rng.choice([len(c), 17, 64, 100, 333, 1000, 2000, 5000]))
+        s = int(rng.integers(max(1, w // 40), w + 1)) if rng.random() < 0.5 else w
+        tips = rng.random() < 0.25
+        cli = "-c %s -x %d -w %d -s %d -t %d -k %d -d %d -l %d -y %.2f" % (
+            c, int(rng.integers(0, 3)), w, s, int(rng.choice([50, 300, 5000, 50000])),
+            int(rng.choice([5, 20, 50])), int(rng.choice([10, 100, 500])), int(rng.choice([12, 60, 300])),
+            float(rng.choice([0.3, 0.5, 0.9])))
+        if not tips:
+            cli += " " + " ".join(rng.choice(["-r", "-g", "-e", "-m", "-i"], size=3, replace=False)) + " -g"
+        opts = H.parse_cli("x.fa " + cli)
+        if len(c) > w:
+            continue
+        prod, orac = ProductBackend(opts), OracleBackend(opts)
+        if orac.ambiguous:
+            # the same k-mer is reachable from both orientations (e.g. k = 5, -x 2): the reference's
+            # flag then depends on std::sort's order among equal keys (DESIGN.md §2); give the oracle
+            # the pattern list the product built so that the scan itself is what is compared
+            assert [p for p, _, _ in prod.patterns] == [p for p, _, _, _ in orac.patterns]
+            orac = OracleBackend(opts, patterns=prod.patterns)
+        else:
+            assert [(p, f) for p, f, _ in prod.patterns] == [(p, f) for p, f, _, _ in orac.patterns]
+        segs = [(b"", 0), (c[:-1].encode(), 3), (b"N" * 500, 0), (b"A" * 3000, 9), (b"RYKMSWBDHV" * 40, 1),
+                (seqgen.chromosome(rng, 2500).lower(), 77), (c.encode() * 300, 5),
+                (seqgen.chromosome(rng, int(rng.integers(1, 40000)), opts.canonical_fwd, opts.canonical_rev,
+                                   telo_repeats=60, n_its=3, iupac=5, n_runs=2), int(rng.integers(0, 10 ** 9))),
+                (seqgen.chromosome(rng, int(rng.integers(8000, 90000)), opts.canonical_fwd, opts.canonical_rev,
+                                   telo_repeats=300, n_its=6), 0)]
+        got = prod.scan_segments([(q, a, tips) for q, a in segs])
+        for (q, a), g in zip(segs, got):
+            seq_up = q.upper() if True else q                     # fold_case = 1 == unmaskSequence + scanSegment
+            assert_segment_equal(g, orac.scan_segment(seq_up, a, tips), tips, ctx="fuzz %d cli=%r len=%d" % (it, cli, len(q)))
