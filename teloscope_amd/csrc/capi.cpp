@@ -125,12 +125,13 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     kp.rep_mask = c->table_replicas - 1u;
     kp.fold_mask = P.fold_case ? 0xDFDFDFDFu : 0xFFFFFFFFu;
     if (tips) {
-        kp.q = 0; kp.r = 0; kp.qq = 0;
+        kp.q = 0; kp.r = 0; kp.qq = 0; kp.halo_blocks = 0;
         kp.straddle_fix = 0; kp.windows_on = 0; kp.nuc_on = 0;
     } else {
         const uint32_t s = P.step, w = P.window_size;
         kp.s = s; kp.w = w;
         kp.q = w / s; kp.r = w % s;
+        kp.halo_blocks = kp.r ? kp.q : kp.q - 1;         // window i needs blocks i .. i+q-1 (+ head of i+q if r)
         kp.qq = (w - k) / s; kp.hh = (w - k) % s;
         kp.straddle_fix = (w == s) ? 1u : 0u;
         kp.windows_on = 1;
@@ -141,7 +142,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
         kp.waves_per_wg = waves;
         // smallest tile that holds one window, then grow towards the preferred size
         uint32_t nch_min = 1;
-        if (!tips) nch_min = (uint32_t)ceil_div((uint64_t)(1 + kp.q) * kp.s + 63, TS_CHUNK);
+        if (!tips) nch_min = (uint32_t)ceil_div((uint64_t)(1 + kp.halo_blocks) * kp.s + 63, TS_CHUNK);
         for (uint32_t nch = std::max(nch_min, kPreferredChunks);; --nch) {
             kp.nch = nch;
             const uint32_t span_max = nch * TS_CHUNK - 63u;
@@ -154,8 +155,8 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
                 wpt = 1;
             } else {
                 const uint32_t nblk = span_max / kp.s;
-                wpt = nblk > kp.q ? std::min<uint32_t>(nblk - kp.q, kMaxBlocksPerTile) : 0u;
-                kp.max_blocks = wpt + kp.q + 1;
+                wpt = nblk > kp.halo_blocks ? std::min<uint32_t>(nblk - kp.halo_blocks, kMaxBlocksPerTile) : 0u;
+                kp.max_blocks = wpt + kp.halo_blocks + 1;
             }
             if (wpt >= 1 && (uint32_t)ts_k_lds_bytes(&kp) <= kMaxLds) return true;
             if (nch <= nch_min) break;

@@ -162,7 +162,7 @@ void ts_scan_tiles(const TsScanParams P) {
         const TsTile T = P.tiles[tile];           // wave-uniform: scalar loads
         const uint32_t sh = (uint32_t)(T.in_off & 15ull);
         const unsigned char *src = P.in + (T.in_off - sh);
-        const uint32_t nblk = T.nwin + P.q;                       // step blocks whose partials are needed
+        const uint32_t nblk = T.nwin + P.halo_blocks;             // step blocks whose partials are needed
         const uint32_t span = nblk * P.s;
         const uint32_t count_lim = T.nrel < span ? T.nrel : span;  // u-range that is ever counted
         const uint32_t xend = sh + T.nrel;                         // plane coord of the segment end

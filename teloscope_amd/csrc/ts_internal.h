@@ -47,6 +47,7 @@ struct TsScanParams {
     uint32_t        s, w;           // step and window (tips mode: s = w = tile size)
     uint32_t        s_inv;          // ceil(2^32 / s) for multiply-high division by s
     uint32_t        q, r;           // w = q*s + r
+    uint32_t        halo_blocks;    // step blocks read beyond the owned ones: q, or q-1 when r == 0
     uint32_t        qq, hh;         // w - k = qq*s + hh
     uint32_t        nch;            // chunks of TS_CHUNK positions per tile
     uint32_t        max_blocks;     // rows of the LDS block accumulators
