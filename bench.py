@@ -258,6 +258,11 @@ def main():
         alg_bytes = int(info.algorithmic_bytes)
         kern_ms = float(info.last_kernel_ms)           # HIP events around the last scan, on its stream
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+        if args.gbases == 3.0 and args.contigs == 200 and os.path.exists(tpath):
+            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
         out = {
             "metric": "Gbases/s scanned (whole node), 3 Gb FASTA TTAGGG w=1000 s=500",
             "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
@@ -271,7 +276,7 @@ def main():
                                        + (" + RCCL gather of per-segment hit summaries" if world > 1 else ""),
                        "device_ms_per_step_events": round(dev_ms, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "ts_scan_tiles", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes": alg_bytes},
         }
