@@ -155,6 +155,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--verify", action="store_true", help="untimed full-size parity properties (torch)")
     ap.add_argument("--blocks", action="store_true", help="also time device block calling (untimed in value)")
+    ap.add_argument("--flags", default=FLAGS, help="Teloscope flags of the workload (default: configs[1])")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -185,7 +186,7 @@ def main():
     from tests import harness as H
     from tests.backends import _user_input
 
-    opts = H.parse_cli("x.fa " + FLAGS)
+    opts = H.parse_cli("x.fa " + args.flags)
     ui = _user_input(opts)
     ui.device = dev_index
     tel = ta.Teloscope(ui)
@@ -260,7 +261,7 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-        if args.gbases == 3.0 and args.contigs == 200 and os.path.exists(tpath):
+        if args.gbases == 3.0 and args.contigs == 200 and args.flags == FLAGS and os.path.exists(tpath):
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
         out = {
@@ -268,8 +269,9 @@ def main():
             "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic %.2f Gb / %d contigs per GPU, %s, 124 patterns k=6"
-                                   % (args.gbases, n, FLAGS),
+            "config": {"workload": "%s: synthetic %.2f Gb / %d contigs per GPU, %s, %d patterns k=%d"
+                                   % ("configs[1]" if args.flags == FLAGS else "custom", args.gbases, n, args.flags,
+                                      len(ui.patternInfo), len(ui.patternInfo[0][0])),
                        "bases_per_gpu": total, "windows": int(info.n_windows),
                        "matches": int(info.n_matches), "tiles": int(info.n_tiles),
                        "timed_region": "resident ASCII in HBM -> window records + packed match stream in HBM"
