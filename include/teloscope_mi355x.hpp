@@ -1,0 +1,293 @@
+// teloscope_mi355x.hpp — C++17 host-side mirror of the reference's scan-path interface, above
+// the C-ABI of libteloscan.so (include/teloscan.h).
+//
+// Same class names, member names and argument meaning as the reference, so reference call
+// sites compile against it unchanged:
+//
+//     UserInputTeloscope userInput;                       // include/input.h:15-64
+//     userInput.patternInfo = expandPatternsWithOrientation(userInput.rawPatterns,
+//                                 userInput.editDistance, userInput.canonicalFwd);   // src/tools.cpp:201
+//     Teloscope teloscope(userInput);                      // include/teloscope.h:241
+//     SegmentData sd = teloscope.scanSegment(sequence, absPos, tipsOnly);            // :260
+//     ReadTelomereFilter filter(userInput);  bool keep = filter.matches(read);       // read-filter.h:16
+//
+// plus the batched forms a GPU needs (scanSegments, matchesBatch).  Header-only; link with
+// -lteloscan.  Errors the reference would answer with exit(EXIT_FAILURE) are thrown as
+// std::runtime_error carrying ts_last_error(); nothing falls back to a CPU scan.
+#ifndef TELOSCOPE_MI355X_HPP
+#define TELOSCOPE_MI355X_HPP
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "teloscan.h"
+
+namespace teloscope_mi355x {
+
+enum class ScaffoldType : uint8_t {            // include/tools.h:13-19
+    T2T, GAPPED_T2T, MISASSEMBLY, GAPPED_MISASSEMBLY, INCOMPLETE, GAPPED_INCOMPLETE,
+    NONE, GAPPED_NONE, DISCORDANT, GAPPED_DISCORDANT
+};
+
+struct UserInputTeloscope {                    // include/input.h:15-64 (fields the scan path reads)
+    std::string canonicalFwd = "CCCTAA";
+    std::string canonicalRev = "TTAGGG";
+    unsigned short int canonicalSize = 6;
+    std::vector<std::string> rawPatterns = {"TTAGGG", "CCCTAA"};
+    std::vector<std::string> patterns = {"TTAGGG", "CCCTAA"};
+    std::vector<std::pair<std::string, bool>> patternInfo;      // (pattern, isForward)
+    uint32_t windowSize = 1000;
+    uint32_t step = 1000;
+    uint32_t terminalLimit = 50000;
+    uint8_t editDistance = 1;
+    unsigned short int maxMatchDist = 50;
+    unsigned short int minBlockLen = 300;
+    bool minBlockLenSet = false;
+    unsigned short int maxBlockDist = 500;
+    unsigned short int minBlockCounts = 2;
+    float minBlockDensity = 0.5f;
+    bool outWinRepeats = false, outGC = false, outEntropy = false, outMatches = false, outITS = false;
+    bool ultraFastMode = true;
+    int device = -1;                           // HIP device ordinal (-1 = current); not in the reference
+};
+
+struct MatchInfo {                             // include/teloscope.h:89-95
+    bool isCanonical = false;
+    bool isForward = false;
+    uint64_t position = 0;
+    uint16_t matchSize = 0;
+    std::string matchSeq;
+};
+
+struct TelomereBlock {                         // include/teloscope.h:103-117
+    uint64_t start = 0;
+    uint32_t blockLen = 0, blockCounts = 0, forwardCount = 0, reverseCount = 0, canonicalCount = 0,
+             nonCanonicalCount = 0, totalCovered = 0, fwdCovered = 0, canCovered = 0;
+    bool hasValidOr = true;
+    bool isLongest = false;
+    char blockLabel = '\0';
+};
+
+struct WindowData {                            // include/teloscope.h:119-137 (fields any writer reads)
+    uint64_t windowStart = 0;
+    uint32_t currentWindowSize = 0;
+    uint32_t nucleotideCounts[4] = {0, 0, 0, 0};
+    float gcContent = 0.0f;
+    float shannonEntropy = 0.0f;
+    uint32_t canonicalCovered = 0, nonCanonicalCovered = 0, fwdCovered = 0, revCovered = 0;
+};
+
+struct SegmentData {                           // include/teloscope.h:139-148
+    std::vector<WindowData> windows;
+    std::vector<TelomereBlock> terminalBlocks;
+    std::vector<TelomereBlock> interstitialBlocks;
+    std::vector<MatchInfo> canonicalMatches;
+    std::vector<MatchInfo> nonCanonicalMatches;
+    std::vector<MatchInfo> fwdMatches;
+    std::vector<MatchInfo> revMatches;
+    std::vector<MatchInfo> allMatches;
+};
+
+// src/main.cpp:287-296: the lexicographically smaller of (pattern, reverse complement) is "forward"
+inline void setCanonical(UserInputTeloscope &ui, const std::string &canonical) {
+    char f[64], r[64];
+    if (ts_canonical_orientation(canonical.c_str(), f, r) != TS_OK) throw std::runtime_error("bad canonical pattern");
+    ui.canonicalFwd = f;
+    ui.canonicalRev = r;
+    ui.canonicalSize = static_cast<unsigned short>(ui.canonicalFwd.size());
+}
+
+// src/tools.cpp:201-283
+inline std::vector<std::pair<std::string, bool>> expandPatternsWithOrientation(
+    const std::vector<std::string> &rawPatterns, uint8_t editDistance, const std::string &canonicalFwd) {
+    std::string csv;
+    for (size_t i = 0; i < rawPatterns.size(); ++i) { if (i) csv += ','; csv += rawPatterns[i]; }
+    ts_pattern *arr = nullptr;
+    size_t n = 0;
+    if (ts_expand_patterns(csv.c_str(), editDistance, canonicalFwd.c_str(), &arr, &n) != TS_OK)
+        throw std::runtime_error("expandPatternsWithOrientation: invalid arguments");
+    std::vector<std::pair<std::string, bool>> out;
+    out.reserve(n);
+    for (size_t i = 0; i < n; ++i) out.emplace_back(std::string(arr[i].seq, arr[i].len), arr[i].is_forward != 0);
+    ts_free_patterns(arr);
+    return out;
+}
+
+namespace detail {
+
+struct CtxDeleter { void operator()(ts_ctx *c) const { ts_destroy(c); } };
+using CtxPtr = std::unique_ptr<ts_ctx, CtxDeleter>;
+
+inline ts_params makeParams(const UserInputTeloscope &ui) {
+    ts_params p{};
+    p.struct_size = sizeof p;
+    p.window_size = ui.windowSize; p.step = ui.step; p.terminal_limit = ui.terminalLimit;
+    p.max_match_dist = ui.maxMatchDist; p.min_block_len = ui.minBlockLen;
+    p.max_block_dist = ui.maxBlockDist; p.min_block_counts = ui.minBlockCounts;
+    p.min_block_density = ui.minBlockDensity; p.canonical_size = ui.canonicalSize;
+    p.out_gc = ui.outGC; p.out_entropy = ui.outEntropy; p.out_matches = ui.outMatches; p.out_its = ui.outITS;
+    p.fold_case = 1;                                   // every reference caller runs unmaskSequence first
+    p.device = ui.device;
+    return p;
+}
+
+inline std::vector<ts_pattern> makePatterns(UserInputTeloscope &ui) {
+    if (ui.patternInfo.empty())
+        ui.patternInfo = expandPatternsWithOrientation(ui.rawPatterns, ui.editDistance, ui.canonicalFwd);
+    ui.patterns.clear();
+    std::vector<ts_pattern> pats;
+    for (const auto &pi : ui.patternInfo) {
+        ui.patterns.push_back(pi.first);
+        ts_pattern t{};
+        std::strncpy(t.seq, pi.first.c_str(), 63);
+        t.len = static_cast<uint8_t>(pi.first.size());
+        t.is_forward = pi.second;
+        t.is_canonical = (pi.first == ui.canonicalFwd || pi.first == ui.canonicalRev);   // teloscope.h:243-244
+        pats.push_back(t);
+    }
+    return pats;
+}
+
+inline TelomereBlock toBlock(const ts_block &b) {
+    TelomereBlock t;
+    t.start = b.start; t.blockLen = b.block_len; t.blockCounts = b.block_counts;
+    t.forwardCount = b.forward_count; t.reverseCount = b.reverse_count; t.canonicalCount = b.canonical_count;
+    t.nonCanonicalCount = b.non_canonical_count; t.totalCovered = b.total_covered;
+    t.fwdCovered = b.fwd_covered; t.canCovered = b.can_covered;
+    t.hasValidOr = b.has_valid_or != 0; t.isLongest = b.is_longest != 0; t.blockLabel = b.block_label;
+    return t;
+}
+
+inline ts_block fromBlock(const TelomereBlock &t) {
+    ts_block b{};
+    b.start = t.start; b.block_len = t.blockLen; b.block_counts = t.blockCounts;
+    b.forward_count = t.forwardCount; b.reverse_count = t.reverseCount; b.canonical_count = t.canonicalCount;
+    b.non_canonical_count = t.nonCanonicalCount; b.total_covered = t.totalCovered;
+    b.fwd_covered = t.fwdCovered; b.can_covered = t.canCovered;
+    b.has_valid_or = t.hasValidOr; b.is_longest = t.isLongest; b.block_label = t.blockLabel;
+    return b;
+}
+
+}  // namespace detail
+
+class Teloscope {                              // include/teloscope.h:166-300 (scan path only)
+    UserInputTeloscope userInput;
+    detail::CtxPtr ctx;
+
+    SegmentData convert(const ts_segment_out &o, const std::string &sequence, uint64_t absPos, bool tipsOnly) const {
+        SegmentData sd;
+        sd.windows.reserve(o.n_windows);
+        for (uint64_t i = 0; i < o.n_windows; ++i) {
+            const ts_window &g = o.windows[i];
+            WindowData w;
+            w.windowStart = g.window_start; w.currentWindowSize = g.current_window_size;
+            for (int c = 0; c < 4; ++c) w.nucleotideCounts[c] = g.nucleotide_counts[c];
+            w.gcContent = g.gc_content; w.shannonEntropy = g.shannon_entropy;
+            w.canonicalCovered = g.canonical_covered; w.nonCanonicalCovered = g.non_canonical_covered;
+            w.fwdCovered = g.fwd_covered; w.revCovered = g.rev_covered;
+            sd.windows.push_back(w);
+        }
+        for (uint64_t i = 0; i < o.n_matches; ++i) {
+            const ts_match &g = o.matches[i];
+            MatchInfo m;
+            m.position = g.position; m.matchSize = g.match_size;
+            m.isForward = (g.flags & TS_MATCH_FORWARD) != 0;
+            m.isCanonical = (g.flags & TS_MATCH_CANONICAL) != 0;
+            if (userInput.outMatches && !tipsOnly)                      // src/teloscope.cpp:466-468
+                m.matchSeq = sequence.substr(static_cast<size_t>(g.position - absPos), g.match_size);
+            (m.isForward ? sd.fwdMatches : sd.revMatches).push_back(m);
+            if (!tipsOnly) {                                            // routing of src/teloscope.cpp:485-509
+                sd.allMatches.push_back(m);
+                if (m.isCanonical) sd.canonicalMatches.push_back(m);
+                else if (g.flags & TS_MATCH_TERMINAL) sd.nonCanonicalMatches.push_back(m);
+            }
+        }
+        for (uint64_t i = 0; i < o.n_terminal_blocks; ++i) sd.terminalBlocks.push_back(detail::toBlock(o.terminal_blocks[i]));
+        for (uint64_t i = 0; i < o.n_interstitial_blocks; ++i) sd.interstitialBlocks.push_back(detail::toBlock(o.interstitial_blocks[i]));
+        return sd;
+    }
+
+public:
+    explicit Teloscope(UserInputTeloscope ui) : userInput(std::move(ui)) {
+        std::vector<ts_pattern> pats = detail::makePatterns(userInput);
+        ts_params p = detail::makeParams(userInput);
+        ctx.reset(ts_create(&p, pats.data(), pats.size()));
+        if (!ctx) throw std::runtime_error(ts_last_error(nullptr));
+    }
+
+    const UserInputTeloscope &input() const { return userInput; }
+
+    struct Segment { const std::string *sequence; uint64_t absPos; bool tipsOnly; };
+
+    // batched scanSegment: result[i] is what scanSegment(*segs[i].sequence, absPos, tipsOnly) returns
+    std::vector<SegmentData> scanSegments(const std::vector<Segment> &segs) {
+        std::vector<ts_segment_in> in(segs.size());
+        for (size_t i = 0; i < segs.size(); ++i) {
+            in[i] = ts_segment_in{segs[i].sequence->data(), segs[i].sequence->size(), segs[i].absPos,
+                                  static_cast<uint8_t>(segs[i].tipsOnly), {}};
+        }
+        std::vector<ts_segment_out> out(segs.size());
+        if (ts_scan_segments(ctx.get(), in.data(), in.size(), out.data()) != TS_OK)
+            throw std::runtime_error(ts_last_error(ctx.get()));
+        std::vector<SegmentData> res;
+        res.reserve(segs.size());
+        for (size_t i = 0; i < segs.size(); ++i)
+            res.push_back(convert(out[i], *segs[i].sequence, segs[i].absPos, segs[i].tipsOnly));
+        ts_free_segments(out.data(), out.size());
+        return res;
+    }
+
+    // SegmentData Teloscope::scanSegment(std::string &sequence, uint64_t absPos, bool tipsOnly)
+    SegmentData scanSegment(std::string &sequence, uint64_t absPos, bool tipsOnly) {
+        return std::move(scanSegments({Segment{&sequence, absPos, tipsOnly}})[0]);
+    }
+
+    // void Teloscope::labelTerminalBlocks(blocks, gaps, terminalLabel, scaffoldType, pathSize, terminalLimit)
+    void labelTerminalBlocks(std::vector<TelomereBlock> &blocks, uint16_t gaps, std::string &terminalLabel,
+                             ScaffoldType &scaffoldType, uint64_t pathSize, uint32_t terminalLimit) {
+        std::vector<ts_block> raw;
+        for (const TelomereBlock &b : blocks) raw.push_back(detail::fromBlock(b));
+        std::string label(2 * raw.size() + 2, '\0');
+        int st = 0;
+        if (ts_label_terminal_blocks(raw.data(), raw.size(), gaps, pathSize, terminalLimit, &label[0], &st) != TS_OK)
+            throw std::runtime_error("labelTerminalBlocks failed");
+        terminalLabel = label.c_str();
+        scaffoldType = static_cast<ScaffoldType>(st);
+        for (size_t i = 0; i < raw.size(); ++i) blocks[i] = detail::toBlock(raw[i]);
+    }
+};
+
+class ReadTelomereFilter {                     // include/read-filter.h:10-18
+    detail::CtxPtr ctx;
+
+public:
+    explicit ReadTelomereFilter(const UserInputTeloscope &input) {
+        UserInputTeloscope ui = input;
+        std::vector<ts_pattern> pats = detail::makePatterns(ui);
+        ts_params p = detail::makeParams(ui);
+        ctx.reset(ts_create_read_filter(&p, ui.minBlockLenSet ? 1 : 0, pats.data(), pats.size()));
+        if (!ctx) throw std::runtime_error(ts_last_error(nullptr));
+    }
+
+    std::vector<bool> matchesBatch(const std::vector<std::string> &sequences) {
+        std::vector<const char *> ptr(sequences.size());
+        std::vector<uint64_t> len(sequences.size());
+        for (size_t i = 0; i < sequences.size(); ++i) { ptr[i] = sequences[i].data(); len[i] = sequences[i].size(); }
+        std::vector<uint8_t> pass(sequences.size());
+        if (ts_filter_reads(ctx.get(), ptr.data(), len.data(), sequences.size(), pass.data()) != TS_OK)
+            throw std::runtime_error(ts_last_error(ctx.get()));
+        return std::vector<bool>(pass.begin(), pass.end());
+    }
+
+    // bool ReadTelomereFilter::matches(std::string sequence)
+    bool matches(std::string sequence) { return matchesBatch({std::move(sequence)})[0]; }
+};
+
+}  // namespace teloscope_mi355x
+
+#endif

@@ -1,0 +1,59 @@
+"""The C++17 host-side mirror (include/teloscope_mi355x.hpp: Teloscope::scanSegment,
+ReadTelomereFilter::matches, expandPatternsWithOrientation, labelTerminalBlocks above the C-ABI)
+driven by tests/cpp/manifest_cli.cpp: on a GPU box every legacy `.tst` manifest of the reference is
+replayed through it and must reproduce the expected CLI stdout; on CPU it must build and refuse
+to run without a HIP device."""
+import glob
+import gzip
+import os
+import shlex
+import subprocess
+
+import pytest
+
+from tests import harness as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MANIFESTS = sorted(glob.glob(os.path.join(H.GOLDEN, "validateFiles", "*.tst")))
+LEGACY = [m for m in MANIFESTS if H.load_manifest(m)["mode"] == "embedded"]
+
+
+@pytest.fixture(scope="module")
+def cli(tmp_path_factory):
+    import teloscope_amd  # noqa: F401  (makes sure libteloscan.so is built)
+    out = tmp_path_factory.mktemp("cpp") / "manifest_cli"
+    libdir = os.path.join(ROOT, "teloscope_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "manifest_cli.cpp"), "-L", libdir, "-lteloscan",
+                           "-Wl,-rpath," + libdir, "-o", str(out)])
+    return str(out)
+
+
+def test_cpp_mirror_builds_and_refuses_without_gpu(cli):
+    from teloscope_amd import _capi as K
+    if K.lib().ts_device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([cli, "-f", H.golden_path("testFiles/t2t.fa"), "-i"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr and r.stdout == ""
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_replays_all_legacy_manifests(cli, tmp_path):
+    failures = []
+    for path in LEGACY:
+        m = H.load_manifest(path)
+        args = []
+        for tok in shlex.split(m["command"]):
+            if tok.startswith("testFiles/"):
+                src = H.golden_path(tok)
+                if src.endswith(".gz"):                       # the driver reads plain FASTA
+                    plain = tmp_path / os.path.basename(src)[:-3]
+                    if not plain.exists():
+                        plain.write_bytes(gzip.open(src, "rb").read())
+                    src = str(plain)
+                tok = src
+            args.append(tok)
+        r = subprocess.run([cli] + args, capture_output=True, text=True, timeout=120)
+        if r.returncode != 0 or r.stdout.split("\n") != m["expected"].split("\n"):
+            failures.append((os.path.basename(path), r.returncode, r.stderr[-200:]))
+    assert not failures, failures[:5]
