@@ -27,6 +27,14 @@
 
 #include "ts_internal.h"
 
+// Profiling only: -DTS_ABL=<mask> builds a kernel with one stage removed (results are then wrong)
+// so that stage costs can be measured under real overlap; see profiles/ablate.sh.
+//   1 emit loop  2 nucleotide sums  4 match sums  8 window records  16 flag resolution
+//   32 table probes  64 plane stores
+#ifndef TS_ABL
+#define TS_ABL 0
+#endif
+
 namespace {
 
 typedef unsigned long long u64;
@@ -93,18 +101,23 @@ __device__ __forceinline__ void plane_clear(uint32_t *p, uint32_t lo, uint32_t h
 
 __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
-// LDS: [match table][wave 0 slice][wave 1 slice]...; a slice = codes | V | M | F | C | blk
-struct SliceLayout { uint32_t codes, pV, pM, pF, pC, blk, bytes; };
+// LDS: [match table][wave 0 slice][wave 1 slice]...; a slice = codes | M | F | C | nuc | blk
+//   codes   2-bit codes, one dword per 16 positions
+//   M F C   bit planes (match / forward / canonical), one halfword per 16 positions
+//   nuc     four byte planes: number of valid A, C, G, T among each dword's 16 positions
+//   blk     [0, 4 NB) nucleotide counts of the tile's windows; then 6 match counters per step block
+struct SliceLayout { uint32_t codes, pM, pF, pC, nuc, nuc_stride, blk, bytes; };
 
 __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     SliceLayout s;
     uint32_t o = 0;
     s.codes = o; o += align16(P.nch * 63u * 4u + 16u);
     const uint32_t pb = align16(P.nch * 63u * 2u + 16u);
-    s.pV = o; o += pb;
     s.pM = o; o += pb;
     s.pF = o; o += pb;
     s.pC = o; o += pb;
+    s.nuc_stride = align16(P.nch * 63u + 16u);
+    s.nuc = o; o += 4u * s.nuc_stride;
     s.blk = o; o += align16(P.max_blocks * TS_BLK_COUNTERS * 4u);
     s.bytes = o;
     return s;
@@ -137,10 +150,11 @@ void ts_scan_tiles(const TsScanParams P) {
     const SliceLayout SL = slice_layout(P);
     unsigned char *slice = lds_raw + table_bytes + wave * SL.bytes;
     uint32_t *codes = (uint32_t *)(slice + SL.codes);
-    uint16_t *pV = (uint16_t *)(slice + SL.pV);
     uint16_t *pM = (uint16_t *)(slice + SL.pM);
     uint16_t *pF = (uint16_t *)(slice + SL.pF);
     uint16_t *pC = (uint16_t *)(slice + SL.pC);
+    unsigned char *nuc = slice + SL.nuc;
+    const uint32_t NS = SL.nuc_stride;
     uint32_t *blk = (uint32_t *)(slice + SL.blk);
     const uint32_t NB = P.max_blocks;             // blk[counter * NB + block]
 
@@ -218,6 +232,9 @@ void ts_scan_tiles(const TsScanParams P) {
             // starts at an even position and holds {match at p, match at p+1} (16 entries per dword:
             // row = index >> 4, bit = 2 * (index & 15)).  All eight ds_read_b32 are issued back to
             // back (inline asm) and consumed behind one counted wait.
+#if TS_ABL & 32
+            uint32_t M16 = (w2 & nxt & (w2 >> 7) & (nxt >> 3) & (w2 >> 11)) & 0xFFFFu;
+#else
             uint32_t tmp[8], ent[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -233,6 +250,7 @@ void ts_scan_tiles(const TsScanParams P) {
             for (int j = 0; j < 8; ++j)
                 aM = __builtin_amdgcn_alignbit(ent[j] >> ((tmp[j] << 1) & 31u), aM, 2);
             uint32_t M16 = aM >> 16;
+#endif
 
             if (slow) {                                           // k-mers touching an invalid base
                 const uint32_t inv32 = inv16 | ((uint32_t)__builtin_amdgcn_mov_dpp((int)inv16, 0x130, 0xf, 0xf, false) << 16);
@@ -246,6 +264,9 @@ void ts_scan_tiles(const TsScanParams P) {
             // that keeps ctz defined for lanes that have run out of matches; its writes land in
             // bit 16 of F16/C16 and are masked off).  Flag table: one byte per k-mer, or 2 bits.
             uint32_t F16 = 0, C16 = 0;
+#if TS_ABL & 16
+            F16 = M16 & w2; C16 = M16 & nxt;
+#else
             for (uint32_t m = M16 | 0x10000u; __any((m & 0xFFFFu) != 0u);) {
                 const uint32_t j = (uint32_t)__builtin_ctz(m);
                 const uint32_t idx = __builtin_amdgcn_alignbit(nxt, w2, 2u * j) & kmask;
@@ -256,15 +277,29 @@ void ts_scan_tiles(const TsScanParams P) {
                 F16 |= (fc & 1u) << j;
                 C16 |= (fc >> 1) << j;
             }
+#endif
             F16 &= 0xFFFFu; C16 &= 0xFFFFu;
 
-            if (lane < 63u) {
+            // valid A/C/G/T among this lane's 16 bases (codes A0 C1 T2 G3: low bit set in C and G,
+            // high bit in T and G); invalid positions are masked out on the slow path
+            uint32_t sel = 0x55555555u;
+            if (slow) sel = spread16(~inv16 & 0xFFFFu);
+            const uint32_t lbits = w2 & sel, hbits = (w2 >> 1) & sel;
+            const uint32_t nG = __popc(lbits & hbits);
+            const uint32_t nL = __popc(lbits), nH = __popc(hbits);
+            const uint32_t nA = __popc(sel) + nG - nL - nH;
+
+            if (lane < 63u && !(TS_ABL & 64)) {
                 const uint32_t h = c * 63u + lane;
                 codes[h] = w2;
                 pM[h] = (uint16_t)M16;
                 pF[h] = (uint16_t)F16;
                 pC[h] = (uint16_t)C16;
-                pV[h] = (uint16_t)(~inv16);
+                unsigned char *np = nuc + h;
+                np[0] = (unsigned char)nA;
+                np[NS] = (unsigned char)(nL - nG);
+                np[2u * NS] = (unsigned char)nG;
+                np[3u * NS] = (unsigned char)(nH - nG);
             }
         };
         {
@@ -316,7 +351,7 @@ void ts_scan_tiles(const TsScanParams P) {
 
                 {   // matches, split at offsets {0, hh+1} of every step block
                     const u64 M = gM[g], F = gF[g], C = gC[g];
-                    if (M) {
+                    if (M && !(TS_ABL & 4)) {
                         uint32_t u = u0, b = b0, o = o0;
                         while (u < u1) {
                             const bool head = o <= P.hh;
@@ -325,7 +360,7 @@ void ts_scan_tiles(const TsScanParams P) {
                             const u64 m = mask64(u + sh - gx, eu + sh - gx);
                             const uint32_t nm = __popcll(M & m);
                             if (nm) {
-                                uint32_t *a = &blk[(head ? 8u : 11u) * NB + b];
+                                uint32_t *a = &blk[(head ? 4u : 7u) * NB + b];
                                 const uint32_t nf = __popcll(F & m), nc = __popcll(C & m);
                                 atomicAdd(&a[0], nm);
                                 if (nc) atomicAdd(&a[NB], nc);
@@ -336,74 +371,79 @@ void ts_scan_tiles(const TsScanParams P) {
                         }
                     }
                 }
-                if (P.nuc_on) {   // nucleotides, split at offsets {0, r}
-                    uint32_t u = u0, b = b0, o = o0;
-                    while (u < u1) {
-                        const bool head = o < P.r;
-                        uint32_t eu = head ? (u - o + P.r) : (u - o + P.s);
-                        if (eu > u1) eu = u1;
-                        const uint32_t xa = u + sh, xb = eu + sh;
-                        uint32_t n1 = 0, n2 = 0, n3 = 0, nt = 0;
-                        if (xb - xa == 64u && !has_invalid) {           // whole granule, all bases valid
-                            const uint4 cd4 = *(const uint4 *)&codes[g << 2];
-                            const uint32_t cd[4] = {cd4.x, cd4.y, cd4.z, cd4.w};
-#pragma unroll
-                            for (int tq = 0; tq < 4; ++tq) {
-                                const uint32_t l0 = cd[tq] & 0x55555555u, h0 = (cd[tq] >> 1) & 0x55555555u;
-                                n3 += __popc(l0 & h0);
-                                n1 += __popc(l0 & ~h0);
-                                n2 += __popc(h0 & ~l0);
-                            }
-                            nt = 64u;
-                        } else {
-#pragma unroll
-                            for (uint32_t tq = 0; tq < 4; ++tq) {
-                                const uint32_t d = (g << 2) + tq, base = d << 4;
-                                const uint32_t lo = xa > base ? xa : base;
-                                const uint32_t hi = xb < base + 16u ? xb : base + 16u;
-                                if (lo < hi) {
-                                    const uint32_t nb2 = (hi - lo) * 2u;
-                                    uint32_t sel = (nb2 >= 32u ? ~0u : ((1u << nb2) - 1u)) << ((lo - base) * 2u);
-                                    sel &= 0x55555555u;
-                                    if (has_invalid) sel &= spread16(pV[d]);
-                                    const uint32_t cd = codes[d];
-                                    const uint32_t l0 = cd & sel, h0 = (cd >> 1) & sel;
-                                    n3 += __popc(l0 & h0);
-                                    n1 += __popc(l0 & ~h0);
-                                    n2 += __popc(h0 & ~l0);
-                                    nt += __popc(sel);
-                                }
-                            }
+            }
+        }
+
+        // ------------------------------------- nucleotide counts: one lane per (window, A|C|G|T)
+        // count = sum of the field's byte plane over the dwords wholly inside the window (aligned
+        // ds reads, v_sad_u8 adds four at a time) + the two partial dwords at the window's ends,
+        // counted from the 2-bit codes.
+        if (P.windows_on && P.nuc_on && !(TS_ABL & 2)) {
+            const uint32_t nitems = T.nwin * 4u;
+            for (uint32_t it = lane; it < nitems; it += 64u) {
+                const uint32_t i = it >> 2, f = it & 3u;
+                const uint32_t us = i * P.s;
+                const uint32_t ue = us + P.w < T.nrel ? us + P.w : T.nrel;
+                const uint32_t xs = sh + us, xe = sh + ue;           // plane coords, xs < xe
+                const uint32_t hs = xs >> 4, he = xe >> 4;
+                // the field's code: A0 C1 G3 T2 -> bits to flip so that "equal" reads as 1/1
+                const uint32_t code = (f == 2u) ? 3u : (f == 3u ? 2u : f);
+                const uint32_t xl = (code & 1u) ? 0u : 0x55555555u, xh = (code & 2u) ? 0u : 0x55555555u;
+                const uint32_t letter = (0x54474341u >> (8u * f)) & 0xFFu;
+                auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // lo < hi <= 16, hi - lo < 16
+                    if (has_invalid) {                                // rare: re-read the bases themselves
+                        uint32_t n = 0;
+                        for (uint32_t pp = lo; pp < hi; ++pp)
+                            n += ((uint32_t)src[h * 16u + pp] & (P.fold_mask & 0xFFu)) == letter;
+                        return n;
+                    }
+                    const uint32_t m = (((1u << (2u * (hi - lo))) - 1u) << (2u * lo)) & 0x55555555u;
+                    const uint32_t cd = codes[h];
+                    return __popc((cd ^ xl) & ((cd >> 1) ^ xh) & m);
+                };
+                uint32_t val = 0;
+                if (hs == he) {
+                    val = partial(hs, xs & 15u, xe & 15u);
+                } else {
+                    uint32_t ha = hs;
+                    if (xs & 15u) { val += partial(hs, xs & 15u, 16u); ++ha; }
+                    if (xe & 15u) val += partial(he, 0u, xe & 15u);
+                    if (ha < he) {                                    // whole dwords ha .. he-1
+                        const uint32_t *pl = (const uint32_t *)(nuc + f * NS);
+                        uint32_t d = ha >> 2;
+                        const uint32_t db = (he - 1u) >> 2;
+                        const uint32_t m0 = ~0u << (8u * (ha & 3u));
+                        const uint32_t m1 = ~0u >> (8u * (3u - ((he - 1u) & 3u)));
+                        uint32_t v0 = pl[d] & m0;
+                        if (d == db) v0 &= m1;
+                        val = __builtin_amdgcn_sad_u8(v0, 0u, val);
+                        ++d;
+                        for (; d + 4u <= db; d += 4u) {
+                            val = __builtin_amdgcn_sad_u8(pl[d], 0u, val);
+                            val = __builtin_amdgcn_sad_u8(pl[d + 1u], 0u, val);
+                            val = __builtin_amdgcn_sad_u8(pl[d + 2u], 0u, val);
+                            val = __builtin_amdgcn_sad_u8(pl[d + 3u], 0u, val);
                         }
-                        uint32_t *a = &blk[(head ? 0u : 4u) * NB + b];
-                        const uint32_t n0 = nt - n1 - n2 - n3;
-                        if (n0) atomicAdd(&a[0], n0);
-                        if (n1) atomicAdd(&a[NB], n1);
-                        if (n2) atomicAdd(&a[2u * NB], n2);
-                        if (n3) atomicAdd(&a[3u * NB], n3);
-                        o += eu - u; u = eu;
-                        if (o >= P.s) { o = 0; ++b; }
+                        for (; d < db; ++d) val = __builtin_amdgcn_sad_u8(pl[d], 0u, val);
+                        if (d == db) val = __builtin_amdgcn_sad_u8(pl[db] & m1, 0u, val);
                     }
                 }
+                blk[it] = val;
             }
         }
         __builtin_amdgcn_wave_barrier();
 
         // ------------------------------------------------- phase 2b: window records, 8 x u32 each
-        if (P.windows_on) {
+        if (P.windows_on && !(TS_ABL & 8)) {
             const uint32_t nitems = T.nwin * 8u;
             uint32_t *wout = P.windows_out + T.win_out * 8ull;
             for (uint32_t it = lane; it < nitems; it += 64u) {
                 const uint32_t i = it >> 3, f = it & 7u;
                 uint32_t val;
-                if (f < 4u) {                                       // A C G T  (codes: A0 C1 T2 G3)
-                    const uint32_t c = (f == 2u) ? 3u : (f == 3u ? 2u : f);
-                    const uint32_t *hd = &blk[c * NB], *rs = &blk[(4u + c) * NB];
-                    val = 0;
-                    for (uint32_t j = 0; j < P.q; ++j) val += hd[i + j] + rs[i + j];
-                    if (P.r) val += hd[i + P.q];
+                if (f < 4u) {                                       // A C G T, counted above
+                    val = blk[i * 4u + f];
                 } else {                                            // covered bases = k x count
-                    const uint32_t *mh = &blk[8u * NB], *mr = &blk[11u * NB];
+                    const uint32_t *mh = &blk[4u * NB], *mr = &blk[7u * NB];
                     const uint32_t sel = (f & 2u) ? 2u * NB : NB;   // canonical (f=4,5) or forward (f=6,7)
                     uint32_t mm = 0, ms = 0;
                     for (uint32_t j = 0; j < P.qq; ++j) {
@@ -444,7 +484,7 @@ void ts_scan_tiles(const TsScanParams P) {
                 const uint32_t incl = wave_scan_incl(cnt);
                 uint32_t o = cursor + done + (incl - cnt);         // index inside this wave's region
                 const uint32_t ubase = (h << 5) - sh;               // tile-relative position of bit 0
-                while (M) {
+                while (M && !(TS_ABL & 1)) {
                     const uint32_t j = (uint32_t)__builtin_ctz(M);
                     M &= M - 1u;
                     const uint32_t rec = ((ubase + j) << 2) | (((F >> j) & 1u) << 1) | ((C >> j) & 1u);

@@ -14,7 +14,7 @@
 
 #define TS_MAX_WG_THREADS 1024         // up to 16 wavefronts per workgroup, one workgroup per CU
 #define TS_CHUNK        1008           // positions a wave resolves per iteration (63 lanes x 16)
-#define TS_BLK_COUNTERS 14             // per step-block: nuc head[4] rest[4], match head[3] rest[3]
+#define TS_BLK_COUNTERS 10             // 4 NB dwords of window nucleotide counts, then per step block: match head[3] rest[3]
 #define TS_IN_PAD       4096           // bytes of zero padding after the last segment in the input buffer
 
 struct TsTile {                 // 32 bytes
