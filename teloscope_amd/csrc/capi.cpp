@@ -46,7 +46,7 @@ struct ts_ctx {
     std::string why_not;            // reason when a scan mode is unsupported
     int device = 0;
     int num_cu = 0;
-    uint32_t table_rows = 0, table_replicas = 8, fc_bytes = 0;
+    uint32_t table_rows = 0, fc_bytes = 0;
     bool fc_byte_table = true;
     // general kernels (generic.hip): sorted 2-bit codes per pattern length
     bool generic_ok = false;
@@ -119,24 +119,19 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     const uint32_t k = c->k;
     kp.k = k;
     kp.table_rows = c->table_rows;
-    kp.row_shift = c->table_replicas == 8 ? 5u : (c->table_replicas == 2 ? 3u : 2u);      // replicas * 4 bytes
     kp.fc_bytes = c->fc_bytes;
     kp.fc_byte_table = c->fc_byte_table ? 1u : 0u;
-    kp.rep_mask = c->table_replicas - 1u;
     kp.fold_mask = P.fold_case ? 0xDFDFDFDFu : 0xFFFFFFFFu;
     if (tips) {
-        kp.q = 0; kp.r = 0; kp.qq = 0; kp.halo_blocks = 0;
+        kp.halo_blocks = 0;
         kp.straddle_fix = 0; kp.windows_on = 0; kp.nuc_on = 0;
     } else {
         const uint32_t s = P.step, w = P.window_size;
         kp.s = s; kp.w = w;
-        kp.q = w / s; kp.r = w % s;
-        kp.halo_blocks = kp.r ? kp.q : kp.q - 1;         // window i needs blocks i .. i+q-1 (+ head of i+q if r)
-        kp.qq = (w - k) / s; kp.hh = (w - k) % s;
+        kp.halo_blocks = (w + s - 1) / s - 1;            // window i reaches into step blocks i .. i + ceil(w/s) - 1
         kp.straddle_fix = (w == s) ? 1u : 0u;
         kp.windows_on = 1;
         kp.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u;
-        kp.s_inv = (uint32_t)(((1ull << 32) + s - 1) / s);
     }
     for (uint32_t waves = 16; waves >= 1; waves >>= 1) {
         kp.waves_per_wg = waves;
@@ -149,14 +144,12 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
             if (tips) {
                 const uint32_t tb = span_max & ~15u;            // one pseudo block per tile
                 kp.s = kp.w = tb;
-                kp.hh = tb - k;
-                kp.s_inv = (uint32_t)(((1ull << 32) + tb - 1) / tb);
-                kp.max_blocks = 2;
+                kp.max_windows = 1;
                 wpt = 1;
             } else {
                 const uint32_t nblk = span_max / kp.s;
                 wpt = nblk > kp.halo_blocks ? std::min<uint32_t>(nblk - kp.halo_blocks, kMaxBlocksPerTile) : 0u;
-                kp.max_blocks = wpt + kp.halo_blocks + 1;
+                kp.max_windows = wpt;
             }
             if (wpt >= 1 && (uint32_t)ts_k_lds_bytes(&kp) <= kMaxLds) return true;
             if (nch <= nch_min) break;
@@ -365,7 +358,7 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
         c->why_not = "mixed-length pattern set";
     } else {
         std::vector<uint32_t> table;
-        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows, c->table_replicas, c->fc_bytes, c->fc_byte_table)) {
+        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows, c->fc_bytes, c->fc_byte_table)) {
             c->why_not = "pattern length outside 3..8 or non-ACGT pattern";
         } else {
             c->k = kmin;

@@ -80,12 +80,6 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
     return x;
 }
 
-// bits [lo, hi) of a 64-bit word, 0 <= lo < hi <= 64
-__device__ __forceinline__ u64 mask64(uint32_t lo, uint32_t hi) {
-    u64 m = (hi >= 64u) ? ~0ull : ((1ull << hi) - 1ull);
-    return m & (~0ull << lo);
-}
-
 // clear bits [lo, hi) of a bit plane held as dwords (hi - lo <= 31)
 __device__ __forceinline__ void plane_clear(uint32_t *p, uint32_t lo, uint32_t hi) {
     const uint32_t d0 = lo >> 5, d1 = (hi - 1u) >> 5;
@@ -101,30 +95,31 @@ __device__ __forceinline__ void plane_clear(uint32_t *p, uint32_t lo, uint32_t h
 
 __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
-// LDS: [match table][wave 0 slice][wave 1 slice]...; a slice = codes | M | F | C | nuc | blk
+// LDS: [match table][wave 0 slice][wave 1 slice]...; a slice = codes | M | F | C | cnt | rec
 //   codes   2-bit codes, one dword per 16 positions
 //   M F C   bit planes (match / forward / canonical), one halfword per 16 positions
-//   nuc     four byte planes: number of valid A, C, G, T among each dword's 16 positions
-//   blk     [0, 4 NB) nucleotide counts of the tile's windows; then 6 match counters per step block
-struct SliceLayout { uint32_t codes, pM, pF, pC, nuc, nuc_stride, blk, bytes; };
+//   cnt     eight byte planes, one byte per 16 positions: valid A, C, G, T and canonical,
+//           non-canonical, forward, reverse matches among them (the order of a window record)
+//   rec     the tile's window records while they are assembled, 8 x u32 per window
+struct SliceLayout { uint32_t codes, pM, pF, pC, cnt, cnt_stride, rec, bytes; };
 
 __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     SliceLayout s;
     uint32_t o = 0;
-    s.codes = o; o += align16(P.nch * 63u * 4u + 16u);
-    const uint32_t pb = align16(P.nch * 63u * 2u + 16u);
+    s.codes = o; o += align16(P.nch * 63u * 4u);
+    const uint32_t pb = align16(P.nch * 63u * 2u);
     s.pM = o; o += pb;
     s.pF = o; o += pb;
     s.pC = o; o += pb;
-    s.nuc_stride = align16(P.nch * 63u + 16u);
-    s.nuc = o; o += 4u * s.nuc_stride;
-    s.blk = o; o += align16(P.max_blocks * TS_BLK_COUNTERS * 4u);
+    s.cnt_stride = (P.nch * 63u + 7u) & ~7u;
+    s.cnt = o; o += align16(8u * s.cnt_stride);
+    s.rec = o; o += align16(P.max_windows * 32u);
     s.bytes = o;
     return s;
 }
 
 __host__ __device__ inline uint32_t lds_total(const TsScanParams &P) {
-    return (P.table_rows << P.row_shift) + P.fc_bytes + P.waves_per_wg * slice_layout(P).bytes;
+    return P.table_rows * 4u + P.fc_bytes + P.waves_per_wg * slice_layout(P).bytes;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -138,7 +133,7 @@ void ts_scan_tiles(const TsScanParams P) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 
     // the replicated bit table is loaded once and stays for the lifetime of the workgroup
-    const uint32_t table_bytes = (P.table_rows << P.row_shift) + P.fc_bytes;      // pair table + flag table
+    const uint32_t table_bytes = P.table_rows * 4u + P.fc_bytes;                  // pair table + flag table
     {
         const uint4 *src = (const uint4 *)P.table;
         uint4 *dst = (uint4 *)lds_raw;
@@ -153,16 +148,14 @@ void ts_scan_tiles(const TsScanParams P) {
     uint16_t *pM = (uint16_t *)(slice + SL.pM);
     uint16_t *pF = (uint16_t *)(slice + SL.pF);
     uint16_t *pC = (uint16_t *)(slice + SL.pC);
-    unsigned char *nuc = slice + SL.nuc;
-    const uint32_t NS = SL.nuc_stride;
-    uint32_t *blk = (uint32_t *)(slice + SL.blk);
-    const uint32_t NB = P.max_blocks;             // blk[counter * NB + block]
+    unsigned char *cnt = slice + SL.cnt;
+    const uint32_t NS = SL.cnt_stride;
+    uint32_t *rec = (uint32_t *)(slice + SL.rec);
 
     const uint32_t k = P.k;
     const uint32_t rowbits = 2u * (k + 1u) - 4u;      // pair table: 4^(k+1) entries, 16 per dword
-    const uint32_t repoff = (lane & P.rep_mask) * 4u;
     const uint32_t kmask = (1u << (2u * k)) - 1u;
-    const uint32_t *fc_table = (const uint32_t *)(lds_raw + (P.table_rows << P.row_shift));
+    const uint32_t *fc_table = (const uint32_t *)(lds_raw + P.table_rows * 4u);
     const unsigned char *fc_bytes = (const unsigned char *)fc_table;
     // LDS byte address of the table (it sits at the dynamic-LDS base)
     const uint32_t tab_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw;
@@ -176,17 +169,13 @@ void ts_scan_tiles(const TsScanParams P) {
         const TsTile T = P.tiles[tile];           // wave-uniform: scalar loads
         const uint32_t sh = (uint32_t)(T.in_off & 15ull);
         const unsigned char *src = P.in + (T.in_off - sh);
-        const uint32_t nblk = T.nwin + P.halo_blocks;             // step blocks whose partials are needed
+        const uint32_t nblk = T.nwin + P.halo_blocks;             // step blocks the tile's windows reach into
         const uint32_t span = nblk * P.s;
-        const uint32_t count_lim = T.nrel < span ? T.nrel : span;  // u-range that is ever counted
         const uint32_t xend = sh + T.nrel;                         // plane coord of the segment end
         uint32_t need = sh + (T.nrel < span + 16u ? T.nrel : span + 16u);
         uint32_t nch = (need + 16u + TS_CHUNK - 1u) / TS_CHUNK;
         if (nch > P.nch) nch = P.nch;
         bool has_invalid = false;
-
-        if (P.windows_on)
-            for (uint32_t i = lane; i < NB * TS_BLK_COUNTERS; i += 64u) blk[i] = 0;
 
         // ------------------------------------------------------------------ phase 1
         // Chunk c+1's 16 B/lane load is in flight while chunk c is resolved; the loop is unrolled
@@ -240,7 +229,7 @@ void ts_scan_tiles(const TsScanParams P) {
             for (int j = 0; j < 8; ++j) {
                 tmp[j] = (j == 0) ? w2 : __builtin_amdgcn_alignbit(nxt, w2, 4 * j);
                 const uint32_t row = __builtin_amdgcn_ubfe(tmp[j], 4, rowbits);
-                const uint32_t addr = tab_base + (row << P.row_shift) + repoff;
+                const uint32_t addr = tab_base + (row << 2);
                 asm volatile("ds_read_b32 %0, %1" : "=v"(ent[j]) : "v"(addr));
             }
             uint32_t aM = 0;
@@ -295,11 +284,18 @@ void ts_scan_tiles(const TsScanParams P) {
                 pM[h] = (uint16_t)M16;
                 pF[h] = (uint16_t)F16;
                 pC[h] = (uint16_t)C16;
-                unsigned char *np = nuc + h;
-                np[0] = (unsigned char)nA;
-                np[NS] = (unsigned char)(nL - nG);
-                np[2u * NS] = (unsigned char)nG;
-                np[3u * NS] = (unsigned char)(nH - nG);
+                if (P.windows_on) {
+                    const uint32_t nC16 = __popc(C16), nF16 = __popc(F16), nM16 = __popc(M16);
+                    unsigned char *np = cnt + h;
+                    np[0] = (unsigned char)nA;
+                    np[NS] = (unsigned char)(nL - nG);
+                    np[2u * NS] = (unsigned char)nG;
+                    np[3u * NS] = (unsigned char)(nH - nG);
+                    np[4u * NS] = (unsigned char)nC16;
+                    np[5u * NS] = (unsigned char)(nM16 - nC16);
+                    np[6u * NS] = (unsigned char)nF16;
+                    np[7u * NS] = (unsigned char)(nM16 - nF16);
+                }
             }
         };
         {
@@ -333,128 +329,104 @@ void ts_scan_tiles(const TsScanParams P) {
             __builtin_amdgcn_wave_barrier();
         }
 
-        // ------------------------------------------------------------------ phase 2a
+        // ------------------------------------------------------------------ phase 2: windows
+        // One lane per (window, field).  A field is the sum of its byte plane over the dwords that
+        // lie wholly inside the field's range (aligned ds reads, v_sad_u8 adds four bytes at a time)
+        // plus the two partial dwords at the ends, counted from the codes / bit planes.
+        // Nucleotides range over the window [us, ue); matches over the starts that keep the k-mer
+        // inside it, [us, ue - k + 1) (analyzeWindow counts a match only when it ends in the window).
         if (P.windows_on) {
-            const uint32_t ngran = (sh + count_lim + 63u) >> 6;
-            const u64 *gM = (const u64 *)pM, *gF = (const u64 *)pF, *gC = (const u64 *)pC;
-            for (uint32_t g = lane; g < ngran; g += 64u) {
-                const uint32_t gx = g << 6;
-                const uint32_t x_lo = gx > sh ? gx : sh;
-                const uint32_t x_hi = (gx + 64u < sh + count_lim) ? gx + 64u : sh + count_lim;
-                if (x_lo >= x_hi) continue;
-                const uint32_t u0 = x_lo - sh, u1 = x_hi - sh;
-                // block index / offset of u0 (u0 < 2^22: multiply-high by ceil(2^32/s), then fix up)
-                uint32_t b0 = __umulhi(u0, P.s_inv);
-                if (b0 * P.s > u0) --b0;
-                uint32_t o0 = u0 - b0 * P.s;
-                if (o0 >= P.s) { o0 -= P.s; ++b0; }
-
-                {   // matches, split at offsets {0, hh+1} of every step block
-                    const u64 M = gM[g], F = gF[g], C = gC[g];
-                    if (M && !(TS_ABL & 4)) {
-                        uint32_t u = u0, b = b0, o = o0;
-                        while (u < u1) {
-                            const bool head = o <= P.hh;
-                            uint32_t eu = head ? (u - o + P.hh + 1u) : (u - o + P.s);
-                            if (eu > u1) eu = u1;
-                            const u64 m = mask64(u + sh - gx, eu + sh - gx);
-                            const uint32_t nm = __popcll(M & m);
-                            if (nm) {
-                                uint32_t *a = &blk[(head ? 4u : 7u) * NB + b];
-                                const uint32_t nf = __popcll(F & m), nc = __popcll(C & m);
-                                atomicAdd(&a[0], nm);
-                                if (nc) atomicAdd(&a[NB], nc);
-                                if (nf) atomicAdd(&a[2u * NB], nf);
-                            }
-                            o += eu - u; u = eu;
-                            if (o >= P.s) { o = 0; ++b; }
-                        }
-                    }
+            auto plane_sum = [&](const unsigned char *plane, uint32_t ha, uint32_t he, uint32_t acc) -> uint32_t {
+                const uint32_t *pl = (const uint32_t *)plane;         // bytes ha .. he-1, ha < he
+                uint32_t d = ha >> 2;
+                const uint32_t db = (he - 1u) >> 2;
+                const uint32_t m0 = ~0u << (8u * (ha & 3u));
+                const uint32_t m1 = ~0u >> (8u * (3u - ((he - 1u) & 3u)));
+                uint32_t v0 = pl[d] & m0;
+                if (d == db) v0 &= m1;
+                acc = __builtin_amdgcn_sad_u8(v0, 0u, acc);
+                ++d;
+                for (; d + 4u <= db; d += 4u) {
+                    acc = __builtin_amdgcn_sad_u8(pl[d], 0u, acc);
+                    acc = __builtin_amdgcn_sad_u8(pl[d + 1u], 0u, acc);
+                    acc = __builtin_amdgcn_sad_u8(pl[d + 2u], 0u, acc);
+                    acc = __builtin_amdgcn_sad_u8(pl[d + 3u], 0u, acc);
                 }
-            }
-        }
-
-        // ------------------------------------- nucleotide counts: one lane per (window, A|C|G|T)
-        // count = sum of the field's byte plane over the dwords wholly inside the window (aligned
-        // ds reads, v_sad_u8 adds four at a time) + the two partial dwords at the window's ends,
-        // counted from the 2-bit codes.
-        if (P.windows_on && P.nuc_on && !(TS_ABL & 2)) {
+                for (; d < db; ++d) acc = __builtin_amdgcn_sad_u8(pl[d], 0u, acc);
+                if (d == db) acc = __builtin_amdgcn_sad_u8(pl[db] & m1, 0u, acc);
+                return acc;
+            };
             const uint32_t nitems = T.nwin * 4u;
-            for (uint32_t it = lane; it < nitems; it += 64u) {
-                const uint32_t i = it >> 2, f = it & 3u;
-                const uint32_t us = i * P.s;
-                const uint32_t ue = us + P.w < T.nrel ? us + P.w : T.nrel;
-                const uint32_t xs = sh + us, xe = sh + ue;           // plane coords, xs < xe
-                const uint32_t hs = xs >> 4, he = xe >> 4;
-                // the field's code: A0 C1 G3 T2 -> bits to flip so that "equal" reads as 1/1
-                const uint32_t code = (f == 2u) ? 3u : (f == 3u ? 2u : f);
-                const uint32_t xl = (code & 1u) ? 0u : 0x55555555u, xh = (code & 2u) ? 0u : 0x55555555u;
-                const uint32_t letter = (0x54474341u >> (8u * f)) & 0xFFu;
-                auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // lo < hi <= 16, hi - lo < 16
-                    if (has_invalid) {                                // rare: re-read the bases themselves
-                        uint32_t n = 0;
-                        for (uint32_t pp = lo; pp < hi; ++pp)
-                            n += ((uint32_t)src[h * 16u + pp] & (P.fold_mask & 0xFFu)) == letter;
-                        return n;
-                    }
-                    const uint32_t m = (((1u << (2u * (hi - lo))) - 1u) << (2u * lo)) & 0x55555555u;
-                    const uint32_t cd = codes[h];
-                    return __popc((cd ^ xl) & ((cd >> 1) ^ xh) & m);
-                };
-                uint32_t val = 0;
-                if (hs == he) {
-                    val = partial(hs, xs & 15u, xe & 15u);
-                } else {
-                    uint32_t ha = hs;
-                    if (xs & 15u) { val += partial(hs, xs & 15u, 16u); ++ha; }
-                    if (xe & 15u) val += partial(he, 0u, xe & 15u);
-                    if (ha < he) {                                    // whole dwords ha .. he-1
-                        const uint32_t *pl = (const uint32_t *)(nuc + f * NS);
-                        uint32_t d = ha >> 2;
-                        const uint32_t db = (he - 1u) >> 2;
-                        const uint32_t m0 = ~0u << (8u * (ha & 3u));
-                        const uint32_t m1 = ~0u >> (8u * (3u - ((he - 1u) & 3u)));
-                        uint32_t v0 = pl[d] & m0;
-                        if (d == db) v0 &= m1;
-                        val = __builtin_amdgcn_sad_u8(v0, 0u, val);
-                        ++d;
-                        for (; d + 4u <= db; d += 4u) {
-                            val = __builtin_amdgcn_sad_u8(pl[d], 0u, val);
-                            val = __builtin_amdgcn_sad_u8(pl[d + 1u], 0u, val);
-                            val = __builtin_amdgcn_sad_u8(pl[d + 2u], 0u, val);
-                            val = __builtin_amdgcn_sad_u8(pl[d + 3u], 0u, val);
-                        }
-                        for (; d < db; ++d) val = __builtin_amdgcn_sad_u8(pl[d], 0u, val);
-                        if (d == db) val = __builtin_amdgcn_sad_u8(pl[db] & m1, 0u, val);
-                    }
-                }
-                blk[it] = val;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
 
-        // ------------------------------------------------- phase 2b: window records, 8 x u32 each
-        if (P.windows_on && !(TS_ABL & 8)) {
-            const uint32_t nitems = T.nwin * 8u;
-            uint32_t *wout = P.windows_out + T.win_out * 8ull;
-            for (uint32_t it = lane; it < nitems; it += 64u) {
-                const uint32_t i = it >> 3, f = it & 7u;
-                uint32_t val;
-                if (f < 4u) {                                       // A C G T, counted above
-                    val = blk[i * 4u + f];
-                } else {                                            // covered bases = k x count
-                    const uint32_t *mh = &blk[4u * NB], *mr = &blk[7u * NB];
-                    const uint32_t sel = (f & 2u) ? 2u * NB : NB;   // canonical (f=4,5) or forward (f=6,7)
-                    uint32_t mm = 0, ms = 0;
-                    for (uint32_t j = 0; j < P.qq; ++j) {
-                        mm += mh[i + j] + mr[i + j];
-                        ms += mh[sel + i + j] + mr[sel + i + j];
+            if (P.nuc_on && !(TS_ABL & 2)) {
+                for (uint32_t it = lane; it < nitems; it += 64u) {
+                    const uint32_t i = it >> 2, f = it & 3u;              // f: A C G T
+                    const uint32_t us = i * P.s;
+                    const uint32_t ue = us + P.w < T.nrel ? us + P.w : T.nrel;
+                    const uint32_t xs = sh + us, xe = sh + ue;           // plane coords, xs < xe
+                    const uint32_t hs = xs >> 4, he = xe >> 4;
+                    // the field's code (A0 C1 G3 T2) as the bits to flip so that "equal" reads 1/1
+                    const uint32_t code = (f == 2u) ? 3u : (f == 3u ? 2u : f);
+                    const uint32_t xl = (code & 1u) ? 0u : 0x55555555u, xh = (code & 2u) ? 0u : 0x55555555u;
+                    const uint32_t letter = (0x54474341u >> (8u * f)) & 0xFFu;
+                    auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // 0 < hi - lo < 16
+                        if (has_invalid) {                                // rare: re-read the bases themselves
+                            uint32_t n = 0;
+                            for (uint32_t pp = lo; pp < hi; ++pp)
+                                n += ((uint32_t)src[h * 16u + pp] & (P.fold_mask & 0xFFu)) == letter;
+                            return n;
+                        }
+                        const uint32_t m = (((1u << (2u * (hi - lo))) - 1u) << (2u * lo)) & 0x55555555u;
+                        const uint32_t cd = codes[h];
+                        return __popc((cd ^ xl) & ((cd >> 1) ^ xh) & m);
+                    };
+                    uint32_t val = 0;
+                    if (hs == he) {
+                        val = partial(hs, xs & 15u, xe & 15u);
+                    } else {
+                        uint32_t ha = hs;
+                        if (xs & 15u) { val += partial(hs, xs & 15u, 16u); ++ha; }
+                        if (xe & 15u) val += partial(he, 0u, xe & 15u);
+                        if (ha < he) val = plane_sum(cnt + f * NS, ha, he, val);
                     }
-                    mm += mh[i + P.qq];
-                    ms += mh[sel + i + P.qq];
-                    val = ((f & 1u) ? (mm - ms) : ms) * k;
+                    rec[i * 8u + f] = val;
                 }
-                wout[it] = val;
+            }
+
+            if (!(TS_ABL & 4)) {
+                for (uint32_t it = lane; it < nitems; it += 64u) {
+                    const uint32_t i = it >> 2, f = it & 3u;              // f: canonical, non-canonical, forward, reverse
+                    const uint32_t us = i * P.s;
+                    const uint32_t ue = us + P.w < T.nrel ? us + P.w : T.nrel;
+                    uint32_t val = 0;
+                    if (ue - us >= k) {
+                        const uint32_t xs = sh + us, xe = sh + ue - k + 1u;
+                        const uint32_t hs = xs >> 4, he = xe >> 4;
+                        const uint16_t *pQ = (f & 2u) ? pF : pC;
+                        const uint32_t inv = (f & 1u) ? 0xFFFFu : 0u;
+                        auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // 0 < hi - lo < 16
+                            const uint32_t m = ((1u << (hi - lo)) - 1u) << lo;
+                            return __popc((uint32_t)pM[h] & ((uint32_t)pQ[h] ^ inv) & m);
+                        };
+                        if (hs == he) {
+                            val = partial(hs, xs & 15u, xe & 15u);
+                        } else {
+                            uint32_t ha = hs;
+                            if (xs & 15u) { val += partial(hs, xs & 15u, 16u); ++ha; }
+                            if (xe & 15u) val += partial(he, 0u, xe & 15u);
+                            if (ha < he) val = plane_sum(cnt + (4u + f) * NS, ha, he, val);
+                        }
+                    }
+                    rec[i * 8u + 4u + f] = val * k;                    // covered bases
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // records leave as whole dwords in order: 8 x u32 per window, coalesced
+            if (!(TS_ABL & 8)) {
+                uint32_t *wout = P.windows_out + T.win_out * 8ull;
+                for (uint32_t it = lane; it < T.nwin * 8u; it += 64u)
+                    wout[it] = (P.nuc_on || (it & 4u)) ? rec[it] : 0u;
             }
         }
 

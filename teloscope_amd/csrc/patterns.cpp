@@ -1,3 +1,4 @@
+#include <cstdlib>
 // patterns.cpp — host-side pattern preparation of libteloscan (C++17).
 //
 // Product restatement of the reference's pattern expansion
@@ -165,13 +166,14 @@ int base_code(char c) {
 
 // Match tables for uniform-length pattern sets (k-mer index x: base i at bits 2i..2i+1).
 //  * pair table: indexed by the (k+1)-mer y = bases p..p+k; entry = 2 bits {x(p) is a pattern,
-//    x(p+1) is a pattern}, 16 entries per dword (row = y >> 4), each row replicated R times so
-//    that the lanes of a ds_read_b32 group spread over the LDS banks (R = 8 / 2 / 1 for k <= 6 / 7 / 8);
+//    x(p+1) is a pattern}, 16 entries per dword (row = y >> 4).  Not replicated: the kernel is
+//    bound by VALU issue, and spreading rows over the LDS banks (8 copies) bought 0.4 % when it
+//    was measured, while the 28 KB it cost is what the per-wave count planes now live in;
 //  * flag table: {forward, canonical} per k-mer, looked up only at matched positions: one byte
 //    per k-mer for k <= 7 (cheapest lookup), 2 bits per k-mer at k = 8 (LDS capacity).
-// Layout in `table`: [rows x R dwords][flag table].
+// Layout in `table`: [rows dwords][flag table].
 bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
-                       uint32_t &rows, uint32_t &replicas, uint32_t &fc_bytes, bool &fc_byte_table) {
+                       uint32_t &rows, uint32_t &fc_bytes, bool &fc_byte_table) {
     if (k < 3 || k > 8) return false;
     const uint64_t nk = 1ull << (2 * k);
     std::vector<uint8_t> m(nk, 0), fl(nk, 0);
@@ -188,19 +190,17 @@ bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector
     }
     const uint64_t npairs = nk * 4;                                   // (k+1)-mers
     rows = static_cast<uint32_t>(npairs / 16);
-    replicas = k <= 6 ? 8u : (k == 7 ? 2u : 1u);
     fc_byte_table = k <= 7;
     const size_t fc_words = static_cast<size_t>(std::max<uint64_t>(fc_byte_table ? nk / 4 : nk / 16, 4));
     fc_bytes = static_cast<uint32_t>(fc_words * 4);
-    table.assign(static_cast<size_t>(rows) * replicas + fc_words, 0u);
+    table.assign(static_cast<size_t>(rows) + fc_words, 0u);
     const uint32_t kmask = static_cast<uint32_t>(nk - 1);
     for (uint64_t y = 0; y < npairs; ++y) {
         const uint32_t bits = (m[y & kmask] ? 1u : 0u) | (m[(y >> 2) & kmask] ? 2u : 0u);
         if (!bits) continue;
-        for (uint32_t rep = 0; rep < replicas; ++rep)
-            table[(y >> 4) * replicas + rep] |= bits << (2 * (y & 15));
+        table[y >> 4] |= bits << (2 * (y & 15));
     }
-    uint32_t *fc = &table[static_cast<size_t>(rows) * replicas];
+    uint32_t *fc = &table[rows];
     for (uint64_t x = 0; x < nk; ++x) {
         if (fc_byte_table) fc[x >> 2] |= static_cast<uint32_t>(fl[x]) << (8 * (x & 3));
         else fc[x >> 4] |= static_cast<uint32_t>(fl[x]) << (2 * (x & 15));

@@ -29,7 +29,7 @@ struct TsTile {                 // 32 bytes
 struct TsScanParams {
     const uint8_t  *in;
     const TsTile   *tiles;
-    const uint32_t *table;      // pair table (rows x replicas dwords) followed by the flag table (fc_bytes)
+    const uint32_t *table;      // pair table (table_rows dwords) followed by the flag table (fc_bytes)
     uint32_t       *windows_out;    // 8 x u32 per window
     uint32_t       *matches_out;    // packed records, one region of region_cap records per wave
     unsigned long long *tile_off;   // tile directory: first record of each tile (index into matches_out)
@@ -41,16 +41,11 @@ struct TsScanParams {
     uint32_t        table_rows;     // 4^(k+1) / 16
     uint32_t        fc_bytes;       // flag table size in bytes (16-byte multiple)
     uint32_t        fc_byte_table;  // 1: one byte {forward, canonical} per k-mer; 0: 2 bits per k-mer
-    uint32_t        row_shift;      // log2(bytes per table row) = log2(replicas * 4)
-    uint32_t        rep_mask;       // replicas - 1 (replica = lane & rep_mask)
     uint32_t        k;              // pattern length
     uint32_t        s, w;           // step and window (tips mode: s = w = tile size)
-    uint32_t        s_inv;          // ceil(2^32 / s) for multiply-high division by s
-    uint32_t        q, r;           // w = q*s + r
-    uint32_t        halo_blocks;    // step blocks read beyond the owned ones: q, or q-1 when r == 0
-    uint32_t        qq, hh;         // w - k = qq*s + hh
+    uint32_t        halo_blocks;    // step blocks read beyond the owned ones: ceil(w / s) - 1
     uint32_t        nch;            // chunks of TS_CHUNK positions per tile
-    uint32_t        max_blocks;     // rows of the LDS block accumulators
+    uint32_t        max_windows;    // windows per tile (rows of the LDS record buffer)
     uint32_t        fold_mask;      // 0xDFDFDFDF (fold case) or 0xFFFFFFFF
     uint32_t        straddle_fix;   // 1: w == s, drop matches that straddle a window end
     uint32_t        windows_on;     // 0 in tips-only mode
