@@ -110,7 +110,8 @@ uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 constexpr uint32_t kMaxLds = 160u * 1024u;
 constexpr uint32_t kMaxBlocksPerTile = 448;
-constexpr uint32_t kPreferredChunks = 8;       // ~8 k positions per wave tile
+constexpr uint32_t kMaxChunks = 16;            // tiles up to ~16 k positions per wave
+constexpr uint32_t kTipsChunks = 8;            // tips-only / read batches: ~8 k positions per tile
 
 // Chooses waves per workgroup, chunks per tile and windows per tile so that the match table plus
 // one LDS slice per wave fit in 160 KB; false if even one wave cannot hold one window.
@@ -133,28 +134,43 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
         kp.windows_on = 1;
         kp.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u;
     }
-    for (uint32_t waves = 16; waves >= 1; waves >>= 1) {
-        kp.waves_per_wg = waves;
-        // smallest tile that holds one window, then grow towards the preferred size
-        uint32_t nch_min = 1;
-        if (!tips) nch_min = (uint32_t)ceil_div((uint64_t)(1 + kp.halo_blocks) * kp.s + 63, TS_CHUNK);
-        for (uint32_t nch = std::max(nch_min, kPreferredChunks);; --nch) {
-            kp.nch = nch;
+    // Search (waves per workgroup, chunks per tile) for the best modelled throughput:
+    //   owned bases per tile x occupancy factor / instructions per tile.
+    // Instructions: ~272 per chunk (decode, probes, planes, emit), ~200 per pass of the window loops
+    // (64 window fields per pass), ~100 fixed.  Occupancy factors are measured (profiles/r01/
+    // geometry_sweep.txt): the kernel is VALU-bound at 16 waves per CU and loses 12 % at 12, 31 % at 8.
+    static const struct { uint32_t waves; double factor; } kOccupancy[] = {
+        {16, 1.0}, {12, 0.88}, {8, 0.69}, {4, 0.43}, {2, 0.22}, {1, 0.11}};
+    uint32_t nch_min = 1;
+    if (!tips) nch_min = (uint32_t)ceil_div((uint64_t)(1 + kp.halo_blocks) * kp.s + 63, TS_CHUNK);
+    const uint32_t nch_max = tips ? kTipsChunks : std::max(nch_min, kMaxChunks);
+    double best = 0.0;
+    TsScanParams best_kp{};
+    uint32_t best_wpt = 0;
+    for (const auto &occ : kOccupancy) {
+        for (uint32_t nch = nch_min; nch <= nch_max; ++nch) {
+            TsScanParams cand = kp;
+            cand.waves_per_wg = occ.waves;
+            cand.nch = nch;
             const uint32_t span_max = nch * TS_CHUNK - 63u;
+            uint32_t cwpt;
             if (tips) {
                 const uint32_t tb = span_max & ~15u;            // one pseudo block per tile
-                kp.s = kp.w = tb;
-                kp.max_windows = 1;
-                wpt = 1;
+                cand.s = cand.w = tb;
+                cand.max_windows = 1;
+                cwpt = 1;
             } else {
-                const uint32_t nblk = span_max / kp.s;
-                wpt = nblk > kp.halo_blocks ? std::min<uint32_t>(nblk - kp.halo_blocks, kMaxBlocksPerTile) : 0u;
-                kp.max_windows = wpt;
+                const uint32_t nblk = span_max / cand.s;
+                cwpt = nblk > cand.halo_blocks ? std::min<uint32_t>(nblk - cand.halo_blocks, kMaxBlocksPerTile) : 0u;
+                cand.max_windows = cwpt;
             }
-            if (wpt >= 1 && (uint32_t)ts_k_lds_bytes(&kp) <= kMaxLds) return true;
-            if (nch <= nch_min) break;
+            if (cwpt < 1 || (uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) continue;
+            const double passes = tips ? 0.0 : (double)ceil_div((uint64_t)cwpt * 4, 64);
+            const double score = (double)cwpt * cand.s * occ.factor / (272.0 * nch + 200.0 * passes + 100.0);
+            if (score > best) { best = score; best_kp = cand; best_wpt = cwpt; }
         }
     }
+    if (best > 0.0) { kp = best_kp; wpt = best_wpt; return true; }
     why = "window/step geometry does not fit the 160 KB LDS of a CU";
     return false;
 }

@@ -111,9 +111,9 @@ __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     s.pM = o; o += pb;
     s.pF = o; o += pb;
     s.pC = o; o += pb;
-    s.cnt_stride = (P.nch * 63u + 7u) & ~7u;
-    s.cnt = o; o += align16(8u * s.cnt_stride);
-    s.rec = o; o += align16(P.max_windows * 32u);
+    s.cnt_stride = (P.nch * 63u + 3u) & ~3u;
+    s.cnt = o; o += P.windows_on ? align16(8u * s.cnt_stride) : 0u;     // tips-only scans keep no counts
+    s.rec = o; o += P.windows_on ? align16(P.max_windows * 32u) : 0u;
     s.bytes = o;
     return s;
 }
