@@ -38,7 +38,11 @@
 namespace {
 
 typedef unsigned long long u64;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// LDS pointers are declared in their own address space so that indexing stays 32-bit arithmetic
+#define LDS __attribute__((address_space(3)))
+typedef LDS unsigned char lds_u8;
+typedef LDS uint16_t lds_u16;
+typedef LDS uint32_t lds_u32;
 
 // Wave-wide inclusive prefix sum in 6 DPP adds (row_shr 1/2/4/8 inside each row of 16,
 // then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3); no LDS traffic.
@@ -81,7 +85,8 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
 }
 
 // clear bits [lo, hi) of a bit plane held as dwords (hi - lo <= 31)
-__device__ __forceinline__ void plane_clear(uint32_t *p, uint32_t lo, uint32_t hi) {
+__device__ __forceinline__ void plane_clear(lds_u16 *p16, uint32_t lo, uint32_t hi) {
+    uint32_t *p = (uint32_t *)p16;
     const uint32_t d0 = lo >> 5, d1 = (hi - 1u) >> 5;
     const uint32_t m0 = ~0u << (lo & 31u);
     const uint32_t m1 = ~0u >> (31u - ((hi - 1u) & 31u));
@@ -98,10 +103,12 @@ __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15
 // LDS: [match table][wave 0 slice][wave 1 slice]...; a slice = codes | M | F | C | cnt | rec
 //   codes   2-bit codes, one dword per 16 positions
 //   M F C   bit planes (match / forward / canonical), one halfword per 16 positions
-//   cnt     eight byte planes, one byte per 16 positions: valid A, C, G, T and canonical,
-//           non-canonical, forward, reverse matches among them (the order of a window record)
+//   cnt     one byte per 16 positions (a "dword" h of the planes) and window-record field: valid
+//           A, C, G, T and canonical, non-canonical, forward, reverse matches among the 16.
+//           Layout [h / 4][field][h % 4]: a field's counts of four consecutive h share a dword
+//           (summed by one v_sad_u8), and a lane's eight counts of one h sit at fixed offsets
 //   rec     the tile's window records while they are assembled, 8 x u32 per window
-struct SliceLayout { uint32_t codes, pM, pF, pC, cnt, cnt_stride, rec, bytes; };
+struct SliceLayout { uint32_t codes, pM, pF, pC, cnt, rec, bytes; };
 
 __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     SliceLayout s;
@@ -111,8 +118,7 @@ __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     s.pM = o; o += pb;
     s.pF = o; o += pb;
     s.pC = o; o += pb;
-    s.cnt_stride = (P.nch * 63u + 3u) & ~3u;
-    s.cnt = o; o += P.windows_on ? align16(8u * s.cnt_stride) : 0u;     // tips-only scans keep no counts
+    s.cnt = o; o += P.windows_on ? ((P.nch * 63u + 3u) >> 2) * 32u : 0u;      // tips-only scans keep no counts
     s.rec = o; o += P.windows_on ? align16(P.max_windows * 32u) : 0u;
     s.bytes = o;
     return s;
@@ -143,22 +149,22 @@ void ts_scan_tiles(const TsScanParams P) {
     __syncthreads();                              // the only workgroup barrier in the kernel
 
     const SliceLayout SL = slice_layout(P);
-    unsigned char *slice = lds_raw + table_bytes + wave * SL.bytes;
-    uint32_t *codes = (uint32_t *)(slice + SL.codes);
-    uint16_t *pM = (uint16_t *)(slice + SL.pM);
-    uint16_t *pF = (uint16_t *)(slice + SL.pF);
-    uint16_t *pC = (uint16_t *)(slice + SL.pC);
-    unsigned char *cnt = slice + SL.cnt;
-    const uint32_t NS = SL.cnt_stride;
-    uint32_t *rec = (uint32_t *)(slice + SL.rec);
+    lds_u8 *lds = (lds_u8 *)lds_raw;
+    lds_u8 *slice = lds + table_bytes + wave * SL.bytes;
+    lds_u32 *codes = (lds_u32 *)(slice + SL.codes);
+    lds_u16 *pM = (lds_u16 *)(slice + SL.pM);
+    lds_u16 *pF = (lds_u16 *)(slice + SL.pF);
+    lds_u16 *pC = (lds_u16 *)(slice + SL.pC);
+    lds_u8 *cnt = slice + SL.cnt;
+    lds_u32 *rec = (lds_u32 *)(slice + SL.rec);
 
     const uint32_t k = P.k;
     const uint32_t rowbits = 2u * (k + 1u) - 4u;      // pair table: 4^(k+1) entries, 16 per dword
     const uint32_t kmask = (1u << (2u * k)) - 1u;
-    const uint32_t *fc_table = (const uint32_t *)(lds_raw + P.table_rows * 4u);
-    const unsigned char *fc_bytes = (const unsigned char *)fc_table;
+    const lds_u32 *fc_table = (const lds_u32 *)(lds + P.table_rows * 4u);
+    const lds_u8 *fc_bytes = (const lds_u8 *)fc_table;
     // LDS byte address of the table (it sits at the dynamic-LDS base)
-    const uint32_t tab_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw;
+    const uint32_t tab_base = (uint32_t)(uintptr_t)lds;
 
     const uint32_t total_waves = gridDim.x * P.waves_per_wg;
     const uint32_t gw = blockIdx.x * P.waves_per_wg + wave;
@@ -175,13 +181,14 @@ void ts_scan_tiles(const TsScanParams P) {
         uint32_t need = sh + (T.nrel < span + 16u ? T.nrel : span + 16u);
         uint32_t nch = (need + 16u + TS_CHUNK - 1u) / TS_CHUNK;
         if (nch > P.nch) nch = P.nch;
+        nch = (uint32_t)__builtin_amdgcn_readfirstlane((int)nch);
         bool has_invalid = false;
 
         // ------------------------------------------------------------------ phase 1
         // Chunk c+1's 16 B/lane load is in flight while chunk c is resolved; the loop is unrolled
         // by two with alternating registers so the loaded value is never copied (a copy would
         // make the compiler wait for the load it was meant to overlap).
-        auto resolve_chunk = [&](const uint32_t c, const uint4 v) {
+        auto resolve_chunk = [&](const uint32_t cpos, const uint32_t ch, const uint4 v) {   // cpos = c * TS_CHUNK, ch = c * 63
             // ASCII -> 2-bit codes (A0 C1 T2 G3) and a validity check, 4 bases per dword
             const uint32_t x[4] = {v.x, v.y, v.z, v.w};
             uint32_t t[4], e[4], sad = 0;
@@ -193,9 +200,9 @@ void ts_scan_tiles(const TsScanParams P) {
             }
             uint32_t w2 = pack16(t);
 
-            const uint32_t pos0 = c * TS_CHUNK + lane * 16u;     // plane coord of this lane's first base
+            const uint32_t pos0 = cpos + lane * 16u;             // plane coord of this lane's first base
             uint32_t inv16 = 0;
-            const bool slow = __any(sad != 0) || (c * TS_CHUNK + 1024u > xend);
+            const bool slow = __any(sad != 0) || (cpos + 1024u > xend);
             if (slow) {                                           // wave-uniform, rare
                 uint32_t b4[4];
 #pragma unroll
@@ -256,15 +263,18 @@ void ts_scan_tiles(const TsScanParams P) {
 #if TS_ABL & 16
             F16 = M16 & w2; C16 = M16 & nxt;
 #else
-            for (uint32_t m = M16 | 0x10000u; __any((m & 0xFFFFu) != 0u);) {
-                const uint32_t j = (uint32_t)__builtin_ctz(m);
-                const uint32_t idx = __builtin_amdgcn_alignbit(nxt, w2, 2u * j) & kmask;
-                uint32_t fc;
-                if (FC_BYTES) fc = fc_bytes[idx];
-                else fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
-                m = (m & (m - 1u)) | 0x10000u;
-                F16 |= (fc & 1u) << j;
-                C16 |= (fc >> 1) << j;
+            if (__any(M16 != 0u)) {
+                uint32_t m = M16 | 0x10000u;
+                do {
+                    const uint32_t j = (uint32_t)__builtin_ctz(m);
+                    const uint32_t idx = __builtin_amdgcn_alignbit(nxt, w2, 2u * j) & kmask;
+                    uint32_t fc;
+                    if (FC_BYTES) fc = fc_bytes[idx];
+                    else fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
+                    m = (m & (m - 1u)) | 0x10000u;
+                    F16 |= (fc & 1u) << j;
+                    C16 |= (fc >> 1) << j;
+                } while (__any((m & 0xFFFFu) != 0u));
             }
 #endif
             F16 &= 0xFFFFu; C16 &= 0xFFFFu;
@@ -279,38 +289,44 @@ void ts_scan_tiles(const TsScanParams P) {
             const uint32_t nA = __popc(sel) + nG - nL - nH;
 
             if (lane < 63u && !(TS_ABL & 64)) {
-                const uint32_t h = c * 63u + lane;
+                const uint32_t h = ch + lane;
                 codes[h] = w2;
                 pM[h] = (uint16_t)M16;
                 pF[h] = (uint16_t)F16;
                 pC[h] = (uint16_t)C16;
                 if (P.windows_on) {
                     const uint32_t nC16 = __popc(C16), nF16 = __popc(F16), nM16 = __popc(M16);
-                    unsigned char *np = cnt + h;
+                    lds_u8 *np = cnt + ((h >> 2) << 5) + (h & 3u);
                     np[0] = (unsigned char)nA;
-                    np[NS] = (unsigned char)(nL - nG);
-                    np[2u * NS] = (unsigned char)nG;
-                    np[3u * NS] = (unsigned char)(nH - nG);
-                    np[4u * NS] = (unsigned char)nC16;
-                    np[5u * NS] = (unsigned char)(nM16 - nC16);
-                    np[6u * NS] = (unsigned char)nF16;
-                    np[7u * NS] = (unsigned char)(nM16 - nF16);
+                    np[4] = (unsigned char)(nL - nG);
+                    np[8] = (unsigned char)nG;
+                    np[12] = (unsigned char)(nH - nG);
+                    np[16] = (unsigned char)nC16;
+                    np[20] = (unsigned char)(nM16 - nC16);
+                    np[24] = (unsigned char)nF16;
+                    np[28] = (unsigned char)(nM16 - nF16);
                 }
             }
         };
         {
             // loads are unconditional (the last one re-reads the final chunk) so that the wait
             // before each resolve is a counted vmcnt(1), never vmcnt(0)
-            const uint32_t last = nch - 1u;
-            uint4 va = *(const uint4 *)(src + lane * 16u), vb;
+            // (chunk offsets are carried as scalars that step by a constant: no vector multiplies)
+            const uint32_t last_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)((nch - 1u) * TS_CHUNK));
+            const unsigned char *lsrc = src + lane * 16u;
+            uint4 va = *(const uint4 *)lsrc, vb;
+            uint32_t cpos = 0, ch = 0;
             for (uint32_t c = 0; c < nch; c += 2u) {
-                const uint32_t c1 = c + 1u < last ? c + 1u : last;
-                vb = *(const uint4 *)(src + (size_t)c1 * TS_CHUNK + lane * 16u);
-                resolve_chunk(c, va);
+                const uint32_t p1 = cpos + TS_CHUNK < last_pos ? cpos + TS_CHUNK : last_pos;
+                vb = *(const uint4 *)(lsrc + p1);
+                __builtin_amdgcn_sched_barrier(0);         // the load is issued before chunk c is touched
+                resolve_chunk(cpos, ch, va);
                 if (c + 1u >= nch) break;
-                const uint32_t c2 = c + 2u < last ? c + 2u : last;
-                va = *(const uint4 *)(src + (size_t)c2 * TS_CHUNK + lane * 16u);
-                resolve_chunk(c + 1u, vb);
+                const uint32_t p2 = cpos + 2u * TS_CHUNK < last_pos ? cpos + 2u * TS_CHUNK : last_pos;
+                va = *(const uint4 *)(lsrc + p2);
+                __builtin_amdgcn_sched_barrier(0);
+                resolve_chunk(cpos + TS_CHUNK, ch + 63u, vb);
+                cpos += 2u * TS_CHUNK; ch += 126u;
             }
         }
         __builtin_amdgcn_wave_barrier();          // planes written above are read by other lanes below
@@ -321,9 +337,9 @@ void ts_scan_tiles(const TsScanParams P) {
                 const uint32_t hi = sh + (b + 1u) * P.s;
                 if (hi <= nch * TS_CHUNK) {
                     const uint32_t lo = hi - (k - 1u);
-                    plane_clear((uint32_t *)pM, lo, hi);
-                    plane_clear((uint32_t *)pF, lo, hi);
-                    plane_clear((uint32_t *)pC, lo, hi);
+                    plane_clear(pM, lo, hi);
+                    plane_clear(pF, lo, hi);
+                    plane_clear(pC, lo, hi);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -336,24 +352,26 @@ void ts_scan_tiles(const TsScanParams P) {
         // Nucleotides range over the window [us, ue); matches over the starts that keep the k-mer
         // inside it, [us, ue - k + 1) (analyzeWindow counts a match only when it ends in the window).
         if (P.windows_on) {
-            auto plane_sum = [&](const unsigned char *plane, uint32_t ha, uint32_t he, uint32_t acc) -> uint32_t {
-                const uint32_t *pl = (const uint32_t *)plane;         // bytes ha .. he-1, ha < he
+            // sum of field f's counts over the dwords ha .. he-1 of the planes (ha < he)
+            auto plane_sum = [&](uint32_t f, uint32_t ha, uint32_t he, uint32_t acc) -> uint32_t {
+                const lds_u32 *pl = (const lds_u32 *)cnt + f;        // group g of four h: pl[8 g]
                 uint32_t d = ha >> 2;
                 const uint32_t db = (he - 1u) >> 2;
                 const uint32_t m0 = ~0u << (8u * (ha & 3u));
                 const uint32_t m1 = ~0u >> (8u * (3u - ((he - 1u) & 3u)));
-                uint32_t v0 = pl[d] & m0;
+                uint32_t v0 = pl[8u * d] & m0;
                 if (d == db) v0 &= m1;
                 acc = __builtin_amdgcn_sad_u8(v0, 0u, acc);
                 ++d;
                 for (; d + 4u <= db; d += 4u) {
-                    acc = __builtin_amdgcn_sad_u8(pl[d], 0u, acc);
-                    acc = __builtin_amdgcn_sad_u8(pl[d + 1u], 0u, acc);
-                    acc = __builtin_amdgcn_sad_u8(pl[d + 2u], 0u, acc);
-                    acc = __builtin_amdgcn_sad_u8(pl[d + 3u], 0u, acc);
+                    const lds_u32 *q = pl + 8u * d;
+                    acc = __builtin_amdgcn_sad_u8(q[0], 0u, acc);
+                    acc = __builtin_amdgcn_sad_u8(q[8], 0u, acc);
+                    acc = __builtin_amdgcn_sad_u8(q[16], 0u, acc);
+                    acc = __builtin_amdgcn_sad_u8(q[24], 0u, acc);
                 }
-                for (; d < db; ++d) acc = __builtin_amdgcn_sad_u8(pl[d], 0u, acc);
-                if (d == db) acc = __builtin_amdgcn_sad_u8(pl[db] & m1, 0u, acc);
+                for (; d < db; ++d) acc = __builtin_amdgcn_sad_u8(pl[8u * d], 0u, acc);
+                if (d == db) acc = __builtin_amdgcn_sad_u8(pl[8u * db] & m1, 0u, acc);
                 return acc;
             };
             const uint32_t nitems = T.nwin * 4u;
@@ -387,7 +405,7 @@ void ts_scan_tiles(const TsScanParams P) {
                         uint32_t ha = hs;
                         if (xs & 15u) { val += partial(hs, xs & 15u, 16u); ++ha; }
                         if (xe & 15u) val += partial(he, 0u, xe & 15u);
-                        if (ha < he) val = plane_sum(cnt + f * NS, ha, he, val);
+                        if (ha < he) val = plane_sum(f, ha, he, val);
                     }
                     rec[i * 8u + f] = val;
                 }
@@ -402,7 +420,7 @@ void ts_scan_tiles(const TsScanParams P) {
                     if (ue - us >= k) {
                         const uint32_t xs = sh + us, xe = sh + ue - k + 1u;
                         const uint32_t hs = xs >> 4, he = xe >> 4;
-                        const uint16_t *pQ = (f & 2u) ? pF : pC;
+                        const lds_u16 *pQ = (f & 2u) ? pF : pC;
                         const uint32_t inv = (f & 1u) ? 0xFFFFu : 0u;
                         auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // 0 < hi - lo < 16
                             const uint32_t m = ((1u << (hi - lo)) - 1u) << lo;
@@ -414,7 +432,7 @@ void ts_scan_tiles(const TsScanParams P) {
                             uint32_t ha = hs;
                             if (xs & 15u) { val += partial(hs, xs & 15u, 16u); ++ha; }
                             if (xe & 15u) val += partial(he, 0u, xe & 15u);
-                            if (ha < he) val = plane_sum(cnt + (4u + f) * NS, ha, he, val);
+                            if (ha < he) val = plane_sum(4u + f, ha, he, val);
                         }
                     }
                     rec[i * 8u + 4u + f] = val * k;                    // covered bases
@@ -436,7 +454,7 @@ void ts_scan_tiles(const TsScanParams P) {
         {
             const uint32_t own_end = sh + T.own_len;              // plane coord
             const uint32_t w_hi = (own_end + 31u) >> 5;
-            const uint32_t *wM = (const uint32_t *)pM, *wF = (const uint32_t *)pF, *wC = (const uint32_t *)pC;
+            const lds_u32 *wM = (const lds_u32 *)pM, *wF = (const lds_u32 *)pF, *wC = (const lds_u32 *)pC;
             const u64 obase0 = region_base + cursor;
             uint32_t done = 0, ccan = 0, cfwd = 0;
             for (uint32_t h0 = 0; h0 < w_hi; h0 += 64u) {
