@@ -217,6 +217,9 @@ typedef struct ts_batch_info {
     uint64_t n_matches;         /* valid after ts_batch_sync() */
     uint64_t algorithmic_bytes; /* 1 B/base + 32 B/window + 4 B/match (after sync) */
     double   last_kernel_ms;    /* HIP-event time of the last scan (after sync) */
+    double   avg_kernel_ms;     /* mean HIP-event time of the scans enqueued since the previous sync
+                                   (the latest 64 at most) */
+    uint64_t kernel_launches;   /* how many scans avg_kernel_ms averages over */
 } ts_batch_info;
 
 /* Plans a batch of n_segs segments of the given lengths (all tips_only or all full scan).

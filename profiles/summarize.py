@@ -30,6 +30,10 @@ for f in find("*kernel_trace.csv"):
     for name, v in sorted(durs.items(), key=lambda kv: -sum(kv[1]))[:6]:
         print("   %-60s n=%d avg=%.1f us min=%.1f us max=%.1f us" % (name[:60], len(v), sum(v) / len(v) / 1e3,
                                                               min(v) / 1e3, max(v) / 1e3))
+        if "ts_scan_tiles" in name and len(v) > 5:
+            # bench.py runs 5 untimed warm-up launches first; its roofline uses the timed ones
+            t = v[5:]
+            print("   %-60s      timed launches only (first 5 dropped): n=%d avg=%.1f us" % ("", len(t), sum(t) / len(t) / 1e3))
 for f in find("*counter_collection.csv"):
     acc = {}
     with open(f) as fh:

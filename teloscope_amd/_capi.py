@@ -72,7 +72,8 @@ class BatchInfo(C.Structure):
     _fields_ = [("n_segments", C.c_uint64), ("total_bases", C.c_uint64), ("input_bytes", C.c_uint64),
                 ("n_windows", C.c_uint64), ("n_tiles", C.c_uint64), ("match_capacity", C.c_uint64),
                 ("n_matches", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
-                ("last_kernel_ms", C.c_double)]
+                ("last_kernel_ms", C.c_double), ("avg_kernel_ms", C.c_double),
+                ("kernel_launches", C.c_uint64)]
 
 
 MATCH_DT = np.dtype(Match)

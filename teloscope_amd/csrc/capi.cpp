@@ -94,7 +94,10 @@ struct ts_batch {
     DevBuf d_in, d_tiles, d_windows, d_matches, d_tile_off, d_stats, d_fill, d_segtab, d_dense, d_dense_base;
     uint32_t total_waves = 0, region_cap = 0;
     std::vector<uint32_t> wave_fill;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> evs;                 // ring of {start, stop} pairs, one per enqueued scan
+    uint64_t scan_seq = 0, harvested = 0;        // scans enqueued / scans whose time has been read
+    double avg_ms = 0.0;
+    uint64_t avg_n = 0;
 };
 
 namespace {
@@ -109,6 +112,7 @@ namespace {
 uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 constexpr uint32_t kMaxLds = 160u * 1024u;
+constexpr uint64_t kEventRing = 64;            // scans whose HIP-event times a batch remembers
 constexpr uint32_t kMaxBlocksPerTile = 448;
 constexpr uint32_t kMaxChunks = 16;            // tiles up to ~16 k positions per wave
 constexpr uint32_t kTipsChunks = 8;            // tips-only / read batches: ~8 k positions per tile
@@ -511,8 +515,10 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
     b->region_cap = (uint32_t)((cap + 3) & ~3ull);
     b->match_cap = (uint64_t)b->region_cap * b->total_waves;
 
-    if (batch_alloc_outputs(b) != TS_OK || hipEventCreate(&b->ev0) != hipSuccess ||
-        hipEventCreate(&b->ev1) != hipSuccess) {
+    bool ev_ok = true;
+    b->evs.assign(2 * kEventRing, nullptr);
+    for (hipEvent_t &e : b->evs) ev_ok = ev_ok && hipEventCreate(&e) == hipSuccess;
+    if (batch_alloc_outputs(b) != TS_OK || !ev_ok) {
         if (ctx->error.empty()) ctx->fail(TS_ERR_HIP, "batch allocation failed");
         ts_batch_destroy(b);
         return nullptr;
@@ -525,8 +531,8 @@ void ts_batch_destroy(ts_batch *b) {
     b->d_in.release(); b->d_tiles.release(); b->d_windows.release(); b->d_matches.release();
     b->d_tile_off.release(); b->d_stats.release(); b->d_fill.release(); b->d_dense.release(); b->d_dense_base.release();
     b->d_segtab.release();
-    if (b->ev0) (void)hipEventDestroy(b->ev0);
-    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    for (hipEvent_t e : b->evs)
+        if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -578,12 +584,14 @@ int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
     kp.region_cap = b->region_cap;
     kp.ntiles = (uint32_t)nt;
 
-    HIP_TRY(c, hipEventRecord(b->ev0, st));
+    const size_t slot = (size_t)(b->scan_seq % kEventRing);
+    HIP_TRY(c, hipEventRecord(b->evs[2 * slot], st));
     {
         int e = ts_k_launch_scan(&kp, b->grid, b->lds_bytes, stream);
         if (e != 0) return c->fail(TS_ERR_HIP, std::string("scan kernel launch: ") + hipGetErrorString((hipError_t)e));
     }
-    HIP_TRY(c, hipEventRecord(b->ev1, st));
+    HIP_TRY(c, hipEventRecord(b->evs[2 * slot + 1], st));
+    ++b->scan_seq;
     return TS_OK;
 }
 
@@ -593,10 +601,24 @@ int ts_batch_sync(ts_batch *b) {
     if (!b->scanned) return c->fail(TS_ERR_STATE, "ts_batch_sync before ts_batch_scan");
     HIP_TRY(c, hipSetDevice(c->device));
     for (int attempt = 0; attempt < 3; ++attempt) {
-        HIP_TRY(c, hipEventSynchronize(b->ev1));
-        float ms = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, b->ev0, b->ev1));
-        b->last_ms = ms;
+        {   // kernel times of the scans since the previous sync (the ring keeps the latest kEventRing)
+            const size_t last = (size_t)((b->scan_seq - 1) % kEventRing);
+            HIP_TRY(c, hipEventSynchronize(b->evs[2 * last + 1]));
+            const uint64_t from = std::max(b->harvested, b->scan_seq > kEventRing ? b->scan_seq - kEventRing : 0);
+            double sum = 0.0;
+            float ms = 0.f;
+            for (uint64_t q = from; q < b->scan_seq; ++q) {
+                const size_t s2 = (size_t)(q % kEventRing);
+                HIP_TRY(c, hipEventElapsedTime(&ms, b->evs[2 * s2], b->evs[2 * s2 + 1]));
+                sum += ms;
+            }
+            if (b->scan_seq > from) {
+                b->avg_n = b->scan_seq - from;
+                b->avg_ms = sum / (double)b->avg_n;
+                b->last_ms = ms;
+            }
+            b->harvested = b->scan_seq;
+        }
         b->wave_fill.assign(b->total_waves, 0u);
         HIP_TRY(c, hipMemcpy(b->wave_fill.data(), b->d_fill.p, (size_t)b->total_waves * 4, hipMemcpyDeviceToHost));
         uint64_t total = 0;
@@ -625,6 +647,8 @@ int ts_batch_get_info(const ts_batch *b, ts_batch_info *info) {
     info->n_matches = b->synced ? b->n_matches : 0;
     info->algorithmic_bytes = b->total_bases + 32ull * b->n_windows + 4ull * info->n_matches;
     info->last_kernel_ms = b->last_ms;
+    info->avg_kernel_ms = b->avg_ms;
+    info->kernel_launches = b->avg_n;
     return TS_OK;
 }
 
