@@ -114,8 +114,8 @@ uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 constexpr uint32_t kMaxLds = 160u * 1024u;
 constexpr uint64_t kEventRing = 64;            // scans whose HIP-event times a batch remembers
 constexpr uint32_t kMaxBlocksPerTile = 448;
-constexpr uint32_t kMaxChunks = 16;            // tiles up to ~16 k positions per wave
-constexpr uint32_t kTipsChunks = 8;            // tips-only / read batches: ~8 k positions per tile
+constexpr uint32_t kMaxChunks = 8;             // tiles up to ~16 k positions per wave
+constexpr uint32_t kTipsChunks = 4;            // tips-only / read batches: ~8 k positions per tile
 
 // Chooses waves per workgroup, chunks per tile and windows per tile so that the match table plus
 // one LDS slice per wave fit in 160 KB; false if even one wave cannot hold one window.
@@ -170,7 +170,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
             }
             if (cwpt < 1 || (uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) continue;
             const double passes = tips ? 0.0 : (double)ceil_div((uint64_t)cwpt * 4, 64);
-            const double score = (double)cwpt * cand.s * occ.factor / (272.0 * nch + 200.0 * passes + 100.0);
+            const double score = (double)cwpt * cand.s * occ.factor / (470.0 * nch + 170.0 * passes + 100.0);
             if (score > best) { best = score; best_kp = cand; best_wpt = cwpt; }
         }
     }

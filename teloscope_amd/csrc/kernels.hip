@@ -40,6 +40,7 @@ namespace {
 typedef unsigned long long u64;
 // LDS pointers are declared in their own address space so that indexing stays 32-bit arithmetic
 #define LDS __attribute__((address_space(3)))
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef LDS unsigned char lds_u8;
 typedef LDS uint16_t lds_u16;
 typedef LDS uint32_t lds_u32;
@@ -85,8 +86,8 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
 }
 
 // clear bits [lo, hi) of a bit plane held as dwords (hi - lo <= 31)
-__device__ __forceinline__ void plane_clear(lds_u16 *p16, uint32_t lo, uint32_t hi) {
-    uint32_t *p = (uint32_t *)p16;
+__device__ __forceinline__ void plane_clear(lds_u32 *p32, uint32_t lo, uint32_t hi) {
+    uint32_t *p = (uint32_t *)p32;
     const uint32_t d0 = lo >> 5, d1 = (hi - 1u) >> 5;
     const uint32_t m0 = ~0u << (lo & 31u);
     const uint32_t m1 = ~0u >> (31u - ((hi - 1u) & 31u));
@@ -101,10 +102,10 @@ __device__ __forceinline__ void plane_clear(lds_u16 *p16, uint32_t lo, uint32_t 
 __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
 // LDS: [match table][wave 0 slice][wave 1 slice]...; a slice = codes | M | F | C | cnt | rec
-//   codes   2-bit codes, one dword per 16 positions
-//   M F C   bit planes (match / forward / canonical), one halfword per 16 positions
-//   cnt     one byte per 16 positions (a "dword" h of the planes) and window-record field: valid
-//           A, C, G, T and canonical, non-canonical, forward, reverse matches among the 16.
+//   codes   2-bit codes, two dwords per 32 positions
+//   M F C   bit planes (match / forward / canonical), one dword per 32 positions
+//   cnt     one byte per 32 positions (a dword h of the bit planes) and window-record field: valid
+//           A, C, G, T and canonical, non-canonical, forward, reverse matches among the 32.
 //           Layout [h / 4][field][h % 4]: a field's counts of four consecutive h share a dword
 //           (summed by one v_sad_u8), and a lane's eight counts of one h sit at fixed offsets
 //   rec     the tile's window records while they are assembled, 8 x u32 per window
@@ -113,8 +114,8 @@ struct SliceLayout { uint32_t codes, pM, pF, pC, cnt, rec, bytes; };
 __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     SliceLayout s;
     uint32_t o = 0;
-    s.codes = o; o += align16(P.nch * 63u * 4u);
-    const uint32_t pb = align16(P.nch * 63u * 2u);
+    s.codes = o; o += align16(P.nch * 63u * 8u);
+    const uint32_t pb = align16(P.nch * 63u * 4u);
     s.pM = o; o += pb;
     s.pF = o; o += pb;
     s.pC = o; o += pb;
@@ -152,9 +153,9 @@ void ts_scan_tiles(const TsScanParams P) {
     lds_u8 *lds = (lds_u8 *)lds_raw;
     lds_u8 *slice = lds + table_bytes + wave * SL.bytes;
     lds_u32 *codes = (lds_u32 *)(slice + SL.codes);
-    lds_u16 *pM = (lds_u16 *)(slice + SL.pM);
-    lds_u16 *pF = (lds_u16 *)(slice + SL.pF);
-    lds_u16 *pC = (lds_u16 *)(slice + SL.pC);
+    lds_u32 *pM = (lds_u32 *)(slice + SL.pM);
+    lds_u32 *pF = (lds_u32 *)(slice + SL.pF);
+    lds_u32 *pC = (lds_u32 *)(slice + SL.pC);
     lds_u8 *cnt = slice + SL.cnt;
     lds_u32 *rec = (lds_u32 *)(slice + SL.rec);
 
@@ -188,144 +189,160 @@ void ts_scan_tiles(const TsScanParams P) {
         // Chunk c+1's 16 B/lane load is in flight while chunk c is resolved; the loop is unrolled
         // by two with alternating registers so the loaded value is never copied (a copy would
         // make the compiler wait for the load it was meant to overlap).
-        auto resolve_chunk = [&](const uint32_t cpos, const uint32_t ch, const uint4 v) {   // cpos = c * TS_CHUNK, ch = c * 63
+        auto resolve_chunk = [&](const uint32_t cpos, const uint32_t ch, const uint4 v0, const uint4 v1) {
+            // cpos = c * TS_CHUNK, ch = c * 63.  A lane holds 32 consecutive bases (two packed dwords).
             // ASCII -> 2-bit codes (A0 C1 T2 G3) and a validity check, 4 bases per dword
-            const uint32_t x[4] = {v.x, v.y, v.z, v.w};
-            uint32_t t[4], e[4], sad = 0;
+            const uint32_t x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            uint32_t t[8], e[8], sad = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 t[i] = (x[i] >> 1) & 0x07070707u;
                 e[i] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x47544341u, t[i]);
                 sad = __builtin_amdgcn_sad_u8(x[i] & P.fold_mask, e[i], sad);
             }
-            uint32_t w2 = pack16(t);
+            uint32_t wa = pack16(t), wb = pack16(t + 4);
 
-            const uint32_t pos0 = cpos + lane * 16u;             // plane coord of this lane's first base
-            uint32_t inv16 = 0;
-            const bool slow = __any(sad != 0) || (cpos + 1024u > xend);
+            const uint32_t pos0 = cpos + lane * 32u;             // plane coord of this lane's first base
+            uint32_t inv = 0;                                     // invalid bases among the lane's 32
+            const bool slow = __any(sad != 0) || (cpos + 2048u > xend);
             if (slow) {                                           // wave-uniform, rare
-                uint32_t b4[4];
+                uint32_t b4[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 8; ++i) {
                     const uint32_t d = (x[i] & P.fold_mask) ^ e[i];
                     const uint32_t nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;
                     b4[i] = __builtin_amdgcn_udot4(nz, 0x08040201u, 0u, false);
                     t[i] &= 0x03030303u;
                 }
-                inv16 = b4[0] | (b4[1] << 4) | (b4[2] << 8) | (b4[3] << 12);
-                if (pos0 + 16u > xend) {
-                    const uint32_t nv = xend > pos0 ? xend - pos0 : 0u;
-                    inv16 |= (0xFFFFu << nv) & 0xFFFFu;
+                inv = b4[0] | (b4[1] << 4) | (b4[2] << 8) | (b4[3] << 12) |
+                      (b4[4] << 16) | (b4[5] << 20) | (b4[6] << 24) | (b4[7] << 28);
+                if (pos0 + 32u > xend) {
+                    const uint32_t nv = xend > pos0 ? xend - pos0 : 0u;     // < 32
+                    inv |= ~0u << nv;
                 }
-                w2 = pack16(t);
+                wa = pack16(t); wb = pack16(t + 4);
                 has_invalid = true;
             }
 
-            // next lane's 16 bases (DPP wave_shl:1, lane i <- lane i+1; lane 63's value is unused)
-            const uint32_t nxt = (uint32_t)__builtin_amdgcn_mov_dpp((int)w2, 0x130, 0xf, 0xf, false);
+            // next lane's first 16 bases (DPP wave_shl:1, lane i <- lane i+1; lane 63's value is unused)
+            const uint32_t nx = (uint32_t)__builtin_amdgcn_mov_dpp((int)wa, 0x130, 0xf, 0xf, false);
 
             // ONE table probe per TWO positions: the pair table is indexed by the (k+1)-mer that
             // starts at an even position and holds {match at p, match at p+1} (16 entries per dword:
-            // row = index >> 4, bit = 2 * (index & 15)).  All eight ds_read_b32 are issued back to
+            // row = index >> 4, bit = 2 * (index & 15)).  All sixteen ds_read_b32 are issued back to
             // back (inline asm) and consumed behind one counted wait.
 #if TS_ABL & 32
-            uint32_t M16 = (w2 & nxt & (w2 >> 7) & (nxt >> 3) & (w2 >> 11)) & 0xFFFFu;
+            uint32_t M32 = wa & wb & (wa >> 7) & (nx >> 3) & (wb >> 11);
 #else
-            uint32_t tmp[8], ent[8];
+            uint32_t tmp[16], ent[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                tmp[j] = (j == 0) ? w2 : __builtin_amdgcn_alignbit(nxt, w2, 4 * j);
+            for (int j = 0; j < 16; ++j) {
+                if (j < 8) tmp[j] = (j == 0) ? wa : __builtin_amdgcn_alignbit(wb, wa, 4 * j);
+                else tmp[j] = (j == 8) ? wb : __builtin_amdgcn_alignbit(nx, wb, 4 * (j - 8));
                 const uint32_t row = __builtin_amdgcn_ubfe(tmp[j], 4, rowbits);
                 const uint32_t addr = tab_base + (row << 2);
                 asm volatile("ds_read_b32 %0, %1" : "=v"(ent[j]) : "v"(addr));
             }
-            uint32_t aM = 0;
+            uint32_t M32 = 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                aM = __builtin_amdgcn_alignbit(ent[j] >> ((tmp[j] << 1) & 31u), aM, 2);
-            uint32_t M16 = aM >> 16;
+            for (int j = 0; j < 16; ++j)
+                M32 = __builtin_amdgcn_alignbit(ent[j] >> ((tmp[j] << 1) & 31u), M32, 2);
 #endif
 
             if (slow) {                                           // k-mers touching an invalid base
-                const uint32_t inv32 = inv16 | ((uint32_t)__builtin_amdgcn_mov_dpp((int)inv16, 0x130, 0xf, 0xf, false) << 16);
+                const uint32_t inv_next = (uint32_t)__builtin_amdgcn_mov_dpp((int)inv, 0x130, 0xf, 0xf, false);
+                const u64 iv = (u64)inv | ((u64)inv_next << 32);
                 uint32_t kb = 0;
-                for (uint32_t i = 0; i < k; ++i) kb |= inv32 >> i;
-                M16 &= ~kb;
+                for (uint32_t i = 0; i < k; ++i) kb |= (uint32_t)(iv >> i);
+                M32 &= ~kb;
             }
 
             // forward / canonical flags only where something matched (a few per cent of positions):
-            // one pass per set bit of the fullest lane, branch-free per lane (bit 16 is a sentinel
-            // that keeps ctz defined for lanes that have run out of matches; its writes land in
-            // bit 16 of F16/C16 and are masked off).  Flag table: one byte per k-mer, or 2 bits.
-            uint32_t F16 = 0, C16 = 0;
+            // one pass per set bit of the fullest half-lane, both halves of a lane in the same pass
+            // (two independent lookups in flight), branch-free per lane: bit 16 of each half's mask is
+            // a sentinel that keeps ctz defined once the half has run out of matches; what it writes
+            // lands in bit 16 of the half's flags and is dropped.  Flag table: one byte per k-mer, or 2 bits.
+            uint32_t F32 = 0, C32 = 0;
 #if TS_ABL & 16
-            F16 = M16 & w2; C16 = M16 & nxt;
+            F32 = M32 & wa; C32 = M32 & wb;
 #else
-            if (__any(M16 != 0u)) {
-                uint32_t m = M16 | 0x10000u;
+            if (__any(M32 != 0u)) {
+                uint32_t ma = (M32 & 0xFFFFu) | 0x10000u, mb = (M32 >> 16) | 0x10000u;
+                uint32_t Fa = 0, Ca = 0, Fb = 0, Cb = 0;
                 do {
-                    const uint32_t j = (uint32_t)__builtin_ctz(m);
-                    const uint32_t idx = __builtin_amdgcn_alignbit(nxt, w2, 2u * j) & kmask;
-                    uint32_t fc;
-                    if (FC_BYTES) fc = fc_bytes[idx];
-                    else fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
-                    m = (m & (m - 1u)) | 0x10000u;
-                    F16 |= (fc & 1u) << j;
-                    C16 |= (fc >> 1) << j;
-                } while (__any((m & 0xFFFFu) != 0u));
+                    const uint32_t ja = (uint32_t)__builtin_ctz(ma), jb = (uint32_t)__builtin_ctz(mb);
+                    const uint32_t ia = __builtin_amdgcn_alignbit(wb, wa, 2u * ja) & kmask;
+                    const uint32_t ib = __builtin_amdgcn_alignbit(nx, wb, 2u * jb) & kmask;
+                    uint32_t fa, fb;
+                    if (FC_BYTES) { fa = fc_bytes[ia]; fb = fc_bytes[ib]; }
+                    else {
+                        fa = (fc_table[ia >> 4] >> ((ia & 15u) << 1)) & 3u;
+                        fb = (fc_table[ib >> 4] >> ((ib & 15u) << 1)) & 3u;
+                    }
+                    ma = (ma & (ma - 1u)) | 0x10000u;
+                    mb = (mb & (mb - 1u)) | 0x10000u;
+                    Fa |= (fa & 1u) << ja; Ca |= (fa >> 1) << ja;
+                    Fb |= (fb & 1u) << jb; Cb |= (fb >> 1) << jb;
+                } while (__any(((ma | mb) & 0xFFFFu) != 0u));
+                F32 = (Fa & 0xFFFFu) | (Fb << 16);
+                C32 = (Ca & 0xFFFFu) | (Cb << 16);
             }
 #endif
-            F16 &= 0xFFFFu; C16 &= 0xFFFFu;
-
-            // valid A/C/G/T among this lane's 16 bases (codes A0 C1 T2 G3: low bit set in C and G,
-            // high bit in T and G); invalid positions are masked out on the slow path
-            uint32_t sel = 0x55555555u;
-            if (slow) sel = spread16(~inv16 & 0xFFFFu);
-            const uint32_t lbits = w2 & sel, hbits = (w2 >> 1) & sel;
-            const uint32_t nG = __popc(lbits & hbits);
-            const uint32_t nL = __popc(lbits), nH = __popc(hbits);
-            const uint32_t nA = __popc(sel) + nG - nL - nH;
 
             if (lane < 63u && !(TS_ABL & 64)) {
-                const uint32_t h = ch + lane;
-                codes[h] = w2;
-                pM[h] = (uint16_t)M16;
-                pF[h] = (uint16_t)F16;
-                pC[h] = (uint16_t)C16;
+                const uint32_t h = ch + lane;                     // index of the lane's 32 positions in the planes
+                *(LDS u32x2 *)(codes + 2u * h) = (u32x2){wa, wb};
+                pM[h] = M32;
+                pF[h] = F32;
+                pC[h] = C32;
                 if (P.windows_on) {
-                    const uint32_t nC16 = __popc(C16), nF16 = __popc(F16), nM16 = __popc(M16);
+                    // valid A/C/G/T among the 32 bases (codes A0 C1 T2 G3: low bit set in C and G, high
+                    // bit in T and G); invalid positions are masked out on the slow path
+                    uint32_t sa = 0x55555555u, sb = 0x55555555u, nV = 32u;
+                    if (slow) {
+                        sa = spread16(~inv & 0xFFFFu); sb = spread16(~inv >> 16);
+                        nV = __popc(~inv);
+                    }
+                    const uint32_t la = wa & sa, ha = (wa >> 1) & sa, lb = wb & sb, hb = (wb >> 1) & sb;
+                    const uint32_t nG = __popc(la & ha) + __popc(lb & hb);
+                    const uint32_t nL = __popc(la) + __popc(lb), nH = __popc(ha) + __popc(hb);
+                    const uint32_t nCc = __popc(C32), nFf = __popc(F32), nMm = __popc(M32);
                     lds_u8 *np = cnt + ((h >> 2) << 5) + (h & 3u);
-                    np[0] = (unsigned char)nA;
+                    np[0] = (unsigned char)(nV + nG - nL - nH);
                     np[4] = (unsigned char)(nL - nG);
                     np[8] = (unsigned char)nG;
                     np[12] = (unsigned char)(nH - nG);
-                    np[16] = (unsigned char)nC16;
-                    np[20] = (unsigned char)(nM16 - nC16);
-                    np[24] = (unsigned char)nF16;
-                    np[28] = (unsigned char)(nM16 - nF16);
+                    np[16] = (unsigned char)nCc;
+                    np[20] = (unsigned char)(nMm - nCc);
+                    np[24] = (unsigned char)nFf;
+                    np[28] = (unsigned char)(nMm - nFf);
                 }
             }
         };
         {
-            // loads are unconditional (the last one re-reads the final chunk) so that the wait
-            // before each resolve is a counted vmcnt(1), never vmcnt(0)
-            // (chunk offsets are carried as scalars that step by a constant: no vector multiplies)
+            // Chunk c+1's two 16 B/lane loads are in flight while chunk c is resolved; the loop is
+            // unrolled by two with alternating registers so the loaded values are never copied, and
+            // loads are unconditional (the last ones re-read the final chunk) so that the wait before
+            // each resolve is a counted vmcnt(2), never vmcnt(0).  Chunk offsets are carried as
+            // scalars that step by a constant: no vector multiplies.
             const uint32_t last_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)((nch - 1u) * TS_CHUNK));
-            const unsigned char *lsrc = src + lane * 16u;
-            uint4 va = *(const uint4 *)lsrc, vb;
+            const unsigned char *lsrc = src + lane * 32u;
+            uint4 a0 = *(const uint4 *)lsrc, a1 = *(const uint4 *)(lsrc + 16), b0, b1;
             uint32_t cpos = 0, ch = 0;
             for (uint32_t c = 0; c < nch; c += 2u) {
                 const uint32_t p1 = cpos + TS_CHUNK < last_pos ? cpos + TS_CHUNK : last_pos;
-                vb = *(const uint4 *)(lsrc + p1);
-                __builtin_amdgcn_sched_barrier(0);         // the load is issued before chunk c is touched
-                resolve_chunk(cpos, ch, va);
+                b0 = *(const uint4 *)(lsrc + p1);
+                b1 = *(const uint4 *)(lsrc + p1 + 16);
+                __builtin_amdgcn_sched_barrier(0);         // the loads are issued before chunk c is touched
+                resolve_chunk(cpos, ch, a0, a1);
                 if (c + 1u >= nch) break;
                 const uint32_t p2 = cpos + 2u * TS_CHUNK < last_pos ? cpos + 2u * TS_CHUNK : last_pos;
-                va = *(const uint4 *)(lsrc + p2);
+                a0 = *(const uint4 *)(lsrc + p2);
+                a1 = *(const uint4 *)(lsrc + p2 + 16);
                 __builtin_amdgcn_sched_barrier(0);
-                resolve_chunk(cpos + TS_CHUNK, ch + 63u, vb);
+                resolve_chunk(cpos + TS_CHUNK, ch + 63u, b0, b1);
                 cpos += 2u * TS_CHUNK; ch += 126u;
             }
         }
@@ -348,7 +365,7 @@ void ts_scan_tiles(const TsScanParams P) {
         // ------------------------------------------------------------------ phase 2: windows
         // One lane per (window, field).  A field is the sum of its byte plane over the dwords that
         // lie wholly inside the field's range (aligned ds reads, v_sad_u8 adds four bytes at a time)
-        // plus the two partial dwords at the ends, counted from the codes / bit planes.
+        // plus the two partial units at the ends, counted from the codes / bit planes.
         // Nucleotides range over the window [us, ue); matches over the starts that keep the k-mer
         // inside it, [us, ue - k + 1) (analyzeWindow counts a match only when it ends in the window).
         if (P.windows_on) {
@@ -382,29 +399,31 @@ void ts_scan_tiles(const TsScanParams P) {
                     const uint32_t us = i * P.s;
                     const uint32_t ue = us + P.w < T.nrel ? us + P.w : T.nrel;
                     const uint32_t xs = sh + us, xe = sh + ue;           // plane coords, xs < xe
-                    const uint32_t hs = xs >> 4, he = xe >> 4;
+                    const uint32_t hs = xs >> 5, he = xe >> 5;           // 32-position units of the planes
                     // the field's code (A0 C1 G3 T2) as the bits to flip so that "equal" reads 1/1
                     const uint32_t code = (f == 2u) ? 3u : (f == 3u ? 2u : f);
-                    const uint32_t xl = (code & 1u) ? 0u : 0x55555555u, xh = (code & 2u) ? 0u : 0x55555555u;
+                    const u64 xl = (code & 1u) ? 0ull : 0x5555555555555555ull;
+                    const u64 xh = (code & 2u) ? 0ull : 0x5555555555555555ull;
                     const uint32_t letter = (0x54474341u >> (8u * f)) & 0xFFu;
-                    auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // 0 < hi - lo < 16
+                    auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // 0 < hi - lo < 32
                         if (has_invalid) {                                // rare: re-read the bases themselves
                             uint32_t n = 0;
                             for (uint32_t pp = lo; pp < hi; ++pp)
-                                n += ((uint32_t)src[h * 16u + pp] & (P.fold_mask & 0xFFu)) == letter;
+                                n += ((uint32_t)src[h * 32u + pp] & (P.fold_mask & 0xFFu)) == letter;
                             return n;
                         }
-                        const uint32_t m = (((1u << (2u * (hi - lo))) - 1u) << (2u * lo)) & 0x55555555u;
-                        const uint32_t cd = codes[h];
-                        return __popc((cd ^ xl) & ((cd >> 1) ^ xh) & m);
+                        const u64 m = (((1ull << (2u * (hi - lo))) - 1ull) << (2u * lo)) & 0x5555555555555555ull;
+                        const u32x2 c2 = *(const LDS u32x2 *)(codes + 2u * h);
+                        const u64 cd = (u64)c2.x | ((u64)c2.y << 32);
+                        return (uint32_t)__popcll((cd ^ xl) & ((cd >> 1) ^ xh) & m);
                     };
                     uint32_t val = 0;
                     if (hs == he) {
-                        val = partial(hs, xs & 15u, xe & 15u);
+                        val = partial(hs, xs & 31u, xe & 31u);
                     } else {
                         uint32_t ha = hs;
-                        if (xs & 15u) { val += partial(hs, xs & 15u, 16u); ++ha; }
-                        if (xe & 15u) val += partial(he, 0u, xe & 15u);
+                        if (xs & 31u) { val += partial(hs, xs & 31u, 32u); ++ha; }
+                        if (xe & 31u) val += partial(he, 0u, xe & 31u);
                         if (ha < he) val = plane_sum(f, ha, he, val);
                     }
                     rec[i * 8u + f] = val;
@@ -419,19 +438,19 @@ void ts_scan_tiles(const TsScanParams P) {
                     uint32_t val = 0;
                     if (ue - us >= k) {
                         const uint32_t xs = sh + us, xe = sh + ue - k + 1u;
-                        const uint32_t hs = xs >> 4, he = xe >> 4;
-                        const lds_u16 *pQ = (f & 2u) ? pF : pC;
-                        const uint32_t inv = (f & 1u) ? 0xFFFFu : 0u;
-                        auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // 0 < hi - lo < 16
+                        const uint32_t hs = xs >> 5, he = xe >> 5;
+                        const lds_u32 *pQ = (f & 2u) ? pF : pC;
+                        const uint32_t inv = (f & 1u) ? ~0u : 0u;
+                        auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // 0 < hi - lo < 32
                             const uint32_t m = ((1u << (hi - lo)) - 1u) << lo;
-                            return __popc((uint32_t)pM[h] & ((uint32_t)pQ[h] ^ inv) & m);
+                            return __popc(pM[h] & (pQ[h] ^ inv) & m);
                         };
                         if (hs == he) {
-                            val = partial(hs, xs & 15u, xe & 15u);
+                            val = partial(hs, xs & 31u, xe & 31u);
                         } else {
                             uint32_t ha = hs;
-                            if (xs & 15u) { val += partial(hs, xs & 15u, 16u); ++ha; }
-                            if (xe & 15u) val += partial(he, 0u, xe & 15u);
+                            if (xs & 31u) { val += partial(hs, xs & 31u, 32u); ++ha; }
+                            if (xe & 31u) val += partial(he, 0u, xe & 31u);
                             if (ha < he) val = plane_sum(4u + f, ha, he, val);
                         }
                     }
@@ -454,7 +473,7 @@ void ts_scan_tiles(const TsScanParams P) {
         {
             const uint32_t own_end = sh + T.own_len;              // plane coord
             const uint32_t w_hi = (own_end + 31u) >> 5;
-            const lds_u32 *wM = (const lds_u32 *)pM, *wF = (const lds_u32 *)pF, *wC = (const lds_u32 *)pC;
+            const lds_u32 *wM = pM, *wF = pF, *wC = pC;
             const u64 obase0 = region_base + cursor;
             uint32_t done = 0, ccan = 0, cfwd = 0;
             for (uint32_t h0 = 0; h0 < w_hi; h0 += 64u) {
