@@ -168,7 +168,14 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
                 cwpt = nblk > cand.halo_blocks ? std::min<uint32_t>(nblk - cand.halo_blocks, kMaxBlocksPerTile) : 0u;
                 cand.max_windows = cwpt;
             }
+            // staging room for match records: what is left of the CU's LDS, 64 .. 1024 records per wave
+            cand.stage_cap = 64;
             if (cwpt < 1 || (uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) continue;
+            {
+                const uint32_t spare = (kMaxLds - (uint32_t)ts_k_lds_bytes(&cand)) / occ.waves / 4u;
+                cand.stage_cap = std::min<uint32_t>(1024u, std::max<uint32_t>(cand.max_windows * 8u, 64u) + (spare & ~15u));
+                while ((uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) cand.stage_cap -= 16;
+            }
             const double passes = tips ? 0.0 : (double)ceil_div((uint64_t)cwpt * 4, 64);
             const double score = (double)cwpt * cand.s * occ.factor / (470.0 * nch + 170.0 * passes + 100.0);
             if (score > best) { best = score; best_kp = cand; best_wpt = cwpt; }

@@ -24,6 +24,7 @@
 //   emit     prefix-sum (DPP) compaction of the match plane into packed 32-bit records.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "ts_internal.h"
 
@@ -85,20 +86,6 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
     return x;
 }
 
-// clear bits [lo, hi) of a bit plane held as dwords (hi - lo <= 31)
-__device__ __forceinline__ void plane_clear(lds_u32 *p32, uint32_t lo, uint32_t hi) {
-    uint32_t *p = (uint32_t *)p32;
-    const uint32_t d0 = lo >> 5, d1 = (hi - 1u) >> 5;
-    const uint32_t m0 = ~0u << (lo & 31u);
-    const uint32_t m1 = ~0u >> (31u - ((hi - 1u) & 31u));
-    if (d0 == d1) {
-        atomicAnd(&p[d0], ~(m0 & m1));
-    } else {
-        atomicAnd(&p[d0], ~m0);
-        atomicAnd(&p[d1], ~m1);
-    }
-}
-
 __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
 // LDS: [match table][wave 0 slice][wave 1 slice]...; a slice = codes | M | F | C | cnt | rec
@@ -108,7 +95,10 @@ __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15
 //           A, C, G, T and canonical, non-canonical, forward, reverse matches among the 32.
 //           Layout [h / 4][field][h % 4]: a field's counts of four consecutive h share a dword
 //           (summed by one v_sad_u8), and a lane's eight counts of one h sit at fixed offsets
-//   rec     the tile's window records while they are assembled, 8 x u32 per window
+//   rec     during phase 1: the tile's packed match records, staged so that they leave in whole
+//           coalesced rows when the tile is done (and so that no global store sits between the
+//           chunk loads, whose counted vmcnt waits it would lengthen);
+//           afterwards: the tile's window records while they are assembled, 8 x u32 per window
 struct SliceLayout { uint32_t codes, pM, pF, pC, cnt, rec, bytes; };
 
 __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
@@ -120,7 +110,7 @@ __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     s.pF = o; o += pb;
     s.pC = o; o += pb;
     s.cnt = o; o += P.windows_on ? ((P.nch * 63u + 3u) >> 2) * 32u : 0u;      // tips-only scans keep no counts
-    s.rec = o; o += P.windows_on ? align16(P.max_windows * 32u) : 0u;
+    s.rec = o; o += align16((P.windows_on ? P.max_windows * 32u : 0u) > P.stage_cap * 4u + 256u ? P.max_windows * 32u : P.stage_cap * 4u + 256u);
     s.bytes = o;
     return s;
 }
@@ -170,7 +160,10 @@ void ts_scan_tiles(const TsScanParams P) {
     const uint32_t total_waves = gridDim.x * P.waves_per_wg;
     const uint32_t gw = blockIdx.x * P.waves_per_wg + wave;
     const u64 region_base = (u64)gw * P.region_cap;
+    uint32_t *const wave_out = P.matches_out + region_base;
     uint32_t cursor = 0;                          // records this wave has produced so far
+    const uint32_t own_full = lane < 63u ? ~0u : 0u;       // lane 63 only looks ahead for lane 62
+    const uint32_t chunk_mod_s = P.straddle_fix ? TS_CHUNK % P.s : 0u;
 
     for (uint32_t tile = gw; tile < P.ntiles; tile += total_waves) {
         const TsTile T = P.tiles[tile];           // wave-uniform: scalar loads
@@ -184,6 +177,21 @@ void ts_scan_tiles(const TsScanParams P) {
         if (nch > P.nch) nch = P.nch;
         nch = (uint32_t)__builtin_amdgcn_readfirstlane((int)nch);
         bool has_invalid = false;
+        const uint32_t own_end = sh + T.own_len;                   // plane coord: positions [sh, own_end) are this tile's
+        uint32_t done = 0, ccan = 0, cfwd = 0;                     // records of this tile so far (uniform); per-lane flag counts
+        uint32_t flushed = 0;                                      // how many of them have left the staging buffer
+        auto flush_stage = [&]() {                                 // rec[0 .. done - flushed) -> wave_out[cursor + flushed ..)
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n = done - flushed;
+            for (uint32_t i = lane; i < n; i += 64u) {
+                const uint32_t o = cursor + flushed + i;
+                if (o < P.region_cap && !(TS_ABL & 1)) wave_out[o] = rec[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            flushed = done;
+        };
+        // w == s: offset of the lane's first base inside its window, carried from chunk to chunk
+        uint32_t r0 = P.straddle_fix ? (lane * 32u + 16u * P.s - sh) % P.s : 0u;
 
         // ------------------------------------------------------------------ phase 1
         // Chunk c+1's 16 B/lane load is in flight while chunk c is resolved; the loop is unrolled
@@ -206,6 +214,7 @@ void ts_scan_tiles(const TsScanParams P) {
             uint32_t inv = 0;                                     // invalid bases among the lane's 32
             const bool slow = __any(sad != 0) || (cpos + 2048u > xend);
             if (slow) {                                           // wave-uniform, rare
+                asm volatile("; non-ACGT bases or segment end in this chunk" ::: "memory");   // keeps the compiler from hoisting this block
                 uint32_t b4[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -259,35 +268,100 @@ void ts_scan_tiles(const TsScanParams P) {
                 M32 &= ~kb;
             }
 
-            // forward / canonical flags only where something matched (a few per cent of positions):
-            // one pass per set bit of the fullest half-lane, both halves of a lane in the same pass
-            // (two independent lookups in flight), branch-free per lane: bit 16 of each half's mask is
-            // a sentinel that keeps ctz defined once the half has run out of matches; what it writes
-            // lands in bit 16 of the half's flags and is dropped.  Flag table: one byte per k-mer, or 2 bits.
+            if (P.straddle_fix) {
+                // w == s: a match that would straddle a window end is lost (src/teloscope.cpp:611-628 via
+                // the carry rule; pinned by t2t.fa -i = 199): drop the starts whose offset in the window
+                // exceeds s - k.  One zone per window end; a lane of 32 sees one at most unless s < 32.
+                uint32_t zm = 0;
+                for (int z = (int)(P.s - k + 1u) - (int)r0; z < 32; z += (int)P.s) {
+                    const int lo = z > 0 ? z : 0;
+                    int hi = z + (int)k - 1;
+                    if (hi > 32) hi = 32;
+                    if (lo < hi) zm |= (hi >= 32 ? ~0u : ((1u << hi) - 1u)) & (~0u << lo);
+                }
+                M32 &= ~zm;
+                r0 += chunk_mod_s;
+                if (r0 >= P.s) r0 -= P.s;
+            }
+
+            // Forward / canonical flags only where something matched (a few per cent of positions),
+            // and the packed match records in the same pass: one pass per set bit of the fullest
+            // half-lane, both halves of a lane in the same pass (two independent lookups in flight),
+            // branch-free per lane: bit 16 of each half's mask is a sentinel that keeps ctz defined
+            // once the half has run out of matches; what it writes lands in bit 16 of the half's
+            // flags and is dropped, and it owns nothing, so it stores nothing.
+            // Flag table: one byte per k-mer, or 2 bits; value = forward << 1 | canonical.
             uint32_t F32 = 0, C32 = 0;
 #if TS_ABL & 16
             F32 = M32 & wa; C32 = M32 & wb;
 #else
             if (__any(M32 != 0u)) {
+                // positions of this lane that the tile owns: plane coords [sh, own_end)
+                uint32_t own = own_full;
+                if (cpos < 32u || cpos + TS_CHUNK > own_end) {           // wave-uniform: first or last owned chunk
+                    const uint32_t lo = pos0 >= sh ? 0u : sh - pos0;
+                    const uint32_t hi = pos0 >= own_end ? 0u : (own_end - pos0 >= 32u ? 32u : own_end - pos0);
+                    const uint32_t m = (hi >= 32u ? ~0u : ((1u << hi) - 1u)) & (~0u << lo);
+                    own = (lo < hi) ? (m & own_full) : 0u;
+                }
+                // where the lane's records go: prefix sum of the owned matches over the wave
+                const uint32_t Mo = M32 & own;
+                const uint32_t nown = __popc(Mo);
+                const uint32_t incl = wave_scan_incl(nown);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                // records are staged in LDS; a chunk that does not fit next to what is staged flushes it,
+                // one that would not fit on its own (dense repeats) goes straight to global memory
+                if (done - flushed + total > P.stage_cap) flush_stage();
+                const bool direct = total > P.stage_cap;                  // wave-uniform
+                uint32_t oa = (direct ? cursor + done : done - flushed) + (incl - nown);
+                uint32_t ob = oa + __popc(Mo & 0xFFFFu);
+                done += total;
+                if (direct) flushed = done;
+                const uint32_t own_a = own & 0xFFFFu, own_b = own >> 16;
+                const uint32_t ubase = pos0 - sh;                         // tile-relative position of bit 0
+
                 uint32_t ma = (M32 & 0xFFFFu) | 0x10000u, mb = (M32 >> 16) | 0x10000u;
                 uint32_t Fa = 0, Ca = 0, Fb = 0, Cb = 0;
-                do {
-                    const uint32_t ja = (uint32_t)__builtin_ctz(ma), jb = (uint32_t)__builtin_ctz(mb);
-                    const uint32_t ia = __builtin_amdgcn_alignbit(wb, wa, 2u * ja) & kmask;
-                    const uint32_t ib = __builtin_amdgcn_alignbit(nx, wb, 2u * jb) & kmask;
-                    uint32_t fa, fb;
-                    if (FC_BYTES) { fa = fc_bytes[ia]; fb = fc_bytes[ib]; }
-                    else {
-                        fa = (fc_table[ia >> 4] >> ((ia & 15u) << 1)) & 3u;
-                        fb = (fc_table[ib >> 4] >> ((ib & 15u) << 1)) & 3u;
-                    }
-                    ma = (ma & (ma - 1u)) | 0x10000u;
-                    mb = (mb & (mb - 1u)) | 0x10000u;
-                    Fa |= (fa & 1u) << ja; Ca |= (fa >> 1) << ja;
-                    Fb |= (fb & 1u) << jb; Cb |= (fb >> 1) << jb;
-                } while (__any(((ma | mb) & 0xFFFFu) != 0u));
+                auto flag_loop = [&](auto direct_tag) {
+                    constexpr bool kDirect = decltype(direct_tag)::value;
+                    uint32_t pa = oa * 4u, pb = ob * 4u;                  // staged: byte offsets into rec
+                    const uint32_t dummy = (P.stage_cap + lane) * 4u;     // the lane's own slot past the staged records
+                    do {
+                        const uint32_t ja = (uint32_t)__builtin_ctz(ma), jb = (uint32_t)__builtin_ctz(mb);
+                        const uint32_t ia = __builtin_amdgcn_alignbit(wb, wa, 2u * ja) & kmask;
+                        const uint32_t ib = __builtin_amdgcn_alignbit(nx, wb, 2u * jb) & kmask;
+                        uint32_t fa, fb;
+                        if (FC_BYTES) { fa = fc_bytes[ia]; fb = fc_bytes[ib]; }
+                        else {
+                            fa = (fc_table[ia >> 4] >> ((ia & 15u) << 1)) & 3u;
+                            fb = (fc_table[ib >> 4] >> ((ib & 15u) << 1)) & 3u;
+                        }
+                        ma = (ma & (ma - 1u)) | 0x10000u;
+                        mb = (mb & (mb - 1u)) | 0x10000u;
+                        Ca |= (fa & 1u) << ja; Fa |= (fa >> 1) << ja;
+                        Cb |= (fb & 1u) << jb; Fb |= (fb >> 1) << jb;
+                        // (a sentinel pass has j = 16, which no lane owns)
+                        const uint32_t ea = (own_a >> ja) & 1u, eb = (own_b >> jb) & 1u;
+                        const uint32_t ra = ((ubase + ja) << 2) | fa, rb = ((ubase + 16u + jb) << 2) | fb;
+                        if (kDirect) {                                    // dense chunk: straight to global memory
+                            if (!(TS_ABL & 1)) {
+                                if (ea && oa < P.region_cap) wave_out[oa] = ra;
+                                if (eb && ob < P.region_cap) wave_out[ob] = rb;
+                            }
+                            oa += ea; ob += eb;
+                        } else {                                          // branch-free: unowned passes hit the dummy slot
+                            *(lds_u32 *)((lds_u8 *)rec + (ea ? pa : dummy)) = ra;
+                            *(lds_u32 *)((lds_u8 *)rec + (eb ? pb : dummy)) = rb;
+                            pa += ea * 4u; pb += eb * 4u;
+                        }
+                    } while (__any(((ma | mb) & 0xFFFFu) != 0u));
+                };
+                if (direct) flag_loop(std::true_type{});
+                else flag_loop(std::false_type{});
                 F32 = (Fa & 0xFFFFu) | (Fb << 16);
                 C32 = (Ca & 0xFFFFu) | (Cb << 16);
+                ccan += __popc(C32 & own);
+                cfwd += __popc(F32 & own);
             }
 #endif
 
@@ -347,20 +421,7 @@ void ts_scan_tiles(const TsScanParams P) {
             }
         }
         __builtin_amdgcn_wave_barrier();          // planes written above are read by other lanes below
-
-        // -------------------------------------------- w == s: matches may not straddle a window end
-        if (P.straddle_fix && k > 1u) {
-            for (uint32_t b = lane; b < nblk; b += 64u) {
-                const uint32_t hi = sh + (b + 1u) * P.s;
-                if (hi <= nch * TS_CHUNK) {
-                    const uint32_t lo = hi - (k - 1u);
-                    plane_clear(pM, lo, hi);
-                    plane_clear(pF, lo, hi);
-                    plane_clear(pC, lo, hi);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        if (P.windows_on) flush_stage();          // the window records are assembled where the matches were staged
 
         // ------------------------------------------------------------------ phase 2: windows
         // One lane per (window, field).  A field is the sum of its byte plane over the dwords that
@@ -467,46 +528,13 @@ void ts_scan_tiles(const TsScanParams P) {
             }
         }
 
-        // ------------------------------------------------------- emit: packed match records
-        // 32 positions per lane and iteration (plane dwords): the per-match loop runs for the
-        // fullest lane, so wider lanes waste fewer of its iterations.
+        // ------------------------------------------------------- tile directory
         {
-            const uint32_t own_end = sh + T.own_len;              // plane coord
-            const uint32_t w_hi = (own_end + 31u) >> 5;
-            const lds_u32 *wM = pM, *wF = pF, *wC = pC;
-            const u64 obase0 = region_base + cursor;
-            uint32_t done = 0, ccan = 0, cfwd = 0;
-            for (uint32_t h0 = 0; h0 < w_hi; h0 += 64u) {
-                const uint32_t h = h0 + lane;
-                uint32_t M = 0, F = 0, C = 0;
-                if (h < w_hi) {
-                    const uint32_t hb = h << 5;
-                    const uint32_t lo = hb > sh ? 0u : sh - hb;
-                    const uint32_t hi = (hb + 32u <= own_end) ? 32u : own_end - hb;
-                    uint32_t m = hi >= 32u ? ~0u : ((1u << hi) - 1u);
-                    m &= ~0u << lo;
-                    M = wM[h] & m; F = wF[h]; C = wC[h];
-                }
-                const uint32_t cnt = __popc(M);
-                ccan += __popc(M & C);
-                cfwd += __popc(M & F);
-                const uint32_t incl = wave_scan_incl(cnt);
-                uint32_t o = cursor + done + (incl - cnt);         // index inside this wave's region
-                const uint32_t ubase = (h << 5) - sh;               // tile-relative position of bit 0
-                while (M && !(TS_ABL & 1)) {
-                    const uint32_t j = (uint32_t)__builtin_ctz(M);
-                    M &= M - 1u;
-                    const uint32_t rec = ((ubase + j) << 2) | (((F >> j) & 1u) << 1) | ((C >> j) & 1u);
-                    if (o < P.region_cap) P.matches_out[region_base + o] = rec;
-                    ++o;
-                }
-                done += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            }
-            ccan = wave_sum(ccan);
-            cfwd = wave_sum(cfwd);
+            if (!P.windows_on) flush_stage();
+            const uint32_t tcan = wave_sum(ccan), tfwd = wave_sum(cfwd);
             if (lane == 0) {
-                P.tile_off[tile] = obase0;
-                *(uint4 *)&P.tile_stats[4ull * tile] = make_uint4(done, ccan, cfwd, 0u);
+                P.tile_off[tile] = region_base + cursor;
+                *(uint4 *)&P.tile_stats[4ull * tile] = make_uint4(done, tcan, tfwd, 0u);
             }
             cursor += done;
         }

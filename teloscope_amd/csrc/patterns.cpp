@@ -169,7 +169,7 @@ int base_code(char c) {
 //    x(p+1) is a pattern}, 16 entries per dword (row = y >> 4).  Not replicated: the kernel is
 //    bound by VALU issue, and spreading rows over the LDS banks (8 copies) bought 0.4 % when it
 //    was measured, while the 28 KB it cost is what the per-wave count planes now live in;
-//  * flag table: {forward, canonical} per k-mer, looked up only at matched positions: one byte
+//  * flag table: {canonical, forward} (bit 0, bit 1: the low bits of a match record) per k-mer, looked up only at matched positions: one byte
 //    per k-mer for k <= 7 (cheapest lookup), 2 bits per k-mer at k = 8 (LDS capacity).
 // Layout in `table`: [rows dwords][flag table].
 bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
@@ -186,7 +186,7 @@ bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector
             x |= static_cast<uint32_t>(c) << (2 * i);
         }
         m[x] = 1;
-        fl[x] = static_cast<uint8_t>((p.is_forward ? 1 : 0) | (p.is_canonical ? 2 : 0));
+        fl[x] = static_cast<uint8_t>((p.is_canonical ? 1 : 0) | (p.is_forward ? 2 : 0));   // a match record's low bits
     }
     const uint64_t npairs = nk * 4;                                   // (k+1)-mers
     rows = static_cast<uint32_t>(npairs / 16);

@@ -46,6 +46,7 @@ struct TsScanParams {
     uint32_t        halo_blocks;    // step blocks read beyond the owned ones: ceil(w / s) - 1
     uint32_t        nch;            // chunks of TS_CHUNK positions per tile
     uint32_t        max_windows;    // windows per tile (rows of the LDS record buffer)
+    uint32_t        stage_cap;      // match records a wave can stage in LDS before it flushes them
     uint32_t        fold_mask;      // 0xDFDFDFDF (fold case) or 0xFFFFFFFF
     uint32_t        straddle_fix;   // 1: w == s, drop matches that straddle a window end
     uint32_t        windows_on;     // 0 in tips-only mode
