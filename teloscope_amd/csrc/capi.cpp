@@ -133,6 +133,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     } else {
         const uint32_t s = P.step, w = P.window_size;
         kp.s = s; kp.w = w;
+        kp.s_inv = (uint32_t)(((1ull << 32) + s - 1) / s);
         kp.halo_blocks = (w + s - 1) / s - 1;            // window i reaches into step blocks i .. i + ceil(w/s) - 1
         kp.straddle_fix = (w == s) ? 1u : 0u;
         kp.windows_on = 1;
@@ -161,6 +162,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
             if (tips) {
                 const uint32_t tb = span_max & ~15u;            // one pseudo block per tile
                 cand.s = cand.w = tb;
+                cand.s_inv = (uint32_t)(((1ull << 32) + tb - 1) / tb);
                 cand.max_windows = 1;
                 cwpt = 1;
             } else {
@@ -169,11 +171,13 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
                 cand.max_windows = cwpt;
             }
             // staging room for match records: what is left of the CU's LDS, 64 .. 1024 records per wave
-            cand.stage_cap = 64;
+            cand.stage_cap = 128;
+            cand.acc_copies = 8;
+            while (cand.acc_copies > 1 && (uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) cand.acc_copies >>= 1;
             if (cwpt < 1 || (uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) continue;
             {
                 const uint32_t spare = (kMaxLds - (uint32_t)ts_k_lds_bytes(&cand)) / occ.waves / 4u;
-                cand.stage_cap = std::min<uint32_t>(1024u, std::max<uint32_t>(cand.max_windows * 8u, 64u) + (spare & ~15u));
+                cand.stage_cap = std::min<uint32_t>(1024u, 128u + (spare & ~15u));
                 while ((uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) cand.stage_cap -= 16;
             }
             const double passes = tips ? 0.0 : (double)ceil_div((uint64_t)cwpt * 4, 64);

@@ -88,29 +88,32 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
 
 __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
-// LDS: [match table][wave 0 slice][wave 1 slice]...; a slice = codes | M | F | C | cnt | rec
-//   codes   2-bit codes, two dwords per 32 positions
-//   M F C   bit planes (match / forward / canonical), one dword per 32 positions
-//   cnt     one byte per 32 positions (a dword h of the bit planes) and window-record field: valid
-//           A, C, G, T and canonical, non-canonical, forward, reverse matches among the 32.
-//           Layout [h / 4][field][h % 4]: a field's counts of four consecutive h share a dword
-//           (summed by one v_sad_u8), and a lane's eight counts of one h sit at fixed offsets
-//   rec     during phase 1: the tile's packed match records, staged so that they leave in whole
-//           coalesced rows when the tile is done (and so that no global store sits between the
-//           chunk loads, whose counted vmcnt waits it would lengthen);
-//           afterwards: the tile's window records while they are assembled, 8 x u32 per window
-struct SliceLayout { uint32_t codes, pM, pF, pC, cnt, rec, bytes; };
+// LDS: [match table][wave 0 slice][wave 1 slice]...; a slice = codes | cnt | mlist | rec | stage
+//   codes   2-bit codes of the tile, two dwords per 32 positions (+ one look-ahead dword pair)
+//   cnt     nucleotide counts, one byte per 32 positions and letter (valid A, C, G, T among them).
+//           Layout [h / 4][letter][h % 4]: a letter's counts of four consecutive h share a dword
+//           (summed by one v_sad_u8), and a lane's four counts of one h sit at fixed offsets
+//   mlist   the match positions of the chunk being resolved (u16, chunk-relative), compacted in
+//           position order so that the per-match work runs on full wavefronts
+//   rec     the nucleotide fields of the tile's window records, 4 x u32 per window
+//   wacc    the match fields of the tile's window records while they accumulate: one u64 per window
+//           = four 16-bit counters {canonical, non-canonical, forward, reverse}, bumped by ONE
+//           ds_add_u64 per (match, window); kept in acc_copies lane-interleaved copies so that the
+//           matches of a pass, which mostly fall into the same few windows, do not serialise on one
+//           address
+//   stage   packed match records waiting to leave in whole coalesced rows (and kept out of the
+//           chunk loads' counted vmcnt waits), + one spare slot per lane for predicated-off writes
+struct SliceLayout { uint32_t codes, cnt, mlist, rec, wacc, stage, bytes; };
 
 __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     SliceLayout s;
     uint32_t o = 0;
-    s.codes = o; o += align16(P.nch * 63u * 8u);
-    const uint32_t pb = align16(P.nch * 63u * 4u);
-    s.pM = o; o += pb;
-    s.pF = o; o += pb;
-    s.pC = o; o += pb;
-    s.cnt = o; o += P.windows_on ? ((P.nch * 63u + 3u) >> 2) * 32u : 0u;      // tips-only scans keep no counts
-    s.rec = o; o += align16((P.windows_on ? P.max_windows * 32u : 0u) > P.stage_cap * 4u + 256u ? P.max_windows * 32u : P.stage_cap * 4u + 256u);
+    s.codes = o; o += align16((P.nch * 63u + 1u) * 8u);
+    s.cnt = o; o += (P.windows_on && P.nuc_on) ? ((P.nch * 63u + 3u) >> 2) * 16u : 0u;
+    s.mlist = o; o += align16(TS_CHUNK * 2u);
+    s.rec = o; o += (P.windows_on && P.nuc_on) ? align16(P.max_windows * 16u) : 0u;
+    s.wacc = o; o += P.windows_on ? align16(P.max_windows * 8u * P.acc_copies) : 0u;
+    s.stage = o; o += (P.stage_cap + 64u) * 4u;
     s.bytes = o;
     return s;
 }
@@ -143,11 +146,12 @@ void ts_scan_tiles(const TsScanParams P) {
     lds_u8 *lds = (lds_u8 *)lds_raw;
     lds_u8 *slice = lds + table_bytes + wave * SL.bytes;
     lds_u32 *codes = (lds_u32 *)(slice + SL.codes);
-    lds_u32 *pM = (lds_u32 *)(slice + SL.pM);
-    lds_u32 *pF = (lds_u32 *)(slice + SL.pF);
-    lds_u32 *pC = (lds_u32 *)(slice + SL.pC);
     lds_u8 *cnt = slice + SL.cnt;
+    lds_u16 *mlist = (lds_u16 *)(slice + SL.mlist);
     lds_u32 *rec = (lds_u32 *)(slice + SL.rec);
+    lds_u32 *stage = (lds_u32 *)(slice + SL.stage);
+    LDS u64 *wacc = (LDS u64 *)(slice + SL.wacc);
+    const uint32_t acc_off = (lane & (P.acc_copies - 1u)) * P.max_windows;     // this lane's copy of wacc
 
     const uint32_t k = P.k;
     const uint32_t rowbits = 2u * (k + 1u) - 4u;      // pair table: 4^(k+1) entries, 16 per dword
@@ -162,8 +166,7 @@ void ts_scan_tiles(const TsScanParams P) {
     const u64 region_base = (u64)gw * P.region_cap;
     uint32_t *const wave_out = P.matches_out + region_base;
     uint32_t cursor = 0;                          // records this wave has produced so far
-    const uint32_t own_full = lane < 63u ? ~0u : 0u;       // lane 63 only looks ahead for lane 62
-    const uint32_t chunk_mod_s = P.straddle_fix ? TS_CHUNK % P.s : 0u;
+    const uint32_t nwper = P.halo_blocks + 1u;             // windows a position can belong to: ceil(w / s)
 
     for (uint32_t tile = gw; tile < P.ntiles; tile += total_waves) {
         const TsTile T = P.tiles[tile];           // wave-uniform: scalar loads
@@ -180,18 +183,18 @@ void ts_scan_tiles(const TsScanParams P) {
         const uint32_t own_end = sh + T.own_len;                   // plane coord: positions [sh, own_end) are this tile's
         uint32_t done = 0, ccan = 0, cfwd = 0;                     // records of this tile so far (uniform); per-lane flag counts
         uint32_t flushed = 0;                                      // how many of them have left the staging buffer
-        auto flush_stage = [&]() {                                 // rec[0 .. done - flushed) -> wave_out[cursor + flushed ..)
+        auto flush_stage = [&]() {                                 // stage[0 .. done - flushed) -> wave_out[cursor + flushed ..)
             __builtin_amdgcn_wave_barrier();
             const uint32_t n = done - flushed;
             for (uint32_t i = lane; i < n; i += 64u) {
                 const uint32_t o = cursor + flushed + i;
-                if (o < P.region_cap && !(TS_ABL & 1)) wave_out[o] = rec[i];
+                if (o < P.region_cap && !(TS_ABL & 1)) wave_out[o] = stage[i];
             }
             __builtin_amdgcn_wave_barrier();
             flushed = done;
         };
-        // w == s: offset of the lane's first base inside its window, carried from chunk to chunk
-        uint32_t r0 = P.straddle_fix ? (lane * 32u + 16u * P.s - sh) % P.s : 0u;
+        if (P.windows_on)                                          // match fields accumulate from zero
+            for (uint32_t it = lane; it < P.max_windows * 2u * P.acc_copies; it += 64u) ((lds_u32 *)wacc)[it] = 0u;
 
         // ------------------------------------------------------------------ phase 1
         // Chunk c+1's 16 B/lane load is in flight while chunk c is resolved; the loop is unrolled
@@ -268,110 +271,12 @@ void ts_scan_tiles(const TsScanParams P) {
                 M32 &= ~kb;
             }
 
-            if (P.straddle_fix) {
-                // w == s: a match that would straddle a window end is lost (src/teloscope.cpp:611-628 via
-                // the carry rule; pinned by t2t.fa -i = 199): drop the starts whose offset in the window
-                // exceeds s - k.  One zone per window end; a lane of 32 sees one at most unless s < 32.
-                uint32_t zm = 0;
-                for (int z = (int)(P.s - k + 1u) - (int)r0; z < 32; z += (int)P.s) {
-                    const int lo = z > 0 ? z : 0;
-                    int hi = z + (int)k - 1;
-                    if (hi > 32) hi = 32;
-                    if (lo < hi) zm |= (hi >= 32 ? ~0u : ((1u << hi) - 1u)) & (~0u << lo);
-                }
-                M32 &= ~zm;
-                r0 += chunk_mod_s;
-                if (r0 >= P.s) r0 -= P.s;
-            }
-
-            // Forward / canonical flags only where something matched (a few per cent of positions),
-            // and the packed match records in the same pass: one pass per set bit of the fullest
-            // half-lane, both halves of a lane in the same pass (two independent lookups in flight),
-            // branch-free per lane: bit 16 of each half's mask is a sentinel that keeps ctz defined
-            // once the half has run out of matches; what it writes lands in bit 16 of the half's
-            // flags and is dropped, and it owns nothing, so it stores nothing.
-            // Flag table: one byte per k-mer, or 2 bits; value = forward << 1 | canonical.
-            uint32_t F32 = 0, C32 = 0;
-#if TS_ABL & 16
-            F32 = M32 & wa; C32 = M32 & wb;
-#else
-            if (__any(M32 != 0u)) {
-                // positions of this lane that the tile owns: plane coords [sh, own_end)
-                uint32_t own = own_full;
-                if (cpos < 32u || cpos + TS_CHUNK > own_end) {           // wave-uniform: first or last owned chunk
-                    const uint32_t lo = pos0 >= sh ? 0u : sh - pos0;
-                    const uint32_t hi = pos0 >= own_end ? 0u : (own_end - pos0 >= 32u ? 32u : own_end - pos0);
-                    const uint32_t m = (hi >= 32u ? ~0u : ((1u << hi) - 1u)) & (~0u << lo);
-                    own = (lo < hi) ? (m & own_full) : 0u;
-                }
-                // where the lane's records go: prefix sum of the owned matches over the wave
-                const uint32_t Mo = M32 & own;
-                const uint32_t nown = __popc(Mo);
-                const uint32_t incl = wave_scan_incl(nown);
-                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                // records are staged in LDS; a chunk that does not fit next to what is staged flushes it,
-                // one that would not fit on its own (dense repeats) goes straight to global memory
-                if (done - flushed + total > P.stage_cap) flush_stage();
-                const bool direct = total > P.stage_cap;                  // wave-uniform
-                uint32_t oa = (direct ? cursor + done : done - flushed) + (incl - nown);
-                uint32_t ob = oa + __popc(Mo & 0xFFFFu);
-                done += total;
-                if (direct) flushed = done;
-                const uint32_t own_a = own & 0xFFFFu, own_b = own >> 16;
-                const uint32_t ubase = pos0 - sh;                         // tile-relative position of bit 0
-
-                uint32_t ma = (M32 & 0xFFFFu) | 0x10000u, mb = (M32 >> 16) | 0x10000u;
-                uint32_t Fa = 0, Ca = 0, Fb = 0, Cb = 0;
-                auto flag_loop = [&](auto direct_tag) {
-                    constexpr bool kDirect = decltype(direct_tag)::value;
-                    uint32_t pa = oa * 4u, pb = ob * 4u;                  // staged: byte offsets into rec
-                    const uint32_t dummy = (P.stage_cap + lane) * 4u;     // the lane's own slot past the staged records
-                    do {
-                        const uint32_t ja = (uint32_t)__builtin_ctz(ma), jb = (uint32_t)__builtin_ctz(mb);
-                        const uint32_t ia = __builtin_amdgcn_alignbit(wb, wa, 2u * ja) & kmask;
-                        const uint32_t ib = __builtin_amdgcn_alignbit(nx, wb, 2u * jb) & kmask;
-                        uint32_t fa, fb;
-                        if (FC_BYTES) { fa = fc_bytes[ia]; fb = fc_bytes[ib]; }
-                        else {
-                            fa = (fc_table[ia >> 4] >> ((ia & 15u) << 1)) & 3u;
-                            fb = (fc_table[ib >> 4] >> ((ib & 15u) << 1)) & 3u;
-                        }
-                        ma = (ma & (ma - 1u)) | 0x10000u;
-                        mb = (mb & (mb - 1u)) | 0x10000u;
-                        Ca |= (fa & 1u) << ja; Fa |= (fa >> 1) << ja;
-                        Cb |= (fb & 1u) << jb; Fb |= (fb >> 1) << jb;
-                        // (a sentinel pass has j = 16, which no lane owns)
-                        const uint32_t ea = (own_a >> ja) & 1u, eb = (own_b >> jb) & 1u;
-                        const uint32_t ra = ((ubase + ja) << 2) | fa, rb = ((ubase + 16u + jb) << 2) | fb;
-                        if (kDirect) {                                    // dense chunk: straight to global memory
-                            if (!(TS_ABL & 1)) {
-                                if (ea && oa < P.region_cap) wave_out[oa] = ra;
-                                if (eb && ob < P.region_cap) wave_out[ob] = rb;
-                            }
-                            oa += ea; ob += eb;
-                        } else {                                          // branch-free: unowned passes hit the dummy slot
-                            *(lds_u32 *)((lds_u8 *)rec + (ea ? pa : dummy)) = ra;
-                            *(lds_u32 *)((lds_u8 *)rec + (eb ? pb : dummy)) = rb;
-                            pa += ea * 4u; pb += eb * 4u;
-                        }
-                    } while (__any(((ma | mb) & 0xFFFFu) != 0u));
-                };
-                if (direct) flag_loop(std::true_type{});
-                else flag_loop(std::false_type{});
-                F32 = (Fa & 0xFFFFu) | (Fb << 16);
-                C32 = (Ca & 0xFFFFu) | (Cb << 16);
-                ccan += __popc(C32 & own);
-                cfwd += __popc(F32 & own);
-            }
-#endif
-
-            if (lane < 63u && !(TS_ABL & 64)) {
+            // the lane's bases go to the tile's code plane (lane 63's first dword is the look-ahead of lane 62's
+            // last k-mers; the next chunk's lane 0 rewrites the same slot with the same value)
+            if (!(TS_ABL & 64)) {
                 const uint32_t h = ch + lane;                     // index of the lane's 32 positions in the planes
                 *(LDS u32x2 *)(codes + 2u * h) = (u32x2){wa, wb};
-                pM[h] = M32;
-                pF[h] = F32;
-                pC[h] = C32;
-                if (P.windows_on) {
+                if (lane < 63u && P.windows_on && P.nuc_on) {
                     // valid A/C/G/T among the 32 bases (codes A0 C1 T2 G3: low bit set in C and G, high
                     // bit in T and G); invalid positions are masked out on the slow path
                     uint32_t sa = 0x55555555u, sb = 0x55555555u, nV = 32u;
@@ -382,17 +287,76 @@ void ts_scan_tiles(const TsScanParams P) {
                     const uint32_t la = wa & sa, ha = (wa >> 1) & sa, lb = wb & sb, hb = (wb >> 1) & sb;
                     const uint32_t nG = __popc(la & ha) + __popc(lb & hb);
                     const uint32_t nL = __popc(la) + __popc(lb), nH = __popc(ha) + __popc(hb);
-                    const uint32_t nCc = __popc(C32), nFf = __popc(F32), nMm = __popc(M32);
-                    lds_u8 *np = cnt + ((h >> 2) << 5) + (h & 3u);
+                    lds_u8 *np = cnt + ((h >> 2) << 4) + (h & 3u);
                     np[0] = (unsigned char)(nV + nG - nL - nH);
                     np[4] = (unsigned char)(nL - nG);
                     np[8] = (unsigned char)nG;
                     np[12] = (unsigned char)(nH - nG);
-                    np[16] = (unsigned char)nCc;
-                    np[20] = (unsigned char)(nMm - nCc);
-                    np[24] = (unsigned char)nFf;
-                    np[28] = (unsigned char)(nMm - nFf);
                 }
+            }
+
+            // ---- per-match work on full wavefronts.  Matches are a few per cent of the positions, so a
+            // lane-per-position loop would idle most lanes: instead the chunk's match positions are
+            // compacted into a list (prefix sum over the wave, then each lane writes out its set bits)
+            // and the list is consumed 64 matches at a time: flags from the flag table, the packed
+            // record, and the match's contribution to every window that contains it.
+#if TS_ABL & 16
+            M32 = 0;
+#endif
+            if (lane == 63u) M32 = 0;                             // lane 63 only looks ahead for lane 62
+            if (__any(M32 != 0u)) {
+                const uint32_t nm = __popc(M32);
+                const uint32_t incl = wave_scan_incl(nm);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                {
+                    uint32_t o = incl - nm, m = M32;
+                    const uint32_t lbase = lane * 32u;
+                    while (m) {
+                        mlist[o++] = (uint16_t)(lbase + (uint32_t)__builtin_ctz(m));
+                        m &= m - 1u;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
+                    if (done - flushed + 64u > P.stage_cap) flush_stage();
+                    const uint32_t tt = t0 + lane;
+                    const bool live = tt < total;
+                    const uint32_t xp = cpos + (live ? (uint32_t)mlist[tt] : 0u);      // plane coord of the match
+                    // its k-mer, from the code plane (16 positions per dword)
+                    const lds_u32 *cw = codes + (xp >> 4);
+                    const uint32_t idx = __builtin_amdgcn_alignbit(cw[1], cw[0], (xp & 15u) * 2u) & kmask;
+                    uint32_t fc;                                  // forward << 1 | canonical
+                    if (FC_BYTES) fc = fc_bytes[idx];
+                    else fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
+                    // position in the tile, step block and offset inside it
+                    const uint32_t u = xp - sh;                   // wraps for the few bases before the tile
+                    uint32_t q = __umulhi(u, P.s_inv);
+                    if (q * P.s > u) --q;
+                    const uint32_t o = u - q * P.s;
+                    // w == s: a match that would straddle a window end is lost (the carry rule of
+                    // src/teloscope.cpp:611-628; pinned by t2t.fa -i = 199)
+                    const bool valid = live && xp >= sh && !(P.straddle_fix && o + k > P.s);
+                    const bool owned = valid && xp < own_end;
+                    // record slot = rank among the owned matches of this pass
+                    const u64 bal = __ballot(owned);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    const uint32_t slot = owned ? (done - flushed) + rank : P.stage_cap + lane;
+                    stage[slot] = (u << 2) | fc;
+                    done += (uint32_t)__popcll(bal);
+                    ccan += owned ? (fc & 1u) : 0u;
+                    cfwd += owned ? (fc >> 1) : 0u;
+                    // {canonical, non-canonical, forward, reverse} as one 4 x 16-bit increment
+                    const u64 inc = (u64)((fc & 1u) ? 1u : 0x10000u) | ((u64)((fc & 2u) ? 1u : 0x10000u) << 32);
+                    // windows q, q-1, ... contain the match as long as it ends inside them
+                    if (P.windows_on && !(TS_ABL & 4)) {
+                        for (uint32_t j = 0; j < nwper; ++j) {
+                            const uint32_t wi = q - j;            // wraps past window 0
+                            const bool in = valid && wi < T.nwin && o + k + j * P.s <= P.w;
+                            if (in) atomicAdd((unsigned long long *)(wacc + acc_off + wi), inc);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                  // the list is rewritten by the next chunk
             }
         };
         {
@@ -421,35 +385,34 @@ void ts_scan_tiles(const TsScanParams P) {
             }
         }
         __builtin_amdgcn_wave_barrier();          // planes written above are read by other lanes below
-        if (P.windows_on) flush_stage();          // the window records are assembled where the matches were staged
 
         // ------------------------------------------------------------------ phase 2: windows
-        // One lane per (window, field).  A field is the sum of its byte plane over the dwords that
-        // lie wholly inside the field's range (aligned ds reads, v_sad_u8 adds four bytes at a time)
-        // plus the two partial units at the ends, counted from the codes / bit planes.
-        // Nucleotides range over the window [us, ue); matches over the starts that keep the k-mer
-        // inside it, [us, ue - k + 1) (analyzeWindow counts a match only when it ends in the window).
+        // The match fields of the tile's window records are complete (accumulated above).  Nucleotides:
+        // one lane per (window, letter); a count is the sum of the letter's bytes over the 32-position
+        // units that lie wholly inside the window (aligned ds reads, v_sad_u8 adds four bytes at a time)
+        // plus the two partial units at the ends, counted from the codes.
+        flush_stage();
         if (P.windows_on) {
-            // sum of field f's counts over the dwords ha .. he-1 of the planes (ha < he)
+            // sum of letter f's counts over the units ha .. he-1 (ha < he)
             auto plane_sum = [&](uint32_t f, uint32_t ha, uint32_t he, uint32_t acc) -> uint32_t {
-                const lds_u32 *pl = (const lds_u32 *)cnt + f;        // group g of four h: pl[8 g]
+                const lds_u32 *pl = (const lds_u32 *)cnt + f;        // group g of four units: pl[4 g]
                 uint32_t d = ha >> 2;
                 const uint32_t db = (he - 1u) >> 2;
                 const uint32_t m0 = ~0u << (8u * (ha & 3u));
                 const uint32_t m1 = ~0u >> (8u * (3u - ((he - 1u) & 3u)));
-                uint32_t v0 = pl[8u * d] & m0;
+                uint32_t v0 = pl[4u * d] & m0;
                 if (d == db) v0 &= m1;
                 acc = __builtin_amdgcn_sad_u8(v0, 0u, acc);
                 ++d;
                 for (; d + 4u <= db; d += 4u) {
-                    const lds_u32 *q = pl + 8u * d;
+                    const lds_u32 *q = pl + 4u * d;
                     acc = __builtin_amdgcn_sad_u8(q[0], 0u, acc);
+                    acc = __builtin_amdgcn_sad_u8(q[4], 0u, acc);
                     acc = __builtin_amdgcn_sad_u8(q[8], 0u, acc);
-                    acc = __builtin_amdgcn_sad_u8(q[16], 0u, acc);
-                    acc = __builtin_amdgcn_sad_u8(q[24], 0u, acc);
+                    acc = __builtin_amdgcn_sad_u8(q[12], 0u, acc);
                 }
-                for (; d < db; ++d) acc = __builtin_amdgcn_sad_u8(pl[8u * d], 0u, acc);
-                if (d == db) acc = __builtin_amdgcn_sad_u8(pl[8u * db] & m1, 0u, acc);
+                for (; d < db; ++d) acc = __builtin_amdgcn_sad_u8(pl[4u * d], 0u, acc);
+                if (d == db) acc = __builtin_amdgcn_sad_u8(pl[4u * db] & m1, 0u, acc);
                 return acc;
             };
             const uint32_t nitems = T.nwin * 4u;
@@ -487,50 +450,32 @@ void ts_scan_tiles(const TsScanParams P) {
                         if (xe & 31u) val += partial(he, 0u, xe & 31u);
                         if (ha < he) val = plane_sum(f, ha, he, val);
                     }
-                    rec[i * 8u + f] = val;
-                }
-            }
-
-            if (!(TS_ABL & 4)) {
-                for (uint32_t it = lane; it < nitems; it += 64u) {
-                    const uint32_t i = it >> 2, f = it & 3u;              // f: canonical, non-canonical, forward, reverse
-                    const uint32_t us = i * P.s;
-                    const uint32_t ue = us + P.w < T.nrel ? us + P.w : T.nrel;
-                    uint32_t val = 0;
-                    if (ue - us >= k) {
-                        const uint32_t xs = sh + us, xe = sh + ue - k + 1u;
-                        const uint32_t hs = xs >> 5, he = xe >> 5;
-                        const lds_u32 *pQ = (f & 2u) ? pF : pC;
-                        const uint32_t inv = (f & 1u) ? ~0u : 0u;
-                        auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // 0 < hi - lo < 32
-                            const uint32_t m = ((1u << (hi - lo)) - 1u) << lo;
-                            return __popc(pM[h] & (pQ[h] ^ inv) & m);
-                        };
-                        if (hs == he) {
-                            val = partial(hs, xs & 31u, xe & 31u);
-                        } else {
-                            uint32_t ha = hs;
-                            if (xs & 31u) { val += partial(hs, xs & 31u, 32u); ++ha; }
-                            if (xe & 31u) val += partial(he, 0u, xe & 31u);
-                            if (ha < he) val = plane_sum(4u + f, ha, he, val);
-                        }
-                    }
-                    rec[i * 8u + 4u + f] = val * k;                    // covered bases
+                    rec[i * 4u + f] = val;
                 }
             }
             __builtin_amdgcn_wave_barrier();
 
-            // records leave as whole dwords in order: 8 x u32 per window, coalesced
+            // records leave as whole dwords in order: 8 x u32 per window, coalesced; the match fields
+            // count covered bases = k x matches
             if (!(TS_ABL & 8)) {
                 uint32_t *wout = P.windows_out + T.win_out * 8ull;
-                for (uint32_t it = lane; it < T.nwin * 8u; it += 64u)
-                    wout[it] = (P.nuc_on || (it & 4u)) ? rec[it] : 0u;
+                for (uint32_t it = lane; it < T.nwin * 8u; it += 64u) {
+                    const uint32_t i = it >> 3, f = it & 7u;
+                    uint32_t val = 0;
+                    if (f < 4u) {
+                        if (P.nuc_on) val = rec[i * 4u + f];
+                    } else {
+                        const lds_u16 *a16 = (const lds_u16 *)(wacc + i) + (f - 4u);
+                        for (uint32_t c = 0; c < P.acc_copies; ++c) val += a16[c * P.max_windows * 4u];
+                        val *= k;
+                    }
+                    wout[it] = val;
+                }
             }
         }
 
         // ------------------------------------------------------- tile directory
         {
-            if (!P.windows_on) flush_stage();
             const uint32_t tcan = wave_sum(ccan), tfwd = wave_sum(cfwd);
             if (lane == 0) {
                 P.tile_off[tile] = region_base + cursor;

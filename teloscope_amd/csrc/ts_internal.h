@@ -43,9 +43,11 @@ struct TsScanParams {
     uint32_t        fc_byte_table;  // 1: one byte {forward, canonical} per k-mer; 0: 2 bits per k-mer
     uint32_t        k;              // pattern length
     uint32_t        s, w;           // step and window (tips mode: s = w = tile size)
+    uint32_t        s_inv;          // ceil(2^32 / s): multiply-high division by s (tile-relative positions < 2^22)
     uint32_t        halo_blocks;    // step blocks read beyond the owned ones: ceil(w / s) - 1
     uint32_t        nch;            // chunks of TS_CHUNK positions per tile
     uint32_t        max_windows;    // windows per tile (rows of the LDS record buffer)
+    uint32_t        acc_copies;     // lane-interleaved copies of the window match accumulators (power of two)
     uint32_t        stage_cap;      // match records a wave can stage in LDS before it flushes them
     uint32_t        fold_mask;      // 0xDFDFDFDF (fold case) or 0xFFFFFFFF
     uint32_t        straddle_fix;   // 1: w == s, drop matches that straddle a window end
