@@ -5,7 +5,7 @@
 #   profiles/ablate.sh build && gpurun -- 'profiles/ablate.sh run > gpurun_out/ablate.txt'
 set -e
 cd "$(dirname "$0")/.."
-MASKS="0 1 2 4 8 16 32 64 6 127"
+MASKS="0 1 2 4 8 16 32 64"
 if [ "$1" = build ]; then
     for m in $MASKS; do
         (cd teloscope_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 \
@@ -15,7 +15,7 @@ if [ "$1" = build ]; then
     wait
 else
     for m in $MASKS; do
-        TELOSCAN_LIB=$PWD/profiles/abl_$m.so python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline $BENCH_FLAGS \
+        TELOSCAN_LIB=$PWD/profiles/abl_$m.so python3 bench.py --no-cpu-baseline $BENCH_FLAGS \
             | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('mask %3d  kernel_ms %.4f  ms_per_step %.4f' % ($m, d['roofline']['kernel_ms'], d['ms_per_step']))"
     done
 fi

@@ -14,24 +14,25 @@
 // the stream addressable in position order).  Latency is hidden by the 16 waves per CU.
 //
 // Per tile:
-//   phase 1  1008 positions per iteration: one coalesced 16 B/lane load, SWAR ASCII -> 2-bit
-//            codes (v_perm / v_sad_u8 / v_dot4), ONE ds_read_b32 per TWO positions from the
-//            replicated pair table in LDS ((k+1)-mer -> match bits of both positions), forward /
-//            canonical flags resolved only at matched positions; results are kept as bit planes
-//            in the wave's LDS slice.
-//   phase 2  per-step-block partial sums by range popcounts over the planes; windows are
-//            assembled from ceil(w/s)+1 block partials -> 8 x u32 per window, coalesced.
-//   emit     prefix-sum (DPP) compaction of the match plane into packed 32-bit records.
+//   phase 1  2016 positions per iteration, 32 per lane: two coalesced 16 B/lane loads (the next
+//            chunk's in flight), SWAR ASCII -> 2-bit codes (v_perm / v_sad_u8 / v_dot4), ONE
+//            ds_read_b32 per TWO positions from the pair table in LDS ((k+1)-mer -> match bits of
+//            both positions), nucleotide counts per 32 positions into byte planes.
+//            Then the chunk's matches (a few per cent of the positions) are compacted into a list
+//            and resolved 64 at a time on full wavefronts: forward/canonical flags from the flag
+//            table, the packed 32-bit record (staged in LDS, flushed in coalesced rows), and one
+//            packed ds_add_u64 per window that contains the match.
+//   phase 2  nucleotide fields of the windows: byte-plane sums (v_sad_u8) + partial ends from the
+//            codes; 8 x u32 per window leave coalesced.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
 
 #include "ts_internal.h"
 
 // Profiling only: -DTS_ABL=<mask> builds a kernel with one stage removed (results are then wrong)
 // so that stage costs can be measured under real overlap; see profiles/ablate.sh.
-//   1 emit loop  2 nucleotide sums  4 match sums  8 window records  16 flag resolution
-//   32 table probes  64 plane stores
+//   1 record flush to global  2 nucleotide window sums  4 window match accumulation
+//   8 window record stores  16 the whole per-match pass  32 table probes  64 code/count plane stores
 #ifndef TS_ABL
 #define TS_ABL 0
 #endif
