@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -56,6 +57,10 @@ struct ts_ctx {
     mutable std::mutex mtx;
     mutable std::string error;
     bool read_filter = false;
+    // pinned staging ring for host -> device uploads (batch_upload_all)
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    hipStream_t up_stream = nullptr;
 
     int fail(int code, const std::string &msg) const { error = msg; return code; }
 };
@@ -419,6 +424,11 @@ void ts_destroy(ts_ctx *ctx) {
     ctx->d_table.release();
     ctx->d_gcodes.release();
     ctx->d_gflags.release();
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
+        if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
+    }
+    if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
     delete ctx;
 }
 
@@ -1034,16 +1044,41 @@ static int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::v
     return rc;
 }
 
-// Stages all segments of a batch in one host buffer laid out like the device buffer and uploads
-// it with a single copy (one hipMemcpy per read would cost ~10 us each).
+// Uploads all segments of a batch: the bases are gathered into a ring of two pinned chunks laid out
+// like the device buffer, each chunk leaving by DMA (hipMemcpyAsync on a private stream) while the
+// next one is being filled — one copy per read would cost ~10 us each, one pageable 3 GB copy ~0.5 s.
+// Bytes between segments are never read as bases (the kernel masks everything past a segment's end).
 static int batch_upload_all(ts_batch *b, const std::vector<const char *> &seqs) {
     ts_ctx *c = b->ctx;
     if (!ts_batch_input_ptr(b)) return c->fail(TS_ERR_ALLOC, "cannot allocate device input buffer");
-    std::vector<char> stage;
-    try { stage.assign(b->input_bytes, 0); } catch (...) { return c->fail(TS_ERR_ALLOC, "out of host memory"); }
-    for (size_t i = 0; i < b->segs.size(); ++i)
-        if (b->segs[i].len) std::memcpy(stage.data() + b->segs[i].in_off, seqs[i], b->segs[i].len);
-    HIP_TRY(c, hipMemcpy(b->d_in.p, stage.data(), b->input_bytes, hipMemcpyHostToDevice));
+    constexpr size_t kChunk = 32u << 20;
+    if (!c->up_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(c, hipHostMalloc(&c->pin[i], kChunk, hipHostMallocDefault));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+        }
+    }
+    const size_t nseg = b->segs.size();
+    size_t seg = 0;                 // first segment that may still have bytes at or beyond the chunk start
+    int slot = 0;
+    bool used[2] = {false, false};
+    for (uint64_t c0 = 0; c0 < b->input_bytes; c0 += kChunk) {
+        const uint64_t c1 = std::min<uint64_t>(c0 + kChunk, b->input_bytes);
+        if (used[slot]) HIP_TRY(c, hipEventSynchronize(c->pin_ev[slot]));
+        char *dst = (char *)c->pin[slot];
+        while (seg < nseg && b->segs[seg].in_off + b->segs[seg].len <= c0) ++seg;
+        for (size_t i = seg; i < nseg && b->segs[i].in_off < c1; ++i) {
+            const uint64_t s0 = std::max<uint64_t>(b->segs[i].in_off, c0);
+            const uint64_t s1 = std::min<uint64_t>(b->segs[i].in_off + b->segs[i].len, c1);
+            if (s1 > s0) std::memcpy(dst + (s0 - c0), seqs[i] + (s0 - b->segs[i].in_off), s1 - s0);
+        }
+        HIP_TRY(c, hipMemcpyAsync((char *)b->d_in.p + c0, dst, c1 - c0, hipMemcpyHostToDevice, c->up_stream));
+        HIP_TRY(c, hipEventRecord(c->pin_ev[slot], c->up_stream));
+        used[slot] = true;
+        slot ^= 1;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->up_stream));
     return TS_OK;
 }
 
@@ -1112,11 +1147,20 @@ int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
     }
     // tiled path: whole-read tips scan, then the terminal-block predicate on the device; only one
     // byte per read comes back
+    const bool timing = getenv("TS_TIMING") != nullptr;          // stage times to stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
+        return std::chrono::duration<double, std::milli>(b2 - a).count();
+    };
+    const auto t0 = now();
     ts_batch *b = ts_batch_create(ctx, rl.data(), nullptr, n_reads, 1, 0);
     if (!b) return ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP;
+    const auto t1 = now();
     int rc = batch_upload_all(b, std::vector<const char *>(seqs, seqs + n_reads));
+    const auto t2 = now();
     if (rc == TS_OK) rc = ts_batch_scan(b, nullptr, nullptr);
     if (rc == TS_OK) rc = ts_batch_sync(b);
+    const auto t3 = now();
     if (rc == TS_OK) {
         ts_ctx *c = ctx;
         auto run = [&]() -> int {
@@ -1153,7 +1197,11 @@ int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
         };
         rc = run();
     }
+    const auto t4 = now();
     ts_batch_destroy(b);
+    if (timing)
+        fprintf(stderr, "ts_filter_reads: plan %.1f ms, upload %.1f ms, scan %.1f ms, predicate %.1f ms, free %.1f ms\n",
+                ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
     return rc;
 }
 
