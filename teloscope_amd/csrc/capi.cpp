@@ -443,6 +443,9 @@ static bool full_scan_supported(const ts_ctx *c, std::string &why) {
         why = "longest pattern exceeds min(step, window-step): reference start-index arithmetic wraps";
         return false;
     }
+    // the tiled kernel accumulates a window's match counts in 16-bit lanes of one packed LDS word, and a
+    // tile (one wave's LDS slice) has to hold a whole window: larger windows take the general kernels
+    if (w > 32768u) { why = "window larger than 32768 bases"; return false; }
     return true;
 }
 

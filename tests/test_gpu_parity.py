@@ -146,6 +146,36 @@ def test_random_segments_match_oracle(cli):
         assert_segment_equal(g, e, tips, ctx="cli=%r len=%d" % (cli, len(s)))
 
 
+DENSE_GRID = [
+    # every position of a homopolymer run is a match: the per-chunk match list, the staging flushes and
+    # the packed 16-bit window counters of the tiled kernel at their limits
+    ("-c AAAAAA -x 0 -w 1000 -s 500 -r -g -e -m -i", b"A"),
+    ("-c AAAAAA -x 0 -r -g -e -m -i", b"A"),                       # w = s = 1000
+    ("-c AAAAAA -x 1 -w 20000 -s 10000 -g -e -m -i", b"A"),        # windows of 20 kb: ~20 k matches each
+    ("-c AAAAAA -x 0 -w 40000 -s 20000 -g -i", b"A"),              # > 32768: general kernels
+    ("-c ACACAC -x 1 -w 3000 -s 1000 -g -e -m -i", b"AC"),
+    ("-c AAAAAA -x 0 -t 6000", b"A"),                              # tips only
+]
+
+
+@pytest.mark.parametrize("cli,unit", DENSE_GRID)
+def test_dense_repeats_and_large_windows(cli, unit):
+    opts = H.parse_cli("x.fa " + cli)
+    prod, orac = ProductBackend(opts), OracleBackend(opts)
+    rng = np.random.default_rng(len(cli))
+    segs = []
+    for n, runs in [(9000, [(100, 8200)]), (70000, [(0, 30000), (41000, 29000)]), (150000, [(5, 149990)]),
+                    (33000, [(1000, 2100), (16000, 2017), (30000, 3000)])]:
+        s = bytearray(seqgen.random_dna(rng, n).tobytes())
+        for a, ln in runs:
+            s[a:a + ln] = (unit * (ln // len(unit) + 1))[:ln]
+        s[n // 2] = ord("N")                                       # one invalid base inside a dense run or not
+        segs.append((bytes(s), int(rng.integers(0, 10 ** 6)), opts.ultra_fast))
+    got = prod.scan_segments(segs)
+    for (s, ap, tips), g in zip(segs, got):
+        assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="cli=%r len=%d" % (cli, len(s)))
+
+
 def test_non_acgt_and_case_handling():
     """IUPAC codes / N inside a segment kill every k-mer that touches them; lower case follows
     fold_case (default: folded, like unmaskSequence + scanSegment; 0: strict scanSegment)."""
