@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -62,7 +64,8 @@ struct ts_ctx {
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     hipStream_t up_stream = nullptr;
 
-    int fail(int code, const std::string &msg) const { error = msg; return code; }
+    mutable std::mutex err_mtx;
+    int fail(int code, const std::string &msg) const { std::lock_guard<std::mutex> g(err_mtx); error = msg; return code; }
 };
 
 namespace {
@@ -805,37 +808,61 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
         tile_off[t] = tile_off[t] - (unsigned long long)w * b->region_cap + dense_base[w];
     }
 
+    // Host post-processing (absolute positions, terminal flags, block calling, float window metrics)
+    // is O(matches) per segment and independent between segments: one job per segment, largest
+    // first, on up to 16 host threads — the reference's own decomposition (one job per path).
     const uint16_t klen = (uint16_t)c->k;
-    std::vector<ts_match> matches;
-    for (size_t si = 0; si < ns; ++si) {
-        const SegPlan &sp = b->segs[si];
-        // matches: tile-relative packed records -> absolute MatchInfo, tiles in position order
-        uint64_t nm = 0;
-        for (uint32_t t = 0; t < sp.n_tiles; ++t) nm += tile_stats[4ull * (sp.first_tile + t)];
-        matches.clear();
-        matches.reserve(nm);
-        for (const Region &rg : sp.regions) {
-            for (uint32_t t = 0; t < rg.n_tiles; ++t) {
-                const uint32_t ti = rg.first_tile + t;
-                const uint64_t tile_rel = rg.start + (uint64_t)t * rg.tile_bases;   // segment-relative
-                const uint64_t r0 = tile_off[ti], r1 = r0 + tile_stats[4ull * ti];
-                if (r1 > recs.size()) return c->fail(TS_ERR_STATE, "tile directory out of range");
-                for (uint64_t ri = r0; ri < r1; ++ri) {
-                    const uint32_t rec = recs[ri];
-                    ts_match m{};
-                    m.position = sp.abs_pos + tile_rel + (rec >> 2);
-                    m.match_size = klen;
-                    m.flags = (uint8_t)(((rec & 2u) ? TS_MATCH_FORWARD : 0u) | ((rec & 1u) ? TS_MATCH_CANONICAL : 0u));
-                    matches.push_back(m);
+    std::vector<size_t> order(ns);
+    for (size_t i = 0; i < ns; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return b->segs[x].len > b->segs[y].len; });
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_err{TS_OK};
+    auto worker = [&]() {
+        std::vector<ts_match> matches;
+        for (;;) {
+            const size_t oi = next.fetch_add(1);
+            if (oi >= ns || first_err.load() != TS_OK) return;
+            const size_t si = order[oi];
+            const SegPlan &sp = b->segs[si];
+            // matches: tile-relative packed records -> absolute MatchInfo, tiles in position order
+            uint64_t nm = 0;
+            for (uint32_t t = 0; t < sp.n_tiles; ++t) nm += tile_stats[4ull * (sp.first_tile + t)];
+            matches.clear();
+            matches.reserve(nm);
+            int rc = TS_OK;
+            for (const Region &rg : sp.regions) {
+                for (uint32_t t = 0; t < rg.n_tiles && rc == TS_OK; ++t) {
+                    const uint32_t ti = rg.first_tile + t;
+                    const uint64_t tile_rel = rg.start + (uint64_t)t * rg.tile_bases;   // segment-relative
+                    const uint64_t r0 = tile_off[ti], r1 = r0 + tile_stats[4ull * ti];
+                    if (r1 > recs.size()) { rc = c->fail(TS_ERR_STATE, "tile directory out of range"); break; }
+                    for (uint64_t ri = r0; ri < r1; ++ri) {
+                        const uint32_t rec = recs[ri];
+                        ts_match m{};
+                        m.position = sp.abs_pos + tile_rel + (rec >> 2);
+                        m.match_size = klen;
+                        m.flags = (uint8_t)(((rec & 2u) ? TS_MATCH_FORWARD : 0u) | ((rec & 1u) ? TS_MATCH_CANONICAL : 0u));
+                        matches.push_back(m);
+                    }
                 }
             }
+            if (rc == TS_OK)
+                rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos,
+                                      sp.n_windows ? &wins[sp.win_base * 8] : nullptr, b->tips ? 0 : sp.n_windows,
+                                      matches, out[si]);
+            if (rc != TS_OK) { int expected = TS_OK; first_err.compare_exchange_strong(expected, rc); return; }
         }
-        int rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos,
-                                  sp.n_windows ? &wins[sp.win_base * 8] : nullptr, b->tips ? 0 : sp.n_windows,
-                                  matches, out[si]);
-        if (rc != TS_OK) return rc;
+    };
+    for (size_t i = 0; i < ns; ++i) std::memset(&out[i], 0, sizeof out[i]);
+    const unsigned nthreads = (unsigned)std::min<size_t>({(size_t)16, ns, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+    if (nthreads <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned i = 0; i < nthreads; ++i) pool.emplace_back(worker);
+        for (std::thread &th : pool) th.join();
     }
-    return TS_OK;
+    return first_err.load();
 }
 
 // --------------------------------------------------------------- device block calling (row f1)
@@ -1089,17 +1116,29 @@ static int batch_upload_all(ts_batch *b, const std::vector<const char *> &seqs) 
 static int scan_group(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<size_t> &which,
                       bool tips, ts_segment_out *out) {
     if (which.empty()) return TS_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<uint64_t> lens(which.size()), abs(which.size());
     for (size_t i = 0; i < which.size(); ++i) { lens[i] = segs[which[i]].len; abs[i] = segs[which[i]].abs_pos; }
     ts_batch *b = ts_batch_create(ctx, lens.data(), abs.data(), which.size(), tips, 0);
     if (!b) return ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP;
     std::vector<const char *> ptrs(which.size());
     for (size_t i = 0; i < which.size(); ++i) ptrs[i] = segs[which[i]].seq;
+    const bool timing = getenv("TS_TIMING") != nullptr;          // stage times to stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
+        return std::chrono::duration<double, std::milli>(y - x).count();
+    };
+    const auto t0 = now();
     int rc = batch_upload_all(b, ptrs);
+    const auto t1 = now();
     if (rc == TS_OK) rc = ts_batch_scan(b, nullptr, nullptr);
     if (rc == TS_OK) rc = ts_batch_sync(b);
+    const auto t2 = now();
     std::vector<ts_segment_out> tmp(which.size());
     if (rc == TS_OK) rc = ts_batch_download(b, nullptr, tmp.data());
+    if (timing)
+        fprintf(stderr, "ts_scan_segments: plan %.1f ms, upload %.1f ms, scan %.1f ms, download + host post-processing %.1f ms\n",
+                ms(t_begin, t0), ms(t0, t1), ms(t1, t2), ms(t2, now()));
     if (rc == TS_OK)
         for (size_t i = 0; i < which.size(); ++i) out[which[i]] = tmp[i];
     else

@@ -104,20 +104,48 @@ class SegmentData:
         self.terminalBlocks = K.copy_array(out.terminal_blocks, out.n_terminal_blocks, K.BLOCK_DT)
         self.interstitialBlocks = K.copy_array(out.interstitial_blocks, out.n_interstitial_blocks,
                                                K.BLOCK_DT)
-        m = K.copy_array(out.matches, out.n_matches, K.MATCH_DT)
-        fwd = (m["flags"] & K.MATCH_FORWARD) != 0
-        can = (m["flags"] & K.MATCH_CANONICAL) != 0
-        term = (m["flags"] & K.MATCH_TERMINAL) != 0
-        self.fwdMatches = m[fwd]
-        self.revMatches = m[~fwd]
-        if tipsOnly:                       # src/teloscope.cpp:566-570 fills fwd/rev only
-            self.allMatches = m[:0]
-            self.canonicalMatches = m[:0]
-            self.nonCanonicalMatches = m[:0]
-        else:
-            self.allMatches = m
-            self.canonicalMatches = m[can]
-            self.nonCanonicalMatches = m[~can & term]
+        self._m = K.copy_array(out.matches, out.n_matches, K.MATCH_DT)
+        self._tips = tipsOnly
+        self._split = {}
+
+    # The five match vectors of SegmentData are views/selections of one record array; the selections
+    # are made on first use (a 250 Mb contig has ~8 M matches: five eager copies cost more than the scan).
+    def _sel(self, name):
+        if name not in self._split:
+            m = self._m
+            f = m["flags"]
+            if name == "fwd":
+                v = m[(f & K.MATCH_FORWARD) != 0]
+            elif name == "rev":
+                v = m[(f & K.MATCH_FORWARD) == 0]
+            elif self._tips:                   # src/teloscope.cpp:566-570 fills fwd/rev only
+                v = m[:0]
+            elif name == "can":
+                v = m[(f & K.MATCH_CANONICAL) != 0]
+            else:
+                v = m[((f & K.MATCH_CANONICAL) == 0) & ((f & K.MATCH_TERMINAL) != 0)]
+            self._split[name] = v
+        return self._split[name]
+
+    @property
+    def allMatches(self):
+        return self._m[:0] if self._tips else self._m
+
+    @property
+    def fwdMatches(self):
+        return self._sel("fwd")
+
+    @property
+    def revMatches(self):
+        return self._sel("rev")
+
+    @property
+    def canonicalMatches(self):
+        return self._sel("can")
+
+    @property
+    def nonCanonicalMatches(self):
+        return self._sel("noncan")
 
 
 class _Ctx:
