@@ -149,9 +149,10 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     }
     // Search (waves per workgroup, chunks per tile) for the best modelled throughput:
     //   owned bases per tile x occupancy factor / instructions per tile.
-    // Instructions: ~272 per chunk (decode, probes, planes, emit), ~200 per pass of the window loops
-    // (64 window fields per pass), ~100 fixed.  Occupancy factors are measured (profiles/r01/
-    // geometry_sweep.txt): the kernel is VALU-bound at 16 waves per CU and loses 12 % at 12, 31 % at 8.
+    // Instructions: ~470 per 2016-position chunk (decode, probes, count planes, per-match pass), ~170 per
+    // pass of the window loop (64 window fields per pass), ~100 fixed per tile.  Occupancy factors are
+    // measured (profiles/r01/geometry_sweep.txt): against 16 waves per CU the kernel loses 12 % at 12
+    // waves and 31 % at 8; more than 16 is not reachable (two workgroups per CU did not co-reside).
     static const struct { uint32_t waves; double factor; } kOccupancy[] = {
         {16, 1.0}, {12, 0.88}, {8, 0.69}, {4, 0.43}, {2, 0.22}, {1, 0.11}};
     uint32_t nch_min = 1;
