@@ -17,11 +17,14 @@
 #ifndef TELOSCOPE_MI355X_HPP
 #define TELOSCOPE_MI355X_HPP
 
+#include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -192,6 +195,9 @@ class Teloscope {                              // include/teloscope.h:166-300 (s
             w.fwdCovered = g.fwd_covered; w.revCovered = g.rev_covered;
             sd.windows.push_back(w);
         }
+        if (!tipsOnly) sd.allMatches.reserve(o.n_matches);
+        sd.fwdMatches.reserve(o.n_matches / 2 + 1);
+        sd.revMatches.reserve(o.n_matches / 2 + 1);
         for (uint64_t i = 0; i < o.n_matches; ++i) {
             const ts_match &g = o.matches[i];
             MatchInfo m;
@@ -234,10 +240,27 @@ public:
         std::vector<ts_segment_out> out(segs.size());
         if (ts_scan_segments(ctx.get(), in.data(), in.size(), out.data()) != TS_OK)
             throw std::runtime_error(ts_last_error(ctx.get()));
-        std::vector<SegmentData> res;
-        res.reserve(segs.size());
-        for (size_t i = 0; i < segs.size(); ++i)
-            res.push_back(convert(out[i], *segs[i].sequence, segs[i].absPos, segs[i].tipsOnly));
+        // SegmentData's five MatchInfo vectors (56-byte records holding a std::string) are the costly part
+        // of the mirror: segments are converted on up to 16 host threads, largest first
+        std::vector<SegmentData> res(segs.size());
+        std::vector<size_t> order(segs.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return out[a].n_matches > out[b].n_matches; });
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t k; (k = next.fetch_add(1)) < order.size();) {
+                const size_t i = order[k];
+                res[i] = convert(out[i], *segs[i].sequence, segs[i].absPos, segs[i].tipsOnly);
+            }
+        };
+        const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), segs.size(), size_t(std::max(1u, std::thread::hardware_concurrency()))}));
+        if (nt <= 1) {
+            worker();
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned i = 0; i < nt; ++i) pool.emplace_back(worker);
+            for (std::thread &th : pool) th.join();
+        }
         ts_free_segments(out.data(), out.size());
         return res;
     }

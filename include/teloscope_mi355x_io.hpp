@@ -1,0 +1,389 @@
+// teloscope_mi355x_io.hpp — the callers and writers either side of the scan path (SURVEY §8 row f2,
+// and the part of f3 the writers need), host-side C++17 above teloscope_mi355x.hpp:
+//
+//   splitPath / walkPaths   what Teloscope::walkPath does per path (src/input.cpp:942-1041): cut a
+//                           record into '+' segments and N-gaps, scan, concatenate, label — but with
+//                           ONE batched scanSegments call for every segment of every path, which is
+//                           what a GPU back end needs;
+//   writeBEDFiles           the eleven output files of handleBEDFile / writeBEDFile
+//                           (src/teloscope.cpp:661-957; formats in docs/outputs.md) and the console
+//                           path report;
+//   printSummary            the assembly summary (src/teloscope.cpp:959-1055), to console and report.
+//
+// Once the scan takes milliseconds, formatting 6-15 M lines x 5 files is the end-to-end bottleneck, so
+// lines are formatted by a pool of host threads into per-task buffers (std::to_chars: integers, and
+// floats exactly as operator<<(float) prints them — "%g" with 6 significant digits) and written in
+// path order.  Output is byte-identical for any thread count.
+#ifndef TELOSCOPE_MI355X_IO_HPP
+#define TELOSCOPE_MI355X_IO_HPP
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <charconv>
+#include <cstdio>
+#include <fstream>
+#include <ostream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "teloscope_mi355x.hpp"
+
+namespace teloscope_mi355x {
+
+struct GapInfo {                               // include/teloscope.h:97-100
+    uint64_t start = 0;
+    uint32_t length = 0;
+};
+
+struct PathData {                              // include/teloscope.h:151-163
+    unsigned int seqPos = 0;
+    std::string header;
+    std::vector<GapInfo> gapInfos;
+    uint64_t pathSize = 0;
+    std::vector<WindowData> windows;
+    std::vector<TelomereBlock> terminalBlocks;
+    std::vector<TelomereBlock> interstitialBlocks;
+    std::vector<MatchInfo> canonicalMatches;
+    std::vector<MatchInfo> nonCanonicalMatches;
+    std::string terminalLabel;
+    ScaffoldType scaffoldType = ScaffoldType::NONE;
+};
+
+struct FastaRecord {
+    std::string header;                        // first word after '>'
+    std::string sequence;
+};
+
+// Plain-text FASTA (the gz/BAM front ends are rows f3/f4).  '\r' is dropped, as gfalibs does.
+inline std::vector<FastaRecord> readFasta(const std::string &file) {
+    std::ifstream in(file);
+    if (!in) throw std::runtime_error("cannot open " + file);
+    std::vector<FastaRecord> recs;
+    std::string line;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!line.empty() && line[0] == '>') {
+            FastaRecord r;
+            const size_t e = line.find_first_of(" \t", 1);
+            r.header = line.substr(1, e == std::string::npos ? std::string::npos : e - 1);
+            recs.push_back(std::move(r));
+        } else if (!recs.empty()) {
+            recs.back().sequence += line;
+        }
+    }
+    return recs;
+}
+
+// A record as the path model sees it: every run of N/n (X/x) is one gap, what lies between is a '+'
+// segment, upper-cased (unmaskSequence).  Pinned by testFiles/expected/*_gaps.bed.
+struct PathComponents {
+    std::vector<std::pair<uint64_t, std::string>> segments;    // (absPos, bases)
+    std::vector<GapInfo> gaps;
+};
+
+inline PathComponents splitPath(const std::string &seq) {
+    PathComponents pc;
+    auto isGap = [](char c) { return c == 'N' || c == 'n' || c == 'X' || c == 'x'; };
+    const size_t n = seq.size();
+    size_t i = 0;
+    while (i < n) {
+        const bool gap = isGap(seq[i]);
+        size_t j = i;
+        while (j < n && isGap(seq[j]) == gap) ++j;
+        if (gap) {
+            pc.gaps.push_back(GapInfo{i, static_cast<uint32_t>(j - i)});
+        } else {
+            std::string s = seq.substr(i, j - i);
+            for (char &c : s)
+                if (c >= 'a' && c <= 'z') c = static_cast<char>(c - 32);
+            pc.segments.emplace_back(i, std::move(s));
+        }
+        i = j;
+    }
+    return pc;
+}
+
+// walkPath for every record, with one batched scan (result order = record order = seqPos order).
+inline std::vector<PathData> walkPaths(Teloscope &teloscope, const std::vector<FastaRecord> &records) {
+    const UserInputTeloscope &ui = teloscope.input();
+    std::vector<PathComponents> comps;
+    comps.reserve(records.size());
+    for (const FastaRecord &r : records) comps.push_back(splitPath(r.sequence));
+    std::vector<Teloscope::Segment> batch;
+    for (const PathComponents &pc : comps)
+        for (const auto &sg : pc.segments) batch.push_back(Teloscope::Segment{&sg.second, sg.first, ui.ultraFastMode});
+    std::vector<SegmentData> scanned = teloscope.scanSegments(batch);
+
+    std::vector<PathData> paths(records.size());
+    size_t si = 0;
+    for (size_t pi = 0; pi < records.size(); ++pi) {
+        PathData &pd = paths[pi];
+        pd.seqPos = static_cast<unsigned int>(pi);
+        pd.header = records[pi].header;
+        pd.pathSize = records[pi].sequence.size();
+        pd.gapInfos = comps[pi].gaps;
+        for (size_t k = 0; k < comps[pi].segments.size(); ++k, ++si) {
+            SegmentData &sd = scanned[si];
+            auto append = [](auto &dst, auto &src) {
+                dst.insert(dst.end(), std::make_move_iterator(src.begin()), std::make_move_iterator(src.end()));
+            };
+            append(pd.windows, sd.windows);
+            append(pd.terminalBlocks, sd.terminalBlocks);
+            append(pd.interstitialBlocks, sd.interstitialBlocks);
+            append(pd.canonicalMatches, sd.canonicalMatches);
+            append(pd.nonCanonicalMatches, sd.nonCanonicalMatches);
+        }
+        teloscope.labelTerminalBlocks(pd.terminalBlocks, static_cast<uint16_t>(pd.gapInfos.size()), pd.terminalLabel,
+                                      pd.scaffoldType, pd.pathSize, ui.terminalLimit);
+    }
+    return paths;
+}
+
+inline const char *scaffoldTypeToString(ScaffoldType t) {       // src/tools.cpp
+    static const char *names[] = {"t2t", "gapped_t2t", "misassembly", "gapped_misassembly", "incomplete",
+                                  "gapped_incomplete", "none", "gapped_none", "discordant", "gapped_discordant"};
+    return names[static_cast<int>(t)];
+}
+
+// Totals that writeBEDFile accumulates and printSummary reports.
+struct AssemblySummary {
+    uint32_t totalPaths = 0, totalNWindows = 0, totalITS = 0, totalCanMatches = 0, totalTelomeres = 0, totalGaps = 0;
+    uint32_t byType[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t scaffoldN50 = 0, contigN50 = 0;
+    float teloMean = 0.0f, teloMedian = 0.0f, teloMin = 0.0f, teloMax = 0.0f;
+};
+
+namespace detail {
+
+// the text operator<< produces, appended to a string without a stream
+inline void put(std::string &s, uint64_t v) {
+    char b[24];
+    s.append(b, std::to_chars(b, b + sizeof b, v).ptr);
+}
+inline void put(std::string &s, float v) {                      // default ostream float: %g, precision 6
+    char b[48];
+    s.append(b, std::to_chars(b, b + sizeof b, v, std::chars_format::general, 6).ptr);
+}
+inline void put(std::string &s, const std::string &v) { s += v; }
+inline void put(std::string &s, const char *v) { s += v; }
+inline void put(std::string &s, char v) { s += v; }
+
+template <typename... A>
+inline void line(std::string &s, const A &...a) { (put(s, a), ...); }
+
+inline uint64_t computeN50(std::vector<uint64_t> v) {           // include/teloscope.h:224-235
+    if (v.empty()) return 0;
+    std::sort(v.begin(), v.end(), [](uint64_t a, uint64_t b) { return a > b; });
+    uint64_t total = 0, cum = 0;
+    for (uint64_t l : v) total += l;
+    for (uint64_t l : v) { cum += l; if (cum * 2 >= total) return l; }
+    return v.back();
+}
+
+enum File { DENSITY, CANON_RATIO, STRAND_RATIO, GC, ENTROPY, CAN_MATCH, NONCAN_MATCH, TERMINAL, ITS, GAPS, REPORT, CONSOLE, NFILES };
+
+struct Task {                                  // a path's blocks/gaps/matches/report row, or a run of its windows
+    uint32_t path;
+    bool windows;
+    size_t w0, w1;
+};
+
+}  // namespace detail
+
+// handleBEDFile + writeBEDFile: writes <outBase>_*.bed / .bedgraph / _report.tsv and the console path
+// report; fills the totals printSummary needs.  `paths` must be in seqPos order (walkPaths' order).
+inline void writeBEDFiles(const std::string &outBase, const std::vector<PathData> &paths, const UserInputTeloscope &ui,
+                          std::ostream &console, AssemblySummary &sum, bool manualCuration = false, unsigned threads = 0) {
+    using namespace detail;
+    static const char *suffix[NFILES] = {"_window_repeat_density.bedgraph", "_window_canonical_ratio.bedgraph",
+                                         "_window_strand_ratio.bedgraph", "_window_gc.bedgraph", "_window_entropy.bedgraph",
+                                         "_canonical_matches.bed", "_noncanonical_matches.bed", "_terminal_telomeres.bed",
+                                         "_interstitial_telomeres.bed", "_gaps.bed", "_report.tsv", ""};
+    bool on[NFILES] = {ui.outWinRepeats, ui.outWinRepeats, ui.outWinRepeats, ui.outGC, ui.outEntropy, ui.outMatches,
+                       ui.outMatches, true, ui.outITS, true, true, false};
+    std::ofstream files[NFILES];
+    for (int f = 0; f < NFILES; ++f) {
+        if (!on[f]) continue;
+        files[f].open(outBase + suffix[f], std::ios::binary);
+        if (!files[f]) throw std::runtime_error("Could not open '" + outBase + suffix[f] + "' for writing.");
+    }
+    if (ui.outWinRepeats) {
+        files[DENSITY] << "track type=bedGraph name=\"Repeat Density\" description=\"Total repeat density per window\"\n";
+        files[CANON_RATIO] << "track type=bedGraph name=\"Canonical Ratio\" description=\"Canonical fraction of repeat density per window\"\n";
+        files[STRAND_RATIO] << "track type=bedGraph name=\"Strand Ratio\" description=\"Forward-strand fraction of repeat density per window\"\n";
+    }
+    if (ui.outEntropy) files[ENTROPY] << "track type=bedGraph name=\"Shannon Entropy\" description=\"Shannon entropy per window\"\n";
+    if (ui.outGC) files[GC] << "track type=bedGraph name=\"GC Content\" description=\"GC content per window\"\n";
+    console << "\n+++ Path Summary Report +++\n";
+    const char *cols = ui.ultraFastMode ? "pos\theader\ttelomeres\tlabels\tgaps\ttype\tgranular\n"
+                                        : "pos\theader\ttelomeres\tlabels\tgaps\ttype\tgranular\tits\tcanonical\twindows\n";
+    console << cols;
+    files[REPORT] << cols;
+
+    // work list in output order: per path its row/blocks/gaps/matches, then its windows in runs
+    constexpr size_t kRun = 1u << 16;
+    std::vector<Task> tasks;
+    for (uint32_t p = 0; p < paths.size(); ++p) {
+        tasks.push_back(Task{p, false, 0, 0});
+        for (size_t w = 0; w < paths[p].windows.size(); w += kRun)
+            tasks.push_back(Task{p, true, w, std::min(paths[p].windows.size(), w + kRun)});
+    }
+    std::vector<float> telomereLengths;
+    sum = AssemblySummary{};
+    sum.totalPaths = static_cast<uint32_t>(paths.size());
+
+    auto format = [&](const Task &t, std::array<std::string, NFILES> &o) {
+        const PathData &pd = paths[t.path];
+        const std::string &h = pd.header;
+        if (t.windows) {
+            for (size_t i = t.w0; i < t.w1; ++i) {
+                const WindowData &w = pd.windows[i];
+                const uint64_t end = w.windowStart + w.currentWindowSize;
+                if (ui.outWinRepeats) {
+                    const uint32_t covered = w.fwdCovered + w.revCovered;
+                    const float density = static_cast<float>(covered) / w.currentWindowSize;
+                    const float canon = covered > 0 ? static_cast<float>(w.canonicalCovered) / (w.canonicalCovered + w.nonCanonicalCovered) : -1.0f;
+                    const float strand = covered > 0 ? static_cast<float>(w.fwdCovered) / (w.fwdCovered + w.revCovered) : -1.0f;
+                    line(o[DENSITY], h, '\t', w.windowStart, '\t', end, '\t', density, '\n');
+                    line(o[CANON_RATIO], h, '\t', w.windowStart, '\t', end, '\t', canon, '\n');
+                    line(o[STRAND_RATIO], h, '\t', w.windowStart, '\t', end, '\t', strand, '\n');
+                }
+                if (ui.outEntropy) line(o[ENTROPY], h, '\t', w.windowStart, '\t', end, '\t', w.shannonEntropy, '\n');
+                if (ui.outGC) line(o[GC], h, '\t', w.windowStart, '\t', end, '\t', w.gcContent, '\n');
+            }
+            return;
+        }
+        for (const TelomereBlock &b : pd.terminalBlocks) {
+            const uint64_t end = b.start + b.blockLen;
+            const bool scaffoldTerminal = b.start < ui.terminalLimit || end > pd.pathSize - ui.terminalLimit;
+            if (scaffoldTerminal || manualCuration)
+                line(o[TERMINAL], h, '\t', b.start, '\t', end, '\t', uint64_t(b.blockLen), '\t', b.blockLabel, '\t',
+                     uint64_t(b.forwardCount), '\t', uint64_t(b.reverseCount), '\t', uint64_t(b.canonicalCount), '\t',
+                     uint64_t(b.nonCanonicalCount), '\t', pd.pathSize, '\t', scaffoldTerminal ? "scaffold" : "contig", '\n');
+        }
+        if (ui.outITS)
+            for (const TelomereBlock &b : pd.interstitialBlocks)
+                line(o[ITS], h, '\t', b.start, '\t', b.start + b.blockLen, '\t', uint64_t(b.blockLen), '\t', b.blockLabel, '\t',
+                     uint64_t(b.forwardCount), '\t', uint64_t(b.reverseCount), '\t', uint64_t(b.canonicalCount), '\t',
+                     uint64_t(b.nonCanonicalCount), '\t', pd.pathSize, '\n');
+        for (const GapInfo &g : pd.gapInfos) line(o[GAPS], h, '\t', g.start, '\t', g.start + g.length, '\n');
+        if (ui.outMatches) {
+            for (const MatchInfo &m : pd.canonicalMatches)
+                line(o[CAN_MATCH], h, '\t', m.position, '\t', m.position + m.matchSize, '\t', m.matchSeq, '\n');
+            for (const MatchInfo &m : pd.nonCanonicalMatches)
+                line(o[NONCAN_MATCH], h, '\t', m.position, '\t', m.position + m.matchSize, '\t', m.matchSeq, '\n');
+        }
+        uint64_t longest = 0;
+        std::string labels;
+        for (const TelomereBlock &b : pd.terminalBlocks)
+            if (b.isLongest) { ++longest; labels += b.blockLabel; }
+        std::string row;
+        line(row, uint64_t(pd.seqPos) + 1, '\t', h, '\t', longest, '\t', labels.empty() ? std::string("none") : labels, '\t',
+             uint64_t(static_cast<uint16_t>(pd.gapInfos.size())), '\t', scaffoldTypeToString(pd.scaffoldType), '\t', pd.terminalLabel);
+        if (!ui.ultraFastMode)
+            line(row, '\t', uint64_t(pd.interstitialBlocks.size()), '\t', uint64_t(pd.canonicalMatches.size()), '\t',
+                 uint64_t(pd.windows.size()));
+        row += '\n';
+        o[REPORT] += row;
+        o[CONSOLE] += row;
+    };
+
+    // batches of tasks are formatted in parallel and written in order
+    if (threads == 0) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t batch = static_cast<size_t>(threads) * 4;
+    std::vector<std::array<std::string, NFILES>> outs(batch);
+    for (size_t b0 = 0; b0 < tasks.size(); b0 += batch) {
+        const size_t nb = std::min(batch, tasks.size() - b0);
+        for (size_t i = 0; i < nb; ++i)
+            for (std::string &s : outs[i]) s.clear();
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < nb;) format(tasks[b0 + i], outs[i]);
+        };
+        const unsigned nt = static_cast<unsigned>(std::min<size_t>(threads, nb));
+        if (nt <= 1) {
+            worker();
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned i = 0; i < nt; ++i) pool.emplace_back(worker);
+            for (std::thread &th : pool) th.join();
+        }
+        for (size_t i = 0; i < nb; ++i) {
+            for (int f = 0; f < NFILES; ++f)
+                if (f != CONSOLE && on[f] && !outs[i][f].empty()) files[f].write(outs[i][f].data(), static_cast<std::streamsize>(outs[i][f].size()));
+            console << outs[i][CONSOLE];
+        }
+    }
+
+    // totals (what writeBEDFile accumulates while writing) and summary counts (computeSummaryCounts)
+    std::vector<uint64_t> scaffoldLens, contigLens;
+    for (const PathData &pd : paths) {
+        for (const TelomereBlock &b : pd.terminalBlocks)
+            if (b.isLongest) { ++sum.totalTelomeres; telomereLengths.push_back(static_cast<float>(b.blockLen)); }
+        sum.totalGaps += static_cast<uint16_t>(pd.gapInfos.size());
+        if (!ui.ultraFastMode) {
+            sum.totalNWindows += static_cast<uint32_t>(pd.windows.size());
+            sum.totalITS += static_cast<uint32_t>(pd.interstitialBlocks.size());
+            sum.totalCanMatches += static_cast<uint32_t>(pd.canonicalMatches.size());
+        }
+        sum.byType[static_cast<int>(pd.scaffoldType)]++;
+        scaffoldLens.push_back(pd.pathSize);
+        std::vector<GapInfo> gaps = pd.gapInfos;
+        std::sort(gaps.begin(), gaps.end(), [](const GapInfo &a, const GapInfo &b) { return a.start < b.start; });
+        uint64_t prevEnd = 0;
+        for (const GapInfo &g : gaps) {
+            if (g.start > prevEnd) contigLens.push_back(g.start - prevEnd);
+            prevEnd = g.start + g.length;
+        }
+        if (pd.pathSize > prevEnd) contigLens.push_back(pd.pathSize - prevEnd);
+    }
+    sum.scaffoldN50 = computeN50(scaffoldLens);
+    sum.contigN50 = computeN50(contigLens);
+    if (!telomereLengths.empty()) {                              // getStats, src/tools.cpp:23-51
+        std::vector<float> &v = telomereLengths;
+        float total = 0.0f;
+        sum.teloMin = sum.teloMax = v[0];
+        for (float x : v) { sum.teloMin = std::min(sum.teloMin, x); sum.teloMax = std::max(sum.teloMax, x); total += x; }
+        sum.teloMean = total / v.size();
+        std::sort(v.begin(), v.end());
+        const size_t mid = v.size() / 2;
+        sum.teloMedian = v.size() % 2 ? v[mid] : (v[mid] + v[mid - 1]) / 2;
+    }
+}
+
+// printSummary: the same text to the console and (appended) to <outBase>_report.tsv when given.
+inline void printSummary(std::ostream &console, const AssemblySummary &s, bool ultraFastMode, const std::string &reportFile = "") {
+    using detail::line;
+    std::string t;
+    line(t, "\n+++ Assembly Summary Report +++\n", "Total paths:\t", uint64_t(s.totalPaths), '\n', "Total gaps:\t", uint64_t(s.totalGaps), '\n',
+         "Scaffold N50:\t", s.scaffoldN50, '\n', "Contig N50:\t", s.contigN50, '\n', "Total telomeres:\t", uint64_t(s.totalTelomeres), '\n');
+    if (!ultraFastMode)
+        line(t, "Total ITS blocks:\t", uint64_t(s.totalITS), '\n', "Total canonical matches:\t", uint64_t(s.totalCanMatches), '\n',
+             "Total windows analyzed:\t", uint64_t(s.totalNWindows), '\n');
+    line(t, "\n+++ Telomere Statistics +++\n");
+    if (s.totalTelomeres > 0)
+        line(t, "Mean length:\t", s.teloMean, '\n', "Median length:\t", s.teloMedian, '\n', "Min length:\t", s.teloMin, '\n',
+             "Max length:\t", s.teloMax, '\n');
+    else
+        line(t, "No telomeres found for statistics.\n");
+    const uint32_t *c = s.byType;
+    line(t, "\n+++ Chromosome Telomere Counts+++\n", "Two telomeres:\t", uint64_t(c[0] + c[1] + c[2] + c[3]), '\n',
+         "One telomere:\t", uint64_t(c[4] + c[5]), '\n', "Zero telomeres:\t", uint64_t(c[6] + c[7]), '\n');
+    line(t, "\n+++ Chromosome Telomere/Gap Completeness+++\n", "T2T:\t", uint64_t(c[0]), '\n', "Gapped T2T:\t", uint64_t(c[1]), '\n',
+         "Misassembled:\t", uint64_t(c[2]), '\n', "Gapped misassembled:\t", uint64_t(c[3]), '\n', "Incomplete:\t", uint64_t(c[4]), '\n',
+         "Gapped incomplete:\t", uint64_t(c[5]), '\n', "No telomeres:\t", uint64_t(c[6]), '\n', "Gapped no telomeres:\t", uint64_t(c[7]), '\n',
+         "Discordant:\t", uint64_t(c[8]), '\n', "Gapped discordant:\t", uint64_t(c[9]), '\n');
+    console << t;
+    if (!reportFile.empty()) {
+        std::ofstream f(reportFile, std::ios::binary | std::ios::app);
+        if (!f) throw std::runtime_error("Could not open '" + reportFile + "' for writing.");
+        f << t;
+    }
+}
+
+}  // namespace teloscope_mi355x
+
+#endif

@@ -3,80 +3,34 @@
 // that the reference's own `.tst` manifests can be replayed through the GPU from C++:
 //   option loop of src/main.cpp:186-565 (flags the manifests use), FASTA -> '+' segments / N-gaps
 //   (gfalibs behaviour pinned by testFiles/expected/*_gaps.bed), walkPath (src/input.cpp:942-1041)
-//   with ONE batched scanSegments call for all segments, and the stdout of writeBEDFile /
-//   printSummary (src/teloscope.cpp:687-694, 815-857, 959-1055).
+//   with ONE batched scanSegments call for all segments, and writeBEDFile / printSummary
+//   (src/teloscope.cpp:661-1055) — the last three through include/teloscope_mi355x_io.hpp.
 // Usage: manifest_cli <flags as in the manifest's first line, input path already resolved>
-#include <algorithm>
+//        [--out-base <prefix>]   where the eleven output files go (default: a scratch prefix)
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include <fstream>
 #include <iostream>
+#include <unistd.h>
 #include <sstream>
 #include <string>
 #include <vector>
 
-#include "teloscope_mi355x.hpp"
+#include "teloscope_mi355x_io.hpp"
 
 using namespace teloscope_mi355x;
 
-struct Path {
-    std::string header, seq;
-    std::vector<std::pair<uint64_t, uint32_t>> gaps;
-    std::vector<std::pair<uint64_t, std::string>> segs;      // (absPos, upper-cased sequence)
-};
-
-static std::vector<Path> readFasta(const std::string &file) {
-    std::ifstream in(file);
-    if (!in) { fprintf(stderr, "Error: cannot open %s\n", file.c_str()); exit(EXIT_FAILURE); }
-    std::vector<Path> paths;
-    std::string line;
-    while (std::getline(in, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (!line.empty() && line[0] == '>') {
-            Path p;
-            std::istringstream hs(line.substr(1));
-            hs >> p.header;
-            paths.push_back(p);
-        } else if (!paths.empty()) {
-            paths.back().seq += line;
-        }
-    }
-    for (Path &p : paths) {
-        size_t i = 0, n = p.seq.size();
-        while (i < n) {
-            const bool gap = p.seq[i] == 'N' || p.seq[i] == 'n' || p.seq[i] == 'X' || p.seq[i] == 'x';
-            size_t j = i;
-            while (j < n && ((p.seq[j] == 'N' || p.seq[j] == 'n' || p.seq[j] == 'X' || p.seq[j] == 'x') == gap)) ++j;
-            if (gap) p.gaps.emplace_back(i, static_cast<uint32_t>(j - i));
-            else {
-                std::string s = p.seq.substr(i, j - i);
-                for (char &c : s) c = static_cast<char>(toupper(static_cast<unsigned char>(c)));   // unmaskSequence
-                p.segs.emplace_back(i, std::move(s));
-            }
-            i = j;
-        }
-    }
-    return paths;
-}
-
-static uint64_t n50(std::vector<uint64_t> v) {                // Teloscope::computeN50, include/teloscope.h:224-235
-    if (v.empty()) return 0;
-    std::sort(v.begin(), v.end(), [](uint64_t a, uint64_t b) { return a > b; });
-    uint64_t total = 0, cum = 0;
-    for (uint64_t l : v) total += l;
-    for (uint64_t l : v) { cum += l; if (cum * 2 >= total) return l; }
-    return v.back();
-}
-
 int main(int argc, char **argv) {
     UserInputTeloscope ui;
-    std::string input, canonical;
+    std::string input, canonical, outBase;
+    bool scratch = false, manualCuration = false;
     std::vector<std::string> rawPatterns;
     bool hasPatterns = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> std::string { if (i + 1 >= argc) exit(EXIT_FAILURE); return argv[++i]; };
         if (a == "-f") input = val();
+        else if (a == "--out-base") outBase = val();
         else if (a == "-o" || a == "-j") (void)val();
         else if (a == "-c") canonical = val();
         else if (a == "-p") {
@@ -100,7 +54,7 @@ int main(int argc, char **argv) {
         else if (a == "-i") { ui.outITS = true; ui.ultraFastMode = false; }
         else if (a == "-a") ui.ultraFastMode = false;
         else if (a == "-u") ui.ultraFastMode = !(ui.outWinRepeats || ui.outGC || ui.outEntropy || ui.outITS || ui.outMatches);
-        else if (a == "-n") {}
+        else if (a == "-n") manualCuration = true;              // --manual-curation, src/main.cpp:510
         else if (!a.empty() && a[0] != '-' && input.empty()) input = a;
     }
     if (ui.step > ui.windowSize) { fprintf(stderr, "Error: Step size cannot be larger than window size.\n"); return EXIT_FAILURE; }
@@ -111,79 +65,33 @@ int main(int argc, char **argv) {
         ui.patternInfo = expandPatternsWithOrientation(ui.rawPatterns, ui.editDistance, ui.canonicalFwd);
         Teloscope teloscope(ui);
 
-        std::vector<Path> paths = readFasta(input);
-        std::vector<Teloscope::Segment> batch;                 // every '+' segment of every path, one launch
-        for (const Path &p : paths)
-            for (const auto &sg : p.segs) batch.push_back(Teloscope::Segment{&sg.second, sg.first, ui.ultraFastMode});
-        std::vector<SegmentData> scanned = teloscope.scanSegments(batch);
-
-        std::cout << "\n+++ Path Summary Report +++\n";
-        std::cout << (ui.ultraFastMode ? "pos\theader\ttelomeres\tlabels\tgaps\ttype\tgranular\n"
-                                        : "pos\theader\ttelomeres\tlabels\tgaps\ttype\tgranular\tits\tcanonical\twindows\n");
-        static const char *typeNames[] = {"t2t", "gapped_t2t", "misassembly", "gapped_misassembly", "incomplete",
-                                          "gapped_incomplete", "none", "gapped_none", "discordant", "gapped_discordant"};
-        uint32_t counts[10] = {0}, totalTelomeres = 0, totalGaps = 0, totalITS = 0, totalCan = 0, totalWin = 0;
-        std::vector<float> teloLens;
-        std::vector<uint64_t> scafLens, contigLens;
-        size_t si = 0;
-        for (size_t pi = 0; pi < paths.size(); ++pi) {
-            const Path &p = paths[pi];
-            std::vector<TelomereBlock> terminal;
-            size_t its = 0, can = 0, win = 0;
-            for (size_t k = 0; k < p.segs.size(); ++k, ++si) {
-                const SegmentData &sd = scanned[si];
-                terminal.insert(terminal.end(), sd.terminalBlocks.begin(), sd.terminalBlocks.end());
-                its += sd.interstitialBlocks.size(); can += sd.canonicalMatches.size(); win += sd.windows.size();
-            }
-            std::string label;
-            ScaffoldType type;
-            teloscope.labelTerminalBlocks(terminal, static_cast<uint16_t>(p.gaps.size()), label, type, p.seq.size(), ui.terminalLimit);
-            int longest = 0;
-            std::string labels;
-            for (const TelomereBlock &b : terminal)
-                if (b.isLongest) { ++longest; labels += b.blockLabel; teloLens.push_back(static_cast<float>(b.blockLen)); }
-            std::cout << pi + 1 << "\t" << p.header << "\t" << longest << "\t" << (labels.empty() ? "none" : labels) << "\t"
-                      << static_cast<uint16_t>(p.gaps.size()) << "\t" << typeNames[static_cast<int>(type)] << "\t" << label;
-            if (!ui.ultraFastMode) std::cout << "\t" << its << "\t" << can << "\t" << win;
-            std::cout << "\n";
-            totalTelomeres += longest; totalGaps += static_cast<uint16_t>(p.gaps.size());
-            totalITS += its; totalCan += can; totalWin += win;
-            counts[static_cast<int>(type)]++;
-            scafLens.push_back(p.seq.size());
-            uint64_t prevEnd = 0;
-            for (const auto &g : p.gaps) { if (g.first > prevEnd) contigLens.push_back(g.first - prevEnd); prevEnd = g.first + g.second; }
-            if (p.seq.size() > prevEnd) contigLens.push_back(p.seq.size() - prevEnd);
+        const bool timing = getenv("TS_TIMING") != nullptr;      // stage times to stderr
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](auto x, auto y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+        const auto t0 = now();
+        std::vector<FastaRecord> records = readFasta(input);
+        const auto t1 = now();
+        std::vector<PathData> paths = walkPaths(teloscope, records);
+        const auto t2 = now();
+        if (outBase.empty()) {
+            const char *tmp = getenv("TMPDIR");
+            outBase = std::string(tmp ? tmp : "/tmp") + "/manifest_cli_" + std::to_string(static_cast<long>(getpid()));
+            scratch = true;
         }
-        std::cout << "\n+++ Assembly Summary Report +++\n";
-        std::cout << "Total paths:\t" << paths.size() << "\n" << "Total gaps:\t" << totalGaps << "\n"
-                  << "Scaffold N50:\t" << n50(scafLens) << "\n" << "Contig N50:\t" << n50(contigLens) << "\n"
-                  << "Total telomeres:\t" << totalTelomeres << "\n";
-        if (!ui.ultraFastMode)
-            std::cout << "Total ITS blocks:\t" << totalITS << "\n" << "Total canonical matches:\t" << totalCan << "\n"
-                      << "Total windows analyzed:\t" << totalWin << "\n";
-        std::cout << "\n+++ Telomere Statistics +++\n";
-        if (totalTelomeres > 0) {                                // getStats, src/tools.cpp:23-51
-            float sum = 0.0f, mn = teloLens[0], mx = teloLens[0];
-            for (float v : teloLens) { mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
-            const float mean = sum / teloLens.size();
-            std::vector<float> srt = teloLens;
-            std::sort(srt.begin(), srt.end());
-            const size_t mid = srt.size() / 2;
-            const float median = srt.size() % 2 ? srt[mid] : (srt[mid] + srt[mid - 1]) / 2;
-            std::cout << "Mean length:\t" << mean << "\n" << "Median length:\t" << median << "\n"
-                      << "Min length:\t" << mn << "\n" << "Max length:\t" << mx << "\n";
-        } else {
-            std::cout << "No telomeres found for statistics.\n";
+        AssemblySummary summary;
+        writeBEDFiles(outBase, paths, ui, std::cout, summary, manualCuration);
+        printSummary(std::cout, summary, ui.ultraFastMode, outBase + "_report.tsv");
+        if (timing) {
+            uint64_t bases = 0, windows = 0;
+            for (const PathData &pd : paths) { bases += pd.pathSize; windows += pd.windows.size(); }
+            fprintf(stderr, "manifest_cli: %.1f Mb, %llu windows: read %.0f ms, walkPaths (scan + host post-processing) %.0f ms, "
+                            "writeBEDFiles + printSummary %.0f ms\n", bases / 1e6, (unsigned long long)windows, ms(t0, t1), ms(t1, t2), ms(t2, now()));
         }
-        std::cout << "\n+++ Chromosome Telomere Counts+++\n"
-                  << "Two telomeres:\t" << counts[0] + counts[1] + counts[2] + counts[3] << "\n"
-                  << "One telomere:\t" << counts[4] + counts[5] << "\n" << "Zero telomeres:\t" << counts[6] + counts[7] << "\n";
-        std::cout << "\n+++ Chromosome Telomere/Gap Completeness+++\n"
-                  << "T2T:\t" << counts[0] << "\n" << "Gapped T2T:\t" << counts[1] << "\n"
-                  << "Misassembled:\t" << counts[2] << "\n" << "Gapped misassembled:\t" << counts[3] << "\n"
-                  << "Incomplete:\t" << counts[4] << "\n" << "Gapped incomplete:\t" << counts[5] << "\n"
-                  << "No telomeres:\t" << counts[6] << "\n" << "Gapped no telomeres:\t" << counts[7] << "\n"
-                  << "Discordant:\t" << counts[8] << "\n" << "Gapped discordant:\t" << counts[9] << "\n";
+        if (scratch)
+            for (const char *sfx : {"_window_repeat_density.bedgraph", "_window_canonical_ratio.bedgraph", "_window_strand_ratio.bedgraph",
+                                    "_window_gc.bedgraph", "_window_entropy.bedgraph", "_canonical_matches.bed", "_noncanonical_matches.bed",
+                                    "_terminal_telomeres.bed", "_interstitial_telomeres.bed", "_gaps.bed", "_report.tsv"})
+                std::remove((outBase + sfx).c_str());
     } catch (const std::exception &e) {
         fprintf(stderr, "Error: %s\n", e.what());
         return EXIT_FAILURE;

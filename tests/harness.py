@@ -329,6 +329,89 @@ def format_report(paths, opts):
     return "\n".join(out) + "\n"
 
 
+# ------------------------------------------------------------------ output files (row f2)
+BED_SUFFIXES = ("_window_repeat_density.bedgraph", "_window_canonical_ratio.bedgraph",
+                "_window_strand_ratio.bedgraph", "_window_gc.bedgraph", "_window_entropy.bedgraph",
+                "_canonical_matches.bed", "_noncanonical_matches.bed", "_terminal_telomeres.bed",
+                "_interstitial_telomeres.bed", "_gaps.bed", "_report.tsv")
+
+
+def format_bed_files(paths, records, opts):
+    """Independent restatement of handleBEDFile / writeBEDFile / printSummary
+    (src/teloscope.cpp:661-957, 994-1055; formats in docs/outputs.md): {suffix: text} for the files
+    the flags switch on.  `records` are the FASTA records the paths came from (matchSeq is a
+    substring of the upper-cased record, src/teloscope.cpp:466-468)."""
+    f32 = np.float32
+    out = {"_terminal_telomeres.bed": [], "_gaps.bed": [], "_report.tsv": []}
+    if opts.out_win_repeats:
+        out["_window_repeat_density.bedgraph"] = [
+            'track type=bedGraph name="Repeat Density" description="Total repeat density per window"']
+        out["_window_canonical_ratio.bedgraph"] = [
+            'track type=bedGraph name="Canonical Ratio" description="Canonical fraction of repeat density per window"']
+        out["_window_strand_ratio.bedgraph"] = [
+            'track type=bedGraph name="Strand Ratio" description="Forward-strand fraction of repeat density per window"']
+    if opts.out_entropy:
+        out["_window_entropy.bedgraph"] = [
+            'track type=bedGraph name="Shannon Entropy" description="Shannon entropy per window"']
+    if opts.out_gc:
+        out["_window_gc.bedgraph"] = ['track type=bedGraph name="GC Content" description="GC content per window"']
+    if opts.out_matches:
+        out["_canonical_matches.bed"] = []
+        out["_noncanonical_matches.bed"] = []
+    if opts.out_its:
+        out["_interstitial_telomeres.bed"] = []
+    report = format_report(paths, opts).split("\n")
+    # the report file holds the column header + path rows, then everything printSummary prints
+    out["_report.tsv"] = report[2:-1]
+    for pd, (_, seq) in zip(paths, records):
+        h, size = pd["header"], pd["path_size"]
+        for b in pd["terminal_blocks"]:
+            start, end = int(b["start"]), int(b["start"]) + int(b["block_len"])
+            limit = opts.terminal_limit
+            scaffold = start < limit or end > ((size - limit) & 0xFFFFFFFFFFFFFFFF)
+            if scaffold or opts.manual_curation:
+                out["_terminal_telomeres.bed"].append("\t".join(map(str, [
+                    h, start, end, int(b["block_len"]), b["block_label"].decode(), int(b["forward_count"]),
+                    int(b["reverse_count"]), int(b["canonical_count"]), int(b["non_canonical_count"]), size,
+                    "scaffold" if scaffold else "contig"])))
+        if opts.out_its and pd["interstitial_blocks"] is not None:
+            for b in pd["interstitial_blocks"]:
+                out["_interstitial_telomeres.bed"].append("\t".join(map(str, [
+                    h, int(b["start"]), int(b["start"]) + int(b["block_len"]), int(b["block_len"]),
+                    b["block_label"].decode(), int(b["forward_count"]), int(b["reverse_count"]),
+                    int(b["canonical_count"]), int(b["non_canonical_count"]), size])))
+        for gs, gl in pd["gaps"]:
+            out["_gaps.bed"].append("%s\t%d\t%d" % (h, gs, gs + gl))
+        if opts.out_matches:
+            up = seq.upper()
+            for key, name in (("canonical_matches", "_canonical_matches.bed"),
+                              ("non_canonical_matches", "_noncanonical_matches.bed")):
+                if pd[key] is None:
+                    continue
+                for m in pd[key]:
+                    p0, ln = int(m["position"]), int(m["match_size"])
+                    out[name].append("%s\t%d\t%d\t%s" % (h, p0, p0 + ln, up[p0:p0 + ln]))
+        if pd["windows"] is not None:
+            for w in pd["windows"]:
+                ws, sz = int(w["window_start"]), int(w["current_window_size"])
+                pre = "%s\t%d\t%d\t" % (h, ws, ws + sz)
+                if opts.out_win_repeats:
+                    fwd, rev = int(w["fwd_covered"]), int(w["rev_covered"])
+                    can, non = int(w["canonical_covered"]), int(w["non_canonical_covered"])
+                    tot = (fwd + rev) & 0xFFFFFFFF
+                    dens = f32(f32(tot) / f32(sz))
+                    cr = f32(f32(can) / f32((can + non) & 0xFFFFFFFF)) if tot > 0 else f32(-1.0)
+                    sr = f32(f32(fwd) / f32((fwd + rev) & 0xFFFFFFFF)) if tot > 0 else f32(-1.0)
+                    out["_window_repeat_density.bedgraph"].append(pre + _fmt_float(dens))
+                    out["_window_canonical_ratio.bedgraph"].append(pre + _fmt_float(cr))
+                    out["_window_strand_ratio.bedgraph"].append(pre + _fmt_float(sr))
+                if opts.out_entropy:
+                    out["_window_entropy.bedgraph"].append(pre + _fmt_float(w["shannon_entropy"]))
+                if opts.out_gc:
+                    out["_window_gc.bedgraph"].append(pre + _fmt_float(w["gc_content"]))
+    return {k: "".join(l + "\n" for l in v) for k, v in out.items()}
+
+
 # --------------------------------------------------------------------------- FASTQ
 def read_fastq_records(data):
     """4-line reader of src/input.cpp:113-138: blank lines between records are skipped,

@@ -25,7 +25,7 @@ def cli(tmp_path_factory):
     libdir = os.path.join(ROOT, "teloscope_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "manifest_cli.cpp"), "-L", libdir, "-lteloscan",
-                           "-Wl,-rpath," + libdir, "-o", str(out)])
+                           "-Wl,-rpath," + libdir, "-pthread", "-o", str(out)])
     return str(out)
 
 

@@ -1,0 +1,78 @@
+"""Row f2: the output files of handleBEDFile / writeBEDFile / printSummary
+(src/teloscope.cpp:661-1055), written by include/teloscope_mi355x_io.hpp from GPU results, against an
+independent restatement of the formats (tests/harness.py: format_bed_files) fed by the CPU oracle.
+The reference ships expected files only for the gap BEDs (testFiles/expected/*_gaps.bed) and, through
+the manifests' stdout, for the report rows; those are checked directly."""
+import glob
+import gzip
+import os
+import shlex
+import subprocess
+
+import pytest
+
+from tests import harness as H
+from tests.backends import OracleBackend
+from tests.test_cpp_mirror import cli  # noqa: F401  (fixture: builds tests/cpp/manifest_cli.cpp)
+
+CASES = [
+    ("t2t.fa", "-r -g -e -m -i"),
+    ("t2t.fa", ""),                                            # ultra-fast: terminal, gaps, report only
+    ("gapped_t2t.fa", "-w 500 -s 250 -r -g -e -m -i"),
+    ("multi_gap_t2t.fa", "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -m -i"),
+    ("multi.fa", "-r -i"),
+    ("discordant.fa", "-i -m -n"),
+    ("boundary_multiple_p.fa", "-r -g -i -n -t 700"),
+    ("bTaeGut7_chr33_mat.fa.gz", "-w 2000 -s 1000 -r -g -e -i"),
+]
+
+
+def _plain_fasta(tmp_path, name):
+    src = H.golden_path("testFiles/" + name)
+    if not src.endswith(".gz"):
+        return src
+    plain = tmp_path / name[:-3]
+    plain.write_bytes(gzip.open(src, "rb").read())
+    return str(plain)
+
+
+def expected_files(fasta, flags):
+    opts = H.parse_cli("%s %s" % (fasta, flags))
+    backend = OracleBackend(opts)
+    records = H.read_fasta(fasta)
+    paths = [H.walk_path(backend, opts, i, h, s) for i, (h, s) in enumerate(records)]
+    return H.format_bed_files(paths, records, opts), H.format_report(paths, opts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,flags", CASES)
+def test_output_files_match_the_reference_formats(cli, tmp_path, name, flags):  # noqa: F811
+    fasta = _plain_fasta(tmp_path, name)
+    base = str(tmp_path / "out")
+    r = subprocess.run([cli, "-f", fasta, "--out-base", base] + shlex.split(flags), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    exp, stdout = expected_files(fasta, flags)
+    assert r.stdout == stdout
+    for sfx in H.BED_SUFFIXES:
+        path = base + sfx
+        if sfx in exp:
+            with open(path) as fh:
+                got = fh.read()
+            assert got == exp[sfx], "%s differs" % sfx
+        else:
+            assert not os.path.exists(path), "%s must not be written with flags %r" % (sfx, flags)
+    golden = H.golden_path("testFiles/expected/%s_gaps.bed" % name)
+    if os.path.exists(golden):
+        assert open(base + "_gaps.bed").read() == open(golden).read()
+
+
+GAP_BEDS = sorted(glob.glob(os.path.join(H.golden_path("testFiles/expected"), "*_gaps.bed")))
+
+
+@pytest.mark.parametrize("bed", GAP_BEDS, ids=[os.path.basename(b) for b in GAP_BEDS])
+def test_format_restatement_reproduces_the_golden_gap_beds(bed):
+    """The formatter the GPU writers are checked against is itself pinned where the reference has files."""
+    fasta = H.golden_path("testFiles/" + os.path.basename(bed)[:-len("_gaps.bed")])
+    exp, _ = expected_files(fasta, "")
+    assert exp["_gaps.bed"] == open(bed).read()
