@@ -205,6 +205,20 @@ int ts_label_terminal_blocks(ts_block *blocks, size_t n, uint16_t gaps, uint64_t
 float ts_gc_content(const uint32_t counts[4], uint32_t window_size);
 float ts_shannon_entropy(const uint32_t counts[4], uint32_t window_size);
 
+/* ts_scan_segments for callers that do not read the match vectors (every reference run without -m:
+ * writeBEDFile reads windows, blocks and canonicalMatches.size() only, src/teloscope.cpp:700-868).
+ * Scan, terminal/interstitial block calling and the counts below all happen on the device; out[i] is
+ * what ts_scan_segments returns with matches == NULL / n_matches == 0, and counts[i] (optional, may be
+ * NULL) carries the sizes the match vectors would have had.  Free out with ts_free_segments(). */
+typedef struct ts_segment_counts {
+    uint64_t n_windows;         /* = windows.size() (0 for a tips-only segment) */
+    uint64_t n_matches;         /* full scan: allMatches.size(); tips-only: fwdMatches.size() + revMatches.size() */
+    uint64_t n_canonical;       /* canonicalMatches.size() of a full scan */
+    uint64_t n_forward;         /* fwdMatches.size() */
+} ts_segment_counts;
+int ts_scan_segments_blocks(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out,
+                            ts_segment_counts *counts);
+
 /* ---- device-resident batches: the same scan with inputs and outputs kept in HBM.
  *      Used by bench.py and the multi-GPU driver; ts_scan_segments is built on it. ----- */
 typedef struct ts_batch_info {

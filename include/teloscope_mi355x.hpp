@@ -182,7 +182,7 @@ class Teloscope {                              // include/teloscope.h:166-300 (s
     UserInputTeloscope userInput;
     detail::CtxPtr ctx;
 
-    SegmentData convert(const ts_segment_out &o, const std::string &sequence, uint64_t absPos, bool tipsOnly) const {
+    SegmentData convert(const ts_segment_out &o, const char *sequence, uint64_t absPos, bool tipsOnly) const {
         SegmentData sd;
         sd.windows.reserve(o.n_windows);
         for (uint64_t i = 0; i < o.n_windows; ++i) {
@@ -204,8 +204,11 @@ class Teloscope {                              // include/teloscope.h:166-300 (s
             m.position = g.position; m.matchSize = g.match_size;
             m.isForward = (g.flags & TS_MATCH_FORWARD) != 0;
             m.isCanonical = (g.flags & TS_MATCH_CANONICAL) != 0;
-            if (userInput.outMatches && !tipsOnly)                      // src/teloscope.cpp:466-468
-                m.matchSeq = sequence.substr(static_cast<size_t>(g.position - absPos), g.match_size);
+            if (userInput.outMatches && !tipsOnly) {                    // src/teloscope.cpp:466-468 (of the unmasked sequence)
+                m.matchSeq.assign(sequence + static_cast<size_t>(g.position - absPos), g.match_size);
+                for (char &ch : m.matchSeq)
+                    if (ch >= 'a' && ch <= 'z') ch = static_cast<char>(ch - 32);
+            }
             (m.isForward ? sd.fwdMatches : sd.revMatches).push_back(m);
             if (!tipsOnly) {                                            // routing of src/teloscope.cpp:485-509
                 sd.allMatches.push_back(m);
@@ -228,14 +231,22 @@ public:
 
     const UserInputTeloscope &input() const { return userInput; }
 
-    struct Segment { const std::string *sequence; uint64_t absPos; bool tipsOnly; };
+    // one scanSegment call of a batch; the bases are borrowed for the duration of the call (any case:
+    // the library folds case itself, as unmaskSequence would have)
+    struct Segment {
+        const char *data;
+        size_t size;
+        uint64_t absPos;
+        bool tipsOnly;
+        Segment(const char *d, size_t n, uint64_t a, bool t) : data(d), size(n), absPos(a), tipsOnly(t) {}
+        Segment(const std::string *s, uint64_t a, bool t) : data(s->data()), size(s->size()), absPos(a), tipsOnly(t) {}
+    };
 
     // batched scanSegment: result[i] is what scanSegment(*segs[i].sequence, absPos, tipsOnly) returns
     std::vector<SegmentData> scanSegments(const std::vector<Segment> &segs) {
         std::vector<ts_segment_in> in(segs.size());
         for (size_t i = 0; i < segs.size(); ++i) {
-            in[i] = ts_segment_in{segs[i].sequence->data(), segs[i].sequence->size(), segs[i].absPos,
-                                  static_cast<uint8_t>(segs[i].tipsOnly), {}};
+            in[i] = ts_segment_in{segs[i].data, segs[i].size, segs[i].absPos, static_cast<uint8_t>(segs[i].tipsOnly), {}};
         }
         std::vector<ts_segment_out> out(segs.size());
         if (ts_scan_segments(ctx.get(), in.data(), in.size(), out.data()) != TS_OK)
@@ -250,7 +261,7 @@ public:
         auto worker = [&]() {
             for (size_t k; (k = next.fetch_add(1)) < order.size();) {
                 const size_t i = order[k];
-                res[i] = convert(out[i], *segs[i].sequence, segs[i].absPos, segs[i].tipsOnly);
+                res[i] = convert(out[i], segs[i].data, segs[i].absPos, segs[i].tipsOnly);
             }
         };
         const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), segs.size(), size_t(std::max(1u, std::thread::hardware_concurrency()))}));
@@ -261,6 +272,25 @@ public:
             for (unsigned i = 0; i < nt; ++i) pool.emplace_back(worker);
             for (std::thread &th : pool) th.join();
         }
+        ts_free_segments(out.data(), out.size());
+        return res;
+    }
+
+    // scanSegments for callers that do not read the match vectors (every run without -m): scan, block
+    // calling and counting on the device (ts_scan_segments_blocks).  result[i] has windows and blocks;
+    // counts[i] = the sizes the match vectors would have had.
+    std::vector<SegmentData> scanSegmentsNoMatches(const std::vector<Segment> &segs, std::vector<ts_segment_counts> &counts) {
+        std::vector<ts_segment_in> in(segs.size());
+        for (size_t i = 0; i < segs.size(); ++i)
+            in[i] = ts_segment_in{segs[i].data, segs[i].size, segs[i].absPos, static_cast<uint8_t>(segs[i].tipsOnly), {}};
+        std::vector<ts_segment_out> out(segs.size());
+        counts.assign(segs.size(), ts_segment_counts{0, 0, 0, 0});
+        if (ts_scan_segments_blocks(ctx.get(), in.data(), in.size(), out.data(), counts.data()) != TS_OK)
+            throw std::runtime_error(ts_last_error(ctx.get()));
+        std::vector<SegmentData> res;
+        res.reserve(segs.size());
+        for (size_t i = 0; i < segs.size(); ++i)
+            res.push_back(convert(out[i], segs[i].data, segs[i].absPos, segs[i].tipsOnly));
         ts_free_segments(out.data(), out.size());
         return res;
     }

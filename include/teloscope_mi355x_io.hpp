@@ -50,6 +50,9 @@ struct PathData {                              // include/teloscope.h:151-163
     std::vector<MatchInfo> nonCanonicalMatches;
     std::string terminalLabel;
     ScaffoldType scaffoldType = ScaffoldType::NONE;
+    // not in the reference: canonicalMatches.size() as the report prints it, also when the match
+    // vectors were never brought to the host (walkPaths without -m counts on the device)
+    uint64_t canonicalMatchCount = 0;
 };
 
 struct FastaRecord {
@@ -78,9 +81,10 @@ inline std::vector<FastaRecord> readFasta(const std::string &file) {
 }
 
 // A record as the path model sees it: every run of N/n (X/x) is one gap, what lies between is a '+'
-// segment, upper-cased (unmaskSequence).  Pinned by testFiles/expected/*_gaps.bed.
+// segment.  Segments are views into the record (no copy; the library folds case itself, which is what
+// unmaskSequence does before every reference scanSegment call).  Pinned by testFiles/expected/*_gaps.bed.
 struct PathComponents {
-    std::vector<std::pair<uint64_t, std::string>> segments;    // (absPos, bases)
+    std::vector<std::pair<uint64_t, uint64_t>> segments;       // (absPos = offset in the record, length)
     std::vector<GapInfo> gaps;
 };
 
@@ -93,14 +97,8 @@ inline PathComponents splitPath(const std::string &seq) {
         const bool gap = isGap(seq[i]);
         size_t j = i;
         while (j < n && isGap(seq[j]) == gap) ++j;
-        if (gap) {
-            pc.gaps.push_back(GapInfo{i, static_cast<uint32_t>(j - i)});
-        } else {
-            std::string s = seq.substr(i, j - i);
-            for (char &c : s)
-                if (c >= 'a' && c <= 'z') c = static_cast<char>(c - 32);
-            pc.segments.emplace_back(i, std::move(s));
-        }
+        if (gap) pc.gaps.push_back(GapInfo{i, static_cast<uint32_t>(j - i)});
+        else pc.segments.emplace_back(i, j - i);
         i = j;
     }
     return pc;
@@ -113,9 +111,13 @@ inline std::vector<PathData> walkPaths(Teloscope &teloscope, const std::vector<F
     comps.reserve(records.size());
     for (const FastaRecord &r : records) comps.push_back(splitPath(r.sequence));
     std::vector<Teloscope::Segment> batch;
-    for (const PathComponents &pc : comps)
-        for (const auto &sg : pc.segments) batch.push_back(Teloscope::Segment{&sg.second, sg.first, ui.ultraFastMode});
-    std::vector<SegmentData> scanned = teloscope.scanSegments(batch);
+    for (size_t pi = 0; pi < records.size(); ++pi)
+        for (const auto &sg : comps[pi].segments)
+            batch.emplace_back(records[pi].sequence.data() + sg.first, static_cast<size_t>(sg.second), sg.first, ui.ultraFastMode);
+    // without -m nothing downstream reads a match record: blocks and counts come from the device
+    std::vector<ts_segment_counts> counts;
+    std::vector<SegmentData> scanned = ui.outMatches ? teloscope.scanSegments(batch)
+                                                      : teloscope.scanSegmentsNoMatches(batch, counts);
 
     std::vector<PathData> paths(records.size());
     size_t si = 0;
@@ -133,6 +135,7 @@ inline std::vector<PathData> walkPaths(Teloscope &teloscope, const std::vector<F
             append(pd.windows, sd.windows);
             append(pd.terminalBlocks, sd.terminalBlocks);
             append(pd.interstitialBlocks, sd.interstitialBlocks);
+            pd.canonicalMatchCount += ui.outMatches ? sd.canonicalMatches.size() : counts[si].n_canonical;
             append(pd.canonicalMatches, sd.canonicalMatches);
             append(pd.nonCanonicalMatches, sd.nonCanonicalMatches);
         }
@@ -284,7 +287,7 @@ inline void writeBEDFiles(const std::string &outBase, const std::vector<PathData
         line(row, uint64_t(pd.seqPos) + 1, '\t', h, '\t', longest, '\t', labels.empty() ? std::string("none") : labels, '\t',
              uint64_t(static_cast<uint16_t>(pd.gapInfos.size())), '\t', scaffoldTypeToString(pd.scaffoldType), '\t', pd.terminalLabel);
         if (!ui.ultraFastMode)
-            line(row, '\t', uint64_t(pd.interstitialBlocks.size()), '\t', uint64_t(pd.canonicalMatches.size()), '\t',
+            line(row, '\t', uint64_t(pd.interstitialBlocks.size()), '\t', pd.canonicalMatchCount, '\t',
                  uint64_t(pd.windows.size()));
         row += '\n';
         o[REPORT] += row;
@@ -327,7 +330,7 @@ inline void writeBEDFiles(const std::string &outBase, const std::vector<PathData
         if (!ui.ultraFastMode) {
             sum.totalNWindows += static_cast<uint32_t>(pd.windows.size());
             sum.totalITS += static_cast<uint32_t>(pd.interstitialBlocks.size());
-            sum.totalCanMatches += static_cast<uint32_t>(pd.canonicalMatches.size());
+            sum.totalCanMatches += static_cast<uint32_t>(pd.canonicalMatchCount);
         }
         sum.byType[static_cast<int>(pd.scaffoldType)]++;
         scaffoldLens.push_back(pd.pathSize);

@@ -68,6 +68,11 @@ class SegmentOut(C.Structure):
                 ("interstitial_blocks", C.POINTER(Block)), ("n_interstitial_blocks", C.c_uint64)]
 
 
+class SegmentCounts(C.Structure):
+    _fields_ = [("n_windows", C.c_uint64), ("n_matches", C.c_uint64), ("n_canonical", C.c_uint64),
+                ("n_forward", C.c_uint64)]
+
+
 class BatchInfo(C.Structure):
     _fields_ = [("n_segments", C.c_uint64), ("total_bases", C.c_uint64), ("input_bytes", C.c_uint64),
                 ("n_windows", C.c_uint64), ("n_tiles", C.c_uint64), ("match_capacity", C.c_uint64),
@@ -84,7 +89,7 @@ BLOCK_DT = np.dtype(Block)
 SYMBOLS = [
     "ts_abi_version", "ts_last_error", "ts_device_count", "ts_canonical_orientation",
     "ts_expand_patterns", "ts_free_patterns", "ts_create", "ts_destroy", "ts_uses_fast_path",
-    "ts_scan_segments", "ts_free_segments", "ts_create_read_filter", "ts_filter_reads",
+    "ts_scan_segments", "ts_scan_segments_blocks", "ts_free_segments", "ts_create_read_filter", "ts_filter_reads",
     "ts_label_terminal_blocks", "ts_gc_content", "ts_shannon_entropy", "ts_batch_create",
     "ts_batch_destroy", "ts_batch_segment_offset", "ts_batch_input_ptr", "ts_batch_upload",
     "ts_batch_scan", "ts_batch_sync", "ts_batch_get_info", "ts_batch_windows_ptr",
@@ -132,6 +137,8 @@ def lib():
     L.ts_destroy.argtypes = [C.c_void_p]
     L.ts_uses_fast_path.argtypes = [C.c_void_p]
     L.ts_scan_segments.argtypes = [C.c_void_p, C.POINTER(SegmentIn), C.c_size_t, C.POINTER(SegmentOut)]
+    L.ts_scan_segments_blocks.argtypes = [C.c_void_p, C.POINTER(SegmentIn), C.c_size_t, C.POINTER(SegmentOut),
+                                          C.POINTER(SegmentCounts)]
     L.ts_free_segments.argtypes = [C.POINTER(SegmentOut), C.c_size_t]
     L.ts_filter_reads.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
                                   C.c_size_t, C.POINTER(C.c_uint8)]

@@ -1165,6 +1165,80 @@ int ts_scan_segments(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_s
     return rc;
 }
 
+// scanSegment for callers that do not read the match vectors: scan, block calling and the per-segment
+// counts all stay on the device; windows, blocks and four counters per segment cross PCIe.
+static int scan_group_blocks(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<size_t> &which, bool tips,
+                             ts_segment_out *out, ts_segment_counts *counts) {
+    if (which.empty()) return TS_OK;
+    std::vector<uint64_t> lens(which.size()), abs(which.size());
+    for (size_t i = 0; i < which.size(); ++i) { lens[i] = segs[which[i]].len; abs[i] = segs[which[i]].abs_pos; }
+    ts_batch *b = ts_batch_create(ctx, lens.data(), abs.data(), which.size(), tips, 0);
+    if (!b) return ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP;
+    std::vector<const char *> ptrs(which.size());
+    for (size_t i = 0; i < which.size(); ++i) ptrs[i] = segs[which[i]].seq;
+    int rc = batch_upload_all(b, ptrs);
+    if (rc == TS_OK) rc = ts_batch_scan(b, nullptr, nullptr);
+    if (rc == TS_OK) rc = ts_batch_sync(b);
+    std::vector<ts_segment_out> tmp(which.size());
+    if (rc == TS_OK) rc = ts_batch_download_blocks(b, tmp.data());
+    std::vector<unsigned long long> summary(4 * which.size());
+    if (rc == TS_OK && counts) {
+        DevBuf d_sum;
+        if (d_sum.ensure(summary.size() * 8 + 16) != hipSuccess) rc = ctx->fail(TS_ERR_ALLOC, "out of device memory");
+        if (rc == TS_OK) rc = ts_batch_segment_summary(b, d_sum.p, nullptr);
+        if (rc == TS_OK && hipMemcpy(summary.data(), d_sum.p, summary.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = ctx->fail(TS_ERR_HIP, "summary download failed");
+        d_sum.release();
+    }
+    if (rc == TS_OK) {
+        for (size_t i = 0; i < which.size(); ++i) {
+            out[which[i]] = tmp[i];
+            if (counts)
+                counts[which[i]] = ts_segment_counts{tips ? 0 : summary[4 * i], summary[4 * i + 1], summary[4 * i + 2], summary[4 * i + 3]};
+        }
+    } else {
+        ts_free_segments(tmp.data(), tmp.size());
+    }
+    ts_batch_destroy(b);
+    return rc;
+}
+
+int ts_scan_segments_blocks(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out,
+                            ts_segment_counts *counts) {
+    if (!ctx || (n_segs && (!segs || !out))) return TS_ERR_INVALID_ARG;
+    for (size_t i = 0; i < n_segs; ++i) {
+        std::memset(&out[i], 0, sizeof out[i]);
+        if (counts) counts[i] = ts_segment_counts{0, 0, 0, 0};
+        if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
+    }
+    std::vector<size_t> full, tips;
+    for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
+    // parameter sets outside the tiled kernel take the general path and drop the match vectors afterwards
+    auto via_matches = [&](const std::vector<size_t> &which, bool tips_mode) -> int {
+        int rc = scan_group_generic(ctx, segs, which, tips_mode, out);
+        if (rc != TS_OK) return rc;
+        for (size_t i : which) {
+            if (counts) {
+                ts_segment_counts cnt{tips_mode ? 0 : out[i].n_windows, out[i].n_matches, 0, 0};
+                for (uint64_t m = 0; m < out[i].n_matches; ++m) {
+                    cnt.n_canonical += (out[i].matches[m].flags & TS_MATCH_CANONICAL) ? 1 : 0;
+                    cnt.n_forward += (out[i].matches[m].flags & TS_MATCH_FORWARD) ? 1 : 0;
+                }
+                counts[i] = cnt;
+            }
+            std::free(out[i].matches);
+            out[i].matches = nullptr;
+            out[i].n_matches = 0;
+        }
+        return TS_OK;
+    };
+    std::string why;
+    int rc = full_scan_supported(ctx, why) ? scan_group_blocks(ctx, segs, full, false, out, counts) : via_matches(full, false);
+    if (rc == TS_OK) rc = ctx->fast_ok ? scan_group_blocks(ctx, segs, tips, true, out, counts) : via_matches(tips, true);
+    if (rc != TS_OK) ts_free_segments(out, n_segs);
+    return rc;
+}
+
 // =========================================================================== ReadTelomereFilter
 int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, size_t n_reads,
                     uint8_t *pass) {

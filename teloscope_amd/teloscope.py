@@ -206,36 +206,29 @@ class Teloscope:
         K.lib().ts_free_segments(out, n)
         return res
 
-    def scanSegmentsBlocksOnly(self, segments, tipsOnly=False):
-        """Device-resident variant: scan + block calling ON THE DEVICE (ts_batch_download_blocks);
-        returns SegmentData whose match vectors are empty (windows and blocks only).
-        segments = [(sequence, absPos)], all full-scan or all tips-only."""
+    def scanSegmentsBlocksOnly(self, segments, tipsOnly=False, with_counts=False):
+        """scanSegment for callers that do not read the match vectors (ts_scan_segments_blocks): scan +
+        block calling ON THE DEVICE; returns SegmentData whose match vectors are empty (windows and
+        blocks only).  segments = [(sequence, absPos)].  with_counts=True also returns, per segment,
+        the sizes the match vectors would have had: (n_windows, n_matches, n_canonical, n_forward)."""
         n = len(segments)
         seqs = [s.encode() if isinstance(s, str) else bytes(s) for s, _ in segments]
-        lens = (C.c_uint64 * max(1, n))(*[len(s) for s in seqs])
-        absp = (C.c_uint64 * max(1, n))(*[int(a) for _, a in segments])
-        L = K.lib()
-        b = L.ts_batch_create(self._ctx.ptr, lens, absp, n, int(bool(tipsOnly)), 0)
-        if not b:
-            raise K.TeloscanError(K.TS_ERR_UNSUPPORTED, self._ctx.error())
-        try:
-            for i, s in enumerate(seqs):
-                rc = L.ts_batch_upload(b, i, s)
-                if rc != K.TS_OK:
-                    raise K.TeloscanError(rc, self._ctx.error())
-            for fn in (lambda: L.ts_batch_scan(b, None, None), lambda: L.ts_batch_sync(b)):
-                rc = fn()
-                if rc != K.TS_OK:
-                    raise K.TeloscanError(rc, self._ctx.error())
-            out = (K.SegmentOut * max(1, n))()
-            rc = L.ts_batch_download_blocks(b, out)
-            if rc != K.TS_OK:
-                raise K.TeloscanError(rc, self._ctx.error())
-            res = [SegmentData(out[i], bool(tipsOnly)) for i in range(n)]
-            L.ts_free_segments(out, n)
-            return res
-        finally:
-            L.ts_batch_destroy(b)
+        arr = (K.SegmentIn * max(1, n))()
+        for i, (s, (_, a)) in enumerate(zip(seqs, segments)):
+            arr[i].seq = s
+            arr[i].len = len(s)
+            arr[i].abs_pos = int(a)
+            arr[i].tips_only = 1 if tipsOnly else 0
+        out = (K.SegmentOut * max(1, n))()
+        cnt = (K.SegmentCounts * max(1, n))()
+        rc = K.lib().ts_scan_segments_blocks(self._ctx.ptr, arr, n, out, cnt)
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, self._ctx.error())
+        res = [SegmentData(out[i], bool(tipsOnly)) for i in range(n)]
+        K.lib().ts_free_segments(out, n)
+        if with_counts:
+            return res, [(int(c.n_windows), int(c.n_matches), int(c.n_canonical), int(c.n_forward)) for c in cnt[:n]]
+        return res
 
     def scanSegment(self, sequence, absPos=0, tipsOnly=False):
         """SegmentData Teloscope::scanSegment(std::string&, uint64_t absPos, bool tipsOnly)."""

@@ -407,10 +407,15 @@ def test_device_block_calling_matches_oracle(cli):
         if i % 3 == 0 and n > 3000:                          # an inverted telomere and a mid-contig tract
             s = s[:n // 2] + seqgen.repeat_array(opts.canonical_fwd, 40).tobytes() + s[n // 2 + 240:]
         segs.append((s, int(rng.integers(0, 10 ** 6))))
-    got = prod.teloscope.scanSegmentsBlocksOnly(segs, tipsOnly=opts.ultra_fast)
+    got, counts = prod.teloscope.scanSegmentsBlocksOnly(segs, tipsOnly=opts.ultra_fast, with_counts=True)
     n_its = 0
-    for (s, ap), g in zip(segs, got):
+    for (s, ap), g, cnt in zip(segs, got, counts):
         e = orac.scan_segment(s, ap, opts.ultra_fast)
+        # the sizes the match vectors would have had, counted on the device
+        nfwd, nrev = len(e["fwd_matches"]), len(e["rev_matches"])
+        assert cnt[1] == nfwd + nrev and cnt[3] == nfwd, "%s counts len=%d" % (cli, len(s))
+        if not opts.ultra_fast:
+            assert cnt[0] == len(e["windows"]) and cnt[2] == len(e["canonical_matches"])
         for name, gb in (("terminal_blocks", g.terminalBlocks), ("interstitial_blocks", g.interstitialBlocks)):
             assert len(gb) == len(e[name]), "%s %s count len=%d" % (cli, name, len(s))
             for f in BLOCK_FIELDS:
