@@ -163,6 +163,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     uint32_t best_wpt = 0;
     for (const auto &occ : kOccupancy) {
         for (uint32_t nch = nch_min; nch <= nch_max; ++nch) {
+            if (nch * TS_CHUNK + 64u > 65535u) break;        // the match queue holds 16-bit plane coordinates
             TsScanParams cand = kp;
             cand.waves_per_wg = occ.waves;
             cand.nch = nch;

@@ -94,8 +94,9 @@ __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15
 //   cnt     nucleotide counts, one byte per 32 positions and letter (valid A, C, G, T among them).
 //           Layout [h / 4][letter][h % 4]: a letter's counts of four consecutive h share a dword
 //           (summed by one v_sad_u8), and a lane's four counts of one h sit at fixed offsets
-//   mlist   the match positions of the chunk being resolved (u16, chunk-relative), compacted in
-//           position order so that the per-match work runs on full wavefronts
+//   mlist   queue (ring of TS_LIST u16 plane coordinates) of match positions, appended to by every
+//           chunk in position order and consumed 64 at a time, so that the per-match work runs
+//           on full wavefronts
 //   rec     the nucleotide fields of the tile's window records, 4 x u32 per window
 //   wacc    the match fields of the tile's window records while they accumulate: one u64 per window
 //           = four 16-bit counters {canonical, non-canonical, forward, reverse}, bumped by ONE
@@ -111,7 +112,7 @@ __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     uint32_t o = 0;
     s.codes = o; o += align16((P.nch * 63u + 1u) * 8u);
     s.cnt = o; o += (P.windows_on && P.nuc_on) ? ((P.nch * 63u + 3u) >> 2) * 16u : 0u;
-    s.mlist = o; o += align16(TS_CHUNK * 2u);
+    s.mlist = o; o += TS_LIST * 2u;
     s.rec = o; o += (P.windows_on && P.nuc_on) ? align16(P.max_windows * 16u) : 0u;
     s.wacc = o; o += P.windows_on ? align16(P.max_windows * 8u * P.acc_copies) : 0u;
     s.stage = o; o += (P.stage_cap + 64u) * 4u;
@@ -201,6 +202,58 @@ void ts_scan_tiles(const TsScanParams P) {
         // Chunk c+1's 16 B/lane load is in flight while chunk c is resolved; the loop is unrolled
         // by two with alternating registers so the loaded value is never copied (a copy would
         // make the compiler wait for the load it was meant to overlap).
+        // ---- per-match work on full wavefronts.  Matches are a few per cent of the positions, so a
+        // lane-per-position loop would idle most lanes: instead every chunk appends its match positions,
+        // compacted in position order (prefix sum over the wave, then each lane writes out its set bits),
+        // to a queue in LDS, and the queue is consumed 64 matches at a time: flags from the flag table,
+        // the packed record, and the match's contribution to every window that contains it.  A pass only
+        // runs on 64 queued matches (fewer when the tile ends or the queue must make room).
+        uint32_t qhead = 0, qcount = 0;
+        auto drain_queue = [&](const uint32_t threshold) {
+            while (qcount >= threshold && qcount > 0u) {
+                const uint32_t n = qcount < 64u ? qcount : 64u;
+                if (done - flushed + 64u > P.stage_cap) flush_stage();
+                const bool live = lane < n;
+                const uint32_t xp = live ? (uint32_t)mlist[(qhead + lane) & (TS_LIST - 1u)] : 0u;   // plane coord of the match
+                // its k-mer, from the code plane (16 positions per dword)
+                const lds_u32 *cw = codes + (xp >> 4);
+                const uint32_t idx = __builtin_amdgcn_alignbit(cw[1], cw[0], (xp & 15u) * 2u) & kmask;
+                uint32_t fc;                                  // forward << 1 | canonical
+                if (FC_BYTES) fc = fc_bytes[idx];
+                else fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
+                // position in the tile, step block and offset inside it
+                const uint32_t u = xp - sh;                   // wraps for the few bases before the tile
+                uint32_t q = __umulhi(u, P.s_inv);
+                if (q * P.s > u) --q;
+                const uint32_t o = u - q * P.s;
+                // w == s: a match that would straddle a window end is lost (the carry rule of
+                // src/teloscope.cpp:611-628; pinned by t2t.fa -i = 199)
+                const bool valid = live && xp >= sh && !(P.straddle_fix && o + k > P.s);
+                const bool owned = valid && xp < own_end;
+                // record slot = rank among the owned matches of this pass
+                const u64 bal = __ballot(owned);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                const uint32_t slot = owned ? (done - flushed) + rank : P.stage_cap + lane;
+                stage[slot] = (u << 2) | fc;
+                done += (uint32_t)__popcll(bal);
+                ccan += owned ? (fc & 1u) : 0u;
+                cfwd += owned ? (fc >> 1) : 0u;
+                // {canonical, non-canonical, forward, reverse} as one 4 x 16-bit increment
+                const u64 inc = (u64)((fc & 1u) ? 1u : 0x10000u) | ((u64)((fc & 2u) ? 1u : 0x10000u) << 32);
+                // windows q, q-1, ... contain the match as long as it ends inside them
+                if (P.windows_on && !(TS_ABL & 4)) {
+                    for (uint32_t j = 0; j < nwper; ++j) {
+                        const uint32_t wi = q - j;            // wraps past window 0
+                        const bool in = valid && wi < T.nwin && o + k + j * P.s <= P.w;
+                        if (in) atomicAdd((unsigned long long *)(wacc + acc_off + wi), inc);
+                    }
+                }
+                qhead = (qhead + n) & (TS_LIST - 1u);
+                qcount -= n;
+            }
+            __builtin_amdgcn_wave_barrier();                  // the queue is appended to next
+        };
+
         auto resolve_chunk = [&](const uint32_t cpos, const uint32_t ch, const uint4 v0, const uint4 v1) {
             // cpos = c * TS_CHUNK, ch = c * 63.  A lane holds 32 consecutive bases (two packed dwords).
             // ASCII -> 2-bit codes (A0 C1 T2 G3) and a validity check, 4 bases per dword
@@ -296,11 +349,6 @@ void ts_scan_tiles(const TsScanParams P) {
                 }
             }
 
-            // ---- per-match work on full wavefronts.  Matches are a few per cent of the positions, so a
-            // lane-per-position loop would idle most lanes: instead the chunk's match positions are
-            // compacted into a list (prefix sum over the wave, then each lane writes out its set bits)
-            // and the list is consumed 64 matches at a time: flags from the flag table, the packed
-            // record, and the match's contribution to every window that contains it.
 #if TS_ABL & 16
             M32 = 0;
 #endif
@@ -309,55 +357,19 @@ void ts_scan_tiles(const TsScanParams P) {
                 const uint32_t nm = __popc(M32);
                 const uint32_t incl = wave_scan_incl(nm);
                 const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                // the queue keeps whatever is short of a full pass; it is emptied first if this chunk's
+                // matches would not fit behind it (dense repeats)
+                drain_queue(qcount + total > TS_LIST ? 1u : 64u);
                 {
-                    uint32_t o = incl - nm, m = M32;
-                    const uint32_t lbase = lane * 32u;
+                    uint32_t o = qhead + qcount + incl - nm, m = M32;
+                    const uint32_t lbase = cpos + lane * 32u;     // plane coordinates, < 65536 (nch <= 32)
                     while (m) {
-                        mlist[o++] = (uint16_t)(lbase + (uint32_t)__builtin_ctz(m));
+                        mlist[o++ & (TS_LIST - 1u)] = (uint16_t)(lbase + (uint32_t)__builtin_ctz(m));
                         m &= m - 1u;
                     }
                 }
+                qcount += total;
                 __builtin_amdgcn_wave_barrier();
-                for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
-                    if (done - flushed + 64u > P.stage_cap) flush_stage();
-                    const uint32_t tt = t0 + lane;
-                    const bool live = tt < total;
-                    const uint32_t xp = cpos + (live ? (uint32_t)mlist[tt] : 0u);      // plane coord of the match
-                    // its k-mer, from the code plane (16 positions per dword)
-                    const lds_u32 *cw = codes + (xp >> 4);
-                    const uint32_t idx = __builtin_amdgcn_alignbit(cw[1], cw[0], (xp & 15u) * 2u) & kmask;
-                    uint32_t fc;                                  // forward << 1 | canonical
-                    if (FC_BYTES) fc = fc_bytes[idx];
-                    else fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
-                    // position in the tile, step block and offset inside it
-                    const uint32_t u = xp - sh;                   // wraps for the few bases before the tile
-                    uint32_t q = __umulhi(u, P.s_inv);
-                    if (q * P.s > u) --q;
-                    const uint32_t o = u - q * P.s;
-                    // w == s: a match that would straddle a window end is lost (the carry rule of
-                    // src/teloscope.cpp:611-628; pinned by t2t.fa -i = 199)
-                    const bool valid = live && xp >= sh && !(P.straddle_fix && o + k > P.s);
-                    const bool owned = valid && xp < own_end;
-                    // record slot = rank among the owned matches of this pass
-                    const u64 bal = __ballot(owned);
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    const uint32_t slot = owned ? (done - flushed) + rank : P.stage_cap + lane;
-                    stage[slot] = (u << 2) | fc;
-                    done += (uint32_t)__popcll(bal);
-                    ccan += owned ? (fc & 1u) : 0u;
-                    cfwd += owned ? (fc >> 1) : 0u;
-                    // {canonical, non-canonical, forward, reverse} as one 4 x 16-bit increment
-                    const u64 inc = (u64)((fc & 1u) ? 1u : 0x10000u) | ((u64)((fc & 2u) ? 1u : 0x10000u) << 32);
-                    // windows q, q-1, ... contain the match as long as it ends inside them
-                    if (P.windows_on && !(TS_ABL & 4)) {
-                        for (uint32_t j = 0; j < nwper; ++j) {
-                            const uint32_t wi = q - j;            // wraps past window 0
-                            const bool in = valid && wi < T.nwin && o + k + j * P.s <= P.w;
-                            if (in) atomicAdd((unsigned long long *)(wacc + acc_off + wi), inc);
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();                  // the list is rewritten by the next chunk
             }
         };
         {
@@ -385,6 +397,7 @@ void ts_scan_tiles(const TsScanParams P) {
                 cpos += 2u * TS_CHUNK; ch += 126u;
             }
         }
+        drain_queue(1u);                          // the matches still queued when the tile ends
         __builtin_amdgcn_wave_barrier();          // planes written above are read by other lanes below
 
         // ------------------------------------------------------------------ phase 2: windows

@@ -13,6 +13,7 @@
 // byte offset from the 16-byte-aligned address at or below the tile's first owned base.
 
 #define TS_MAX_WG_THREADS 1024         // up to 16 wavefronts per workgroup, one workgroup per CU
+#define TS_LIST         2048           // entries of a wave's match queue (power of two; a chunk adds at most 2016)
 #define TS_CHUNK        2016           // positions a wave resolves per iteration (63 lanes x 32)
 #define TS_BLK_COUNTERS 10             // 4 NB dwords of window nucleotide counts, then per step block: match head[3] rest[3]
 #define TS_IN_PAD       4096           // bytes of zero padding after the last segment in the input buffer
