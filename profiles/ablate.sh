@@ -5,7 +5,7 @@
 #   profiles/ablate.sh build && gpurun -- 'profiles/ablate.sh run > gpurun_out/ablate.txt'
 set -e
 cd "$(dirname "$0")/.."
-MASKS="0 1 2 4 8 16 32 64"
+MASKS="0 1 2 4 8 16 32 64 128"
 if [ "$1" = build ]; then
     for m in $MASKS; do
         (cd teloscope_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 \

@@ -33,6 +33,7 @@
 // so that stage costs can be measured under real overlap; see profiles/ablate.sh.
 //   1 record flush to global  2 nucleotide window sums  4 window match accumulation
 //   8 window record stores  16 the whole per-match pass  32 table probes  64 code/count plane stores
+//   128 the consumption of the match queue (compaction still runs)
 #ifndef TS_ABL
 #define TS_ABL 0
 #endif
@@ -210,6 +211,7 @@ void ts_scan_tiles(const TsScanParams P) {
         // runs on 64 queued matches (fewer when the tile ends or the queue must make room).
         uint32_t qhead = 0, qcount = 0;
         auto drain_queue = [&](const uint32_t threshold) {
+            if (TS_ABL & 128) { qcount = 0; return; }           // profiling: compaction only, nothing consumed
             while (qcount >= threshold && qcount > 0u) {
                 const uint32_t n = qcount < 64u ? qcount : 64u;
                 if (done - flushed + 64u > P.stage_cap) flush_stage();
