@@ -5,7 +5,7 @@
 // scanSegment (:642-657).  With it only blocks (a few per segment) have to leave the GPU instead
 // of the whole match stream.
 //
-//   ts_terminal_blocks      one thread per segment: the reference's two-phase walk (chain matches
+//   ts_terminal_blocks      one wave per segment: the reference's two-phase walk (chain matches
 //                           <= -k apart inside the terminal zone, keep dense canonical sub-blocks,
 //                           merge sub-blocks <= -d apart, keep >= -l) over the forward list from
 //                           the start and the reverse list from the end; emits the blocks and the
@@ -92,14 +92,17 @@ __device__ void emit_block(const TsBlockCallParams &Q, TsDevBlock &b, uint32_t s
     Q.blocks[slot] = b;
 }
 
-// one direction of getTerminalBlocks for one segment; returns the boundary
+// One direction of getTerminalBlocks for one segment; returns the boundary.  Run by a whole wave: the
+// records are fetched 64 at a time (one coalesced load, lane i holds record i of the batch) and the
+// state machine steps through them with v_readlane, so every value it touches is wave-uniform and it
+// costs no memory round trip per match; lane 0 writes the blocks.
 __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, uint32_t seg, u64 n, u64 abs_pos,
-                                  bool from_start, uint32_t &seq) {
+                                  bool from_start, uint32_t &seq, uint32_t lane) {
     u64 boundary = from_start ? 0 : n;                     // segment-relative
-    Cursor c;
-    if (!(from_start ? V.first(c) : V.last(c))) return boundary;
     Chain ch; bool open = false;
+    ch.start = ch.end = ch.prev = 0; ch.counts = ch.fwd = ch.canon = ch.cov = ch.fwd_cov = ch.can_cov = 0;
     TsDevBlock cur; bool have_cur = false;
+    cur.start = 0; cur.block_len = 0;
     auto close_block = [&]() {
         if (cur.block_len >= Q.min_block_len) {
             cur.block_label = from_start ? 'p' : 'q';
@@ -107,8 +110,11 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
             const u64 left = rel_start, right = rel_end <= n ? n - rel_end : 0;
             cur.has_valid_or = from_start ? (left <= right) : (left >= right);
             boundary = from_start ? cur.start + cur.block_len : cur.start;
-            TsDevBlock out = cur;
-            emit_block(Q, out, seg, from_start ? 0u : 1u, seq++, abs_pos);
+            if (lane == 0) {
+                TsDevBlock out = cur;
+                emit_block(Q, out, seg, from_start ? 0u : 1u, seq, abs_pos);
+            }
+            ++seq;
         }
     };
     auto close_sub = [&]() {
@@ -131,28 +137,40 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
         }
         open = false;
     };
-    bool more = true;
-    while (more) {
-        const uint32_t r = V.rec(c);
-        if ((((r >> 1) & 1u) != 0u) == from_start) {      // forward list from the start, reverse from the end
-            const u64 p = V.pos(c, r);
-            bool handled = false;
-            if (open) {
-                const u64 gap = from_start ? p - ch.prev : ch.prev - p;
-                if (gap <= Q.max_match_dist) {
-                    if (from_start) ch.end = p + Q.k; else ch.start = p;
-                    ch.add(p, r, Q.k);
-                    handled = true;
-                } else close_sub();
-            }
-            if (!handled) {
-                const bool in_zone = n <= Q.terminal_limit ? true
-                                   : (from_start ? p < Q.terminal_limit : p >= n - Q.terminal_limit);
-                if (!in_zone) break;
-                ch.begin(p, r, Q.k); open = true;
+    bool stop = false;
+    const uint32_t ntile = V.t1 - V.t0;
+    for (uint32_t ti = 0; ti < ntile && !stop; ++ti) {
+        const uint32_t t = from_start ? V.t0 + ti : V.t1 - 1u - ti;
+        const uint32_t cnt = V.count(t);
+        if (cnt == 0u) continue;
+        const u64 off = V.tile_off[t];
+        const u64 tile_rel = V.tiles[t].in_off - V.base;
+        for (uint32_t b0 = 0; b0 < cnt && !stop; b0 += 64u) {
+            const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
+            const uint32_t lo = from_start ? b0 : cnt - b0 - nb;          // first record of the batch
+            const uint32_t mine = lane < nb ? V.matches[off + lo + lane] : 0u;
+            for (uint32_t j = 0; j < nb && !stop; ++j) {
+                const uint32_t jj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(from_start ? j : nb - 1u - j));
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)jj);
+                if ((((r >> 1) & 1u) != 0u) != from_start) continue;      // forward list from the start, reverse from the end
+                const u64 p = tile_rel + (r >> 2);
+                bool handled = false;
+                if (open) {
+                    const u64 gap = from_start ? p - ch.prev : ch.prev - p;
+                    if (gap <= Q.max_match_dist) {
+                        if (from_start) ch.end = p + Q.k; else ch.start = p;
+                        ch.add(p, r, Q.k);
+                        handled = true;
+                    } else close_sub();
+                }
+                if (!handled) {
+                    const bool in_zone = n <= Q.terminal_limit ? true
+                                       : (from_start ? p < Q.terminal_limit : p >= n - Q.terminal_limit);
+                    if (!in_zone) { stop = true; break; }
+                    ch.begin(p, r, Q.k); open = true;
+                }
             }
         }
-        more = from_start ? V.next(c) : V.prev(c);
     }
     if (open) close_sub();
     if (have_cur) close_block();
@@ -161,23 +179,35 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
 
 __global__ void ts_terminal_blocks(const TsBlockCallParams Q, const uint32_t *seg_first_tile, const u64 *seg_in_off,
                                    const u64 *seg_len, const u64 *seg_abs, uint32_t nseg, u64 *bounds) {
-    // one wave per segment: the lanes add up the segment's tile counts (a 250 Mb contig has ~35 k
-    // tiles), lane 0 then walks the two ends
+    // one workgroup of four waves per segment: all threads add up the segment's tile counts (a 250 Mb
+    // contig has ~35 k tiles), then wave 0 walks the forward list from the start while wave 1 walks
+    // the reverse list from the end
+    __shared__ u64 part[2][256];
     const uint32_t si = blockIdx.x;
     if (si >= nseg) return;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     SegView V{Q.tiles, Q.tile_off, Q.tile_stats, Q.matches, seg_first_tile[si], seg_first_tile[si + 1], seg_in_off[si]};
     const u64 n = seg_len[si];
     u64 total = 0, nfwd = 0;
-    for (uint32_t t = V.t0 + lane; t < V.t1; t += 64u) { total += V.tile_stats[4u * t]; nfwd += V.tile_stats[4u * t + 2u]; }
-    for (int o = 32; o >= 1; o >>= 1) { total += __shfl_xor(total, o); nfwd += __shfl_xor(nfwd, o); }
-    if (lane != 0) return;
-    uint32_t seq = 0;
-    u64 fb = 0, rb = n;
-    if (nfwd >= 2) fb = terminal_direction(Q, V, si, n, seg_abs[si], true, seq);
-    if (total - nfwd >= 2) rb = terminal_direction(Q, V, si, n, seg_abs[si], false, seq);
-    bounds[2ull * si] = fb;
-    bounds[2ull * si + 1] = (total >= 2 && fb < rb) ? rb : 0;   // rb = 0 disables the interstitial search
+    for (uint32_t t = V.t0 + threadIdx.x; t < V.t1; t += blockDim.x) { total += V.tile_stats[4u * t]; nfwd += V.tile_stats[4u * t + 2u]; }
+    part[0][threadIdx.x] = total; part[1][threadIdx.x] = nfwd;
+    __syncthreads();
+    for (uint32_t o = 128; o >= 1; o >>= 1) {
+        if (threadIdx.x < o) { part[0][threadIdx.x] += part[0][threadIdx.x + o]; part[1][threadIdx.x] += part[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    total = part[0][0]; nfwd = part[1][0];
+    if (wave >= 2) return;
+    uint32_t seq = 0;                                      // blocks are ordered by (direction, seq)
+    if (wave == 0) {
+        u64 fb = 0;
+        if (nfwd >= 2) fb = terminal_direction(Q, V, si, n, seg_abs[si], true, seq, lane);
+        if (lane == 0) bounds[2ull * si] = fb;
+    } else {
+        u64 rb = n;
+        if (total - nfwd >= 2) rb = terminal_direction(Q, V, si, n, seg_abs[si], false, seq, lane);
+        if (lane == 0) bounds[2ull * si + 1] = total >= 2 ? rb : 0;       // 0 disables the interstitial search
+    }
 }
 
 // computeBlockLabel, include/teloscope.h:217-222
@@ -188,18 +218,57 @@ __device__ char its_label(uint32_t fwd_count, uint32_t counts) {
     return 'b';
 }
 
+// A segment view that serves one tile's records from LDS (they were loaded with one coalesced sweep)
+// and everything else from global memory: chains rarely leave the tile they start in.
+struct TileView {
+    SegView V;
+    uint32_t tile, cnt;                      // the cached tile and its record count
+    u64 tile_rel;                            // segment-relative position of the tile's first base
+    const uint32_t *cache;                   // LDS copy of the tile's records (nullptr: not cached)
+
+    __device__ uint32_t count(uint32_t t) const { return t == tile ? cnt : V.count(t); }
+    __device__ uint32_t rec(Cursor c) const { return (cache && c.t == tile) ? cache[c.i] : V.rec(c); }
+    __device__ u64 pos(Cursor c, uint32_t r) const { return c.t == tile ? tile_rel + (r >> 2) : V.pos(c, r); }
+    __device__ bool next(Cursor &c) const {
+        if (c.i + 1u < count(c.t)) { ++c.i; return true; }
+        for (uint32_t t = c.t + 1u; t < V.t1; ++t)
+            if (V.count(t)) { c.t = t; c.i = 0; return true; }
+        return false;
+    }
+    __device__ bool prev(Cursor &c) const {
+        if (c.i > 0u) { --c.i; return true; }
+        for (uint32_t t = c.t; t > V.t0; --t)
+            if (V.count(t - 1u)) { c.t = t - 1u; c.i = V.count(t - 1u) - 1u; return true; }
+        return false;
+    }
+};
+
+#define TS_ITS_CACHE 1024                    // records of a tile kept in LDS (a tile holds ~230)
+
 __global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t *seg_first_tile,
                                        const u64 *seg_in_off, const u64 *seg_abs, const u64 *bounds,
                                        uint32_t ntiles) {
     // one wave per tile, lanes over its records
-    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    __shared__ uint32_t cache_all[4][TS_ITS_CACHE];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wave;
     if (tile >= ntiles) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t si = Q.tiles[tile].seg;
     const u64 fb = bounds[2ull * si], rb = bounds[2ull * si + 1];
-    if (rb == 0) return;
-    SegView V{Q.tiles, Q.tile_off, Q.tile_stats, Q.matches, seg_first_tile[si], seg_first_tile[si + 1], seg_in_off[si]};
-    const uint32_t cnt = V.count(tile);
+    if (rb == 0 || fb >= rb) return;
+    if (Q.tile_stats[4u * tile + 1u] == 0u) return;       // no canonical match in the tile: nothing can lead a block
+    TileView V{{Q.tiles, Q.tile_off, Q.tile_stats, Q.matches, seg_first_tile[si], seg_first_tile[si + 1], seg_in_off[si]},
+               tile, 0, 0, nullptr};
+    V.cnt = V.V.count(tile);
+    V.tile_rel = Q.tiles[tile].in_off - V.V.base;
+    const uint32_t cnt = V.cnt;
+    if (cnt <= TS_ITS_CACHE) {
+        const uint32_t *src = Q.matches + Q.tile_off[tile];
+        for (uint32_t i = lane; i < cnt; i += 64u) cache_all[wave][i] = src[i];
+        V.cache = cache_all[wave];
+        __builtin_amdgcn_wave_barrier();
+    }
     for (uint32_t i = lane; i < cnt; i += 64u) {
         Cursor c{tile, i};
         const uint32_t r = V.rec(c);
@@ -244,7 +313,7 @@ int ts_k_launch_block_call(const TsBlockCallParams *Q, const uint32_t *seg_first
                            const unsigned long long *seg_abs, uint32_t nseg, uint32_t ntiles,
                            unsigned long long *bounds, int with_its, void *stream) {
     if (nseg == 0) return 0;
-    hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(64), 0, (hipStream_t)stream, *Q,
+    hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(256), 0, (hipStream_t)stream, *Q,
                        seg_first_tile, seg_in_off, seg_len, seg_abs, nseg, bounds);
     if (with_its && ntiles)
         hipLaunchKernelGGL(ts_interstitial_blocks, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *Q,

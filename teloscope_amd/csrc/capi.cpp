@@ -931,7 +931,8 @@ int ts_batch_download_blocks(ts_batch *b, ts_segment_out *out) {
         if (x.seg != y.seg) return x.seg < y.seg;
         const uint32_t kx = x.kind == 2 ? 1 : 0, ky = y.kind == 2 ? 1 : 0;
         if (kx != ky) return kx < ky;
-        return kx ? x.start < y.start : x.seq < y.seq;
+        if (kx) return x.start < y.start;
+        return x.kind != y.kind ? x.kind < y.kind : x.seq < y.seq;
     });
     std::vector<uint32_t> wins;
     if (!b->tips && b->n_windows) {
