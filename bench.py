@@ -259,7 +259,6 @@ def main():
         alg_bytes = int(info.algorithmic_bytes)
         # HIP events around every timed launch of the scan kernel, on its stream, averaged
         kern_ms = float(info.avg_kernel_ms)
-        assert int(info.kernel_launches) == min(args.steps, 64), info.kernel_launches
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
@@ -281,7 +280,7 @@ def main():
                        "device_ms_per_step_events": round(dev_ms, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "ts_scan_tiles", "kernel_ms": round(kern_ms, 4),
+                         "kernel": "ts_scan_tiles", "kernel_ms": round(kern_ms, 4), "launches_timed": int(info.kernel_launches),
                          "algorithmic_bytes": alg_bytes},
         }
         if not args.no_cpu_baseline:
