@@ -939,32 +939,54 @@ int ts_batch_download_blocks(ts_batch *b, ts_segment_out *out) {
         wins.resize(b->n_windows * 8);
         HIP_TRY(c, hipMemcpy(wins.data(), b->d_windows.p, b->n_windows * 32, hipMemcpyDeviceToHost));
     }
-    size_t bi = 0;
-    std::vector<ts_match> none;
-    for (size_t si = 0; si < ns; ++si) {
-        const SegPlan &sp = b->segs[si];
-        int rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos, sp.n_windows ? &wins[sp.win_base * 8] : nullptr,
-                                  b->tips ? 0 : sp.n_windows, none, out[si]);       // windows only
-        if (rc != TS_OK) return rc;
-        std::vector<ts_block> term, its;
-        for (; bi < blocks.size() && blocks[bi].seg == si; ++bi) {
-            ts_block t{};
-            std::memcpy(&t, &blocks[bi], sizeof(ts_block));
-            (blocks[bi].kind == 2 ? its : term).push_back(t);
+    // per segment: window records (float metrics on the host) + its slice of the sorted block list;
+    // independent between segments, so they are finalised on up to 16 host threads
+    std::vector<size_t> blk_begin(ns + 1, blocks.size());
+    {
+        size_t bi = 0;
+        for (size_t si = 0; si < ns; ++si) {
+            blk_begin[si] = bi;
+            while (bi < blocks.size() && blocks[bi].seg == si) ++bi;
         }
-        auto put = [&](const std::vector<ts_block> &v, ts_block *&dst, uint64_t &n) -> bool {
-            n = v.size(); dst = nullptr;
-            if (v.empty()) return true;
-            dst = (ts_block *)std::malloc(v.size() * sizeof(ts_block));
-            if (!dst) return false;
-            std::memcpy(dst, v.data(), v.size() * sizeof(ts_block));
-            return true;
-        };
-        if (!put(term, out[si].terminal_blocks, out[si].n_terminal_blocks) ||
-            !put(its, out[si].interstitial_blocks, out[si].n_interstitial_blocks))
-            return c->fail(TS_ERR_ALLOC, "out of host memory");
+        blk_begin[ns] = bi;
     }
-    return TS_OK;
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_err{TS_OK};
+    auto worker = [&]() {
+        std::vector<ts_match> none;
+        for (size_t si; (si = next.fetch_add(1)) < ns && first_err.load() == TS_OK;) {
+            const SegPlan &sp = b->segs[si];
+            int rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos, sp.n_windows ? &wins[sp.win_base * 8] : nullptr,
+                                      b->tips ? 0 : sp.n_windows, none, out[si]);       // windows only
+            std::vector<ts_block> term, its;
+            for (size_t bi = blk_begin[si]; rc == TS_OK && bi < blk_begin[si + 1]; ++bi) {
+                ts_block t{};
+                std::memcpy(&t, &blocks[bi], sizeof(ts_block));
+                (blocks[bi].kind == 2 ? its : term).push_back(t);
+            }
+            auto put = [&](const std::vector<ts_block> &v, ts_block *&dst, uint64_t &n) -> bool {
+                n = v.size(); dst = nullptr;
+                if (v.empty()) return true;
+                dst = (ts_block *)std::malloc(v.size() * sizeof(ts_block));
+                if (!dst) return false;
+                std::memcpy(dst, v.data(), v.size() * sizeof(ts_block));
+                return true;
+            };
+            if (rc == TS_OK && (!put(term, out[si].terminal_blocks, out[si].n_terminal_blocks) ||
+                                !put(its, out[si].interstitial_blocks, out[si].n_interstitial_blocks)))
+                rc = c->fail(TS_ERR_ALLOC, "out of host memory");
+            if (rc != TS_OK) { int expected = TS_OK; first_err.compare_exchange_strong(expected, rc); return; }
+        }
+    };
+    const unsigned nthreads = (unsigned)std::min<size_t>({(size_t)16, ns, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+    if (nthreads <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned i = 0; i < nthreads; ++i) pool.emplace_back(worker);
+        for (std::thread &th : pool) th.join();
+    }
+    return first_err.load();
 }
 
 void ts_free_segments(ts_segment_out *out, size_t n_segs) {
