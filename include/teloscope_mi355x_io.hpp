@@ -22,12 +22,15 @@
 #include <atomic>
 #include <charconv>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <ostream>
 #include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <zlib.h>
 
 #include "teloscope_mi355x.hpp"
 
@@ -60,23 +63,53 @@ struct FastaRecord {
     std::string sequence;
 };
 
-// Plain-text FASTA (the gz/BAM front ends are rows f3/f4).  '\r' is dropped, as gfalibs does.
+// FASTA, plain or gzip-compressed (zlib reads both through the same calls; link with -lz).  The header
+// is the first word after '>', line ends and '\r' are dropped, as gfalibs does.  The FASTQ/BAM front
+// ends are rows f3/f4.
 inline std::vector<FastaRecord> readFasta(const std::string &file) {
-    std::ifstream in(file);
+    gzFile in = gzopen(file.c_str(), "rb");
     if (!in) throw std::runtime_error("cannot open " + file);
+    gzbuffer(in, 1u << 20);
     std::vector<FastaRecord> recs;
-    std::string line;
-    while (std::getline(in, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (!line.empty() && line[0] == '>') {
-            FastaRecord r;
-            const size_t e = line.find_first_of(" \t", 1);
-            r.header = line.substr(1, e == std::string::npos ? std::string::npos : e - 1);
-            recs.push_back(std::move(r));
-        } else if (!recs.empty()) {
-            recs.back().sequence += line;
+    std::vector<char> buf(1u << 22);
+    bool in_header = false, at_line_start = true;
+    std::string header_line;
+    for (;;) {
+        const int n = gzread(in, buf.data(), static_cast<unsigned>(buf.size()));
+        if (n < 0) { gzclose(in); throw std::runtime_error("read error in " + file); }
+        if (n == 0) break;
+        const char *p = buf.data(), *end = p + n;
+        while (p < end) {
+            if (in_header) {                                    // collect the header line
+                const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+                header_line.append(p, nl ? nl : end);
+                if (!nl) break;
+                if (!header_line.empty() && header_line.back() == '\r') header_line.pop_back();
+                FastaRecord r;
+                const size_t e = header_line.find_first_of(" \t");
+                r.header = header_line.substr(0, e);
+                recs.push_back(std::move(r));
+                header_line.clear();
+                in_header = false; at_line_start = true;
+                p = nl + 1;
+            } else if (at_line_start && *p == '>') {
+                in_header = true;
+                ++p;
+            } else {                                            // sequence bytes up to the end of the line
+                const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+                const char *stop = nl ? nl : end;
+                if (!recs.empty() && stop > p) {
+                    std::string &seq = recs.back().sequence;
+                    const size_t before = seq.size();
+                    seq.append(p, stop);
+                    if (seq.size() > before && seq.back() == '\r') seq.pop_back();
+                }
+                at_line_start = nl != nullptr;
+                p = nl ? nl + 1 : end;
+            }
         }
     }
+    gzclose(in);
     return recs;
 }
 

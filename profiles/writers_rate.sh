@@ -14,6 +14,6 @@ with open('/tmp/writers_rate.fa', 'wb') as fh:
         s = seqgen.chromosome(rng, 50_000_000, telo_repeats=2000, n_its=10)
         fh.write(b'>chr%d\n' % (i + 1)); fh.write(bytes(s)); fh.write(b'\n')
 PY
-g++ -std=c++17 -O2 -I include tests/cpp/manifest_cli.cpp -L teloscope_amd -lteloscan -Wl,-rpath,$PWD/teloscope_amd -pthread -o /tmp/manifest_cli
+g++ -std=c++17 -O2 -I include tests/cpp/manifest_cli.cpp -L teloscope_amd -lteloscan -Wl,-rpath,$PWD/teloscope_amd -pthread -lz -o /tmp/manifest_cli
 TS_TIMING=1 /tmp/manifest_cli -f /tmp/writers_rate.fa --out-base /tmp/writers_rate -c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -i > /tmp/writers_rate.stdout
 ls -la /tmp/writers_rate_* | awk '{print $5, $9}'

@@ -4,7 +4,6 @@ driven by tests/cpp/manifest_cli.cpp: on a GPU box every legacy `.tst` manifest 
 replayed through it and must reproduce the expected CLI stdout; on CPU it must build and refuse
 to run without a HIP device."""
 import glob
-import gzip
 import os
 import shlex
 import subprocess
@@ -25,7 +24,7 @@ def cli(tmp_path_factory):
     libdir = os.path.join(ROOT, "teloscope_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "manifest_cli.cpp"), "-L", libdir, "-lteloscan",
-                           "-Wl,-rpath," + libdir, "-pthread", "-o", str(out)])
+                           "-Wl,-rpath," + libdir, "-pthread", "-lz", "-o", str(out)])
     return str(out)
 
 
@@ -45,13 +44,7 @@ def test_cpp_mirror_replays_all_legacy_manifests(cli, tmp_path):
         args = []
         for tok in shlex.split(m["command"]):
             if tok.startswith("testFiles/"):
-                src = H.golden_path(tok)
-                if src.endswith(".gz"):                       # the driver reads plain FASTA
-                    plain = tmp_path / os.path.basename(src)[:-3]
-                    if not plain.exists():
-                        plain.write_bytes(gzip.open(src, "rb").read())
-                    src = str(plain)
-                tok = src
+                tok = H.golden_path(tok)                      # .fa and .fa.gz alike (zlib in readFasta)
             args.append(tok)
         r = subprocess.run([cli] + args, capture_output=True, text=True, timeout=120)
         if r.returncode != 0 or r.stdout.split("\n") != m["expected"].split("\n"):

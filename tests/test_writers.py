@@ -4,7 +4,6 @@ independent restatement of the formats (tests/harness.py: format_bed_files) fed 
 The reference ships expected files only for the gap BEDs (testFiles/expected/*_gaps.bed) and, through
 the manifests' stdout, for the report rows; those are checked directly."""
 import glob
-import gzip
 import os
 import shlex
 import subprocess
@@ -27,15 +26,6 @@ CASES = [
 ]
 
 
-def _plain_fasta(tmp_path, name):
-    src = H.golden_path("testFiles/" + name)
-    if not src.endswith(".gz"):
-        return src
-    plain = tmp_path / name[:-3]
-    plain.write_bytes(gzip.open(src, "rb").read())
-    return str(plain)
-
-
 def expected_files(fasta, flags):
     opts = H.parse_cli("%s %s" % (fasta, flags))
     backend = OracleBackend(opts)
@@ -47,7 +37,7 @@ def expected_files(fasta, flags):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,flags", CASES)
 def test_output_files_match_the_reference_formats(cli, tmp_path, name, flags):  # noqa: F811
-    fasta = _plain_fasta(tmp_path, name)
+    fasta = H.golden_path("testFiles/" + name)              # .fa.gz is read through zlib
     base = str(tmp_path / "out")
     r = subprocess.run([cli, "-f", fasta, "--out-base", base] + shlex.split(flags), capture_output=True, text=True,
                        timeout=300)
