@@ -337,6 +337,11 @@ public:
         return std::vector<bool>(pass.begin(), pass.end());
     }
 
+    // the same on borrowed buffers (no copies): pass[i] = matches(std::string(seqs[i], lens[i]))
+    void matchesPointers(const char *const *seqs, const uint64_t *lens, size_t n, uint8_t *pass) {
+        if (ts_filter_reads(ctx.get(), seqs, lens, n, pass) != TS_OK) throw std::runtime_error(ts_last_error(ctx.get()));
+    }
+
     // bool ReadTelomereFilter::matches(std::string sequence)
     bool matches(std::string sequence) { return matchesBatch({std::move(sequence)})[0]; }
 };

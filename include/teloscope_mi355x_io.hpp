@@ -178,6 +178,110 @@ inline std::vector<PathData> walkPaths(Teloscope &teloscope, const std::vector<F
     return paths;
 }
 
+// ---------------------------------------------------------------------------------------------
+// --fastq-subset (Input::readFastqSubset, src/input.cpp:737-832): echo the reads that carry a terminal
+// telomere block, in input order, byte for byte.  Records are read by the 4-line rules of
+// readFastqRecord (src/input.cpp:113-138: blank lines before a header are skipped, line contents are
+// kept verbatim, '\r' included) from a plain or gzip file ("-" = stdin) and filtered in batches of up
+// to readsPerBatch reads / basesPerBatch bases — a GPU batch, not the reference's 2048-record one.
+// Malformed input throws std::runtime_error with the reference's message.
+struct FastqSubsetResult { uint64_t kept = 0, total = 0; };
+
+namespace detail {
+class GzLines {                                // getline over zlib; '\n' removed, everything else kept
+    gzFile f;
+    std::vector<char> buf;
+    size_t pos = 0, len = 0;
+public:
+    explicit GzLines(const std::string &file) : f(file == "-" ? gzdopen(0, "rb") : gzopen(file.c_str(), "rb")), buf(1u << 22) {
+        if (!f) throw std::runtime_error("Stream not successful: " + file);
+        gzbuffer(f, 1u << 20);
+    }
+    ~GzLines() { if (f) gzclose(f); }
+    GzLines(const GzLines &) = delete;
+    GzLines &operator=(const GzLines &) = delete;
+    int peek() {
+        if (pos == len && !fill()) return -1;
+        return static_cast<unsigned char>(buf[pos]);
+    }
+    bool getline(std::string &line) {
+        line.clear();
+        bool any = false;
+        for (;;) {
+            if (pos == len && !fill()) return any;
+            any = true;
+            const char *p = buf.data() + pos;
+            const char *nl = static_cast<const char *>(std::memchr(p, '\n', len - pos));
+            if (nl) { line.append(p, nl); pos = static_cast<size_t>(nl - buf.data()) + 1; return true; }
+            line.append(p, static_cast<const char *>(buf.data()) + len);
+            pos = len;
+        }
+    }
+private:
+    bool fill() {
+        const int n = gzread(f, buf.data(), static_cast<unsigned>(buf.size()));
+        if (n < 0) throw std::runtime_error("read error in FASTQ input");
+        pos = 0; len = static_cast<size_t>(n);
+        return n > 0;
+    }
+};
+inline size_t logicalLineLength(const std::string &l) { return (!l.empty() && l.back() == '\r') ? l.size() - 1 : l.size(); }
+}  // namespace detail
+
+inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &out, ReadTelomereFilter &filter,
+                                     size_t readsPerBatch = 1u << 20, size_t basesPerBatch = 1u << 30) {
+    detail::GzLines in(inFile);
+    const int first = in.peek();
+    if (first < 0) throw std::runtime_error("FASTQ input is empty");
+    if (first != '@') throw std::runtime_error("FASTQ input must start with '@'");
+    struct Record { std::string header, sequence, plus, quality; };
+    std::vector<Record> batch;
+    FastqSubsetResult res;
+    size_t batchBases = 0;
+    uint64_t recordNumber = 0;
+    auto fail = [&](const char *msg) { throw std::runtime_error("FASTQ record " + std::to_string(recordNumber + 1) + ": " + msg); };
+    auto processBatch = [&]() {
+        if (batch.empty()) return;
+        std::vector<const char *> ptr(batch.size());
+        std::vector<uint64_t> len(batch.size());
+        for (size_t i = 0; i < batch.size(); ++i) { ptr[i] = batch[i].sequence.data(); len[i] = batch[i].sequence.size(); }
+        std::vector<uint8_t> pass(batch.size());
+        filter.matchesPointers(ptr.data(), len.data(), batch.size(), pass.data());
+        std::string text;
+        for (size_t i = 0; i < batch.size(); ++i) {
+            if (!pass[i]) continue;
+            const Record &r = batch[i];
+            text.append(r.header).push_back('\n');
+            text.append(r.sequence).push_back('\n');
+            text.append(r.plus).push_back('\n');
+            text.append(r.quality).push_back('\n');
+            ++res.kept;
+        }
+        res.total += batch.size();
+        out.write(text.data(), static_cast<std::streamsize>(text.size()));
+        if (!out.good()) throw std::runtime_error("failed while writing FASTQ subset");
+        batch.clear();
+        batchBases = 0;
+    };
+    for (;;) {
+        Record r;
+        bool got;
+        do { got = in.getline(r.header); } while (got && detail::logicalLineLength(r.header) == 0);
+        if (!got) break;
+        if (!in.getline(r.sequence) || !in.getline(r.plus) || !in.getline(r.quality)) fail("truncated FASTQ record");
+        if (r.header.empty() || r.header.front() != '@') fail("expected header line starting with '@'");
+        if (r.plus.empty() || r.plus.front() != '+') fail("expected separator line starting with '+'");
+        if (detail::logicalLineLength(r.sequence) != detail::logicalLineLength(r.quality)) fail("sequence and quality length differ");
+        ++recordNumber;
+        batchBases += r.sequence.size();
+        batch.push_back(std::move(r));
+        if (batch.size() >= readsPerBatch || batchBases >= basesPerBatch) processBatch();
+    }
+    processBatch();
+    out.flush();
+    return res;
+}
+
 inline const char *scaffoldTypeToString(ScaffoldType t) {       // src/tools.cpp
     static const char *names[] = {"t2t", "gapped_t2t", "misassembly", "gapped_misassembly", "incomplete",
                                   "gapped_incomplete", "none", "gapped_none", "discordant", "gapped_discordant"};

@@ -23,13 +23,14 @@ using namespace teloscope_mi355x;
 int main(int argc, char **argv) {
     UserInputTeloscope ui;
     std::string input, canonical, outBase;
-    bool scratch = false, manualCuration = false;
+    bool scratch = false, manualCuration = false, fastqSubsetMode = false;
     std::vector<std::string> rawPatterns;
     bool hasPatterns = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> std::string { if (i + 1 >= argc) exit(EXIT_FAILURE); return argv[++i]; };
         if (a == "-f") input = val();
+        else if (a == "--fastq-subset") fastqSubsetMode = true;
         else if (a == "--out-base") outBase = val();
         else if (a == "-o" || a == "-j") (void)val();
         else if (a == "-c") canonical = val();
@@ -63,6 +64,12 @@ int main(int argc, char **argv) {
         ui.rawPatterns = (hasPatterns && !rawPatterns.empty()) ? rawPatterns
                        : std::vector<std::string>{ui.canonicalFwd, ui.canonicalRev};
         ui.patternInfo = expandPatternsWithOrientation(ui.rawPatterns, ui.editDistance, ui.canonicalFwd);
+        if (fastqSubsetMode) {                                  // src/main.cpp:699-716: reads in, telomeric reads out
+            ReadTelomereFilter filter(ui);
+            const FastqSubsetResult r = fastqSubset(input.empty() ? "-" : input, std::cout, filter);
+            fprintf(stderr, "FASTQ subset: kept %llu of %llu reads.\n", (unsigned long long)r.kept, (unsigned long long)r.total);
+            return 0;
+        }
         Teloscope teloscope(ui);
 
         const bool timing = getenv("TS_TIMING") != nullptr;      // stage times to stderr

@@ -50,3 +50,40 @@ def test_cpp_mirror_replays_all_legacy_manifests(cli, tmp_path):
         if r.returncode != 0 or r.stdout.split("\n") != m["expected"].split("\n"):
             failures.append((os.path.basename(path), r.returncode, r.stderr[-200:]))
     assert not failures, failures[:5]
+
+
+FASTQ = [m for m in MANIFESTS if os.path.basename(m).startswith("fastq_subset")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FASTQ, ids=[os.path.basename(p) for p in FASTQ])
+def test_cpp_mirror_replays_fastq_manifests(cli, path):
+    """--fastq-subset through include/teloscope_mi355x_io.hpp (fastqSubset + ReadTelomereFilter on the
+    GPU): stdout must equal the reference's expected subset file byte for byte, the kept/total line and
+    the malformed-input message must match (src/input.cpp:737-832, 113-138)."""
+    m = H.load_manifest(path)
+    d = {}
+    for k, v in m["directives"]:
+        d.setdefault(k, []).append(v)
+    if " -o " in m["command"]:
+        pytest.skip("-o (file instead of stdout) belongs to the reference's front end")
+    args, stdin = [], None
+    toks = shlex.split(m["command"])
+    i = 0
+    while i < len(toks):
+        tok = toks[i]
+        if tok == "<":
+            stdin = open(H.golden_path(toks[i + 1]), "rb")
+            i += 2
+            continue
+        if tok.startswith("testFiles/"):
+            tok = H.golden_path(tok)
+        args.append(tok)
+        i += 1
+    r = subprocess.run([cli] + args, stdin=stdin, capture_output=True, timeout=120)
+    assert (r.returncode != 0) == (int(d["expect_exit"][0]) != 0), r.stderr
+    so = d.get("expect_stdout", ["ignore"])[0]
+    if so != "ignore":
+        assert r.stdout == open(H.golden_path(so), "rb").read()
+    for sub in d.get("expect_stderr_substr", []):
+        assert sub.encode() in r.stderr, (sub, r.stderr)
