@@ -30,6 +30,8 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "teloscope_mi355x.hpp"
@@ -188,96 +190,114 @@ inline std::vector<PathData> walkPaths(Teloscope &teloscope, const std::vector<F
 struct FastqSubsetResult { uint64_t kept = 0, total = 0; };
 
 namespace detail {
-class GzLines {                                // getline over zlib; '\n' removed, everything else kept
-    gzFile f;
-    std::vector<char> buf;
-    size_t pos = 0, len = 0;
-public:
-    explicit GzLines(const std::string &file) : f(file == "-" ? gzdopen(0, "rb") : gzopen(file.c_str(), "rb")), buf(1u << 22) {
-        if (!f) throw std::runtime_error("Stream not successful: " + file);
-        gzbuffer(f, 1u << 20);
-    }
-    ~GzLines() { if (f) gzclose(f); }
-    GzLines(const GzLines &) = delete;
-    GzLines &operator=(const GzLines &) = delete;
-    int peek() {
-        if (pos == len && !fill()) return -1;
-        return static_cast<unsigned char>(buf[pos]);
-    }
-    bool getline(std::string &line) {
-        line.clear();
-        bool any = false;
-        for (;;) {
-            if (pos == len && !fill()) return any;
-            any = true;
-            const char *p = buf.data() + pos;
-            const char *nl = static_cast<const char *>(std::memchr(p, '\n', len - pos));
-            if (nl) { line.append(p, nl); pos = static_cast<size_t>(nl - buf.data()) + 1; return true; }
-            line.append(p, static_cast<const char *>(buf.data()) + len);
-            pos = len;
-        }
-    }
-private:
-    bool fill() {
-        const int n = gzread(f, buf.data(), static_cast<unsigned>(buf.size()));
-        if (n < 0) throw std::runtime_error("read error in FASTQ input");
-        pos = 0; len = static_cast<size_t>(n);
-        return n > 0;
-    }
-};
-inline size_t logicalLineLength(const std::string &l) { return (!l.empty() && l.back() == '\r') ? l.size() - 1 : l.size(); }
+inline size_t logicalLineLength(const char *b, const char *e) { return (e > b && e[-1] == '\r') ? static_cast<size_t>(e - b) - 1 : static_cast<size_t>(e - b); }
 }  // namespace detail
 
 inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &out, ReadTelomereFilter &filter,
-                                     size_t readsPerBatch = 1u << 20, size_t basesPerBatch = 1u << 30) {
-    detail::GzLines in(inFile);
-    const int first = in.peek();
-    if (first < 0) throw std::runtime_error("FASTQ input is empty");
-    if (first != '@') throw std::runtime_error("FASTQ input must start with '@'");
-    struct Record { std::string header, sequence, plus, quality; };
-    std::vector<Record> batch;
+                                     size_t readsPerBatch = 1u << 20, size_t bytesPerBatch = 512u << 20) {
+    // The input is read in large blocks into one arena and parsed in place: a batch's sequences are
+    // handed to the filter as pointers into the arena and a kept record is echoed as the byte range of
+    // its four lines — no per-line copies.
+    // (a plain file is read with read(2) straight into the arena; gzip input and stdin go through zlib)
+    struct Source {
+        gzFile gz = nullptr;
+        int fd = -1;
+        ~Source() { if (gz) gzclose(gz); if (fd >= 0) ::close(fd); }
+        long get(char *dst, size_t n) {
+            if (gz) return gzread(gz, dst, static_cast<unsigned>(std::min<size_t>(n, 1u << 30)));
+            return static_cast<long>(::read(fd, dst, std::min<size_t>(n, 1u << 30)));
+        }
+    } src;
+    if (inFile != "-") {
+        src.fd = ::open(inFile.c_str(), O_RDONLY);
+        if (src.fd < 0) throw std::runtime_error("Stream not successful: " + inFile);
+        unsigned char magic[2] = {0, 0};
+        const bool gz = ::pread(src.fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (gz) { src.gz = gzdopen(src.fd, "rb"); src.fd = -1; }
+    } else {
+        src.gz = gzdopen(0, "rb");
+    }
+    if (!src.gz && src.fd < 0) throw std::runtime_error("Stream not successful: " + inFile);
+    if (src.gz) gzbuffer(src.gz, 1u << 20);
+    std::vector<char> arena(std::max<size_t>(bytesPerBatch, 1u << 16));
+    size_t have = 0;                       // valid bytes in the arena
+    bool eof = false, first = true;
     FastqSubsetResult res;
-    size_t batchBases = 0;
     uint64_t recordNumber = 0;
     auto fail = [&](const char *msg) { throw std::runtime_error("FASTQ record " + std::to_string(recordNumber + 1) + ": " + msg); };
-    auto processBatch = [&]() {
-        if (batch.empty()) return;
-        std::vector<const char *> ptr(batch.size());
-        std::vector<uint64_t> len(batch.size());
-        for (size_t i = 0; i < batch.size(); ++i) { ptr[i] = batch[i].sequence.data(); len[i] = batch[i].sequence.size(); }
-        std::vector<uint8_t> pass(batch.size());
-        filter.matchesPointers(ptr.data(), len.data(), batch.size(), pass.data());
-        std::string text;
-        for (size_t i = 0; i < batch.size(); ++i) {
-            if (!pass[i]) continue;
-            const Record &r = batch[i];
-            text.append(r.header).push_back('\n');
-            text.append(r.sequence).push_back('\n');
-            text.append(r.plus).push_back('\n');
-            text.append(r.quality).push_back('\n');
-            ++res.kept;
+    struct Rec { const char *begin, *seq, *end; uint64_t seqLen; bool needNewline; };
+    std::vector<Rec> batch;
+    std::vector<const char *> ptr;
+    std::vector<uint64_t> len;
+    std::vector<uint8_t> pass;
+    std::string text;
+    while (!eof || have > 0) {
+        while (!eof && have < arena.size()) {                  // fill
+            const long n = src.get(arena.data() + have, arena.size() - have);
+            if (n < 0) throw std::runtime_error("read error in FASTQ input");
+            if (n == 0) eof = true;
+            have += static_cast<size_t>(n);
         }
-        res.total += batch.size();
-        out.write(text.data(), static_cast<std::streamsize>(text.size()));
-        if (!out.good()) throw std::runtime_error("failed while writing FASTQ subset");
+        if (first) {
+            if (have == 0) throw std::runtime_error("FASTQ input is empty");
+            if (arena[0] != '@') throw std::runtime_error("FASTQ input must start with '@'");
+            first = false;
+        }
+        // parse whole records out of arena[0, have)
         batch.clear();
-        batchBases = 0;
-    };
-    for (;;) {
-        Record r;
-        bool got;
-        do { got = in.getline(r.header); } while (got && detail::logicalLineLength(r.header) == 0);
-        if (!got) break;
-        if (!in.getline(r.sequence) || !in.getline(r.plus) || !in.getline(r.quality)) fail("truncated FASTQ record");
-        if (r.header.empty() || r.header.front() != '@') fail("expected header line starting with '@'");
-        if (r.plus.empty() || r.plus.front() != '+') fail("expected separator line starting with '+'");
-        if (detail::logicalLineLength(r.sequence) != detail::logicalLineLength(r.quality)) fail("sequence and quality length differ");
-        ++recordNumber;
-        batchBases += r.sequence.size();
-        batch.push_back(std::move(r));
-        if (batch.size() >= readsPerBatch || batchBases >= basesPerBatch) processBatch();
+        const char *p = arena.data(), *end = arena.data() + have;
+        const char *consumed = p;
+        while (p < end && batch.size() < readsPerBatch) {
+            // a line = [p, nl); at end of input the last line may lack its '\n'
+            auto nextLine = [&](const char *from, const char *&lb, const char *&le, const char *&next) -> bool {
+                if (from >= end) return false;
+                const char *nl = static_cast<const char *>(std::memchr(from, '\n', static_cast<size_t>(end - from)));
+                if (!nl && !eof) return false;                 // incomplete line: wait for more input
+                lb = from; le = nl ? nl : end; next = nl ? nl + 1 : end;
+                return true;
+            };
+            const char *hb, *he, *nx;
+            if (!nextLine(p, hb, he, nx)) break;
+            if (detail::logicalLineLength(hb, he) == 0) { p = nx; consumed = p; continue; }   // blank line before a header
+            const char *sb, *se, *pb, *pe, *qb, *qe, *n2, *n3, *n4;
+            const bool l2 = nextLine(nx, sb, se, n2), l3 = l2 && nextLine(n2, pb, pe, n3), l4 = l3 && nextLine(n3, qb, qe, n4);
+            if (!l4) {
+                if (eof) fail("truncated FASTQ record");
+                break;                                          // the record continues in the next block
+            }
+            if (he == hb || *hb != '@') fail("expected header line starting with '@'");
+            if (pe == pb || *pb != '+') fail("expected separator line starting with '+'");
+            if (detail::logicalLineLength(sb, se) != detail::logicalLineLength(qb, qe)) fail("sequence and quality length differ");
+            ++recordNumber;
+            batch.push_back(Rec{hb, sb, qe, static_cast<uint64_t>(se - sb), true});
+            p = n4;
+            consumed = p;
+        }
+        if (batch.empty() && !eof && consumed == arena.data()) {
+            arena.resize(arena.size() * 2);                     // one record larger than the arena
+            continue;
+        }
+        if (!batch.empty()) {
+            ptr.resize(batch.size()); len.resize(batch.size()); pass.resize(batch.size());
+            for (size_t i = 0; i < batch.size(); ++i) { ptr[i] = batch[i].seq; len[i] = batch[i].seqLen; }
+            filter.matchesPointers(ptr.data(), len.data(), batch.size(), pass.data());
+            text.clear();
+            for (size_t i = 0; i < batch.size(); ++i) {
+                if (!pass[i]) continue;
+                text.append(batch[i].begin, batch[i].end);
+                text.push_back('\n');
+                ++res.kept;
+            }
+            res.total += batch.size();
+            out.write(text.data(), static_cast<std::streamsize>(text.size()));
+            if (!out.good()) throw std::runtime_error("failed while writing FASTQ subset");
+        }
+        // keep what was not consumed (a partial record) for the next round
+        const size_t left = static_cast<size_t>(end - consumed);
+        if (left && consumed != arena.data()) std::memmove(arena.data(), consumed, left);
+        have = left;
+        if (eof && batch.empty()) break;
     }
-    processBatch();
     out.flush();
     return res;
 }

@@ -65,8 +65,14 @@ int main(int argc, char **argv) {
                        : std::vector<std::string>{ui.canonicalFwd, ui.canonicalRev};
         ui.patternInfo = expandPatternsWithOrientation(ui.rawPatterns, ui.editDistance, ui.canonicalFwd);
         if (fastqSubsetMode) {                                  // src/main.cpp:699-716: reads in, telomeric reads out
+            const auto f0 = std::chrono::steady_clock::now();
             ReadTelomereFilter filter(ui);
+            const auto f1 = std::chrono::steady_clock::now();
             const FastqSubsetResult r = fastqSubset(input.empty() ? "-" : input, std::cout, filter);
+            if (getenv("TS_TIMING"))
+                fprintf(stderr, "manifest_cli: filter construction (device start-up) %.0f ms, fastqSubset %.0f ms\n",
+                        std::chrono::duration<double, std::milli>(f1 - f0).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f1).count());
             fprintf(stderr, "FASTQ subset: kept %llu of %llu reads.\n", (unsigned long long)r.kept, (unsigned long long)r.total);
             return 0;
         }
