@@ -11,7 +11,7 @@ window records (8 x u32 per window) and the packed match stream are produced in 
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scans its own
 3.0 Gb shard of contigs (weak scaling, contigs are independent units) and the per-segment
-hit summaries are gathered to rank 0 over RCCL inside the timed step.
+hit summaries are gathered to rank 0 over RCCL inside the timed region (asynchronously, overlapping the next step's scan).
 """
 import argparse
 import ctypes as C
@@ -205,10 +205,14 @@ def main():
 
     buf = torch.zeros(int(info.input_bytes), dtype=torch.uint8, device=dev)
     fill_synthetic(buf, offsets, lens, 42 + rank, dev)
-    summary = torch.zeros(n * 4, dtype=torch.int64, device=dev)
+    # the per-segment hit summaries of a step are gathered while the next step scans: two buffers in turn,
+    # the gather of step i is waited for before its buffer is written again (and at the end of the timed region)
     xdev = dev if backend == "nccl" else torch.device("cpu")
-    gathered = [torch.zeros(n * 4, dtype=torch.int64, device=xdev) for _ in range(world)] \
-        if (world > 1 and rank == 0) else None
+    summaries = [torch.zeros(n * 4, dtype=torch.int64, device=dev) for _ in range(2)]
+    gathered = [[torch.zeros(n * 4, dtype=torch.int64, device=xdev) for _ in range(world)]
+                if (world > 1 and rank == 0) else None for _ in range(2)]
+    pending = [None, None]
+    step_no = [0]
     stream = torch.cuda.current_stream()
     sptr = C.c_void_p(stream.cuda_stream)
     dptr = C.c_void_p(buf.data_ptr())
@@ -218,13 +222,25 @@ def main():
         if rc != 0:
             raise RuntimeError(tel._ctx.error())
         if world > 1:
-            rc = L.ts_batch_segment_summary(batch, C.c_void_p(summary.data_ptr()), sptr)
+            j = step_no[0] & 1
+            step_no[0] += 1
+            if pending[j] is not None:
+                pending[j].wait()
+            rc = L.ts_batch_segment_summary(batch, C.c_void_p(summaries[j].data_ptr()), sptr)
             if rc != 0:
                 raise RuntimeError(tel._ctx.error())
-            dist.gather(summary if backend == "nccl" else summary.cpu(), gathered, dst=0)
+            pending[j] = dist.gather(summaries[j] if backend == "nccl" else summaries[j].cpu(), gathered[j], dst=0,
+                                     async_op=True)
+
+    def drain_gathers():
+        for j in range(2):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
 
     for _ in range(args.warmup):
         step()
+    drain_gathers()
     if L.ts_batch_sync(batch) != 0:          # also grows the match buffer if it overflowed
         raise RuntimeError(tel._ctx.error())
 
@@ -239,6 +255,7 @@ def main():
     ev0.record(stream)
     for _ in range(args.steps):
         step()
+    drain_gathers()
     ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
