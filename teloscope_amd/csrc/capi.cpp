@@ -50,7 +50,7 @@ struct ts_ctx {
     int device = 0;
     int num_cu = 0;
     uint32_t table_rows = 0, fc_bytes = 0;
-    bool fc_byte_table = true;
+    bool fc_byte_table = true, pair_byte_table = false;
     // general kernels (generic.hip): sorted 2-bit codes per pattern length
     bool generic_ok = false;
     TsGenericPatterns gpat{};
@@ -134,6 +134,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     kp.table_rows = c->table_rows;
     kp.fc_bytes = c->fc_bytes;
     kp.fc_byte_table = c->fc_byte_table ? 1u : 0u;
+    kp.pair_byte_table = c->pair_byte_table ? 1u : 0u;
     kp.fold_mask = P.fold_case ? 0xDFDFDFDFu : 0xFFFFFFFFu;
     if (tips) {
         kp.halo_blocks = 0;
@@ -399,7 +400,7 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
         c->why_not = "mixed-length pattern set";
     } else {
         std::vector<uint32_t> table;
-        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows, c->fc_bytes, c->fc_byte_table)) {
+        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows, c->fc_bytes, c->fc_byte_table, c->pair_byte_table)) {
             c->why_not = "pattern length outside 3..8 or non-ACGT pattern";
         } else {
             c->k = kmin;

@@ -127,7 +127,7 @@ __host__ __device__ inline uint32_t lds_total(const TsScanParams &P) {
 
 // ---------------------------------------------------------------------------------------
 // 16 waves per CU = 4 per SIMD: at most 128 VGPRs
-template <bool FC_BYTES>
+template <bool FC_BYTES, bool PAIR_BYTES>
 __global__ __launch_bounds__(TS_MAX_WG_THREADS, 4)
 void ts_scan_tiles(const TsScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -159,10 +159,12 @@ void ts_scan_tiles(const TsScanParams P) {
     const uint32_t k = P.k;
     const uint32_t rowbits = 2u * (k + 1u) - 4u;      // pair table: 4^(k+1) entries, 16 per dword
     const uint32_t kmask = (1u << (2u * k)) - 1u;
+    const uint32_t pmask = (1u << (2u * (k + 1u))) - 1u;              // a (k+1)-mer = an index into the byte pair table
     const lds_u32 *fc_table = (const lds_u32 *)(lds + P.table_rows * 4u);
     const lds_u8 *fc_bytes = (const lds_u8 *)fc_table;
-    // LDS byte address of the table (it sits at the dynamic-LDS base)
+    // LDS byte address of the table (it sits at the dynamic-LDS base, which is 0: the kernel has no static LDS)
     const uint32_t tab_base = (uint32_t)(uintptr_t)lds;
+    if (PAIR_BYTES && (tab_base & pmask) != 0u) __builtin_trap();     // the byte-table probes OR the index into the base
 
     const uint32_t total_waves = gridDim.x * P.waves_per_wg;
     const uint32_t gw = blockIdx.x * P.waves_per_wg + wave;
@@ -307,16 +309,21 @@ void ts_scan_tiles(const TsScanParams P) {
             for (int j = 0; j < 16; ++j) {
                 if (j < 8) tmp[j] = (j == 0) ? wa : __builtin_amdgcn_alignbit(wb, wa, 4 * j);
                 else tmp[j] = (j == 8) ? wb : __builtin_amdgcn_alignbit(nx, wb, 4 * (j - 8));
-                const uint32_t row = __builtin_amdgcn_ubfe(tmp[j], 4, rowbits);
-                const uint32_t addr = tab_base + (row << 2);
-                asm volatile("ds_read_b32 %0, %1" : "=v"(ent[j]) : "v"(addr));
+                if (PAIR_BYTES) {                                 // one byte per (k+1)-mer: index = address
+                    const uint32_t addr = (tmp[j] & pmask) | tab_base;
+                    asm volatile("ds_read_u8 %0, %1" : "=v"(ent[j]) : "v"(addr));
+                } else {                                          // 16 entries per dword: row, then shift
+                    const uint32_t row = __builtin_amdgcn_ubfe(tmp[j], 4, rowbits);
+                    const uint32_t addr = tab_base + (row << 2);
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(ent[j]) : "v"(addr));
+                }
             }
             uint32_t M32 = 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                M32 = __builtin_amdgcn_alignbit(ent[j] >> ((tmp[j] << 1) & 31u), M32, 2);
+                M32 = __builtin_amdgcn_alignbit(PAIR_BYTES ? ent[j] : ent[j] >> ((tmp[j] << 1) & 31u), M32, 2);
 #endif
 
             if (slow) {                                           // k-mers touching an invalid base
@@ -655,18 +662,23 @@ __global__ void ts_compact_regions(const uint32_t *regions, const uint32_t *wave
 int ts_k_lds_bytes(const TsScanParams *p) { return (int)lds_total(*p); }
 
 int ts_k_prepare(uint32_t lds_bytes) {
-    int e = (int)hipFuncSetAttribute((const void *)ts_scan_tiles<true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e) return e;
-    return (int)hipFuncSetAttribute((const void *)ts_scan_tiles<false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const void *fns[] = {(const void *)ts_scan_tiles<true, true>, (const void *)ts_scan_tiles<true, false>,
+                         (const void *)ts_scan_tiles<false, false>};
+    for (const void *fn : fns) {
+        int e = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e) return e;
+    }
+    return 0;
 }
 
 int ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, void *stream) {
-    if (p->fc_byte_table)
-        hipLaunchKernelGGL(ts_scan_tiles<true>, dim3(grid), dim3(p->waves_per_wg * 64u), lds_bytes, (hipStream_t)stream, *p);
+    const dim3 block(p->waves_per_wg * 64u);
+    if (p->pair_byte_table && p->fc_byte_table)
+        hipLaunchKernelGGL((ts_scan_tiles<true, true>), dim3(grid), block, lds_bytes, (hipStream_t)stream, *p);
+    else if (p->fc_byte_table)
+        hipLaunchKernelGGL((ts_scan_tiles<true, false>), dim3(grid), block, lds_bytes, (hipStream_t)stream, *p);
     else
-        hipLaunchKernelGGL(ts_scan_tiles<false>, dim3(grid), dim3(p->waves_per_wg * 64u), lds_bytes, (hipStream_t)stream, *p);
+        hipLaunchKernelGGL((ts_scan_tiles<false, false>), dim3(grid), block, lds_bytes, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 

@@ -166,14 +166,15 @@ int base_code(char c) {
 
 // Match tables for uniform-length pattern sets (k-mer index x: base i at bits 2i..2i+1).
 //  * pair table: indexed by the (k+1)-mer y = bases p..p+k; entry = 2 bits {x(p) is a pattern,
-//    x(p+1) is a pattern}, 16 entries per dword (row = y >> 4).  Not replicated: the kernel is
+//    x(p+1) is a pattern}, one byte per entry for k <= 6, else 16 entries per dword (row = y >> 4).
+//    Not replicated: the kernel is
 //    bound by VALU issue, and spreading rows over the LDS banks (8 copies) bought 0.4 % when it
 //    was measured, while the 28 KB it cost is what the per-wave count planes now live in;
 //  * flag table: {canonical, forward} (bit 0, bit 1: the low bits of a match record) per k-mer, looked up only at matched positions: one byte
 //    per k-mer for k <= 7 (cheapest lookup), 2 bits per k-mer at k = 8 (LDS capacity).
 // Layout in `table`: [rows dwords][flag table].
 bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
-                       uint32_t &rows, uint32_t &fc_bytes, bool &fc_byte_table) {
+                       uint32_t &rows, uint32_t &fc_bytes, bool &fc_byte_table, bool &pair_byte_table) {
     if (k < 3 || k > 8) return false;
     const uint64_t nk = 1ull << (2 * k);
     std::vector<uint8_t> m(nk, 0), fl(nk, 0);
@@ -189,7 +190,10 @@ bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector
         fl[x] = static_cast<uint8_t>((p.is_canonical ? 1 : 0) | (p.is_forward ? 2 : 0));   // a match record's low bits
     }
     const uint64_t npairs = nk * 4;                                   // (k+1)-mers
-    rows = static_cast<uint32_t>(npairs / 16);
+    // k <= 6: one BYTE per (k+1)-mer (16 KB at k = 6): a probe is then alignbit / and / ds_read_u8 /
+    // alignbit, no row-and-shift arithmetic; larger k keeps 2 bits per (k+1)-mer (LDS capacity)
+    pair_byte_table = k <= 6;
+    rows = static_cast<uint32_t>(pair_byte_table ? npairs / 4 : npairs / 16);
     fc_byte_table = k <= 7;
     const size_t fc_words = static_cast<size_t>(std::max<uint64_t>(fc_byte_table ? nk / 4 : nk / 16, 4));
     fc_bytes = static_cast<uint32_t>(fc_words * 4);
@@ -198,7 +202,8 @@ bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector
     for (uint64_t y = 0; y < npairs; ++y) {
         const uint32_t bits = (m[y & kmask] ? 1u : 0u) | (m[(y >> 2) & kmask] ? 2u : 0u);
         if (!bits) continue;
-        table[y >> 4] |= bits << (2 * (y & 15));
+        if (pair_byte_table) table[y >> 2] |= bits << (8 * (y & 3));
+        else table[y >> 4] |= bits << (2 * (y & 15));
     }
     uint32_t *fc = &table[rows];
     for (uint64_t x = 0; x < nk; ++x) {

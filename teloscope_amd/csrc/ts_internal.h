@@ -39,7 +39,8 @@ struct TsScanParams {
     uint32_t        region_cap;     // records per wave region
     uint32_t        ntiles;
     uint32_t        waves_per_wg;
-    uint32_t        table_rows;     // 4^(k+1) / 16
+    uint32_t        table_rows;     // dwords of the pair table: 4^(k+1) / 16, or 4^(k+1) / 4 as a byte table
+    uint32_t        pair_byte_table;// 1: one byte per (k+1)-mer (k <= 6); 0: 2 bits per (k+1)-mer
     uint32_t        fc_bytes;       // flag table size in bytes (16-byte multiple)
     uint32_t        fc_byte_table;  // 1: one byte {forward, canonical} per k-mer; 0: 2 bits per k-mer
     uint32_t        k;              // pattern length
