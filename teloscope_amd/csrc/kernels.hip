@@ -307,9 +307,17 @@ void ts_scan_tiles(const TsScanParams P) {
             uint32_t tmp[16], ent[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
+                if (PAIR_BYTES && (j & 7) <= 4) {
+                    // one byte per (k+1)-mer: index = address; a (k+1)-mer of k <= 6 that starts at base
+                    // 2 (j & 7) <= 8 lies inside one code dword: a single v_bfe
+                    tmp[j] = 0;
+                    const uint32_t addr = __builtin_amdgcn_ubfe(j < 8 ? wa : wb, 4 * (j & 7), 2u * (k + 1u)) | tab_base;
+                    asm volatile("ds_read_u8 %0, %1" : "=v"(ent[j]) : "v"(addr));
+                    continue;
+                }
                 if (j < 8) tmp[j] = (j == 0) ? wa : __builtin_amdgcn_alignbit(wb, wa, 4 * j);
                 else tmp[j] = (j == 8) ? wb : __builtin_amdgcn_alignbit(nx, wb, 4 * (j - 8));
-                if (PAIR_BYTES) {                                 // one byte per (k+1)-mer: index = address
+                if (PAIR_BYTES) {
                     const uint32_t addr = (tmp[j] & pmask) | tab_base;
                     asm volatile("ds_read_u8 %0, %1" : "=v"(ent[j]) : "v"(addr));
                 } else {                                          // 16 entries per dword: row, then shift
