@@ -227,9 +227,9 @@ void ts_scan_tiles(const TsScanParams P) {
                 else fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
                 // position in the tile, step block and offset inside it
                 const uint32_t u = xp - sh;                   // wraps for the few bases before the tile
-                uint32_t q = __umulhi(u, P.s_inv);
-                if (q * P.s > u) --q;
-                const uint32_t o = u - q * P.s;
+                uint32_t q = __umulhi(u, P.s_inv), qs = q * P.s;   // (multiplies are quarter rate: one mul_hi, one mul_lo)
+                if (qs > u) { --q; qs -= P.s; }
+                const uint32_t o = u - qs;
                 // w == s: a match that would straddle a window end is lost (the carry rule of
                 // src/teloscope.cpp:611-628; pinned by t2t.fa -i = 199)
                 const bool valid = live && xp >= sh && !(P.straddle_fix && o + k > P.s);
