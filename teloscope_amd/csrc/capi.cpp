@@ -482,6 +482,10 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
         delete b;
         return nullptr;
     }
+    if (getenv("TS_TIMING"))
+        fprintf(stderr, "ts_batch_create: %s scan, k=%u, %u waves per workgroup, %u chunks and %u windows per tile, LDS %d B "
+                        "(match queue %u, record stage %u, %u accumulator copies)\n", b->tips ? "tips-only" : "window", ctx->k,
+                b->kp.waves_per_wg, b->kp.nch, wpt, ts_k_lds_bytes(&b->kp), (unsigned)TS_LIST, b->kp.stage_cap, b->kp.acc_copies);
     const uint64_t tile_bases = (uint64_t)wpt * b->kp.s;
     const uint32_t tl = ctx->params.terminal_limit;
 
