@@ -219,7 +219,7 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
     }
     if (!src.gz && src.fd < 0) throw std::runtime_error("Stream not successful: " + inFile);
     if (src.gz) gzbuffer(src.gz, 1u << 20);
-    std::vector<char> arena(std::max<size_t>(bytesPerBatch, 1u << 16));
+    std::vector<char> arena(std::max<size_t>(bytesPerBatch, 64));           // grows if a record does not fit
     size_t have = 0;                       // valid bytes in the arena
     bool eof = false, first = true;
     FastqSubsetResult res;

@@ -24,6 +24,7 @@ int main(int argc, char **argv) {
     UserInputTeloscope ui;
     std::string input, canonical, outBase;
     bool scratch = false, manualCuration = false, fastqSubsetMode = false;
+    size_t fastqBlock = 512u << 20;
     std::vector<std::string> rawPatterns;
     bool hasPatterns = false;
     for (int i = 1; i < argc; ++i) {
@@ -31,6 +32,7 @@ int main(int argc, char **argv) {
         auto val = [&]() -> std::string { if (i + 1 >= argc) exit(EXIT_FAILURE); return argv[++i]; };
         if (a == "-f") input = val();
         else if (a == "--fastq-subset") fastqSubsetMode = true;
+        else if (a == "--fastq-block") fastqBlock = static_cast<size_t>(std::stoull(val()));   // test hook: arena size in bytes
         else if (a == "--out-base") outBase = val();
         else if (a == "-o" || a == "-j") (void)val();
         else if (a == "-c") canonical = val();
@@ -68,7 +70,7 @@ int main(int argc, char **argv) {
             const auto f0 = std::chrono::steady_clock::now();
             ReadTelomereFilter filter(ui);
             const auto f1 = std::chrono::steady_clock::now();
-            const FastqSubsetResult r = fastqSubset(input.empty() ? "-" : input, std::cout, filter);
+            const FastqSubsetResult r = fastqSubset(input.empty() ? "-" : input, std::cout, filter, 1u << 20, fastqBlock);
             if (getenv("TS_TIMING"))
                 fprintf(stderr, "manifest_cli: filter construction (device start-up) %.0f ms, fastqSubset %.0f ms\n",
                         std::chrono::duration<double, std::milli>(f1 - f0).count(),
