@@ -168,13 +168,31 @@ void ts_scan_tiles(const TsScanParams P) {
 
     const uint32_t total_waves = gridDim.x * P.waves_per_wg;
     const uint32_t gw = blockIdx.x * P.waves_per_wg + wave;
-    const u64 region_base = (u64)gw * P.region_cap;
-    uint32_t *const wave_out = P.matches_out + region_base;
+    // Parameters that are only needed when a tile is finished (output pointers, capacities) are read
+    // from the kernel-argument segment (scalar loads, constant address space) where they are used,
+    // through a pointer the compiler cannot see through: held in SGPRs for the whole kernel they push the
+    // hot loops' scalars into spills (v_readlane / v_writelane are VALU instructions).
+    typedef const TsScanParams __attribute__((address_space(4))) *KernArgs;
+    auto tail_params = [&]() -> KernArgs {
+        KernArgs q = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(q));
+        return q;
+    };
     uint32_t cursor = 0;                          // records this wave has produced so far
     const uint32_t nwper = P.halo_blocks + 1u;             // windows a position can belong to: ceil(w / s)
 
+    // The first chunk of a tile is fetched while the previous tile's window phase runs (its loads would
+    // otherwise be waited for with nothing else to do): descriptor and 32 B/lane of the next tile are
+    // requested at the end of phase 1 and picked up here.
+    TsTile Tn = {};
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+    if (gw < P.ntiles) {
+        Tn = P.tiles[gw];
+        const unsigned char *ls = P.in + (Tn.in_off & ~15ull) + lane * 32u;
+        n0 = *(const uint4 *)ls; n1 = *(const uint4 *)(ls + 16);
+    }
     for (uint32_t tile = gw; tile < P.ntiles; tile += total_waves) {
-        const TsTile T = P.tiles[tile];           // wave-uniform: scalar loads
+        const TsTile T = Tn;                      // wave-uniform: came by scalar loads
         const uint32_t sh = (uint32_t)(T.in_off & 15ull);
         const unsigned char *src = P.in + (T.in_off - sh);
         const uint32_t nblk = T.nwin + P.halo_blocks;             // step blocks the tile's windows reach into
@@ -191,9 +209,12 @@ void ts_scan_tiles(const TsScanParams P) {
         auto flush_stage = [&]() {                                 // stage[0 .. done - flushed) -> wave_out[cursor + flushed ..)
             __builtin_amdgcn_wave_barrier();
             const uint32_t n = done - flushed;
+            KernArgs Q = tail_params();
+            const uint32_t cap = Q->region_cap;
+            uint32_t *const wave_out = Q->matches_out + (u64)gw * cap;
             for (uint32_t i = lane; i < n; i += 64u) {
                 const uint32_t o = cursor + flushed + i;
-                if (o < P.region_cap && !(TS_ABL & 1)) wave_out[o] = stage[i];
+                if (o < cap && !(TS_ABL & 1)) wave_out[o] = stage[i];
             }
             __builtin_amdgcn_wave_barrier();
             flushed = done;
@@ -397,7 +418,7 @@ void ts_scan_tiles(const TsScanParams P) {
             // scalars that step by a constant: no vector multiplies.
             const uint32_t last_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)((nch - 1u) * TS_CHUNK));
             const unsigned char *lsrc = src + lane * 32u;
-            uint4 a0 = *(const uint4 *)lsrc, a1 = *(const uint4 *)(lsrc + 16), b0, b1;
+            uint4 a0 = n0, a1 = n1, b0, b1;
             uint32_t cpos = 0, ch = 0;
             for (uint32_t c = 0; c < nch; c += 2u) {
                 const uint32_t p1 = cpos + TS_CHUNK < last_pos ? cpos + TS_CHUNK : last_pos;
@@ -413,6 +434,11 @@ void ts_scan_tiles(const TsScanParams P) {
                 resolve_chunk(cpos + TS_CHUNK, ch + 63u, b0, b1);
                 cpos += 2u * TS_CHUNK; ch += 126u;
             }
+        }
+        if (tile + total_waves < P.ntiles) {      // next tile: descriptor + first chunk, in flight during phase 2
+            Tn = P.tiles[tile + total_waves];
+            const unsigned char *ls = P.in + (Tn.in_off & ~15ull) + lane * 32u;
+            n0 = *(const uint4 *)ls; n1 = *(const uint4 *)(ls + 16);
         }
         drain_queue(1u);                          // the matches still queued when the tile ends
         __builtin_amdgcn_wave_barrier();          // planes written above are read by other lanes below
@@ -489,7 +515,7 @@ void ts_scan_tiles(const TsScanParams P) {
             // records leave as whole dwords in order: 8 x u32 per window, coalesced; the match fields
             // count covered bases = k x matches
             if (!(TS_ABL & 8)) {
-                uint32_t *wout = P.windows_out + T.win_out * 8ull;
+                uint32_t *wout = tail_params()->windows_out + T.win_out * 8ull;
                 for (uint32_t it = lane; it < T.nwin * 8u; it += 64u) {
                     const uint32_t i = it >> 3, f = it & 7u;
                     uint32_t val = 0;
@@ -509,14 +535,15 @@ void ts_scan_tiles(const TsScanParams P) {
         {
             const uint32_t tcan = wave_sum(ccan), tfwd = wave_sum(cfwd);
             if (lane == 0) {
-                P.tile_off[tile] = region_base + cursor;
-                *(uint4 *)&P.tile_stats[4ull * tile] = make_uint4(done, tcan, tfwd, 0u);
+                KernArgs Q = tail_params();
+                Q->tile_off[tile] = (u64)gw * Q->region_cap + cursor;
+                *(uint4 *)&Q->tile_stats[4ull * tile] = make_uint4(done, tcan, tfwd, 0u);
             }
             cursor += done;
         }
         __builtin_amdgcn_wave_barrier();          // next tile overwrites the planes
     }
-    if (lane == 0) P.wave_fill[gw] = cursor;      // records needed by this wave (may exceed region_cap)
+    if (lane == 0) tail_params()->wave_fill[gw] = cursor;      // records needed by this wave (may exceed region_cap)
 }
 
 // Per-segment hit summary {windows, matches, canonical, forward}: the buffer ranks gather.
