@@ -302,6 +302,157 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
     return res;
 }
 
+// ---------------------------------------------------------------------------------------------
+// --bam-subset (subsetBam, src/bam.cpp:188-259): copy the header and the alignment records whose read
+// carries a terminal telomere block, byte for byte, into a new BAM.  BGZF is a series of gzip members,
+// so zlib's gz* API reads the input as one stream; the output is written as BGZF blocks of <= 0xff00
+// payload bytes (raw deflate + the "BC" extra field + CRC32/ISIZE) closed by the EOF marker.  Sequences
+// (4-bit codes "=ACMGRSVTWYHKDBN") are decoded into one arena per batch and filtered on the GPU in
+// batches of up to readsPerBatch records / bytesPerBatch record bytes.
+struct BamSubsetStats { uint64_t totalRecords = 0, passedRecords = 0, missingSequenceRecords = 0; bool missingEofBlock = false; };
+
+namespace detail {
+class BgzfWriter {
+    std::ostream &out;
+    std::vector<unsigned char> pending;
+    void block(const unsigned char *data, size_t n) {
+        unsigned char comp[65536];
+        z_stream zs{};
+        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+        zs.next_in = const_cast<unsigned char *>(data); zs.avail_in = static_cast<unsigned>(n);
+        zs.next_out = comp + 18; zs.avail_out = sizeof comp - 18 - 8;
+        const int rc = deflate(&zs, Z_FINISH);
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) throw std::runtime_error("BGZF block does not fit");
+        const size_t clen = zs.total_out, total = 18 + clen + 8;
+        static const unsigned char head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        std::memcpy(comp, head, 16);
+        comp[16] = static_cast<unsigned char>((total - 1) & 0xff); comp[17] = static_cast<unsigned char>((total - 1) >> 8);
+        const uint32_t crc = static_cast<uint32_t>(crc32(crc32(0L, Z_NULL, 0), data, static_cast<unsigned>(n)));
+        unsigned char *tail = comp + 18 + clen;
+        for (int i = 0; i < 4; ++i) { tail[i] = static_cast<unsigned char>(crc >> (8 * i)); tail[4 + i] = static_cast<unsigned char>(static_cast<uint32_t>(n) >> (8 * i)); }
+        out.write(reinterpret_cast<const char *>(comp), static_cast<std::streamsize>(total));
+    }
+public:
+    explicit BgzfWriter(std::ostream &o) : out(o) {}
+    void write(const unsigned char *data, size_t n) {
+        constexpr size_t kPayload = 0xff00;
+        while (n) {
+            const size_t take = std::min(n, kPayload - pending.size());
+            pending.insert(pending.end(), data, data + take);
+            data += take; n -= take;
+            if (pending.size() == kPayload) { block(pending.data(), pending.size()); pending.clear(); }
+        }
+    }
+    void finish() {
+        if (!pending.empty()) { block(pending.data(), pending.size()); pending.clear(); }
+        static const unsigned char eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        out.write(reinterpret_cast<const char *>(eof), sizeof eof);
+        out.flush();
+        if (!out.good()) throw std::runtime_error("failed while writing BAM subset");
+    }
+};
+}  // namespace detail
+
+inline BamSubsetStats bamSubset(const std::string &inFile, std::ostream &out, ReadTelomereFilter &filter,
+                                size_t readsPerBatch = 1u << 20, size_t bytesPerBatch = 512u << 20) {
+    BamSubsetStats stats;
+    int fd = 0;
+    if (inFile != "-") {
+        fd = ::open(inFile.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open BAM input '" + inFile + "'");
+        unsigned char tail[28];
+        static const unsigned char eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const off_t size = ::lseek(fd, 0, SEEK_END);
+        stats.missingEofBlock = !(size >= 28 && ::pread(fd, tail, 28, size - 28) == 28 && std::memcmp(tail, eof, 28) == 0);
+        ::lseek(fd, 0, SEEK_SET);
+    }
+    gzFile in = gzdopen(fd, "rb");
+    if (!in) throw std::runtime_error("cannot read BAM input");
+    struct Closer { gzFile f; ~Closer() { gzclose(f); } } closer{in};
+    gzbuffer(in, 1u << 20);
+    auto readExact = [&](void *dst, size_t n, const char *what) {
+        size_t got = 0;
+        while (got < n) {
+            const int r = gzread(in, static_cast<char *>(dst) + got, static_cast<unsigned>(std::min<size_t>(n - got, 1u << 30)));
+            if (r <= 0) throw std::runtime_error(std::string("truncated BAM ") + what);
+            got += static_cast<size_t>(r);
+        }
+    };
+    auto le32 = [](const unsigned char *p) { return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16) | (static_cast<uint32_t>(p[3]) << 24); };
+
+    detail::BgzfWriter writer(out);
+    {   // header: magic, text, reference list — copied verbatim (copyBamHeader)
+        std::vector<unsigned char> h(12);
+        readExact(h.data(), 8, "header");
+        if (std::memcmp(h.data(), "BAM\1", 4) != 0) throw std::runtime_error("input is not a BAM file");
+        const uint32_t ltext = le32(h.data() + 4);
+        h.resize(8 + static_cast<size_t>(ltext) + 4);
+        readExact(h.data() + 8, static_cast<size_t>(ltext) + 4, "header");
+        const uint32_t nref = le32(h.data() + 8 + ltext);
+        for (uint32_t r = 0; r < nref; ++r) {
+            const size_t at = h.size();
+            h.resize(at + 4);
+            readExact(h.data() + at, 4, "reference");
+            const uint32_t lname = le32(h.data() + at);
+            h.resize(at + 4 + static_cast<size_t>(lname) + 4);
+            readExact(h.data() + at + 4, static_cast<size_t>(lname) + 4, "reference");
+        }
+        writer.write(h.data(), h.size());
+    }
+
+    struct Rec { size_t rawOff, rawLen, seqOff; uint64_t seqLen; };
+    std::vector<unsigned char> raw;             // the batch's records, back to back (block_size included)
+    std::vector<char> seqs;                     // their decoded sequences, back to back
+    std::vector<Rec> batch;
+    std::vector<const char *> ptr;
+    std::vector<uint64_t> len;
+    std::vector<uint8_t> pass;
+    static const char bases[] = "=ACMGRSVTWYHKDBN";
+    auto processBatch = [&]() {
+        if (batch.empty()) return;
+        ptr.clear(); len.clear();
+        for (const Rec &r : batch)
+            if (r.seqLen) { ptr.push_back(seqs.data() + r.seqOff); len.push_back(r.seqLen); }
+        pass.assign(ptr.size(), 0);
+        if (!ptr.empty()) filter.matchesPointers(ptr.data(), len.data(), ptr.size(), pass.data());
+        size_t k = 0;
+        for (const Rec &r : batch) {
+            ++stats.totalRecords;
+            if (!r.seqLen) { ++stats.missingSequenceRecords; continue; }
+            if (pass[k++]) { writer.write(raw.data() + r.rawOff, r.rawLen); ++stats.passedRecords; }
+        }
+        batch.clear(); raw.clear(); seqs.clear();
+    };
+    for (;;) {
+        unsigned char sz[4];
+        const int got = gzread(in, sz, 4);
+        if (got == 0) break;
+        if (got != 4) throw std::runtime_error("truncated BAM record size");
+        const int32_t blockSize = static_cast<int32_t>(le32(sz));
+        if (blockSize < 32 || static_cast<uint32_t>(blockSize) > (1u << 29)) throw std::runtime_error("invalid BAM record block_size");
+        const size_t at = raw.size();
+        raw.resize(at + 4 + static_cast<size_t>(blockSize));
+        std::memcpy(raw.data() + at, sz, 4);
+        readExact(raw.data() + at + 4, static_cast<size_t>(blockSize), "record");
+        const unsigned char *core = raw.data() + at + 4;
+        const uint32_t lname = core[8], ncigar = static_cast<uint32_t>(core[12]) | (static_cast<uint32_t>(core[13]) << 8), lseq = le32(core + 16);
+        const uint64_t seqAt = 32ull + lname + 4ull * ncigar;
+        if (lname == 0 || seqAt + (static_cast<uint64_t>(lseq) + 1) / 2 + lseq > static_cast<uint64_t>(blockSize))
+            throw std::runtime_error("BAM record fields exceed block_size");
+        if (core[32 + lname - 1] != 0) throw std::runtime_error("BAM read name is not NUL-terminated");
+        const size_t so = seqs.size();
+        seqs.resize(so + lseq);
+        const unsigned char *packed = core + seqAt;
+        for (uint32_t i = 0; i < lseq; ++i) seqs[so + i] = bases[(i & 1u) ? (packed[i >> 1] & 0x0f) : (packed[i >> 1] >> 4)];
+        batch.push_back(Rec{at, 4 + static_cast<size_t>(blockSize), so, lseq});
+        if (batch.size() >= readsPerBatch || raw.size() >= bytesPerBatch) processBatch();
+    }
+    processBatch();
+    writer.finish();
+    return stats;
+}
+
 inline const char *scaffoldTypeToString(ScaffoldType t) {       // src/tools.cpp
     static const char *names[] = {"t2t", "gapped_t2t", "misassembly", "gapped_misassembly", "incomplete",
                                   "gapped_incomplete", "none", "gapped_none", "discordant", "gapped_discordant"};

@@ -23,7 +23,7 @@ using namespace teloscope_mi355x;
 int main(int argc, char **argv) {
     UserInputTeloscope ui;
     std::string input, canonical, outBase;
-    bool scratch = false, manualCuration = false, fastqSubsetMode = false;
+    bool scratch = false, manualCuration = false, fastqSubsetMode = false, bamSubsetMode = false;
     size_t fastqBlock = 512u << 20;
     std::vector<std::string> rawPatterns;
     bool hasPatterns = false;
@@ -32,6 +32,7 @@ int main(int argc, char **argv) {
         auto val = [&]() -> std::string { if (i + 1 >= argc) exit(EXIT_FAILURE); return argv[++i]; };
         if (a == "-f") input = val();
         else if (a == "--fastq-subset") fastqSubsetMode = true;
+        else if (a == "--bam-subset") bamSubsetMode = true;
         else if (a == "--fastq-block") fastqBlock = static_cast<size_t>(std::stoull(val()));   // test hook: arena size in bytes
         else if (a == "--out-base") outBase = val();
         else if (a == "-o" || a == "-j") (void)val();
@@ -66,6 +67,16 @@ int main(int argc, char **argv) {
         ui.rawPatterns = (hasPatterns && !rawPatterns.empty()) ? rawPatterns
                        : std::vector<std::string>{ui.canonicalFwd, ui.canonicalRev};
         ui.patternInfo = expandPatternsWithOrientation(ui.rawPatterns, ui.editDistance, ui.canonicalFwd);
+        if (bamSubsetMode) {                                    // runBamSubsetMode, src/bam.cpp:262-316
+            ReadTelomereFilter filter(ui);
+            const BamSubsetStats st = bamSubset(input.empty() ? "-" : input, std::cout, filter);
+            if (st.missingEofBlock) fprintf(stderr, "Warning: BAM input is missing the BGZF EOF marker.\n");
+            if (st.missingSequenceRecords)
+                fprintf(stderr, "BAM subset: skipped %llu record%s without SEQ.\n", (unsigned long long)st.missingSequenceRecords,
+                        st.missingSequenceRecords == 1 ? "" : "s");
+            fprintf(stderr, "BAM subset: kept %llu of %llu records.\n", (unsigned long long)st.passedRecords, (unsigned long long)st.totalRecords);
+            return 0;
+        }
         if (fastqSubsetMode) {                                  // src/main.cpp:699-716: reads in, telomeric reads out
             const auto f0 = std::chrono::steady_clock::now();
             ReadTelomereFilter filter(ui);

@@ -1,0 +1,116 @@
+"""Row f4: --bam-subset through include/teloscope_mi355x_io.hpp (bamSubset, the device read filter):
+subsetBam of src/bam.cpp:188-259 — the header and every record whose read has a terminal telomere
+block are copied byte for byte into a new BGZF-compressed BAM closed by the EOF marker.  The reference
+ships no BAM fixtures (its scripts/test_bam_subset.py builds them on the fly); so does this test, with
+its own BGZF/BAM encoder, and the kept set is checked against the CPU oracle's read filter."""
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import harness as H
+from tests import seqgen
+from tests.backends import OracleReadFilter
+from tests.test_cpp_mirror import cli  # noqa: F401  (fixture: builds tests/cpp/manifest_cli.cpp)
+
+EOF_BLOCK = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+NIBBLE = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+
+
+def bgzf(data, chunk):
+    out = []
+    for a in range(0, len(data), chunk):
+        piece = data[a:a + chunk]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = co.compress(piece) + co.flush()
+        total = 18 + len(payload) + 8
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", total - 1) + payload +
+                   struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece)))
+    return b"".join(out) + EOF_BLOCK
+
+
+def gunzip_members(data):
+    out, pos = bytearray(), 0
+    while pos < len(data):
+        d = zlib.decompressobj(31)
+        out += d.decompress(data[pos:])
+        pos = len(data) - len(d.unused_data)
+    return bytes(out)
+
+
+def bam_record(name, seq):
+    packed = bytearray((len(seq) + 1) // 2)
+    for i, ch in enumerate(seq):
+        packed[i >> 1] |= NIBBLE[ch] << (0 if i & 1 else 4)
+    body = struct.pack("<iiBBHHHiiii", -1, -1, len(name) + 1, 0, 4680, 0, 4, len(seq), -1, -1, 0)
+    body += name.encode() + b"\0" + bytes(packed) + b"\xff" * len(seq)
+    return struct.pack("<i", len(body)) + body
+
+
+def build_bam(reads, chunk):
+    text = b"@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:1000\n"
+    header = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + \
+        struct.pack("<i", 1000)
+    records = [bam_record(n, s) for n, s in reads]
+    return header, records, bgzf(header + b"".join(records), chunk)
+
+
+def make_reads():
+    rng = np.random.default_rng(99)
+    reads = [("kat_pass", "TTAGGG" * 60), ("kat_short", "TTAGGG" * 6), ("kat_rev", "CCCTAA" * 70), ("acgt", "ACGT" * 100),
+             ("noseq", ""), ("iupac", "TTAGGG" * 30 + "NRYK" + "TTAGGG" * 30), ("odd", "TTAGGG" * 55 + "A")]
+    for i in range(400):
+        n = int(rng.integers(50, 20000))
+        s = bytearray(seqgen.random_dna(rng, n).tobytes())
+        if i % 5 == 0:
+            t = seqgen.mutate(rng, seqgen.repeat_array("TTAGGG" if i % 2 else "CCCTAA", int(rng.integers(8, 400))), 0.02).tobytes()
+            t = t[:n]
+            if i % 3:
+                s[:len(t)] = t
+            else:
+                s[n - len(t):] = t
+        reads.append(("r%d" % i, s.decode()))
+    return reads
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,chunk,via_stdin", [("", 60000, False), ("-l 42", 1000, False), ("-x 0 -l 18 -y 0.8 -k 10 -d 10", 64000, True)])
+def test_bam_subset_matches_oracle(cli, tmp_path, flags, chunk, via_stdin):  # noqa: F811
+    reads = make_reads()
+    header, records, bam = build_bam(reads, chunk)
+    path = tmp_path / "in.bam"
+    path.write_bytes(bam)
+    args = [cli, "--bam-subset"] + flags.split()
+    if via_stdin:
+        r = subprocess.run(args, stdin=open(path, "rb"), capture_output=True, timeout=300)
+    else:
+        r = subprocess.run(args + [str(path)], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    opts = H.parse_cli("--fastq-subset " + flags)
+    with_seq = [i for i, (_, s) in enumerate(reads) if s]
+    passes = OracleReadFilter(opts).filter([reads[i][1].encode() for i in with_seq])
+    keep = [i for i, ok in zip(with_seq, passes) if ok]
+    assert 0 < len(keep) < len(with_seq)
+    out = r.stdout
+    assert out.endswith(EOF_BLOCK) and out[:4] == b"\x1f\x8b\x08\x04"
+    plain = gunzip_members(out)
+    assert plain[:len(header)] == header
+    assert plain[len(header):] == b"".join(records[i] for i in keep)          # kept records, in order, byte for byte
+    err = r.stderr.decode()
+    assert "BAM subset: kept %d of %d records." % (len(keep), len(reads)) in err
+    assert "BAM subset: skipped 1 record without SEQ." in err
+
+
+@pytest.mark.gpu
+def test_bam_subset_rejects_garbage_and_flags_missing_eof(cli, tmp_path):  # noqa: F811
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(bgzf(b"NOTBAM" + b"\0" * 100, 60000))
+    r = subprocess.run([cli, "--bam-subset", str(bad)], capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"not a BAM" in r.stderr
+    header, records, bam = build_bam(make_reads()[:8], 60000)
+    noeof = tmp_path / "noeof.bam"
+    noeof.write_bytes(bam[:-len(EOF_BLOCK)])
+    r = subprocess.run([cli, "--bam-subset", str(noeof)], capture_output=True, timeout=120)
+    assert r.returncode == 0 and b"missing the BGZF EOF marker" in r.stderr
