@@ -65,6 +65,8 @@ struct ts_ctx {
     hipStream_t up_stream = nullptr;
 
     mutable std::mutex err_mtx;
+    std::mutex api_mtx;             // ts_scan_segments / ts_scan_segments_blocks / ts_filter_reads run one at a time per context
+                                    // (they share the pinned upload ring; results never depend on call order)
     int fail(int code, const std::string &msg) const { std::lock_guard<std::mutex> g(err_mtx); error = msg; return code; }
 };
 
@@ -1179,6 +1181,7 @@ static int scan_group(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<
 
 int ts_scan_segments(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out) {
     if (!ctx || (n_segs && (!segs || !out))) return TS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> api(ctx->api_mtx);
     for (size_t i = 0; i < n_segs; ++i) {
         std::memset(&out[i], 0, sizeof out[i]);
         if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
@@ -1235,6 +1238,7 @@ static int scan_group_blocks(ts_ctx *ctx, const ts_segment_in *segs, const std::
 int ts_scan_segments_blocks(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out,
                             ts_segment_counts *counts) {
     if (!ctx || (n_segs && (!segs || !out))) return TS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> api(ctx->api_mtx);
     for (size_t i = 0; i < n_segs; ++i) {
         std::memset(&out[i], 0, sizeof out[i]);
         if (counts) counts[i] = ts_segment_counts{0, 0, 0, 0};
@@ -1274,6 +1278,7 @@ int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
     if (!ctx || (n_reads && (!seqs || !lens || !pass))) return TS_ERR_INVALID_ARG;
     if (!ctx->read_filter) return ctx->fail(TS_ERR_STATE, "context was not made by ts_create_read_filter");
     if (n_reads == 0) return TS_OK;
+    std::lock_guard<std::mutex> api(ctx->api_mtx);
     std::vector<uint64_t> rl(n_reads);
     for (size_t i = 0; i < n_reads; ++i) {
         uint64_t n = lens[i];

@@ -467,3 +467,33 @@ def test_fuzz_parameters_and_degenerate_segments():
         for (q, a), g in zip(segs, got):
             seq_up = q.upper() if True else q                     # fold_case = 1 == unmaskSequence + scanSegment
             assert_segment_equal(g, orac.scan_segment(seq_up, a, tips), tips, ctx="fuzz %d cli=%r len=%d" % (it, cli, len(q)))
+
+
+def test_concurrent_calls_on_one_context():
+    """The reference calls scanSegment concurrently from its thread-pool workers on one shared Teloscope
+    (src/input.cpp:719-724, 977); calls on one ts_ctx are serialised inside the library and must give what
+    sequential calls give."""
+    import threading
+    opts = H.parse_cli("x.fa -w 1000 -s 500 -r -g -e -m -i")
+    prod, orac = ProductBackend(opts), OracleBackend(opts)
+    rng = np.random.default_rng(77)
+    jobs = [[(seqgen.chromosome(rng, int(rng.integers(2000, 300000)), telo_repeats=200, n_its=3), int(rng.integers(0, 10 ** 6)), False)
+             for _ in range(3)] for _ in range(8)]
+    results, errors = [None] * len(jobs), []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                results[i] = prod.scan_segments(jobs[i])
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for job, res in zip(jobs, results):
+        for (s, ap, tips), g in zip(job, res):
+            assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="concurrent len=%d" % len(s))
