@@ -15,11 +15,13 @@
 //
 // Per tile:
 //   phase 1  2016 positions per iteration, 32 per lane: two coalesced 16 B/lane loads (the next
-//            chunk's in flight), SWAR ASCII -> 2-bit codes (v_perm / v_sad_u8 / v_dot4), ONE
-//            ds_read_b32 per TWO positions from the pair table in LDS ((k+1)-mer -> match bits of
-//            both positions), nucleotide counts per 32 positions into byte planes.
-//            Then the chunk's matches (a few per cent of the positions) are compacted into a list
-//            and resolved 64 at a time on full wavefronts: forward/canonical flags from the flag
+//            chunk's in flight; a tile's first chunk is requested while the previous tile's window
+//            phase runs), SWAR ASCII -> 2-bit codes (v_perm / v_sad_u8 / v_dot4), ONE LDS read per
+//            TWO positions from the pair table ((k+1)-mer -> match bits of both positions; one byte
+//            per (k+1)-mer for k <= 6, so the (k+1)-mer is the address), nucleotide counts per 32
+//            positions into byte planes.
+//            The chunk's matches (a few per cent of the positions) are compacted onto a queue and
+//            resolved 64 at a time on full wavefronts: forward/canonical flags from the flag
 //            table, the packed 32-bit record (staged in LDS, flushed in coalesced rows), and one
 //            packed ds_add_u64 per window that contains the match.
 //   phase 2  nucleotide fields of the windows: byte-plane sums (v_sad_u8) + partial ends from the
