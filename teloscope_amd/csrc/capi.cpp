@@ -185,7 +185,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
             }
             // staging room for match records: what is left of the CU's LDS, 64 .. 1024 records per wave
             cand.stage_cap = 128;
-            cand.acc_copies = 8;
+            cand.acc_copies = 4;             // (8 copies measured no better than 4; the LDS goes to the record stage)
             while (cand.acc_copies > 1 && (uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) cand.acc_copies >>= 1;
             if (cwpt < 1 || (uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) continue;
             {

@@ -244,9 +244,11 @@ void ts_scan_tiles(const TsScanParams P) {
                 const uint32_t xp = live ? (uint32_t)mlist[(qhead + lane) & (TS_LIST - 1u)] : 0u;   // plane coord of the match
                 // its k-mer, from the code plane (16 positions per dword)
                 const lds_u32 *cw = codes + (xp >> 4);
-                const uint32_t idx = __builtin_amdgcn_alignbit(cw[1], cw[0], (xp & 15u) * 2u) & kmask;
+                const uint32_t kw = __builtin_amdgcn_alignbit(cw[1], cw[0], (xp & 15u) * 2u);
+                const uint32_t idx = kw & kmask;
                 uint32_t fc;                                  // forward << 1 | canonical
-                if (FC_BYTES) fc = fc_bytes[idx];
+                if (PAIR_BYTES) fc = ((uint32_t)lds[kw & pmask] >> 2) & 3u;        // bits 2..3 of the pair-table byte
+                else if (FC_BYTES) fc = fc_bytes[idx];
                 else fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
                 // position in the tile, step block and offset inside it
                 const uint32_t u = xp - sh;                   // wraps for the few bases before the tile

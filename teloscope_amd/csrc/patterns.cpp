@@ -170,7 +170,8 @@ int base_code(char c) {
 //    Not replicated: the kernel is
 //    bound by VALU issue, and spreading rows over the LDS banks (8 copies) bought 0.4 % when it
 //    was measured, while the 28 KB it cost is what the per-wave count planes now live in;
-//  * flag table: {canonical, forward} (bit 0, bit 1: the low bits of a match record) per k-mer, looked up only at matched positions: one byte
+//  * flags {canonical, forward} (bit 0, bit 1: the low bits of a match record) per k-mer: bits 2..3 of the
+//    byte pair table's entries for k <= 6 (no separate table), else a flag table, looked up only at matched positions: one byte
 //    per k-mer for k <= 7 (cheapest lookup), 2 bits per k-mer at k = 8 (LDS capacity).
 // Layout in `table`: [rows dwords][flag table].
 bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
@@ -195,18 +196,23 @@ bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector
     pair_byte_table = k <= 6;
     rows = static_cast<uint32_t>(pair_byte_table ? npairs / 4 : npairs / 16);
     fc_byte_table = k <= 7;
-    const size_t fc_words = static_cast<size_t>(std::max<uint64_t>(fc_byte_table ? nk / 4 : nk / 16, 4));
+    // with a byte pair table the flags of the k-mer at p ride in bits 2..3 of its entries: no flag table
+    const size_t fc_words = pair_byte_table ? 0 : static_cast<size_t>(std::max<uint64_t>(fc_byte_table ? nk / 4 : nk / 16, 4));
     fc_bytes = static_cast<uint32_t>(fc_words * 4);
     table.assign(static_cast<size_t>(rows) + fc_words, 0u);
     const uint32_t kmask = static_cast<uint32_t>(nk - 1);
     for (uint64_t y = 0; y < npairs; ++y) {
         const uint32_t bits = (m[y & kmask] ? 1u : 0u) | (m[(y >> 2) & kmask] ? 2u : 0u);
+        if (pair_byte_table) {
+            const uint32_t entry = bits | (static_cast<uint32_t>(fl[y & kmask]) << 2);
+            table[y >> 2] |= entry << (8 * (y & 3));
+            continue;
+        }
         if (!bits) continue;
-        if (pair_byte_table) table[y >> 2] |= bits << (8 * (y & 3));
-        else table[y >> 4] |= bits << (2 * (y & 15));
+        table[y >> 4] |= bits << (2 * (y & 15));
     }
-    uint32_t *fc = &table[rows];
-    for (uint64_t x = 0; x < nk; ++x) {
+    uint32_t *fc = fc_words ? &table[rows] : nullptr;
+    for (uint64_t x = 0; fc && x < nk; ++x) {
         if (fc_byte_table) fc[x >> 2] |= static_cast<uint32_t>(fl[x]) << (8 * (x & 3));
         else fc[x >> 4] |= static_cast<uint32_t>(fl[x]) << (2 * (x & 15));
     }
