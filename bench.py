@@ -218,6 +218,7 @@ def main():
                 if (world > 1 and rank == 0) else None for _ in range(2)]
     pending = [None, None]
     step_no = [0]
+    gather_mode = ["async"]
     stream = torch.cuda.current_stream()
     sptr = C.c_void_p(stream.cuda_stream)
     dptr = C.c_void_p(buf.data_ptr())
@@ -234,8 +235,15 @@ def main():
             rc = L.ts_batch_segment_summary(batch, C.c_void_p(summaries[j].data_ptr()), sptr)
             if rc != 0:
                 raise RuntimeError(tel._ctx.error())
-            pending[j] = dist.gather(summaries[j] if backend == "nccl" else summaries[j].cpu(), gathered[j], dst=0,
-                                     async_op=True)
+            src = summaries[j] if backend == "nccl" else summaries[j].cpu()
+            if gather_mode[0] == "async":
+                try:
+                    pending[j] = dist.gather(src, gathered[j], dst=0, async_op=True)
+                    return
+                except (RuntimeError, NotImplementedError, TypeError):   # a backend without an asynchronous gather
+                    gather_mode[0] = "sync"
+            pending[j] = None
+            dist.gather(src, gathered[j], dst=0)
 
     def drain_gathers():
         for j in range(2):
