@@ -2,8 +2,8 @@
 """bench.py — Gbases/s scanned by the HIP telomeric-motif scan on MI355X.
 
 Workload (BASELINE.json configs[1]): synthetic 3.0 Gb human-scale assembly, 200 contigs
-(log-uniform 1-250 Mb), telomeric arrays + TVRs at contig ends, planted ITS blocks, 0.1 %
-soft-masked bases; flags -c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -x 1 -w 1000 -s 500
+(log-uniform 1-250 Mb), telomeric arrays + TVRs at contig ends, planted ITS blocks, an N-run
+in 1 % of the contigs, 0.1 % soft-masked bases; flags -c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -x 1 -w 1000 -s 500
 -r -g -e -m -i  (124 patterns, k = 6).  One "step" = one full scan of the resident batch:
 window records (8 x u32 per window) and the packed match stream are produced in HBM.
 
@@ -39,7 +39,7 @@ def contig_lengths(total, n, seed):
 
 
 def fill_synthetic(buf, offsets, lens, seed, dev):
-    """Random ACGT + telomeres/TVRs at both ends of every contig + ITS blocks + soft-masking,
+    """Random ACGT + telomeres/TVRs at both ends of every contig + ITS blocks + N-runs + soft-masking,
     generated on the device (model of src/get-mock-chr.cpp:96-136)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -74,6 +74,10 @@ def fill_synthetic(buf, offsets, lens, seed, dev):
         at = int(rng.integers(20000, max(20001, lens[ci] - 20000 - 6 * ln)))
         t = tract(unit, ln, 0.02)
         buf[offsets[ci] + at:offsets[ci] + at + len(t)] = t
+    for ci in rng.choice(len(lens), size=max(1, len(lens) // 100), replace=False):    # 1 % of contigs: an N-run
+        ln = int(rng.integers(100, 10001))
+        at = int(rng.integers(20000, max(20001, lens[ci] - 20000 - ln)))
+        buf[offsets[ci] + at:offsets[ci] + at + ln] = ord("N")
 
 
 def verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev):

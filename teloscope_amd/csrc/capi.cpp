@@ -164,9 +164,15 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     double best = 0.0;
     TsScanParams best_kp{};
     uint32_t best_wpt = 0;
+    // TS_GEOMETRY="waves,chunks" pins the search to one point (0 = any): a test knob for the contract that the
+    // output does not depend on the tiling ("independent of GPU count and tile size")
+    uint32_t pin_waves = 0, pin_nch = 0;
+    if (const char *g = getenv("TS_GEOMETRY")) sscanf(g, "%u,%u", &pin_waves, &pin_nch);
     for (const auto &occ : kOccupancy) {
+        if (pin_waves && occ.waves != pin_waves) continue;
         for (uint32_t nch = nch_min; nch <= nch_max; ++nch) {
             if (nch * TS_CHUNK + 64u > 65535u) break;        // the match queue holds 16-bit plane coordinates
+            if (pin_nch && nch != pin_nch) continue;
             TsScanParams cand = kp;
             cand.waves_per_wg = occ.waves;
             cand.nch = nch;

@@ -497,3 +497,38 @@ def test_concurrent_calls_on_one_context():
     for job, res in zip(jobs, results):
         for (s, ap, tips), g in zip(job, res):
             assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="concurrent len=%d" % len(s))
+
+
+TILINGS = ["16,1", "16,3", "12,5", "8,2", "4,7", "2,4", "1,1", "1,8"]
+
+
+@pytest.mark.parametrize("cli", ["-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -m -i",
+                                 "-r -g -e -m -i", "-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i",
+                                 "-w 300 -s 100 -g -e -m -i", "-t 3000"])
+def test_output_independent_of_tiling(cli, monkeypatch):
+    """SURVEY 8b determinism contract: the output does not depend on the tile size or the waves per
+    workgroup.  TS_GEOMETRY pins the planner to one (waves, chunks per tile) point; every tiling the
+    parameter set admits must reproduce the oracle bit for bit (same windows, matches, blocks)."""
+    opts = H.parse_cli("x.fa " + cli)
+    orac = OracleBackend(opts)
+    rng = np.random.default_rng(len(cli) * 31 + 5)
+    unit_f, unit_r = opts.canonical_fwd, opts.canonical_rev
+    segs = []
+    for i, n in enumerate([1, 999, 2016, 4033, 30011, 64513, 129023, 400003]):
+        s = seqgen.chromosome(rng, n, unit_f, unit_r, telo_repeats=min(300, max(1, n // 40)),
+                              tvr_rate=0.03, n_its=4, iupac=(n // 20000), lower=0.01, n_runs=i % 2)
+        segs.append((s, int(rng.integers(0, 10 ** 6)), opts.ultra_fast))
+    want = [orac.scan_segment(bytes(s).upper(), ap, tips) for s, ap, tips in segs]   # the product folds case
+    ran = 0
+    for tiling in TILINGS:
+        monkeypatch.setenv("TS_GEOMETRY", tiling)
+        try:
+            prod = ProductBackend(opts)
+            got = prod.scan_segments(segs)
+        except Exception as exc:                   # this tiling does not fit the LDS for this window / step
+            assert "unsupported" in str(exc) or "does not fit" in str(exc), exc
+            continue
+        ran += 1
+        for (s, ap, tips), g, e in zip(segs, got, want):
+            assert_segment_equal(g, e, tips, ctx="tiling=%s cli=%r len=%d" % (tiling, cli, len(s)))
+    assert ran >= 4, "too few tilings ran for %r" % cli
