@@ -585,7 +585,7 @@ __global__ void ts_segment_summary(const uint32_t *tile_stats, const uint32_t *s
 // ts_terminal_predicate: "does this segment have a terminal telomere block?" decided on the
 // device from the packed match stream — Teloscope::getTerminalBlocks (src/teloscope.cpp:29-176)
 // for both orientations, reduced to whether outBlocks would be non-empty.  One thread per
-// segment walks its tiles' records (ascending for the forward list, descending for the reverse
+// segment (one wave for a segment with a long match list) walks its tiles' records (ascending for the forward list, descending for the reverse
 // list) through the same two-phase state machine: chain matches <= -k apart into sub-blocks,
 // keep those with >= minBlockCounts matches, a canonical match and canonical density >= -y,
 // merge kept sub-blocks <= -d apart, pass if a merged block is >= -l long.  This is what turns
@@ -639,50 +639,124 @@ __device__ __forceinline__ bool pred_feed(PredState &st, const TsPredParams &Q, 
     return true;
 }
 
-__global__ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
-                                      const uint32_t *matches, const uint32_t *seg_first_tile,
-                                      const u64 *seg_in_off, const u64 *seg_len, uint32_t nseg,
-                                      const TsPredParams Q, unsigned char *pass) {
-    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
-    if (si >= nseg) return;
-    const uint32_t t0 = seg_first_tile[si], t1 = seg_first_tile[si + 1];
-    const u64 n = seg_len[si], base = seg_in_off[si];
-    u64 total = 0, nfwd = 0;
-    for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
+// One orientation of the walk, one thread per read.  Records are visited in walk order (ascending for the
+// forward list, descending for the reverse list), eight at a time with the next eight already requested: a
+// thread's loads are scattered (every lane walks its own read), so the walk is bound by load latency.
+template <bool FROM_START>
+__device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                                          const uint32_t *matches, uint32_t t0, uint32_t t1, u64 base, u64 n,
+                                          const TsPredParams &Q) {
+    PredState st = {};
+    bool go = true;
+    for (uint32_t tt = 0; tt < t1 - t0 && go && !st.pass; ++tt) {
+        const uint32_t t = FROM_START ? t0 + tt : t1 - 1u - tt;
+        const uint32_t cnt = tile_stats[4u * t];
+        if (cnt == 0u) continue;
+        const u64 rel0 = tiles[t].in_off - base;
+        const uint32_t *r = matches + tile_off[t];
+        auto at = [&](uint32_t i) -> uint32_t {            // i-th record in walk order (clamped: loads are unconditional)
+            const uint32_t j = i < cnt ? i : cnt - 1u;
+            return r[FROM_START ? j : cnt - 1u - j];
+        };
+        uint32_t v[8], w[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) v[j] = at(j);
+        for (uint32_t i = 0; i < cnt && go; i += 8u) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) w[j] = at(i + 8u + j);
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j)
+                if (i + j < cnt && go && ((v[j] & 2u) != 0u) == FROM_START)
+                    go = pred_feed(st, Q, FROM_START, rel0 + (v[j] >> 2), v[j] & 1u, n);
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) v[j] = w[j];
+        }
+    }
+    if (st.in_block) pred_close_sub(st, Q, FROM_START);
+    if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
+    return st.pass;
+}
+
+// The same walk run by a whole wave for ONE read (all arguments wave-uniform): the records come in 64 at a
+// time with one coalesced load and the state machine steps through them by v_readlane, so it is scalar
+// code with no memory round trip per match.  For reads with long match lists (a telomeric read has
+// thousands of chained matches), which would otherwise keep one lane busy long after its wave has finished.
+template <bool FROM_START>
+__device__ bool pred_walk_wave(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                               const uint32_t *matches, uint32_t t0, uint32_t t1, u64 base, u64 n,
+                               const TsPredParams &Q, uint32_t lane) {
+    PredState st = {};
+    bool go = true;
+    for (uint32_t tt = 0; tt < t1 - t0 && go && !st.pass; ++tt) {
+        const uint32_t t = FROM_START ? t0 + tt : t1 - 1u - tt;
+        const uint32_t cnt = tile_stats[4u * t];
+        if (cnt == 0u) continue;
+        const u64 rel0 = tiles[t].in_off - base;
+        const uint32_t *r = matches + tile_off[t];
+        for (uint32_t b0 = 0; b0 < cnt && go; b0 += 64u) {
+            const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
+            const uint32_t lo = FROM_START ? b0 : cnt - b0 - nb;          // first record of the batch
+            const uint32_t mine = lane < nb ? r[lo + lane] : 0u;
+            for (uint32_t j = 0; j < nb && go; ++j) {
+                const uint32_t jj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(FROM_START ? j : nb - 1u - j));
+                const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)jj);
+                if (((rec & 2u) != 0u) == FROM_START)
+                    go = pred_feed(st, Q, FROM_START, rel0 + (rec >> 2), rec & 1u, n);
+            }
+        }
+    }
+    if (st.in_block) pred_close_sub(st, Q, FROM_START);
+    if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
+    return st.pass;
+}
+
+constexpr uint32_t kLongRead = 384;        // records; above this a read is walked by the whole wave
+
+__global__ __launch_bounds__(64)
+void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                           const uint32_t *matches, const uint32_t *seg_first_tile,
+                           const u64 *seg_in_off, const u64 *seg_len, uint32_t nseg,
+                           const TsPredParams Q, unsigned char *pass) {
+    const uint32_t lane = threadIdx.x;                       // one wave per workgroup
+    const uint32_t si = blockIdx.x * 64u + lane;
+    const bool live = si < nseg;                              // every lane stays: the long reads below need the whole wave
+    uint32_t t0 = 0, t1 = 0;
+    u64 n = 0, base = 0, total = 0, nfwd = 0;
+    if (live) {
+        t0 = seg_first_tile[si]; t1 = seg_first_tile[si + 1];
+        n = seg_len[si]; base = seg_in_off[si];
+        for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
+    }
+    const bool is_long = live && total > kLongRead;
     bool ok = false;
-    if (nfwd >= 2) {                                        // forward list, from the segment start
-        PredState st = {};
-        bool go = true;
-        for (uint32_t t = t0; t < t1 && go && !st.pass; ++t) {
-            const u64 rel0 = tiles[t].in_off - base;
-            const uint32_t *r = matches + tile_off[t];
-            const uint32_t cnt = tile_stats[4u * t];
-            for (uint32_t i = 0; i < cnt && go; ++i) {
-                const uint32_t rec = r[i];
-                if (rec & 2u) go = pred_feed(st, Q, true, rel0 + (rec >> 2), rec & 1u, n);
-            }
-        }
-        if (st.in_block) pred_close_sub(st, Q, true);
-        if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
-        ok = st.pass;
+    if (live && !is_long) {
+        if (nfwd >= 2)                                      // forward list, from the segment start
+            ok = pred_walk<true>(tiles, tile_off, tile_stats, matches, t0, t1, base, n, Q);
+        if (!ok && total - nfwd >= 2)                       // reverse list, from the segment end
+            ok = pred_walk<false>(tiles, tile_off, tile_stats, matches, t0, t1, base, n, Q);
     }
-    if (!ok && total - nfwd >= 2) {                         // reverse list, from the segment end
-        PredState st = {};
-        bool go = true;
-        for (uint32_t t = t1; t > t0 && go && !st.pass; --t) {
-            const u64 rel0 = tiles[t - 1].in_off - base;
-            const uint32_t *r = matches + tile_off[t - 1];
-            const uint32_t cnt = tile_stats[4u * (t - 1)];
-            for (uint32_t i = cnt; i > 0 && go; --i) {
-                const uint32_t rec = r[i - 1];
-                if (!(rec & 2u)) go = pred_feed(st, Q, false, rel0 + (rec >> 2), rec & 1u, n);
-            }
-        }
-        if (st.in_block) pred_close_sub(st, Q, false);
-        if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
-        ok = st.pass;
+    u64 todo = __ballot(is_long);
+    while (todo) {                                          // wave-uniform: one long read at a time
+        const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t ut0 = (uint32_t)__builtin_amdgcn_readlane((int)t0, (int)l);
+        const uint32_t ut1 = (uint32_t)__builtin_amdgcn_readlane((int)t1, (int)l);
+        const u64 un = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(n >> 32), (int)l) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)n, (int)l);
+        const u64 ubase = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), (int)l) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, (int)l);
+        const u64 utotal = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(total >> 32), (int)l) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)total, (int)l);
+        const u64 unfwd = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(nfwd >> 32), (int)l) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nfwd, (int)l);
+        bool uok = false;
+        if (unfwd >= 2)
+            uok = pred_walk_wave<true>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, un, Q, lane);
+        if (!uok && utotal - unfwd >= 2)
+            uok = pred_walk_wave<false>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, un, Q, lane);
+        if (lane == l) ok = uok;
     }
-    pass[si] = ok ? 1 : 0;
+    if (live) pass[si] = ok ? 1 : 0;
 }
 
 // Packs the per-wave record regions into one dense stream (used before a D2H copy).
