@@ -50,6 +50,9 @@ typedef LDS unsigned char lds_u8;
 typedef LDS uint16_t lds_u16;
 typedef LDS uint32_t lds_u32;
 
+// an LDS byte address (the dynamic-LDS base is 0) as a pointer
+__device__ __forceinline__ lds_u16 *lds_at16(uint32_t addr) { return (lds_u16 *)(uintptr_t)addr; }
+
 // Wave-wide inclusive prefix sum in 6 DPP adds (row_shr 1/2/4/8 inside each row of 16,
 // then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3); no LDS traffic.
 template <int CTRL, int ROW_MASK>
@@ -92,12 +95,12 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
 
 __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
-// LDS: [match table][wave 0 slice][wave 1 slice]...; a slice = codes | cnt | mlist | rec | stage
+// LDS: [match table][wave 0 queue][wave 1 queue]...[wave 0 slice][wave 1 slice]...; a slice = codes | cnt | rec | wacc | stage
 //   codes   2-bit codes of the tile, two dwords per 32 positions (+ one look-ahead dword pair)
 //   cnt     nucleotide counts, one byte per 32 positions and letter (valid A, C, G, T among them).
 //           Layout [h / 4][letter][h % 4]: a letter's counts of four consecutive h share a dword
 //           (summed by one v_sad_u8), and a lane's four counts of one h sit at fixed offsets
-//   mlist   queue (ring of TS_LIST u16 plane coordinates) of match positions, appended to by every
+//   queue   (its own region) ring of TS_LIST u16 plane coordinates of match positions, appended to by every
 //           chunk in position order and consumed 64 at a time, so that the per-match work runs
 //           on full wavefronts
 //   rec     the nucleotide fields of the tile's window records, 4 x u32 per window
@@ -108,14 +111,13 @@ __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15
 //           address
 //   stage   packed match records waiting to leave in whole coalesced rows (and kept out of the
 //           chunk loads' counted vmcnt waits), + one spare slot per lane for predicated-off writes
-struct SliceLayout { uint32_t codes, cnt, mlist, rec, wacc, stage, bytes; };
+struct SliceLayout { uint32_t codes, cnt, rec, wacc, stage, bytes; };
 
 __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     SliceLayout s;
     uint32_t o = 0;
     s.codes = o; o += align16((P.nch * 63u + 1u) * 8u);
     s.cnt = o; o += (P.windows_on && P.nuc_on) ? ((P.nch * 63u + 3u) >> 2) * 16u : 0u;
-    s.mlist = o; o += TS_LIST * 2u;
     s.rec = o; o += (P.windows_on && P.nuc_on) ? align16(P.max_windows * 16u) : 0u;
     s.wacc = o; o += P.windows_on ? align16(P.max_windows * 8u * P.acc_copies) : 0u;
     s.stage = o; o += (P.stage_cap + 64u) * 4u;
@@ -123,8 +125,15 @@ __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     return s;
 }
 
+// The match queues of all waves sit together behind the table, each aligned to its own size, so that a
+// queue slot's LDS address is (byte offset & mask) | base: one v_and_or instead of mask, shift and add.
+__host__ __device__ inline uint32_t queue_region(const TsScanParams &P) {
+    const uint32_t a = TS_LIST * 2u;
+    return (P.table_rows * 4u + P.fc_bytes + a - 1u) & ~(a - 1u);
+}
+
 __host__ __device__ inline uint32_t lds_total(const TsScanParams &P) {
-    return P.table_rows * 4u + P.fc_bytes + P.waves_per_wg * slice_layout(P).bytes;
+    return queue_region(P) + P.waves_per_wg * (TS_LIST * 2u + slice_layout(P).bytes);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -149,10 +158,13 @@ void ts_scan_tiles(const TsScanParams P) {
 
     const SliceLayout SL = slice_layout(P);
     lds_u8 *lds = (lds_u8 *)lds_raw;
-    lds_u8 *slice = lds + table_bytes + wave * SL.bytes;
+    uint32_t qbase = queue_region(P) + wave * (TS_LIST * 2u);                    // LDS byte address of this wave's queue
+    uint32_t qmask = TS_LIST * 2u - 2u;
+    asm volatile("" : "+v"(qbase));               // base in a VGPR, mask in an SGPR: (offset & mask) | base is one v_and_or_b32
+    asm volatile("" : "+s"(qmask));
+    lds_u8 *slice = lds + queue_region(P) + P.waves_per_wg * (TS_LIST * 2u) + wave * SL.bytes;
     lds_u32 *codes = (lds_u32 *)(slice + SL.codes);
     lds_u8 *cnt = slice + SL.cnt;
-    lds_u16 *mlist = (lds_u16 *)(slice + SL.mlist);
     lds_u32 *rec = (lds_u32 *)(slice + SL.rec);
     lds_u32 *stage = (lds_u32 *)(slice + SL.stage);
     LDS u64 *wacc = (LDS u64 *)(slice + SL.wacc);
@@ -234,14 +246,14 @@ void ts_scan_tiles(const TsScanParams P) {
         // to a queue in LDS, and the queue is consumed 64 matches at a time: flags from the flag table,
         // the packed record, and the match's contribution to every window that contains it.  A pass only
         // runs on 64 queued matches (fewer when the tile ends or the queue must make room).
-        uint32_t qhead = 0, qcount = 0;
+        uint32_t qhead = 0, qcount = 0;                            // head as a byte offset into the ring, entries queued
         auto drain_queue = [&](const uint32_t threshold) {
             if (TS_ABL & 128) { qcount = 0; return; }           // profiling: compaction only, nothing consumed
             while (qcount >= threshold && qcount > 0u) {
                 const uint32_t n = qcount < 64u ? qcount : 64u;
                 if (done - flushed + 64u > P.stage_cap) flush_stage();
                 const bool live = lane < n;
-                const uint32_t xp = live ? (uint32_t)mlist[(qhead + lane) & (TS_LIST - 1u)] : 0u;   // plane coord of the match
+                const uint32_t xp = live ? (uint32_t)*lds_at16(((qhead + lane * 2u) & qmask) | qbase) : 0u;   // plane coord of the match
                 // its k-mer, from the code plane (16 positions per dword)
                 const lds_u32 *cw = codes + (xp >> 4);
                 const uint32_t kw = __builtin_amdgcn_alignbit(cw[1], cw[0], (xp & 15u) * 2u);
@@ -277,7 +289,7 @@ void ts_scan_tiles(const TsScanParams P) {
                         if (in) atomicAdd((unsigned long long *)(wacc + acc_off + wi), inc);
                     }
                 }
-                qhead = (qhead + n) & (TS_LIST - 1u);
+                qhead = (qhead + 2u * n) & (TS_LIST * 2u - 1u);
                 qcount -= n;
             }
             __builtin_amdgcn_wave_barrier();                  // the queue is appended to next
@@ -330,22 +342,24 @@ void ts_scan_tiles(const TsScanParams P) {
             uint32_t M32 = wa & wb & (wa >> 7) & (nx >> 3) & (wb >> 11);
 #else
             uint32_t tmp[16], ent[16];
+            // bases 16..31 of a code dword followed by bases 0..15 of the next one: the (k+1)-mers that start
+            // at bases 10, 12, 14 lie inside it (k <= 6)
+            const uint32_t xa = PAIR_BYTES ? __builtin_amdgcn_alignbit(wb, wa, 16) : 0u;
+            const uint32_t xb = PAIR_BYTES ? __builtin_amdgcn_alignbit(nx, wb, 16) : 0u;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                if (PAIR_BYTES && (j & 7) <= 4) {
-                    // one byte per (k+1)-mer: index = address; a (k+1)-mer of k <= 6 that starts at base
-                    // 2 (j & 7) <= 8 lies inside one code dword: a single v_bfe
+                if (PAIR_BYTES) {
+                    // one byte per (k+1)-mer: index = address; every probe is a single v_bfe
                     tmp[j] = 0;
-                    const uint32_t addr = __builtin_amdgcn_ubfe(j < 8 ? wa : wb, 4 * (j & 7), 2u * (k + 1u)) | tab_base;
+                    const uint32_t word = (j & 7) <= 4 ? (j < 8 ? wa : wb) : (j < 8 ? xa : xb);
+                    const uint32_t bit = (j & 7) <= 4 ? 4 * (j & 7) : 4 * ((j & 7) - 4);
+                    const uint32_t addr = __builtin_amdgcn_ubfe(word, bit, 2u * (k + 1u)) | tab_base;
                     asm volatile("ds_read_u8 %0, %1" : "=v"(ent[j]) : "v"(addr));
                     continue;
                 }
                 if (j < 8) tmp[j] = (j == 0) ? wa : __builtin_amdgcn_alignbit(wb, wa, 4 * j);
                 else tmp[j] = (j == 8) ? wb : __builtin_amdgcn_alignbit(nx, wb, 4 * (j - 8));
-                if (PAIR_BYTES) {
-                    const uint32_t addr = (tmp[j] & pmask) | tab_base;
-                    asm volatile("ds_read_u8 %0, %1" : "=v"(ent[j]) : "v"(addr));
-                } else {                                          // 16 entries per dword: row, then shift
+                {                                                 // 16 entries per dword: row, then shift
                     const uint32_t row = __builtin_amdgcn_ubfe(tmp[j], 4, rowbits);
                     const uint32_t addr = tab_base + (row << 2);
                     asm volatile("ds_read_b32 %0, %1" : "=v"(ent[j]) : "v"(addr));
@@ -375,14 +389,17 @@ void ts_scan_tiles(const TsScanParams P) {
                 if (lane < 63u && P.windows_on && P.nuc_on) {
                     // valid A/C/G/T among the 32 bases (codes A0 C1 T2 G3: low bit set in C and G, high
                     // bit in T and G); invalid positions are masked out on the slow path
-                    uint32_t sa = 0x55555555u, sb = 0x55555555u, nV = 32u;
+                    // low code bits of the 32 bases in one dword (wa's at the even positions, wb's at the odd
+                    // ones), high code bits in another with the same placement: three popcounts
+                    uint32_t lo = (wa & 0x55555555u) | ((wb << 1) & 0xAAAAAAAAu);
+                    uint32_t hi = ((wa >> 1) & 0x55555555u) | (wb & 0xAAAAAAAAu);
+                    uint32_t nV = 32u;
                     if (slow) {
-                        sa = spread16(~inv & 0xFFFFu); sb = spread16(~inv >> 16);
+                        const uint32_t ok = spread16(~inv & 0xFFFFu) | (spread16(~inv >> 16) << 1);
+                        lo &= ok; hi &= ok;
                         nV = __popc(~inv);
                     }
-                    const uint32_t la = wa & sa, ha = (wa >> 1) & sa, lb = wb & sb, hb = (wb >> 1) & sb;
-                    const uint32_t nG = __popc(la & ha) + __popc(lb & hb);
-                    const uint32_t nL = __popc(la) + __popc(lb), nH = __popc(ha) + __popc(hb);
+                    const uint32_t nG = __popc(lo & hi), nL = __popc(lo), nH = __popc(hi);
                     lds_u8 *np = cnt + ((h >> 2) << 4) + (h & 3u);
                     np[0] = (unsigned char)(nV + nG - nL - nH);
                     np[4] = (unsigned char)(nL - nG);
@@ -403,10 +420,11 @@ void ts_scan_tiles(const TsScanParams P) {
                 // matches would not fit behind it (dense repeats)
                 drain_queue(qcount + total > TS_LIST ? 1u : 64u);
                 {
-                    uint32_t o = qhead + qcount + incl - nm, m = M32;
+                    uint32_t o = qhead + 2u * (qcount + incl - nm), m = M32;        // byte offset of the lane's first slot
                     const uint32_t lbase = cpos + lane * 32u;     // plane coordinates, < 65536 (nch <= 32)
                     while (m) {
-                        mlist[o++ & (TS_LIST - 1u)] = (uint16_t)(lbase + (uint32_t)__builtin_ctz(m));
+                        *lds_at16((o & qmask) | qbase) = (uint16_t)(lbase + (uint32_t)__builtin_ctz(m));
+                        o += 2u;
                         m &= m - 1u;
                     }
                 }
