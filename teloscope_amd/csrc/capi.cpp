@@ -144,7 +144,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     } else {
         const uint32_t s = P.step, w = P.window_size;
         kp.s = s; kp.w = w;
-        kp.s_inv = (uint32_t)(((1ull << 32) + s - 1) / s);
+        kp.s_inv = (65536u + s - 1u) / s;
         kp.halo_blocks = (w + s - 1) / s - 1;            // window i reaches into step blocks i .. i + ceil(w/s) - 1
         kp.straddle_fix = (w == s) ? 1u : 0u;
         kp.windows_on = 1;
@@ -167,7 +167,8 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     // TS_GEOMETRY="waves,chunks" pins the search to one point (0 = any): a test knob for the contract that the
     // output does not depend on the tiling ("independent of GPU count and tile size")
     uint32_t pin_waves = 0, pin_nch = 0;
-    if (const char *g = getenv("TS_GEOMETRY")) sscanf(g, "%u,%u", &pin_waves, &pin_nch);
+    uint32_t pin_stage = 0;
+    if (const char *g = getenv("TS_GEOMETRY")) sscanf(g, "%u,%u,%u", &pin_waves, &pin_nch, &pin_stage);
     for (const auto &occ : kOccupancy) {
         if (pin_waves && occ.waves != pin_waves) continue;
         for (uint32_t nch = nch_min; nch <= nch_max; ++nch) {
@@ -181,7 +182,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
             if (tips) {
                 const uint32_t tb = span_max & ~15u;            // one pseudo block per tile
                 cand.s = cand.w = tb;
-                cand.s_inv = (uint32_t)(((1ull << 32) + tb - 1) / tb);
+                cand.s_inv = (65536u + tb - 1u) / tb;
                 cand.max_windows = 1;
                 cwpt = 1;
             } else {
@@ -196,11 +197,14 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
             if (cwpt < 1 || (uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) continue;
             {
                 const uint32_t spare = (kMaxLds - (uint32_t)ts_k_lds_bytes(&cand)) / occ.waves / 4u;
-                cand.stage_cap = std::min<uint32_t>(1024u, 128u + (spare & ~15u));
+                cand.stage_cap = std::min<uint32_t>(pin_stage ? pin_stage : 1024u, 128u + (spare & ~15u));
                 while ((uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) cand.stage_cap -= 16;
             }
             const double passes = tips ? 0.0 : (double)ceil_div((uint64_t)cwpt * 4, 64);
-            const double score = (double)cwpt * cand.s * occ.factor / (470.0 * nch + 170.0 * passes + 100.0);
+            // fewer accumulator copies serialise the window adds of a pass: 8 chunks with 2 copies measured 2.5 %
+            // slower than 7 chunks with 4 on the headline configuration, where the model alone says 1 % faster
+            const double copies = cand.acc_copies >= 4 ? 1.0 : cand.acc_copies == 2 ? 0.96 : 0.92;
+            const double score = (double)cwpt * cand.s * occ.factor * copies / (470.0 * nch + 170.0 * passes + 100.0);
             if (score > best) { best = score; best_kp = cand; best_wpt = cwpt; }
         }
     }

@@ -52,6 +52,7 @@ typedef LDS uint32_t lds_u32;
 
 // an LDS byte address (the dynamic-LDS base is 0) as a pointer
 __device__ __forceinline__ lds_u16 *lds_at16(uint32_t addr) { return (lds_u16 *)(uintptr_t)addr; }
+__device__ __forceinline__ lds_u8 *lds_at8(uint32_t addr) { return (lds_u8 *)(uintptr_t)addr; }
 
 // Wave-wide inclusive prefix sum in 6 DPP adds (row_shr 1/2/4/8 inside each row of 16,
 // then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3); no LDS traffic.
@@ -255,16 +256,17 @@ void ts_scan_tiles(const TsScanParams P) {
                 const bool live = lane < n;
                 const uint32_t xp = live ? (uint32_t)*lds_at16(((qhead + lane * 2u) & qmask) | qbase) : 0u;   // plane coord of the match
                 // its k-mer, from the code plane (16 positions per dword)
-                const lds_u32 *cw = codes + (xp >> 4);
+                const lds_u32 *cw = codes + __builtin_amdgcn_ubfe(xp, 4, 12);
                 const uint32_t kw = __builtin_amdgcn_alignbit(cw[1], cw[0], (xp & 15u) * 2u);
                 const uint32_t idx = kw & kmask;
                 uint32_t fc;                                  // forward << 1 | canonical
-                if (PAIR_BYTES) fc = ((uint32_t)lds[kw & pmask] >> 2) & 3u;        // bits 2..3 of the pair-table byte
+                if (PAIR_BYTES) fc = __builtin_amdgcn_ubfe((uint32_t)*lds_at8(kw & pmask), 2, 2);   // bits 2..3 of the pair-table byte (table at LDS address 0)
                 else if (FC_BYTES) fc = fc_bytes[idx];
                 else fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
-                // position in the tile, step block and offset inside it
+                // position in the tile, step block and offset inside it: u < 2^16, so the quotient is one 24-bit
+                // multiply by ceil(2^16 / s) (full rate; exact or one too large, corrected below)
                 const uint32_t u = xp - sh;                   // wraps for the few bases before the tile
-                uint32_t q = __umulhi(u, P.s_inv), qs = q * P.s;   // (multiplies are quarter rate: one mul_hi, one mul_lo)
+                uint32_t q = __umul24(u, P.s_inv) >> 16, qs = __umul24(q, P.s);
                 if (qs > u) { --q; qs -= P.s; }
                 const uint32_t o = u - qs;
                 // w == s: a match that would straddle a window end is lost (the carry rule of
@@ -277,11 +279,13 @@ void ts_scan_tiles(const TsScanParams P) {
                 const uint32_t slot = owned ? (done - flushed) + rank : P.stage_cap + lane;
                 stage[slot] = (u << 2) | fc;
                 done += (uint32_t)__popcll(bal);
+                const bool is_can = (fc & 1u) != 0u, is_fwd = (fc & 2u) != 0u;
                 ccan += owned ? (fc & 1u) : 0u;
                 cfwd += owned ? (fc >> 1) : 0u;
                 // {canonical, non-canonical, forward, reverse} as one 4 x 16-bit increment
-                const u64 inc = (u64)((fc & 1u) ? 1u : 0x10000u) | ((u64)((fc & 2u) ? 1u : 0x10000u) << 32);
-                // windows q, q-1, ... contain the match as long as it ends inside them
+                const u64 inc = (u64)(is_can ? 1u : 0x10000u) | ((u64)(is_fwd ? 1u : 0x10000u) << 32);
+                // windows q, q-1, ... contain the match as long as it ends inside them.  Window q always does:
+                // o + k <= w holds for every valid match (w == s: the straddle rule above; w > s: k <= w - s)
                 if (P.windows_on && !(TS_ABL & 4)) {
                     for (uint32_t j = 0; j < nwper; ++j) {
                         const uint32_t wi = q - j;            // wraps past window 0
@@ -413,23 +417,35 @@ void ts_scan_tiles(const TsScanParams P) {
 #endif
             if (lane == 63u) M32 = 0;                             // lane 63 only looks ahead for lane 62
             if (__any(M32 != 0u)) {
-                const uint32_t nm = __popc(M32);
-                const uint32_t incl = wave_scan_incl(nm);
-                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                // the queue keeps whatever is short of a full pass; it is emptied first if this chunk's
-                // matches would not fit behind it (dense repeats)
-                drain_queue(qcount + total > TS_LIST ? 1u : 64u);
-                {
-                    uint32_t o = qhead + 2u * (qcount + incl - nm), m = M32;        // byte offset of the lane's first slot
-                    const uint32_t lbase = cpos + lane * 32u;     // plane coordinates, < 65536 (nch <= 32)
+                const uint32_t nm0 = __popc(M32);
+                const uint32_t incl0 = wave_scan_incl(nm0);
+                const uint32_t total0 = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
+                const uint32_t lbase = cpos + lane * 32u;         // plane coordinates, < 65536 (nch <= 32)
+                // A chunk with more matches than the queue holds (dense repeats) is appended one lane group
+                // at a time — a group's matches always fit, and groups are in position order.
+                constexpr uint32_t kGroup = TS_LIST / 32u;
+                const bool dense = TS_LIST < TS_CHUNK && total0 > TS_LIST;
+                const uint32_t ngroups = dense ? 64u / kGroup : 1u;
+                for (uint32_t gi = 0; gi < ngroups; ++gi) {
+                    uint32_t m = M32, nm = nm0, incl = incl0, total = total0;
+                    if (dense) {
+                        m = (lane / kGroup == gi) ? M32 : 0u;
+                        nm = __popc(m);
+                        incl = wave_scan_incl(nm);
+                        total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    }
+                    // the queue keeps whatever is short of a full pass; it is emptied first if these
+                    // matches would not fit behind it
+                    drain_queue(qcount + total > TS_LIST ? 1u : 64u);
+                    uint32_t o = qhead + 2u * (qcount + incl - nm);               // byte offset of the lane's first slot
                     while (m) {
                         *lds_at16((o & qmask) | qbase) = (uint16_t)(lbase + (uint32_t)__builtin_ctz(m));
                         o += 2u;
                         m &= m - 1u;
                     }
+                    qcount += total;
+                    __builtin_amdgcn_wave_barrier();
                 }
-                qcount += total;
-                __builtin_amdgcn_wave_barrier();
             }
         };
         {

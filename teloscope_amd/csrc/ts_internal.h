@@ -13,7 +13,9 @@
 // byte offset from the 16-byte-aligned address at or below the tile's first owned base.
 
 #define TS_MAX_WG_THREADS 1024         // up to 16 wavefronts per workgroup, one workgroup per CU
-#define TS_LIST         2048           // entries of a wave's match queue (power of two; a chunk adds at most 2016)
+#ifndef TS_LIST
+#define TS_LIST         512            // entries of a wave's match queue (power of two >= 64; a denser chunk is appended in lane groups)
+#endif
 #define TS_CHUNK        2016           // positions a wave resolves per iteration (63 lanes x 32)
 #define TS_BLK_COUNTERS 10             // 4 NB dwords of window nucleotide counts, then per step block: match head[3] rest[3]
 #define TS_IN_PAD       4096           // bytes of zero padding after the last segment in the input buffer
@@ -45,7 +47,7 @@ struct TsScanParams {
     uint32_t        fc_byte_table;  // 1: one byte {forward, canonical} per k-mer; 0: 2 bits per k-mer
     uint32_t        k;              // pattern length
     uint32_t        s, w;           // step and window (tips mode: s = w = tile size)
-    uint32_t        s_inv;          // ceil(2^32 / s): multiply-high division by s (tile-relative positions < 2^22)
+    uint32_t        s_inv;          // ceil(2^16 / s): 24-bit multiply division by s (tile-relative positions < 2^16)
     uint32_t        halo_blocks;    // step blocks read beyond the owned ones: ceil(w / s) - 1
     uint32_t        nch;            // chunks of TS_CHUNK positions per tile
     uint32_t        max_windows;    // windows per tile (rows of the LDS record buffer)

@@ -171,6 +171,18 @@ def test_dense_repeats_and_large_windows(cli, unit):
             s[a:a + ln] = (unit * (ln // len(unit) + 1))[:ln]
         s[n // 2] = ord("N")                                       # one invalid base inside a dense run or not
         segs.append((bytes(s), int(rng.integers(0, 10 ** 6)), opts.ultra_fast))
+    # match density around the match queue's capacity (512 of a chunk's 2016 positions): runs of random length
+    # alternate with random sequence, so some chunks overflow the queue (appended in lane groups) and their
+    # neighbours do not; plus single dense lane groups inside sparse chunks
+    for n, frac in [(60000, 0.2), (60000, 0.3), (90000, 0.5), (40000, 0.05)]:
+        s = bytearray(seqgen.random_dna(rng, n).tobytes())
+        at = 0
+        while at < n:
+            ln = int(rng.integers(20, 700))
+            if rng.random() < frac:
+                s[at:at + ln] = (unit * (ln // len(unit) + 1))[:ln][:n - at]
+            at += ln
+        segs.append((bytes(s), int(rng.integers(0, 10 ** 6)), opts.ultra_fast))
     got = prod.scan_segments(segs)
     for (s, ap, tips), g in zip(segs, got):
         assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="cli=%r len=%d" % (cli, len(s)))
