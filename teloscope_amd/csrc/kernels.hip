@@ -342,9 +342,7 @@ void ts_scan_tiles(const TsScanParams P) {
             // starts at an even position and holds {match at p, match at p+1} (16 entries per dword:
             // row = index >> 4, bit = 2 * (index & 15)).  All sixteen ds_read_b32 are issued back to
             // back (inline asm) and consumed behind one counted wait.
-#if TS_ABL & 32
-            uint32_t M32 = wa & wb & (wa >> 7) & (nx >> 3) & (wb >> 11);
-#else
+#if !(TS_ABL & 32)
             uint32_t tmp[16], ent[16];
             // bases 16..31 of a code dword followed by bases 0..15 of the next one: the (k+1)-mers that start
             // at bases 10, 12, 14 lie inside it (k <= 6)
@@ -369,22 +367,8 @@ void ts_scan_tiles(const TsScanParams P) {
                     asm volatile("ds_read_b32 %0, %1" : "=v"(ent[j]) : "v"(addr));
                 }
             }
-            uint32_t M32 = 0;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                M32 = __builtin_amdgcn_alignbit(PAIR_BYTES ? ent[j] : ent[j] >> ((tmp[j] << 1) & 31u), M32, 2);
 #endif
-
-            if (slow) {                                           // k-mers touching an invalid base
-                const uint32_t inv_next = (uint32_t)__builtin_amdgcn_mov_dpp((int)inv, 0x130, 0xf, 0xf, false);
-                const u64 iv = (u64)inv | ((u64)inv_next << 32);
-                uint32_t kb = 0;
-                for (uint32_t i = 0; i < k; ++i) kb |= (uint32_t)(iv >> i);
-                M32 &= ~kb;
-            }
-
+            // (issued while the probes are in flight: the stores and the counting need nothing from them)
             // the lane's bases go to the tile's code plane (lane 63's first dword is the look-ahead of lane 62's
             // last k-mers; the next chunk's lane 0 rewrites the same slot with the same value)
             if (!(TS_ABL & 64)) {
@@ -410,6 +394,25 @@ void ts_scan_tiles(const TsScanParams P) {
                     np[8] = (unsigned char)nG;
                     np[12] = (unsigned char)(nH - nG);
                 }
+            }
+
+#if TS_ABL & 32
+            uint32_t M32 = wa & wb & (wa >> 7) & (nx >> 3) & (wb >> 11);
+#else
+            uint32_t M32 = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                M32 = __builtin_amdgcn_alignbit(PAIR_BYTES ? ent[j] : ent[j] >> ((tmp[j] << 1) & 31u), M32, 2);
+#endif
+
+            if (slow) {                                           // k-mers touching an invalid base
+                const uint32_t inv_next = (uint32_t)__builtin_amdgcn_mov_dpp((int)inv, 0x130, 0xf, 0xf, false);
+                const u64 iv = (u64)inv | ((u64)inv_next << 32);
+                uint32_t kb = 0;
+                for (uint32_t i = 0; i < k; ++i) kb |= (uint32_t)(iv >> i);
+                M32 &= ~kb;
             }
 
 #if TS_ABL & 16
