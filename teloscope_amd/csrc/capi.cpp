@@ -140,7 +140,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     kp.fold_mask = P.fold_case ? 0xDFDFDFDFu : 0xFFFFFFFFu;
     if (tips) {
         kp.halo_blocks = 0;
-        kp.straddle_fix = 0; kp.windows_on = 0; kp.nuc_on = 0;
+        kp.straddle_fix = 0; kp.windows_on = 0; kp.nuc_on = 0; kp.block_sums = 0;
     } else {
         const uint32_t s = P.step, w = P.window_size;
         kp.s = s; kp.w = w;
@@ -149,6 +149,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
         kp.straddle_fix = (w == s) ? 1u : 0u;
         kp.windows_on = 1;
         kp.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u;
+        kp.block_sums = (w % s == 0) ? 1u : 0u;
     }
     // Search (waves per workgroup, chunks per tile) for the best modelled throughput:
     //   owned bases per tile x occupancy factor / instructions per tile.

@@ -104,7 +104,8 @@ __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15
 //   queue   (its own region) ring of TS_LIST u16 plane coordinates of match positions, appended to by every
 //           chunk in position order and consumed 64 at a time, so that the per-match work runs
 //           on full wavefronts
-//   rec     the nucleotide fields of the tile's window records, 4 x u32 per window
+//   rec     nucleotide counts {A, C, G, T}, 4 x u32 per step block of the tile (windows + halo) when w is a
+//           multiple of s (a window is the sum of w / s rows), else per window
 //   wacc    the match fields of the tile's window records while they accumulate: one u64 per window
 //           = four 16-bit counters {canonical, non-canonical, forward, reverse}, bumped by ONE
 //           ds_add_u64 per (match, window); kept in acc_copies lane-interleaved copies so that the
@@ -119,7 +120,7 @@ __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     uint32_t o = 0;
     s.codes = o; o += align16((P.nch * 63u + 1u) * 8u);
     s.cnt = o; o += (P.windows_on && P.nuc_on) ? ((P.nch * 63u + 3u) >> 2) * 16u : 0u;
-    s.rec = o; o += (P.windows_on && P.nuc_on) ? align16(P.max_windows * 16u) : 0u;
+    s.rec = o; o += (P.windows_on && P.nuc_on) ? align16((P.max_windows + P.halo_blocks) * 16u) : 0u;
     s.wacc = o; o += P.windows_on ? align16(P.max_windows * 8u * P.acc_copies) : 0u;
     s.stage = o; o += (P.stage_cap + 64u) * 4u;
     s.bytes = o;
@@ -513,61 +514,77 @@ void ts_scan_tiles(const TsScanParams P) {
                 if (d == db) acc = __builtin_amdgcn_sad_u8(pl[4u * db] & m1, 0u, acc);
                 return acc;
             };
-            const uint32_t nitems = T.nwin * 4u;
-
+            // letter f's count over the tile positions [us, ue), us < ue
+            auto range_count = [&](uint32_t f, uint32_t us, uint32_t ue) -> uint32_t {
+                const uint32_t xs = sh + us, xe = sh + ue;               // plane coords, xs < xe
+                const uint32_t hs = xs >> 5, he = xe >> 5;               // 32-position units of the planes
+                // the field's code (A0 C1 G3 T2) as the bits to flip so that "equal" reads 1/1
+                const uint32_t code = (f == 2u) ? 3u : (f == 3u ? 2u : f);
+                const u64 xl = (code & 1u) ? 0ull : 0x5555555555555555ull;
+                const u64 xh = (code & 2u) ? 0ull : 0x5555555555555555ull;
+                const uint32_t letter = (0x54474341u >> (8u * f)) & 0xFFu;
+                auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // 0 < hi - lo < 32
+                    if (has_invalid) {                                    // rare: re-read the bases themselves
+                        uint32_t n = 0;
+                        for (uint32_t pp = lo; pp < hi; ++pp)
+                            n += ((uint32_t)src[h * 32u + pp] & (P.fold_mask & 0xFFu)) == letter;
+                        return n;
+                    }
+                    const u64 m = (((1ull << (2u * (hi - lo))) - 1ull) << (2u * lo)) & 0x5555555555555555ull;
+                    const u32x2 c2 = *(const LDS u32x2 *)(codes + 2u * h);
+                    const u64 cd = (u64)c2.x | ((u64)c2.y << 32);
+                    return (uint32_t)__popcll((cd ^ xl) & ((cd >> 1) ^ xh) & m);
+                };
+                uint32_t val = 0;
+                if (hs == he) {
+                    val = partial(hs, xs & 31u, xe & 31u);
+                } else {
+                    uint32_t ha = hs;
+                    if (xs & 31u) { val += partial(hs, xs & 31u, 32u); ++ha; }
+                    if (xe & 31u) val += partial(he, 0u, xe & 31u);
+                    if (ha < he) val = plane_sum(f, ha, he, val);
+                }
+                return val;
+            };
+            // When w is a multiple of s a window is the sum of w / s step blocks, and overlapping windows share
+            // them: rec[] then holds one row per step block (the tile's windows + halo), otherwise one per window.
+            const bool by_blocks = P.block_sums != 0u;
             if (P.nuc_on && !(TS_ABL & 2)) {
-                for (uint32_t it = lane; it < nitems; it += 64u) {
+                const uint32_t rows = by_blocks ? T.nwin + P.halo_blocks : T.nwin;
+                const uint32_t len = by_blocks ? P.s : P.w;
+                for (uint32_t it = lane; it < rows * 4u; it += 64u) {
                     const uint32_t i = it >> 2, f = it & 3u;              // f: A C G T
                     const uint32_t us = i * P.s;
-                    const uint32_t ue = us + P.w < T.nrel ? us + P.w : T.nrel;
-                    const uint32_t xs = sh + us, xe = sh + ue;           // plane coords, xs < xe
-                    const uint32_t hs = xs >> 5, he = xe >> 5;           // 32-position units of the planes
-                    // the field's code (A0 C1 G3 T2) as the bits to flip so that "equal" reads 1/1
-                    const uint32_t code = (f == 2u) ? 3u : (f == 3u ? 2u : f);
-                    const u64 xl = (code & 1u) ? 0ull : 0x5555555555555555ull;
-                    const u64 xh = (code & 2u) ? 0ull : 0x5555555555555555ull;
-                    const uint32_t letter = (0x54474341u >> (8u * f)) & 0xFFu;
-                    auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // 0 < hi - lo < 32
-                        if (has_invalid) {                                // rare: re-read the bases themselves
-                            uint32_t n = 0;
-                            for (uint32_t pp = lo; pp < hi; ++pp)
-                                n += ((uint32_t)src[h * 32u + pp] & (P.fold_mask & 0xFFu)) == letter;
-                            return n;
-                        }
-                        const u64 m = (((1ull << (2u * (hi - lo))) - 1ull) << (2u * lo)) & 0x5555555555555555ull;
-                        const u32x2 c2 = *(const LDS u32x2 *)(codes + 2u * h);
-                        const u64 cd = (u64)c2.x | ((u64)c2.y << 32);
-                        return (uint32_t)__popcll((cd ^ xl) & ((cd >> 1) ^ xh) & m);
-                    };
-                    uint32_t val = 0;
-                    if (hs == he) {
-                        val = partial(hs, xs & 31u, xe & 31u);
-                    } else {
-                        uint32_t ha = hs;
-                        if (xs & 31u) { val += partial(hs, xs & 31u, 32u); ++ha; }
-                        if (xe & 31u) val += partial(he, 0u, xe & 31u);
-                        if (ha < he) val = plane_sum(f, ha, he, val);
-                    }
-                    rec[i * 4u + f] = val;
+                    const uint32_t ue = us + len < T.nrel ? us + len : T.nrel;
+                    rec[it] = us < ue ? range_count(f, us, ue) : 0u;     // a halo block may lie past the segment end
                 }
             }
             __builtin_amdgcn_wave_barrier();
 
-            // records leave as whole dwords in order: 8 x u32 per window, coalesced; the match fields
-            // count covered bases = k x matches
+            // records leave as whole 16-byte halves in order: {A, C, G, T} and {canonical, non-canonical, forward,
+            // reverse} covered bases (= k x matches) per window, coalesced
             if (!(TS_ABL & 8)) {
-                uint32_t *wout = tail_params()->windows_out + T.win_out * 8ull;
-                for (uint32_t it = lane; it < T.nwin * 8u; it += 64u) {
-                    const uint32_t i = it >> 3, f = it & 7u;
-                    uint32_t val = 0;
-                    if (f < 4u) {
-                        if (P.nuc_on) val = rec[i * 4u + f];
+                uint4 *wout = (uint4 *)(tail_params()->windows_out + T.win_out * 8ull);
+                for (uint32_t it = lane; it < T.nwin * 2u; it += 64u) {
+                    const uint32_t i = it >> 1;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (!(it & 1u)) {
+                        if (P.nuc_on) {
+                            const uint32_t nrow = by_blocks ? P.halo_blocks + 1u : 1u;
+                            for (uint32_t j = 0; j < nrow; ++j) {
+                                const LDS uint32_t *r4 = rec + (i + j) * 4u;
+                                v.x += r4[0]; v.y += r4[1]; v.z += r4[2]; v.w += r4[3];
+                            }
+                        }
                     } else {
-                        const lds_u16 *a16 = (const lds_u16 *)(wacc + i) + (f - 4u);
-                        for (uint32_t c = 0; c < P.acc_copies; ++c) val += a16[c * P.max_windows * 4u];
-                        val *= k;
+                        // the packed 4 x 16-bit counters of the copies add without carries between fields: a
+                        // field's total is at most the matches of one window (<= 32768)
+                        u64 a = 0;
+                        for (uint32_t c = 0; c < P.acc_copies; ++c) a += wacc[c * P.max_windows + i];
+                        v.x = ((uint32_t)a & 0xFFFFu) * k; v.y = ((uint32_t)a >> 16) * k;
+                        v.z = ((uint32_t)(a >> 32) & 0xFFFFu) * k; v.w = (uint32_t)(a >> 48) * k;
                     }
-                    wout[it] = val;
+                    wout[it] = v;
                 }
             }
         }

@@ -57,6 +57,7 @@ struct TsScanParams {
     uint32_t        straddle_fix;   // 1: w == s, drop matches that straddle a window end
     uint32_t        windows_on;     // 0 in tips-only mode
     uint32_t        nuc_on;         // nucleotide counts wanted (-g / -e)
+    uint32_t        block_sums;     // 1: w is a multiple of s, nucleotide counts are summed per step block
 };
 
 // parameters of getTerminalBlocks for the device-side predicate (kernels.hip: ts_terminal_predicate)
