@@ -75,14 +75,15 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v), 63);
 }
 
-// sixteen 2-bit codes (one per byte of t[0..3], values 0..3) -> one dword, base i at bits 2i..2i+1;
-// four independent v_dot4_u32_u8 (weights 1,4,16,64) and three v_lshl_or, no dependent dot chain
+// sixteen 2-bit codes, held doubled (2 * code = ASCII & 6) one per byte of t[0..3] -> one dword, base i at
+// bits 2i..2i+1; four independent v_dot4_u32_u8 (weights 1,4,16,64: twice the packed byte, 9 bits) and four
+// shift/or, no dependent dot chain
 __device__ __forceinline__ uint32_t pack16(const uint32_t t[4]) {
     const uint32_t b0 = __builtin_amdgcn_udot4(t[0], 0x40100401u, 0u, false);
     const uint32_t b1 = __builtin_amdgcn_udot4(t[1], 0x40100401u, 0u, false);
     const uint32_t b2 = __builtin_amdgcn_udot4(t[2], 0x40100401u, 0u, false);
     const uint32_t b3 = __builtin_amdgcn_udot4(t[3], 0x40100401u, 0u, false);
-    return (b0 | (b1 << 8)) | ((b2 | (b3 << 8)) << 16);
+    return ((b0 | (b1 << 8)) >> 1) | ((b2 | (b3 << 8)) << 15);
 }
 
 // spread the 16 bits of v to the even bit positions of a dword
@@ -304,18 +305,21 @@ void ts_scan_tiles(const TsScanParams P) {
             // cpos = c * TS_CHUNK, ch = c * 63.  A lane holds 32 consecutive bases (two packed dwords).
             // ASCII -> 2-bit codes (A0 C1 T2 G3) and a validity check, 4 bases per dword
             const uint32_t x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            uint32_t t[8], e[8], sad = 0;
+            // ASCII & 6 = twice the code (A 0, C 2, T 4, G 6) and at the same time the v_perm selector of the
+            // letter that code stands for (8-byte LUT, letters at the even bytes); any byte that is not that
+            // letter (up to case folding) leaves a bit in `bad`: three instructions per four bases
+            uint32_t t[8], e[8], bad = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                t[i] = (x[i] >> 1) & 0x07070707u;
-                e[i] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x47544341u, t[i]);
-                sad = __builtin_amdgcn_sad_u8(x[i] & P.fold_mask, e[i], sad);
+                t[i] = x[i] & 0x06060606u;
+                e[i] = __builtin_amdgcn_perm(0xFF47FF54u, 0xFF43FF41u, t[i]);
+                bad = __builtin_amdgcn_bitop3_b32(x[i], e[i], bad, 0xBE);      // bad | (x ^ e), one v_bitop3_b32
             }
             uint32_t wa = pack16(t), wb = pack16(t + 4);
 
             const uint32_t pos0 = cpos + lane * 32u;             // plane coord of this lane's first base
             uint32_t inv = 0;                                     // invalid bases among the lane's 32
-            const bool slow = __any(sad != 0) || (cpos + 2048u > xend);
+            const bool slow = __any((bad & P.fold_mask) != 0u) || (cpos + 2048u > xend);
             if (slow) {                                           // wave-uniform, rare
                 asm volatile("; non-ACGT bases or segment end in this chunk" ::: "memory");   // keeps the compiler from hoisting this block
                 uint32_t b4[8];
@@ -324,7 +328,6 @@ void ts_scan_tiles(const TsScanParams P) {
                     const uint32_t d = (x[i] & P.fold_mask) ^ e[i];
                     const uint32_t nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;
                     b4[i] = __builtin_amdgcn_udot4(nz, 0x08040201u, 0u, false);
-                    t[i] &= 0x03030303u;
                 }
                 inv = b4[0] | (b4[1] << 4) | (b4[2] << 8) | (b4[3] << 12) |
                       (b4[4] << 16) | (b4[5] << 20) | (b4[6] << 24) | (b4[7] << 28);
