@@ -6,7 +6,7 @@
 // no MFMA on purpose.
 //
 // Execution model: ONE WAVEFRONT PER TILE.  A tile is a run of consecutive windows of one
-// segment (~8 k bases plus the w-s halo); a wave scans its tile start to finish out of its own
+// segment (up to ~16 k bases incl. the w-s halo); a wave scans its tile start to finish out of its own
 // slice of LDS, and the waves of a workgroup share nothing but the read-only match table.
 // After the table is loaded there is no workgroup barrier, no global atomic and no wait on
 // another wave anywhere: tiles are dealt round-robin, and every wave appends its packed
@@ -16,7 +16,7 @@
 // Per tile:
 //   phase 1  2016 positions per iteration, 32 per lane: two coalesced 16 B/lane loads (the next
 //            chunk's in flight; a tile's first chunk is requested while the previous tile's window
-//            phase runs), SWAR ASCII -> 2-bit codes (v_perm / v_sad_u8 / v_dot4), ONE LDS read per
+//            phase runs), SWAR ASCII -> 2-bit codes (v_and / v_perm / v_bitop3, v_dot4 packs), ONE LDS read per
 //            TWO positions from the pair table ((k+1)-mer -> match bits of both positions; one byte
 //            per (k+1)-mer for k <= 6, so the (k+1)-mer is the address), nucleotide counts per 32
 //            positions into byte planes.
@@ -25,7 +25,7 @@
 //            table, the packed 32-bit record (staged in LDS, flushed in coalesced rows), and one
 //            packed ds_add_u64 per window that contains the match.
 //   phase 2  nucleotide fields of the windows: byte-plane sums (v_sad_u8) + partial ends from the
-//            codes; 8 x u32 per window leave coalesced.
+//            codes, per step block when w is a multiple of s; 8 x u32 per window leave coalesced.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
