@@ -317,7 +317,7 @@ def main():
                          "kernel": "ts_scan_tiles", "kernel_ms": round(kern_ms, 4), "launches_timed": int(info.kernel_launches),
                          "algorithmic_bytes": alg_bytes},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # the host-core baseline is timed at N = 1 only
             # Bounded sample of the same workload on the host cores through the oracle port, with the
             # reference's own parallel decomposition: one job per path (src/input.cpp:719-724), here
             # one contig slice per thread (ctypes releases the GIL inside the C call).
