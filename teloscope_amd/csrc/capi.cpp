@@ -413,10 +413,32 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
         c->why_not = "mixed-length pattern set";
     } else {
         std::vector<uint32_t> table;
-        if (!ts::build_match_table(c->patterns, kmin, table, c->table_rows, c->fc_bytes, c->fc_byte_table, c->pair_byte_table)) {
+        c->k = kmin;
+        bool built = false;
+        if (kmin == 7) {
+            // k = 7: the byte pair table (64 KB) makes every probe a single v_bfe, but leaves the wave slices
+            // less LDS: it pays when tiles of >= 5 chunks still fit 16 waves (measured on -w 2000 -s 1000:
+            // 5 chunks with bytes 0.836 ms, 7 chunks with the 2-bit table 0.863 ms, 4 chunks with bytes 0.892 ms);
+            // read filters scan in tips mode, whose tiles are small either way
+            built = ts::build_match_table(c->patterns, kmin, 7, table, c->table_rows, c->fc_bytes, c->fc_byte_table, c->pair_byte_table);
+            if (built) {
+                TsScanParams kp{};
+                uint32_t wpt = 0;
+                std::string why;
+                // (windows the tiled kernel does not take — see full_scan_supported — go to the general kernels)
+                const uint32_t s_ = c->params.step, w_ = c->params.window_size, ov = w_ - s_;
+                const bool win_tiled = !read_filter && kmin <= w_ && (ov == 0 || kmin <= std::min(s_, ov)) && w_ <= 32768u;
+                const bool tips = !win_tiled;
+                const bool fits = plan_geometry(c, tips, kp, wpt, why) && kp.waves_per_wg == 16u && (tips || kp.nch >= 5u);
+                if (!fits) built = false;
+            }
+        }
+        if (!built)
+            built = ts::build_match_table(c->patterns, kmin, 6, table, c->table_rows, c->fc_bytes, c->fc_byte_table, c->pair_byte_table);
+        if (!built) {
+            c->k = 0;
             c->why_not = "pattern length outside 3..8 or non-ACGT pattern";
         } else {
-            c->k = kmin;
             if (c->d_table.ensure(table.size() * 4) != hipSuccess ||
                 hipMemcpy(c->d_table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
                 g_create_error = "ts_create: cannot upload match table";
@@ -496,8 +518,9 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
         return nullptr;
     }
     if (getenv("TS_TIMING"))
-        fprintf(stderr, "ts_batch_create: %s scan, k=%u, %u waves per workgroup, %u chunks and %u windows per tile, LDS %d B "
+        fprintf(stderr, "ts_batch_create: %s scan, k=%u (%s pair table), %u waves per workgroup, %u chunks and %u windows per tile, LDS %d B "
                         "(match queue %u, record stage %u, %u accumulator copies)\n", b->tips ? "tips-only" : "window", ctx->k,
+                ctx->pair_byte_table ? "byte" : "2-bit",
                 b->kp.waves_per_wg, b->kp.nch, wpt, ts_k_lds_bytes(&b->kp), (unsigned)TS_LIST, b->kp.stage_cap, b->kp.acc_copies);
     const uint64_t tile_bases = (uint64_t)wpt * b->kp.s;
     const uint32_t tl = ctx->params.terminal_limit;

@@ -23,7 +23,7 @@ void canonical_orientation(const std::string &canonical_in, std::string &fwd, st
 std::vector<Pattern> expand_patterns(const std::string &raw_csv, int edit_distance,
                                      const std::string &canonical_fwd);
 int  base_code(char c);
-bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
+bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, uint32_t max_byte_k, std::vector<uint32_t> &table,
                        uint32_t &rows, uint32_t &fc_bytes, bool &fc_byte_table, bool &pair_byte_table);
 
 // blocks.cpp — block calling on the match stream (src/teloscope.cpp:29-383)

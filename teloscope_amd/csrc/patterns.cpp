@@ -1,4 +1,3 @@
-#include <cstdlib>
 // patterns.cpp — host-side pattern preparation of libteloscan (C++17).
 //
 // Product restatement of the reference's pattern expansion
@@ -174,7 +173,7 @@ int base_code(char c) {
 //    byte pair table's entries for k <= 6 (no separate table), else a flag table, looked up only at matched positions: one byte
 //    per k-mer for k <= 7 (cheapest lookup), 2 bits per k-mer at k = 8 (LDS capacity).
 // Layout in `table`: [rows dwords][flag table].
-bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector<uint32_t> &table,
+bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, uint32_t max_byte_k, std::vector<uint32_t> &table,
                        uint32_t &rows, uint32_t &fc_bytes, bool &fc_byte_table, bool &pair_byte_table) {
     if (k < 3 || k > 8) return false;
     const uint64_t nk = 1ull << (2 * k);
@@ -191,9 +190,10 @@ bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, std::vector
         fl[x] = static_cast<uint8_t>((p.is_canonical ? 1 : 0) | (p.is_forward ? 2 : 0));   // a match record's low bits
     }
     const uint64_t npairs = nk * 4;                                   // (k+1)-mers
-    // k <= 6: one BYTE per (k+1)-mer (16 KB at k = 6): a probe is then alignbit / and / ds_read_u8 /
-    // alignbit, no row-and-shift arithmetic; larger k keeps 2 bits per (k+1)-mer (LDS capacity)
-    pair_byte_table = k <= 6;
+    // k <= max_byte_k (6, or 7 when the caller has the LDS for it): one BYTE per (k+1)-mer (16 KB at k = 6,
+    // 64 KB at k = 7): a probe is then v_bfe / ds_read_u8 / alignbit, no row-and-shift arithmetic; larger k
+    // keeps 2 bits per (k+1)-mer
+    pair_byte_table = k <= max_byte_k;
     rows = static_cast<uint32_t>(pair_byte_table ? npairs / 4 : npairs / 16);
     fc_byte_table = k <= 7;
     // with a byte pair table the flags of the k-mer at p ride in bits 2..3 of its entries: no flag table
