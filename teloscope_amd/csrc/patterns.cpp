@@ -155,7 +155,7 @@ std::vector<Pattern> expand_patterns(const std::string &raw_csv, int edit_distan
     return out;
 }
 
-// 2-bit code used by the kernels' SWAR decode: (ascii >> 1) & 3  ->  A0 C1 T2 G3
+// 2-bit code used by the kernels' SWAR decode: (ascii & 6) >> 1  ->  A0 C1 T2 G3
 int base_code(char c) {
     switch (c) {
         case 'A': return 0; case 'C': return 1; case 'T': return 2; case 'G': return 3;
@@ -165,12 +165,13 @@ int base_code(char c) {
 
 // Match tables for uniform-length pattern sets (k-mer index x: base i at bits 2i..2i+1).
 //  * pair table: indexed by the (k+1)-mer y = bases p..p+k; entry = 2 bits {x(p) is a pattern,
-//    x(p+1) is a pattern}, one byte per entry for k <= 6, else 16 entries per dword (row = y >> 4).
+//    x(p+1) is a pattern}, one byte per entry for k <= max_byte_k (6, or 7 when the caller has 64 KB of
+//    LDS for it), else 16 entries per dword (row = y >> 4).
 //    Not replicated: the kernel is
 //    bound by VALU issue, and spreading rows over the LDS banks (8 copies) bought 0.4 % when it
 //    was measured, while the 28 KB it cost is what the per-wave count planes now live in;
 //  * flags {canonical, forward} (bit 0, bit 1: the low bits of a match record) per k-mer: bits 2..3 of the
-//    byte pair table's entries for k <= 6 (no separate table), else a flag table, looked up only at matched positions: one byte
+//    byte pair table's entries (no separate table then), else a flag table, looked up only at matched positions: one byte
 //    per k-mer for k <= 7 (cheapest lookup), 2 bits per k-mer at k = 8 (LDS capacity).
 // Layout in `table`: [rows dwords][flag table].
 bool build_match_table(const std::vector<Pattern> &pats, uint32_t k, uint32_t max_byte_k, std::vector<uint32_t> &table,
