@@ -757,7 +757,7 @@ int ts_batch_segment_summary(ts_batch *b, void *d_out, void *stream) {
 // (src/teloscope.cpp:642-657).  `matches` arrive with absolute positions and FORWARD/CANONICAL set.
 static int finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos,
                             const uint32_t *win_raw, uint64_t n_windows, std::vector<ts_match> &matches,
-                            ts_segment_out &o) {
+                            ts_segment_out &o, unsigned spare_threads) {
     const ts_params &P = c->params;
     std::memset(&o, 0, sizeof o);
     if (!tips && n_windows) {
@@ -765,7 +765,10 @@ static int finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs
         if (!o.windows) return c->fail(TS_ERR_ALLOC, "out of host memory");
         o.n_windows = n_windows;
         const bool nuc = P.out_gc || P.out_entropy;
-        for (uint64_t kwin = 0; kwin < n_windows; ++kwin) {
+        // windows are independent: a segment with very many of them (a multi-gigabase contig) is split over the
+        // host threads its job can spare
+        auto convert = [&](uint64_t k0, uint64_t k1) {
+        for (uint64_t kwin = k0; kwin < k1; ++kwin) {
             const uint32_t *r = &win_raw[kwin * 8];
             ts_window &w = o.windows[kwin];
             const uint64_t ws = kwin * P.step;
@@ -778,6 +781,17 @@ static int finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs
             w.non_canonical_covered = r[5];
             w.fwd_covered = r[6];
             w.rev_covered = r[7];
+        }
+        };
+        const unsigned nth = n_windows >= (1u << 18) ? std::min<unsigned>(spare_threads, (unsigned)(n_windows >> 16)) : 1u;
+        if (nth <= 1u) {
+            convert(0, n_windows);
+        } else {
+            std::vector<std::thread> pool;
+            const uint64_t share = (n_windows + nth - 1) / nth;
+            for (unsigned t = 0; t < nth; ++t)
+                pool.emplace_back(convert, std::min<uint64_t>(n_windows, t * share), std::min<uint64_t>(n_windows, (t + 1) * share));
+            for (std::thread &th : pool) th.join();
         }
     }
     const uint64_t nm = matches.size();
@@ -864,6 +878,8 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
     std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return b->segs[x].len > b->segs[y].len; });
     std::atomic<size_t> next{0};
     std::atomic<int> first_err{TS_OK};
+    const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned spare = std::max(1u, std::min(16u, hw_threads) / (unsigned)std::max<size_t>(1, std::min<size_t>(ns, 16)));
     auto worker = [&]() {
         std::vector<ts_match> matches;
         for (;;) {
@@ -896,7 +912,7 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
             if (rc == TS_OK)
                 rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos,
                                       sp.n_windows ? &wins[sp.win_base * 8] : nullptr, b->tips ? 0 : sp.n_windows,
-                                      matches, out[si]);
+                                      matches, out[si], spare);
             if (rc != TS_OK) { int expected = TS_OK; first_err.compare_exchange_strong(expected, rc); return; }
         }
     };
@@ -997,12 +1013,14 @@ int ts_batch_download_blocks(ts_batch *b, ts_segment_out *out) {
     }
     std::atomic<size_t> next{0};
     std::atomic<int> first_err{TS_OK};
+    const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned spare = std::max(1u, std::min(16u, hw_threads) / (unsigned)std::max<size_t>(1, std::min<size_t>(ns, 16)));
     auto worker = [&]() {
         std::vector<ts_match> none;
         for (size_t si; (si = next.fetch_add(1)) < ns && first_err.load() == TS_OK;) {
             const SegPlan &sp = b->segs[si];
             int rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos, sp.n_windows ? &wins[sp.win_base * 8] : nullptr,
-                                      b->tips ? 0 : sp.n_windows, none, out[si]);       // windows only
+                                      b->tips ? 0 : sp.n_windows, none, out[si], spare);       // windows only
             std::vector<ts_block> term, its;
             for (size_t bi = blk_begin[si]; rc == TS_OK && bi < blk_begin[si + 1]; ++bi) {
                 ts_block t{};
@@ -1138,7 +1156,7 @@ static int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::v
             }
         }
         if (rc != TS_OK) break;
-        rc = finalize_segment(c, tips, N, sg.abs_pos, wins.data(), nwin, matches, out[which[wi]]);
+        rc = finalize_segment(c, tips, N, sg.abs_pos, wins.data(), nwin, matches, out[which[wi]], 16u);   // (general path: one segment at a time)
     }
     d_seq.release(); d_mask.release(); d_win.release();
     return rc;
