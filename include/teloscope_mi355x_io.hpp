@@ -23,6 +23,7 @@
 #include <charconv>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <ostream>
 #include <sstream>
@@ -198,7 +199,7 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
     // The input is read in large blocks into one arena and parsed in place: a batch's sequences are
     // handed to the filter as pointers into the arena and a kept record is echoed as the byte range of
     // its four lines — no per-line copies.
-    // (a plain file is read with read(2) straight into the arena; gzip input and stdin go through zlib)
+    // (a plain file is read with pread(2) straight into the block; gzip input and stdin go through zlib)
     struct Source {
         gzFile gz = nullptr;
         int fd = -1;
@@ -219,9 +220,66 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
     }
     if (!src.gz && src.fd < 0) throw std::runtime_error("Stream not successful: " + inFile);
     if (src.gz) gzbuffer(src.gz, 1u << 20);
-    std::vector<char> arena(std::max<size_t>(bytesPerBatch, 64));           // grows if a record does not fit
-    size_t have = 0;                       // valid bytes in the arena
-    bool eof = false, first = true;
+    const bool seekable = !src.gz && ::lseek(src.fd, 0, SEEK_CUR) != static_cast<off_t>(-1);   // a FIFO is read in order
+    // Two blocks in turn: while one is parsed and filtered on the GPU, a reader thread fills the other (a plain
+    // file by up to eight concurrent pread(2) streams, gzip / stdin through zlib).  A block's data starts at `head`
+    // bytes into its buffer, so that the partial record left over from the previous block can be put in front
+    // of it without moving the block.
+    const size_t blockBytes = std::max<size_t>(bytesPerBatch, 64);
+    struct Block {
+        std::vector<char> buf;
+        size_t begin = 0, end = 0;         // valid bytes [begin, end)
+        bool last = false;                 // the input ended inside (or right before) this block
+    } blk[2];
+    size_t head = std::min<size_t>(blockBytes, 1u << 20);
+    uint64_t fileOff = 0;                  // next byte of a plain file
+    auto fill = [&](Block &b) {            // reads up to blockBytes bytes to b.buf[head ..)
+        if (b.buf.size() < head + blockBytes) b.buf.resize(head + blockBytes);
+        char *dst = b.buf.data() + head;
+        size_t got = 0;
+        b.last = false;
+        if (seekable) {
+            // slices of the block are read concurrently; a short slice means the file ends there
+            const unsigned nth = blockBytes >= (64u << 20) ? std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 2u)) : 1u;
+            const size_t share = (blockBytes + nth - 1) / nth;
+            std::vector<size_t> done(nth, 0);
+            std::vector<int> bad(nth, 0);
+            auto readSlice = [&](unsigned t) {
+                const size_t lo = std::min(blockBytes, t * share), hi = std::min(blockBytes, lo + share);
+                size_t n = 0;
+                while (lo + n < hi) {
+                    const ssize_t r = ::pread(src.fd, dst + lo + n, std::min<size_t>(hi - lo - n, 1u << 30), static_cast<off_t>(fileOff + lo + n));
+                    if (r < 0) { bad[t] = 1; break; }
+                    if (r == 0) break;
+                    n += static_cast<size_t>(r);
+                }
+                done[t] = n;
+            };
+            if (nth == 1) readSlice(0);
+            else {
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < nth; ++t) pool.emplace_back(readSlice, t);
+                for (std::thread &th : pool) th.join();
+            }
+            for (unsigned t = 0; t < nth; ++t) {
+                if (bad[t]) throw std::runtime_error("read error in FASTQ input");
+                const size_t lo = std::min(blockBytes, t * share), hi = std::min(blockBytes, lo + share);
+                got += done[t];
+                if (done[t] < hi - lo) { b.last = true; break; }      // end of file inside this slice
+            }
+            fileOff += got;
+        } else {
+            while (got < blockBytes) {
+                const long n = src.get(dst + got, blockBytes - got);
+                if (n < 0) throw std::runtime_error("read error in FASTQ input");
+                if (n == 0) { b.last = true; break; }
+                got += static_cast<size_t>(n);
+            }
+        }
+        b.begin = head;
+        b.end = head + got;
+    };
+    bool first = true;
     FastqSubsetResult res;
     uint64_t recordNumber = 0;
     auto fail = [&](const char *msg) { throw std::runtime_error("FASTQ record " + std::to_string(recordNumber + 1) + ": " + msg); };
@@ -231,72 +289,87 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
     std::vector<uint64_t> len;
     std::vector<uint8_t> pass;
     std::string text;
-    while (!eof || have > 0) {
-        while (!eof && have < arena.size()) {                  // fill
-            const long n = src.get(arena.data() + have, arena.size() - have);
-            if (n < 0) throw std::runtime_error("read error in FASTQ input");
-            if (n == 0) eof = true;
-            have += static_cast<size_t>(n);
-        }
+    int cur = 0;
+    fill(blk[0]);
+    for (;;) {
+        Block &B = blk[cur], &N = blk[cur ^ 1];
+        const bool eof = B.last;
+        // the next block is read while this one is parsed and filtered
+        std::exception_ptr readError;
+        std::thread reader;
+        if (!eof) reader = std::thread([&] { try { fill(N); } catch (...) { readError = std::current_exception(); } });
+        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reader};
         if (first) {
-            if (have == 0) throw std::runtime_error("FASTQ input is empty");
-            if (arena[0] != '@') throw std::runtime_error("FASTQ input must start with '@'");
+            if (B.end == B.begin) throw std::runtime_error("FASTQ input is empty");
+            if (B.buf[B.begin] != '@') throw std::runtime_error("FASTQ input must start with '@'");
             first = false;
         }
-        // parse whole records out of arena[0, have)
-        batch.clear();
-        const char *p = arena.data(), *end = arena.data() + have;
+        // parse whole records out of the block; several GPU batches if it holds more than readsPerBatch reads
+        const char *p = B.buf.data() + B.begin, *end = B.buf.data() + B.end;
         const char *consumed = p;
-        while (p < end && batch.size() < readsPerBatch) {
-            // a line = [p, nl); at end of input the last line may lack its '\n'
-            auto nextLine = [&](const char *from, const char *&lb, const char *&le, const char *&next) -> bool {
-                if (from >= end) return false;
-                const char *nl = static_cast<const char *>(std::memchr(from, '\n', static_cast<size_t>(end - from)));
-                if (!nl && !eof) return false;                 // incomplete line: wait for more input
-                lb = from; le = nl ? nl : end; next = nl ? nl + 1 : end;
-                return true;
-            };
-            const char *hb, *he, *nx;
-            if (!nextLine(p, hb, he, nx)) break;
-            if (detail::logicalLineLength(hb, he) == 0) { p = nx; consumed = p; continue; }   // blank line before a header
-            const char *sb, *se, *pb, *pe, *qb, *qe, *n2, *n3, *n4;
-            const bool l2 = nextLine(nx, sb, se, n2), l3 = l2 && nextLine(n2, pb, pe, n3), l4 = l3 && nextLine(n3, qb, qe, n4);
-            if (!l4) {
-                if (eof) fail("truncated FASTQ record");
-                break;                                          // the record continues in the next block
+        bool more = true;
+        while (more) {
+            batch.clear();
+            more = false;
+            while (p < end) {
+                if (batch.size() >= readsPerBatch) { more = true; break; }
+                // a line = [p, nl); at end of input the last line may lack its '\n'
+                auto nextLine = [&](const char *from, const char *&lb, const char *&le, const char *&next) -> bool {
+                    if (from >= end) return false;
+                    const char *nl = static_cast<const char *>(std::memchr(from, '\n', static_cast<size_t>(end - from)));
+                    if (!nl && !eof) return false;                 // incomplete line: wait for more input
+                    lb = from; le = nl ? nl : end; next = nl ? nl + 1 : end;
+                    return true;
+                };
+                const char *hb, *he, *nx;
+                if (!nextLine(p, hb, he, nx)) break;
+                if (detail::logicalLineLength(hb, he) == 0) { p = nx; consumed = p; continue; }   // blank line before a header
+                const char *sb, *se, *pb, *pe, *qb, *qe, *n2, *n3, *n4;
+                const bool l2 = nextLine(nx, sb, se, n2), l3 = l2 && nextLine(n2, pb, pe, n3), l4 = l3 && nextLine(n3, qb, qe, n4);
+                if (!l4) {
+                    if (eof) fail("truncated FASTQ record");
+                    break;                                          // the record continues in the next block
+                }
+                if (he == hb || *hb != '@') fail("expected header line starting with '@'");
+                if (pe == pb || *pb != '+') fail("expected separator line starting with '+'");
+                if (detail::logicalLineLength(sb, se) != detail::logicalLineLength(qb, qe)) fail("sequence and quality length differ");
+                ++recordNumber;
+                batch.push_back(Rec{hb, sb, qe, static_cast<uint64_t>(se - sb), true});
+                p = n4;
+                consumed = p;
             }
-            if (he == hb || *hb != '@') fail("expected header line starting with '@'");
-            if (pe == pb || *pb != '+') fail("expected separator line starting with '+'");
-            if (detail::logicalLineLength(sb, se) != detail::logicalLineLength(qb, qe)) fail("sequence and quality length differ");
-            ++recordNumber;
-            batch.push_back(Rec{hb, sb, qe, static_cast<uint64_t>(se - sb), true});
-            p = n4;
-            consumed = p;
-        }
-        if (batch.empty() && !eof && consumed == arena.data()) {
-            arena.resize(arena.size() * 2);                     // one record larger than the arena
-            continue;
-        }
-        if (!batch.empty()) {
-            ptr.resize(batch.size()); len.resize(batch.size()); pass.resize(batch.size());
-            for (size_t i = 0; i < batch.size(); ++i) { ptr[i] = batch[i].seq; len[i] = batch[i].seqLen; }
-            filter.matchesPointers(ptr.data(), len.data(), batch.size(), pass.data());
-            text.clear();
-            for (size_t i = 0; i < batch.size(); ++i) {
-                if (!pass[i]) continue;
-                text.append(batch[i].begin, batch[i].end);
-                text.push_back('\n');
-                ++res.kept;
+            if (!batch.empty()) {
+                ptr.resize(batch.size()); len.resize(batch.size()); pass.resize(batch.size());
+                for (size_t i = 0; i < batch.size(); ++i) { ptr[i] = batch[i].seq; len[i] = batch[i].seqLen; }
+                filter.matchesPointers(ptr.data(), len.data(), batch.size(), pass.data());
+                text.clear();
+                for (size_t i = 0; i < batch.size(); ++i) {
+                    if (!pass[i]) continue;
+                    text.append(batch[i].begin, batch[i].end);
+                    text.push_back('\n');
+                    ++res.kept;
+                }
+                res.total += batch.size();
+                out.write(text.data(), static_cast<std::streamsize>(text.size()));
+                if (!out.good()) throw std::runtime_error("failed while writing FASTQ subset");
             }
-            res.total += batch.size();
-            out.write(text.data(), static_cast<std::streamsize>(text.size()));
-            if (!out.good()) throw std::runtime_error("failed while writing FASTQ subset");
         }
-        // keep what was not consumed (a partial record) for the next round
+        if (eof) break;
+        reader.join();
+        if (readError) std::rethrow_exception(readError);
+        // what was not consumed (a partial record) goes in front of the next block's data
         const size_t left = static_cast<size_t>(end - consumed);
-        if (left && consumed != arena.data()) std::memmove(arena.data(), consumed, left);
-        have = left;
-        if (eof && batch.empty()) break;
+        if (left > N.begin) {                                   // more than the headroom (a record larger than a block)
+            const size_t have = N.end - N.begin;
+            std::vector<char> grown(left + std::max(blockBytes, have) + head);
+            std::memcpy(grown.data() + left, N.buf.data() + N.begin, have);
+            N.buf.swap(grown);
+            N.begin = left; N.end = left + have;
+            head = std::max(head, left);                        // later blocks leave that much room
+        }
+        if (left) std::memcpy(N.buf.data() + N.begin - left, consumed, left);
+        N.begin -= left;
+        cur ^= 1;
     }
     out.flush();
     return res;
