@@ -699,6 +699,7 @@ __device__ __forceinline__ bool pred_feed(PredState &st, const TsPredParams &Q, 
 // One orientation of the walk, one thread per read.  Records are visited in walk order (ascending for the
 // forward list, descending for the reverse list), eight at a time with the next eight already requested: a
 // thread's loads are scattered (every lane walks its own read), so the walk is bound by load latency.
+constexpr uint32_t kPredGroup = 8;       // records a thread requests at a time (and as many again in flight)
 template <bool FROM_START>
 __device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
                                           const uint32_t *matches, uint32_t t0, uint32_t t1, u64 base, u64 n,
@@ -715,18 +716,18 @@ __device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_o
             const uint32_t j = i < cnt ? i : cnt - 1u;
             return r[FROM_START ? j : cnt - 1u - j];
         };
-        uint32_t v[8], w[8];
+        uint32_t v[kPredGroup], w[kPredGroup];
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; ++j) v[j] = at(j);
-        for (uint32_t i = 0; i < cnt && go; i += 8u) {
+        for (uint32_t j = 0; j < kPredGroup; ++j) v[j] = at(j);
+        for (uint32_t i = 0; i < cnt && go; i += kPredGroup) {
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j) w[j] = at(i + 8u + j);
+            for (uint32_t j = 0; j < kPredGroup; ++j) w[j] = at(i + kPredGroup + j);
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j)
+            for (uint32_t j = 0; j < kPredGroup; ++j)
                 if (i + j < cnt && go && ((v[j] & 2u) != 0u) == FROM_START)
                     go = pred_feed(st, Q, FROM_START, rel0 + (v[j] >> 2), v[j] & 1u, n);
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j) v[j] = w[j];
+            for (uint32_t j = 0; j < kPredGroup; ++j) v[j] = w[j];
         }
     }
     if (st.in_block) pred_close_sub(st, Q, FROM_START);
@@ -763,6 +764,80 @@ __device__ bool pred_walk_wave(const TsTile *tiles, const u64 *tile_off, const u
         }
     }
     if (st.in_block) pred_close_sub(st, Q, FROM_START);
+    if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
+    return st.pass;
+}
+
+// Wave-wide inclusive prefix maximum (same DPP pattern as wave_scan_incl; lanes outside a shift read 0).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return v > o ? v : o;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+    v = dpp_max<0x111, 0xf>(v);
+    v = dpp_max<0x112, 0xf>(v);
+    v = dpp_max<0x114, 0xf>(v);
+    v = dpp_max<0x118, 0xf>(v);
+    v = dpp_max<0x142, 0xa>(v);
+    v = dpp_max<0x143, 0xc>(v);
+    return v;
+}
+
+// A long match list walked by a whole wave, 64 records per step IN PARALLEL (all arguments wave-uniform).
+// Valid when the whole segment is terminal zone (n <= terminal_limit: every read): then the walk never stops
+// early, and the two-phase state machine gives the same answer in either direction, so both lists are taken in
+// ascending order.  Per batch: the lanes hold the records; a prefix maximum gives every selected record its
+// predecessor, a ballot marks the records that start a new sub-block (gap > -k), and the scalar state machine
+// then steps once per SUB-BLOCK (counts by popcount of ballots) instead of once per record — a telomeric read
+// is one sub-block of thousands of matches.
+template <bool FWD_LIST>
+__device__ bool pred_scan_wave(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                               const uint32_t *matches, uint32_t t0, uint32_t t1, u64 base,
+                               const TsPredParams &Q, uint32_t lane) {
+    PredState st = {};
+    bool have_prev = false;
+    u64 prev = 0;                                            // last selected position so far
+    for (uint32_t t = t0; t < t1 && !st.pass; ++t) {
+        const uint32_t cnt = tile_stats[4u * t];
+        if (cnt == 0u) continue;
+        const u64 rel0 = tiles[t].in_off - base;
+        const uint32_t *r = matches + tile_off[t];
+        for (uint32_t b0 = 0; b0 < cnt; b0 += 64u) {
+            const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
+            const uint32_t rec = lane < nb ? r[b0 + lane] : 0u;
+            const bool sel = lane < nb && (((rec & 2u) != 0u) == FWD_LIST);
+            u64 rem = __ballot(sel);
+            if (rem == 0ull) continue;
+            const uint32_t p32 = rec >> 2;                   // tile-relative position (a batch lies in one tile)
+            // predecessor among the selected records of this batch: prefix maximum of (position + 1), one lane down
+            const uint32_t incl = wave_scan_max(sel ? p32 + 1u : 0u);
+            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xf, 0xf, false);   // wave_shr:1
+            const uint32_t first_lane = (uint32_t)__builtin_ctzll(rem);
+            const u64 first_pos = rel0 + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)first_lane);
+            const bool first_head = !have_prev || first_pos - prev > Q.max_match_dist;
+            const bool head = sel && (before == 0u ? first_head : p32 - (before - 1u) > Q.max_match_dist);
+            const u64 heads = __ballot(head), canon = __ballot(sel && (rec & 1u));
+            while (rem) {                                    // one step per run of chained records
+                const uint32_t l0 = (uint32_t)__builtin_ctzll(rem);
+                if ((heads >> l0) & 1ull) {
+                    if (st.in_block) { st.can_cov = st.canon * Q.k; pred_close_sub(st, Q, true); }
+                    st.bstart = rel0 + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)l0);
+                    st.counts = 0; st.canon = 0; st.in_block = true;
+                }
+                const u64 later = l0 < 63u ? heads & ~((2ull << l0) - 1ull) : 0ull;      // heads after l0
+                const u64 run = later ? rem & ((1ull << (uint32_t)__builtin_ctzll(later)) - 1ull) : rem;
+                st.counts += (uint32_t)__popcll(run);
+                st.canon += (uint32_t)__popcll(run & canon);
+                const uint32_t last_lane = 63u - (uint32_t)__builtin_clzll(run);
+                prev = rel0 + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)last_lane);
+                st.bend = prev + Q.k;
+                have_prev = true;
+                rem &= ~run;
+            }
+        }
+    }
+    if (st.in_block) { st.can_cov = st.canon * Q.k; pred_close_sub(st, Q, true); }
     if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
     return st.pass;
 }
@@ -807,10 +882,17 @@ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint3
         const u64 unfwd = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(nfwd >> 32), (int)l) << 32) |
                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nfwd, (int)l);
         bool uok = false;
-        if (unfwd >= 2)
-            uok = pred_walk_wave<true>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, un, Q, lane);
-        if (!uok && utotal - unfwd >= 2)
-            uok = pred_walk_wave<false>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, un, Q, lane);
+        if (un <= Q.terminal_limit) {                        // every read: the batch-parallel walk
+            if (unfwd >= 2)
+                uok = pred_scan_wave<true>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, Q, lane);
+            if (!uok && utotal - unfwd >= 2)
+                uok = pred_scan_wave<false>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, Q, lane);
+        } else {                                             // terminal zones of a long segment: record by record
+            if (unfwd >= 2)
+                uok = pred_walk_wave<true>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, un, Q, lane);
+            if (!uok && utotal - unfwd >= 2)
+                uok = pred_walk_wave<false>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, un, Q, lane);
+        }
         if (lane == l) ok = uok;
     }
     if (live) pass[si] = ok ? 1 : 0;

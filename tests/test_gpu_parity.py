@@ -544,3 +544,36 @@ def test_output_independent_of_tiling(cli, monkeypatch):
         for (s, ap, tips), g, e in zip(segs, got, want):
             assert_segment_equal(g, e, tips, ctx="tiling=%s cli=%r len=%d" % (tiling, cli, len(s)))
     assert ran >= 4, "too few tilings ran for %r" % cli
+
+
+@pytest.mark.parametrize("cli", ["-l 42", "-l 300 -k 30 -d 200 -y 0.7", "-x 0 -l 100 -k 12 -d 2000 -y 0.3",
+                                 "-c CCCTAAA -l 500 -k 60 -d 50 -y 0.5"])
+def test_read_filter_long_match_lists(cli):
+    """Reads whose match lists are far longer than the 384 records above which the predicate kernel walks a
+    read with the whole wave, 64 records per step in parallel: several tracts of both orientations, clean and
+    noisy, separated by gaps around -k (sub-block chaining) and -d (block merging), at either end or inside."""
+    opts = H.parse_cli("--fastq-subset " + cli)
+    rng = np.random.default_rng(len(cli) * 101 + 3)
+    k_gap = opts.max_match_dist
+    d_gap = opts.max_block_dist
+    reads = []
+    for i in range(240):
+        n = int(rng.integers(30000, 260000))
+        s = bytearray(seqgen.random_dna(rng, n).tobytes())
+        at = 0 if i % 3 == 0 else int(rng.integers(0, n // 2))
+        for _ in range(int(rng.integers(1, 7))):
+            unit = opts.canonical_fwd if rng.random() < 0.5 else opts.canonical_rev
+            ln = int(rng.integers(2, 1500)) * len(unit)
+            t = seqgen.mutate(rng, seqgen.repeat_array(unit, ln // len(unit)), float(rng.choice([0.0, 0.01, 0.08, 0.2]))).tobytes()
+            if at + len(t) >= n:
+                break
+            s[at:at + len(t)] = t
+            gap = int(rng.choice([0, 1, k_gap - 1, k_gap, k_gap + 1, k_gap + 7, d_gap - 1, d_gap, d_gap + 1, d_gap + 9, 3000]))
+            at += len(t) + max(0, gap)
+        if i % 4 == 1:                                          # the same at the far end
+            s = bytearray(bytes(s)[::-1])
+        reads.append(bytes(s))
+    got = ProductReadFilter(opts).filter(reads)
+    exp = OracleReadFilter(opts).filter(reads)
+    assert got == exp
+    assert 0 < sum(got) < len(got)
