@@ -642,7 +642,7 @@ __global__ void ts_segment_summary(const uint32_t *tile_stats, const uint32_t *s
 // ts_terminal_predicate: "does this segment have a terminal telomere block?" decided on the
 // device from the packed match stream — Teloscope::getTerminalBlocks (src/teloscope.cpp:29-176)
 // for both orientations, reduced to whether outBlocks would be non-empty.  One thread per
-// segment (one wave for a segment with a long match list) walks its tiles' records (ascending for the forward list, descending for the reverse
+// segment (one wave for a read with a long match list, see pred_scan_wave) walks its tiles' records (ascending for the forward list, descending for the reverse
 // list) through the same two-phase state machine: chain matches <= -k apart into sub-blocks,
 // keep those with >= minBlockCounts matches, a canonical match and canonical density >= -y,
 // merge kept sub-blocks <= -d apart, pass if a merged block is >= -l long.  This is what turns
@@ -728,39 +728,6 @@ __device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_o
                     go = pred_feed(st, Q, FROM_START, rel0 + (v[j] >> 2), v[j] & 1u, n);
 #pragma unroll
             for (uint32_t j = 0; j < kPredGroup; ++j) v[j] = w[j];
-        }
-    }
-    if (st.in_block) pred_close_sub(st, Q, FROM_START);
-    if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
-    return st.pass;
-}
-
-// The same walk run by a whole wave for ONE read (all arguments wave-uniform): the records come in 64 at a
-// time with one coalesced load and the state machine steps through them by v_readlane, so it is scalar
-// code with no memory round trip per match.  For reads with long match lists (a telomeric read has
-// thousands of chained matches), which would otherwise keep one lane busy long after its wave has finished.
-template <bool FROM_START>
-__device__ bool pred_walk_wave(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
-                               const uint32_t *matches, uint32_t t0, uint32_t t1, u64 base, u64 n,
-                               const TsPredParams &Q, uint32_t lane) {
-    PredState st = {};
-    bool go = true;
-    for (uint32_t tt = 0; tt < t1 - t0 && go && !st.pass; ++tt) {
-        const uint32_t t = FROM_START ? t0 + tt : t1 - 1u - tt;
-        const uint32_t cnt = tile_stats[4u * t];
-        if (cnt == 0u) continue;
-        const u64 rel0 = tiles[t].in_off - base;
-        const uint32_t *r = matches + tile_off[t];
-        for (uint32_t b0 = 0; b0 < cnt && go; b0 += 64u) {
-            const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
-            const uint32_t lo = FROM_START ? b0 : cnt - b0 - nb;          // first record of the batch
-            const uint32_t mine = lane < nb ? r[lo + lane] : 0u;
-            for (uint32_t j = 0; j < nb && go; ++j) {
-                const uint32_t jj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(FROM_START ? j : nb - 1u - j));
-                const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)jj);
-                if (((rec & 2u) != 0u) == FROM_START)
-                    go = pred_feed(st, Q, FROM_START, rel0 + (rec >> 2), rec & 1u, n);
-            }
         }
     }
     if (st.in_block) pred_close_sub(st, Q, FROM_START);
@@ -859,7 +826,8 @@ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint3
         n = seg_len[si]; base = seg_in_off[si];
         for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
     }
-    const bool is_long = live && total > kLongRead;
+    // (the whole-wave walk assumes that the whole segment is terminal zone: every read; otherwise one thread walks it)
+    const bool is_long = live && total > kLongRead && n <= Q.terminal_limit;
     bool ok = false;
     if (live && !is_long) {
         if (nfwd >= 2)                                      // forward list, from the segment start
@@ -873,8 +841,6 @@ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint3
         todo &= todo - 1ull;
         const uint32_t ut0 = (uint32_t)__builtin_amdgcn_readlane((int)t0, (int)l);
         const uint32_t ut1 = (uint32_t)__builtin_amdgcn_readlane((int)t1, (int)l);
-        const u64 un = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(n >> 32), (int)l) << 32) |
-                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)n, (int)l);
         const u64 ubase = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), (int)l) << 32) |
                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, (int)l);
         const u64 utotal = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(total >> 32), (int)l) << 32) |
@@ -882,17 +848,10 @@ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint3
         const u64 unfwd = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(nfwd >> 32), (int)l) << 32) |
                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nfwd, (int)l);
         bool uok = false;
-        if (un <= Q.terminal_limit) {                        // every read: the batch-parallel walk
-            if (unfwd >= 2)
-                uok = pred_scan_wave<true>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, Q, lane);
-            if (!uok && utotal - unfwd >= 2)
-                uok = pred_scan_wave<false>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, Q, lane);
-        } else {                                             // terminal zones of a long segment: record by record
-            if (unfwd >= 2)
-                uok = pred_walk_wave<true>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, un, Q, lane);
-            if (!uok && utotal - unfwd >= 2)
-                uok = pred_walk_wave<false>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, un, Q, lane);
-        }
+        if (unfwd >= 2)
+            uok = pred_scan_wave<true>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, Q, lane);
+        if (!uok && utotal - unfwd >= 2)
+            uok = pred_scan_wave<false>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, Q, lane);
         if (lane == l) ok = uok;
     }
     if (live) pass[si] = ok ? 1 : 0;
