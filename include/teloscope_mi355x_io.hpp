@@ -32,6 +32,8 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -289,30 +291,18 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
     std::vector<uint64_t> len;
     std::vector<uint8_t> pass;
     std::string text;
-    int cur = 0;
-    fill(blk[0]);
-    for (;;) {
-        Block &B = blk[cur], &N = blk[cur ^ 1];
-        const bool eof = B.last;
-        // the next block is read while this one is parsed and filtered
-        std::exception_ptr readError;
-        std::thread reader;
-        if (!eof) reader = std::thread([&] { try { fill(N); } catch (...) { readError = std::current_exception(); } });
-        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reader};
-        if (first) {
-            if (B.end == B.begin) throw std::runtime_error("FASTQ input is empty");
-            if (B.buf[B.begin] != '@') throw std::runtime_error("FASTQ input must start with '@'");
-            first = false;
-        }
-        // parse whole records out of the block; several GPU batches if it holds more than readsPerBatch reads
-        const char *p = B.buf.data() + B.begin, *end = B.buf.data() + B.end;
+    // Parses whole records out of [p, end) — several GPU batches if the range holds more than readsPerBatch reads or
+    // bytesPerBatch record bytes — filters them and echoes the kept ones; returns the end of the last whole record.
+    auto processRange = [&](const char *p, const char *const end, const bool eof) -> const char * {
         const char *consumed = p;
+        // parse whole records out of the block; several GPU batches if it holds more than readsPerBatch reads
         bool more = true;
         while (more) {
             batch.clear();
             more = false;
+            size_t batchBytes = 0;
             while (p < end) {
-                if (batch.size() >= readsPerBatch) { more = true; break; }
+                if (batch.size() >= readsPerBatch || batchBytes >= bytesPerBatch) { more = true; break; }
                 // a line = [p, nl); at end of input the last line may lack its '\n'
                 auto nextLine = [&](const char *from, const char *&lb, const char *&le, const char *&next) -> bool {
                     if (from >= end) return false;
@@ -335,6 +325,7 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
                 if (detail::logicalLineLength(sb, se) != detail::logicalLineLength(qb, qe)) fail("sequence and quality length differ");
                 ++recordNumber;
                 batch.push_back(Rec{hb, sb, qe, static_cast<uint64_t>(se - sb), true});
+                batchBytes += static_cast<size_t>(n4 - hb);
                 p = n4;
                 consumed = p;
             }
@@ -354,6 +345,43 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
                 if (!out.good()) throw std::runtime_error("failed while writing FASTQ subset");
             }
         }
+        return consumed;
+    };
+    if (seekable) {
+        // A regular file is mapped and parsed where the page cache holds it: the only copy of a sequence is the one
+        // into the pinned upload ring.
+        struct stat sb;
+        if (::fstat(src.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            const size_t size = static_cast<size_t>(sb.st_size);
+            void *map = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, src.fd, 0);
+            if (map != MAP_FAILED) {
+                (void)::madvise(map, size, MADV_SEQUENTIAL);
+                struct Unmap { void *p; size_t n; ~Unmap() { ::munmap(p, n); } } unmap{map, size};
+                const char *data = static_cast<const char *>(map);
+                if (data[0] != '@') throw std::runtime_error("FASTQ input must start with '@'");
+                (void)processRange(data, data + size, true);
+                out.flush();
+                return res;
+            }
+        }
+    }
+    int cur = 0;
+    fill(blk[0]);
+    for (;;) {
+        Block &B = blk[cur], &N = blk[cur ^ 1];
+        const bool eof = B.last;
+        // the next block is read while this one is parsed and filtered
+        std::exception_ptr readError;
+        std::thread reader;
+        if (!eof) reader = std::thread([&] { try { fill(N); } catch (...) { readError = std::current_exception(); } });
+        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reader};
+        if (first) {
+            if (B.end == B.begin) throw std::runtime_error("FASTQ input is empty");
+            if (B.buf[B.begin] != '@') throw std::runtime_error("FASTQ input must start with '@'");
+            first = false;
+        }
+        const char *const end = B.buf.data() + B.end;
+        const char *const consumed = processRange(B.buf.data() + B.begin, end, eof);
         if (eof) break;
         reader.join();
         if (readError) std::rethrow_exception(readError);

@@ -93,13 +93,19 @@ def test_cpp_mirror_replays_fastq_manifests(cli, path):
 @pytest.mark.parametrize("block", [64, 257, 1000, 4096, 70000])
 @pytest.mark.parametrize("name", ["fastq_subset_large.fq", "fastq_subset_crlf.fq", "fastq_subset_blanklines.fq"])
 def test_fastq_reader_block_boundaries(cli, name, block):
-    """fastqSubset parses records in place out of fixed-size blocks: records that straddle a block end
-    are carried over, a record larger than the block grows it.  Any block size must give the bytes the
-    one-block run gives (which the manifests pin against the reference's expected files)."""
+    """fastqSubset parses records in place.  A stream (stdin, gzip) comes in fixed-size blocks: records that
+    straddle a block end are carried over to the next block, a record larger than the block grows it; a regular
+    file is mapped and cut into GPU batches by record bytes.  Any block size, through either reader, must give
+    the bytes the one-block run gives (which the manifests pin against the reference's expected files)."""
     src = H.golden_path("testFiles/" + name)
     flags = ["--fastq-subset", "-x", "0", "-l", "18", "-y", "0.8", "-k", "10", "-d", "10"]
     ref = subprocess.run([cli] + flags + [src], capture_output=True, timeout=120)
-    got = subprocess.run([cli] + flags + ["--fastq-block", str(block), src], capture_output=True, timeout=120)
-    assert ref.returncode == 0 and got.returncode == 0, (ref.stderr, got.stderr)
-    assert got.stdout == ref.stdout and len(ref.stdout) > 0
-    assert got.stderr.splitlines()[-1] == ref.stderr.splitlines()[-1]        # kept N of M reads
+    assert ref.returncode == 0 and len(ref.stdout) > 0, ref.stderr
+    with open(src, "rb") as fh:
+        data = fh.read()
+    runs = [subprocess.run([cli] + flags + ["--fastq-block", str(block), src], capture_output=True, timeout=120),       # mapped file
+            subprocess.run([cli] + flags + ["--fastq-block", str(block)], input=data, capture_output=True, timeout=120)]  # stdin: block reader
+    for got in runs:
+        assert got.returncode == 0, got.stderr
+        assert got.stdout == ref.stdout
+        assert got.stderr.splitlines()[-1] == ref.stderr.splitlines()[-1]        # kept N of M reads
