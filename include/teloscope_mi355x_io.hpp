@@ -71,7 +71,79 @@ struct FastaRecord {
 // FASTA, plain or gzip-compressed (zlib reads both through the same calls; link with -lz).  The header
 // is the first word after '>', line ends and '\r' are dropped, as gfalibs does.  The FASTQ/BAM front
 // ends are rows f3/f4.
+namespace detail {
+// the body lines of one record, [p, end), joined into `seq` without their line ends
+inline void joinFastaLines(const char *p, const char *end, std::string &seq) {
+    seq.reserve(static_cast<size_t>(end - p));
+    while (p < end) {
+        const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        const char *stop = nl ? nl : end;
+        if (stop > p) seq.append(p, stop[-1] == '\r' ? stop - 1 : stop);
+        p = nl ? nl + 1 : end;
+    }
+    seq.shrink_to_fit();
+}
+inline std::string fastaHeaderWord(const char *b, const char *e) {
+    if (e > b && e[-1] == '\r') --e;
+    const char *w = b;
+    while (w < e && *w != ' ' && *w != '\t') ++w;
+    return std::string(b, w);
+}
+}  // namespace detail
+
 inline std::vector<FastaRecord> readFasta(const std::string &file) {
+    // A regular uncompressed file is mapped: one pass finds the records ('>' at a line start), then the lines of
+    // every record are joined by a pool of threads, largest record first.  Anything else goes through zlib below.
+    {
+        const int fd = ::open(file.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + file);
+        struct Close { int fd; ~Close() { ::close(fd); } } closer{fd};
+        struct stat sb;
+        unsigned char magic[2] = {0, 0};
+        const bool gz = ::pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (!gz && ::fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            const size_t size = static_cast<size_t>(sb.st_size);
+            void *map = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map != MAP_FAILED) {
+                struct Unmap { void *p; size_t n; ~Unmap() { ::munmap(p, n); } } unmap{map, size};
+                const char *data = static_cast<const char *>(map), *end = data + size;
+                struct Span { const char *head, *body, *stop; };
+                std::vector<Span> spans;
+                for (const char *p = data; p < end;) {
+                    const char *gt = static_cast<const char *>(std::memchr(p, '>', static_cast<size_t>(end - p)));
+                    if (!gt) break;
+                    p = gt + 1;
+                    if (gt != data && gt[-1] != '\n') continue;            // a '>' inside a line
+                    if (!spans.empty()) spans.back().stop = gt;
+                    const char *nl = static_cast<const char *>(std::memchr(gt, '\n', static_cast<size_t>(end - gt)));
+                    spans.push_back(Span{gt + 1, nl ? nl + 1 : end, end});
+                    if (!nl) break;
+                    p = nl + 1;
+                }
+                std::vector<FastaRecord> recs(spans.size());
+                std::vector<size_t> order(spans.size());
+                for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+                std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return spans[a].stop - spans[a].body > spans[b].stop - spans[b].body; });
+                std::atomic<size_t> next{0};
+                auto worker = [&]() {
+                    for (size_t k; (k = next.fetch_add(1)) < order.size();) {
+                        const Span &sp = spans[order[k]];
+                        const char *he = sp.body > sp.head && sp.body[-1] == '\n' ? sp.body - 1 : sp.body;
+                        recs[order[k]].header = detail::fastaHeaderWord(sp.head, he);
+                        detail::joinFastaLines(sp.body, sp.stop, recs[order[k]].sequence);
+                    }
+                };
+                const unsigned nthr = static_cast<unsigned>(std::min<size_t>(std::min<size_t>(16, spans.size()), std::max(1u, std::thread::hardware_concurrency())));
+                if (nthr <= 1) worker();
+                else {
+                    std::vector<std::thread> pool;
+                    for (unsigned t = 0; t < nthr; ++t) pool.emplace_back(worker);
+                    for (std::thread &th : pool) th.join();
+                }
+                return recs;
+            }
+        }
+    }
     gzFile in = gzopen(file.c_str(), "rb");
     if (!in) throw std::runtime_error("cannot open " + file);
     gzbuffer(in, 1u << 20);
@@ -126,15 +198,36 @@ struct PathComponents {
     std::vector<GapInfo> gaps;
 };
 
+namespace detail {
+// first position in [i, n) whose "is a gap letter" (N n X x) state equals `want`; n if none.  Eight bytes at
+// a time: with the case bit set, a gap letter is 'n' or 'x', and (v ^ pattern) has a zero byte exactly there.
+inline size_t scanGapState(const char *s, size_t i, size_t n, bool want) {
+    auto isGap = [](char c) { return c == 'N' || c == 'n' || c == 'X' || c == 'x'; };
+    const uint64_t ones = 0x0101010101010101ull, highs = 0x8080808080808080ull;
+    const uint64_t low7 = 0x7F7F7F7F7F7F7F7Full;
+    auto zeroBytes = [&](uint64_t v) { return ~(((v & low7) + low7) | v | low7); };            // 0x80 in every zero byte, exactly
+    while (i < n && (reinterpret_cast<uintptr_t>(s + i) & 7u)) { if (isGap(s[i]) == want) return i; ++i; }
+    for (; i + 8 <= n; i += 8) {
+        uint64_t v;
+        std::memcpy(&v, s + i, 8);
+        v |= 0x2020202020202020ull;
+        const uint64_t hit = zeroBytes(v ^ (ones * 'n')) | zeroBytes(v ^ (ones * 'x'));
+        // want = true: stop at a word that holds a gap letter; want = false: at one that holds anything else
+        if (want ? hit != 0 : hit != highs) break;
+    }
+    while (i < n && isGap(s[i]) != want) ++i;
+    return i;
+}
+}  // namespace detail
+
 inline PathComponents splitPath(const std::string &seq) {
     PathComponents pc;
-    auto isGap = [](char c) { return c == 'N' || c == 'n' || c == 'X' || c == 'x'; };
     const size_t n = seq.size();
+    const char *s = seq.data();
     size_t i = 0;
     while (i < n) {
-        const bool gap = isGap(seq[i]);
-        size_t j = i;
-        while (j < n && isGap(seq[j]) == gap) ++j;
+        const bool gap = s[i] == 'N' || s[i] == 'n' || s[i] == 'X' || s[i] == 'x';
+        const size_t j = detail::scanGapState(s, i + 1, n, !gap);   // the run ends where the state flips
         if (gap) pc.gaps.push_back(GapInfo{i, static_cast<uint32_t>(j - i)});
         else pc.segments.emplace_back(i, j - i);
         i = j;

@@ -1,0 +1,70 @@
+// Host-only self-test of the FASTA reader and the path splitter of include/teloscope_mi355x_io.hpp (no GPU
+// call is made): the mapped, multi-threaded reader of plain files must return what the zlib stream reader
+// returns for the same text gzip-compressed, and splitPath's 8-bytes-at-a-time scan must equal a per-character
+// walk.  Usage: io_selftest <scratch directory>
+#include "teloscope_mi355x_io.hpp"
+
+#include <cstdlib>
+#include <random>
+
+using namespace teloscope_mi355x;
+
+static void check(bool ok, const char *what) {
+    if (!ok) { fprintf(stderr, "io_selftest: FAILED: %s\n", what); std::exit(1); }
+}
+
+int main(int argc, char **argv) {
+    check(argc == 2, "usage: io_selftest <scratch directory>");
+    const std::string dir = argv[1];
+    std::mt19937_64 rng(11);
+    // ---- splitPath against a per-character walk
+    const char alpha[] = "ACGTNnXxYyOoacgtRWm";
+    for (int it = 0; it < 20000; ++it) {
+        const size_t n = rng() % 200;
+        const int mode = static_cast<int>(rng() % 3);
+        std::string s(n, 'A');
+        for (size_t i = 0; i < n; ++i)
+            s[i] = mode == 0 ? alpha[rng() % (sizeof(alpha) - 1)]
+                             : (rng() % (mode == 1 ? 7 : 40) == 0 ? "NnXx"[rng() % 4] : alpha[rng() % (sizeof(alpha) - 1)]);
+        if (mode == 2 && n > 30) for (size_t i = 5; i < 29; ++i) s[i] = "Nn"[i & 1];
+        const std::string view = (std::string(rng() % 8, 'A') + s).substr(0);     // varying alignment of the data
+        const PathComponents pc = splitPath(view);
+        auto isGap = [](char c) { return c == 'N' || c == 'n' || c == 'X' || c == 'x'; };
+        size_t i = 0, gi = 0, si = 0;
+        while (i < view.size()) {
+            const bool g = isGap(view[i]);
+            size_t j = i;
+            while (j < view.size() && isGap(view[j]) == g) ++j;
+            if (g) { check(gi < pc.gaps.size() && pc.gaps[gi].start == i && pc.gaps[gi].length == j - i, "gap run"); ++gi; }
+            else { check(si < pc.segments.size() && pc.segments[si].first == i && pc.segments[si].second == j - i, "segment run"); ++si; }
+            i = j;
+        }
+        check(gi == pc.gaps.size() && si == pc.segments.size(), "run counts");
+    }
+    // ---- readFasta: plain (mapped) vs gzip (stream) on awkward texts
+    for (int it = 0; it < 40; ++it) {
+        std::string text;
+        if (it % 5 == 1) text += "stray line before the first header\n";
+        const int nrec = 1 + static_cast<int>(rng() % 6);
+        const bool crlf = it % 3 == 1;
+        for (int r = 0; r < nrec; ++r) {
+            text += ">rec" + std::to_string(r) + (r % 2 ? " description > with a bracket" : "") + (crlf ? "\r\n" : "\n");
+            const size_t len = rng() % 5000, width = 1 + rng() % 90;
+            for (size_t i = 0; i < len; ++i) {
+                text += "ACGTNacgtn>"[rng() % (i % width == 0 ? 10 : 11)];      // '>' never at a line start
+                if ((i + 1) % width == 0) text += crlf ? "\r\n" : "\n";
+            }
+            if (rng() % 3) text += crlf ? "\r\n" : "\n";
+            if (rng() % 4 == 0) text += "\n";
+        }
+        if (it % 7 == 3 && !text.empty() && text.back() == '\n') text.pop_back();     // no newline at the end of the file
+        const std::string plain = dir + "/t.fa", packed = dir + "/t.fa.gz";
+        { std::ofstream f(plain, std::ios::binary); f << text; }
+        { gzFile g = gzopen(packed.c_str(), "wb"); check(g != nullptr, "gzopen"); gzwrite(g, text.data(), static_cast<unsigned>(text.size())); gzclose(g); }
+        const std::vector<FastaRecord> a = readFasta(plain), b = readFasta(packed);
+        check(a.size() == b.size(), "record count");
+        for (size_t i = 0; i < a.size(); ++i) check(a[i].header == b[i].header && a[i].sequence == b[i].sequence, "record content");
+    }
+    puts("io_selftest ok");
+    return 0;
+}
