@@ -243,13 +243,14 @@ struct TileView {
     }
 };
 
-#define TS_ITS_CACHE 1024                    // records of a tile kept in LDS (a tile holds ~230)
+#define TS_ITS_CACHE 1024                    // records of a tile kept in LDS (a tile of 13.5 kb holds ~400 at 3 % density)
 
 __global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t *seg_first_tile,
                                        const u64 *seg_in_off, const u64 *seg_abs, const u64 *bounds,
                                        uint32_t ntiles) {
     // one wave per tile, lanes over its records
     __shared__ uint32_t cache_all[4][TS_ITS_CACHE];
+    __shared__ uint16_t cand_all[4][TS_ITS_CACHE];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wave;
     if (tile >= ntiles) return;
@@ -269,7 +270,29 @@ __global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t
         V.cache = cache_all[wave];
         __builtin_amdgcn_wave_barrier();
     }
-    for (uint32_t i = lane; i < cnt; i += 64u) {
+    // Only canonical matches inside the interstitial range can lead a block, and they are ~2 % of the records:
+    // their indices are compacted first (ballot + rank) so that the chain walks below run on dense lanes
+    // instead of one or two lanes per 64 records.
+    uint32_t ncand = 0;
+    const bool compacted = cnt <= TS_ITS_CACHE;
+    if (compacted) {
+        for (uint32_t i0 = 0; i0 < cnt; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            bool cand = false;
+            if (i < cnt) {
+                const uint32_t r = V.cache[i];
+                const u64 p = V.tile_rel + (r >> 2);
+                cand = (r & 1u) && p >= fb && p < rb;
+            }
+            const u64 m = __ballot(cand);
+            if (cand) cand_all[wave][ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
+            ncand += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t nwork = compacted ? ncand : cnt;
+    for (uint32_t w = lane; w < nwork; w += 64u) {
+        const uint32_t i = compacted ? (uint32_t)cand_all[wave][w] : w;
         Cursor c{tile, i};
         const uint32_t r = V.rec(c);
         if (!(r & 1u)) continue;                           // only canonical matches can lead a block
