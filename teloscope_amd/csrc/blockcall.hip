@@ -5,16 +5,17 @@
 // scanSegment (:642-657).  With it only blocks (a few per segment) have to leave the GPU instead
 // of the whole match stream.
 //
-//   ts_terminal_blocks      one wave per segment: the reference's two-phase walk (chain matches
+//   ts_terminal_blocks      one wave per segment and direction: the reference's two-phase walk (chain matches
 //                           <= -k apart inside the terminal zone, keep dense canonical sub-blocks,
 //                           merge sub-blocks <= -d apart, keep >= -l) over the forward list from
-//                           the start and the reverse list from the end; emits the blocks and the
-//                           two boundaries that fence the interstitial search.
-//   ts_interstitial_blocks  one thread per match record, sparse: an interstitial block needs >= 4
-//                           canonical matches, and canonical matches are ~2 % of the stream, so
-//                           only the FIRST canonical match of a chain ("leader") walks its chain
-//                           (matches <= -k apart inside [fwdBoundary, revBoundary)) and evaluates
-//                           the reference's filters; every other thread returns after a few loads.
+//                           the start and the reverse list from the end, 64 records per step in parallel
+//                           (prefix maximum for the predecessor, ballot of chain heads, one scalar step per
+//                           chain); emits the blocks and the two boundaries that fence the interstitial search.
+//   ts_interstitial_blocks  one wave per tile, sparse: an interstitial block needs >= 4
+//                           canonical matches, and canonical matches are ~2 % of the stream, so the canonical
+//                           records of the tile are compacted first and only the FIRST canonical match of a
+//                           chain ("leader") walks its chain (matches <= -k apart inside [fwdBoundary,
+//                           revBoundary)) and evaluates the reference's filters.
 //
 // Records are addressed through the tile directory {tile_off, tile_stats}; tiles of one segment
 // are consecutive and position-ordered, so prev/next step across tile boundaries.
@@ -92,10 +93,29 @@ __device__ void emit_block(const TsBlockCallParams &Q, TsDevBlock &b, uint32_t s
     Q.blocks[slot] = b;
 }
 
-// One direction of getTerminalBlocks for one segment; returns the boundary.  Run by a whole wave: the
-// records are fetched 64 at a time (one coalesced load, lane i holds record i of the batch) and the
-// state machine steps through them with v_readlane, so every value it touches is wave-uniform and it
-// costs no memory round trip per match; lane 0 writes the blocks.
+// Wave-wide inclusive prefix maximum in 6 DPP steps (row_shr 1/2/4/8 inside each row of 16, then row_bcast:15
+// into rows 1,3 and row_bcast:31 into rows 2,3); lanes outside a shift read 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return v > o ? v : o;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+    v = dpp_max<0x111, 0xf>(v);
+    v = dpp_max<0x112, 0xf>(v);
+    v = dpp_max<0x114, 0xf>(v);
+    v = dpp_max<0x118, 0xf>(v);
+    v = dpp_max<0x142, 0xa>(v);
+    v = dpp_max<0x143, 0xc>(v);
+    return v;
+}
+
+// One direction of getTerminalBlocks for one segment; returns the boundary.  Run by a whole wave, 64 records
+// per step IN PARALLEL: lane i holds the i-th record of the batch in walk order (ascending for the forward list
+// from the start, descending for the reverse list from the end); a prefix maximum gives every record of the
+// wanted orientation its predecessor in the walk, a ballot marks those that open a new chain (gap > -k), and the
+// state machine — wave-uniform, scalar — steps once per CHAIN (counts are popcounts of ballots), not once per
+// record: a telomere is one chain of thousands of matches.  Lane 0 writes the blocks.
 __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, uint32_t seg, u64 n, u64 abs_pos,
                                   bool from_start, uint32_t &seq, uint32_t lane) {
     u64 boundary = from_start ? 0 : n;                     // segment-relative
@@ -147,28 +167,44 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
         const u64 tile_rel = V.tiles[t].in_off - V.base;
         for (uint32_t b0 = 0; b0 < cnt && !stop; b0 += 64u) {
             const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
-            const uint32_t lo = from_start ? b0 : cnt - b0 - nb;          // first record of the batch
-            const uint32_t mine = lane < nb ? V.matches[off + lo + lane] : 0u;
-            for (uint32_t j = 0; j < nb && !stop; ++j) {
-                const uint32_t jj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(from_start ? j : nb - 1u - j));
-                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)jj);
-                if ((((r >> 1) & 1u) != 0u) != from_start) continue;      // forward list from the start, reverse from the end
-                const u64 p = tile_rel + (r >> 2);
-                bool handled = false;
-                if (open) {
-                    const u64 gap = from_start ? p - ch.prev : ch.prev - p;
-                    if (gap <= Q.max_match_dist) {
-                        if (from_start) ch.end = p + Q.k; else ch.start = p;
-                        ch.add(p, r, Q.k);
-                        handled = true;
-                    } else close_sub();
-                }
-                if (!handled) {
+            const uint32_t idx = from_start ? b0 + lane : cnt - 1u - b0 - lane;        // walk order
+            const uint32_t rec = lane < nb ? V.matches[off + idx] : 0u;
+            const bool sel = lane < nb && (((rec >> 1) & 1u) != 0u) == from_start;      // forward list from the start, reverse from the end
+            u64 rem = __ballot(sel);
+            if (rem == 0ull) continue;
+            const uint32_t p32 = rec >> 2;                 // tile-relative (a batch lies in one tile), < 2^30
+            // predecessor in the walk among the wanted records of this batch: prefix maximum of position + 1
+            // (ascending walk) or of ~position (descending walk: the maximum of ~p is the minimum of p), one lane down
+            const uint32_t incl = wave_scan_max(sel ? (from_start ? p32 + 1u : ~p32) : 0u);
+            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xf, 0xf, false);   // wave_shr:1
+            const uint32_t gap_in = from_start ? p32 - (before - 1u) : ~before - p32;
+            const uint32_t first_lane = (uint32_t)__builtin_ctzll(rem);
+            const u64 first_pos = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)first_lane);
+            const bool first_head = !open || (from_start ? first_pos - ch.prev : ch.prev - first_pos) > Q.max_match_dist;
+            const bool head = sel && (before == 0u ? first_head : gap_in > Q.max_match_dist);
+            const u64 heads = __ballot(head), canon = __ballot(sel && (rec & 1u));
+            while (rem) {                                  // one step per chain (or per piece of a chain that spans batches)
+                const uint32_t l0 = (uint32_t)__builtin_ctzll(rem);
+                if ((heads >> l0) & 1ull) {
+                    if (open) close_sub();
+                    const u64 p0 = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)l0);
                     const bool in_zone = n <= Q.terminal_limit ? true
-                                       : (from_start ? p < Q.terminal_limit : p >= n - Q.terminal_limit);
+                                       : (from_start ? p0 < Q.terminal_limit : p0 >= n - Q.terminal_limit);
                     if (!in_zone) { stop = true; break; }
-                    ch.begin(p, r, Q.k); open = true;
+                    ch.start = p0; ch.end = p0 + Q.k; ch.prev = p0;
+                    ch.counts = ch.fwd = ch.canon = ch.cov = ch.fwd_cov = ch.can_cov = 0;
+                    open = true;
                 }
+                const u64 later = l0 < 63u ? heads & ~((2ull << l0) - 1ull) : 0ull;      // heads after l0
+                const u64 run = later ? rem & ((1ull << (uint32_t)__builtin_ctzll(later)) - 1ull) : rem;
+                const uint32_t nrun = (uint32_t)__popcll(run), ncan = (uint32_t)__popcll(run & canon);
+                const uint32_t nfwd = from_start ? nrun : 0u;                              // the list has one orientation
+                ch.counts += nrun; ch.fwd += nfwd; ch.canon += ncan;
+                ch.cov += nrun * Q.k; ch.fwd_cov += nfwd * Q.k; ch.can_cov += ncan * Q.k;
+                const uint32_t last_lane = 63u - (uint32_t)__builtin_clzll(run);
+                ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)last_lane);
+                if (from_start) ch.end = ch.prev + Q.k; else ch.start = ch.prev;
+                rem &= ~run;
             }
         }
     }
