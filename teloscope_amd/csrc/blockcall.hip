@@ -279,6 +279,7 @@ struct TileView {
     }
 };
 
+#define TS_ITS_CAND  256                     // canonical candidates of a tile kept in LDS (~2 % of its records)
 #define TS_ITS_CACHE 1024                    // records of a tile kept in LDS (a tile of 13.5 kb holds ~400 at 3 % density)
 
 __global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t *seg_first_tile,
@@ -286,7 +287,7 @@ __global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t
                                        uint32_t ntiles) {
     // one wave per tile, lanes over its records
     __shared__ uint32_t cache_all[4][TS_ITS_CACHE];
-    __shared__ uint16_t cand_all[4][TS_ITS_CACHE];
+    __shared__ uint16_t cand_all[4][TS_ITS_CAND];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wave;
     if (tile >= ntiles) return;
@@ -310,7 +311,7 @@ __global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t
     // their indices are compacted first (ballot + rank) so that the chain walks below run on dense lanes
     // instead of one or two lanes per 64 records.
     uint32_t ncand = 0;
-    const bool compacted = cnt <= TS_ITS_CACHE;
+    bool compacted = cnt <= TS_ITS_CACHE;
     if (compacted) {
         for (uint32_t i0 = 0; i0 < cnt; i0 += 64u) {
             const uint32_t i = i0 + lane;
@@ -321,10 +322,12 @@ __global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t
                 cand = (r & 1u) && p >= fb && p < rb;
             }
             const u64 m = __ballot(cand);
-            if (cand) cand_all[wave][ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
+            const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (cand && slot < TS_ITS_CAND) cand_all[wave][slot] = (uint16_t)i;
             ncand += (uint32_t)__popcll(m);
         }
         __builtin_amdgcn_wave_barrier();
+        if (ncand > TS_ITS_CAND) compacted = false;        // a tile full of canonical repeats: every record is tried
     }
     const uint32_t nwork = compacted ? ncand : cnt;
     for (uint32_t w = lane; w < nwork; w += 64u) {
