@@ -164,6 +164,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--verify", action="store_true", help="untimed full-size parity properties (torch)")
     ap.add_argument("--blocks", action="store_true", help="also time device block calling (untimed in value)")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time the host-buffer C-ABI calls on the same workload (PCIe-inclusive; never in value)")
     ap.add_argument("--flags", default=FLAGS, help="Teloscope flags of the workload (default: configs[1])")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -367,6 +369,36 @@ def main():
                 "terminal_blocks": int(sum(seg_out[i].n_terminal_blocks for i in range(n))),
                 "interstitial_blocks": int(sum(seg_out[i].n_interstitial_blocks for i in range(n)))}
             L.ts_free_segments(seg_out, n)
+        if args.e2e:
+            # PCIe-inclusive: ASCII in host memory in, results in host memory out, through the drop-in entry points
+            # (upload through the pinned ring, scan, block calling, D2H, host post-processing) — SURVEY 8d's second
+            # figure; reported beside `value`, never in it.
+            host = buf.cpu().numpy()
+            segs = (K.SegmentIn * n)()
+            base = host.ctypes.data
+            for i in range(n):
+                segs[i].seq = C.cast(C.c_void_p(base + offsets[i]), C.c_char_p)
+                segs[i].len = lens[i]
+                segs[i].abs_pos = 0
+                segs[i].tips_only = 0
+            e2e = {}
+            for name, with_matches in (("blocks_windows_counts", False), ("with_match_vectors", True)):
+                res = (K.SegmentOut * n)()
+                cnts = (K.SegmentCounts * n)()
+                best = None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    rc = (L.ts_scan_segments(tel._ctx.ptr, segs, n, res) if with_matches
+                          else L.ts_scan_segments_blocks(tel._ctx.ptr, segs, n, res, cnts))
+                    dt = time.perf_counter() - t0
+                    if rc != 0:
+                        raise RuntimeError(tel._ctx.error())
+                    nm = int(sum(res[i].n_matches for i in range(n))) if with_matches else int(sum(c.n_matches for c in cnts))
+                    L.ts_free_segments(res, n)
+                    best = dt if best is None else min(best, dt)
+                e2e[name] = {"seconds": round(best, 4), "gbases_per_s": round(total / best / 1e9, 3), "matches": nm}
+            out["pcie_inclusive"] = {"entry_points": "ts_scan_segments_blocks / ts_scan_segments (pageable host buffers in, "
+                                                     "host results out, best of 2)", **e2e}
         print(json.dumps(out))
     L.ts_batch_destroy(batch)
     if world > 1:
