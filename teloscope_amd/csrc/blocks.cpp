@@ -69,7 +69,11 @@ char its_label(uint32_t fwd_count, uint32_t counts) {       // computeBlockLabel
 }  // namespace
 
 uint64_t terminal_blocks(const BlockParams &bp, const ts_match *m, const uint32_t *idx, size_t n,
-                         std::vector<ts_block> &out, uint64_t seg_size, uint64_t abs_pos, bool from_start) {
+                         std::vector<ts_block> &out, uint64_t seg_size, uint64_t abs_pos, bool from_start,
+                         int only_forward) {
+    // only_forward >= 0 (and idx == nullptr): m[0..n) holds both orientations in position order and the walk
+    // takes the records whose forward flag equals it — the walk leaves the terminal zone after a few thousand
+    // records, so the per-orientation index lists of a whole segment need not be built
     uint64_t boundary = from_start ? abs_pos : abs_pos + seg_size;
     auto at = [&](size_t i) -> const ts_match & { return idx ? m[idx[i]] : m[i]; };
     auto in_zone = [&](uint64_t pos) {
@@ -89,6 +93,7 @@ uint64_t terminal_blocks(const BlockParams &bp, const ts_match *m, const uint32_
     };
     for (size_t step = 0; step < n; ++step) {
         const ts_match &cur = at(from_start ? step : n - 1 - step);
+        if (only_forward >= 0 && ((cur.flags & TS_MATCH_FORWARD) != 0) != (only_forward != 0)) continue;
         if (ch.open) {
             const uint64_t gap = from_start ? cur.position - ch.prev : ch.prev - cur.position;
             if (gap <= bp.max_match_dist) {

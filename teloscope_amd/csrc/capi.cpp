@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -755,8 +756,10 @@ int ts_batch_segment_summary(ts_batch *b, void *d_out, void *stream) {
 // Turns one segment's raw results into SegmentData: window records (float metrics evaluated on
 // the host from the integer counts, as the reference does), terminal flags, block calling
 // (src/teloscope.cpp:642-657).  `matches` arrive with absolute positions and FORWARD/CANONICAL set.
+// `matches` (malloc'd by the caller, position-ordered, terminal flags not yet set; may be null when nm == 0)
+// becomes the segment's match array.
 static int finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos,
-                            const uint32_t *win_raw, uint64_t n_windows, std::vector<ts_match> &matches,
+                            const uint32_t *win_raw, uint64_t n_windows, ts_match *matches, uint64_t nm,
                             ts_segment_out &o, unsigned spare_threads) {
     const ts_params &P = c->params;
     std::memset(&o, 0, sizeof o);
@@ -794,29 +797,26 @@ static int finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs
             for (std::thread &th : pool) th.join();
         }
     }
-    const uint64_t nm = matches.size();
-    if (nm > 0xFFFFFFFFull) return c->fail(TS_ERR_UNSUPPORTED, "more than 2^32 matches in one segment");
+    if (nm > 0xFFFFFFFFull) { std::free(matches); return c->fail(TS_ERR_UNSUPPORTED, "more than 2^32 matches in one segment"); }
+    o.matches = nm ? matches : nullptr;
+    o.n_matches = nm;
+    if (!nm) std::free(matches);
     const uint64_t term_end = seg_len > P.terminal_limit ? seg_len - P.terminal_limit : 0;
-    for (ts_match &m : matches) {                                   // isTerminal, src/teloscope.cpp:451-459
+    uint64_t nfwd = 0;
+    for (uint64_t i = 0; i < nm; ++i) {                             // isTerminal, src/teloscope.cpp:451-459
+        ts_match &m = o.matches[i];
         const uint64_t rel = m.position - abs_pos;
         if (rel <= P.terminal_limit || rel >= term_end) m.flags |= TS_MATCH_TERMINAL;
+        nfwd += (m.flags & TS_MATCH_FORWARD) ? 1u : 0u;
     }
-    if (nm) {
-        o.matches = (ts_match *)std::malloc(nm * sizeof(ts_match));
-        if (!o.matches) return c->fail(TS_ERR_ALLOC, "out of host memory");
-        std::memcpy(o.matches, matches.data(), nm * sizeof(ts_match));
-        o.n_matches = nm;
-    }
-    std::vector<uint32_t> fwd_idx, rev_idx;
-    fwd_idx.reserve(nm / 2 + 1); rev_idx.reserve(nm / 2 + 1);
-    for (uint64_t i = 0; i < nm; ++i)
-        ((o.matches[i].flags & TS_MATCH_FORWARD) ? fwd_idx : rev_idx).push_back((uint32_t)i);
+    // the two walks take their orientation's records out of the one position-ordered array (they leave the
+    // terminal zone after a few thousand records: no per-orientation index lists of the whole segment)
     std::vector<ts_block> term, its;
     uint64_t fwd_boundary = abs_pos, rev_boundary = abs_pos + seg_len;
-    if (fwd_idx.size() >= 2)
-        fwd_boundary = ts::terminal_blocks(c->bp, o.matches, fwd_idx.data(), fwd_idx.size(), term, seg_len, abs_pos, true);
-    if (rev_idx.size() >= 2)
-        rev_boundary = ts::terminal_blocks(c->bp, o.matches, rev_idx.data(), rev_idx.size(), term, seg_len, abs_pos, false);
+    if (nfwd >= 2)
+        fwd_boundary = ts::terminal_blocks(c->bp, o.matches, nullptr, nm, term, seg_len, abs_pos, true, 1);
+    if (nm - nfwd >= 2)
+        rev_boundary = ts::terminal_blocks(c->bp, o.matches, nullptr, nm, term, seg_len, abs_pos, false, 0);
     if (!tips && fwd_boundary < rev_boundary && nm >= 2)
         ts::interstitial_blocks(c->bp, o.matches, nm, its, fwd_boundary, rev_boundary);
     auto copy_blocks = [&](const std::vector<ts_block> &v, ts_block *&dst, uint64_t &n) -> bool {
@@ -842,12 +842,14 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
     if (!b->synced) { int rc = ts_batch_sync(b); if (rc != TS_OK) return rc; }
     const size_t nt = b->tiles.size(), ns = b->segs.size();
 
-    std::vector<uint32_t> wins(b->n_windows * 8);
-    std::vector<uint32_t> recs(b->n_matches);
+    // (plain arrays: a vector would zero-fill hundreds of MB that the copies below overwrite)
+    const std::unique_ptr<uint32_t[]> wins_buf(new uint32_t[b->n_windows * 8 + 1]), recs_buf(new uint32_t[b->n_matches + 1]);
+    uint32_t *const wins = wins_buf.get(), *const recs = recs_buf.get();
+    const uint64_t nrecs = b->n_matches;
     // tile directory: records of tile t are recs[tile_off[t] .. +tile_stats[4t]), in position order
     std::vector<unsigned long long> tile_off(nt + 1);
     std::vector<uint32_t> tile_stats(4 * (nt + 1));
-    if (b->n_windows) HIP_TRY(c, hipMemcpy(wins.data(), b->d_windows.p, b->n_windows * 32, hipMemcpyDeviceToHost));
+    if (b->n_windows) HIP_TRY(c, hipMemcpy(wins, b->d_windows.p, b->n_windows * 32, hipMemcpyDeviceToHost));
     // pack the per-wave regions into one dense stream on the device, then one D2H copy
     std::vector<unsigned long long> dense_base(b->total_waves + 1, 0);
     for (uint32_t w = 0; w < b->total_waves; ++w) dense_base[w + 1] = dense_base[w] + b->wave_fill[w];
@@ -859,7 +861,7 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
                                     (const unsigned long long *)b->d_dense_base.p, b->region_cap,
                                     b->total_waves, (uint32_t *)b->d_dense.p, nullptr);
         if (e != 0) return c->fail(TS_ERR_HIP, "compaction kernel launch failed");
-        HIP_TRY(c, hipMemcpy(recs.data(), b->d_dense.p, b->n_matches * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(recs, b->d_dense.p, b->n_matches * 4, hipMemcpyDeviceToHost));
     }
     if (nt) HIP_TRY(c, hipMemcpy(tile_off.data(), b->d_tile_off.p, nt * 8, hipMemcpyDeviceToHost));
     if (nt) HIP_TRY(c, hipMemcpy(tile_stats.data(), b->d_stats.p, nt * 16, hipMemcpyDeviceToHost));
@@ -881,7 +883,6 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
     const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
     const unsigned spare = std::max(1u, std::min(16u, hw_threads) / (unsigned)std::max<size_t>(1, std::min<size_t>(ns, 16)));
     auto worker = [&]() {
-        std::vector<ts_match> matches;
         for (;;) {
             const size_t oi = next.fetch_add(1);
             if (oi >= ns || first_err.load() != TS_OK) return;
@@ -890,29 +891,32 @@ int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out 
             // matches: tile-relative packed records -> absolute MatchInfo, tiles in position order
             uint64_t nm = 0;
             for (uint32_t t = 0; t < sp.n_tiles; ++t) nm += tile_stats[4ull * (sp.first_tile + t)];
-            matches.clear();
-            matches.reserve(nm);
+            ts_match *arr = nm ? (ts_match *)std::malloc(nm * sizeof(ts_match)) : nullptr;
+            if (nm && !arr) { int expected = TS_OK; first_err.compare_exchange_strong(expected, c->fail(TS_ERR_ALLOC, "out of host memory")); return; }
+            uint64_t at = 0;
             int rc = TS_OK;
             for (const Region &rg : sp.regions) {
                 for (uint32_t t = 0; t < rg.n_tiles && rc == TS_OK; ++t) {
                     const uint32_t ti = rg.first_tile + t;
                     const uint64_t tile_rel = rg.start + (uint64_t)t * rg.tile_bases;   // segment-relative
                     const uint64_t r0 = tile_off[ti], r1 = r0 + tile_stats[4ull * ti];
-                    if (r1 > recs.size()) { rc = c->fail(TS_ERR_STATE, "tile directory out of range"); break; }
+                    if (r1 > nrecs || at + (r1 - r0) > nm) { rc = c->fail(TS_ERR_STATE, "tile directory out of range"); break; }
+                    const uint64_t pos0 = sp.abs_pos + tile_rel;
                     for (uint64_t ri = r0; ri < r1; ++ri) {
                         const uint32_t rec = recs[ri];
-                        ts_match m{};
-                        m.position = sp.abs_pos + tile_rel + (rec >> 2);
+                        ts_match &m = arr[at++];
+                        std::memset(&m, 0, sizeof m);
+                        m.position = pos0 + (rec >> 2);
                         m.match_size = klen;
                         m.flags = (uint8_t)(((rec & 2u) ? TS_MATCH_FORWARD : 0u) | ((rec & 1u) ? TS_MATCH_CANONICAL : 0u));
-                        matches.push_back(m);
                     }
                 }
             }
+            if (rc != TS_OK) std::free(arr);
             if (rc == TS_OK)
                 rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos,
                                       sp.n_windows ? &wins[sp.win_base * 8] : nullptr, b->tips ? 0 : sp.n_windows,
-                                      matches, out[si], spare);
+                                      arr, nm, out[si], spare);
             if (rc != TS_OK) { int expected = TS_OK; first_err.compare_exchange_strong(expected, rc); return; }
         }
     };
@@ -995,11 +999,10 @@ int ts_batch_download_blocks(ts_batch *b, ts_segment_out *out) {
         if (kx) return x.start < y.start;
         return x.kind != y.kind ? x.kind < y.kind : x.seq < y.seq;
     });
-    std::vector<uint32_t> wins;
-    if (!b->tips && b->n_windows) {
-        wins.resize(b->n_windows * 8);
-        HIP_TRY(c, hipMemcpy(wins.data(), b->d_windows.p, b->n_windows * 32, hipMemcpyDeviceToHost));
-    }
+    const std::unique_ptr<uint32_t[]> wins_buf(new uint32_t[(b->tips ? 0 : b->n_windows * 8) + 1]);   // (not zero-filled)
+    uint32_t *const wins = wins_buf.get();
+    if (!b->tips && b->n_windows)
+        HIP_TRY(c, hipMemcpy(wins, b->d_windows.p, b->n_windows * 32, hipMemcpyDeviceToHost));
     // per segment: window records (float metrics on the host) + its slice of the sorted block list;
     // independent between segments, so they are finalised on up to 16 host threads
     std::vector<size_t> blk_begin(ns + 1, blocks.size());
@@ -1016,11 +1019,10 @@ int ts_batch_download_blocks(ts_batch *b, ts_segment_out *out) {
     const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
     const unsigned spare = std::max(1u, std::min(16u, hw_threads) / (unsigned)std::max<size_t>(1, std::min<size_t>(ns, 16)));
     auto worker = [&]() {
-        std::vector<ts_match> none;
         for (size_t si; (si = next.fetch_add(1)) < ns && first_err.load() == TS_OK;) {
             const SegPlan &sp = b->segs[si];
             int rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos, sp.n_windows ? &wins[sp.win_base * 8] : nullptr,
-                                      b->tips ? 0 : sp.n_windows, none, out[si], spare);       // windows only
+                                      b->tips ? 0 : sp.n_windows, nullptr, 0, out[si], spare);       // windows only
             std::vector<ts_block> term, its;
             for (size_t bi = blk_begin[si]; rc == TS_OK && bi < blk_begin[si + 1]; ++bi) {
                 ts_block t{};
@@ -1156,7 +1158,10 @@ static int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::v
             }
         }
         if (rc != TS_OK) break;
-        rc = finalize_segment(c, tips, N, sg.abs_pos, wins.data(), nwin, matches, out[which[wi]], 16u);   // (general path: one segment at a time)
+        ts_match *arr = matches.empty() ? nullptr : (ts_match *)std::malloc(matches.size() * sizeof(ts_match));
+        if (!matches.empty() && !arr) { rc = c->fail(TS_ERR_ALLOC, "out of host memory"); break; }
+        if (arr) std::memcpy(arr, matches.data(), matches.size() * sizeof(ts_match));
+        rc = finalize_segment(c, tips, N, sg.abs_pos, wins.data(), nwin, arr, matches.size(), out[which[wi]], 16u);   // (general path: one segment at a time)
     }
     d_seq.release(); d_mask.release(); d_win.release();
     return rc;

@@ -37,7 +37,8 @@ struct BlockParams {
 // Matches are passed as parallel views over ts_match records; `idx` selects a subsequence
 // (fwdMatches / revMatches) without copying, nullptr = all.
 uint64_t terminal_blocks(const BlockParams &bp, const ts_match *m, const uint32_t *idx, size_t n,
-                         std::vector<ts_block> &out, uint64_t seg_size, uint64_t abs_pos, bool from_start);
+                         std::vector<ts_block> &out, uint64_t seg_size, uint64_t abs_pos, bool from_start,
+                         int only_forward = -1);
 void interstitial_blocks(const BlockParams &bp, const ts_match *m, size_t n, std::vector<ts_block> &out,
                          uint64_t fwd_boundary, uint64_t rev_boundary);
 int  label_terminal_blocks(ts_block *blocks, size_t n, uint16_t gaps, uint64_t path_size,
