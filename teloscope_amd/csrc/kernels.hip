@@ -301,7 +301,7 @@ void ts_scan_tiles(const TsScanParams P) {
             __builtin_amdgcn_wave_barrier();                  // the queue is appended to next
         };
 
-        auto resolve_chunk = [&](const uint32_t cpos, const uint32_t ch, const uint4 v0, const uint4 v1) {
+        auto scan_chunk = [&](const uint32_t cpos, const uint32_t ch, const uint4 v0, const uint4 v1) -> uint32_t {
             // cpos = c * TS_CHUNK, ch = c * 63.  A lane holds 32 consecutive bases (two packed dwords).
             // ASCII -> 2-bit codes (A0 C1 T2 G3) and a validity check, 4 bases per dword
             const uint32_t x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -423,37 +423,68 @@ void ts_scan_tiles(const TsScanParams P) {
             M32 = 0;
 #endif
             if (lane == 63u) M32 = 0;                             // lane 63 only looks ahead for lane 62
-            if (__any(M32 != 0u)) {
-                const uint32_t nm0 = __popc(M32);
-                const uint32_t incl0 = wave_scan_incl(nm0);
-                const uint32_t total0 = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
-                const uint32_t lbase = cpos + lane * 32u;         // plane coordinates, < 65536 (nch <= 32)
-                // A chunk with more matches than the queue holds (dense repeats) is appended one lane group
-                // at a time — a group's matches always fit, and groups are in position order.
-                constexpr uint32_t kGroup = TS_LIST / 32u;
-                const bool dense = TS_LIST < TS_CHUNK && total0 > TS_LIST;
-                const uint32_t ngroups = dense ? 64u / kGroup : 1u;
-                for (uint32_t gi = 0; gi < ngroups; ++gi) {
-                    uint32_t m = M32, nm = nm0, incl = incl0, total = total0;
-                    if (dense) {
-                        m = (lane / kGroup == gi) ? M32 : 0u;
-                        nm = __popc(m);
-                        incl = wave_scan_incl(nm);
-                        total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    }
-                    // the queue keeps whatever is short of a full pass; it is emptied first if these
-                    // matches would not fit behind it
-                    drain_queue(qcount + total > TS_LIST ? 1u : 64u);
-                    uint32_t o = qhead + 2u * (qcount + incl - nm);               // byte offset of the lane's first slot
-                    while (m) {
-                        *lds_at16((o & qmask) | qbase) = (uint16_t)(lbase + (uint32_t)__builtin_ctz(m));
-                        o += 2u;
-                        m &= m - 1u;
-                    }
-                    qcount += total;
-                    __builtin_amdgcn_wave_barrier();
+            return M32;
+        };
+        // One chunk's matches onto the queue (nm = the lane's count, incl = its inclusive prefix sum, total).
+        // A chunk with more matches than the queue holds (dense repeats) is appended one lane group at a time —
+        // a group's matches always fit, and groups are in position order.
+        auto append_chunk = [&](const uint32_t M32, const uint32_t cpos, const uint32_t nm0, const uint32_t incl0, const uint32_t total0) {
+            const uint32_t lbase = cpos + lane * 32u;             // plane coordinates, < 65536 (nch <= 32)
+            constexpr uint32_t kGroup = TS_LIST / 32u;
+            const bool dense = TS_LIST < TS_CHUNK && total0 > TS_LIST;
+            const uint32_t ngroups = dense ? 64u / kGroup : 1u;
+            for (uint32_t gi = 0; gi < ngroups; ++gi) {
+                uint32_t m = M32, nm = nm0, incl = incl0, total = total0;
+                if (dense) {
+                    m = (lane / kGroup == gi) ? M32 : 0u;
+                    nm = __popc(m);
+                    incl = wave_scan_incl(nm);
+                    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 }
+                // the queue keeps whatever is short of a full pass; it is emptied first if these
+                // matches would not fit behind it
+                drain_queue(qcount + total > TS_LIST ? 1u : 64u);
+                uint32_t o = qhead + 2u * (qcount + incl - nm);                   // byte offset of the lane's first slot
+                while (m) {
+                    *lds_at16((o & qmask) | qbase) = (uint16_t)(lbase + (uint32_t)__builtin_ctz(m));
+                    o += 2u;
+                    m &= m - 1u;
+                }
+                qcount += total;
+                __builtin_amdgcn_wave_barrier();
             }
+        };
+        // The matches of TWO consecutive chunks go onto the queue behind one prefix sum (both per-lane counts
+        // ride in one register), one drain decision and one pass over the queue: A's matches first, then B's.
+        auto append_pair = [&](const uint32_t mA, const uint32_t cposA, const uint32_t mB, const uint32_t cposB) {
+            if (!__any((mA | mB) != 0u)) return;
+            const uint32_t nA = __popc(mA), nB = __popc(mB);
+            const uint32_t incl = wave_scan_incl(nA | (nB << 16));
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t totA = tot & 0xFFFFu, totB = tot >> 16;
+            if (totA + totB + 63u > TS_LIST) {                    // rare: does not fit behind what a pass may leave
+                asm volatile("; dense pair of chunks" ::: "memory");
+                if (totA) append_chunk(mA, cposA, nA, incl & 0xFFFFu, totA);
+                if (totB) append_chunk(mB, cposB, nB, incl >> 16, totB);
+                return;
+            }
+            drain_queue(64u);                                     // leaves fewer than 64 queued
+            uint32_t o = qhead + 2u * (qcount + (incl & 0xFFFFu) - nA), m = mA;
+            uint32_t lbase = cposA + lane * 32u;
+            while (m) {
+                *lds_at16((o & qmask) | qbase) = (uint16_t)(lbase + (uint32_t)__builtin_ctz(m));
+                o += 2u;
+                m &= m - 1u;
+            }
+            o = qhead + 2u * (qcount + totA + (incl >> 16) - nB); m = mB;
+            lbase = cposB + lane * 32u;
+            while (m) {
+                *lds_at16((o & qmask) | qbase) = (uint16_t)(lbase + (uint32_t)__builtin_ctz(m));
+                o += 2u;
+                m &= m - 1u;
+            }
+            qcount += totA + totB;
+            __builtin_amdgcn_wave_barrier();
         };
         {
             // Chunk c+1's two 16 B/lane loads are in flight while chunk c is resolved; the loop is
@@ -470,13 +501,17 @@ void ts_scan_tiles(const TsScanParams P) {
                 b0 = *(const uint4 *)(lsrc + p1);
                 b1 = *(const uint4 *)(lsrc + p1 + 16);
                 __builtin_amdgcn_sched_barrier(0);         // the loads are issued before chunk c is touched
-                resolve_chunk(cpos, ch, a0, a1);
-                if (c + 1u >= nch) break;
-                const uint32_t p2 = cpos + 2u * TS_CHUNK < last_pos ? cpos + 2u * TS_CHUNK : last_pos;
-                a0 = *(const uint4 *)(lsrc + p2);
-                a1 = *(const uint4 *)(lsrc + p2 + 16);
-                __builtin_amdgcn_sched_barrier(0);
-                resolve_chunk(cpos + TS_CHUNK, ch + 63u, b0, b1);
+                const uint32_t mA = scan_chunk(cpos, ch, a0, a1);
+                uint32_t mB = 0u;
+                const bool pair = c + 1u < nch;
+                if (pair) {
+                    const uint32_t p2 = cpos + 2u * TS_CHUNK < last_pos ? cpos + 2u * TS_CHUNK : last_pos;
+                    a0 = *(const uint4 *)(lsrc + p2);
+                    a1 = *(const uint4 *)(lsrc + p2 + 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mB = scan_chunk(cpos + TS_CHUNK, ch + 63u, b0, b1);
+                }
+                append_pair(mA, cpos, mB, cpos + TS_CHUNK);
                 cpos += 2u * TS_CHUNK; ch += 126u;
             }
         }
