@@ -192,6 +192,15 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # a fresh checkout has no built artefacts: rank 0 builds them (hipcc, gcc), the others wait; nothing here is
+    # a fallback — without the HIP library the import below raises
+    if not (os.path.exists(os.path.join(ROOT, "teloscope_amd", "libteloscan.so"))
+            and os.path.exists(os.path.join(ROOT, "oracle", "libteloscope_oracle.so"))):
+        if rank == 0:
+            import __graft_entry__ as entry
+            entry.build()
+    if world > 1:
+        dist.barrier()
     import teloscope_amd as ta
     from teloscope_amd import _capi as K
     from tests import harness as H
