@@ -1,36 +1,113 @@
 #!/usr/bin/env python3
 """bench.py — Gbases/s scanned by the HIP telomeric-motif scan on MI355X.
 
-Workload (BASELINE.json configs[1]): synthetic 3.0 Gb human-scale assembly, 200 contigs
-(log-uniform 1-250 Mb), telomeric arrays + TVRs at contig ends, planted ITS blocks, an N-run
-in 1 % of the contigs, 0.1 % soft-masked bases; flags -c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -x 1 -w 1000 -s 500
--r -g -e -m -i  (124 patterns, k = 6).  One "step" = one full scan of the resident batch:
-window records (8 x u32 per window) and the packed match stream are produced in HBM.
+Workload (BASELINE.json configs[1] / configs[2]): synthetic 3.0 Gb human-scale assembly, 200 contigs
+(log-uniform 1-250 Mb, seed 42), telomeric arrays + TVRs at contig ends, planted ITS blocks, an N-run in 1 % of
+the contigs, 0.1 % soft-masked bases; flags -c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -x 1 -w 1000 -s 500
+-r -g -e -m -i  (124 patterns, k = 6).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--gbases G]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scans its own
-3.0 Gb shard of contigs (weak scaling, contigs are independent units) and the per-segment
-hit summaries are gathered to rank 0 over RCCL inside the timed region (asynchronously, overlapping the next step's scan).
+N = 1: one "step" = one full scan of the resident assembly: window records (8 x u32 per window) and the packed
+match stream are produced in HBM.
+N > 1 (strong scaling, configs[2]): the SAME assembly; every rank builds the same plan and scans the p-th of N
+consecutive tile ranges (teloscope_amd/distributed.py), then ONE exchange — an all-gather of record counts and a
+grouped send/recv of window records, tile directory and tile-ordered match records over RCCL — leaves on rank 0
+what the single-GPU scan leaves there.  A step = scan + exchange; the exchange of step i overlaps the scan of
+step i+1 (two buffer sets), and every exchange is complete before the clock stops.  Ranks are started by
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, when those are absent, by this
+script itself (`python bench.py --gpus N` spawns N rank processes before anything touches a GPU).
+
+  python bench.py --reads [--gpus N]        the read filter (configs[3]) instead of the assembly scan
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402  (imported before libteloscan so both share one HIP runtime)
-
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLAGS = "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -x 1 -w 1000 -s 500 -r -g -e -m -i"
+LIB = os.path.join(ROOT, "teloscope_amd", "libteloscan.so")
+ORACLE = os.path.join(ROOT, "oracle", "libteloscope_oracle.so")
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--verify", action="store_true",
+                    help="untimed full-size parity properties (independent torch computation; at N > 1 also "
+                         "bit-equality of the assembled arrays with a single-GPU scan of the whole assembly on rank 0)")
+    ap.add_argument("--blocks", action="store_true", help="also time device block calling (untimed in value)")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the PCIe-inclusive leg (host buffers through the C-ABI entry points; never in value)")
+    ap.add_argument("--e2e", action="store_true", help="(kept for compatibility: the PCIe-inclusive leg is on by default at N = 1)")
+    ap.add_argument("--flags", default=FLAGS, help="Teloscope flags of the workload (default: configs[1])")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gbases", type=float, default=3.0, help="bases of the assembly (Gb); 3.0 = BASELINE config")
+    ap.add_argument("--contigs", type=int, default=200)
+    ap.add_argument("--weak", action="store_true", help="N > 1: every rank scans its own --gbases assembly (weak scaling; "
+                                                          "only per-segment hit summaries are gathered)")
+    ap.add_argument("--cpu-sample-mb", type=float, default=384.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reads", action="store_true", help="benchmark the read filter (configs[3]) instead of the assembly scan")
+    ap.add_argument("--n-reads", type=float, default=5e6, help="--reads: reads filtered per step across all GPUs")
+    return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def ensure_built():
+    """A fresh checkout has no built artefacts: build them BEFORE any GPU or torch.distributed call (hipcc, gcc;
+    the first local rank builds, the others wait for the files).  Nothing here is a fallback — without the HIP
+    library the import of teloscope_amd raises."""
+    if os.path.exists(LIB) and os.path.exists(ORACLE):
+        return
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        import __graft_entry__ as entry
+        entry.build()
+        return
+    t0 = time.time()
+    while not (os.path.exists(LIB) and os.path.exists(ORACLE)):
+        if time.time() - t0 > 900:
+            raise RuntimeError("libteloscan.so was not built by local rank 0")
+        time.sleep(1.0)
+    time.sleep(2.0)                                            # let the linker finish writing
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (the parent makes no
+    GPU call).  Rank 0 writes the JSON line to our stdout."""
+    ensure_built()
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ------------------------------------------------------------------------------------------- synthetic data
 def contig_lengths(total, n, seed):
+    import numpy as np
     rng = np.random.default_rng(seed)
     raw = np.exp(rng.uniform(np.log(1e6), np.log(250e6), size=n))
     lens = np.maximum((raw * (total / raw.sum())).astype(np.int64), 20000)
@@ -40,7 +117,10 @@ def contig_lengths(total, n, seed):
 
 def fill_synthetic(buf, offsets, lens, seed, dev):
     """Random ACGT + telomeres/TVRs at both ends of every contig + ITS blocks + N-runs + soft-masking,
-    generated on the device (model of src/get-mock-chr.cpp:96-136)."""
+    generated on the device (model of src/get-mock-chr.cpp:96-136).  Deterministic in (seed, lens): every rank
+    of a sharded run generates the same assembly."""
+    import numpy as np
+    import torch
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
@@ -87,7 +167,10 @@ def verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev):
       * per contig: A,C,G,T totals == sum of the nucleotide counts of the windows that tile the contig
         (w = 2s: the even-indexed ones; w = s: all of them);
       * w = s: matches straddling a window end are excluded, as the reference loses them.
+    `batch` holds the results (a scanned batch, or one that adopted the ranks' shards).
     Returns a dict for the bench line; raises on any mismatch."""
+    import torch
+    from teloscope_amd import _capi as K
     n = len(lens)
     k = len(ui.patternInfo[0][0])
     code_of = {"A": 0, "C": 1, "T": 2, "G": 3}
@@ -108,7 +191,7 @@ def verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev):
         raise RuntimeError(tel._ctx.error())
     torch.cuda.synchronize()
     summ = summ.view(n, 4).cpu().numpy()
-    info = __import__("teloscope_amd")._capi.BatchInfo()
+    info = K.BatchInfo()
     L.ts_batch_get_info(batch, C.byref(info))
     wins = torch.empty(int(info.n_windows) * 8, dtype=torch.int32, device=dev)
     hip = C.CDLL("libamdhip64.so")
@@ -160,216 +243,355 @@ def verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev):
                           "A/C/G/T totals vs the sums of the windows that tile each contig"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--verify", action="store_true", help="untimed full-size parity properties (torch)")
-    ap.add_argument("--blocks", action="store_true", help="also time device block calling (untimed in value)")
-    ap.add_argument("--e2e", action="store_true",
-                    help="also time the host-buffer C-ABI calls on the same workload (PCIe-inclusive; never in value)")
-    ap.add_argument("--flags", default=FLAGS, help="Teloscope flags of the workload (default: configs[1])")
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--gbases", type=float, default=3.0, help="bases per GPU (Gb); 3.0 = BASELINE config")
-    ap.add_argument("--contigs", type=int, default=200)
-    ap.add_argument("--cpu-sample-mb", type=float, default=384.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def traffic_from_profile(args):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of the default command, with where it came
+    from; null when the kernel source is newer than the profile (a stale figure is worse than none)."""
+    if args.gbases != 3.0 or args.contigs != 200 or args.flags != FLAGS:
+        return None, None
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for rd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        cand = os.path.join(pdir, rd, "pmc_traffic.json")
+        if os.path.exists(cand):
+            best = cand
+    if best is None:
+        return None, None
+    d = json.load(open(best))
+    src = "static: %s" % os.path.relpath(best, ROOT)
+    want = d.get("kernels_hip_sha256")
+    if want:
+        import hashlib
+        have = hashlib.sha256(open(os.path.join(ROOT, "teloscope_amd", "csrc", "kernels.hip"), "rb").read()).hexdigest()
+        if have != want:
+            return None, src + " is stale (kernels.hip changed since it was measured)"
+        src += " @ kernels.hip sha256 %s" % want[:12]
+    else:
+        return None, src + " carries no kernel hash (measured for an earlier kernel)"
+    return d["hbm_bytes_per_launch"], src
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    dev_index = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    backend = os.environ.get("TS_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse N > 1 on one GPU
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
 
-    # a fresh checkout has no built artefacts: rank 0 builds them (hipcc, gcc), the others wait; nothing here is
-    # a fallback — without the HIP library the import below raises
-    if not (os.path.exists(os.path.join(ROOT, "teloscope_amd", "libteloscan.so"))
-            and os.path.exists(os.path.join(ROOT, "oracle", "libteloscope_oracle.so"))):
-        if rank == 0:
-            import __graft_entry__ as entry
-            entry.build()
-    if world > 1:
-        dist.barrier()
-    import teloscope_amd as ta
-    from teloscope_amd import _capi as K
-    from tests import harness as H
-    from tests.backends import _user_input
-
-    opts = H.parse_cli("x.fa " + args.flags)
-    ui = _user_input(opts)
-    ui.device = dev_index
-    tel = ta.Teloscope(ui)
-    L = K.lib()
-
-    total = int(args.gbases * 1e9)
-    lens = contig_lengths(total, args.contigs, 42 + rank)
+# ------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(args, opts, buf, offsets, lens):
+    """Bounded sample of the same workload on the host cores through the oracle port, with the reference's own
+    parallel decomposition: one job per path (src/input.cpp:719-724), here one contig slice per thread (ctypes
+    releases the GIL inside the C call).  The reference binary itself cannot be built (gfalibs is absent from
+    the reference tree and stand-in headers are not allowed), so this port is not calibrated against it."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tests.backends import OracleBackend
     n = len(lens)
-    lens_c = (C.c_uint64 * n)(*lens)
-    batch = L.ts_batch_create(tel._ctx.ptr, lens_c, None, n, 0, 0)
-    if not batch:
-        raise RuntimeError(tel._ctx.error())
-    info = K.BatchInfo()
-    L.ts_batch_get_info(batch, C.byref(info))
-    offsets = [int(L.ts_batch_segment_offset(batch, i)) for i in range(n)]
+    ncpu = os.cpu_count() or 1
+    cores = max(1, min(ncpu, n))
+    total_sample = args.cpu_sample_mb * 1e6 * max(1.0, cores / 4.0)       # ~10-30 s of work whatever the core count
+    per_job = int(total_sample / cores)
+    order = sorted(range(n), key=lambda i: -lens[i])[:cores]
+    jobs = []
+    for ci in order:
+        nb = int(min(per_job, lens[ci]))
+        jobs.append(buf[offsets[ci]:offsets[ci] + nb].cpu().numpy().tobytes().upper())
+    backends = [OracleBackend(opts) for _ in jobs]
 
-    buf = torch.zeros(int(info.input_bytes), dtype=torch.uint8, device=dev)
-    fill_synthetic(buf, offsets, lens, 42 + rank, dev)
-    # the per-segment hit summaries of a step are gathered while the next step scans: two buffers in turn,
-    # the gather of step i is waited for before its buffer is written again (and at the end of the timed region)
-    xdev = dev if backend == "nccl" else torch.device("cpu")
-    summaries = [torch.zeros(n * 4, dtype=torch.int64, device=dev) for _ in range(2)]
-    gathered = [[torch.zeros(n * 4, dtype=torch.int64, device=xdev) for _ in range(world)]
-                if (world > 1 and rank == 0) else None for _ in range(2)]
-    pending = [None, None]
-    step_no = [0]
-    gather_mode = ["async"]
-    stream = torch.cuda.current_stream()
-    sptr = C.c_void_p(stream.cuda_stream)
-    dptr = C.c_void_p(buf.data_ptr())
+    def run(i):
+        return backends[i].oracle.bench_scan(jobs[i])
 
-    def step():
-        rc = L.ts_batch_scan(batch, dptr, sptr)
-        if rc != 0:
-            raise RuntimeError(tel._ctx.error())
-        if world > 1:
-            j = step_no[0] & 1
-            step_no[0] += 1
-            if pending[j] is not None:
-                pending[j].wait()
-            rc = L.ts_batch_segment_summary(batch, C.c_void_p(summaries[j].data_ptr()), sptr)
+    c0 = time.perf_counter()
+    r1 = run(0)                                                 # one core, one job
+    t1 = time.perf_counter() - c0
+    c0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        res = list(ex.map(run, range(len(jobs))))
+    tn = time.perf_counter() - c0
+    took = sum(len(j) for j in jobs)
+    assert r1[0] == res[0][0]
+    return {"value": round(took / tn / 1e9, 5), "unit": "Gbases/s", "cores": cores, "host_cpus": ncpu, "kind": "port",
+            "single_core_value": round(len(jobs[0]) / t1 / 1e9, 5),
+            "calibrated_against_reference": False,
+            "sample": "first %.0f Mb of each of the %d largest contigs of the same synthetic assembly "
+                      "(%.0f Mb), same flags, scan stage only incl. block calling "
+                      "(oracle/teloscope_oracle.c: trie walk + carry loop), one job per contig as the "
+                      "reference's -j N does; %d windows, %d matches, %.1f s wall (%.1f s for one job on "
+                      "one core); the reference binary cannot be built here (gfalibs absent), so the port is "
+                      "not calibrated against it" % (per_job / 1e6, len(jobs), took / 1e6, sum(r[1] for r in res),
+                                                      sum(r[2] for r in res), tn, t1)}
+
+
+def pcie_inclusive(L, K, tel, buf, offsets, lens, total):
+    """ASCII in host memory in, results in host memory out, through the drop-in entry points (pipelined upload,
+    scan, block calling, D2H, host post-processing) — SURVEY 8d's second figure; reported beside `value`, never
+    in it."""
+    n = len(lens)
+    host = buf.cpu().numpy()
+    segs = (K.SegmentIn * n)()
+    base = host.ctypes.data
+    for i in range(n):
+        segs[i].seq = C.cast(C.c_void_p(base + offsets[i]), C.c_char_p)
+        segs[i].len = lens[i]
+        segs[i].abs_pos = 0
+        segs[i].tips_only = 0
+    e2e = {}
+    for name, with_matches in (("blocks_windows_counts", False), ("with_match_vectors", True)):
+        res = (K.SegmentOut * n)()
+        cnts = (K.SegmentCounts * n)()
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = (L.ts_scan_segments(tel._ctx.ptr, segs, n, res) if with_matches
+                  else L.ts_scan_segments_blocks(tel._ctx.ptr, segs, n, res, cnts))
+            dt = time.perf_counter() - t0
             if rc != 0:
                 raise RuntimeError(tel._ctx.error())
-            src = summaries[j] if backend == "nccl" else summaries[j].cpu()
-            if gather_mode[0] == "async":
-                try:
-                    pending[j] = dist.gather(src, gathered[j], dst=0, async_op=True)
-                    return
-                except (RuntimeError, NotImplementedError, TypeError):   # a backend without an asynchronous gather
-                    gather_mode[0] = "sync"
-            pending[j] = None
-            dist.gather(src, gathered[j], dst=0)
+            nm = int(sum(res[i].n_matches for i in range(n))) if with_matches else int(sum(c.n_matches for c in cnts))
+            L.ts_free_segments(res, n)
+            best = dt if best is None else min(best, dt)
+        e2e[name] = {"seconds": round(best, 4), "gbases_per_s": round(total / best / 1e9, 3), "matches": nm}
+    return {"entry_points": "ts_scan_segments_blocks / ts_scan_segments (pageable host buffers in, host results out; "
+                            "groups of ~256 MB pipelined through upload / scan / download stages; best of 3)", **e2e}
 
-    def drain_gathers():
-        for j in range(2):
-            if pending[j] is not None:
-                pending[j].wait()
-                pending[j] = None
 
-    for _ in range(args.warmup):
-        step()
-    drain_gathers()
-    if L.ts_batch_sync(batch) != 0:          # also grows the match buffer if it overflowed
-        raise RuntimeError(tel._ctx.error())
+# ------------------------------------------------------------------------------------------- the assembly scan
+def run_scan(args, rank, local_rank, world, dev, backend):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd import distributed as D
+    from teloscope_amd.cli import parse_cli, user_input
+
+    opts = parse_cli("x.fa " + args.flags)
+    ui = user_input(opts, device=dev.index)
+    tel = ta.Teloscope(ui)
+    L = K.lib()
+    strong = world > 1 and not args.weak
+    total = int(args.gbases * 1e9)
+    lens = contig_lengths(total, args.contigs, 42 + (rank if args.weak else 0))
+    n = len(lens)
+    plan = D.ShardPlan(tel, lens, world=world if strong else 1)
+    offsets = plan.segment_offsets()
+    info = plan.info
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    xdev = dev if backend == "nccl" else torch.device("cpu")
+
+    # the assembly: generated whole on every rank (same seed -> same bytes); a strong-scaling rank keeps only
+    # the bytes its tile range reads
+    full = torch.zeros(int(info.input_bytes), dtype=torch.uint8, device=dev)
+    fill_synthetic(full, offsets, lens, 42 + (rank if args.weak else 0), dev)
+    keep_full = (not strong) or (rank == 0 and args.verify)
+    if strong:
+        r = plan.ranges[rank]
+        buf = full[r.input_begin:r.input_end].clone()
+        if not keep_full:
+            del full
+            torch.cuda.empty_cache()
+    else:
+        buf = full
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    drain_gathers()
-    ev1.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1) / args.steps
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=xdev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    if L.ts_batch_sync(batch) != 0:
-        raise RuntimeError(tel._ctx.error())
-    L.ts_batch_get_info(batch, C.byref(info))
+    def timed(step_fn, drain_fn, nsteps):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for i in range(nsteps):
+            step_fn(i)
+        drain_fn()
+        ev1.record(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        return max_over_ranks(elapsed), ev0.elapsed_time(ev1) / max(1, nsteps)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tmax = float(tmax.item())
+    out = None
+    if not strong:
+        # ---------------------------------------------------------------- N = 1 (or weak scaling)
+        batch = plan.batch
+        dptr = C.c_void_p(buf.data_ptr())
+        summaries = [torch.zeros(n * 4, dtype=torch.int64, device=dev) for _ in range(2)]
+        gathered = [[torch.zeros(n * 4, dtype=torch.int64, device=xdev) for _ in range(world)]
+                    if (world > 1 and rank == 0) else None for _ in range(2)]
+        pending = [None, None]
+
+        def step(i):
+            if L.ts_batch_scan(batch, dptr, sptr) != 0:
+                raise RuntimeError(tel._ctx.error())
+            if world > 1:                                       # weak scaling: per-segment hit summaries to rank 0
+                j = i & 1
+                if pending[j] is not None:
+                    pending[j].wait()
+                if L.ts_batch_segment_summary(batch, C.c_void_p(summaries[j].data_ptr()), sptr) != 0:
+                    raise RuntimeError(tel._ctx.error())
+                src = summaries[j] if backend == "nccl" else summaries[j].cpu()
+                pending[j] = dist.gather(src, gathered[j], dst=0, async_op=True)
+
+        def drain():
+            for j in range(2):
+                if pending[j] is not None:
+                    pending[j].wait()
+                    pending[j] = None
+
+        for i in range(args.warmup):
+            step(i)
+        drain()
+        if L.ts_batch_sync(batch) != 0:          # also grows the match buffer if it overflowed
+            raise RuntimeError(tel._ctx.error())
+        tmax, dev_ms = timed(step, drain, args.steps)
+        if L.ts_batch_sync(batch) != 0:
+            raise RuntimeError(tel._ctx.error())
+        L.ts_batch_get_info(batch, C.byref(info))
+        kern_ms, launches = float(info.avg_kernel_ms), int(info.kernel_launches)
+        alg_bytes, n_matches, n_windows, n_tiles = int(info.algorithmic_bytes), int(info.n_matches), int(info.n_windows), int(info.n_tiles)
+        result_batch = batch
+        extra_cfg = {"timed_region": "resident ASCII in HBM -> window records + packed match stream in HBM"
+                                     + (" + RCCL gather of per-segment hit summaries (weak scaling: every rank its own assembly)"
+                                        if world > 1 else "")}
+        bases_done = world * total
+    else:
+        # ---------------------------------------------------------------- N > 1, strong scaling (configs[2])
+        r = plan.ranges[rank]
+        slots = 2
+        cap0 = total // 4 + 4096
+        assembled = None
+        if rank == 0:
+            assembled = [D.Assembled(torch.empty(8 * plan.n_windows, dtype=torch.int32, device=dev),
+                                     torch.empty(4 * plan.n_tiles, dtype=torch.int32, device=dev),
+                                     torch.empty(cap0, dtype=torch.int32, device=dev), 0, [0] * world) for _ in range(slots)]
+        shard = D.HipShard(plan, rank, dev, slots=slots, assembled=assembled)
+        in_ptr = buf.data_ptr()
+        pending = [None] * slots
+        n_local = [0] * slots
+        dir_only = [False]
+
+        def step(i):
+            j = i % slots
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
+            shard.scan(in_ptr, sptr, j)
+            n_local[j] = shard.finish(in_ptr, sptr, j)
+            pending[j] = D.gather_shards(plan, rank, shard.windows[j], shard.stats[j], shard.dense[j], n_local[j], dst=0,
+                                         out=assembled[j] if rank == 0 else None, async_op=True, directory_only=dir_only[0])
+
+        def drain():
+            for j in range(slots):
+                if pending[j] is not None:
+                    pending[j].wait()
+                    pending[j] = None
+
+        for i in range(max(args.warmup, slots)):
+            step(i)
+        drain()
+        for j in range(slots):                                   # (a sync also grows a shard's match regions if they overflowed)
+            shard.kernel_ms(j)
+        tmax, dev_ms = timed(step, drain, args.steps)
+        last = (args.steps - 1) % slots
+        km = [shard.kernel_ms(j) for j in range(slots)]
+        launches = sum(k[1] for k in km)
+        kern_ms = sum(k[0] * k[1] for k in km) / max(1, launches)
+        rinfo = km[last][2]
+        alg_bytes = int(rinfo.algorithmic_bytes)
+
+        # the summaries-only variant, measured not argued: only the tile directory (16 B per tile) travels
+        dir_only[0] = True
+        t_dir, _ = timed(step, drain, args.steps)
+        dir_only[0] = False
+        # where a step's time goes when nothing overlaps: scan + export / exchange / merge, each waited for
+        nb = min(10, args.steps)
+        t_scan = t_x = t_merge = 0.0
+        for i in range(nb):
+            barrier()
+            c0 = time.perf_counter()
+            shard.scan(in_ptr, sptr, 0)
+            nl = shard.finish(in_ptr, sptr, 0)
+            torch.cuda.synchronize()
+            c1 = time.perf_counter()
+            a = D.gather_shards(plan, rank, shard.windows[0], shard.stats[0], shard.dense[0], nl, dst=0,
+                                out=assembled[0] if rank == 0 else None)
+            torch.cuda.synchronize()
+            c2 = time.perf_counter()
+            if rank == 0:
+                hb = D.adopt(plan, a, sptr)
+                L.ts_batch_destroy(hb)
+            c3 = time.perf_counter()
+            t_scan += c1 - c0; t_x += c2 - c1; t_merge += c3 - c2
+        split = {"scan_export_ms": round(max_over_ranks(t_scan / nb) * 1e3, 4), "exchange_ms": round(max_over_ranks(t_x / nb) * 1e3, 4),
+                 "merge_ms_rank0": round(t_merge / nb * 1e3, 4), "steps": nb,
+                 "note": "serialised (each phase waited for on the host); the timed region overlaps the exchange of step i "
+                         "with the scan of step i+1"}
+        step(0)
+        drain()
+        a = assembled[0] if rank == 0 else None
+        result_batch = D.adopt(plan, a, sptr) if rank == 0 else None
+        n_matches = a.n_records if rank == 0 else 0
+        n_windows, n_tiles = plan.n_windows, plan.n_tiles
+        gather_bytes = (8 * 4 * plan.n_windows + 16 * plan.n_tiles + 4 * n_matches) if rank == 0 else 0
+        own = plan.ranges[0]
+        gather_bytes_rx = gather_bytes - (32 * (own.window_end - own.window_begin) + 16 * (own.tile_end - own.tile_begin)
+                                          + 4 * (a.counts[0] if rank == 0 else 0)) if rank == 0 else 0
+        extra_cfg = {"timed_region": "resident ASCII in HBM on %d ranks (consecutive tile ranges of ONE plan) -> scan + tile-ordered "
+                                     "export + ONE exchange (all-gather of record counts, grouped send/recv of window records, tile "
+                                     "directory, match records) -> the whole assembly's results in rank 0's HBM; exchange of step i "
+                                     "overlaps scan of step i+1" % world,
+                     "backend": backend + ("" if backend == "nccl" else " (rehearsal: ranks share a GPU, tensors staged through the host)"),
+                     "bases_per_rank": [int(x.bases) for x in plan.ranges],
+                     "records_per_rank": a.counts if rank == 0 else None,
+                     "gather_bytes_per_step": {"assembled_on_rank0": gather_bytes, "received_over_links": gather_bytes_rx},
+                     "step_split": split,
+                     "summaries_only_variant": {"ms_per_step": round(t_dir / args.steps * 1e3, 4),
+                                                "value": round(total / (t_dir / args.steps) / 1e9, 3),
+                                                "what_travels": "tile directory entries only (16 B per tile: %d B per step)" % (16 * plan.n_tiles)}}
+        bases_done = total
 
     if rank == 0:
         ms_per_step = tmax / args.steps * 1e3
-        value = world * total / (tmax / args.steps) / 1e9
-        alg_bytes = int(info.algorithmic_bytes)
-        # HIP events around every timed launch of the scan kernel, on its stream, averaged
-        kern_ms = float(info.avg_kernel_ms)
+        value = bases_done / (tmax / args.steps) / 1e9
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-        if args.gbases == 3.0 and args.contigs == 200 and args.flags == FLAGS and os.path.exists(tpath):
-            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+        traffic, traffic_source = traffic_from_profile(args) if world == 1 else (None, None)
         out = {
             "metric": "Gbases/s scanned (whole node), 3 Gb FASTA TTAGGG w=1000 s=500",
             "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: synthetic %.2f Gb / %d contigs per GPU, %s, %d patterns k=%d"
-                                   % ("configs[1]" if args.flags == FLAGS else "custom", args.gbases, n, args.flags,
-                                      len(ui.patternInfo), len(ui.patternInfo[0][0])),
-                       "bases_per_gpu": total, "windows": int(info.n_windows),
-                       "matches": int(info.n_matches), "tiles": int(info.n_tiles),
-                       "timed_region": "resident ASCII in HBM -> window records + packed match stream in HBM"
-                                       + (" + RCCL gather of per-segment hit summaries" if world > 1 else ""),
-                       "device_ms_per_step_events": round(dev_ms, 4)},
+            "scaling": "weak" if (world > 1 and args.weak) else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s: synthetic %.2f Gb / %d contigs%s, %s, %d patterns k=%d"
+                                   % (("configs[1]" if world == 1 else "configs[2]") if args.flags == FLAGS and args.gbases == 3.0 else "custom",
+                                      args.gbases, n, " per GPU" if args.weak and world > 1 else (" sharded over %d GPUs" % world if world > 1 else ""),
+                                      args.flags, len(ui.patternInfo), len(ui.patternInfo[0][0])),
+                       "bases": total, "windows": n_windows, "matches": n_matches, "tiles": n_tiles,
+                       "device_ms_per_step_events": round(dev_ms, 4), **extra_cfg},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "ts_scan_tiles", "kernel_ms": round(kern_ms, 4), "launches_timed": int(info.kernel_launches),
-                         "algorithmic_bytes": alg_bytes},
+                         "traffic_source": traffic_source,
+                         "kernel": "ts_scan_tiles" + (" (rank 0's range)" if strong else ""), "kernel_ms": round(kern_ms, 4),
+                         "launches_timed": launches, "algorithmic_bytes": alg_bytes},
         }
-        if not args.no_cpu_baseline and world == 1:           # the host-core baseline is timed at N = 1 only
-            # Bounded sample of the same workload on the host cores through the oracle port, with the
-            # reference's own parallel decomposition: one job per path (src/input.cpp:719-724), here
-            # one contig slice per thread (ctypes releases the GIL inside the C call).
-            from concurrent.futures import ThreadPoolExecutor
-            from tests.backends import OracleBackend
-            cores = max(1, min(16, os.cpu_count() or 1, n))
-            per_job = int(args.cpu_sample_mb * 1e6 / 4)                 # 96 Mb per job by default
-            order = sorted(range(n), key=lambda i: -lens[i])[:cores]
-            jobs = []
-            for ci in order:
-                nb = int(min(per_job, lens[ci]))
-                jobs.append(buf[offsets[ci]:offsets[ci] + nb].cpu().numpy().tobytes().upper())
-            backends = [OracleBackend(opts) for _ in jobs]
-
-            def run(i):
-                return backends[i].oracle.bench_scan(jobs[i])
-
-            c0 = time.perf_counter()
-            r1 = run(0)                                                 # one core, one job
-            t1 = time.perf_counter() - c0
-            c0 = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=cores) as ex:
-                res = list(ex.map(run, range(len(jobs))))
-            tn = time.perf_counter() - c0
-            took = sum(len(j) for j in jobs)
-            out["cpu_baseline"] = {
-                "value": round(took / tn / 1e9, 5), "unit": "Gbases/s", "cores": cores, "kind": "port",
-                "single_core_value": round(len(jobs[0]) / t1 / 1e9, 5),
-                "sample": "first %.0f Mb of each of the %d largest contigs of the same synthetic assembly "
-                          "(%.0f Mb), same flags, scan stage only incl. block calling "
-                          "(oracle/teloscope_oracle.c: trie walk + carry loop), one job per contig as the "
-                          "reference's -j N does; %d windows, %d matches, %.1f s wall (%.1f s for one job on "
-                          "one core)" % (per_job / 1e6, len(jobs), took / 1e6, sum(r[1] for r in res),
-                                         sum(r[2] for r in res), tn, t1)}
-            assert r1[0] == res[0][0]
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, opts, buf, offsets, lens)
         if args.verify:
-            out["verify"] = verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev)
+            out["verify"] = verify_full_size(L, result_batch, tel, full if strong else buf, offsets, lens, ui, dev)
+            if strong:
+                # the assembled arrays against a single-GPU scan of the whole assembly, bit for bit
+                one = D.ShardPlan(tel, lens, world=1)
+                hs = D.HipShard(one, 0, dev, slots=1)
+                hs.scan(full.data_ptr(), sptr, 0)
+                n1 = hs.finish(full.data_ptr(), sptr, 0)
+                a = assembled[0]
+                assert n1 == a.n_records, (n1, a.n_records)
+                assert torch.equal(hs.windows[0], a.windows) and torch.equal(hs.stats[0], a.stats)
+                assert torch.equal(hs.dense[0][:n1], a.dense[:n1])
+                out["verify"]["sharded_equals_single_gpu"] = {"windows": int(plan.n_windows), "tiles": int(plan.n_tiles), "records": int(n1)}
+                hs.close()
         if args.blocks:
             seg_out = (K.SegmentOut * n)()
             b0 = time.perf_counter()
-            rc = L.ts_batch_download_blocks(batch, seg_out)
+            rc = L.ts_batch_download_blocks(result_batch, seg_out)
             bdt = time.perf_counter() - b0
             if rc != 0:
                 raise RuntimeError(tel._ctx.error())
@@ -378,40 +600,257 @@ def main():
                 "terminal_blocks": int(sum(seg_out[i].n_terminal_blocks for i in range(n))),
                 "interstitial_blocks": int(sum(seg_out[i].n_interstitial_blocks for i in range(n)))}
             L.ts_free_segments(seg_out, n)
-        if args.e2e:
-            # PCIe-inclusive: ASCII in host memory in, results in host memory out, through the drop-in entry points
-            # (upload through the pinned ring, scan, block calling, D2H, host post-processing) — SURVEY 8d's second
-            # figure; reported beside `value`, never in it.
-            host = buf.cpu().numpy()
-            segs = (K.SegmentIn * n)()
-            base = host.ctypes.data
-            for i in range(n):
-                segs[i].seq = C.cast(C.c_void_p(base + offsets[i]), C.c_char_p)
-                segs[i].len = lens[i]
-                segs[i].abs_pos = 0
-                segs[i].tips_only = 0
-            e2e = {}
-            for name, with_matches in (("blocks_windows_counts", False), ("with_match_vectors", True)):
-                res = (K.SegmentOut * n)()
-                cnts = (K.SegmentCounts * n)()
-                best = None
-                for _ in range(2):
-                    t0 = time.perf_counter()
-                    rc = (L.ts_scan_segments(tel._ctx.ptr, segs, n, res) if with_matches
-                          else L.ts_scan_segments_blocks(tel._ctx.ptr, segs, n, res, cnts))
-                    dt = time.perf_counter() - t0
-                    if rc != 0:
-                        raise RuntimeError(tel._ctx.error())
-                    nm = int(sum(res[i].n_matches for i in range(n))) if with_matches else int(sum(c.n_matches for c in cnts))
-                    L.ts_free_segments(res, n)
-                    best = dt if best is None else min(best, dt)
-                e2e[name] = {"seconds": round(best, 4), "gbases_per_s": round(total / best / 1e9, 3), "matches": nm}
-            out["pcie_inclusive"] = {"entry_points": "ts_scan_segments_blocks / ts_scan_segments (pageable host buffers in, "
-                                                     "host results out, best of 2)", **e2e}
-        print(json.dumps(out))
-    L.ts_batch_destroy(batch)
+        if world == 1 and not args.no_e2e:
+            out["pcie_inclusive"] = pcie_inclusive(L, K, tel, buf, offsets, lens, total)
+        print(json.dumps(out), flush=True)
+    if strong:
+        if result_batch:
+            L.ts_batch_destroy(result_batch)
+        shard.close()
+    barrier()
+
+
+# ------------------------------------------------------------------------------------------- the read filter
+READ_FLAGS = "--fastq-subset -l 42"
+
+
+def read_lengths(n, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    return np.clip(rng.normal(15000, 3000, size=n), 1000, 40000).astype(np.int64)
+
+
+def fill_reads(buf, offsets, lens, seed, dev):
+    """configs[3]'s synthetic HiFi reads on the device: uniform ACGT, 0.5 % of the reads carry a 300-8000 b
+    terminal TTAGGG / CCCTAA tract with 1 % substitutions.  Returns the indices of the reads that carry one."""
+    import numpy as np
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    chunk = 1 << 28
+    for a in range(0, buf.numel(), chunk):
+        b = min(buf.numel(), a + chunk)
+        buf[a:b] = lut[torch.randint(0, 4, (b - a,), dtype=torch.uint8, device=dev, generator=g).long()]
+    rng = np.random.default_rng(seed + 1)
+    carriers = np.flatnonzero(rng.random(len(lens)) < 0.005)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i in carriers:
+        ln = int(min(rng.integers(300, 8001), lens[i]))
+        unit = b"TTAGGG" if rng.random() < 0.5 else b"CCCTAA"
+        t = np.tile(np.frombuffer(unit, dtype=np.uint8), ln // 6 + 1)[:ln].copy()
+        k = rng.random(ln) < 0.01
+        t[k] = acgt[rng.integers(0, 4, size=int(k.sum()))]
+        at = offsets[i] if unit == b"CCCTAA" else offsets[i] + int(lens[i]) - ln
+        buf[at:at + ln] = torch.from_numpy(t).to(dev)
+    return carriers
+
+
+def run_reads(args, rank, local_rank, world, dev, backend):
+    """configs[3]: --fastq-subset -l 42 on synthetic HiFi reads (~15 kb), the reads dealt to the ranks in consecutive
+    shards of equal count (the reference deals a batch's records to its workers in chunks and writes the chunk
+    outputs in chunk order, src/input.cpp:753-812); the only exchange is one gather of the pass bytes, in input
+    order, to rank 0.  `value` = resident rate (reads in HBM -> pass bytes in HBM [-> rank 0]); the streaming
+    PCIe-inclusive rate through ts_filter_reads is reported beside it."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import parse_cli, user_input
+
+    opts = parse_cli(READ_FLAGS)
+    ui = user_input(opts, device=dev.index)
+    rf = ta.ReadTelomereFilter(ui)
+    L = K.lib()
+    n_total = int(args.n_reads)
+    lo, hi = rank * n_total // world, (rank + 1) * n_total // world       # this rank's shard of the reads
+    all_lens = read_lengths(n_total, 43)
+    lens = all_lens[lo:hi]
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    xdev = dev if backend == "nccl" else torch.device("cpu")
+
+    # resident sub-batches of <= 500 k reads (~7.5 Gb each): input, match stream and pass bytes stay in HBM
+    sub = 500_000
+    batches = []
+    for a in range(0, len(lens), sub):
+        sl = lens[a:a + sub]
+        n = len(sl)
+        arr = (C.c_uint64 * n)(*[int(x) for x in sl])
+        b = L.ts_batch_create(rf._ctx.ptr, arr, None, n, 1, int(sl.sum()) // 8 + 4096)
+        if not b:
+            raise RuntimeError(rf._ctx.error())
+        info = K.BatchInfo()
+        L.ts_batch_get_info(b, C.byref(info))
+        offs = np.concatenate(([0], np.cumsum((sl + 15) & ~15)))[:-1]
+        buf = torch.zeros(int(info.input_bytes), dtype=torch.uint8, device=dev)
+        carriers = fill_reads(buf, offs, sl, 43 + 1000 * rank + a, dev)
+        batches.append(dict(b=b, n=n, buf=buf, lens=sl, offs=offs, carriers=carriers,
+                            d_pass=torch.zeros(n + 16, dtype=torch.uint8, device=dev)))
+    my_bases = int(lens.sum())
+    total_bases = int(all_lens.sum())
+    max_n = max((rank_hi - rank_lo) for rank_lo, rank_hi in ((r * n_total // world, (r + 1) * n_total // world) for r in range(world)))
+    pass_local = torch.zeros(max_n, dtype=torch.uint8, device=dev)
+    gathered = [torch.zeros(max_n, dtype=torch.uint8, device=xdev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step(_i=0):
+        at = 0
+        for e in batches:
+            if L.ts_batch_scan(e["b"], C.c_void_p(e["buf"].data_ptr()), sptr) != 0:
+                raise RuntimeError(rf._ctx.error())
+            if L.ts_batch_read_pass(e["b"], C.c_void_p(e["d_pass"].data_ptr()), sptr) != 0:
+                raise RuntimeError(rf._ctx.error())
+            pass_local[at:at + e["n"]] = e["d_pass"][:e["n"]]
+            at += e["n"]
+        if world > 1:                                            # the 1-byte-per-read gather, in input order
+            dist.gather(pass_local if backend == "nccl" else pass_local.cpu(), gathered, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    for e in batches:                                            # (a sync grows a match buffer that overflowed, and rescans)
+        if L.ts_batch_sync(e["b"]) != 0:
+            raise RuntimeError(rf._ctx.error())
+    step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
     if world > 1:
-        dist.destroy_process_group()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tmax = float(t.item())
+
+    kern_ms = alg = nm = launches = 0
+    for e in batches:
+        if L.ts_batch_sync(e["b"]) != 0:
+            raise RuntimeError(rf._ctx.error())
+        info = K.BatchInfo()
+        L.ts_batch_get_info(e["b"], C.byref(info))
+        kern_ms += float(info.avg_kernel_ms)
+        launches += int(info.kernel_launches)
+        alg += int(info.algorithmic_bytes)
+        nm += int(info.n_matches)
+    kept_local = int(pass_local[:len(lens)].sum().item())
+    n_carriers = int(sum(len(e["carriers"]) for e in batches))
+    # every read that carries a planted terminal tract of >= 300 b must pass; (a random 15 kb read passes with negligible probability)
+    at = 0
+    for e in batches:
+        got = e["d_pass"][:e["n"]].cpu().numpy()
+        assert got[e["carriers"]].all(), "a read with a planted terminal telomere tract was not kept"
+        at += e["n"]
+
+    if rank == 0:
+        kept = kept_local if world == 1 else int(sum(int(gathered[r][:((r + 1) * n_total // world - r * n_total // world)].sum()) for r in range(world)))
+        sec = tmax / args.steps
+        achieved = alg / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Gbases/s filtered (whole node), --fastq-subset -l 42 on synthetic ~15 kb HiFi reads",
+            "value": round(total_bases / sec / 1e9, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(sec * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[3] at %d reads: %s, lengths N(15000, 3000^2) clipped to [1000, 40000], seed 43, 0.5 %% of the reads with a "
+                                   "300-8000 b terminal tract; %d patterns k=%d" % (n_total, READ_FLAGS, len(ui.patternInfo), len(ui.patternInfo[0][0])),
+                       "reads": n_total, "reads_per_s": round(n_total / sec, 1), "bases": total_bases, "kept": kept,
+                       "planted_carriers_rank0": n_carriers, "matches_rank0": nm,
+                       "timed_region": "reads resident in HBM -> whole-read tips scan + terminal-block predicate on the device -> one pass byte "
+                                       "per read in HBM" + (" -> one gather of the pass bytes to rank 0" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "ts_scan_tiles (tips mode, rank 0's reads)", "kernel_ms": round(kern_ms, 4), "launches_timed": launches,
+                         "algorithmic_bytes": alg},
+        }
+        # streaming, PCIe-inclusive: host reads through ts_filter_reads (groups pipelined through upload / scan / predicate);
+        # a pool of 200 k host reads is cycled, so that any read count streams through bounded host memory
+        e = batches[0]
+        npool = min(200_000, e["n"])
+        host = e["buf"][:int(e["offs"][npool - 1] + e["lens"][npool - 1])].cpu().numpy()
+        ptrs = (C.c_char_p * npool)()
+        base = host.ctypes.data
+        for i in range(npool):
+            ptrs[i] = C.cast(C.c_void_p(base + int(e["offs"][i])), C.c_char_p)
+        hl = (C.c_uint64 * npool)(*[int(x) for x in e["lens"][:npool]])
+        hp = (C.c_uint8 * npool)()
+        pool_bases = int(e["lens"][:npool].sum())
+        rounds = max(1, min(25, int(round(n_total / world / npool))))
+        assert L.ts_filter_reads(rf._ctx.ptr, ptrs, hl, npool, hp) == 0, rf._ctx.error()        # warm: pool, pinned rings
+        assert bytes(hp) == bytes(e["d_pass"][:npool].cpu().numpy().tobytes()), "streaming and resident filters disagree"
+        c0 = time.perf_counter()
+        for _ in range(rounds):
+            if L.ts_filter_reads(rf._ctx.ptr, ptrs, hl, npool, hp) != 0:
+                raise RuntimeError(rf._ctx.error())
+        dt = time.perf_counter() - c0
+        out["pcie_inclusive"] = {"entry_point": "ts_filter_reads (pageable host reads in, pass bytes out; groups of ~256 MB pipelined)",
+                                 "reads": rounds * npool, "seconds": round(dt, 4), "reads_per_s": round(rounds * npool / dt, 1),
+                                 "gbases_per_s": round(rounds * pool_bases / dt / 1e9, 3),
+                                 "note": "a pool of %d host reads filtered %d times on one GPU" % (npool, rounds)}
+        if world == 1 and not args.no_cpu_baseline:
+            from concurrent.futures import ThreadPoolExecutor
+            from tests.backends import OracleReadFilter
+            cores = max(1, os.cpu_count() or 1)
+            per = 600                                             # reads per core: ~9 Mb each, ~10-30 s of CPU work in all
+            take = min(npool, per * cores)
+            seqs = [bytes(host[int(e["offs"][i]):int(e["offs"][i]) + int(e["lens"][i])]) for i in range(take)]
+            filt = [OracleReadFilter(opts) for _ in range(cores)]
+            share = -(-take // cores)
+
+            def job(ci):
+                return filt[ci].filter(seqs[ci * share:(ci + 1) * share])
+            c0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as ex:
+                res = [x for part in ex.map(job, range(cores)) for x in part]
+            tn = time.perf_counter() - c0
+            assert res == [bool(x) for x in hp[:take]], "oracle and HIP read filter disagree on the sample"
+            sb = sum(len(x) for x in seqs)
+            out["cpu_baseline"] = {"value": round(sb / tn / 1e9, 5), "unit": "Gbases/s", "cores": cores, "kind": "port",
+                                   "calibrated_against_reference": False,
+                                   "sample": "%d of the same reads (%.0f Mb), ReadTelomereFilter::matches through the oracle port, one chunk of "
+                                             "reads per thread as the reference's -j N does; %.1f s wall; identical pass bits"
+                                             % (take, sb / 1e6, tn)}
+        print(json.dumps(out), flush=True)
+    for e in batches:
+        L.ts_batch_destroy(e["b"])
+    barrier()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    ensure_built()                                              # before any GPU / torch.distributed call
+
+    import torch  # noqa: E402  (imported before libteloscan so both share one HIP runtime)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev
+    # one rank per GPU over RCCL; "gloo" only to rehearse N > 1 where ranks have to share a GPU
+    backend = os.environ.get("TS_BENCH_BACKEND") or ("nccl" if ndev >= int(os.environ.get("LOCAL_WORLD_SIZE", world)) else "gloo")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    try:
+        if args.reads:
+            run_reads(args, rank, local_rank, world, dev, backend)
+        else:
+            run_scan(args, rank, local_rank, world, dev, backend)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -28,7 +28,13 @@
 extern "C" {
 #endif
 
-#define TELOSCAN_ABI_VERSION 1
+#define TELOSCAN_ABI_VERSION 2
+
+/* ts_params.device value of a PLANNING-ONLY context: no HIP call is ever made behind it.  It plans batches
+ * (ts_batch_create, ts_batch_get_info, ts_batch_get_tiles, ts_batch_partition, ts_batch_range_info) so that a
+ * host without a GPU — the rank that only merges, a test — sees the same tiling as the ranks that scan; every
+ * entry point that needs the device fails on it with TS_ERR_NO_DEVICE.  It is not a CPU scan path. */
+#define TS_DEVICE_NONE (-2)
 
 typedef enum ts_status {
     TS_OK               =  0,
@@ -77,7 +83,7 @@ typedef struct ts_params {
                                        caller gets by calling unmaskSequence first);
                                     0: strict scanSegment semantics (lower case = non-ACGT) */
     uint8_t  reserved0;
-    int32_t  device;             /* HIP device ordinal, -1 = current device */
+    int32_t  device;             /* HIP device ordinal, -1 = current device, TS_DEVICE_NONE = planning only */
     uint32_t reserved1;
 } ts_params;
 
@@ -274,6 +280,72 @@ int       ts_batch_download_blocks(ts_batch *b, ts_segment_out *out);
  * segment) written to a device buffer of 32*n_segments bytes: the "hit buffer" ranks
  * gather over RCCL. */
 int       ts_batch_segment_summary(ts_batch *b, void *d_out, void *stream);
+
+
+/* ---- the tile directory and tile-range shards: multi-GPU form of the scan.
+ *      The reference runs one thread-pool job per path (src/input.cpp:719-724) and merges the jobs' PathData
+ *      in seqPos order (sortBySeqPos, include/teloscope.h:262-266).  Here the unit of work is a TILE of the
+ *      batch's plan (a run of consecutive windows of one segment, plus its w-s halo); ranks scan disjoint tile
+ *      ranges of the SAME plan and one rank adopts all their results, after which it holds exactly what a
+ *      single-GPU scan of the whole batch holds.  Nothing here communicates: the exchange itself
+ *      (RCCL through torch.distributed) belongs to the caller, teloscope_amd/distributed.py. ---------- */
+typedef struct ts_tile_info {
+    uint64_t seg_index;        /* segment the tile belongs to */
+    uint64_t seg_offset;       /* segment-relative position of the tile's first owned base; the position field
+                                  of a packed match record is relative to it */
+    uint64_t first_window;     /* index of the tile's first window record in the batch's window array */
+    uint32_t n_windows;        /* window records the tile owns (0 in a tips-only batch) */
+    uint32_t owned_bases;
+} ts_tile_info;
+/* Fills out[0..n) with tiles first .. first+n-1 of the plan (host data; works on a planning-only context). */
+int ts_batch_get_tiles(const ts_batch *b, uint64_t first, uint64_t n, ts_tile_info *out);
+
+typedef struct ts_range_info {
+    uint64_t tile_begin, tile_end;
+    uint64_t window_begin, window_end;   /* window records the range owns */
+    uint64_t input_begin, input_end;     /* bytes of the batch's input layout the range reads (halo and the kernel's
+                                            over-read slack included; bytes past a segment's data may hold anything) */
+    uint64_t bases;                      /* owned bases */
+} ts_range_info;
+int ts_batch_range_info(const ts_batch *b, uint64_t tile_begin, uint64_t tile_end, ts_range_info *out);
+/* Deterministic split of the plan into n_parts consecutive tile ranges of equal owned bases (+-1 tile);
+ * part p owns [*tile_begin, *tile_end).  Consecutive ranges make the gather a concatenation: window records,
+ * the tile directory and the tile-ordered record stream of part p follow those of part p-1. */
+int ts_batch_partition(const ts_batch *b, uint32_t n_parts, uint32_t part, uint64_t *tile_begin, uint64_t *tile_end);
+/* Before the first scan: the batch will execute only tiles [tile_begin, tile_end) — device buffers are sized for
+ * the range, ts_batch_scan expects d_input to point at byte input_begin of the input layout
+ * (ts_batch_range_info), and ts_batch_upload copies only the part of a segment the range reads. */
+int ts_batch_restrict(ts_batch *b, uint64_t tile_begin, uint64_t tile_end);
+/* Caller-owned result buffers (device): the scan writes the range's window records (32 B each, from
+ * window_begin) to d_windows and its tile directory entries {matches, canonical, forward, 0} x uint32 (16 B per
+ * tile, from tile_begin) to d_tile_stats.  Either may be NULL = the batch's own buffer.  Before the first scan. */
+int ts_batch_bind_results(ts_batch *b, void *d_windows, void *d_tile_stats);
+/* After a scan (asynchronous on `stream`): packs the range's match records into ONE stream in tile order
+ * (= position order within each segment) at d_dense (capacity in records) and writes to d_total (2 x uint64 on
+ * the device) {records the range produced, 1 if the stream is incomplete: a wave's region overflowed — call
+ * ts_batch_sync, which grows it and rescans — or dense_capacity was too small}. */
+int ts_batch_export(ts_batch *b, void *d_dense, uint64_t dense_capacity, void *d_total, void *stream);
+/* On a whole (unrestricted) batch: take results produced elsewhere — window records, tile directory entries and
+ * the tile-ordered record stream of ALL tiles, i.e. the concatenation over the parts of what ts_batch_bind_results
+ * / ts_batch_export delivered — as this batch's results.  The buffers stay owned by the caller and must outlive
+ * the batch's use.  Afterwards ts_batch_download, ts_batch_download_blocks and ts_batch_segment_summary work as
+ * after a local scan + sync. */
+int ts_batch_adopt(ts_batch *b, void *d_windows, void *d_tile_stats, const void *d_dense, uint64_t n_matches,
+                   void *stream);
+/* Device pointer of the batch's tile directory entries (16 B per tile of the range). */
+const void *ts_batch_tile_stats_ptr(const ts_batch *b);
+
+/* ---- ReadTelomereFilter over several devices (the read shard of --fastq-subset / --bam-subset:
+ *      the reference deals a batch's reads to its thread-pool workers in chunks and writes the chunk outputs in
+ *      chunk order, src/input.cpp:753-812).  ctxs[0..n_ctx) are read-filter contexts (ts_create_read_filter),
+ *      normally one per GPU; the batch is cut into n_ctx consecutive shards of equal bases, each filtered by one
+ *      host thread on its context, and pass[] comes back in input order.  Contexts may share a device. */
+/* ReadTelomereFilter::matches for reads that already are in HBM: on a tips-only batch made from a read-filter
+ * context and scanned on `stream` (ts_batch_scan), writes pass[i] (one byte per read, device memory) asynchronously
+ * on the same stream; the match stream never leaves the device. */
+int ts_batch_read_pass(ts_batch *b, void *d_pass, void *stream);
+int ts_filter_reads_multi(ts_ctx *const *ctxs, size_t n_ctx, const char *const *seqs, const uint64_t *lens,
+                          size_t n_reads, uint8_t *pass);
 
 #ifdef __cplusplus
 }

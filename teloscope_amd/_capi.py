@@ -81,7 +81,20 @@ class BatchInfo(C.Structure):
                 ("kernel_launches", C.c_uint64)]
 
 
+class TileInfo(C.Structure):
+    _fields_ = [("seg_index", C.c_uint64), ("seg_offset", C.c_uint64), ("first_window", C.c_uint64),
+                ("n_windows", C.c_uint32), ("owned_bases", C.c_uint32)]
+
+
+class RangeInfo(C.Structure):
+    _fields_ = [("tile_begin", C.c_uint64), ("tile_end", C.c_uint64), ("window_begin", C.c_uint64),
+                ("window_end", C.c_uint64), ("input_begin", C.c_uint64), ("input_end", C.c_uint64),
+                ("bases", C.c_uint64)]
+
+
+DEVICE_NONE = -2            # TS_DEVICE_NONE: planning-only context
 MATCH_DT = np.dtype(Match)
+TILE_DT = np.dtype(TileInfo)
 WINDOW_DT = np.dtype(Window)
 BLOCK_DT = np.dtype(Block)
 
@@ -94,6 +107,8 @@ SYMBOLS = [
     "ts_batch_destroy", "ts_batch_segment_offset", "ts_batch_input_ptr", "ts_batch_upload",
     "ts_batch_scan", "ts_batch_sync", "ts_batch_get_info", "ts_batch_windows_ptr",
     "ts_batch_matches_ptr", "ts_batch_download", "ts_batch_download_blocks", "ts_batch_segment_summary",
+    "ts_batch_get_tiles", "ts_batch_range_info", "ts_batch_partition", "ts_batch_restrict", "ts_batch_bind_results",
+    "ts_batch_export", "ts_batch_adopt", "ts_batch_tile_stats_ptr", "ts_filter_reads_multi", "ts_batch_read_pass",
 ]
 
 
@@ -167,6 +182,18 @@ def lib():
     L.ts_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SegmentOut)]
     L.ts_batch_download_blocks.argtypes = [C.c_void_p, C.POINTER(SegmentOut)]
     L.ts_batch_segment_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ts_batch_get_tiles.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.ts_batch_range_info.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(RangeInfo)]
+    L.ts_batch_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.ts_batch_restrict.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    L.ts_batch_bind_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ts_batch_export.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.ts_batch_adopt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.ts_batch_tile_stats_ptr.restype = C.c_void_p
+    L.ts_batch_tile_stats_ptr.argtypes = [C.c_void_p]
+    L.ts_batch_read_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ts_filter_reads_multi.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+                                        C.c_size_t, C.POINTER(C.c_uint8)]
     _lib = L
     return L
 

@@ -17,110 +17,55 @@
 #include <string>
 #include <vector>
 
-#include "host.hpp"
-#include "ts_internal.h"
+#include "capi_internal.hpp"
 
 namespace {
 
 thread_local std::string g_create_error;
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    hipError_t ensure(size_t need) {
-        if (need <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, need ? need : 16);
-        if (e == hipSuccess) bytes = need;
-        return e;
+}  // namespace
+
+// ---------------------------------------------------------------------------------------- buffer pool
+hipError_t BufferPool::take(size_t need, DevBuf &out) {
+    if (need == 0) need = 16;
+    {
+        std::lock_guard<std::mutex> g(m_);
+        size_t best = free_.size();
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].bytes >= need && free_[i].bytes <= 2 * need + (1u << 20) &&
+                (best == free_.size() || free_[i].bytes < free_[best].bytes)) best = i;
+        if (best != free_.size()) {
+            held_ -= free_[best].bytes;
+            out = std::move(free_[best]);
+            free_.erase(free_.begin() + (long)best);
+            return hipSuccess;
+        }
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-};
+    out.release();
+    hipError_t e = out.ensure(need);
+    if (e != hipSuccess) {                       // out of memory: drop what the pool holds and try once more
+        clear();
+        (void)hipGetLastError();
+        e = out.ensure(need);
+    }
+    return e;
+}
 
-}  // namespace
+void BufferPool::give(DevBuf &&b) {
+    if (!b.p) return;
+    std::lock_guard<std::mutex> g(m_);
+    if (free_.size() >= kMaxBlocks || held_ + b.bytes > kMaxHeld) { b.release(); return; }
+    held_ += b.bytes;
+    free_.push_back(std::move(b));
+}
 
-struct ts_ctx {
-    ts_params params{};
-    std::vector<ts::Pattern> patterns;
-    ts::BlockParams bp{};
-    uint32_t k = 0;                 // uniform pattern length (0 = mixed)
-    uint32_t longest = 0;
-    bool fast_ok = false;           // table-driven tiled kernel usable for the pattern set
-    std::string why_not;            // reason when a scan mode is unsupported
-    int device = 0;
-    int num_cu = 0;
-    uint32_t table_rows = 0, fc_bytes = 0;
-    bool fc_byte_table = true, pair_byte_table = false;
-    // general kernels (generic.hip): sorted 2-bit codes per pattern length
-    bool generic_ok = false;
-    TsGenericPatterns gpat{};
-    DevBuf d_gcodes, d_gflags;
-    DevBuf d_table;
-    mutable std::mutex mtx;
-    mutable std::string error;
-    bool read_filter = false;
-    // pinned staging ring for host -> device uploads (batch_upload_all)
-    void *pin[2] = {nullptr, nullptr};
-    hipEvent_t pin_ev[2] = {nullptr, nullptr};
-    hipStream_t up_stream = nullptr;
-
-    mutable std::mutex err_mtx;
-    std::mutex api_mtx;             // ts_scan_segments / ts_scan_segments_blocks / ts_filter_reads run one at a time per context
-                                    // (they share the pinned upload ring; results never depend on call order)
-    int fail(int code, const std::string &msg) const { std::lock_guard<std::mutex> g(err_mtx); error = msg; return code; }
-};
+void BufferPool::clear() {
+    std::lock_guard<std::mutex> g(m_);
+    free_.clear();
+    held_ = 0;
+}
 
 namespace {
-
-struct Region {                     // one scanned interval of a segment
-    uint64_t start, len;            // relative to the segment
-    uint32_t first_tile, n_tiles;
-    uint64_t tile_bases;            // owned bases per tile
-};
-
-struct SegPlan {
-    uint64_t len = 0, abs_pos = 0;
-    uint64_t in_off = 0;            // byte offset in the device input buffer
-    uint64_t win_base = 0, n_windows = 0;
-    uint32_t first_tile = 0, n_tiles = 0;
-    std::vector<Region> regions;
-};
-
-}  // namespace
-
-struct ts_batch {
-    ts_ctx *ctx = nullptr;
-    bool tips = false;
-    std::vector<SegPlan> segs;
-    std::vector<TsTile> tiles;
-    TsScanParams kp{};
-    uint32_t grid = 0, lds_bytes = 0;
-    uint64_t total_bases = 0, input_bytes = 0, n_windows = 0, match_cap = 0;
-    uint64_t n_matches = 0;
-    double last_ms = 0.0;
-    bool scanned = false, synced = false;
-    const void *last_input = nullptr;
-    void *last_stream = nullptr;
-    DevBuf d_in, d_tiles, d_windows, d_matches, d_tile_off, d_stats, d_fill, d_segtab, d_dense, d_dense_base;
-    uint32_t total_waves = 0, region_cap = 0;
-    std::vector<uint32_t> wave_fill;
-    std::vector<hipEvent_t> evs;                 // ring of {start, stop} pairs, one per enqueued scan
-    uint64_t scan_seq = 0, harvested = 0;        // scans enqueued / scans whose time has been read
-    double avg_ms = 0.0;
-    uint64_t avg_n = 0;
-};
-
-namespace {
-
-#define HIP_TRY(ctx, expr)                                                                   \
-    do {                                                                                     \
-        hipError_t _e = (expr);                                                              \
-        if (_e != hipSuccess)                                                                \
-            return (ctx)->fail(TS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-    } while (0)
-
-uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 constexpr uint32_t kMaxLds = 160u * 1024u;
 constexpr uint64_t kEventRing = 64;            // scans whose HIP-event times a batch remembers
@@ -241,17 +186,99 @@ void add_region_tiles(ts_batch *b, SegPlan &sp, uint32_t seg_index, uint64_t sta
     sp.regions.push_back(rg);
 }
 
-int batch_alloc_outputs(ts_batch *b) {
+// the first tile at or after `t` whose segment differs from tile t's is found by the callers; here: the range
+// [lo, hi) of tiles -> what it covers (window records, bytes of the input layout, owned bases)
+void range_cover(const ts_batch *b, uint64_t lo, uint64_t hi, ts_range_info &r) {
+    r = ts_range_info{};
+    r.tile_begin = lo; r.tile_end = hi;
+    if (lo >= hi) return;
+    const TsTile &first = b->tiles[lo];
+    r.window_begin = b->tips ? 0 : first.win_out;
+    r.window_end = r.window_begin;
+    r.input_begin = first.in_off & ~15ull;
+    uint64_t in_end = 0;
+    for (uint64_t t = lo; t < hi; ++t) {
+        const TsTile &T = b->tiles[t];
+        r.bases += T.own_len;
+        if (!b->tips) r.window_end = std::max<uint64_t>(r.window_end, T.win_out + T.nwin);
+        // what ts_scan_tiles loads for this tile: nch chunks of TS_CHUNK positions from the 16-byte-aligned
+        // address at or below its first base, each lane 32 bytes (the last lane reaches 32 bytes past a chunk)
+        const uint32_t sh = (uint32_t)(T.in_off & 15ull);
+        const uint64_t span = (uint64_t)(T.nwin + b->kp.halo_blocks) * b->kp.s;
+        const uint64_t need = sh + std::min<uint64_t>(T.nrel, span + 16u);
+        uint64_t nch = (need + 16u + TS_CHUNK - 1u) / TS_CHUNK;
+        nch = std::min<uint64_t>(std::max<uint64_t>(nch, 1), b->kp.nch);
+        in_end = std::max<uint64_t>(in_end, (T.in_off - sh) + nch * TS_CHUNK + 64u);
+    }
+    r.input_end = std::min<uint64_t>(in_end, b->input_bytes);
+}
+
+}  // namespace
+
+// Allocates (from the context's pool) the device state of the batch's tile range; idempotent.
+int ts_batch_ensure_device(ts_batch *b) {
     ts_ctx *c = b->ctx;
-    const size_t nt = b->tiles.size();
-    HIP_TRY(c, b->d_tiles.ensure(nt * sizeof(TsTile)));
-    HIP_TRY(c, b->d_windows.ensure(std::max<uint64_t>(b->n_windows, 1) * 32));
-    HIP_TRY(c, b->d_matches.ensure((uint64_t)b->region_cap * b->total_waves * 4));
-    HIP_TRY(c, b->d_tile_off.ensure((nt + 1) * 8));
-    HIP_TRY(c, b->d_stats.ensure((nt + 1) * 16));
-    HIP_TRY(c, b->d_fill.ensure((size_t)b->total_waves * 4 + 16));
-    if (nt) HIP_TRY(c, hipMemcpy(b->d_tiles.p, b->tiles.data(), nt * sizeof(TsTile), hipMemcpyHostToDevice));
+    if (b->allocated) return TS_OK;
+    DEVICE_TRY(c);
+    const size_t nt = (size_t)b->range_tiles();
+    if (b->evs.empty()) {
+        b->evs.assign(2 * kEventRing, nullptr);
+        for (hipEvent_t &e : b->evs) HIP_TRY(c, hipEventCreate(&e));
+    }
+    HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * sizeof(TsTile), b->d_tiles));
+    if (!b->ext_windows) HIP_TRY(c, c->pool.take(std::max<uint64_t>(b->win_hi - b->win_lo, 1) * 32, b->d_windows));
+    HIP_TRY(c, c->pool.take(std::max<uint64_t>((uint64_t)b->region_cap * b->total_waves, 4) * 4, b->d_matches));
+    HIP_TRY(c, c->pool.take((nt + 1) * 8, b->d_tile_off));
+    if (!b->ext_stats) HIP_TRY(c, c->pool.take((nt + 1) * 16, b->d_stats));
+    HIP_TRY(c, c->pool.take((size_t)b->total_waves * 4 + 16, b->d_fill));
+    if (nt) HIP_TRY(c, hipMemcpy(b->d_tiles.p, b->tiles.data() + b->tile_lo, nt * sizeof(TsTile), hipMemcpyHostToDevice));
+    if (ts_k_prepare(b->lds_bytes) != 0) return c->fail(TS_ERR_HIP, "cannot raise dynamic LDS limit");
+    b->allocated = true;
     return TS_OK;
+}
+
+void ts_batch_release_input(ts_batch *b) {
+    if (b && b->d_in.p) b->ctx->pool.give(std::move(b->d_in));
+}
+
+namespace {
+
+// Sizes the launch (one persistent workgroup per CU, tiles dealt round-robin to its waves) and the per-wave
+// record regions for the batch's tile range.  Every wave appends to its own region of the match buffer;
+// small ranges get the worst case (every base a match), large ones bases/4 spread evenly, grown on overflow
+// by ts_batch_sync (worst case for wave w = the owned bases of the tiles it is dealt: t = w, w + waves, ...).
+void size_launch(ts_batch *b) {
+    const uint32_t wpw = b->kp.waves_per_wg;
+    const uint64_t nt = b->range_tiles();
+    const int ncu = b->ctx->num_cu > 0 ? b->ctx->num_cu : 256;
+    b->grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(nt, wpw), 1), (uint64_t)ncu);
+    b->total_waves = b->grid * wpw;
+    uint64_t worst = 256;
+    {
+        std::vector<uint64_t> per_wave(b->total_waves, 0);
+        for (uint64_t t = 0; t < nt; ++t) per_wave[t % b->total_waves] += b->tiles[b->tile_lo + t].own_len;
+        for (uint64_t v : per_wave) worst = std::max(worst, v);
+    }
+    const uint64_t want = b->match_cap_request ? b->match_cap_request : b->range_bases / 4 + 4096;
+    uint64_t cap = ceil_div(want, b->total_waves);
+    if (b->range_bases <= (64ull << 20) && !b->match_cap_request) cap = worst;
+    cap = std::min<uint64_t>(std::max<uint64_t>(cap, 256), worst);
+    b->region_cap = (uint32_t)((cap + 3) & ~3ull);
+    b->match_cap = (uint64_t)b->region_cap * b->total_waves;
+}
+
+void set_range(ts_batch *b, uint64_t lo, uint64_t hi) {
+    ts_range_info r;
+    range_cover(b, lo, hi, r);
+    b->tile_lo = lo; b->tile_hi = hi;
+    b->win_lo = r.window_begin; b->win_hi = r.window_end;
+    b->in_lo = r.input_begin; b->in_hi = r.input_end;
+    b->range_bases = r.bases;
+    if (lo == 0 && hi == b->tiles.size()) {          // the whole plan: every byte of the layout, every window
+        b->in_lo = 0; b->in_hi = b->input_bytes;
+        b->win_lo = 0; b->win_hi = b->n_windows;
+    }
+    size_launch(b);
 }
 
 }  // namespace
@@ -324,8 +351,9 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
         g_create_error = "ts_create: need 0 < step <= window_size";
         return nullptr;
     }
+    const bool plan_only = params->device == kNoDevice;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    if (!plan_only && (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)) {
         g_create_error = "ts_create: no usable HIP device (libteloscan has no CPU fallback)";
         return nullptr;
     }
@@ -338,17 +366,22 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
         c->params.out_gc = c->params.out_entropy = c->params.out_matches = c->params.out_its = 0;
         c->params.fold_case = 1;
     }
-    int dev = params->device;
-    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
-    if (dev >= ndev || hipSetDevice(dev) != hipSuccess) {
-        g_create_error = "ts_create: cannot select HIP device";
-        delete c;
-        return nullptr;
+    if (plan_only) {
+        c->device = kNoDevice;
+        c->num_cu = 256;                                 // MI355X: the plan of a batch does not depend on it (the launch grid does)
+    } else {
+        int dev = params->device;
+        if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+        if (dev >= ndev || hipSetDevice(dev) != hipSuccess) {
+            g_create_error = "ts_create: cannot select HIP device";
+            delete c;
+            return nullptr;
+        }
+        c->device = dev;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+        if (c->num_cu <= 0) c->num_cu = 256;
     }
-    c->device = dev;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->num_cu = prop.multiProcessorCount;
-    if (c->num_cu <= 0) c->num_cu = 256;
 
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
     for (size_t i = 0; i < n_patterns; ++i) {
@@ -399,7 +432,9 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
             }
             c->gpat.first[lens.size()] = (uint32_t)codes.size();
         }
-        if (ok && c->d_gcodes.ensure(codes.size() * 8) == hipSuccess && c->d_gflags.ensure(flags.size() + 16) == hipSuccess &&
+        if (ok && plan_only) {
+            c->generic_ok = true;                        // (tables stay on the host: nothing is ever launched)
+        } else if (ok && c->d_gcodes.ensure(codes.size() * 8) == hipSuccess && c->d_gflags.ensure(flags.size() + 16) == hipSuccess &&
             hipMemcpy(c->d_gcodes.p, codes.data(), codes.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(c->d_gflags.p, flags.data(), flags.size(), hipMemcpyHostToDevice) == hipSuccess) {
             c->gpat.codes = (const unsigned long long *)c->d_gcodes.p;
@@ -440,8 +475,8 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
             c->k = 0;
             c->why_not = "pattern length outside 3..8 or non-ACGT pattern";
         } else {
-            if (c->d_table.ensure(table.size() * 4) != hipSuccess ||
-                hipMemcpy(c->d_table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            if (!plan_only && (c->d_table.ensure(table.size() * 4) != hipSuccess ||
+                hipMemcpy(c->d_table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) {
                 g_create_error = "ts_create: cannot upload match table";
                 delete c;
                 return nullptr;
@@ -463,21 +498,31 @@ ts_ctx *ts_create_read_filter(const ts_params *params, int min_block_len_set,
 
 void ts_destroy(ts_ctx *ctx) {
     if (!ctx) return;
-    ctx->d_table.release();
-    ctx->d_gcodes.release();
-    ctx->d_gflags.release();
-    for (int i = 0; i < 2; ++i) {
-        if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
-        if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
+    if (ctx->device != kNoDevice) {
+        DeviceGuard g(ctx->device);
+        ctx->d_table.release();
+        ctx->d_gcodes.release();
+        ctx->d_gflags.release();
+        ctx->pool.clear();
+        for (int i = 0; i < ts_ctx::kUpSlots; ++i) {
+            ctx->pin_up[i].release();
+            if (ctx->pin_up_ev[i]) (void)hipEventDestroy(ctx->pin_up_ev[i]);
+        }
+        for (PinBuf &pb : ctx->pin_down) pb.release();
+        for (hipStream_t st : {ctx->up_stream, ctx->scan_stream, ctx->down_stream})
+            if (st) (void)hipStreamDestroy(st);
+        delete ctx;
+        return;
     }
-    if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
     delete ctx;
 }
+
+}  // extern "C"
 
 // The tiled kernel implements the closed form of the reference's carry loop, valid when
 // w == s or longest <= min(s, w - s); outside it the reference's uint32
 // arithmetic wraps and only a literal emulation reproduces it.
-static bool full_scan_supported(const ts_ctx *c, std::string &why) {
+bool ts_full_scan_supported(const ts_ctx *c, std::string &why) {
     if (!c->fast_ok) { why = c->why_not; return false; }
     const uint32_t s = c->params.step, w = c->params.window_size, ov = w - s, L = c->longest;
     if (L > w) { why = "pattern longer than window"; return false; }
@@ -491,23 +536,25 @@ static bool full_scan_supported(const ts_ctx *c, std::string &why) {
     return true;
 }
 
+extern "C" {
+
 int ts_uses_fast_path(const ts_ctx *ctx) {
     std::string why;
-    return ctx && full_scan_supported(ctx, why) ? 1 : 0;
+    return ctx && ts_full_scan_supported(ctx, why) ? 1 : 0;
 }
 
 // =========================================================================== batches
+// Planning is host work only (it also runs on a planning-only context); device state is allocated from the
+// context's pool when the batch first needs it.
 ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t *abs_pos,
                           size_t n_segs, int tips_only, uint64_t match_capacity) {
     if (!ctx) return nullptr;
-    std::lock_guard<std::mutex> lk(ctx->mtx);
     if (n_segs && !seg_lens) { ctx->fail(TS_ERR_INVALID_ARG, "ts_batch_create: null seg_lens"); return nullptr; }
     std::string why;
-    if (tips_only ? !ctx->fast_ok : !full_scan_supported(ctx, why)) {
+    if (tips_only ? !ctx->fast_ok : !ts_full_scan_supported(ctx, why)) {
         ctx->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: " + (tips_only ? ctx->why_not : why));
         return nullptr;
     }
-    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->fail(TS_ERR_HIP, "hipSetDevice failed"); return nullptr; }
 
     ts_batch *b = new ts_batch();
     b->ctx = ctx;
@@ -518,6 +565,7 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
         delete b;
         return nullptr;
     }
+    b->wpt = wpt;
     if (getenv("TS_TIMING"))
         fprintf(stderr, "ts_batch_create: %s scan, k=%u (%s pair table), %u waves per workgroup, %u chunks and %u windows per tile, LDS %d B "
                         "(match queue %u, record stage %u, %u accumulator copies)\n", b->tips ? "tips-only" : "window", ctx->k,
@@ -554,56 +602,28 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
     }
     b->input_bytes = off + TS_IN_PAD;
     b->n_windows = wins;
-    b->match_cap = match_capacity ? match_capacity : b->total_bases / 4 + 4096;
+    b->match_cap_request = match_capacity;
     if (b->tiles.size() >= 0x7FFFFFFFull) {
         ctx->fail(TS_ERR_UNSUPPORTED, "too many tiles in one batch");
         delete b;
         return nullptr;
     }
-
     b->lds_bytes = (uint32_t)ts_k_lds_bytes(&b->kp);
-    if (ts_k_prepare(b->lds_bytes) != 0) {
-        ctx->fail(TS_ERR_HIP, "cannot raise dynamic LDS limit");
-        delete b;
-        return nullptr;
-    }
-    // one persistent workgroup per CU; tiles are dealt round-robin to its waves
-    const uint32_t wpw = b->kp.waves_per_wg;
-    b->grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(b->tiles.size(), wpw), 1), (uint64_t)ctx->num_cu);
-    b->total_waves = b->grid * wpw;
-    // every wave appends to its own region of the match buffer; small batches get the worst case
-    // (every base a match), large ones bases/4 spread evenly, grown on overflow by ts_batch_sync
-    // (worst case for wave w = the owned bases of the tiles it is dealt: t = w, w + waves, ...)
-    uint64_t worst = 256;
-    {
-        std::vector<uint64_t> per_wave(b->total_waves, 0);
-        for (size_t t = 0; t < b->tiles.size(); ++t) per_wave[t % b->total_waves] += b->tiles[t].own_len;
-        for (uint64_t v : per_wave) worst = std::max(worst, v);
-    }
-    uint64_t cap = ceil_div(b->match_cap, b->total_waves);
-    if (b->total_bases <= (64ull << 20) && !match_capacity) cap = worst;
-    cap = std::min<uint64_t>(std::max<uint64_t>(cap, 256), worst);
-    b->region_cap = (uint32_t)((cap + 3) & ~3ull);
-    b->match_cap = (uint64_t)b->region_cap * b->total_waves;
-
-    bool ev_ok = true;
-    b->evs.assign(2 * kEventRing, nullptr);
-    for (hipEvent_t &e : b->evs) ev_ok = ev_ok && hipEventCreate(&e) == hipSuccess;
-    if (batch_alloc_outputs(b) != TS_OK || !ev_ok) {
-        if (ctx->error.empty()) ctx->fail(TS_ERR_HIP, "batch allocation failed");
-        ts_batch_destroy(b);
-        return nullptr;
-    }
+    set_range(b, 0, b->tiles.size());
     return b;
 }
 
 void ts_batch_destroy(ts_batch *b) {
     if (!b) return;
-    b->d_in.release(); b->d_tiles.release(); b->d_windows.release(); b->d_matches.release();
-    b->d_tile_off.release(); b->d_stats.release(); b->d_fill.release(); b->d_dense.release(); b->d_dense_base.release();
-    b->d_segtab.release();
-    for (hipEvent_t e : b->evs)
-        if (e) (void)hipEventDestroy(e);
+    ts_ctx *c = b->ctx;
+    if (c->device != kNoDevice) {
+        DeviceGuard g(c->device);
+        for (DevBuf *d : {&b->d_in, &b->d_tiles, &b->d_windows, &b->d_matches, &b->d_tile_off, &b->d_stats, &b->d_fill,
+                          &b->d_segtab, &b->d_dense, &b->d_dense_base, &b->d_scan_tmp, &b->d_readtab})
+            c->pool.give(std::move(*d));
+        for (hipEvent_t e : b->evs)
+            if (e) (void)hipEventDestroy(e);
+    }
     delete b;
 }
 
@@ -611,57 +631,126 @@ uint64_t ts_batch_segment_offset(const ts_batch *b, size_t i) {
     return (b && i < b->segs.size()) ? b->segs[i].in_off : 0;
 }
 
+int ts_batch_get_tiles(const ts_batch *b, uint64_t first, uint64_t n, ts_tile_info *out) {
+    if (!b || (n && !out) || first > b->tiles.size() || n > b->tiles.size() - first) return TS_ERR_INVALID_ARG;
+    for (uint64_t i = 0; i < n; ++i) {
+        const TsTile &T = b->tiles[first + i];
+        out[i].seg_index = T.seg;
+        out[i].seg_offset = T.in_off - b->segs[T.seg].in_off;
+        out[i].first_window = b->tips ? 0 : T.win_out;
+        out[i].n_windows = b->tips ? 0 : T.nwin;
+        out[i].owned_bases = T.own_len;
+    }
+    return TS_OK;
+}
+
+int ts_batch_range_info(const ts_batch *b, uint64_t tile_begin, uint64_t tile_end, ts_range_info *out) {
+    if (!b || !out || tile_begin > tile_end || tile_end > b->tiles.size()) return TS_ERR_INVALID_ARG;
+    range_cover(b, tile_begin, tile_end, *out);
+    return TS_OK;
+}
+
+int ts_batch_partition(const ts_batch *b, uint32_t n_parts, uint32_t part, uint64_t *tile_begin, uint64_t *tile_end) {
+    if (!b || !n_parts || part >= n_parts || !tile_begin || !tile_end) return TS_ERR_INVALID_ARG;
+    // boundary q = the first tile whose preceding owned bases reach q/n_parts of the total (tiles are near-equal
+    // work: ~wpt*s bases each), so every part gets the same bases +- one tile and the parts are consecutive
+    uint64_t total = 0;
+    for (const TsTile &T : b->tiles) total += T.own_len;
+    auto boundary = [&](uint32_t q) -> uint64_t {
+        if (q == 0) return 0;
+        if (q >= n_parts) return b->tiles.size();
+        const unsigned __int128 target = (unsigned __int128)total * q;
+        uint64_t acc = 0, t = 0;
+        for (; t < b->tiles.size(); ++t) {
+            if ((unsigned __int128)acc * n_parts >= target) break;
+            acc += b->tiles[t].own_len;
+        }
+        return t;
+    };
+    *tile_begin = boundary(part);
+    *tile_end = boundary(part + 1);
+    return TS_OK;
+}
+
+int ts_batch_restrict(ts_batch *b, uint64_t tile_begin, uint64_t tile_end) {
+    if (!b || tile_begin > tile_end || tile_end > b->tiles.size()) return TS_ERR_INVALID_ARG;
+    if (b->allocated || b->scanned) return b->ctx->fail(TS_ERR_STATE, "ts_batch_restrict after the batch was used on the device");
+    set_range(b, tile_begin, tile_end);
+    return TS_OK;
+}
+
+int ts_batch_bind_results(ts_batch *b, void *d_windows, void *d_tile_stats) {
+    if (!b) return TS_ERR_INVALID_ARG;
+    if (b->allocated || b->scanned) return b->ctx->fail(TS_ERR_STATE, "ts_batch_bind_results after the batch was used on the device");
+    b->ext_windows = (uint32_t *)d_windows;
+    b->ext_stats = (uint32_t *)d_tile_stats;
+    return TS_OK;
+}
+
 // The kernels never look past a segment's end (the padding between segments is masked by position), so
 // zero-filling only serves callers that fill the buffer piecewise and later inspect it.
 static void *batch_input(ts_batch *b, bool zero_fill) {
-    if (!b) return nullptr;
+    if (!b || b->ctx->device == kNoDevice) return nullptr;
     if (!b->d_in.p) {
-        if (b->d_in.ensure(b->input_bytes) != hipSuccess) return nullptr;
-        if (zero_fill) (void)hipMemset(b->d_in.p, 0, b->input_bytes);
+        DeviceGuard g(b->ctx->device);
+        const size_t bytes = (size_t)(b->in_hi - b->in_lo) + 64;
+        if (b->ctx->pool.take(bytes, b->d_in) != hipSuccess) return nullptr;
+        if (zero_fill) (void)hipMemset(b->d_in.p, 0, bytes);
     }
     return b->d_in.p;
 }
 
 void *ts_batch_input_ptr(ts_batch *b) { return batch_input(b, true); }
+}  // extern "C"
+void *ts_batch_input_ptr_nozero(ts_batch *b) { return batch_input(b, false); }
+extern "C" {
 
 int ts_batch_upload(ts_batch *b, size_t i, const char *seq) {
     if (!b || i >= b->segs.size() || (!seq && b->segs[i].len)) return TS_ERR_INVALID_ARG;
     ts_ctx *c = b->ctx;
+    DEVICE_TRY(c);
     if (!ts_batch_input_ptr(b)) return c->fail(TS_ERR_ALLOC, "cannot allocate device input buffer");
-    if (b->segs[i].len)
-        HIP_TRY(c, hipMemcpy((char *)b->d_in.p + b->segs[i].in_off, seq, b->segs[i].len, hipMemcpyHostToDevice));
+    // the part of the segment the batch's range reads
+    const uint64_t s0 = std::max<uint64_t>(b->segs[i].in_off, b->in_lo);
+    const uint64_t s1 = std::min<uint64_t>(b->segs[i].in_off + b->segs[i].len, b->in_hi);
+    if (s1 > s0)
+        HIP_TRY(c, hipMemcpy((char *)b->d_in.p + (s0 - b->in_lo), seq + (s0 - b->segs[i].in_off), s1 - s0, hipMemcpyHostToDevice));
     return TS_OK;
 }
 
 int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
     if (!b) return TS_ERR_INVALID_ARG;
     ts_ctx *c = b->ctx;
-    std::lock_guard<std::mutex> lk(c->mtx);
-    HIP_TRY(c, hipSetDevice(c->device));
+    DEVICE_TRY(c);
+    if (b->dense) return c->fail(TS_ERR_STATE, "ts_batch_scan on a batch that adopted results");
+    { int rc = ts_batch_ensure_device(b); if (rc != TS_OK) return rc; }
     if (!d_input) d_input = ts_batch_input_ptr(b);
     if (!d_input) return c->fail(TS_ERR_ALLOC, "no device input buffer");
     hipStream_t st = (hipStream_t)stream;
-    const size_t nt = b->tiles.size();
     b->last_input = d_input;
     b->last_stream = stream;
     b->scanned = true;
     b->synced = false;
 
+    // The device sees the range's slice of every array; tile descriptors carry offsets of the WHOLE plan
+    // (in_off into the input layout, win_out into the window array), so those two base pointers are shifted
+    // back by what precedes the range (never dereferenced there).
     TsScanParams &kp = b->kp;
-    kp.in = (const uint8_t *)d_input;
+    kp.in = (const uint8_t *)d_input - b->in_lo;
     kp.tiles = (const TsTile *)b->d_tiles.p;
     kp.table = (const uint32_t *)c->d_table.p;
-    kp.windows_out = (uint32_t *)b->d_windows.p;
+    kp.windows_out = b->windows_ptr() - b->win_lo * 8ull;
     kp.matches_out = (uint32_t *)b->d_matches.p;
     kp.tile_off = (unsigned long long *)b->d_tile_off.p;
-    kp.tile_stats = (uint32_t *)b->d_stats.p;
+    kp.tile_stats = b->stats_ptr();
     kp.wave_fill = (uint32_t *)b->d_fill.p;
     kp.region_cap = b->region_cap;
-    kp.ntiles = (uint32_t)nt;
+    kp.ntiles = (uint32_t)b->range_tiles();
 
     const size_t slot = (size_t)(b->scan_seq % kEventRing);
     HIP_TRY(c, hipEventRecord(b->evs[2 * slot], st));
     {
+        std::lock_guard<std::mutex> lk(c->mtx);
         int e = ts_k_launch_scan(&kp, b->grid, b->lds_bytes, stream);
         if (e != 0) return c->fail(TS_ERR_HIP, std::string("scan kernel launch: ") + hipGetErrorString((hipError_t)e));
     }
@@ -673,8 +762,9 @@ int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
 int ts_batch_sync(ts_batch *b) {
     if (!b) return TS_ERR_INVALID_ARG;
     ts_ctx *c = b->ctx;
+    if (b->dense && b->synced) return TS_OK;
     if (!b->scanned) return c->fail(TS_ERR_STATE, "ts_batch_sync before ts_batch_scan");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DEVICE_TRY(c);
     for (int attempt = 0; attempt < 3; ++attempt) {
         {   // kernel times of the scans since the previous sync (the ring keeps the latest kEventRing)
             const size_t last = (size_t)((b->scan_seq - 1) % kEventRing);
@@ -695,7 +785,8 @@ int ts_batch_sync(ts_batch *b) {
             b->harvested = b->scan_seq;
         }
         b->wave_fill.assign(b->total_waves, 0u);
-        HIP_TRY(c, hipMemcpy(b->wave_fill.data(), b->d_fill.p, (size_t)b->total_waves * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpyAsync(b->wave_fill.data(), b->d_fill.p, (size_t)b->total_waves * 4, hipMemcpyDeviceToHost, (hipStream_t)b->last_stream));
+        HIP_TRY(c, hipStreamSynchronize((hipStream_t)b->last_stream));
         uint64_t total = 0;
         uint32_t worst = 0;
         for (uint32_t f : b->wave_fill) { total += f; worst = std::max(worst, f); }
@@ -704,7 +795,10 @@ int ts_batch_sync(ts_batch *b) {
         // a wave's region overflowed: size the regions for the fullest wave and rescan
         b->region_cap = (uint32_t)(((uint64_t)worst + worst / 8 + 64 + 3) & ~3ull);
         b->match_cap = (uint64_t)b->region_cap * b->total_waves;
-        HIP_TRY(c, b->d_matches.ensure(b->match_cap * 4));
+        if (b->d_matches.bytes < b->match_cap * 4) {
+            c->pool.give(std::move(b->d_matches));
+            HIP_TRY(c, c->pool.take(b->match_cap * 4, b->d_matches));
+        }
         int rc = ts_batch_scan(b, b->last_input, b->last_stream);
         if (rc != TS_OK) return rc;
     }
@@ -720,19 +814,69 @@ int ts_batch_get_info(const ts_batch *b, ts_batch_info *info) {
     info->n_tiles = b->tiles.size();
     info->match_capacity = b->match_cap;
     info->n_matches = b->synced ? b->n_matches : 0;
-    info->algorithmic_bytes = b->total_bases + 32ull * b->n_windows + 4ull * info->n_matches;
+    // of the range the batch executes: the whole plan unless restricted
+    info->algorithmic_bytes = b->range_bases + 32ull * (b->win_hi - b->win_lo) + 4ull * info->n_matches;
     info->last_kernel_ms = b->last_ms;
     info->avg_kernel_ms = b->avg_ms;
     info->kernel_launches = b->avg_n;
     return TS_OK;
 }
 
-const void *ts_batch_windows_ptr(const ts_batch *b) { return b ? b->d_windows.p : nullptr; }
-const void *ts_batch_matches_ptr(const ts_batch *b) { return b ? b->d_matches.p : nullptr; }
+const void *ts_batch_windows_ptr(const ts_batch *b) { return b ? b->windows_ptr() : nullptr; }
+const void *ts_batch_matches_ptr(const ts_batch *b) { return b ? b->records_ptr() : nullptr; }
+const void *ts_batch_tile_stats_ptr(const ts_batch *b) { return b ? b->stats_ptr() : nullptr; }
+
+int ts_batch_export(ts_batch *b, void *d_dense, uint64_t dense_capacity, void *d_total, void *stream) {
+    if (!b || !d_dense || !d_total) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    DEVICE_TRY(c);
+    if (!b->scanned || b->dense) return c->fail(TS_ERR_STATE, "ts_batch_export needs a scanned batch");
+    const uint32_t nt = (uint32_t)b->range_tiles();
+    HIP_TRY(c, b->d_dense_base.p && b->d_dense_base.bytes >= ((size_t)nt + 1) * 8 ? hipSuccess : c->pool.take(((size_t)nt + 1) * 8, b->d_dense_base));
+    const size_t tmp_bytes = (size_t)ts_k_scan_tmp_bytes(nt);
+    HIP_TRY(c, b->d_scan_tmp.p && b->d_scan_tmp.bytes >= tmp_bytes ? hipSuccess : c->pool.take(tmp_bytes, b->d_scan_tmp));
+    int e = ts_k_launch_tile_order_export(b->stats_ptr(), (const unsigned long long *)b->d_tile_off.p, (const uint32_t *)b->d_matches.p,
+                                          (const uint32_t *)b->d_fill.p, b->region_cap, b->total_waves, nt,
+                                          (unsigned long long *)b->d_dense_base.p, b->d_scan_tmp.p, (uint32_t *)d_dense,
+                                          dense_capacity, (unsigned long long *)d_total, stream);
+    if (e != 0) return c->fail(TS_ERR_HIP, std::string("export kernel launch: ") + hipGetErrorString((hipError_t)e));
+    return TS_OK;
+}
+
+int ts_batch_adopt(ts_batch *b, void *d_windows, void *d_tile_stats, const void *d_dense, uint64_t n_matches, void *stream) {
+    if (!b || !d_tile_stats || (n_matches && !d_dense) || (!b->tips && b->n_windows && !d_windows)) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    DEVICE_TRY(c);
+    if (!b->whole()) return c->fail(TS_ERR_STATE, "ts_batch_adopt needs an unrestricted batch");
+    if (b->scanned && !b->dense) return c->fail(TS_ERR_STATE, "ts_batch_adopt on a batch that was scanned locally");
+    const size_t nt = b->tiles.size();
+    if (!b->d_tiles.p) {
+        HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * sizeof(TsTile), b->d_tiles));
+        if (nt) HIP_TRY(c, hipMemcpy(b->d_tiles.p, b->tiles.data(), nt * sizeof(TsTile), hipMemcpyHostToDevice));
+        HIP_TRY(c, c->pool.take((nt + 1) * 8, b->d_tile_off));
+        HIP_TRY(c, c->pool.take((size_t)ts_k_scan_tmp_bytes((uint32_t)nt), b->d_scan_tmp));
+    }
+    b->ext_windows = (uint32_t *)d_windows;
+    b->ext_stats = (uint32_t *)d_tile_stats;
+    b->ext_dense = (const uint32_t *)d_dense;
+    // tile directory of a dense tile-ordered stream: first record of tile t = records of the tiles before it
+    int e = ts_k_launch_tile_offsets(b->ext_stats, (uint32_t)nt, (unsigned long long *)b->d_tile_off.p, b->d_scan_tmp.p, stream);
+    if (e != 0) return c->fail(TS_ERR_HIP, std::string("tile-offset kernel launch: ") + hipGetErrorString((hipError_t)e));
+    HIP_TRY(c, hipStreamSynchronize((hipStream_t)stream));
+    b->dense = true;
+    b->scanned = true;
+    b->synced = true;
+    b->allocated = true;
+    b->n_matches = n_matches;
+    b->last_stream = stream;
+    return TS_OK;
+}
 
 int ts_batch_segment_summary(ts_batch *b, void *d_out, void *stream) {
     if (!b || !d_out) return TS_ERR_INVALID_ARG;
     ts_ctx *c = b->ctx;
+    DEVICE_TRY(c);
+    if (!b->whole()) return c->fail(TS_ERR_STATE, "ts_batch_segment_summary needs an unrestricted batch");
     const size_t ns = b->segs.size();
     if (!b->d_segtab.p) {
         std::vector<uint32_t> first(ns + 1);
@@ -740,17 +884,19 @@ int ts_batch_segment_summary(ts_batch *b, void *d_out, void *stream) {
         for (size_t i = 0; i < ns; ++i) { first[i] = b->segs[i].first_tile; nwin[i] = b->segs[i].n_windows; }
         first[ns] = (uint32_t)b->tiles.size();
         const size_t bytes_first = ((ns + 1) * 4 + 15) & ~15ull;
-        HIP_TRY(c, b->d_segtab.ensure(bytes_first + ns * 8 + 16));
+        HIP_TRY(c, c->pool.take(bytes_first + ns * 8 + 16, b->d_segtab));
         HIP_TRY(c, hipMemcpy(b->d_segtab.p, first.data(), (ns + 1) * 4, hipMemcpyHostToDevice));
         if (ns) HIP_TRY(c, hipMemcpy((char *)b->d_segtab.p + bytes_first, nwin.data(), ns * 8, hipMemcpyHostToDevice));
     }
     const size_t bytes_first = ((ns + 1) * 4 + 15) & ~15ull;
-    int e = ts_k_launch_summary((const uint32_t *)b->d_stats.p, (const uint32_t *)b->d_segtab.p,
+    int e = ts_k_launch_summary(b->stats_ptr(), (const uint32_t *)b->d_segtab.p,
                                 (const uint64_t *)((char *)b->d_segtab.p + bytes_first), (uint32_t)ns,
                                 (unsigned long long *)d_out, stream);
     if (e != 0) return c->fail(TS_ERR_HIP, "summary kernel launch failed");
     return TS_OK;
 }
+
+}  // extern "C"
 
 // --------------------------------------------------------------- shared host post-processing
 // Turns one segment's raw results into SegmentData: window records (float metrics evaluated on
@@ -758,13 +904,13 @@ int ts_batch_segment_summary(ts_batch *b, void *d_out, void *stream) {
 // (src/teloscope.cpp:642-657).  `matches` arrive with absolute positions and FORWARD/CANONICAL set.
 // `matches` (malloc'd by the caller, position-ordered, terminal flags not yet set; may be null when nm == 0)
 // becomes the segment's match array.
-static int finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos,
-                            const uint32_t *win_raw, uint64_t n_windows, ts_match *matches, uint64_t nm,
-                            ts_segment_out &o, unsigned spare_threads) {
+int ts_finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos,
+                        const uint32_t *win_raw, uint64_t n_windows, ts_match *matches, uint64_t nm,
+                        ts_segment_out &o, unsigned spare_threads) {
     const ts_params &P = c->params;
     std::memset(&o, 0, sizeof o);
     if (!tips && n_windows) {
-        o.windows = (ts_window *)std::calloc(n_windows, sizeof(ts_window));
+        o.windows = (ts_window *)std::malloc(n_windows * sizeof(ts_window));
         if (!o.windows) return c->fail(TS_ERR_ALLOC, "out of host memory");
         o.n_windows = n_windows;
         const bool nuc = P.out_gc || P.out_entropy;
@@ -774,6 +920,7 @@ static int finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs
         for (uint64_t kwin = k0; kwin < k1; ++kwin) {
             const uint32_t *r = &win_raw[kwin * 8];
             ts_window &w = o.windows[kwin];
+            std::memset(&w, 0, sizeof w);
             const uint64_t ws = kwin * P.step;
             w.window_start = abs_pos + ws;
             w.current_window_size = (uint32_t)std::min<uint64_t>(P.window_size, seg_len - ws);
@@ -786,7 +933,7 @@ static int finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs
             w.rev_covered = r[7];
         }
         };
-        const unsigned nth = n_windows >= (1u << 18) ? std::min<unsigned>(spare_threads, (unsigned)(n_windows >> 16)) : 1u;
+        const unsigned nth = n_windows >= (1u << 16) ? std::min<unsigned>(spare_threads, (unsigned)(n_windows >> 14)) : 1u;
         if (nth <= 1u) {
             convert(0, n_windows);
         } else {
@@ -834,164 +981,102 @@ static int finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs
     return TS_OK;
 }
 
-// --------------------------------------------------------------- download + host post-processing
-int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out *out) {
-    (void)host_seqs;
-    if (!b || !out) return TS_ERR_INVALID_ARG;
-    ts_ctx *c = b->ctx;
-    if (!b->synced) { int rc = ts_batch_sync(b); if (rc != TS_OK) return rc; }
-    const size_t nt = b->tiles.size(), ns = b->segs.size();
+namespace {
 
-    // (plain arrays: a vector would zero-fill hundreds of MB that the copies below overwrite)
-    const std::unique_ptr<uint32_t[]> wins_buf(new uint32_t[b->n_windows * 8 + 1]), recs_buf(new uint32_t[b->n_matches + 1]);
-    uint32_t *const wins = wins_buf.get(), *const recs = recs_buf.get();
-    const uint64_t nrecs = b->n_matches;
-    // tile directory: records of tile t are recs[tile_off[t] .. +tile_stats[4t]), in position order
-    std::vector<unsigned long long> tile_off(nt + 1);
-    std::vector<uint32_t> tile_stats(4 * (nt + 1));
-    if (b->n_windows) HIP_TRY(c, hipMemcpy(wins, b->d_windows.p, b->n_windows * 32, hipMemcpyDeviceToHost));
-    // pack the per-wave regions into one dense stream on the device, then one D2H copy
-    std::vector<unsigned long long> dense_base(b->total_waves + 1, 0);
-    for (uint32_t w = 0; w < b->total_waves; ++w) dense_base[w + 1] = dense_base[w] + b->wave_fill[w];
-    if (b->n_matches) {
-        HIP_TRY(c, b->d_dense.ensure(b->n_matches * 4));
-        HIP_TRY(c, b->d_dense_base.ensure((size_t)(b->total_waves + 1) * 8));
-        HIP_TRY(c, hipMemcpy(b->d_dense_base.p, dense_base.data(), (size_t)(b->total_waves + 1) * 8, hipMemcpyHostToDevice));
-        int e = ts_k_launch_compact((const uint32_t *)b->d_matches.p, (const uint32_t *)b->d_fill.p,
-                                    (const unsigned long long *)b->d_dense_base.p, b->region_cap,
-                                    b->total_waves, (uint32_t *)b->d_dense.p, nullptr);
-        if (e != 0) return c->fail(TS_ERR_HIP, "compaction kernel launch failed");
-        HIP_TRY(c, hipMemcpy(recs, b->d_dense.p, b->n_matches * 4, hipMemcpyDeviceToHost));
-    }
-    if (nt) HIP_TRY(c, hipMemcpy(tile_off.data(), b->d_tile_off.p, nt * 8, hipMemcpyDeviceToHost));
-    if (nt) HIP_TRY(c, hipMemcpy(tile_stats.data(), b->d_stats.p, nt * 16, hipMemcpyDeviceToHost));
-    // region offset -> dense offset (tile t was scanned by wave t mod total_waves)
-    for (size_t t = 0; t < nt; ++t) {
-        const uint32_t w = (uint32_t)(t % b->total_waves);
-        tile_off[t] = tile_off[t] - (unsigned long long)w * b->region_cap + dense_base[w];
-    }
-
-    // Host post-processing (absolute positions, terminal flags, block calling, float window metrics)
-    // is O(matches) per segment and independent between segments: one job per segment, largest
-    // first, on up to 16 host threads — the reference's own decomposition (one job per path).
-    const uint16_t klen = (uint16_t)c->k;
-    std::vector<size_t> order(ns);
-    for (size_t i = 0; i < ns; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return b->segs[x].len > b->segs[y].len; });
-    std::atomic<size_t> next{0};
-    std::atomic<int> first_err{TS_OK};
-    const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned spare = std::max(1u, std::min(16u, hw_threads) / (unsigned)std::max<size_t>(1, std::min<size_t>(ns, 16)));
-    auto worker = [&]() {
-        for (;;) {
-            const size_t oi = next.fetch_add(1);
-            if (oi >= ns || first_err.load() != TS_OK) return;
-            const size_t si = order[oi];
-            const SegPlan &sp = b->segs[si];
-            // matches: tile-relative packed records -> absolute MatchInfo, tiles in position order
-            uint64_t nm = 0;
-            for (uint32_t t = 0; t < sp.n_tiles; ++t) nm += tile_stats[4ull * (sp.first_tile + t)];
-            ts_match *arr = nm ? (ts_match *)std::malloc(nm * sizeof(ts_match)) : nullptr;
-            if (nm && !arr) { int expected = TS_OK; first_err.compare_exchange_strong(expected, c->fail(TS_ERR_ALLOC, "out of host memory")); return; }
-            uint64_t at = 0;
-            int rc = TS_OK;
-            for (const Region &rg : sp.regions) {
-                for (uint32_t t = 0; t < rg.n_tiles && rc == TS_OK; ++t) {
-                    const uint32_t ti = rg.first_tile + t;
-                    const uint64_t tile_rel = rg.start + (uint64_t)t * rg.tile_bases;   // segment-relative
-                    const uint64_t r0 = tile_off[ti], r1 = r0 + tile_stats[4ull * ti];
-                    if (r1 > nrecs || at + (r1 - r0) > nm) { rc = c->fail(TS_ERR_STATE, "tile directory out of range"); break; }
-                    const uint64_t pos0 = sp.abs_pos + tile_rel;
-                    for (uint64_t ri = r0; ri < r1; ++ri) {
-                        const uint32_t rec = recs[ri];
-                        ts_match &m = arr[at++];
-                        std::memset(&m, 0, sizeof m);
-                        m.position = pos0 + (rec >> 2);
-                        m.match_size = klen;
-                        m.flags = (uint8_t)(((rec & 2u) ? TS_MATCH_FORWARD : 0u) | ((rec & 1u) ? TS_MATCH_CANONICAL : 0u));
-                    }
-                }
-            }
-            if (rc != TS_OK) std::free(arr);
-            if (rc == TS_OK)
-                rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos,
-                                      sp.n_windows ? &wins[sp.win_base * 8] : nullptr, b->tips ? 0 : sp.n_windows,
-                                      arr, nm, out[si], spare);
-            if (rc != TS_OK) { int expected = TS_OK; first_err.compare_exchange_strong(expected, rc); return; }
+// Host landing area of a download: pinned memory of the context when the download fits it (a group of the
+// host entry points' pipeline: DMA at link rate, no runtime staging), plain heap memory otherwise.
+struct HostLanding {
+    std::unique_ptr<char[]> heap;
+    char *base = nullptr;
+    size_t used = 0, cap = 0;
+    static constexpr size_t kPinnedMax = 768ull << 20;
+    HostLanding(PinBuf &pin, size_t bytes) {
+        bytes += 256;
+        if (bytes <= kPinnedMax && pin.ensure(std::max<size_t>(bytes + bytes / 4, 32u << 20)) == hipSuccess) {
+            base = (char *)pin.p;
+        } else {
+            (void)hipGetLastError();
+            heap.reset(new char[bytes]);            // (not zero-filled)
+            base = heap.get();
         }
-    };
-    for (size_t i = 0; i < ns; ++i) std::memset(&out[i], 0, sizeof out[i]);
-    const unsigned nthreads = (unsigned)std::min<size_t>({(size_t)16, ns, (size_t)std::max(1u, std::thread::hardware_concurrency())});
-    if (nthreads <= 1) {
-        worker();
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned i = 0; i < nthreads; ++i) pool.emplace_back(worker);
-        for (std::thread &th : pool) th.join();
+        cap = bytes;
     }
-    return first_err.load();
+    void *carve(size_t bytes) {
+        void *p = base + used;
+        used += (bytes + 63) & ~(size_t)63;
+        return used <= cap ? p : nullptr;
+    }
+};
+
+// f(i) for i in [0, n) on up to max_threads host threads (dynamic: an atomic counter hands out the indices)
+template <typename F>
+void parallel_for(size_t n, unsigned max_threads, F &&f) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (unsigned)std::min<size_t>({(size_t)max_threads, (size_t)hw, n});
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
+    for (std::thread &th : pool) th.join();
 }
 
-// --------------------------------------------------------------- device block calling (row f1)
-int ts_batch_download_blocks(ts_batch *b, ts_segment_out *out) {
-    if (!b || !out) return TS_ERR_INVALID_ARG;
+// Block calling ON THE DEVICE (getTerminalBlocks / getInterstitialBlocks, src/teloscope.cpp:29-256) over the
+// batch's resident match stream: the blocks of all segments, sorted by (segment; terminal blocks in push order:
+// forward walk then reverse walk; interstitial blocks by start).
+int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &blocks) {
     ts_ctx *c = b->ctx;
-    if (!b->synced) { int rc = ts_batch_sync(b); if (rc != TS_OK) return rc; }
     const ts_params &P = c->params;
     const size_t ns = b->segs.size(), nt = b->tiles.size();
-    for (size_t i = 0; i < ns; ++i) std::memset(&out[i], 0, sizeof out[i]);
-    if (ns == 0) return TS_OK;
-
-    std::vector<uint32_t> first(ns + 1);
-    std::vector<unsigned long long> inoff(ns), slen(ns), sabs(ns);
+    blocks.clear();
+    if (!ns) return TS_OK;
+    // segment table for the kernels: {first tile} x uint32, then {input offset, length, absolute position} x uint64
+    const size_t off_first = 0, off_in = (((ns + 1) * 4 + 15) & ~(size_t)15), off_len = off_in + ns * 8, off_abs = off_len + ns * 8,
+                 off_bounds = off_abs + ns * 8, off_count = off_bounds + ns * 16, tab_bytes = off_count + 16;
+    std::vector<char> tab(off_bounds);
     for (size_t i = 0; i < ns; ++i) {
-        first[i] = b->segs[i].first_tile; inoff[i] = b->segs[i].in_off;
-        slen[i] = b->segs[i].len; sabs[i] = b->segs[i].abs_pos;
+        ((uint32_t *)(tab.data() + off_first))[i] = b->segs[i].first_tile;
+        ((unsigned long long *)(tab.data() + off_in))[i] = b->segs[i].in_off;
+        ((unsigned long long *)(tab.data() + off_len))[i] = b->segs[i].len;
+        ((unsigned long long *)(tab.data() + off_abs))[i] = b->segs[i].abs_pos;
     }
-    first[ns] = (uint32_t)nt;
-    DevBuf d_first, d_inoff, d_len, d_abs, d_bounds, d_blocks, d_count;
-    auto release = [&]() { d_first.release(); d_inoff.release(); d_len.release(); d_abs.release();
-                           d_bounds.release(); d_blocks.release(); d_count.release(); };
-    std::vector<TsDevBlock> blocks;
+    ((uint32_t *)(tab.data() + off_first))[ns] = (uint32_t)nt;
+    DevBuf d_tab, d_blocks;
+    struct Return { ts_ctx *c; DevBuf &a, &b2; ~Return() { c->pool.give(std::move(a)); c->pool.give(std::move(b2)); } } give_back{c, d_tab, d_blocks};
+    HIP_TRY(c, c->pool.take(tab_bytes, d_tab));
+    char *const dt = (char *)d_tab.p;
     uint32_t cap = (uint32_t)std::min<uint64_t>(64ull * ns + 4096 + b->n_matches / 256, 1u << 26);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (d_first.ensure((ns + 1) * 4) != hipSuccess || d_inoff.ensure(ns * 8) != hipSuccess ||
-            d_len.ensure(ns * 8) != hipSuccess || d_abs.ensure(ns * 8) != hipSuccess ||
-            d_bounds.ensure(ns * 16) != hipSuccess || d_blocks.ensure((size_t)cap * sizeof(TsDevBlock)) != hipSuccess ||
-            d_count.ensure(16) != hipSuccess) { release(); return c->fail(TS_ERR_ALLOC, "device allocation failed"); }
-        if (hipMemcpy(d_first.p, first.data(), (ns + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(d_inoff.p, inoff.data(), ns * 8, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(d_len.p, slen.data(), ns * 8, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(d_abs.p, sabs.data(), ns * 8, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemset(d_count.p, 0, 16) != hipSuccess) { release(); return c->fail(TS_ERR_HIP, "H2D copy failed"); }
+        HIP_TRY(c, c->pool.take((size_t)cap * sizeof(TsDevBlock), d_blocks));
+        HIP_TRY(c, hipMemcpyAsync(dt, tab.data(), off_bounds, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemsetAsync(dt + off_count, 0, 16, st));
         TsBlockCallParams Q{};
         Q.tiles = (const TsTile *)b->d_tiles.p;
         Q.tile_off = (const unsigned long long *)b->d_tile_off.p;
-        Q.tile_stats = (const uint32_t *)b->d_stats.p;
-        Q.matches = (const uint32_t *)b->d_matches.p;
+        Q.tile_stats = b->stats_ptr();
+        Q.matches = b->records_ptr();
         Q.blocks = (TsDevBlock *)d_blocks.p;
-        Q.n_blocks = (uint32_t *)d_count.p;
+        Q.n_blocks = (uint32_t *)(dt + off_count);
         Q.block_cap = cap;
         Q.terminal_limit = P.terminal_limit; Q.max_match_dist = P.max_match_dist;
         Q.min_block_len = P.min_block_len; Q.max_block_dist = P.max_block_dist;
         Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;
         Q.k = c->k; Q.its_min_len = (uint32_t)(uint16_t)(2 * c->bp.first_pattern_len);
-        if (ts_k_launch_block_call(&Q, (const uint32_t *)d_first.p, (const unsigned long long *)d_inoff.p,
-                                   (const unsigned long long *)d_len.p, (const unsigned long long *)d_abs.p,
-                                   (uint32_t)ns, (uint32_t)nt, (unsigned long long *)d_bounds.p, b->tips ? 0 : 1,
-                                   nullptr) != 0) { release(); return c->fail(TS_ERR_HIP, "block-calling kernel launch failed"); }
+        if (ts_k_launch_block_call(&Q, (const uint32_t *)(dt + off_first), (const unsigned long long *)(dt + off_in),
+                                   (const unsigned long long *)(dt + off_len), (const unsigned long long *)(dt + off_abs),
+                                   (uint32_t)ns, (uint32_t)nt, (unsigned long long *)(dt + off_bounds), b->tips ? 0 : 1,
+                                   st) != 0) return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
         uint32_t nb = 0;
-        if (hipMemcpy(&nb, d_count.p, 4, hipMemcpyDeviceToHost) != hipSuccess) { release(); return c->fail(TS_ERR_HIP, "D2H copy failed"); }
-        if (nb > cap) { cap = nb + 1024; continue; }            // rare: more blocks than provisioned, rerun
+        HIP_TRY(c, hipMemcpyAsync(&nb, dt + off_count, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (nb > cap) { cap = nb + 1024; c->pool.give(std::move(d_blocks)); continue; }   // rare: more blocks than provisioned, rerun
         blocks.resize(nb);
-        if (nb && hipMemcpy(blocks.data(), d_blocks.p, (size_t)nb * sizeof(TsDevBlock), hipMemcpyDeviceToHost) != hipSuccess) {
-            release(); return c->fail(TS_ERR_HIP, "D2H copy failed");
+        if (nb) {
+            HIP_TRY(c, hipMemcpyAsync(blocks.data(), d_blocks.p, (size_t)nb * sizeof(TsDevBlock), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
         }
         break;
     }
-    release();
-
-    // order: terminal blocks in push order (forward walk, then reverse walk); interstitial by start
     std::sort(blocks.begin(), blocks.end(), [](const TsDevBlock &x, const TsDevBlock &y) {
         if (x.seg != y.seg) return x.seg < y.seg;
         const uint32_t kx = x.kind == 2 ? 1 : 0, ky = y.kind == 2 ? 1 : 0;
@@ -999,60 +1084,241 @@ int ts_batch_download_blocks(ts_batch *b, ts_segment_out *out) {
         if (kx) return x.start < y.start;
         return x.kind != y.kind ? x.kind < y.kind : x.seq < y.seq;
     });
-    const std::unique_ptr<uint32_t[]> wins_buf(new uint32_t[(b->tips ? 0 : b->n_windows * 8) + 1]);   // (not zero-filled)
-    uint32_t *const wins = wins_buf.get();
-    if (!b->tips && b->n_windows)
-        HIP_TRY(c, hipMemcpy(wins, b->d_windows.p, b->n_windows * 32, hipMemcpyDeviceToHost));
-    // per segment: window records (float metrics on the host) + its slice of the sorted block list;
-    // independent between segments, so they are finalised on up to 16 host threads
-    std::vector<size_t> blk_begin(ns + 1, blocks.size());
-    {
-        size_t bi = 0;
-        for (size_t si = 0; si < ns; ++si) {
-            blk_begin[si] = bi;
-            while (bi < blocks.size() && blocks[bi].seg == si) ++bi;
-        }
-        blk_begin[ns] = bi;
-    }
-    std::atomic<size_t> next{0};
-    std::atomic<int> first_err{TS_OK};
-    const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned spare = std::max(1u, std::min(16u, hw_threads) / (unsigned)std::max<size_t>(1, std::min<size_t>(ns, 16)));
-    auto worker = [&]() {
-        for (size_t si; (si = next.fetch_add(1)) < ns && first_err.load() == TS_OK;) {
-            const SegPlan &sp = b->segs[si];
-            int rc = finalize_segment(c, b->tips, sp.len, sp.abs_pos, sp.n_windows ? &wins[sp.win_base * 8] : nullptr,
-                                      b->tips ? 0 : sp.n_windows, nullptr, 0, out[si], spare);       // windows only
-            std::vector<ts_block> term, its;
-            for (size_t bi = blk_begin[si]; rc == TS_OK && bi < blk_begin[si + 1]; ++bi) {
-                ts_block t{};
-                std::memcpy(&t, &blocks[bi], sizeof(ts_block));
-                (blocks[bi].kind == 2 ? its : term).push_back(t);
-            }
-            auto put = [&](const std::vector<ts_block> &v, ts_block *&dst, uint64_t &n) -> bool {
-                n = v.size(); dst = nullptr;
-                if (v.empty()) return true;
-                dst = (ts_block *)std::malloc(v.size() * sizeof(ts_block));
-                if (!dst) return false;
-                std::memcpy(dst, v.data(), v.size() * sizeof(ts_block));
-                return true;
-            };
-            if (rc == TS_OK && (!put(term, out[si].terminal_blocks, out[si].n_terminal_blocks) ||
-                                !put(its, out[si].interstitial_blocks, out[si].n_interstitial_blocks)))
-                rc = c->fail(TS_ERR_ALLOC, "out of host memory");
-            if (rc != TS_OK) { int expected = TS_OK; first_err.compare_exchange_strong(expected, rc); return; }
-        }
-    };
-    const unsigned nthreads = (unsigned)std::min<size_t>({(size_t)16, ns, (size_t)std::max(1u, std::thread::hardware_concurrency())});
-    if (nthreads <= 1) {
-        worker();
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned i = 0; i < nthreads; ++i) pool.emplace_back(worker);
-        for (std::thread &th : pool) th.join();
-    }
-    return first_err.load();
+    return TS_OK;
 }
+
+// What a download leaves in host memory before post-processing.
+struct Fetched {
+    std::unique_ptr<HostLanding> land;
+    std::vector<TsDevBlock> blocks;
+    const uint32_t *wins = nullptr, *recs = nullptr, *tile_stats = nullptr;
+    unsigned long long *tile_off = nullptr;
+    uint64_t nrecs = 0;
+    bool with_matches = false;
+};
+
+// Device work + D2H of a synced whole batch (on its stream), into pinned landing area `pin`.
+int batch_fetch(ts_batch *b, bool with_matches, PinBuf &pin, Fetched &F) {
+    ts_ctx *c = b->ctx;
+    const size_t nt = b->tiles.size();
+    hipStream_t st = (hipStream_t)b->last_stream;
+    F.with_matches = with_matches;
+    { int rc = device_block_call(b, st, F.blocks); if (rc != TS_OK) return rc; }
+    const uint64_t nwin_dl = b->tips ? 0 : b->n_windows;
+    const uint64_t nrecs = with_matches ? b->n_matches : 0;
+    F.nrecs = nrecs;
+    F.land.reset(new HostLanding(pin, nwin_dl * 32 + (with_matches ? nrecs * 4 + (nt + 1) * 24 : 0) + 1024));
+    HostLanding &land = *F.land;
+    uint32_t *const wins = (uint32_t *)land.carve(nwin_dl * 32 + 4);
+    if (!wins) return c->fail(TS_ERR_ALLOC, "out of host memory");
+    F.wins = wins;
+    if (nwin_dl) HIP_TRY(c, hipMemcpyAsync(wins, b->windows_ptr(), nwin_dl * 32, hipMemcpyDeviceToHost, st));
+    if (with_matches) {
+        uint32_t *const recs = (uint32_t *)land.carve(nrecs * 4 + 4);
+        // tile directory: records of tile t are recs[tile_off[t] .. +tile_stats[4t]), in position order
+        unsigned long long *const tile_off = (unsigned long long *)land.carve((nt + 1) * 8);
+        uint32_t *const tile_stats = (uint32_t *)land.carve((nt + 1) * 16);
+        if (!recs || !tile_off || !tile_stats) return c->fail(TS_ERR_ALLOC, "out of host memory");
+        F.recs = recs; F.tile_off = tile_off; F.tile_stats = tile_stats;
+        std::vector<unsigned long long> dense_base;
+        if (b->dense) {
+            if (nrecs) HIP_TRY(c, hipMemcpyAsync(recs, b->records_ptr(), nrecs * 4, hipMemcpyDeviceToHost, st));
+        } else if (nrecs) {
+            // pack the per-wave regions into one dense stream on the device, then one D2H copy
+            dense_base.assign(b->total_waves + 1, 0);
+            for (uint32_t w = 0; w < b->total_waves; ++w) dense_base[w + 1] = dense_base[w] + b->wave_fill[w];
+            if (b->d_dense.bytes < nrecs * 4) { c->pool.give(std::move(b->d_dense)); HIP_TRY(c, c->pool.take(nrecs * 4, b->d_dense)); }
+            if (b->d_dense_base.bytes < (size_t)(b->total_waves + 1) * 8) {
+                c->pool.give(std::move(b->d_dense_base));
+                HIP_TRY(c, c->pool.take((size_t)(b->total_waves + 1) * 8, b->d_dense_base));
+            }
+            HIP_TRY(c, hipMemcpyAsync(b->d_dense_base.p, dense_base.data(), (size_t)(b->total_waves + 1) * 8, hipMemcpyHostToDevice, st));
+            int e = ts_k_launch_compact((const uint32_t *)b->d_matches.p, (const uint32_t *)b->d_fill.p,
+                                        (const unsigned long long *)b->d_dense_base.p, b->region_cap,
+                                        b->total_waves, (uint32_t *)b->d_dense.p, st);
+            if (e != 0) return c->fail(TS_ERR_HIP, "compaction kernel launch failed");
+            HIP_TRY(c, hipMemcpyAsync(recs, b->d_dense.p, nrecs * 4, hipMemcpyDeviceToHost, st));
+        }
+        if (nt) HIP_TRY(c, hipMemcpyAsync(tile_off, b->d_tile_off.p, nt * 8, hipMemcpyDeviceToHost, st));
+        if (nt) HIP_TRY(c, hipMemcpyAsync(tile_stats, b->stats_ptr(), nt * 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (!b->dense && nrecs) {
+            // region offset -> dense offset (tile t was scanned by wave t mod total_waves)
+            for (size_t t = 0; t < nt; ++t) {
+                const uint32_t w = (uint32_t)(t % b->total_waves);
+                tile_off[t] = tile_off[t] - (unsigned long long)w * b->region_cap + dense_base[w];
+            }
+        }
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(st));
+    }
+    return TS_OK;
+}
+
+// Host post-processing of a fetched batch: SegmentData per segment.  Everything is independent per window, per
+// tile and per block, so the work is cut into pieces of a few ten thousand records and spread over the host
+// threads whatever the segment sizes are (one 250 Mb contig keeps all threads busy): window records with their
+// float metrics (evaluated on the host from the integer counts, as the reference does), packed records ->
+// MatchInfo with absolute position and the terminal flag (isTerminal, src/teloscope.cpp:451-459), and the
+// device-called blocks.
+int batch_finalize(ts_batch *b, const Fetched &F, ts_segment_out *out) {
+    ts_ctx *c = b->ctx;
+    const ts_params &P = c->params;
+    const size_t ns = b->segs.size();
+    for (size_t i = 0; i < ns; ++i) std::memset(&out[i], 0, sizeof out[i]);
+    const bool nuc = P.out_gc || P.out_entropy;
+    // per-segment arrays
+    std::vector<uint64_t> seg_nm(ns, 0);
+    std::vector<uint64_t> tile_out;                              // output index (within its segment's array) of a tile's first record
+    if (F.with_matches) {
+        tile_out.resize(b->tiles.size());
+        for (size_t si = 0; si < ns; ++si) {
+            const SegPlan &sp = b->segs[si];
+            uint64_t nm = 0;
+            for (uint32_t t = 0; t < sp.n_tiles; ++t) { tile_out[sp.first_tile + t] = nm; nm += F.tile_stats[4ull * (sp.first_tile + t)]; }
+            if (nm > 0xFFFFFFFFull) return c->fail(TS_ERR_UNSUPPORTED, "more than 2^32 matches in one segment");
+            seg_nm[si] = nm;
+        }
+    }
+    int rc = TS_OK;
+    for (size_t si = 0; si < ns && rc == TS_OK; ++si) {
+        const SegPlan &sp = b->segs[si];
+        if (!b->tips && sp.n_windows) {
+            out[si].windows = (ts_window *)std::malloc(sp.n_windows * sizeof(ts_window));
+            if (!out[si].windows) rc = c->fail(TS_ERR_ALLOC, "out of host memory");
+            out[si].n_windows = sp.n_windows;
+        }
+        if (rc == TS_OK && seg_nm[si]) {
+            out[si].matches = (ts_match *)std::malloc(seg_nm[si] * sizeof(ts_match));
+            if (!out[si].matches) rc = c->fail(TS_ERR_ALLOC, "out of host memory");
+            out[si].n_matches = seg_nm[si];
+        }
+    }
+    if (rc != TS_OK) { ts_free_segments(out, ns); return rc; }
+
+    struct Piece { uint32_t seg; bool windows; uint64_t a, z; };     // windows [a, z) of a segment, or its tiles [a, z)
+    std::vector<Piece> pieces;
+    constexpr uint64_t kWinPiece = 1u << 13, kTilePiece = 64;
+    for (size_t si = 0; si < ns; ++si) {
+        const SegPlan &sp = b->segs[si];
+        if (!b->tips)
+            for (uint64_t a = 0; a < sp.n_windows; a += kWinPiece) pieces.push_back({(uint32_t)si, true, a, std::min<uint64_t>(sp.n_windows, a + kWinPiece)});
+        if (seg_nm[si])
+            for (uint64_t a = 0; a < sp.n_tiles; a += kTilePiece) pieces.push_back({(uint32_t)si, false, a, std::min<uint64_t>(sp.n_tiles, a + kTilePiece)});
+    }
+    const uint16_t klen = (uint16_t)c->k;
+    std::atomic<int> bad{0};
+    parallel_for(pieces.size(), 16, [&](size_t pi) {
+        const Piece &pc = pieces[pi];
+        const SegPlan &sp = b->segs[pc.seg];
+        ts_segment_out &o = out[pc.seg];
+        if (pc.windows) {
+            for (uint64_t kwin = pc.a; kwin < pc.z; ++kwin) {
+                const uint32_t *r = &F.wins[(sp.win_base + kwin) * 8];
+                ts_window &w = o.windows[kwin];
+                std::memset(&w, 0, sizeof w);
+                const uint64_t ws = kwin * P.step;
+                w.window_start = sp.abs_pos + ws;
+                w.current_window_size = (uint32_t)std::min<uint64_t>(P.window_size, sp.len - ws);
+                if (nuc) for (int i = 0; i < 4; ++i) w.nucleotide_counts[i] = r[i];
+                if (P.out_gc) w.gc_content = ts::gc_content(w.nucleotide_counts, w.current_window_size);
+                if (P.out_entropy) w.shannon_entropy = ts::shannon_entropy(w.nucleotide_counts, w.current_window_size);
+                w.canonical_covered = r[4];
+                w.non_canonical_covered = r[5];
+                w.fwd_covered = r[6];
+                w.rev_covered = r[7];
+            }
+            return;
+        }
+        const uint64_t term_end = sp.len > P.terminal_limit ? sp.len - P.terminal_limit : 0;
+        for (uint64_t t = pc.a; t < pc.z; ++t) {
+            const size_t ti = sp.first_tile + t;
+            const uint32_t cnt = F.tile_stats[4ull * ti];
+            if (!cnt) continue;
+            const uint64_t r0 = F.tile_off[ti];
+            if (r0 + cnt > F.nrecs) { bad.store(1); return; }
+            const uint64_t rel0 = b->tiles[ti].in_off - sp.in_off;          // segment-relative position of the tile
+            ts_match *m = o.matches + tile_out[ti];
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint32_t rec = F.recs[r0 + i];
+                const uint64_t rel = rel0 + (rec >> 2);
+                std::memset(&m[i], 0, sizeof m[i]);
+                m[i].position = sp.abs_pos + rel;
+                m[i].match_size = klen;
+                m[i].flags = (uint8_t)(((rec & 2u) ? TS_MATCH_FORWARD : 0u) | ((rec & 1u) ? TS_MATCH_CANONICAL : 0u) |
+                                       ((rel <= P.terminal_limit || rel >= term_end) ? TS_MATCH_TERMINAL : 0u));
+            }
+        }
+    });
+    if (bad.load()) { ts_free_segments(out, ns); return c->fail(TS_ERR_STATE, "tile directory out of range"); }
+    // blocks: the sorted list's slice of every segment
+    size_t bi = 0;
+    for (size_t si = 0; si < ns; ++si) {
+        size_t nterm = 0, nits = 0;
+        const size_t b0 = bi;
+        while (bi < F.blocks.size() && F.blocks[bi].seg == si) { (F.blocks[bi].kind == 2 ? nits : nterm)++; ++bi; }
+        auto fill = [&](ts_block *&dst, uint64_t &n, size_t count, bool its) -> bool {
+            n = count; dst = nullptr;
+            if (!count) return true;
+            dst = (ts_block *)std::malloc(count * sizeof(ts_block));
+            if (!dst) return false;
+            size_t at = 0;
+            for (size_t q = b0; q < bi; ++q)
+                if ((F.blocks[q].kind == 2) == its) std::memcpy(&dst[at++], &F.blocks[q], sizeof(ts_block));
+            return true;
+        };
+        if (!fill(out[si].terminal_blocks, out[si].n_terminal_blocks, nterm, false) ||
+            !fill(out[si].interstitial_blocks, out[si].n_interstitial_blocks, nits, true)) {
+            ts_free_segments(out, ns);
+            return c->fail(TS_ERR_ALLOC, "out of host memory");
+        }
+    }
+    return TS_OK;
+}
+
+int download_impl(ts_batch *b, ts_segment_out *out, bool with_matches) {
+    if (!b || !out) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    DEVICE_TRY(c);
+    if (!b->whole()) return c->fail(TS_ERR_STATE, "a download needs an unrestricted batch (adopt the shards' results first)");
+    if (!b->synced) { int rc = ts_batch_sync(b); if (rc != TS_OK) return rc; }
+    std::lock_guard<std::mutex> dl(c->down_mtx);
+    Fetched F;
+    int rc = batch_fetch(b, with_matches, c->pin_down[0], F);
+    if (rc == TS_OK) rc = batch_finalize(b, F, out);
+    return rc;
+}
+
+}  // namespace
+
+// the two phases of a download, for the host entry points' pipeline (pipeline.cpp): device work + D2H into the
+// pinned landing area `slot` of the context, then host post-processing (which may run while the next group's
+// fetch uses the other slot)
+struct ts_fetched { Fetched F; };
+ts_fetched *ts_batch_fetch(ts_batch *b, bool with_matches, int slot, int *rc_out) {
+    ts_fetched *f = new ts_fetched();
+    *rc_out = batch_fetch(b, with_matches, b->ctx->pin_down[slot & 1], f->F);
+    if (*rc_out != TS_OK) { delete f; return nullptr; }
+    return f;
+}
+int ts_batch_finalize(ts_batch *b, ts_fetched *f, ts_segment_out *out) {
+    const int rc = batch_finalize(b, f->F, out);
+    delete f;
+    return rc;
+}
+
+extern "C" {
+
+// --------------------------------------------------------------- download + host post-processing
+// SegmentData of every segment of a synced whole batch: windows, all match records, and the blocks — called on the
+// device, like ts_batch_download_blocks — so the only host work per record is its expansion to MatchInfo.
+int ts_batch_download(ts_batch *b, const char *const *host_seqs, ts_segment_out *out) {
+    (void)host_seqs;
+    return download_impl(b, out, true);
+}
+
+// --------------------------------------------------------------- device block calling (row f1)
+int ts_batch_download_blocks(ts_batch *b, ts_segment_out *out) { return download_impl(b, out, false); }
 
 void ts_free_segments(ts_segment_out *out, size_t n_segs) {
     if (!out) return;
@@ -1063,387 +1329,6 @@ void ts_free_segments(ts_segment_out *out, size_t n_segs) {
         std::free(out[i].interstitial_blocks);
         std::memset(&out[i], 0, sizeof out[i]);
     }
-}
-
-// =========================================================================== general path
-// For parameter sets outside the tiled kernel's closed form (mixed-length pattern sets, pattern
-// lengths > 9, or a longest pattern exceeding min(step, window-step) where the reference's
-// uint32 start index wraps): ts_generic_match + ts_generic_windows (generic.hip) on the device,
-// then only ordering work on the host.  One segment at a time; this is the slow exact path.
-static int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<size_t> &which,
-                              bool tips, ts_segment_out *out) {
-    if (which.empty()) return TS_OK;
-    if (!c->generic_ok)
-        return c->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: more than 8 pattern lengths, a pattern longer "
-                                           "than 32 or a non-ACGT pattern");
-    std::lock_guard<std::mutex> lk(c->mtx);
-    HIP_TRY(c, hipSetDevice(c->device));
-    const ts_params &P = c->params;
-    const uint32_t s = P.step, w = P.window_size, ov = w - s, L = c->longest;
-    DevBuf d_seq, d_mask, d_win;
-    std::vector<uint32_t> mask, wins;
-    std::vector<ts_match> matches;
-    struct Hit { uint64_t k, p; uint16_t len; uint8_t flags; };
-    std::vector<Hit> hits;
-    int rc = TS_OK;
-    for (size_t wi = 0; wi < which.size() && rc == TS_OK; ++wi) {
-        const ts_segment_in &sg = segs[which[wi]];
-        const uint64_t N = sg.len;
-        matches.clear();
-        uint64_t nwin = 0;
-        // regions exactly as scanSegment picks them (src/teloscope.cpp:576-583; uint32 product)
-        std::vector<std::pair<uint64_t, uint64_t>> regions;
-        if (tips) {
-            const uint32_t twice = 2u * P.terminal_limit;
-            if (N > twice) { regions.emplace_back(0, P.terminal_limit); regions.emplace_back(N - P.terminal_limit, P.terminal_limit); }
-            else if (N) regions.emplace_back(0, N);
-        } else if (N) {
-            regions.emplace_back(0, N);
-            nwin = ceil_div(N, s);
-        }
-        for (const auto &rg : regions) {
-            const uint64_t r0 = rg.first, n = rg.second;
-            if (d_seq.ensure(n + 16) != hipSuccess || d_mask.ensure(n * 4 + 16) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "device allocation failed"); break; }
-            if (hipMemcpy(d_seq.p, sg.seq + r0, n, hipMemcpyHostToDevice) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "H2D copy failed"); break; }
-            if (ts_k_launch_generic_match((const unsigned char *)d_seq.p, n, &c->gpat, P.fold_case, (uint32_t *)d_mask.p, nullptr) != 0) { rc = c->fail(TS_ERR_HIP, "generic match kernel launch failed"); break; }
-            if (!tips) {
-                TsGenericGeom Q{};
-                Q.n = N; Q.s = s; Q.w = w; Q.longest = L; Q.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u; Q.fold = P.fold_case;
-                if (d_win.ensure(nwin * 32 + 16) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "device allocation failed"); break; }
-                if (ts_k_launch_generic_windows((const unsigned char *)d_seq.p, (const uint32_t *)d_mask.p, &c->gpat, &Q, nwin, (uint32_t *)d_win.p, nullptr) != 0) { rc = c->fail(TS_ERR_HIP, "generic window kernel launch failed"); break; }
-                wins.resize(nwin * 8);
-                if (hipMemcpy(wins.data(), d_win.p, nwin * 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "D2H copy failed"); break; }
-            }
-            mask.resize(n);
-            if (hipMemcpy(mask.data(), d_mask.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "D2H copy failed"); break; }
-
-            // enumerate matches in (position, length) order; in full-scan mode keep those some
-            // window's own scan pushes (src/teloscope.cpp:485) and order them by that window
-            hits.clear();
-            const uint32_t t1 = s - L, t2 = ov - L;                     // uint32 wrap, src/teloscope.cpp:413-415
-            const uint32_t start_index = t1 < t2 ? t1 : t2;
-            for (uint64_t p = 0; p < n; ++p) {
-                const uint32_t m = mask[p];
-                if (!m) continue;
-                for (uint32_t li = 0; li < c->gpat.nlen; ++li) {
-                    const uint32_t b = (m >> (3 * li)) & 7u;
-                    if (!(b & 1u)) continue;
-                    const uint32_t len = c->gpat.len[li];
-                    const uint8_t fl = (uint8_t)(((b & 2u) ? TS_MATCH_FORWARD : 0u) | ((b & 4u) ? TS_MATCH_CANONICAL : 0u));
-                    uint64_t k = 0;
-                    if (!tips) {
-                        const uint64_t e = p + len - 1;
-                        if (ov == 0) {
-                            k = p / s;
-                            const uint64_t cws = std::min<uint64_t>(w, N - k * s);
-                            if ((p - k * s) + len > cws) continue;      // crosses its only window's end
-                        } else if (e < std::min<uint64_t>(w, N)) {
-                            k = 0;                                      // window 0 scans everything it holds
-                        } else {
-                            k = (e - ov) / s;                           // the one window with j >= overlap
-                            if (p < k * s || (p - k * s) < start_index) continue;
-                        }
-                    }
-                    hits.push_back(Hit{k, r0 + p, (uint16_t)len, fl});
-                }
-            }
-            if (!tips)
-                std::stable_sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.k < b.k; });
-            for (const Hit &h : hits) {
-                ts_match m{};
-                m.position = sg.abs_pos + h.p;
-                m.match_size = h.len;
-                m.flags = h.flags;
-                matches.push_back(m);
-            }
-        }
-        if (rc != TS_OK) break;
-        ts_match *arr = matches.empty() ? nullptr : (ts_match *)std::malloc(matches.size() * sizeof(ts_match));
-        if (!matches.empty() && !arr) { rc = c->fail(TS_ERR_ALLOC, "out of host memory"); break; }
-        if (arr) std::memcpy(arr, matches.data(), matches.size() * sizeof(ts_match));
-        rc = finalize_segment(c, tips, N, sg.abs_pos, wins.data(), nwin, arr, matches.size(), out[which[wi]], 16u);   // (general path: one segment at a time)
-    }
-    d_seq.release(); d_mask.release(); d_win.release();
-    return rc;
-}
-
-// Uploads all segments of a batch: the bases are gathered into a ring of two pinned chunks laid out
-// like the device buffer, each chunk leaving by DMA (hipMemcpyAsync on a private stream) while the
-// next one is being filled — one copy per read would cost ~10 us each, one pageable 3 GB copy ~0.5 s.
-// Bytes between segments are never read as bases (the kernel masks everything past a segment's end).
-static int batch_upload_all(ts_batch *b, const std::vector<const char *> &seqs) {
-    ts_ctx *c = b->ctx;
-    if (!batch_input(b, false)) return c->fail(TS_ERR_ALLOC, "cannot allocate device input buffer");   // every byte is uploaded below
-    constexpr size_t kChunk = 32u << 20;
-    if (!c->up_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(c, hipHostMalloc(&c->pin[i], kChunk, hipHostMallocDefault));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
-        }
-    }
-    const size_t nseg = b->segs.size();
-    size_t seg = 0;                 // first segment that may still have bytes at or beyond the chunk start
-    int slot = 0;
-    bool used[2] = {false, false};
-    // A chunk is staged by several threads (one memcpy stream fills pinned memory at ~10 GB/s, a fraction of
-    // what the link moves) while the previous chunk's DMA is in flight.
-    struct Piece { char *dst; const char *src; size_t len; };
-    std::vector<Piece> pieces;
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nthr = std::min(8u, std::max(1u, hw / 2u));
-    for (uint64_t c0 = 0; c0 < b->input_bytes; c0 += kChunk) {
-        const uint64_t c1 = std::min<uint64_t>(c0 + kChunk, b->input_bytes);
-        if (used[slot]) HIP_TRY(c, hipEventSynchronize(c->pin_ev[slot]));
-        char *dst = (char *)c->pin[slot];
-        while (seg < nseg && b->segs[seg].in_off + b->segs[seg].len <= c0) ++seg;
-        pieces.clear();
-        size_t bytes = 0;
-        for (size_t i = seg; i < nseg && b->segs[i].in_off < c1; ++i) {
-            const uint64_t s0 = std::max<uint64_t>(b->segs[i].in_off, c0);
-            const uint64_t s1 = std::min<uint64_t>(b->segs[i].in_off + b->segs[i].len, c1);
-            if (s1 > s0) { pieces.push_back({dst + (s0 - c0), seqs[i] + (s0 - b->segs[i].in_off), (size_t)(s1 - s0)}); bytes += s1 - s0; }
-        }
-        const unsigned nt = bytes >= (4u << 20) ? nthr : 1u;
-        if (nt == 1u) {
-            for (const Piece &pc : pieces) std::memcpy(pc.dst, pc.src, pc.len);
-        } else {
-            // thread t copies the bytes [t, t+1) * share of the concatenated pieces
-            const size_t share = (bytes + nt - 1) / nt;
-            std::vector<std::thread> pool;
-            pool.reserve(nt);
-            for (unsigned t = 0; t < nt; ++t)
-                pool.emplace_back([&, t] {
-                    const size_t lo = (size_t)t * share, hi = std::min(bytes, lo + share);
-                    size_t at = 0;
-                    for (const Piece &pc : pieces) {
-                        const size_t a = std::max(lo, at), z = std::min(hi, at + pc.len);
-                        if (z > a) std::memcpy(pc.dst + (a - at), pc.src + (a - at), z - a);
-                        at += pc.len;
-                        if (at >= hi) break;
-                    }
-                });
-            for (std::thread &th : pool) th.join();
-        }
-        HIP_TRY(c, hipMemcpyAsync((char *)b->d_in.p + c0, dst, c1 - c0, hipMemcpyHostToDevice, c->up_stream));
-        HIP_TRY(c, hipEventRecord(c->pin_ev[slot], c->up_stream));
-        used[slot] = true;
-        slot ^= 1;
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->up_stream));
-    return TS_OK;
-}
-
-// =========================================================================== scanSegment, batched
-static int scan_group(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<size_t> &which,
-                      bool tips, ts_segment_out *out) {
-    if (which.empty()) return TS_OK;
-    const auto t_begin = std::chrono::steady_clock::now();
-    std::vector<uint64_t> lens(which.size()), abs(which.size());
-    for (size_t i = 0; i < which.size(); ++i) { lens[i] = segs[which[i]].len; abs[i] = segs[which[i]].abs_pos; }
-    ts_batch *b = ts_batch_create(ctx, lens.data(), abs.data(), which.size(), tips, 0);
-    if (!b) return ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP;
-    std::vector<const char *> ptrs(which.size());
-    for (size_t i = 0; i < which.size(); ++i) ptrs[i] = segs[which[i]].seq;
-    const bool timing = getenv("TS_TIMING") != nullptr;          // stage times to stderr
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
-        return std::chrono::duration<double, std::milli>(y - x).count();
-    };
-    const auto t0 = now();
-    int rc = batch_upload_all(b, ptrs);
-    const auto t1 = now();
-    if (rc == TS_OK) rc = ts_batch_scan(b, nullptr, nullptr);
-    if (rc == TS_OK) rc = ts_batch_sync(b);
-    const auto t2 = now();
-    std::vector<ts_segment_out> tmp(which.size());
-    if (rc == TS_OK) rc = ts_batch_download(b, nullptr, tmp.data());
-    if (timing)
-        fprintf(stderr, "ts_scan_segments: plan %.1f ms, upload %.1f ms, scan %.1f ms, download + host post-processing %.1f ms\n",
-                ms(t_begin, t0), ms(t0, t1), ms(t1, t2), ms(t2, now()));
-    if (rc == TS_OK)
-        for (size_t i = 0; i < which.size(); ++i) out[which[i]] = tmp[i];
-    else
-        ts_free_segments(tmp.data(), tmp.size());
-    ts_batch_destroy(b);
-    return rc;
-}
-
-int ts_scan_segments(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out) {
-    if (!ctx || (n_segs && (!segs || !out))) return TS_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> api(ctx->api_mtx);
-    for (size_t i = 0; i < n_segs; ++i) {
-        std::memset(&out[i], 0, sizeof out[i]);
-        if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
-    }
-    std::vector<size_t> full, tips;
-    for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
-    std::string why;
-    int rc = full_scan_supported(ctx, why) ? scan_group(ctx, segs, full, false, out)
-                                           : scan_group_generic(ctx, segs, full, false, out);
-    if (rc == TS_OK) rc = ctx->fast_ok ? scan_group(ctx, segs, tips, true, out)
-                                       : scan_group_generic(ctx, segs, tips, true, out);
-    if (rc != TS_OK) ts_free_segments(out, n_segs);
-    return rc;
-}
-
-// scanSegment for callers that do not read the match vectors: scan, block calling and the per-segment
-// counts all stay on the device; windows, blocks and four counters per segment cross PCIe.
-static int scan_group_blocks(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<size_t> &which, bool tips,
-                             ts_segment_out *out, ts_segment_counts *counts) {
-    if (which.empty()) return TS_OK;
-    std::vector<uint64_t> lens(which.size()), abs(which.size());
-    for (size_t i = 0; i < which.size(); ++i) { lens[i] = segs[which[i]].len; abs[i] = segs[which[i]].abs_pos; }
-    ts_batch *b = ts_batch_create(ctx, lens.data(), abs.data(), which.size(), tips, 0);
-    if (!b) return ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP;
-    std::vector<const char *> ptrs(which.size());
-    for (size_t i = 0; i < which.size(); ++i) ptrs[i] = segs[which[i]].seq;
-    int rc = batch_upload_all(b, ptrs);
-    if (rc == TS_OK) rc = ts_batch_scan(b, nullptr, nullptr);
-    if (rc == TS_OK) rc = ts_batch_sync(b);
-    std::vector<ts_segment_out> tmp(which.size());
-    if (rc == TS_OK) rc = ts_batch_download_blocks(b, tmp.data());
-    std::vector<unsigned long long> summary(4 * which.size());
-    if (rc == TS_OK && counts) {
-        DevBuf d_sum;
-        if (d_sum.ensure(summary.size() * 8 + 16) != hipSuccess) rc = ctx->fail(TS_ERR_ALLOC, "out of device memory");
-        if (rc == TS_OK) rc = ts_batch_segment_summary(b, d_sum.p, nullptr);
-        if (rc == TS_OK && hipMemcpy(summary.data(), d_sum.p, summary.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
-            rc = ctx->fail(TS_ERR_HIP, "summary download failed");
-        d_sum.release();
-    }
-    if (rc == TS_OK) {
-        for (size_t i = 0; i < which.size(); ++i) {
-            out[which[i]] = tmp[i];
-            if (counts)
-                counts[which[i]] = ts_segment_counts{tips ? 0 : summary[4 * i], summary[4 * i + 1], summary[4 * i + 2], summary[4 * i + 3]};
-        }
-    } else {
-        ts_free_segments(tmp.data(), tmp.size());
-    }
-    ts_batch_destroy(b);
-    return rc;
-}
-
-int ts_scan_segments_blocks(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out,
-                            ts_segment_counts *counts) {
-    if (!ctx || (n_segs && (!segs || !out))) return TS_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> api(ctx->api_mtx);
-    for (size_t i = 0; i < n_segs; ++i) {
-        std::memset(&out[i], 0, sizeof out[i]);
-        if (counts) counts[i] = ts_segment_counts{0, 0, 0, 0};
-        if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
-    }
-    std::vector<size_t> full, tips;
-    for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
-    // parameter sets outside the tiled kernel take the general path and drop the match vectors afterwards
-    auto via_matches = [&](const std::vector<size_t> &which, bool tips_mode) -> int {
-        int rc = scan_group_generic(ctx, segs, which, tips_mode, out);
-        if (rc != TS_OK) return rc;
-        for (size_t i : which) {
-            if (counts) {
-                ts_segment_counts cnt{tips_mode ? 0 : out[i].n_windows, out[i].n_matches, 0, 0};
-                for (uint64_t m = 0; m < out[i].n_matches; ++m) {
-                    cnt.n_canonical += (out[i].matches[m].flags & TS_MATCH_CANONICAL) ? 1 : 0;
-                    cnt.n_forward += (out[i].matches[m].flags & TS_MATCH_FORWARD) ? 1 : 0;
-                }
-                counts[i] = cnt;
-            }
-            std::free(out[i].matches);
-            out[i].matches = nullptr;
-            out[i].n_matches = 0;
-        }
-        return TS_OK;
-    };
-    std::string why;
-    int rc = full_scan_supported(ctx, why) ? scan_group_blocks(ctx, segs, full, false, out, counts) : via_matches(full, false);
-    if (rc == TS_OK) rc = ctx->fast_ok ? scan_group_blocks(ctx, segs, tips, true, out, counts) : via_matches(tips, true);
-    if (rc != TS_OK) ts_free_segments(out, n_segs);
-    return rc;
-}
-
-// =========================================================================== ReadTelomereFilter
-int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, size_t n_reads,
-                    uint8_t *pass) {
-    if (!ctx || (n_reads && (!seqs || !lens || !pass))) return TS_ERR_INVALID_ARG;
-    if (!ctx->read_filter) return ctx->fail(TS_ERR_STATE, "context was not made by ts_create_read_filter");
-    if (n_reads == 0) return TS_OK;
-    std::lock_guard<std::mutex> api(ctx->api_mtx);
-    std::vector<uint64_t> rl(n_reads);
-    for (size_t i = 0; i < n_reads; ++i) {
-        uint64_t n = lens[i];
-        if (n && seqs[i][n - 1] == '\r') --n;             // src/read-filter.cpp:38-40
-        rl[i] = n;
-    }
-    if (!ctx->fast_ok) {
-        // mixed-length pattern sets: general kernels + host block predicate
-        std::vector<ts_segment_in> in(n_reads);
-        for (size_t i = 0; i < n_reads; ++i) { in[i].seq = seqs[i]; in[i].len = rl[i]; in[i].abs_pos = 0; in[i].tips_only = 1; }
-        std::vector<ts_segment_out> out(n_reads);
-        int rc = ts_scan_segments(ctx, in.data(), n_reads, out.data());
-        if (rc != TS_OK) return rc;
-        for (size_t i = 0; i < n_reads; ++i) pass[i] = out[i].n_terminal_blocks != 0;
-        ts_free_segments(out.data(), n_reads);
-        return TS_OK;
-    }
-    // tiled path: whole-read tips scan, then the terminal-block predicate on the device; only one
-    // byte per read comes back
-    const bool timing = getenv("TS_TIMING") != nullptr;          // stage times to stderr
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
-        return std::chrono::duration<double, std::milli>(b2 - a).count();
-    };
-    const auto t0 = now();
-    ts_batch *b = ts_batch_create(ctx, rl.data(), nullptr, n_reads, 1, 0);
-    if (!b) return ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP;
-    const auto t1 = now();
-    int rc = batch_upload_all(b, std::vector<const char *>(seqs, seqs + n_reads));
-    const auto t2 = now();
-    if (rc == TS_OK) rc = ts_batch_scan(b, nullptr, nullptr);
-    if (rc == TS_OK) rc = ts_batch_sync(b);
-    const auto t3 = now();
-    if (rc == TS_OK) {
-        ts_ctx *c = ctx;
-        auto run = [&]() -> int {
-            const size_t ns = n_reads;
-            std::vector<uint32_t> first(ns + 1);
-            std::vector<unsigned long long> inoff(ns), slen(ns);
-            for (size_t i = 0; i < ns; ++i) { first[i] = b->segs[i].first_tile; inoff[i] = b->segs[i].in_off; slen[i] = b->segs[i].len; }
-            first[ns] = (uint32_t)b->tiles.size();
-            DevBuf d_first, d_inoff, d_len, d_pass;
-            HIP_TRY(c, d_first.ensure((ns + 1) * 4));
-            HIP_TRY(c, d_inoff.ensure(ns * 8));
-            HIP_TRY(c, d_len.ensure(ns * 8));
-            HIP_TRY(c, d_pass.ensure(ns + 16));
-            HIP_TRY(c, hipMemcpy(d_first.p, first.data(), (ns + 1) * 4, hipMemcpyHostToDevice));
-            HIP_TRY(c, hipMemcpy(d_inoff.p, inoff.data(), ns * 8, hipMemcpyHostToDevice));
-            HIP_TRY(c, hipMemcpy(d_len.p, slen.data(), ns * 8, hipMemcpyHostToDevice));
-            TsPredParams Q{};
-            Q.terminal_limit = c->params.terminal_limit;
-            Q.max_match_dist = c->params.max_match_dist;
-            Q.min_block_len = c->params.min_block_len;
-            Q.max_block_dist = c->params.max_block_dist;
-            Q.min_block_counts = c->params.min_block_counts;
-            Q.min_block_density = c->params.min_block_density;
-            Q.k = c->k;
-            int e = ts_k_launch_predicate((const TsTile *)b->d_tiles.p, (const unsigned long long *)b->d_tile_off.p,
-                                          (const uint32_t *)b->d_stats.p, (const uint32_t *)b->d_matches.p,
-                                          (const uint32_t *)d_first.p, (const unsigned long long *)d_inoff.p,
-                                          (const unsigned long long *)d_len.p, (uint32_t)ns, &Q,
-                                          (unsigned char *)d_pass.p, nullptr);
-            if (e != 0) return c->fail(TS_ERR_HIP, "predicate kernel launch failed");
-            HIP_TRY(c, hipMemcpy(pass, d_pass.p, ns, hipMemcpyDeviceToHost));
-            d_first.release(); d_inoff.release(); d_len.release(); d_pass.release();
-            return TS_OK;
-        };
-        rc = run();
-    }
-    const auto t4 = now();
-    ts_batch_destroy(b);
-    if (timing)
-        fprintf(stderr, "ts_filter_reads: plan %.1f ms, upload %.1f ms, scan %.1f ms, predicate %.1f ms, free %.1f ms\n",
-                ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
-    return rc;
 }
 
 }  // extern "C"

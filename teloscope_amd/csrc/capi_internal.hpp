@@ -1,0 +1,217 @@
+// capi_internal.hpp — structures shared by the host translation units of libteloscan
+// (capi.cpp: contexts and device-resident batches; pipeline.cpp: the host-buffer entry points).
+#ifndef TS_CAPI_INTERNAL_HPP
+#define TS_CAPI_INTERNAL_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "host.hpp"
+#include "ts_internal.h"
+
+// A planning-only context (ts_params.device == TS_DEVICE_NONE) never touches HIP: it plans batches
+// (tiles, windows, input layout) and every device entry point fails on it with TS_ERR_NO_DEVICE.
+constexpr int kNoDevice = TS_DEVICE_NONE;
+
+// Device memory block; move-only, frees itself.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    hipError_t ensure(size_t need) {
+        if (need <= bytes && p) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&p, need ? need : 16);
+        if (e == hipSuccess) bytes = need ? need : 16; else p = nullptr;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+// Pinned host block (hipHostMalloc); move-only, frees itself.
+struct PinBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    PinBuf(PinBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    PinBuf &operator=(PinBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~PinBuf() { release(); }
+    hipError_t ensure(size_t need) {
+        if (need <= bytes && p) return hipSuccess;
+        release();
+        hipError_t e = hipHostMalloc(&p, need ? need : 16, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = need ? need : 16; else p = nullptr;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+};
+
+// Device blocks kept between calls: the host entry points plan a batch per group of segments, and a
+// hipMalloc / hipFree pair per multi-GB buffer per call costs more than the scan (hipFree also waits for
+// the device).  take() hands out the smallest free block that fits within 2x, else allocates.
+class BufferPool {
+public:
+    hipError_t take(size_t need, DevBuf &out);
+    void give(DevBuf &&b);
+    void clear();
+private:
+    std::mutex m_;
+    std::vector<DevBuf> free_;
+    size_t held_ = 0;
+    static constexpr size_t kMaxBlocks = 96;
+    static constexpr size_t kMaxHeld = 48ull << 30;
+};
+
+// Sets the calling thread's HIP device for the scope (every entry point that touches the device: a pool
+// thread's current device need not be the context's) and restores the previous one.
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int device) {
+        if (device < 0) { err_ = hipErrorNoDevice; return; }
+        if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+        err_ = prev_ == device ? hipSuccess : hipSetDevice(device);
+        changed_ = err_ == hipSuccess && prev_ != device;
+    }
+    ~DeviceGuard() { if (changed_ && prev_ >= 0) (void)hipSetDevice(prev_); }
+    hipError_t error() const { return err_; }
+private:
+    int prev_ = -1;
+    bool changed_ = false;
+    hipError_t err_ = hipSuccess;
+};
+
+struct ts_ctx {
+    ts_params params{};
+    std::vector<ts::Pattern> patterns;
+    ts::BlockParams bp{};
+    uint32_t k = 0;                 // uniform pattern length (0 = mixed)
+    uint32_t longest = 0;
+    bool fast_ok = false;           // table-driven tiled kernel usable for the pattern set
+    std::string why_not;            // reason when a scan mode is unsupported
+    int device = 0;                 // HIP ordinal, or kNoDevice for a planning-only context
+    int num_cu = 0;
+    uint32_t table_rows = 0, fc_bytes = 0;
+    bool fc_byte_table = true, pair_byte_table = false;
+    // general kernels (generic.hip): sorted 2-bit codes per pattern length
+    bool generic_ok = false;
+    TsGenericPatterns gpat{};
+    DevBuf d_gcodes, d_gflags;
+    DevBuf d_table;
+    mutable std::mutex mtx;         // guards batch planning / launches that read the context's tables
+    mutable std::string error;
+    bool read_filter = false;
+    BufferPool pool;
+    // host-buffer entry points (pipeline.cpp): pinned staging rings and their streams
+    static constexpr int kUpSlots = 3;
+    PinBuf pin_up[kUpSlots];
+    hipEvent_t pin_up_ev[kUpSlots] = {nullptr, nullptr, nullptr};
+    PinBuf pin_down[2];
+    hipStream_t up_stream = nullptr, scan_stream = nullptr, down_stream = nullptr;
+
+    std::mutex down_mtx;            // one download (pinned landing area + its stream) at a time
+    mutable std::mutex err_mtx;
+    std::mutex api_mtx;             // ts_scan_segments / ts_scan_segments_blocks / ts_filter_reads run one at a time per context
+                                    // (they share the pinned rings and streams; results never depend on call order)
+    int fail(int code, const std::string &msg) const { std::lock_guard<std::mutex> g(err_mtx); error = msg; return code; }
+};
+
+struct Region {                     // one scanned interval of a segment
+    uint64_t start, len;            // relative to the segment
+    uint32_t first_tile, n_tiles;
+    uint64_t tile_bases;            // owned bases per tile
+};
+
+struct SegPlan {
+    uint64_t len = 0, abs_pos = 0;
+    uint64_t in_off = 0;            // byte offset in the (whole-batch) input layout
+    uint64_t win_base = 0, n_windows = 0;
+    uint32_t first_tile = 0, n_tiles = 0;
+    std::vector<Region> regions;
+};
+
+// A batch is a PLAN over all its segments (tiles, window records, input layout) plus the device state of
+// the tile range [tile_lo, tile_hi) it executes: the whole plan by default, one rank's shard after
+// ts_batch_restrict, or — on the rank that assembles — results produced elsewhere (ts_batch_adopt).
+struct ts_batch {
+    ts_ctx *ctx = nullptr;
+    bool tips = false;
+    std::vector<SegPlan> segs;
+    std::vector<TsTile> tiles;      // the whole plan
+    TsScanParams kp{};
+    uint32_t wpt = 1;               // windows per tile
+    uint32_t grid = 0, lds_bytes = 0;
+    uint64_t total_bases = 0, input_bytes = 0, n_windows = 0, match_cap = 0, match_cap_request = 0;
+    uint64_t n_matches = 0;
+    // executed range and what it covers
+    uint64_t tile_lo = 0, tile_hi = 0, win_lo = 0, win_hi = 0, in_lo = 0, in_hi = 0, range_bases = 0;
+    bool allocated = false;
+    double last_ms = 0.0;
+    bool scanned = false, synced = false;
+    bool dense = false;             // match records form one dense stream in tile order (adopted / exported results)
+    const void *last_input = nullptr;
+    void *last_stream = nullptr;
+    DevBuf d_in, d_tiles, d_windows, d_matches, d_tile_off, d_stats, d_fill, d_segtab, d_dense, d_dense_base, d_scan_tmp, d_readtab;
+    // caller-owned result buffers (ts_batch_bind_results / ts_batch_adopt); null = the batch's own
+    uint32_t *ext_windows = nullptr, *ext_stats = nullptr;
+    const uint32_t *ext_dense = nullptr;
+    uint32_t total_waves = 0, region_cap = 0;
+    std::vector<uint32_t> wave_fill;
+    std::vector<hipEvent_t> evs;                 // ring of {start, stop} pairs, one per enqueued scan
+    uint64_t scan_seq = 0, harvested = 0;        // scans enqueued / scans whose time has been read
+    double avg_ms = 0.0;
+    uint64_t avg_n = 0;
+
+    uint32_t *windows_ptr() const { return ext_windows ? ext_windows : (uint32_t *)d_windows.p; }
+    uint32_t *stats_ptr() const { return ext_stats ? ext_stats : (uint32_t *)d_stats.p; }
+    const uint32_t *records_ptr() const { return dense ? (ext_dense ? ext_dense : (const uint32_t *)d_dense.p) : (const uint32_t *)d_matches.p; }
+    uint64_t range_tiles() const { return tile_hi - tile_lo; }
+    bool whole() const { return tile_lo == 0 && tile_hi == tiles.size(); }
+};
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return (ctx)->fail(TS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define DEVICE_TRY(ctx)                                                                       \
+    if ((ctx)->device == kNoDevice)                                                           \
+        return (ctx)->fail(TS_ERR_NO_DEVICE, "planning-only context: no HIP device behind it"); \
+    DeviceGuard _dev_guard((ctx)->device);                                                    \
+    if (_dev_guard.error() != hipSuccess)                                                     \
+        return (ctx)->fail(TS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_dev_guard.error()))
+
+inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// capi.cpp internals used by pipeline.cpp
+bool ts_full_scan_supported(const ts_ctx *c, std::string &why);
+int  ts_finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos, const uint32_t *win_raw,
+                         uint64_t n_windows, ts_match *matches, uint64_t nm, ts_segment_out &o, unsigned spare_threads);
+int  ts_batch_ensure_device(ts_batch *b);        // allocates the range's device state (idempotent)
+void ts_batch_release_input(ts_batch *b);        // returns the batch's input buffer to the context's pool
+void *ts_batch_input_ptr_nozero(ts_batch *b);
+struct ts_fetched;                               // what a download left in host memory, before post-processing
+ts_fetched *ts_batch_fetch(ts_batch *b, bool with_matches, int slot, int *rc_out);   // device work + D2H (pinned slot 0/1)
+int  ts_batch_finalize(ts_batch *b, ts_fetched *f, ts_segment_out *out);             // host post-processing; frees f
+    // the batch's own input buffer, not zero-filled (every byte read is uploaded)
+
+#endif

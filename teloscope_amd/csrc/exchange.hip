@@ -1,0 +1,151 @@
+// exchange.hip — gfx950 kernels behind ts_batch_export / ts_batch_adopt: the device side of the multi-GPU
+// gather.  A scan leaves its match records in per-wave regions, addressable through the tile
+// directory; what ranks exchange is ONE stream per rank in tile order (= position order inside every segment),
+// so that the concatenation over ranks is again a tile-ordered stream and the assembling rank only has to
+// prefix-sum the tile counts to get its directory back.  All of it is HBM-bound copying: coalesced 4-byte
+// records, one wave per tile.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ts_internal.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr uint32_t kScanThreads = 256;
+constexpr uint32_t kScanPerThread = 8;
+constexpr uint32_t kScanBlock = kScanThreads * kScanPerThread;      // tiles per workgroup
+
+// block-wide exclusive prefix sum of one u64 per thread (256 threads); returns the thread's exclusive prefix,
+// *total = the block's sum
+__device__ __forceinline__ u64 block_excl_scan(u64 v, u64 *total) {
+    __shared__ u64 part[kScanThreads];
+    const uint32_t t = threadIdx.x;
+    part[t] = v;
+    __syncthreads();
+    for (uint32_t o = 1; o < kScanThreads; o <<= 1) {
+        const u64 add = t >= o ? part[t - o] : 0ull;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    const u64 incl = part[t];
+    *total = part[kScanThreads - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+// pass 1: records per workgroup of kScanBlock tiles; also raises the "incomplete" flag when a wave's region
+// overflowed in the scan (its tile counts then promise records that were never stored)
+__global__ __launch_bounds__(kScanThreads)
+void ts_tile_count_blocks(const uint32_t *tile_stats, uint32_t ntiles, u64 *block_sums,
+                          const uint32_t *wave_fill, uint32_t region_cap, uint32_t nwaves, u64 *total_out) {
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
+    u64 v = 0;
+    for (uint32_t i = 0; i < kScanPerThread; ++i)
+        if (base + i < ntiles) v += tile_stats[4ull * (base + i)];
+    u64 total;
+    (void)block_excl_scan(v, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    if (wave_fill) {
+        bool over = false;
+        for (uint32_t w = blockIdx.x * kScanThreads + threadIdx.x; w < nwaves; w += gridDim.x * kScanThreads)
+            over |= wave_fill[w] > region_cap;
+        if (over) atomicOr(total_out + 1, 1ull);
+    }
+}
+
+// pass 2 (one workgroup): exclusive scan of the block sums in place; the grand total goes to block_sums[nblocks]
+__global__ __launch_bounds__(kScanThreads)
+void ts_tile_scan_blocks(u64 *block_sums, uint32_t nblocks) {
+    u64 carry = 0;
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += kScanThreads) {
+        const uint32_t i = b0 + threadIdx.x;
+        const u64 v = i < nblocks ? block_sums[i] : 0ull;
+        u64 total;
+        const u64 ex = block_excl_scan(v, &total);
+        if (i < nblocks) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) block_sums[nblocks] = carry;
+}
+
+// pass 3: tile_off[t] = records of the tiles before t; tile_off[ntiles] = all records.  With total_out: the
+// grand total and the "stream does not fit" flag.
+__global__ __launch_bounds__(kScanThreads)
+void ts_tile_offsets(const uint32_t *tile_stats, uint32_t ntiles, const u64 *block_sums, uint32_t nblocks,
+                     u64 *tile_off, u64 *total_out, u64 capacity) {
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
+    uint32_t c[kScanPerThread];
+    u64 v = 0;
+    for (uint32_t i = 0; i < kScanPerThread; ++i) {
+        c[i] = base + i < ntiles ? tile_stats[4ull * (base + i)] : 0u;
+        v += c[i];
+    }
+    u64 total;
+    u64 run = block_sums[blockIdx.x] + block_excl_scan(v, &total);
+    for (uint32_t i = 0; i < kScanPerThread; ++i) {
+        if (base + i < ntiles) tile_off[base + i] = run;
+        run += c[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const u64 all = block_sums[nblocks];
+        tile_off[ntiles] = all;
+        if (total_out) {
+            total_out[0] = all;
+            if (all > capacity) atomicOr(total_out + 1, 1ull);
+        }
+    }
+}
+
+// One wave per tile: its records, wherever the scan's wave put them, to their place in the tile-ordered stream.
+__global__ __launch_bounds__(256)
+void ts_tile_order_copy(const uint32_t *tile_stats, const u64 *region_off, const uint32_t *regions,
+                        const u64 *dense_off, uint32_t ntiles, uint32_t *dense, const u64 *total_out) {
+    if (total_out[1] != 0ull) return;                        // incomplete: the caller rescans (ts_batch_sync) and exports again
+    const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (t >= ntiles) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = tile_stats[4ull * t];
+    const uint32_t *src = regions + region_off[t];
+    uint32_t *dst = dense + dense_off[t];
+    for (uint32_t i = lane; i < n; i += 64u) dst[i] = src[i];
+}
+
+uint32_t scan_blocks(uint32_t ntiles) { return ntiles ? (ntiles + kScanBlock - 1u) / kScanBlock : 1u; }
+
+}  // namespace
+
+unsigned long long ts_k_scan_tmp_bytes(uint32_t ntiles) { return ((unsigned long long)scan_blocks(ntiles) + 2ull) * 8ull; }
+
+int ts_k_launch_tile_offsets(const uint32_t *tile_stats, uint32_t ntiles, unsigned long long *tile_off, void *tmp,
+                             void *stream) {
+    const uint32_t nb = scan_blocks(ntiles);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ts_tile_count_blocks, dim3(nb), dim3(kScanThreads), 0, st, tile_stats, ntiles, (u64 *)tmp,
+                       (const uint32_t *)nullptr, 0u, 0u, (u64 *)nullptr);
+    hipLaunchKernelGGL(ts_tile_scan_blocks, dim3(1), dim3(kScanThreads), 0, st, (u64 *)tmp, nb);
+    hipLaunchKernelGGL(ts_tile_offsets, dim3(nb), dim3(kScanThreads), 0, st, tile_stats, ntiles, (const u64 *)tmp, nb,
+                       tile_off, (u64 *)nullptr, 0ull);
+    return (int)hipGetLastError();
+}
+
+int ts_k_launch_tile_order_export(const uint32_t *tile_stats, const unsigned long long *region_off, const uint32_t *regions,
+                                  const uint32_t *wave_fill, uint32_t region_cap, uint32_t nwaves, uint32_t ntiles,
+                                  unsigned long long *dense_off, void *tmp, uint32_t *dense, unsigned long long capacity,
+                                  unsigned long long *total_out, void *stream) {
+    const uint32_t nb = scan_blocks(ntiles);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(total_out, 0, 16, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(ts_tile_count_blocks, dim3(nb), dim3(kScanThreads), 0, st, tile_stats, ntiles, (u64 *)tmp,
+                       wave_fill, region_cap, nwaves, total_out);
+    hipLaunchKernelGGL(ts_tile_scan_blocks, dim3(1), dim3(kScanThreads), 0, st, (u64 *)tmp, nb);
+    hipLaunchKernelGGL(ts_tile_offsets, dim3(nb), dim3(kScanThreads), 0, st, tile_stats, ntiles, (const u64 *)tmp, nb,
+                       dense_off, total_out, capacity);
+    if (ntiles)
+        hipLaunchKernelGGL(ts_tile_order_copy, dim3((ntiles + 3u) / 4u), dim3(256), 0, st, tile_stats, region_off, regions,
+                           (const u64 *)dense_off, ntiles, dense, (const u64 *)total_out);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,669 @@
+// pipeline.cpp — the host-buffer entry points of libteloscan: ts_scan_segments, ts_scan_segments_blocks,
+// ts_filter_reads(_multi).  Host memory in, host results out.
+//
+// A call's segments (or reads) are cut into GROUPS of about 256 MB of input and the groups flow through three
+// stages that run concurrently, each on its own host thread and HIP stream:
+//
+//   upload     plan the group's batch, stage its bases into a ring of pinned chunks (several memcpy threads)
+//              and DMA them to the device (up_stream)                                 — bound by PCIe
+//   scan       ts_scan_tiles on the group (scan_stream), read back the per-wave fill, regrow + rescan on
+//              overflow; the group's input buffer goes back to the pool                — ~0.1 ms per group
+//   download   mode-specific device work (block calling / read predicate / record compaction), D2H into a
+//              pinned landing area, host post-processing on the host threads (down_stream)
+//
+// so that the wall time of a call is the upload plus the tail of the last group, instead of the sum of the
+// three.  Device buffers come from the context's pool: a call neither allocates nor frees device memory once
+// the pool is warm.  The reference's own decomposition is one thread-pool job per path (src/input.cpp:719-724)
+// and one job per chunk of a 2048-record FASTQ batch (src/input.cpp:753-812); a group is the GPU-sized
+// equivalent of such a job, and results come back in input order whatever the grouping.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "capi_internal.hpp"
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+double ms_between(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+uint64_t group_target_bytes() {
+    static const uint64_t v = [] {
+        if (const char *e = getenv("TS_GROUP_MB")) { const long mb = atol(e); if (mb > 0) return (uint64_t)mb << 20; }
+        return (uint64_t)256 << 20;
+    }();
+    return v;
+}
+
+template <typename T>
+class Channel {                                   // unbounded FIFO between two pipeline stages
+public:
+    void push(T v) { { std::lock_guard<std::mutex> g(m_); q_.push_back(std::move(v)); } cv_.notify_one(); }
+    void close() { { std::lock_guard<std::mutex> g(m_); closed_ = true; } cv_.notify_all(); }
+    bool pop(T &out) {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        return true;
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    bool closed_ = false;
+};
+
+class Semaphore {
+public:
+    explicit Semaphore(int n) : n_(n) {}
+    void acquire() { std::unique_lock<std::mutex> g(m_); cv_.wait(g, [&] { return n_ > 0; }); --n_; }
+    void release() { { std::lock_guard<std::mutex> g(m_); ++n_; } cv_.notify_one(); }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    int n_;
+};
+
+enum class Mode { Matches, Blocks, ReadPass };
+
+struct Item { const char *seq; uint64_t len, abs_pos; };
+
+struct Group {
+    size_t first = 0, count = 0;                  // items [first, first + count) of the call's item list
+    ts_batch *b = nullptr;
+    hipEvent_t uploaded = nullptr;
+    double t_plan = 0, t_upload = 0, t_scan = 0, t_down = 0;
+};
+
+int ensure_streams(ts_ctx *c) {
+    if (c->up_stream) return TS_OK;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
+    for (int i = 0; i < ts_ctx::kUpSlots; ++i) {
+        HIP_TRY(c, c->pin_up[i].ensure(32u << 20));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->pin_up_ev[i], hipEventDisableTiming));
+    }
+    return TS_OK;
+}
+
+// Uploads the bases a batch reads (whole segments of a full scan; only the two terminal regions of a long
+// segment in tips-only mode — the rest of the layout is never read).  Dense layouts (full scans, reads) are
+// mirrored chunk by chunk in a ring of pinned buffers, each chunk leaving by ONE DMA while the next is being
+// filled by several memcpy threads (one memcpy stream fills pinned memory at ~10 GB/s, a fraction of what the
+// link moves; one copy per read would cost ~10 us each, one pageable 3 GB copy ~0.5 s).  Sparse layouts
+// (tips-only regions of long contigs) go piece by piece.  Bytes between pieces are never read as bases (the
+// kernel masks everything past a region's end).  Asynchronous: the DMAs are queued on up_stream.
+int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
+    ts_ctx *c = b->ctx;
+    void *din = ts_batch_input_ptr_nozero(b);
+    if (!din) return c->fail(TS_ERR_ALLOC, "cannot allocate device input buffer");
+    struct Piece { uint64_t off; const char *src; uint64_t len; };              // off: byte offset in the input layout
+    std::vector<Piece> pieces;
+    uint64_t piece_bytes = 0;
+    for (size_t i = 0; i < b->segs.size(); ++i) {
+        const SegPlan &sp = b->segs[i];
+        for (const Region &rg : sp.regions) {
+            // (consecutive regions of one segment never overlap: tips regions are [0,t) and [N-t,N) with N > 2t)
+            const uint64_t s0 = std::max<uint64_t>(sp.in_off + rg.start, b->in_lo);
+            const uint64_t s1 = std::min<uint64_t>(sp.in_off + rg.start + rg.len, b->in_hi);
+            if (s1 > s0) { pieces.push_back({s0, items[i].seq + (s0 - sp.in_off), s1 - s0}); piece_bytes += s1 - s0; }
+        }
+    }
+    constexpr size_t kChunk = 32u << 20;
+    const uint64_t span = b->in_hi - b->in_lo;
+    const bool dense = piece_bytes * 2 >= span || pieces.size() > 4096;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nthr = std::min(8u, std::max(1u, hw / 2u));
+    auto stage = [&](std::vector<std::pair<char *, Piece>> &work, size_t bytes) {   // work: (pinned destination, piece part)
+        const unsigned nt = bytes >= (4u << 20) ? nthr : 1u;
+        if (nt == 1u) {
+            for (auto &w : work) std::memcpy(w.first, w.second.src, w.second.len);
+            return;
+        }
+        // thread t copies the bytes [t, t+1) * share of the concatenated parts
+        const size_t share = (bytes + nt - 1) / nt;
+        std::vector<std::thread> pool;
+        pool.reserve(nt);
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&, t] {
+                const size_t lo = (size_t)t * share, hi = std::min(bytes, lo + share);
+                size_t at = 0;
+                for (auto &w : work) {
+                    const size_t a = std::max(lo, at), z = std::min<size_t>(hi, at + w.second.len);
+                    if (z > a) std::memcpy(w.first + (a - at), w.second.src + (a - at), z - a);
+                    at += w.second.len;
+                    if (at >= hi) break;
+                }
+            });
+        for (std::thread &th : pool) th.join();
+    };
+    std::vector<std::pair<char *, Piece>> work;
+    if (dense) {
+        size_t pi = 0;                // first piece that may still have bytes at or beyond the chunk start
+        for (uint64_t c0 = b->in_lo; c0 < b->in_hi; c0 += kChunk) {
+            const uint64_t c1 = std::min<uint64_t>(c0 + kChunk, b->in_hi);
+            while (pi < pieces.size() && pieces[pi].off + pieces[pi].len <= c0) ++pi;
+            if (pi == pieces.size()) break;
+            if (pieces[pi].off >= c1) continue;
+            if (used[slot]) HIP_TRY(c, hipEventSynchronize(c->pin_up_ev[slot]));
+            char *dst = (char *)c->pin_up[slot].p;
+            work.clear();
+            size_t bytes = 0;
+            uint64_t lo = c1, hi = c0;                                          // bytes of the chunk that carry bases
+            for (size_t i = pi; i < pieces.size() && pieces[i].off < c1; ++i) {
+                const uint64_t s0 = std::max(pieces[i].off, c0), s1 = std::min(pieces[i].off + pieces[i].len, c1);
+                if (s1 <= s0) continue;
+                work.push_back({dst + (s0 - c0), Piece{s0, pieces[i].src + (s0 - pieces[i].off), s1 - s0}});
+                bytes += s1 - s0;
+                lo = std::min(lo, s0); hi = std::max(hi, s1);
+            }
+            stage(work, bytes);
+            HIP_TRY(c, hipMemcpyAsync((char *)din + (lo - b->in_lo), dst + (lo - c0), hi - lo, hipMemcpyHostToDevice, c->up_stream));
+            HIP_TRY(c, hipEventRecord(c->pin_up_ev[slot], c->up_stream));
+            used[slot] = true;
+            slot = (slot + 1) % ts_ctx::kUpSlots;
+        }
+    } else {
+        for (const Piece &pc : pieces) {
+            for (uint64_t a = 0; a < pc.len; a += kChunk) {
+                const uint64_t n = std::min<uint64_t>(kChunk, pc.len - a);
+                if (used[slot]) HIP_TRY(c, hipEventSynchronize(c->pin_up_ev[slot]));
+                char *dst = (char *)c->pin_up[slot].p;
+                work.clear();
+                work.push_back({dst, Piece{pc.off + a, pc.src + a, n}});
+                stage(work, n);
+                HIP_TRY(c, hipMemcpyAsync((char *)din + (pc.off + a - b->in_lo), dst, n, hipMemcpyHostToDevice, c->up_stream));
+                HIP_TRY(c, hipEventRecord(c->pin_up_ev[slot], c->up_stream));
+                used[slot] = true;
+                slot = (slot + 1) % ts_ctx::kUpSlots;
+            }
+        }
+    }
+    return TS_OK;
+}
+
+// The terminal-block predicate of a scanned tips batch on the device: one byte per read
+// (ReadTelomereFilter::matches, src/read-filter.cpp:37-45, reduced to !terminalBlocks.empty()), written to
+// d_pass (device).  The per-read table the kernel walks is built once per batch.
+int batch_read_pass_device(ts_batch *b, unsigned char *d_pass, hipStream_t st) {
+    ts_ctx *c = b->ctx;
+    const size_t ns = b->segs.size();
+    if (!ns) return TS_OK;
+    const size_t off_in = (((ns + 1) * 4 + 15) & ~(size_t)15), off_len = off_in + ns * 8, bytes = off_len + ns * 8 + 16;
+    if (!b->d_readtab.p) {
+        std::vector<char> tab(bytes);
+        for (size_t i = 0; i < ns; ++i) {
+            ((uint32_t *)tab.data())[i] = b->segs[i].first_tile;
+            ((unsigned long long *)(tab.data() + off_in))[i] = b->segs[i].in_off;
+            ((unsigned long long *)(tab.data() + off_len))[i] = b->segs[i].len;
+        }
+        ((uint32_t *)tab.data())[ns] = (uint32_t)b->tiles.size();
+        HIP_TRY(c, c->pool.take(bytes, b->d_readtab));
+        HIP_TRY(c, hipMemcpyAsync(b->d_readtab.p, tab.data(), bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipStreamSynchronize(st));                    // (tab is a local)
+    }
+    char *const dt = (char *)b->d_readtab.p;
+    TsPredParams Q{};
+    Q.terminal_limit = c->params.terminal_limit;
+    Q.max_match_dist = c->params.max_match_dist;
+    Q.min_block_len = c->params.min_block_len;
+    Q.max_block_dist = c->params.max_block_dist;
+    Q.min_block_counts = c->params.min_block_counts;
+    Q.min_block_density = c->params.min_block_density;
+    Q.k = c->k;
+    int e = ts_k_launch_predicate((const TsTile *)b->d_tiles.p, (const unsigned long long *)b->d_tile_off.p,
+                                  b->stats_ptr(), b->records_ptr(), (const uint32_t *)dt,
+                                  (const unsigned long long *)(dt + off_in), (const unsigned long long *)(dt + off_len),
+                                  (uint32_t)ns, &Q, d_pass, st);
+    if (e != 0) return c->fail(TS_ERR_HIP, "predicate kernel launch failed");
+    return TS_OK;
+}
+
+int batch_read_pass(ts_batch *b, uint8_t *pass_out, hipStream_t st) {
+    ts_ctx *c = b->ctx;
+    const size_t ns = b->segs.size();
+    if (!ns) return TS_OK;
+    DevBuf d_pass;
+    struct Return { ts_ctx *c; DevBuf &a; ~Return() { c->pool.give(std::move(a)); } } give_back{c, d_pass};
+    HIP_TRY(c, c->pool.take(ns + 16, d_pass));
+    int rc = batch_read_pass_device(b, (unsigned char *)d_pass.p, st);
+    if (rc != TS_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(pass_out, d_pass.p, ns, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return TS_OK;
+}
+
+int batch_counts(ts_batch *b, ts_segment_counts *counts, bool tips, hipStream_t st) {
+    ts_ctx *c = b->ctx;
+    const size_t ns = b->segs.size();
+    std::vector<unsigned long long> summary(4 * ns);
+    DevBuf d_sum;
+    struct Return { ts_ctx *c; DevBuf &a; ~Return() { c->pool.give(std::move(a)); } } give_back{c, d_sum};
+    HIP_TRY(c, c->pool.take(summary.size() * 8 + 16, d_sum));
+    int rc = ts_batch_segment_summary(b, d_sum.p, st);
+    if (rc != TS_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(summary.data(), d_sum.p, summary.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (size_t i = 0; i < ns; ++i)
+        counts[i] = ts_segment_counts{tips ? 0 : summary[4 * i], summary[4 * i + 1], summary[4 * i + 2], summary[4 * i + 3]};
+    return TS_OK;
+}
+
+// The three-stage pipeline over the groups of one call.  items: the call's segments or reads in input order;
+// results go to out / counts / pass at the same indices.
+int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &items, ts_segment_out *out,
+                 ts_segment_counts *counts, uint8_t *pass) {
+    if (items.empty()) return TS_OK;
+    if (ctx->device == kNoDevice) return ctx->fail(TS_ERR_NO_DEVICE, "planning-only context: no HIP device behind it");
+    const auto t_begin = Clock::now();
+    const bool timing = getenv("TS_TIMING") != nullptr;          // stage times to stderr
+    {
+        DeviceGuard g(ctx->device);
+        if (g.error() != hipSuccess) return ctx->fail(TS_ERR_HIP, "hipSetDevice failed");
+        int rc = ensure_streams(ctx);
+        if (rc != TS_OK) return rc;
+    }
+    // groups of consecutive items, ~256 MB of input layout each (an item larger than that is its own group)
+    std::vector<Group> groups;
+    {
+        const uint64_t target = group_target_bytes();
+        uint64_t acc = 0;
+        Group g;
+        for (size_t i = 0; i < items.size(); ++i) {
+            const uint64_t bytes = (items[i].len + 15) & ~15ull;
+            if (g.count && acc + bytes > target) { groups.push_back(g); g = Group{}; g.first = i; acc = 0; }
+            ++g.count;
+            acc += bytes;
+        }
+        if (g.count) groups.push_back(g);
+    }
+    std::atomic<int> first_err{TS_OK};
+    auto set_err = [&](int rc) { int expected = TS_OK; first_err.compare_exchange_strong(expected, rc); };
+    Channel<Group *> to_scan, to_down;
+    Semaphore inputs_in_flight(2);                               // device input buffers alive at a time
+
+    std::thread uploader([&] {
+        DeviceGuard g(ctx->device);
+        int slot = 0;
+        bool used[ts_ctx::kUpSlots] = {false, false, false};
+        std::vector<uint64_t> lens, abs;
+        for (Group &gr : groups) {
+            if (first_err.load() != TS_OK) break;
+            const auto t0 = Clock::now();
+            lens.resize(gr.count); abs.resize(gr.count);
+            for (size_t i = 0; i < gr.count; ++i) { lens[i] = items[gr.first + i].len; abs[i] = items[gr.first + i].abs_pos; }
+            inputs_in_flight.acquire();
+            gr.b = ts_batch_create(ctx, lens.data(), abs.data(), gr.count, tips ? 1 : 0, 0);
+            if (!gr.b) { set_err(ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP); inputs_in_flight.release(); break; }
+            int rc = ts_batch_ensure_device(gr.b);
+            const auto t1 = Clock::now();
+            if (rc == TS_OK) rc = upload_batch(gr.b, items.data() + gr.first, slot, used);
+            if (rc == TS_OK && hipEventCreateWithFlags(&gr.uploaded, hipEventDisableTiming) != hipSuccess) rc = ctx->fail(TS_ERR_HIP, "hipEventCreate failed");
+            if (rc == TS_OK && hipEventRecord(gr.uploaded, ctx->up_stream) != hipSuccess) rc = ctx->fail(TS_ERR_HIP, "hipEventRecord failed");
+            gr.t_plan = ms_between(t0, t1);
+            gr.t_upload = ms_between(t1, Clock::now());
+            if (rc != TS_OK) { set_err(rc); ts_batch_destroy(gr.b); gr.b = nullptr; inputs_in_flight.release(); break; }
+            to_scan.push(&gr);
+        }
+        (void)hipStreamSynchronize(ctx->up_stream);              // the pinned ring is free again when the call returns
+        to_scan.close();
+    });
+
+    std::thread scanner([&] {
+        DeviceGuard g(ctx->device);
+        Group *gr;
+        while (to_scan.pop(gr)) {
+            const auto t0 = Clock::now();
+            int rc = first_err.load();
+            if (rc == TS_OK && hipStreamWaitEvent(ctx->scan_stream, gr->uploaded, 0) != hipSuccess) rc = ctx->fail(TS_ERR_HIP, "hipStreamWaitEvent failed");
+            if (rc == TS_OK) rc = ts_batch_scan(gr->b, nullptr, ctx->scan_stream);
+            if (rc == TS_OK) rc = ts_batch_sync(gr->b);          // waits for the scan; regrows + rescans on overflow
+            ts_batch_release_input(gr->b);
+            inputs_in_flight.release();
+            gr->t_scan = ms_between(t0, Clock::now());
+            if (rc != TS_OK) set_err(rc);
+            to_down.push(gr);
+        }
+        to_down.close();
+    });
+
+    std::thread downloader([&] {
+        DeviceGuard g(ctx->device);
+        std::lock_guard<std::mutex> dl(ctx->down_mtx);           // the pinned landing areas are this call's
+        Group *gr;
+        std::thread post;                                        // host post-processing of the previous group
+        int slot = 0;
+        auto retire = [&](Group *g2, double t_from) {
+            if (g2->uploaded) (void)hipEventDestroy(g2->uploaded);
+            ts_batch_destroy(g2->b);
+            g2->b = nullptr;
+            g2->t_down += t_from;
+        };
+        while (to_down.pop(gr)) {
+            const auto t0 = Clock::now();
+            int rc = first_err.load();
+            if (rc == TS_OK) gr->b->last_stream = ctx->down_stream;   // the scan is complete (synced): later work runs on this stage's stream
+            if (rc == TS_OK && mode == Mode::ReadPass) {
+                rc = batch_read_pass(gr->b, pass + gr->first, ctx->down_stream);
+            } else if (rc == TS_OK) {
+                // device work + D2H of this group while the previous group's records are expanded on the host threads
+                ts_fetched *f = ts_batch_fetch(gr->b, mode == Mode::Matches, slot, &rc);
+                if (rc == TS_OK && mode == Mode::Blocks && counts) rc = batch_counts(gr->b, counts + gr->first, tips, ctx->down_stream);
+                if (post.joinable()) post.join();
+                if (rc == TS_OK) {
+                    Group *g2 = gr;
+                    post = std::thread([&, g2, f] {
+                        DeviceGuard g3(ctx->device);
+                        const auto p0 = Clock::now();
+                        const int prc = ts_batch_finalize(g2->b, f, out + g2->first);
+                        if (prc != TS_OK) set_err(prc);
+                        retire(g2, ms_between(p0, Clock::now()));
+                    });
+                    slot ^= 1;
+                    gr->t_down += ms_between(t0, Clock::now());
+                    continue;
+                }
+                if (f) { std::vector<ts_segment_out> scratch(gr->count); (void)ts_batch_finalize(gr->b, f, scratch.data()); ts_free_segments(scratch.data(), scratch.size()); }
+            }
+            if (rc != TS_OK) set_err(rc);
+            retire(gr, ms_between(t0, Clock::now()));
+        }
+        if (post.joinable()) post.join();
+    });
+    uploader.join();
+    scanner.join();
+    downloader.join();
+    if (timing) {
+        double p = 0, u = 0, s = 0, d = 0;
+        for (const Group &gr : groups) { p += gr.t_plan; u += gr.t_upload; s += gr.t_scan; d += gr.t_down; }
+        const char *name = mode == Mode::Matches ? "ts_scan_segments" : mode == Mode::Blocks ? "ts_scan_segments_blocks" : "ts_filter_reads";
+        fprintf(stderr, "%s: %zu items in %zu groups, wall %.1f ms; stage sums (concurrent): plan %.1f ms, stage+upload %.1f ms, "
+                        "scan (incl. waiting for the upload) %.1f ms, download + host post-processing %.1f ms\n",
+                name, items.size(), groups.size(), ms_between(t_begin, Clock::now()), p, u, s, d);
+    }
+    return first_err.load();
+}
+
+// =========================================================================== general path
+// For parameter sets outside the tiled kernel's closed form (mixed-length pattern sets, pattern
+// lengths > 9, or a longest pattern exceeding min(step, window-step) where the reference's
+// uint32 start index wraps): ts_generic_match + ts_generic_windows (generic.hip) on the device,
+// then only ordering work on the host.  One segment at a time; this is the slow exact path.
+int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<size_t> &which,
+                       bool tips, ts_segment_out *out) {
+    if (which.empty()) return TS_OK;
+    if (!c->generic_ok)
+        return c->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: more than 8 pattern lengths, a pattern longer "
+                                           "than 32 or a non-ACGT pattern");
+    DEVICE_TRY(c);
+    std::lock_guard<std::mutex> lk(c->mtx);
+    const ts_params &P = c->params;
+    const uint32_t s = P.step, w = P.window_size, ov = w - s, L = c->longest;
+    DevBuf d_seq, d_mask, d_win;                 // (freed by their destructors on every path)
+    std::vector<uint32_t> mask, wins;
+    std::vector<ts_match> matches;
+    struct Hit { uint64_t k, p; uint16_t len; uint8_t flags; };
+    std::vector<Hit> hits;
+    int rc = TS_OK;
+    for (size_t wi = 0; wi < which.size() && rc == TS_OK; ++wi) {
+        const ts_segment_in &sg = segs[which[wi]];
+        const uint64_t N = sg.len;
+        matches.clear();
+        uint64_t nwin = 0;
+        // regions exactly as scanSegment picks them (src/teloscope.cpp:576-583; uint32 product)
+        std::vector<std::pair<uint64_t, uint64_t>> regions;
+        if (tips) {
+            const uint32_t twice = 2u * P.terminal_limit;
+            if (N > twice) { regions.emplace_back(0, P.terminal_limit); regions.emplace_back(N - P.terminal_limit, P.terminal_limit); }
+            else if (N) regions.emplace_back(0, N);
+        } else if (N) {
+            regions.emplace_back(0, N);
+            nwin = ceil_div(N, s);
+        }
+        for (const auto &rg : regions) {
+            const uint64_t r0 = rg.first, n = rg.second;
+            if (d_seq.ensure(n + 16) != hipSuccess || d_mask.ensure(n * 4 + 16) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "device allocation failed"); break; }
+            if (hipMemcpy(d_seq.p, sg.seq + r0, n, hipMemcpyHostToDevice) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "H2D copy failed"); break; }
+            if (ts_k_launch_generic_match((const unsigned char *)d_seq.p, n, &c->gpat, P.fold_case, (uint32_t *)d_mask.p, nullptr) != 0) { rc = c->fail(TS_ERR_HIP, "generic match kernel launch failed"); break; }
+            if (!tips) {
+                TsGenericGeom Q{};
+                Q.n = N; Q.s = s; Q.w = w; Q.longest = L; Q.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u; Q.fold = P.fold_case;
+                if (d_win.ensure(nwin * 32 + 16) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "device allocation failed"); break; }
+                if (ts_k_launch_generic_windows((const unsigned char *)d_seq.p, (const uint32_t *)d_mask.p, &c->gpat, &Q, nwin, (uint32_t *)d_win.p, nullptr) != 0) { rc = c->fail(TS_ERR_HIP, "generic window kernel launch failed"); break; }
+                wins.resize(nwin * 8);
+                if (hipMemcpy(wins.data(), d_win.p, nwin * 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "D2H copy failed"); break; }
+            }
+            mask.resize(n);
+            if (hipMemcpy(mask.data(), d_mask.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "D2H copy failed"); break; }
+
+            // enumerate matches in (position, length) order; in full-scan mode keep those some
+            // window's own scan pushes (src/teloscope.cpp:485) and order them by that window
+            hits.clear();
+            const uint32_t t1 = s - L, t2 = ov - L;                     // uint32 wrap, src/teloscope.cpp:413-415
+            const uint32_t start_index = t1 < t2 ? t1 : t2;
+            for (uint64_t p = 0; p < n; ++p) {
+                const uint32_t m = mask[p];
+                if (!m) continue;
+                for (uint32_t li = 0; li < c->gpat.nlen; ++li) {
+                    const uint32_t b = (m >> (3 * li)) & 7u;
+                    if (!(b & 1u)) continue;
+                    const uint32_t len = c->gpat.len[li];
+                    const uint8_t fl = (uint8_t)(((b & 2u) ? TS_MATCH_FORWARD : 0u) | ((b & 4u) ? TS_MATCH_CANONICAL : 0u));
+                    uint64_t k = 0;
+                    if (!tips) {
+                        const uint64_t e = p + len - 1;
+                        if (ov == 0) {
+                            k = p / s;
+                            const uint64_t cws = std::min<uint64_t>(w, N - k * s);
+                            if ((p - k * s) + len > cws) continue;      // crosses its only window's end
+                        } else if (e < std::min<uint64_t>(w, N)) {
+                            k = 0;                                      // window 0 scans everything it holds
+                        } else {
+                            k = (e - ov) / s;                           // the one window with j >= overlap
+                            if (p < k * s || (p - k * s) < start_index) continue;
+                        }
+                    }
+                    hits.push_back(Hit{k, r0 + p, (uint16_t)len, fl});
+                }
+            }
+            if (!tips)
+                std::stable_sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.k < b.k; });
+            for (const Hit &h : hits) {
+                ts_match m{};
+                m.position = sg.abs_pos + h.p;
+                m.match_size = h.len;
+                m.flags = h.flags;
+                matches.push_back(m);
+            }
+        }
+        if (rc != TS_OK) break;
+        ts_match *arr = matches.empty() ? nullptr : (ts_match *)std::malloc(matches.size() * sizeof(ts_match));
+        if (!matches.empty() && !arr) { rc = c->fail(TS_ERR_ALLOC, "out of host memory"); break; }
+        if (arr) std::memcpy(arr, matches.data(), matches.size() * sizeof(ts_match));
+        rc = ts_finalize_segment(c, tips, N, sg.abs_pos, wins.data(), nwin, arr, matches.size(), out[which[wi]], 16u);   // (general path: one segment at a time)
+    }
+    return rc;
+}
+
+std::vector<Item> items_of(const ts_segment_in *segs, const std::vector<size_t> &which) {
+    std::vector<Item> v(which.size());
+    for (size_t i = 0; i < which.size(); ++i) v[i] = Item{segs[which[i]].seq, segs[which[i]].len, segs[which[i]].abs_pos};
+    return v;
+}
+
+// scanSegment over the subset `which` (all full scans or all tips-only) on the tiled kernel
+int scan_subset(ts_ctx *ctx, Mode mode, const ts_segment_in *segs, const std::vector<size_t> &which, bool tips,
+                ts_segment_out *out, ts_segment_counts *counts) {
+    if (which.empty()) return TS_OK;
+    const std::vector<Item> items = items_of(segs, which);
+    // results land in arrays parallel to `which`, then move to their places
+    std::vector<ts_segment_out> tmp(which.size());
+    std::vector<ts_segment_counts> cnt(counts ? which.size() : 0);
+    int rc = run_pipeline(ctx, mode, tips, items, tmp.data(), counts ? cnt.data() : nullptr, nullptr);
+    if (rc != TS_OK) { ts_free_segments(tmp.data(), tmp.size()); return rc; }
+    for (size_t i = 0; i < which.size(); ++i) {
+        out[which[i]] = tmp[i];
+        if (counts) counts[which[i]] = cnt[i];
+    }
+    return TS_OK;
+}
+
+// ts_scan_segments without the per-context call lock (ts_filter_reads holds it when it comes here)
+int scan_segments_unlocked(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out) {
+    for (size_t i = 0; i < n_segs; ++i) {
+        std::memset(&out[i], 0, sizeof out[i]);
+        if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
+    }
+    std::vector<size_t> full, tips;
+    for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
+    std::string why;
+    int rc = ts_full_scan_supported(ctx, why) ? scan_subset(ctx, Mode::Matches, segs, full, false, out, nullptr)
+                                              : scan_group_generic(ctx, segs, full, false, out);
+    if (rc == TS_OK) rc = ctx->fast_ok ? scan_subset(ctx, Mode::Matches, segs, tips, true, out, nullptr)
+                                       : scan_group_generic(ctx, segs, tips, true, out);
+    if (rc != TS_OK) ts_free_segments(out, n_segs);
+    return rc;
+}
+
+}  // namespace
+
+// =========================================================================== scanSegment, batched
+extern "C" {
+
+int ts_scan_segments(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out) {
+    if (!ctx || (n_segs && (!segs || !out))) return TS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> api(ctx->api_mtx);
+    return scan_segments_unlocked(ctx, segs, n_segs, out);
+}
+
+// scanSegment for callers that do not read the match vectors: scan, block calling and the per-segment
+// counts all stay on the device; windows, blocks and four counters per segment cross PCIe.
+int ts_scan_segments_blocks(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out,
+                            ts_segment_counts *counts) {
+    if (!ctx || (n_segs && (!segs || !out))) return TS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> api(ctx->api_mtx);
+    for (size_t i = 0; i < n_segs; ++i) {
+        std::memset(&out[i], 0, sizeof out[i]);
+        if (counts) counts[i] = ts_segment_counts{0, 0, 0, 0};
+        if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
+    }
+    std::vector<size_t> full, tips;
+    for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
+    // parameter sets outside the tiled kernel take the general path and drop the match vectors afterwards
+    auto via_matches = [&](const std::vector<size_t> &which, bool tips_mode) -> int {
+        int rc = scan_group_generic(ctx, segs, which, tips_mode, out);
+        if (rc != TS_OK) return rc;
+        for (size_t i : which) {
+            if (counts) {
+                ts_segment_counts cnt{tips_mode ? 0 : out[i].n_windows, out[i].n_matches, 0, 0};
+                for (uint64_t m = 0; m < out[i].n_matches; ++m) {
+                    cnt.n_canonical += (out[i].matches[m].flags & TS_MATCH_CANONICAL) ? 1 : 0;
+                    cnt.n_forward += (out[i].matches[m].flags & TS_MATCH_FORWARD) ? 1 : 0;
+                }
+                counts[i] = cnt;
+            }
+            std::free(out[i].matches);
+            out[i].matches = nullptr;
+            out[i].n_matches = 0;
+        }
+        return TS_OK;
+    };
+    std::string why;
+    int rc = ts_full_scan_supported(ctx, why) ? scan_subset(ctx, Mode::Blocks, segs, full, false, out, counts) : via_matches(full, false);
+    if (rc == TS_OK) rc = ctx->fast_ok ? scan_subset(ctx, Mode::Blocks, segs, tips, true, out, counts) : via_matches(tips, true);
+    if (rc != TS_OK) ts_free_segments(out, n_segs);
+    return rc;
+}
+
+// =========================================================================== ReadTelomereFilter
+int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, size_t n_reads,
+                    uint8_t *pass) {
+    if (!ctx || (n_reads && (!seqs || !lens || !pass))) return TS_ERR_INVALID_ARG;
+    if (!ctx->read_filter) return ctx->fail(TS_ERR_STATE, "context was not made by ts_create_read_filter");
+    if (n_reads == 0) return TS_OK;
+    std::lock_guard<std::mutex> api(ctx->api_mtx);
+    std::vector<Item> items(n_reads);
+    for (size_t i = 0; i < n_reads; ++i) {
+        uint64_t n = lens[i];
+        if (n && !seqs[i]) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
+        if (n && seqs[i][n - 1] == '\r') --n;             // src/read-filter.cpp:38-40
+        items[i] = Item{seqs[i], n, 0};
+    }
+    if (!ctx->fast_ok) {
+        // pattern sets outside the tiled kernel (mixed lengths, k > 8): general kernels + host block calling.
+        // (the call lock is already held: the unlocked form of ts_scan_segments)
+        std::vector<ts_segment_in> in(n_reads);
+        for (size_t i = 0; i < n_reads; ++i) { in[i] = ts_segment_in{}; in[i].seq = items[i].seq; in[i].len = items[i].len; in[i].abs_pos = 0; in[i].tips_only = 1; }
+        std::vector<ts_segment_out> out(n_reads);
+        int rc = scan_segments_unlocked(ctx, in.data(), n_reads, out.data());
+        if (rc != TS_OK) return rc;
+        for (size_t i = 0; i < n_reads; ++i) pass[i] = out[i].n_terminal_blocks != 0;
+        ts_free_segments(out.data(), n_reads);
+        return TS_OK;
+    }
+    // tiled path: whole-read tips scan, then the terminal-block predicate on the device; only one
+    // byte per read comes back
+    return run_pipeline(ctx, Mode::ReadPass, true, items, nullptr, nullptr, pass);
+}
+
+// ReadTelomereFilter::matches over a device-resident tips-only batch (reads already in HBM, scanned on `stream`):
+// the pass byte of every read to d_pass, asynchronously on the same stream.
+int ts_batch_read_pass(ts_batch *b, void *d_pass, void *stream) {
+    if (!b || !d_pass) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    DEVICE_TRY(c);
+    if (!b->tips || !b->whole() || !b->scanned) return c->fail(TS_ERR_STATE, "ts_batch_read_pass needs a scanned, unrestricted tips-only batch");
+    return batch_read_pass_device(b, (unsigned char *)d_pass, (hipStream_t)stream);
+}
+
+int ts_filter_reads_multi(ts_ctx *const *ctxs, size_t n_ctx, const char *const *seqs, const uint64_t *lens,
+                          size_t n_reads, uint8_t *pass) {
+    if (!ctxs || !n_ctx || (n_reads && (!seqs || !lens || !pass))) return TS_ERR_INVALID_ARG;
+    for (size_t i = 0; i < n_ctx; ++i) if (!ctxs[i]) return TS_ERR_INVALID_ARG;
+    if (n_ctx == 1 || n_reads < 2 * n_ctx) return ts_filter_reads(ctxs[0], seqs, lens, n_reads, pass);
+    // consecutive shards of equal bases: shard d ends at the first read where the running total reaches
+    // (d + 1) / n_ctx of all bases; pass[] is written in place, so the result is in input order by construction
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_reads; ++i) total += lens[i];
+    std::vector<size_t> cut(n_ctx + 1, n_reads);
+    cut[0] = 0;
+    {
+        uint64_t acc = 0;
+        size_t d = 1;
+        for (size_t i = 0; i < n_reads && d < n_ctx; ++i) {
+            acc += lens[i];
+            while (d < n_ctx && (unsigned __int128)acc * n_ctx >= (unsigned __int128)total * d) cut[d++] = i + 1;
+        }
+    }
+    std::vector<int> rcs(n_ctx, TS_OK);
+    std::vector<std::thread> pool;
+    for (size_t d = 0; d < n_ctx; ++d)
+        pool.emplace_back([&, d] {
+            const size_t a = cut[d], z = cut[d + 1];
+            if (z > a) rcs[d] = ts_filter_reads(ctxs[d], seqs + a, lens + a, z - a, pass + a);
+        });
+    for (std::thread &th : pool) th.join();
+    for (size_t d = 0; d < n_ctx; ++d)
+        if (rcs[d] != TS_OK) {
+            if (d != 0) ctxs[0]->fail(rcs[d], std::string("shard on context ") + std::to_string(d) + ": " + ts_last_error(ctxs[d]));
+            return rcs[d];
+        }
+    return TS_OK;
+}
+
+}  // extern "C"

@@ -136,6 +136,15 @@ int  ts_k_launch_block_call(const TsBlockCallParams *Q, const uint32_t *seg_firs
                             const unsigned long long *seg_in_off, const unsigned long long *seg_len,
                             const unsigned long long *seg_abs, uint32_t nseg, uint32_t ntiles,
                             unsigned long long *bounds, int with_its, void *stream);
+// exchange.hip: tile directory of a dense tile-ordered stream, and the export of a scan's records into one
+unsigned long long ts_k_scan_tmp_bytes(uint32_t ntiles);
+int  ts_k_launch_tile_offsets(const uint32_t *tile_stats, uint32_t ntiles, unsigned long long *tile_off, void *tmp,
+                              void *stream);
+int  ts_k_launch_tile_order_export(const uint32_t *tile_stats, const unsigned long long *region_off,
+                                   const uint32_t *regions, const uint32_t *wave_fill, uint32_t region_cap,
+                                   uint32_t nwaves, uint32_t ntiles, unsigned long long *dense_off, void *tmp,
+                                   uint32_t *dense, unsigned long long capacity, unsigned long long *total_out,
+                                   void *stream);
 int  ts_k_launch_compact(const uint32_t *regions, const uint32_t *wave_fill,
                          const unsigned long long *wave_dense_base, uint32_t region_cap,
                          uint32_t nwaves, uint32_t *dense, void *stream);

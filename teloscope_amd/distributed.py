@@ -1,21 +1,39 @@
-"""Multi-GPU sharding of the scan path: one process per GPU, torch.distributed (RCCL on
-ROCm; gloo for CPU rehearsal).
+"""Multi-GPU form of the scan path: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" for CPU tests and for rehearsing several ranks on one GPU).
 
-The reference parallelises by path (one thread-pool job per path, src/input.cpp:719-724);
-segments are independent units here too, so ranks scan disjoint sets of segments with no
-data-path collective.  The only exchange is ONE gather of the per-segment hit summaries
-({windows, matches, canonical, forward} x int64, produced on the device by
-ts_batch_segment_summary) to rank 0, which needs them for the path summary report; window
-records and match streams stay on the rank that produced them.
+The reference parallelises by path — one thread-pool job per path (src/input.cpp:719-724), results merged
+in seqPos order (sortBySeqPos, include/teloscope.h:262-266).  Here the unit is a TILE of the batch's plan
+(a run of consecutive windows of one segment + its w-s halo; windows are independent):
+
+  * every rank builds the SAME plan from the segment lengths (host-only, deterministic) and takes the p-th of
+    `world` CONSECUTIVE tile ranges of equal bases (ts_batch_partition): a 250 Mb chromosome spreads over
+    ranks, and no data-path collective is needed to scan;
+  * a rank's results are three arrays — window records (8 x u32 per window), tile directory entries
+    ({matches, canonical, forward, 0} x u32 per tile) and its packed match records as ONE stream in tile order
+    (ts_batch_export) — and because the ranges are consecutive, the whole batch's arrays are their
+    concatenation in rank order;
+  * ONE exchange per scan puts them together on the destination rank: an all-gather of the record counts
+    (8 B per rank) and one grouped round of send/recv (a Gatherv: 7 senders -> rank 0 over 7 distinct xGMI
+    links) straight into their places in the destination's arrays.  The destination then adopts the arrays
+    (ts_batch_adopt: a prefix sum over the tile counts rebuilds the directory) and holds exactly what a
+    single-GPU scan of the whole batch holds: ts_batch_download / _download_blocks / _segment_summary apply.
+
+`gather_shards` is backend-agnostic and is what bench.py runs at N > 1; tests/test_distributed_gloo.py drives
+the same function on two gloo ranks (no GPU: the tile results there are computed by the test itself).
 """
-from typing import List, Sequence
+import ctypes as C
+from typing import List, Optional, Sequence
 
 import numpy as np
 
+from . import _capi as K
+
 
 def lpt_partition(lengths: Sequence[int], world_size: int) -> List[List[int]]:
-    """Longest-processing-time-first assignment of segments to ranks (deterministic):
-    returns, per rank, the ascending list of segment indices it scans."""
+    """Longest-processing-time-first assignment of whole segments to ranks (deterministic): per rank, the
+    ascending list of segment indices.  The tile-range split of ShardPlan balances better (a segment may
+    spread over ranks); this remains for callers that must keep segments whole (e.g. one FASTA record per
+    host upload)."""
     order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
     load = [0] * world_size
     shards: List[List[int]] = [[] for _ in range(world_size)]
@@ -26,8 +44,354 @@ def lpt_partition(lengths: Sequence[int], world_size: int) -> List[List[int]]:
     return [sorted(s) for s in shards]
 
 
+class ShardPlan:
+    """The plan of one batch (all segments) and its split into `world` consecutive tile ranges.
+    Host-only: `teloscope` may sit on a planning-only context (UserInputTeloscope.device = DEVICE_NONE)."""
+
+    def __init__(self, teloscope, seg_lens: Sequence[int], abs_pos: Optional[Sequence[int]] = None,
+                 tips_only: bool = False, world: int = 1, match_capacity: int = 0):
+        self.L = K.lib()
+        self.teloscope = teloscope
+        self.seg_lens = [int(x) for x in seg_lens]
+        self.abs_pos = [int(x) for x in abs_pos] if abs_pos is not None else None
+        self.tips_only = bool(tips_only)
+        self.world = int(world)
+        self.match_capacity = int(match_capacity)
+        self.batch = self._create()
+        self.info = K.BatchInfo()
+        self.L.ts_batch_get_info(self.batch, C.byref(self.info))
+        self.n_tiles = int(self.info.n_tiles)
+        self.n_windows = 0 if self.tips_only else int(self.info.n_windows)
+        self.ranges = []
+        for p in range(self.world):
+            lo, hi = C.c_uint64(), C.c_uint64()
+            rc = self.L.ts_batch_partition(self.batch, self.world, p, C.byref(lo), C.byref(hi))
+            if rc != K.TS_OK:
+                raise K.TeloscanError(rc, "ts_batch_partition failed")
+            self.ranges.append(self.range_info(lo.value, hi.value))
+        self._tiles = None
+
+    def _create(self):
+        n = len(self.seg_lens)
+        lens = (C.c_uint64 * max(1, n))(*self.seg_lens)
+        ab = (C.c_uint64 * max(1, n))(*self.abs_pos) if self.abs_pos is not None else None
+        b = self.L.ts_batch_create(self.teloscope._ctx.ptr, lens, ab, n, int(self.tips_only), self.match_capacity)
+        if not b:
+            raise K.TeloscanError(K.TS_ERR_UNSUPPORTED, self.teloscope._ctx.error())
+        return b
+
+    def new_batch(self):
+        """Another batch object over the same plan (a rank's shard, the destination's assembly)."""
+        return self._create()
+
+    def range_info(self, lo, hi):
+        r = K.RangeInfo()
+        rc = self.L.ts_batch_range_info(self.batch, lo, hi, C.byref(r))
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, "ts_batch_range_info failed")
+        return r
+
+    @property
+    def tiles(self):
+        """numpy structured array of ts_tile_info for every tile of the plan."""
+        if self._tiles is None:
+            t = np.zeros(self.n_tiles, dtype=K.TILE_DT)
+            if self.n_tiles:
+                rc = self.L.ts_batch_get_tiles(self.batch, 0, self.n_tiles, t.ctypes.data)
+                if rc != K.TS_OK:
+                    raise K.TeloscanError(rc, "ts_batch_get_tiles failed")
+            self._tiles = t
+        return self._tiles
+
+    def segment_offsets(self):
+        return [int(self.L.ts_batch_segment_offset(self.batch, i)) for i in range(len(self.seg_lens))]
+
+    def close(self):
+        if self.batch:
+            self.L.ts_batch_destroy(self.batch)
+            self.batch = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Assembled:
+    """The whole batch's result arrays on the destination rank (torch tensors, int32 = the bits of u32)."""
+
+    def __init__(self, windows, stats, dense, n_records, counts):
+        self.windows, self.stats, self.dense = windows, stats, dense
+        self.n_records = int(n_records)
+        self.counts = [int(c) for c in counts]              # records per rank
+
+
+class GatherHandle:
+    def __init__(self, works, finish, keep=None):
+        self._works, self._finish, self.result = works, finish, None
+        self._keep = keep                                   # tensors that must outlive the transfers
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._keep = None
+        if self._finish is not None:
+            self.result = self._finish()
+            self._finish = None
+        return self.result
+
+
+def gather_shards(plan: ShardPlan, rank: int, windows, stats, dense, n_records: int, dst: int = 0,
+                  group=None, out: Optional[Assembled] = None, async_op: bool = False, directory_only: bool = False):
+    """The one exchange of a sharded scan (a Gatherv to `dst`).
+
+    windows / stats / dense: this rank's result arrays as flat int32 torch tensors — windows of its range
+    (8 per window), tile directory entries of its range (4 per tile), and its tile-ordered record stream
+    (the first n_records elements are sent).  On `dst` they may be views into `out` already (its own results
+    are then in place and not copied).  Returns (on dst) an Assembled whose arrays hold the whole batch, None
+    elsewhere; with async_op a GatherHandle whose wait() returns that.
+
+    directory_only: the summaries-only variant — only the tile directory entries travel (16 B per tile: what the
+    path summary report needs, per-segment match / canonical / forward counts, is a sum over a segment's
+    tiles); window and match records stay on the rank that produced them.
+
+    Works on any backend: tensors on the device for "nccl" (RCCL, straight between HBMs over xGMI), staged
+    through host memory for "gloo"."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    assert world == plan.world, "the plan was split for a different number of ranks"
+    backend = dist.get_backend(group)
+    on_device = backend == "nccl"
+    dev = windows.device
+    wire_dev = dev if on_device else torch.device("cpu")
+    r = plan.ranges[rank]
+    assert windows.numel() == 8 * (0 if plan.tips_only else (r.window_end - r.window_begin))
+    assert stats.numel() == 4 * (r.tile_end - r.tile_begin)
+
+    # 1. record counts of all ranks (8 B each)
+    if directory_only:
+        counts = [0] * world
+        n_records = 0
+    else:
+        mine = torch.tensor([int(n_records)], dtype=torch.int64, device=wire_dev)
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine, group=group)
+        counts = [int(c.item()) for c in allc]
+
+    def wire(t):
+        return t if t.device == wire_dev else t.to(wire_dev)
+
+    # 2. grouped send/recv: every rank's three arrays go to their places on dst
+    if rank != dst:
+        ops, keep = [], []
+        if windows.numel() and not directory_only:
+            keep.append(wire(windows))
+            ops.append(dist.P2POp(dist.isend, keep[-1], dst, group=group, tag=1))
+        if stats.numel():
+            keep.append(wire(stats))
+            ops.append(dist.P2POp(dist.isend, keep[-1], dst, group=group, tag=2))
+        if n_records:
+            keep.append(wire(dense[:n_records]))
+            ops.append(dist.P2POp(dist.isend, keep[-1], dst, group=group, tag=3))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        h = GatherHandle(works, None, keep)
+        return h if async_op else h.wait()
+
+    total = sum(counts)
+    if out is None:
+        out = Assembled(torch.empty(8 * plan.n_windows, dtype=torch.int32, device=dev),
+                        torch.empty(4 * plan.n_tiles, dtype=torch.int32, device=dev),
+                        torch.empty(max(total, 1), dtype=torch.int32, device=dev), 0, counts)
+    if out.dense.numel() < total:
+        grown = torch.empty(total + total // 8 + 1024, dtype=torch.int32, device=dev)
+        out.dense = grown
+    out.n_records, out.counts = total, counts
+    rec_off = [0]
+    for c in counts:
+        rec_off.append(rec_off[-1] + c)
+
+    def place(dst_t, src_t):                                   # dst's own arrays, unless they are already views of `out`
+        if src_t.numel() and dst_t.data_ptr() != src_t.data_ptr():
+            dst_t.copy_(src_t)
+
+    ops, landing = [], []
+    for p in range(world):
+        rp = plan.ranges[p]
+        w = out.windows[8 * rp.window_begin:8 * rp.window_end] if not plan.tips_only else out.windows[:0]
+        s = out.stats[4 * rp.tile_begin:4 * rp.tile_end]
+        d = out.dense[rec_off[p]:rec_off[p + 1]]
+        if p == dst:
+            if not directory_only:
+                place(w, windows)
+                place(d, dense[:counts[p]])
+            place(s, stats)
+            continue
+        for t, tag in ((w, 1), (s, 2), (d, 3)):
+            if not t.numel() or (directory_only and tag != 2):
+                continue
+            if on_device:
+                ops.append(dist.P2POp(dist.irecv, t, p, group=group, tag=tag))
+            else:
+                tmp = torch.empty(t.numel(), dtype=torch.int32)
+                ops.append(dist.P2POp(dist.irecv, tmp, p, group=group, tag=tag))
+                landing.append((t, tmp))
+    works = dist.batch_isend_irecv(ops) if ops else []
+
+    def finish():
+        for t, tmp in landing:
+            t.copy_(tmp)
+        return out
+
+    h = GatherHandle(works, finish)
+    return h if async_op else h.wait()
+
+
+def decode_segments(plan: ShardPlan, windows: np.ndarray, stats: np.ndarray, dense: np.ndarray):
+    """Host view of a whole batch's raw arrays: per segment a dict with `windows` ([n, 8] u32: A, C, G, T,
+    canonical/non-canonical/forward/reverse covered bases) and `matches` (structured: absolute position,
+    forward, canonical) in position order."""
+    tiles = plan.tiles
+    stats = np.asarray(stats, dtype=np.uint32).reshape(-1, 4)
+    dense = np.asarray(dense, dtype=np.uint32)
+    wins = np.asarray(windows, dtype=np.uint32).reshape(-1, 8)
+    counts = stats[:, 0].astype(np.int64)
+    offs = np.concatenate(([0], np.cumsum(counts)))
+    # absolute position of every record: segment abs_pos + tile offset + tile-relative position
+    abs_pos = np.asarray(plan.abs_pos if plan.abs_pos is not None else [0] * len(plan.seg_lens), dtype=np.uint64)
+    tile_base = abs_pos[tiles["seg_index"].astype(np.int64)] + tiles["seg_offset"]
+    rec_tile = np.repeat(np.arange(len(tiles)), counts)
+    n = int(offs[-1])
+    pos = tile_base[rec_tile] + (dense[:n] >> 2).astype(np.uint64)
+    fwd = (dense[:n] & 2) != 0
+    can = (dense[:n] & 1) != 0
+    seg_of_tile = tiles["seg_index"].astype(np.int64)
+    out = []
+    win_at = 0
+    step = plan.teloscope.userInput.step
+    for si, ln in enumerate(plan.seg_lens):
+        tsel = np.flatnonzero(seg_of_tile == si)
+        if len(tsel):
+            a, b = int(offs[tsel[0]]), int(offs[tsel[-1] + 1])
+        else:
+            a = b = 0
+        m = np.zeros(b - a, dtype=[("position", np.uint64), ("is_forward", np.bool_), ("is_canonical", np.bool_)])
+        m["position"], m["is_forward"], m["is_canonical"] = pos[a:b], fwd[a:b], can[a:b]
+        nwin = 0 if plan.tips_only else -(-ln // step)
+        out.append(dict(windows=wins[win_at:win_at + nwin], matches=m))
+        win_at += nwin
+    return out
+
+
+class HipShard:
+    """One rank's shard on its GPU: a batch restricted to the rank's tile range, bound to torch-owned result
+    buffers, with the tile-ordered export that feeds gather_shards.  `slots` independent buffer sets (each its
+    own batch object) let the exchange of one scan overlap the next scan."""
+
+    def __init__(self, plan: ShardPlan, rank: int, device, slots: int = 1, assembled: Optional[List[Assembled]] = None):
+        import torch
+        self.plan, self.rank, self.device = plan, rank, device
+        self.L = plan.L
+        self.r = plan.ranges[rank]
+        r = self.r
+        self.n_tiles = int(r.tile_end - r.tile_begin)
+        self.n_windows = 0 if plan.tips_only else int(r.window_end - r.window_begin)
+        self.input_bytes = int(r.input_end - r.input_begin)
+        self.batches, self.windows, self.stats, self.dense, self.total = [], [], [], [], []
+        cap = max(int(r.bases) // 4 + 4096, 4096)
+        for j in range(slots):
+            b = plan.new_batch()
+            rc = self.L.ts_batch_restrict(b, r.tile_begin, r.tile_end)
+            if rc != K.TS_OK:
+                raise K.TeloscanError(rc, plan.teloscope._ctx.error())
+            if assembled is not None:                          # the destination scans straight into the assembly
+                a = assembled[j]
+                w = a.windows[8 * r.window_begin:8 * r.window_end] if not plan.tips_only else a.windows[:0]
+                s = a.stats[4 * r.tile_begin:4 * r.tile_end]
+            else:
+                w = torch.empty(8 * self.n_windows, dtype=torch.int32, device=device)
+                s = torch.empty(4 * self.n_tiles, dtype=torch.int32, device=device)
+            rc = self.L.ts_batch_bind_results(b, C.c_void_p(w.data_ptr()) if w.numel() else None,
+                                              C.c_void_p(s.data_ptr()) if s.numel() else None)
+            if rc != K.TS_OK:
+                raise K.TeloscanError(rc, plan.teloscope._ctx.error())
+            self.batches.append(b)
+            self.windows.append(w)
+            self.stats.append(s)
+            self.dense.append(torch.empty(cap, dtype=torch.int32, device=device))
+            self.total.append(torch.zeros(2, dtype=torch.int64, device=device))
+
+    def scan(self, d_input, stream_ptr, slot=0):
+        """Enqueue scan + tile-ordered export of this rank's range (asynchronous on the stream).
+        d_input: device address of byte `input_begin` of the input layout."""
+        b = self.batches[slot]
+        rc = self.L.ts_batch_scan(b, C.c_void_p(d_input), stream_ptr)
+        if rc == K.TS_OK:
+            rc = self.L.ts_batch_export(b, C.c_void_p(self.dense[slot].data_ptr()), self.dense[slot].numel(),
+                                        C.c_void_p(self.total[slot].data_ptr()), stream_ptr)
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, self.plan.teloscope._ctx.error())
+
+    def finish(self, d_input, stream_ptr, slot=0):
+        """Wait for the slot's scan + export; returns its record count.  If the stream came out incomplete
+        (a wave's region or the export buffer was too small) the batch is synced — which grows the regions and
+        rescans — the export buffer grown, and the export repeated."""
+        import torch
+        for _ in range(4):
+            n, bad = (int(x) for x in self.total[slot].tolist())         # D2H of 16 bytes: waits for the stream
+            if not bad:
+                return n
+            b = self.batches[slot]
+            rc = self.L.ts_batch_sync(b)
+            if rc != K.TS_OK:
+                raise K.TeloscanError(rc, self.plan.teloscope._ctx.error())
+            info = K.BatchInfo()
+            self.L.ts_batch_get_info(b, C.byref(info))
+            need = int(info.n_matches)
+            if self.dense[slot].numel() < need:
+                self.dense[slot] = torch.empty(need + need // 8 + 1024, dtype=torch.int32, device=self.device)
+            rc = self.L.ts_batch_export(b, C.c_void_p(self.dense[slot].data_ptr()), self.dense[slot].numel(),
+                                        C.c_void_p(self.total[slot].data_ptr()), stream_ptr)
+            if rc != K.TS_OK:
+                raise K.TeloscanError(rc, self.plan.teloscope._ctx.error())
+        raise K.TeloscanError(K.TS_ERR_STATE, "tile-ordered export kept coming out incomplete")
+
+    def kernel_ms(self, slot=0):
+        """(avg HIP-event ms of the slot's scans since its last sync, launches averaged)."""
+        b = self.batches[slot]
+        rc = self.L.ts_batch_sync(b)
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, self.plan.teloscope._ctx.error())
+        info = K.BatchInfo()
+        self.L.ts_batch_get_info(b, C.byref(info))
+        return float(info.avg_kernel_ms), int(info.kernel_launches), info
+
+    def close(self):
+        for b in self.batches:
+            self.L.ts_batch_destroy(b)
+        self.batches = []
+
+
+def adopt(plan: ShardPlan, a: Assembled, stream_ptr=None):
+    """A whole-plan batch holding the assembled results (ts_batch_adopt): block calling, downloads and the
+    segment summary then work as after a single-GPU scan.  The caller destroys it (ts_batch_destroy) and
+    keeps `a` alive meanwhile."""
+    L = plan.L
+    b = plan.new_batch()
+    rc = L.ts_batch_adopt(b, C.c_void_p(a.windows.data_ptr()) if a.windows.numel() else None,
+                          C.c_void_p(a.stats.data_ptr()), C.c_void_p(a.dense.data_ptr()), a.n_records, stream_ptr)
+    if rc != K.TS_OK:
+        L.ts_batch_destroy(b)
+        raise K.TeloscanError(rc, plan.teloscope._ctx.error())
+    return b
+
+
 def gather_segment_summaries(local_summary, local_indices, n_total, dst=0, group=None):
-    """One fixed-size gather of per-segment summaries to `dst`.
+    """The summaries-only variant: one fixed-size gather of per-segment {windows, matches, canonical, forward}
+    (what the path summary report prints) to `dst`; window and match records stay where they were produced.
 
     local_summary: tensor [n_local, 4] int64 on the rank's device (cuda for nccl, cpu for gloo),
     rows in the order of local_indices.  Returns on dst a numpy array [n_total, 4] in global

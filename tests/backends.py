@@ -42,19 +42,8 @@ class OracleReadFilter:
 
 
 def _user_input(opts):
-    import teloscope_amd as ta
-    ui = ta.UserInputTeloscope(
-        canonicalFwd=opts.canonical_fwd, canonicalRev=opts.canonical_rev,
-        canonicalSize=opts.canonical_size, rawPatterns=list(opts.raw_patterns),
-        windowSize=opts.window_size, step=opts.step, terminalLimit=opts.terminal_limit,
-        editDistance=opts.edit_distance, maxMatchDist=opts.max_match_dist,
-        minBlockLen=opts.min_block_len, minBlockLenSet=opts.min_block_len_set,
-        maxBlockDist=opts.max_block_dist, minBlockCounts=opts.min_block_counts,
-        minBlockDensity=float(opts.min_block_density), outGC=opts.out_gc,
-        outEntropy=opts.out_entropy, outMatches=opts.out_matches, outITS=opts.out_its,
-        outWinRepeats=opts.out_win_repeats, ultraFastMode=opts.ultra_fast)
-    ui.patternInfo = ta.expandPatternsWithOrientation(ui.rawPatterns, ui.editDistance, ui.canonicalFwd)
-    return ui
+    from teloscope_amd.cli import user_input
+    return user_input(opts)
 
 
 class ProductBackend:

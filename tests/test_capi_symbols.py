@@ -28,7 +28,7 @@ def test_header_symbols_exported(ta):
     lib = C.CDLL(_capi.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.ts_abi_version() == 1
+    assert lib.ts_abi_version() == 2
 
 
 def test_struct_sizes_match_header(ta, tmp_path):
@@ -36,14 +36,14 @@ def test_struct_sizes_match_header(ta, tmp_path):
     import subprocess
     from teloscope_amd import _capi as K
     names = ["ts_params", "ts_match", "ts_window", "ts_block", "ts_pattern", "ts_segment_in",
-             "ts_segment_out", "ts_batch_info"]
+             "ts_segment_out", "ts_batch_info", "ts_tile_info", "ts_range_info"]
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "teloscan.h"\nint main(void){' +
                    "".join('printf("%%zu\\n", sizeof(%s));' % n for n in names) + "return 0;}")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    mirrors = [K.Params, K.Match, K.Window, K.Block, K.Pattern, K.SegmentIn, K.SegmentOut, K.BatchInfo]
+    mirrors = [K.Params, K.Match, K.Window, K.Block, K.Pattern, K.SegmentIn, K.SegmentOut, K.BatchInfo, K.TileInfo, K.RangeInfo]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 
