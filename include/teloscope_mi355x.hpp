@@ -316,30 +316,44 @@ public:
 };
 
 class ReadTelomereFilter {                     // include/read-filter.h:10-18
-    detail::CtxPtr ctx;
+    // one context per device: the reference makes one ReadTelomereFilter per thread-pool job and deals a batch's
+    // records to the jobs in chunks (src/input.cpp:780-793); here a batch is dealt to the devices in consecutive
+    // shards of equal bases (ts_filter_reads_multi) and the pass bits come back in input order
+    std::vector<detail::CtxPtr> ctxs;
+    std::vector<ts_ctx *> raw;
 
 public:
-    explicit ReadTelomereFilter(const UserInputTeloscope &input) {
+    // devices: HIP ordinals, one context each (an ordinal may repeat: several contexts share that GPU);
+    // empty = one context on the current device
+    explicit ReadTelomereFilter(const UserInputTeloscope &input, const std::vector<int> &devices = {}) {
         UserInputTeloscope ui = input;
         std::vector<ts_pattern> pats = detail::makePatterns(ui);
-        ts_params p = detail::makeParams(ui);
-        ctx.reset(ts_create_read_filter(&p, ui.minBlockLenSet ? 1 : 0, pats.data(), pats.size()));
-        if (!ctx) throw std::runtime_error(ts_last_error(nullptr));
+        const std::vector<int> devs = devices.empty() ? std::vector<int>{ui.device} : devices;
+        for (int d : devs) {
+            ui.device = d;
+            ts_params p = detail::makeParams(ui);
+            detail::CtxPtr c(ts_create_read_filter(&p, ui.minBlockLenSet ? 1 : 0, pats.data(), pats.size()));
+            if (!c) throw std::runtime_error(ts_last_error(nullptr));
+            raw.push_back(c.get());
+            ctxs.push_back(std::move(c));
+        }
     }
+
+    size_t deviceCount() const { return raw.size(); }
 
     std::vector<bool> matchesBatch(const std::vector<std::string> &sequences) {
         std::vector<const char *> ptr(sequences.size());
         std::vector<uint64_t> len(sequences.size());
         for (size_t i = 0; i < sequences.size(); ++i) { ptr[i] = sequences[i].data(); len[i] = sequences[i].size(); }
         std::vector<uint8_t> pass(sequences.size());
-        if (ts_filter_reads(ctx.get(), ptr.data(), len.data(), sequences.size(), pass.data()) != TS_OK)
-            throw std::runtime_error(ts_last_error(ctx.get()));
+        matchesPointers(ptr.data(), len.data(), sequences.size(), pass.data());
         return std::vector<bool>(pass.begin(), pass.end());
     }
 
     // the same on borrowed buffers (no copies): pass[i] = matches(std::string(seqs[i], lens[i]))
     void matchesPointers(const char *const *seqs, const uint64_t *lens, size_t n, uint8_t *pass) {
-        if (ts_filter_reads(ctx.get(), seqs, lens, n, pass) != TS_OK) throw std::runtime_error(ts_last_error(ctx.get()));
+        if (ts_filter_reads_multi(raw.data(), raw.size(), seqs, lens, n, pass) != TS_OK)
+            throw std::runtime_error(ts_last_error(raw[0]));
     }
 
     // bool ReadTelomereFilter::matches(std::string sequence)

@@ -9,13 +9,13 @@ MASKS="0 1 2 4 8 16 32 64 128"
 if [ "$1" = build ]; then
     for m in $MASKS; do
         (cd teloscope_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 \
-            -DTS_ABL=$m -x hip -shared -o ../../profiles/abl_$m.so kernels.hip generic.hip blockcall.hip capi.cpp \
-            patterns.cpp blocks.cpp 2>/dev/null) &
+            -DTS_ABL=$m -x hip -shared -o ../../profiles/abl_$m.so kernels.hip generic.hip blockcall.hip exchange.hip capi.cpp \
+            pipeline.cpp patterns.cpp blocks.cpp -lpthread 2>/dev/null) &
     done
     wait
 else
     for m in $MASKS; do
-        TELOSCAN_LIB=$PWD/profiles/abl_$m.so python3 bench.py --no-cpu-baseline $BENCH_FLAGS \
+        TELOSCAN_LIB=$PWD/profiles/abl_$m.so python3 bench.py --no-cpu-baseline --no-e2e $BENCH_FLAGS \
             | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('mask %3d  kernel_ms %.4f  ms_per_step %.4f' % ($m, d['roofline']['kernel_ms'], d['ms_per_step']))"
     done
 fi

@@ -13,14 +13,26 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """A fresh checkout has no built artefacts (they are git-ignored): build them once before any test runs —
-    hipcc cross-compiles libteloscan.so without a GPU, gcc builds the oracle.  (The product itself never builds
-    or falls back: importing teloscope_amd without the library raises ImportError.)"""
-    lib = os.path.join(ROOT, "teloscope_amd", "libteloscan.so")
+    """A fresh checkout has no built artefacts (they are git-ignored).  The oracle only needs gcc and is built
+    unconditionally; libteloscan.so needs hipcc (which cross-compiles gfx950 without a GPU): it is built when hipcc
+    is there, and otherwise the run goes on — the oracle / manifest / KAT tests do not need it, and every test that
+    does fails on its own with the ImportError teloscope_amd raises (the product never builds or falls back)."""
+    import shutil
+    import subprocess
+    import warnings
     ora = os.path.join(ROOT, "oracle", "libteloscope_oracle.so")
-    if not (os.path.exists(lib) and os.path.exists(ora)):
-        import __graft_entry__ as entry
-        entry.build()
+    if not os.path.exists(ora):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    lib = os.path.join(ROOT, "teloscope_amd", "libteloscan.so")
+    if not os.path.exists(lib):
+        hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+        if hipcc is None:
+            warnings.warn("libteloscan.so is not built and hipcc is not installed: tests that load the library will fail")
+            return
+        try:
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "teloscope_amd", "csrc")])
+        except subprocess.CalledProcessError as e:
+            warnings.warn("building libteloscan.so failed (%s): tests that load the library will fail" % e)
 
 
 @pytest.fixture(scope="session")

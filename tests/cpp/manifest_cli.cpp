@@ -7,6 +7,8 @@
 //   (src/teloscope.cpp:661-1055) — the last three through include/teloscope_mi355x_io.hpp.
 // Usage: manifest_cli <flags as in the manifest's first line, input path already resolved>
 //        [--out-base <prefix>]   where the eleven output files go (default: a scratch prefix)
+//        [--read-devices 0,0]    read filter over several contexts (one per listed HIP ordinal; repeats allowed)
+//        [--reads-per-batch n]   reads per GPU batch of --fastq-subset / --bam-subset (test hook)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -24,7 +26,8 @@ int main(int argc, char **argv) {
     UserInputTeloscope ui;
     std::string input, canonical, outBase;
     bool scratch = false, manualCuration = false, fastqSubsetMode = false, bamSubsetMode = false;
-    size_t fastqBlock = 512u << 20;
+    size_t fastqBlock = 512u << 20, readsPerBatch = 1u << 20;
+    std::vector<int> readDevices;
     std::vector<std::string> rawPatterns;
     bool hasPatterns = false;
     for (int i = 1; i < argc; ++i) {
@@ -35,6 +38,12 @@ int main(int argc, char **argv) {
         else if (a == "--bam-subset") bamSubsetMode = true;
         else if (a == "--fastq-block") fastqBlock = static_cast<size_t>(std::stoull(val()));   // test hook: arena size in bytes
         else if (a == "--out-base") outBase = val();
+        else if (a == "--reads-per-batch") readsPerBatch = static_cast<size_t>(std::stoull(val()));
+        else if (a == "--read-devices") {
+            std::istringstream ds(val());
+            std::string d;
+            while (std::getline(ds, d, ',')) if (!d.empty()) readDevices.push_back(std::stoi(d));
+        }
         else if (a == "-o" || a == "-j") (void)val();
         else if (a == "-c") canonical = val();
         else if (a == "-p") {
@@ -68,8 +77,8 @@ int main(int argc, char **argv) {
                        : std::vector<std::string>{ui.canonicalFwd, ui.canonicalRev};
         ui.patternInfo = expandPatternsWithOrientation(ui.rawPatterns, ui.editDistance, ui.canonicalFwd);
         if (bamSubsetMode) {                                    // runBamSubsetMode, src/bam.cpp:262-316
-            ReadTelomereFilter filter(ui);
-            const BamSubsetStats st = bamSubset(input.empty() ? "-" : input, std::cout, filter);
+            ReadTelomereFilter filter(ui, readDevices);
+            const BamSubsetStats st = bamSubset(input.empty() ? "-" : input, std::cout, filter, readsPerBatch);
             if (st.missingEofBlock) fprintf(stderr, "Warning: BAM input is missing the BGZF EOF marker.\n");
             if (st.missingSequenceRecords)
                 fprintf(stderr, "BAM subset: skipped %llu record%s without SEQ.\n", (unsigned long long)st.missingSequenceRecords,
@@ -79,9 +88,9 @@ int main(int argc, char **argv) {
         }
         if (fastqSubsetMode) {                                  // src/main.cpp:699-716: reads in, telomeric reads out
             const auto f0 = std::chrono::steady_clock::now();
-            ReadTelomereFilter filter(ui);
+            ReadTelomereFilter filter(ui, readDevices);
             const auto f1 = std::chrono::steady_clock::now();
-            const FastqSubsetResult r = fastqSubset(input.empty() ? "-" : input, std::cout, filter, 1u << 20, fastqBlock);
+            const FastqSubsetResult r = fastqSubset(input.empty() ? "-" : input, std::cout, filter, readsPerBatch, fastqBlock);
             if (getenv("TS_TIMING"))
                 fprintf(stderr, "manifest_cli: filter construction (device start-up) %.0f ms, fastqSubset %.0f ms\n",
                         std::chrono::duration<double, std::milli>(f1 - f0).count(),

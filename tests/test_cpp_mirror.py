@@ -56,11 +56,14 @@ FASTQ = [m for m in MANIFESTS if os.path.basename(m).startswith("fastq_subset")]
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["", "0,0"], ids=["D1", "D2"])
 @pytest.mark.parametrize("path", FASTQ, ids=[os.path.basename(p) for p in FASTQ])
-def test_cpp_mirror_replays_fastq_manifests(cli, path):
+def test_cpp_mirror_replays_fastq_manifests(cli, path, devices):
     """--fastq-subset through include/teloscope_mi355x_io.hpp (fastqSubset + ReadTelomereFilter on the
     GPU): stdout must equal the reference's expected subset file byte for byte, the kept/total line and
-    the malformed-input message must match (src/input.cpp:737-832, 113-138)."""
+    the malformed-input message must match (src/input.cpp:737-832, 113-138).  D2: the same with the read shard —
+    two read-filter contexts (here on one GPU), every batch dealt to them in consecutive shards, pass bits and
+    output order unchanged (the reference's -j 1 / -j 8 manifests expect identical bytes)."""
     m = H.load_manifest(path)
     d = {}
     for k, v in m["directives"]:
@@ -80,6 +83,8 @@ def test_cpp_mirror_replays_fastq_manifests(cli, path):
             tok = H.golden_path(tok)
         args.append(tok)
         i += 1
+    if devices:
+        args += ["--read-devices", devices, "--reads-per-batch", "64"]      # several batches, each cut into two shards
     r = subprocess.run([cli] + args, stdin=stdin, capture_output=True, timeout=120)
     assert (r.returncode != 0) == (int(d["expect_exit"][0]) != 0), r.stderr
     so = d.get("expect_stdout", ["ignore"])[0]

@@ -398,21 +398,21 @@ def test_bench_full_size_properties_small():
 
 
 def test_bench_line_contract_and_host_entry_points_small():
-    """The bench line's contract fields, and the --e2e / --blocks legs (the host-buffer entry points and the
+    """The bench line's contract fields, and the PCIe-inclusive (default at N = 1) / --blocks legs (the host-buffer entry points and the
     device block calling on the bench workload): both entry points must see the matches the resident scan counted."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gbases", "0.1", "--contigs", "9",
-                        "--steps", "2", "--warmup", "1", "--cpu-sample-mb", "8", "--e2e", "--blocks"],
+                        "--steps", "2", "--warmup", "1", "--cpu-sample-mb", "8", "--blocks"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in out, key
-    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["scaling"] == "strong" and out["vs_baseline"] is None
     assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1 and out["roofline"]["launches_timed"] == 2
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
     n = out["config"]["matches"]

@@ -1,0 +1,311 @@
+"""GPU parity of the pieces added in round 2:
+
+  * tile-range shards: the parts of one plan scanned separately (ts_batch_restrict / bind_results / export),
+    concatenated, adopted (ts_batch_adopt) — equal to the whole scan and to the oracle, for any number of parts;
+  * bench.py --gpus 2 on one GPU (two rank processes, gloo): the assembled arrays equal a single-GPU scan;
+  * full-size parity under the driver's eyes: bench.py --verify at configs[1] (3.0 Gb) and configs[4] (15 Gb),
+    a segment compared record for record with the oracle behind 2^32 input bytes and > 65 536 tiles, and a slice
+    around position 2^32 of one 4.5 Gb contig;
+  * the read filter: pattern sets outside the tiled kernel (the path that used to relock its own mutex), and the
+    read shard over several contexts.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import harness as H
+from tests import seqgen
+from tests.backends import (BLOCK_FIELDS, WINDOW_FIELDS, OracleBackend, OracleReadFilter, ProductBackend,
+                            ProductReadFilter, assert_segment_equal, segment_as_dict)
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADLINE = "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -m -i"
+
+
+def _teloscope(cli, device=0):
+    import teloscope_amd as ta
+    from teloscope_amd.cli import parse_cli, user_input
+    opts = parse_cli("x.fa " + cli)
+    return opts, ta.Teloscope(user_input(opts, device=device))
+
+
+def _scan_parts(plan, buf, dev):
+    """Every part of the plan scanned on its own restricted batch (as a rank would), the parts' arrays
+    concatenated in rank order (what the gather does): (windows, stats, dense[:n], counts)."""
+    import torch
+    from teloscope_amd.distributed import HipShard
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    ws, ss, ds, counts = [], [], [], []
+    for p in range(plan.world):
+        r = plan.ranges[p]
+        local = buf[r.input_begin:r.input_end].clone()         # a rank holds only the bytes its range reads
+        hs = HipShard(plan, p, dev, slots=1)
+        hs.scan(local.data_ptr(), sptr, 0)
+        n = hs.finish(local.data_ptr(), sptr, 0)
+        ws.append(hs.windows[0].clone()); ss.append(hs.stats[0].clone()); ds.append(hs.dense[0][:n].clone())
+        counts.append(n)
+        hs.close()
+    return torch.cat(ws), torch.cat(ss), torch.cat(ds), counts
+
+
+@pytest.mark.parametrize("cli", [HEADLINE, "-r -g -e -m -i", "-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i", "", "-t 3000"])
+def test_sharded_scan_equals_whole_scan_and_oracle(cli):
+    import torch
+    from teloscope_amd import _capi as K
+    from teloscope_amd.distributed import Assembled, ShardPlan, adopt
+    dev = torch.device("cuda", 0)
+    opts, tel = _teloscope(cli)
+    rng = np.random.default_rng(len(cli) + 17)
+    lens = [70001, 7, 250003, 0, 1999, 1_000_000, 16500, 333_333]
+    seqs = [seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, n_its=3, iupac=2) if n else b"" for n in lens]
+    abs_pos = [11 * i for i in range(len(lens))]
+    tips = opts.ultra_fast
+    whole = None
+    for world in (1, 2, 3, 5):
+        plan = ShardPlan(tel, lens, abs_pos=abs_pos, tips_only=tips, world=world)
+        buf = torch.zeros(int(plan.info.input_bytes), dtype=torch.uint8, device=dev)
+        for off, s in zip(plan.segment_offsets(), seqs):
+            if len(s):
+                buf[off:off + len(s)] = torch.frombuffer(bytearray(s), dtype=torch.uint8).to(dev)
+        w, s_, d, counts = _scan_parts(plan, buf, dev)
+        if whole is None:
+            whole = (w, s_, d)
+        else:
+            assert torch.equal(w, whole[0]) and torch.equal(s_, whole[1]) and torch.equal(d, whole[2]), world
+        # adopt the concatenation and download: must be what the oracle says, segment by segment
+        a = Assembled(w, s_, d if d.numel() else torch.zeros(1, dtype=torch.int32, device=dev), int(d.numel()), counts)
+        b = adopt(plan, a)
+        L = K.lib()
+        out = (K.SegmentOut * len(lens))()
+        assert L.ts_batch_download(b, None, out) == 0, tel._ctx.error()
+        import teloscope_amd as ta
+        orac = OracleBackend(opts)
+        for i, sq in enumerate(seqs):
+            got = segment_as_dict(ta.SegmentData(out[i], tips))
+            assert_segment_equal(got, orac.scan_segment(sq, abs_pos[i], tips), tips, ctx="world %d segment %d" % (world, i))
+        L.ts_free_segments(out, len(lens))
+        out2 = (K.SegmentOut * len(lens))()
+        assert L.ts_batch_download_blocks(b, out2) == 0, tel._ctx.error()
+        for i, sq in enumerate(seqs):
+            e = orac.scan_segment(sq, abs_pos[i], tips)
+            g = ta.SegmentData(out2[i], tips)
+            for f in BLOCK_FIELDS:
+                assert np.array_equal(g.terminalBlocks[f], e["terminal_blocks"][f]), (world, i, f)
+                assert np.array_equal(g.interstitialBlocks[f], e["interstitial_blocks"][f]), (world, i, f)
+        L.ts_free_segments(out2, len(lens))
+        L.ts_batch_destroy(b)
+        plan.close()
+
+
+def _bench(*args, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_two_ranks_on_one_gpu_equals_single_gpu():
+    """`python bench.py --gpus 2` spawns its own two ranks (they share this GPU, so the exchange runs over gloo):
+    configs[2] in small — the same assembly, two tile ranges, one exchange — and rank 0's assembled arrays are
+    compared bit for bit with a single-GPU scan of the whole assembly (--verify)."""
+    out = _bench("--gpus", "2", "--gbases", "0.3", "--contigs", "14", "--steps", "4", "--warmup", "2", "--verify")
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 4
+    cfg = out["config"]
+    assert len(cfg["bases_per_rank"]) == 2 and abs(cfg["bases_per_rank"][0] - cfg["bases_per_rank"][1]) <= 2 * 13500
+    assert sum(cfg["records_per_rank"]) == cfg["matches"] == out["verify"]["sharded_equals_single_gpu"]["records"]
+    assert out["verify"]["contigs_checked"] == 14
+    assert cfg["summaries_only_variant"]["value"] > 0 and cfg["step_split"]["exchange_ms"] > 0
+
+
+def test_bench_verify_full_size_configs1():
+    """configs[1] at its real size: 3.0 Gb, 200 contigs, 91.5 M matches — per-contig counts and nucleotide totals
+    against the independent torch computation."""
+    out = _bench("--verify", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e")
+    assert out["config"]["bases"] == 3_000_000_000 and out["verify"]["contigs_checked"] == 200
+    assert out["verify"]["matches_checked"] == out["config"]["matches"] > 90_000_000
+
+
+def test_bench_verify_full_size_configs4_plant():
+    """configs[4] on one GPU: 15 Gb, -c CCCTAAA -w 2000 -s 1000 (k = 7), ~15 M windows — the same properties."""
+    out = _bench("--verify", "--gbases", "15", "--contigs", "521", "--flags", "-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i",
+                 "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", timeout=1500)
+    assert out["config"]["bases"] == 15_000_000_000 and out["verify"]["contigs_checked"] == 521
+    assert out["config"]["windows"] > 14_000_000 and out["verify"]["matches_checked"] == out["config"]["matches"]
+
+
+def _device_random(n, dev, seed):
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    for a in range(0, n, 1 << 28):
+        b = min(n, a + (1 << 28))
+        out[a:b] = lut[torch.randint(0, 4, (b - a,), dtype=torch.uint8, device=dev, generator=g).long()]
+    return out
+
+
+def test_segment_behind_4g_bytes_and_65536_tiles_record_for_record():
+    """A 2 Mb segment placed behind a 4.4 Gb one in the same batch: its bytes start beyond input offset 2^32 and
+    its tiles beyond index 65 536.  Windows, every match (position, orientation, canonical) in push order and the
+    blocks of that segment equal the oracle's."""
+    import torch
+    from teloscope_amd import _capi as K
+    from teloscope_amd.distributed import HipShard, ShardPlan
+    import teloscope_amd as ta
+    dev = torch.device("cuda", 0)
+    opts, tel = _teloscope(HEADLINE)
+    rng = np.random.default_rng(99)
+    fixture = seqgen.chromosome(rng, 2_000_003, opts.canonical_fwd, opts.canonical_rev, n_its=6, iupac=3)
+    lens = [4_400_000_000, len(fixture)]
+    plan = ShardPlan(tel, lens, abs_pos=[0, 5_000_000_000], world=1)
+    offs = plan.segment_offsets()
+    tiles = plan.tiles
+    first_tile = int(np.flatnonzero(tiles["seg_index"] == 1)[0])
+    assert offs[1] > 2 ** 32 and first_tile > 65536
+    buf = torch.empty(int(plan.info.input_bytes), dtype=torch.uint8, device=dev)
+    buf[:lens[0]] = _device_random(lens[0], dev, 5)
+    buf[offs[1]:offs[1] + lens[1]] = torch.frombuffer(bytearray(fixture), dtype=torch.uint8).to(dev)
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    hs = HipShard(plan, 0, dev, slots=1)
+    hs.scan(buf.data_ptr(), sptr, 0)
+    n = hs.finish(buf.data_ptr(), sptr, 0)
+    stats = hs.stats[0].view(-1, 4)
+    start = int(stats[:first_tile, 0].to(torch.int64).sum().item())
+    recs = hs.dense[0][start:n].cpu().numpy().view(np.uint32)
+    tcount = stats[first_tile:, 0].cpu().numpy().astype(np.int64)
+    tbase = tiles["seg_offset"][first_tile:].astype(np.uint64)
+    pos = 5_000_000_000 + np.repeat(tbase, tcount) + (recs >> 2).astype(np.uint64)
+    e = OracleBackend(opts).scan_segment(fixture, 5_000_000_000, False)
+    em = e["all_matches"]
+    assert len(em) == len(recs) > 50_000
+    assert np.array_equal(pos, em["position"])
+    assert np.array_equal((recs & 2) != 0, em["is_forward"] != 0) and np.array_equal((recs & 1) != 0, em["is_canonical"] != 0)
+    w0 = int(tiles["first_window"][first_tile])
+    wins = hs.windows[0].view(-1, 8)[w0:].cpu().numpy().view(np.uint32)
+    assert len(wins) == len(e["windows"])
+    assert np.array_equal(wins[:, :4], e["windows"]["nucleotide_counts"])
+    for col, f in zip(range(4, 8), ("canonical_covered", "non_canonical_covered", "fwd_covered", "rev_covered")):
+        assert np.array_equal(wins[:, col], e["windows"][f]), f
+    # blocks of the segment, called on the device over the same resident stream
+    L = K.lib()
+    out = (K.SegmentOut * 2)()
+    b = hs.batches[0]
+    assert L.ts_batch_sync(b) == 0 and L.ts_batch_download_blocks(b, out) == 0, tel._ctx.error()
+    g = ta.SegmentData(out[1], False)
+    assert len(g.terminalBlocks) == len(e["terminal_blocks"]) >= 2
+    for f in BLOCK_FIELDS:
+        assert np.array_equal(g.terminalBlocks[f], e["terminal_blocks"][f]), f
+        assert np.array_equal(g.interstitialBlocks[f], e["interstitial_blocks"][f]), f
+    for f in WINDOW_FIELDS:
+        assert np.array_equal(g.windows[f], e["windows"][f]), f
+    L.ts_free_segments(out, 2)
+    hs.close()
+    plan.close()
+
+
+def test_slice_around_position_4g_of_one_contig():
+    """One 4.5 Gb contig: the windows and matches of a 1 Mb slice around position 2^32 equal what the oracle gives
+    for that slice scanned on its own (windows are independent: window j of the slice is window j0 + j of the
+    contig when the slice starts at a multiple of the step)."""
+    import torch
+    from teloscope_amd.distributed import HipShard, ShardPlan
+    dev = torch.device("cuda", 0)
+    opts, tel = _teloscope(HEADLINE)
+    n_total = 4_500_000_000
+    plan = ShardPlan(tel, [n_total], world=1)
+    buf = torch.empty(int(plan.info.input_bytes), dtype=torch.uint8, device=dev)
+    buf[:n_total] = _device_random(n_total, dev, 6)
+    s, w = opts.step, opts.window_size
+    a = (2 ** 32 - 500_000) // s * s
+    ln = 1_000_000
+    rep = torch.frombuffer(bytearray(b"TTAGGG" * 2000 + b"CCCTAA" * 2000), dtype=torch.uint8).to(dev)
+    buf[2 ** 32 - 9000:2 ** 32 - 9000 + rep.numel()] = rep                 # a dense stretch across the 2^32 boundary
+    buf[2 ** 32 + 40_000:2 ** 32 + 40_100] = ord("N")
+    sl = bytes(buf[a:a + ln].cpu().numpy().tobytes())
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    hs = HipShard(plan, 0, dev, slots=1)
+    hs.scan(buf.data_ptr(), sptr, 0)
+    n = hs.finish(buf.data_ptr(), sptr, 0)
+    e = OracleBackend(opts).scan_segment(sl, a, False)
+    nw = ln // s - 2                                                      # windows wholly inside the slice
+    wins = hs.windows[0].view(-1, 8)[a // s:a // s + nw].cpu().numpy().view(np.uint32)
+    assert np.array_equal(wins[:, :4], e["windows"]["nucleotide_counts"][:nw])
+    for col, f in zip(range(4, 8), ("canonical_covered", "non_canonical_covered", "fwd_covered", "rev_covered")):
+        assert np.array_equal(wins[:, col], e["windows"][f][:nw]), f
+    tiles = plan.tiles
+    tb = int(tiles["owned_bases"][0])
+    t0, t1 = a // tb, (a + ln) // tb + 1
+    stats = hs.stats[0].view(-1, 4)
+    start = int(stats[:t0, 0].to(torch.int64).sum().item())
+    cnt = stats[t0:t1, 0].cpu().numpy().astype(np.int64)
+    recs = hs.dense[0][start:start + int(cnt.sum())].cpu().numpy().view(np.uint32)
+    pos = np.repeat(tiles["seg_offset"][t0:t1].astype(np.uint64), cnt) + (recs >> 2).astype(np.uint64)
+    hi = a + nw * s
+    sel = (pos >= a) & (pos < hi)
+    em = e["all_matches"]
+    esel = em["position"] < hi
+    assert sel.sum() == esel.sum() > 10_000
+    assert np.array_equal(pos[sel], em["position"][esel])
+    assert np.array_equal((recs[sel] & 2) != 0, em["is_forward"][esel] != 0)
+    assert np.array_equal((recs[sel] & 1) != 0, em["is_canonical"][esel] != 0)
+    hs.close()
+    plan.close()
+
+
+@pytest.mark.parametrize("cli", ["--fastq-subset -p TTAGGG,TTAGG", "--fastq-subset -c TTAGGGTTA -x 0 -l 30",
+                                 "--fastq-subset -c AACCCTAACC -x 1"])
+def test_read_filter_on_pattern_sets_outside_the_tiled_kernel(cli):
+    """Mixed-length -p sets and 9-10 nt canonical motifs take the general kernels inside ts_filter_reads (the path
+    that used to relock the context's call mutex and hang)."""
+    opts = H.parse_cli(cli)
+    rng = np.random.default_rng(7)
+    unit_f, unit_r = opts.canonical_fwd.encode(), opts.canonical_rev.encode()
+    reads = []
+    for i in range(60):
+        body = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.integers(200, 4000))))
+        if i % 3 == 0:
+            body = unit_f * int(rng.integers(3, 40)) + body
+        elif i % 3 == 1:
+            body = body + unit_r * int(rng.integers(3, 40))
+        reads.append(body)
+    got = ProductReadFilter(opts).filter(reads)
+    assert got == OracleReadFilter(opts).filter(reads)
+    assert 0 < sum(got) < len(got)
+
+
+def test_read_shard_over_two_contexts_equals_one():
+    """ts_filter_reads_multi: the batch cut into consecutive shards of equal bases, one per context (here two
+    contexts on one GPU), pass bytes in input order — equal to one context and to the oracle."""
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import user_input
+    opts = H.parse_cli("--fastq-subset -l 42")
+    rng = np.random.default_rng(11)
+    reads = []
+    for i in range(400):
+        n = int(rng.integers(500, 30000))
+        s = seqgen.chromosome(rng, n, n_its=1) if i % 7 else seqgen.chromosome(rng, n)
+        if i % 5 == 0:
+            s = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n))
+        reads.append(s)
+    exp = OracleReadFilter(opts).filter(reads)
+    filters = [ta.ReadTelomereFilter(user_input(opts, device=0)) for _ in range(3)]
+    L = K.lib()
+    n = len(reads)
+    arr = (C.c_char_p * n)(*reads)
+    lens = (C.c_uint64 * n)(*[len(r) for r in reads])
+    for nctx in (1, 2, 3):
+        ctxs = (C.c_void_p * nctx)(*[f._ctx.ptr for f in filters[:nctx]])
+        out = (C.c_uint8 * n)()
+        assert L.ts_filter_reads_multi(ctxs, nctx, arr, lens, n, out) == 0
+        assert [bool(x) for x in out] == exp, nctx
+    assert 0 < sum(exp) < n
