@@ -287,10 +287,20 @@ public:
         counts.assign(segs.size(), ts_segment_counts{0, 0, 0, 0});
         if (ts_scan_segments_blocks(ctx.get(), in.data(), in.size(), out.data(), counts.data()) != TS_OK)
             throw std::runtime_error(ts_last_error(ctx.get()));
-        std::vector<SegmentData> res;
-        res.reserve(segs.size());
-        for (size_t i = 0; i < segs.size(); ++i)
-            res.push_back(convert(out[i], segs[i].data, segs[i].absPos, segs[i].tipsOnly));
+        // (window records of a long contig are millions: segments are converted on up to 16 host threads)
+        std::vector<SegmentData> res(segs.size());
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < segs.size();) res[i] = convert(out[i], segs[i].data, segs[i].absPos, segs[i].tipsOnly);
+        };
+        const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), segs.size(), size_t(std::max(1u, std::thread::hardware_concurrency()))}));
+        if (nt <= 1) {
+            worker();
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned i = 0; i < nt; ++i) pool.emplace_back(worker);
+            for (std::thread &th : pool) th.join();
+        }
         ts_free_segments(out.data(), out.size());
         return res;
     }

@@ -21,6 +21,12 @@
 #include <array>
 #include <atomic>
 #include <charconv>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -220,10 +226,8 @@ inline size_t scanGapState(const char *s, size_t i, size_t n, bool want) {
 }
 }  // namespace detail
 
-inline PathComponents splitPath(const std::string &seq) {
+inline PathComponents splitPath(const char *s, size_t n) {
     PathComponents pc;
-    const size_t n = seq.size();
-    const char *s = seq.data();
     size_t i = 0;
     while (i < n) {
         const bool gap = s[i] == 'N' || s[i] == 'n' || s[i] == 'X' || s[i] == 'x';
@@ -234,17 +238,35 @@ inline PathComponents splitPath(const std::string &seq) {
     }
     return pc;
 }
+inline PathComponents splitPath(const std::string &seq) { return splitPath(seq.data(), seq.size()); }
 
-// walkPath for every record, with one batched scan (result order = record order = seqPos order).
-inline std::vector<PathData> walkPaths(Teloscope &teloscope, const std::vector<FastaRecord> &records) {
+// A record as walkPaths sees it: header + bases, wherever they live (a FastaRecord's std::string, or a buffer the
+// streaming reader filled).
+struct RecordView {
+    const std::string *header;
+    const char *data;
+    size_t size;
+};
+
+// walkPath for every record, with one batched scan (result order = record order; seqPos = seqPosBase + index).
+inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::vector<RecordView> &records, size_t seqPosBase = 0) {
     const UserInputTeloscope &ui = teloscope.input();
-    std::vector<PathComponents> comps;
-    comps.reserve(records.size());
-    for (const FastaRecord &r : records) comps.push_back(splitPath(r.sequence));
+    std::vector<PathComponents> comps(records.size());
+    {   // N-run -> gap splitting is independent per record: on the host threads
+        std::atomic<size_t> next{0};
+        auto worker = [&]() { for (size_t i; (i = next.fetch_add(1)) < records.size();) comps[i] = splitPath(records[i].data, records[i].size); };
+        const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), records.size(), size_t(std::max(1u, std::thread::hardware_concurrency()))}));
+        if (nt <= 1) worker();
+        else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; ++t) pool.emplace_back(worker);
+            for (std::thread &th : pool) th.join();
+        }
+    }
     std::vector<Teloscope::Segment> batch;
     for (size_t pi = 0; pi < records.size(); ++pi)
         for (const auto &sg : comps[pi].segments)
-            batch.emplace_back(records[pi].sequence.data() + sg.first, static_cast<size_t>(sg.second), sg.first, ui.ultraFastMode);
+            batch.emplace_back(records[pi].data + sg.first, static_cast<size_t>(sg.second), sg.first, ui.ultraFastMode);
     // without -m nothing downstream reads a match record: blocks and counts come from the device
     std::vector<ts_segment_counts> counts;
     std::vector<SegmentData> scanned = ui.outMatches ? teloscope.scanSegments(batch)
@@ -254,26 +276,44 @@ inline std::vector<PathData> walkPaths(Teloscope &teloscope, const std::vector<F
     size_t si = 0;
     for (size_t pi = 0; pi < records.size(); ++pi) {
         PathData &pd = paths[pi];
-        pd.seqPos = static_cast<unsigned int>(pi);
-        pd.header = records[pi].header;
-        pd.pathSize = records[pi].sequence.size();
+        pd.seqPos = static_cast<unsigned int>(seqPosBase + pi);
+        pd.header = *records[pi].header;
+        pd.pathSize = records[pi].size;
         pd.gapInfos = comps[pi].gaps;
-        for (size_t k = 0; k < comps[pi].segments.size(); ++k, ++si) {
+        const size_t nseg = comps[pi].segments.size();
+        if (nseg == 1) {                                        // the common case: the record is one segment — no copies
             SegmentData &sd = scanned[si];
-            auto append = [](auto &dst, auto &src) {
-                dst.insert(dst.end(), std::make_move_iterator(src.begin()), std::make_move_iterator(src.end()));
-            };
-            append(pd.windows, sd.windows);
-            append(pd.terminalBlocks, sd.terminalBlocks);
-            append(pd.interstitialBlocks, sd.interstitialBlocks);
-            pd.canonicalMatchCount += ui.outMatches ? sd.canonicalMatches.size() : counts[si].n_canonical;
-            append(pd.canonicalMatches, sd.canonicalMatches);
-            append(pd.nonCanonicalMatches, sd.nonCanonicalMatches);
+            pd.canonicalMatchCount = ui.outMatches ? sd.canonicalMatches.size() : counts[si].n_canonical;
+            pd.windows = std::move(sd.windows);
+            pd.terminalBlocks = std::move(sd.terminalBlocks);
+            pd.interstitialBlocks = std::move(sd.interstitialBlocks);
+            pd.canonicalMatches = std::move(sd.canonicalMatches);
+            pd.nonCanonicalMatches = std::move(sd.nonCanonicalMatches);
+            ++si;
+        } else {
+            for (size_t k = 0; k < nseg; ++k, ++si) {
+                SegmentData &sd = scanned[si];
+                auto append = [](auto &dst, auto &src) {
+                    dst.insert(dst.end(), std::make_move_iterator(src.begin()), std::make_move_iterator(src.end()));
+                };
+                append(pd.windows, sd.windows);
+                append(pd.terminalBlocks, sd.terminalBlocks);
+                append(pd.interstitialBlocks, sd.interstitialBlocks);
+                pd.canonicalMatchCount += ui.outMatches ? sd.canonicalMatches.size() : counts[si].n_canonical;
+                append(pd.canonicalMatches, sd.canonicalMatches);
+                append(pd.nonCanonicalMatches, sd.nonCanonicalMatches);
+            }
         }
         teloscope.labelTerminalBlocks(pd.terminalBlocks, static_cast<uint16_t>(pd.gapInfos.size()), pd.terminalLabel,
                                       pd.scaffoldType, pd.pathSize, ui.terminalLimit);
     }
     return paths;
+}
+
+inline std::vector<PathData> walkPaths(Teloscope &teloscope, const std::vector<FastaRecord> &records) {
+    std::vector<RecordView> views(records.size());
+    for (size_t i = 0; i < records.size(); ++i) views[i] = RecordView{&records[i].header, records[i].sequence.data(), records[i].sequence.size()};
+    return walkRecordViews(teloscope, views, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -699,49 +739,22 @@ struct Task {                                  // a path's blocks/gaps/matches/r
 }  // namespace detail
 
 // handleBEDFile + writeBEDFile: writes <outBase>_*.bed / .bedgraph / _report.tsv and the console path
-// report; fills the totals printSummary needs.  `paths` must be in seqPos order (walkPaths' order).
-inline void writeBEDFiles(const std::string &outBase, const std::vector<PathData> &paths, const UserInputTeloscope &ui,
-                          std::ostream &console, AssemblySummary &sum, bool manualCuration = false, unsigned threads = 0) {
-    using namespace detail;
-    static const char *suffix[NFILES] = {"_window_repeat_density.bedgraph", "_window_canonical_ratio.bedgraph",
-                                         "_window_strand_ratio.bedgraph", "_window_gc.bedgraph", "_window_entropy.bedgraph",
-                                         "_canonical_matches.bed", "_noncanonical_matches.bed", "_terminal_telomeres.bed",
-                                         "_interstitial_telomeres.bed", "_gaps.bed", "_report.tsv", ""};
-    bool on[NFILES] = {ui.outWinRepeats, ui.outWinRepeats, ui.outWinRepeats, ui.outGC, ui.outEntropy, ui.outMatches,
-                       ui.outMatches, true, ui.outITS, true, true, false};
-    std::ofstream files[NFILES];
-    for (int f = 0; f < NFILES; ++f) {
-        if (!on[f]) continue;
-        files[f].open(outBase + suffix[f], std::ios::binary);
-        if (!files[f]) throw std::runtime_error("Could not open '" + outBase + suffix[f] + "' for writing.");
-    }
-    if (ui.outWinRepeats) {
-        files[DENSITY] << "track type=bedGraph name=\"Repeat Density\" description=\"Total repeat density per window\"\n";
-        files[CANON_RATIO] << "track type=bedGraph name=\"Canonical Ratio\" description=\"Canonical fraction of repeat density per window\"\n";
-        files[STRAND_RATIO] << "track type=bedGraph name=\"Strand Ratio\" description=\"Forward-strand fraction of repeat density per window\"\n";
-    }
-    if (ui.outEntropy) files[ENTROPY] << "track type=bedGraph name=\"Shannon Entropy\" description=\"Shannon entropy per window\"\n";
-    if (ui.outGC) files[GC] << "track type=bedGraph name=\"GC Content\" description=\"GC content per window\"\n";
-    console << "\n+++ Path Summary Report +++\n";
-    const char *cols = ui.ultraFastMode ? "pos\theader\ttelomeres\tlabels\tgaps\ttype\tgranular\n"
-                                        : "pos\theader\ttelomeres\tlabels\tgaps\ttype\tgranular\tits\tcanonical\twindows\n";
-    console << cols;
-    files[REPORT] << cols;
-
-    // work list in output order: per path its row/blocks/gaps/matches, then its windows in runs
-    constexpr size_t kRun = 1u << 16;
-    std::vector<Task> tasks;
-    for (uint32_t p = 0; p < paths.size(); ++p) {
-        tasks.push_back(Task{p, false, 0, 0});
-        for (size_t w = 0; w < paths[p].windows.size(); w += kRun)
-            tasks.push_back(Task{p, true, w, std::min(paths[p].windows.size(), w + kRun)});
-    }
+// report; fills the totals printSummary needs.  Incremental: paths are added in seqPos order, all at once
+// (writeBEDFiles) or group by group while later records are still being read and scanned (scanFastaToFiles).
+class BedWriter {
+    std::string outBase;
+    const UserInputTeloscope &ui;
+    std::ostream &console;
+    bool manualCuration;
+    unsigned threads;
+    bool on[detail::NFILES];
+    std::ofstream files[detail::NFILES];
     std::vector<float> telomereLengths;
-    sum = AssemblySummary{};
-    sum.totalPaths = static_cast<uint32_t>(paths.size());
+    std::vector<uint64_t> scaffoldLens, contigLens;
+    AssemblySummary sum;
 
-    auto format = [&](const Task &t, std::array<std::string, NFILES> &o) {
-        const PathData &pd = paths[t.path];
+    void format(const PathData &pd, const detail::Task &t, std::array<std::string, detail::NFILES> &o) const {
+        using namespace detail;
         const std::string &h = pd.header;
         if (t.windows) {
             for (size_t i = t.w0; i < t.w1; ++i) {
@@ -794,69 +807,131 @@ inline void writeBEDFiles(const std::string &outBase, const std::vector<PathData
         row += '\n';
         o[REPORT] += row;
         o[CONSOLE] += row;
-    };
-
-    // batches of tasks are formatted in parallel and written in order
-    if (threads == 0) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const size_t batch = static_cast<size_t>(threads) * 4;
-    std::vector<std::array<std::string, NFILES>> outs(batch);
-    for (size_t b0 = 0; b0 < tasks.size(); b0 += batch) {
-        const size_t nb = std::min(batch, tasks.size() - b0);
-        for (size_t i = 0; i < nb; ++i)
-            for (std::string &s : outs[i]) s.clear();
-        std::atomic<size_t> next{0};
-        auto worker = [&]() {
-            for (size_t i; (i = next.fetch_add(1)) < nb;) format(tasks[b0 + i], outs[i]);
-        };
-        const unsigned nt = static_cast<unsigned>(std::min<size_t>(threads, nb));
-        if (nt <= 1) {
-            worker();
-        } else {
-            std::vector<std::thread> pool;
-            for (unsigned i = 0; i < nt; ++i) pool.emplace_back(worker);
-            for (std::thread &th : pool) th.join();
-        }
-        for (size_t i = 0; i < nb; ++i) {
-            for (int f = 0; f < NFILES; ++f)
-                if (f != CONSOLE && on[f] && !outs[i][f].empty()) files[f].write(outs[i][f].data(), static_cast<std::streamsize>(outs[i][f].size()));
-            console << outs[i][CONSOLE];
-        }
     }
 
-    // totals (what writeBEDFile accumulates while writing) and summary counts (computeSummaryCounts)
-    std::vector<uint64_t> scaffoldLens, contigLens;
-    for (const PathData &pd : paths) {
-        for (const TelomereBlock &b : pd.terminalBlocks)
-            if (b.isLongest) { ++sum.totalTelomeres; telomereLengths.push_back(static_cast<float>(b.blockLen)); }
-        sum.totalGaps += static_cast<uint16_t>(pd.gapInfos.size());
-        if (!ui.ultraFastMode) {
-            sum.totalNWindows += static_cast<uint32_t>(pd.windows.size());
-            sum.totalITS += static_cast<uint32_t>(pd.interstitialBlocks.size());
-            sum.totalCanMatches += static_cast<uint32_t>(pd.canonicalMatchCount);
+public:
+    BedWriter(const std::string &outBase_, const UserInputTeloscope &ui_, std::ostream &console_, bool manualCuration_ = false,
+              unsigned threads_ = 0)
+        : outBase(outBase_), ui(ui_), console(console_), manualCuration(manualCuration_), threads(threads_) {
+        using namespace detail;
+        static const char *suffix[NFILES] = {"_window_repeat_density.bedgraph", "_window_canonical_ratio.bedgraph",
+                                             "_window_strand_ratio.bedgraph", "_window_gc.bedgraph", "_window_entropy.bedgraph",
+                                             "_canonical_matches.bed", "_noncanonical_matches.bed", "_terminal_telomeres.bed",
+                                             "_interstitial_telomeres.bed", "_gaps.bed", "_report.tsv", ""};
+        const bool want[NFILES] = {ui.outWinRepeats, ui.outWinRepeats, ui.outWinRepeats, ui.outGC, ui.outEntropy, ui.outMatches,
+                                   ui.outMatches, true, ui.outITS, true, true, false};
+        for (int f = 0; f < NFILES; ++f) {
+            on[f] = want[f];
+            if (!on[f]) continue;
+            files[f].open(outBase + suffix[f], std::ios::binary);
+            if (!files[f]) throw std::runtime_error("Could not open '" + outBase + suffix[f] + "' for writing.");
         }
-        sum.byType[static_cast<int>(pd.scaffoldType)]++;
-        scaffoldLens.push_back(pd.pathSize);
-        std::vector<GapInfo> gaps = pd.gapInfos;
-        std::sort(gaps.begin(), gaps.end(), [](const GapInfo &a, const GapInfo &b) { return a.start < b.start; });
-        uint64_t prevEnd = 0;
-        for (const GapInfo &g : gaps) {
-            if (g.start > prevEnd) contigLens.push_back(g.start - prevEnd);
-            prevEnd = g.start + g.length;
+        if (ui.outWinRepeats) {
+            files[DENSITY] << "track type=bedGraph name=\"Repeat Density\" description=\"Total repeat density per window\"\n";
+            files[CANON_RATIO] << "track type=bedGraph name=\"Canonical Ratio\" description=\"Canonical fraction of repeat density per window\"\n";
+            files[STRAND_RATIO] << "track type=bedGraph name=\"Strand Ratio\" description=\"Forward-strand fraction of repeat density per window\"\n";
         }
-        if (pd.pathSize > prevEnd) contigLens.push_back(pd.pathSize - prevEnd);
+        if (ui.outEntropy) files[ENTROPY] << "track type=bedGraph name=\"Shannon Entropy\" description=\"Shannon entropy per window\"\n";
+        if (ui.outGC) files[GC] << "track type=bedGraph name=\"GC Content\" description=\"GC content per window\"\n";
+        console << "\n+++ Path Summary Report +++\n";
+        const char *cols = ui.ultraFastMode ? "pos\theader\ttelomeres\tlabels\tgaps\ttype\tgranular\n"
+                                            : "pos\theader\ttelomeres\tlabels\tgaps\ttype\tgranular\tits\tcanonical\twindows\n";
+        console << cols;
+        files[REPORT] << cols;
+        if (threads == 0) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     }
-    sum.scaffoldN50 = computeN50(scaffoldLens);
-    sum.contigN50 = computeN50(contigLens);
-    if (!telomereLengths.empty()) {                              // getStats, src/tools.cpp:23-51
-        std::vector<float> &v = telomereLengths;
-        float total = 0.0f;
-        sum.teloMin = sum.teloMax = v[0];
-        for (float x : v) { sum.teloMin = std::min(sum.teloMin, x); sum.teloMax = std::max(sum.teloMax, x); total += x; }
-        sum.teloMean = total / v.size();
-        std::sort(v.begin(), v.end());
-        const size_t mid = v.size() / 2;
-        sum.teloMedian = v.size() % 2 ? v[mid] : (v[mid] + v[mid - 1]) / 2;
+
+    // formats and writes these paths (which follow, in seqPos order, the ones added before)
+    void add(const std::vector<PathData> &paths) {
+        using namespace detail;
+        // work list in output order: per path its row/blocks/gaps/matches, then its windows in runs
+        constexpr size_t kRun = 1u << 16;
+        std::vector<Task> tasks;
+        for (uint32_t p = 0; p < paths.size(); ++p) {
+            tasks.push_back(Task{p, false, 0, 0});
+            for (size_t w = 0; w < paths[p].windows.size(); w += kRun)
+                tasks.push_back(Task{p, true, w, std::min(paths[p].windows.size(), w + kRun)});
+        }
+        // batches of tasks are formatted in parallel and written in order
+        const size_t batch = static_cast<size_t>(threads) * 4;
+        std::vector<std::array<std::string, NFILES>> outs(batch);
+        for (size_t b0 = 0; b0 < tasks.size(); b0 += batch) {
+            const size_t nb = std::min(batch, tasks.size() - b0);
+            for (size_t i = 0; i < nb; ++i)
+                for (std::string &s : outs[i]) s.clear();
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                for (size_t i; (i = next.fetch_add(1)) < nb;) format(paths[tasks[b0 + i].path], tasks[b0 + i], outs[i]);
+            };
+            const unsigned nt = static_cast<unsigned>(std::min<size_t>(threads, nb));
+            if (nt <= 1) {
+                worker();
+            } else {
+                std::vector<std::thread> pool;
+                for (unsigned i = 0; i < nt; ++i) pool.emplace_back(worker);
+                for (std::thread &th : pool) th.join();
+            }
+            for (size_t i = 0; i < nb; ++i) {
+                for (int f = 0; f < NFILES; ++f)
+                    if (f != CONSOLE && on[f] && !outs[i][f].empty()) files[f].write(outs[i][f].data(), static_cast<std::streamsize>(outs[i][f].size()));
+                console << outs[i][CONSOLE];
+            }
+        }
+        // totals (what writeBEDFile accumulates while writing) and summary counts (computeSummaryCounts)
+        sum.totalPaths += static_cast<uint32_t>(paths.size());
+        for (const PathData &pd : paths) {
+            for (const TelomereBlock &b : pd.terminalBlocks)
+                if (b.isLongest) { ++sum.totalTelomeres; telomereLengths.push_back(static_cast<float>(b.blockLen)); }
+            sum.totalGaps += static_cast<uint16_t>(pd.gapInfos.size());
+            if (!ui.ultraFastMode) {
+                sum.totalNWindows += static_cast<uint32_t>(pd.windows.size());
+                sum.totalITS += static_cast<uint32_t>(pd.interstitialBlocks.size());
+                sum.totalCanMatches += static_cast<uint32_t>(pd.canonicalMatchCount);
+            }
+            sum.byType[static_cast<int>(pd.scaffoldType)]++;
+            scaffoldLens.push_back(pd.pathSize);
+            std::vector<GapInfo> gaps = pd.gapInfos;
+            std::sort(gaps.begin(), gaps.end(), [](const GapInfo &a, const GapInfo &b) { return a.start < b.start; });
+            uint64_t prevEnd = 0;
+            for (const GapInfo &g : gaps) {
+                if (g.start > prevEnd) contigLens.push_back(g.start - prevEnd);
+                prevEnd = g.start + g.length;
+            }
+            if (pd.pathSize > prevEnd) contigLens.push_back(pd.pathSize - prevEnd);
+        }
     }
+
+    // closes the files and returns the totals printSummary reports
+    AssemblySummary finish() {
+        using namespace detail;
+        for (int f = 0; f < NFILES; ++f)
+            if (on[f]) {
+                files[f].flush();
+                if (!files[f].good()) throw std::runtime_error("failed while writing the output files of " + outBase);
+                files[f].close();
+            }
+        sum.scaffoldN50 = computeN50(scaffoldLens);
+        sum.contigN50 = computeN50(contigLens);
+        if (!telomereLengths.empty()) {                              // getStats, src/tools.cpp:23-51
+            std::vector<float> &v = telomereLengths;
+            float total = 0.0f;
+            sum.teloMin = sum.teloMax = v[0];
+            for (float x : v) { sum.teloMin = std::min(sum.teloMin, x); sum.teloMax = std::max(sum.teloMax, x); total += x; }
+            sum.teloMean = total / v.size();
+            std::sort(v.begin(), v.end());
+            const size_t mid = v.size() / 2;
+            sum.teloMedian = v.size() % 2 ? v[mid] : (v[mid] + v[mid - 1]) / 2;
+        }
+        return sum;
+    }
+};
+
+// `paths` must be in seqPos order (walkPaths' order).
+inline void writeBEDFiles(const std::string &outBase, const std::vector<PathData> &paths, const UserInputTeloscope &ui,
+                          std::ostream &console, AssemblySummary &sum, bool manualCuration = false, unsigned threads = 0) {
+    BedWriter w(outBase, ui, console, manualCuration, threads);
+    w.add(paths);
+    sum = w.finish();
 }
 
 // printSummary: the same text to the console and (appended) to <outBase>_report.tsv when given.
@@ -887,6 +962,290 @@ inline void printSummary(std::ostream &console, const AssemblySummary &s, bool u
         if (!f) throw std::runtime_error("Could not open '" + reportFile + "' for writing.");
         f << t;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FASTA text in, all output files out, as ONE pipeline (rows f2 + f3 together).  The reference loads the whole
+// genome, runs one job per path, sorts and then writes (Input::read, src/input.cpp:575-734); with the scan in
+// milliseconds that order leaves three whole-genome phases — parse, scan, format — one after the other on the
+// host.  Here records flow in groups of ~256 MB through three stages that overlap:
+//
+//   read    a mapped file's records are located by one parallel pass over the text; a group's body lines are
+//           joined into one buffer per record by all host threads (two passes: count, copy — no zero-fill, no
+//           per-line allocation)                                                    [reader thread + pool]
+//   scan    splitPath + ONE batched scan of the group's segments + labelTerminalBlocks (walkRecordViews)
+//   write   BedWriter::add formats the group's lines on the host threads and appends them to the files
+//
+// Groups are consecutive runs of records, so everything leaves in seqPos order: the files and the console text
+// are byte-identical to readFasta + walkPaths + writeBEDFiles (tests/test_writers.py runs both).
+namespace detail {
+
+template <typename T>
+class BoundedQueue {
+public:
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    void push(T v) {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return q_.size() < cap_ || closed_; });
+        q_.push_back(std::move(v));
+        cv_.notify_all();
+    }
+    void close() { { std::lock_guard<std::mutex> g(m_); closed_ = true; } cv_.notify_all(); }
+    bool pop(T &out) {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        cv_.notify_all();
+        return true;
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+};
+
+template <typename F>
+inline void onThreads(size_t n, F &&f) {                        // f(i) for i in [0, n), dynamic, on up to 16 host threads
+    const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), n, size_t(std::max(1u, std::thread::hardware_concurrency()))}));
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t) pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
+    for (std::thread &th : pool) th.join();
+}
+
+// bases of [p, end) without the line ends ('\n', and a '\r' right before it or at the very end)
+inline size_t countFastaBases(const char *p, const char *end) {
+    size_t n = 0;
+    while (p < end) {
+        const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        const char *stop = nl ? nl : end;
+        if (stop > p) n += static_cast<size_t>((stop[-1] == '\r' ? stop - 1 : stop) - p);
+        p = nl ? nl + 1 : end;
+    }
+    return n;
+}
+inline char *copyFastaBases(const char *p, const char *end, char *dst) {
+    while (p < end) {
+        const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        const char *stop = nl ? nl : end;
+        if (stop > p) {
+            const size_t n = static_cast<size_t>((stop[-1] == '\r' ? stop - 1 : stop) - p);
+            std::memcpy(dst, p, n);
+            dst += n;
+        }
+        p = nl ? nl + 1 : end;
+    }
+    return dst;
+}
+
+struct RawRecord {                                              // a record of a streamed group
+    std::string header;
+    std::unique_ptr<char[]> data;                               // (new char[]: not zero-filled)
+    size_t size = 0;
+};
+
+struct FastaGroup {
+    size_t firstRecord = 0;
+    std::vector<RawRecord> records;
+    std::vector<FastaRecord> owned;                             // gzip / stdin input: records read the plain way
+};
+
+}  // namespace detail
+
+// Groups of consecutive records of a FASTA file, each with its records' lines joined.
+class FastaGroupReader {
+    struct Span { const char *head, *body, *stop; };
+    int fd = -1;
+    void *map = nullptr;
+    size_t mapSize = 0;
+    std::vector<Span> spans;
+    size_t nextSpan = 0;
+    size_t groupBytes;
+    std::vector<FastaRecord> all;                               // not a mapped plain file: everything was read up front
+    bool mapped = false;
+
+public:
+    explicit FastaGroupReader(const std::string &file, size_t groupBytes_ = size_t(256) << 20) : groupBytes(std::max<size_t>(groupBytes_, 1)) {
+        fd = ::open(file.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + file);
+        struct stat sb;
+        unsigned char magic[2] = {0, 0};
+        const bool gz = ::pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (!gz && ::fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            mapSize = static_cast<size_t>(sb.st_size);
+            map = ::mmap(nullptr, mapSize, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map == MAP_FAILED) map = nullptr;
+        }
+        if (!map) {                                              // gzip (zlib is one serial stream anyway), FIFOs, empty files
+            ::close(fd); fd = -1;
+            all = readFasta(file);
+            return;
+        }
+        mapped = true;
+        (void)::madvise(map, mapSize, MADV_SEQUENTIAL);
+        const char *data = static_cast<const char *>(map), *end = data + mapSize;
+        // record starts = '>' at a line start; found by slices of the text in parallel, then put in order
+        const size_t nslice = std::max<size_t>(1, std::min<size_t>(64, mapSize >> 24));
+        std::vector<std::vector<const char *>> found(nslice);
+        detail::onThreads(nslice, [&](size_t k) {
+            const char *lo = data + mapSize / nslice * k, *hi = k + 1 == nslice ? end : data + mapSize / nslice * (k + 1);
+            for (const char *p = lo; p < hi;) {
+                const char *gt = static_cast<const char *>(std::memchr(p, '>', static_cast<size_t>(hi - p)));
+                if (!gt) break;
+                if (gt == data || gt[-1] == '\n') found[k].push_back(gt);
+                p = gt + 1;
+            }
+        });
+        std::vector<const char *> starts;
+        for (const auto &v : found) starts.insert(starts.end(), v.begin(), v.end());
+        for (size_t i = 0; i < starts.size(); ++i) {
+            const char *gt = starts[i];
+            const char *lim = i + 1 < starts.size() ? starts[i + 1] : end;
+            const char *nl = static_cast<const char *>(std::memchr(gt, '\n', static_cast<size_t>(lim - gt)));
+            spans.push_back(Span{gt + 1, nl ? nl + 1 : lim, lim});
+        }
+    }
+    ~FastaGroupReader() {
+        if (map) ::munmap(map, mapSize);
+        if (fd >= 0) ::close(fd);
+    }
+    FastaGroupReader(const FastaGroupReader &) = delete;
+    FastaGroupReader &operator=(const FastaGroupReader &) = delete;
+
+    // the next group (false at the end of the file)
+    bool next(detail::FastaGroup &g) {
+        g = detail::FastaGroup{};
+        if (!mapped) {
+            if (nextSpan >= all.size()) return false;
+            g.firstRecord = nextSpan;
+            size_t bytes = 0;
+            while (nextSpan < all.size() && (g.owned.empty() || bytes + all[nextSpan].sequence.size() <= groupBytes)) {
+                bytes += all[nextSpan].sequence.size();
+                g.owned.push_back(std::move(all[nextSpan++]));
+            }
+            return true;
+        }
+        if (nextSpan >= spans.size()) return false;
+        g.firstRecord = nextSpan;
+        size_t first = nextSpan, bytes = 0;
+        while (nextSpan < spans.size() && (nextSpan == first || bytes + static_cast<size_t>(spans[nextSpan].stop - spans[nextSpan].body) <= groupBytes)) {
+            bytes += static_cast<size_t>(spans[nextSpan].stop - spans[nextSpan].body);
+            ++nextSpan;
+        }
+        const size_t nrec = nextSpan - first;
+        g.records.resize(nrec);
+        // pieces of ~4 MB of text, cut at line starts; pass 1 counts every piece's bases, pass 2 copies them to
+        // their place in the record's buffer
+        struct Piece { size_t rec; const char *a, *z; size_t bases, at; };
+        std::vector<Piece> pieces;
+        constexpr size_t kPiece = size_t(4) << 20;
+        for (size_t r = 0; r < nrec; ++r) {
+            const Span &sp = spans[first + r];
+            const char *he = sp.body > sp.head && sp.body[-1] == '\n' ? sp.body - 1 : sp.body;
+            g.records[r].header = detail::fastaHeaderWord(sp.head, he);
+            for (const char *a = sp.body; a < sp.stop;) {
+                const char *z = sp.stop - a > static_cast<ptrdiff_t>(kPiece) ? a + kPiece : sp.stop;
+                if (z < sp.stop) {
+                    const char *nl = static_cast<const char *>(std::memchr(z, '\n', static_cast<size_t>(sp.stop - z)));
+                    z = nl ? nl + 1 : sp.stop;
+                }
+                pieces.push_back(Piece{r, a, z, 0, 0});
+                a = z;
+            }
+        }
+        detail::onThreads(pieces.size(), [&](size_t i) { pieces[i].bases = detail::countFastaBases(pieces[i].a, pieces[i].z); });
+        for (size_t i = 0; i < pieces.size(); ++i) {
+            pieces[i].at = g.records[pieces[i].rec].size;
+            g.records[pieces[i].rec].size += pieces[i].bases;
+        }
+        for (detail::RawRecord &rr : g.records) rr.data.reset(new char[rr.size + 1]);
+        detail::onThreads(pieces.size(), [&](size_t i) {
+            (void)detail::copyFastaBases(pieces[i].a, pieces[i].z, g.records[pieces[i].rec].data.get() + pieces[i].at);
+        });
+        return true;
+    }
+};
+
+struct ScanFastaTimes { double read_ms = 0, scan_ms = 0, write_ms = 0, wall_ms = 0; uint64_t bases = 0, windows = 0; size_t groups = 0; };
+
+// FASTA file -> the eleven output files + console path report; returns the totals for printSummary.
+inline AssemblySummary scanFastaToFiles(Teloscope &teloscope, const std::string &fastaFile, const std::string &outBase,
+                                        std::ostream &console, bool manualCuration = false,
+                                        size_t groupBytes = size_t(256) << 20, ScanFastaTimes *times = nullptr) {
+    using Clock = std::chrono::steady_clock;
+    auto ms = [](Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_begin = Clock::now();
+    struct Scanned { detail::FastaGroup group; std::vector<PathData> paths; };
+    detail::BoundedQueue<detail::FastaGroup> toScan(2);
+    detail::BoundedQueue<Scanned> toWrite(2);
+    std::exception_ptr readError, scanError;
+    ScanFastaTimes T;
+
+    std::thread reader([&] {
+        try {
+            FastaGroupReader rd(fastaFile, groupBytes);
+            detail::FastaGroup g;
+            for (;;) {
+                const auto t0 = Clock::now();
+                if (!rd.next(g)) break;
+                T.read_ms += ms(t0, Clock::now());
+                toScan.push(std::move(g));
+            }
+        } catch (...) { readError = std::current_exception(); }
+        toScan.close();
+    });
+    std::thread scanner([&] {
+        try {
+            detail::FastaGroup g;
+            while (toScan.pop(g)) {
+                const auto t0 = Clock::now();
+                std::vector<RecordView> views;
+                for (const detail::RawRecord &r : g.records) views.push_back(RecordView{&r.header, r.data.get(), r.size});
+                for (const FastaRecord &r : g.owned) views.push_back(RecordView{&r.header, r.sequence.data(), r.sequence.size()});
+                Scanned s;
+                s.paths = walkRecordViews(teloscope, views, g.firstRecord);
+                s.group = std::move(g);                           // (-m: matchSeq was copied out of the bases already)
+                T.scan_ms += ms(t0, Clock::now());
+                toWrite.push(std::move(s));
+            }
+        } catch (...) {
+            scanError = std::current_exception();
+            detail::FastaGroup drop;
+            while (toScan.pop(drop)) {}
+        }
+        toWrite.close();
+    });
+    AssemblySummary sum;
+    std::exception_ptr writeError;
+    try {
+        BedWriter writer(outBase, teloscope.input(), console, manualCuration);
+        Scanned s;
+        while (toWrite.pop(s)) {
+            const auto t0 = Clock::now();
+            writer.add(s.paths);
+            for (const PathData &pd : s.paths) { T.bases += pd.pathSize; T.windows += pd.windows.size(); }
+            ++T.groups;
+            T.write_ms += ms(t0, Clock::now());
+        }
+        sum = writer.finish();
+    } catch (...) {
+        writeError = std::current_exception();
+        Scanned drop;
+        while (toWrite.pop(drop)) {}
+    }
+    reader.join();
+    scanner.join();
+    if (readError) std::rethrow_exception(readError);
+    if (scanError) std::rethrow_exception(scanError);
+    if (writeError) std::rethrow_exception(writeError);
+    T.wall_ms = ms(t_begin, Clock::now());
+    if (times) *times = T;
+    return sum;
 }
 
 }  // namespace teloscope_mi355x

@@ -64,6 +64,26 @@ int main(int argc, char **argv) {
         const std::vector<FastaRecord> a = readFasta(plain), b = readFasta(packed);
         check(a.size() == b.size(), "record count");
         for (size_t i = 0; i < a.size(); ++i) check(a[i].header == b[i].header && a[i].sequence == b[i].sequence, "record content");
+        // the streaming reader (groups of records, lines joined in pieces by the thread pool): any group size must
+        // give the same records in the same order, from the mapped file and from the gzip stream
+        for (const std::string &file : {plain, packed})
+            for (size_t groupBytes : {size_t(1), size_t(700), size_t(1) << 20}) {
+                FastaGroupReader rd(file, groupBytes);
+                detail::FastaGroup g;
+                size_t at = 0;
+                while (rd.next(g)) {
+                    check(g.firstRecord == at, "group order");
+                    for (const detail::RawRecord &r : g.records) {
+                        check(at < a.size() && r.header == a[at].header && std::string(r.data.get(), r.size) == a[at].sequence, "streamed record");
+                        ++at;
+                    }
+                    for (const FastaRecord &r : g.owned) {
+                        check(at < a.size() && r.header == a[at].header && r.sequence == a[at].sequence, "streamed record (zlib)");
+                        ++at;
+                    }
+                }
+                check(at == a.size(), "streamed record count");
+            }
     }
     puts("io_selftest ok");
     return 0;

@@ -9,6 +9,8 @@
 //        [--out-base <prefix>]   where the eleven output files go (default: a scratch prefix)
 //        [--read-devices 0,0]    read filter over several contexts (one per listed HIP ordinal; repeats allowed)
 //        [--reads-per-batch n]   reads per GPU batch of --fastq-subset / --bam-subset (test hook)
+//        [--no-stream]           readFasta, then walkPaths, then writeBEDFiles (default: the three overlap in
+//                                scanFastaToFiles, records flowing in groups)   [--group-bytes n: group size, test hook]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -26,7 +28,8 @@ int main(int argc, char **argv) {
     UserInputTeloscope ui;
     std::string input, canonical, outBase;
     bool scratch = false, manualCuration = false, fastqSubsetMode = false, bamSubsetMode = false;
-    size_t fastqBlock = 512u << 20, readsPerBatch = 1u << 20;
+    size_t fastqBlock = 512u << 20, readsPerBatch = 1u << 20, groupBytes = size_t(256) << 20;
+    bool stream = true;
     std::vector<int> readDevices;
     std::vector<std::string> rawPatterns;
     bool hasPatterns = false;
@@ -38,6 +41,8 @@ int main(int argc, char **argv) {
         else if (a == "--bam-subset") bamSubsetMode = true;
         else if (a == "--fastq-block") fastqBlock = static_cast<size_t>(std::stoull(val()));   // test hook: arena size in bytes
         else if (a == "--out-base") outBase = val();
+        else if (a == "--no-stream") stream = false;
+        else if (a == "--group-bytes") groupBytes = static_cast<size_t>(std::stoull(val()));
         else if (a == "--reads-per-batch") readsPerBatch = static_cast<size_t>(std::stoull(val()));
         else if (a == "--read-devices") {
             std::istringstream ds(val());
@@ -103,24 +108,34 @@ int main(int argc, char **argv) {
         const bool timing = getenv("TS_TIMING") != nullptr;      // stage times to stderr
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms = [](auto x, auto y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
-        const auto t0 = now();
-        std::vector<FastaRecord> records = readFasta(input);
-        const auto t1 = now();
-        std::vector<PathData> paths = walkPaths(teloscope, records);
-        const auto t2 = now();
         if (outBase.empty()) {
             const char *tmp = getenv("TMPDIR");
             outBase = std::string(tmp ? tmp : "/tmp") + "/manifest_cli_" + std::to_string(static_cast<long>(getpid()));
             scratch = true;
         }
-        AssemblySummary summary;
-        writeBEDFiles(outBase, paths, ui, std::cout, summary, manualCuration);
-        printSummary(std::cout, summary, ui.ultraFastMode, outBase + "_report.tsv");
-        if (timing) {
-            uint64_t bases = 0, windows = 0;
-            for (const PathData &pd : paths) { bases += pd.pathSize; windows += pd.windows.size(); }
-            fprintf(stderr, "manifest_cli: %.1f Mb, %llu windows: read %.0f ms, walkPaths (scan + host post-processing) %.0f ms, "
-                            "writeBEDFiles + printSummary %.0f ms\n", bases / 1e6, (unsigned long long)windows, ms(t0, t1), ms(t1, t2), ms(t2, now()));
+        const auto t0 = now();
+        if (stream) {
+            ScanFastaTimes T;
+            const AssemblySummary summary = scanFastaToFiles(teloscope, input, outBase, std::cout, manualCuration, groupBytes, &T);
+            printSummary(std::cout, summary, ui.ultraFastMode, outBase + "_report.tsv");
+            if (timing)
+                fprintf(stderr, "manifest_cli (streaming): %.1f Mb, %llu windows, %zu groups: wall %.0f ms = %.2f Gbases/s; stage sums (the stages "
+                                "overlap): read + join lines %.0f ms, scan + host post-processing %.0f ms, format + write %.0f ms\n",
+                        T.bases / 1e6, (unsigned long long)T.windows, T.groups, ms(t0, now()), T.bases / 1e6 / ms(t0, now()), T.read_ms, T.scan_ms, T.write_ms);
+        } else {
+            std::vector<FastaRecord> records = readFasta(input);
+            const auto t1 = now();
+            std::vector<PathData> paths = walkPaths(teloscope, records);
+            const auto t2 = now();
+            AssemblySummary summary;
+            writeBEDFiles(outBase, paths, ui, std::cout, summary, manualCuration);
+            printSummary(std::cout, summary, ui.ultraFastMode, outBase + "_report.tsv");
+            if (timing) {
+                uint64_t bases = 0, windows = 0;
+                for (const PathData &pd : paths) { bases += pd.pathSize; windows += pd.windows.size(); }
+                fprintf(stderr, "manifest_cli: %.1f Mb, %llu windows: read %.0f ms, walkPaths (scan + host post-processing) %.0f ms, "
+                                "writeBEDFiles + printSummary %.0f ms\n", bases / 1e6, (unsigned long long)windows, ms(t0, t1), ms(t1, t2), ms(t2, now()));
+            }
         }
         if (scratch)
             for (const char *sfx : {"_window_repeat_density.bedgraph", "_window_canonical_ratio.bedgraph", "_window_strand_ratio.bedgraph",

@@ -1,5 +1,5 @@
 """Host-only checks of the C++ mirror's ingest (include/teloscope_mi355x_io.hpp): the mapped multi-threaded FASTA
-reader against the zlib stream reader, splitPath's word-at-a-time scan against a per-character walk.  No GPU."""
+reader against the zlib stream reader, the streaming group reader against both, splitPath's word-at-a-time scan against a per-character walk.  No GPU."""
 import os
 import subprocess
 

@@ -57,6 +57,28 @@ def test_output_files_match_the_reference_formats(cli, tmp_path, name, flags):  
         assert open(base + "_gaps.bed").read() == open(golden).read()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,flags", [("multi.fa", "-r -g -e -m -i"), ("multi_gap_t2t.fa", "-w 500 -s 250 -r -g -e -i"),
+                                        ("bTaeGut7_chr33_mat.fa.gz", "-r -i"), ("multi.fa", "")])
+def test_streaming_pipeline_equals_three_phase_path(cli, tmp_path, name, flags):  # noqa: F811
+    """scanFastaToFiles (records flowing in groups through read / scan / write stages that overlap) against
+    readFasta + walkPaths + writeBEDFiles: the same files and the same console text, byte for byte, for groups of
+    one record, of a few and of the whole file."""
+    fasta = H.golden_path("testFiles/" + name)
+    ref_base = str(tmp_path / "ref")
+    ref = subprocess.run([cli, "-f", fasta, "--out-base", ref_base, "--no-stream"] + shlex.split(flags), capture_output=True, timeout=300)
+    assert ref.returncode == 0, ref.stderr
+    for group in ("1", "5000", str(1 << 30)):
+        base = str(tmp_path / ("g" + group))
+        got = subprocess.run([cli, "-f", fasta, "--out-base", base, "--group-bytes", group] + shlex.split(flags), capture_output=True, timeout=300)
+        assert got.returncode == 0, got.stderr
+        assert got.stdout == ref.stdout
+        for sfx in H.BED_SUFFIXES:
+            assert os.path.exists(base + sfx) == os.path.exists(ref_base + sfx), sfx
+            if os.path.exists(base + sfx):
+                assert open(base + sfx, "rb").read() == open(ref_base + sfx, "rb").read(), (sfx, group)
+
+
 GAP_BEDS = sorted(glob.glob(os.path.join(H.golden_path("testFiles/expected"), "*_gaps.bed")))
 
 
