@@ -248,21 +248,53 @@ struct RecordView {
     size_t size;
 };
 
+// splitPath for every record of a group, on the host threads: records are cut into pieces (16 MB) that are scanned
+// independently — one 250 Mb chromosome keeps all threads busy — and a run that crosses a cut is put together again.
+inline std::vector<PathComponents> splitPaths(const std::vector<RecordView> &records, size_t pieceBytes = size_t(16) << 20) {
+    std::vector<PathComponents> comps(records.size());
+    struct Piece { size_t rec, a, z; PathComponents pc; bool firstIsGap, lastIsGap; };
+    std::vector<Piece> pieces;
+    pieceBytes = std::max<size_t>(pieceBytes, 1);
+    for (size_t r = 0; r < records.size(); ++r)
+        for (size_t a = 0; a < records[r].size; a += pieceBytes) pieces.push_back(Piece{r, a, std::min(records[r].size, a + pieceBytes), {}, false, false});
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (size_t i; (i = next.fetch_add(1)) < pieces.size();) {
+            Piece &p = pieces[i];
+            p.pc = splitPath(records[p.rec].data + p.a, p.z - p.a);
+            for (auto &sg : p.pc.segments) sg.first += p.a;
+            for (GapInfo &g : p.pc.gaps) g.start += p.a;
+            auto isGap = [](char c) { return c == 'N' || c == 'n' || c == 'X' || c == 'x'; };
+            p.firstIsGap = isGap(records[p.rec].data[p.a]);
+            p.lastIsGap = isGap(records[p.rec].data[p.z - 1]);
+        }
+    };
+    const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), pieces.size(), size_t(std::max(1u, std::thread::hardware_concurrency()))}));
+    if (nt <= 1) worker();
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(worker);
+        for (std::thread &th : pool) th.join();
+    }
+    for (size_t i = 0; i < pieces.size(); ++i) {
+        Piece &p = pieces[i];
+        PathComponents &out = comps[p.rec];
+        const bool joins = p.a != 0 && pieces[i - 1].lastIsGap == p.firstIsGap;     // the run continues across the cut
+        size_t si = 0, gi = 0;
+        if (joins) {
+            if (p.firstIsGap) { out.gaps.back().length += p.pc.gaps[0].length; gi = 1; }
+            else { out.segments.back().second += p.pc.segments[0].second; si = 1; }
+        }
+        out.segments.insert(out.segments.end(), p.pc.segments.begin() + static_cast<long>(si), p.pc.segments.end());
+        out.gaps.insert(out.gaps.end(), p.pc.gaps.begin() + static_cast<long>(gi), p.pc.gaps.end());
+    }
+    return comps;
+}
+
 // walkPath for every record, with one batched scan (result order = record order; seqPos = seqPosBase + index).
 inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::vector<RecordView> &records, size_t seqPosBase = 0) {
     const UserInputTeloscope &ui = teloscope.input();
-    std::vector<PathComponents> comps(records.size());
-    {   // N-run -> gap splitting is independent per record: on the host threads
-        std::atomic<size_t> next{0};
-        auto worker = [&]() { for (size_t i; (i = next.fetch_add(1)) < records.size();) comps[i] = splitPath(records[i].data, records[i].size); };
-        const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), records.size(), size_t(std::max(1u, std::thread::hardware_concurrency()))}));
-        if (nt <= 1) worker();
-        else {
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < nt; ++t) pool.emplace_back(worker);
-            for (std::thread &th : pool) th.join();
-        }
-    }
+    const std::vector<PathComponents> comps = splitPaths(records);
     std::vector<Teloscope::Segment> batch;
     for (size_t pi = 0; pi < records.size(); ++pi)
         for (const auto &sg : comps[pi].segments)
@@ -616,23 +648,31 @@ inline BamSubsetStats bamSubset(const std::string &inFile, std::ostream &out, Re
     auto le32 = [](const unsigned char *p) { return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16) | (static_cast<uint32_t>(p[3]) << 24); };
 
     detail::BgzfWriter writer(out);
-    {   // header: magic, text, reference list — copied verbatim (copyBamHeader)
+    {   // header: magic, text, reference list — validated like copyBamHeader (src/bam.cpp:75-120: text <= 1 GiB,
+        // names 1 .. 1 MiB and NUL-terminated, no negative counts or lengths) and copied verbatim
+        constexpr uint32_t kMaxHeaderText = 1u << 30, kMaxReferenceName = 1u << 20;
         std::vector<unsigned char> h(12);
         readExact(h.data(), 8, "header");
         if (std::memcmp(h.data(), "BAM\1", 4) != 0) throw std::runtime_error("input is not a BAM file");
         const uint32_t ltext = le32(h.data() + 4);
+        if (ltext > kMaxHeaderText) throw std::runtime_error("invalid BAM header text length");
         h.resize(8 + static_cast<size_t>(ltext) + 4);
         readExact(h.data() + 8, static_cast<size_t>(ltext) + 4, "header");
         const uint32_t nref = le32(h.data() + 8 + ltext);
-        for (uint32_t r = 0; r < nref; ++r) {
-            const size_t at = h.size();
-            h.resize(at + 4);
-            readExact(h.data() + at, 4, "reference");
-            const uint32_t lname = le32(h.data() + at);
-            h.resize(at + 4 + static_cast<size_t>(lname) + 4);
-            readExact(h.data() + at + 4, static_cast<size_t>(lname) + 4, "reference");
-        }
+        if (nref > 0x7fffffffu) throw std::runtime_error("invalid BAM reference count");
         writer.write(h.data(), h.size());
+        std::vector<unsigned char> ref;
+        for (uint32_t r = 0; r < nref; ++r) {
+            ref.resize(4);
+            readExact(ref.data(), 4, "reference");
+            const uint32_t lname = le32(ref.data());
+            if (lname == 0 || lname > kMaxReferenceName) throw std::runtime_error("invalid BAM reference name length");
+            ref.resize(4 + static_cast<size_t>(lname) + 4);
+            readExact(ref.data() + 4, static_cast<size_t>(lname) + 4, "reference");
+            if (ref[4 + lname - 1] != 0) throw std::runtime_error("BAM reference name is not NUL-terminated");
+            if (le32(ref.data() + 4 + lname) > 0x7fffffffu) throw std::runtime_error("invalid BAM reference length");
+            writer.write(ref.data(), ref.size());
+        }
     }
 
     struct Rec { size_t rawOff, rawLen, seqOff; uint64_t seqLen; };
@@ -664,7 +704,7 @@ inline BamSubsetStats bamSubset(const std::string &inFile, std::ostream &out, Re
         if (got == 0) break;
         if (got != 4) throw std::runtime_error("truncated BAM record size");
         const int32_t blockSize = static_cast<int32_t>(le32(sz));
-        if (blockSize < 32 || static_cast<uint32_t>(blockSize) > (1u << 29)) throw std::runtime_error("invalid BAM record block_size");
+        if (blockSize < 32 || static_cast<uint32_t>(blockSize) > (256u << 20)) throw std::runtime_error("invalid BAM record block_size");   // BAM_MAX_RECORD_SIZE, src/bam.cpp:29
         const size_t at = raw.size();
         raw.resize(at + 4 + static_cast<size_t>(blockSize));
         std::memcpy(raw.data() + at, sz, 4);
@@ -672,7 +712,8 @@ inline BamSubsetStats bamSubset(const std::string &inFile, std::ostream &out, Re
         const unsigned char *core = raw.data() + at + 4;
         const uint32_t lname = core[8], ncigar = static_cast<uint32_t>(core[12]) | (static_cast<uint32_t>(core[13]) << 8), lseq = le32(core + 16);
         const uint64_t seqAt = 32ull + lname + 4ull * ncigar;
-        if (lname == 0 || seqAt + (static_cast<uint64_t>(lseq) + 1) / 2 + lseq > static_cast<uint64_t>(blockSize))
+        if (lname == 0 || lseq > 0x7fffffffu) throw std::runtime_error("invalid BAM record lengths");          // decodeSequence, src/bam.cpp:122-163
+        if (seqAt + (static_cast<uint64_t>(lseq) + 1) / 2 + lseq > static_cast<uint64_t>(blockSize))
             throw std::runtime_error("BAM record fields exceed block_size");
         if (core[32 + lname - 1] != 0) throw std::runtime_error("BAM read name is not NUL-terminated");
         const size_t so = seqs.size();
@@ -709,8 +750,23 @@ inline void put(std::string &s, uint64_t v) {
     s.append(b, std::to_chars(b, b + sizeof b, v).ptr);
 }
 inline void put(std::string &s, float v) {                      // default ostream float: %g, precision 6
-    char b[48];
-    s.append(b, std::to_chars(b, b + sizeof b, v, std::chars_format::general, 6).ptr);
+    // The float columns of the window files take few distinct values (ratios of small integers, entropy rounded to
+    // three decimals), and shortest-round-trip formatting is the costly part of a line: every thread remembers the
+    // text of the values it has formatted (4096-entry direct-mapped table keyed by the float's bits).
+    struct Memo { uint32_t key; uint8_t len; char text[19]; };
+    thread_local std::vector<Memo> memo;
+    if (memo.empty()) { memo.resize(4096); for (Memo &m : memo) { m.key = 0; m.len = 0; } }
+    uint32_t bits;
+    std::memcpy(&bits, &v, 4);
+    Memo &m = memo[(bits * 2654435761u) >> 20];
+    if (m.len == 0 || m.key != bits) {
+        char b[48];
+        const size_t n = static_cast<size_t>(std::to_chars(b, b + sizeof b, v, std::chars_format::general, 6).ptr - b);
+        if (n > sizeof m.text) { s.append(b, n); return; }
+        m.key = bits; m.len = static_cast<uint8_t>(n);
+        std::memcpy(m.text, b, n);
+    }
+    s.append(m.text, m.len);
 }
 inline void put(std::string &s, const std::string &v) { s += v; }
 inline void put(std::string &s, const char *v) { s += v; }
@@ -1018,14 +1074,28 @@ inline void onThreads(size_t n, F &&f) {                        // f(i) for i in
     for (std::thread &th : pool) th.join();
 }
 
-// bases of [p, end) without the line ends ('\n', and a '\r' right before it or at the very end)
+// bases of [p, end) without the line ends ('\n', and a '\r' right before it or at the very end); [p, end) starts
+// at a line start.  Eight bytes at a time: line ends are counted, not searched for.
 inline size_t countFastaBases(const char *p, const char *end) {
+    const size_t len = static_cast<size_t>(end - p);
+    const uint64_t ones = 0x0101010101010101ull, low7 = 0x7F7F7F7F7F7F7F7Full;
+    auto zeroBytes = [&](uint64_t v) { return ~(((v & low7) + low7) | v | low7); };            // 0x80 in every zero byte, exactly
+    size_t nl = 0, cr = 0, i = 0;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t v;
+        std::memcpy(&v, p + i, 8);
+        nl += static_cast<size_t>(__builtin_popcountll(zeroBytes(v ^ (ones * 0x0A))));
+        cr += static_cast<size_t>(__builtin_popcountll(zeroBytes(v ^ (ones * 0x0D))));
+    }
+    for (; i < len; ++i) { nl += p[i] == '\n'; cr += p[i] == '\r'; }
+    if (cr == 0) return len - nl;
+    // carriage returns: only those that end a line are dropped (rare input: count them the careful way)
     size_t n = 0;
     while (p < end) {
-        const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
-        const char *stop = nl ? nl : end;
+        const char *q = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        const char *stop = q ? q : end;
         if (stop > p) n += static_cast<size_t>((stop[-1] == '\r' ? stop - 1 : stop) - p);
-        p = nl ? nl + 1 : end;
+        p = q ? q + 1 : end;
     }
     return n;
 }

@@ -40,6 +40,15 @@ int main(int argc, char **argv) {
             i = j;
         }
         check(gi == pc.gaps.size() && si == pc.segments.size(), "run counts");
+        // the same record cut into pieces that are scanned independently and stitched (splitPaths): any piece size
+        const std::string header = "h";
+        for (size_t piece : {size_t(1), size_t(7), size_t(64), size_t(1000), size_t(1) << 20}) {
+            if (it % 16 != 0) break;                                   // (each call starts a thread pool)
+            const std::vector<PathComponents> got = splitPaths({RecordView{&header, view.data(), view.size()}}, piece);
+            check(got.size() == 1 && got[0].segments == pc.segments && got[0].gaps.size() == pc.gaps.size(), "stitched runs");
+            for (size_t g = 0; g < pc.gaps.size() && g < got[0].gaps.size(); ++g)
+                check(got[0].gaps[g].start == pc.gaps[g].start && got[0].gaps[g].length == pc.gaps[g].length, "stitched gap");
+        }
     }
     // ---- readFasta: plain (mapped) vs gzip (stream) on awkward texts
     for (int it = 0; it < 40; ++it) {

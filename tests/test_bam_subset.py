@@ -114,3 +114,98 @@ def test_bam_subset_rejects_garbage_and_flags_missing_eof(cli, tmp_path):  # noq
     noeof.write_bytes(bam[:-len(EOF_BLOCK)])
     r = subprocess.run([cli, "--bam-subset", str(noeof)], capture_output=True, timeout=120)
     assert r.returncode == 0 and b"missing the BGZF EOF marker" in r.stderr
+
+
+def _kept_names(plain, header):
+    """read names of the records of an uncompressed BAM payload (validating its structure on the way)."""
+    assert plain[:len(header)] == header
+    names, pos = [], len(header)
+    while pos < len(plain):
+        (bs,) = struct.unpack_from("<i", plain, pos)
+        assert 32 <= bs and pos + 4 + bs <= len(plain)
+        lname = plain[pos + 4 + 8]
+        names.append(plain[pos + 36:pos + 36 + lname - 1].decode())
+        pos += 4 + bs
+    return names
+
+
+def _run_bam(cli, tmp_path, reads, flags, tag):
+    header, records, bam = build_bam(reads, 60000)
+    path = tmp_path / ("%s.bam" % tag)
+    path.write_bytes(bam)
+    r = subprocess.run([cli, "--bam-subset"] + flags + [str(path)], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return _kept_names(gunzip_members(r.stdout), header)
+
+
+@pytest.mark.gpu
+def test_bam_threshold_known_answers(cli, tmp_path):  # noqa: F811
+    """The exact threshold cases the reference pins through its BAM entry (scripts/test_bam_subset.py:339-381:
+    default -l 42 boundary, exact 12 / 18 bp lengths at -y 1, the 2/3 density boundary, a custom plant canonical),
+    here through bamSubset on the GPU."""
+    default = [("short", "TTAGGG" * 6), ("default_pass", "TTAGGG" * 7), ("long", "CCCTAA" * 15), ("fail", "ACGT" * 20)]
+    assert _run_bam(cli, tmp_path, default, [], "d") == ["default_pass", "long"]
+    lengths = [("one_repeat", "TTAGGG"), ("exact_12", "TTAGGG" * 2), ("flanked_exact", "ACGT" + "CCCTAA" * 2 + "TGCA"),
+               ("exact_18", "TTAGGG" * 3)]
+    l12 = ["-x", "0", "-l", "12", "-y", "1", "-k", "10", "-d", "10"]
+    l18 = ["-x", "0", "-l", "18", "-y", "1", "-k", "10", "-d", "10"]
+    assert _run_bam(cli, tmp_path, lengths, l12, "l12") == ["exact_12", "flanked_exact", "exact_18"]
+    assert _run_bam(cli, tmp_path, lengths, l18, "l18") == ["exact_18"]
+    density = [("two_thirds", "TTAGGGAAAAAATTAGGG")]
+    assert _run_bam(cli, tmp_path, density, ["-x", "0", "-l", "18", "-y", "0.666", "-k", "20", "-d", "10"], "y1") == ["two_thirds"]
+    assert _run_bam(cli, tmp_path, density, ["-x", "0", "-l", "18", "-y", "0.667", "-k", "20", "-d", "10"], "y2") == []
+    plant = [("plant_pass", "TTTAGGG" * 3), ("vertebrate_fail", "TTAGGG" * 4)]
+    assert _run_bam(cli, tmp_path, plant, ["-c", "CCCTAAA", "-x", "0", "-l", "21", "-y", "1"], "p") == ["plant_pass"]
+
+
+@pytest.mark.gpu
+def test_bam_mutation_robustness(cli, tmp_path):  # noqa: F811
+    """Deterministic damage to a small BAM — random bytes, truncated payloads, single bit flips, a corrupt
+    block_size / l_read_name / n_cigar_op, dropped records (the idea of the reference's mutation suite,
+    scripts/test_bam_subset.py:589-633) — must end in a clean error (exit 1 + message) or in a valid BAM; never in a
+    crash, a hang or a structurally broken output."""
+    import random
+    gen = random.Random(91)
+    reads = [("record_%d" % i, "TTAGGG" * (3 + i % 5)) for i in range(8)]
+    header, records, _ = build_bam(reads, 60000)
+    payload = header + b"".join(records)
+    roff = len(header)
+    for index in range(70):
+        mode = index % 7
+        if mode == 0:
+            data = bytes(gen.getrandbits(8) for _ in range(gen.randrange(0, 2048)))
+        elif mode == 1:
+            data = bgzf(payload[:gen.randrange(len(payload) + 1)], 60000)
+        elif mode == 2:
+            m = bytearray(payload)
+            m[gen.randrange(roff + 36, len(m))] ^= 1 << gen.randrange(8)
+            data = bgzf(bytes(m), 60000)
+        elif mode == 3:
+            m = bytearray(payload)
+            struct.pack_into("<i", m, roff, gen.randrange(-16, 129))
+            data = bgzf(bytes(m), 60000)
+        elif mode == 4:
+            m = bytearray(payload)
+            m[roff + 12] = gen.randrange(256)
+            data = bgzf(bytes(m), 60000)
+        elif mode == 5:
+            m = bytearray(payload)
+            struct.pack_into("<H", m, roff + 16, gen.randrange(65536))
+            data = bgzf(bytes(m), 60000)
+        else:
+            data = bgzf(header + b"".join(records[:gen.randrange(len(records) + 1)]), 60000)
+        path = tmp_path / "m.bam"
+        path.write_bytes(data)
+        r = subprocess.run([cli, "--bam-subset", "-x", "0", "-l", "18", str(path)], capture_output=True, timeout=60)
+        assert r.returncode in (0, 1), (index, mode, r.returncode, r.stderr[-300:])       # a signal would be negative
+        if r.returncode == 0:
+            plain = gunzip_members(r.stdout)
+            assert r.stdout.endswith(EOF_BLOCK)
+            pos = plain.index(b"chr1\0") + 5 + 4                                           # past the reference list
+            while pos < len(plain):
+                (bs,) = struct.unpack_from("<i", plain, pos)
+                assert 32 <= bs and pos + 4 + bs <= len(plain), (index, mode)
+                pos += 4 + bs
+        else:
+            assert r.stderr.startswith(b"Error:") or b"Error:" in r.stderr, (index, mode, r.stderr[-300:])
+            assert r.stdout == b"" or not r.stdout.endswith(EOF_BLOCK), (index, mode)      # no complete-looking output on failure
