@@ -182,7 +182,11 @@ class Teloscope {                              // include/teloscope.h:166-300 (s
     UserInputTeloscope userInput;
     detail::CtxPtr ctx;
 
-    SegmentData convert(const ts_segment_out &o, const char *sequence, uint64_t absPos, bool tipsOnly) const {
+    // writerViewOnly: fill only what writeBEDFile reads (src/teloscope.cpp:700-868) — windows, blocks,
+    // canonicalMatches and nonCanonicalMatches; the other three match vectors (all / fwd / rev, which only block
+    // calling reads, and that has happened on the device) stay empty.  Of ~90 M matches of a 3 Gb assembly ~3 M are
+    // written, and a MatchInfo is 56 bytes with a std::string.
+    SegmentData convert(const ts_segment_out &o, const char *sequence, uint64_t absPos, bool tipsOnly, bool writerViewOnly = false) const {
         SegmentData sd;
         sd.windows.reserve(o.n_windows);
         for (uint64_t i = 0; i < o.n_windows; ++i) {
@@ -195,11 +199,14 @@ class Teloscope {                              // include/teloscope.h:166-300 (s
             w.fwdCovered = g.fwd_covered; w.revCovered = g.rev_covered;
             sd.windows.push_back(w);
         }
-        if (!tipsOnly) sd.allMatches.reserve(o.n_matches);
-        sd.fwdMatches.reserve(o.n_matches / 2 + 1);
-        sd.revMatches.reserve(o.n_matches / 2 + 1);
+        if (!writerViewOnly) {
+            if (!tipsOnly) sd.allMatches.reserve(o.n_matches);
+            sd.fwdMatches.reserve(o.n_matches / 2 + 1);
+            sd.revMatches.reserve(o.n_matches / 2 + 1);
+        }
         for (uint64_t i = 0; i < o.n_matches; ++i) {
             const ts_match &g = o.matches[i];
+            if (writerViewOnly && (tipsOnly || !(g.flags & (TS_MATCH_CANONICAL | TS_MATCH_TERMINAL)))) continue;
             MatchInfo m;
             m.position = g.position; m.matchSize = g.match_size;
             m.isForward = (g.flags & TS_MATCH_FORWARD) != 0;
@@ -209,9 +216,9 @@ class Teloscope {                              // include/teloscope.h:166-300 (s
                 for (char &ch : m.matchSeq)
                     if (ch >= 'a' && ch <= 'z') ch = static_cast<char>(ch - 32);
             }
-            (m.isForward ? sd.fwdMatches : sd.revMatches).push_back(m);
+            if (!writerViewOnly) (m.isForward ? sd.fwdMatches : sd.revMatches).push_back(m);
             if (!tipsOnly) {                                            // routing of src/teloscope.cpp:485-509
-                sd.allMatches.push_back(m);
+                if (!writerViewOnly) sd.allMatches.push_back(m);
                 if (m.isCanonical) sd.canonicalMatches.push_back(m);
                 else if (g.flags & TS_MATCH_TERMINAL) sd.nonCanonicalMatches.push_back(m);
             }
@@ -243,7 +250,8 @@ public:
     };
 
     // batched scanSegment: result[i] is what scanSegment(*segs[i].sequence, absPos, tipsOnly) returns
-    std::vector<SegmentData> scanSegments(const std::vector<Segment> &segs) {
+    // (writerViewOnly: see convert())
+    std::vector<SegmentData> scanSegments(const std::vector<Segment> &segs, bool writerViewOnly = false) {
         std::vector<ts_segment_in> in(segs.size());
         for (size_t i = 0; i < segs.size(); ++i) {
             in[i] = ts_segment_in{segs[i].data, segs[i].size, segs[i].absPos, static_cast<uint8_t>(segs[i].tipsOnly), {}};
@@ -261,7 +269,7 @@ public:
         auto worker = [&]() {
             for (size_t k; (k = next.fetch_add(1)) < order.size();) {
                 const size_t i = order[k];
-                res[i] = convert(out[i], segs[i].data, segs[i].absPos, segs[i].tipsOnly);
+                res[i] = convert(out[i], segs[i].data, segs[i].absPos, segs[i].tipsOnly, writerViewOnly);
             }
         };
         const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), segs.size(), size_t(std::max(1u, std::thread::hardware_concurrency()))}));

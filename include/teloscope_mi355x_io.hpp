@@ -248,6 +248,20 @@ struct RecordView {
     size_t size;
 };
 
+namespace detail {
+// appends the runs of a piece (already in record coordinates) to the record's components; when the piece continues
+// a record and its first run is of the kind the previous piece ended with, the two are one run
+inline void appendPieceRuns(PathComponents &out, const PathComponents &pc, bool continues, bool prevLastIsGap, bool firstIsGap) {
+    size_t si = 0, gi = 0;
+    if (continues && prevLastIsGap == firstIsGap) {
+        if (firstIsGap) { out.gaps.back().length += pc.gaps[0].length; gi = 1; }
+        else { out.segments.back().second += pc.segments[0].second; si = 1; }
+    }
+    out.segments.insert(out.segments.end(), pc.segments.begin() + static_cast<long>(si), pc.segments.end());
+    out.gaps.insert(out.gaps.end(), pc.gaps.begin() + static_cast<long>(gi), pc.gaps.end());
+}
+}  // namespace detail
+
 // splitPath for every record of a group, on the host threads: records are cut into pieces (16 MB) that are scanned
 // independently — one 250 Mb chromosome keeps all threads busy — and a run that crosses a cut is put together again.
 inline std::vector<PathComponents> splitPaths(const std::vector<RecordView> &records, size_t pieceBytes = size_t(16) << 20) {
@@ -278,30 +292,26 @@ inline std::vector<PathComponents> splitPaths(const std::vector<RecordView> &rec
     }
     for (size_t i = 0; i < pieces.size(); ++i) {
         Piece &p = pieces[i];
-        PathComponents &out = comps[p.rec];
-        const bool joins = p.a != 0 && pieces[i - 1].lastIsGap == p.firstIsGap;     // the run continues across the cut
-        size_t si = 0, gi = 0;
-        if (joins) {
-            if (p.firstIsGap) { out.gaps.back().length += p.pc.gaps[0].length; gi = 1; }
-            else { out.segments.back().second += p.pc.segments[0].second; si = 1; }
-        }
-        out.segments.insert(out.segments.end(), p.pc.segments.begin() + static_cast<long>(si), p.pc.segments.end());
-        out.gaps.insert(out.gaps.end(), p.pc.gaps.begin() + static_cast<long>(gi), p.pc.gaps.end());
+        detail::appendPieceRuns(comps[p.rec], p.pc, p.a != 0, p.a != 0 && pieces[i - 1].lastIsGap, p.firstIsGap);
     }
     return comps;
 }
 
 // walkPath for every record, with one batched scan (result order = record order; seqPos = seqPosBase + index).
-inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::vector<RecordView> &records, size_t seqPosBase = 0) {
+inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::vector<RecordView> &records, size_t seqPosBase = 0,
+                                             const std::vector<PathComponents> *precomputed = nullptr) {
     const UserInputTeloscope &ui = teloscope.input();
-    const std::vector<PathComponents> comps = splitPaths(records);
+    // (the streaming reader finds the N-runs while the freshly joined bases are still in cache)
+    const std::vector<PathComponents> split = precomputed ? std::vector<PathComponents>() : splitPaths(records);
+    const std::vector<PathComponents> &comps = precomputed ? *precomputed : split;
     std::vector<Teloscope::Segment> batch;
     for (size_t pi = 0; pi < records.size(); ++pi)
         for (const auto &sg : comps[pi].segments)
             batch.emplace_back(records[pi].data + sg.first, static_cast<size_t>(sg.second), sg.first, ui.ultraFastMode);
     // without -m nothing downstream reads a match record: blocks and counts come from the device
     std::vector<ts_segment_counts> counts;
-    std::vector<SegmentData> scanned = ui.outMatches ? teloscope.scanSegments(batch)
+    // (with -m: only the two match vectors the writers read are materialised; block calling has happened on the device)
+    std::vector<SegmentData> scanned = ui.outMatches ? teloscope.scanSegments(batch, true)
                                                       : teloscope.scanSegmentsNoMatches(batch, counts);
 
     std::vector<PathData> paths(records.size());
@@ -1122,6 +1132,7 @@ struct RawRecord {                                              // a record of a
 struct FastaGroup {
     size_t firstRecord = 0;
     std::vector<RawRecord> records;
+    std::vector<PathComponents> comps;                          // of `records`, found while their bases were copied
     std::vector<FastaRecord> owned;                             // gzip / stdin input: records read the plain way
 };
 
@@ -1135,12 +1146,14 @@ class FastaGroupReader {
     size_t mapSize = 0;
     std::vector<Span> spans;
     size_t nextSpan = 0;
-    size_t groupBytes;
+    size_t groupBytes, pieceBytes;
     std::vector<FastaRecord> all;                               // not a mapped plain file: everything was read up front
     bool mapped = false;
 
 public:
-    explicit FastaGroupReader(const std::string &file, size_t groupBytes_ = size_t(256) << 20) : groupBytes(std::max<size_t>(groupBytes_, 1)) {
+    // pieceBytes: text bytes a host thread joins at a time (a record's lines are joined by pieces, in parallel)
+    explicit FastaGroupReader(const std::string &file, size_t groupBytes_ = size_t(256) << 20, size_t pieceBytes_ = size_t(4) << 20)
+        : groupBytes(std::max<size_t>(groupBytes_, 1)), pieceBytes(std::max<size_t>(pieceBytes_, 1)) {
         fd = ::open(file.c_str(), O_RDONLY);
         if (fd < 0) throw std::runtime_error("cannot open " + file);
         struct stat sb;
@@ -1211,9 +1224,9 @@ public:
         g.records.resize(nrec);
         // pieces of ~4 MB of text, cut at line starts; pass 1 counts every piece's bases, pass 2 copies them to
         // their place in the record's buffer
-        struct Piece { size_t rec; const char *a, *z; size_t bases, at; };
+        struct Piece { size_t rec; const char *a, *z; size_t bases, at; PathComponents pc; bool firstIsGap, lastIsGap; };
         std::vector<Piece> pieces;
-        constexpr size_t kPiece = size_t(4) << 20;
+        const size_t kPiece = pieceBytes;
         for (size_t r = 0; r < nrec; ++r) {
             const Span &sp = spans[first + r];
             const char *he = sp.body > sp.head && sp.body[-1] == '\n' ? sp.body - 1 : sp.body;
@@ -1224,7 +1237,7 @@ public:
                     const char *nl = static_cast<const char *>(std::memchr(z, '\n', static_cast<size_t>(sp.stop - z)));
                     z = nl ? nl + 1 : sp.stop;
                 }
-                pieces.push_back(Piece{r, a, z, 0, 0});
+                pieces.push_back(Piece{r, a, z, 0, 0, {}, false, false});
                 a = z;
             }
         }
@@ -1235,8 +1248,25 @@ public:
         }
         for (detail::RawRecord &rr : g.records) rr.data.reset(new char[rr.size + 1]);
         detail::onThreads(pieces.size(), [&](size_t i) {
-            (void)detail::copyFastaBases(pieces[i].a, pieces[i].z, g.records[pieces[i].rec].data.get() + pieces[i].at);
+            Piece &p = pieces[i];
+            char *dst = g.records[p.rec].data.get() + p.at;
+            (void)detail::copyFastaBases(p.a, p.z, dst);
+            if (!p.bases) return;
+            // N-runs of the piece, while its bases are still in this core's cache (in record coordinates)
+            p.pc = splitPath(dst, p.bases);
+            for (auto &sg : p.pc.segments) sg.first += p.at;
+            for (GapInfo &gp : p.pc.gaps) gp.start += p.at;
+            auto isGap = [](char c) { return c == 'N' || c == 'n' || c == 'X' || c == 'x'; };
+            p.firstIsGap = isGap(dst[0]);
+            p.lastIsGap = isGap(dst[p.bases - 1]);
         });
+        g.comps.resize(nrec);
+        std::vector<int> prevLast(nrec, -1);                      // -1: no bases of the record yet
+        for (const Piece &p : pieces) {
+            if (!p.bases) continue;
+            detail::appendPieceRuns(g.comps[p.rec], p.pc, prevLast[p.rec] >= 0, prevLast[p.rec] == 1, p.firstIsGap);
+            prevLast[p.rec] = p.lastIsGap ? 1 : 0;
+        }
         return true;
     }
 };
@@ -1278,7 +1308,7 @@ inline AssemblySummary scanFastaToFiles(Teloscope &teloscope, const std::string 
                 for (const detail::RawRecord &r : g.records) views.push_back(RecordView{&r.header, r.data.get(), r.size});
                 for (const FastaRecord &r : g.owned) views.push_back(RecordView{&r.header, r.sequence.data(), r.sequence.size()});
                 Scanned s;
-                s.paths = walkRecordViews(teloscope, views, g.firstRecord);
+                s.paths = walkRecordViews(teloscope, views, g.firstRecord, g.owned.empty() ? &g.comps : nullptr);
                 s.group = std::move(g);                           // (-m: matchSeq was copied out of the bases already)
                 T.scan_ms += ms(t0, Clock::now());
                 toWrite.push(std::move(s));

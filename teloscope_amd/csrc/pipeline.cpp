@@ -86,7 +86,7 @@ struct Group {
     size_t first = 0, count = 0;                  // items [first, first + count) of the call's item list
     ts_batch *b = nullptr;
     hipEvent_t uploaded = nullptr;
-    double t_plan = 0, t_upload = 0, t_scan = 0, t_down = 0;
+    double t_plan = 0, t_upload = 0, t_scan = 0, t_down = 0, t_fetch = 0, t_final = 0;
 };
 
 int ensure_streams(ts_ctx *c) {
@@ -364,6 +364,7 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
                 // device work + D2H of this group while the previous group's records are expanded on the host threads
                 ts_fetched *f = ts_batch_fetch(gr->b, mode == Mode::Matches, slot, &rc);
                 if (rc == TS_OK && mode == Mode::Blocks && counts) rc = batch_counts(gr->b, counts + gr->first, tips, ctx->down_stream);
+                gr->t_fetch = ms_between(t0, Clock::now());
                 if (post.joinable()) post.join();
                 if (rc == TS_OK) {
                     Group *g2 = gr;
@@ -372,7 +373,8 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
                         const auto p0 = Clock::now();
                         const int prc = ts_batch_finalize(g2->b, f, out + g2->first);
                         if (prc != TS_OK) set_err(prc);
-                        retire(g2, ms_between(p0, Clock::now()));
+                        g2->t_final = ms_between(p0, Clock::now());
+                        retire(g2, g2->t_final);
                     });
                     slot ^= 1;
                     gr->t_down += ms_between(t0, Clock::now());
@@ -389,12 +391,12 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
     scanner.join();
     downloader.join();
     if (timing) {
-        double p = 0, u = 0, s = 0, d = 0;
-        for (const Group &gr : groups) { p += gr.t_plan; u += gr.t_upload; s += gr.t_scan; d += gr.t_down; }
+        double p = 0, u = 0, s = 0, d = 0, f = 0, z = 0;
+        for (const Group &gr : groups) { p += gr.t_plan; u += gr.t_upload; s += gr.t_scan; d += gr.t_down; f += gr.t_fetch; z += gr.t_final; }
         const char *name = mode == Mode::Matches ? "ts_scan_segments" : mode == Mode::Blocks ? "ts_scan_segments_blocks" : "ts_filter_reads";
         fprintf(stderr, "%s: %zu items in %zu groups, wall %.1f ms; stage sums (concurrent): plan %.1f ms, stage+upload %.1f ms, "
-                        "scan (incl. waiting for the upload) %.1f ms, download + host post-processing %.1f ms\n",
-                name, items.size(), groups.size(), ms_between(t_begin, Clock::now()), p, u, s, d);
+                        "scan (incl. waiting for the upload) %.1f ms, download + host post-processing %.1f ms (device work + D2H %.1f ms, host expansion %.1f ms)\n",
+                name, items.size(), groups.size(), ms_between(t_begin, Clock::now()), p, u, s, d, f, z);
     }
     return first_err.load();
 }

@@ -77,13 +77,19 @@ int main(int argc, char **argv) {
         // give the same records in the same order, from the mapped file and from the gzip stream
         for (const std::string &file : {plain, packed})
             for (size_t groupBytes : {size_t(1), size_t(700), size_t(1) << 20}) {
-                FastaGroupReader rd(file, groupBytes);
+                FastaGroupReader rd(file, groupBytes, groupBytes == 700 ? size_t(37) : size_t(4) << 20);     // (tiny pieces: every record is stitched)
                 detail::FastaGroup g;
                 size_t at = 0;
                 while (rd.next(g)) {
                     check(g.firstRecord == at, "group order");
-                    for (const detail::RawRecord &r : g.records) {
+                    check(g.comps.size() == g.records.size(), "components per record");
+                    for (size_t ri = 0; ri < g.records.size(); ++ri) {
+                        const detail::RawRecord &r = g.records[ri];
                         check(at < a.size() && r.header == a[at].header && std::string(r.data.get(), r.size) == a[at].sequence, "streamed record");
+                        const PathComponents want = splitPath(a[at].sequence);
+                        check(ri < g.comps.size() && g.comps[ri].segments == want.segments && g.comps[ri].gaps.size() == want.gaps.size(), "streamed components");
+                        for (size_t q = 0; ri < g.comps.size() && q < want.gaps.size() && q < g.comps[ri].gaps.size(); ++q)
+                            check(g.comps[ri].gaps[q].start == want.gaps[q].start && g.comps[ri].gaps[q].length == want.gaps[q].length, "streamed gap");
                         ++at;
                     }
                     for (const FastaRecord &r : g.owned) {
