@@ -101,35 +101,24 @@ int ensure_streams(ts_ctx *c) {
     return TS_OK;
 }
 
-// Uploads the bases a batch reads (whole segments of a full scan; only the two terminal regions of a long
-// segment in tips-only mode — the rest of the layout is never read).  Dense layouts (full scans, reads) are
-// mirrored chunk by chunk in a ring of pinned buffers, each chunk leaving by ONE DMA while the next is being
-// filled by several memcpy threads (one memcpy stream fills pinned memory at ~10 GB/s, a fraction of what the
-// link moves; one copy per read would cost ~10 us each, one pageable 3 GB copy ~0.5 s).  Sparse layouts
-// (tips-only regions of long contigs) go piece by piece.  Bytes between pieces are never read as bases (the
-// kernel masks everything past a region's end).  Asynchronous: the DMAs are queued on up_stream.
-int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
-    ts_ctx *c = b->ctx;
-    void *din = ts_batch_input_ptr_nozero(b);
-    if (!din) return c->fail(TS_ERR_ALLOC, "cannot allocate device input buffer");
-    struct Piece { uint64_t off; const char *src; uint64_t len; };              // off: byte offset in the input layout
-    std::vector<Piece> pieces;
+struct UpPiece { uint64_t off; const char *src; uint64_t len; };            // off: byte offset in the input layout
+
+// Uploads pieces of an input layout to the device buffer that holds its bytes [lo, hi) (din = address of byte lo).
+// Dense layouts (full scans, reads) are mirrored chunk by chunk in a ring of pinned buffers, each chunk leaving by
+// ONE DMA while the next is being filled by several memcpy threads (one memcpy stream fills pinned memory at
+// ~10 GB/s, a fraction of what the link moves; one copy per read would cost ~10 us each, one pageable 3 GB copy
+// ~0.5 s).  Sparse layouts (tips-only regions of long contigs) go piece by piece.  Bytes between pieces are never
+// read as bases (the kernels mask everything past a region's end).  Asynchronous: the DMAs are queued on up_stream.
+// `pieces` ascend by offset and do not overlap.
+int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces, void *din, uint64_t lo_all, uint64_t hi_all, int &slot, bool used[]) {
     uint64_t piece_bytes = 0;
-    for (size_t i = 0; i < b->segs.size(); ++i) {
-        const SegPlan &sp = b->segs[i];
-        for (const Region &rg : sp.regions) {
-            // (consecutive regions of one segment never overlap: tips regions are [0,t) and [N-t,N) with N > 2t)
-            const uint64_t s0 = std::max<uint64_t>(sp.in_off + rg.start, b->in_lo);
-            const uint64_t s1 = std::min<uint64_t>(sp.in_off + rg.start + rg.len, b->in_hi);
-            if (s1 > s0) { pieces.push_back({s0, items[i].seq + (s0 - sp.in_off), s1 - s0}); piece_bytes += s1 - s0; }
-        }
-    }
+    for (const UpPiece &pc : pieces) piece_bytes += pc.len;
     constexpr size_t kChunk = 32u << 20;
-    const uint64_t span = b->in_hi - b->in_lo;
+    const uint64_t span = hi_all - lo_all;
     const bool dense = piece_bytes * 2 >= span || pieces.size() > 4096;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned nthr = std::min(8u, std::max(1u, hw / 2u));
-    auto stage = [&](std::vector<std::pair<char *, Piece>> &work, size_t bytes) {   // work: (pinned destination, piece part)
+    auto stage = [&](std::vector<std::pair<char *, UpPiece>> &work, size_t bytes) {   // work: (pinned destination, piece part)
         const unsigned nt = bytes >= (4u << 20) ? nthr : 1u;
         if (nt == 1u) {
             for (auto &w : work) std::memcpy(w.first, w.second.src, w.second.len);
@@ -152,11 +141,11 @@ int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
             });
         for (std::thread &th : pool) th.join();
     };
-    std::vector<std::pair<char *, Piece>> work;
+    std::vector<std::pair<char *, UpPiece>> work;
     if (dense) {
         size_t pi = 0;                // first piece that may still have bytes at or beyond the chunk start
-        for (uint64_t c0 = b->in_lo; c0 < b->in_hi; c0 += kChunk) {
-            const uint64_t c1 = std::min<uint64_t>(c0 + kChunk, b->in_hi);
+        for (uint64_t c0 = lo_all; c0 < hi_all; c0 += kChunk) {
+            const uint64_t c1 = std::min<uint64_t>(c0 + kChunk, hi_all);
             while (pi < pieces.size() && pieces[pi].off + pieces[pi].len <= c0) ++pi;
             if (pi == pieces.size()) break;
             if (pieces[pi].off >= c1) continue;
@@ -168,26 +157,26 @@ int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
             for (size_t i = pi; i < pieces.size() && pieces[i].off < c1; ++i) {
                 const uint64_t s0 = std::max(pieces[i].off, c0), s1 = std::min(pieces[i].off + pieces[i].len, c1);
                 if (s1 <= s0) continue;
-                work.push_back({dst + (s0 - c0), Piece{s0, pieces[i].src + (s0 - pieces[i].off), s1 - s0}});
+                work.push_back({dst + (s0 - c0), UpPiece{s0, pieces[i].src + (s0 - pieces[i].off), s1 - s0}});
                 bytes += s1 - s0;
                 lo = std::min(lo, s0); hi = std::max(hi, s1);
             }
             stage(work, bytes);
-            HIP_TRY(c, hipMemcpyAsync((char *)din + (lo - b->in_lo), dst + (lo - c0), hi - lo, hipMemcpyHostToDevice, c->up_stream));
+            HIP_TRY(c, hipMemcpyAsync((char *)din + (lo - lo_all), dst + (lo - c0), hi - lo, hipMemcpyHostToDevice, c->up_stream));
             HIP_TRY(c, hipEventRecord(c->pin_up_ev[slot], c->up_stream));
             used[slot] = true;
             slot = (slot + 1) % ts_ctx::kUpSlots;
         }
     } else {
-        for (const Piece &pc : pieces) {
+        for (const UpPiece &pc : pieces) {
             for (uint64_t a = 0; a < pc.len; a += kChunk) {
                 const uint64_t n = std::min<uint64_t>(kChunk, pc.len - a);
                 if (used[slot]) HIP_TRY(c, hipEventSynchronize(c->pin_up_ev[slot]));
                 char *dst = (char *)c->pin_up[slot].p;
                 work.clear();
-                work.push_back({dst, Piece{pc.off + a, pc.src + a, n}});
+                work.push_back({dst, UpPiece{pc.off + a, pc.src + a, n}});
                 stage(work, n);
-                HIP_TRY(c, hipMemcpyAsync((char *)din + (pc.off + a - b->in_lo), dst, n, hipMemcpyHostToDevice, c->up_stream));
+                HIP_TRY(c, hipMemcpyAsync((char *)din + (pc.off + a - lo_all), dst, n, hipMemcpyHostToDevice, c->up_stream));
                 HIP_TRY(c, hipEventRecord(c->pin_up_ev[slot], c->up_stream));
                 used[slot] = true;
                 slot = (slot + 1) % ts_ctx::kUpSlots;
@@ -195,6 +184,25 @@ int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
         }
     }
     return TS_OK;
+}
+
+// Uploads the bases a batch reads: whole segments of a full scan; only the two terminal regions of a long segment
+// in tips-only mode — the rest of the layout is never read.
+int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
+    ts_ctx *c = b->ctx;
+    void *din = ts_batch_input_ptr_nozero(b);
+    if (!din) return c->fail(TS_ERR_ALLOC, "cannot allocate device input buffer");
+    std::vector<UpPiece> pieces;
+    for (size_t i = 0; i < b->segs.size(); ++i) {
+        const SegPlan &sp = b->segs[i];
+        for (const Region &rg : sp.regions) {
+            // (consecutive regions of one segment never overlap: tips regions are [0,t) and [N-t,N) with N > 2t)
+            const uint64_t s0 = std::max<uint64_t>(sp.in_off + rg.start, b->in_lo);
+            const uint64_t s1 = std::min<uint64_t>(sp.in_off + rg.start + rg.len, b->in_hi);
+            if (s1 > s0) pieces.push_back({s0, items[i].seq + (s0 - sp.in_off), s1 - s0});
+        }
+    }
+    return upload_pieces(c, pieces, din, b->in_lo, b->in_hi, slot, used);
 }
 
 // The terminal-block predicate of a scanned tips batch on the device: one byte per read
@@ -402,10 +410,11 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
 }
 
 // =========================================================================== general path
-// For parameter sets outside the tiled kernel's closed form (mixed-length pattern sets, pattern
-// lengths > 9, or a longest pattern exceeding min(step, window-step) where the reference's
-// uint32 start index wraps): ts_generic_match + ts_generic_windows (generic.hip) on the device,
-// then only ordering work on the host.  One segment at a time; this is the slow exact path.
+// Parameter sets outside the tiled kernel's closed form (mixed-length pattern sets, pattern lengths above 8, or a
+// longest pattern exceeding min(step, window-step) where the reference's uint32 start index wraps): the general
+// kernels of generic.hip over groups of ~256 MB of regions at a time — match masks, the records the reference pushes
+// and the window records all come off the device; the host orders the records by the window that pushes them (only
+// mixed-length sets can be out of position order at all), expands them and calls blocks (ts_finalize_segment).
 int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<size_t> &which,
                        bool tips, ts_segment_out *out) {
     if (which.empty()) return TS_OK;
@@ -413,93 +422,188 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         return c->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: more than 8 pattern lengths, a pattern longer "
                                            "than 32 or a non-ACGT pattern");
     DEVICE_TRY(c);
-    std::lock_guard<std::mutex> lk(c->mtx);
+    { int rc = ensure_streams(c); if (rc != TS_OK) return rc; }
     const ts_params &P = c->params;
     const uint32_t s = P.step, w = P.window_size, ov = w - s, L = c->longest;
-    DevBuf d_seq, d_mask, d_win;                 // (freed by their destructors on every path)
-    std::vector<uint32_t> mask, wins;
-    std::vector<ts_match> matches;
-    struct Hit { uint64_t k, p; uint16_t len; uint8_t flags; };
-    std::vector<Hit> hits;
-    int rc = TS_OK;
-    for (size_t wi = 0; wi < which.size() && rc == TS_OK; ++wi) {
-        const ts_segment_in &sg = segs[which[wi]];
-        const uint64_t N = sg.len;
-        matches.clear();
-        uint64_t nwin = 0;
-        // regions exactly as scanSegment picks them (src/teloscope.cpp:576-583; uint32 product)
-        std::vector<std::pair<uint64_t, uint64_t>> regions;
-        if (tips) {
-            const uint32_t twice = 2u * P.terminal_limit;
-            if (N > twice) { regions.emplace_back(0, P.terminal_limit); regions.emplace_back(N - P.terminal_limit, P.terminal_limit); }
-            else if (N) regions.emplace_back(0, N);
-        } else if (N) {
-            regions.emplace_back(0, N);
-            nwin = ceil_div(N, s);
-        }
-        for (const auto &rg : regions) {
-            const uint64_t r0 = rg.first, n = rg.second;
-            if (d_seq.ensure(n + 16) != hipSuccess || d_mask.ensure(n * 4 + 16) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "device allocation failed"); break; }
-            if (hipMemcpy(d_seq.p, sg.seq + r0, n, hipMemcpyHostToDevice) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "H2D copy failed"); break; }
-            if (ts_k_launch_generic_match((const unsigned char *)d_seq.p, n, &c->gpat, P.fold_case, (uint32_t *)d_mask.p, nullptr) != 0) { rc = c->fail(TS_ERR_HIP, "generic match kernel launch failed"); break; }
-            if (!tips) {
-                TsGenericGeom Q{};
-                Q.n = N; Q.s = s; Q.w = w; Q.longest = L; Q.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u; Q.fold = P.fold_case;
-                if (d_win.ensure(nwin * 32 + 16) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "device allocation failed"); break; }
-                if (ts_k_launch_generic_windows((const unsigned char *)d_seq.p, (const uint32_t *)d_mask.p, &c->gpat, &Q, nwin, (uint32_t *)d_win.p, nullptr) != 0) { rc = c->fail(TS_ERR_HIP, "generic window kernel launch failed"); break; }
-                wins.resize(nwin * 8);
-                if (hipMemcpy(wins.data(), d_win.p, nwin * 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "D2H copy failed"); break; }
-            }
-            mask.resize(n);
-            if (hipMemcpy(mask.data(), d_mask.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = c->fail(TS_ERR_HIP, "D2H copy failed"); break; }
+    hipStream_t st = c->scan_stream;
+    TsGenericGeom Q{};
+    Q.s = s; Q.w = w; Q.longest = L; Q.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u; Q.fold = P.fold_case;
+    const bool timing = getenv("TS_TIMING") != nullptr;
+    const auto t_begin = Clock::now();
+    double t_up = 0, t_dev = 0, t_host = 0;
 
-            // enumerate matches in (position, length) order; in full-scan mode keep those some
-            // window's own scan pushes (src/teloscope.cpp:485) and order them by that window
-            hits.clear();
-            const uint32_t t1 = s - L, t2 = ov - L;                     // uint32 wrap, src/teloscope.cpp:413-415
-            const uint32_t start_index = t1 < t2 ? t1 : t2;
-            for (uint64_t p = 0; p < n; ++p) {
-                const uint32_t m = mask[p];
-                if (!m) continue;
-                for (uint32_t li = 0; li < c->gpat.nlen; ++li) {
-                    const uint32_t b = (m >> (3 * li)) & 7u;
-                    if (!(b & 1u)) continue;
-                    const uint32_t len = c->gpat.len[li];
-                    const uint8_t fl = (uint8_t)(((b & 2u) ? TS_MATCH_FORWARD : 0u) | ((b & 4u) ? TS_MATCH_CANONICAL : 0u));
-                    uint64_t k = 0;
-                    if (!tips) {
-                        const uint64_t e = p + len - 1;
-                        if (ov == 0) {
-                            k = p / s;
-                            const uint64_t cws = std::min<uint64_t>(w, N - k * s);
-                            if ((p - k * s) + len > cws) continue;      // crosses its only window's end
-                        } else if (e < std::min<uint64_t>(w, N)) {
-                            k = 0;                                      // window 0 scans everything it holds
-                        } else {
-                            k = (e - ov) / s;                           // the one window with j >= overlap
-                            if (p < k * s || (p - k * s) < start_index) continue;
+    struct RegionL { uint64_t seg_start, len, layout_off; };                   // a scanned region and where it lies in the layout
+    struct SegL { size_t idx; uint64_t len, abs_pos, layout_off; std::vector<RegionL> regions; uint64_t first_tile = 0, n_tiles = 0, win_base = 0, n_windows = 0; };
+    const uint64_t target = group_target_bytes();
+    int slot = 0;
+    bool used[ts_ctx::kUpSlots] = {false, false, false};
+    size_t wi = 0;
+    while (wi < which.size()) {
+        // ---- a group of consecutive segments, ~256 MB of regions; layout = the regions back to back, 16-byte aligned
+        std::vector<SegL> G;
+        std::vector<TsGeneralTile> tiles;
+        std::vector<UpPiece> pieces;
+        uint64_t off = 0, nwin_total = 0;
+        while (wi < which.size() && (G.empty() || off < target)) {
+            const ts_segment_in &sg = segs[which[wi]];
+            SegL sl{which[wi], sg.len, sg.abs_pos, off, {}};
+            // regions exactly as scanSegment picks them (src/teloscope.cpp:576-583; uint32 product)
+            if (tips) {
+                const uint32_t twice = 2u * P.terminal_limit;
+                if (sg.len > twice) { sl.regions.push_back({0, P.terminal_limit, 0}); sl.regions.push_back({sg.len - P.terminal_limit, P.terminal_limit, 0}); }
+                else if (sg.len) sl.regions.push_back({0, sg.len, 0});
+            } else if (sg.len) {
+                sl.regions.push_back({0, sg.len, 0});
+                sl.n_windows = ceil_div(sg.len, s);
+            }
+            sl.first_tile = tiles.size();
+            for (RegionL &rg : sl.regions) {
+                rg.layout_off = off;
+                pieces.push_back({off, sg.seq + rg.seg_start, rg.len});
+                for (uint64_t a = 0; a < rg.len; a += TS_GENERAL_TILE) {
+                    TsGeneralTile T{};
+                    T.in_off = off + a;
+                    T.seg_rel = rg.seg_start + a;
+                    T.n = (uint32_t)std::min<uint64_t>(TS_GENERAL_TILE, rg.len - a);
+                    T.avail = (uint32_t)std::min<uint64_t>(rg.len - a, (uint64_t)T.n + 32u);
+                    T.seg = (uint32_t)G.size();
+                    tiles.push_back(T);
+                }
+                off += (rg.len + 15) & ~15ull;
+            }
+            sl.n_tiles = tiles.size() - sl.first_tile;
+            sl.win_base = nwin_total;
+            nwin_total += sl.n_windows;
+            G.push_back(std::move(sl));
+            ++wi;
+        }
+        const uint64_t span = off + 64;
+        const size_t ns = G.size(), nt = tiles.size();
+        if (nt >= 0x7FFFFFFFull) return c->fail(TS_ERR_UNSUPPORTED, "too many tiles in one group");
+        // ---- device buffers from the pool
+        DevBuf d_in, d_mask, d_tiles, d_tab, d_stats, d_off, d_tmp, d_rec, d_win;
+        struct Return { ts_ctx *c; std::vector<DevBuf *> v; ~Return() { for (DevBuf *d : v) c->pool.give(std::move(*d)); } }
+            give_back{c, {&d_in, &d_mask, &d_tiles, &d_tab, &d_stats, &d_off, &d_tmp, &d_rec, &d_win}};
+        const size_t tab_len = 0, tab_in = ns * 8, tab_win = 2 * ns * 8, tab_bytes = 3 * ns * 8 + 8 + 16;
+        HIP_TRY(c, c->pool.take(span, d_in));
+        HIP_TRY(c, c->pool.take(span * 4, d_mask));
+        HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * sizeof(TsGeneralTile), d_tiles));
+        HIP_TRY(c, c->pool.take(tab_bytes, d_tab));
+        HIP_TRY(c, c->pool.take((nt + 1) * 16, d_stats));
+        HIP_TRY(c, c->pool.take((nt + 1) * 8, d_off));
+        HIP_TRY(c, c->pool.take((size_t)ts_k_scan_tmp_bytes((uint32_t)nt), d_tmp));
+        if (nwin_total) HIP_TRY(c, c->pool.take(nwin_total * 32, d_win));
+        std::vector<unsigned long long> tab(3 * ns + 1);
+        for (size_t i = 0; i < ns; ++i) { tab[i] = G[i].len; tab[ns + i] = G[i].layout_off; tab[2 * ns + i] = G[i].win_base; }
+        tab[3 * ns] = nwin_total;
+        const auto t0 = Clock::now();
+        { int rc = upload_pieces(c, pieces, d_in.p, 0, off, slot, used); if (rc != TS_OK) return rc; }
+        HIP_TRY(c, hipMemcpyAsync(d_tiles.p, tiles.data(), nt * sizeof(TsGeneralTile), hipMemcpyHostToDevice, c->up_stream));
+        HIP_TRY(c, hipMemcpyAsync(d_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->up_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->up_stream));
+        const auto t1 = Clock::now();
+        // ---- kernels
+        char *const dt = (char *)d_tab.p;
+        std::vector<uint32_t> wins, recs;
+        std::vector<unsigned long long> tile_off(nt + 1, 0);
+        {
+            std::lock_guard<std::mutex> lk(c->mtx);
+            if (ts_k_launch_general_match((const unsigned char *)d_in.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt, &c->gpat,
+                                          P.fold_case, (uint32_t *)d_mask.p, st) != 0) return c->fail(TS_ERR_HIP, "general match kernel launch failed");
+            if (ts_k_launch_general_records((const uint32_t *)d_mask.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt,
+                                            (const unsigned long long *)(dt + tab_len), &c->gpat, &Q, tips ? 1 : 0, (uint32_t *)d_stats.p,
+                                            nullptr, nullptr, 0, st) != 0) return c->fail(TS_ERR_HIP, "general count kernel launch failed");
+            if (ts_k_launch_tile_offsets((const uint32_t *)d_stats.p, (uint32_t)nt, (unsigned long long *)d_off.p, d_tmp.p, st) != 0)
+                return c->fail(TS_ERR_HIP, "tile-offset kernel launch failed");
+        }
+        if (nt) HIP_TRY(c, hipMemcpyAsync(tile_off.data(), d_off.p, (nt + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        const uint64_t nrec = tile_off[nt];
+        HIP_TRY(c, c->pool.take(std::max<uint64_t>(nrec, 1) * 4, d_rec));
+        {
+            std::lock_guard<std::mutex> lk(c->mtx);
+            if (ts_k_launch_general_records((const uint32_t *)d_mask.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt,
+                                            (const unsigned long long *)(dt + tab_len), &c->gpat, &Q, tips ? 1 : 0, (uint32_t *)d_stats.p,
+                                            (const unsigned long long *)d_off.p, (uint32_t *)d_rec.p, 1, st) != 0)
+                return c->fail(TS_ERR_HIP, "general emit kernel launch failed");
+            if (!tips && ts_k_launch_general_windows((const unsigned char *)d_in.p, (const uint32_t *)d_mask.p, &c->gpat, &Q,
+                                                     (const unsigned long long *)(dt + tab_win), (const unsigned long long *)(dt + tab_in),
+                                                     (const unsigned long long *)(dt + tab_len), (uint32_t)ns, nwin_total, (uint32_t *)d_win.p, st) != 0)
+                return c->fail(TS_ERR_HIP, "general window kernel launch failed");
+        }
+        recs.resize(nrec + 1);
+        wins.resize(nwin_total * 8 + 1);
+        if (nrec) HIP_TRY(c, hipMemcpyAsync(recs.data(), d_rec.p, nrec * 4, hipMemcpyDeviceToHost, st));
+        if (nwin_total) HIP_TRY(c, hipMemcpyAsync(wins.data(), d_win.p, nwin_total * 32, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        const auto t2 = Clock::now();
+        // ---- host: records -> MatchInfo in the reference's push order, then block calling; one job per segment
+        std::atomic<size_t> next{0};
+        std::atomic<int> first_err{TS_OK};
+        const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned spare = std::max(1u, std::min(16u, hw_threads) / (unsigned)std::max<size_t>(1, std::min<size_t>(ns, 16)));
+        const uint32_t t1w = s - L, t2w = ov - L;                                // uint32 wrap, src/teloscope.cpp:413-415
+        (void)t1w; (void)t2w;
+        auto worker = [&]() {
+            for (size_t gi; (gi = next.fetch_add(1)) < ns && first_err.load() == TS_OK;) {
+                const SegL &sl = G[gi];
+                const uint64_t r0 = tile_off[sl.first_tile], r1 = tile_off[sl.first_tile + sl.n_tiles], nm = r1 - r0;
+                ts_match *arr = nm ? (ts_match *)std::malloc(nm * sizeof(ts_match)) : nullptr;
+                if (nm && !arr) { int e = TS_OK; first_err.compare_exchange_strong(e, c->fail(TS_ERR_ALLOC, "out of host memory")); return; }
+                std::vector<uint64_t> key;                                        // the window that pushes the match
+                if (!tips) key.resize(nm);
+                uint64_t at = 0;
+                bool sorted = true;
+                for (uint64_t t = 0; t < sl.n_tiles; ++t) {
+                    const TsGeneralTile &T = tiles[sl.first_tile + t];
+                    for (uint64_t ri = tile_off[sl.first_tile + t]; ri < tile_off[sl.first_tile + t + 1]; ++ri, ++at) {
+                        const uint32_t rec = recs[ri];
+                        const uint64_t p = T.seg_rel + (rec >> 5);
+                        const uint32_t len = c->gpat.len[(rec >> 2) & 7u];
+                        ts_match &m = arr[at];
+                        std::memset(&m, 0, sizeof m);
+                        m.position = sl.abs_pos + p;
+                        m.match_size = (uint16_t)len;
+                        m.flags = (uint8_t)(((rec & 2u) ? TS_MATCH_FORWARD : 0u) | ((rec & 1u) ? TS_MATCH_CANONICAL : 0u));
+                        if (!tips) {
+                            const uint64_t e = p + len - 1;
+                            const uint64_t k = ov == 0 ? p / s : (e < std::min<uint64_t>(w, sl.len) ? 0 : (e - ov) / s);
+                            key[at] = k;
+                            if (at && k < key[at - 1]) sorted = false;
                         }
                     }
-                    hits.push_back(Hit{k, r0 + p, (uint16_t)len, fl});
                 }
+                if (!tips && !sorted) {
+                    // mixed-length sets: a long match near a window start is pushed by the NEXT window, after shorter
+                    // matches that begin behind it — order by pushing window, position order within it
+                    std::vector<uint32_t> idx(nm);
+                    for (uint64_t i = 0; i < nm; ++i) idx[i] = (uint32_t)i;
+                    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b2) { return key[a] < key[b2]; });
+                    ts_match *sorted_arr = (ts_match *)std::malloc(nm * sizeof(ts_match));
+                    if (!sorted_arr) { std::free(arr); int e = TS_OK; first_err.compare_exchange_strong(e, c->fail(TS_ERR_ALLOC, "out of host memory")); return; }
+                    for (uint64_t i = 0; i < nm; ++i) sorted_arr[i] = arr[idx[i]];
+                    std::free(arr);
+                    arr = sorted_arr;
+                }
+                const int rc = ts_finalize_segment(c, tips, sl.len, sl.abs_pos, sl.n_windows ? &wins[sl.win_base * 8] : nullptr,
+                                                   tips ? 0 : sl.n_windows, arr, nm, out[sl.idx], spare);
+                if (rc != TS_OK) { int e = TS_OK; first_err.compare_exchange_strong(e, rc); return; }
             }
-            if (!tips)
-                std::stable_sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.k < b.k; });
-            for (const Hit &h : hits) {
-                ts_match m{};
-                m.position = sg.abs_pos + h.p;
-                m.match_size = h.len;
-                m.flags = h.flags;
-                matches.push_back(m);
-            }
+        };
+        const unsigned nthreads = (unsigned)std::min<size_t>({(size_t)16, ns, (size_t)hw_threads});
+        if (nthreads <= 1) worker();
+        else {
+            std::vector<std::thread> pool;
+            for (unsigned i = 0; i < nthreads; ++i) pool.emplace_back(worker);
+            for (std::thread &th : pool) th.join();
         }
-        if (rc != TS_OK) break;
-        ts_match *arr = matches.empty() ? nullptr : (ts_match *)std::malloc(matches.size() * sizeof(ts_match));
-        if (!matches.empty() && !arr) { rc = c->fail(TS_ERR_ALLOC, "out of host memory"); break; }
-        if (arr) std::memcpy(arr, matches.data(), matches.size() * sizeof(ts_match));
-        rc = ts_finalize_segment(c, tips, N, sg.abs_pos, wins.data(), nwin, arr, matches.size(), out[which[wi]], 16u);   // (general path: one segment at a time)
+        if (first_err.load() != TS_OK) return first_err.load();
+        t_up += ms_between(t0, t1); t_dev += ms_between(t1, t2); t_host += ms_between(t2, Clock::now());
     }
-    return rc;
+    if (timing)
+        fprintf(stderr, "general path: %zu segments, wall %.1f ms: upload %.1f ms, kernels + D2H %.1f ms, host ordering + block calling %.1f ms\n",
+                which.size(), ms_between(t_begin, Clock::now()), t_up, t_dev, t_host);
+    return TS_OK;
 }
 
 std::vector<Item> items_of(const ts_segment_in *segs, const std::vector<size_t> &which) {

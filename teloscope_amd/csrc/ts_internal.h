@@ -106,9 +106,18 @@ struct TsGenericPatterns {
 };
 
 struct TsGenericGeom {
-    unsigned long long n;               // segment length
     uint32_t s, w, longest;
     uint32_t nuc_on, fold;
+};
+
+#define TS_GENERAL_TILE 4096            // positions per tile of the general kernels (generic.hip)
+struct TsGeneralTile {                  // 32 bytes
+    unsigned long long in_off;          // byte offset (input layout) of the tile's first base; the match mask is indexed alike
+    unsigned long long seg_rel;         // segment-relative position of that base
+    uint32_t n;                         // positions of the tile (<= TS_GENERAL_TILE)
+    uint32_t avail;                     // bases from the tile's first base to the end of its region (clamped to n + 32)
+    uint32_t seg;                       // segment index within the group
+    uint32_t pad;
 };
 
 struct TsLaunchInfo {
@@ -124,10 +133,16 @@ int  ts_k_prepare(uint32_t lds_bytes);                       // raises the dynam
 int  ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, void *stream);
 int  ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_tile,
                          const uint64_t *seg_nwin, uint32_t nseg, unsigned long long *out, void *stream);
-int  ts_k_launch_generic_match(const unsigned char *seq, unsigned long long n, const TsGenericPatterns *G,
-                               uint32_t fold, uint32_t *mask, void *stream);
-int  ts_k_launch_generic_windows(const unsigned char *seq, const uint32_t *mask, const TsGenericPatterns *G,
-                                 const TsGenericGeom *Q, unsigned long long nwin, uint32_t *out, void *stream);
+int  ts_k_launch_general_match(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
+                               const TsGenericPatterns *G, uint32_t fold, uint32_t *mask, void *stream);
+int  ts_k_launch_general_records(const uint32_t *mask, const TsGeneralTile *tiles, uint32_t ntiles,
+                                 const unsigned long long *seg_len, const TsGenericPatterns *G, const TsGenericGeom *Q,
+                                 int tips, uint32_t *tile_stats, const unsigned long long *tile_off, uint32_t *records,
+                                 int emit, void *stream);
+int  ts_k_launch_general_windows(const unsigned char *in, const uint32_t *mask, const TsGenericPatterns *G,
+                                 const TsGenericGeom *Q, const unsigned long long *seg_win_base,
+                                 const unsigned long long *seg_in_off, const unsigned long long *seg_len, uint32_t nseg,
+                                 unsigned long long nwin, uint32_t *out, void *stream);
 int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,
                            const uint32_t *matches, const uint32_t *seg_first_tile,
                            const unsigned long long *seg_in_off, const unsigned long long *seg_len,
