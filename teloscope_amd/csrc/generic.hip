@@ -114,7 +114,7 @@ __device__ __forceinline__ bool full_scan_pushes(u64 p, uint32_t l, u64 n, const
 
 // EMIT == false: counts the records of every tile into tile_stats[4 t] (the layout ts_k_launch_tile_offsets
 // reads); EMIT == true: writes them, in position then length order, from tile_off[t].
-// Record: (tile-relative position << 5) | (length index << 2) | forward << 1 | canonical.
+// Record: (tile-relative position << 5) | (length index << 2) | canonical << 1 | forward.
 template <bool EMIT>
 __global__ __launch_bounds__(256)
 void ts_general_records(const uint32_t *mask, const TsGeneralTile *tiles, uint32_t ntiles, const u64 *seg_len,

@@ -564,7 +564,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                         std::memset(&m, 0, sizeof m);
                         m.position = sl.abs_pos + p;
                         m.match_size = (uint16_t)len;
-                        m.flags = (uint8_t)(((rec & 2u) ? TS_MATCH_FORWARD : 0u) | ((rec & 1u) ? TS_MATCH_CANONICAL : 0u));
+                        m.flags = (uint8_t)(((rec & 1u) ? TS_MATCH_FORWARD : 0u) | ((rec & 2u) ? TS_MATCH_CANONICAL : 0u));   // (general records: forward is bit 0)
                         if (!tips) {
                             const uint64_t e = p + len - 1;
                             const uint64_t k = ov == 0 ? p / s : (e < std::min<uint64_t>(w, sl.len) ? 0 : (e - ov) / s);
