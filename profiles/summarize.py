@@ -18,7 +18,7 @@ for f in find("*kernel_stats.csv"):
     with open(f) as fh:
         for i, row in enumerate(csv.reader(fh)):
             if i < 8:
-                print("  ", ",".join(row))
+                print("  ", ",".join(row)[:200])
 for f in find("*kernel_trace.csv"):
     durs = {}
     with open(f) as fh:
@@ -44,3 +44,36 @@ for f in find("*counter_collection.csv"):
     print("== counters (ts_scan_tiles, per dispatch avg):", os.path.relpath(f, root))
     for k, v in sorted(acc.items()):
         print("   %-28s n=%d avg=%.6g" % (k, len(v), sum(v) / len(v)))
+
+# HBM bytes per launch of ts_scan_tiles for bench.py's roofline.traffic: FETCH_SIZE and WRITE_SIZE (KB, separate --pmc
+# passes; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream -> x2, WRITE_SIZE is exact for 16-byte
+# streaming stores: /opt/skills/guides/MI355X_MICROARCH.md, HBM section), stamped with the hash of the kernel source
+# they were measured for — bench.py reports them only while that hash still matches.
+import hashlib
+import json
+
+fetch = write = None
+for f in find("*counter_collection.csv"):
+    acc = {}
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if "ts_scan_tiles" in row.get("Kernel_Name", ""):
+                acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    if "FETCH_SIZE" in acc:
+        v = acc["FETCH_SIZE"][5:] or acc["FETCH_SIZE"]
+        fetch = sum(v) / len(v)
+    if "WRITE_SIZE" in acc:
+        v = acc["WRITE_SIZE"][5:] or acc["WRITE_SIZE"]
+        write = sum(v) / len(v)
+if fetch is not None and write is not None:
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(repo, "teloscope_amd", "csrc", "kernels.hip")
+    out = {"kernel": "ts_scan_tiles", "workload": "configs[1] 3.0 Gb / 200 contigs, bench.py defaults (timed launches)",
+           "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+           "correction": "gfx950: FETCH_SIZE reports half of a wide coalesced read stream -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
+           "hbm_bytes_per_launch": int(round((2 * fetch + write) * 1024)),
+           "kernels_hip_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(),
+           "source": "separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python3 bench.py --no-cpu-baseline --no-e2e` (profiles/run_profile.sh)"}
+    with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("== pmc_traffic.json:", json.dumps(out))
