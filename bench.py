@@ -536,6 +536,8 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         own = plan.ranges[0]
         gather_bytes_rx = gather_bytes - (32 * (own.window_end - own.window_begin) + 16 * (own.tile_end - own.tile_begin)
                                           + 4 * (a.counts[0] if rank == 0 else 0)) if rank == 0 else 0
+        if plan.wire16_ok:
+            gather_bytes_rx //= 2                               # every value travels as u16 and is widened on rank 0
         extra_cfg = {"timed_region": "resident ASCII in HBM on %d ranks (consecutive tile ranges of ONE plan) -> scan + tile-ordered "
                                      "export + ONE exchange (all-gather of record counts, grouped send/recv of window records, tile "
                                      "directory, match records) -> the whole assembly's results in rank 0's HBM; exchange of step i "
@@ -543,7 +545,9 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                      "backend": backend + ("" if backend == "nccl" else " (rehearsal: ranks share a GPU, tensors staged through the host)"),
                      "bases_per_rank": [int(x.bases) for x in plan.ranges],
                      "records_per_rank": a.counts if rank == 0 else None,
-                     "gather_bytes_per_step": {"assembled_on_rank0": gather_bytes, "received_over_links": gather_bytes_rx},
+                     "gather_bytes_per_step": {"assembled_on_rank0": gather_bytes, "received_over_links": gather_bytes_rx,
+                                               "wire_format": "u16 per value (records, tile counts and window fields all fit), widened on rank 0"
+                                                              if plan.wire16_ok else "u32"},
                      "step_split": split,
                      "summaries_only_variant": {"ms_per_step": round(t_dir / args.steps * 1e3, 4),
                                                 "value": round(total / (t_dir / args.steps) / 1e9, 3),

@@ -332,6 +332,13 @@ int ts_batch_export(ts_batch *b, void *d_dense, uint64_t dense_capacity, void *d
  * after a local scan + sync. */
 int ts_batch_adopt(ts_batch *b, void *d_windows, void *d_tile_stats, const void *d_dense, uint64_t n_matches,
                    void *stream);
+/* The exchange's wire format.  Every u32 of the three result arrays fits 16 bits when ts_batch_wire16_ok() says so
+ * (packed match records always do: position < 2^14 plus two flag bits; tile counts too; window fields when
+ * pattern length x window <= 65535), so ranks may send them as u16 — half the bytes over the link-bound gather — and
+ * the destination widens them where they land: dst[i] = src[i] for n values, asynchronously on `stream`
+ * (device pointers; ctx names the device). */
+int ts_batch_wire16_ok(const ts_batch *b);
+int ts_wire_widen_u16(ts_ctx *ctx, const void *d_src_u16, void *d_dst_u32, uint64_t n, void *stream);
 /* Device pointer of the batch's tile directory entries (16 B per tile of the range). */
 const void *ts_batch_tile_stats_ptr(const ts_batch *b);
 

@@ -109,6 +109,7 @@ SYMBOLS = [
     "ts_batch_matches_ptr", "ts_batch_download", "ts_batch_download_blocks", "ts_batch_segment_summary",
     "ts_batch_get_tiles", "ts_batch_range_info", "ts_batch_partition", "ts_batch_restrict", "ts_batch_bind_results",
     "ts_batch_export", "ts_batch_adopt", "ts_batch_tile_stats_ptr", "ts_filter_reads_multi", "ts_batch_read_pass",
+    "ts_batch_wire16_ok", "ts_wire_widen_u16",
 ]
 
 
@@ -191,6 +192,8 @@ def lib():
     L.ts_batch_adopt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.ts_batch_tile_stats_ptr.restype = C.c_void_p
     L.ts_batch_tile_stats_ptr.argtypes = [C.c_void_p]
+    L.ts_batch_wire16_ok.argtypes = [C.c_void_p]
+    L.ts_wire_widen_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.ts_batch_read_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ts_filter_reads_multi.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
                                         C.c_size_t, C.POINTER(C.c_uint8)]

@@ -845,6 +845,24 @@ int ts_batch_export(ts_batch *b, void *d_dense, uint64_t dense_capacity, void *d
     return TS_OK;
 }
 
+int ts_batch_wire16_ok(const ts_batch *b) {
+    if (!b) return 0;
+    const ts_ctx *c = b->ctx;
+    // records: (position << 2 | flags) with position < nch * TS_CHUNK + 64 <= 2^14; tile counts <= a tile's bases;
+    // window fields: nucleotide counts <= w, covered bases = k x matches <= k x w
+    const bool records = (uint64_t)b->kp.nch * TS_CHUNK + 64u <= (1u << 14);
+    const bool windows = b->tips || (uint64_t)c->k * c->params.window_size <= 65535u;
+    return records && windows ? 1 : 0;
+}
+
+int ts_wire_widen_u16(ts_ctx *ctx, const void *d_src_u16, void *d_dst_u32, uint64_t n, void *stream) {
+    if (!ctx || (n && (!d_src_u16 || !d_dst_u32))) return TS_ERR_INVALID_ARG;
+    DEVICE_TRY(ctx);
+    const int e = ts_k_launch_widen_u16((const uint16_t *)d_src_u16, (uint32_t *)d_dst_u32, n, stream);
+    if (e != 0) return ctx->fail(TS_ERR_HIP, std::string("widen kernel launch: ") + hipGetErrorString((hipError_t)e));
+    return TS_OK;
+}
+
 int ts_batch_adopt(ts_batch *b, void *d_windows, void *d_tile_stats, const void *d_dense, uint64_t n_matches, void *stream) {
     if (!b || !d_tile_stats || (n_matches && !d_dense) || (!b->tips && b->n_windows && !d_windows)) return TS_ERR_INVALID_ARG;
     ts_ctx *c = b->ctx;

@@ -113,6 +113,23 @@ void ts_tile_order_copy(const uint32_t *tile_stats, const u64 *region_off, const
     for (uint32_t i = lane; i < n; i += 64u) dst[i] = src[i];
 }
 
+// The exchange's wire format: every u32 of a rank's three arrays fits 16 bits (a packed match record is a
+// tile-relative position < 2^14 plus two flag bits; window fields are at most k x window; tile counts at most a
+// tile's bases), so they travel as u16 — half the bytes over the per-link-bound xGMI gather — and are widened again
+// where they land.  Eight values per lane: one 16-byte load, two 16-byte stores.
+__global__ __launch_bounds__(256)
+void ts_widen_u16(const uint16_t *src, uint32_t *dst, u64 n) {
+    const u64 i8 = ((u64)blockIdx.x * 256u + threadIdx.x) * 8ull;
+    if (i8 >= n) return;
+    if (i8 + 8ull <= n && (((uintptr_t)(src + i8)) & 15u) == 0u && (((uintptr_t)(dst + i8)) & 15u) == 0u) {
+        const uint4 v = *(const uint4 *)(src + i8);
+        *(uint4 *)(dst + i8) = make_uint4(v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16);
+        *(uint4 *)(dst + i8 + 4) = make_uint4(v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16);
+    } else {
+        for (u64 i = i8; i < n && i < i8 + 8ull; ++i) dst[i] = src[i];
+    }
+}
+
 uint32_t scan_blocks(uint32_t ntiles) { return ntiles ? (ntiles + kScanBlock - 1u) / kScanBlock : 1u; }
 
 }  // namespace
@@ -147,5 +164,12 @@ int ts_k_launch_tile_order_export(const uint32_t *tile_stats, const unsigned lon
     if (ntiles)
         hipLaunchKernelGGL(ts_tile_order_copy, dim3((ntiles + 3u) / 4u), dim3(256), 0, st, tile_stats, region_off, regions,
                            (const u64 *)dense_off, ntiles, dense, (const u64 *)total_out);
+    return (int)hipGetLastError();
+}
+
+int ts_k_launch_widen_u16(const uint16_t *src, uint32_t *dst, unsigned long long n, void *stream) {
+    if (n == 0) return 0;
+    const unsigned long long nb = (n + 2047ull) / 2048ull;
+    hipLaunchKernelGGL(ts_widen_u16, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     return (int)hipGetLastError();
 }

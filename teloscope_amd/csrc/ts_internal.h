@@ -160,6 +160,7 @@ int  ts_k_launch_tile_order_export(const uint32_t *tile_stats, const unsigned lo
                                    uint32_t nwaves, uint32_t ntiles, unsigned long long *dense_off, void *tmp,
                                    uint32_t *dense, unsigned long long capacity, unsigned long long *total_out,
                                    void *stream);
+int  ts_k_launch_widen_u16(const uint16_t *src, uint32_t *dst, unsigned long long n, void *stream);
 int  ts_k_launch_compact(const uint32_t *regions, const uint32_t *wave_fill,
                          const unsigned long long *wave_dense_base, uint32_t region_cap,
                          uint32_t nwaves, uint32_t *dense, void *stream);

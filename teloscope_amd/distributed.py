@@ -62,6 +62,8 @@ class ShardPlan:
         self.L.ts_batch_get_info(self.batch, C.byref(self.info))
         self.n_tiles = int(self.info.n_tiles)
         self.n_windows = 0 if self.tips_only else int(self.info.n_windows)
+        # every value of the three result arrays fits 16 bits: the exchange may halve its bytes (ts_batch_wire16_ok)
+        self.wire16_ok = bool(self.L.ts_batch_wire16_ok(self.batch))
         self.ranges = []
         for p in range(self.world):
             lo, hi = C.c_uint64(), C.c_uint64()
@@ -125,6 +127,7 @@ class Assembled:
         self.windows, self.stats, self.dense = windows, stats, dense
         self.n_records = int(n_records)
         self.counts = [int(c) for c in counts]              # records per rank
+        self.landing = {}                                   # (rank, array) -> int16 buffer the wire format lands in
 
 
 class GatherHandle:
@@ -143,8 +146,22 @@ class GatherHandle:
         return self.result
 
 
+def _widen_u16(plan, src16, dst32):
+    """dst32[i] = the u16 in src16[i] (int16 / int32 tensors carrying the bits of u16 / u32)."""
+    if dst32.is_cuda:
+        import torch
+        rc = plan.L.ts_wire_widen_u16(plan.teloscope._ctx.ptr, C.c_void_p(src16.data_ptr()), C.c_void_p(dst32.data_ptr()),
+                                      src16.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, plan.teloscope._ctx.error())
+    else:
+        import torch
+        torch.bitwise_and(src16.to(torch.int32), 0xFFFF, out=dst32)
+
+
 def gather_shards(plan: ShardPlan, rank: int, windows, stats, dense, n_records: int, dst: int = 0,
-                  group=None, out: Optional[Assembled] = None, async_op: bool = False, directory_only: bool = False):
+                  group=None, out: Optional[Assembled] = None, async_op: bool = False, directory_only: bool = False,
+                  wire16: Optional[bool] = None):
     """The one exchange of a sharded scan (a Gatherv to `dst`).
 
     windows / stats / dense: this rank's result arrays as flat int32 torch tensors — windows of its range
@@ -152,6 +169,11 @@ def gather_shards(plan: ShardPlan, rank: int, windows, stats, dense, n_records: 
     (the first n_records elements are sent).  On `dst` they may be views into `out` already (its own results
     are then in place and not copied).  Returns (on dst) an Assembled whose arrays hold the whole batch, None
     elsewhere; with async_op a GatherHandle whose wait() returns that.
+
+    wire16 (default: whenever the plan allows, ShardPlan.wire16_ok): the arrays travel as u16 — every value fits
+    (packed records are a tile-relative position < 2^14 plus two flag bits, tile counts at most a tile's bases, window
+    fields at most pattern length x window) — and are widened where they land: half the bytes over a gather that is
+    bound by the per-link xGMI rate into the destination.
 
     directory_only: the summaries-only variant — only the tile directory entries travel (16 B per tile: what the
     path summary report needs, per-segment match / canonical / forward counts, is a sum over a segment's
@@ -168,6 +190,9 @@ def gather_shards(plan: ShardPlan, rank: int, windows, stats, dense, n_records: 
     on_device = backend == "nccl"
     dev = windows.device
     wire_dev = dev if on_device else torch.device("cpu")
+    if wire16 is None:
+        wire16 = plan.wire16_ok
+    wire16 = bool(wire16) and plan.wire16_ok
     r = plan.ranges[rank]
     assert windows.numel() == 8 * (0 if plan.tips_only else (r.window_end - r.window_begin))
     assert stats.numel() == 4 * (r.tile_end - r.tile_begin)
@@ -183,6 +208,8 @@ def gather_shards(plan: ShardPlan, rank: int, windows, stats, dense, n_records: 
         counts = [int(c.item()) for c in allc]
 
     def wire(t):
+        if wire16:
+            t = t.to(torch.int16)                            # keeps the low 16 bits: the whole value
         return t if t.device == wire_dev else t.to(wire_dev)
 
     # 2. grouped send/recv: every rank's three arrays go to their places on dst
@@ -233,17 +260,28 @@ def gather_shards(plan: ShardPlan, rank: int, windows, stats, dense, n_records: 
         for t, tag in ((w, 1), (s, 2), (d, 3)):
             if not t.numel() or (directory_only and tag != 2):
                 continue
-            if on_device:
+            if on_device and not wire16:
                 ops.append(dist.P2POp(dist.irecv, t, p, group=group, tag=tag))
-            else:
-                tmp = torch.empty(t.numel(), dtype=torch.int32)
-                ops.append(dist.P2POp(dist.irecv, tmp, p, group=group, tag=tag))
-                landing.append((t, tmp))
+                continue
+            # a landing buffer (kept between exchanges): u16 on the wire, and / or host memory for gloo
+            key = (p, tag, wire16)
+            tmp = out.landing.get(key)
+            if tmp is None or tmp.numel() < t.numel() or tmp.device != wire_dev:
+                tmp = torch.empty(t.numel() + t.numel() // 8 + 16, dtype=torch.int16 if wire16 else torch.int32, device=wire_dev)
+                out.landing[key] = tmp
+            tmp = tmp[:t.numel()]
+            ops.append(dist.P2POp(dist.irecv, tmp, p, group=group, tag=tag))
+            landing.append((t, tmp))
     works = dist.batch_isend_irecv(ops) if ops else []
 
     def finish():
         for t, tmp in landing:
-            t.copy_(tmp)
+            if tmp.device != t.device:
+                tmp = tmp.to(t.device)
+            if wire16:
+                _widen_u16(plan, tmp, t)
+            else:
+                t.copy_(tmp)
         return out
 
     h = GatherHandle(works, finish)

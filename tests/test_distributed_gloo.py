@@ -96,11 +96,16 @@ def _worker(rank, world, port, mode, q):
                         torch.cat([torch.from_numpy(d.copy()), spare]), len(d), dst=0)
     again = gather_shards(plan, rank, torch.from_numpy(w.copy()), torch.from_numpy(s.copy()),
                           torch.from_numpy(d.copy()), len(d), dst=0, async_op=True, directory_only=True).wait()
+    assert plan.wire16_ok                                        # (the first exchange went over the wire as u16)
+    plain = gather_shards(plan, rank, torch.from_numpy(w.copy()), torch.from_numpy(s.copy()),
+                          torch.from_numpy(d.copy()), len(d), dst=0, wire16=False)
     if rank == 0:
         assert again.n_records == 0 and torch.equal(again.stats, got.stats)
+        assert torch.equal(plain.windows, got.windows) and torch.equal(plain.stats, got.stats)
+        assert plain.n_records == got.n_records and torch.equal(plain.dense[:plain.n_records], got.dense[:got.n_records])
         q.put((got.windows.numpy(), got.stats.numpy(), got.dense[:got.n_records].numpy(), got.counts))
     else:
-        assert got is None and again is None
+        assert got is None and again is None and plain is None
     dist.barrier()
     dist.destroy_process_group()
 
