@@ -129,6 +129,32 @@ def build(force=False):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One process, one HIP runtime.  libteloscan.so needs libamdhip64.so.7; PyTorch-ROCm ships its own copy under
+    torch/lib with the same SONAME, and whichever is loaded first serves both.  When torch comes second it finds a
+    runtime it was not built against and reports "No HIP GPUs are available" — so, if PyTorch is installed but not
+    imported yet, its runtime libraries are loaded first (what `import torch` would have done); without PyTorch the
+    system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -137,6 +163,7 @@ def lib():
         raise ImportError(
             "libteloscan.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C teloscope_amd/csrc`; teloscope_amd has no CPU fallback." % LIB_PATH)
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.ts_abi_version.restype = C.c_int
     L.ts_last_error.restype = C.c_char_p
