@@ -27,3 +27,6 @@ g++ -std=c++17 -O2 -I include tests/cpp/manifest_cli.cpp -L teloscope_amd -ltelo
 /tmp/manifest_cli --fastq-subset -l 42 /tmp/reads.fq > /tmp/kept.fq     # warm-up (page cache, device init)
 t0=$(date +%s%N); TS_TIMING=1 /tmp/manifest_cli --fastq-subset -l 42 /tmp/reads.fq > /tmp/kept.fq; t1=$(date +%s%N); echo "wall $(( (t1 - t0) / 1000000 )) ms"
 ls -la /tmp/reads.fq /tmp/kept.fq | awk '{print $5, $9}'
+echo "# the read shard: two read-filter contexts (here on one GPU), every batch cut into two consecutive shards"
+t0=$(date +%s%N); TS_TIMING=1 /tmp/manifest_cli --fastq-subset -l 42 --read-devices 0,0 /tmp/reads.fq > /tmp/kept2.fq; t1=$(date +%s%N); echo "wall $(( (t1 - t0) / 1000000 )) ms"
+cmp /tmp/kept.fq /tmp/kept2.fq && echo "# identical output"
