@@ -369,6 +369,95 @@ struct FastqSubsetResult { uint64_t kept = 0, total = 0; };
 
 namespace detail {
 inline size_t logicalLineLength(const char *b, const char *e) { return (e > b && e[-1] == '\r') ? static_cast<size_t>(e - b) - 1 : static_cast<size_t>(e - b); }
+
+struct FastqRec { const char *begin, *seq, *end; uint64_t seqLen; bool needNewline; };
+
+// Parses the records that START in [p, limit) of a complete FASTQ text ending at `end` (the last line may lack its
+// '\n'), by readFastqRecord's rules (src/input.cpp:113-138).  Returns where it stopped — the start of the first record
+// at or beyond `limit`, or `end` — or nullptr at the first thing that is not a well-formed record (the caller then
+// re-parses sequentially to report it the way the reference does).
+inline const char *parseFastqPiece(const char *p, const char *limit, const char *end, std::vector<FastqRec> &out) {
+    auto nextLine = [&](const char *from, const char *&lb, const char *&le, const char *&next) -> bool {
+        if (from >= end) return false;
+        const char *nl = static_cast<const char *>(std::memchr(from, '\n', static_cast<size_t>(end - from)));
+        lb = from; le = nl ? nl : end; next = nl ? nl + 1 : end;
+        return true;
+    };
+    while (p < limit) {
+        const char *hb, *he, *nx;
+        if (!nextLine(p, hb, he, nx)) break;
+        if (logicalLineLength(hb, he) == 0) { p = nx; continue; }             // blank line before a header
+        const char *sb, *se, *pb, *pe, *qb, *qe, *n2, *n3, *n4;
+        if (!(nextLine(nx, sb, se, n2) && nextLine(n2, pb, pe, n3) && nextLine(n3, qb, qe, n4))) return nullptr;
+        if (he == hb || *hb != '@' || pe == pb || *pb != '+' || logicalLineLength(sb, se) != logicalLineLength(qb, qe)) return nullptr;
+        out.push_back(FastqRec{hb, sb, qe, static_cast<uint64_t>(se - sb), true});
+        p = n4;
+    }
+    return p;
+}
+
+// All records of a mapped FASTQ text, found by the host threads: the text is cut into pieces; a piece starts at the first
+// line that looks like a header ('@' first, the line after next begins with '+', the next line does not begin with '@' — a
+// quality line may begin with '@', but then the line after it is a header), every piece is parsed on its own, and the
+// pieces are accepted only if each parse lands exactly on the next piece's start.  false = not provably well-formed this
+// way: parse sequentially instead.
+inline bool splitFastqRecords(const char *data, size_t size, std::vector<FastqRec> &records, size_t pieceBytes = size_t(32) << 20) {
+    const char *end = data + size;
+    const size_t np = std::max<size_t>(1, std::min<size_t>(256, size / std::max<size_t>(pieceBytes, 1)));
+    if (np < 2) return false;
+    std::vector<const char *> start(np + 1, nullptr);
+    start[0] = data; start[np] = end;
+    std::atomic<bool> bad{false};
+    auto lineAfter = [&](const char *q) -> const char * {                    // start of the line after the one holding q
+        const char *nl = static_cast<const char *>(std::memchr(q, '\n', static_cast<size_t>(end - q)));
+        return nl ? nl + 1 : end;
+    };
+    {
+        std::atomic<size_t> next{1};
+        auto worker = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < np;) {
+                const char *q = lineAfter(data + size / np * i - 1);          // a line start at or after the cut
+                int tries = 0;
+                for (; q < end && tries < 64; ++tries) {
+                    const char *l1 = lineAfter(q), *l2 = l1 < end ? lineAfter(l1) : end;
+                    if (*q == '@' && l1 < end && *l1 != '@' && l2 < end && *l2 == '+') break;
+                    q = l1;
+                }
+                if (q < end && tries == 64) { bad.store(true); return; }       // 64 lines without a header: not FASTQ-shaped
+                start[i] = q < end ? q : end;                                     // (no record starts behind this cut)
+            }
+        };
+        const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), np, size_t(std::max(1u, std::thread::hardware_concurrency()))}));
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(worker);
+        for (std::thread &th : pool) th.join();
+    }
+    if (bad.load()) return false;
+    for (size_t i = 1; i <= np; ++i) if (start[i] < start[i - 1]) return false;
+    std::vector<std::vector<FastqRec>> parts(np);
+    {
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < np;) {
+                if (start[i] == start[i + 1]) continue;
+                parts[i].reserve(static_cast<size_t>(start[i + 1] - start[i]) / 20000 + 16);
+                const char *stop = parseFastqPiece(start[i], start[i + 1], end, parts[i]);
+                if (stop != start[i + 1]) { bad.store(true); return; }
+            }
+        };
+        const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), np, size_t(std::max(1u, std::thread::hardware_concurrency()))}));
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(worker);
+        for (std::thread &th : pool) th.join();
+    }
+    if (bad.load()) return false;
+    size_t total = 0;
+    for (const auto &v : parts) total += v.size();
+    records.clear();
+    records.reserve(total);
+    for (const auto &v : parts) records.insert(records.end(), v.begin(), v.end());
+    return true;
+}
 }  // namespace detail
 
 inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &out, ReadTelomereFilter &filter,
@@ -460,12 +549,29 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
     FastqSubsetResult res;
     uint64_t recordNumber = 0;
     auto fail = [&](const char *msg) { throw std::runtime_error("FASTQ record " + std::to_string(recordNumber + 1) + ": " + msg); };
-    struct Rec { const char *begin, *seq, *end; uint64_t seqLen; bool needNewline; };
+    using Rec = detail::FastqRec;
     std::vector<Rec> batch;
     std::vector<const char *> ptr;
     std::vector<uint64_t> len;
     std::vector<uint8_t> pass;
     std::string text;
+    // filters `batch` on the GPU and echoes the kept records
+    auto runBatch = [&]() {
+        if (batch.empty()) return;
+        ptr.resize(batch.size()); len.resize(batch.size()); pass.resize(batch.size());
+        for (size_t i = 0; i < batch.size(); ++i) { ptr[i] = batch[i].seq; len[i] = batch[i].seqLen; }
+        filter.matchesPointers(ptr.data(), len.data(), batch.size(), pass.data());
+        text.clear();
+        for (size_t i = 0; i < batch.size(); ++i) {
+            if (!pass[i]) continue;
+            text.append(batch[i].begin, batch[i].end);
+            text.push_back('\n');
+            ++res.kept;
+        }
+        res.total += batch.size();
+        out.write(text.data(), static_cast<std::streamsize>(text.size()));
+        if (!out.good()) throw std::runtime_error("failed while writing FASTQ subset");
+    };
     // Parses whole records out of [p, end) — several GPU batches if the range holds more than readsPerBatch reads or
     // bytesPerBatch record bytes — filters them and echoes the kept ones; returns the end of the last whole record.
     auto processRange = [&](const char *p, const char *const end, const bool eof) -> const char * {
@@ -504,21 +610,7 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
                 p = n4;
                 consumed = p;
             }
-            if (!batch.empty()) {
-                ptr.resize(batch.size()); len.resize(batch.size()); pass.resize(batch.size());
-                for (size_t i = 0; i < batch.size(); ++i) { ptr[i] = batch[i].seq; len[i] = batch[i].seqLen; }
-                filter.matchesPointers(ptr.data(), len.data(), batch.size(), pass.data());
-                text.clear();
-                for (size_t i = 0; i < batch.size(); ++i) {
-                    if (!pass[i]) continue;
-                    text.append(batch[i].begin, batch[i].end);
-                    text.push_back('\n');
-                    ++res.kept;
-                }
-                res.total += batch.size();
-                out.write(text.data(), static_cast<std::streamsize>(text.size()));
-                if (!out.good()) throw std::runtime_error("failed while writing FASTQ subset");
-            }
+            runBatch();
         }
         return consumed;
     };
@@ -534,6 +626,24 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
                 struct Unmap { void *p; size_t n; ~Unmap() { ::munmap(p, n); } } unmap{map, size};
                 const char *data = static_cast<const char *>(map);
                 if (data[0] != '@') throw std::runtime_error("FASTQ input must start with '@'");
+                // a large file's records are located by all host threads at once (one thread walks 3 GB of text in
+                // ~0.5 s); anything that is not provably well-formed that way takes the sequential parser, which
+                // reports errors the way the reference does
+                std::vector<Rec> all;
+                if (size >= (size_t(64) << 20) && detail::splitFastqRecords(data, size, all)) {
+                    size_t i = 0;
+                    while (i < all.size()) {
+                        batch.clear();
+                        size_t batchBytes = 0;
+                        while (i < all.size() && batch.size() < readsPerBatch && batchBytes < bytesPerBatch) {
+                            batchBytes += static_cast<size_t>(all[i].end - all[i].begin) + 1;
+                            batch.push_back(all[i++]);
+                        }
+                        runBatch();
+                    }
+                    out.flush();
+                    return res;
+                }
                 (void)processRange(data, data + size, true);
                 out.flush();
                 return res;

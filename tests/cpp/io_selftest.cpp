@@ -100,6 +100,40 @@ int main(int argc, char **argv) {
                 check(at == a.size(), "streamed record count");
             }
     }
+    // ---- splitFastqRecords (pieces parsed in parallel) against the sequential piece parser on awkward FASTQ texts
+    size_t accepted = 0, offered = 0;
+    for (int it = 0; it < 24; ++it) {
+        std::string text;
+        const int nrec = 50 + static_cast<int>(rng() % 400);
+        const bool crlf = it % 4 == 1;
+        const char *eol = crlf ? "\r\n" : "\n";
+        for (int r = 0; r < nrec; ++r) {
+            if (rng() % 11 == 0) text += eol;                                   // blank line before a header
+            const size_t len = rng() % 300;
+            text += "@r" + std::to_string(r) + (r % 3 ? " extra @ + words" : "") + eol;
+            for (size_t i = 0; i < len; ++i) text += "ACGTN"[rng() % 5];
+            text += eol;
+            text += (r % 5 == 0 ? std::string("+r") + std::to_string(r) : std::string("+")) + eol;
+            for (size_t i = 0; i < len; ++i) text += (i == 0 && rng() % 3 == 0) ? '@' : static_cast<char>('!' + rng() % 60);   // quality lines may begin with '@' or '+'
+            text += eol;
+        }
+        if (it % 5 == 2) { text.pop_back(); if (crlf) text.pop_back(); }         // no newline at the end of the file
+        if (it % 13 == 7) text.insert(text.size() / 2, "garbage line\n");         // malformed: must be refused, not mis-split
+        std::vector<detail::FastqRec> seq, par;
+        const char *stop = detail::parseFastqPiece(text.data(), text.data() + text.size(), text.data() + text.size(), seq);
+        const bool wellFormed = stop == text.data() + text.size();
+        for (size_t piece : {size_t(200), size_t(1500), size_t(20000)}) {
+            const bool ok = detail::splitFastqRecords(text.data(), text.size(), par, piece);
+            if (!wellFormed) { check(!ok, "malformed FASTQ accepted by the parallel splitter"); continue; }
+            ++offered;
+            if (!ok) continue;                                                  // refusing is always allowed (sequential fallback)
+            ++accepted;
+            check(par.size() == seq.size(), "parallel FASTQ record count");
+            for (size_t i = 0; i < seq.size() && i < par.size(); ++i)
+                check(par[i].begin == seq[i].begin && par[i].seq == seq[i].seq && par[i].end == seq[i].end && par[i].seqLen == seq[i].seqLen, "parallel FASTQ record");
+        }
+    }
+    check(offered > 20 && accepted * 10 >= offered * 9, "the parallel splitter refuses well-formed FASTQ too often");
     puts("io_selftest ok");
     return 0;
 }
