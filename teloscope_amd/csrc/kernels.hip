@@ -39,11 +39,6 @@
 #ifndef TS_ABL
 #define TS_ABL 0
 #endif
-// Experiments under A/B measurement (profiles/ab.sh): -DTS_EXP=<mask>
-//   1 plane stores issued after the probe results are consumed (not queued behind the probes in the in-order LDS)
-#ifndef TS_EXP
-#define TS_EXP 0
-#endif
 
 namespace {
 
@@ -377,17 +372,13 @@ void ts_scan_tiles(const TsScanParams P) {
                 }
             }
 #endif
-            // (done while the probes are in flight: the counting needs nothing from them.  TS_EXP & 1: the plane STORES
-            // are issued after the probe results have been consumed — LDS completes in order, so stores queued behind
-            // the probes would make the wait for the probes a wait for the stores as well)
+            // (issued while the probes are in flight: the stores and the counting need nothing from them)
             // the lane's bases go to the tile's code plane (lane 63's first dword is the look-ahead of lane 62's
             // last k-mers; the next chunk's lane 0 rewrites the same slot with the same value)
-            const uint32_t h = ch + lane;                         // index of the lane's 32 positions in the planes
-            uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
-            const bool count_on = lane < 63u && P.windows_on && P.nuc_on;
             if (!(TS_ABL & 64)) {
-                if (!(TS_EXP & 1)) *(LDS u32x2 *)(codes + 2u * h) = (u32x2){wa, wb};
-                if (count_on) {
+                const uint32_t h = ch + lane;                     // index of the lane's 32 positions in the planes
+                *(LDS u32x2 *)(codes + 2u * h) = (u32x2){wa, wb};
+                if (lane < 63u && P.windows_on && P.nuc_on) {
                     // valid A/C/G/T among the 32 bases (codes A0 C1 T2 G3: low bit set in C and G, high
                     // bit in T and G); invalid positions are masked out on the slow path
                     // low code bits of the 32 bases in one dword (wa's at the even positions, wb's at the odd
@@ -401,11 +392,11 @@ void ts_scan_tiles(const TsScanParams P) {
                         nV = __popc(~inv);
                     }
                     const uint32_t nG = __popc(lo & hi), nL = __popc(lo), nH = __popc(hi);
-                    cA = nV + nG - nL - nH; cC = nL - nG; cG = nG; cT = nH - nG;
-                    if (!(TS_EXP & 1)) {
-                        lds_u8 *np = cnt + ((h >> 2) << 4) + (h & 3u);
-                        np[0] = (unsigned char)cA; np[4] = (unsigned char)cC; np[8] = (unsigned char)cG; np[12] = (unsigned char)cT;
-                    }
+                    lds_u8 *np = cnt + ((h >> 2) << 4) + (h & 3u);
+                    np[0] = (unsigned char)(nV + nG - nL - nH);
+                    np[4] = (unsigned char)(nL - nG);
+                    np[8] = (unsigned char)nG;
+                    np[12] = (unsigned char)(nH - nG);
                 }
             }
 
@@ -419,13 +410,6 @@ void ts_scan_tiles(const TsScanParams P) {
             for (int j = 0; j < 16; ++j)
                 M32 = __builtin_amdgcn_alignbit(PAIR_BYTES ? ent[j] : ent[j] >> ((tmp[j] << 1) & 31u), M32, 2);
 #endif
-            if ((TS_EXP & 1) && !(TS_ABL & 64)) {                 // the plane stores, behind the consumed probes
-                *(LDS u32x2 *)(codes + 2u * h) = (u32x2){wa, wb};
-                if (count_on) {
-                    lds_u8 *np = cnt + ((h >> 2) << 4) + (h & 3u);
-                    np[0] = (unsigned char)cA; np[4] = (unsigned char)cC; np[8] = (unsigned char)cG; np[12] = (unsigned char)cT;
-                }
-            }
 
             if (slow) {                                           // k-mers touching an invalid base
                 const uint32_t inv_next = (uint32_t)__builtin_amdgcn_mov_dpp((int)inv, 0x130, 0xf, 0xf, false);
