@@ -130,13 +130,29 @@ typedef struct ts_block {
     uint8_t  reserved;
 } ts_block;
 
-/* One scanSegment() call: (sequence, absPos, tipsOnly). */
+/* One scanSegment() call: (sequence, absPos, tipsOnly).
+ *
+ * input_format TS_INPUT_BASES (0): `seq` points to the segment's `len` bases.
+ * input_format TS_INPUT_TEXT_PIECES: `seq` points to a ts_text_piece array instead — FASTA body text as it lies in the
+ * file, line ends included; the pieces, in order, hold the segment's `len` bases.  The library skips the line ends while
+ * it stages the bases for upload, so a front end never has to join the lines of a record into one buffer (what gfalibs
+ * does before walkPath, and the largest host cost once the scan itself takes milliseconds).  The entry points read
+ * pieces until `len` bases are covered; of the last piece only what is needed. */
+#define TS_INPUT_BASES       0
+#define TS_INPUT_TEXT_PIECES 1
+typedef struct ts_text_piece {
+    const char *text;        /* text_len bytes: n_bases bases and the line ends between / behind them ('\n', and a '\r'
+                                right before one or at the very end of the piece) */
+    uint64_t    text_len;    /* at most 16 MiB */
+    uint64_t    n_bases;
+} ts_text_piece;
 typedef struct ts_segment_in {
     const char *seq;        /* borrowed for the duration of the call; need not be NUL-terminated */
     uint64_t    len;
     uint64_t    abs_pos;
     uint8_t     tips_only;
-    uint8_t     reserved[7];
+    uint8_t     input_format;   /* TS_INPUT_BASES / TS_INPUT_TEXT_PIECES (tiled kernel's parameter sets only) */
+    uint8_t     reserved[6];
 } ts_segment_in;
 
 /* SegmentData, include/teloscope.h:139-148.  `matches` holds what the
@@ -183,6 +199,8 @@ void    ts_destroy(ts_ctx *ctx);
  * 0 if on the general kernels (mixed-length sets, k > 9, or a longest pattern exceeding
  * min(step, window-step), where the reference's start-index arithmetic wraps). */
 int     ts_uses_fast_path(const ts_ctx *ctx);
+/* 1 if segments of this kind (full scan / tips-only) may come as TS_INPUT_TEXT_PIECES: those the tiled kernel scans. */
+int     ts_takes_text_input(const ts_ctx *ctx, int tips_only);
 
 /* ---- Teloscope::scanSegment, batched (src/teloscope.cpp:537-658).  out[i] receives the
  *      SegmentData of segs[i]; a one-element call equals one scanSegment() call.  Host

@@ -179,6 +179,9 @@ inline ts_block fromBlock(const TelomereBlock &t) {
 }  // namespace detail
 
 class Teloscope {                              // include/teloscope.h:166-300 (scan path only)
+public:
+    struct Segment;
+private:
     UserInputTeloscope userInput;
     detail::CtxPtr ctx;
 
@@ -186,7 +189,9 @@ class Teloscope {                              // include/teloscope.h:166-300 (s
     // canonicalMatches and nonCanonicalMatches; the other three match vectors (all / fwd / rev, which only block
     // calling reads, and that has happened on the device) stay empty.  Of ~90 M matches of a 3 Gb assembly ~3 M are
     // written, and a MatchInfo is 56 bytes with a std::string.
-    SegmentData convert(const ts_segment_out &o, const char *sequence, uint64_t absPos, bool tipsOnly, bool writerViewOnly = false) const {
+    SegmentData convert(const ts_segment_out &o, const Segment &seg, bool writerViewOnly = false) const {
+        const uint64_t absPos = seg.absPos;
+        const bool tipsOnly = seg.tipsOnly;
         SegmentData sd;
         sd.windows.reserve(o.n_windows);
         for (uint64_t i = 0; i < o.n_windows; ++i) {
@@ -211,11 +216,8 @@ class Teloscope {                              // include/teloscope.h:166-300 (s
             m.position = g.position; m.matchSize = g.match_size;
             m.isForward = (g.flags & TS_MATCH_FORWARD) != 0;
             m.isCanonical = (g.flags & TS_MATCH_CANONICAL) != 0;
-            if (userInput.outMatches && !tipsOnly) {                    // src/teloscope.cpp:466-468 (of the unmasked sequence)
-                m.matchSeq.assign(sequence + static_cast<size_t>(g.position - absPos), g.match_size);
-                for (char &ch : m.matchSeq)
-                    if (ch >= 'a' && ch <= 'z') ch = static_cast<char>(ch - 32);
-            }
+            if (userInput.outMatches && !tipsOnly)                      // src/teloscope.cpp:466-468 (of the unmasked sequence)
+                m.matchSeq = seg.bases(g.position - absPos, g.match_size);
             if (!writerViewOnly) (m.isForward ? sd.fwdMatches : sd.revMatches).push_back(m);
             if (!tipsOnly) {                                            // routing of src/teloscope.cpp:485-509
                 if (!writerViewOnly) sd.allMatches.push_back(m);
@@ -237,25 +239,63 @@ public:
     }
 
     const UserInputTeloscope &input() const { return userInput; }
+    // does the library take TS_INPUT_TEXT_PIECES segments for this parameter set (the tiled kernel's; the general path
+    // wants the bases joined)?
+    bool takesTextPieces() const { return ts_takes_text_input(ctx.get(), userInput.ultraFastMode ? 1 : 0) != 0; }
 
     // one scanSegment call of a batch; the bases are borrowed for the duration of the call (any case:
     // the library folds case itself, as unmaskSequence would have)
     struct Segment {
-        const char *data;
+        const char *data;                      // the bases — or nullptr when `pieces` is set
         size_t size;
         uint64_t absPos;
         bool tipsOnly;
+        const ts_text_piece *pieces = nullptr; // FASTA body text as it lies in the file (TS_INPUT_TEXT_PIECES): the
+                                               // library skips the line ends on the way to the device
         Segment(const char *d, size_t n, uint64_t a, bool t) : data(d), size(n), absPos(a), tipsOnly(t) {}
         Segment(const std::string *s, uint64_t a, bool t) : data(s->data()), size(s->size()), absPos(a), tipsOnly(t) {}
+        Segment(const ts_text_piece *p, size_t nBases, uint64_t a, bool t) : data(nullptr), size(nBases), absPos(a), tipsOnly(t), pieces(p) {}
+        ts_segment_in in() const {
+            ts_segment_in x{};
+            x.seq = pieces ? reinterpret_cast<const char *>(pieces) : data;
+            x.len = size; x.abs_pos = absPos; x.tips_only = static_cast<uint8_t>(tipsOnly);
+            x.input_format = pieces ? TS_INPUT_TEXT_PIECES : TS_INPUT_BASES;
+            return x;
+        }
+        // bases [pos, pos + n) of the segment, upper-cased (matchSeq, src/teloscope.cpp:466-468)
+        std::string bases(uint64_t pos, size_t n) const {
+            std::string out;
+            out.reserve(n);
+            if (!pieces) out.assign(data + pos, n);
+            else {
+                uint64_t cum = 0;
+                for (const ts_text_piece *p = pieces; out.size() < n; ++p) {
+                    if (pos >= cum + p->n_bases) { cum += p->n_bases; continue; }
+                    uint64_t skip = pos > cum ? pos - cum : 0;
+                    const char *q = p->text, *end = p->text + p->text_len;
+                    while (q < end && out.size() < n) {                       // line by line
+                        const char *nl = static_cast<const char *>(std::memchr(q, '\n', static_cast<size_t>(end - q)));
+                        const char *stop = nl ? nl : end;
+                        uint64_t line = static_cast<uint64_t>(stop - q);
+                        if (line && stop[-1] == '\r') --line;
+                        if (skip < line) { out.append(q + skip, static_cast<size_t>(std::min<uint64_t>(line - skip, n - out.size()))); skip = 0; }
+                        else skip -= line;
+                        q = nl ? nl + 1 : end;
+                    }
+                    cum += p->n_bases;
+                }
+            }
+            for (char &ch : out)
+                if (ch >= 'a' && ch <= 'z') ch = static_cast<char>(ch - 32);
+            return out;
+        }
     };
 
     // batched scanSegment: result[i] is what scanSegment(*segs[i].sequence, absPos, tipsOnly) returns
     // (writerViewOnly: see convert())
     std::vector<SegmentData> scanSegments(const std::vector<Segment> &segs, bool writerViewOnly = false) {
         std::vector<ts_segment_in> in(segs.size());
-        for (size_t i = 0; i < segs.size(); ++i) {
-            in[i] = ts_segment_in{segs[i].data, segs[i].size, segs[i].absPos, static_cast<uint8_t>(segs[i].tipsOnly), {}};
-        }
+        for (size_t i = 0; i < segs.size(); ++i) in[i] = segs[i].in();
         std::vector<ts_segment_out> out(segs.size());
         if (ts_scan_segments(ctx.get(), in.data(), in.size(), out.data()) != TS_OK)
             throw std::runtime_error(ts_last_error(ctx.get()));
@@ -269,7 +309,7 @@ public:
         auto worker = [&]() {
             for (size_t k; (k = next.fetch_add(1)) < order.size();) {
                 const size_t i = order[k];
-                res[i] = convert(out[i], segs[i].data, segs[i].absPos, segs[i].tipsOnly, writerViewOnly);
+                res[i] = convert(out[i], segs[i], writerViewOnly);
             }
         };
         const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), segs.size(), size_t(std::max(1u, std::thread::hardware_concurrency()))}));
@@ -289,8 +329,7 @@ public:
     // counts[i] = the sizes the match vectors would have had.
     std::vector<SegmentData> scanSegmentsNoMatches(const std::vector<Segment> &segs, std::vector<ts_segment_counts> &counts) {
         std::vector<ts_segment_in> in(segs.size());
-        for (size_t i = 0; i < segs.size(); ++i)
-            in[i] = ts_segment_in{segs[i].data, segs[i].size, segs[i].absPos, static_cast<uint8_t>(segs[i].tipsOnly), {}};
+        for (size_t i = 0; i < segs.size(); ++i) in[i] = segs[i].in();
         std::vector<ts_segment_out> out(segs.size());
         counts.assign(segs.size(), ts_segment_counts{0, 0, 0, 0});
         if (ts_scan_segments_blocks(ctx.get(), in.data(), in.size(), out.data(), counts.data()) != TS_OK)
@@ -299,7 +338,7 @@ public:
         std::vector<SegmentData> res(segs.size());
         std::atomic<size_t> next{0};
         auto worker = [&]() {
-            for (size_t i; (i = next.fetch_add(1)) < segs.size();) res[i] = convert(out[i], segs[i].data, segs[i].absPos, segs[i].tipsOnly);
+            for (size_t i; (i = next.fetch_add(1)) < segs.size();) res[i] = convert(out[i], segs[i]);
         };
         const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), segs.size(), size_t(std::max(1u, std::thread::hardware_concurrency()))}));
         if (nt <= 1) {

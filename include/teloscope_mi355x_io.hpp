@@ -244,11 +244,62 @@ inline PathComponents splitPath(const std::string &seq) { return splitPath(seq.d
 // streaming reader filled).
 struct RecordView {
     const std::string *header;
-    const char *data;
-    size_t size;
+    const char *data;                          // the bases, or nullptr when `pieces` is set
+    size_t size;                               // bases
+    const ts_text_piece *pieces = nullptr;     // FASTA body text in the file (line ends included), in order
+    size_t nPieces = 0;
 };
 
 namespace detail {
+// text position of base `skip` of a run of FASTA body text (line ends are not bases)
+inline const char *textLocate(const char *text, uint64_t textLen, uint64_t skip) {
+    const char *p = text, *end = text + textLen;
+    while (p < end) {
+        const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        const char *stop = nl ? nl : end;
+        uint64_t line = static_cast<uint64_t>(stop - p);
+        if (line && stop[-1] == '\r') --line;
+        if (skip < line) return p + skip;
+        skip -= line;
+        p = nl ? nl + 1 : end;
+    }
+    return end;
+}
+
+// splitPath over FASTA body text [p, end) that starts at a line start: runs in BASE coordinates (line ends are
+// skipped, a run goes on across them); *nBases = the bases of the text; firstIsGap / lastIsGap as splitPaths needs them
+inline PathComponents splitPathText(const char *p, const char *end, uint64_t *nBases, bool *firstIsGap, bool *lastIsGap) {
+    PathComponents pc;
+    auto isGap = [](char c) { return c == 'N' || c == 'n' || c == 'X' || c == 'x'; };
+    uint64_t base = 0, runStart = 0;
+    bool have = false, runGap = false;
+    *firstIsGap = *lastIsGap = false;
+    auto close = [&](uint64_t at) {
+        if (!have || at == runStart) return;
+        if (runGap) pc.gaps.push_back(GapInfo{runStart, static_cast<uint32_t>(at - runStart)});
+        else pc.segments.emplace_back(runStart, at - runStart);
+    };
+    while (p < end) {
+        const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        const char *stop = nl ? nl : end;
+        size_t n = static_cast<size_t>(stop - p);
+        if (n && stop[-1] == '\r') --n;
+        size_t i = 0;
+        while (i < n) {
+            const bool gap = isGap(p[i]);
+            if (!have) { have = true; runGap = gap; runStart = base; *firstIsGap = gap; }
+            else if (gap != runGap) { close(base + i); runGap = gap; runStart = base + i; }
+            i = scanGapState(p, i + 1, n, !gap);                            // the run goes on to where the state flips (or the line ends)
+        }
+        if (n) *lastIsGap = isGap(p[n - 1]);
+        base += n;
+        p = nl ? nl + 1 : end;
+    }
+    close(base);
+    *nBases = base;
+    return pc;
+}
+
 // appends the runs of a piece (already in record coordinates) to the record's components; when the piece continues
 // a record and its first run is of the kind the previous piece ended with, the two are one run
 inline void appendPieceRuns(PathComponents &out, const PathComponents &pc, bool continues, bool prevLastIsGap, bool firstIsGap) {
@@ -305,9 +356,50 @@ inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::ve
     const std::vector<PathComponents> split = precomputed ? std::vector<PathComponents>() : splitPaths(records);
     const std::vector<PathComponents> &comps = precomputed ? *precomputed : split;
     std::vector<Teloscope::Segment> batch;
+    // text records that N-runs cut into several segments: every segment gets its own piece list (reserved up front, so
+    // the lists do not move while the batch points into them)
+    auto oneSegment = [&](size_t pi) {
+        return comps[pi].segments.size() == 1 && comps[pi].segments[0].first == 0 && comps[pi].segments[0].second == records[pi].size;
+    };
+    size_t nSub = 0;
     for (size_t pi = 0; pi < records.size(); ++pi)
-        for (const auto &sg : comps[pi].segments)
-            batch.emplace_back(records[pi].data + sg.first, static_cast<size_t>(sg.second), sg.first, ui.ultraFastMode);
+        if (records[pi].pieces && !oneSegment(pi)) nSub += comps[pi].segments.size();
+    std::vector<std::vector<ts_text_piece>> subPieces;
+    subPieces.reserve(nSub);
+    for (size_t pi = 0; pi < records.size(); ++pi) {
+        const RecordView &rv = records[pi];
+        if (!rv.pieces) {
+            for (const auto &sg : comps[pi].segments)
+                batch.emplace_back(rv.data + sg.first, static_cast<size_t>(sg.second), sg.first, ui.ultraFastMode);
+            continue;
+        }
+        if (oneSegment(pi)) {
+            batch.emplace_back(rv.pieces, rv.size, 0, ui.ultraFastMode);          // its pieces as they are
+            continue;
+        }
+        // a segment = bases [a, a + n) of the record: the text pieces that hold them, the first one entered at base a
+        uint64_t cum = 0;
+        size_t k = 0;
+        for (const auto &sg : comps[pi].segments) {
+            while (k < rv.nPieces && cum + rv.pieces[k].n_bases <= sg.first) cum += rv.pieces[k++].n_bases;
+            subPieces.emplace_back();
+            std::vector<ts_text_piece> &sp = subPieces.back();
+            uint64_t at = sg.first, left = sg.second, c2 = cum;
+            for (size_t q = k; left && q < rv.nPieces; ++q) {
+                ts_text_piece t = rv.pieces[q];
+                const uint64_t skip = at - c2;
+                if (skip) {
+                    const char *from = detail::textLocate(t.text, t.text_len, skip);
+                    t.text_len -= static_cast<uint64_t>(from - t.text); t.text = from; t.n_bases -= skip;
+                }
+                const uint64_t n = std::min<uint64_t>(t.n_bases, left);
+                t.n_bases = n;                                                     // (of the last piece only what is needed)
+                sp.push_back(t);
+                at += n; left -= n; c2 += rv.pieces[q].n_bases;
+            }
+            batch.emplace_back(sp.data(), static_cast<size_t>(sg.second), sg.first, ui.ultraFastMode);
+        }
+    }
     // without -m nothing downstream reads a match record: blocks and counts come from the device
     std::vector<ts_segment_counts> counts;
     // (with -m: only the two match vectors the writers read are materialised; block calling has happened on the device)
@@ -354,7 +446,7 @@ inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::ve
 
 inline std::vector<PathData> walkPaths(Teloscope &teloscope, const std::vector<FastaRecord> &records) {
     std::vector<RecordView> views(records.size());
-    for (size_t i = 0; i < records.size(); ++i) views[i] = RecordView{&records[i].header, records[i].sequence.data(), records[i].sequence.size()};
+    for (size_t i = 0; i < records.size(); ++i) views[i] = RecordView{&records[i].header, records[i].sequence.data(), records[i].sequence.size(), nullptr, 0};
     return walkRecordViews(teloscope, views, 0);
 }
 
@@ -1235,8 +1327,9 @@ inline char *copyFastaBases(const char *p, const char *end, char *dst) {
 
 struct RawRecord {                                              // a record of a streamed group
     std::string header;
-    std::unique_ptr<char[]> data;                               // (new char[]: not zero-filled)
-    size_t size = 0;
+    std::unique_ptr<char[]> data;                               // joined bases (new char[]: not zero-filled) — or,
+    std::vector<ts_text_piece> pieces;                          // text mode: the record's body text where the file is mapped
+    size_t size = 0;                                            // bases
 };
 
 struct FastaGroup {
@@ -1257,13 +1350,19 @@ class FastaGroupReader {
     std::vector<Span> spans;
     size_t nextSpan = 0;
     size_t groupBytes, pieceBytes;
+    bool textPieces;                                            // records as text pieces (line ends skipped by the library's staging)
     std::vector<FastaRecord> all;                               // not a mapped plain file: everything was read up front
     bool mapped = false;
 
 public:
-    // pieceBytes: text bytes a host thread joins at a time (a record's lines are joined by pieces, in parallel)
-    explicit FastaGroupReader(const std::string &file, size_t groupBytes_ = size_t(256) << 20, size_t pieceBytes_ = size_t(4) << 20)
-        : groupBytes(std::max<size_t>(groupBytes_, 1)), pieceBytes(std::max<size_t>(pieceBytes_, 1)) {
+    // pieceBytes: text bytes a host thread handles at a time (a record's lines are counted / joined by pieces, in parallel).
+    // textPieces: do not join the lines at all — a record is the list of its text pieces in the mapped file, with their
+    // base counts and N-runs (one pass over the text); the library strips the line ends while it stages the upload
+    // (TS_INPUT_TEXT_PIECES).  Only for a mapped plain file; gzip / stdin input is joined by zlib's reader anyway.
+    explicit FastaGroupReader(const std::string &file, size_t groupBytes_ = size_t(256) << 20, size_t pieceBytes_ = size_t(4) << 20,
+                              bool textPieces_ = false)
+        : groupBytes(std::max<size_t>(groupBytes_, 1)), pieceBytes(std::min<size_t>(std::max<size_t>(pieceBytes_, 1), size_t(16) << 20)),
+          textPieces(textPieces_) {
         fd = ::open(file.c_str(), O_RDONLY);
         if (fd < 0) throw std::runtime_error("cannot open " + file);
         struct stat sb;
@@ -1351,6 +1450,23 @@ public:
                 a = z;
             }
         }
+        if (textPieces) {
+            // ONE pass over the text: every piece's base count and N-runs; nothing is copied
+            detail::onThreads(pieces.size(), [&](size_t i) {
+                Piece &p = pieces[i];
+                uint64_t nb = 0;
+                p.pc = detail::splitPathText(p.a, p.z, &nb, &p.firstIsGap, &p.lastIsGap);
+                p.bases = static_cast<size_t>(nb);
+            });
+            for (size_t i = 0; i < pieces.size(); ++i) {
+                Piece &p = pieces[i];
+                p.at = g.records[p.rec].size;
+                g.records[p.rec].size += p.bases;
+                for (auto &sg : p.pc.segments) sg.first += p.at;
+                for (GapInfo &gp : p.pc.gaps) gp.start += p.at;
+                if (p.bases) g.records[p.rec].pieces.push_back(ts_text_piece{p.a, static_cast<uint64_t>(p.z - p.a), static_cast<uint64_t>(p.bases)});
+            }
+        } else {
         detail::onThreads(pieces.size(), [&](size_t i) { pieces[i].bases = detail::countFastaBases(pieces[i].a, pieces[i].z); });
         for (size_t i = 0; i < pieces.size(); ++i) {
             pieces[i].at = g.records[pieces[i].rec].size;
@@ -1370,6 +1486,7 @@ public:
             p.firstIsGap = isGap(dst[0]);
             p.lastIsGap = isGap(dst[p.bases - 1]);
         });
+        }
         g.comps.resize(nrec);
         std::vector<int> prevLast(nrec, -1);                      // -1: no bases of the record yet
         for (const Piece &p : pieces) {
@@ -1386,7 +1503,9 @@ struct ScanFastaTimes { double read_ms = 0, scan_ms = 0, write_ms = 0, wall_ms =
 // FASTA file -> the eleven output files + console path report; returns the totals for printSummary.
 inline AssemblySummary scanFastaToFiles(Teloscope &teloscope, const std::string &fastaFile, const std::string &outBase,
                                         std::ostream &console, bool manualCuration = false,
-                                        size_t groupBytes = size_t(256) << 20, ScanFastaTimes *times = nullptr) {
+                                        size_t groupBytes = size_t(256) << 20, ScanFastaTimes *times = nullptr,
+                                        size_t pieceBytes = size_t(4) << 20, int textPieces = -1) {
+    // textPieces: -1 = whenever the library takes text input for this parameter set (the tiled kernel's), 0 / 1 = forced
     using Clock = std::chrono::steady_clock;
     auto ms = [](Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t_begin = Clock::now();
@@ -1398,7 +1517,8 @@ inline AssemblySummary scanFastaToFiles(Teloscope &teloscope, const std::string 
 
     std::thread reader([&] {
         try {
-            FastaGroupReader rd(fastaFile, groupBytes);
+            const bool text = textPieces < 0 ? teloscope.takesTextPieces() : textPieces != 0;
+            FastaGroupReader rd(fastaFile, groupBytes, pieceBytes, text);
             detail::FastaGroup g;
             for (;;) {
                 const auto t0 = Clock::now();
@@ -1415,8 +1535,10 @@ inline AssemblySummary scanFastaToFiles(Teloscope &teloscope, const std::string 
             while (toScan.pop(g)) {
                 const auto t0 = Clock::now();
                 std::vector<RecordView> views;
-                for (const detail::RawRecord &r : g.records) views.push_back(RecordView{&r.header, r.data.get(), r.size});
-                for (const FastaRecord &r : g.owned) views.push_back(RecordView{&r.header, r.sequence.data(), r.sequence.size()});
+                for (const detail::RawRecord &r : g.records)
+                    views.push_back(r.pieces.empty() && r.size ? RecordView{&r.header, r.data.get(), r.size, nullptr, 0}
+                                                               : RecordView{&r.header, nullptr, r.size, r.pieces.data(), r.pieces.size()});
+                for (const FastaRecord &r : g.owned) views.push_back(RecordView{&r.header, r.sequence.data(), r.sequence.size(), nullptr, 0});
                 Scanned s;
                 s.paths = walkRecordViews(teloscope, views, g.firstRecord, g.owned.empty() ? &g.comps : nullptr);
                 s.group = std::move(g);                           // (-m: matchSeq was copied out of the bases already)

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Rows f2 + f3 at scale: FASTA text in, all window/block files out, for a synthetic assembly (default 3 Gb:
 # 60 x 50 Mb records, 80-column lines) through the C++ mirror (tests/cpp/manifest_cli.cpp on
-# include/teloscope_mi355x_io.hpp): the streaming pipeline (scanFastaToFiles) and the three-phase path.
+# include/teloscope_mi355x_io.hpp): the streaming pipeline (scanFastaToFiles: text pieces, lines never joined; and with
+# lines joined on the host) and the three-phase path.
 # Run on the GPU box:  profiles/writers_rate.sh [records] [Mb per record]
 set -e
 cd "$(dirname "$0")/.."
@@ -35,6 +36,9 @@ for run in 1 2; do
   echo "# streaming (scanFastaToFiles), run $run"
   TS_TIMING=1 /tmp/manifest_cli -f /tmp/writers_rate.fa --out-base /tmp/writers_rate $FLAGS 2>&1 >/tmp/writers_rate.stdout | grep -E "manifest_cli|ts_scan_segments"
 done
+echo "# streaming, records joined on the host (--join-lines)"
+TS_TIMING=1 /tmp/manifest_cli -f /tmp/writers_rate.fa --out-base /tmp/writers_rate_j --join-lines $FLAGS 2>&1 >/tmp/writers_rate_j.stdout | grep -E "manifest_cli"
+for f in /tmp/writers_rate_j_*; do cmp $f /tmp/writers_rate_${f#/tmp/writers_rate_j_} || echo "DIFFERS: $f"; done
 echo "# three phases (readFasta, walkPaths, writeBEDFiles)"
 TS_TIMING=1 /tmp/manifest_cli -f /tmp/writers_rate.fa --out-base /tmp/writers_rate_3p --no-stream $FLAGS 2>&1 >/tmp/writers_rate_3p.stdout | grep -E "manifest_cli"
 cmp /tmp/writers_rate.stdout /tmp/writers_rate_3p.stdout && echo "# console text identical"

@@ -58,7 +58,11 @@ class Block(C.Structure):
 
 class SegmentIn(C.Structure):
     _fields_ = [("seq", C.c_char_p), ("len", C.c_uint64), ("abs_pos", C.c_uint64),
-                ("tips_only", C.c_uint8), ("reserved", C.c_uint8 * 7)]
+                ("tips_only", C.c_uint8), ("input_format", C.c_uint8), ("reserved", C.c_uint8 * 6)]
+
+
+class TextPiece(C.Structure):
+    _fields_ = [("text", C.c_char_p), ("text_len", C.c_uint64), ("n_bases", C.c_uint64)]
 
 
 class SegmentOut(C.Structure):
@@ -109,7 +113,7 @@ SYMBOLS = [
     "ts_batch_matches_ptr", "ts_batch_download", "ts_batch_download_blocks", "ts_batch_segment_summary",
     "ts_batch_get_tiles", "ts_batch_range_info", "ts_batch_partition", "ts_batch_restrict", "ts_batch_bind_results",
     "ts_batch_export", "ts_batch_adopt", "ts_batch_tile_stats_ptr", "ts_filter_reads_multi", "ts_batch_read_pass",
-    "ts_batch_wire16_ok", "ts_wire_widen_u16",
+    "ts_batch_wire16_ok", "ts_wire_widen_u16", "ts_takes_text_input",
 ]
 
 
@@ -179,6 +183,7 @@ def lib():
     L.ts_create_read_filter.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(Pattern), C.c_size_t]
     L.ts_destroy.argtypes = [C.c_void_p]
     L.ts_uses_fast_path.argtypes = [C.c_void_p]
+    L.ts_takes_text_input.argtypes = [C.c_void_p, C.c_int]
     L.ts_scan_segments.argtypes = [C.c_void_p, C.POINTER(SegmentIn), C.c_size_t, C.POINTER(SegmentOut)]
     L.ts_scan_segments_blocks.argtypes = [C.c_void_p, C.POINTER(SegmentIn), C.c_size_t, C.POINTER(SegmentOut),
                                           C.POINTER(SegmentCounts)]

@@ -545,6 +545,11 @@ int ts_uses_fast_path(const ts_ctx *ctx) {
     return ctx && ts_full_scan_supported(ctx, why) ? 1 : 0;
 }
 
+int ts_takes_text_input(const ts_ctx *ctx, int tips_only) {
+    std::string why;
+    return ctx && (tips_only ? ctx->fast_ok : ts_full_scan_supported(ctx, why)) ? 1 : 0;
+}
+
 // =========================================================================== batches
 // Planning is host work only (it also runs on a planning-only context); device state is allocated from the
 // context's pool when the batch first needs it.

@@ -80,7 +80,7 @@ private:
 
 enum class Mode { Matches, Blocks, ReadPass };
 
-struct Item { const char *seq; uint64_t len, abs_pos; };
+struct Item { const char *seq; uint64_t len, abs_pos; uint8_t format; };     // format: TS_INPUT_BASES / TS_INPUT_TEXT_PIECES (seq = ts_text_piece[])
 
 struct Group {
     size_t first = 0, count = 0;                  // items [first, first + count) of the call's item list
@@ -101,88 +101,113 @@ int ensure_streams(ts_ctx *c) {
     return TS_OK;
 }
 
-struct UpPiece { uint64_t off; const char *src; uint64_t len; };            // off: byte offset in the input layout
+struct UpPiece { uint64_t off; const char *src; uint64_t len; uint64_t text_len; };   // off: byte offset in the input layout; len: bases;
+                                                                                     // text_len != 0: src is FASTA text (line ends to skip)
 
-// Uploads pieces of an input layout to the device buffer that holds its bytes [lo, hi) (din = address of byte lo).
-// Dense layouts (full scans, reads) are mirrored chunk by chunk in a ring of pinned buffers, each chunk leaving by
-// ONE DMA while the next is being filled by several memcpy threads (one memcpy stream fills pinned memory at
-// ~10 GB/s, a fraction of what the link moves; one copy per read would cost ~10 us each, one pageable 3 GB copy
-// ~0.5 s).  Sparse layouts (tips-only regions of long contigs) go piece by piece.  Bytes between pieces are never
-// read as bases (the kernels mask everything past a region's end).  Asynchronous: the DMAs are queued on up_stream.
-// `pieces` ascend by offset and do not overlap.
-int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces, void *din, uint64_t lo_all, uint64_t hi_all, int &slot, bool used[]) {
-    uint64_t piece_bytes = 0;
-    for (const UpPiece &pc : pieces) piece_bytes += pc.len;
-    constexpr size_t kChunk = 32u << 20;
-    const uint64_t span = hi_all - lo_all;
-    const bool dense = piece_bytes * 2 >= span || pieces.size() > 4096;
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nthr = std::min(8u, std::max(1u, hw / 2u));
-    auto stage = [&](std::vector<std::pair<char *, UpPiece>> &work, size_t bytes) {   // work: (pinned destination, piece part)
-        const unsigned nt = bytes >= (4u << 20) ? nthr : 1u;
-        if (nt == 1u) {
-            for (auto &w : work) std::memcpy(w.first, w.second.src, w.second.len);
-            return;
-        }
-        // thread t copies the bytes [t, t+1) * share of the concatenated parts
-        const size_t share = (bytes + nt - 1) / nt;
-        std::vector<std::thread> pool;
-        pool.reserve(nt);
-        for (unsigned t = 0; t < nt; ++t)
-            pool.emplace_back([&, t] {
-                const size_t lo = (size_t)t * share, hi = std::min(bytes, lo + share);
-                size_t at = 0;
-                for (auto &w : work) {
-                    const size_t a = std::max(lo, at), z = std::min<size_t>(hi, at + w.second.len);
-                    if (z > a) std::memcpy(w.first + (a - at), w.second.src + (a - at), z - a);
-                    at += w.second.len;
-                    if (at >= hi) break;
-                }
-            });
-        for (std::thread &th : pool) th.join();
-    };
-    std::vector<std::pair<char *, UpPiece>> work;
-    if (dense) {
-        size_t pi = 0;                // first piece that may still have bytes at or beyond the chunk start
-        for (uint64_t c0 = lo_all; c0 < hi_all; c0 += kChunk) {
-            const uint64_t c1 = std::min<uint64_t>(c0 + kChunk, hi_all);
-            while (pi < pieces.size() && pieces[pi].off + pieces[pi].len <= c0) ++pi;
-            if (pi == pieces.size()) break;
-            if (pieces[pi].off >= c1) continue;
-            if (used[slot]) HIP_TRY(c, hipEventSynchronize(c->pin_up_ev[slot]));
-            char *dst = (char *)c->pin_up[slot].p;
-            work.clear();
-            size_t bytes = 0;
-            uint64_t lo = c1, hi = c0;                                          // bytes of the chunk that carry bases
-            for (size_t i = pi; i < pieces.size() && pieces[i].off < c1; ++i) {
-                const uint64_t s0 = std::max(pieces[i].off, c0), s1 = std::min(pieces[i].off + pieces[i].len, c1);
-                if (s1 <= s0) continue;
-                work.push_back({dst + (s0 - c0), UpPiece{s0, pieces[i].src + (s0 - pieces[i].off), s1 - s0}});
-                bytes += s1 - s0;
-                lo = std::min(lo, s0); hi = std::max(hi, s1);
-            }
-            stage(work, bytes);
-            HIP_TRY(c, hipMemcpyAsync((char *)din + (lo - lo_all), dst + (lo - c0), hi - lo, hipMemcpyHostToDevice, c->up_stream));
-            HIP_TRY(c, hipEventRecord(c->pin_up_ev[slot], c->up_stream));
-            used[slot] = true;
-            slot = (slot + 1) % ts_ctx::kUpSlots;
-        }
-    } else {
-        for (const UpPiece &pc : pieces) {
-            for (uint64_t a = 0; a < pc.len; a += kChunk) {
-                const uint64_t n = std::min<uint64_t>(kChunk, pc.len - a);
-                if (used[slot]) HIP_TRY(c, hipEventSynchronize(c->pin_up_ev[slot]));
-                char *dst = (char *)c->pin_up[slot].p;
-                work.clear();
-                work.push_back({dst, UpPiece{pc.off + a, pc.src + a, n}});
-                stage(work, n);
-                HIP_TRY(c, hipMemcpyAsync((char *)din + (pc.off + a - lo_all), dst, n, hipMemcpyHostToDevice, c->up_stream));
-                HIP_TRY(c, hipEventRecord(c->pin_up_ev[slot], c->up_stream));
-                used[slot] = true;
-                slot = (slot + 1) % ts_ctx::kUpSlots;
-            }
+// the bases of a run of FASTA body text, without its line ends ('\n', and a '\r' right before one or at the very end)
+bool strip_copy(char *dst, const char *text, uint64_t text_len, uint64_t n_bases) {
+    const char *p = text, *end = text + text_len;
+    uint64_t left = n_bases;
+    while (left && p < end) {
+        const char *nl = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+        const char *stop = nl ? nl : end;
+        uint64_t line = (uint64_t)(stop - p);
+        if (line && stop[-1] == '\r') --line;
+        const uint64_t take = std::min(line, left);
+        std::memcpy(dst, p, take);
+        dst += take; left -= take;
+        p = nl ? nl + 1 : end;
+    }
+    return left == 0;
+}
+
+// text position of base `skip` of a text piece (skip < its n_bases)
+const char *text_locate(const char *text, uint64_t text_len, uint64_t skip) {
+    const char *p = text, *end = text + text_len;
+    while (p < end) {
+        const char *nl = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+        const char *stop = nl ? nl : end;
+        uint64_t line = (uint64_t)(stop - p);
+        if (line && stop[-1] == '\r') --line;
+        if (skip < line) return p + skip;
+        skip -= line;
+        p = nl ? nl + 1 : end;
+    }
+    return end;
+}
+
+// Uploads pieces of an input layout to the device buffer that holds its bytes from lo_all on (din = address of byte
+// lo_all).  Consecutive pieces that lie close together in the layout (full scans, reads: a few padding bytes apart) are
+// mirrored together in one of three pinned 32 MB buffers, filled by several host threads — plain bases by memcpy, FASTA
+// text by a copy that skips the line ends — and leave by ONE DMA while the next buffer is being filled (one memcpy
+// stream fills pinned memory at ~10 GB/s, a fraction of what the link moves; one copy per read would cost ~10 us each,
+// one pageable 3 GB copy ~0.5 s).  Pieces far apart (the two terminal regions of a long contig in tips-only mode) go
+// separately.  Bytes between pieces are never read as bases (the kernels mask everything past a region's end).
+// Asynchronous: the DMAs are queued on up_stream.  `pieces` ascend by offset and do not overlap.
+int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, uint64_t lo_all, int &slot, bool used[]) {
+    constexpr uint64_t kChunk = 32u << 20, kMaxGap = 64u << 10;
+    std::vector<UpPiece> pieces;
+    pieces.reserve(pieces_in.size());
+    bool any_text = false;
+    for (const UpPiece &pc : pieces_in) {
+        if (pc.text_len) {
+            if (pc.len > kChunk) return c->fail(TS_ERR_INVALID_ARG, "a text piece holds more than 32 MiB of bases");
+            pieces.push_back(pc);
+            any_text = true;
+        } else {
+            for (uint64_t a = 0; a < pc.len; a += kChunk) pieces.push_back({pc.off + a, pc.src + a, std::min<uint64_t>(kChunk, pc.len - a), 0});
         }
     }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nthr = std::min(8u, std::max(1u, hw / 2u));
+    std::atomic<int> bad_text{0};
+    size_t i = 0;
+    while (i < pieces.size()) {
+        const uint64_t c0 = pieces[i].off;
+        size_t j = i + 1;
+        uint64_t bytes = pieces[i].len;
+        while (j < pieces.size() && pieces[j].off + pieces[j].len - c0 <= kChunk &&
+               pieces[j].off - (pieces[j - 1].off + pieces[j - 1].len) <= kMaxGap) { bytes += pieces[j].len; ++j; }
+        if (used[slot]) HIP_TRY(c, hipEventSynchronize(c->pin_up_ev[slot]));
+        char *dst = (char *)c->pin_up[slot].p;
+        const unsigned nt = bytes >= (4u << 20) ? nthr : 1u;
+        auto copy_part = [&](size_t k) {
+            const UpPiece &pc = pieces[k];
+            if (pc.text_len) { if (!strip_copy(dst + (pc.off - c0), pc.src, pc.text_len, pc.len)) bad_text.store(1); }
+            else std::memcpy(dst + (pc.off - c0), pc.src, pc.len);
+        };
+        if (nt == 1u) {
+            for (size_t k = i; k < j; ++k) copy_part(k);
+        } else if (any_text) {                                   // whole parts, handed out dynamically
+            std::atomic<size_t> next{i};
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; ++t) pool.emplace_back([&] { for (size_t k; (k = next.fetch_add(1)) < j;) copy_part(k); });
+            for (std::thread &th : pool) th.join();
+        } else {                                                 // thread t copies the bytes [t, t+1) * share of the concatenated parts
+            const size_t share = (bytes + nt - 1) / nt;
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; ++t)
+                pool.emplace_back([&, t] {
+                    const size_t lo = (size_t)t * share, hi = std::min<size_t>(bytes, lo + share);
+                    size_t at = 0;
+                    for (size_t k = i; k < j; ++k) {
+                        const UpPiece &pc = pieces[k];
+                        const size_t a = std::max(lo, at), z = std::min<size_t>(hi, at + pc.len);
+                        if (z > a) std::memcpy(dst + (pc.off - c0) + (a - at), pc.src + (a - at), z - a);
+                        at += pc.len;
+                        if (at >= hi) break;
+                    }
+                });
+            for (std::thread &th : pool) th.join();
+        }
+        const uint64_t hi = pieces[j - 1].off + pieces[j - 1].len;
+        HIP_TRY(c, hipMemcpyAsync((char *)din + (c0 - lo_all), dst, hi - c0, hipMemcpyHostToDevice, c->up_stream));
+        HIP_TRY(c, hipEventRecord(c->pin_up_ev[slot], c->up_stream));
+        used[slot] = true;
+        slot = (slot + 1) % ts_ctx::kUpSlots;
+        i = j;
+    }
+    if (bad_text.load()) return c->fail(TS_ERR_INVALID_ARG, "a text piece holds fewer bases than it declares");
     return TS_OK;
 }
 
@@ -197,12 +222,29 @@ int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
         const SegPlan &sp = b->segs[i];
         for (const Region &rg : sp.regions) {
             // (consecutive regions of one segment never overlap: tips regions are [0,t) and [N-t,N) with N > 2t)
-            const uint64_t s0 = std::max<uint64_t>(sp.in_off + rg.start, b->in_lo);
-            const uint64_t s1 = std::min<uint64_t>(sp.in_off + rg.start + rg.len, b->in_hi);
-            if (s1 > s0) pieces.push_back({s0, items[i].seq + (s0 - sp.in_off), s1 - s0});
+            if (items[i].format == TS_INPUT_TEXT_PIECES) {
+                // the region's bases [rg.start, rg.start + rg.len) out of the segment's text pieces
+                const ts_text_piece *tp = (const ts_text_piece *)items[i].seq;
+                uint64_t cum = 0, want = rg.start, left = rg.len, off = sp.in_off + rg.start;
+                for (size_t k = 0; left; ++k) {
+                    if (cum >= sp.len) return c->fail(TS_ERR_INVALID_ARG, "text pieces hold fewer bases than the segment's length");
+                    const ts_text_piece &t = tp[k];
+                    if (t.text_len > (16ull << 20) + 4096) return c->fail(TS_ERR_INVALID_ARG, "a text piece is larger than 16 MiB");
+                    if (want >= cum + t.n_bases) { cum += t.n_bases; continue; }      // wholly before the region
+                    const uint64_t skip = want - cum;
+                    const char *from = skip ? text_locate(t.text, t.text_len, skip) : t.text;
+                    const uint64_t n = std::min<uint64_t>(t.n_bases - skip, left);
+                    pieces.push_back({off, from, n, (uint64_t)(t.text + t.text_len - from)});
+                    off += n; left -= n; want += n; cum += t.n_bases;
+                }
+            } else {
+                const uint64_t s0 = std::max<uint64_t>(sp.in_off + rg.start, b->in_lo);
+                const uint64_t s1 = std::min<uint64_t>(sp.in_off + rg.start + rg.len, b->in_hi);
+                if (s1 > s0) pieces.push_back({s0, items[i].seq + (s0 - sp.in_off), s1 - s0, 0});
+            }
         }
     }
-    return upload_pieces(c, pieces, din, b->in_lo, b->in_hi, slot, used);
+    return upload_pieces(c, pieces, din, b->in_lo, slot, used);
 }
 
 // The terminal-block predicate of a scanned tips batch on the device: one byte per read
@@ -421,6 +463,9 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     if (!c->generic_ok)
         return c->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: more than 8 pattern lengths, a pattern longer "
                                            "than 32 or a non-ACGT pattern");
+    for (size_t i : which)
+        if (segs[i].input_format != TS_INPUT_BASES)
+            return c->fail(TS_ERR_UNSUPPORTED, "text-piece input is taken by the tiled kernel's parameter sets only: join the lines for this one");
     DEVICE_TRY(c);
     { int rc = ensure_streams(c); if (rc != TS_OK) return rc; }
     const ts_params &P = c->params;
@@ -459,7 +504,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
             sl.first_tile = tiles.size();
             for (RegionL &rg : sl.regions) {
                 rg.layout_off = off;
-                pieces.push_back({off, sg.seq + rg.seg_start, rg.len});
+                pieces.push_back({off, sg.seq + rg.seg_start, rg.len, 0});
                 for (uint64_t a = 0; a < rg.len; a += TS_GENERAL_TILE) {
                     TsGeneralTile T{};
                     T.in_off = off + a;
@@ -497,7 +542,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         for (size_t i = 0; i < ns; ++i) { tab[i] = G[i].len; tab[ns + i] = G[i].layout_off; tab[2 * ns + i] = G[i].win_base; }
         tab[3 * ns] = nwin_total;
         const auto t0 = Clock::now();
-        { int rc = upload_pieces(c, pieces, d_in.p, 0, off, slot, used); if (rc != TS_OK) return rc; }
+        { int rc = upload_pieces(c, pieces, d_in.p, 0, slot, used); if (rc != TS_OK) return rc; }
         HIP_TRY(c, hipMemcpyAsync(d_tiles.p, tiles.data(), nt * sizeof(TsGeneralTile), hipMemcpyHostToDevice, c->up_stream));
         HIP_TRY(c, hipMemcpyAsync(d_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->up_stream));
         HIP_TRY(c, hipStreamSynchronize(c->up_stream));
@@ -608,7 +653,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
 
 std::vector<Item> items_of(const ts_segment_in *segs, const std::vector<size_t> &which) {
     std::vector<Item> v(which.size());
-    for (size_t i = 0; i < which.size(); ++i) v[i] = Item{segs[which[i]].seq, segs[which[i]].len, segs[which[i]].abs_pos};
+    for (size_t i = 0; i < which.size(); ++i) v[i] = Item{segs[which[i]].seq, segs[which[i]].len, segs[which[i]].abs_pos, segs[which[i]].input_format};
     return v;
 }
 
@@ -634,6 +679,7 @@ int scan_segments_unlocked(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs
     for (size_t i = 0; i < n_segs; ++i) {
         std::memset(&out[i], 0, sizeof out[i]);
         if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
+        if (segs[i].input_format > TS_INPUT_TEXT_PIECES) return ctx->fail(TS_ERR_INVALID_ARG, "unknown input_format");
     }
     std::vector<size_t> full, tips;
     for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
@@ -708,7 +754,7 @@ int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
         uint64_t n = lens[i];
         if (n && !seqs[i]) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
         if (n && seqs[i][n - 1] == '\r') --n;             // src/read-filter.cpp:38-40
-        items[i] = Item{seqs[i], n, 0};
+        items[i] = Item{seqs[i], n, 0, TS_INPUT_BASES};
     }
     if (!ctx->fast_ok) {
         // pattern sets outside the tiled kernel (mixed lengths, k > 8): general kernels + host block calling.

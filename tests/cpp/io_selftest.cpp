@@ -99,6 +99,39 @@ int main(int argc, char **argv) {
                 }
                 check(at == a.size(), "streamed record count");
             }
+        // text mode (no lines joined: a record = its text pieces in the mapped file + base counts + N-runs): the pieces
+        // must hold exactly the record's bases, the components must equal splitPath of the joined record, and any base
+        // range must read back out of the pieces (what -m's matchSeq and the N-cut segments rely on)
+        for (size_t pieceBytes : {size_t(1), size_t(53), size_t(4) << 20}) {
+            FastaGroupReader rd(plain, 900, pieceBytes, true);
+            detail::FastaGroup g;
+            size_t at = 0;
+            while (rd.next(g)) {
+                for (size_t ri = 0; ri < g.records.size(); ++ri, ++at) {
+                    const detail::RawRecord &r = g.records[ri];
+                    check(at < a.size() && r.header == a[at].header && r.size == a[at].sequence.size(), "text record size");
+                    if (at >= a.size()) continue;
+                    uint64_t sum = 0;
+                    for (const ts_text_piece &t : r.pieces) sum += t.n_bases;
+                    check(sum == r.size, "text pieces hold the record's bases");
+                    const PathComponents want = splitPath(a[at].sequence);
+                    check(g.comps[ri].segments == want.segments && g.comps[ri].gaps.size() == want.gaps.size(), "text components");
+                    for (size_t q = 0; q < want.gaps.size() && q < g.comps[ri].gaps.size(); ++q)
+                        check(g.comps[ri].gaps[q].start == want.gaps[q].start && g.comps[ri].gaps[q].length == want.gaps[q].length, "text gap");
+                    if (r.size) {
+                        const Teloscope::Segment seg(r.pieces.data(), r.size, 0, false);
+                        for (int probe = 0; probe < 6; ++probe) {
+                            const uint64_t pos = rng() % r.size, n = 1 + rng() % std::min<uint64_t>(r.size - pos, 200);
+                            std::string want2 = a[at].sequence.substr(pos, n);
+                            for (char &ch : want2) if (ch >= 'a' && ch <= 'z') ch = static_cast<char>(ch - 32);
+                            check(seg.bases(pos, n) == want2, "bases out of text pieces");
+                            check(*detail::textLocate(r.pieces[0].text, r.pieces[0].text_len, 0) == a[at].sequence[0] || r.pieces[0].n_bases == 0, "textLocate");
+                        }
+                    }
+                }
+            }
+            check(at == a.size(), "text record count");
+        }
     }
     // ---- splitFastqRecords (pieces parsed in parallel) against the sequential piece parser on awkward FASTQ texts
     size_t accepted = 0, offered = 0;

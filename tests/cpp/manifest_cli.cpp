@@ -11,6 +11,8 @@
 //        [--reads-per-batch n]   reads per GPU batch of --fastq-subset / --bam-subset (test hook)
 //        [--no-stream]           readFasta, then walkPaths, then writeBEDFiles (default: the three overlap in
 //                                scanFastaToFiles, records flowing in groups)   [--group-bytes n: group size, test hook]
+//        [--join-lines]          streaming, but a record's lines are joined on the host (default: text pieces — the
+//                                library strips the line ends while staging)     [--piece-bytes n: test hook]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -28,8 +30,9 @@ int main(int argc, char **argv) {
     UserInputTeloscope ui;
     std::string input, canonical, outBase;
     bool scratch = false, manualCuration = false, fastqSubsetMode = false, bamSubsetMode = false;
-    size_t fastqBlock = 512u << 20, readsPerBatch = 1u << 20, groupBytes = size_t(256) << 20;
+    size_t fastqBlock = 512u << 20, readsPerBatch = 1u << 20, groupBytes = size_t(256) << 20, pieceBytes = size_t(4) << 20;
     bool stream = true;
+    int textPieces = -1;
     std::vector<int> readDevices;
     std::vector<std::string> rawPatterns;
     bool hasPatterns = false;
@@ -43,6 +46,8 @@ int main(int argc, char **argv) {
         else if (a == "--out-base") outBase = val();
         else if (a == "--no-stream") stream = false;
         else if (a == "--group-bytes") groupBytes = static_cast<size_t>(std::stoull(val()));
+        else if (a == "--piece-bytes") pieceBytes = static_cast<size_t>(std::stoull(val()));   // test hook: text bytes per piece
+        else if (a == "--join-lines") textPieces = 0;                                            // streaming, but records joined on the host
         else if (a == "--reads-per-batch") readsPerBatch = static_cast<size_t>(std::stoull(val()));
         else if (a == "--read-devices") {
             std::istringstream ds(val());
@@ -116,7 +121,7 @@ int main(int argc, char **argv) {
         const auto t0 = now();
         if (stream) {
             ScanFastaTimes T;
-            const AssemblySummary summary = scanFastaToFiles(teloscope, input, outBase, std::cout, manualCuration, groupBytes, &T);
+            const AssemblySummary summary = scanFastaToFiles(teloscope, input, outBase, std::cout, manualCuration, groupBytes, &T, pieceBytes, textPieces);
             printSummary(std::cout, summary, ui.ultraFastMode, outBase + "_report.tsv");
             if (timing)
                 fprintf(stderr, "manifest_cli (streaming): %.1f Mb, %llu windows, %zu groups: wall %.0f ms = %.2f Gbases/s; stage sums (the stages "

@@ -58,8 +58,9 @@ def test_output_files_match_the_reference_formats(cli, tmp_path, name, flags):  
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,flags", [("multi.fa", "-r -g -e -m -i"), ("multi_gap_t2t.fa", "-w 500 -s 250 -r -g -e -i"),
-                                        ("bTaeGut7_chr33_mat.fa.gz", "-r -i"), ("multi.fa", "")])
+@pytest.mark.parametrize("name,flags", [("multi.fa", "-r -g -e -m -i"), ("multi_gap_t2t.fa", "-w 500 -s 250 -r -g -e -m -i"),
+                                        ("bTaeGut7_chr33_mat.fa.gz", "-r -i"), ("multi.fa", ""), ("gapped_t2t.fa", "-t 300"),
+                                        ("multi_gap_t2t.fa", "-p TTAGGG,TTAGG -r -g -i")])
 def test_streaming_pipeline_equals_three_phase_path(cli, tmp_path, name, flags):  # noqa: F811
     """scanFastaToFiles (records flowing in groups through read / scan / write stages that overlap) against
     readFasta + walkPaths + writeBEDFiles: the same files and the same console text, byte for byte, for groups of
@@ -68,15 +69,18 @@ def test_streaming_pipeline_equals_three_phase_path(cli, tmp_path, name, flags):
     ref_base = str(tmp_path / "ref")
     ref = subprocess.run([cli, "-f", fasta, "--out-base", ref_base, "--no-stream"] + shlex.split(flags), capture_output=True, timeout=300)
     assert ref.returncode == 0, ref.stderr
-    for group in ("1", "5000", str(1 << 30)):
-        base = str(tmp_path / ("g" + group))
-        got = subprocess.run([cli, "-f", fasta, "--out-base", base, "--group-bytes", group] + shlex.split(flags), capture_output=True, timeout=300)
+    # groups of one record, of a few, of the whole file; records as text pieces (the library strips the line ends while
+    # staging; tiny pieces, so that every record and every N-cut segment is stitched from many) and joined on the host
+    for group, extra in (("1", ["--piece-bytes", "61"]), ("5000", ["--piece-bytes", "1000"]), (str(1 << 30), []),
+                         ("5000", ["--join-lines"]), (str(1 << 30), ["--join-lines", "--piece-bytes", "97"])):
+        base = str(tmp_path / ("g" + group + "_".join(extra)))
+        got = subprocess.run([cli, "-f", fasta, "--out-base", base, "--group-bytes", group] + extra + shlex.split(flags), capture_output=True, timeout=300)
         assert got.returncode == 0, got.stderr
         assert got.stdout == ref.stdout
         for sfx in H.BED_SUFFIXES:
             assert os.path.exists(base + sfx) == os.path.exists(ref_base + sfx), sfx
             if os.path.exists(base + sfx):
-                assert open(base + sfx, "rb").read() == open(ref_base + sfx, "rb").read(), (sfx, group)
+                assert open(base + sfx, "rb").read() == open(ref_base + sfx, "rb").read(), (sfx, group, extra)
 
 
 GAP_BEDS = sorted(glob.glob(os.path.join(H.golden_path("testFiles/expected"), "*_gaps.bed")))
