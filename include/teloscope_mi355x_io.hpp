@@ -1336,6 +1336,7 @@ struct FastaGroup {
     size_t firstRecord = 0;
     std::vector<RawRecord> records;
     std::vector<PathComponents> comps;                          // of `records`, found while their bases were copied
+    std::shared_ptr<void> mapping;                              // text mode: the records' pieces point into the mapped file
     std::vector<FastaRecord> owned;                             // gzip / stdin input: records read the plain way
 };
 
@@ -1347,6 +1348,7 @@ class FastaGroupReader {
     int fd = -1;
     void *map = nullptr;
     size_t mapSize = 0;
+    std::shared_ptr<void> mapping;                              // unmaps when the reader AND every group that points into it are gone
     std::vector<Span> spans;
     size_t nextSpan = 0;
     size_t groupBytes, pieceBytes;
@@ -1379,6 +1381,10 @@ public:
             return;
         }
         mapped = true;
+        {
+            const size_t n = mapSize;
+            mapping = std::shared_ptr<void>(map, [n](void *p) { ::munmap(p, n); });
+        }
         (void)::madvise(map, mapSize, MADV_SEQUENTIAL);
         const char *data = static_cast<const char *>(map), *end = data + mapSize;
         // record starts = '>' at a line start; found by slices of the text in parallel, then put in order
@@ -1403,7 +1409,7 @@ public:
         }
     }
     ~FastaGroupReader() {
-        if (map) ::munmap(map, mapSize);
+        if (map && !mapping) ::munmap(map, mapSize);
         if (fd >= 0) ::close(fd);
     }
     FastaGroupReader(const FastaGroupReader &) = delete;
@@ -1451,6 +1457,7 @@ public:
             }
         }
         if (textPieces) {
+            g.mapping = mapping;
             // ONE pass over the text: every piece's base count and N-runs; nothing is copied
             detail::onThreads(pieces.size(), [&](size_t i) {
                 Piece &p = pieces[i];
