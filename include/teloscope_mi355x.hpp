@@ -121,6 +121,11 @@ inline std::vector<std::pair<std::string, bool>> expandPatternsWithOrientation(
     return out;
 }
 
+// How the lines of a ts_text_piece lie, when they are regular (what a FASTA writer produces): `first` bases on the first
+// line (a piece may be entered mid-line), then lines of `width` bases (the last one may be shorter), every line end `eol`
+// bytes long.  width == 0: irregular — positions are found by walking the lines.
+struct TextLines { uint32_t first = 0, width = 0, eol = 0; };
+
 namespace detail {
 
 struct CtxDeleter { void operator()(ts_ctx *c) const { ts_destroy(c); } };
@@ -252,9 +257,13 @@ public:
         bool tipsOnly;
         const ts_text_piece *pieces = nullptr; // FASTA body text as it lies in the file (TS_INPUT_TEXT_PIECES): the
                                                // library skips the line ends on the way to the device
+        const TextLines *lines = nullptr;      // per piece, optional: lets bases() jump to a position instead of walking lines
+        mutable size_t cursorPiece = 0;        // bases() is asked for ascending positions: where the last answer lay
+        mutable uint64_t cursorCum = 0;
         Segment(const char *d, size_t n, uint64_t a, bool t) : data(d), size(n), absPos(a), tipsOnly(t) {}
         Segment(const std::string *s, uint64_t a, bool t) : data(s->data()), size(s->size()), absPos(a), tipsOnly(t) {}
-        Segment(const ts_text_piece *p, size_t nBases, uint64_t a, bool t) : data(nullptr), size(nBases), absPos(a), tipsOnly(t), pieces(p) {}
+        Segment(const ts_text_piece *p, size_t nBases, uint64_t a, bool t, const TextLines *l = nullptr)
+            : data(nullptr), size(nBases), absPos(a), tipsOnly(t), pieces(p), lines(l) {}
         ts_segment_in in() const {
             ts_segment_in x{};
             x.seq = pieces ? reinterpret_cast<const char *>(pieces) : data;
@@ -268,11 +277,24 @@ public:
             out.reserve(n);
             if (!pieces) out.assign(data + pos, n);
             else {
-                uint64_t cum = 0;
-                for (const ts_text_piece *p = pieces; out.size() < n; ++p) {
-                    if (pos >= cum + p->n_bases) { cum += p->n_bases; continue; }
-                    uint64_t skip = pos > cum ? pos - cum : 0;
-                    const char *q = p->text, *end = p->text + p->text_len;
+                if (pos < cursorCum) { cursorPiece = 0; cursorCum = 0; }
+                size_t k = cursorPiece;
+                uint64_t cum = cursorCum;
+                while (pos >= cum + pieces[k].n_bases) cum += pieces[k++].n_bases;
+                cursorPiece = k; cursorCum = cum;
+                uint64_t skip = pos - cum;
+                for (; out.size() < n; ++k, skip = 0) {
+                    const ts_text_piece &p = pieces[k];
+                    const char *q = p.text, *end = p.text + p.text_len;
+                    if (skip && lines && lines[k].width) {                    // regular lines: jump to the position
+                        const TextLines &L = lines[k];
+                        if (skip >= L.first) {
+                            const uint64_t r = skip - L.first;
+                            q += L.first + L.eol + (r / L.width) * (uint64_t(L.width) + L.eol) + r % L.width;
+                            skip = 0;
+                            // (q may sit at a line's end when r % width == 0 and the line is the last, shorter one: the walk below moves on)
+                        }
+                    }
                     while (q < end && out.size() < n) {                       // line by line
                         const char *nl = static_cast<const char *>(std::memchr(q, '\n', static_cast<size_t>(end - q)));
                         const char *stop = nl ? nl : end;
@@ -282,7 +304,6 @@ public:
                         else skip -= line;
                         q = nl ? nl + 1 : end;
                     }
-                    cum += p->n_bases;
                 }
             }
             for (char &ch : out)

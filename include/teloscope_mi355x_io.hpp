@@ -248,6 +248,7 @@ struct RecordView {
     size_t size;                               // bases
     const ts_text_piece *pieces = nullptr;     // FASTA body text in the file (line ends included), in order
     size_t nPieces = 0;
+    const TextLines *lines = nullptr;          // per piece, optional
 };
 
 namespace detail {
@@ -267,8 +268,10 @@ inline const char *textLocate(const char *text, uint64_t textLen, uint64_t skip)
 }
 
 // splitPath over FASTA body text [p, end) that starts at a line start: runs in BASE coordinates (line ends are
-// skipped, a run goes on across them); *nBases = the bases of the text; firstIsGap / lastIsGap as splitPaths needs them
-inline PathComponents splitPathText(const char *p, const char *end, uint64_t *nBases, bool *firstIsGap, bool *lastIsGap) {
+// skipped, a run goes on across them); *nBases = the bases of the text; firstIsGap / lastIsGap as splitPaths needs them;
+// *lines (optional) = how the lines lie, if they are regular (TextLines)
+inline PathComponents splitPathText(const char *p, const char *end, uint64_t *nBases, bool *firstIsGap, bool *lastIsGap,
+                                    TextLines *lines = nullptr) {
     PathComponents pc;
     auto isGap = [](char c) { return c == 'N' || c == 'n' || c == 'X' || c == 'x'; };
     uint64_t base = 0, runStart = 0;
@@ -279,11 +282,24 @@ inline PathComponents splitPathText(const char *p, const char *end, uint64_t *nB
         if (runGap) pc.gaps.push_back(GapInfo{runStart, static_cast<uint32_t>(at - runStart)});
         else pc.segments.emplace_back(runStart, at - runStart);
     };
+    // line structure: `first` bases on the first line, `width` on every line between the first and the last, the last
+    // at most `width`, every line end `eol` bytes
+    uint64_t nLines = 0, first = 0, width = 0, eol = 0, prevLen = 0, prevEol = 0;
+    bool regular = true;
     while (p < end) {
         const char *nl = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
         const char *stop = nl ? nl : end;
         size_t n = static_cast<size_t>(stop - p);
-        if (n && stop[-1] == '\r') --n;
+        const bool cr = n && stop[-1] == '\r';
+        if (cr) --n;
+        const uint64_t thisEol = (nl ? 1u : 0u) + (cr ? 1u : 0u);
+        if (nLines == 0) { first = n; eol = thisEol; }
+        else {
+            if (prevEol != eol) regular = false;
+            if (nLines == 1) width = n;
+            else if (prevLen != width) regular = false;                     // the previous line turned out to be a middle one
+        }
+        prevLen = n; prevEol = thisEol; ++nLines;
         size_t i = 0;
         while (i < n) {
             const bool gap = isGap(p[i]);
@@ -297,6 +313,15 @@ inline PathComponents splitPathText(const char *p, const char *end, uint64_t *nB
     }
     close(base);
     *nBases = base;
+    if (lines) {
+        *lines = TextLines{};
+        if (nLines >= 3 && prevLen > width) regular = false;
+        if (nLines == 1) width = first;
+        if (width == 0) width = 1;
+        if (eol == 0) eol = 1;
+        if (regular && nLines >= 1 && first < (1u << 31) && width < (1u << 31))
+            *lines = TextLines{static_cast<uint32_t>(first), static_cast<uint32_t>(width), static_cast<uint32_t>(eol)};
+    }
     return pc;
 }
 
@@ -365,7 +390,9 @@ inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::ve
     for (size_t pi = 0; pi < records.size(); ++pi)
         if (records[pi].pieces && !oneSegment(pi)) nSub += comps[pi].segments.size();
     std::vector<std::vector<ts_text_piece>> subPieces;
+    std::vector<std::vector<TextLines>> subLines;
     subPieces.reserve(nSub);
+    subLines.reserve(nSub);
     for (size_t pi = 0; pi < records.size(); ++pi) {
         const RecordView &rv = records[pi];
         if (!rv.pieces) {
@@ -374,7 +401,7 @@ inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::ve
             continue;
         }
         if (oneSegment(pi)) {
-            batch.emplace_back(rv.pieces, rv.size, 0, ui.ultraFastMode);          // its pieces as they are
+            batch.emplace_back(rv.pieces, rv.size, 0, ui.ultraFastMode, rv.lines);   // its pieces as they are
             continue;
         }
         // a segment = bases [a, a + n) of the record: the text pieces that hold them, the first one entered at base a
@@ -383,21 +410,31 @@ inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::ve
         for (const auto &sg : comps[pi].segments) {
             while (k < rv.nPieces && cum + rv.pieces[k].n_bases <= sg.first) cum += rv.pieces[k++].n_bases;
             subPieces.emplace_back();
+            subLines.emplace_back();
             std::vector<ts_text_piece> &sp = subPieces.back();
+            std::vector<TextLines> &sl = subLines.back();
             uint64_t at = sg.first, left = sg.second, c2 = cum;
             for (size_t q = k; left && q < rv.nPieces; ++q) {
                 ts_text_piece t = rv.pieces[q];
+                TextLines L = rv.lines ? rv.lines[q] : TextLines{};
                 const uint64_t skip = at - c2;
                 if (skip) {
                     const char *from = detail::textLocate(t.text, t.text_len, skip);
                     t.text_len -= static_cast<uint64_t>(from - t.text); t.text = from; t.n_bases -= skip;
+                    if (L.width) {                                                 // entered mid-line: what is left of that line comes first
+                        const char *nl = static_cast<const char *>(std::memchr(from, '\n', static_cast<size_t>(t.text_len)));
+                        uint64_t rest = static_cast<uint64_t>((nl ? nl : from + t.text_len) - from);
+                        if (rest && from[rest - 1] == '\r') --rest;
+                        L.first = static_cast<uint32_t>(rest);
+                    }
                 }
                 const uint64_t n = std::min<uint64_t>(t.n_bases, left);
                 t.n_bases = n;                                                     // (of the last piece only what is needed)
                 sp.push_back(t);
+                sl.push_back(L);
                 at += n; left -= n; c2 += rv.pieces[q].n_bases;
             }
-            batch.emplace_back(sp.data(), static_cast<size_t>(sg.second), sg.first, ui.ultraFastMode);
+            batch.emplace_back(sp.data(), static_cast<size_t>(sg.second), sg.first, ui.ultraFastMode, sl.data());
         }
     }
     // without -m nothing downstream reads a match record: blocks and counts come from the device
@@ -446,7 +483,7 @@ inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::ve
 
 inline std::vector<PathData> walkPaths(Teloscope &teloscope, const std::vector<FastaRecord> &records) {
     std::vector<RecordView> views(records.size());
-    for (size_t i = 0; i < records.size(); ++i) views[i] = RecordView{&records[i].header, records[i].sequence.data(), records[i].sequence.size(), nullptr, 0};
+    for (size_t i = 0; i < records.size(); ++i) views[i] = RecordView{&records[i].header, records[i].sequence.data(), records[i].sequence.size(), nullptr, 0, nullptr};
     return walkRecordViews(teloscope, views, 0);
 }
 
@@ -1329,6 +1366,7 @@ struct RawRecord {                                              // a record of a
     std::string header;
     std::unique_ptr<char[]> data;                               // joined bases (new char[]: not zero-filled) — or,
     std::vector<ts_text_piece> pieces;                          // text mode: the record's body text where the file is mapped
+    std::vector<TextLines> lines;                               //            and how each piece's lines lie (for matchSeq)
     size_t size = 0;                                            // bases
 };
 
@@ -1439,7 +1477,7 @@ public:
         g.records.resize(nrec);
         // pieces of ~4 MB of text, cut at line starts; pass 1 counts every piece's bases, pass 2 copies them to
         // their place in the record's buffer
-        struct Piece { size_t rec; const char *a, *z; size_t bases, at; PathComponents pc; bool firstIsGap, lastIsGap; };
+        struct Piece { size_t rec; const char *a, *z; size_t bases, at; PathComponents pc; bool firstIsGap, lastIsGap; TextLines lines; };
         std::vector<Piece> pieces;
         const size_t kPiece = pieceBytes;
         for (size_t r = 0; r < nrec; ++r) {
@@ -1452,7 +1490,7 @@ public:
                     const char *nl = static_cast<const char *>(std::memchr(z, '\n', static_cast<size_t>(sp.stop - z)));
                     z = nl ? nl + 1 : sp.stop;
                 }
-                pieces.push_back(Piece{r, a, z, 0, 0, {}, false, false});
+                pieces.push_back(Piece{r, a, z, 0, 0, {}, false, false, TextLines{}});
                 a = z;
             }
         }
@@ -1462,7 +1500,7 @@ public:
             detail::onThreads(pieces.size(), [&](size_t i) {
                 Piece &p = pieces[i];
                 uint64_t nb = 0;
-                p.pc = detail::splitPathText(p.a, p.z, &nb, &p.firstIsGap, &p.lastIsGap);
+                p.pc = detail::splitPathText(p.a, p.z, &nb, &p.firstIsGap, &p.lastIsGap, &p.lines);
                 p.bases = static_cast<size_t>(nb);
             });
             for (size_t i = 0; i < pieces.size(); ++i) {
@@ -1471,7 +1509,10 @@ public:
                 g.records[p.rec].size += p.bases;
                 for (auto &sg : p.pc.segments) sg.first += p.at;
                 for (GapInfo &gp : p.pc.gaps) gp.start += p.at;
-                if (p.bases) g.records[p.rec].pieces.push_back(ts_text_piece{p.a, static_cast<uint64_t>(p.z - p.a), static_cast<uint64_t>(p.bases)});
+                if (p.bases) {
+                    g.records[p.rec].pieces.push_back(ts_text_piece{p.a, static_cast<uint64_t>(p.z - p.a), static_cast<uint64_t>(p.bases)});
+                    g.records[p.rec].lines.push_back(p.lines);
+                }
             }
         } else {
         detail::onThreads(pieces.size(), [&](size_t i) { pieces[i].bases = detail::countFastaBases(pieces[i].a, pieces[i].z); });
@@ -1543,9 +1584,9 @@ inline AssemblySummary scanFastaToFiles(Teloscope &teloscope, const std::string 
                 const auto t0 = Clock::now();
                 std::vector<RecordView> views;
                 for (const detail::RawRecord &r : g.records)
-                    views.push_back(r.pieces.empty() && r.size ? RecordView{&r.header, r.data.get(), r.size, nullptr, 0}
-                                                               : RecordView{&r.header, nullptr, r.size, r.pieces.data(), r.pieces.size()});
-                for (const FastaRecord &r : g.owned) views.push_back(RecordView{&r.header, r.sequence.data(), r.sequence.size(), nullptr, 0});
+                    views.push_back(r.pieces.empty() && r.size ? RecordView{&r.header, r.data.get(), r.size, nullptr, 0, nullptr}
+                                                               : RecordView{&r.header, nullptr, r.size, r.pieces.data(), r.pieces.size(), r.lines.data()});
+                for (const FastaRecord &r : g.owned) views.push_back(RecordView{&r.header, r.sequence.data(), r.sequence.size(), nullptr, 0, nullptr});
                 Scanned s;
                 s.paths = walkRecordViews(teloscope, views, g.firstRecord, g.owned.empty() ? &g.comps : nullptr);
                 s.group = std::move(g);                           // (-m: matchSeq was copied out of the bases already)

@@ -119,8 +119,9 @@ int main(int argc, char **argv) {
                     for (size_t q = 0; q < want.gaps.size() && q < g.comps[ri].gaps.size(); ++q)
                         check(g.comps[ri].gaps[q].start == want.gaps[q].start && g.comps[ri].gaps[q].length == want.gaps[q].length, "text gap");
                     if (r.size) {
-                        const Teloscope::Segment seg(r.pieces.data(), r.size, 0, false);
-                        for (int probe = 0; probe < 6; ++probe) {
+                        check(r.lines.size() == r.pieces.size(), "line structure per piece");
+                        const Teloscope::Segment seg(r.pieces.data(), r.size, 0, false, (at % 2) ? r.lines.data() : nullptr);
+                        for (int probe = 0; probe < 12; ++probe) {
                             const uint64_t pos = rng() % r.size, n = 1 + rng() % std::min<uint64_t>(r.size - pos, 200);
                             std::string want2 = a[at].sequence.substr(pos, n);
                             for (char &ch : want2) if (ch >= 'a' && ch <= 'z') ch = static_cast<char>(ch - 32);
