@@ -75,8 +75,22 @@ constexpr uint32_t kMaxBlocksPerTile = 448;
 constexpr uint32_t kMaxChunks = 8;             // tiles up to ~16 k positions per wave
 constexpr uint32_t kTipsChunks = 4;            // tips-only / read batches: ~8 k positions per tile
 
+// diagnostics: TS_DEALT_TILES=1 keeps every scan on the round-robin tile assignment (A/B against on-demand tiles)
+bool ts_env_flag(const char *name) {
+    const char *v = getenv(name);
+    return v && *v && *v != '0';
+}
+
+// groups of workgroups that share a ticket counter (TS_TICKET_GROUPS overrides, for measurements)
+uint32_t ticket_groups_wanted() {
+    uint32_t g = 32;
+    if (const char *e = getenv("TS_TICKET_GROUPS")) { const int n = atoi(e); if (n > 0) g = (uint32_t)n; }
+    return std::min<uint32_t>(g, TS_MAX_TICKET_GROUPS);
+}
+
 // Chooses waves per workgroup, chunks per tile and windows per tile so that the match table plus
 // one LDS slice per wave fit in 160 KB; false if even one wave cannot hold one window.
+
 bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, std::string &why) {
     const ts_params &P = c->params;
     const uint32_t k = c->k;
@@ -233,6 +247,8 @@ int ts_batch_ensure_device(ts_batch *b) {
     HIP_TRY(c, c->pool.take((nt + 1) * 8, b->d_tile_off));
     if (!b->ext_stats) HIP_TRY(c, c->pool.take((nt + 1) * 16, b->d_stats));
     HIP_TRY(c, c->pool.take((size_t)b->total_waves * 4 + 16, b->d_fill));
+    HIP_TRY(c, c->pool.take(2 * TS_MAX_TICKET_GROUPS * TS_TICKET_STRIDE * 4, b->d_tickets));
+    HIP_TRY(c, hipMemset(b->d_tickets.p, 0, 2 * TS_MAX_TICKET_GROUPS * TS_TICKET_STRIDE * 4));
     if (nt) HIP_TRY(c, hipMemcpy(b->d_tiles.p, b->tiles.data() + b->tile_lo, nt * sizeof(TsTile), hipMemcpyHostToDevice));
     if (ts_k_prepare(b->lds_bytes) != 0) return c->fail(TS_ERR_HIP, "cannot raise dynamic LDS limit");
     b->allocated = true;
@@ -263,7 +279,8 @@ void size_launch(ts_batch *b) {
     }
     const uint64_t want = b->match_cap_request ? b->match_cap_request : b->range_bases / 4 + 4096;
     uint64_t cap = ceil_div(want, b->total_waves);
-    if (b->range_bases <= (64ull << 20) && !b->match_cap_request) cap = worst;
+    b->dealt_tiles = false;
+    if (b->range_bases <= (64ull << 20) && !b->match_cap_request) { cap = worst; b->dealt_tiles = true; }
     cap = std::min<uint64_t>(std::max<uint64_t>(cap, 256), worst);
     b->region_cap = (uint32_t)((cap + 3) & ~3ull);
     b->match_cap = (uint64_t)b->region_cap * b->total_waves;
@@ -625,7 +642,7 @@ void ts_batch_destroy(ts_batch *b) {
     ts_ctx *c = b->ctx;
     if (c->device != kNoDevice) {
         DeviceGuard g(c->device);
-        for (DevBuf *d : {&b->d_in, &b->d_tiles, &b->d_windows, &b->d_matches, &b->d_tile_off, &b->d_stats, &b->d_fill,
+        for (DevBuf *d : {&b->d_in, &b->d_tiles, &b->d_windows, &b->d_matches, &b->d_tile_off, &b->d_stats, &b->d_fill, &b->d_tickets,
                           &b->d_segtab, &b->d_dense, &b->d_dense_base, &b->d_scan_tmp, &b->d_readtab})
             c->pool.give(std::move(*d));
         for (hipEvent_t e : b->evs)
@@ -751,6 +768,13 @@ int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
     kp.tile_off = (unsigned long long *)b->d_tile_off.p;
     kp.tile_stats = b->stats_ptr();
     kp.wave_fill = (uint32_t *)b->d_fill.p;
+    // Tiles are handed out on demand (see ts_scan_tiles) unless the per-wave record counts must be reproducible:
+    // small ranges, whose regions are sized for the worst case of the tiles a wave is DEALT, and the rescans after
+    // an overflow, which size the regions from the counts of the scan before.
+    kp.tile_tickets = (uint32_t *)b->d_tickets.p;
+    kp.ticket_groups = std::min<uint32_t>(b->grid, ticket_groups_wanted());
+    kp.dynamic_tiles = (b->dealt_tiles || ts_env_flag("TS_DEALT_TILES")) ? 0u : 1u;
+    kp.ticket_slot = (uint32_t)(b->ticket_seq & 1u);
     kp.region_cap = b->region_cap;
     kp.ntiles = (uint32_t)b->range_tiles();
 
@@ -761,6 +785,7 @@ int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
         int e = ts_k_launch_scan(&kp, b->grid, b->lds_bytes, stream);
         if (e != 0) return c->fail(TS_ERR_HIP, std::string("scan kernel launch: ") + hipGetErrorString((hipError_t)e));
     }
+    if (kp.dynamic_tiles) ++b->ticket_seq;        // the launch is enqueued: it zeroes the other counter for the next one
     HIP_TRY(c, hipEventRecord(b->evs[2 * slot + 1], st));
     ++b->scan_seq;
     return TS_OK;
@@ -772,7 +797,7 @@ int ts_batch_sync(ts_batch *b) {
     if (b->dense && b->synced) return TS_OK;
     if (!b->scanned) return c->fail(TS_ERR_STATE, "ts_batch_sync before ts_batch_scan");
     DEVICE_TRY(c);
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         {   // kernel times of the scans since the previous sync (the ring keeps the latest kEventRing)
             const size_t last = (size_t)((b->scan_seq - 1) % kEventRing);
             HIP_TRY(c, hipEventSynchronize(b->evs[2 * last + 1]));
@@ -799,7 +824,9 @@ int ts_batch_sync(ts_batch *b) {
         for (uint32_t f : b->wave_fill) { total += f; worst = std::max(worst, f); }
         b->n_matches = total;
         if (worst <= b->region_cap) { b->synced = true; return TS_OK; }
-        // a wave's region overflowed: size the regions for the fullest wave and rescan
+        // a wave's region overflowed: size the regions for the fullest wave and rescan, from now on with the tiles
+        // dealt round-robin (the counts of one such scan are those of the next)
+        b->dealt_tiles = true;
         b->region_cap = (uint32_t)(((uint64_t)worst + worst / 8 + 64 + 3) & ~3ull);
         b->match_cap = (uint64_t)b->region_cap * b->total_waves;
         if (b->d_matches.bytes < b->match_cap * 4) {
@@ -1187,9 +1214,10 @@ int batch_fetch(ts_batch *b, bool with_matches, PinBuf &pin, Fetched &F) {
         if (nt) HIP_TRY(c, hipMemcpyAsync(tile_stats, b->stats_ptr(), nt * 16, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         if (!b->dense && nrecs) {
-            // region offset -> dense offset (tile t was scanned by wave t mod total_waves)
+            // region offset -> dense offset.  The wave that scanned a tile is read off its region offset (a tile
+            // without records at the very end of a full region lands on the next wave's base: the same place).
             for (size_t t = 0; t < nt; ++t) {
-                const uint32_t w = (uint32_t)(t % b->total_waves);
+                const uint32_t w = (uint32_t)(tile_off[t] / b->region_cap);
                 tile_off[t] = tile_off[t] - (unsigned long long)w * b->region_cap + dense_base[w];
             }
         }

@@ -168,11 +168,13 @@ struct ts_batch {
     bool dense = false;             // match records form one dense stream in tile order (adopted / exported results)
     const void *last_input = nullptr;
     void *last_stream = nullptr;
-    DevBuf d_in, d_tiles, d_windows, d_matches, d_tile_off, d_stats, d_fill, d_segtab, d_dense, d_dense_base, d_scan_tmp, d_readtab;
+    DevBuf d_in, d_tiles, d_windows, d_matches, d_tile_off, d_stats, d_fill, d_tickets, d_segtab, d_dense, d_dense_base, d_scan_tmp, d_readtab;
     // caller-owned result buffers (ts_batch_bind_results / ts_batch_adopt); null = the batch's own
     uint32_t *ext_windows = nullptr, *ext_stats = nullptr;
     const uint32_t *ext_dense = nullptr;
     uint32_t total_waves = 0, region_cap = 0;
+    bool dealt_tiles = false;               // tiles dealt round-robin instead of taken on demand (see ts_batch_scan)
+    uint64_t ticket_seq = 0;                // launches with on-demand tiles so far: parity = the ticket counter in use
     std::vector<uint32_t> wave_fill;
     std::vector<hipEvent_t> evs;                 // ring of {start, stop} pairs, one per enqueued scan
     uint64_t scan_seq = 0, harvested = 0;        // scans enqueued / scans whose time has been read

@@ -39,6 +39,12 @@
 #ifndef TS_ABL
 #define TS_ABL 0
 #endif
+// Experiments and diagnostics (profiles/abx.sh): -DTS_EXP=<mask>.  8: every tile leaves the 100 MHz timestamp of its end
+// (20 bits) and the wave that scanned it (12 bits) in the spare word of its tile_stats row (profiles/tile_timeline.py
+// reads the waves' timelines from them).
+#ifndef TS_EXP
+#define TS_EXP 0
+#endif
 
 namespace {
 
@@ -201,14 +207,47 @@ void ts_scan_tiles(const TsScanParams P) {
     // The first chunk of a tile is fetched while the previous tile's window phase runs (its loads would
     // otherwise be waited for with nothing else to do): descriptor and 32 B/lane of the next tile are
     // requested at the end of phase 1 and picked up here.
+    //
+    // Which tile a wave scans next.  Dealt round-robin (tile = gw, gw + waves, ...) the waves of a launch do not finish
+    // together: those that share a SIMD are not served evenly and a tile inside a telomere costs more than one outside —
+    // on configs[1] the fastest wave was done after 66 % of the kernel's time and the median one after 80 %
+    // (profiles/r02/tile_timeline_dealt.txt), so the last fifth of the kernel ran on half-empty SIMDs.  With
+    // P.dynamic_tiles a wave TAKES its next tile: the workgroups form P.ticket_groups groups (workgroup % groups), group g
+    // owns the tiles t = g (mod groups) and hands them out in order through a ticket counter (one relaxed atomic add per
+    // tile, by lane 0).  Several counters because same-address atomics are served one at a time at the memory side
+    // (~7 ns each: one counter for all 222 k tiles of configs[1] made the kernel 2.7x slower); interleaved ownership so
+    // that every group sees the same mix of contigs.  The ticket is taken a whole tile ahead — the atomic for the tile
+    // after next is issued where the next tile's first chunk is requested and its result is needed one phase 1 later —
+    // so no wait is spent on it.  Without P.dynamic_tiles the per-wave record counts are reproducible, which the sizing
+    // of small batches and the rescan after an overflow rely on.  The counters of the NEXT launch are zeroed here (two
+    // sets used alternately: launches of one batch are ordered on its stream).
     TsTile Tn = {};
     uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
-    if (gw < P.ntiles) {
-        Tn = P.tiles[gw];
+    uint32_t ticket = 0;                          // lane 0: tickets taken in the group before this one
+    const uint32_t ngroups = P.dynamic_tiles ? P.ticket_groups : 1u;
+    const uint32_t group = blockIdx.x % ngroups;
+    const uint32_t group_waves = ((gridDim.x - group + ngroups - 1u) / ngroups) * P.waves_per_wg;
+    // The counter's address goes through a VGPR pair the compiler cannot see through: for an atomic on a uniform
+    // address in divergent code it would otherwise build its wave-reduction form, which waits for the returned
+    // value on the spot (s_waitcnt vmcnt(0) behind the next tile's loads).
+    auto take_ticket = [&](KernArgs Q) -> uint32_t {
+        const u64 a = (u64)(uintptr_t)(Q->tile_tickets + (Q->ticket_slot * Q->ticket_groups + group) * TS_TICKET_STRIDE);
+        uint32_t lo = (uint32_t)a, hi = (uint32_t)(a >> 32);
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        typedef __attribute__((address_space(1))) uint32_t *GlobalU32;       // global, not flat: a flat atomic also counts on lgkmcnt
+        return __hip_atomic_fetch_add((GlobalU32)(uintptr_t)(((u64)hi << 32) | lo), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (P.dynamic_tiles && gw == 0 && lane < ngroups) P.tile_tickets[((1u - P.ticket_slot) * ngroups + lane) * TS_TICKET_STRIDE] = 0u;
+    // dealt: tile = gw + i * waves; taken: tile = group + groups * (index in the group's order), the wave's first index
+    // being its own number in the group
+    const uint32_t first_tile = P.dynamic_tiles ? group + ngroups * ((blockIdx.x / ngroups) * P.waves_per_wg + wave) : gw;
+    if (first_tile < P.ntiles) {
+        if (P.dynamic_tiles && lane == 0) ticket = take_ticket(tail_params());
+        Tn = P.tiles[first_tile];
         const unsigned char *ls = P.in + (Tn.in_off & ~15ull) + lane * 32u;
         n0 = *(const uint4 *)ls; n1 = *(const uint4 *)(ls + 16);
     }
-    for (uint32_t tile = gw; tile < P.ntiles; tile += total_waves) {
+    for (uint32_t tile = first_tile, tile_next = 0; tile < P.ntiles; tile = tile_next) {
         const TsTile T = Tn;                      // wave-uniform: came by scalar loads
         const uint32_t sh = (uint32_t)(T.in_off & 15ull);
         const unsigned char *src = P.in + (T.in_off - sh);
@@ -515,10 +554,17 @@ void ts_scan_tiles(const TsScanParams P) {
                 cpos += 2u * TS_CHUNK; ch += 126u;
             }
         }
-        if (tile + total_waves < P.ntiles) {      // next tile: descriptor + first chunk, in flight during phase 2
-            Tn = P.tiles[tile + total_waves];
-            const unsigned char *ls = P.in + (Tn.in_off & ~15ull) + lane * 32u;
-            n0 = *(const uint4 *)ls; n1 = *(const uint4 *)(ls + 16);
+        {
+            KernArgs Q = tail_params();
+            const bool dyn = Q->dynamic_tiles != 0u;
+            tile_next = dyn ? group + Q->ticket_groups * (group_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket))
+                            : tile + total_waves;
+            if (tile_next < P.ntiles) {           // next tile: descriptor + first chunk, in flight during phase 2
+                Tn = P.tiles[tile_next];
+                const unsigned char *ls = P.in + (Tn.in_off & ~15ull) + lane * 32u;
+                n0 = *(const uint4 *)ls; n1 = *(const uint4 *)(ls + 16);
+                if (dyn && lane == 0) ticket = take_ticket(Q);      // and the ticket for the tile after it
+            }
         }
         drain_queue(1u);                          // the matches still queued when the tile ends
         __builtin_amdgcn_wave_barrier();          // planes written above are read by other lanes below
@@ -633,7 +679,7 @@ void ts_scan_tiles(const TsScanParams P) {
             if (lane == 0) {
                 KernArgs Q = tail_params();
                 Q->tile_off[tile] = (u64)gw * Q->region_cap + cursor;
-                *(uint4 *)&Q->tile_stats[4ull * tile] = make_uint4(done, tcan, tfwd, 0u);
+                *(uint4 *)&Q->tile_stats[4ull * tile] = make_uint4(done, tcan, tfwd, (TS_EXP & 8) ? (((uint32_t)wall_clock64() & 0xFFFFFu) | (gw << 20)) : 0u);
             }
             cursor += done;
         }

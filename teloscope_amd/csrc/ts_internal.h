@@ -18,6 +18,8 @@
 #endif
 #define TS_CHUNK        2016           // positions a wave resolves per iteration (63 lanes x 32)
 #define TS_BLK_COUNTERS 10             // 4 NB dwords of window nucleotide counts, then per step block: match head[3] rest[3]
+#define TS_TICKET_STRIDE 64            // dwords between two ticket counters (each in its own 256 bytes)
+#define TS_MAX_TICKET_GROUPS 64
 #define TS_IN_PAD       4096           // bytes of zero padding after the last segment in the input buffer
 
 struct TsTile {                 // 32 bytes
@@ -38,6 +40,7 @@ struct TsScanParams {
     unsigned long long *tile_off;   // tile directory: first record of each tile (index into matches_out)
     uint32_t       *tile_stats;     // tile directory: {matches, canonical, forward, 0} per tile
     uint32_t       *wave_fill;      // per wave: records it needed (> region_cap means overflow)
+    uint32_t       *tile_tickets;   // 2 x ticket_groups ticket counters, TS_TICKET_STRIDE dwords apart; set [ticket_slot] is zero at launch
     uint32_t        region_cap;     // records per wave region
     uint32_t        ntiles;
     uint32_t        waves_per_wg;
@@ -58,6 +61,9 @@ struct TsScanParams {
     uint32_t        windows_on;     // 0 in tips-only mode
     uint32_t        nuc_on;         // nucleotide counts wanted (-g / -e)
     uint32_t        block_sums;     // 1: w is a multiple of s, nucleotide counts are summed per step block
+    uint32_t        dynamic_tiles;  // 1: a wave takes the next free tile (ticket counter); 0: tiles dealt round-robin
+    uint32_t        ticket_slot;    // which of the two counter sets this launch counts on (it zeroes the other)
+    uint32_t        ticket_groups;  // groups of workgroups with a counter each (<= 64; group g owns the tiles t = g mod groups)
 };
 
 // parameters of getTerminalBlocks for the device-side predicate (kernels.hip: ts_terminal_predicate)
