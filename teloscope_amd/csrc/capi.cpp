@@ -123,15 +123,15 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
         {16, 1.0}, {12, 0.88}, {8, 0.69}, {4, 0.43}, {2, 0.22}, {1, 0.11}};
     uint32_t nch_min = 1;
     if (!tips) nch_min = (uint32_t)ceil_div((uint64_t)(1 + kp.halo_blocks) * kp.s + 63, TS_CHUNK);
-    const uint32_t nch_max = tips ? kTipsChunks : std::max(nch_min, kMaxChunks);
-    double best = 0.0;
-    TsScanParams best_kp{};
-    uint32_t best_wpt = 0;
     // TS_GEOMETRY="waves,chunks" pins the search to one point (0 = any): a test knob for the contract that the
     // output does not depend on the tiling ("independent of GPU count and tile size")
     uint32_t pin_waves = 0, pin_nch = 0;
     uint32_t pin_stage = 0;
     if (const char *g = getenv("TS_GEOMETRY")) sscanf(g, "%u,%u,%u", &pin_waves, &pin_nch, &pin_stage);
+    const uint32_t nch_max = tips ? kTipsChunks : std::max(nch_min, std::max(kMaxChunks, pin_nch));
+    double best = 0.0;
+    TsScanParams best_kp{};
+    uint32_t best_wpt = 0;
     for (const auto &occ : kOccupancy) {
         if (pin_waves && occ.waves != pin_waves) continue;
         for (uint32_t nch = nch_min; nch <= nch_max; ++nch) {

@@ -92,22 +92,12 @@ __device__ __forceinline__ uint32_t pack16(const uint32_t t[4]) {
     return ((b0 | (b1 << 8)) >> 1) | ((b2 | (b3 << 8)) << 15);
 }
 
-// spread the 16 bits of v to the even bit positions of a dword
-__device__ __forceinline__ uint32_t spread16(uint32_t x) {
-    x = (x | (x << 8)) & 0x00FF00FFu;
-    x = (x | (x << 4)) & 0x0F0F0F0Fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
-}
 
 __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
-// LDS: [match table][wave 0 queue][wave 1 queue]...[wave 0 slice][wave 1 slice]...; a slice = codes | cnt | rec | wacc | stage
-//   codes   2-bit codes of the tile, two dwords per 32 positions (+ one look-ahead dword pair)
-//   cnt     nucleotide counts, one byte per 32 positions and letter (valid A, C, G, T among them).
-//           Layout [h / 4][letter][h % 4]: a letter's counts of four consecutive h share a dword
-//           (summed by one v_sad_u8), and a lane's four counts of one h sit at fixed offsets
+// LDS: [match table][wave 0 queue][wave 1 queue]...[wave 0 slice][wave 1 slice]...; a slice = codes | rec | wacc | stage
+//   codes   2-bit codes of the tile, two dwords per 32 positions (+ one look-ahead dword pair); the per-match pass
+//           reads k-mers from it and the window phase counts the nucleotides of every step block in it
 //   queue   (its own region) ring of TS_LIST u16 plane coordinates of match positions, appended to by every
 //           chunk in position order and consumed 64 at a time, so that the per-match work runs
 //           on full wavefronts
@@ -120,13 +110,12 @@ __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15
 //           address
 //   stage   packed match records waiting to leave in whole coalesced rows (and kept out of the
 //           chunk loads' counted vmcnt waits), + one spare slot per lane for predicated-off writes
-struct SliceLayout { uint32_t codes, cnt, rec, wacc, stage, bytes; };
+struct SliceLayout { uint32_t codes, rec, wacc, stage, bytes; };
 
 __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     SliceLayout s;
     uint32_t o = 0;
     s.codes = o; o += align16((P.nch * 63u + 1u) * 8u);
-    s.cnt = o; o += (P.windows_on && P.nuc_on) ? ((P.nch * 63u + 3u) >> 2) * 16u : 0u;
     s.rec = o; o += (P.windows_on && P.nuc_on) ? align16((P.max_windows + P.halo_blocks) * 16u) : 0u;
     s.wacc = o; o += P.windows_on ? align16(P.max_windows * 8u * P.acc_copies) : 0u;
     s.stage = o; o += (P.stage_cap + 64u) * 4u;
@@ -173,7 +162,6 @@ void ts_scan_tiles(const TsScanParams P) {
     asm volatile("" : "+s"(qmask));
     lds_u8 *slice = lds + queue_region(P) + P.waves_per_wg * (TS_LIST * 2u) + wave * SL.bytes;
     lds_u32 *codes = (lds_u32 *)(slice + SL.codes);
-    lds_u8 *cnt = slice + SL.cnt;
     lds_u32 *rec = (lds_u32 *)(slice + SL.rec);
     lds_u32 *stage = (lds_u32 *)(slice + SL.stage);
     LDS u64 *wacc = (LDS u64 *)(slice + SL.wacc);
@@ -370,12 +358,18 @@ void ts_scan_tiles(const TsScanParams P) {
                 }
                 inv = b4[0] | (b4[1] << 4) | (b4[2] << 8) | (b4[3] << 12) |
                       (b4[4] << 16) | (b4[5] << 20) | (b4[6] << 24) | (b4[7] << 28);
+                // non-ACGT bytes among the tile's own positions [sh, xend): the window phase then counts the tile's
+                // nucleotides from the bytes, not from the codes (what lies before the tile or behind the segment
+                // end is never counted)
+                uint32_t inside = inv;
+                if (pos0 < sh) inside &= ~0u << (sh - pos0);             // chunk 0, lane 0: sh < 16
                 if (pos0 + 32u > xend) {
                     const uint32_t nv = xend > pos0 ? xend - pos0 : 0u;     // < 32
+                    inside &= ~(~0u << nv);
                     inv |= ~0u << nv;
                 }
+                if (__any(inside != 0u)) has_invalid = true;
                 wa = pack16(t); wb = pack16(t + 4);
-                has_invalid = true;
             }
 
             // next lane's first 16 bases (DPP wave_shl:1, lane i <- lane i+1; lane 63's value is unused)
@@ -415,28 +409,8 @@ void ts_scan_tiles(const TsScanParams P) {
             // the lane's bases go to the tile's code plane (lane 63's first dword is the look-ahead of lane 62's
             // last k-mers; the next chunk's lane 0 rewrites the same slot with the same value)
             if (!(TS_ABL & 64)) {
-                const uint32_t h = ch + lane;                     // index of the lane's 32 positions in the planes
+                const uint32_t h = ch + lane;                     // index of the lane's 32 positions in the plane
                 *(LDS u32x2 *)(codes + 2u * h) = (u32x2){wa, wb};
-                if (lane < 63u && P.windows_on && P.nuc_on) {
-                    // valid A/C/G/T among the 32 bases (codes A0 C1 T2 G3: low bit set in C and G, high
-                    // bit in T and G); invalid positions are masked out on the slow path
-                    // low code bits of the 32 bases in one dword (wa's at the even positions, wb's at the odd
-                    // ones), high code bits in another with the same placement: three popcounts
-                    uint32_t lo = (wa & 0x55555555u) | ((wb << 1) & 0xAAAAAAAAu);
-                    uint32_t hi = ((wa >> 1) & 0x55555555u) | (wb & 0xAAAAAAAAu);
-                    uint32_t nV = 32u;
-                    if (slow) {
-                        const uint32_t ok = spread16(~inv & 0xFFFFu) | (spread16(~inv >> 16) << 1);
-                        lo &= ok; hi &= ok;
-                        nV = __popc(~inv);
-                    }
-                    const uint32_t nG = __popc(lo & hi), nL = __popc(lo), nH = __popc(hi);
-                    lds_u8 *np = cnt + ((h >> 2) << 4) + (h & 3u);
-                    np[0] = (unsigned char)(nV + nG - nL - nH);
-                    np[4] = (unsigned char)(nL - nG);
-                    np[8] = (unsigned char)nG;
-                    np[12] = (unsigned char)(nH - nG);
-                }
             }
 
 #if TS_ABL & 32
@@ -576,71 +550,69 @@ void ts_scan_tiles(const TsScanParams P) {
         // plus the two partial units at the ends, counted from the codes.
         flush_stage();
         if (P.windows_on) {
-            // sum of letter f's counts over the units ha .. he-1 (ha < he)
-            auto plane_sum = [&](uint32_t f, uint32_t ha, uint32_t he, uint32_t acc) -> uint32_t {
-                const lds_u32 *pl = (const lds_u32 *)cnt + f;        // group g of four units: pl[4 g]
-                uint32_t d = ha >> 2;
-                const uint32_t db = (he - 1u) >> 2;
-                const uint32_t m0 = ~0u << (8u * (ha & 3u));
-                const uint32_t m1 = ~0u >> (8u * (3u - ((he - 1u) & 3u)));
-                uint32_t v0 = pl[4u * d] & m0;
-                if (d == db) v0 &= m1;
-                acc = __builtin_amdgcn_sad_u8(v0, 0u, acc);
-                ++d;
-                for (; d + 4u <= db; d += 4u) {
-                    const lds_u32 *q = pl + 4u * d;
-                    acc = __builtin_amdgcn_sad_u8(q[0], 0u, acc);
-                    acc = __builtin_amdgcn_sad_u8(q[4], 0u, acc);
-                    acc = __builtin_amdgcn_sad_u8(q[8], 0u, acc);
-                    acc = __builtin_amdgcn_sad_u8(q[12], 0u, acc);
-                }
-                for (; d < db; ++d) acc = __builtin_amdgcn_sad_u8(pl[4u * d], 0u, acc);
-                if (d == db) acc = __builtin_amdgcn_sad_u8(pl[4u * db] & m1, 0u, acc);
-                return acc;
-            };
-            // letter f's count over the tile positions [us, ue), us < ue
-            auto range_count = [&](uint32_t f, uint32_t us, uint32_t ue) -> uint32_t {
-                const uint32_t xs = sh + us, xe = sh + ue;               // plane coords, xs < xe
-                const uint32_t hs = xs >> 5, he = xe >> 5;               // 32-position units of the planes
-                // the field's code (A0 C1 G3 T2) as the bits to flip so that "equal" reads 1/1
-                const uint32_t code = (f == 2u) ? 3u : (f == 3u ? 2u : f);
-                const u64 xl = (code & 1u) ? 0ull : 0x5555555555555555ull;
-                const u64 xh = (code & 2u) ? 0ull : 0x5555555555555555ull;
-                const uint32_t letter = (0x54474341u >> (8u * f)) & 0xFFu;
-                auto partial = [&](uint32_t h, uint32_t lo, uint32_t hi) -> uint32_t {   // 0 < hi - lo < 32
-                    if (has_invalid) {                                    // rare: re-read the bases themselves
-                        uint32_t n = 0;
-                        for (uint32_t pp = lo; pp < hi; ++pp)
-                            n += ((uint32_t)src[h * 32u + pp] & (P.fold_mask & 0xFFu)) == letter;
-                        return n;
-                    }
-                    const u64 m = (((1ull << (2u * (hi - lo))) - 1ull) << (2u * lo)) & 0x5555555555555555ull;
-                    const u32x2 c2 = *(const LDS u32x2 *)(codes + 2u * h);
-                    const u64 cd = (u64)c2.x | ((u64)c2.y << 32);
-                    return (uint32_t)__popcll((cd ^ xl) & ((cd >> 1) ^ xh) & m);
+            // Nucleotides.  Counted here, from the tile's code plane, not per chunk: a row (a step block when w is a
+            // multiple of s — a window is then the sum of w / s of them and overlapping windows share them — else a
+            // window) is cut into pieces for 1, 2 or 4 lanes, and a lane counts its piece 32 positions at a time:
+            // the low code bits of two code dwords merged into one dword, the high bits into another (codes A0 C1 T2
+            // G3: low bit set in C and G, high bit in T and G), three popcounts — 4 instructions per 16 positions on
+            // full wavefronts, against 23 per chunk for per-lane byte planes plus their sums (v5 .. v11).
+            auto count_piece = [&](uint32_t xs, uint32_t xe, uint32_t &nL, uint32_t &nH, uint32_t &nG) {   // plane coords, xs < xe
+                const uint32_t d0 = xs >> 4, d1 = (xe - 1u) >> 4;            // code dwords of the piece
+                const uint32_t m0 = ~0u << (2u * (xs & 15u));
+                const uint32_t m1 = ~0u >> (2u * (15u - ((xe - 1u) & 15u)));
+                auto add2 = [&](uint32_t wA, uint32_t wB) {                  // two code dwords = 32 positions
+                    const uint32_t lo = (wA & 0x55555555u) | ((wB << 1) & 0xAAAAAAAAu);
+                    const uint32_t hi = ((wA >> 1) & 0x55555555u) | (wB & 0xAAAAAAAAu);
+                    nL += __popc(lo); nH += __popc(hi); nG += __popc(lo & hi);
                 };
-                uint32_t val = 0;
-                if (hs == he) {
-                    val = partial(hs, xs & 31u, xe & 31u);
-                } else {
-                    uint32_t ha = hs;
-                    if (xs & 31u) { val += partial(hs, xs & 31u, 32u); ++ha; }
-                    if (xe & 31u) val += partial(he, 0u, xe & 31u);
-                    if (ha < he) val = plane_sum(f, ha, he, val);
-                }
-                return val;
+                // the two end dwords (masked) as one pair, the dwords between them two at a time
+                uint32_t first = codes[d0] & m0, last = 0u;
+                if (d1 == d0) first &= m1; else last = codes[d1] & m1;
+                add2(first, last);
+                uint32_t d = d0 + 1u;
+                for (; d + 2u <= d1; d += 2u) add2(codes[d], codes[d + 1u]);
+                if (d < d1) add2(codes[d], 0u);
             };
-            // When w is a multiple of s a window is the sum of w / s step blocks, and overlapping windows share
-            // them: rec[] then holds one row per step block (the tile's windows + halo), otherwise one per window.
+            // the same from the bytes themselves, in tiles with non-ACGT bytes (rare: segments end at gaps)
+            auto count_piece_bytes = [&](uint32_t xs, uint32_t xe, uint32_t n[4]) {
+                const uint32_t fold = P.fold_mask & 0xFFu;
+                for (uint32_t x = xs; x < xe; ++x) {
+                    const uint32_t c = (uint32_t)src[x] & fold;
+                    n[0] += c == 0x41u; n[1] += c == 0x43u; n[2] += c == 0x47u; n[3] += c == 0x54u;
+                }
+            };
+            // When w is a multiple of s rec[] holds one row per step block (the tile's windows + halo), otherwise one
+            // per window.
             const bool by_blocks = P.block_sums != 0u;
             if (P.nuc_on && !(TS_ABL & 2)) {
                 const uint32_t rows = by_blocks ? T.nwin + P.halo_blocks : T.nwin;
                 const uint32_t len = by_blocks ? P.s : P.w;
-                for (uint32_t it = lane; it < rows * 4u; it += 64u) {
-                    const uint32_t i = it >> 2, f = it & 3u;              // f: A C G T
-                    const uint32_t us = i * P.s;
-                    const uint32_t ue = us + len < T.nrel ? us + len : T.nrel;
-                    rec[it] = us < ue ? range_count(f, us, ue) : 0u;     // a halo block may lie past the segment end
+                for (uint32_t it = lane; it < rows * 4u; it += 64u) rec[it] = 0u;
+                // pieces per row: as many lanes as there are busy, as long as a piece keeps 128 positions
+                uint32_t pshift = 0;
+                while (pshift < 2u && (rows << (pshift + 1u)) <= 64u && (len >> (pshift + 1u)) >= 128u) ++pshift;
+                const uint32_t piece = (len + (1u << pshift) - 1u) >> pshift;
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t it = lane; it < (rows << pshift); it += 64u) {
+                    const uint32_t row = it >> pshift, part = it & ((1u << pshift) - 1u);
+                    const uint32_t row_end = row * P.s + len < T.nrel ? row * P.s + len : T.nrel;   // a halo block may lie past the segment end
+                    const uint32_t us = row * P.s + part * piece;
+                    const uint32_t ue = us + piece < row_end ? us + piece : row_end;
+                    if (us >= ue) continue;
+                    uint32_t n[4] = {0u, 0u, 0u, 0u};                         // A C G T
+                    if (has_invalid) {
+                        count_piece_bytes(sh + us, sh + ue, n);
+                    } else {
+                        uint32_t nL = 0, nH = 0, nG = 0;
+                        count_piece(sh + us, sh + ue, nL, nH, nG);
+                        n[0] = (ue - us) + nG - nL - nH; n[1] = nL - nG; n[2] = nG; n[3] = nH - nG;
+                    }
+                    LDS uint32_t *r4 = rec + row * 4u;
+                    if (pshift == 0u) { r4[0] = n[0]; r4[1] = n[1]; r4[2] = n[2]; r4[3] = n[3]; }
+                    else {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) (void)__hip_atomic_fetch_add(r4 + f, n[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
