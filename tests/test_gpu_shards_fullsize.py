@@ -309,3 +309,53 @@ def test_read_shard_over_two_contexts_equals_one():
         assert L.ts_filter_reads_multi(ctxs, nctx, arr, lens, n, out) == 0
         assert [bool(x) for x in out] == exp, nctx
     assert 0 < sum(exp) < n
+
+
+def test_taken_tiles_equal_dealt_tiles_and_survive_overflow():
+    """A range above 64 Mb is scanned with the waves TAKING their tiles (ticket counters); below it, after an overflow of a
+    wave's record region, and with TS_DEALT_TILES=1 the tiles are dealt round-robin.  Which wave scans a tile must not
+    show in the results: window records, tile directory and the tile-ordered record stream are compared array for array —
+    taken vs dealt, and a plan whose tiny match capacity forces overflow -> grow -> rescan vs both."""
+    import torch
+    from teloscope_amd import distributed as D
+    dev = torch.device("cuda:0")
+    opts, tel = _teloscope(HEADLINE)
+    lens = [120_000_123, 60_000_001, 29_999_999, 777]
+    plan = D.ShardPlan(tel, lens, world=1)
+    offsets = plan.segment_offsets()
+    buf = torch.zeros(int(plan.info.input_bytes), dtype=torch.uint8, device=dev)
+    rng = np.random.default_rng(77)
+    for i, (o, n) in enumerate(zip(offsets, lens)):
+        buf[o:o + n] = _device_random(n, dev, 500 + i)
+        tract = torch.from_numpy(seqgen.mutate(rng, seqgen.repeat_array("TTAGGG", 3000), 0.02).copy()).to(dev)
+        m = min(n, tract.numel())
+        buf[o:o + m] = tract[:m]                                  # a dense telomere at every segment start
+    assert "TS_DEALT_TILES" not in os.environ
+    taken = _scan_parts(plan, buf, dev)
+    os.environ["TS_DEALT_TILES"] = "1"
+    try:
+        dealt = _scan_parts(plan, buf, dev)
+    finally:
+        del os.environ["TS_DEALT_TILES"]
+    tight = D.ShardPlan(tel, lens, world=1, match_capacity=5000)     # far below the ~6.4 M records of this input
+    regrown = _scan_parts(tight, buf, dev)
+    assert taken[3] == dealt[3] == regrown[3] and taken[3][0] > 6_000_000
+    for name, a, b, c in zip(("windows", "tile directory", "records"), taken, dealt, regrown):
+        assert torch.equal(a, b), name + ": taken vs dealt"
+        assert torch.equal(a, c), name + ": taken vs regrown after overflow"
+    # and two segments against the oracle, so that "equal" is not "equally wrong"
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    w, s_, d, counts = taken
+    b = D.adopt(plan, D.Assembled(w, s_, d, int(d.numel()), counts))
+    L = K.lib()
+    out = (K.SegmentOut * len(lens))()
+    assert L.ts_batch_download(b, None, out) == 0, tel._ctx.error()
+    orac = OracleBackend(opts)
+    for i in (2, 3):
+        seq = bytes(buf[offsets[i]:offsets[i] + lens[i]].cpu().numpy())
+        assert_segment_equal(segment_as_dict(ta.SegmentData(out[i], False)), orac.scan_segment(seq, 0, False), False, ctx="segment %d" % i)
+    L.ts_free_segments(out, len(lens))
+    L.ts_batch_destroy(b)
+    plan.close()
+    tight.close()
