@@ -279,11 +279,11 @@ void size_launch(ts_batch *b) {
     }
     const uint64_t want = b->match_cap_request ? b->match_cap_request : b->range_bases / 4 + 4096;
     uint64_t cap = ceil_div(want, b->total_waves);
-    // Tiles are taken on demand by the waves of a window scan; dealt round-robin (a) to small ranges, whose regions are
-    // sized for the worst case of the tiles a wave is dealt, and (b) to tips / read batches: their consumer, the
-    // per-read predicate, reads a read's records wherever the scan put them, and measured 38 % slower on the
-    // placement taken tiles produce (profiles/r02/reads_taken_vs_dealt.txt) — more than the scan gains (11 %).
-    b->dealt_tiles = b->tips;
+    // Tiles are taken on demand by the waves (see ts_scan_tiles); dealt round-robin to small ranges, whose regions are
+    // sized for the worst case of the tiles a wave is dealt, and to the rescans after an overflow.  (TS_DEALT_TIPS=1
+    // deals the tiles of tips / read batches: the read predicate's sensitivity to the record placement was measured with it,
+    // profiles/r02/reads_taken_vs_dealt.txt.)
+    b->dealt_tiles = b->tips && ts_env_flag("TS_DEALT_TIPS");
     if (b->range_bases <= (64ull << 20) && !b->match_cap_request) { cap = worst; b->dealt_tiles = true; }
     cap = std::min<uint64_t>(std::max<uint64_t>(cap, 256), worst);
     b->region_cap = (uint32_t)((cap + 3) & ~3ull);

@@ -184,6 +184,8 @@ struct ts_batch {
     uint32_t *windows_ptr() const { return ext_windows ? ext_windows : (uint32_t *)d_windows.p; }
     uint32_t *stats_ptr() const { return ext_stats ? ext_stats : (uint32_t *)d_stats.p; }
     const uint32_t *records_ptr() const { return dense ? (ext_dense ? ext_dense : (const uint32_t *)d_dense.p) : (const uint32_t *)d_matches.p; }
+    // records that may be read behind records_ptr(): the per-wave regions, or the dense stream
+    unsigned long long records_limit() const { return dense ? n_matches : (unsigned long long)region_cap * total_waves; }
     uint64_t range_tiles() const { return tile_hi - tile_lo; }
     bool whole() const { return tile_lo == 0 && tile_hi == tiles.size(); }
 };

@@ -750,12 +750,15 @@ __device__ __forceinline__ bool pred_feed(PredState &st, const TsPredParams &Q, 
 }
 
 // One orientation of the walk, one thread per read.  Records are visited in walk order (ascending for the
-// forward list, descending for the reverse list), eight at a time with the next eight already requested: a
-// thread's loads are scattered (every lane walks its own read), so the walk is bound by load latency.
-constexpr uint32_t kPredGroup = 8;       // records a thread requests at a time (and as many again in flight)
+// forward list, descending for the reverse list).  Every lane walks its own read, so its loads are scattered and the
+// kernel is bound by the number of load INSTRUCTIONS (the address unit takes one lane's address per cycle): records are
+// therefore fetched as aligned 16-byte blocks — the four-record blocks that cover the tile's records, the ends
+// masked — two blocks at a time with the next two already requested (round 2; dword loads before: 4x the instructions).
+// A block that would reach outside [matches, matches + nrec_limit) is read record by record.
+constexpr uint32_t kPredBlocks = 2;      // 16-byte blocks a thread requests at a time (and as many again in flight)
 template <bool FROM_START>
 __device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
-                                          const uint32_t *matches, uint32_t t0, uint32_t t1, u64 base, u64 n,
+                                          const uint32_t *matches, u64 nrec_limit, uint32_t t0, uint32_t t1, u64 base, u64 n,
                                           const TsPredParams &Q) {
     PredState st = {};
     bool go = true;
@@ -764,23 +767,46 @@ __device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_o
         const uint32_t cnt = tile_stats[4u * t];
         if (cnt == 0u) continue;
         const u64 rel0 = tiles[t].in_off - base;
-        const uint32_t *r = matches + tile_off[t];
-        auto at = [&](uint32_t i) -> uint32_t {            // i-th record in walk order (clamped: loads are unconditional)
-            const uint32_t j = i < cnt ? i : cnt - 1u;
-            return r[FROM_START ? j : cnt - 1u - j];
+        const u64 off = tile_off[t];
+        const uint32_t *r = matches + off;
+        const uint32_t m = (uint32_t)(((uintptr_t)r >> 2) & 3u);      // records of the first block that are not ours
+        const uint32_t nb = (m + cnt + 3u) >> 2;                         // blocks covering records 0 .. cnt-1: record i = dword m + i
+        const uint4 *ra = (const uint4 *)(r - m);
+        const bool inside = off >= m && off - m + 4ull * nb <= nrec_limit;
+        auto blk = [&](uint32_t bi) -> uint4 {             // bi-th block in walk order (clamped: loads are unconditional)
+            const uint32_t qi = bi < nb ? bi : nb - 1u;
+            const uint32_t q = FROM_START ? qi : nb - 1u - qi;
+            if (inside) return ra[q];
+            uint32_t e[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t i = 4u * q + j - m;         // wraps below the first record
+                e[j] = i < cnt ? r[i] : 0u;
+            }
+            return make_uint4(e[0], e[1], e[2], e[3]);
         };
-        uint32_t v[kPredGroup], w[kPredGroup];
+        auto feed_block = [&](uint32_t bi, const uint4 &v) {
+            if (bi >= nb) return;
+            const uint32_t q = FROM_START ? bi : nb - 1u - bi;
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (uint32_t j = 0; j < kPredGroup; ++j) v[j] = at(j);
-        for (uint32_t i = 0; i < cnt && go; i += kPredGroup) {
+            for (uint32_t jj = 0; jj < 4u; ++jj) {
+                const uint32_t j = FROM_START ? jj : 3u - jj;
+                const uint32_t i = 4u * q + j - m;
+                if (i < cnt && go && ((e[j] & 2u) != 0u) == FROM_START)
+                    go = pred_feed(st, Q, FROM_START, rel0 + (e[j] >> 2), e[j] & 1u, n);
+            }
+        };
+        uint4 v[kPredBlocks], w[kPredBlocks];
 #pragma unroll
-            for (uint32_t j = 0; j < kPredGroup; ++j) w[j] = at(i + kPredGroup + j);
+        for (uint32_t j = 0; j < kPredBlocks; ++j) v[j] = blk(j);
+        for (uint32_t bi = 0; bi < nb && go; bi += kPredBlocks) {
 #pragma unroll
-            for (uint32_t j = 0; j < kPredGroup; ++j)
-                if (i + j < cnt && go && ((v[j] & 2u) != 0u) == FROM_START)
-                    go = pred_feed(st, Q, FROM_START, rel0 + (v[j] >> 2), v[j] & 1u, n);
+            for (uint32_t j = 0; j < kPredBlocks; ++j) w[j] = blk(bi + kPredBlocks + j);
 #pragma unroll
-            for (uint32_t j = 0; j < kPredGroup; ++j) v[j] = w[j];
+            for (uint32_t j = 0; j < kPredBlocks; ++j) feed_block(bi + j, v[j]);
+#pragma unroll
+            for (uint32_t j = 0; j < kPredBlocks; ++j) v[j] = w[j];
         }
     }
     if (st.in_block) pred_close_sub(st, Q, FROM_START);
@@ -866,7 +892,7 @@ constexpr uint32_t kLongRead = 384;        // records; above this a read is walk
 
 __global__ __launch_bounds__(64)
 void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
-                           const uint32_t *matches, const uint32_t *seg_first_tile,
+                           const uint32_t *matches, const u64 nrec_limit, const uint32_t *seg_first_tile,
                            const u64 *seg_in_off, const u64 *seg_len, uint32_t nseg,
                            const TsPredParams Q, unsigned char *pass) {
     const uint32_t lane = threadIdx.x;                       // one wave per workgroup
@@ -884,9 +910,9 @@ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint3
     bool ok = false;
     if (live && !is_long) {
         if (nfwd >= 2)                                      // forward list, from the segment start
-            ok = pred_walk<true>(tiles, tile_off, tile_stats, matches, t0, t1, base, n, Q);
+            ok = pred_walk<true>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
         if (!ok && total - nfwd >= 2)                       // reverse list, from the segment end
-            ok = pred_walk<false>(tiles, tile_off, tile_stats, matches, t0, t1, base, n, Q);
+            ok = pred_walk<false>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
     }
     u64 todo = __ballot(is_long);
     while (todo) {                                          // wave-uniform: one long read at a time
@@ -955,12 +981,12 @@ int ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_ti
 }
 
 int ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,
-                          const uint32_t *matches, const uint32_t *seg_first_tile,
+                          const uint32_t *matches, unsigned long long nrec_limit, const uint32_t *seg_first_tile,
                           const unsigned long long *seg_in_off, const unsigned long long *seg_len, uint32_t nseg,
                           const TsPredParams *Q, unsigned char *pass, void *stream) {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(ts_terminal_predicate, dim3((nseg + 63u) / 64u), dim3(64), 0, (hipStream_t)stream,
-                       tiles, tile_off, tile_stats, matches, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass);
+                       tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass);
     return (int)hipGetLastError();
 }
 

@@ -277,7 +277,7 @@ int batch_read_pass_device(ts_batch *b, unsigned char *d_pass, hipStream_t st) {
     Q.min_block_density = c->params.min_block_density;
     Q.k = c->k;
     int e = ts_k_launch_predicate((const TsTile *)b->d_tiles.p, (const unsigned long long *)b->d_tile_off.p,
-                                  b->stats_ptr(), b->records_ptr(), (const uint32_t *)dt,
+                                  b->stats_ptr(), b->records_ptr(), b->records_limit(), (const uint32_t *)dt,
                                   (const unsigned long long *)(dt + off_in), (const unsigned long long *)(dt + off_len),
                                   (uint32_t)ns, &Q, d_pass, st);
     if (e != 0) return c->fail(TS_ERR_HIP, "predicate kernel launch failed");

@@ -150,9 +150,10 @@ int  ts_k_launch_general_windows(const unsigned char *in, const uint32_t *mask, 
                                  const unsigned long long *seg_in_off, const unsigned long long *seg_len, uint32_t nseg,
                                  unsigned long long nwin, uint32_t *out, void *stream);
 int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,
-                           const uint32_t *matches, const uint32_t *seg_first_tile,
+                           const uint32_t *matches, unsigned long long nrec_limit, const uint32_t *seg_first_tile,
                            const unsigned long long *seg_in_off, const unsigned long long *seg_len,
                            uint32_t nseg, const TsPredParams *Q, unsigned char *pass, void *stream);
+                           // (nrec_limit: records that may be READ behind `matches` — the predicate fetches aligned 16-byte blocks)
 int  ts_k_launch_block_call(const TsBlockCallParams *Q, const uint32_t *seg_first_tile,
                             const unsigned long long *seg_in_off, const unsigned long long *seg_len,
                             const unsigned long long *seg_abs, uint32_t nseg, uint32_t ntiles,
