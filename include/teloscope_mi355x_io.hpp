@@ -28,6 +28,7 @@
 #include <memory>
 #include <mutex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <fstream>
@@ -819,48 +820,252 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
 
 // ---------------------------------------------------------------------------------------------
 // --bam-subset (subsetBam, src/bam.cpp:188-259): copy the header and the alignment records whose read
-// carries a terminal telomere block, byte for byte, into a new BAM.  BGZF is a series of gzip members,
-// so zlib's gz* API reads the input as one stream; the output is written as BGZF blocks of <= 0xff00
-// payload bytes (raw deflate + the "BC" extra field + CRC32/ISIZE) closed by the EOF marker.  Sequences
-// (4-bit codes "=ACMGRSVTWYHKDBN") are decoded into one arena per batch and filtered on the GPU in
-// batches of up to readsPerBatch records / bytesPerBatch record bytes.
+// carries a terminal telomere block, byte for byte, into a new BAM.
+//
+// BGZF is a series of independent gzip members of at most 64 KB, each carrying its own size ("BC" extra subfield), so the
+// input is not read as one stream: a few hundred MB of blocks are LOCATED by walking their headers (validated like
+// BgzfReader::loadBlock, src/bgzf.cpp:57-196: FEXTRA set, reserved flag bits clear, exactly one BC subfield of length 2,
+// block and uncompressed sizes <= 64 KB, optional file name / comment / header checksum), INFLATED by all host threads
+// straight into their places of one buffer (raw inflate must use the whole payload and yield exactly ISIZE bytes, CRC32
+// checked), the records in it are walked and validated, and their sequences (4-bit codes "=ACMGRSVTWYHKDBN") are decoded
+// by all host threads into one arena that the GPU filters in batches of up to readsPerBatch records.  The output is
+// written as BGZF blocks of <= 0xff00 payload bytes (raw deflate + the BC field + CRC32/ISIZE) closed by the EOF marker.
+// (Round 2 until here read the input with zlib's gz* API on one thread: 0.14 Gbases/s on a HiFi BAM;
+// profiles/r02/bam_subset_rate.txt.)
 struct BamSubsetStats { uint64_t totalRecords = 0, passedRecords = 0, missingSequenceRecords = 0; bool missingEofBlock = false; };
 
 namespace detail {
+// the host-side helpers of this header: a bounded queue between pipeline stages, and a dynamic parallel-for
+template <typename T>
+class BoundedQueue {
+public:
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    void push(T v) {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return q_.size() < cap_ || closed_; });
+        q_.push_back(std::move(v));
+        cv_.notify_all();
+    }
+    void close() { { std::lock_guard<std::mutex> g(m_); closed_ = true; } cv_.notify_all(); }
+    bool pop(T &out) {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        cv_.notify_all();
+        return true;
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+};
+
+template <typename F>
+inline void onThreads(size_t n, F &&f) {                        // f(i) for i in [0, n), dynamic, on up to 16 host threads
+    const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), n, size_t(std::max(1u, std::thread::hardware_concurrency()))}));
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t) pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
+    for (std::thread &th : pool) th.join();
+}
+
+struct BgzfBlockRef { const unsigned char *payload; uint32_t payloadLen, isize, crc; size_t outOff; };
+
+// The BGZF block that starts at p, of which n bytes are at hand: its total size, or 0 when it is not complete within n
+// bytes (more input is needed).  Throws on anything that is not a BGZF block.
+inline size_t parseBgzfBlock(const unsigned char *p, size_t n, BgzfBlockRef &ref, bool &eofMarker) {
+    static const unsigned char kEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto u16 = [](const unsigned char *q) { return static_cast<uint32_t>(q[0]) | (static_cast<uint32_t>(q[1]) << 8); };
+    auto u32 = [&](const unsigned char *q) { return u16(q) | (u16(q + 2) << 16); };
+    if (n < 12) return 0;
+    if (p[0] != 31 || p[1] != 139 || p[2] != 8) throw std::runtime_error("input is not BGZF-compressed BAM (not a BAM file)");
+    const unsigned flags = p[3];
+    if ((flags & 0x04) == 0 || (flags & 0xe0) != 0) throw std::runtime_error("invalid BGZF gzip flags");
+    const size_t xlen = u16(p + 10);
+    if (n < 12 + xlen) return 0;
+    bool found = false;
+    size_t total = 0;
+    for (size_t pos = 12; pos < 12 + xlen;) {
+        if (12 + xlen - pos < 4) throw std::runtime_error("malformed BGZF extra field");
+        const size_t slen = u16(p + pos + 2), end = pos + 4 + slen;
+        if (end > 12 + xlen) throw std::runtime_error("malformed BGZF extra subfield");
+        if (p[pos] == 'B' && p[pos + 1] == 'C') {
+            if (slen != 2 || found) throw std::runtime_error("invalid BGZF BC subfield");
+            total = static_cast<size_t>(u16(p + pos + 4)) + 1;
+            found = true;
+        }
+        pos = end;
+    }
+    if (!found) throw std::runtime_error("BGZF block is missing the BC subfield");
+    if (total > 65536 || total < 12 + xlen + 8) throw std::runtime_error("invalid BGZF block size");
+    if (n < total) return 0;
+    size_t at = 12 + xlen;
+    const size_t footer = total - 8;
+    auto skipText = [&](const char *what) {
+        while (at < footer && p[at] != 0) ++at;
+        if (at == footer) throw std::runtime_error(std::string("unterminated BGZF ") + what);
+        ++at;
+    };
+    if (flags & 0x08) skipText("filename");
+    if (flags & 0x10) skipText("comment");
+    if (flags & 0x02) {
+        if (footer - at < 2) throw std::runtime_error("truncated BGZF header checksum");
+        const uLong crc = crc32(crc32(0L, Z_NULL, 0), p, static_cast<uInt>(at));
+        if (static_cast<uint32_t>(crc & 0xffffu) != u16(p + at)) throw std::runtime_error("BGZF header checksum mismatch");
+        at += 2;
+    }
+    ref.payload = p + at;
+    ref.payloadLen = static_cast<uint32_t>(footer - at);
+    ref.crc = u32(p + footer);
+    ref.isize = u32(p + footer + 4);
+    if (ref.isize > 65536) throw std::runtime_error("BGZF uncompressed block is too large");
+    eofMarker = total == sizeof kEof && std::memcmp(p, kEof, sizeof kEof) == 0;
+    return total;
+}
+
+inline void inflateBgzfBlock(const BgzfBlockRef &b, unsigned char *dst) {
+    z_stream zs{};
+    unsigned char dummy = 0;
+    zs.next_in = const_cast<unsigned char *>(b.payload); zs.avail_in = b.payloadLen;
+    zs.next_out = b.isize ? dst : &dummy; zs.avail_out = b.isize ? b.isize : 1;
+    if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("could not initialize BGZF decompressor");
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool whole = rc == Z_STREAM_END && zs.total_out == b.isize && zs.total_in == b.payloadLen;
+    inflateEnd(&zs);
+    if (!whole) throw std::runtime_error("invalid BGZF deflate payload");
+    const uLong crc = crc32(crc32(0L, Z_NULL, 0), b.isize ? dst : Z_NULL, b.isize);
+    if (static_cast<uint32_t>(crc) != b.crc) throw std::runtime_error("BGZF checksum mismatch");
+}
+
+// Uncompressed bytes of a BGZF file or stream, a few hundred MB per call, inflated by all host threads.
+class BgzfParallelReader {
+    int fd_;
+    const unsigned char *map_ = nullptr;        // a regular file is mapped ...
+    size_t mapSize_ = 0, mapPos_ = 0;
+    std::vector<unsigned char> buf_;            // ... a pipe is read into a buffer (the incomplete block at its end is kept)
+    bool streamEof_ = false;
+    std::vector<BgzfBlockRef> blocks_;
+public:
+    bool sawEofMarker = false;
+    explicit BgzfParallelReader(int fd) : fd_(fd) {
+        struct stat st;
+        if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = ::mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                map_ = static_cast<const unsigned char *>(m); mapSize_ = static_cast<size_t>(st.st_size);
+                ::madvise(m, mapSize_, MADV_SEQUENTIAL);
+            }
+        }
+    }
+    ~BgzfParallelReader() { if (map_) ::munmap(const_cast<unsigned char *>(map_), mapSize_); }
+    BgzfParallelReader(const BgzfParallelReader &) = delete;
+    BgzfParallelReader &operator=(const BgzfParallelReader &) = delete;
+
+    // Inflates the next whole blocks into dst[0 .. cap) (cap >= 64 KB): the number of bytes produced; `more` = false when
+    // the input is exhausted.
+    size_t next(unsigned char *dst, size_t cap, bool &more) {
+        const unsigned char *w;
+        size_t wn;
+        bool atEnd;
+        if (map_) { w = map_ + mapPos_; wn = mapSize_ - mapPos_; atEnd = true; }
+        else {
+            while (!streamEof_ && buf_.size() < cap) {             // compressed bytes: never more than the uncompressed room
+                const size_t at = buf_.size();
+                buf_.resize(at + (8u << 20));
+                const ssize_t r = ::read(fd_, buf_.data() + at, 8u << 20);
+                if (r < 0) throw std::runtime_error("cannot read BAM input");
+                buf_.resize(at + static_cast<size_t>(r));
+                if (r == 0) streamEof_ = true;
+            }
+            w = buf_.data(); wn = buf_.size(); atEnd = streamEof_;
+        }
+        blocks_.clear();
+        size_t used = 0, produced = 0;
+        while (used < wn) {
+            BgzfBlockRef ref{};
+            bool eofm = false;
+            const size_t total = parseBgzfBlock(w + used, wn - used, ref, eofm);
+            if (total == 0) {
+                if (atEnd) throw std::runtime_error(wn - used < 12 ? "truncated BGZF header" : "truncated BGZF block");
+                break;
+            }
+            if (produced + ref.isize > cap) break;
+            sawEofMarker = sawEofMarker || eofm;
+            ref.outOff = produced;
+            produced += ref.isize;
+            blocks_.push_back(ref);
+            used += total;
+        }
+        if (!blocks_.empty()) {
+            const size_t per = 32, tasks = (blocks_.size() + per - 1) / per;
+            std::mutex em;
+            std::exception_ptr err;
+            onThreads(tasks, [&](size_t t) {
+                try {
+                    for (size_t i = t * per; i < std::min(blocks_.size(), (t + 1) * per); ++i) inflateBgzfBlock(blocks_[i], dst + blocks_[i].outOff);
+                } catch (...) { std::lock_guard<std::mutex> g(em); if (!err) err = std::current_exception(); }
+            });
+            if (err) std::rethrow_exception(err);
+        }
+        if (map_) mapPos_ += used; else buf_.erase(buf_.begin(), buf_.begin() + static_cast<std::ptrdiff_t>(used));
+        more = used > 0 && (map_ ? mapPos_ < mapSize_ : !(streamEof_ && buf_.empty()));
+        return produced;
+    }
+};
+}  // namespace detail
+
+namespace detail {
 class BgzfWriter {
+    static constexpr size_t kPayload = 0xff00, kSlot = 65536, kBlocksPerFlush = 64;
     std::ostream &out;
-    std::vector<unsigned char> pending;
-    void block(const unsigned char *data, size_t n) {
-        unsigned char comp[65536];
+    std::vector<unsigned char> pending, comp;
+    std::vector<size_t> sizes;
+    static size_t block(const unsigned char *data, size_t n, unsigned char *slot) {         // one BGZF block into its 64 KB slot
         z_stream zs{};
         if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
         zs.next_in = const_cast<unsigned char *>(data); zs.avail_in = static_cast<unsigned>(n);
-        zs.next_out = comp + 18; zs.avail_out = sizeof comp - 18 - 8;
+        zs.next_out = slot + 18; zs.avail_out = kSlot - 18 - 8;
         const int rc = deflate(&zs, Z_FINISH);
         deflateEnd(&zs);
         if (rc != Z_STREAM_END) throw std::runtime_error("BGZF block does not fit");
         const size_t clen = zs.total_out, total = 18 + clen + 8;
         static const unsigned char head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-        std::memcpy(comp, head, 16);
-        comp[16] = static_cast<unsigned char>((total - 1) & 0xff); comp[17] = static_cast<unsigned char>((total - 1) >> 8);
+        std::memcpy(slot, head, 16);
+        slot[16] = static_cast<unsigned char>((total - 1) & 0xff); slot[17] = static_cast<unsigned char>((total - 1) >> 8);
         const uint32_t crc = static_cast<uint32_t>(crc32(crc32(0L, Z_NULL, 0), data, static_cast<unsigned>(n)));
-        unsigned char *tail = comp + 18 + clen;
+        unsigned char *tail = slot + 18 + clen;
         for (int i = 0; i < 4; ++i) { tail[i] = static_cast<unsigned char>(crc >> (8 * i)); tail[4 + i] = static_cast<unsigned char>(static_cast<uint32_t>(n) >> (8 * i)); }
-        out.write(reinterpret_cast<const char *>(comp), static_cast<std::streamsize>(total));
+        return total;
+    }
+    // the first `bytes` pending bytes leave as blocks of kPayload (the last one may be shorter), deflated by all host threads
+    void flush(size_t bytes) {
+        const size_t nb = (bytes + kPayload - 1) / kPayload;
+        if (!nb) return;
+        comp.resize(nb * kSlot);
+        sizes.assign(nb, 0);
+        std::mutex em;
+        std::exception_ptr err;
+        onThreads(nb, [&](size_t i) {
+            try { sizes[i] = block(pending.data() + i * kPayload, std::min(kPayload, bytes - i * kPayload), comp.data() + i * kSlot); }
+            catch (...) { std::lock_guard<std::mutex> g(em); if (!err) err = std::current_exception(); }
+        });
+        if (err) std::rethrow_exception(err);
+        for (size_t i = 0; i < nb; ++i) out.write(reinterpret_cast<const char *>(comp.data() + i * kSlot), static_cast<std::streamsize>(sizes[i]));
+        pending.erase(pending.begin(), pending.begin() + static_cast<std::ptrdiff_t>(bytes));
     }
 public:
     explicit BgzfWriter(std::ostream &o) : out(o) {}
     void write(const unsigned char *data, size_t n) {
-        constexpr size_t kPayload = 0xff00;
-        while (n) {
-            const size_t take = std::min(n, kPayload - pending.size());
-            pending.insert(pending.end(), data, data + take);
-            data += take; n -= take;
-            if (pending.size() == kPayload) { block(pending.data(), pending.size()); pending.clear(); }
-        }
+        pending.insert(pending.end(), data, data + n);
+        if (pending.size() >= kBlocksPerFlush * kPayload) flush(pending.size() / kPayload * kPayload);      // whole blocks only
     }
     void finish() {
-        if (!pending.empty()) { block(pending.data(), pending.size()); pending.clear(); }
+        flush(pending.size());
         static const unsigned char eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         out.write(reinterpret_cast<const char *>(eof), sizeof eof);
         out.flush();
@@ -870,110 +1075,194 @@ public:
 }  // namespace detail
 
 inline BamSubsetStats bamSubset(const std::string &inFile, std::ostream &out, ReadTelomereFilter &filter,
-                                size_t readsPerBatch = 1u << 20, size_t bytesPerBatch = 512u << 20) {
+                                size_t readsPerBatch = 1u << 20, size_t bytesPerBatch = 256u << 20) {
     BamSubsetStats stats;
     int fd = 0;
     if (inFile != "-") {
         fd = ::open(inFile.c_str(), O_RDONLY);
         if (fd < 0) throw std::runtime_error("cannot open BAM input '" + inFile + "'");
-        unsigned char tail[28];
-        static const unsigned char eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const off_t size = ::lseek(fd, 0, SEEK_END);
-        stats.missingEofBlock = !(size >= 28 && ::pread(fd, tail, 28, size - 28) == 28 && std::memcmp(tail, eof, 28) == 0);
-        ::lseek(fd, 0, SEEK_SET);
     }
-    gzFile in = gzdopen(fd, "rb");
-    if (!in) throw std::runtime_error("cannot read BAM input");
-    struct Closer { gzFile f; ~Closer() { gzclose(f); } } closer{in};
-    gzbuffer(in, 1u << 20);
-    auto readExact = [&](void *dst, size_t n, const char *what) {
-        size_t got = 0;
-        while (got < n) {
-            const int r = gzread(in, static_cast<char *>(dst) + got, static_cast<unsigned>(std::min<size_t>(n - got, 1u << 30)));
-            if (r <= 0) throw std::runtime_error(std::string("truncated BAM ") + what);
-            got += static_cast<size_t>(r);
-        }
-    };
+    struct Closer { int fd; ~Closer() { if (fd > 0) ::close(fd); } } closer{fd};
+    detail::BgzfParallelReader reader(fd);
     auto le32 = [](const unsigned char *p) { return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16) | (static_cast<uint32_t>(p[3]) << 24); };
 
     detail::BgzfWriter writer(out);
-    {   // header: magic, text, reference list — validated like copyBamHeader (src/bam.cpp:75-120: text <= 1 GiB,
-        // names 1 .. 1 MiB and NUL-terminated, no negative counts or lengths) and copied verbatim
-        constexpr uint32_t kMaxHeaderText = 1u << 30, kMaxReferenceName = 1u << 20;
-        std::vector<unsigned char> h(12);
-        readExact(h.data(), 8, "header");
-        if (std::memcmp(h.data(), "BAM\1", 4) != 0) throw std::runtime_error("input is not a BAM file");
-        const uint32_t ltext = le32(h.data() + 4);
-        if (ltext > kMaxHeaderText) throw std::runtime_error("invalid BAM header text length");
-        h.resize(8 + static_cast<size_t>(ltext) + 4);
-        readExact(h.data() + 8, static_cast<size_t>(ltext) + 4, "header");
-        const uint32_t nref = le32(h.data() + 8 + ltext);
-        if (nref > 0x7fffffffu) throw std::runtime_error("invalid BAM reference count");
-        writer.write(h.data(), h.size());
-        std::vector<unsigned char> ref;
-        for (uint32_t r = 0; r < nref; ++r) {
-            ref.resize(4);
-            readExact(ref.data(), 4, "reference");
-            const uint32_t lname = le32(ref.data());
-            if (lname == 0 || lname > kMaxReferenceName) throw std::runtime_error("invalid BAM reference name length");
-            ref.resize(4 + static_cast<size_t>(lname) + 4);
-            readExact(ref.data() + 4, static_cast<size_t>(lname) + 4, "reference");
-            if (ref[4 + lname - 1] != 0) throw std::runtime_error("BAM reference name is not NUL-terminated");
-            if (le32(ref.data() + 4 + lname) > 0x7fffffffu) throw std::runtime_error("invalid BAM reference length");
-            writer.write(ref.data(), ref.size());
+    // Uncompressed bytes arrive in chunks of ~bytesPerBatch, inflated by a reader thread (which spreads the blocks over the
+    // host threads) into one of two buffers while the other one is parsed and filtered.  What a chunk leaves unconsumed —
+    // the head of a record that continues in the next chunk — is carried into the headroom in front of the next one.
+    constexpr size_t kHeadroom = 1u << 20;
+    const size_t chunkBytes = std::max<size_t>(bytesPerBatch, 1u << 20);
+    struct Chunk { std::unique_ptr<unsigned char[]> buf; size_t n = 0; bool more = false; std::exception_ptr err; };
+    Chunk chunks[2];
+    for (Chunk &c : chunks) c.buf.reset(new unsigned char[kHeadroom + chunkBytes]);
+    detail::BoundedQueue<Chunk *> ready(2), spare(2);
+    spare.push(&chunks[0]); spare.push(&chunks[1]);
+    double msInflate = 0;
+    using Clock = std::chrono::steady_clock;
+    std::thread inflater([&] {
+        Chunk *c;
+        while (spare.pop(c)) {
+            const Clock::time_point t0 = Clock::now();
+            try { c->err = nullptr; c->n = reader.next(c->buf.get() + kHeadroom, chunkBytes, c->more); }
+            catch (...) { c->err = std::current_exception(); c->n = 0; c->more = false; }
+            msInflate += std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+            const bool last = !c->more;
+            ready.push(c);
+            if (last) break;
         }
-    }
+        ready.close();
+    });
+    struct Joiner { std::thread &t; detail::BoundedQueue<Chunk *> &q; ~Joiner() { q.close(); if (t.joinable()) t.join(); } } joiner{inflater, spare};
 
-    struct Rec { size_t rawOff, rawLen, seqOff; uint64_t seqLen; };
-    std::vector<unsigned char> raw;             // the batch's records, back to back (block_size included)
-    std::vector<char> seqs;                     // their decoded sequences, back to back
-    std::vector<Rec> batch;
+    const unsigned char *plain = nullptr;       // the bytes being parsed: [plain + pos, plain + plainSize)
+    size_t plainSize = 0, pos = 0;
+    std::vector<unsigned char> carry, joined;   // unconsumed tail of the last chunk; (rare) a tail larger than the headroom + the next chunk
+    // header: magic, text, reference list — validated like copyBamHeader (src/bam.cpp:75-120: text <= 1 GiB, names
+    // 1 .. 1 MiB and NUL-terminated, no negative counts or lengths) and copied verbatim.  A step of the parse that lacks
+    // bytes returns false and is retried when the next chunk has been inflated.
+    constexpr uint32_t kMaxHeaderText = 1u << 30, kMaxReferenceName = 1u << 20;
+    enum { Magic, Text, Refs, Records } phase = Magic;
+    uint32_t ltext = 0, nref = 0, refsDone = 0;
+    auto have = [&](size_t n) { return plainSize - pos >= n; };
+    auto parseHeader = [&]() -> bool {                      // true when the header is complete
+        for (;;) {
+            if (phase == Magic) {
+                if (!have(8)) return false;
+                if (std::memcmp(plain + pos, "BAM\1", 4) != 0) throw std::runtime_error("input is not a BAM file");
+                ltext = le32(plain + pos + 4);
+                if (ltext > kMaxHeaderText) throw std::runtime_error("invalid BAM header text length");
+                phase = Text;
+            } else if (phase == Text) {
+                if (!have(8 + static_cast<size_t>(ltext) + 4)) return false;
+                nref = le32(plain + pos + 8 + ltext);
+                if (nref > 0x7fffffffu) throw std::runtime_error("invalid BAM reference count");
+                writer.write(plain + pos, 8 + static_cast<size_t>(ltext) + 4);
+                pos += 8 + static_cast<size_t>(ltext) + 4;
+                phase = Refs;
+            } else if (phase == Refs) {
+                if (refsDone == nref) { phase = Records; return true; }
+                if (!have(4)) return false;
+                const uint32_t lname = le32(plain + pos);
+                if (lname == 0 || lname > kMaxReferenceName) throw std::runtime_error("invalid BAM reference name length");
+                if (!have(4 + static_cast<size_t>(lname) + 4)) return false;
+                if (plain[pos + 4 + lname - 1] != 0) throw std::runtime_error("BAM reference name is not NUL-terminated");
+                if (le32(plain + pos + 4 + lname) > 0x7fffffffu) throw std::runtime_error("invalid BAM reference length");
+                writer.write(plain + pos, 4 + static_cast<size_t>(lname) + 4);
+                pos += 4 + static_cast<size_t>(lname) + 4;
+                ++refsDone;
+            } else {
+                return true;
+            }
+        }
+    };
+
+    struct Rec { size_t rawOff, rawLen, seqAt; uint32_t seqLen; size_t seqOff; };
+    std::vector<Rec> recs;
+    std::unique_ptr<char[]> seqs;               // the chunk's decoded sequences, back to back
+    size_t seqsCap = 0;
     std::vector<const char *> ptr;
     std::vector<uint64_t> len;
     std::vector<uint8_t> pass;
-    static const char bases[] = "=ACMGRSVTWYHKDBN";
-    auto processBatch = [&]() {
-        if (batch.empty()) return;
-        ptr.clear(); len.clear();
-        for (const Rec &r : batch)
-            if (r.seqLen) { ptr.push_back(seqs.data() + r.seqOff); len.push_back(r.seqLen); }
-        pass.assign(ptr.size(), 0);
-        if (!ptr.empty()) filter.matchesPointers(ptr.data(), len.data(), ptr.size(), pass.data());
-        size_t k = 0;
-        for (const Rec &r : batch) {
-            ++stats.totalRecords;
-            if (!r.seqLen) { ++stats.missingSequenceRecords; continue; }
-            if (pass[k++]) { writer.write(raw.data() + r.rawOff, r.rawLen); ++stats.passedRecords; }
+    double msDecode = 0, msFilter = 0, msRecords = 0;
+    // two bases per packed byte
+    static const std::array<uint16_t, 256> pairs = [] {
+        std::array<uint16_t, 256> t{};
+        const char *bases = "=ACMGRSVTWYHKDBN";
+        for (unsigned v = 0; v < 256; ++v) {
+            const unsigned char two[2] = {static_cast<unsigned char>(bases[v >> 4]), static_cast<unsigned char>(bases[v & 15])};
+            uint16_t w;
+            std::memcpy(&w, two, 2);
+            t[v] = w;
         }
-        batch.clear(); raw.clear(); seqs.clear();
+        return t;
+    }();
+    auto processRecords = [&]() {
+        if (recs.empty()) return;
+        size_t total = 0;
+        for (Rec &r : recs) { r.seqOff = total; total += (static_cast<size_t>(r.seqLen) + 1) & ~size_t(1); }      // even lengths: whole pairs are stored
+        if (total > seqsCap) { seqsCap = total + total / 8; seqs.reset(new char[seqsCap]); }
+        // decode on all host threads: tasks of ~2 MB of bases
+        std::vector<size_t> cut{0};
+        for (size_t i = 0, acc = 0; i < recs.size(); ++i) { acc += recs[i].seqLen; if (acc >= (2u << 20)) { cut.push_back(i + 1); acc = 0; } }
+        if (cut.back() != recs.size()) cut.push_back(recs.size());
+        const Clock::time_point td = Clock::now();
+        detail::onThreads(cut.size() - 1, [&](size_t t) {
+            for (size_t i = cut[t]; i < cut[t + 1]; ++i) {
+                const Rec &r = recs[i];
+                const unsigned char *packed = plain + r.seqAt;
+                char *dst = seqs.get() + r.seqOff;
+                for (size_t j = 0, n = (static_cast<size_t>(r.seqLen) + 1) / 2; j < n; ++j) std::memcpy(dst + 2 * j, &pairs[packed[j]], 2);
+            }
+        });
+        msDecode += std::chrono::duration<double, std::milli>(Clock::now() - td).count();
+        for (size_t a = 0; a < recs.size(); a += readsPerBatch) {
+            const size_t z = std::min(recs.size(), a + readsPerBatch);
+            ptr.clear(); len.clear();
+            for (size_t i = a; i < z; ++i)
+                if (recs[i].seqLen) { ptr.push_back(seqs.get() + recs[i].seqOff); len.push_back(recs[i].seqLen); }
+            pass.assign(ptr.size(), 0);
+            const Clock::time_point tf = Clock::now();
+            if (!ptr.empty()) filter.matchesPointers(ptr.data(), len.data(), ptr.size(), pass.data());
+            msFilter += std::chrono::duration<double, std::milli>(Clock::now() - tf).count();
+            size_t k = 0;
+            for (size_t i = a; i < z; ++i) {
+                const Rec &r = recs[i];
+                ++stats.totalRecords;
+                if (!r.seqLen) { ++stats.missingSequenceRecords; continue; }
+                if (pass[k++]) { writer.write(plain + r.rawOff, r.rawLen); ++stats.passedRecords; }
+            }
+        }
+        recs.clear();
     };
-    for (;;) {
-        unsigned char sz[4];
-        const int got = gzread(in, sz, 4);
-        if (got == 0) break;
-        if (got != 4) throw std::runtime_error("truncated BAM record size");
-        const int32_t blockSize = static_cast<int32_t>(le32(sz));
-        if (blockSize < 32 || static_cast<uint32_t>(blockSize) > (256u << 20)) throw std::runtime_error("invalid BAM record block_size");   // BAM_MAX_RECORD_SIZE, src/bam.cpp:29
-        const size_t at = raw.size();
-        raw.resize(at + 4 + static_cast<size_t>(blockSize));
-        std::memcpy(raw.data() + at, sz, 4);
-        readExact(raw.data() + at + 4, static_cast<size_t>(blockSize), "record");
-        const unsigned char *core = raw.data() + at + 4;
-        const uint32_t lname = core[8], ncigar = static_cast<uint32_t>(core[12]) | (static_cast<uint32_t>(core[13]) << 8), lseq = le32(core + 16);
-        const uint64_t seqAt = 32ull + lname + 4ull * ncigar;
-        if (lname == 0 || lseq > 0x7fffffffu) throw std::runtime_error("invalid BAM record lengths");          // decodeSequence, src/bam.cpp:122-163
-        if (seqAt + (static_cast<uint64_t>(lseq) + 1) / 2 + lseq > static_cast<uint64_t>(blockSize))
-            throw std::runtime_error("BAM record fields exceed block_size");
-        if (core[32 + lname - 1] != 0) throw std::runtime_error("BAM read name is not NUL-terminated");
-        const size_t so = seqs.size();
-        seqs.resize(so + lseq);
-        const unsigned char *packed = core + seqAt;
-        for (uint32_t i = 0; i < lseq; ++i) seqs[so + i] = bases[(i & 1u) ? (packed[i >> 1] & 0x0f) : (packed[i >> 1] >> 4)];
-        batch.push_back(Rec{at, 4 + static_cast<size_t>(blockSize), so, lseq});
-        if (batch.size() >= readsPerBatch || raw.size() >= bytesPerBatch) processBatch();
+
+    bool more = true;
+    while (more) {
+        Chunk *c = nullptr;
+        if (!ready.pop(c)) break;
+        if (c->err) std::rethrow_exception(c->err);
+        more = c->more;
+        const Clock::time_point t1 = Clock::now();
+        // the unconsumed tail of the chunk before goes in front of this one
+        if (carry.size() <= kHeadroom) {
+            unsigned char *start = c->buf.get() + kHeadroom - carry.size();
+            if (!carry.empty()) std::memcpy(start, carry.data(), carry.size());
+            plain = start; plainSize = carry.size() + c->n;
+        } else {                                            // a record of many MB that spans chunks
+            joined.assign(carry.begin(), carry.end());
+            joined.insert(joined.end(), c->buf.get() + kHeadroom, c->buf.get() + kHeadroom + c->n);
+            plain = joined.data(); plainSize = joined.size();
+        }
+        pos = 0;
+        if (phase == Records || parseHeader()) {
+            while (have(4)) {
+                const int32_t blockSize = static_cast<int32_t>(le32(plain + pos));
+                if (blockSize < 32 || static_cast<uint32_t>(blockSize) > (256u << 20)) throw std::runtime_error("invalid BAM record block_size");   // BAM_MAX_RECORD_SIZE, src/bam.cpp:29
+                if (!have(4 + static_cast<size_t>(blockSize))) break;
+                const unsigned char *core = plain + pos + 4;
+                const uint32_t lname = core[8], ncigar = static_cast<uint32_t>(core[12]) | (static_cast<uint32_t>(core[13]) << 8), lseq = le32(core + 16);
+                const uint64_t seqAt = 32ull + lname + 4ull * ncigar;
+                if (lname == 0 || lseq > 0x7fffffffu) throw std::runtime_error("invalid BAM record lengths");          // decodeSequence, src/bam.cpp:122-163
+                if (seqAt + (static_cast<uint64_t>(lseq) + 1) / 2 + lseq > static_cast<uint64_t>(blockSize))
+                    throw std::runtime_error("BAM record fields exceed block_size");
+                if (core[32 + lname - 1] != 0) throw std::runtime_error("BAM read name is not NUL-terminated");
+                recs.push_back(Rec{pos, 4 + static_cast<size_t>(blockSize), pos + 4 + static_cast<size_t>(seqAt), lseq, 0});
+                pos += 4 + static_cast<size_t>(blockSize);
+            }
+            processRecords();                   // (record offsets point into `plain`: used before the chunk goes back)
+        }
+        carry.assign(plain + pos, plain + plainSize);
+        msRecords += std::chrono::duration<double, std::milli>(Clock::now() - t1).count();
+        if (more) spare.push(c);
     }
-    processBatch();
+    if (phase != Records) throw std::runtime_error(phase == Refs ? "truncated BAM reference" : "truncated BAM header");
+    if (!carry.empty()) throw std::runtime_error(carry.size() < 4 ? "truncated BAM record size" : "truncated BAM record");
+    spare.close();
+    if (inflater.joinable()) inflater.join();
+    stats.missingEofBlock = !reader.sawEofMarker;
     writer.finish();
+    if (std::getenv("TS_TIMING"))
+        std::fprintf(stderr, "bamSubset: locate + inflate %.0f ms (reader thread), records (walk, decode, filter, write) %.0f ms of which decode %.0f ms, filter %.0f ms\n",
+                     msInflate, msRecords, msDecode, msFilter);
     return stats;
 }
 
@@ -1304,44 +1593,6 @@ inline void printSummary(std::ostream &console, const AssemblySummary &s, bool u
 // Groups are consecutive runs of records, so everything leaves in seqPos order: the files and the console text
 // are byte-identical to readFasta + walkPaths + writeBEDFiles (tests/test_writers.py runs both).
 namespace detail {
-
-template <typename T>
-class BoundedQueue {
-public:
-    explicit BoundedQueue(size_t cap) : cap_(cap) {}
-    void push(T v) {
-        std::unique_lock<std::mutex> g(m_);
-        cv_.wait(g, [&] { return q_.size() < cap_ || closed_; });
-        q_.push_back(std::move(v));
-        cv_.notify_all();
-    }
-    void close() { { std::lock_guard<std::mutex> g(m_); closed_ = true; } cv_.notify_all(); }
-    bool pop(T &out) {
-        std::unique_lock<std::mutex> g(m_);
-        cv_.wait(g, [&] { return !q_.empty() || closed_; });
-        if (q_.empty()) return false;
-        out = std::move(q_.front());
-        q_.pop_front();
-        cv_.notify_all();
-        return true;
-    }
-private:
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::deque<T> q_;
-    size_t cap_;
-    bool closed_ = false;
-};
-
-template <typename F>
-inline void onThreads(size_t n, F &&f) {                        // f(i) for i in [0, n), dynamic, on up to 16 host threads
-    const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), n, size_t(std::max(1u, std::thread::hardware_concurrency()))}));
-    if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nt; ++t) pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
-    for (std::thread &th : pool) th.join();
-}
 
 // bases of [p, end) without the line ends ('\n', and a '\r' right before it or at the very end); [p, end) starts
 // at a line start.  Eight bytes at a time: line ends are counted, not searched for.
