@@ -9,6 +9,7 @@
 //        [--out-base <prefix>]   where the eleven output files go (default: a scratch prefix)
 //        [--read-devices 0,0]    read filter over several contexts (one per listed HIP ordinal; repeats allowed)
 //        [--reads-per-batch n]   reads per GPU batch of --fastq-subset / --bam-subset (test hook)
+//        [--bam-chunk-bytes n]   uncompressed BAM bytes inflated at a time by --bam-subset (test hook; at least 1 MiB)
 //        [--no-stream]           readFasta, then walkPaths, then writeBEDFiles (default: the three overlap in
 //                                scanFastaToFiles, records flowing in groups)   [--group-bytes n: group size, test hook]
 //        [--join-lines]          streaming, but a record's lines are joined on the host (default: text pieces — the
@@ -30,7 +31,7 @@ int main(int argc, char **argv) {
     UserInputTeloscope ui;
     std::string input, canonical, outBase;
     bool scratch = false, manualCuration = false, fastqSubsetMode = false, bamSubsetMode = false;
-    size_t fastqBlock = 512u << 20, readsPerBatch = 1u << 20, groupBytes = size_t(256) << 20, pieceBytes = size_t(4) << 20;
+    size_t fastqBlock = 512u << 20, readsPerBatch = 1u << 20, groupBytes = size_t(256) << 20, pieceBytes = size_t(4) << 20, bamChunk = size_t(256) << 20;
     bool stream = true;
     int textPieces = -1;
     std::vector<int> readDevices;
@@ -49,6 +50,7 @@ int main(int argc, char **argv) {
         else if (a == "--piece-bytes") pieceBytes = static_cast<size_t>(std::stoull(val()));   // test hook: text bytes per piece
         else if (a == "--join-lines") textPieces = 0;                                            // streaming, but records joined on the host
         else if (a == "--reads-per-batch") readsPerBatch = static_cast<size_t>(std::stoull(val()));
+        else if (a == "--bam-chunk-bytes") bamChunk = static_cast<size_t>(std::stoull(val()));    // test hook: uncompressed bytes inflated at a time
         else if (a == "--read-devices") {
             std::istringstream ds(val());
             std::string d;
@@ -88,7 +90,7 @@ int main(int argc, char **argv) {
         ui.patternInfo = expandPatternsWithOrientation(ui.rawPatterns, ui.editDistance, ui.canonicalFwd);
         if (bamSubsetMode) {                                    // runBamSubsetMode, src/bam.cpp:262-316
             ReadTelomereFilter filter(ui, readDevices);
-            const BamSubsetStats st = bamSubset(input.empty() ? "-" : input, std::cout, filter, readsPerBatch);
+            const BamSubsetStats st = bamSubset(input.empty() ? "-" : input, std::cout, filter, readsPerBatch, bamChunk);
             if (st.missingEofBlock) fprintf(stderr, "Warning: BAM input is missing the BGZF EOF marker.\n");
             if (st.missingSequenceRecords)
                 fprintf(stderr, "BAM subset: skipped %llu record%s without SEQ.\n", (unsigned long long)st.missingSequenceRecords,

@@ -209,3 +209,80 @@ def test_bam_mutation_robustness(cli, tmp_path):  # noqa: F811
         else:
             assert r.stderr.startswith(b"Error:") or b"Error:" in r.stderr, (index, mode, r.stderr[-300:])
             assert r.stdout == b"" or not r.stdout.endswith(EOF_BLOCK), (index, mode)      # no complete-looking output on failure
+
+
+def bgzf_fancy(data, chunk, gen):
+    """BGZF the way the format allows and htslib does not write it: further extra subfields around BC, a file name, a
+    comment, a header checksum (FHCRC = low 16 bits of the CRC32 of the header), empty blocks in between."""
+    out = []
+    for n, a in enumerate(range(0, len(data), chunk)):
+        piece = data[a:a + chunk]
+        co = zlib.compressobj(gen.choice([1, 6, 9]), zlib.DEFLATED, -15)
+        payload = co.compress(piece) + co.flush()
+        flags, extra_pre, extra_post, tail = 4, b"", b"", b""
+        if n % 2:
+            extra_pre = b"XY" + struct.pack("<H", 3) + b"abc"
+        if n % 3 == 0:
+            extra_post = b"ZZ" + struct.pack("<H", 0)
+        if n % 4 == 1:
+            flags |= 8; tail += b"name.bam\0"
+        if n % 5 == 2:
+            flags |= 16; tail += b"a comment\0"
+        xlen = len(extra_pre) + 6 + len(extra_post)
+        hcrc = 2 if n % 3 == 1 else 0
+        if hcrc:
+            flags |= 2
+        total = 12 + xlen + len(tail) + hcrc + len(payload) + 8
+        assert total <= 65536
+        head = b"\x1f\x8b\x08" + bytes([flags]) + b"\0\0\0\0\0\xff" + struct.pack("<H", xlen) + extra_pre + \
+            b"BC\x02\x00" + struct.pack("<H", total - 1) + extra_post + tail
+        if hcrc:
+            head += struct.pack("<H", zlib.crc32(head) & 0xFFFF)
+        out.append(head + payload + struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece)))
+        if n % 7 == 3:
+            out.append(EOF_BLOCK)                                   # an empty block in mid-stream is legal
+    return b"".join(out) + EOF_BLOCK
+
+
+@pytest.mark.gpu
+def test_bam_blocks_chunks_and_large_records(cli, tmp_path):  # noqa: F811
+    """The parallel BGZF front end: blocks with every optional gzip header field the format allows, records that span
+    blocks and inflate chunks (--bam-chunk-bytes 1 MiB against ~10 MB of records), one record larger than the headroom in
+    front of a chunk (a 1.4 Mb read), small filter batches — kept records byte for byte, in order, as the oracle says."""
+    import random
+    gen = random.Random(5)
+    rng = np.random.default_rng(123)
+    reads = make_reads()
+    big = bytearray(seqgen.random_dna(rng, 1_400_000).tobytes())
+    t = seqgen.repeat_array("CCCTAA", 2000).tobytes()
+    big[-len(t):] = t
+    reads.insert(200, ("big_telomeric", big.decode()))
+    reads.insert(300, ("big_plain", seqgen.random_dna(rng, 1_200_000).tobytes().decode()))
+    header, records, _ = build_bam(reads, 60000)
+    payload = header + b"".join(records)
+    path = tmp_path / "fancy.bam"
+    path.write_bytes(bgzf_fancy(payload, 30011, gen))
+    r = subprocess.run([cli, "--bam-subset", "--bam-chunk-bytes", str(1 << 20), "--reads-per-batch", "97", str(path)],
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-500:]
+    opts = H.parse_cli("--fastq-subset")
+    with_seq = [i for i, (_, s) in enumerate(reads) if s]
+    passes = OracleReadFilter(opts).filter([reads[i][1].encode() for i in with_seq])
+    keep = [i for i, ok in zip(with_seq, passes) if ok]
+    assert reads.index(("big_telomeric", big.decode())) in keep
+    plain = gunzip_members(r.stdout)
+    assert plain[:len(header)] == header
+    assert plain[len(header):] == b"".join(records[i] for i in keep)
+    assert b"missing the BGZF EOF marker" not in r.stderr
+    # the same bytes through a pipe
+    r2 = subprocess.run([cli, "--bam-subset", "--bam-chunk-bytes", str(1 << 20)], stdin=open(path, "rb"), capture_output=True, timeout=600)
+    assert r2.returncode == 0 and gunzip_members(r2.stdout) == plain
+    # a wrong header checksum, a BC subfield of the wrong length, reserved flag bits: clean errors
+    good = bgzf_fancy(payload, 30011, random.Random(5))
+    for what, damage in (("flags", lambda b: b[:3] + bytes([b[3] | 0x20]) + b[4:]),
+                         ("bc length", lambda b: b[:14] + b"\x03" + b[15:]),
+                         ("not gzip", lambda b: b"\x1f\x8c" + b[2:])):
+        bad = tmp_path / "bad.bam"
+        bad.write_bytes(damage(good))
+        r3 = subprocess.run([cli, "--bam-subset", str(bad)], capture_output=True, timeout=120)
+        assert r3.returncode == 1 and b"Error:" in r3.stderr, (what, r3.returncode, r3.stderr[-200:])
