@@ -132,15 +132,15 @@ def test_partition_is_consecutive_balanced_and_complete():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mode", ["windows", "tips"])
-def test_two_rank_gather_equals_single_process(mode):
+@pytest.mark.parametrize("mode,world", [("windows", 2), ("tips", 2), ("windows", 3)])
+def test_gather_over_ranks_equals_single_process(mode, world):
     import torch.multiprocessing as mp
     from teloscope_amd.distributed import decode_segments
     from tests.backends import OracleBackend
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
     windows, stats, dense, counts = q.get(timeout=240)
