@@ -73,7 +73,7 @@ constexpr uint32_t kMaxLds = 160u * 1024u;
 constexpr uint64_t kEventRing = 64;            // scans whose HIP-event times a batch remembers
 constexpr uint32_t kMaxBlocksPerTile = 448;
 constexpr uint32_t kMaxChunks = 8;             // tiles up to ~16 k positions per wave
-constexpr uint32_t kTipsChunks = 4;            // tips-only / read batches: ~8 k positions per tile
+constexpr uint32_t kTipsChunks = 6;            // tips-only / read batches: ~12 k positions per tile (measured on 15 kb reads: 2..8 chunks, TS_GEOMETRY)
 
 // diagnostics: TS_DEALT_TILES=1 keeps every scan on the round-robin tile assignment (A/B against on-demand tiles)
 bool ts_env_flag(const char *name) {
@@ -128,7 +128,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     uint32_t pin_waves = 0, pin_nch = 0;
     uint32_t pin_stage = 0;
     if (const char *g = getenv("TS_GEOMETRY")) sscanf(g, "%u,%u,%u", &pin_waves, &pin_nch, &pin_stage);
-    const uint32_t nch_max = tips ? kTipsChunks : std::max(nch_min, std::max(kMaxChunks, pin_nch));
+    const uint32_t nch_max = tips ? std::max(kTipsChunks, pin_nch) : std::max(nch_min, std::max(kMaxChunks, pin_nch));
     double best = 0.0;
     TsScanParams best_kp{};
     uint32_t best_wpt = 0;
