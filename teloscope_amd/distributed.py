@@ -212,18 +212,23 @@ def gather_shards(plan: ShardPlan, rank: int, windows, stats, dense, n_records: 
             t = t.to(torch.int16)                            # keeps the low 16 bits: the whole value
         return t if t.device == wire_dev else t.to(wire_dev)
 
+    def on_wire(t):
+        # what is handed to send / recv: 16-bit integers are not a type the NCCL / RCCL process group transports
+        # (ProcessGroupNCCL maps no int16), so they travel as their bytes
+        return t.view(torch.uint8) if t.dtype == torch.int16 else t
+
     # 2. grouped send/recv: every rank's three arrays go to their places on dst
     if rank != dst:
         ops, keep = [], []
         if windows.numel() and not directory_only:
             keep.append(wire(windows))
-            ops.append(dist.P2POp(dist.isend, keep[-1], dst, group=group, tag=1))
+            ops.append(dist.P2POp(dist.isend, on_wire(keep[-1]), dst, group=group, tag=1))
         if stats.numel():
             keep.append(wire(stats))
-            ops.append(dist.P2POp(dist.isend, keep[-1], dst, group=group, tag=2))
+            ops.append(dist.P2POp(dist.isend, on_wire(keep[-1]), dst, group=group, tag=2))
         if n_records:
             keep.append(wire(dense[:n_records]))
-            ops.append(dist.P2POp(dist.isend, keep[-1], dst, group=group, tag=3))
+            ops.append(dist.P2POp(dist.isend, on_wire(keep[-1]), dst, group=group, tag=3))
         works = dist.batch_isend_irecv(ops) if ops else []
         h = GatherHandle(works, None, keep)
         return h if async_op else h.wait()
@@ -270,7 +275,7 @@ def gather_shards(plan: ShardPlan, rank: int, windows, stats, dense, n_records: 
                 tmp = torch.empty(t.numel() + t.numel() // 8 + 16, dtype=torch.int16 if wire16 else torch.int32, device=wire_dev)
                 out.landing[key] = tmp
             tmp = tmp[:t.numel()]
-            ops.append(dist.P2POp(dist.irecv, tmp, p, group=group, tag=tag))
+            ops.append(dist.P2POp(dist.irecv, on_wire(tmp), p, group=group, tag=tag))
             landing.append((t, tmp))
     works = dist.batch_isend_irecv(ops) if ops else []
 
