@@ -115,7 +115,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     }
     // Search (waves per workgroup, chunks per tile) for the best modelled throughput:
     //   owned bases per tile x occupancy factor / instructions per tile.
-    // Instructions: ~470 per 2016-position chunk (decode, probes, count planes, per-match pass), ~170 per
+    // Instructions: ~470 per 2016-position chunk (decode, probes, planes, per-match pass: the weights of round 1's kernel), ~170 per
     // pass of the window loop (64 window fields per pass), ~100 fixed per tile.  Occupancy factors are
     // measured (profiles/r01/geometry_sweep.txt): against 16 waves per CU the kernel loses 12 % at 12
     // waves and 31 % at 8; more than 16 is not reachable (two workgroups per CU did not co-reside).
@@ -261,7 +261,7 @@ void ts_batch_release_input(ts_batch *b) {
 
 namespace {
 
-// Sizes the launch (one persistent workgroup per CU, tiles dealt round-robin to its waves) and the per-wave
+// Sizes the launch (one persistent workgroup per CU, whose waves take tiles or are dealt them) and the per-wave
 // record regions for the batch's tile range.  Every wave appends to its own region of the match buffer;
 // small ranges get the worst case (every base a match), large ones bases/4 spread evenly, grown on overflow
 // by ts_batch_sync (worst case for wave w = the owned bases of the tiles it is dealt: t = w, w + waves, ...).

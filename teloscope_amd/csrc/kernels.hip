@@ -8,8 +8,9 @@
 // Execution model: ONE WAVEFRONT PER TILE.  A tile is a run of consecutive windows of one
 // segment (up to ~16 k bases incl. the w-s halo); a wave scans its tile start to finish out of its own
 // slice of LDS, and the waves of a workgroup share nothing but the read-only match table.
-// After the table is loaded there is no workgroup barrier, no global atomic and no wait on
-// another wave anywhere: tiles are dealt round-robin, and every wave appends its packed
+// After the table is loaded there is no workgroup barrier and no wait on another wave anywhere: a wave takes
+// its next tile from a ticket counter (one relaxed global atomic per tile, issued a tile ahead of its use; tiles
+// are dealt round-robin instead where per-wave record counts must be reproducible), and every wave appends its packed
 // match records to its own region of the output (a per-tile directory {offset, count} makes
 // the stream addressable in position order).  Latency is hidden by the 16 waves per CU.
 //
@@ -18,14 +19,13 @@
 //            chunk's in flight; a tile's first chunk is requested while the previous tile's window
 //            phase runs), SWAR ASCII -> 2-bit codes (v_and / v_perm / v_bitop3, v_dot4 packs), ONE LDS read per
 //            TWO positions from the pair table ((k+1)-mer -> match bits of both positions; one byte
-//            per (k+1)-mer for k <= 6, so the (k+1)-mer is the address), nucleotide counts per 32
-//            positions into byte planes.
+//            per (k+1)-mer for k <= 6, so the (k+1)-mer is the address); the codes go to the tile's code plane.
 //            The chunk's matches (a few per cent of the positions) are compacted onto a queue and
 //            resolved 64 at a time on full wavefronts: forward/canonical flags from the flag
 //            table, the packed 32-bit record (staged in LDS, flushed in coalesced rows), and one
 //            packed ds_add_u64 per window that contains the match.
-//   phase 2  nucleotide fields of the windows: byte-plane sums (v_sad_u8) + partial ends from the
-//            codes, per step block when w is a multiple of s; 8 x u32 per window leave coalesced.
+//   phase 2  nucleotide fields of the windows, counted from the code plane (three popcounts per 32 positions,
+//            per step block when w is a multiple of s); 8 x u32 per window leave coalesced.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,7 +34,7 @@
 // Profiling only: -DTS_ABL=<mask> builds a kernel with one stage removed (results are then wrong)
 // so that stage costs can be measured under real overlap; see profiles/ablate.sh.
 //   1 record flush to global  2 nucleotide window sums  4 window match accumulation
-//   8 window record stores  16 the whole per-match pass  32 table probes  64 code/count plane stores
+//   8 window record stores  16 the whole per-match pass  32 table probes  64 code plane stores
 //   128 the consumption of the match queue (compaction still runs)
 #ifndef TS_ABL
 #define TS_ABL 0
@@ -544,10 +544,7 @@ void ts_scan_tiles(const TsScanParams P) {
         __builtin_amdgcn_wave_barrier();          // planes written above are read by other lanes below
 
         // ------------------------------------------------------------------ phase 2: windows
-        // The match fields of the tile's window records are complete (accumulated above).  Nucleotides:
-        // one lane per (window, letter); a count is the sum of the letter's bytes over the 32-position
-        // units that lie wholly inside the window (aligned ds reads, v_sad_u8 adds four bytes at a time)
-        // plus the two partial units at the ends, counted from the codes.
+        // The match fields of the tile's window records are complete (accumulated above).
         flush_stage();
         if (P.windows_on) {
             // Nucleotides.  Counted here, from the tile's code plane, not per chunk: a row (a step block when w is a
