@@ -46,4 +46,8 @@ for f in /tmp/writers_rate_3p_*; do cmp $f /tmp/writers_rate_${f#/tmp/writers_ra
 ls -la /tmp/writers_rate_* | awk '{s += $5} END {print "# output bytes (both runs):", s}'
 echo "# with -m (match vectors cross PCIe, matchSeq per record), streaming"
 TS_TIMING=1 /tmp/manifest_cli -f /tmp/writers_rate.fa --out-base /tmp/writers_rate_m $FLAGS -m 2>&1 >/dev/null | grep -E "manifest_cli"
+echo "# the reference's default mode (no -r: tips-only scan of the contig ends, terminal blocks + summary), streaming, twice"
+for run in 1 2; do
+TS_TIMING=1 /tmp/manifest_cli -f /tmp/writers_rate.fa --out-base /tmp/writers_rate_t -c TTAGGG 2>&1 >/dev/null | grep -E "manifest_cli"
+done
 rm -f /tmp/writers_rate*
