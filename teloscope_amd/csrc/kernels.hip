@@ -752,7 +752,7 @@ __device__ __forceinline__ bool pred_feed(PredState &st, const TsPredParams &Q, 
 // therefore fetched as aligned 16-byte blocks — the four-record blocks that cover the tile's records, the ends
 // masked — two blocks at a time with the next two already requested (round 2; dword loads before: 4x the instructions).
 // A block that would reach outside [matches, matches + nrec_limit) is read record by record.
-constexpr uint32_t kPredBlocks = 2;      // 16-byte blocks a thread requests at a time (and as many again in flight)
+constexpr uint32_t kPredBlocks = 2;      // 16-byte blocks a thread requests at a time (and as many again in flight; four measured the same)
 template <bool FROM_START>
 __device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
                                           const uint32_t *matches, u64 nrec_limit, uint32_t t0, uint32_t t1, u64 base, u64 n,
@@ -809,6 +809,89 @@ __device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_o
     if (st.in_block) pred_close_sub(st, Q, FROM_START);
     if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
     return st.pass;
+}
+
+// The walk of a segment that is terminal zone as a whole (n <= terminal_limit: every read), one thread per segment:
+// BOTH lists in ONE ascending pass over the records, 32-bit positions, the state machine cut down to what such a
+// segment needs.  Nothing stops the walk early there, and chaining (gap <= -k), the sub-block filters and the merging
+// (gap <= -d) are symmetric, so the reverse list gives the same blocks walked from the start as from the end (the
+// whole-wave walk of long reads below relies on the same fact).  A chain is {first position, last position, matches,
+// canonical matches}: its end is last + k and its canonical coverage canonical x k, as pred_feed accumulates them; a
+// kept chain is merged into the running block exactly like pred_close_sub does (same u32 / float expressions).
+// pred_walk<> (64-bit, zone rule, either direction) costs ~4x the instructions per record; it stays for segments longer
+// than the terminal limit.
+struct ReadChain { uint32_t first, last, counts, canon, cstart, clen; bool have_cur, pass; };
+
+__device__ __forceinline__ void read_chain_close(ReadChain &c, const TsPredParams &Q) {
+    if (c.counts >= Q.min_block_counts && c.canon > 0u) {
+        const uint32_t sstart = c.first, slen = c.last + Q.k - c.first;
+        if ((float)(c.canon * Q.k) >= Q.min_block_density * (float)slen) {
+            if (!c.have_cur) { c.cstart = sstart; c.clen = slen; c.have_cur = true; }
+            else if (sstart - (c.cstart + c.clen) <= Q.max_block_dist) c.clen = sstart + slen - c.cstart;   // (wraps to "far" when chains overlap)
+            else { if (c.clen >= Q.min_block_len) c.pass = true; c.cstart = sstart; c.clen = slen; }
+        }
+    }
+}
+
+__device__ __forceinline__ void read_chain_feed(ReadChain &c, const TsPredParams &Q, uint32_t pos, uint32_t canonical) {
+    if (c.counts != 0u && pos - c.last <= Q.max_match_dist) { ++c.counts; c.canon += canonical; c.last = pos; return; }
+    if (c.counts != 0u) read_chain_close(c, Q);
+    c.first = pos; c.last = pos; c.counts = 1u; c.canon = canonical;
+}
+
+__device__ __forceinline__ bool pred_walk_read(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                                               const uint32_t *matches, u64 nrec_limit, uint32_t t0, uint32_t t1, u64 base,
+                                               const TsPredParams &Q, bool walk_fwd, bool walk_rev) {
+    ReadChain cf = {}, cr = {};                 // (a list of fewer than two matches is not walked: walk_fwd / walk_rev)
+    for (uint32_t t = t0; t < t1 && !cf.pass && !cr.pass; ++t) {
+        const uint32_t cnt = tile_stats[4u * t];
+        if (cnt == 0u) continue;
+        const uint32_t rel0 = (uint32_t)(tiles[t].in_off - base);
+        const u64 off = tile_off[t];
+        const uint32_t *r = matches + off;
+        const uint32_t m = (uint32_t)(((uintptr_t)r >> 2) & 3u);      // see pred_walk: aligned 16-byte blocks, record i = dword m + i
+        const uint32_t nb = (m + cnt + 3u) >> 2;
+        const uint4 *ra = (const uint4 *)(r - m);
+        const bool inside = off >= m && off - m + 4ull * nb <= nrec_limit;
+        auto blk = [&](uint32_t bi) -> uint4 {
+            const uint32_t q = bi < nb ? bi : nb - 1u;
+            if (inside) return ra[q];
+            uint32_t e[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t i = 4u * q + j - m;
+                e[j] = i < cnt ? r[i] : 0u;
+            }
+            return make_uint4(e[0], e[1], e[2], e[3]);
+        };
+        auto feed_block = [&](uint32_t bi, const uint4 &v) {
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t i = 4u * bi + j - m;          // wraps below the first record, runs past the last one
+                if (i < cnt) {
+                    if (e[j] & 2u) { if (walk_fwd) read_chain_feed(cf, Q, rel0 + (e[j] >> 2), e[j] & 1u); }
+                    else if (walk_rev) read_chain_feed(cr, Q, rel0 + (e[j] >> 2), e[j] & 1u);
+                }
+            }
+        };
+        uint4 v[kPredBlocks], w[kPredBlocks];
+#pragma unroll
+        for (uint32_t j = 0; j < kPredBlocks; ++j) v[j] = blk(j);
+        for (uint32_t bi = 0; bi < nb; bi += kPredBlocks) {
+#pragma unroll
+            for (uint32_t j = 0; j < kPredBlocks; ++j) w[j] = blk(bi + kPredBlocks + j);
+#pragma unroll
+            for (uint32_t j = 0; j < kPredBlocks; ++j) if (bi + j < nb) feed_block(bi + j, v[j]);
+#pragma unroll
+            for (uint32_t j = 0; j < kPredBlocks; ++j) v[j] = w[j];
+        }
+    }
+    if (cf.counts != 0u) read_chain_close(cf, Q);
+    if (cf.have_cur && cf.clen >= Q.min_block_len) cf.pass = true;
+    if (cr.counts != 0u) read_chain_close(cr, Q);
+    if (cr.have_cur && cr.clen >= Q.min_block_len) cr.pass = true;
+    return cf.pass || cr.pass;
 }
 
 // Wave-wide inclusive prefix maximum (same DPP pattern as wave_scan_incl; lanes outside a shift read 0).
@@ -905,7 +988,10 @@ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint3
     // (the whole-wave walk assumes that the whole segment is terminal zone: every read; otherwise one thread walks it)
     const bool is_long = live && total > kLongRead && n <= Q.terminal_limit;
     bool ok = false;
-    if (live && !is_long) {
+    if (live && !is_long && n <= Q.terminal_limit) {
+        if (nfwd >= 2 || total - nfwd >= 2)
+            ok = pred_walk_read(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, Q, nfwd >= 2, total - nfwd >= 2);
+    } else if (live && !is_long) {
         if (nfwd >= 2)                                      // forward list, from the segment start
             ok = pred_walk<true>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
         if (!ok && total - nfwd >= 2)                       // reverse list, from the segment end
