@@ -243,7 +243,7 @@ int ts_batch_ensure_device(ts_batch *b) {
     }
     HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * sizeof(TsTile), b->d_tiles));
     if (!b->ext_windows) HIP_TRY(c, c->pool.take(std::max<uint64_t>(b->win_hi - b->win_lo, 1) * 32, b->d_windows));
-    HIP_TRY(c, c->pool.take(std::max<uint64_t>((uint64_t)b->region_cap * b->total_waves, 4) * 4, b->d_matches));
+    HIP_TRY(c, c->pool.take(std::max<uint64_t>((uint64_t)b->region_cap * b->total_waves, 4) * 4 + 16, b->d_matches));   // + 16: the read predicate fetches whole aligned 16-byte blocks
     HIP_TRY(c, c->pool.take((nt + 1) * 8, b->d_tile_off));
     if (!b->ext_stats) HIP_TRY(c, c->pool.take((nt + 1) * 16, b->d_stats));
     HIP_TRY(c, c->pool.take((size_t)b->total_waves * 4 + 16, b->d_fill));
@@ -833,9 +833,9 @@ int ts_batch_sync(ts_batch *b) {
         b->dealt_tiles = true;
         b->region_cap = (uint32_t)(((uint64_t)worst + worst / 8 + 64 + 3) & ~3ull);
         b->match_cap = (uint64_t)b->region_cap * b->total_waves;
-        if (b->d_matches.bytes < b->match_cap * 4) {
+        if (b->d_matches.bytes < b->match_cap * 4 + 16) {
             c->pool.give(std::move(b->d_matches));
-            HIP_TRY(c, c->pool.take(b->match_cap * 4, b->d_matches));
+            HIP_TRY(c, c->pool.take(b->match_cap * 4 + 16, b->d_matches));
         }
         int rc = ts_batch_scan(b, b->last_input, b->last_stream);
         if (rc != TS_OK) return rc;

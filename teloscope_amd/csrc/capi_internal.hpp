@@ -173,6 +173,7 @@ struct ts_batch {
     uint32_t *ext_windows = nullptr, *ext_stats = nullptr;
     const uint32_t *ext_dense = nullptr;
     uint32_t total_waves = 0, region_cap = 0;
+    bool all_terminal = false;              // (set with d_readtab) no segment longer than the terminal limit
     bool dealt_tiles = false;               // tiles dealt round-robin instead of taken on demand (see ts_batch_scan)
     uint64_t ticket_seq = 0;                // launches with on-demand tiles so far: parity = the ticket counter in use
     std::vector<uint32_t> wave_fill;

@@ -820,30 +820,55 @@ __device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_o
 // kept chain is merged into the running block exactly like pred_close_sub does (same u32 / float expressions).
 // pred_walk<> (64-bit, zone rule, either direction) costs ~4x the instructions per record; it stays for segments longer
 // than the terminal limit.
-struct ReadChain { uint32_t first, last, counts, canon, cstart, clen; bool have_cur, pass; };
+struct ReadChain { uint32_t first, last, counts, canon; };            // the open chain of one list (counts == 0: none)
+struct ReadBlock { uint32_t cstart, clen; bool have_cur, pass; };      // the running merged block of one list
 
-__device__ __forceinline__ void read_chain_close(ReadChain &c, const TsPredParams &Q) {
-    if (c.counts >= Q.min_block_counts && c.canon > 0u) {
-        const uint32_t sstart = c.first, slen = c.last + Q.k - c.first;
-        if ((float)(c.canon * Q.k) >= Q.min_block_density * (float)slen) {
-            if (!c.have_cur) { c.cstart = sstart; c.clen = slen; c.have_cur = true; }
-            else if (sstart - (c.cstart + c.clen) <= Q.max_block_dist) c.clen = sstart + slen - c.cstart;   // (wraps to "far" when chains overlap)
-            else { if (c.clen >= Q.min_block_len) c.pass = true; c.cstart = sstart; c.clen = slen; }
-        }
+// a kept chain [sstart, sstart + slen) into its list's running block: pred_close_sub's merge, same u32 expressions
+__device__ __forceinline__ void read_block_merge(ReadBlock &b, const TsPredParams &Q, uint32_t sstart, uint32_t slen) {
+    if (!b.have_cur) { b.cstart = sstart; b.clen = slen; b.have_cur = true; }
+    else if (sstart - (b.cstart + b.clen) <= Q.max_block_dist) b.clen = sstart + slen - b.cstart;   // (wraps to "far" when chains overlap)
+    else { if (b.clen >= Q.min_block_len) b.pass = true; b.cstart = sstart; b.clen = slen; }
+}
+
+// is the chain kept when it closes?  enough matches, a canonical one, the density (pred_close_sub's float expression)
+__device__ __forceinline__ bool read_chain_kept(const ReadChain &c, const TsPredParams &Q) {
+    const uint32_t slen = c.last + Q.k - c.first;
+    return (c.counts >= Q.min_block_counts) & (c.canon > 0u) & ((float)(c.canon * Q.k) >= Q.min_block_density * (float)slen);
+}
+
+// One record into the chain of ITS list, without a branch on the record: every lane walks its own read, so a branch
+// taken by any lane is paid by all sixty-four (the branchy form cost ~100 executed instructions per record, and the
+// predicate of 500 k reads as many wave-instructions as two thirds of a 3 Gb scan).  The record's list is selected by
+// v_cndmask (four chain fields in, four out per list); only a chain that is KEPT when it closes takes a branch, into
+// the merge: one record in a few thousand outside telomeres.
+__device__ __forceinline__ void read_feed(ReadChain &cf, ReadChain &cr, ReadBlock &bf, ReadBlock &br, const TsPredParams &Q,
+                                          bool sel, bool fwd, uint32_t pos, uint32_t canonical) {
+    ReadChain c;
+    c.first = fwd ? cf.first : cr.first; c.last = fwd ? cf.last : cr.last;
+    c.counts = fwd ? cf.counts : cr.counts; c.canon = fwd ? cf.canon : cr.canon;
+    const bool open = c.counts != 0u;
+    const bool ext = sel & open & (pos - c.last <= Q.max_match_dist);
+    const bool kept = sel & open & !ext & read_chain_kept(c, Q);
+    if (kept) {
+        const uint32_t slen = c.last + Q.k - c.first;
+        if (fwd) read_block_merge(bf, Q, c.first, slen); else read_block_merge(br, Q, c.first, slen);
     }
+    c.first = ext ? c.first : pos;
+    c.counts = ext ? c.counts + 1u : 1u;
+    c.canon = ext ? c.canon + canonical : canonical;
+    const bool wf = sel & fwd, wr = sel & !fwd;
+    cf.first = wf ? c.first : cf.first; cf.last = wf ? pos : cf.last; cf.counts = wf ? c.counts : cf.counts; cf.canon = wf ? c.canon : cf.canon;
+    cr.first = wr ? c.first : cr.first; cr.last = wr ? pos : cr.last; cr.counts = wr ? c.counts : cr.counts; cr.canon = wr ? c.canon : cr.canon;
 }
 
-__device__ __forceinline__ void read_chain_feed(ReadChain &c, const TsPredParams &Q, uint32_t pos, uint32_t canonical) {
-    if (c.counts != 0u && pos - c.last <= Q.max_match_dist) { ++c.counts; c.canon += canonical; c.last = pos; return; }
-    if (c.counts != 0u) read_chain_close(c, Q);
-    c.first = pos; c.last = pos; c.counts = 1u; c.canon = canonical;
-}
-
+template <uint32_t NB, bool PADDED>              // NB: 16-byte blocks a thread requests at a time (and as many again in flight);
+                                                // PADDED: the records lie in a 16-byte aligned buffer with 16 bytes of slack
 __device__ __forceinline__ bool pred_walk_read(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
                                                const uint32_t *matches, u64 nrec_limit, uint32_t t0, uint32_t t1, u64 base,
                                                const TsPredParams &Q, bool walk_fwd, bool walk_rev) {
     ReadChain cf = {}, cr = {};                 // (a list of fewer than two matches is not walked: walk_fwd / walk_rev)
-    for (uint32_t t = t0; t < t1 && !cf.pass && !cr.pass; ++t) {
+    ReadBlock bf = {}, br = {};
+    for (uint32_t t = t0; t < t1 && !bf.pass && !br.pass; ++t) {
         const uint32_t cnt = tile_stats[4u * t];
         if (cnt == 0u) continue;
         const uint32_t rel0 = (uint32_t)(tiles[t].in_off - base);
@@ -852,10 +877,10 @@ __device__ __forceinline__ bool pred_walk_read(const TsTile *tiles, const u64 *t
         const uint32_t m = (uint32_t)(((uintptr_t)r >> 2) & 3u);      // see pred_walk: aligned 16-byte blocks, record i = dword m + i
         const uint32_t nb = (m + cnt + 3u) >> 2;
         const uint4 *ra = (const uint4 *)(r - m);
-        const bool inside = off >= m && off - m + 4ull * nb <= nrec_limit;
+        const bool inside = PADDED || (off >= m && off - m + 4ull * nb <= nrec_limit);
         auto blk = [&](uint32_t bi) -> uint4 {
             const uint32_t q = bi < nb ? bi : nb - 1u;
-            if (inside) return ra[q];
+            if (PADDED || inside) return ra[q];
             uint32_t e[4];
 #pragma unroll
             for (uint32_t j = 0; j < 4u; ++j) {
@@ -869,29 +894,28 @@ __device__ __forceinline__ bool pred_walk_read(const TsTile *tiles, const u64 *t
 #pragma unroll
             for (uint32_t j = 0; j < 4u; ++j) {
                 const uint32_t i = 4u * bi + j - m;          // wraps below the first record, runs past the last one
-                if (i < cnt) {
-                    if (e[j] & 2u) { if (walk_fwd) read_chain_feed(cf, Q, rel0 + (e[j] >> 2), e[j] & 1u); }
-                    else if (walk_rev) read_chain_feed(cr, Q, rel0 + (e[j] >> 2), e[j] & 1u);
-                }
+                const bool valid = i < cnt, fwd = (e[j] & 2u) != 0u;
+                const uint32_t pos = rel0 + (e[j] >> 2), can = e[j] & 1u;
+                read_feed(cf, cr, bf, br, Q, valid & (fwd ? walk_fwd : walk_rev), fwd, pos, can);
             }
         };
-        uint4 v[kPredBlocks], w[kPredBlocks];
+        uint4 v[NB], w[NB];
 #pragma unroll
-        for (uint32_t j = 0; j < kPredBlocks; ++j) v[j] = blk(j);
-        for (uint32_t bi = 0; bi < nb; bi += kPredBlocks) {
+        for (uint32_t j = 0; j < NB; ++j) v[j] = blk(j);
+        for (uint32_t bi = 0; bi < nb; bi += NB) {
 #pragma unroll
-            for (uint32_t j = 0; j < kPredBlocks; ++j) w[j] = blk(bi + kPredBlocks + j);
+            for (uint32_t j = 0; j < NB; ++j) w[j] = blk(bi + NB + j);
 #pragma unroll
-            for (uint32_t j = 0; j < kPredBlocks; ++j) if (bi + j < nb) feed_block(bi + j, v[j]);
+            for (uint32_t j = 0; j < NB; ++j) if (bi + j < nb) feed_block(bi + j, v[j]);
 #pragma unroll
-            for (uint32_t j = 0; j < kPredBlocks; ++j) v[j] = w[j];
+            for (uint32_t j = 0; j < NB; ++j) v[j] = w[j];
         }
     }
-    if (cf.counts != 0u) read_chain_close(cf, Q);
-    if (cf.have_cur && cf.clen >= Q.min_block_len) cf.pass = true;
-    if (cr.counts != 0u) read_chain_close(cr, Q);
-    if (cr.have_cur && cr.clen >= Q.min_block_len) cr.pass = true;
-    return cf.pass || cr.pass;
+    if (cf.counts != 0u && read_chain_kept(cf, Q)) read_block_merge(bf, Q, cf.first, cf.last + Q.k - cf.first);
+    if (bf.have_cur && bf.clen >= Q.min_block_len) bf.pass = true;
+    if (cr.counts != 0u && read_chain_kept(cr, Q)) read_block_merge(br, Q, cr.first, cr.last + Q.k - cr.first);
+    if (br.have_cur && br.clen >= Q.min_block_len) br.pass = true;
+    return bf.pass || br.pass;
 }
 
 // Wave-wide inclusive prefix maximum (same DPP pattern as wave_scan_incl; lanes outside a shift read 0).
@@ -968,55 +992,75 @@ __device__ bool pred_scan_wave(const TsTile *tiles, const u64 *tile_off, const u
     return st.pass;
 }
 
-constexpr uint32_t kLongRead = 384;        // records; above this a read is walked by the whole wave
+constexpr uint32_t kLongRead = 384;        // records; above this a read is walked by a whole wave
 
-__global__ __launch_bounds__(64)
+// One thread per segment.  A read with a long match list (a telomeric read has thousands of chained matches) would leave
+// one lane running alone for hundreds of microseconds: such reads are only listed here — long_list[atomicAdd(long_count)]
+// — and walked by ts_terminal_predicate_long, one WAVE per listed read, so that they spread over the whole device instead
+// of queueing up behind each other in the waves that happen to hold several of them (0.5 % of the reads are long in
+// configs[3]: the fullest of 7 800 waves held five, and the kernel took as long as that wave: 544 us per 500 k reads).
+// READS: every segment of the batch is terminal zone as a whole and the records lie in the batch's own padded regions (the
+// host checks both): the kernel then holds only the lean
+// one-pass walk — 40-odd VGPRs instead of 63, eight waves per SIMD, and room for four blocks in flight per thread.  The walk
+// is a chain of dependent scattered loads (a launch of 280 waves takes 150 us: its latency, not its work), so what counts is
+// how many loads a thread has in flight and whether all reads of a batch are resident at once.
+#ifndef TS_PRED_WAVES
+#define TS_PRED_WAVES 8
+#endif
+#ifndef TS_PRED_NB
+#define TS_PRED_NB 4u
+#endif
+template <bool READS>
+__global__ __launch_bounds__(64, TS_PRED_WAVES)
 void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
                            const uint32_t *matches, const u64 nrec_limit, const uint32_t *seg_first_tile,
                            const u64 *seg_in_off, const u64 *seg_len, uint32_t nseg,
-                           const TsPredParams Q, unsigned char *pass) {
+                           const TsPredParams Q, unsigned char *pass, uint32_t *long_list, uint32_t *long_count) {
     const uint32_t lane = threadIdx.x;                       // one wave per workgroup
     const uint32_t si = blockIdx.x * 64u + lane;
-    const bool live = si < nseg;                              // every lane stays: the long reads below need the whole wave
-    uint32_t t0 = 0, t1 = 0;
-    u64 n = 0, base = 0, total = 0, nfwd = 0;
-    if (live) {
-        t0 = seg_first_tile[si]; t1 = seg_first_tile[si + 1];
-        n = seg_len[si]; base = seg_in_off[si];
-        for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
-    }
+    if (si >= nseg) return;
+    const uint32_t t0 = seg_first_tile[si], t1 = seg_first_tile[si + 1];
+    const u64 n = seg_len[si], base = seg_in_off[si];
+    u64 total = 0, nfwd = 0;
+    for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
     // (the whole-wave walk assumes that the whole segment is terminal zone: every read; otherwise one thread walks it)
-    const bool is_long = live && total > kLongRead && n <= Q.terminal_limit;
+    if (total > kLongRead && n <= Q.terminal_limit) {
+        long_list[atomicAdd(long_count, 1u)] = si;
+        return;
+    }
     bool ok = false;
-    if (live && !is_long && n <= Q.terminal_limit) {
+    if (READS || n <= Q.terminal_limit) {
         if (nfwd >= 2 || total - nfwd >= 2)
-            ok = pred_walk_read(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, Q, nfwd >= 2, total - nfwd >= 2);
-    } else if (live && !is_long) {
+            ok = pred_walk_read<READS ? TS_PRED_NB : 2u, READS>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, Q, nfwd >= 2, total - nfwd >= 2);
+    } else if (!READS) {
         if (nfwd >= 2)                                      // forward list, from the segment start
             ok = pred_walk<true>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
         if (!ok && total - nfwd >= 2)                       // reverse list, from the segment end
             ok = pred_walk<false>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
     }
-    u64 todo = __ballot(is_long);
-    while (todo) {                                          // wave-uniform: one long read at a time
-        const uint32_t l = (uint32_t)__builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t ut0 = (uint32_t)__builtin_amdgcn_readlane((int)t0, (int)l);
-        const uint32_t ut1 = (uint32_t)__builtin_amdgcn_readlane((int)t1, (int)l);
-        const u64 ubase = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), (int)l) << 32) |
-                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, (int)l);
-        const u64 utotal = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(total >> 32), (int)l) << 32) |
-                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)total, (int)l);
-        const u64 unfwd = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(nfwd >> 32), (int)l) << 32) |
-                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nfwd, (int)l);
-        bool uok = false;
-        if (unfwd >= 2)
-            uok = pred_scan_wave<true>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, Q, lane);
-        if (!uok && utotal - unfwd >= 2)
-            uok = pred_scan_wave<false>(tiles, tile_off, tile_stats, matches, ut0, ut1, ubase, Q, lane);
-        if (lane == l) ok = uok;
+    pass[si] = ok ? 1 : 0;
+}
+
+// One wave per listed read (grid-stride over the list), 64 records per step in parallel (pred_scan_wave).
+__global__ __launch_bounds__(64)
+void ts_terminal_predicate_long(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                                const uint32_t *matches, const uint32_t *seg_first_tile, const u64 *seg_in_off,
+                                const TsPredParams Q, unsigned char *pass, const uint32_t *long_list, const uint32_t *long_count) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = *long_count;
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t si = long_list[i];                    // wave-uniform
+        const uint32_t t0 = seg_first_tile[si], t1 = seg_first_tile[si + 1];
+        const u64 base = seg_in_off[si];
+        u64 total = 0, nfwd = 0;
+        for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
+        bool ok = false;
+        if (nfwd >= 2)
+            ok = pred_scan_wave<true>(tiles, tile_off, tile_stats, matches, t0, t1, base, Q, lane);
+        if (!ok && total - nfwd >= 2)
+            ok = pred_scan_wave<false>(tiles, tile_off, tile_stats, matches, t0, t1, base, Q, lane);
+        if (lane == 0) pass[si] = ok ? 1 : 0;
     }
-    if (live) pass[si] = ok ? 1 : 0;
 }
 
 // Packs the per-wave record regions into one dense stream (used before a D2H copy).
@@ -1066,10 +1110,24 @@ int ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_ti
 int ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,
                           const uint32_t *matches, unsigned long long nrec_limit, const uint32_t *seg_first_tile,
                           const unsigned long long *seg_in_off, const unsigned long long *seg_len, uint32_t nseg,
-                          const TsPredParams *Q, unsigned char *pass, void *stream) {
+                          const TsPredParams *Q, unsigned char *pass, uint32_t *long_list, uint32_t *long_count, int all_terminal,
+                          void *stream) {
     if (nseg == 0) return 0;
-    hipLaunchKernelGGL(ts_terminal_predicate, dim3((nseg + 63u) / 64u), dim3(64), 0, (hipStream_t)stream,
-                       tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(long_count, 0, 4, st);
+    if (e != hipSuccess) return (int)e;
+    if (all_terminal)
+        hipLaunchKernelGGL((ts_terminal_predicate<true>), dim3((nseg + 63u) / 64u), dim3(64), 0, st,
+                           tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
+                           long_list, long_count);
+    else
+        hipLaunchKernelGGL((ts_terminal_predicate<false>), dim3((nseg + 63u) / 64u), dim3(64), 0, st,
+                           tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
+                           long_list, long_count);
+    const uint32_t grid = nseg < 8192u ? nseg : 8192u;      // waves of the second kernel: it strides over the list
+    hipLaunchKernelGGL(ts_terminal_predicate_long, dim3(grid), dim3(64), 0, st,
+                       tiles, tile_off, tile_stats, matches, seg_first_tile, seg_in_off, *Q, pass,
+                       (const uint32_t *)long_list, (const uint32_t *)long_count);
     return (int)hipGetLastError();
 }
 

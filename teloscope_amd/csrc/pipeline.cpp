@@ -254,7 +254,8 @@ int batch_read_pass_device(ts_batch *b, unsigned char *d_pass, hipStream_t st) {
     ts_ctx *c = b->ctx;
     const size_t ns = b->segs.size();
     if (!ns) return TS_OK;
-    const size_t off_in = (((ns + 1) * 4 + 15) & ~(size_t)15), off_len = off_in + ns * 8, bytes = off_len + ns * 8 + 16;
+    const size_t off_in = (((ns + 1) * 4 + 15) & ~(size_t)15), off_len = off_in + ns * 8, off_long = off_len + ns * 8,
+                 off_count = (off_long + ns * 4 + 15) & ~(size_t)15, bytes = off_count + 16;      // + the list of long reads and its counter
     if (!b->d_readtab.p) {
         std::vector<char> tab(bytes);
         for (size_t i = 0; i < ns; ++i) {
@@ -263,6 +264,8 @@ int batch_read_pass_device(ts_batch *b, unsigned char *d_pass, hipStream_t st) {
             ((unsigned long long *)(tab.data() + off_len))[i] = b->segs[i].len;
         }
         ((uint32_t *)tab.data())[ns] = (uint32_t)b->tiles.size();
+        b->all_terminal = true;                                   // every segment terminal zone as a whole: the lean predicate kernel
+        for (size_t i = 0; i < ns; ++i) if (b->segs[i].len > c->params.terminal_limit) b->all_terminal = false;
         HIP_TRY(c, c->pool.take(bytes, b->d_readtab));
         HIP_TRY(c, hipMemcpyAsync(b->d_readtab.p, tab.data(), bytes, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipStreamSynchronize(st));                    // (tab is a local)
@@ -279,7 +282,10 @@ int batch_read_pass_device(ts_batch *b, unsigned char *d_pass, hipStream_t st) {
     int e = ts_k_launch_predicate((const TsTile *)b->d_tiles.p, (const unsigned long long *)b->d_tile_off.p,
                                   b->stats_ptr(), b->records_ptr(), b->records_limit(), (const uint32_t *)dt,
                                   (const unsigned long long *)(dt + off_in), (const unsigned long long *)(dt + off_len),
-                                  (uint32_t)ns, &Q, d_pass, st);
+                                  (uint32_t)ns, &Q, d_pass, (uint32_t *)(dt + off_long), (uint32_t *)(dt + off_count),
+                                  // the lean kernel: every segment terminal zone as a whole, and the records in the batch's own
+                                  // regions (16-byte aligned, 16 bytes of slack behind them: whole aligned blocks can be fetched)
+                                  (b->all_terminal && !b->dense && ((uintptr_t)b->records_ptr() & 15u) == 0) ? 1 : 0, st);
     if (e != 0) return c->fail(TS_ERR_HIP, "predicate kernel launch failed");
     return TS_OK;
 }

@@ -152,8 +152,11 @@ int  ts_k_launch_general_windows(const unsigned char *in, const uint32_t *mask, 
 int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,
                            const uint32_t *matches, unsigned long long nrec_limit, const uint32_t *seg_first_tile,
                            const unsigned long long *seg_in_off, const unsigned long long *seg_len,
-                           uint32_t nseg, const TsPredParams *Q, unsigned char *pass, void *stream);
-                           // (nrec_limit: records that may be READ behind `matches` — the predicate fetches aligned 16-byte blocks)
+                           uint32_t nseg, const TsPredParams *Q, unsigned char *pass, uint32_t *long_list,
+                           uint32_t *long_count, int all_terminal, void *stream);
+                           // (nrec_limit: records that may be READ behind `matches` — the predicate fetches aligned 16-byte blocks;
+                           //  long_list: nseg entries of scratch + long_count: one counter, for the reads a whole wave walks;
+                           //  all_terminal: no segment is longer than the terminal limit — every read batch — the lean kernel)
 int  ts_k_launch_block_call(const TsBlockCallParams *Q, const uint32_t *seg_first_tile,
                             const unsigned long long *seg_in_off, const unsigned long long *seg_len,
                             const unsigned long long *seg_abs, uint32_t nseg, uint32_t ntiles,
