@@ -9,7 +9,7 @@ MASKS="0 1 2 4 8 16 32 64 128"
 if [ "$1" = build ]; then
     for m in $MASKS; do
         (cd teloscope_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 \
-            -DTS_ABL=$m -x hip -shared -o ../../profiles/abl_$m.so kernels.hip generic.hip blockcall.hip exchange.hip capi.cpp \
+            -DTS_ABL=$m -x hip -shared -o ../../profiles/abl_$m.so kernels.hip predicate.hip generic.hip blockcall.hip exchange.hip capi.cpp \
             pipeline.cpp patterns.cpp blocks.cpp -lpthread 2>/dev/null) &
     done
     wait

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
     for m in $2; do
         (cd teloscope_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 \
-            -DTS_EXP=$m -x hip -shared -o ../../profiles/abx_$m.so kernels.hip generic.hip blockcall.hip exchange.hip capi.cpp \
+            -DTS_EXP=$m -x hip -shared -o ../../profiles/abx_$m.so kernels.hip predicate.hip generic.hip blockcall.hip exchange.hip capi.cpp \
             pipeline.cpp patterns.cpp blocks.cpp -lpthread 2>/dev/null) &
     done
     wait

@@ -1,0 +1,415 @@
+// predicate.hip — gfx950 kernels of the read predicate: "does this segment have a terminal telomere block?" decided on
+// the device from the packed match stream that ts_scan_tiles (kernels.hip) leaves behind.  Kept in a file of its own so
+// that work on it does not touch the scan kernel's source (whose hash stamps the profiled HBM traffic).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ts_internal.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------------------
+// ts_terminal_predicate: "does this segment have a terminal telomere block?" decided on the
+// device from the packed match stream — Teloscope::getTerminalBlocks (src/teloscope.cpp:29-176)
+// for both orientations, reduced to whether outBlocks would be non-empty.  One thread per
+// segment (one wave for a read with a long match list, see pred_scan_wave) walks its tiles' records (ascending for the forward list, descending for the reverse
+// list) through the same two-phase state machine: chain matches <= -k apart into sub-blocks,
+// keep those with >= minBlockCounts matches, a canonical match and canonical density >= -y,
+// merge kept sub-blocks <= -d apart, pass if a merged block is >= -l long.  This is what turns
+// ReadTelomereFilter::matches (src/read-filter.cpp:37-45) into one byte per read off the device.
+struct PredState {
+    bool in_block, have_cur, pass;
+    u64 bstart, bend, prev;                 // running sub-block
+    uint32_t counts, canon, can_cov;
+    u64 cstart, clen;                       // running merged block
+};
+
+__device__ __forceinline__ void pred_close_sub(PredState &st, const TsPredParams &Q, bool from_start) {
+    const float need = Q.min_block_density * (float)(st.bend - st.bstart);
+    if (st.counts >= Q.min_block_counts && st.canon > 0u && (float)st.can_cov >= need) {
+        const u64 sstart = st.bstart, slen = (uint32_t)(st.bend - st.bstart);
+        if (!st.have_cur) {
+            st.cstart = sstart; st.clen = slen; st.have_cur = true;
+        } else {
+            const u64 gap = from_start ? sstart - (st.cstart + st.clen) : st.cstart - (sstart + slen);
+            if (gap <= Q.max_block_dist) {
+                if (from_start) st.clen = (uint32_t)((sstart + slen) - st.cstart);
+                else { st.clen = (uint32_t)((st.cstart + st.clen) - sstart); st.cstart = sstart; }
+            } else {
+                if (st.clen >= Q.min_block_len) st.pass = true;
+                st.cstart = sstart; st.clen = slen;
+            }
+        }
+    }
+    st.in_block = false;
+}
+
+// returns false when the walk must stop (a match outside the terminal zone while no chain is open)
+__device__ __forceinline__ bool pred_feed(PredState &st, const TsPredParams &Q, bool from_start, u64 pos,
+                                          bool canonical, u64 seg_len) {
+    if (st.in_block) {
+        const u64 gap = from_start ? pos - st.prev : st.prev - pos;
+        if (gap <= Q.max_match_dist) {
+            if (from_start) st.bend = pos + Q.k; else st.bstart = pos;
+            st.counts++; st.canon += canonical; st.can_cov += canonical ? Q.k : 0u;
+            st.prev = pos;
+            return true;
+        }
+        pred_close_sub(st, Q, from_start);
+    }
+    const bool in_zone = seg_len <= Q.terminal_limit ? true
+                       : (from_start ? pos < Q.terminal_limit : pos >= seg_len - Q.terminal_limit);
+    if (!in_zone) return false;
+    st.bstart = pos; st.bend = pos + Q.k; st.prev = pos;
+    st.counts = 1; st.canon = canonical; st.can_cov = canonical ? Q.k : 0u;
+    st.in_block = true;
+    return true;
+}
+
+// One orientation of the walk, one thread per read.  Records are visited in walk order (ascending for the
+// forward list, descending for the reverse list).  Every lane walks its own read, so its loads are scattered and the
+// kernel is bound by the number of load INSTRUCTIONS (the address unit takes one lane's address per cycle): records are
+// therefore fetched as aligned 16-byte blocks — the four-record blocks that cover the tile's records, the ends
+// masked — two blocks at a time with the next two already requested (round 2; dword loads before: 4x the instructions).
+// A block that would reach outside [matches, matches + nrec_limit) is read record by record.
+constexpr uint32_t kPredBlocks = 2;      // 16-byte blocks a thread requests at a time (and as many again in flight; four measured the same)
+template <bool FROM_START>
+__device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                                          const uint32_t *matches, u64 nrec_limit, uint32_t t0, uint32_t t1, u64 base, u64 n,
+                                          const TsPredParams &Q) {
+    PredState st = {};
+    bool go = true;
+    for (uint32_t tt = 0; tt < t1 - t0 && go && !st.pass; ++tt) {
+        const uint32_t t = FROM_START ? t0 + tt : t1 - 1u - tt;
+        const uint32_t cnt = tile_stats[4u * t];
+        if (cnt == 0u) continue;
+        const u64 rel0 = tiles[t].in_off - base;
+        const u64 off = tile_off[t];
+        const uint32_t *r = matches + off;
+        const uint32_t m = (uint32_t)(((uintptr_t)r >> 2) & 3u);      // records of the first block that are not ours
+        const uint32_t nb = (m + cnt + 3u) >> 2;                         // blocks covering records 0 .. cnt-1: record i = dword m + i
+        const uint4 *ra = (const uint4 *)(r - m);
+        const bool inside = off >= m && off - m + 4ull * nb <= nrec_limit;
+        auto blk = [&](uint32_t bi) -> uint4 {             // bi-th block in walk order (clamped: loads are unconditional)
+            const uint32_t qi = bi < nb ? bi : nb - 1u;
+            const uint32_t q = FROM_START ? qi : nb - 1u - qi;
+            if (inside) return ra[q];
+            uint32_t e[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t i = 4u * q + j - m;         // wraps below the first record
+                e[j] = i < cnt ? r[i] : 0u;
+            }
+            return make_uint4(e[0], e[1], e[2], e[3]);
+        };
+        auto feed_block = [&](uint32_t bi, const uint4 &v) {
+            if (bi >= nb) return;
+            const uint32_t q = FROM_START ? bi : nb - 1u - bi;
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t jj = 0; jj < 4u; ++jj) {
+                const uint32_t j = FROM_START ? jj : 3u - jj;
+                const uint32_t i = 4u * q + j - m;
+                if (i < cnt && go && ((e[j] & 2u) != 0u) == FROM_START)
+                    go = pred_feed(st, Q, FROM_START, rel0 + (e[j] >> 2), e[j] & 1u, n);
+            }
+        };
+        uint4 v[kPredBlocks], w[kPredBlocks];
+#pragma unroll
+        for (uint32_t j = 0; j < kPredBlocks; ++j) v[j] = blk(j);
+        for (uint32_t bi = 0; bi < nb && go; bi += kPredBlocks) {
+#pragma unroll
+            for (uint32_t j = 0; j < kPredBlocks; ++j) w[j] = blk(bi + kPredBlocks + j);
+#pragma unroll
+            for (uint32_t j = 0; j < kPredBlocks; ++j) feed_block(bi + j, v[j]);
+#pragma unroll
+            for (uint32_t j = 0; j < kPredBlocks; ++j) v[j] = w[j];
+        }
+    }
+    if (st.in_block) pred_close_sub(st, Q, FROM_START);
+    if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
+    return st.pass;
+}
+
+// The walk of a segment that is terminal zone as a whole (n <= terminal_limit: every read), one thread per segment:
+// BOTH lists in ONE ascending pass over the records, 32-bit positions, the state machine cut down to what such a
+// segment needs.  Nothing stops the walk early there, and chaining (gap <= -k), the sub-block filters and the merging
+// (gap <= -d) are symmetric, so the reverse list gives the same blocks walked from the start as from the end (the
+// whole-wave walk of long reads below relies on the same fact).  A chain is {first position, last position, matches,
+// canonical matches}: its end is last + k and its canonical coverage canonical x k, as pred_feed accumulates them; a
+// kept chain is merged into the running block exactly like pred_close_sub does (same u32 / float expressions).
+// pred_walk<> (64-bit, zone rule, either direction) costs ~4x the instructions per record; it stays for segments longer
+// than the terminal limit.
+struct ReadChain { uint32_t first, last, counts, canon; };            // the open chain of one list (counts == 0: none)
+struct ReadBlock { uint32_t cstart, clen; bool have_cur, pass; };      // the running merged block of one list
+
+// a kept chain [sstart, sstart + slen) into its list's running block: pred_close_sub's merge, same u32 expressions
+__device__ __forceinline__ void read_block_merge(ReadBlock &b, const TsPredParams &Q, uint32_t sstart, uint32_t slen) {
+    if (!b.have_cur) { b.cstart = sstart; b.clen = slen; b.have_cur = true; }
+    else if (sstart - (b.cstart + b.clen) <= Q.max_block_dist) b.clen = sstart + slen - b.cstart;   // (wraps to "far" when chains overlap)
+    else { if (b.clen >= Q.min_block_len) b.pass = true; b.cstart = sstart; b.clen = slen; }
+}
+
+// is the chain kept when it closes?  enough matches, a canonical one, the density (pred_close_sub's float expression)
+__device__ __forceinline__ bool read_chain_kept(const ReadChain &c, const TsPredParams &Q) {
+    const uint32_t slen = c.last + Q.k - c.first;
+    return (c.counts >= Q.min_block_counts) & (c.canon > 0u) & ((float)(c.canon * Q.k) >= Q.min_block_density * (float)slen);
+}
+
+// One record into the chain of ITS list, without a branch on the record: every lane walks its own read, so a branch
+// taken by any lane is paid by all sixty-four (the branchy form cost ~100 executed instructions per record, and the
+// predicate of 500 k reads as many wave-instructions as two thirds of a 3 Gb scan).  The record's list is selected by
+// v_cndmask (four chain fields in, four out per list); only a chain that is KEPT when it closes takes a branch, into
+// the merge: one record in a few thousand outside telomeres.
+__device__ __forceinline__ void read_feed(ReadChain &cf, ReadChain &cr, ReadBlock &bf, ReadBlock &br, const TsPredParams &Q,
+                                          bool sel, bool fwd, uint32_t pos, uint32_t canonical) {
+    ReadChain c;
+    c.first = fwd ? cf.first : cr.first; c.last = fwd ? cf.last : cr.last;
+    c.counts = fwd ? cf.counts : cr.counts; c.canon = fwd ? cf.canon : cr.canon;
+    const bool open = c.counts != 0u;
+    const bool ext = sel & open & (pos - c.last <= Q.max_match_dist);
+    const bool kept = sel & open & !ext & read_chain_kept(c, Q);
+    if (kept) {
+        const uint32_t slen = c.last + Q.k - c.first;
+        if (fwd) read_block_merge(bf, Q, c.first, slen); else read_block_merge(br, Q, c.first, slen);
+    }
+    c.first = ext ? c.first : pos;
+    c.counts = ext ? c.counts + 1u : 1u;
+    c.canon = ext ? c.canon + canonical : canonical;
+    const bool wf = sel & fwd, wr = sel & !fwd;
+    cf.first = wf ? c.first : cf.first; cf.last = wf ? pos : cf.last; cf.counts = wf ? c.counts : cf.counts; cf.canon = wf ? c.canon : cf.canon;
+    cr.first = wr ? c.first : cr.first; cr.last = wr ? pos : cr.last; cr.counts = wr ? c.counts : cr.counts; cr.canon = wr ? c.canon : cr.canon;
+}
+
+template <uint32_t NB, bool PADDED>              // NB: 16-byte blocks a thread requests at a time (and as many again in flight);
+                                                // PADDED: the records lie in a 16-byte aligned buffer with 16 bytes of slack
+__device__ __forceinline__ bool pred_walk_read(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                                               const uint32_t *matches, u64 nrec_limit, uint32_t t0, uint32_t t1, u64 base,
+                                               const TsPredParams &Q, bool walk_fwd, bool walk_rev) {
+    ReadChain cf = {}, cr = {};                 // (a list of fewer than two matches is not walked: walk_fwd / walk_rev)
+    ReadBlock bf = {}, br = {};
+    for (uint32_t t = t0; t < t1 && !bf.pass && !br.pass; ++t) {
+        const uint32_t cnt = tile_stats[4u * t];
+        if (cnt == 0u) continue;
+        const uint32_t rel0 = (uint32_t)(tiles[t].in_off - base);
+        const u64 off = tile_off[t];
+        const uint32_t *r = matches + off;
+        const uint32_t m = (uint32_t)(((uintptr_t)r >> 2) & 3u);      // see pred_walk: aligned 16-byte blocks, record i = dword m + i
+        const uint32_t nb = (m + cnt + 3u) >> 2;
+        const uint4 *ra = (const uint4 *)(r - m);
+        const bool inside = PADDED || (off >= m && off - m + 4ull * nb <= nrec_limit);
+        auto blk = [&](uint32_t bi) -> uint4 {
+            const uint32_t q = bi < nb ? bi : nb - 1u;
+            if (PADDED || inside) return ra[q];
+            uint32_t e[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t i = 4u * q + j - m;
+                e[j] = i < cnt ? r[i] : 0u;
+            }
+            return make_uint4(e[0], e[1], e[2], e[3]);
+        };
+        auto feed_block = [&](uint32_t bi, const uint4 &v) {
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t i = 4u * bi + j - m;          // wraps below the first record, runs past the last one
+                const bool valid = i < cnt, fwd = (e[j] & 2u) != 0u;
+                const uint32_t pos = rel0 + (e[j] >> 2), can = e[j] & 1u;
+                read_feed(cf, cr, bf, br, Q, valid & (fwd ? walk_fwd : walk_rev), fwd, pos, can);
+            }
+        };
+        uint4 v[NB], w[NB];
+#pragma unroll
+        for (uint32_t j = 0; j < NB; ++j) v[j] = blk(j);
+        for (uint32_t bi = 0; bi < nb; bi += NB) {
+#pragma unroll
+            for (uint32_t j = 0; j < NB; ++j) w[j] = blk(bi + NB + j);
+#pragma unroll
+            for (uint32_t j = 0; j < NB; ++j) if (bi + j < nb) feed_block(bi + j, v[j]);
+#pragma unroll
+            for (uint32_t j = 0; j < NB; ++j) v[j] = w[j];
+        }
+    }
+    if (cf.counts != 0u && read_chain_kept(cf, Q)) read_block_merge(bf, Q, cf.first, cf.last + Q.k - cf.first);
+    if (bf.have_cur && bf.clen >= Q.min_block_len) bf.pass = true;
+    if (cr.counts != 0u && read_chain_kept(cr, Q)) read_block_merge(br, Q, cr.first, cr.last + Q.k - cr.first);
+    if (br.have_cur && br.clen >= Q.min_block_len) br.pass = true;
+    return bf.pass || br.pass;
+}
+
+// Wave-wide inclusive prefix maximum in 6 DPP steps (row_shr 1/2/4/8 inside each row of 16, then row_bcast:15 into rows
+// 1,3 and row_bcast:31 into rows 2,3); lanes outside a shift read 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return v > o ? v : o;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+    v = dpp_max<0x111, 0xf>(v);
+    v = dpp_max<0x112, 0xf>(v);
+    v = dpp_max<0x114, 0xf>(v);
+    v = dpp_max<0x118, 0xf>(v);
+    v = dpp_max<0x142, 0xa>(v);
+    v = dpp_max<0x143, 0xc>(v);
+    return v;
+}
+
+// A long match list walked by a whole wave, 64 records per step IN PARALLEL (all arguments wave-uniform).
+// Valid when the whole segment is terminal zone (n <= terminal_limit: every read): then the walk never stops
+// early, and the two-phase state machine gives the same answer in either direction, so both lists are taken in
+// ascending order.  Per batch: the lanes hold the records; a prefix maximum gives every selected record its
+// predecessor, a ballot marks the records that start a new sub-block (gap > -k), and the scalar state machine
+// then steps once per SUB-BLOCK (counts by popcount of ballots) instead of once per record — a telomeric read
+// is one sub-block of thousands of matches.
+template <bool FWD_LIST>
+__device__ bool pred_scan_wave(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                               const uint32_t *matches, uint32_t t0, uint32_t t1, u64 base,
+                               const TsPredParams &Q, uint32_t lane) {
+    PredState st = {};
+    bool have_prev = false;
+    u64 prev = 0;                                            // last selected position so far
+    for (uint32_t t = t0; t < t1 && !st.pass; ++t) {
+        const uint32_t cnt = tile_stats[4u * t];
+        if (cnt == 0u) continue;
+        const u64 rel0 = tiles[t].in_off - base;
+        const uint32_t *r = matches + tile_off[t];
+        for (uint32_t b0 = 0; b0 < cnt; b0 += 64u) {
+            const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
+            const uint32_t rec = lane < nb ? r[b0 + lane] : 0u;
+            const bool sel = lane < nb && (((rec & 2u) != 0u) == FWD_LIST);
+            u64 rem = __ballot(sel);
+            if (rem == 0ull) continue;
+            const uint32_t p32 = rec >> 2;                   // tile-relative position (a batch lies in one tile)
+            // predecessor among the selected records of this batch: prefix maximum of (position + 1), one lane down
+            const uint32_t incl = wave_scan_max(sel ? p32 + 1u : 0u);
+            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xf, 0xf, false);   // wave_shr:1
+            const uint32_t first_lane = (uint32_t)__builtin_ctzll(rem);
+            const u64 first_pos = rel0 + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)first_lane);
+            const bool first_head = !have_prev || first_pos - prev > Q.max_match_dist;
+            const bool head = sel && (before == 0u ? first_head : p32 - (before - 1u) > Q.max_match_dist);
+            const u64 heads = __ballot(head), canon = __ballot(sel && (rec & 1u));
+            while (rem) {                                    // one step per run of chained records
+                const uint32_t l0 = (uint32_t)__builtin_ctzll(rem);
+                if ((heads >> l0) & 1ull) {
+                    if (st.in_block) { st.can_cov = st.canon * Q.k; pred_close_sub(st, Q, true); }
+                    st.bstart = rel0 + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)l0);
+                    st.counts = 0; st.canon = 0; st.in_block = true;
+                }
+                const u64 later = l0 < 63u ? heads & ~((2ull << l0) - 1ull) : 0ull;      // heads after l0
+                const u64 run = later ? rem & ((1ull << (uint32_t)__builtin_ctzll(later)) - 1ull) : rem;
+                st.counts += (uint32_t)__popcll(run);
+                st.canon += (uint32_t)__popcll(run & canon);
+                const uint32_t last_lane = 63u - (uint32_t)__builtin_clzll(run);
+                prev = rel0 + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)last_lane);
+                st.bend = prev + Q.k;
+                have_prev = true;
+                rem &= ~run;
+            }
+        }
+    }
+    if (st.in_block) { st.can_cov = st.canon * Q.k; pred_close_sub(st, Q, true); }
+    if (st.have_cur && st.clen >= Q.min_block_len) st.pass = true;
+    return st.pass;
+}
+
+constexpr uint32_t kLongRead = 384;        // records; above this a read is walked by a whole wave
+
+// One thread per segment.  A read with a long match list (a telomeric read has thousands of chained matches) would leave
+// one lane running alone for hundreds of microseconds: such reads are only listed here — long_list[atomicAdd(long_count)]
+// — and walked by ts_terminal_predicate_long, one WAVE per listed read, so that they spread over the whole device instead
+// of queueing up behind each other in the waves that happen to hold several of them (0.5 % of the reads are long in
+// configs[3]: the fullest of 7 800 waves held five, and the kernel took as long as that wave: 544 us per 500 k reads).
+// READS: every segment of the batch is terminal zone as a whole and the records lie in the batch's own padded regions (the
+// host checks both): the kernel then holds only the lean
+// one-pass walk — 40-odd VGPRs instead of 63, eight waves per SIMD, and room for four blocks in flight per thread.  The walk
+// is a chain of dependent scattered loads (a launch of 280 waves takes 150 us: its latency, not its work), so what counts is
+// how many loads a thread has in flight and whether all reads of a batch are resident at once.
+#ifndef TS_PRED_WAVES
+#define TS_PRED_WAVES 8
+#endif
+#ifndef TS_PRED_NB
+#define TS_PRED_NB 4u
+#endif
+template <bool READS>
+__global__ __launch_bounds__(64, TS_PRED_WAVES)
+void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                           const uint32_t *matches, const u64 nrec_limit, const uint32_t *seg_first_tile,
+                           const u64 *seg_in_off, const u64 *seg_len, uint32_t nseg,
+                           const TsPredParams Q, unsigned char *pass, uint32_t *long_list, uint32_t *long_count) {
+    const uint32_t lane = threadIdx.x;                       // one wave per workgroup
+    const uint32_t si = blockIdx.x * 64u + lane;
+    if (si >= nseg) return;
+    const uint32_t t0 = seg_first_tile[si], t1 = seg_first_tile[si + 1];
+    const u64 n = seg_len[si], base = seg_in_off[si];
+    u64 total = 0, nfwd = 0;
+    for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
+    // (the whole-wave walk assumes that the whole segment is terminal zone: every read; otherwise one thread walks it)
+    if (total > kLongRead && n <= Q.terminal_limit) {
+        long_list[atomicAdd(long_count, 1u)] = si;
+        return;
+    }
+    bool ok = false;
+    if (READS || n <= Q.terminal_limit) {
+        if (nfwd >= 2 || total - nfwd >= 2)
+            ok = pred_walk_read<READS ? TS_PRED_NB : 2u, READS>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, Q, nfwd >= 2, total - nfwd >= 2);
+    } else if (!READS) {
+        if (nfwd >= 2)                                      // forward list, from the segment start
+            ok = pred_walk<true>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
+        if (!ok && total - nfwd >= 2)                       // reverse list, from the segment end
+            ok = pred_walk<false>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
+    }
+    pass[si] = ok ? 1 : 0;
+}
+
+// One wave per listed read (grid-stride over the list), 64 records per step in parallel (pred_scan_wave).
+__global__ __launch_bounds__(64)
+void ts_terminal_predicate_long(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+                                const uint32_t *matches, const uint32_t *seg_first_tile, const u64 *seg_in_off,
+                                const TsPredParams Q, unsigned char *pass, const uint32_t *long_list, const uint32_t *long_count) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = *long_count;
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t si = long_list[i];                    // wave-uniform
+        const uint32_t t0 = seg_first_tile[si], t1 = seg_first_tile[si + 1];
+        const u64 base = seg_in_off[si];
+        u64 total = 0, nfwd = 0;
+        for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
+        bool ok = false;
+        if (nfwd >= 2)
+            ok = pred_scan_wave<true>(tiles, tile_off, tile_stats, matches, t0, t1, base, Q, lane);
+        if (!ok && total - nfwd >= 2)
+            ok = pred_scan_wave<false>(tiles, tile_off, tile_stats, matches, t0, t1, base, Q, lane);
+        if (lane == 0) pass[si] = ok ? 1 : 0;
+    }
+}
+
+
+}  // namespace
+
+int ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,
+                          const uint32_t *matches, unsigned long long nrec_limit, const uint32_t *seg_first_tile,
+                          const unsigned long long *seg_in_off, const unsigned long long *seg_len, uint32_t nseg,
+                          const TsPredParams *Q, unsigned char *pass, uint32_t *long_list, uint32_t *long_count, int all_terminal,
+                          void *stream) {
+    if (nseg == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(long_count, 0, 4, st);
+    if (e != hipSuccess) return (int)e;
+    if (all_terminal)
+        hipLaunchKernelGGL((ts_terminal_predicate<true>), dim3((nseg + 63u) / 64u), dim3(64), 0, st,
+                           tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
+                           long_list, long_count);
+    else
+        hipLaunchKernelGGL((ts_terminal_predicate<false>), dim3((nseg + 63u) / 64u), dim3(64), 0, st,
+                           tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
+                           long_list, long_count);
+    const uint32_t grid = nseg < 8192u ? nseg : 8192u;      // waves of the second kernel: it strides over the list
+    hipLaunchKernelGGL(ts_terminal_predicate_long, dim3(grid), dim3(64), 0, st,
+                       tiles, tile_off, tile_stats, matches, seg_first_tile, seg_in_off, *Q, pass,
+                       (const uint32_t *)long_list, (const uint32_t *)long_count);
+    return (int)hipGetLastError();
+}
+
