@@ -489,10 +489,18 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     int slot = 0;
     bool used[ts_ctx::kUpSlots] = {false, false, false};
     size_t wi = 0;
+    // The host stage of group g (ordering + block calling on the host threads) runs on a background thread while the
+    // device stage of group g + 1 (upload, kernels, D2H) runs here: what a group's host stage reads lives in a GroupHost.
+    struct GroupHost { std::vector<SegL> G; std::vector<TsGeneralTile> tiles; std::vector<unsigned long long> tile_off;
+                       std::vector<uint32_t> recs, wins; };
+    std::thread host_job;
+    std::atomic<int> host_err{TS_OK};
+    struct JoinJob { std::thread &t; ~JoinJob() { if (t.joinable()) t.join(); } } join_job{host_job};
     while (wi < which.size()) {
         // ---- a group of consecutive segments, ~256 MB of regions; layout = the regions back to back, 16-byte aligned
-        std::vector<SegL> G;
-        std::vector<TsGeneralTile> tiles;
+        std::shared_ptr<GroupHost> gh = std::make_shared<GroupHost>();
+        std::vector<SegL> &G = gh->G;
+        std::vector<TsGeneralTile> &tiles = gh->tiles;
         std::vector<UpPiece> pieces;
         uint64_t off = 0, nwin_total = 0;
         while (wi < which.size() && (G.empty() || off < target)) {
@@ -555,8 +563,9 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         const auto t1 = Clock::now();
         // ---- kernels
         char *const dt = (char *)d_tab.p;
-        std::vector<uint32_t> wins, recs;
-        std::vector<unsigned long long> tile_off(nt + 1, 0);
+        std::vector<uint32_t> &wins = gh->wins, &recs = gh->recs;
+        std::vector<unsigned long long> &tile_off = gh->tile_off;
+        tile_off.assign(nt + 1, 0);
         {
             std::lock_guard<std::mutex> lk(c->mtx);
             if (ts_k_launch_general_match((const unsigned char *)d_in.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt, &c->gpat,
@@ -588,13 +597,20 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         if (nwin_total) HIP_TRY(c, hipMemcpyAsync(wins.data(), d_win.p, nwin_total * 32, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         const auto t2 = Clock::now();
+        t_up += ms_between(t0, t1); t_dev += ms_between(t1, t2);
         // ---- host: records -> MatchInfo in the reference's push order, then block calling; one job per segment
+        if (host_job.joinable()) host_job.join();                     // (one host stage at a time: it takes all the host threads)
+        if (host_err.load() != TS_OK) return host_err.load();
+        host_job = std::thread([c, gh, ns, tips, s, w, ov, out, &host_err, &t_host]() {
+        const auto th0 = Clock::now();
+        const std::vector<SegL> &G = gh->G;
+        const std::vector<TsGeneralTile> &tiles = gh->tiles;
+        const std::vector<unsigned long long> &tile_off = gh->tile_off;
+        const std::vector<uint32_t> &recs = gh->recs, &wins = gh->wins;
         std::atomic<size_t> next{0};
         std::atomic<int> first_err{TS_OK};
         const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
         const unsigned spare = std::max(1u, std::min(16u, hw_threads) / (unsigned)std::max<size_t>(1, std::min<size_t>(ns, 16)));
-        const uint32_t t1w = s - L, t2w = ov - L;                                // uint32 wrap, src/teloscope.cpp:413-415
-        (void)t1w; (void)t2w;
         auto worker = [&]() {
             for (size_t gi; (gi = next.fetch_add(1)) < ns && first_err.load() == TS_OK;) {
                 const SegL &sl = G[gi];
@@ -648,11 +664,14 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
             for (unsigned i = 0; i < nthreads; ++i) pool.emplace_back(worker);
             for (std::thread &th : pool) th.join();
         }
-        if (first_err.load() != TS_OK) return first_err.load();
-        t_up += ms_between(t0, t1); t_dev += ms_between(t1, t2); t_host += ms_between(t2, Clock::now());
+        if (first_err.load() != TS_OK) { int e = TS_OK; host_err.compare_exchange_strong(e, first_err.load()); }
+        t_host += ms_between(th0, Clock::now());
+        });
     }
+    if (host_job.joinable()) host_job.join();
+    if (host_err.load() != TS_OK) return host_err.load();
     if (timing)
-        fprintf(stderr, "general path: %zu segments, wall %.1f ms: upload %.1f ms, kernels + D2H %.1f ms, host ordering + block calling %.1f ms\n",
+        fprintf(stderr, "general path: %zu segments, wall %.1f ms: upload %.1f ms, kernels + D2H %.1f ms, host ordering + block calling %.1f ms (on a thread of its own, one group behind)\n",
                 which.size(), ms_between(t_begin, Clock::now()), t_up, t_dev, t_host);
     return TS_OK;
 }
