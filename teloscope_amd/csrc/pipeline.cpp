@@ -22,6 +22,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -160,6 +161,52 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
     }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned nthr = std::min(8u, std::max(1u, hw / 2u));
+    // The staging threads live for the whole call, not for one 32 MB chunk (a chunk is staged in ~0.6 ms: spawning and
+    // joining eight threads for each cost a tenth of the upload): job(t) runs on worker t, the caller is worker 0.
+    struct StagePool {
+        std::mutex m;
+        std::condition_variable cv_go, cv_done;
+        std::function<void(unsigned)> job;
+        uint64_t generation = 0;
+        unsigned active = 0, pending = 0;
+        bool quit = false;
+        std::vector<std::thread> threads;
+        explicit StagePool(unsigned n) {
+            for (unsigned t = 1; t < n; ++t)
+                threads.emplace_back([this, t] {
+                    uint64_t seen = 0;
+                    for (;;) {
+                        std::function<void(unsigned)> f;
+                        {
+                            std::unique_lock<std::mutex> g(m);
+                            cv_go.wait(g, [&] { return quit || generation != seen; });
+                            if (quit) return;
+                            seen = generation;
+                            if (t >= active) continue;
+                            f = job;
+                        }
+                        f(t);
+                        { std::lock_guard<std::mutex> g(m); if (--pending == 0) cv_done.notify_one(); }
+                    }
+                });
+        }
+        void run(unsigned n, const std::function<void(unsigned)> &f) {       // f(0 .. n-1), n <= workers
+            if (n <= 1 || threads.empty()) { for (unsigned t = 0; t < n; ++t) f(t); return; }
+            { std::lock_guard<std::mutex> g(m); job = f; active = n; pending = n - 1; ++generation; }
+            cv_go.notify_all();
+            f(0);
+            std::unique_lock<std::mutex> g(m);
+            cv_done.wait(g, [&] { return pending == 0; });
+        }
+        ~StagePool() {
+            { std::lock_guard<std::mutex> g(m); quit = true; }
+            cv_go.notify_all();
+            for (std::thread &th : threads) th.join();
+        }
+    };
+    uint64_t total_bytes = 0;
+    for (const UpPiece &pc : pieces) total_bytes += pc.len;
+    StagePool stage_pool(total_bytes >= (8u << 20) ? nthr : 1u);
     std::atomic<int> bad_text{0};
     size_t i = 0;
     while (i < pieces.size()) {
@@ -180,25 +227,20 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
             for (size_t k = i; k < j; ++k) copy_part(k);
         } else if (any_text) {                                   // whole parts, handed out dynamically
             std::atomic<size_t> next{i};
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < nt; ++t) pool.emplace_back([&] { for (size_t k; (k = next.fetch_add(1)) < j;) copy_part(k); });
-            for (std::thread &th : pool) th.join();
-        } else {                                                 // thread t copies the bytes [t, t+1) * share of the concatenated parts
+            stage_pool.run(nt, [&](unsigned) { for (size_t k; (k = next.fetch_add(1)) < j;) copy_part(k); });
+        } else {                                                 // worker t copies the bytes [t, t+1) * share of the concatenated parts
             const size_t share = (bytes + nt - 1) / nt;
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < nt; ++t)
-                pool.emplace_back([&, t] {
-                    const size_t lo = (size_t)t * share, hi = std::min<size_t>(bytes, lo + share);
-                    size_t at = 0;
-                    for (size_t k = i; k < j; ++k) {
-                        const UpPiece &pc = pieces[k];
-                        const size_t a = std::max(lo, at), z = std::min<size_t>(hi, at + pc.len);
-                        if (z > a) std::memcpy(dst + (pc.off - c0) + (a - at), pc.src + (a - at), z - a);
-                        at += pc.len;
-                        if (at >= hi) break;
-                    }
-                });
-            for (std::thread &th : pool) th.join();
+            stage_pool.run(nt, [&](unsigned t) {
+                const size_t lo = (size_t)t * share, hi = std::min<size_t>(bytes, lo + share);
+                size_t at = 0;
+                for (size_t k = i; k < j; ++k) {
+                    const UpPiece &pc = pieces[k];
+                    const size_t a = std::max(lo, at), z = std::min<size_t>(hi, at + pc.len);
+                    if (z > a) std::memcpy(dst + (pc.off - c0) + (a - at), pc.src + (a - at), z - a);
+                    at += pc.len;
+                    if (at >= hi) break;
+                }
+            });
         }
         const uint64_t hi = pieces[j - 1].off + pieces[j - 1].len;
         HIP_TRY(c, hipMemcpyAsync((char *)din + (c0 - lo_all), dst, hi - c0, hipMemcpyHostToDevice, c->up_stream));
