@@ -160,7 +160,8 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
         }
     }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nthr = std::min(8u, std::max(1u, hw / 2u));
+    unsigned nthr = std::min(8u, std::max(1u, hw / 2u));
+    if (const char *e = getenv("TS_STAGE_THREADS")) { const int n = atoi(e); if (n > 0) nthr = (unsigned)std::min(n, 64); }
     // The staging threads live for the whole call, not for one 32 MB chunk (a chunk is staged in ~0.6 ms: spawning and
     // joining eight threads for each cost a tenth of the upload): job(t) runs on worker t, the caller is worker 0.
     struct StagePool {
