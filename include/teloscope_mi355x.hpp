@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstddef>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -198,17 +199,15 @@ private:
         const uint64_t absPos = seg.absPos;
         const bool tipsOnly = seg.tipsOnly;
         SegmentData sd;
-        sd.windows.reserve(o.n_windows);
-        for (uint64_t i = 0; i < o.n_windows; ++i) {
-            const ts_window &g = o.windows[i];
-            WindowData w;
-            w.windowStart = g.window_start; w.currentWindowSize = g.current_window_size;
-            for (int c = 0; c < 4; ++c) w.nucleotideCounts[c] = g.nucleotide_counts[c];
-            w.gcContent = g.gc_content; w.shannonEntropy = g.shannon_entropy;
-            w.canonicalCovered = g.canonical_covered; w.nonCanonicalCovered = g.non_canonical_covered;
-            w.fwdCovered = g.fwd_covered; w.revCovered = g.rev_covered;
-            sd.windows.push_back(w);
-        }
+        // WindowData mirrors ts_window field for field (the trailing `reserved` word is WindowData's padding): the
+        // 6 M windows of a 3 Gb assembly are copied as bytes, not converted one by one
+        static_assert(sizeof(WindowData) == sizeof(ts_window) && offsetof(WindowData, currentWindowSize) == offsetof(ts_window, current_window_size) &&
+                      offsetof(WindowData, nucleotideCounts) == offsetof(ts_window, nucleotide_counts) && offsetof(WindowData, gcContent) == offsetof(ts_window, gc_content) &&
+                      offsetof(WindowData, shannonEntropy) == offsetof(ts_window, shannon_entropy) && offsetof(WindowData, canonicalCovered) == offsetof(ts_window, canonical_covered) &&
+                      offsetof(WindowData, nonCanonicalCovered) == offsetof(ts_window, non_canonical_covered) && offsetof(WindowData, fwdCovered) == offsetof(ts_window, fwd_covered) &&
+                      offsetof(WindowData, revCovered) == offsetof(ts_window, rev_covered), "WindowData and ts_window must share their layout");
+        sd.windows.resize(o.n_windows);
+        if (o.n_windows) std::memcpy(static_cast<void *>(sd.windows.data()), o.windows, o.n_windows * sizeof(ts_window));
         if (!writerViewOnly) {
             if (!tipsOnly) sd.allMatches.reserve(o.n_matches);
             sd.fwdMatches.reserve(o.n_matches / 2 + 1);
