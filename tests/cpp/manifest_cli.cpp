@@ -35,6 +35,7 @@ int main(int argc, char **argv) {
     bool stream = true;
     int textPieces = -1;
     std::vector<int> readDevices;
+    std::string bamList;
     std::vector<std::string> rawPatterns;
     bool hasPatterns = false;
     for (int i = 1; i < argc; ++i) {
@@ -43,6 +44,7 @@ int main(int argc, char **argv) {
         if (a == "-f") input = val();
         else if (a == "--fastq-subset") fastqSubsetMode = true;
         else if (a == "--bam-subset") bamSubsetMode = true;
+        else if (a == "--bam-subset-each") { bamSubsetMode = true; bamList = val(); }   // test hook: one filter, many inputs (below)
         else if (a == "--fastq-block") fastqBlock = static_cast<size_t>(std::stoull(val()));   // test hook: arena size in bytes
         else if (a == "--out-base") outBase = val();
         else if (a == "--no-stream") stream = false;
@@ -88,6 +90,26 @@ int main(int argc, char **argv) {
         ui.rawPatterns = (hasPatterns && !rawPatterns.empty()) ? rawPatterns
                        : std::vector<std::string>{ui.canonicalFwd, ui.canonicalRev};
         ui.patternInfo = expandPatternsWithOrientation(ui.rawPatterns, ui.editDistance, ui.canonicalFwd);
+        if (bamSubsetMode && !bamList.empty()) {
+            // the mutation suite: every file named in the list through bamSubset with ONE filter (device start-up once);
+            // <file>.out = the subset, or <file>.err = the error message when bamSubset threw
+            ReadTelomereFilter filter(ui, readDevices);
+            std::ifstream list(bamList);
+            std::string path;
+            while (std::getline(list, path)) {
+                if (path.empty()) continue;
+                try {
+                    std::ofstream out(path + ".out", std::ios::binary);
+                    const BamSubsetStats st = bamSubset(path, out, filter, readsPerBatch, bamChunk);
+                    out.close();
+                    std::ofstream(path + ".ok") << st.passedRecords << " " << st.totalRecords << " " << (st.missingEofBlock ? 1 : 0) << "\n";
+                } catch (const std::exception &e) {
+                    std::remove((path + ".out").c_str());
+                    std::ofstream(path + ".err") << e.what() << "\n";
+                }
+            }
+            return 0;
+        }
         if (bamSubsetMode) {                                    // runBamSubsetMode, src/bam.cpp:262-316
             ReadTelomereFilter filter(ui, readDevices);
             const BamSubsetStats st = bamSubset(input.empty() ? "-" : input, std::cout, filter, readsPerBatch, bamChunk);

@@ -286,3 +286,87 @@ def test_bam_blocks_chunks_and_large_records(cli, tmp_path):  # noqa: F811
         bad.write_bytes(damage(good))
         r3 = subprocess.run([cli, "--bam-subset", str(bad)], capture_output=True, timeout=120)
         assert r3.returncode == 1 and b"Error:" in r3.stderr, (what, r3.returncode, r3.stderr[-200:])
+
+
+@pytest.mark.gpu
+def test_bam_mutation_suite_512(cli, tmp_path):  # noqa: F811
+    """512 deterministic mutations of a small BAM (the size of the reference's fast suite, scripts/test_bam_subset.py:589-633:
+    random bytes, truncations of the compressed file and of the payload, bit flips in the compressed bytes and in the
+    payload, corrupt block_size / l_read_name / n_cigar_op / l_seq, a damaged BGZF header field, dropped and duplicated
+    blocks), all through ONE process and one filter (--bam-subset-each): every input ends in a clean error or in a
+    structurally valid BAM whose records are a subset of the input's, in order — never a crash, never a hang."""
+    import random
+    gen = random.Random(20260)
+    reads = [("record_%d" % i, ("TTAGGG" * (3 + i % 9)) if i % 3 else "ACGT" * (5 + i % 7)) for i in range(24)]
+    header, records, _ = build_bam(reads, 60000)
+    payload = header + b"".join(records)
+    roff = len(header)
+    good = bgzf(payload, 700)                                     # several blocks
+    blocks = []
+    pos = 0
+    while pos < len(good):
+        size = struct.unpack_from("<H", good, pos + 16)[0] + 1
+        blocks.append(good[pos:pos + size]); pos += size
+    paths = []
+    for index in range(512):
+        mode = index % 11
+        if mode == 0:
+            data = bytes(gen.getrandbits(8) for _ in range(gen.randrange(0, 3000)))
+        elif mode == 1:
+            data = good[:gen.randrange(len(good) + 1)]
+        elif mode == 2:
+            data = bgzf(payload[:gen.randrange(len(payload) + 1)], 700)
+        elif mode == 3:
+            m = bytearray(good); m[gen.randrange(len(m))] ^= 1 << gen.randrange(8); data = bytes(m)
+        elif mode == 4:
+            m = bytearray(payload); m[gen.randrange(len(m))] ^= 1 << gen.randrange(8); data = bgzf(bytes(m), 700)
+        elif mode == 5:
+            m = bytearray(payload); struct.pack_into("<i", m, roff, gen.randrange(-64, 4096)); data = bgzf(bytes(m), 700)
+        elif mode == 6:
+            m = bytearray(payload); m[roff + 12] = gen.randrange(256); data = bgzf(bytes(m), 700)
+        elif mode == 7:
+            m = bytearray(payload); struct.pack_into("<H", m, roff + 16, gen.randrange(65536)); data = bgzf(bytes(m), 700)
+        elif mode == 8:
+            m = bytearray(payload); struct.pack_into("<i", m, roff + 20, gen.randrange(-8, 1 << 20)); data = bgzf(bytes(m), 700)
+        elif mode == 9:
+            m = bytearray(good); at = gen.randrange(18); m[at] = gen.randrange(256); data = bytes(m)      # first block's gzip / BGZF header
+        else:
+            bl = list(blocks)
+            k = gen.randrange(len(bl))
+            if gen.random() < 0.5: del bl[k]
+            else: bl.insert(k, bl[k])
+            data = b"".join(bl)
+        path = tmp_path / ("m%03d.bam" % index)
+        path.write_bytes(data)
+        paths.append(path)
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join(str(p) + "\n" for p in paths))
+    r = subprocess.run([cli, "--bam-subset-each", str(lst), "-x", "0", "-l", "18"], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-500:]
+    record_set = {bytes(x) for x in records}
+    n_ok = n_err = 0
+    for index, path in enumerate(paths):
+        ok, err, out = (tmp_path / (path.name + ext) for ext in (".ok", ".err", ".out"))
+        assert ok.exists() != err.exists(), (index, "neither / both verdicts")
+        if err.exists():
+            n_err += 1
+            assert err.read_text().strip() and not out.exists(), index
+            continue
+        n_ok += 1
+        data = out.read_bytes()
+        assert data.endswith(EOF_BLOCK), index
+        plain = gunzip_members(data)
+        at = plain.index(b"chr1\0") + 5 + 4 if b"chr1\0" in plain[:len(header) + 8] else None
+        assert at is not None, index
+        prev = -1
+        while at < len(plain):                                    # a valid record stream ...
+            (bs,) = struct.unpack_from("<i", plain, at)
+            assert 32 <= bs and at + 4 + bs <= len(plain), index
+            rec = plain[at:at + 4 + bs]
+            if index % 11 in (1, 2):                              # ... of the input's own records, in order, where the damage kept them whole
+                assert rec in record_set, index
+                where = records.index(rec)
+                assert where > prev, index
+                prev = where
+            at += 4 + bs
+    assert n_ok >= 40 and n_err >= 200, (n_ok, n_err)             # both outcomes occur in numbers
