@@ -606,6 +606,8 @@ def run_scan(args, rank, local_rank, world, dev, backend):
             L.ts_free_segments(seg_out, n)
         if world == 1 and not args.no_e2e:
             out["pcie_inclusive"] = pcie_inclusive(L, K, tel, buf, offsets, lens, total)
+            out["pcie_inclusive"]["host_placement"] = ("process and library threads on NUMA node %d, the GPU's" % HOST_NUMA_NODE
+                                                       if HOST_NUMA_NODE is not None else "not bound to a NUMA node")
         print(json.dumps(out), flush=True)
     if strong:
         if result_batch:
@@ -791,7 +793,9 @@ def run_reads(args, rank, local_rank, world, dev, backend):
             if L.ts_filter_reads(rf._ctx.ptr, ptrs, hl, npool, hp) != 0:
                 raise RuntimeError(rf._ctx.error())
         dt = time.perf_counter() - c0
-        out["pcie_inclusive"] = {"entry_point": "ts_filter_reads (pageable host reads in, pass bytes out; groups of ~256 MB pipelined)",
+        out["pcie_inclusive"] = {"host_placement": ("process and library threads on NUMA node %d, the GPU's" % HOST_NUMA_NODE
+                                                    if HOST_NUMA_NODE is not None else "not bound to a NUMA node"),
+                                 "entry_point": "ts_filter_reads (pageable host reads in, pass bytes out; groups of ~256 MB pipelined)",
                                  "reads": rounds * npool, "seconds": round(dt, 4), "reads_per_s": round(rounds * npool / dt, 1),
                                  "gbases_per_s": round(rounds * pool_bases / dt / 1e9, 3),
                                  "note": "a pool of %d host reads filtered %d times on one GPU" % (npool, rounds)}
@@ -824,7 +828,35 @@ def run_reads(args, rank, local_rank, world, dev, backend):
     barrier()
 
 
+def bind_to_gpu_node(dev_index):
+    """One process per GPU, on the CPUs of the NUMA node the GPU hangs off (what `numactl --cpunodebind` does for a rank):
+    on a two-socket host a pageable buffer or a staging thread on the other socket costs 15-20 % of the PCIe-inclusive
+    rate.  Returns the node, or None when the topology cannot be read (then nothing is bound)."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(dev_index)
+        bus = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+        if node < 0 or os.environ.get("TS_NO_NUMA_BIND"):
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        want = os.sched_getaffinity(0) & cpus
+        if not want:
+            return None
+        os.sched_setaffinity(0, want)
+        return node
+    except Exception:
+        return None
+
+
+HOST_NUMA_NODE = None
+
+
 def main():
+    global HOST_NUMA_NODE
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -840,6 +872,7 @@ def main():
     backend = os.environ.get("TS_BENCH_BACKEND") or ("nccl" if ndev >= int(os.environ.get("LOCAL_WORLD_SIZE", world)) else "gloo")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    HOST_NUMA_NODE = bind_to_gpu_node(dev_index)
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":

@@ -201,6 +201,12 @@ void    ts_destroy(ts_ctx *ctx);
 int     ts_uses_fast_path(const ts_ctx *ctx);
 /* 1 if segments of this kind (full scan / tips-only) may come as TS_INPUT_TEXT_PIECES: those the tiled kernel scans. */
 int     ts_takes_text_input(const ts_ctx *ctx, int tips_only);
+/* Restricts the CALLING thread (and the threads it starts from then on) to the CPUs of the NUMA node the context's
+ * device is attached to; returns 1 if it did, 0 if the topology is unknown, the thread's mask holds none of those CPUs,
+ * or TS_NO_NUMA_BIND is set.  The library's own pipeline threads do this by themselves; a front end calls it on the threads
+ * that read, parse and format around the scan (the reference's ThreadPool workers, src/input.cpp:719-733): on a two-socket
+ * host a buffer or a staging thread on the other socket costs 15-20 % of the PCIe-inclusive rate. */
+int     ts_bind_thread_to_device(const ts_ctx *ctx);
 
 /* ---- Teloscope::scanSegment, batched (src/teloscope.cpp:537-658).  out[i] receives the
  *      SegmentData of segs[i]; a one-element call equals one scanSegment() call.  Host

@@ -246,6 +246,8 @@ public:
     // does the library take TS_INPUT_TEXT_PIECES segments for this parameter set (the tiled kernel's; the general path
     // wants the bases joined)?
     bool takesTextPieces() const { return ts_takes_text_input(ctx.get(), userInput.ultraFastMode ? 1 : 0) != 0; }
+    // keeps the calling thread (and the threads it starts) on the CPUs of the device's NUMA node: ts_bind_thread_to_device
+    bool bindThreadToDevice() const { return ts_bind_thread_to_device(ctx.get()) != 0; }
 
     // one scanSegment call of a batch; the bases are borrowed for the duration of the call (any case:
     // the library folds case itself, as unmaskSequence would have)
@@ -435,6 +437,8 @@ public:
 
     // bool ReadTelomereFilter::matches(std::string sequence)
     bool matches(std::string sequence) { return matchesBatch({std::move(sequence)})[0]; }
+    // keeps the calling thread (and the threads it starts) on the CPUs of the first device's NUMA node
+    bool bindThreadToDevice() const { return !raw.empty() && ts_bind_thread_to_device(raw[0]) != 0; }
 };
 
 }  // namespace teloscope_mi355x

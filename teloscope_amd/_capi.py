@@ -113,7 +113,7 @@ SYMBOLS = [
     "ts_batch_matches_ptr", "ts_batch_download", "ts_batch_download_blocks", "ts_batch_segment_summary",
     "ts_batch_get_tiles", "ts_batch_range_info", "ts_batch_partition", "ts_batch_restrict", "ts_batch_bind_results",
     "ts_batch_export", "ts_batch_adopt", "ts_batch_tile_stats_ptr", "ts_filter_reads_multi", "ts_batch_read_pass",
-    "ts_batch_wire16_ok", "ts_wire_widen_u16", "ts_takes_text_input",
+    "ts_batch_wire16_ok", "ts_wire_widen_u16", "ts_takes_text_input", "ts_bind_thread_to_device",
 ]
 
 
@@ -184,6 +184,7 @@ def lib():
     L.ts_destroy.argtypes = [C.c_void_p]
     L.ts_uses_fast_path.argtypes = [C.c_void_p]
     L.ts_takes_text_input.argtypes = [C.c_void_p, C.c_int]
+    L.ts_bind_thread_to_device.argtypes = [C.c_void_p]
     L.ts_scan_segments.argtypes = [C.c_void_p, C.POINTER(SegmentIn), C.c_size_t, C.POINTER(SegmentOut)]
     L.ts_scan_segments_blocks.argtypes = [C.c_void_p, C.POINTER(SegmentIn), C.c_size_t, C.POINTER(SegmentOut),
                                           C.POINTER(SegmentCounts)]

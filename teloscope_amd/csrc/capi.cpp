@@ -17,6 +17,9 @@
 #include <string>
 #include <vector>
 
+#include <cctype>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/mman.h>
 
 #include "capi_internal.hpp"
@@ -79,6 +82,37 @@ constexpr uint32_t kTipsChunks = 6;            // tips-only / read batches: ~12 
 bool ts_env_flag(const char *name) {
     const char *v = getenv(name);
     return v && *v && *v != '0';
+}
+
+// CPUs of the NUMA node of HIP device `dev`, from sysfs (Linux): /sys/bus/pci/devices/<bus id>/numa_node and
+// /sys/devices/system/node/node<N>/cpulist.  Empty when anything is missing.
+std::vector<int> device_node_cpus(int dev) {
+    std::vector<int> cpus;
+    if (ts_env_flag("TS_NO_NUMA_BIND")) return cpus;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) return cpus;
+    for (char *q = bus; *q; ++q) *q = (char)tolower((unsigned char)*q);
+    int node = -1;
+    {
+        FILE *f = fopen((std::string("/sys/bus/pci/devices/") + bus + "/numa_node").c_str(), "r");
+        if (!f) return cpus;
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    if (node < 0) return cpus;
+    FILE *f = fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+    if (!f) return cpus;
+    int a = 0, b = 0;
+    for (;;) {                                             // "0-63,128-191"
+        if (fscanf(f, "%d", &a) != 1) break;
+        b = a;
+        int ch = fgetc(f);
+        if (ch == '-') { if (fscanf(f, "%d", &b) != 1) break; ch = fgetc(f); }
+        for (int k = a; k <= b && k < 4096; ++k) cpus.push_back(k);
+        if (ch != ',') break;
+    }
+    fclose(f);
+    return cpus;
 }
 
 // groups of workgroups that share a ticket counter (TS_TICKET_GROUPS overrides, for measurements)
@@ -230,6 +264,17 @@ void range_cover(const ts_batch *b, uint64_t lo, uint64_t hi, ts_range_info &r) 
 }
 
 }  // namespace
+
+void ts_ctx::bind_this_thread() const {
+    if (node_cpus.empty()) return;
+    cpu_set_t cur, want;
+    CPU_ZERO(&cur); CPU_ZERO(&want);
+    if (pthread_getaffinity_np(pthread_self(), sizeof cur, &cur) != 0) return;
+    int n = 0;
+    for (int k : node_cpus)
+        if (k < CPU_SETSIZE && CPU_ISSET(k, &cur)) { CPU_SET(k, &want); ++n; }
+    if (n > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof want, &want);       // (threads started from here inherit it)
+}
 
 // Allocates (from the context's pool) the device state of the batch's tile range; idempotent.
 int ts_batch_ensure_device(ts_batch *b) {
@@ -404,6 +449,7 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->num_cu = prop.multiProcessorCount;
         if (c->num_cu <= 0) c->num_cu = 256;
+        c->node_cpus = device_node_cpus(dev);
     }
 
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
@@ -564,6 +610,22 @@ extern "C" {
 int ts_uses_fast_path(const ts_ctx *ctx) {
     std::string why;
     return ctx && ts_full_scan_supported(ctx, why) ? 1 : 0;
+}
+
+int ts_bind_thread_to_device(const ts_ctx *ctx) {
+    if (!ctx || ctx->node_cpus.empty()) return 0;
+    cpu_set_t before, after;
+    CPU_ZERO(&before); CPU_ZERO(&after);
+    if (pthread_getaffinity_np(pthread_self(), sizeof before, &before) != 0) return 0;
+    ctx->bind_this_thread();
+    if (pthread_getaffinity_np(pthread_self(), sizeof after, &after) != 0) return 0;
+    for (int k : ctx->node_cpus) if (k < CPU_SETSIZE && CPU_ISSET(k, &after)) {
+        // bound iff nothing outside the node is left in the mask
+        for (int j = 0; j < CPU_SETSIZE; ++j)
+            if (CPU_ISSET(j, &after) && !std::binary_search(ctx->node_cpus.begin(), ctx->node_cpus.end(), j)) return 0;
+        return 1;
+    }
+    return 0;
 }
 
 int ts_takes_text_input(const ts_ctx *ctx, int tips_only) {

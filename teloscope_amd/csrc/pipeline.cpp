@@ -95,11 +95,19 @@ int ensure_streams(ts_ctx *c) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
-    for (int i = 0; i < ts_ctx::kUpSlots; ++i) {
-        HIP_TRY(c, c->pin_up[i].ensure(32u << 20));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->pin_up_ev[i], hipEventDisableTiming));
-    }
-    return TS_OK;
+    // the pinned staging ring is allocated (and so placed) by a thread on the device's NUMA node
+    int rc = TS_OK;
+    std::thread alloc([&] {
+        c->bind_this_thread();
+        DeviceGuard g(c->device);
+        for (int i = 0; i < ts_ctx::kUpSlots && rc == TS_OK; ++i) {
+            if (c->pin_up[i].ensure(32u << 20) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "cannot allocate the pinned staging ring"); break; }
+            std::memset(c->pin_up[i].p, 0, 32u << 20);           // first touch here
+            if (hipEventCreateWithFlags(&c->pin_up_ev[i], hipEventDisableTiming) != hipSuccess) rc = c->fail(TS_ERR_HIP, "hipEventCreate failed");
+        }
+    });
+    alloc.join();
+    return rc;
 }
 
 struct UpPiece { uint64_t off; const char *src; uint64_t len; uint64_t text_len; };   // off: byte offset in the input layout; len: bases;
@@ -397,6 +405,7 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
     Semaphore inputs_in_flight(2);                               // device input buffers alive at a time
 
     std::thread uploader([&] {
+        ctx->bind_this_thread();
         DeviceGuard g(ctx->device);
         int slot = 0;
         bool used[ts_ctx::kUpSlots] = {false, false, false};
@@ -424,6 +433,7 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
     });
 
     std::thread scanner([&] {
+        ctx->bind_this_thread();
         DeviceGuard g(ctx->device);
         Group *gr;
         while (to_scan.pop(gr)) {
@@ -442,6 +452,7 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
     });
 
     std::thread downloader([&] {
+        ctx->bind_this_thread();
         DeviceGuard g(ctx->device);
         std::lock_guard<std::mutex> dl(ctx->down_mtx);           // the pinned landing areas are this call's
         Group *gr;

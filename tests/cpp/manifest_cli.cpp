@@ -94,6 +94,7 @@ int main(int argc, char **argv) {
             // the mutation suite: every file named in the list through bamSubset with ONE filter (device start-up once);
             // <file>.out = the subset, or <file>.err = the error message when bamSubset threw
             ReadTelomereFilter filter(ui, readDevices);
+            filter.bindThreadToDevice();
             std::ifstream list(bamList);
             std::string path;
             while (std::getline(list, path)) {
@@ -112,6 +113,7 @@ int main(int argc, char **argv) {
         }
         if (bamSubsetMode) {                                    // runBamSubsetMode, src/bam.cpp:262-316
             ReadTelomereFilter filter(ui, readDevices);
+            filter.bindThreadToDevice();                          // this thread and the ones bamSubset starts: the GPU's NUMA node
             const BamSubsetStats st = bamSubset(input.empty() ? "-" : input, std::cout, filter, readsPerBatch, bamChunk);
             if (st.missingEofBlock) fprintf(stderr, "Warning: BAM input is missing the BGZF EOF marker.\n");
             if (st.missingSequenceRecords)
@@ -123,6 +125,7 @@ int main(int argc, char **argv) {
         if (fastqSubsetMode) {                                  // src/main.cpp:699-716: reads in, telomeric reads out
             const auto f0 = std::chrono::steady_clock::now();
             ReadTelomereFilter filter(ui, readDevices);
+            filter.bindThreadToDevice();
             const auto f1 = std::chrono::steady_clock::now();
             const FastqSubsetResult r = fastqSubset(input.empty() ? "-" : input, std::cout, filter, readsPerBatch, fastqBlock);
             if (getenv("TS_TIMING"))
@@ -133,6 +136,7 @@ int main(int argc, char **argv) {
             return 0;
         }
         Teloscope teloscope(ui);
+        teloscope.bindThreadToDevice();                           // reader, scan and writer threads start from here: the GPU's NUMA node
 
         const bool timing = getenv("TS_TIMING") != nullptr;      // stage times to stderr
         auto now = [] { return std::chrono::steady_clock::now(); };
