@@ -128,3 +128,16 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower().replace("no cpu", ""), os.path.join(dp, f)
+
+
+def test_bind_thread_needs_a_device(ta):
+    """ts_bind_thread_to_device: a planning-only context has no device, hence no NUMA node to go to — 0, and the calling
+    thread's CPU mask is left alone (null context likewise)."""
+    import os
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import parse_cli, user_input
+    tel = ta.Teloscope(user_input(parse_cli("x.fa -r"), device=K.DEVICE_NONE))
+    before = os.sched_getaffinity(0)
+    assert K.lib().ts_bind_thread_to_device(tel._ctx.ptr) == 0
+    assert K.lib().ts_bind_thread_to_device(None) == 0
+    assert os.sched_getaffinity(0) == before

@@ -359,3 +359,22 @@ def test_taken_tiles_equal_dealt_tiles_and_survive_overflow():
     L.ts_batch_destroy(b)
     plan.close()
     tight.close()
+
+
+def test_bind_thread_to_device_node():
+    """ts_bind_thread_to_device on a real context: where the host publishes the device's NUMA node, a worker thread that calls
+    it ends up on a subset of its former CPUs (and the call says 1); where it does not, the mask stays and the call says 0."""
+    import threading
+    from teloscope_amd import _capi as K
+    opts, tel = _teloscope(HEADLINE)
+    res = {}
+
+    def worker():
+        before = os.sched_getaffinity(0)
+        res["rc"] = K.lib().ts_bind_thread_to_device(tel._ctx.ptr)
+        res["before"], res["after"] = before, os.sched_getaffinity(0)
+    t = threading.Thread(target=worker)
+    t.start(); t.join()
+    assert res["rc"] in (0, 1) and res["after"] <= res["before"] and len(res["after"]) > 0
+    if res["rc"] == 0:
+        assert res["after"] == res["before"] or len(res["after"]) < len(res["before"])
