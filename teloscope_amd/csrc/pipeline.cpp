@@ -95,14 +95,13 @@ int ensure_streams(ts_ctx *c) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
-    // the pinned staging ring is allocated (and so placed) by a thread on the device's NUMA node
+    // the pinned staging ring is allocated — pinning touches the pages, which places them — by a thread on the device's NUMA node
     int rc = TS_OK;
     std::thread alloc([&] {
         c->bind_this_thread();
         DeviceGuard g(c->device);
         for (int i = 0; i < ts_ctx::kUpSlots && rc == TS_OK; ++i) {
             if (c->pin_up[i].ensure(32u << 20) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "cannot allocate the pinned staging ring"); break; }
-            std::memset(c->pin_up[i].p, 0, 32u << 20);           // first touch here
             if (hipEventCreateWithFlags(&c->pin_up_ev[i], hipEventDisableTiming) != hipSuccess) rc = c->fail(TS_ERR_HIP, "hipEventCreate failed");
         }
     });
