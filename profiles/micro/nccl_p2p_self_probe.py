@@ -21,4 +21,12 @@ for w in dist.batch_isend_irecv(ops):
 torch.cuda.synchronize()
 got = land.to(torch.int32) & 0xFFFF
 print("all_gather:", int(cnt[0].item()), " p2p to self over the NCCL group:", "ok" if torch.equal(got, src) else "MISMATCH")
+# the other collectives bench.py issues at N > 1: gather of pass bytes / int64 summaries (async), MAX all-reduce of a double
+pb = torch.ones(1000, dtype=torch.uint8, device="cuda"); outb = [torch.zeros_like(pb)]
+dist.gather(pb, outb, dst=0)
+sm = torch.arange(800, dtype=torch.int64, device="cuda"); outs = [torch.zeros_like(sm)]
+dist.gather(sm, outs, dst=0, async_op=True).wait()
+t = torch.tensor([1.25], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+torch.cuda.synchronize()
+print("gather u8:", bool(outb[0].all()), " gather i64 async:", torch.equal(outs[0], sm), " all_reduce MAX f64:", float(t.item()))
 dist.destroy_process_group()
