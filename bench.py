@@ -361,7 +361,7 @@ def run_scan(args, rank, local_rank, world, dev, backend):
     ui = user_input(opts, device=dev.index)
     tel = ta.Teloscope(ui)
     L = K.lib()
-    strong = world > 1 and not args.weak
+    strong = (world > 1 or bool(os.environ.get("TS_BENCH_FORCE_STRONG"))) and not args.weak
     total = int(args.gbases * 1e9)
     lens = contig_lengths(total, args.contigs, 42 + (rank if args.weak else 0))
     n = len(lens)
@@ -904,7 +904,15 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     HOST_NUMA_NODE = bind_to_gpu_node(dev_index)
-    if world > 1:
+    # TS_BENCH_FORCE_STRONG=1: the N > 1 code path (shard object, export, exchange, adopt) with ONE rank on the RCCL group — as
+    # far as the sharded path can be taken on real RCCL where two ranks cannot share a GPU (rehearsal hook, not a bench mode)
+    forced = world == 1 and bool(os.environ.get("TS_BENCH_FORCE_STRONG"))
+    if forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or forced:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -916,7 +924,7 @@ def main():
         else:
             run_scan(args, rank, local_rank, world, dev, backend)
     finally:
-        if world > 1:
+        if world > 1 or forced:
             import torch.distributed as dist
             dist.destroy_process_group()
 
