@@ -410,6 +410,19 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         elapsed = time.perf_counter() - t0
         return max_over_ranks(elapsed), ev0.elapsed_time(ev1) / max(1, nsteps)
 
+    # A device that has just been handed its first kernels is not in its steady state: the launch time of this kernel rises
+    # for five launches (0.81 -> 0.97 ms) and then falls for about forty (-> 0.765 ms; profiles/r02/launch_ramp.txt).  The W
+    # warm-up steps of the contract are taken from there: SETTLE_LAUNCHES untimed scans first (reported in config.settle).
+    def settle(step_fn, drain_fn):
+        for n in range(SETTLE_LAUNCHES):
+            step_fn(n)
+            if n % 8 == 7:
+                drain_fn()
+        drain_fn()
+        torch.cuda.synchronize()
+        settle_info["launches"] = SETTLE_LAUNCHES
+
+    settle_info = {"launches": 0}
     out = None
     if not strong:
         # ---------------------------------------------------------------- N = 1 (or weak scaling)
@@ -438,6 +451,7 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                     pending[j].wait()
                     pending[j] = None
 
+        settle(step, drain)
         for i in range(args.warmup):
             step(i)
         drain()
@@ -486,6 +500,7 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                     pending[j].wait()
                     pending[j] = None
 
+        settle(step, drain)
         for i in range(max(args.warmup, slots)):
             step(i)
         drain()
@@ -569,7 +584,9 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                                       args.gbases, n, " per GPU" if args.weak and world > 1 else (" sharded over %d GPUs" % world if world > 1 else ""),
                                       args.flags, len(ui.patternInfo), len(ui.patternInfo[0][0])),
                        "bases": total, "windows": n_windows, "matches": n_matches, "tiles": n_tiles,
-                       "device_ms_per_step_events": round(dev_ms, 4), **extra_cfg},
+                       "device_ms_per_step_events": round(dev_ms, 4),
+                       "settle": "%d untimed scans before the %d warm-up steps: the device's launch time needs ~40 launches to reach "
+                                 "its steady state (profiles/r02/launch_ramp.txt)" % (settle_info["launches"], args.warmup), **extra_cfg},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_source,
@@ -884,6 +901,7 @@ def bind_to_gpu_node(dev_index):
 
 
 HOST_NUMA_NODE = None
+SETTLE_LAUNCHES = 96            # untimed scans before the warm-up steps, see run_scan (profiles/summarize.py drops them too)
 
 
 def main():

@@ -7,6 +7,12 @@ import os
 import sys
 
 root = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from bench import SETTLE_LAUNCHES
+except Exception:
+    SETTLE_LAUNCHES = 0
+DROP = SETTLE_LAUNCHES + 5          # launches of bench.py's default run before its timed region
 
 
 def find(pattern):
@@ -30,10 +36,11 @@ for f in find("*kernel_trace.csv"):
     for name, v in sorted(durs.items(), key=lambda kv: -sum(kv[1]))[:6]:
         print("   %-60s n=%d avg=%.1f us min=%.1f us max=%.1f us" % (name[:60], len(v), sum(v) / len(v) / 1e3,
                                                               min(v) / 1e3, max(v) / 1e3))
-        if "ts_scan_tiles" in name and len(v) > 5:
-            # bench.py runs 5 untimed warm-up launches first; its roofline uses the timed ones
-            t = v[5:]
-            print("   %-60s      timed launches only (first 5 dropped): n=%d avg=%.1f us" % ("", len(t), sum(t) / len(t) / 1e3))
+        if "ts_scan_tiles" in name and len(v) > DROP:
+            # bench.py runs its settling scans and 5 untimed warm-up launches first; its roofline uses the timed ones
+            t = v[DROP:]
+            print("   %-60s      timed launches only (first %d dropped: %d settling + 5 warm-up): n=%d avg=%.1f us" % (
+                "", DROP, DROP - 5, len(t), sum(t) / len(t) / 1e3))
 for f in find("*counter_collection.csv"):
     acc = {}
     with open(f) as fh:
