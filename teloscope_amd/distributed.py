@@ -203,9 +203,9 @@ def gather_shards(plan: ShardPlan, rank: int, windows, stats, dense, n_records: 
         n_records = 0
     else:
         mine = torch.tensor([int(n_records)], dtype=torch.int64, device=wire_dev)
-        allc = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allc, mine, group=group)
-        counts = [int(c.item()) for c in allc]
+        allc = torch.zeros(world, dtype=torch.int64, device=wire_dev)
+        dist.all_gather(list(allc.split(1)), mine, group=group)   # views of one buffer: read back with ONE copy, not one per rank
+        counts = [int(c) for c in allc.tolist()]
 
     def wire(t):
         if wire16:
