@@ -42,9 +42,28 @@
 // Experiments and diagnostics (profiles/abx.sh): -DTS_EXP=<mask>.  8: every tile leaves the 100 MHz timestamp of its end
 // (20 bits) and the wave that scanned it (12 bits) in the spare word of its tile_stats row (profiles/tile_timeline.py
 // reads the waves' timelines from them).
+// 1: no wave priorities (every phase at priority 0, as before they were introduced).
 #ifndef TS_EXP
 #define TS_EXP 0
 #endif
+
+// Wave priorities (s_setprio; the SIMD's arbiter picks the ready wave of the highest priority, the oldest among equals).
+// The dense per-chunk work (decode, probes: long runs of independent vector instructions) stays at 0; the phases that are
+// chains of dependent LDS / memory operations with a few instructions between the waits run above it, so that those few
+// instructions issue as soon as their operand arrives instead of queueing behind another wave's dense run, and the wave
+// is back in dense work sooner: configs[1] -2.8 .. -3.8 %, the k = 7 and default-flag configurations -1.5 %
+// (profiles/r02/kernel_experiments_ab.txt, "wave priorities").
+#ifndef TS_PRIO_PASS
+#define TS_PRIO_PASS 3          // the per-match pass over 64 queued matches
+#endif
+#ifndef TS_PRIO_APPEND
+#define TS_PRIO_APPEND 2        // prefix sum of a chunk pair's match counts + the queue writes
+#endif
+#ifndef TS_PRIO_WINDOWS
+#define TS_PRIO_WINDOWS 2       // phase 2: record flush, nucleotide counts, window records, tile directory
+#endif
+#define set_prio(p) do { if (!(TS_EXP & 1)) __builtin_amdgcn_s_setprio(p); } while (0)
+constexpr int kPrioPass = TS_PRIO_PASS, kPrioAppend = TS_PRIO_APPEND, kPrioWindows = TS_PRIO_WINDOWS;
 
 namespace {
 
@@ -279,6 +298,7 @@ void ts_scan_tiles(const TsScanParams P) {
         uint32_t qhead = 0, qcount = 0;                            // head as a byte offset into the ring, entries queued
         auto drain_queue = [&](const uint32_t threshold) {
             if (TS_ABL & 128) { qcount = 0; return; }           // profiling: compaction only, nothing consumed
+            if (qcount >= threshold && qcount > 0u) set_prio(kPrioPass);
             while (qcount >= threshold && qcount > 0u) {
                 const uint32_t n = qcount < 64u ? qcount : 64u;
                 if (done - flushed + 64u > P.stage_cap) flush_stage();
@@ -325,6 +345,7 @@ void ts_scan_tiles(const TsScanParams P) {
                 qhead = (qhead + 2u * n) & (TS_LIST * 2u - 1u);
                 qcount -= n;
             }
+            set_prio(0);
             __builtin_amdgcn_wave_barrier();                  // the queue is appended to next
         };
 
@@ -471,6 +492,7 @@ void ts_scan_tiles(const TsScanParams P) {
         // ride in one register), one drain decision and one pass over the queue: A's matches first, then B's.
         auto append_pair = [&](const uint32_t mA, const uint32_t cposA, const uint32_t mB, const uint32_t cposB) {
             if (!__any((mA | mB) != 0u)) return;
+            set_prio(kPrioAppend);
             const uint32_t nA = __popc(mA), nB = __popc(mB);
             const uint32_t incl = wave_scan_incl(nA | (nB << 16));
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -479,9 +501,11 @@ void ts_scan_tiles(const TsScanParams P) {
                 asm volatile("; dense pair of chunks" ::: "memory");
                 if (totA) append_chunk(mA, cposA, nA, incl & 0xFFFFu, totA);
                 if (totB) append_chunk(mB, cposB, nB, incl >> 16, totB);
+                set_prio(0);
                 return;
             }
             drain_queue(64u);                                     // leaves fewer than 64 queued
+            set_prio(kPrioAppend);
             uint32_t o = qhead + 2u * (qcount + (incl & 0xFFFFu) - nA), m = mA;
             uint32_t lbase = cposA + lane * 32u;
             while (m) {
@@ -497,6 +521,7 @@ void ts_scan_tiles(const TsScanParams P) {
                 m &= m - 1u;
             }
             qcount += totA + totB;
+            set_prio(0);
             __builtin_amdgcn_wave_barrier();
         };
         {
@@ -544,6 +569,7 @@ void ts_scan_tiles(const TsScanParams P) {
         __builtin_amdgcn_wave_barrier();          // planes written above are read by other lanes below
 
         // ------------------------------------------------------------------ phase 2: windows
+        set_prio(kPrioWindows);
         // The match fields of the tile's window records are complete (accumulated above).
         flush_stage();
         if (P.windows_on) {
@@ -652,6 +678,7 @@ void ts_scan_tiles(const TsScanParams P) {
             }
             cursor += done;
         }
+        set_prio(0);
         __builtin_amdgcn_wave_barrier();          // next tile overwrites the planes
     }
     if (lane == 0) tail_params()->wave_fill[gw] = cursor;      // records needed by this wave (may exceed region_cap)
