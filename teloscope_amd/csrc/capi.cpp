@@ -153,8 +153,15 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     // pass of the window loop (64 window fields per pass), ~100 fixed per tile.  Occupancy factors are
     // measured (profiles/r01/geometry_sweep.txt): against 16 waves per CU the kernel loses 12 % at 12
     // waves and 31 % at 8; more than 16 is not reachable (two workgroups per CU did not co-reside).
-    static const struct { uint32_t waves; double factor; } kOccupancy[] = {
-        {16, 1.0}, {12, 0.88}, {8, 0.69}, {4, 0.43}, {2, 0.22}, {1, 0.11}};
+    // Round 2: built for 80 VGPRs, two workgroups of 10 waves do share a CU (20 waves; each has its own table copy and half of
+    // the LDS, so tiles are shorter): against 16 x 8 chunks, 2 x 10 x 6 chunks measures -3.2 % on configs[1], -1.2 % with the
+    // default flags (-8 % and 0 on another box); with k = 7 (a table of 20 KB per copy) only
+    // 5 chunks and a small record stage fit and it loses 37 %.  So: considered only for window scans with byte tables, at least
+    // 6 chunks, a record stage of 256 and all accumulator copies; its factor is what those measurements give under the
+    // instruction model below.  (Read batches: +4 % on one box, -1 % on another, where the predicate kernel that runs beside
+    // the scan finds fewer free registers; they stay on one workgroup.)
+    static const struct { uint32_t waves, wgs; double factor; } kOccupancy[] = {
+        {16, 1, 1.0}, {10, 2, 1.06}, {12, 1, 0.88}, {8, 1, 0.69}, {4, 1, 0.43}, {2, 1, 0.22}, {1, 1, 0.11}};
     uint32_t nch_min = 1;
     if (!tips) nch_min = (uint32_t)ceil_div((uint64_t)(1 + kp.halo_blocks) * kp.s + 63, TS_CHUNK);
     // TS_GEOMETRY="waves,chunks" pins the search to one point (0 = any): a test knob for the contract that the
@@ -168,11 +175,13 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     uint32_t best_wpt = 0;
     for (const auto &occ : kOccupancy) {
         if (pin_waves && occ.waves != pin_waves) continue;
+        const uint32_t kMaxLds = ::kMaxLds / occ.wgs;
         for (uint32_t nch = nch_min; nch <= nch_max; ++nch) {
             if (nch * TS_CHUNK + 64u > 65535u) break;        // the match queue holds 16-bit plane coordinates
             if (pin_nch && nch != pin_nch) continue;
             TsScanParams cand = kp;
             cand.waves_per_wg = occ.waves;
+            cand.wgs_per_cu = occ.wgs;
             cand.nch = nch;
             const uint32_t span_max = nch * TS_CHUNK - 63u;
             uint32_t cwpt;
@@ -197,6 +206,8 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
                 cand.stage_cap = std::min<uint32_t>(pin_stage ? pin_stage : 1024u, 128u + (spare & ~15u));
                 while ((uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) cand.stage_cap -= 16;
             }
+            // (the kernels for the 2-bit tables of k >= 7 need 97 VGPRs: built for 80 they spill)
+            if (occ.wgs > 1 && !pin_waves && (tips || !(kp.pair_byte_table && kp.fc_byte_table) || nch < 6 || cand.stage_cap < 256 || cand.acc_copies < 4)) continue;
             const double passes = tips ? 0.0 : (double)ceil_div((uint64_t)cwpt * 4, 64);
             // fewer accumulator copies serialise the window adds of a pass: 8 chunks with 2 copies measured 2.5 %
             // slower than 7 chunks with 4 on the headline configuration, where the model alone says 1 % faster
@@ -314,7 +325,7 @@ void size_launch(ts_batch *b) {
     const uint32_t wpw = b->kp.waves_per_wg;
     const uint64_t nt = b->range_tiles();
     const int ncu = b->ctx->num_cu > 0 ? b->ctx->num_cu : 256;
-    b->grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(nt, wpw), 1), (uint64_t)ncu);
+    b->grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(nt, wpw), 1), (uint64_t)ncu * std::max<uint32_t>(b->kp.wgs_per_cu, 1));
     b->total_waves = b->grid * wpw;
     uint64_t worst = 256;
     {
@@ -657,10 +668,10 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
     }
     b->wpt = wpt;
     if (getenv("TS_TIMING"))
-        fprintf(stderr, "ts_batch_create: %s scan, k=%u (%s pair table), %u waves per workgroup, %u chunks and %u windows per tile, LDS %d B "
+        fprintf(stderr, "ts_batch_create: %s scan, k=%u (%s pair table), %u x %u waves per CU, %u chunks and %u windows per tile, LDS %d B per workgroup "
                         "(match queue %u, record stage %u, %u accumulator copies)\n", b->tips ? "tips-only" : "window", ctx->k,
                 ctx->pair_byte_table ? "byte" : "2-bit",
-                b->kp.waves_per_wg, b->kp.nch, wpt, ts_k_lds_bytes(&b->kp), (unsigned)TS_LIST, b->kp.stage_cap, b->kp.acc_copies);
+                b->kp.wgs_per_cu, b->kp.waves_per_wg, b->kp.nch, wpt, ts_k_lds_bytes(&b->kp), (unsigned)TS_LIST, b->kp.stage_cap, b->kp.acc_copies);
     const uint64_t tile_bases = (uint64_t)wpt * b->kp.s;
     const uint32_t tl = ctx->params.terminal_limit;
 

@@ -154,9 +154,12 @@ __host__ __device__ inline uint32_t lds_total(const TsScanParams &P) {
 }
 
 // ---------------------------------------------------------------------------------------
-// 16 waves per CU = 4 per SIMD: at most 128 VGPRs
-template <bool FC_BYTES, bool PAIR_BYTES>
-__global__ __launch_bounds__(TS_MAX_WG_THREADS, 4)
+// Two register budgets.  WAVES_EU = 4: one workgroup of up to 16 waves per CU (4 per SIMD; the allocator takes 81 VGPRs).
+// WAVES_EU = 6: at most 80 VGPRs, so that TWO workgroups of 10 waves share a CU — a workgroup's waves go round the SIMDs
+// 3,3,2,2 and two of them put six on SIMD 0, which 81 registers (five waves per SIMD) do not allow: the second workgroup then
+// waits for the first (measured: 1.14 ms instead of 0.74).
+template <bool FC_BYTES, bool PAIR_BYTES, int WAVES_EU>
+__global__ __launch_bounds__(TS_MAX_WG_THREADS, WAVES_EU)
 void ts_scan_tiles(const TsScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t tid = threadIdx.x;
@@ -730,9 +733,19 @@ __global__ void ts_compact_regions(const uint32_t *regions, const uint32_t *wave
 
 int ts_k_lds_bytes(const TsScanParams *p) { return (int)lds_total(*p); }
 
+namespace {
+template <int WAVES_EU>
+const void *scan_variant(const TsScanParams *p) {
+    if (p->pair_byte_table && p->fc_byte_table) return (const void *)ts_scan_tiles<true, true, WAVES_EU>;
+    if (p->fc_byte_table) return (const void *)ts_scan_tiles<true, false, WAVES_EU>;
+    return (const void *)ts_scan_tiles<false, false, WAVES_EU>;
+}
+}  // namespace
+
 int ts_k_prepare(uint32_t lds_bytes) {
-    const void *fns[] = {(const void *)ts_scan_tiles<true, true>, (const void *)ts_scan_tiles<true, false>,
-                         (const void *)ts_scan_tiles<false, false>};
+    const void *fns[] = {(const void *)ts_scan_tiles<true, true, 4>, (const void *)ts_scan_tiles<true, false, 4>,
+                         (const void *)ts_scan_tiles<false, false, 4>, (const void *)ts_scan_tiles<true, true, 6>,
+                         (const void *)ts_scan_tiles<true, false, 6>, (const void *)ts_scan_tiles<false, false, 6>};
     for (const void *fn : fns) {
         int e = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e) return e;
@@ -742,13 +755,9 @@ int ts_k_prepare(uint32_t lds_bytes) {
 
 int ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, void *stream) {
     const dim3 block(p->waves_per_wg * 64u);
-    if (p->pair_byte_table && p->fc_byte_table)
-        hipLaunchKernelGGL((ts_scan_tiles<true, true>), dim3(grid), block, lds_bytes, (hipStream_t)stream, *p);
-    else if (p->fc_byte_table)
-        hipLaunchKernelGGL((ts_scan_tiles<true, false>), dim3(grid), block, lds_bytes, (hipStream_t)stream, *p);
-    else
-        hipLaunchKernelGGL((ts_scan_tiles<false, false>), dim3(grid), block, lds_bytes, (hipStream_t)stream, *p);
-    return (int)hipGetLastError();
+    const void *fn = p->wgs_per_cu > 1u ? scan_variant<6>(p) : scan_variant<4>(p);
+    void *args[] = {(void *)p};
+    return (int)hipLaunchKernel(fn, dim3(grid), block, args, lds_bytes, (hipStream_t)stream);
 }
 
 int ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_tile, const uint64_t *seg_nwin,

@@ -64,6 +64,7 @@ struct TsScanParams {
     uint32_t        dynamic_tiles;  // 1: a wave takes the next free tile (ticket counter); 0: tiles dealt round-robin
     uint32_t        ticket_slot;    // which of the two counter sets this launch counts on (it zeroes the other)
     uint32_t        ticket_groups;  // groups of workgroups with a counter each (<= 64; group g owns the tiles t = g mod groups)
+    uint32_t        wgs_per_cu;     // host side: workgroups that share a CU (1, or 2 of 10 waves: selects the 80-VGPR build)
 };
 
 // parameters of getTerminalBlocks for the device-side predicate (kernels.hip: ts_terminal_predicate)

@@ -535,7 +535,7 @@ def test_concurrent_calls_on_one_context():
             assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="concurrent len=%d" % len(s))
 
 
-TILINGS = ["16,1", "16,3", "12,5", "8,2", "4,7", "2,4", "1,1", "1,8"]
+TILINGS = ["16,1", "16,3", "12,5", "10,6", "10,3", "8,2", "4,7", "2,4", "1,1", "1,8"]      # 10 waves = two workgroups per CU
 
 
 @pytest.mark.parametrize("cli", ["-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -m -i",
