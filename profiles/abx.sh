@@ -7,8 +7,8 @@ cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
     for m in $2; do
         # a variant is a TS_EXP mask, or pXYZ = wave priorities of the per-match pass / the queue append / the window phase
-        # wN = register allocation for N waves per SIMD (TS_MIN_WAVES_EU)
-        case $m in p???) DEFS="-DTS_PRIO_PASS=${m:1:1} -DTS_PRIO_APPEND=${m:2:1} -DTS_PRIO_WINDOWS=${m:3:1}";; w?) DEFS="-DTS_MIN_WAVES_EU=${m:1:1}";; *) DEFS="-DTS_EXP=$m";; esac
+        # qN = a match queue of N entries (TS_LIST)
+        case $m in p???) DEFS="-DTS_PRIO_PASS=${m:1:1} -DTS_PRIO_APPEND=${m:2:1} -DTS_PRIO_WINDOWS=${m:3:1}";; q*) DEFS="-DTS_LIST=${m:1}";; *) DEFS="-DTS_EXP=$m";; esac
         (cd teloscope_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 \
             $DEFS -x hip -shared -o ../../profiles/abx_$m.so kernels.hip predicate.hip generic.hip blockcall.hip exchange.hip capi.cpp \
             pipeline.cpp patterns.cpp blocks.cpp -lpthread 2>/dev/null) &

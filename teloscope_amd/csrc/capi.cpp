@@ -167,21 +167,22 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     // TS_GEOMETRY="waves,chunks" pins the search to one point (0 = any): a test knob for the contract that the
     // output does not depend on the tiling ("independent of GPU count and tile size")
     uint32_t pin_waves = 0, pin_nch = 0;
-    uint32_t pin_stage = 0;
-    if (const char *g = getenv("TS_GEOMETRY")) sscanf(g, "%u,%u,%u", &pin_waves, &pin_nch, &pin_stage);
+    uint32_t pin_stage = 0, pin_wgs = 0;               // (4th field: workgroups per CU, for measurements such as 2 x 12 waves)
+    if (const char *g = getenv("TS_GEOMETRY")) sscanf(g, "%u,%u,%u,%u", &pin_waves, &pin_nch, &pin_stage, &pin_wgs);
     const uint32_t nch_max = tips ? std::max(kTipsChunks, pin_nch) : std::max(nch_min, std::max(kMaxChunks, pin_nch));
     double best = 0.0;
     TsScanParams best_kp{};
     uint32_t best_wpt = 0;
     for (const auto &occ : kOccupancy) {
         if (pin_waves && occ.waves != pin_waves) continue;
-        const uint32_t kMaxLds = ::kMaxLds / occ.wgs;
+        const uint32_t wgs = (pin_waves && pin_wgs >= 1 && pin_wgs <= 4) ? pin_wgs : occ.wgs;
+        const uint32_t kMaxLds = ::kMaxLds / wgs;
         for (uint32_t nch = nch_min; nch <= nch_max; ++nch) {
             if (nch * TS_CHUNK + 64u > 65535u) break;        // the match queue holds 16-bit plane coordinates
             if (pin_nch && nch != pin_nch) continue;
             TsScanParams cand = kp;
             cand.waves_per_wg = occ.waves;
-            cand.wgs_per_cu = occ.wgs;
+            cand.wgs_per_cu = wgs;
             cand.nch = nch;
             const uint32_t span_max = nch * TS_CHUNK - 63u;
             uint32_t cwpt;
@@ -207,7 +208,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
                 while ((uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) cand.stage_cap -= 16;
             }
             // (the kernels for the 2-bit tables of k >= 7 need 97 VGPRs: built for 80 they spill)
-            if (occ.wgs > 1 && !pin_waves && (tips || !(kp.pair_byte_table && kp.fc_byte_table) || nch < 6 || cand.stage_cap < 256 || cand.acc_copies < 4)) continue;
+            if (wgs > 1 && !pin_waves && (tips || !(kp.pair_byte_table && kp.fc_byte_table) || nch < 6 || cand.stage_cap < 256 || cand.acc_copies < 4)) continue;
             const double passes = tips ? 0.0 : (double)ceil_div((uint64_t)cwpt * 4, 64);
             // fewer accumulator copies serialise the window adds of a pass: 8 chunks with 2 copies measured 2.5 %
             // slower than 7 chunks with 4 on the headline configuration, where the model alone says 1 % faster
