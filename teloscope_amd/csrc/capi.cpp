@@ -155,11 +155,16 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     // waves and 31 % at 8; more than 16 is not reachable (two workgroups per CU did not co-reside).
     // Round 2: built for 80 VGPRs, two workgroups of 10 waves do share a CU (20 waves; each has its own table copy and half of
     // the LDS, so tiles are shorter): against 16 x 8 chunks, 2 x 10 x 6 chunks measures -3.2 % on configs[1], -1.2 % with the
-    // default flags (-8 % and 0 on another box); with k = 7 (a table of 20 KB per copy) only
+    // default flags (-8 % and 0 on another box: see `sparse` below); with k = 7 (a table of 20 KB per copy) only
     // 5 chunks and a small record stage fit and it loses 37 %.  So: considered only for window scans with byte tables, at least
     // 6 chunks, a record stage of 256 and all accumulator copies; its factor is what those measurements give under the
     // instruction model below.  (Read batches: +4 % on one box, -1 % on another, where the predicate kernel that runs beside
     // the scan finds fewer free registers; they stay on one workgroup.)
+    // What the extra waves hide is the latency chains of the per-match work: the gain needs matches.  On random sequence a
+    // position matches with probability patterns / 4^k: 3 % for configs[1] (-2.7 % at 1 Gb) and for a k = 5 motif with one
+    // mismatch (-3 %); 0.9 % with the default flags and 0.05 % with -x 0 (both +-1 %): those stay on 16 waves
+    // (profiles/r02/planner_check.txt).
+    const bool sparse = (double)c->patterns.size() < 0.015 * (double)(1ull << (2 * k));
     static const struct { uint32_t waves, wgs; double factor; } kOccupancy[] = {
         {16, 1, 1.0}, {10, 2, 1.06}, {12, 1, 0.88}, {8, 1, 0.69}, {4, 1, 0.43}, {2, 1, 0.22}, {1, 1, 0.11}};
     uint32_t nch_min = 1;
@@ -208,7 +213,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
                 while ((uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) cand.stage_cap -= 16;
             }
             // (the kernels for the 2-bit tables of k >= 7 need 97 VGPRs: built for 80 they spill)
-            if (wgs > 1 && !pin_waves && (tips || !(kp.pair_byte_table && kp.fc_byte_table) || nch < 6 || cand.stage_cap < 256 || cand.acc_copies < 4)) continue;
+            if (wgs > 1 && !pin_waves && (tips || sparse || !(kp.pair_byte_table && kp.fc_byte_table) || nch < 6 || cand.stage_cap < 256 || cand.acc_copies < 4)) continue;
             const double passes = tips ? 0.0 : (double)ceil_div((uint64_t)cwpt * 4, 64);
             // fewer accumulator copies serialise the window adds of a pass: 8 chunks with 2 copies measured 2.5 %
             // slower than 7 chunks with 4 on the headline configuration, where the model alone says 1 % faster
