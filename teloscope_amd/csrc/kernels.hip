@@ -746,8 +746,11 @@ int ts_k_prepare(uint32_t lds_bytes) {
     const void *fns[] = {(const void *)ts_scan_tiles<true, true, 4>, (const void *)ts_scan_tiles<true, false, 4>,
                          (const void *)ts_scan_tiles<false, false, 4>, (const void *)ts_scan_tiles<true, true, 6>,
                          (const void *)ts_scan_tiles<true, false, 6>, (const void *)ts_scan_tiles<false, false, 6>};
+    // the limit is a property of the function, not of a launch: batches of different geometries share it, so it is
+    // raised to the CU's whole LDS rather than set to the size one batch asked for
+    const int limit = (int)(lds_bytes > 160u * 1024u ? lds_bytes : 160u * 1024u);
     for (const void *fn : fns) {
-        int e = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        int e = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, limit);
         if (e) return e;
     }
     return 0;

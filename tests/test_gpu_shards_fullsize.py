@@ -361,6 +361,52 @@ def test_taken_tiles_equal_dealt_tiles_and_survive_overflow():
     tight.close()
 
 
+def test_batches_of_different_geometries_alternate():
+    """Three batches alive at once whose launches differ in everything the launch depends on — two workgroups of ten waves
+    with 80 KB of LDS each (the headline patterns), one workgroup of sixteen with 160 KB (default flags: sparse matches), the
+    2-bit-table kernel (k = 7) and a tips-only batch — scanned in turn, twice, out of order: the dynamic-LDS limit and the
+    kernel build are properties of a launch's function, not of the last batch prepared.  Every scan of a batch must give
+    the same arrays, and they are the whole-scan arrays of test_sharded_scan_equals_whole_scan_and_oracle's kind."""
+    import torch
+    from teloscope_amd import distributed as D
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    lens = [3_000_017, 999, 1_500_000]
+    clis = [HEADLINE, "-r -g -e -m -i", "-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i", "-t 3000"]
+    keep, plans, shards, bufs = [], [], [], []
+    for j, cli in enumerate(clis):
+        opts, tel = _teloscope(cli)
+        plan = D.ShardPlan(tel, lens, world=1)
+        buf = torch.zeros(int(plan.info.input_bytes), dtype=torch.uint8, device=dev)
+        for i, (o, n) in enumerate(zip(plan.segment_offsets(), lens)):
+            buf[o:o + n] = _device_random(n, dev, 900 + 10 * j + i)
+        keep.append(tel); plans.append(plan); bufs.append(buf)
+        shards.append(D.HipShard(plan, 0, dev, slots=1))
+
+    def scan(j):
+        shards[j].scan(bufs[j].data_ptr(), sptr, 0)
+        n = shards[j].finish(bufs[j].data_ptr(), sptr, 0)
+        return shards[j].windows[0].clone(), shards[j].stats[0].clone(), shards[j].dense[0][:n].clone()
+
+    first = [scan(j) for j in range(len(clis))]
+    assert sum(int(f[2].numel()) for f in first) > 100_000
+    for j in (2, 0, 3, 1, 0, 2):
+        again = scan(j)
+        for name, a, b in zip(("windows", "tile directory", "records"), first[j], again):
+            assert torch.equal(a, b), "%s differ on a later scan of %r" % (name, clis[j])
+    # and against fresh single-batch processes' worth of truth: a new plan, scanned alone
+    for j in (0, 1):
+        opts, tel = _teloscope(clis[j])
+        alone = D.ShardPlan(tel, lens, world=1)
+        w, s_, d, _ = _scan_parts(alone, bufs[j], dev)
+        assert torch.equal(w, first[j][0]) and torch.equal(s_, first[j][1]) and torch.equal(d, first[j][2])
+        alone.close()
+    for sh, plan in zip(shards, plans):
+        sh.close()
+        plan.close()
+
+
 def test_bind_thread_to_device_node():
     """ts_bind_thread_to_device on a real context: where the host publishes the device's NUMA node, a worker thread that calls
     it ends up on a subset of its former CPUs (and the call says 1); where it does not, the mask stays and the call says 0."""
