@@ -323,7 +323,7 @@ void ts_batch_release_input(ts_batch *b) {
 
 namespace {
 
-// Sizes the launch (one persistent workgroup per CU, whose waves take tiles or are dealt them) and the per-wave
+// Sizes the launch (one or two persistent workgroups per CU, whose waves take tiles or are dealt them) and the per-wave
 // record regions for the batch's tile range.  Every wave appends to its own region of the match buffer;
 // small ranges get the worst case (every base a match), large ones bases/4 spread evenly, grown on overflow
 // by ts_batch_sync (worst case for wave w = the owned bases of the tiles it is dealt: t = w, w + waves, ...).

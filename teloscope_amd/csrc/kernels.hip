@@ -12,7 +12,9 @@
 // its next tile from a ticket counter (one relaxed global atomic per tile, issued a tile ahead of its use; tiles
 // are dealt round-robin instead where per-wave record counts must be reproducible), and every wave appends its packed
 // match records to its own region of the output (a per-tile directory {offset, count} makes
-// the stream addressable in position order).  Latency is hidden by the 16 waves per CU.
+// the stream addressable in position order).  Latency is hidden by the 16 waves per CU — or 20, as two workgroups of
+// ten, where the pattern set is dense enough to need them (the WAVES_EU = 6 build below; plan_geometry in capi.cpp decides) —
+// and by wave priorities: the phases that are chains of dependent LDS / memory operations run above the dense per-chunk work.
 //
 // Per tile:
 //   phase 1  2016 positions per iteration, 32 per lane: two coalesced 16 B/lane loads (the next
