@@ -41,6 +41,14 @@ for f in find("*kernel_trace.csv"):
             t = v[DROP:]
             print("   %-60s      timed launches only (first %d dropped: %d settling + 5 warm-up): n=%d avg=%.1f us" % (
                 "", DROP, DROP - 5, len(t), sum(t) / len(t) / 1e3))
+            # what bench.py itself measured in this very run (its JSON line is in trace.log): the two must agree; between
+            # runs the plateau moves by a few per cent
+            log = os.path.join(root, "trace.log")
+            if os.path.exists(log):
+                import re
+                m = re.search(r'"kernel_ms": ([0-9.]+)', open(log, errors="replace").read())
+                if m:
+                    print("   %-60s      bench.py in the same process (HIP events, roofline.kernel_ms): %.1f us" % ("", float(m.group(1)) * 1e3))
 for f in find("*counter_collection.csv"):
     acc = {}
     with open(f) as fh:
