@@ -14,7 +14,7 @@ from tests.backends import BLOCK_FIELDS, OracleBackend, ProductBackend, assert_s
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-motifs = ["TTAGGG", "TTAGG", "CCCTAAA", "TTTTAGGG", "TTAGGGG", "TCAGG", "AAAAAA", "ACACAC", "TTAGGC"]
+motifs = ["TTAGGG", "TTAGG", "CCCTAAA", "TTTTAGGG", "TTAGGGG", "TCAGG", "AAAAAA", "ACACAC", "TTAGGC", "TTAG", "TTA", "CCTA"]
 done = 0
 for it in range(iters):
     c = motifs[int(rng.integers(0, len(motifs)))]

@@ -115,6 +115,8 @@ GRID = [
     "-x 2 -w 1000 -s 500 -r -i -k 20 -d 100",
     "-p TTAGGN -x 0 -w 300 -s 150 -g -i",
     "-c TTAGG -w 100 -s 50 -g -e -i -l 50",                     # k = 5
+    "-c TTAG -x 1 -w 200 -s 100 -r -g -e -i -l 40",             # k = 4: every sixth position matches
+    "-c TTA -x 0 -w 100 -s 50 -g -i -l 30 -k 10",               # k = 3, the shortest the tiled kernel takes
     "-c TTTTAGGG -x 1 -w 1000 -s 1000 -r -g -e -i",             # k = 8
     "-c TTTTTAGGG -x 1 -w 400 -s 200 -r -g",                    # k = 9
     "",                                                         # ultra-fast (tips only), t = 50000
@@ -130,6 +132,11 @@ LENGTHS = [1, 5, 6, 7, 15, 16, 17, 63, 100, 250, 499, 500, 501, 999, 1000, 1001,
 def test_random_segments_match_oracle(cli):
     opts = H.parse_cli("x.fa " + cli)
     prod, orac = ProductBackend(opts), OracleBackend(opts)
+    if orac.ambiguous:
+        # a pattern that is its own reverse complement comes out of the expansion from both strands (TTAA and CTAG from
+        # TTAG with one mismatch): which copy std::sort leaves first is unspecified in the reference; the
+        # oracle then takes the orientation flags the product's expansion chose
+        orac = OracleBackend(opts, patterns=prod.patterns)
     rng = np.random.default_rng(abs(hash(cli)) % (2 ** 32) if False else len(cli) * 7919 + 13)
     unit_f, unit_r = opts.canonical_fwd, opts.canonical_rev
     segs = []
