@@ -743,10 +743,11 @@ def run_reads(args, rank, local_rank, world, dev, backend):
             if overlap[0]:
                 e["judged"].record(pred_stream)
             at += e["n"]
-        if overlap[0]:
-            stream.wait_stream(pred_stream)
-        if world > 1:                                            # the 1-byte-per-read gather, in input order
-            dist.gather(pass_local if backend == "nccl" else pass_local.cpu(), gathered, dst=0)
+        # No join of the two streams at the end of a pass: the next pass's first scans run beside this pass's last predicates,
+        # as the groups of ts_filter_reads do (a sub-batch's scan only waits for the predicate over its own records: "judged").
+        if world > 1:                                            # the 1-byte-per-read gather, in input order, behind the predicates
+            with torch.cuda.stream(pred_stream if overlap[0] else stream):
+                dist.gather(pass_local if backend == "nccl" else pass_local.cpu(), gathered, dst=0)
 
     def barrier():
         if world > 1:
