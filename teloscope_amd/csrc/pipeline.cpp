@@ -329,6 +329,7 @@ int batch_read_pass_device(ts_batch *b, unsigned char *d_pass, hipStream_t st) {
     Q.min_block_counts = c->params.min_block_counts;
     Q.min_block_density = c->params.min_block_density;
     Q.k = c->k;
+    Q.long_list = 128;                                        // floor of the per-wave threshold, see ts_terminal_predicate
     int e = ts_k_launch_predicate((const TsTile *)b->d_tiles.p, (const unsigned long long *)b->d_tile_off.p,
                                   b->stats_ptr(), b->records_ptr(), b->records_limit(), (const uint32_t *)dt,
                                   (const unsigned long long *)(dt + off_in), (const unsigned long long *)(dt + off_len),

@@ -315,13 +315,16 @@ __device__ bool pred_scan_wave(const TsTile *tiles, const u64 *tile_off, const u
     return st.pass;
 }
 
-constexpr uint32_t kLongRead = 384;        // records; above this a read is walked by a whole wave
 
 // One thread per segment.  A read with a long match list (a telomeric read has thousands of chained matches) would leave
 // one lane running alone for hundreds of microseconds: such reads are only listed here — long_list[atomicAdd(long_count)]
 // — and walked by ts_terminal_predicate_long, one WAVE per listed read, so that they spread over the whole device instead
 // of queueing up behind each other in the waves that happen to hold several of them (0.5 % of the reads are long in
 // configs[3]: the fullest of 7 800 waves held five, and the kernel took as long as that wave: 544 us per 500 k reads).
+// "Long" is relative to what the reads around it carry: more than twice the mean list of the wave's 64 reads (and more than
+// Q.long_list = 128).  A launch lasts as long as its slowest wave, i.e. as the longest list a lane walks: with a fixed 384
+// against ~70 records per ordinary read a launch took 310 us, four times the walk of an ordinary wave.  Which kernel walks
+// a read does not show in the result.
 // READS: every segment of the batch is terminal zone as a whole and the records lie in the batch's own padded regions (the
 // host checks both): the kernel then holds only the lean
 // one-pass walk — 40-odd VGPRs instead of 63, eight waves per SIMD, and room for four blocks in flight per thread.  The walk
@@ -341,13 +344,19 @@ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint3
                            const TsPredParams Q, unsigned char *pass, uint32_t *long_list, uint32_t *long_count) {
     const uint32_t lane = threadIdx.x;                       // one wave per workgroup
     const uint32_t si = blockIdx.x * 64u + lane;
-    if (si >= nseg) return;
-    const uint32_t t0 = seg_first_tile[si], t1 = seg_first_tile[si + 1];
-    const u64 n = seg_len[si], base = seg_in_off[si];
+    const bool live = si < nseg;
+    const uint32_t t0 = live ? seg_first_tile[si] : 0u, t1 = live ? seg_first_tile[si + 1] : 0u;
+    const u64 n = live ? seg_len[si] : 0ull, base = live ? seg_in_off[si] : 0ull;
     u64 total = 0, nfwd = 0;
     for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
+    // the wave's mean list length (all 64 lanes take part; a lane beyond the batch counts as an empty read)
+    uint32_t sum = (uint32_t)(total < 0xFFFFFu ? total : 0xFFFFFu);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);
+    if (!live) return;
+    const uint32_t long_from = Q.long_list > sum / 32u ? Q.long_list : sum / 32u;       // twice the mean
     // (the whole-wave walk assumes that the whole segment is terminal zone: every read; otherwise one thread walks it)
-    if (total > kLongRead && n <= Q.terminal_limit) {
+    if (total > long_from && n <= Q.terminal_limit) {
         long_list[atomicAdd(long_count, 1u)] = si;
         return;
     }

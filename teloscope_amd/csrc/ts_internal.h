@@ -73,6 +73,7 @@ struct TsPredParams {
     uint32_t max_match_dist, min_block_len, max_block_dist, min_block_counts;
     float    min_block_density;
     uint32_t k;                         // match length (uniform)
+    uint32_t long_list;                 // least number of match records that makes a read "long" (walked by a whole wave, predicate.hip)
 };
 
 // ---- device block calling (blockcall.hip) ----
