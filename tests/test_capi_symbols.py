@@ -141,3 +141,32 @@ def test_bind_thread_needs_a_device(ta):
     assert K.lib().ts_bind_thread_to_device(tel._ctx.ptr) == 0
     assert K.lib().ts_bind_thread_to_device(None) == 0
     assert os.sched_getaffinity(0) == before
+
+
+def test_planner_tiling_choices(ta, monkeypatch):
+    """plan_geometry's choice between one workgroup of 16 waves per CU and two of 10 (the 80-VGPR build of the scan kernel),
+    read off the plan of a planning-only context (no GPU): windows per tile = what the chosen chunks per tile hold.  Two
+    workgroups (6 chunks: 23 windows at -w 1000 -s 500) only where the pattern set is dense (patterns / 4^k >= 1.5 %), has
+    byte tables (k <= 6) and tiles of six chunks fit; one workgroup of 16 waves (8 chunks: 31) otherwise.  The measurements
+    behind the rule: profiles/r02/occupancy_sweep.txt, planner_check.txt."""
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import parse_cli, user_input
+    from teloscope_amd.distributed import ShardPlan
+    monkeypatch.delenv("TS_GEOMETRY", raising=False)
+
+    def windows_per_tile(cli, n=50_000_000):
+        tel = ta.Teloscope(user_input(parse_cli("x.fa " + cli), device=K.DEVICE_NONE))
+        plan = ShardPlan(tel, [n], world=1)
+        wpt = -(-int(plan.info.n_windows) // int(plan.info.n_tiles))
+        plan.close()
+        return wpt
+
+    headline = "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -x 1 -w 1000 -s 500 -r -g -e -m -i"
+    assert windows_per_tile(headline) == 23                               # 124 patterns of 4096: two workgroups of ten waves
+    assert windows_per_tile("-c TTAGGG -x 0 -w 1000 -s 500 -g -e -i") == 31     # 2 patterns: sparse, one workgroup of 16
+    assert windows_per_tile("-c TTAGGG -r -g -e -m -i") == 16                   # default flags (38 patterns, w = s = 1000): sparse
+    assert windows_per_tile("-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i") == 13  # k = 7: the 64 KB byte table, 7 chunks, one workgroup
+    monkeypatch.setenv("TS_GEOMETRY", "16,0")                             # the search pinned to one workgroup of 16 waves
+    assert windows_per_tile(headline) == 31
+    monkeypatch.setenv("TS_GEOMETRY", "10,6")
+    assert windows_per_tile("-c TTAGGG -r -g -e -m -i") == 12
