@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TELOSCAN_ABI_VERSION 2
+#define TELOSCAN_ABI_VERSION 3
 
 /* ts_params.device value of a PLANNING-ONLY context: no HIP call is ever made behind it.  It plans batches
  * (ts_batch_create, ts_batch_get_info, ts_batch_get_tiles, ts_batch_partition, ts_batch_range_info) so that a
@@ -365,6 +365,82 @@ int ts_batch_wire16_ok(const ts_batch *b);
 int ts_wire_widen_u16(ts_ctx *ctx, const void *d_src_u16, void *d_dst_u32, uint64_t n, void *stream);
 /* Device pointer of the batch's tile directory entries (16 B per tile of the range). */
 const void *ts_batch_tile_stats_ptr(const ts_batch *b);
+
+/* ---- shard results: several devices share ONE scan and hand over what the reference's writers read ----------------
+ *      The reference fans paths out to its thread-pool workers and merges their PathData in seqPos order
+ *      (src/input.cpp:719-733, sortBySeqPos include/teloscope.h:262-266).  Of a path's results its writers read the
+ *      windows, the blocks, canonicalMatches and the terminal nonCanonicalMatches (src/teloscope.cpp:486-496, :700-868;
+ *      walkPath moves only those two match vectors into PathData, src/input.cpp:1000-1009) — about 3 % of the match
+ *      records; allMatches / fwdMatches / revMatches feed block calling (:646-655) and nothing else.  A SHARD therefore
+ *      calls its blocks on its own device and packs ONE message — bit-packed window records, the visible match records
+ *      (16 bits each), its blocks — which is all that crosses xGMI (rank form, teloscope_amd/distributed.py) or PCIe
+ *      (ts_scan_segments_multi): ~60 MB per 3 Gb scan at 8 devices instead of the 245 MB of the full exchange above.
+ *
+ *      A shard OWNS the p-th of n consecutive tile ranges (ts_batch_partition: equal bases; a boundary inside a segment
+ *      keeps at least terminal zone + context tiles from both its ends) and also scans CONTEXT tiles either side where
+ *      a segment continues on a neighbour, so that a chain of matches that starts in an owned tile can be followed.
+ *      Terminal blocks belong to the shard that owns that end of the segment, an interstitial block to the shard that
+ *      owns the tile it starts in.  What the shards assume about each other (the bounds of the interstitial search) is
+ *      checked by ts_shards_finalize; when it does not hold — a telomere that reaches beyond the context tiles —
+ *      ts_shards_finalize returns TS_SHARD_NEED_FULL and the caller takes the full path for that batch. ------------- */
+typedef struct ts_shard_info {
+    uint32_t n_parts, part;
+    uint64_t own_begin, own_end;         /* tiles the shard owns */
+    uint64_t ext_begin, ext_end;         /* tiles it scans: owned + context */
+    uint64_t window_begin, window_end;   /* window records it owns */
+    uint64_t input_begin, input_end;     /* bytes of the batch's input layout its scan reads (ts_batch_scan expects d_input
+                                            to point at byte input_begin) */
+    uint64_t bases;                      /* owned bases */
+    uint64_t seg_begin, seg_end;         /* segments with an owned tile */
+    uint64_t msg_bytes;                  /* size of its result message at this capacity scale */
+    uint64_t visible_capacity;           /* visible match records / blocks the message has room for */
+    uint32_t block_capacity;
+    uint32_t window_bytes;               /* bytes per packed window record */
+    uint32_t visible_bytes;              /* bytes per visible match record (2, or 4 when a tile-relative position needs more) */
+    uint32_t context_tiles;
+} ts_shard_info;
+/* Host only (works on a planning-only context): sender and receiver compute the same numbers.  `scale` >= 1 multiplies
+ * the capacities of the message's variable sections (visible records, blocks). */
+int ts_batch_shard_info(const ts_batch *b, uint32_t n_parts, uint32_t part, uint32_t scale, ts_shard_info *out);
+/* Before the first scan: the batch becomes shard `part` of `n_parts` (ts_batch_restrict to its scanned range). */
+int ts_batch_restrict_shard(ts_batch *b, uint32_t n_parts, uint32_t part, uint32_t scale);
+int ts_batch_set_shard_scale(ts_batch *b, uint32_t scale);
+/* After ts_batch_scan, asynchronous on `stream`, no host synchronisation: block calling on the device and the packed
+ * message at d_msg (device memory, msg_bytes >= ts_shard_info.msg_bytes). */
+int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stream);
+#define TS_SHARD_OVERFLOW_VISIBLE 0x1u   /* ts_shard_status.flags */
+#define TS_SHARD_OVERFLOW_BLOCKS  0x2u
+#define TS_SHARD_OVERFLOW_SCAN    0x4u   /* a wave's record region overflowed in the scan: ts_batch_sync, then pack again */
+#define TS_SHARD_OUT_OF_CONTEXT   0x8u   /* a chain or a terminal walk ran out of the context tiles */
+typedef struct ts_shard_status {
+    uint32_t part, n_parts, flags, n_blocks;
+    uint64_t n_visible, visible_capacity;
+    uint32_t block_capacity;
+    uint32_t scale_factor_needed;        /* 1 when everything fitted, else the factor by which to raise the scale */
+    uint64_t msg_bytes;
+} ts_shard_status;
+/* Reads a message's header (host memory). */
+int ts_shard_peek(const void *msg, uint64_t msg_bytes, ts_shard_status *out);
+/* positive returns of ts_shards_finalize: the messages could not be turned into results as they are */
+#define TS_SHARD_RETRY_SYNC 1            /* a shard's scan overflowed: ts_batch_sync on it, pack again */
+#define TS_SHARD_RETRY_GROW 2            /* a message overflowed: pack again with a larger scale (ts_shard_peek says which) */
+#define TS_SHARD_NEED_FULL  3            /* the shards' assumptions about each other do not hold for this input */
+/* Host: the messages of all n_parts shards of `plan` (a whole batch of the same plan; may sit on a planning-only
+ * context) -> out[i] = SegmentData of segment i with windows, blocks and, as `matches`, the VISIBLE records only
+ * (canonicalMatches + terminal nonCanonicalMatches, position order); counts[i] (optional) = the sizes the match
+ * vectors had on the devices.  Free out with ts_free_segments(). */
+int ts_shards_finalize(const ts_batch *plan, const void *const *msgs, const uint64_t *msg_bytes, uint32_t n_parts,
+                       ts_segment_out *out, ts_segment_counts *counts);
+
+/* ---- Teloscope::scanSegment over several devices (one host thread per context, as ts_filter_reads_multi): the batch's
+ *      plan is split into one shard per context; every device uploads the bases its shard reads and downloads its
+ *      shard's message over its OWN PCIe link; the host merges (ts_shards_finalize).  Replaces the reference's one job
+ *      per path + merge under a mutex (src/input.cpp:719-733, :1036-1037).  out[i].matches holds the VISIBLE records
+ *      only (see above); counts may be NULL.  Contexts must have been created with the same parameters and patterns and
+ *      may share a device.  Parameter sets outside the tiled kernel, and inputs for which the shards' assumptions fail,
+ *      run on ctxs[0] alone (same results). */
+int ts_scan_segments_multi(ts_ctx *const *ctxs, size_t n_ctx, const ts_segment_in *segs, size_t n_segs,
+                           ts_segment_out *out, ts_segment_counts *counts);
 
 /* ---- ReadTelomereFilter over several devices (the read shard of --fastq-subset / --bam-subset:
  *      the reference deals a batch's reads to its thread-pool workers in chunks and writes the chunk outputs in

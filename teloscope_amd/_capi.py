@@ -96,6 +96,23 @@ class RangeInfo(C.Structure):
                 ("bases", C.c_uint64)]
 
 
+class ShardInfo(C.Structure):
+    _fields_ = [("n_parts", C.c_uint32), ("part", C.c_uint32), ("own_begin", C.c_uint64), ("own_end", C.c_uint64),
+                ("ext_begin", C.c_uint64), ("ext_end", C.c_uint64), ("window_begin", C.c_uint64),
+                ("window_end", C.c_uint64), ("input_begin", C.c_uint64), ("input_end", C.c_uint64),
+                ("bases", C.c_uint64), ("seg_begin", C.c_uint64), ("seg_end", C.c_uint64), ("msg_bytes", C.c_uint64),
+                ("visible_capacity", C.c_uint64), ("block_capacity", C.c_uint32), ("window_bytes", C.c_uint32),
+                ("visible_bytes", C.c_uint32), ("context_tiles", C.c_uint32)]
+
+
+class ShardStatus(C.Structure):
+    _fields_ = [("part", C.c_uint32), ("n_parts", C.c_uint32), ("flags", C.c_uint32), ("n_blocks", C.c_uint32),
+                ("n_visible", C.c_uint64), ("visible_capacity", C.c_uint64), ("block_capacity", C.c_uint32),
+                ("scale_factor_needed", C.c_uint32), ("msg_bytes", C.c_uint64)]
+
+
+SHARD_RETRY_SYNC, SHARD_RETRY_GROW, SHARD_NEED_FULL = 1, 2, 3
+SHARD_OVERFLOW_VISIBLE, SHARD_OVERFLOW_BLOCKS, SHARD_OVERFLOW_SCAN, SHARD_OUT_OF_CONTEXT = 1, 2, 4, 8
 DEVICE_NONE = -2            # TS_DEVICE_NONE: planning-only context
 MATCH_DT = np.dtype(Match)
 TILE_DT = np.dtype(TileInfo)
@@ -114,6 +131,8 @@ SYMBOLS = [
     "ts_batch_get_tiles", "ts_batch_range_info", "ts_batch_partition", "ts_batch_restrict", "ts_batch_bind_results",
     "ts_batch_export", "ts_batch_adopt", "ts_batch_tile_stats_ptr", "ts_filter_reads_multi", "ts_batch_read_pass",
     "ts_batch_wire16_ok", "ts_wire_widen_u16", "ts_takes_text_input", "ts_bind_thread_to_device",
+    "ts_batch_shard_info", "ts_batch_restrict_shard", "ts_batch_set_shard_scale", "ts_batch_pack_shard",
+    "ts_shard_peek", "ts_shards_finalize", "ts_scan_segments_multi",
 ]
 
 
@@ -230,6 +249,15 @@ def lib():
     L.ts_batch_read_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ts_filter_reads_multi.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
                                         C.c_size_t, C.POINTER(C.c_uint8)]
+    L.ts_batch_shard_info.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ShardInfo)]
+    L.ts_batch_restrict_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.ts_batch_set_shard_scale.argtypes = [C.c_void_p, C.c_uint32]
+    L.ts_batch_pack_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.ts_shard_peek.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(ShardStatus)]
+    L.ts_shards_finalize.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32,
+                                     C.POINTER(SegmentOut), C.POINTER(SegmentCounts)]
+    L.ts_scan_segments_multi.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(SegmentIn), C.c_size_t,
+                                         C.POINTER(SegmentOut), C.POINTER(SegmentCounts)]
     _lib = L
     return L
 

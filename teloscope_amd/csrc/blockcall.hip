@@ -35,8 +35,12 @@ struct SegView {
     const u64 *tile_off;
     const uint32_t *tile_stats;
     const uint32_t *matches;
-    uint32_t t0, t1;                         // tiles of the segment
+    uint32_t t0, t1;                         // tiles of the segment (a shard: those of them it scanned)
     u64 base;                                // in_off of the segment
+    // a shard's view may be CLIPPED: the segment goes on to the left of t0 / to the right of t1 on a neighbour.
+    // lo_rel / hi_rel: segment-relative position of the first base of tile t0 / behind the last base of tile t1 - 1.
+    bool open_l, open_r;
+    u64 lo_rel, hi_rel;
 
     __device__ uint32_t count(uint32_t t) const { return tile_stats[4u * t]; }
     __device__ uint32_t rec(Cursor c) const { return matches[tile_off[c.t] + c.i]; }
@@ -117,7 +121,7 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 // state machine — wave-uniform, scalar — steps once per CHAIN (counts are popcounts of ballots), not once per
 // record: a telomere is one chain of thousands of matches.  Lane 0 writes the blocks.
 __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, uint32_t seg, u64 n, u64 abs_pos,
-                                  bool from_start, uint32_t &seq, uint32_t lane) {
+                                  bool from_start, uint32_t &seq, uint32_t lane, bool &out_of_context) {
     u64 boundary = from_start ? 0 : n;                     // segment-relative
     Chain ch; bool open = false;
     ch.start = ch.end = ch.prev = 0; ch.counts = ch.fwd = ch.canon = ch.cov = ch.fwd_cov = ch.can_cov = 0;
@@ -208,41 +212,93 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
             }
         }
     }
+    // A clipped view that the walk used up without meeting a chain head outside the terminal zone: the records the
+    // walk would have read next are on a neighbour.  Harmless when they cannot matter — the open chain is too far from
+    // the clip for any of them to extend it, and the clip lies outside the zone, so the next head ends the walk —
+    // else the segment is reported (TS_SEG_F_CONTEXT) and takes the full path.
+    if (!stop && (from_start ? V.open_r : V.open_l)) {
+        const bool zone_clipped = n > Q.terminal_limit && (from_start ? V.hi_rel < Q.terminal_limit : V.lo_rel > n - Q.terminal_limit);
+        const bool chain_clipped = open && (from_start ? ch.prev + Q.max_match_dist >= V.hi_rel : ch.prev <= V.lo_rel + Q.max_match_dist);
+        if (zone_clipped || chain_clipped) out_of_context = true;
+    }
     if (open) close_sub();
     if (have_cur) close_block();
     return boundary;
 }
 
-__global__ void ts_terminal_blocks(const TsBlockCallParams Q, const uint32_t *seg_first_tile, const u64 *seg_in_off,
-                                   const u64 *seg_len, const u64 *seg_abs, uint32_t nseg, u64 *bounds) {
+// the shard's view of segment S (TsShardSegIn): its scanned tiles, clipped where the segment continues on a neighbour
+__device__ __forceinline__ SegView seg_view(const TsBlockCallParams &Q, const TsShardSegIn &S) {
+    SegView V{Q.tiles, Q.tile_off, Q.tile_stats, Q.matches, S.t0, S.t1, S.in_off,
+              !(S.flags & TS_SEG_F_HAS_START), !(S.flags & TS_SEG_F_HAS_END), 0, S.len};
+    if (S.t1 > S.t0) {
+        V.lo_rel = Q.tiles[S.t0].in_off - S.in_off;
+        V.hi_rel = Q.tiles[S.t1 - 1u].in_off - S.in_off + Q.tiles[S.t1 - 1u].own_len;
+    }
+    return V;
+}
+
+__global__ void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t nseg, u64 *bounds,
+                                   TsShardSeg *seg_out) {
     // one workgroup of four waves per segment: all threads add up the segment's tile counts (a 250 Mb
     // contig has ~35 k tiles), then wave 0 walks the forward list from the start while wave 1 walks
-    // the reverse list from the end
-    __shared__ u64 part[2][256];
+    // the reverse list from the end.  A shard (seg_out != nullptr) walks a direction only when it owns that end of
+    // the segment; the bounds of the other end are the widest possible, which the receiver checks against what
+    // the shard that did walk it reports (shard.cpp: finalize).
+    __shared__ u64 part[5][256];
+    __shared__ uint32_t walk_flags;
     const uint32_t si = blockIdx.x;
     if (si >= nseg) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    SegView V{Q.tiles, Q.tile_off, Q.tile_stats, Q.matches, seg_first_tile[si], seg_first_tile[si + 1], seg_in_off[si]};
-    const u64 n = seg_len[si];
-    u64 total = 0, nfwd = 0;
-    for (uint32_t t = V.t0 + threadIdx.x; t < V.t1; t += blockDim.x) { total += V.tile_stats[4u * t]; nfwd += V.tile_stats[4u * t + 2u]; }
+    const TsShardSegIn S = segs[si];
+    const SegView V = seg_view(Q, S);
+    const u64 n = S.len;
+    u64 total = 0, nfwd = 0, own = 0, own_can = 0, own_fwd = 0;
+    for (uint32_t t = V.t0 + threadIdx.x; t < V.t1; t += blockDim.x) {
+        const uint4 st = *(const uint4 *)&V.tile_stats[4ull * t];
+        total += st.x; nfwd += st.z;
+        if (t >= S.o0 && t < S.o1) { own += st.x; own_can += st.y; own_fwd += st.z; }
+    }
     part[0][threadIdx.x] = total; part[1][threadIdx.x] = nfwd;
+    part[2][threadIdx.x] = own; part[3][threadIdx.x] = own_can; part[4][threadIdx.x] = own_fwd;
+    if (threadIdx.x == 0) walk_flags = 0;
     __syncthreads();
     for (uint32_t o = 128; o >= 1; o >>= 1) {
-        if (threadIdx.x < o) { part[0][threadIdx.x] += part[0][threadIdx.x + o]; part[1][threadIdx.x] += part[1][threadIdx.x + o]; }
+        if (threadIdx.x < o)
+            for (int f = 0; f < 5; ++f) part[f][threadIdx.x] += part[f][threadIdx.x + o];
         __syncthreads();
     }
     total = part[0][0]; nfwd = part[1][0];
-    if (wave >= 2) return;
     uint32_t seq = 0;                                      // blocks are ordered by (direction, seq)
     if (wave == 0) {
         u64 fb = 0;
-        if (nfwd >= 2) fb = terminal_direction(Q, V, si, n, seg_abs[si], true, seq, lane);
-        if (lane == 0) bounds[2ull * si] = fb;
-    } else {
+        bool ooc = false;
+        const bool walk = (S.flags & TS_SEG_F_HAS_START) && nfwd >= 2;
+        if (walk) fb = terminal_direction(Q, V, S.seg, n, S.abs_pos, true, seq, lane, ooc);
+        if (lane == 0) {
+            bounds[2ull * si] = fb;
+            atomicOr(&walk_flags, (walk ? TS_SEG_F_FWD_WALKED : 0u) | (ooc ? TS_SEG_F_CONTEXT : 0u));
+        }
+    } else if (wave == 1) {
         u64 rb = n;
-        if (total - nfwd >= 2) rb = terminal_direction(Q, V, si, n, seg_abs[si], false, seq, lane);
-        if (lane == 0) bounds[2ull * si + 1] = total >= 2 ? rb : 0;       // 0 disables the interstitial search
+        bool ooc = false;
+        const bool walk = (S.flags & TS_SEG_F_HAS_END) && total - nfwd >= 2;
+        if (walk) rb = terminal_direction(Q, V, S.seg, n, S.abs_pos, false, seq, lane, ooc);
+        if (lane == 0) {
+            bounds[2ull * si + 1] = total >= 2 ? rb : 0;       // 0 disables the interstitial search
+            atomicOr(&walk_flags, (walk ? TS_SEG_F_REV_WALKED : 0u) | (ooc ? TS_SEG_F_CONTEXT : 0u));
+        }
+    }
+    if (!seg_out) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TsShardSeg o;
+        o.fwd_boundary = bounds[2ull * si];
+        o.rev_boundary = bounds[2ull * si + 1];
+        o.n_matches = part[2][0]; o.n_canonical = part[3][0]; o.n_forward = part[4][0];
+        o.seen_matches = total; o.seen_forward = nfwd;
+        o.flags = (S.flags & (TS_SEG_F_HAS_START | TS_SEG_F_HAS_END)) | walk_flags;
+        o.reserved = 0;
+        seg_out[si] = o;
     }
 }
 
@@ -282,22 +338,23 @@ struct TileView {
 #define TS_ITS_CAND  256                     // canonical candidates of a tile kept in LDS (~2 % of its records)
 #define TS_ITS_CACHE 1024                    // records of a tile kept in LDS (a tile of 13.5 kb holds ~400 at 3 % density)
 
-__global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t *seg_first_tile,
-                                       const u64 *seg_in_off, const u64 *seg_abs, const u64 *bounds,
-                                       uint32_t ntiles) {
-    // one wave per tile, lanes over its records
+__global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base,
+                                       const u64 *bounds, uint32_t ntiles, TsShardSeg *seg_out) {
+    // one wave per tile, lanes over its records.  A block belongs to the tile its chain STARTS in: a shard runs
+    // this over every tile it scanned (a chain that starts in an owned tile may have its first canonical match, the
+    // one that walks it, in the context) and emits the blocks that start in an owned tile.
     __shared__ uint32_t cache_all[4][TS_ITS_CACHE];
     __shared__ uint16_t cand_all[4][TS_ITS_CAND];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wave;
     if (tile >= ntiles) return;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t si = Q.tiles[tile].seg;
+    const uint32_t si = Q.tiles[tile].seg - seg_base;
     const u64 fb = bounds[2ull * si], rb = bounds[2ull * si + 1];
     if (rb == 0 || fb >= rb) return;
     if (Q.tile_stats[4u * tile + 1u] == 0u) return;       // no canonical match in the tile: nothing can lead a block
-    TileView V{{Q.tiles, Q.tile_off, Q.tile_stats, Q.matches, seg_first_tile[si], seg_first_tile[si + 1], seg_in_off[si]},
-               tile, 0, 0, nullptr};
+    const TsShardSegIn S = segs[si];
+    TileView V{seg_view(Q, S), tile, 0, 0, nullptr};
     V.cnt = V.V.count(tile);
     V.tile_rel = Q.tiles[tile].in_off - V.V.base;
     const uint32_t cnt = V.cnt;
@@ -330,6 +387,7 @@ __global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t
         if (ncand > TS_ITS_CAND) compacted = false;        // a tile full of canonical repeats: every record is tried
     }
     const uint32_t nwork = compacted ? ncand : cnt;
+    bool ooc = false;
     for (uint32_t w = lane; w < nwork; w += 64u) {
         const uint32_t i = compacted ? (uint32_t)cand_all[wave][w] : w;
         Cursor c{tile, i};
@@ -340,7 +398,16 @@ __global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t
         // walk left: not the leader if an earlier canonical match is in the same chain
         Cursor s = c; u64 sp = p; bool leader = true;
         for (Cursor q = c;;) {
-            if (!V.prev(q)) break;
+            if (!V.prev(q)) {
+                // The view's left edge, with the segment going on behind it: the chain's start is not known here.  For a
+                // candidate in a context tile that is its owner's business (the left neighbour sees the same records and
+                // more); for one in an owned tile the chain spans the whole left context — reported.
+                if (V.V.open_l && sp <= V.V.lo_rel + Q.max_match_dist && V.V.lo_rel > fb) {
+                    leader = false;
+                    if (tile >= S.o0 && tile < S.o1) ooc = true;
+                }
+                break;
+            }
             const uint32_t rq = V.rec(q);
             const u64 pq = V.pos(q, rq);
             if (pq < fb || sp - pq > Q.max_match_dist) break;
@@ -348,37 +415,38 @@ __global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const uint32_t
             s = q; sp = pq;
         }
         if (!leader) continue;
+        if (s.t < S.o0 || s.t >= S.o1) continue;          // the chain starts in a context tile: its owner emits the block
         // s is the chain's first match: walk the whole chain
         Chain ch;
         ch.begin(sp, V.rec(s), Q.k);
+        bool ended = false;
         for (Cursor q = s; V.next(q);) {
             const uint32_t rq = V.rec(q);
             const u64 pq = V.pos(q, rq);
-            if (pq >= rb || pq - ch.prev > Q.max_match_dist) break;
+            if (pq >= rb || pq - ch.prev > Q.max_match_dist) { ended = true; break; }
             ch.end = pq + Q.k;
             ch.add(pq, rq, Q.k);
         }
+        if (!ended && V.V.open_r && ch.prev + Q.max_match_dist >= V.V.hi_rel && V.V.hi_rel < rb) { ooc = true; continue; }
         const uint32_t blen = (uint32_t)(ch.end - ch.start);
         const char lab = its_label(ch.fwd, ch.counts);
         if (blen >= Q.its_min_len && ch.canon >= 4u && !(lab == 'b' && ch.fwd < 2u && (ch.counts - ch.fwd) < 2u)) {
             TsDevBlock b; ch.to_block(b);
             b.block_label = lab;
-            emit_block(Q, b, si, 2u, 0u, seg_abs[si]);
+            emit_block(Q, b, S.seg, 2u, 0u, S.abs_pos);
         }
     }
+    if (seg_out && __ballot(ooc) != 0ull && lane == 0) atomicOr(&seg_out[si].flags, TS_SEG_F_CONTEXT);
 }
 
 }  // namespace
 
-int ts_k_launch_block_call(const TsBlockCallParams *Q, const uint32_t *seg_first_tile,
-                           const unsigned long long *seg_in_off, const unsigned long long *seg_len,
-                           const unsigned long long *seg_abs, uint32_t nseg, uint32_t ntiles,
-                           unsigned long long *bounds, int with_its, void *stream) {
+int ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
+                           uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its, void *stream) {
     if (nseg == 0) return 0;
-    hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(256), 0, (hipStream_t)stream, *Q,
-                       seg_first_tile, seg_in_off, seg_len, seg_abs, nseg, bounds);
+    hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(256), 0, (hipStream_t)stream, *Q, segs, nseg, bounds, seg_out);
     if (with_its && ntiles)
         hipLaunchKernelGGL(ts_interstitial_blocks, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *Q,
-                           seg_first_tile, seg_in_off, seg_abs, bounds, ntiles);
+                           segs, seg_base, (const u64 *)bounds, ntiles, seg_out);
     return (int)hipGetLastError();
 }

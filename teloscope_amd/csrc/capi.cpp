@@ -726,7 +726,8 @@ void ts_batch_destroy(ts_batch *b) {
     if (c->device != kNoDevice) {
         DeviceGuard g(c->device);
         for (DevBuf *d : {&b->d_in, &b->d_tiles, &b->d_windows, &b->d_matches, &b->d_tile_off, &b->d_stats, &b->d_fill, &b->d_tickets,
-                          &b->d_segtab, &b->d_dense, &b->d_dense_base, &b->d_scan_tmp, &b->d_readtab})
+                          &b->d_segtab, &b->d_dense, &b->d_dense_base, &b->d_scan_tmp, &b->d_readtab, &b->d_shard_segs,
+                          &b->d_shard_bounds, &b->d_shard_tmp})
             c->pool.give(std::move(*d));
         for (hipEvent_t e : b->evs)
             if (e) (void)hipEventDestroy(e);
@@ -759,23 +760,12 @@ int ts_batch_range_info(const ts_batch *b, uint64_t tile_begin, uint64_t tile_en
 
 int ts_batch_partition(const ts_batch *b, uint32_t n_parts, uint32_t part, uint64_t *tile_begin, uint64_t *tile_end) {
     if (!b || !n_parts || part >= n_parts || !tile_begin || !tile_end) return TS_ERR_INVALID_ARG;
-    // boundary q = the first tile whose preceding owned bases reach q/n_parts of the total (tiles are near-equal
-    // work: ~wpt*s bases each), so every part gets the same bases +- one tile and the parts are consecutive
-    uint64_t total = 0;
-    for (const TsTile &T : b->tiles) total += T.own_len;
-    auto boundary = [&](uint32_t q) -> uint64_t {
-        if (q == 0) return 0;
-        if (q >= n_parts) return b->tiles.size();
-        const unsigned __int128 target = (unsigned __int128)total * q;
-        uint64_t acc = 0, t = 0;
-        for (; t < b->tiles.size(); ++t) {
-            if ((unsigned __int128)acc * n_parts >= target) break;
-            acc += b->tiles[t].own_len;
-        }
-        return t;
-    };
-    *tile_begin = boundary(part);
-    *tile_end = boundary(part + 1);
+    // consecutive ranges of equal owned bases (tiles are near-equal work), the boundaries moved — by at most the
+    // terminal zone + context of a segment — so that none falls near a segment's end (shard.cpp)
+    std::vector<uint64_t> cut;
+    ts_shard_boundaries(b, n_parts, cut);
+    *tile_begin = cut[part];
+    *tile_end = cut[part + 1];
     return TS_OK;
 }
 
@@ -1176,23 +1166,25 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
     const size_t ns = b->segs.size(), nt = b->tiles.size();
     blocks.clear();
     if (!ns) return TS_OK;
-    // segment table for the kernels: {first tile} x uint32, then {input offset, length, absolute position} x uint64
-    const size_t off_first = 0, off_in = (((ns + 1) * 4 + 15) & ~(size_t)15), off_len = off_in + ns * 8, off_abs = off_len + ns * 8,
-                 off_bounds = off_abs + ns * 8, off_count = off_bounds + ns * 16, tab_bytes = off_count + 16;
-    std::vector<char> tab(off_bounds);
+    // segment table of the kernels (a whole batch: every segment with all its tiles, both ends its own)
+    const size_t off_bounds = ns * sizeof(TsShardSegIn), off_count = off_bounds + ns * 16, tab_bytes = off_count + 16;
+    std::vector<TsShardSegIn> tab(ns);
     for (size_t i = 0; i < ns; ++i) {
-        ((uint32_t *)(tab.data() + off_first))[i] = b->segs[i].first_tile;
-        ((unsigned long long *)(tab.data() + off_in))[i] = b->segs[i].in_off;
-        ((unsigned long long *)(tab.data() + off_len))[i] = b->segs[i].len;
-        ((unsigned long long *)(tab.data() + off_abs))[i] = b->segs[i].abs_pos;
+        TsShardSegIn &S = tab[i];
+        S.in_off = b->segs[i].in_off; S.len = b->segs[i].len; S.abs_pos = b->segs[i].abs_pos;
+        S.t0 = S.o0 = b->segs[i].first_tile;
+        S.t1 = S.o1 = b->segs[i].first_tile + b->segs[i].n_tiles;
+        S.flags = TS_SEG_F_HAS_START | TS_SEG_F_HAS_END;
+        S.seg = (uint32_t)i;
     }
-    ((uint32_t *)(tab.data() + off_first))[ns] = (uint32_t)nt;
+    (void)nt;
     DevBuf d_tab, d_blocks;
     struct Return { ts_ctx *c; DevBuf &a, &b2; ~Return() { c->pool.give(std::move(a)); c->pool.give(std::move(b2)); } } give_back{c, d_tab, d_blocks};
     HIP_TRY(c, c->pool.take(tab_bytes, d_tab));
     char *const dt = (char *)d_tab.p;
     uint32_t cap = (uint32_t)std::min<uint64_t>(64ull * ns + 4096 + b->n_matches / 256, 1u << 26);
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    bool done = false;
+    for (int attempt = 0; attempt < 2 && !done; ++attempt) {
         HIP_TRY(c, c->pool.take((size_t)cap * sizeof(TsDevBlock), d_blocks));
         HIP_TRY(c, hipMemcpyAsync(dt, tab.data(), off_bounds, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemsetAsync(dt + off_count, 0, 16, st));
@@ -1208,10 +1200,8 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
         Q.min_block_len = P.min_block_len; Q.max_block_dist = P.max_block_dist;
         Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;
         Q.k = c->k; Q.its_min_len = (uint32_t)(uint16_t)(2 * c->bp.first_pattern_len);
-        if (ts_k_launch_block_call(&Q, (const uint32_t *)(dt + off_first), (const unsigned long long *)(dt + off_in),
-                                   (const unsigned long long *)(dt + off_len), (const unsigned long long *)(dt + off_abs),
-                                   (uint32_t)ns, (uint32_t)nt, (unsigned long long *)(dt + off_bounds), b->tips ? 0 : 1,
-                                   st) != 0) return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
+        if (ts_k_launch_block_call(&Q, (const TsShardSegIn *)dt, (uint32_t)ns, 0u, (uint32_t)nt, (unsigned long long *)(dt + off_bounds),
+                                   nullptr, b->tips ? 0 : 1, st) != 0) return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
         uint32_t nb = 0;
         HIP_TRY(c, hipMemcpyAsync(&nb, dt + off_count, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
@@ -1221,8 +1211,10 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
             HIP_TRY(c, hipMemcpyAsync(blocks.data(), d_blocks.p, (size_t)nb * sizeof(TsDevBlock), hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
         }
-        break;
+        done = true;
     }
+    // (block counts are deterministic: the second attempt is sized by the first one's count)
+    if (!done) return c->fail(TS_ERR_STATE, "device block calling overflowed its block buffer twice");
     std::sort(blocks.begin(), blocks.end(), [](const TsDevBlock &x, const TsDevBlock &y) {
         if (x.seg != y.seg) return x.seg < y.seg;
         const uint32_t kx = x.kind == 2 ? 1 : 0, ky = y.kind == 2 ? 1 : 0;

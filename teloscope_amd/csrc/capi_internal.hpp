@@ -152,6 +152,19 @@ struct SegPlan {
     std::vector<Region> regions;
 };
 
+// A shard of a plan (shard.cpp): the tiles it owns, the tiles it scans (owned + context), the segments with an owned tile
+struct ShardRange {
+    uint64_t own_lo, own_hi, ext_lo, ext_hi;
+    uint64_t seg_begin, n_segs;
+};
+// ... and the layout of its result message
+struct ShardLayout {
+    uint64_t off_segs, off_windows, off_tilevis, off_visible, off_blocks, bytes;
+    uint64_t visible_capacity;
+    uint32_t block_capacity, window_bytes, visible_bytes, field_bits;
+    uint64_t n_windows;
+};
+
 // A batch is a PLAN over all its segments (tiles, window records, input layout) plus the device state of
 // the tile range [tile_lo, tile_hi) it executes: the whole plan by default, one rank's shard after
 // ts_batch_restrict, or — on the rank that assembles — results produced elsewhere (ts_batch_adopt).
@@ -174,6 +187,12 @@ struct ts_batch {
     const void *last_input = nullptr;
     void *last_stream = nullptr;
     DevBuf d_in, d_tiles, d_windows, d_matches, d_tile_off, d_stats, d_fill, d_tickets, d_segtab, d_dense, d_dense_base, d_scan_tmp, d_readtab;
+    // a shard (ts_batch_restrict_shard): the range the batch executes is its OWNED tiles [own_lo, own_hi) plus context tiles
+    uint32_t shard_parts = 0, shard_part = 0, shard_scale = 1;
+    uint64_t own_lo = 0, own_hi = 0;
+    DevBuf d_shard_segs, d_shard_bounds, d_shard_tmp;
+    ShardRange shard_r{};
+    ShardLayout shard_L{};
     // caller-owned result buffers (ts_batch_bind_results / ts_batch_adopt); null = the batch's own
     uint32_t *ext_windows = nullptr, *ext_stats = nullptr;
     const uint32_t *ext_dense = nullptr;
@@ -211,6 +230,14 @@ struct ts_batch {
         return (ctx)->fail(TS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_dev_guard.error()))
 
 inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// shard.cpp: boundaries of the split of a plan into n_parts consecutive tile ranges (n_parts + 1 values)
+void ts_shard_boundaries(const ts_batch *b, uint32_t n_parts, std::vector<uint64_t> &out);
+
+// pipeline.cpp: per-context pieces of the host pipeline, for multi.cpp
+int  ts_scan_segments_unlocked(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out);   // ts_scan_segments for a caller that holds api_mtx
+int  ts_pipeline_ensure_streams(ts_ctx *c);
+int  ts_pipeline_upload_batch(ts_batch *b, const ts_segment_in *segs, int *slot, bool used[]);   // segs: the batch's segments, in plan order
 
 // capi.cpp internals used by pipeline.cpp
 bool ts_full_scan_supported(const ts_ctx *c, std::string &why);

@@ -282,9 +282,14 @@ int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
                     if (t.text_len > (16ull << 20) + 4096) return c->fail(TS_ERR_INVALID_ARG, "a text piece is larger than 16 MiB");
                     if (want >= cum + t.n_bases) { cum += t.n_bases; continue; }      // wholly before the region
                     const uint64_t skip = want - cum;
-                    const char *from = skip ? text_locate(t.text, t.text_len, skip) : t.text;
                     const uint64_t n = std::min<uint64_t>(t.n_bases - skip, left);
-                    pieces.push_back({off, from, n, (uint64_t)(t.text + t.text_len - from)});
+                    // of these n bases, those the batch's range reads (a shard uploads only its part of a segment)
+                    const uint64_t a = std::max<uint64_t>(off, b->in_lo), z = std::min<uint64_t>(off + n, b->in_hi);
+                    if (z > a) {
+                        const uint64_t skip2 = skip + (a - off);
+                        const char *from = skip2 ? text_locate(t.text, t.text_len, skip2) : t.text;
+                        pieces.push_back({a, from, z - a, (uint64_t)(t.text + t.text_len - from)});
+                    }
                     off += n; left -= n; want += n; cum += t.n_bases;
                 }
             } else {
@@ -772,6 +777,18 @@ int scan_segments_unlocked(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs
 }
 
 }  // namespace
+
+int ts_scan_segments_unlocked(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out) {
+    return scan_segments_unlocked(ctx, segs, n_segs, out);
+}
+
+// the pieces of the pipeline that ts_scan_segments_multi (multi.cpp) runs per context
+int ts_pipeline_ensure_streams(ts_ctx *c) { return ensure_streams(c); }
+int ts_pipeline_upload_batch(ts_batch *b, const ts_segment_in *segs, int *slot, bool used[]) {
+    std::vector<Item> items(b->segs.size());
+    for (size_t i = 0; i < items.size(); ++i) items[i] = Item{segs[i].seq, segs[i].len, segs[i].abs_pos, segs[i].input_format};
+    return upload_batch(b, items.data(), *slot, used);
+}
 
 // =========================================================================== scanSegment, batched
 extern "C" {

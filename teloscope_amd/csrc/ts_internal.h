@@ -104,6 +104,85 @@ struct TsBlockCallParams {
     uint32_t its_min_len;               // 2 * patterns.front().size()
 };
 
+// ---- shard results (shard.hip, shard.cpp): what one device contributes to a scan that several devices share ----
+// A shard OWNS a run of consecutive tiles of the batch's plan and additionally scans a few CONTEXT tiles either side
+// where a segment continues on a neighbour (blocks are chains of matches: a chain that begins in an owned tile is
+// followed into the context).  After its scan it packs ONE message:
+//
+//   TsShardHeader | TsShardSeg x n_segs | packed window records | u16 visible-record count per owned tile |
+//   visible records (u16 or u32 each, capacity) | TsDevBlock x capacity
+//
+// "visible" = the match records a writer reads: canonicalMatches, and nonCanonicalMatches of the terminal zone
+// (src/teloscope.cpp:486-496, writers :700-868); everything else the match stream holds is consumed by block calling,
+// which has happened on the device.  Section offsets are a pure function of the plan, the split and the capacity scale
+// (shard_layout, shard.cpp), so sender and receiver agree on them without talking.
+#define TS_SHARD_MAGIC   0x44485354u    // "TSHD"
+#define TS_SHARD_VERSION 1u
+#define TS_SHARD_F_VISIBLE_OVERFLOW 0x1u    // more visible records than the section holds (n_visible says how many)
+#define TS_SHARD_F_BLOCK_OVERFLOW   0x2u    // more blocks than the section holds (n_blocks says how many)
+#define TS_SHARD_F_SCAN_OVERFLOW    0x4u    // a wave's record region overflowed in the scan: ts_batch_sync, then pack again
+#define TS_SHARD_F_CONTEXT          0x8u    // a chain or a terminal walk ran out of the context tiles: the segment needs the full path
+
+struct TsShardHeader {                  // 128 bytes
+    uint32_t magic, version;
+    uint32_t part, n_parts;
+    unsigned long long own_begin, own_end;      // tiles (plan indices)
+    unsigned long long ext_begin, ext_end;
+    unsigned long long seg_begin;               // first segment with an owned tile
+    uint32_t n_segs;
+    uint32_t flags;                             // TS_SHARD_F_*
+    unsigned long long n_visible;               // visible records of the owned tiles (may exceed the capacity: overflow)
+    uint32_t n_blocks;                          // blocks emitted (may exceed the capacity: overflow)
+    uint32_t visible_bytes;                     // 2 or 4 per visible record
+    unsigned long long visible_capacity;
+    uint32_t block_capacity;
+    uint32_t window_bytes;                      // bytes per packed window record
+    unsigned long long n_windows;               // owned window records
+    unsigned long long msg_bytes;
+    unsigned long long reserved[2];
+};
+static_assert(sizeof(TsShardHeader) == 128, "TsShardHeader is 128 bytes on the wire");
+
+#define TS_SEG_F_HAS_START   0x1u       // the shard owns the segment's first tile: it walked the forward list from the start
+#define TS_SEG_F_HAS_END     0x2u       // ... its last tile: it walked the reverse list from the end
+#define TS_SEG_F_FWD_WALKED  0x4u       // the forward walk ran (>= 2 forward matches among the tiles the shard sees)
+#define TS_SEG_F_REV_WALKED  0x8u
+#define TS_SEG_F_CONTEXT     0x10u      // a walk or a chain of this segment ran out of context
+struct TsShardSeg {                     // 64 bytes, one per segment with an owned tile
+    unsigned long long fwd_boundary, rev_boundary;  // segment-relative; what this shard used for its interstitial search
+    unsigned long long n_matches, n_canonical, n_forward;   // over the OWNED tiles of the segment
+    unsigned long long seen_matches, seen_forward;  // over all its tiles the shard scanned (owned + context)
+    uint32_t flags;
+    uint32_t reserved;
+};
+static_assert(sizeof(TsShardSeg) == 64, "TsShardSeg is 64 bytes on the wire");
+
+struct TsShardSegIn {                   // per-segment table of the shard kernels, 48 bytes
+    unsigned long long in_off, len, abs_pos;    // input layout offset, length, absolute position of the segment
+    uint32_t t0, t1;                            // its tiles the shard scanned, as indices into the batch's (range-local) arrays
+    uint32_t o0, o1;                            // its OWNED tiles, same indexing (o0 == o1: none)
+    uint32_t flags;                             // TS_SEG_F_HAS_START / HAS_END
+    uint32_t seg;                               // plan index of the segment
+};
+
+struct TsShardPackParams {
+    const TsTile *tiles;                // range-local arrays of the batch (the range = owned + context tiles)
+    const unsigned long long *tile_off;
+    const uint32_t *tile_stats;
+    const uint32_t *matches;
+    const uint32_t *windows;            // 8 x u32 per window of the range, from win_lo
+    const uint32_t *wave_fill;
+    uint32_t region_cap, nwaves;
+    uint32_t own0, own1;                // owned tiles, range-local
+    unsigned long long win_lo;          // plan index of the range's first window record
+    unsigned long long own_win0, own_win1;      // owned window records (plan indices)
+    const TsShardSegIn *segs;
+    uint32_t n_segs;
+    uint32_t terminal_limit, k, nuc_on, field_bits;
+    unsigned char *msg;
+    unsigned long long off_segs, off_windows, off_tilevis, off_visible, off_blocks;   // byte offsets of the sections
+};
+
 // ---- general kernels (generic.hip) ----
 struct TsGenericPatterns {
     const unsigned long long *codes;    // per length: ascending 2-bit codes (base i at bits 2i..2i+1)
@@ -159,10 +238,14 @@ int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_o
                            // (nrec_limit: records that may be READ behind `matches` — the predicate fetches aligned 16-byte blocks;
                            //  long_list: nseg entries of scratch + long_count: one counter, for the reads a whole wave walks;
                            //  all_terminal: no segment is longer than the terminal limit — every read batch — the lean kernel)
-int  ts_k_launch_block_call(const TsBlockCallParams *Q, const uint32_t *seg_first_tile,
-                            const unsigned long long *seg_in_off, const unsigned long long *seg_len,
-                            const unsigned long long *seg_abs, uint32_t nseg, uint32_t ntiles,
-                            unsigned long long *bounds, int with_its, void *stream);
+// blockcall.hip: terminal walks per segment of `segs` (nseg entries; bounds: 2 x u64 per segment), then the interstitial
+// search over the batch's ntiles (range-local) tiles; seg_base = plan index of segs[0]'s segment; seg_out (nullable):
+// what a shard reports per segment
+int  ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
+                            uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its, void *stream);
+// shard.hip: packed window records, visible records + per-tile counts, and the header of a shard's message
+int  ts_k_launch_shard_pack(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, void *stream);
+unsigned long long ts_k_shard_tmp_bytes(uint32_t own_tiles);
 // exchange.hip: tile directory of a dense tile-ordered stream, and the export of a scan's records into one
 unsigned long long ts_k_scan_tmp_bytes(uint32_t ntiles);
 int  ts_k_launch_tile_offsets(const uint32_t *tile_stats, uint32_t ntiles, unsigned long long *tile_off, void *tmp,

@@ -418,6 +418,107 @@ class HipShard:
         self.batches = []
 
 
+# ------------------------------------------------------------------------------------------- shard results
+# The exchange above assembles every record on one rank (0.56 GB per 3 Gb scan): bound by the xGMI links into that
+# rank.  What follows ships what the reference's writers read instead (include/teloscan.h, "shard results"): every
+# rank calls its blocks on its own device and packs ONE message of a size both sides know from the plan —
+# bit-packed window records, the visible match records, its blocks — so that a step needs no count exchange and no
+# host synchronisation, and ~60 MB cross the links at 8 ranks instead of 245.
+
+def shard_info(plan: ShardPlan, part: int, scale: int = 1, world: Optional[int] = None):
+    info = K.ShardInfo()
+    rc = plan.L.ts_batch_shard_info(plan.batch, world or plan.world, part, scale, C.byref(info))
+    if rc != K.TS_OK:
+        raise K.TeloscanError(rc, "ts_batch_shard_info failed")
+    return info
+
+
+class PackedShard:
+    """One rank's shard on its GPU (ts_batch_restrict_shard): scan + device block calling + packed message, all
+    asynchronous on the caller's stream.  `slots` message buffers (each with its own batch object) let the
+    transfer of one scan's message overlap the next scan."""
+
+    def __init__(self, plan: ShardPlan, part: int, device, slots: int = 1, scale: int = 1):
+        import torch
+        self.plan, self.part, self.device, self.scale = plan, part, device, scale
+        self.L = plan.L
+        self.info = shard_info(plan, part, scale)
+        self.batches, self.msgs = [], []
+        for _ in range(slots):
+            b = plan.new_batch()
+            rc = self.L.ts_batch_restrict_shard(b, plan.world, part, scale)
+            if rc != K.TS_OK:
+                raise K.TeloscanError(rc, plan.teloscope._ctx.error())
+            self.batches.append(b)
+            self.msgs.append(torch.zeros(int(self.info.msg_bytes), dtype=torch.uint8, device=device))
+
+    def scan_pack(self, d_input, stream_ptr, slot=0):
+        """d_input: device address of byte `info.input_begin` of the input layout."""
+        b = self.batches[slot]
+        rc = self.L.ts_batch_scan(b, C.c_void_p(d_input), stream_ptr)
+        if rc == K.TS_OK:
+            rc = self.L.ts_batch_pack_shard(b, C.c_void_p(self.msgs[slot].data_ptr()), self.msgs[slot].numel(), stream_ptr)
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, self.plan.teloscope._ctx.error())
+
+    def status(self, slot=0):
+        """The message's header, read back (synchronises with the device)."""
+        head = self.msgs[slot][:128].cpu().numpy()
+        st = K.ShardStatus()
+        rc = self.L.ts_shard_peek(head.ctypes.data, head.nbytes, C.byref(st))
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, "ts_shard_peek failed")
+        return st
+
+    def sync(self, slot=0):
+        """ts_batch_sync of the slot's batch: grows the record regions and rescans if the scan overflowed."""
+        rc = self.L.ts_batch_sync(self.batches[slot])
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, self.plan.teloscope._ctx.error())
+
+    def set_scale(self, scale):
+        """Larger variable sections (after an overflow); every rank and the receiver must use the same scale."""
+        import torch
+        self.scale = scale
+        self.info = shard_info(self.plan, self.part, scale)
+        for j, b in enumerate(self.batches):
+            self.L.ts_batch_set_shard_scale(b, scale)
+            self.msgs[j] = torch.zeros(int(self.info.msg_bytes), dtype=torch.uint8, device=self.device)
+
+    def kernel_ms(self, slot=0):
+        b = self.batches[slot]
+        self.sync(slot)
+        info = K.BatchInfo()
+        self.L.ts_batch_get_info(b, C.byref(info))
+        return float(info.avg_kernel_ms), int(info.kernel_launches), info
+
+    def close(self):
+        for b in self.batches:
+            self.L.ts_batch_destroy(b)
+        self.batches = []
+
+
+def finalize_shards(plan: ShardPlan, msgs, with_counts=True):
+    """ts_shards_finalize: the messages of all parts (host memory: numpy uint8 arrays or bytes) -> (rc, out, counts);
+    rc 0 = out[i] / counts[i] hold segment i (free out with free_segments), else K.SHARD_RETRY_SYNC / _GROW / NEED_FULL."""
+    n = len(msgs)
+    assert n == plan.world
+    arrs = [np.frombuffer(m, dtype=np.uint8) if not isinstance(m, np.ndarray) else np.ascontiguousarray(m) for m in msgs]
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    sizes = (C.c_uint64 * n)(*[a.nbytes for a in arrs])
+    ns = len(plan.seg_lens)
+    out = (K.SegmentOut * max(1, ns))()
+    cnt = (K.SegmentCounts * max(1, ns))()
+    rc = plan.L.ts_shards_finalize(plan.batch, ptrs, sizes, n, out, cnt if with_counts else None)
+    if rc < 0:
+        raise K.TeloscanError(rc, plan.teloscope._ctx.error())
+    return rc, out, cnt
+
+
+def free_segments(plan: ShardPlan, out):
+    plan.L.ts_free_segments(out, len(plan.seg_lens))
+
+
 def adopt(plan: ShardPlan, a: Assembled, stream_ptr=None):
     """A whole-plan batch holding the assembled results (ts_batch_adopt): block calling, downloads and the
     segment summary then work as after a single-GPU scan.  The caller destroys it (ts_batch_destroy) and

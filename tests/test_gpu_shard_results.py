@@ -1,0 +1,202 @@
+"""GPU parity of shard results (include/teloscan.h: ts_batch_restrict_shard / ts_batch_pack_shard /
+ts_shards_finalize) and of ts_scan_segments_multi.
+
+Every part of a plan is scanned on its own restricted batch — its owned tile range plus context tiles — calls its
+blocks on the device and packs its message; the messages of all parts, merged on the host, must be what the oracle
+says about every segment: windows (all fields), terminal and interstitial blocks, the match records a writer reads
+(canonicalMatches, terminal nonCanonicalMatches) and the per-segment counts — for any number of parts, wherever the
+boundaries fall.  Inputs the shards' assumptions do not hold for (a telomere longer than the context tiles, across a
+boundary) must be REPORTED (TS_SHARD_NEED_FULL), never answered wrongly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import harness as H
+from tests import seqgen
+from tests.backends import BLOCK_FIELDS, MATCH_FIELDS, WINDOW_FIELDS, OracleBackend
+
+pytestmark = pytest.mark.gpu
+HEADLINE = "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -m -i"
+
+
+def _teloscope(cli, device=0):
+    import teloscope_amd as ta
+    from teloscope_amd.cli import parse_cli, user_input
+    opts = parse_cli("x.fa " + cli)
+    return opts, ta.Teloscope(user_input(opts, device=device))
+
+
+def assert_visible_view_equal(got, exp, tips, cnt, ctx):
+    """got: teloscope_amd.SegmentData built from a visible-view ts_segment_out; exp: the oracle's dict."""
+    gw, ew = got.windows, exp["windows"]
+    assert len(gw) == len(ew), "%s windows: %d vs %d" % (ctx, len(gw), len(ew))
+    for f in WINDOW_FIELDS:
+        assert np.array_equal(gw[f], ew[f]), "%s windows.%s differs" % (ctx, f)
+    if len(gw):
+        assert np.max(np.abs(gw["gc_content"].astype(np.float64) - ew["gc_content"])) <= 1e-6, ctx
+        assert np.max(np.abs(gw["shannon_entropy"].astype(np.float64) - ew["shannon_entropy"])) <= 1e-6, ctx
+    for name, g in (("terminal_blocks", got.terminalBlocks), ("interstitial_blocks", got.interstitialBlocks)):
+        e = exp[name]
+        assert len(g) == len(e), "%s %s: %d vs %d" % (ctx, name, len(g), len(e))
+        for f in BLOCK_FIELDS:
+            assert np.array_equal(g[f], e[f]), "%s %s.%s differs" % (ctx, name, f)
+    for name, g in (("canonical_matches", got.canonicalMatches), ("non_canonical_matches", got.nonCanonicalMatches)):
+        e = exp[name]
+        assert len(g) == len(e), "%s %s: %d vs %d" % (ctx, name, len(g), len(e))
+        for f in MATCH_FIELDS:
+            assert np.array_equal(g[f], e[f]), "%s %s.%s differs" % (ctx, name, f)
+        assert np.array_equal((g["flags"] & 1) != 0, e["is_forward"] != 0), "%s %s.is_forward" % (ctx, name)
+    if not tips:
+        assert len(got._m) == len(exp["canonical_matches"]) + len(exp["non_canonical_matches"]), ctx
+    if cnt is not None:
+        if tips:
+            assert (cnt.n_windows, cnt.n_matches, cnt.n_forward) == (0, len(exp["fwd_matches"]) + len(exp["rev_matches"]), len(exp["fwd_matches"])), ctx
+        else:
+            assert (cnt.n_windows, cnt.n_matches, cnt.n_canonical, cnt.n_forward) == \
+                (len(ew), len(exp["all_matches"]), len(exp["canonical_matches"]), len(exp["fwd_matches"])), ctx
+
+
+def _pack_all_parts(plan, buf, dev):
+    """Every part scanned and packed on its own restricted batch, as a rank would; returns the host messages."""
+    import torch
+    from teloscope_amd import _capi as K
+    from teloscope_amd.distributed import PackedShard
+    sptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    msgs, stats = [], []
+    for p in range(plan.world):
+        ps = PackedShard(plan, p, dev, slots=1)
+        local = buf[ps.info.input_begin:max(ps.info.input_end, ps.info.input_begin + 64)].clone()   # a rank holds only the bytes its range reads
+        for _ in range(6):
+            ps.scan_pack(local.data_ptr(), sptr, 0)
+            st = ps.status(0)
+            if st.flags & K.SHARD_OVERFLOW_SCAN:
+                ps.sync(0)
+            elif st.flags & (K.SHARD_OVERFLOW_VISIBLE | K.SHARD_OVERFLOW_BLOCKS):
+                raise AssertionError("message overflow at scale 1: visible %d / %d, blocks %d / %d"
+                                     % (st.n_visible, st.visible_capacity, st.n_blocks, st.block_capacity))
+            else:
+                break
+        msgs.append(ps.msgs[0].cpu().numpy().copy())
+        stats.append(st)
+        ps.close()
+    return msgs, stats
+
+
+def _fill(plan, seqs, dev):
+    import torch
+    buf = torch.zeros(int(plan.info.input_bytes), dtype=torch.uint8, device=dev)
+    for off, s in zip(plan.segment_offsets(), seqs):
+        if len(s):
+            buf[off:off + len(s)] = torch.frombuffer(bytearray(s), dtype=torch.uint8).to(dev)
+    return buf
+
+
+CLIS = [HEADLINE, "-r -g -e -m -i", "-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i", HEADLINE + " -t 3000",
+        "-r -i -t 2500 -k 120", "-r -w 700 -s 700 -t 1000", "", "-t 3000"]
+
+
+@pytest.mark.parametrize("cli", CLIS)
+def test_shard_messages_merge_to_the_oracle(cli):
+    import torch
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.distributed import ShardPlan, finalize_shards, free_segments, shard_info
+    dev = torch.device("cuda", 0)
+    opts, tel = _teloscope(cli)
+    rng = np.random.default_rng(len(cli) + 29)
+    lens = [70001, 7, 250003, 0, 1999, 1_000_000, 16500, 333_333, 120_000]
+    seqs = [seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, n_its=4, iupac=2) if n else b"" for n in lens]
+    abs_pos = [13 * i for i in range(len(lens))]
+    tips = opts.ultra_fast
+    orac = OracleBackend(opts)
+    exp = [orac.scan_segment(sq, abs_pos[i], tips) for i, sq in enumerate(seqs)]
+    split_inside = 0
+    for world in (1, 2, 3, 5, 8):
+        plan = ShardPlan(tel, lens, abs_pos=abs_pos, tips_only=tips, world=world)
+        buf = _fill(plan, seqs, dev)
+        msgs, _ = _pack_all_parts(plan, buf, dev)
+        for p in range(world):
+            si = shard_info(plan, p)
+            split_inside += int(si.ext_begin != si.own_begin) + int(si.ext_end != si.own_end)
+        rc, out, cnt = finalize_shards(plan, msgs)
+        assert rc == 0, (world, rc, tel._ctx.error())
+        for i in range(len(lens)):
+            assert_visible_view_equal(ta.SegmentData(out[i], tips), exp[i], tips, cnt[i], "world %d segment %d" % (world, i))
+        free_segments(plan, out)
+        plan.close()
+    if not tips and ("-t 3000" in cli or "-t 2500" in cli or "-t 1000" in cli):
+        assert split_inside > 0, "no boundary fell inside a segment: the context tiles were never exercised"
+
+
+def test_block_at_a_shard_boundary_and_a_telomere_longer_than_the_context():
+    """(a) An interstitial block planted right across every boundary of a 4-way split: it starts in one shard's tiles and
+    ends in the next one's — the owner of its start follows it into its context tiles.  (b) The same segment with a
+    repeat array of 60 kb across a boundary: the chain outruns the context, and the merge must say NEED_FULL."""
+    import torch
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.distributed import ShardPlan, finalize_shards, free_segments, shard_info
+    dev = torch.device("cuda", 0)
+    opts, tel = _teloscope(HEADLINE + " -t 3000")
+    rng = np.random.default_rng(5)
+    n = 1_200_000
+    base = bytearray(seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, n_its=2))
+    plan = ShardPlan(tel, [n], world=4)
+    tiles = plan.tiles
+    cuts = [int(tiles["seg_offset"][shard_info(plan, p).own_begin]) for p in range(1, 4)]
+    assert all(0 < c < n for c in cuts) and len(set(cuts)) == 3
+    orac = OracleBackend(opts)
+    for variant, length in (("block", 900), ("long", 60_000)):
+        seq = bytearray(base)
+        for c in cuts[:(3 if variant == "block" else 1)]:
+            rep = (b"TTAGGG" * (length // 6 + 1))[:length]
+            seq[c - length // 2:c - length // 2 + length] = rep
+        seq = bytes(seq)
+        buf = _fill(plan, [seq], dev)
+        msgs, stats = _pack_all_parts(plan, buf, dev)
+        rc, out, cnt = finalize_shards(plan, msgs)
+        if variant == "block":
+            assert rc == 0, tel._ctx.error()
+            e = orac.scan_segment(seq, 0, False)
+            assert len(e["interstitial_blocks"]) >= 3
+            assert_visible_view_equal(ta.SegmentData(out[0], False), e, False, cnt[0], "blocks across boundaries")
+            free_segments(plan, out)
+        else:
+            assert rc == K.SHARD_NEED_FULL, rc
+            assert any(s.flags & K.SHARD_OUT_OF_CONTEXT for s in stats)
+    plan.close()
+
+
+def test_scan_segments_multi_equals_oracle():
+    """ts_scan_segments_multi over 1, 2 and 3 contexts (sharing this GPU): per segment == oracle, full scans and
+    tips-only segments mixed in one call; a parameter set outside the tiled kernel takes the single-context path."""
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import parse_cli, user_input
+    L = K.lib()
+    rng = np.random.default_rng(77)
+    for cli in (HEADLINE + " -t 3000", "-r -g -i", "-p TTAGGG,TTAGG -r -i -w 1000 -s 500"):
+        opts = parse_cli("x.fa " + cli)
+        tels = [ta.Teloscope(user_input(opts, device=0)) for _ in range(3)]
+        lens = [400_000, 0, 33, 150_000, 20_000, 600_001, 90_000]
+        seqs = [seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, n_its=3, iupac=1) if n else b"" for n in lens]
+        tipsv = [False, False, False, True, False, False, True]
+        n = len(lens)
+        segs = (K.SegmentIn * n)()
+        for i in range(n):
+            segs[i].seq = seqs[i]
+            segs[i].len = lens[i]
+            segs[i].abs_pos = 1000 * i
+            segs[i].tips_only = int(tipsv[i])
+        orac = OracleBackend(opts)
+        exp = [orac.scan_segment(seqs[i], 1000 * i, tipsv[i]) for i in range(n)]
+        for nctx in (1, 2, 3):
+            ctxs = (C.c_void_p * nctx)(*[t._ctx.ptr for t in tels[:nctx]])
+            out = (K.SegmentOut * n)()
+            cnt = (K.SegmentCounts * n)()
+            rc = L.ts_scan_segments_multi(ctxs, nctx, segs, n, out, cnt)
+            assert rc == 0, (cli, nctx, tels[0]._ctx.error())
+            for i in range(n):
+                assert_visible_view_equal(ta.SegmentData(out[i], tipsv[i]), exp[i], tipsv[i], cnt[i], "%s nctx %d segment %d" % (cli, nctx, i))
+            L.ts_free_segments(out, n)
