@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gbases", type=float, default=3.0, help="bases of the assembly (Gb); 3.0 = BASELINE config")
     ap.add_argument("--contigs", type=int, default=200)
+    ap.add_argument("--full-exchange", action="store_true",
+                    help="N > 1: round 2's exchange (every window, directory entry and match record assembled on rank 0) instead of "
+                         "the shard results (blocks called per rank; packed windows, writer-visible records and blocks travel)")
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank scans its own --gbases assembly (weak scaling; "
                                                           "only per-segment hit summaries are gathered)")
     ap.add_argument("--cpu-sample-mb", type=float, default=384.0)
@@ -243,6 +246,42 @@ def verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev):
                           "A/C/G/T totals vs the sums of the windows that tile each contig"}
 
 
+def compare_sharded_with_single_gpu(L, K, tel, batch, sharded, n, with_matches):
+    """The merged shard results (ts_shards_finalize on rank 0) against the downloads of a single-GPU scan of the whole
+    assembly: window records and blocks byte for byte, the per-segment counts, and — when the assembly is small enough
+    to bring every match record to the host — the visible match records.  Raises on any difference."""
+    import numpy as np
+    seg_out, seg_cnt = sharded["seg_out"], sharded["seg_cnt"]
+    ref = (K.SegmentOut * n)()
+    rc = L.ts_batch_download(batch, None, ref) if with_matches else L.ts_batch_download_blocks(batch, ref)
+    if rc != 0:
+        raise RuntimeError(tel._ctx.error())
+
+    def raw(ptr, count, dt):
+        return np.frombuffer(C.string_at(C.cast(ptr, C.c_void_p), int(count) * dt.itemsize), dtype=np.uint8) if count else np.zeros(0, np.uint8)
+
+    nwin = nblk = nvis = 0
+    for i in range(n):
+        g, e = seg_out[i], ref[i]
+        assert g.n_windows == e.n_windows and np.array_equal(raw(g.windows, g.n_windows, K.WINDOW_DT), raw(e.windows, e.n_windows, K.WINDOW_DT)), ("windows", i)
+        assert g.n_terminal_blocks == e.n_terminal_blocks and g.n_interstitial_blocks == e.n_interstitial_blocks, ("block counts", i)
+        assert np.array_equal(raw(g.terminal_blocks, g.n_terminal_blocks, K.BLOCK_DT), raw(e.terminal_blocks, e.n_terminal_blocks, K.BLOCK_DT)), ("terminal blocks", i)
+        assert np.array_equal(raw(g.interstitial_blocks, g.n_interstitial_blocks, K.BLOCK_DT), raw(e.interstitial_blocks, e.n_interstitial_blocks, K.BLOCK_DT)), ("interstitial blocks", i)
+        nwin += int(g.n_windows)
+        nblk += int(g.n_terminal_blocks + g.n_interstitial_blocks)
+        if with_matches:
+            em = np.frombuffer(raw(e.matches, e.n_matches, K.MATCH_DT), dtype=K.MATCH_DT) if e.n_matches else np.zeros(0, K.MATCH_DT)
+            vis = em[(em["flags"] & (K.MATCH_CANONICAL | K.MATCH_TERMINAL)) != 0]
+            gm = np.frombuffer(raw(g.matches, g.n_matches, K.MATCH_DT), dtype=K.MATCH_DT) if g.n_matches else np.zeros(0, K.MATCH_DT)
+            assert len(gm) == len(vis) and np.array_equal(gm["position"], vis["position"]) and np.array_equal(gm["flags"], vis["flags"]), ("visible matches", i)
+            assert int(seg_cnt[i].n_matches) == len(em) and int(seg_cnt[i].n_canonical) == int(((em["flags"] & K.MATCH_CANONICAL) != 0).sum()) \
+                and int(seg_cnt[i].n_forward) == int(((em["flags"] & K.MATCH_FORWARD) != 0).sum()), ("counts", i)
+            nvis += len(gm)
+    L.ts_free_segments(ref, n)
+    return {"segments": n, "windows": nwin, "blocks": nblk, "visible_matches": nvis if with_matches else None,
+            "compared": "window records and blocks byte for byte" + (", visible match records, per-segment counts" if with_matches else "")}
+
+
 def traffic_from_profile(args):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of the default command, with where it came
     from; null when the kernel source is newer than the profile (a stale figure is worse than none)."""
@@ -377,14 +416,8 @@ def run_scan(args, rank, local_rank, world, dev, backend):
     full = torch.zeros(int(info.input_bytes), dtype=torch.uint8, device=dev)
     fill_synthetic(full, offsets, lens, 42 + (rank if args.weak else 0), dev)
     keep_full = (not strong) or (rank == 0 and args.verify)
-    if strong:
-        r = plan.ranges[rank]
-        buf = full[r.input_begin:r.input_end].clone()
-        if not keep_full:
-            del full
-            torch.cuda.empty_cache()
-    else:
-        buf = full
+    buf = full                                                  # (a strong-scaling rank cuts its own range out below)
+    sharded = None
 
     def barrier():
         if world > 1:
@@ -468,9 +501,144 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                                      + (" + RCCL gather of per-segment hit summaries (weak scaling: every rank its own assembly)"
                                         if world > 1 else "")}
         bases_done = world * total
+    elif not args.full_exchange:
+        # ---------------------------------------------------------------- N > 1, strong scaling (configs[2]): shard results
+        # Every rank scans its tile range (+ context tiles), calls its blocks on its own device and packs ONE message of a
+        # size both sides know from the plan; one grouped send / recv per step brings the messages to rank 0.  Nothing is
+        # read back to the host inside a step; the messages' headers are checked (and the messages merged on the host,
+        # ts_shards_finalize) before the timed steps and after them.
+        slots = 2
+        scale = 1
+        exch = D.ShardExchange(plan, rank, dev, dst=0, slots=slots, scale=scale)
+        shard = D.PackedShard(plan, rank, dev, slots=slots, scale=scale)
+        buf = full[int(shard.info.input_begin):max(int(shard.info.input_end), int(shard.info.input_begin) + 64)].clone()
+        if not keep_full:
+            del full
+            torch.cuda.empty_cache()
+        in_ptr = buf.data_ptr()
+        pending = [None] * slots
+
+        def step(i):
+            j = i % slots
+            if pending[j] is not None:
+                for w in pending[j]:
+                    w.wait()
+                pending[j] = None
+            shard.scan_pack(in_ptr, sptr, j)
+            pending[j] = exch.post(shard.msgs[j], j)
+
+        def drain():
+            for j in range(slots):
+                if pending[j] is not None:
+                    for w in pending[j]:
+                        w.wait()
+                    pending[j] = None
+
+        settle(step, drain)
+        for i in range(max(args.warmup, slots)):
+            step(i)
+        drain()
+        torch.cuda.synchronize()
+        # capacities and record regions settle here (untimed): a scan that overflowed its regions is regrown, a message that
+        # overflowed gets a larger scale on every rank; an input the shards' assumptions do not hold for takes the full exchange
+        ok = False
+        for attempt in range(8):
+            action, factor, merged = exch.check(shard.msgs[0], 0)
+            if merged is not None:
+                D.free_segments(plan, merged[1])
+            if action == exch.OK:
+                ok = True
+                break
+            if action == exch.FULL:
+                break
+            if action == exch.SYNC:
+                for j in range(slots):
+                    shard.sync(j)
+            elif action == exch.GROW:
+                scale *= factor
+                shard.set_scale(scale)
+                exch.set_scale(scale)
+            for i in range(slots):
+                step(i)
+            drain()
+            torch.cuda.synchronize()
+        if not ok:
+            raise RuntimeError("the shard results need the full exchange for this input: run with --full-exchange")
+        for j in range(slots):
+            shard.kernel_ms(j)                                   # (harvest the scans' event times so far)
+        tmax, dev_ms = timed(step, drain, args.steps)
+        last = (args.steps - 1) % slots
+        km = [shard.kernel_ms(j) for j in range(slots)]
+        launches = sum(k[1] for k in km)
+        kern_ms = sum(k[0] * k[1] for k in km) / max(1, launches)
+        rinfo = km[last][2]
+        alg_bytes = int(rinfo.algorithmic_bytes)
+        # where a step's time goes when nothing overlaps: scan + pack / exchange, each waited for
+        nb = min(10, args.steps)
+        t_scan = t_pack = t_x = 0.0
+        for i in range(nb):
+            barrier()
+            c0 = time.perf_counter()
+            if L.ts_batch_scan(shard.batches[0], C.c_void_p(in_ptr), sptr) != 0:
+                raise RuntimeError(tel._ctx.error())
+            torch.cuda.synchronize()
+            c1 = time.perf_counter()
+            if L.ts_batch_pack_shard(shard.batches[0], C.c_void_p(shard.msgs[0].data_ptr()), shard.msgs[0].numel(), sptr) != 0:
+                raise RuntimeError(tel._ctx.error())
+            torch.cuda.synchronize()
+            c2 = time.perf_counter()
+            for w in exch.post(shard.msgs[0], 0):
+                w.wait()
+            torch.cuda.synchronize()
+            c3 = time.perf_counter()
+            t_scan += c1 - c0; t_pack += c2 - c1; t_x += c3 - c2
+        split = {"scan_ms": round(max_over_ranks(t_scan / nb) * 1e3, 4), "block_calling_and_pack_ms": round(max_over_ranks(t_pack / nb) * 1e3, 4),
+                 "exchange_ms": round(max_over_ranks(t_x / nb) * 1e3, 4), "steps": nb,
+                 "note": "serialised (each phase waited for on the host); the timed region overlaps the exchange of step i "
+                         "with the scan of step i+1"}
+        # the last timed step's messages, checked and merged on rank 0 (untimed)
+        action, factor, merged = exch.check(shard.msgs[last], last)
+        if action != exch.OK:
+            raise RuntimeError("a timed step's messages came out incomplete (action %d)" % action)
+        result_batch = None
+        n_windows, n_tiles = plan.n_windows, plan.n_tiles
+        n_matches = 0
+        sharded = None
+        if rank == 0:
+            rc_m, seg_out, seg_cnt = merged
+            n_matches = int(sum(int(seg_cnt[i].n_matches) for i in range(n)))
+            statuses = []
+            for m in exch.messages(shard.msgs[last], last):
+                st = K.ShardStatus()
+                L.ts_shard_peek(m.ctypes.data, m.nbytes, C.byref(st))
+                statuses.append(st)
+            sharded = {"seg_out": seg_out, "seg_cnt": seg_cnt}
+            extra_cfg = {"timed_region": "resident ASCII in HBM on %d ranks (consecutive tile ranges of ONE plan, + context tiles) -> scan + block calling "
+                                         "on every rank's own device + ONE message per rank (bit-packed window records, the match records a writer "
+                                         "reads, blocks) -> all messages in rank 0's HBM; no host synchronisation inside a step; the exchange of "
+                                         "step i overlaps the scan of step i+1" % world,
+                         "backend": backend + ("" if backend == "nccl" else " (rehearsal: ranks share a GPU, messages staged through the host)"),
+                         "bases_per_rank": [int(x.bases) for x in exch.infos],
+                         "exchange": {"bytes_over_links_per_step": exch.bytes_over_links,
+                                      "message_bytes_per_rank": [int(x.msg_bytes) for x in exch.infos],
+                                      "window_bytes": int(exch.infos[0].window_bytes), "visible_record_bytes": int(exch.infos[0].visible_bytes),
+                                      "visible_records_per_rank": [int(st.n_visible) for st in statuses],
+                                      "visible_capacity_per_rank": [int(st.visible_capacity) for st in statuses],
+                                      "blocks_per_rank": [int(st.n_blocks) for st in statuses],
+                                      "capacity_scale": scale, "context_tiles": int(exch.infos[0].context_tiles),
+                                      "round2_full_exchange_bytes_over_links": None},
+                         "step_split": split}
+        else:
+            extra_cfg = {}
+        bases_done = total
     else:
-        # ---------------------------------------------------------------- N > 1, strong scaling (configs[2])
+        # ---------------------------------------------------------------- N > 1, strong scaling, round 2's full exchange
         r = plan.ranges[rank]
+        buf = full[r.input_begin:r.input_end].clone()
+        if not keep_full:
+            del full
+            torch.cuda.empty_cache()
+        sharded = None
         slots = 2
         cap0 = total // 4 + 4096
         assembled = None
@@ -595,7 +763,16 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, opts, buf, offsets, lens)
-        if args.verify:
+        if args.verify and sharded is not None:
+            # shard results: a single-GPU scan of the whole assembly on rank 0 is (a) checked against the independent torch
+            # computation and (b) compared, segment by segment, with what the ranks' messages merged to
+            one = D.ShardPlan(tel, lens, world=1)
+            if L.ts_batch_scan(one.batch, C.c_void_p(full.data_ptr()), sptr) != 0 or L.ts_batch_sync(one.batch) != 0:
+                raise RuntimeError(tel._ctx.error())
+            out["verify"] = verify_full_size(L, one.batch, tel, full, offsets, lens, ui, dev)
+            out["verify"]["sharded_equals_single_gpu"] = compare_sharded_with_single_gpu(L, K, tel, one.batch, sharded, n, total <= 1_200_000_000)
+            one.close()
+        elif args.verify:
             out["verify"] = verify_full_size(L, result_batch, tel, full if strong else buf, offsets, lens, ui, dev)
             if strong:
                 # the assembled arrays against a single-GPU scan of the whole assembly, bit for bit
@@ -629,6 +806,8 @@ def run_scan(args, rank, local_rank, world, dev, backend):
     if strong:
         if result_batch:
             L.ts_batch_destroy(result_batch)
+        if sharded is not None:
+            D.free_segments(plan, sharded["seg_out"])
         shard.close()
     barrier()
 

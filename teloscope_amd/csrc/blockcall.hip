@@ -169,10 +169,22 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
         if (cnt == 0u) continue;
         const u64 off = V.tile_off[t];
         const u64 tile_rel = V.tiles[t].in_off - V.base;
-        for (uint32_t b0 = 0; b0 < cnt && !stop; b0 += 64u) {
+        // four batches of 64 records are requested together (the walk is one chain of dependent steps: what it waits
+        // for is memory latency, and a telomere is thirty batches long)
+        for (uint32_t b4 = 0; b4 < cnt && !stop; b4 += 256u) {
+          uint32_t recs[4];
+#pragma unroll
+          for (uint32_t q = 0; q < 4u; ++q) {
+              const uint32_t bq = b4 + 64u * q;
+              const uint32_t idx = from_start ? bq + lane : cnt - 1u - bq - lane;      // walk order
+              recs[q] = bq + lane < cnt ? V.matches[off + idx] : 0u;
+          }
+#pragma unroll
+          for (uint32_t q = 0; q < 4u; ++q) {
+            const uint32_t b0 = b4 + 64u * q;
+            if (b0 >= cnt || stop) break;
             const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
-            const uint32_t idx = from_start ? b0 + lane : cnt - 1u - b0 - lane;        // walk order
-            const uint32_t rec = lane < nb ? V.matches[off + idx] : 0u;
+            const uint32_t rec = recs[q];
             const bool sel = lane < nb && (((rec >> 1) & 1u) != 0u) == from_start;      // forward list from the start, reverse from the end
             u64 rem = __ballot(sel);
             if (rem == 0ull) continue;
@@ -210,6 +222,7 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
                 if (from_start) ch.end = ch.prev + Q.k; else ch.start = ch.prev;
                 rem &= ~run;
             }
+          }
         }
     }
     // A clipped view that the walk used up without meeting a chain head outside the terminal zone: the records the
@@ -228,13 +241,8 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
 
 // the shard's view of segment S (TsShardSegIn): its scanned tiles, clipped where the segment continues on a neighbour
 __device__ __forceinline__ SegView seg_view(const TsBlockCallParams &Q, const TsShardSegIn &S) {
-    SegView V{Q.tiles, Q.tile_off, Q.tile_stats, Q.matches, S.t0, S.t1, S.in_off,
-              !(S.flags & TS_SEG_F_HAS_START), !(S.flags & TS_SEG_F_HAS_END), 0, S.len};
-    if (S.t1 > S.t0) {
-        V.lo_rel = Q.tiles[S.t0].in_off - S.in_off;
-        V.hi_rel = Q.tiles[S.t1 - 1u].in_off - S.in_off + Q.tiles[S.t1 - 1u].own_len;
-    }
-    return V;
+    return SegView{Q.tiles, Q.tile_off, Q.tile_stats, Q.matches, S.t0, S.t1, S.in_off,
+                   !(S.flags & TS_SEG_F_HAS_START), !(S.flags & TS_SEG_F_HAS_END), S.lo_rel, S.hi_rel};
 }
 
 __global__ void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t nseg, u64 *bounds,
@@ -248,15 +256,28 @@ __global__ void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn
     __shared__ uint32_t walk_flags;
     const uint32_t si = blockIdx.x;
     if (si >= nseg) return;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // (readfirstlane: told that the wave index is the same in all lanes, the compiler keeps the walk's state machine — ballots,
+    // chain state, the branch on the wave — in scalar registers instead of predicated vector code)
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const TsShardSegIn S = segs[si];
     const SegView V = seg_view(Q, S);
     const u64 n = S.len;
     u64 total = 0, nfwd = 0, own = 0, own_can = 0, own_fwd = 0;
-    for (uint32_t t = V.t0 + threadIdx.x; t < V.t1; t += blockDim.x) {
-        const uint4 st = *(const uint4 *)&V.tile_stats[4ull * t];
-        total += st.x; nfwd += st.z;
-        if (t >= S.o0 && t < S.o1) { own += st.x; own_can += st.y; own_fwd += st.z; }
+    // (eight directory entries per thread in flight: a 250 Mb contig has ~22 k tiles, and one load per trip of the loop
+    // made this sum the longest part of the kernel)
+    for (uint32_t t8 = V.t0 + threadIdx.x; t8 < V.t1; t8 += 8u * blockDim.x) {
+        uint4 st[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) {
+            const uint32_t t = t8 + q * blockDim.x;
+            st[q] = t < V.t1 ? *(const uint4 *)&V.tile_stats[4ull * t] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) {
+            const uint32_t t = t8 + q * blockDim.x;
+            total += st[q].x; nfwd += st[q].z;
+            if (t >= S.o0 && t < S.o1) { own += st[q].x; own_can += st[q].y; own_fwd += st[q].z; }
+        }
     }
     part[0][threadIdx.x] = total; part[1][threadIdx.x] = nfwd;
     part[2][threadIdx.x] = own; part[3][threadIdx.x] = own_can; part[4][threadIdx.x] = own_fwd;
@@ -310,143 +331,269 @@ __device__ char its_label(uint32_t fwd_count, uint32_t counts) {
     return 'b';
 }
 
-// A segment view that serves one tile's records from LDS (they were loaded with one coalesced sweep)
-// and everything else from global memory: chains rarely leave the tile they start in.
-struct TileView {
-    SegView V;
-    uint32_t tile, cnt;                      // the cached tile and its record count
-    u64 tile_rel;                            // segment-relative position of the tile's first base
-    const uint32_t *cache;                   // LDS copy of the tile's records (nullptr: not cached)
-
-    __device__ uint32_t count(uint32_t t) const { return t == tile ? cnt : V.count(t); }
-    __device__ uint32_t rec(Cursor c) const { return (cache && c.t == tile) ? cache[c.i] : V.rec(c); }
-    __device__ u64 pos(Cursor c, uint32_t r) const { return c.t == tile ? tile_rel + (r >> 2) : V.pos(c, r); }
-    __device__ bool next(Cursor &c) const {
-        if (c.i + 1u < count(c.t)) { ++c.i; return true; }
-        for (uint32_t t = c.t + 1u; t < V.t1; ++t)
-            if (V.count(t)) { c.t = t; c.i = 0; return true; }
-        return false;
-    }
-    __device__ bool prev(Cursor &c) const {
-        if (c.i > 0u) { --c.i; return true; }
-        for (uint32_t t = c.t; t > V.t0; --t)
-            if (V.count(t - 1u)) { c.t = t - 1u; c.i = V.count(t - 1u) - 1u; return true; }
-        return false;
-    }
+// One open chain of the interstitial search, wave-uniform (scalar registers): covered bases are counts x k.
+struct OpenChain {
+    bool open;
+    u64 start, prev;
+    uint32_t counts, fwd, canon;
 };
 
-#define TS_ITS_CAND  256                     // canonical candidates of a tile kept in LDS (~2 % of its records)
-#define TS_ITS_CACHE 1024                    // records of a tile kept in LDS (a tile of 13.5 kb holds ~400 at 3 % density)
+// A closed chain -> a block, if it passes the reference's filters (src/teloscope.cpp:206-233): lane 0 writes it.
+__device__ __forceinline__ void its_close(const TsBlockCallParams &Q, const OpenChain &c, const TsShardSegIn &S, uint32_t lane) {
+    const uint32_t blen = (uint32_t)(c.prev + Q.k - c.start);
+    if (c.canon < 4u || blen < Q.its_min_len) return;
+    const char lab = its_label(c.fwd, c.counts);
+    if (lab == 'b' && c.fwd < 2u && (c.counts - c.fwd) < 2u) return;
+    if (lane != 0u) return;
+    TsDevBlock b;
+    b.start = c.start; b.block_len = blen; b.block_counts = c.counts;
+    b.forward_count = c.fwd; b.reverse_count = c.counts - c.fwd; b.canonical_count = c.canon;
+    b.non_canonical_count = c.counts - c.canon; b.total_covered = c.counts * Q.k; b.fwd_covered = c.fwd * Q.k;
+    b.can_covered = c.canon * Q.k; b.has_valid_or = 1; b.is_longest = 0; b.block_label = lab; b.reserved = 0;
+    emit_block(Q, b, S.seg, 2u, 0u, S.abs_pos);
+}
 
-__global__ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base,
-                                       const u64 *bounds, uint32_t ntiles, TsShardSeg *seg_out) {
-    // one wave per tile, lanes over its records.  A block belongs to the tile its chain STARTS in: a shard runs
-    // this over every tile it scanned (a chain that starts in an owned tile may have its first canonical match, the
-    // one that walks it, in the context) and emits the blocks that start in an owned tile.
-    __shared__ uint32_t cache_all[4][TS_ITS_CACHE];
-    __shared__ uint16_t cand_all[4][TS_ITS_CAND];
-    const uint32_t wave = threadIdx.x >> 6;
+// The value of the lane below (lane 0: 0) by DPP wave_shr:1.  The empty asm keeps it a v_mov_b32_dpp: folded into the
+// subtraction that follows (v_subrev_u32_dpp v, x, x wave_shr:1, what the DPP combiner makes of it) it came back wrong on gfx950.
+__device__ __forceinline__ uint32_t lane_below(uint32_t v) {
+    uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
+__device__ __forceinline__ u64 low_bits(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
+
+// getInterstitialBlocks (src/teloscope.cpp:179-256) over the packed match stream, and — for a shard — the visible
+// match records of the tile on the way (the same records are in registers).
+//
+// One wave per tile, 64 records per step, no LDS, no per-record loop: a record opens a chain iff it is the first in
+// [fwdBoundary, revBoundary) or lies more than -k behind its predecessor; a ballot of those heads cuts the 64 records
+// into chains, and only when the step holds the four canonical matches a block needs does every head lane look at its
+// own chain (popcounts of the ballots under its lane range).  Everything else is scalar: the chain that is open at the
+// end of a step is carried on in wave-uniform registers.  A block belongs to the tile its chain STARTS in: records
+// ahead of a tile's first head belong to a chain of an earlier tile and are skipped; the chain that is open when the
+// tile's records end is followed through the tiles behind until a head closes it.
+//
+// Measured on the 91.5 M records of configs[1] (profiles/r03/its_kernel_variants.txt): the LDS walker of rounds 1-2
+// 0.76 ms; this kernel 0.44 ms; a chunk of eight tiles per wave as one software-pipelined stream 0.70 ms (129 VGPRs);
+// one LANE per tile (a branch-free state machine per record, 128-byte bursts) 0.84 ms, 0.35 of it the loads alone:
+// sixty-four lanes reading sixty-four streams fetch every cache line many times over.
+__global__ __launch_bounds__(256)
+void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base,
+                            const u64 *bounds, uint32_t ntiles, TsShardSeg *seg_out, const TsVisibleOut W) {
+    // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all lanes of a wave; told so, it keeps the
+    // tile's directory entries, the bounds and every ballot in scalar registers and branches instead of predicating)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wave;
     if (tile >= ntiles) return;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t si = Q.tiles[tile].seg - seg_base;
-    const u64 fb = bounds[2ull * si], rb = bounds[2ull * si + 1];
-    if (rb == 0 || fb >= rb) return;
-    if (Q.tile_stats[4u * tile + 1u] == 0u) return;       // no canonical match in the tile: nothing can lead a block
+    // A wave's time here is a chain of memory round trips: everything that does not depend on something else is
+    // requested together — first the directory entries of the tile and its two neighbours, then the segment's entry, the
+    // visible offsets, the record ahead of the tile, the tile's first eight batches and the first batch of the tile behind.
+    const TsTile T = Q.tiles[tile];
+    const uint32_t cnt = Q.tile_stats[4u * tile];
+    const u64 off = Q.tile_off[tile];
+    const uint32_t tp = tile ? tile - 1u : 0u;
+    const u64 prev_in_off = Q.tiles[tp].in_off;
+    const uint32_t prev_cnt = Q.tile_stats[4u * tp];
+    const u64 prev_off = Q.tile_off[tp];
+    const uint32_t tn = tile + 1u < ntiles ? tile + 1u : tile;    // the tile behind: four in five chains run on into it
+    const u64 next_in_off = Q.tiles[tn].in_off;
+    const uint32_t next_cnt = Q.tile_stats[4u * tn];
+    const u64 next_off = Q.tile_off[tn];
+    const uint32_t si = T.seg - seg_base;
     const TsShardSegIn S = segs[si];
-    TileView V{seg_view(Q, S), tile, 0, 0, nullptr};
-    V.cnt = V.V.count(tile);
-    V.tile_rel = Q.tiles[tile].in_off - V.V.base;
-    const uint32_t cnt = V.cnt;
-    if (cnt <= TS_ITS_CACHE) {
-        const uint32_t *src = Q.matches + Q.tile_off[tile];
-        for (uint32_t i = lane; i < cnt; i += 64u) cache_all[wave][i] = src[i];
-        V.cache = cache_all[wave];
-        __builtin_amdgcn_wave_barrier();
+    if (tile < S.o0 || tile >= S.o1) return;              // a context tile: its chains and its records are its owner's
+    const u64 fb = bounds[2ull * si], rb = bounds[2ull * si + 1];
+    const bool its_on = !(rb == 0 || fb >= rb);
+    // visible records of this tile (a shard's message): where they go, and whether there are any
+    u64 vis_at = 0;
+    bool vis_on = false;
+    if (W.off) {
+        const uint32_t i = tile - W.own0;
+        vis_at = W.off[i];
+        vis_on = W.off[i + 1] > vis_at && W.off[W.own1 - W.own0] <= W.capacity;
     }
-    // Only canonical matches inside the interstitial range can lead a block, and they are ~2 % of the records:
-    // their indices are compacted first (ballot + rank) so that the chain walks below run on dense lanes
-    // instead of one or two lanes per 64 records.
-    uint32_t ncand = 0;
-    bool compacted = cnt <= TS_ITS_CACHE;
-    if (compacted) {
-        for (uint32_t i0 = 0; i0 < cnt; i0 += 64u) {
-            const uint32_t i = i0 + lane;
-            bool cand = false;
-            if (i < cnt) {
-                const uint32_t r = V.cache[i];
-                const u64 p = V.tile_rel + (r >> 2);
-                cand = (r & 1u) && p >= fb && p < rb;
-            }
-            const u64 m = __ballot(cand);
-            const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (cand && slot < TS_ITS_CAND) cand_all[wave][slot] = (uint16_t)i;
-            ncand += (uint32_t)__popcll(m);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (ncand > TS_ITS_CAND) compacted = false;        // a tile full of canonical repeats: every record is tried
-    }
-    const uint32_t nwork = compacted ? ncand : cnt;
+    if ((!its_on && !vis_on) || cnt == 0u) return;
+    const SegView V = seg_view(Q, S);
+    const u64 tile_rel = T.in_off - S.in_off;
+    const uint32_t *src = Q.matches + off;
+    const u64 z_lo = W.terminal_limit, z_hi = S.len > W.terminal_limit ? S.len - W.terminal_limit : 0ull;
+    constexpr uint32_t kGroup = 8;                         // batches of 64 records requested together
+    uint32_t recs[kGroup];
+#pragma unroll
+    for (uint32_t q = 0; q < kGroup; ++q) recs[q] = 64u * q + lane < cnt ? src[64u * q + lane] : 0u;
+    const uint32_t next_rec = (tn != tile && lane < next_cnt) ? Q.matches[next_off + lane] : 0u;
+
+    // the record ahead of the tile's first one (head test of that record)
+    bool has_last = false;
+    u64 last_pos = 0;
     bool ooc = false;
-    for (uint32_t w = lane; w < nwork; w += 64u) {
-        const uint32_t i = compacted ? (uint32_t)cand_all[wave][w] : w;
-        Cursor c{tile, i};
-        const uint32_t r = V.rec(c);
-        if (!(r & 1u)) continue;                           // only canonical matches can lead a block
-        const u64 p = V.pos(c, r);
-        if (p < fb || p >= rb) continue;
-        // walk left: not the leader if an earlier canonical match is in the same chain
-        Cursor s = c; u64 sp = p; bool leader = true;
-        for (Cursor q = c;;) {
-            if (!V.prev(q)) {
-                // The view's left edge, with the segment going on behind it: the chain's start is not known here.  For a
-                // candidate in a context tile that is its owner's business (the left neighbour sees the same records and
-                // more); for one in an owned tile the chain spans the whole left context — reported.
-                if (V.V.open_l && sp <= V.V.lo_rel + Q.max_match_dist && V.V.lo_rel > fb) {
-                    leader = false;
-                    if (tile >= S.o0 && tile < S.o1) ooc = true;
+    if (its_on) {
+        bool found = false;
+        if (tile > V.t0 && prev_cnt) {                     // the usual case: the tile before holds it
+            const uint32_t r = Q.matches[prev_off + prev_cnt - 1u];
+            last_pos = prev_in_off - S.in_off + (r >> 2);
+            found = true;
+        } else {
+            for (uint32_t t = tile; t > V.t0; --t) {
+                const uint32_t c = Q.tile_stats[4u * (t - 1u)];
+                if (c) {
+                    const uint32_t r = Q.matches[Q.tile_off[t - 1u] + c - 1u];
+                    last_pos = Q.tiles[t - 1u].in_off - S.in_off + (r >> 2);
+                    found = true;
+                    break;
                 }
-                break;
             }
-            const uint32_t rq = V.rec(q);
-            const u64 pq = V.pos(q, rq);
-            if (pq < fb || sp - pq > Q.max_match_dist) break;
-            if (rq & 1u) { leader = false; break; }
-            s = q; sp = pq;
         }
-        if (!leader) continue;
-        if (s.t < S.o0 || s.t >= S.o1) continue;          // the chain starts in a context tile: its owner emits the block
-        // s is the chain's first match: walk the whole chain
-        Chain ch;
-        ch.begin(sp, V.rec(s), Q.k);
-        bool ended = false;
-        for (Cursor q = s; V.next(q);) {
-            const uint32_t rq = V.rec(q);
-            const u64 pq = V.pos(q, rq);
-            if (pq >= rb || pq - ch.prev > Q.max_match_dist) { ended = true; break; }
-            ch.end = pq + Q.k;
-            ch.add(pq, rq, Q.k);
-        }
-        if (!ended && V.V.open_r && ch.prev + Q.max_match_dist >= V.V.hi_rel && V.V.hi_rel < rb) { ooc = true; continue; }
-        const uint32_t blen = (uint32_t)(ch.end - ch.start);
-        const char lab = its_label(ch.fwd, ch.counts);
-        if (blen >= Q.its_min_len && ch.canon >= 4u && !(lab == 'b' && ch.fwd < 2u && (ch.counts - ch.fwd) < 2u)) {
-            TsDevBlock b; ch.to_block(b);
-            b.block_label = lab;
-            emit_block(Q, b, S.seg, 2u, 0u, S.abs_pos);
+        has_last = found && last_pos >= fb;                // (a record ahead of the search range does not chain)
+        if (!found && V.open_l && V.lo_rel > fb) {
+            // nothing in the whole left context: a record further left is too far to chain if the context is wider than -k
+            // (it is, shard.cpp sizes it so) — unless this tile's first record sits right at the view's edge
+            const u64 p0 = tile_rel + ((uint32_t)__builtin_amdgcn_readfirstlane((int)recs[0]) >> 2);
+            if (p0 <= V.lo_rel + Q.max_match_dist) ooc = true;
         }
     }
-    if (seg_out && __ballot(ooc) != 0ull && lane == 0) atomicOr(&seg_out[si].flags, TS_SEG_F_CONTEXT);
+    OpenChain ch{false, 0, 0, 0, 0, 0};
+    bool finished = false;                                 // the search range ended inside this tile
+    uint32_t vis_done = 0;
+    // Everything a record is compared with, relative to the tile and in 32 bits (a tile's positions are < 2^16); and what
+    // holds for the whole tile is decided once: nearly every tile lies wholly inside the search range and wholly outside
+    // the terminal zone, where "in range" is "valid" and "visible" is "canonical".
+    const u64 tile_end = tile_rel + T.own_len;
+    auto rel32 = [&](u64 x) -> uint32_t { return x <= tile_rel ? 0u : (x - tile_rel > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(x - tile_rel)); };
+    const uint32_t fb32 = rel32(fb), rb32 = rel32(rb);
+    const bool all_in = fb <= tile_rel && rb >= tile_end;
+    const bool vis_all = tile_end - 1 <= z_lo || tile_rel >= z_hi, vis_canon = tile_rel > z_lo && tile_end <= z_hi;
+    const uint32_t zlo32 = z_lo < tile_rel ? 0u : rel32(z_lo), zhi32 = rel32(z_hi);
+    const bool zlo_none = z_lo < tile_rel;                 // no position of the tile is <= z_lo
+    auto batch = [&](uint32_t b0, uint32_t r) {
+        const uint32_t nvalid = cnt - b0 < 64u ? cnt - b0 : 64u;
+        const u64 VALID = low_bits(nvalid);
+        const uint32_t p32 = r >> 2;
+        const u64 CAN = __ballot((r & 1u) != 0u) & VALID;
+        if (vis_on) {
+            u64 m;
+            if (vis_all) m = VALID;
+            else if (vis_canon) m = CAN;
+            else m = __ballot((r & 1u) || (!zlo_none && p32 <= zlo32) || p32 >= zhi32) & VALID;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if ((m >> lane) & 1ull) {
+                if (W.rec_bytes == 2u) ((uint16_t *)W.dst)[vis_at + vis_done + rank] = (uint16_t)r;
+                else ((uint32_t *)W.dst)[vis_at + vis_done + rank] = r;
+            }
+            vis_done += (uint32_t)__popcll(m);
+        }
+        if (!its_on || finished) return;
+        const u64 R = all_in ? VALID : __ballot(p32 >= fb32 && p32 < rb32) & VALID;
+        const bool past = all_in ? false : (__ballot(p32 >= rb32) & VALID) != 0ull;   // records at or behind revBoundary: the search ends here
+        if (R != 0ull) {
+            // a record opens a chain iff its predecessor is out of range or more than -k ahead of it: the lane below, or for
+            // lane 0 the last record of the batch / tile before
+            const uint32_t below = lane_below(p32);
+            const u64 G = __ballot(p32 - below > Q.max_match_dist);
+            u64 H = R & (~(R << 1) | G);
+            if ((R & 1ull) && has_last && tile_rel + (uint32_t)__builtin_amdgcn_readfirstlane((int)p32) - last_pos <= Q.max_match_dist) H &= ~1ull;
+            const u64 Cn = CAN & R, F = __ballot((r & 2u) != 0u) & R;
+            const uint32_t first_head = H ? (uint32_t)__builtin_ctzll(H) : 64u;
+            // 1. the chain carried into this batch takes the records ahead of the first head
+            const u64 pre = R & low_bits(first_head);
+            if (ch.open && pre) {
+                ch.counts += (uint32_t)__popcll(pre); ch.fwd += (uint32_t)__popcll(pre & F); ch.canon += (uint32_t)__popcll(pre & Cn);
+                ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(pre));
+            }
+            if (ch.open && H != 0ull) { its_close(Q, ch, S, lane); ch.open = false; }
+            // 2. the chains that start in this batch
+            if (H != 0ull) {
+                const uint32_t top_head = 63u - (uint32_t)__builtin_clzll(H);
+                const u64 tail = R & ~low_bits(top_head);
+                // a block needs four canonical matches: only then does every head lane look at its own chain — its lane
+                // range runs to the next head — and the ones that are complete and qualify are written by their lanes
+                if (__popcll(Cn & ~(past ? 0ull : tail)) >= 4) {
+                    const u64 above = lane < 63u ? H >> (lane + 1u) : 0ull;
+                    const uint32_t next = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 64u;   // the next head's lane
+                    const u64 mine = R & low_bits(next) & ~low_bits(lane);
+                    const uint32_t ncan = (uint32_t)__popcll(mine & Cn);
+                    const uint32_t last_lane = mine ? 63u - (uint32_t)__builtin_clzll(mine) : lane;
+                    const uint32_t p_last = (uint32_t)__shfl((int)p32, (int)last_lane);
+                    const bool complete = lane != top_head || past;      // the batch's last chain may go on in the next batch
+                    if (((H >> lane) & 1ull) && complete && ncan >= 4u) {
+                        OpenChain c{true, tile_rel + p32, tile_rel + p_last, (uint32_t)__popcll(mine), (uint32_t)__popcll(mine & F), ncan};
+                        its_close(Q, c, S, 0u);                           // (this lane writes it)
+                    }
+                }
+                if (!past) {                                              // the last chain stays open
+                    ch.open = true;
+                    ch.start = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)top_head);
+                    ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(tail));
+                    ch.counts = (uint32_t)__popcll(tail); ch.fwd = (uint32_t)__popcll(tail & F); ch.canon = (uint32_t)__popcll(tail & Cn);
+                }
+            }
+            has_last = true;
+            last_pos = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(R));
+        }
+        if (past) {
+            if (ch.open) { its_close(Q, ch, S, lane); ch.open = false; }
+            finished = true;
+        }
+    };
+#pragma unroll
+    for (uint32_t q = 0; q < kGroup; ++q)
+        if (64u * q < cnt) batch(64u * q, recs[q]);
+    for (uint32_t b0 = 64u * kGroup; b0 < cnt; b0 += 64u)               // a dense tile: the rest, batch by batch
+        batch(b0, b0 + lane < cnt ? src[b0 + lane] : 0u);
+    // the chain that is still open belongs to this tile: follow it through the tiles behind until a head closes it
+    if (its_on && ch.open && !finished) {
+        bool closed = false;
+        auto follow = [&](u64 rel2, uint32_t c2, uint32_t b0, uint32_t r) {
+            const uint32_t nvalid = c2 - b0 < 64u ? c2 - b0 : 64u;
+            const u64 VALID = low_bits(nvalid);
+            const uint32_t p32 = r >> 2;
+            const uint32_t rb2 = rb <= rel2 ? 0u : (rb - rel2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(rb - rel2));
+            const u64 R = __ballot(p32 < rb2) & VALID;                   // (p >= fb: behind a record that was)
+            const bool past = R != VALID;
+            if (R != 0ull) {
+                const uint32_t below = lane_below(p32);
+                u64 H = R & (__ballot(p32 - below > Q.max_match_dist) | 1ull);
+                if ((R & 1ull) && rel2 + (uint32_t)__builtin_amdgcn_readfirstlane((int)p32) - last_pos <= Q.max_match_dist) H &= ~1ull;
+                const u64 pre = R & low_bits(H ? (uint32_t)__builtin_ctzll(H) : 64u);
+                if (pre) {
+                    const u64 Cn = __ballot((r & 1u) != 0u), F = __ballot((r & 2u) != 0u);
+                    ch.counts += (uint32_t)__popcll(pre); ch.fwd += (uint32_t)__popcll(pre & F); ch.canon += (uint32_t)__popcll(pre & Cn);
+                    ch.prev = rel2 + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(pre));
+                }
+                if (H != 0ull) closed = true;
+                last_pos = rel2 + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(R));
+            }
+            if (past) closed = true;
+        };
+        for (uint32_t t = tile + 1u; t < V.t1 && !closed; ++t) {
+            const bool pre_fetched = t == tn;
+            const uint32_t c2 = pre_fetched ? next_cnt : Q.tile_stats[4u * t];
+            if (c2 == 0u) continue;
+            const u64 rel2 = (pre_fetched ? next_in_off : Q.tiles[t].in_off) - S.in_off;
+            const uint32_t *src2 = Q.matches + (pre_fetched ? next_off : Q.tile_off[t]);
+            for (uint32_t b0 = 0; b0 < c2 && !closed; b0 += 64u)
+                follow(rel2, c2, b0, (pre_fetched && b0 == 0u) ? next_rec : (b0 + lane < c2 ? src2[b0 + lane] : 0u));
+        }
+        // the view ended first: the segment's end — or a neighbour's tiles, where the chain may go on
+        if (!closed && V.open_r && ch.prev + Q.max_match_dist >= V.hi_rel && V.hi_rel < rb) ooc = true;
+        else its_close(Q, ch, S, lane);
+    }
+    if (seg_out && ooc && lane == 0) atomicOr(&seg_out[si].flags, TS_SEG_F_CONTEXT);
 }
 
 }  // namespace
 
 int ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
-                           uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its, void *stream) {
+                           uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its,
+                           const TsVisibleOut *vis, void *stream) {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(256), 0, (hipStream_t)stream, *Q, segs, nseg, bounds, seg_out);
-    if (with_its && ntiles)
+    TsVisibleOut W{};
+    if (vis) W = *vis;
+    if ((with_its || W.off) && ntiles)
         hipLaunchKernelGGL(ts_interstitial_blocks, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *Q,
-                           segs, seg_base, (const u64 *)bounds, ntiles, seg_out);
+                           segs, seg_base, (const u64 *)bounds, ntiles, seg_out, W);
     return (int)hipGetLastError();
 }

@@ -1175,6 +1175,7 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
         S.t0 = S.o0 = b->segs[i].first_tile;
         S.t1 = S.o1 = b->segs[i].first_tile + b->segs[i].n_tiles;
         S.flags = TS_SEG_F_HAS_START | TS_SEG_F_HAS_END;
+        S.lo_rel = 0; S.hi_rel = b->segs[i].len;
         S.seg = (uint32_t)i;
     }
     (void)nt;
@@ -1201,7 +1202,7 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
         Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;
         Q.k = c->k; Q.its_min_len = (uint32_t)(uint16_t)(2 * c->bp.first_pattern_len);
         if (ts_k_launch_block_call(&Q, (const TsShardSegIn *)dt, (uint32_t)ns, 0u, (uint32_t)nt, (unsigned long long *)(dt + off_bounds),
-                                   nullptr, b->tips ? 0 : 1, st) != 0) return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
+                                   nullptr, b->tips ? 0 : 1, nullptr, st) != 0) return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
         uint32_t nb = 0;
         HIP_TRY(c, hipMemcpyAsync(&nb, dt + off_count, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));

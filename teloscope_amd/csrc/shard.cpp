@@ -235,6 +235,11 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
             const uint64_t t0 = std::min(std::max(f, r.ext_lo), r.ext_hi), t1 = std::max(std::min(e, r.ext_hi), t0);
             const uint64_t o0 = std::min(std::max(f, r.own_lo), r.own_hi), o1 = std::max(std::min(e, r.own_hi), o0);
             S.t0 = (uint32_t)(t0 - r.ext_lo); S.t1 = (uint32_t)(t1 - r.ext_lo);
+            S.lo_rel = 0; S.hi_rel = sp.len;
+            if (t1 > t0) {
+                S.lo_rel = b->tiles[t0].in_off - sp.in_off;
+                S.hi_rel = b->tiles[t1 - 1].in_off - sp.in_off + b->tiles[t1 - 1].own_len;
+            }
             S.o0 = (uint32_t)(o0 - r.ext_lo); S.o1 = (uint32_t)(o1 - r.ext_lo);
             S.flags = 0;
             if (sp.n_tiles == 0 || (f >= r.own_lo && f < r.own_hi)) S.flags |= TS_SEG_F_HAS_START;
@@ -261,9 +266,6 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     Q.min_block_len = P.min_block_len; Q.max_block_dist = P.max_block_dist;
     Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;
     Q.k = c->k; Q.its_min_len = (uint32_t)(uint16_t)(2 * c->bp.first_pattern_len);
-    if (ts_k_launch_block_call(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
-                               (unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs), b->tips ? 0 : 1, stream) != 0)
-        return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
     TsShardPackParams K{};
     K.tiles = Q.tiles; K.tile_off = Q.tile_off; K.tile_stats = Q.tile_stats; K.matches = Q.matches;
     K.windows = b->windows_ptr();
@@ -289,6 +291,14 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     H.seg_begin = r.seg_begin; H.n_segs = ns;
     H.visible_bytes = L.visible_bytes; H.visible_capacity = L.visible_capacity; H.block_capacity = L.block_capacity;
     H.window_bytes = L.window_bytes; H.n_windows = L.n_windows; H.msg_bytes = L.bytes;
+    // visible records per owned tile and their places; then the terminal walks and the interstitial pass, which also
+    // writes the visible records (it reads the whole stream anyway); then the window records and the header
+    TsVisibleOut vis{};
+    if (ts_k_launch_shard_count(&K, &H, b->d_shard_tmp.p, b->tips ? 0 : 1, &vis, stream) != 0)
+        return c->fail(TS_ERR_HIP, "shard count kernel launch failed");
+    if (ts_k_launch_block_call(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
+                               (unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs), b->tips ? 0 : 1, &vis, stream) != 0)
+        return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
     if (ts_k_launch_shard_pack(&K, &H, b->d_shard_tmp.p, b->tips ? 0 : 1, stream) != 0)
         return c->fail(TS_ERR_HIP, "shard pack kernel launch failed");
     return TS_OK;

@@ -40,25 +40,38 @@ __device__ __forceinline__ uint32_t seg_of_tile(const TsShardPackParams &P, uint
     return P.tiles[t].seg - base;
 }
 
-// pass 1: visible records per owned tile -> vis_stats[4 * i] (the stride the tile-offset scan of exchange.hip reads)
-// and the message's u16 per-tile section.  A tile outside the terminal zone holds exactly its canonical records (the
-// scan counted them: tile_stats[1]); one inside it holds all its records; only the few tiles the zone's edge cuts are read.
+// Visible records per owned tile -> vis_stats[4 * i] (the stride the tile-offset scan of exchange.hip reads) and the
+// message's u16 per-tile section.  A tile outside the terminal zone holds exactly its canonical records (the scan
+// counted them: tile_stats[1]); one inside it holds all its records; only the few tiles the zone's edge cuts are read.
+// One thread per tile.  (The records themselves are written by the interstitial pass, blockcall.hip, which reads the
+// whole stream anyway.)
 __global__ __launch_bounds__(256)
 void ts_shard_visible_count(const TsShardPackParams P, uint32_t *vis_stats) {
-    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t nown = P.own1 - P.own0;
-    if (i >= nown) return;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t = P.own0 + i;
-    const TsTile T = P.tiles[t];
-    const TsShardSegIn S = P.segs[seg_of_tile(P, t)];
-    const Zone z = zone_of(S.len, P.terminal_limit);
-    const u64 rel0 = T.in_off - S.in_off, rel1 = rel0 + T.own_len;        // the tile's records lie in [rel0, rel1)
-    const uint32_t cnt = P.tile_stats[4ull * t];
-    uint32_t vis;
-    if (rel1 - 1 <= z.lo_end || rel0 >= z.hi_begin) vis = cnt;                                  // wholly terminal
-    else if (rel0 > z.lo_end && rel1 <= z.hi_begin) vis = P.tile_stats[4ull * t + 1];         // wholly interstitial
-    else {
+    bool edge = false;
+    uint32_t vis = 0;
+    if (i < nown) {
+        const uint32_t t = P.own0 + i;
+        const TsTile T = P.tiles[t];
+        const uint4 st = *(const uint4 *)&P.tile_stats[4ull * t];
+        const TsShardSegIn S = P.segs[seg_of_tile(P, t)];
+        const Zone z = zone_of(S.len, P.terminal_limit);
+        const u64 rel0 = T.in_off - S.in_off, rel1 = rel0 + T.own_len;    // the tile's records lie in [rel0, rel1)
+        if (rel1 - 1 <= z.lo_end || rel0 >= z.hi_begin) vis = st.x;                           // wholly terminal
+        else if (rel0 > z.lo_end && rel1 <= z.hi_begin) vis = st.y;                          // wholly interstitial
+        else edge = st.x != 0u;
+    }
+    // the tiles the zone's edge cuts (two per long segment): the whole wave counts each of them
+    for (u64 todo = __ballot(edge); todo; todo &= todo - 1ull) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t t = P.own0 + (i - lane + l);
+        const TsTile T = P.tiles[t];
+        const TsShardSegIn S = P.segs[seg_of_tile(P, t)];
+        const Zone z = zone_of(S.len, P.terminal_limit);
+        const u64 rel0 = T.in_off - S.in_off;
+        const uint32_t cnt = P.tile_stats[4ull * t];
         const uint32_t *src = P.matches + P.tile_off[t];
         uint32_t n = 0;
         for (uint32_t j = lane; j < cnt; j += 64u) {
@@ -67,43 +80,11 @@ void ts_shard_visible_count(const TsShardPackParams P, uint32_t *vis_stats) {
             n += ((r & 1u) || rel <= z.lo_end || rel >= z.hi_begin) ? 1u : 0u;
         }
         for (int o = 32; o >= 1; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
-        vis = n;
+        if (lane == l) vis = n;
     }
-    if (lane == 0) {
+    if (i < nown) {
         vis_stats[4ull * i] = vis;
         ((uint16_t *)(P.msg + P.off_tilevis))[i] = (uint16_t)vis;
-    }
-}
-
-// pass 2 (after the prefix sum): the visible records of every owned tile, in order, to their place in the message
-template <typename REC>
-__global__ __launch_bounds__(256)
-void ts_shard_visible_write(const TsShardPackParams P, const u64 *vis_off, u64 capacity) {
-    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t nown = P.own1 - P.own0;
-    if (i >= nown) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const u64 at0 = vis_off[i];
-    const u64 want = vis_off[i + 1] - at0;
-    if (want == 0ull || vis_off[nown] > capacity) return;          // (overflow: nothing is written, the header says so)
-    const uint32_t t = P.own0 + i;
-    const TsTile T = P.tiles[t];
-    const TsShardSegIn S = P.segs[seg_of_tile(P, t)];
-    const Zone z = zone_of(S.len, P.terminal_limit);
-    const u64 rel0 = T.in_off - S.in_off;
-    const uint32_t cnt = P.tile_stats[4ull * t];
-    const uint32_t *src = P.matches + P.tile_off[t];
-    REC *dst = (REC *)(P.msg + P.off_visible) + at0;
-    uint32_t done = 0;
-    for (uint32_t j0 = 0; j0 < cnt; j0 += 64u) {
-        const uint32_t j = j0 + lane;
-        const uint32_t r = j < cnt ? src[j] : 0u;
-        const u64 rel = rel0 + (r >> 2);
-        const bool v = j < cnt && ((r & 1u) || rel <= z.lo_end || rel >= z.hi_begin);
-        const u64 m = __ballot(v);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (v) dst[done + rank] = (REC)r;
-        done += (uint32_t)__popcll(m);
     }
 }
 
@@ -140,14 +121,14 @@ void ts_shard_header(const TsShardPackParams P, TsShardHeader H, const u64 *vis_
     __syncthreads();
     bool o = false;
     for (uint32_t w = threadIdx.x; w < P.nwaves; w += 256u) o |= P.wave_fill[w] > P.region_cap;
-    if (o) atomicOr(&over, 1u);
+    const TsShardSeg *segs = (const TsShardSeg *)(P.msg + P.off_segs);
+    bool ctx = false;
+    for (uint32_t s = threadIdx.x; s < P.n_segs; s += 256u) ctx |= (segs[s].flags & TS_SEG_F_CONTEXT) != 0u;
+    if (o || ctx) atomicOr(&over, (o ? 1u : 0u) | (ctx ? 2u : 0u));
     __syncthreads();
     if (threadIdx.x != 0) return;
     TsShardHeader *dst = (TsShardHeader *)P.msg;
-    const TsShardSeg *segs = (const TsShardSeg *)(P.msg + P.off_segs);
-    uint32_t flags = over ? TS_SHARD_F_SCAN_OVERFLOW : 0u;
-    for (uint32_t s = 0; s < P.n_segs; ++s)
-        if (segs[s].flags & TS_SEG_F_CONTEXT) flags |= TS_SHARD_F_CONTEXT;
+    uint32_t flags = ((over & 1u) ? TS_SHARD_F_SCAN_OVERFLOW : 0u) | ((over & 2u) ? TS_SHARD_F_CONTEXT : 0u);
     H.n_blocks = dst->n_blocks;
     H.n_visible = vis_off ? vis_off[P.own1 - P.own0] : 0ull;
     if (H.n_visible > H.visible_capacity) flags |= TS_SHARD_F_VISIBLE_OVERFLOW;
@@ -170,22 +151,34 @@ static unsigned long long shard_tmp_off(uint32_t own_tiles, int which) {
 }
 unsigned long long ts_k_shard_tmp_bytes(uint32_t own_tiles) { return shard_tmp_off(own_tiles, 2) + ts_k_scan_tmp_bytes(own_tiles) + 16ull; }
 
-// P->msg's header must be zero when the block-calling kernels run (the caller clears it); this runs after them.
-int ts_k_launch_shard_pack(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, void *stream) {
+// Phase 1 (before block calling): visible records per owned tile and where each tile's go.  Fills `vis` for the
+// interstitial pass (off == nullptr when the shard has no owned tile or no visible records: a tips-only batch).
+int ts_k_launch_shard_count(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, TsVisibleOut *vis, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nown = P->own1 - P->own0;
+    *vis = TsVisibleOut{};
+    if (!with_visible || !nown) return 0;
     uint32_t *vis_stats = (uint32_t *)((char *)tmp + shard_tmp_off(nown, 0));
     u64 *vis_off = (u64 *)((char *)tmp + shard_tmp_off(nown, 1));
     void *scan_tmp = (char *)tmp + shard_tmp_off(nown, 2);
-    if (with_visible && nown) {
-        hipLaunchKernelGGL(ts_shard_visible_count, dim3((nown + 3u) / 4u), dim3(256), 0, st, *P, vis_stats);
-        int e = ts_k_launch_tile_offsets(vis_stats, nown, vis_off, scan_tmp, stream);
-        if (e) return e;
-        if (H->visible_bytes == 2u)
-            hipLaunchKernelGGL(ts_shard_visible_write<uint16_t>, dim3((nown + 3u) / 4u), dim3(256), 0, st, *P, (const u64 *)vis_off, (u64)H->visible_capacity);
-        else
-            hipLaunchKernelGGL(ts_shard_visible_write<uint32_t>, dim3((nown + 3u) / 4u), dim3(256), 0, st, *P, (const u64 *)vis_off, (u64)H->visible_capacity);
-    }
+    hipLaunchKernelGGL(ts_shard_visible_count, dim3((nown + 255u) / 256u), dim3(256), 0, st, *P, vis_stats);
+    int e = ts_k_launch_tile_offsets(vis_stats, nown, vis_off, scan_tmp, stream);
+    if (e) return e;
+    vis->off = vis_off;
+    vis->dst = P->msg + P->off_visible;
+    vis->capacity = H->visible_capacity;
+    vis->own0 = P->own0; vis->own1 = P->own1;
+    vis->rec_bytes = H->visible_bytes;
+    vis->terminal_limit = P->terminal_limit;
+    return (int)hipGetLastError();
+}
+
+// Phase 2 (after block calling, which counted the blocks in the zeroed header and wrote the visible records): the packed
+// window records and the header.
+int ts_k_launch_shard_pack(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t nown = P->own1 - P->own0;
+    u64 *vis_off = (u64 *)((char *)tmp + shard_tmp_off(nown, 1));
     const u64 nwin = P->own_win1 - P->own_win0;
     if (nwin)
         hipLaunchKernelGGL(ts_shard_pack_windows, dim3((unsigned)((nwin + 255ull) / 256ull)), dim3(256), 0, st, *P, H->window_bytes);

@@ -157,12 +157,23 @@ struct TsShardSeg {                     // 64 bytes, one per segment with an own
 };
 static_assert(sizeof(TsShardSeg) == 64, "TsShardSeg is 64 bytes on the wire");
 
-struct TsShardSegIn {                   // per-segment table of the shard kernels, 48 bytes
+struct TsShardSegIn {                   // per-segment table of the shard kernels, 64 bytes
     unsigned long long in_off, len, abs_pos;    // input layout offset, length, absolute position of the segment
+    unsigned long long lo_rel, hi_rel;          // segment-relative position of the first base of tile t0 / behind the last base of
+                                                // tile t1 - 1 (0 and len when the shard holds none of its tiles)
     uint32_t t0, t1;                            // its tiles the shard scanned, as indices into the batch's (range-local) arrays
     uint32_t o0, o1;                            // its OWNED tiles, same indexing (o0 == o1: none)
     uint32_t flags;                             // TS_SEG_F_HAS_START / HAS_END
     uint32_t seg;                               // plan index of the segment
+};
+
+struct TsVisibleOut {                   // the visible records of a shard's owned tiles, written by the interstitial pass
+    const unsigned long long *off;      // per owned tile (+1): index of its first visible record; nullptr = not wanted
+    void *dst;                          // the message's visible section
+    unsigned long long capacity;        // records it holds (more in all: nothing is written, the header reports it)
+    uint32_t own0, own1;                // owned tiles, range-local
+    uint32_t rec_bytes;                 // 2 or 4
+    uint32_t terminal_limit;
 };
 
 struct TsShardPackParams {
@@ -241,9 +252,12 @@ int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_o
 // blockcall.hip: terminal walks per segment of `segs` (nseg entries; bounds: 2 x u64 per segment), then the interstitial
 // search over the batch's ntiles (range-local) tiles; seg_base = plan index of segs[0]'s segment; seg_out (nullable):
 // what a shard reports per segment
+// vis (nullable): where the interstitial pass leaves the visible records of the owned tiles (a shard's message)
 int  ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
-                            uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its, void *stream);
+                            uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its,
+                            const TsVisibleOut *vis, void *stream);
 // shard.hip: packed window records, visible records + per-tile counts, and the header of a shard's message
+int  ts_k_launch_shard_count(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, TsVisibleOut *vis, void *stream);
 int  ts_k_launch_shard_pack(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, void *stream);
 unsigned long long ts_k_shard_tmp_bytes(uint32_t own_tiles);
 // exchange.hip: tile directory of a dense tile-ordered stream, and the export of a scan's records into one

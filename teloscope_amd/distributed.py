@@ -498,6 +498,96 @@ class PackedShard:
         self.batches = []
 
 
+class ShardExchange:
+    """The ONE exchange of a sharded scan in its shard-result form: every rank's message to `dst`.
+
+    Both sides know every message's size from the plan (ts_batch_shard_info), so a step is one grouped round of
+    send / recv — no count exchange, nothing read back to the host — and `check` (outside the timed region: once
+    after the warm-up, once at the end) is where rank `dst` reads the headers, merges the messages
+    (ts_shards_finalize) and tells everybody whether something has to change: a scan overflowed its record regions
+    (sync + rescan), a message overflowed (a larger capacity scale on every rank), or the input is one the shards'
+    assumptions do not hold for (the full exchange, gather_shards, is then the path).
+
+    Works on any backend: device tensors for "nccl" (RCCL over xGMI), staged through host memory for "gloo"."""
+    OK, SYNC, GROW, FULL = 0, 1, 2, 3
+
+    def __init__(self, plan: ShardPlan, rank: int, device, dst: int = 0, group=None, slots: int = 2, scale: int = 1):
+        import torch.distributed as dist
+        self.plan, self.rank, self.device, self.dst, self.group, self.slots = plan, rank, device, dst, group, slots
+        self.world = plan.world
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.set_scale(scale)
+
+    def set_scale(self, scale):
+        import torch
+        self.scale = scale
+        self.infos = [shard_info(self.plan, p, scale) for p in range(self.world)]
+        wire_dev = self.device if self.backend == "nccl" else torch.device("cpu")
+        self.recv = None
+        if self.rank == self.dst:
+            self.recv = [[torch.zeros(int(self.infos[p].msg_bytes), dtype=torch.uint8, device=wire_dev) if p != self.dst else None
+                          for p in range(self.world)] for _ in range(self.slots)]
+
+    @property
+    def bytes_over_links(self):
+        return sum(int(self.infos[p].msg_bytes) for p in range(self.world) if p != self.dst)
+
+    def post(self, msg, slot=0):
+        """Enqueue the transfer of this rank's message (`msg`: its device tensor, packed on the current stream);
+        returns the works to wait for before the slot's buffers are reused."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return []
+        ops = []
+        if self.rank != self.dst:
+            t = msg if self.backend == "nccl" else msg.cpu()
+            self._keep = t
+            ops.append(dist.P2POp(dist.isend, t, self.dst, group=self.group))
+        else:
+            for p in range(self.world):
+                if p != self.dst:
+                    ops.append(dist.P2POp(dist.irecv, self.recv[slot][p], p, group=self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def messages(self, own_msg, slot=0):
+        """On dst: the messages of all parts of the slot as host numpy arrays (synchronises)."""
+        assert self.rank == self.dst
+        return [(own_msg if p == self.dst else self.recv[slot][p]).cpu().numpy() for p in range(self.world)]
+
+    def check(self, own_msg, slot=0, finalize=True):
+        """Collective.  Returns (action, factor, merged) — merged = (rc, out, counts) of ts_shards_finalize on dst when
+        the messages were merged (the caller frees out with free_segments), else None."""
+        import torch
+        import torch.distributed as dist
+        action, factor, merged = self.OK, 1, None
+        if self.rank == self.dst:
+            msgs = self.messages(own_msg, slot)
+            flags = 0
+            for m in msgs:
+                st = K.ShardStatus()
+                if self.plan.L.ts_shard_peek(m.ctypes.data, m.nbytes, C.byref(st)) != K.TS_OK:
+                    raise K.TeloscanError(K.TS_ERR_STATE, "a received shard message has no valid header")
+                flags |= st.flags
+                factor = max(factor, int(st.scale_factor_needed))
+            if flags & K.SHARD_OVERFLOW_SCAN:
+                action = self.SYNC
+            elif flags & (K.SHARD_OVERFLOW_VISIBLE | K.SHARD_OVERFLOW_BLOCKS):
+                action, factor = self.GROW, max(2, factor)
+            elif flags & K.SHARD_OUT_OF_CONTEXT:
+                action = self.FULL
+            elif finalize:
+                merged = finalize_shards(self.plan, msgs)
+                if merged[0] != 0:
+                    action = {K.SHARD_RETRY_SYNC: self.SYNC, K.SHARD_RETRY_GROW: self.GROW, K.SHARD_NEED_FULL: self.FULL}[merged[0]]
+                    merged = None
+        if self.world > 1:
+            wire_dev = self.device if self.backend == "nccl" else torch.device("cpu")
+            t = torch.tensor([action, factor], dtype=torch.int64, device=wire_dev)
+            dist.broadcast(t, src=self.dst, group=self.group)
+            action, factor = (int(x) for x in t.tolist())
+        return action, factor, merged
+
+
 def finalize_shards(plan: ShardPlan, msgs, with_counts=True):
     """ts_shards_finalize: the messages of all parts (host memory: numpy uint8 arrays or bytes) -> (rc, out, counts);
     rc 0 = out[i] / counts[i] hold segment i (free out with free_segments), else K.SHARD_RETRY_SYNC / _GROW / NEED_FULL."""
