@@ -517,22 +517,41 @@ def run_scan(args, rank, local_rank, world, dev, backend):
             torch.cuda.empty_cache()
         in_ptr = buf.data_ptr()
         pending = [None] * slots
+        # Two streams: block calling + packing of step i (no LDS, few registers) run beside the scan of step i + 1 (a
+        # persistent kernel that holds every CU's LDS but leaves wave slots and issue cycles free), and the transfer of
+        # step i's message beside both.  A slot's scan waits for the pack that last read its records; a slot's pack
+        # waits for the transfer that last read its message.
+        pack_stream = torch.cuda.Stream(device=dev)
+        pptr = C.c_void_p(pack_stream.cuda_stream)
+        scanned = [torch.cuda.Event() for _ in range(slots)]
+        packed = [torch.cuda.Event() for _ in range(slots)]
+        used = [False] * slots
 
         def step(i):
             j = i % slots
-            if pending[j] is not None:
-                for w in pending[j]:
-                    w.wait()
-                pending[j] = None
-            shard.scan_pack(in_ptr, sptr, j)
-            pending[j] = exch.post(shard.msgs[j], j)
-
-        def drain():
-            for j in range(slots):
+            if used[j]:
+                stream.wait_event(packed[j])
+            shard.scan(in_ptr, sptr, j)
+            scanned[j].record(stream)
+            with torch.cuda.stream(pack_stream):
+                pack_stream.wait_event(scanned[j])
                 if pending[j] is not None:
                     for w in pending[j]:
                         w.wait()
                     pending[j] = None
+                shard.pack(pptr, j)
+                packed[j].record(pack_stream)
+                pending[j] = exch.post(shard.msgs[j], j)
+            used[j] = True
+
+        def drain():
+            with torch.cuda.stream(pack_stream):
+                for j in range(slots):
+                    if pending[j] is not None:
+                        for w in pending[j]:
+                            w.wait()
+                        pending[j] = None
+            stream.wait_stream(pack_stream)
 
         settle(step, drain)
         for i in range(max(args.warmup, slots)):

@@ -163,24 +163,38 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
     };
     bool stop = false;
     const uint32_t ntile = V.t1 - V.t0;
+    // The walk is one chain of dependent steps, and what it waits for is memory: the directory entries of the next tile are
+    // requested while this one is walked, and eight batches of 64 records together (a telomere is thirty batches long).
+    auto tile_at = [&](uint32_t ti) { return from_start ? V.t0 + ti : V.t1 - 1u - ti; };
+    uint32_t n_cnt = ntile ? V.count(tile_at(0)) : 0u;
+    u64 n_off = ntile ? V.tile_off[tile_at(0)] : 0ull, n_in = ntile ? V.tiles[tile_at(0)].in_off : 0ull;
     for (uint32_t ti = 0; ti < ntile && !stop; ++ti) {
-        const uint32_t t = from_start ? V.t0 + ti : V.t1 - 1u - ti;
-        const uint32_t cnt = V.count(t);
+        const uint32_t cnt = n_cnt;
+        const u64 off = n_off;
+        const u64 tile_rel = n_in - V.base;
+        // the terminal zone's edge, relative to the tile: a head is in the zone iff p32 < zone32 (walk from the start) or
+        // p32 >= zone32 (walk from the end); a segment no longer than the limit is zone as a whole
+        uint32_t zone32;
+        {
+            const u64 edge = from_start ? (u64)Q.terminal_limit : n - Q.terminal_limit;
+            if (n <= Q.terminal_limit) zone32 = from_start ? 0xFFFFFFFFu : 0u;
+            else zone32 = edge <= tile_rel ? 0u : (edge - tile_rel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(edge - tile_rel));
+        }
+        if (ti + 1u < ntile) {
+            const uint32_t t2 = tile_at(ti + 1u);
+            n_cnt = V.count(t2); n_off = V.tile_off[t2]; n_in = V.tiles[t2].in_off;
+        }
         if (cnt == 0u) continue;
-        const u64 off = V.tile_off[t];
-        const u64 tile_rel = V.tiles[t].in_off - V.base;
-        // four batches of 64 records are requested together (the walk is one chain of dependent steps: what it waits
-        // for is memory latency, and a telomere is thirty batches long)
-        for (uint32_t b4 = 0; b4 < cnt && !stop; b4 += 256u) {
-          uint32_t recs[4];
+        for (uint32_t b4 = 0; b4 < cnt && !stop; b4 += 512u) {
+          uint32_t recs[8];
 #pragma unroll
-          for (uint32_t q = 0; q < 4u; ++q) {
+          for (uint32_t q = 0; q < 8u; ++q) {
               const uint32_t bq = b4 + 64u * q;
               const uint32_t idx = from_start ? bq + lane : cnt - 1u - bq - lane;      // walk order
               recs[q] = bq + lane < cnt ? V.matches[off + idx] : 0u;
           }
 #pragma unroll
-          for (uint32_t q = 0; q < 4u; ++q) {
+          for (uint32_t q = 0; q < 8u; ++q) {
             const uint32_t b0 = b4 + 64u * q;
             if (b0 >= cnt || stop) break;
             const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
@@ -199,29 +213,64 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
             const bool first_head = !open || (from_start ? first_pos - ch.prev : ch.prev - first_pos) > Q.max_match_dist;
             const bool head = sel && (before == 0u ? first_head : gap_in > Q.max_match_dist);
             const u64 heads = __ballot(head), canon = __ballot(sel && (rec & 1u));
-            while (rem) {                                  // one step per chain (or per piece of a chain that spans batches)
-                const uint32_t l0 = (uint32_t)__builtin_ctzll(rem);
-                if ((heads >> l0) & 1ull) {
-                    if (open) close_sub();
-                    const u64 p0 = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)l0);
-                    const bool in_zone = n <= Q.terminal_limit ? true
-                                       : (from_start ? p0 < Q.terminal_limit : p0 >= n - Q.terminal_limit);
-                    if (!in_zone) { stop = true; break; }
-                    ch.start = p0; ch.end = p0 + Q.k; ch.prev = p0;
-                    ch.counts = ch.fwd = ch.canon = ch.cov = ch.fwd_cov = ch.can_cov = 0;
-                    open = true;
-                }
-                const u64 later = l0 < 63u ? heads & ~((2ull << l0) - 1ull) : 0ull;      // heads after l0
-                const u64 run = later ? rem & ((1ull << (uint32_t)__builtin_ctzll(later)) - 1ull) : rem;
-                const uint32_t nrun = (uint32_t)__popcll(run), ncan = (uint32_t)__popcll(run & canon);
+            // The walk ends at the first head outside the terminal zone; ahead of it every head closes the chain before it.
+            // In the zone's random stretch a batch holds ~15 chains and a sub-block is one in a hundred of them (it needs
+            // min_block_counts records and a canonical one): every head lane counts its own chain, and the scalar state
+            // machine steps only through the chains that pass those two tests — the others leave no trace in it.
+            const u64 Z = __ballot(head && !(from_start ? p32 < zone32 : p32 >= zone32));
+            const uint32_t stop_lane = Z ? (uint32_t)__builtin_ctzll(Z) : 64u;
+            const u64 live = stop_lane < 64u ? (1ull << stop_lane) - 1ull : ~0ull;
+            const u64 h_all = heads & (stop_lane < 64u ? live | (1ull << stop_lane) : ~0ull), h_live = heads & live;
+            rem &= live;
+            const uint32_t first = h_all ? (uint32_t)__builtin_ctzll(h_all) : 64u;
+            const u64 pre = rem & (first < 64u ? (1ull << first) - 1ull : ~0ull);
+            if (open && pre) {                             // the chain carried into the batch takes the records ahead of the first head
+                const uint32_t nrun = (uint32_t)__popcll(pre), ncan = (uint32_t)__popcll(pre & canon);
                 const uint32_t nfwd = from_start ? nrun : 0u;                              // the list has one orientation
                 ch.counts += nrun; ch.fwd += nfwd; ch.canon += ncan;
                 ch.cov += nrun * Q.k; ch.fwd_cov += nfwd * Q.k; ch.can_cov += ncan * Q.k;
-                const uint32_t last_lane = 63u - (uint32_t)__builtin_clzll(run);
-                ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)last_lane);
+                ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(pre));
                 if (from_start) ch.end = ch.prev + Q.k; else ch.start = ch.prev;
-                rem &= ~run;
             }
+            if (open && h_all) close_sub();
+            if (h_live) {
+                const u64 above = lane < 63u ? h_all >> (lane + 1u) : 0ull;
+                const uint32_t next = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 64u;   // the next head's lane
+                const u64 lo_me = lane ? (1ull << lane) - 1ull : 0ull;
+                const u64 mine = rem & (next < 64u ? (1ull << next) - 1ull : ~0ull) & ~lo_me;
+                const uint32_t nrun_l = (uint32_t)__popcll(mine), ncan_l = (uint32_t)__popcll(mine & canon);
+                const uint32_t last_l = mine ? 63u - (uint32_t)__builtin_clzll(mine) : lane;
+                const uint32_t p_last_l = (uint32_t)__shfl((int)p32, (int)last_l);
+                u64 sub = __ballot(((h_live >> lane) & 1ull) && next < 64u && nrun_l >= Q.min_block_counts && ncan_l > 0u);
+                while (sub) {                              // the complete chains that may be sub-blocks, in walk order
+                    const int i = (int)__builtin_ctzll(sub);
+                    sub &= sub - 1ull;
+                    const u64 p_head = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, i);
+                    const u64 p_end = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p_last_l, i);
+                    const uint32_t nrun = (uint32_t)__builtin_amdgcn_readlane((int)nrun_l, i);
+                    const uint32_t ncan = (uint32_t)__builtin_amdgcn_readlane((int)ncan_l, i);
+                    const uint32_t nfwd = from_start ? nrun : 0u;
+                    ch.prev = p_end;
+                    if (from_start) { ch.start = p_head; ch.end = p_end + Q.k; } else { ch.start = p_end; ch.end = p_head + Q.k; }
+                    ch.counts = nrun; ch.fwd = nfwd; ch.canon = ncan;
+                    ch.cov = nrun * Q.k; ch.fwd_cov = nfwd * Q.k; ch.can_cov = ncan * Q.k;
+                    open = true;
+                    close_sub();
+                }
+                if (stop_lane == 64u) {                    // the last head's chain stays open
+                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(h_live);
+                    const u64 tail = rem & ~(top ? (1ull << top) - 1ull : 0ull);
+                    const uint32_t nrun = (uint32_t)__popcll(tail), ncan = (uint32_t)__popcll(tail & canon);
+                    const uint32_t nfwd = from_start ? nrun : 0u;
+                    const u64 p_head = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)top);
+                    ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(tail));
+                    if (from_start) { ch.start = p_head; ch.end = ch.prev + Q.k; } else { ch.start = ch.prev; ch.end = p_head + Q.k; }
+                    ch.counts = nrun; ch.fwd = nfwd; ch.canon = ncan;
+                    ch.cov = nrun * Q.k; ch.fwd_cov = nfwd * Q.k; ch.can_cov = ncan * Q.k;
+                    open = true;
+                }
+            }
+            if (stop_lane < 64u) stop = true;
           }
         }
     }

@@ -452,14 +452,23 @@ class PackedShard:
             self.batches.append(b)
             self.msgs.append(torch.zeros(int(self.info.msg_bytes), dtype=torch.uint8, device=device))
 
-    def scan_pack(self, d_input, stream_ptr, slot=0):
-        """d_input: device address of byte `info.input_begin` of the input layout."""
-        b = self.batches[slot]
-        rc = self.L.ts_batch_scan(b, C.c_void_p(d_input), stream_ptr)
-        if rc == K.TS_OK:
-            rc = self.L.ts_batch_pack_shard(b, C.c_void_p(self.msgs[slot].data_ptr()), self.msgs[slot].numel(), stream_ptr)
+    def scan(self, d_input, stream_ptr, slot=0):
+        """Enqueue the scan of the shard's tiles.  d_input: device address of byte `info.input_begin` of the input layout."""
+        rc = self.L.ts_batch_scan(self.batches[slot], C.c_void_p(d_input), stream_ptr)
         if rc != K.TS_OK:
             raise K.TeloscanError(rc, self.plan.teloscope._ctx.error())
+
+    def pack(self, stream_ptr, slot=0):
+        """Enqueue block calling + the packed message of the slot's last scan (the stream must be ordered behind that
+        scan: the same stream, or one that waits for an event recorded after it — the kernels use no LDS and few
+        registers, so on a stream of their own they run beside the next scan)."""
+        rc = self.L.ts_batch_pack_shard(self.batches[slot], C.c_void_p(self.msgs[slot].data_ptr()), self.msgs[slot].numel(), stream_ptr)
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, self.plan.teloscope._ctx.error())
+
+    def scan_pack(self, d_input, stream_ptr, slot=0):
+        self.scan(d_input, stream_ptr, slot)
+        self.pack(stream_ptr, slot)
 
     def status(self, slot=0):
         """The message's header, read back (synchronises with the device)."""
