@@ -122,3 +122,33 @@ def assert_segment_equal(got, exp, tips_only, float_fields=True, ctx=""):
         assert len(g) == len(e), "%s %s: %d vs %d" % (ctx, name, len(g), len(e))
         for f in BLOCK_FIELDS:
             assert np.array_equal(g[f], e[f]), "%s %s.%s differs" % (ctx, name, f)
+
+
+def assert_visible_view_equal(got, exp, tips, cnt, ctx):
+    """got: teloscope_amd.SegmentData built from a visible-view ts_segment_out; exp: the oracle's dict."""
+    gw, ew = got.windows, exp["windows"]
+    assert len(gw) == len(ew), "%s windows: %d vs %d" % (ctx, len(gw), len(ew))
+    for f in WINDOW_FIELDS:
+        assert np.array_equal(gw[f], ew[f]), "%s windows.%s differs" % (ctx, f)
+    if len(gw):
+        assert np.max(np.abs(gw["gc_content"].astype(np.float64) - ew["gc_content"])) <= 1e-6, ctx
+        assert np.max(np.abs(gw["shannon_entropy"].astype(np.float64) - ew["shannon_entropy"])) <= 1e-6, ctx
+    for name, g in (("terminal_blocks", got.terminalBlocks), ("interstitial_blocks", got.interstitialBlocks)):
+        e = exp[name]
+        assert len(g) == len(e), "%s %s: %d vs %d" % (ctx, name, len(g), len(e))
+        for f in BLOCK_FIELDS:
+            assert np.array_equal(g[f], e[f]), "%s %s.%s differs" % (ctx, name, f)
+    for name, g in (("canonical_matches", got.canonicalMatches), ("non_canonical_matches", got.nonCanonicalMatches)):
+        e = exp[name]
+        assert len(g) == len(e), "%s %s: %d vs %d" % (ctx, name, len(g), len(e))
+        for f in MATCH_FIELDS:
+            assert np.array_equal(g[f], e[f]), "%s %s.%s differs" % (ctx, name, f)
+        assert np.array_equal((g["flags"] & 1) != 0, e["is_forward"] != 0), "%s %s.is_forward" % (ctx, name)
+    if not tips:
+        assert len(got._m) == len(exp["canonical_matches"]) + len(exp["non_canonical_matches"]), ctx
+    if cnt is not None:
+        if tips:
+            assert (cnt.n_windows, cnt.n_matches, cnt.n_forward) == (0, len(exp["fwd_matches"]) + len(exp["rev_matches"]), len(exp["fwd_matches"])), ctx
+        else:
+            assert (cnt.n_windows, cnt.n_matches, cnt.n_canonical, cnt.n_forward) == \
+                (len(ew), len(exp["all_matches"]), len(exp["canonical_matches"]), len(exp["fwd_matches"])), ctx

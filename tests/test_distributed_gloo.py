@@ -110,27 +110,6 @@ def _worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
-def test_partition_is_consecutive_balanced_and_complete():
-    from teloscope_amd.distributed import lpt_partition
-    for mode in CLI:
-        for world in (1, 2, 3, 8):
-            opts, plan = _plan(mode, world)
-            assert plan.ranges[0].tile_begin == 0 and plan.ranges[-1].tile_end == plan.n_tiles
-            for a, b in zip(plan.ranges, plan.ranges[1:]):
-                assert a.tile_end == b.tile_begin and a.window_end == b.window_begin
-            bases = [r.bases for r in plan.ranges]
-            assert sum(bases) == sum(int(t["owned_bases"]) for t in plan.tiles)
-            assert max(bases) - min(bases) <= 2 * int(plan.tiles["owned_bases"].max())
-            # a range reads its own bases plus at most the halo and the kernel's over-read slack
-            for r in plan.ranges:
-                assert r.input_end - r.input_begin <= r.bases + 16 * len(LENS) + 3 * 2016 + 64 or plan.tips_only
-    rng = np.random.default_rng(3)
-    lens = [int(x) for x in np.exp(rng.uniform(np.log(1e6), np.log(250e6), size=200))]
-    for world in (1, 2, 4, 8):
-        shards = lpt_partition(lens, world)
-        assert sorted(i for s in shards for i in s) == list(range(200))
-
-
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("mode,world", [("windows", 2), ("tips", 2), ("windows", 3)])
 def test_gather_over_ranks_equals_single_process(mode, world):

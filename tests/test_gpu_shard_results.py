@@ -14,7 +14,7 @@ import pytest
 
 from tests import harness as H
 from tests import seqgen
-from tests.backends import BLOCK_FIELDS, MATCH_FIELDS, WINDOW_FIELDS, OracleBackend
+from tests.backends import OracleBackend, assert_visible_view_equal
 
 pytestmark = pytest.mark.gpu
 HEADLINE = "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -m -i"
@@ -25,36 +25,6 @@ def _teloscope(cli, device=0):
     from teloscope_amd.cli import parse_cli, user_input
     opts = parse_cli("x.fa " + cli)
     return opts, ta.Teloscope(user_input(opts, device=device))
-
-
-def assert_visible_view_equal(got, exp, tips, cnt, ctx):
-    """got: teloscope_amd.SegmentData built from a visible-view ts_segment_out; exp: the oracle's dict."""
-    gw, ew = got.windows, exp["windows"]
-    assert len(gw) == len(ew), "%s windows: %d vs %d" % (ctx, len(gw), len(ew))
-    for f in WINDOW_FIELDS:
-        assert np.array_equal(gw[f], ew[f]), "%s windows.%s differs" % (ctx, f)
-    if len(gw):
-        assert np.max(np.abs(gw["gc_content"].astype(np.float64) - ew["gc_content"])) <= 1e-6, ctx
-        assert np.max(np.abs(gw["shannon_entropy"].astype(np.float64) - ew["shannon_entropy"])) <= 1e-6, ctx
-    for name, g in (("terminal_blocks", got.terminalBlocks), ("interstitial_blocks", got.interstitialBlocks)):
-        e = exp[name]
-        assert len(g) == len(e), "%s %s: %d vs %d" % (ctx, name, len(g), len(e))
-        for f in BLOCK_FIELDS:
-            assert np.array_equal(g[f], e[f]), "%s %s.%s differs" % (ctx, name, f)
-    for name, g in (("canonical_matches", got.canonicalMatches), ("non_canonical_matches", got.nonCanonicalMatches)):
-        e = exp[name]
-        assert len(g) == len(e), "%s %s: %d vs %d" % (ctx, name, len(g), len(e))
-        for f in MATCH_FIELDS:
-            assert np.array_equal(g[f], e[f]), "%s %s.%s differs" % (ctx, name, f)
-        assert np.array_equal((g["flags"] & 1) != 0, e["is_forward"] != 0), "%s %s.is_forward" % (ctx, name)
-    if not tips:
-        assert len(got._m) == len(exp["canonical_matches"]) + len(exp["non_canonical_matches"]), ctx
-    if cnt is not None:
-        if tips:
-            assert (cnt.n_windows, cnt.n_matches, cnt.n_forward) == (0, len(exp["fwd_matches"]) + len(exp["rev_matches"]), len(exp["fwd_matches"])), ctx
-        else:
-            assert (cnt.n_windows, cnt.n_matches, cnt.n_canonical, cnt.n_forward) == \
-                (len(ew), len(exp["all_matches"]), len(exp["canonical_matches"]), len(exp["fwd_matches"])), ctx
 
 
 def _pack_all_parts(plan, buf, dev):
@@ -127,6 +97,43 @@ def test_shard_messages_merge_to_the_oracle(cli):
         plan.close()
     if not tips and ("-t 3000" in cli or "-t 2500" in cli or "-t 1000" in cli):
         assert split_inside > 0, "no boundary fell inside a segment: the context tiles were never exercised"
+
+
+def test_kernel_messages_equal_the_messages_packed_from_oracle_results():
+    """Byte level: what the kernels pack (header, per-segment entries, bit-packed windows, per-tile counts, visible records,
+    blocks) against tests/shardpack.py's rendering of the oracle's results in the same layout."""
+    import torch
+    from tests import shardpack
+    from teloscope_amd.distributed import ShardPlan
+    dev = torch.device("cuda", 0)
+    for cli in (HEADLINE + " -t 3000", "-r -i -w 700 -s 700 -t 1000"):
+        opts, tel = _teloscope(cli)
+        rng = np.random.default_rng(8)
+        lens = [300_000, 0, 4999, 610_000, 45_000]
+        seqs = [seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, n_its=3, iupac=1) if n else b"" for n in lens]
+        abs_pos = [7 * i for i in range(len(lens))]
+        orac = OracleBackend(opts)
+        exp = [orac.scan_segment(sq, abs_pos[i], False) for i, sq in enumerate(seqs)]
+        for world in (1, 3, 4):
+            plan = ShardPlan(tel, lens, abs_pos=abs_pos, world=world)
+            msgs, _ = _pack_all_parts(plan, _fill(plan, seqs, dev), dev)
+            for p in range(world):
+                want = shardpack.pack_shard(plan, opts, p, exp)
+                got = msgs[p]
+                hg, hw = shardpack.read_header(got), shardpack.read_header(want)
+                assert hg == hw, (cli, world, p, hg, hw)
+                nseg, nown, nwin = int(hg["n_segs"]), int(hg["own_end"] - hg["own_begin"]), int(hg["n_windows"])
+                from teloscope_amd.distributed import shard_info
+                off = shardpack.sections(shard_info(plan, p), nseg, nown, nwin)
+                assert np.array_equal(shardpack.read_segs(got), shardpack.read_segs(want)), (cli, world, p)
+                for name, n in (("windows", nwin * int(hg["window_bytes"])), ("tilevis", nown * 2), ("visible", int(hg["n_visible"]) * int(hg["visible_bytes"]))):
+                    assert np.array_equal(got[off[name]:off[name] + n], want[off[name]:off[name] + n]), (cli, world, p, name)
+                nb = int(hg["n_blocks"])
+                bg = np.frombuffer(got[off["blocks"]:off["blocks"] + nb * 64].tobytes(), dtype=shardpack.DEVBLOCK_DT)
+                bw = np.frombuffer(want[off["blocks"]:off["blocks"] + nb * 64].tobytes(), dtype=shardpack.DEVBLOCK_DT)
+                key = ("seg", "kind", "seq", "start")            # (the kernels append blocks in completion order)
+                assert np.array_equal(np.sort(bg, order=key), np.sort(bw, order=key)), (cli, world, p)
+            plan.close()
 
 
 def test_block_at_a_shard_boundary_and_a_telomere_longer_than_the_context():

@@ -112,14 +112,28 @@ def _bench(*args, timeout=900):
 
 def test_bench_two_ranks_on_one_gpu_equals_single_gpu():
     """`python bench.py --gpus 2` spawns its own two ranks (they share this GPU, so the exchange runs over gloo):
-    configs[2] in small — the same assembly, two tile ranges, one exchange — and rank 0's assembled arrays are
-    compared bit for bit with a single-GPU scan of the whole assembly (--verify)."""
+    configs[2] in small — the same assembly, two shards, one message per rank — and what the messages merge to on
+    rank 0 is compared with a single-GPU scan of the whole assembly: windows and blocks byte for byte, the visible match
+    records, the per-segment counts (--verify)."""
     out = _bench("--gpus", "2", "--gbases", "0.3", "--contigs", "14", "--steps", "4", "--warmup", "2", "--verify")
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 4
     cfg = out["config"]
-    assert len(cfg["bases_per_rank"]) == 2 and abs(cfg["bases_per_rank"][0] - cfg["bases_per_rank"][1]) <= 2 * 13500
+    assert len(cfg["bases_per_rank"]) == 2 and abs(cfg["bases_per_rank"][0] - cfg["bases_per_rank"][1]) <= 400_000
+    x = cfg["exchange"]
+    assert x["bytes_over_links_per_step"] == x["message_bytes_per_rank"][1] and x["window_bytes"] == 9
+    assert all(v <= c for v, c in zip(x["visible_records_per_rank"], x["visible_capacity_per_rank"]))
+    v = out["verify"]
+    assert v["contigs_checked"] == 14 and v["matches_checked"] == cfg["matches"]
+    assert v["sharded_equals_single_gpu"]["segments"] == 14 and v["sharded_equals_single_gpu"]["visible_matches"] == sum(x["visible_records_per_rank"])
+    assert cfg["step_split"]["exchange_ms"] > 0
+
+
+def test_bench_full_exchange_two_ranks_on_one_gpu_equals_single_gpu():
+    """Round 2's exchange (every record assembled on rank 0) stays available behind --full-exchange: it is what a batch
+    takes when the shards' assumptions do not hold for its input."""
+    out = _bench("--gpus", "2", "--gbases", "0.3", "--contigs", "14", "--steps", "4", "--warmup", "2", "--verify", "--full-exchange")
+    cfg = out["config"]
     assert sum(cfg["records_per_rank"]) == cfg["matches"] == out["verify"]["sharded_equals_single_gpu"]["records"]
-    assert out["verify"]["contigs_checked"] == 14
     assert cfg["summaries_only_variant"]["value"] > 0 and cfg["step_split"]["exchange_ms"] > 0
 
 
