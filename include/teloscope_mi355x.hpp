@@ -189,7 +189,12 @@ public:
     struct Segment;
 private:
     UserInputTeloscope userInput;
-    detail::CtxPtr ctx;
+    detail::CtxPtr ctx;                         // the first device's context: every single-device entry point
+    // one context per further device: the reference runs one thread-pool job per path (src/input.cpp:719-733); here a
+    // batch of segments is cut into one shard per device (ts_scan_segments_multi) and each device uploads, scans and
+    // downloads its shard over its own PCIe link
+    std::vector<detail::CtxPtr> more;
+    std::vector<ts_ctx *> all;
 
     // writerViewOnly: fill only what writeBEDFile reads (src/teloscope.cpp:700-868) — windows, blocks,
     // canonicalMatches and nonCanonicalMatches; the other three match vectors (all / fwd / rev, which only block
@@ -235,12 +240,23 @@ private:
     }
 
 public:
-    explicit Teloscope(UserInputTeloscope ui) : userInput(std::move(ui)) {
+    // devices: HIP ordinals, one context each (an ordinal may repeat: several contexts share that GPU);
+    // empty = one context on userInput.device
+    explicit Teloscope(UserInputTeloscope ui, const std::vector<int> &devices = {}) : userInput(std::move(ui)) {
         std::vector<ts_pattern> pats = detail::makePatterns(userInput);
-        ts_params p = detail::makeParams(userInput);
-        ctx.reset(ts_create(&p, pats.data(), pats.size()));
-        if (!ctx) throw std::runtime_error(ts_last_error(nullptr));
+        const std::vector<int> devs = devices.empty() ? std::vector<int>{userInput.device} : devices;
+        for (size_t i = 0; i < devs.size(); ++i) {
+            UserInputTeloscope u = userInput;
+            u.device = devs[i];
+            ts_params p = detail::makeParams(u);
+            detail::CtxPtr c(ts_create(&p, pats.data(), pats.size()));
+            if (!c) throw std::runtime_error(ts_last_error(nullptr));
+            all.push_back(c.get());
+            if (i == 0) ctx = std::move(c); else more.push_back(std::move(c));
+        }
     }
+
+    size_t deviceCount() const { return all.size(); }
 
     const UserInputTeloscope &input() const { return userInput; }
     // does the library take TS_INPUT_TEXT_PIECES segments for this parameter set (the tiled kernel's; the general path
@@ -361,6 +377,34 @@ public:
         std::atomic<size_t> next{0};
         auto worker = [&]() {
             for (size_t i; (i = next.fetch_add(1)) < segs.size();) res[i] = convert(out[i], segs[i]);
+        };
+        const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), segs.size(), size_t(std::max(1u, std::thread::hardware_concurrency()))}));
+        if (nt <= 1) {
+            worker();
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned i = 0; i < nt; ++i) pool.emplace_back(worker);
+            for (std::thread &th : pool) th.join();
+        }
+        ts_free_segments(out.data(), out.size());
+        return res;
+    }
+
+    // scanSegments for a writer (src/teloscope.cpp:700-868 reads a path's windows, blocks, canonicalMatches and terminal
+    // nonCanonicalMatches, nothing else), over ALL the object's devices: ts_scan_segments_multi cuts the batch into one
+    // shard per device; block calling happens on the devices and only that view comes back.  result[i] has windows,
+    // blocks and those two match vectors (the other three stay empty); counts[i] = the sizes the match vectors had.
+    std::vector<SegmentData> scanSegmentsWriterView(const std::vector<Segment> &segs, std::vector<ts_segment_counts> &counts) {
+        std::vector<ts_segment_in> in(segs.size());
+        for (size_t i = 0; i < segs.size(); ++i) in[i] = segs[i].in();
+        std::vector<ts_segment_out> out(segs.size());
+        counts.assign(segs.size(), ts_segment_counts{0, 0, 0, 0});
+        if (ts_scan_segments_multi(all.data(), all.size(), in.data(), in.size(), out.data(), counts.data()) != TS_OK)
+            throw std::runtime_error(ts_last_error(ctx.get()));
+        std::vector<SegmentData> res(segs.size());
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < segs.size();) res[i] = convert(out[i], segs[i], true);
         };
         const unsigned nt = static_cast<unsigned>(std::min<size_t>({size_t(16), segs.size(), size_t(std::max(1u, std::thread::hardware_concurrency()))}));
         if (nt <= 1) {

@@ -441,8 +441,11 @@ inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::ve
     // without -m nothing downstream reads a match record: blocks and counts come from the device
     std::vector<ts_segment_counts> counts;
     // (with -m: only the two match vectors the writers read are materialised; block calling has happened on the device)
-    std::vector<SegmentData> scanned = ui.outMatches ? teloscope.scanSegments(batch, true)
-                                                      : teloscope.scanSegmentsNoMatches(batch, counts);
+    // (several devices: the batch is cut into one shard per device, and what comes back is the writers' view either way)
+    std::vector<SegmentData> scanned = teloscope.deviceCount() > 1 ? teloscope.scanSegmentsWriterView(batch, counts)
+                                     : ui.outMatches ? teloscope.scanSegments(batch, true)
+                                                     : teloscope.scanSegmentsNoMatches(batch, counts);
+    const bool haveCounts = teloscope.deviceCount() > 1 || !ui.outMatches;
 
     std::vector<PathData> paths(records.size());
     size_t si = 0;
@@ -455,7 +458,7 @@ inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::ve
         const size_t nseg = comps[pi].segments.size();
         if (nseg == 1) {                                        // the common case: the record is one segment — no copies
             SegmentData &sd = scanned[si];
-            pd.canonicalMatchCount = ui.outMatches ? sd.canonicalMatches.size() : counts[si].n_canonical;
+            pd.canonicalMatchCount = haveCounts ? counts[si].n_canonical : sd.canonicalMatches.size();
             pd.windows = std::move(sd.windows);
             pd.terminalBlocks = std::move(sd.terminalBlocks);
             pd.interstitialBlocks = std::move(sd.interstitialBlocks);
@@ -471,7 +474,7 @@ inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::ve
                 append(pd.windows, sd.windows);
                 append(pd.terminalBlocks, sd.terminalBlocks);
                 append(pd.interstitialBlocks, sd.interstitialBlocks);
-                pd.canonicalMatchCount += ui.outMatches ? sd.canonicalMatches.size() : counts[si].n_canonical;
+                pd.canonicalMatchCount += haveCounts ? counts[si].n_canonical : sd.canonicalMatches.size();
                 append(pd.canonicalMatches, sd.canonicalMatches);
                 append(pd.nonCanonicalMatches, sd.nonCanonicalMatches);
             }

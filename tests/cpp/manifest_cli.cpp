@@ -8,6 +8,7 @@
 // Usage: manifest_cli <flags as in the manifest's first line, input path already resolved>
 //        [--out-base <prefix>]   where the eleven output files go (default: a scratch prefix)
 //        [--read-devices 0,0]    read filter over several contexts (one per listed HIP ordinal; repeats allowed)
+//        [--devices 0,0]         the assembly scan over several contexts: every batch of segments cut into one shard per context
 //        [--reads-per-batch n]   reads per GPU batch of --fastq-subset / --bam-subset (test hook)
 //        [--bam-chunk-bytes n]   uncompressed BAM bytes inflated at a time by --bam-subset (test hook; at least 1 MiB)
 //        [--no-stream]           readFasta, then walkPaths, then writeBEDFiles (default: the three overlap in
@@ -34,7 +35,7 @@ int main(int argc, char **argv) {
     size_t fastqBlock = 512u << 20, readsPerBatch = 1u << 20, groupBytes = size_t(256) << 20, pieceBytes = size_t(4) << 20, bamChunk = size_t(256) << 20;
     bool stream = true;
     int textPieces = -1;
-    std::vector<int> readDevices;
+    std::vector<int> readDevices, scanDevices;
     std::string bamList;
     std::vector<std::string> rawPatterns;
     bool hasPatterns = false;
@@ -57,6 +58,11 @@ int main(int argc, char **argv) {
             std::istringstream ds(val());
             std::string d;
             while (std::getline(ds, d, ',')) if (!d.empty()) readDevices.push_back(std::stoi(d));
+        }
+        else if (a == "--devices") {
+            std::istringstream ds(val());
+            std::string d;
+            while (std::getline(ds, d, ',')) if (!d.empty()) scanDevices.push_back(std::stoi(d));
         }
         else if (a == "-o" || a == "-j") (void)val();
         else if (a == "-c") canonical = val();
@@ -135,7 +141,7 @@ int main(int argc, char **argv) {
             fprintf(stderr, "FASTQ subset: kept %llu of %llu reads.\n", (unsigned long long)r.kept, (unsigned long long)r.total);
             return 0;
         }
-        Teloscope teloscope(ui);
+        Teloscope teloscope(ui, scanDevices);
         teloscope.bindThreadToDevice();                           // reader, scan and writer threads start from here: the GPU's NUMA node
 
         const bool timing = getenv("TS_TIMING") != nullptr;      // stage times to stderr

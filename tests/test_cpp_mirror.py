@@ -37,7 +37,10 @@ def test_cpp_mirror_builds_and_refuses_without_gpu(cli):
 
 
 @pytest.mark.gpu
-def test_cpp_mirror_replays_all_legacy_manifests(cli, tmp_path):
+@pytest.mark.parametrize("devices", ["", "0,0", "0,0,0"], ids=["D1", "D2", "D3"])
+def test_cpp_mirror_replays_all_legacy_manifests(cli, tmp_path, devices):
+    """D2 / D3: the assembly scan over two / three contexts (here on one GPU) — Teloscope(ui, devices), every batch of
+    segments cut into one shard per context (ts_scan_segments_multi) — must print what one context prints."""
     failures = []
     for path in LEGACY:
         m = H.load_manifest(path)
@@ -46,6 +49,8 @@ def test_cpp_mirror_replays_all_legacy_manifests(cli, tmp_path):
             if tok.startswith("testFiles/"):
                 tok = H.golden_path(tok)                      # .fa and .fa.gz alike (zlib in readFasta)
             args.append(tok)
+        if devices:
+            args += ["--devices", devices]
         r = subprocess.run([cli] + args, capture_output=True, text=True, timeout=120)
         if r.returncode != 0 or r.stdout.split("\n") != m["expected"].split("\n"):
             failures.append((os.path.basename(path), r.returncode, r.stderr[-200:]))
@@ -114,3 +119,30 @@ def test_fastq_reader_block_boundaries(cli, name, block):
         assert got.returncode == 0, got.stderr
         assert got.stdout == ref.stdout
         assert got.stderr.splitlines()[-1] == ref.stderr.splitlines()[-1]        # kept N of M reads
+
+
+SUFFIXES = ["_window_repeat_density.bedgraph", "_window_canonical_ratio.bedgraph", "_window_strand_ratio.bedgraph",
+            "_window_gc.bedgraph", "_window_entropy.bedgraph", "_canonical_matches.bed", "_noncanonical_matches.bed",
+            "_terminal_telomeres.bed", "_interstitial_telomeres.bed", "_gaps.bed", "_report.tsv"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", ["-r -g -e -m -i -w 1000 -s 500 -t 3000", "-r -g -e -i", "-r -m -t 20000"])
+def test_output_files_do_not_depend_on_the_number_of_devices(cli, tmp_path, flags):
+    """Every output file of a run over a real 4.2 Mb chromosome (windows, match BEDs, blocks, report) byte for byte the
+    same from one context and from two and three (a boundary of the split falls inside the chromosome; -t 3000 lets it
+    fall anywhere but the outermost tiles)."""
+    src = H.golden_path("testFiles/bTaeGut7_chr33_mat.fa.gz")
+    outs = {}
+    for devices in ("", "0,0", "0,0,0"):
+        base = str(tmp_path / ("run" + devices.replace(",", "")))
+        args = [cli, "-f", src] + shlex.split(flags) + ["--out-base", base] + (["--devices", devices] if devices else [])
+        r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        outs[devices] = (r.stdout, {sfx: open(base + sfx, "rb").read() if os.path.exists(base + sfx) else None for sfx in SUFFIXES})
+    ref = outs[""]
+    assert any(v for v in ref[1].values())
+    for devices in ("0,0", "0,0,0"):
+        assert outs[devices][0] == ref[0], devices
+        for sfx in SUFFIXES:
+            assert outs[devices][1][sfx] == ref[1][sfx], (devices, sfx)
