@@ -259,7 +259,8 @@ typedef struct ts_batch_info {
     uint64_t n_tiles;
     uint64_t match_capacity;    /* match records the device buffer can hold */
     uint64_t n_matches;         /* valid after ts_batch_sync() */
-    uint64_t algorithmic_bytes; /* 1 B/base + 32 B/window + 4 B/match (after sync) */
+    uint64_t algorithmic_bytes; /* window scan: 1 B/base + 32 B/window + 4 B/match (after sync); tips-only / read batch:
+                                   1 B per scanned base + 1 bit per segment (its match stream is an intermediate) */
     double   last_kernel_ms;    /* HIP-event time of the last scan (after sync) */
     double   avg_kernel_ms;     /* mean HIP-event time of the scans enqueued since the previous sync
                                    (the latest 64 at most) */
@@ -451,6 +452,12 @@ int ts_scan_segments_multi(ts_ctx *const *ctxs, size_t n_ctx, const ts_segment_i
  * context and scanned on `stream` (ts_batch_scan), writes pass[i] (one byte per read, device memory) asynchronously
  * on the same stream; the match stream never leaves the device. */
 int ts_batch_read_pass(ts_batch *b, void *d_pass, void *stream);
+/* The scan may have overflowed a wave's record region (tiles are taken on demand, so the per-wave fill differs from launch
+ * to launch: a launch that fitted, even one ts_batch_sync vouched for, says nothing about the next).  ts_batch_read_pass
+ * then judges NOTHING — d_pass keeps what it held — and raises a flag on the device that stays up until it is read here:
+ * *overflowed = 1 if any pass since the last call was skipped for that reason (then: ts_batch_sync, which regrows and
+ * rescans, and ts_batch_read_pass again).  Waits for the device. */
+int ts_batch_read_pass_status(ts_batch *b, int *overflowed);
 int ts_filter_reads_multi(ts_ctx *const *ctxs, size_t n_ctx, const char *const *seqs, const uint64_t *lens,
                           size_t n_reads, uint8_t *pass);
 

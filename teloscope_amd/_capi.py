@@ -132,7 +132,7 @@ SYMBOLS = [
     "ts_batch_export", "ts_batch_adopt", "ts_batch_tile_stats_ptr", "ts_filter_reads_multi", "ts_batch_read_pass",
     "ts_batch_wire16_ok", "ts_wire_widen_u16", "ts_takes_text_input", "ts_bind_thread_to_device",
     "ts_batch_shard_info", "ts_batch_restrict_shard", "ts_batch_set_shard_scale", "ts_batch_pack_shard",
-    "ts_shard_peek", "ts_shards_finalize", "ts_scan_segments_multi",
+    "ts_shard_peek", "ts_shards_finalize", "ts_scan_segments_multi", "ts_batch_read_pass_status",
 ]
 
 
@@ -247,6 +247,7 @@ def lib():
     L.ts_batch_wire16_ok.argtypes = [C.c_void_p]
     L.ts_wire_widen_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.ts_batch_read_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ts_batch_read_pass_status.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.ts_filter_reads_multi.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
                                         C.c_size_t, C.POINTER(C.c_uint8)]
     L.ts_batch_shard_info.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ShardInfo)]

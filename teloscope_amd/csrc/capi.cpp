@@ -921,8 +921,11 @@ int ts_batch_get_info(const ts_batch *b, ts_batch_info *info) {
     info->n_tiles = b->tiles.size();
     info->match_capacity = b->match_cap;
     info->n_matches = b->synced ? b->n_matches : 0;
-    // of the range the batch executes: the whole plan unless restricted
-    info->algorithmic_bytes = b->range_bases + 32ull * (b->win_hi - b->win_lo) + 4ull * info->n_matches;
+    // of the range the batch executes (the whole plan unless restricted), by SURVEY 8(d): a window scan reads 1 B per base and
+    // writes 32 B per window and 4 B per match; a tips-only / read batch reads 1 B per scanned base and what leaves it is one
+    // bit per segment (the pass bit of a read, the handful of blocks of a contig end) — its match stream is an intermediate
+    info->algorithmic_bytes = b->tips ? b->range_bases + (b->segs.size() + 7) / 8
+                                      : b->range_bases + 32ull * (b->win_hi - b->win_lo) + 4ull * info->n_matches;
     info->last_kernel_ms = b->last_ms;
     info->avg_kernel_ms = b->avg_ms;
     info->kernel_launches = b->avg_n;

@@ -310,7 +310,7 @@ int batch_read_pass_device(ts_batch *b, unsigned char *d_pass, hipStream_t st) {
     const size_t ns = b->segs.size();
     if (!ns) return TS_OK;
     const size_t off_in = (((ns + 1) * 4 + 15) & ~(size_t)15), off_len = off_in + ns * 8, off_long = off_len + ns * 8,
-                 off_count = (off_long + ns * 4 + 15) & ~(size_t)15, bytes = off_count + 16;      // + the list of long reads and its counter
+                 off_count = (off_long + ns * 4 + 15) & ~(size_t)15, off_flag = off_count + 16, bytes = off_flag + 16;   // + the list of long reads, its counter, the overflow flag
     if (!b->d_readtab.p) {
         std::vector<char> tab(bytes);
         for (size_t i = 0; i < ns; ++i) {
@@ -341,7 +341,9 @@ int batch_read_pass_device(ts_batch *b, unsigned char *d_pass, hipStream_t st) {
                                   (uint32_t)ns, &Q, d_pass, (uint32_t *)(dt + off_long), (uint32_t *)(dt + off_count),
                                   // the lean kernel: every segment terminal zone as a whole, and the records in the batch's own
                                   // regions (16-byte aligned, 16 bytes of slack behind them: whole aligned blocks can be fetched)
-                                  (b->all_terminal && !b->dense && ((uintptr_t)b->records_ptr() & 15u) == 0) ? 1 : 0, st);
+                                  (b->all_terminal && !b->dense && ((uintptr_t)b->records_ptr() & 15u) == 0) ? 1 : 0,
+                                  (const uint32_t *)b->d_fill.p, b->dense ? 0xFFFFFFFFu : b->region_cap, b->dense ? 0u : b->total_waves,
+                                  (uint32_t *)(dt + off_flag), st);
     if (e != 0) return c->fail(TS_ERR_HIP, "predicate kernel launch failed");
     return TS_OK;
 }
@@ -877,6 +879,24 @@ int ts_batch_read_pass(ts_batch *b, void *d_pass, void *stream) {
     DEVICE_TRY(c);
     if (!b->tips || !b->whole() || !b->scanned) return c->fail(TS_ERR_STATE, "ts_batch_read_pass needs a scanned, unrestricted tips-only batch");
     return batch_read_pass_device(b, (unsigned char *)d_pass, (hipStream_t)stream);
+}
+
+int ts_batch_read_pass_status(ts_batch *b, int *overflowed) {
+    if (!b || !overflowed) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    DEVICE_TRY(c);
+    *overflowed = 0;
+    if (!b->d_readtab.p) return TS_OK;                            // no pass was ever enqueued
+    const size_t ns = b->segs.size();
+    const size_t off_in = (((ns + 1) * 4 + 15) & ~(size_t)15), off_len = off_in + ns * 8, off_long = off_len + ns * 8,
+                 off_count = (off_long + ns * 4 + 15) & ~(size_t)15, off_flag = off_count + 16;
+    uint32_t flag = 0;
+    char *const dt = (char *)b->d_readtab.p;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(&flag, dt + off_flag, 4, hipMemcpyDeviceToHost));
+    if (flag) HIP_TRY(c, hipMemset(dt + off_flag, 0, 4));
+    *overflowed = flag ? 1 : 0;
+    return TS_OK;
 }
 
 int ts_filter_reads_multi(ts_ctx *const *ctxs, size_t n_ctx, const char *const *seqs, const uint64_t *lens,

@@ -341,7 +341,11 @@ __global__ __launch_bounds__(64, TS_PRED_WAVES)
 void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
                            const uint32_t *matches, const u64 nrec_limit, const uint32_t *seg_first_tile,
                            const u64 *seg_in_off, const u64 *seg_len, uint32_t nseg,
-                           const TsPredParams Q, unsigned char *pass, uint32_t *long_list, uint32_t *long_count) {
+                           const TsPredParams Q, unsigned char *pass, uint32_t *long_list, uint32_t *long_count,
+                           const uint32_t *overflow) {
+    // a wave's record region overflowed in the scan (ts_pred_guard): the directory promises records that were never
+    // stored — nothing is judged, the flag stays up for ts_batch_read_pass_status
+    if (*overflow) return;
     const uint32_t lane = threadIdx.x;                       // one wave per workgroup
     const uint32_t si = blockIdx.x * 64u + lane;
     const bool live = si < nseg;
@@ -396,25 +400,34 @@ void ts_terminal_predicate_long(const TsTile *tiles, const u64 *tile_off, const 
 }
 
 
+// Raises *flag (sticky) when a wave needed more records than its region holds: with tiles taken on demand the per-wave
+// fill differs from launch to launch, so a launch that fitted says nothing about the next.
+__global__ void ts_pred_guard(const uint32_t *wave_fill, uint32_t region_cap, uint32_t nwaves, uint32_t *flag) {
+    bool over = false;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nwaves; w += gridDim.x * blockDim.x) over |= wave_fill[w] > region_cap;
+    if (over) atomicOr(flag, 1u);
+}
+
 }  // namespace
 
 int ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,
                           const uint32_t *matches, unsigned long long nrec_limit, const uint32_t *seg_first_tile,
                           const unsigned long long *seg_in_off, const unsigned long long *seg_len, uint32_t nseg,
                           const TsPredParams *Q, unsigned char *pass, uint32_t *long_list, uint32_t *long_count, int all_terminal,
-                          void *stream) {
+                          const uint32_t *wave_fill, uint32_t region_cap, uint32_t nwaves, uint32_t *overflow, void *stream) {
     if (nseg == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(long_count, 0, 4, st);
     if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(ts_pred_guard, dim3(8), dim3(256), 0, st, wave_fill, region_cap, nwaves, overflow);
     if (all_terminal)
         hipLaunchKernelGGL((ts_terminal_predicate<true>), dim3((nseg + 63u) / 64u), dim3(64), 0, st,
                            tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
-                           long_list, long_count);
+                           long_list, long_count, (const uint32_t *)overflow);
     else
         hipLaunchKernelGGL((ts_terminal_predicate<false>), dim3((nseg + 63u) / 64u), dim3(64), 0, st,
                            tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
-                           long_list, long_count);
+                           long_list, long_count, (const uint32_t *)overflow);
     const uint32_t grid = nseg < 8192u ? nseg : 8192u;      // waves of the second kernel: it strides over the list
     hipLaunchKernelGGL(ts_terminal_predicate_long, dim3(grid), dim3(64), 0, st,
                        tiles, tile_off, tile_stats, matches, seg_first_tile, seg_in_off, *Q, pass,

@@ -245,10 +245,12 @@ int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_o
                            const uint32_t *matches, unsigned long long nrec_limit, const uint32_t *seg_first_tile,
                            const unsigned long long *seg_in_off, const unsigned long long *seg_len,
                            uint32_t nseg, const TsPredParams *Q, unsigned char *pass, uint32_t *long_list,
-                           uint32_t *long_count, int all_terminal, void *stream);
+                           uint32_t *long_count, int all_terminal, const uint32_t *wave_fill, uint32_t region_cap,
+                           uint32_t nwaves, uint32_t *overflow, void *stream);
                            // (nrec_limit: records that may be READ behind `matches` — the predicate fetches aligned 16-byte blocks;
                            //  long_list: nseg entries of scratch + long_count: one counter, for the reads a whole wave walks;
-                           //  all_terminal: no segment is longer than the terminal limit — every read batch — the lean kernel)
+                           //  all_terminal: no segment is longer than the terminal limit — every read batch — the lean kernel;
+                           //  wave_fill / region_cap / nwaves -> *overflow: raised, and nothing judged, when the scan overflowed a wave's region)
 // blockcall.hip: terminal walks per segment of `segs` (nseg entries; bounds: 2 x u64 per segment), then the interstitial
 // search over the batch's ntiles (range-local) tiles; seg_base = plan index of segs[0]'s segment; seg_out (nullable):
 // what a shard reports per segment

@@ -137,10 +137,40 @@ def test_bench_full_exchange_two_ranks_on_one_gpu_equals_single_gpu():
     assert cfg["summaries_only_variant"]["value"] > 0 and cfg["step_split"]["exchange_ms"] > 0
 
 
+def test_bench_read_shard_over_two_ranks_equals_one_rank_and_the_oracle():
+    """configs[3] in small (500 k reads, 7.5 Gb) through bench.py's own read-shard code: `--reads --gpus 2` (two rank
+    processes sharing this GPU, the pass bytes gathered over gloo in input order) against `--reads` on one rank — the same
+    pass bytes (the reference pins -j 1 == -j 8 the same way: validateFiles/fastq_subset_large_j1.tst / _j8.tst) — and both
+    against the oracle's ReadTelomereFilter::matches on a sample from both ends of the read set (--verify)."""
+    one = _bench("--reads", "--n-reads", "5e5", "--steps", "2", "--warmup", "1", "--verify", "--no-cpu-baseline")
+    two = _bench("--reads", "--n-reads", "5e5", "--steps", "2", "--warmup", "1", "--verify", "--no-cpu-baseline", "--gpus", "2")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["config"]["pass_bytes_sha1"] == two["config"]["pass_bytes_sha1"]
+    assert one["config"]["kept"] == two["config"]["kept"] > 2000
+    for o in (one, two):
+        assert o["verify"]["reads_checked_against_oracle"] > 100
+        assert 0.3 < o["roofline"]["frac"] < 1.0 and o["roofline"]["algorithmic_bytes"] < 1.001 * o["config"]["bases"] / o["n_gpus"] + 1e6
+
+
+def test_default_line_carries_the_read_filter_and_the_launch_protocol():
+    """What the driver's plain `python bench.py` prints, minus the slow CPU leg: the `reads` sub-record (configs[3] at
+    500 k reads, roofline over the whole step by 1 B/base + 1 bit/read, oracle-checked sample), the single-shot figures
+    beside the settled value, and the PCIe-inclusive legs incl. ts_scan_segments_multi."""
+    out = _bench("--steps", "5", "--warmup", "2", "--no-cpu-baseline")
+    lp = out["config"]["launch_protocol"]
+    assert lp["single_shot_ms"] > 0 and lp["first_scan_ms_incl_module_load_and_allocation"] >= lp["single_shot_ms"] and lp["settled_ms_per_step"] == out["ms_per_step"]
+    r = out["reads"]
+    assert r["reads"] == 500_000 and r["kept"] >= r["planted_carriers"] > 2000 and r["oracle_checked_reads"] > 100
+    assert abs(r["roofline"]["algorithmic_bytes"] - (r["bases"] + 62500)) <= 1 and 0.2 < r["roofline"]["frac"] < 1.0
+    pc = out["pcie_inclusive"]
+    assert pc["writer_view_multi"]["n_ctx"] >= 1 and pc["writer_view_multi"]["matches"] == out["config"]["matches"]
+    assert 0 < pc["writer_view_multi"]["visible_matches"] < 0.05 * out["config"]["matches"]
+
+
 def test_bench_verify_full_size_configs1():
     """configs[1] at its real size: 3.0 Gb, 200 contigs, 91.5 M matches — per-contig counts and nucleotide totals
     against the independent torch computation."""
-    out = _bench("--verify", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e")
+    out = _bench("--verify", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-reads")
     assert out["config"]["bases"] == 3_000_000_000 and out["verify"]["contigs_checked"] == 200
     assert out["verify"]["matches_checked"] == out["config"]["matches"] > 90_000_000
 
@@ -148,7 +178,7 @@ def test_bench_verify_full_size_configs1():
 def test_bench_verify_full_size_configs4_plant():
     """configs[4] on one GPU: 15 Gb, -c CCCTAAA -w 2000 -s 1000 (k = 7), ~15 M windows — the same properties."""
     out = _bench("--verify", "--gbases", "15", "--contigs", "521", "--flags", "-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i",
-                 "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", timeout=1500)
+                 "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-reads", timeout=1500)
     assert out["config"]["bases"] == 15_000_000_000 and out["verify"]["contigs_checked"] == 521
     assert out["config"]["windows"] > 14_000_000 and out["verify"]["matches_checked"] == out["config"]["matches"]
 
