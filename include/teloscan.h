@@ -191,8 +191,12 @@ int  ts_expand_patterns(const char *raw_csv, int edit_distance, const char *cano
 void ts_free_patterns(ts_pattern *p);
 
 /* ---- context: the Teloscope object (ctor include/teloscope.h:241-247). Builds the
- *      k-mer match tables on the device.  Thread-safe for concurrent scan/filter calls
- *      (calls are serialised on an internal mutex; results are independent of call order). */
+ *      k-mer match tables on the device.  Thread-safe for concurrent scan/filter calls, and made for them: the reference
+ *      calls scanSegment / matches from all its pool workers at once (src/input.cpp:977, :786, src/bam.cpp:217-220), and
+ *      calls that arrive while the device is busy are COALESCED — the next run takes every waiting call of one kind
+ *      (ts_scan_segments, ts_scan_segments_blocks, ts_filter_reads; full scans and tips-only apart) as one batch and hands
+ *      each caller its own results.  Sixty-four threads with one segment each cost about what one call with sixty-four
+ *      segments costs; results never depend on who was merged with whom. */
 ts_ctx *ts_create(const ts_params *params, const ts_pattern *patterns, size_t n_patterns);
 void    ts_destroy(ts_ctx *ctx);
 /* 1 if full scans with this (window, step, patterns) run on the tiled uniform-k kernel,

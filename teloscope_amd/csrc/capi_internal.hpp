@@ -5,7 +5,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -133,8 +135,15 @@ struct ts_ctx {
 
     std::mutex down_mtx;            // one download (pinned landing area + its stream) at a time
     mutable std::mutex err_mtx;
-    std::mutex api_mtx;             // ts_scan_segments / ts_scan_segments_blocks / ts_filter_reads run one at a time per context
-                                    // (they share the pinned rings and streams; results never depend on call order)
+    std::mutex api_mtx;             // one pipeline run at a time per context (the runs share the pinned rings and streams)
+    // Concurrent callers are COALESCED, not queued one behind the other (the reference calls scanSegment / matches
+    // concurrently from its pool workers, src/input.cpp:977, :786): a call that arrives while a run is in flight waits in
+    // `sq`; whoever finds no run in flight becomes the leader, takes every waiting call of one kind, runs them as ONE
+    // batch and hands each caller its slice (pipeline.cpp: submit_pipeline)
+    std::mutex sq_mtx;
+    std::condition_variable sq_cv;
+    std::deque<struct SubmitReq *> sq;
+    bool sq_leader = false;
     int fail(int code, const std::string &msg) const { std::lock_guard<std::mutex> g(err_mtx); error = msg; return code; }
 };
 

@@ -518,6 +518,98 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
     return first_err.load();
 }
 
+// ---------------------------------------------------------------------------------------- coalescing of concurrent callers
+}  // namespace
+struct SubmitReq {
+    int mode; bool tips;
+    const std::vector<Item> *items;
+    ts_segment_out *out; ts_segment_counts *counts; uint8_t *pass;
+    int rc = TS_OK; bool done = false;
+    std::string error;
+};
+namespace {
+
+// One pipeline run for the requests of `group` (all of one mode and kind): their items back to back, every caller's slice of
+// the results to its own arrays.  When the merged run fails and more than one caller is in it, each request is run on its
+// own, so that only the call that brought the bad input fails.
+void run_group(ts_ctx *ctx, std::vector<SubmitReq *> &group) {
+    std::lock_guard<std::mutex> api(ctx->api_mtx);
+    const Mode mode = (Mode)group[0]->mode;
+    const bool tips = group[0]->tips;
+    if (group.size() == 1) {
+        SubmitReq &r = *group[0];
+        r.rc = run_pipeline(ctx, mode, tips, *r.items, r.out, r.counts, r.pass);
+        if (r.rc != TS_OK) r.error = ctx->error;
+        return;
+    }
+    size_t total = 0;
+    for (SubmitReq *r : group) total += r->items->size();
+    std::vector<Item> items;
+    items.reserve(total);
+    for (SubmitReq *r : group) items.insert(items.end(), r->items->begin(), r->items->end());
+    std::vector<ts_segment_out> out(mode == Mode::ReadPass ? 0 : total);
+    std::vector<ts_segment_counts> counts(mode == Mode::Blocks ? total : 0);
+    std::vector<uint8_t> pass(mode == Mode::ReadPass ? total : 0);
+    const int rc = run_pipeline(ctx, mode, tips, items, out.empty() ? nullptr : out.data(), counts.empty() ? nullptr : counts.data(),
+                                pass.empty() ? nullptr : pass.data());
+    if (rc == TS_OK) {
+        size_t at = 0;
+        for (SubmitReq *r : group) {
+            const size_t n = r->items->size();
+            if (r->out) std::memcpy(r->out, out.data() + at, n * sizeof(ts_segment_out));
+            if (r->counts) std::memcpy(r->counts, counts.data() + at, n * sizeof(ts_segment_counts));
+            if (r->pass) std::memcpy(r->pass, pass.data() + at, n);
+            r->rc = TS_OK;
+            at += n;
+        }
+        return;
+    }
+    if (!out.empty()) ts_free_segments(out.data(), out.size());
+    for (SubmitReq *r : group) {
+        r->rc = run_pipeline(ctx, mode, tips, *r->items, r->out, r->counts, r->pass);
+        if (r->rc != TS_OK) r->error = ctx->error;
+    }
+}
+
+// run_pipeline for a caller that does not hold the context's call lock: alone, it runs at once; beside others, it is merged
+// with them.  (A merged run is capped at ~8 GB of input: what is left waits for the next one.)
+int submit_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &items, ts_segment_out *out,
+                    ts_segment_counts *counts, uint8_t *pass) {
+    if (items.empty()) return TS_OK;
+    SubmitReq req{(int)mode, tips, &items, out, counts, pass, TS_OK, false, std::string()};
+    std::unique_lock<std::mutex> lk(ctx->sq_mtx);
+    ctx->sq.push_back(&req);
+    while (!req.done) {
+        if (ctx->sq_leader) { ctx->sq_cv.wait(lk); continue; }
+        ctx->sq_leader = true;
+        while (!ctx->sq.empty()) {
+            std::vector<SubmitReq *> group;
+            const int m = ctx->sq.front()->mode;
+            const bool t = ctx->sq.front()->tips;
+            uint64_t bytes = 0;
+            for (auto it = ctx->sq.begin(); it != ctx->sq.end();) {
+                SubmitReq *r = *it;
+                if (r->mode != m || r->tips != t) { ++it; continue; }
+                uint64_t b = 0;
+                for (const Item &x : *r->items) b += x.len;
+                if (!group.empty() && bytes + b > (8ull << 30)) { ++it; continue; }
+                bytes += b;
+                group.push_back(r);
+                it = ctx->sq.erase(it);
+            }
+            lk.unlock();
+            run_group(ctx, group);
+            lk.lock();
+            for (SubmitReq *r : group) r->done = true;
+            ctx->sq_cv.notify_all();
+        }
+        ctx->sq_leader = false;
+        ctx->sq_cv.notify_all();
+    }
+    if (req.rc != TS_OK && !req.error.empty()) ctx->fail(req.rc, req.error);
+    return req.rc;
+}
+
 // =========================================================================== general path
 // Parameter sets outside the tiled kernel's closed form (mixed-length pattern sets, pattern lengths above 8, or a
 // longest pattern exceeding min(step, window-step) where the reference's uint32 start index wraps): the general
@@ -745,13 +837,14 @@ std::vector<Item> items_of(const ts_segment_in *segs, const std::vector<size_t> 
 
 // scanSegment over the subset `which` (all full scans or all tips-only) on the tiled kernel
 int scan_subset(ts_ctx *ctx, Mode mode, const ts_segment_in *segs, const std::vector<size_t> &which, bool tips,
-                ts_segment_out *out, ts_segment_counts *counts) {
+                ts_segment_out *out, ts_segment_counts *counts, bool have_lock) {
     if (which.empty()) return TS_OK;
     const std::vector<Item> items = items_of(segs, which);
     // results land in arrays parallel to `which`, then move to their places
     std::vector<ts_segment_out> tmp(which.size());
     std::vector<ts_segment_counts> cnt(counts ? which.size() : 0);
-    int rc = run_pipeline(ctx, mode, tips, items, tmp.data(), counts ? cnt.data() : nullptr, nullptr);
+    int rc = have_lock ? run_pipeline(ctx, mode, tips, items, tmp.data(), counts ? cnt.data() : nullptr, nullptr)
+                       : submit_pipeline(ctx, mode, tips, items, tmp.data(), counts ? cnt.data() : nullptr, nullptr);
     if (rc != TS_OK) { ts_free_segments(tmp.data(), tmp.size()); return rc; }
     for (size_t i = 0; i < which.size(); ++i) {
         out[which[i]] = tmp[i];
@@ -760,8 +853,15 @@ int scan_subset(ts_ctx *ctx, Mode mode, const ts_segment_in *segs, const std::ve
     return TS_OK;
 }
 
-// ts_scan_segments without the per-context call lock (ts_filter_reads holds it when it comes here)
-int scan_segments_unlocked(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out) {
+// the general kernels run one call at a time (their groups are not merged across callers)
+int generic_locked(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<size_t> &which, bool tips, ts_segment_out *out, bool have_lock) {
+    if (have_lock) return scan_group_generic(ctx, segs, which, tips, out);
+    std::lock_guard<std::mutex> api(ctx->api_mtx);
+    return scan_group_generic(ctx, segs, which, tips, out);
+}
+
+// ts_scan_segments; have_lock: the caller holds the context's call lock (ts_filter_reads's general path, ts_scan_segments_multi)
+int scan_segments_impl(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out, bool have_lock) {
     for (size_t i = 0; i < n_segs; ++i) {
         std::memset(&out[i], 0, sizeof out[i]);
         if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
@@ -770,10 +870,10 @@ int scan_segments_unlocked(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs
     std::vector<size_t> full, tips;
     for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
     std::string why;
-    int rc = ts_full_scan_supported(ctx, why) ? scan_subset(ctx, Mode::Matches, segs, full, false, out, nullptr)
-                                              : scan_group_generic(ctx, segs, full, false, out);
-    if (rc == TS_OK) rc = ctx->fast_ok ? scan_subset(ctx, Mode::Matches, segs, tips, true, out, nullptr)
-                                       : scan_group_generic(ctx, segs, tips, true, out);
+    int rc = ts_full_scan_supported(ctx, why) ? scan_subset(ctx, Mode::Matches, segs, full, false, out, nullptr, have_lock)
+                                              : generic_locked(ctx, segs, full, false, out, have_lock);
+    if (rc == TS_OK) rc = ctx->fast_ok ? scan_subset(ctx, Mode::Matches, segs, tips, true, out, nullptr, have_lock)
+                                       : generic_locked(ctx, segs, tips, true, out, have_lock);
     if (rc != TS_OK) ts_free_segments(out, n_segs);
     return rc;
 }
@@ -781,7 +881,7 @@ int scan_segments_unlocked(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs
 }  // namespace
 
 int ts_scan_segments_unlocked(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out) {
-    return scan_segments_unlocked(ctx, segs, n_segs, out);
+    return scan_segments_impl(ctx, segs, n_segs, out, true);
 }
 
 // the pieces of the pipeline that ts_scan_segments_multi (multi.cpp) runs per context
@@ -797,8 +897,7 @@ extern "C" {
 
 int ts_scan_segments(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out) {
     if (!ctx || (n_segs && (!segs || !out))) return TS_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> api(ctx->api_mtx);
-    return scan_segments_unlocked(ctx, segs, n_segs, out);
+    return scan_segments_impl(ctx, segs, n_segs, out, false);
 }
 
 // scanSegment for callers that do not read the match vectors: scan, block calling and the per-segment
@@ -806,17 +905,17 @@ int ts_scan_segments(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_s
 int ts_scan_segments_blocks(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts_segment_out *out,
                             ts_segment_counts *counts) {
     if (!ctx || (n_segs && (!segs || !out))) return TS_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> api(ctx->api_mtx);
     for (size_t i = 0; i < n_segs; ++i) {
         std::memset(&out[i], 0, sizeof out[i]);
         if (counts) counts[i] = ts_segment_counts{0, 0, 0, 0};
         if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
+        if (segs[i].input_format > TS_INPUT_TEXT_PIECES) return ctx->fail(TS_ERR_INVALID_ARG, "unknown input_format");
     }
     std::vector<size_t> full, tips;
     for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
     // parameter sets outside the tiled kernel take the general path and drop the match vectors afterwards
     auto via_matches = [&](const std::vector<size_t> &which, bool tips_mode) -> int {
-        int rc = scan_group_generic(ctx, segs, which, tips_mode, out);
+        int rc = generic_locked(ctx, segs, which, tips_mode, out, false);
         if (rc != TS_OK) return rc;
         for (size_t i : which) {
             if (counts) {
@@ -834,8 +933,8 @@ int ts_scan_segments_blocks(ts_ctx *ctx, const ts_segment_in *segs, size_t n_seg
         return TS_OK;
     };
     std::string why;
-    int rc = ts_full_scan_supported(ctx, why) ? scan_subset(ctx, Mode::Blocks, segs, full, false, out, counts) : via_matches(full, false);
-    if (rc == TS_OK) rc = ctx->fast_ok ? scan_subset(ctx, Mode::Blocks, segs, tips, true, out, counts) : via_matches(tips, true);
+    int rc = ts_full_scan_supported(ctx, why) ? scan_subset(ctx, Mode::Blocks, segs, full, false, out, counts, false) : via_matches(full, false);
+    if (rc == TS_OK) rc = ctx->fast_ok ? scan_subset(ctx, Mode::Blocks, segs, tips, true, out, counts, false) : via_matches(tips, true);
     if (rc != TS_OK) ts_free_segments(out, n_segs);
     return rc;
 }
@@ -846,7 +945,6 @@ int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
     if (!ctx || (n_reads && (!seqs || !lens || !pass))) return TS_ERR_INVALID_ARG;
     if (!ctx->read_filter) return ctx->fail(TS_ERR_STATE, "context was not made by ts_create_read_filter");
     if (n_reads == 0) return TS_OK;
-    std::lock_guard<std::mutex> api(ctx->api_mtx);
     std::vector<Item> items(n_reads);
     for (size_t i = 0; i < n_reads; ++i) {
         uint64_t n = lens[i];
@@ -855,12 +953,11 @@ int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
         items[i] = Item{seqs[i], n, 0, TS_INPUT_BASES};
     }
     if (!ctx->fast_ok) {
-        // pattern sets outside the tiled kernel (mixed lengths, k > 8): general kernels + host block calling.
-        // (the call lock is already held: the unlocked form of ts_scan_segments)
+        // pattern sets outside the tiled kernel (mixed lengths, k > 8): general kernels + host block calling
         std::vector<ts_segment_in> in(n_reads);
         for (size_t i = 0; i < n_reads; ++i) { in[i] = ts_segment_in{}; in[i].seq = items[i].seq; in[i].len = items[i].len; in[i].abs_pos = 0; in[i].tips_only = 1; }
         std::vector<ts_segment_out> out(n_reads);
-        int rc = scan_segments_unlocked(ctx, in.data(), n_reads, out.data());
+        int rc = scan_segments_impl(ctx, in.data(), n_reads, out.data(), false);
         if (rc != TS_OK) return rc;
         for (size_t i = 0; i < n_reads; ++i) pass[i] = out[i].n_terminal_blocks != 0;
         ts_free_segments(out.data(), n_reads);
@@ -868,7 +965,7 @@ int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
     }
     // tiled path: whole-read tips scan, then the terminal-block predicate on the device; only one
     // byte per read comes back
-    return run_pipeline(ctx, Mode::ReadPass, true, items, nullptr, nullptr, pass);
+    return submit_pipeline(ctx, Mode::ReadPass, true, items, nullptr, nullptr, pass);
 }
 
 // ReadTelomereFilter::matches over a device-resident tips-only batch (reads already in HBM, scanned on `stream`):

@@ -514,7 +514,7 @@ def test_fuzz_parameters_and_degenerate_segments():
 
 def test_concurrent_calls_on_one_context():
     """The reference calls scanSegment concurrently from its thread-pool workers on one shared Teloscope
-    (src/input.cpp:719-724, 977); calls on one ts_ctx are serialised inside the library and must give what
+    (src/input.cpp:719-724, 977); concurrent calls on one ts_ctx are coalesced inside the library and must give what
     sequential calls give."""
     import threading
     opts = H.parse_cli("x.fa -w 1000 -s 500 -r -g -e -m -i")
@@ -540,6 +540,83 @@ def test_concurrent_calls_on_one_context():
     for job, res in zip(jobs, results):
         for (s, ap, tips), g in zip(job, res):
             assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="concurrent len=%d" % len(s))
+
+
+def test_sixty_four_concurrent_callers_cost_about_one_batched_call():
+    """64 threads, one segment each, on ONE context (the literal drop-in of the reference's pool workers):
+    every caller gets the oracle's result for its own segment, full scans, tips-only calls and read-filter calls mixed; and
+    the 64 one-segment calls together take about as long as one call with the 64 segments (serialised one behind the
+    other, as in round 2, they took 64 launches + 64 downloads)."""
+    import threading
+    import time
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import user_input
+    opts = H.parse_cli("x.fa -c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -i")
+    tel = ta.Teloscope(user_input(opts, device=0))
+    orac = OracleBackend(opts)
+    rng = np.random.default_rng(1234)
+    segs = [(seqgen.chromosome(rng, int(rng.integers(150_000, 260_000)), opts.canonical_fwd, opts.canonical_rev, n_its=2), 1000 * i, i % 8 == 7)
+            for i in range(64)]
+    exp = [orac.scan_segment(s, a, t) for s, a, t in segs]
+    tel.scanSegmentsBlocksOnly([(s, a) for s, a, t in segs if not t])                   # warm: buffers, pinned rings, code objects
+    full = [(s, a) for s, a, t in segs if not t]
+    tipsl = [(s, a) for s, a, t in segs if t]
+    best_batched = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        tel.scanSegmentsBlocksOnly(full)
+        tel.scanSegmentsBlocksOnly(tipsl, tipsOnly=True)
+        d = time.perf_counter() - t0
+        best_batched = d if best_batched is None else min(best_batched, d)
+    results, errors = [None] * 64, []
+    gate = threading.Barrier(64)
+
+    def work(i):
+        try:
+            s, a, t = segs[i]
+            gate.wait()
+            results[i] = tel.scanSegmentsBlocksOnly([(s, a)], tipsOnly=t)[0]
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(e)
+
+    best_threads = None
+    for _ in range(3):
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(64)]
+        for th in threads:
+            th.start()
+        t0 = time.perf_counter()
+        for th in threads:
+            th.join()
+        d = time.perf_counter() - t0
+        best_threads = d if best_threads is None else min(best_threads, d)
+        assert not errors, errors
+    from tests.backends import BLOCK_FIELDS, WINDOW_FIELDS
+    for i, (g, e) in enumerate(zip(results, exp)):
+        for f in WINDOW_FIELDS:
+            assert np.array_equal(g.windows[f], e["windows"][f]), (i, f)
+        for f in BLOCK_FIELDS:
+            assert np.array_equal(g.terminalBlocks[f], e["terminal_blocks"][f]), (i, f)
+            assert np.array_equal(g.interstitialBlocks[f], e["interstitial_blocks"][f]), (i, f)
+    print("64 one-segment calls: %.1f ms; the same segments in two batched calls: %.1f ms" % (best_threads * 1e3, best_batched * 1e3))
+    assert best_threads <= 3.0 * best_batched + 0.010, (best_threads, best_batched)
+    # the read filter's callers are coalesced the same way
+    ropts = H.parse_cli("--fastq-subset -l 42")
+    rf = ta.ReadTelomereFilter(user_input(ropts, device=0))
+    reads = [seqgen.chromosome(rng, int(rng.integers(2000, 20000)), n_its=1) if i % 3 else bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=9000)) for i in range(64)]
+    want = OracleReadFilter(ropts).filter(reads)
+    got = [None] * 64
+
+    def rwork(i):
+        gate.wait()
+        got[i] = rf.matchesBatch([reads[i]])[0]
+
+    threads = [threading.Thread(target=rwork, args=(i,)) for i in range(64)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert got == want
 
 
 TILINGS = ["16,1", "16,3", "12,5", "10,6", "10,3", "8,2", "4,7", "2,4", "1,1", "1,8"]      # 10 waves = two workgroups per CU

@@ -468,3 +468,42 @@ def test_bind_thread_to_device_node():
     assert res["rc"] in (0, 1) and res["after"] <= res["before"] and len(res["after"]) > 0
     if res["rc"] == 0:
         assert res["after"] == res["before"] or len(res["after"]) < len(res["before"])
+
+
+def test_read_pass_reports_a_scan_that_overflowed_its_record_regions():
+    """ts_batch_read_pass on a scan whose record regions were too small judges nothing and raises the flag that
+    ts_batch_read_pass_status reads; after ts_batch_sync (regrow + rescan) the same call gives the oracle's bits."""
+    import torch
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import user_input
+    opts = H.parse_cli("--fastq-subset -l 42")
+    rf = ta.ReadTelomereFilter(user_input(opts, device=0))
+    L = K.lib()
+    rng = np.random.default_rng(21)
+    reads = [seqgen.chromosome(rng, int(rng.integers(3000, 20000)), n_its=1) for _ in range(300)]
+    reads += [seqgen.repeat_array("TTAGGG", 2500).tobytes() for _ in range(40)]          # dense: 2 500 matches each
+    n = len(reads)
+    lens = (C.c_uint64 * n)(*[len(r) for r in reads])
+    b = L.ts_batch_create(rf._ctx.ptr, lens, None, n, 1, 4096)                          # room for 4 096 records in all
+    assert b
+    info = K.BatchInfo()
+    L.ts_batch_get_info(b, C.byref(info))
+    dev = torch.device("cuda", 0)
+    buf = torch.zeros(int(info.input_bytes), dtype=torch.uint8, device=dev)
+    for i, r in enumerate(reads):
+        off = int(L.ts_batch_segment_offset(b, i))
+        buf[off:off + len(r)] = torch.frombuffer(bytearray(r), dtype=torch.uint8).to(dev)
+    d_pass = torch.full((n + 16,), 7, dtype=torch.uint8, device=dev)
+    sptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    flag = C.c_int(0)
+    assert L.ts_batch_scan(b, C.c_void_p(buf.data_ptr()), sptr) == 0
+    assert L.ts_batch_read_pass(b, C.c_void_p(d_pass.data_ptr()), sptr) == 0
+    assert L.ts_batch_read_pass_status(b, C.byref(flag)) == 0 and flag.value == 1
+    assert (d_pass[:n] == 7).all()                                                       # nothing was judged
+    assert L.ts_batch_read_pass_status(b, C.byref(flag)) == 0 and flag.value == 0       # (read once)
+    assert L.ts_batch_sync(b) == 0                                                       # regrows the regions, rescans
+    assert L.ts_batch_read_pass(b, C.c_void_p(d_pass.data_ptr()), sptr) == 0
+    assert L.ts_batch_read_pass_status(b, C.byref(flag)) == 0 and flag.value == 0
+    assert [bool(x) for x in d_pass[:n].cpu().numpy()] == OracleReadFilter(opts).filter(reads)
+    L.ts_batch_destroy(b)
