@@ -20,6 +20,27 @@ class OracleBackend:
     def scan_segment(self, seq, abs_pos, tips_only):
         return self.oracle.scan_segment(seq, abs_pos, tips_only)
 
+    def with_ambiguous_orientation_from(self, product_patterns):
+        """Some pattern sets produce the same expanded k-mer from both strands (a k-mer that is its own reverse
+        complement, or k = 5 with two mismatches): which copy the reference keeps depends on how std::sort orders equal
+        keys (src/tools.cpp:275-280), i.e. is unspecified.  The oracle flags exactly those entries (`ambiguous`).  This
+        returns an oracle whose pattern list is ITS OWN expansion, with the orientation flag of the ambiguous entries — and
+        of those only — taken from the product; every unambiguous entry must agree between the two expansions, or the
+        call fails.  (Rounds 1-2 handed the oracle the product's whole list, which compared the product's orientation
+        flags with themselves.)"""
+        prod = {p: (f, c) for p, f, c in product_patterns}
+        assert sorted(prod) == sorted(p[0] for p in self.patterns), "product and oracle expand to different pattern sets"
+        merged = []
+        for p, f, c, amb in self.patterns:
+            pf, pc = prod[p]
+            assert pc == c, "canonical flag of %s differs" % p
+            if amb:
+                merged.append((p, pf, c))
+            else:
+                assert pf == f, "orientation of the unambiguous pattern %s differs: product %s, oracle %s" % (p, pf, f)
+                merged.append((p, f, c))
+        return OracleBackend(self.opts, patterns=merged)
+
     def empty_blocks(self):
         return np.zeros(0, dtype=self.po.BLOCK_DT)
 

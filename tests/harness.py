@@ -363,3 +363,85 @@ def load_manifest(path):
 def golden_path(rel):
     """testFiles/x -> tests/golden/testFiles/x"""
     return os.path.join(GOLDEN, rel)
+
+
+# ---------------------------------------------------------------------------------------- GFA mode (tips-only pins)
+def parse_gfa(path):
+    """Segments and paths of a GFA 1.x / 2.0 file, as far as the telomere annotation reads them: S lines (name ->
+    sequence, None for '*'; GFA 2 carries the length before the sequence), P lines (GFA 1: comma- or semicolon-separated
+    oriented segments) and O lines (GFA 2 ordered groups)."""
+    segs, paths = {}, []
+    with _open(path) as fh:
+        for line in fh:
+            if isinstance(line, bytes):
+                line = line.decode()
+            f = line.rstrip("\r\n").split("\t")
+            if f[0] == "S" and len(f) >= 3:
+                seq = f[3] if (len(f) >= 4 and f[2].isdigit()) else f[2]
+                segs[f[1]] = None if seq == "*" else seq
+            elif f[0] == "P" and len(f) >= 3:
+                comps = [c for c in f[2].replace(";", ",").split(",") if c]
+                paths.append((f[1], [(c[:-1], c[-1]) for c in comps]))
+            elif f[0] == "O" and len(f) >= 3:
+                comps = [c for c in f[2].split(" ") if c]
+                paths.append((f[1], [(c[:-1], c[-1]) for c in comps if c[-1] in "+-"]))
+    return segs, paths
+
+
+def gfa_annotations(backend, opts, gfa_path):
+    """The telomere nodes the reference's GFA mode adds (src/input.cpp:625-716 job resolution; walkSegment :835-881,
+    walkSegmentForPath :884-939): one tips-only scanSegment per terminal end, the terminal blocks at that end, the
+    longest one's length as the node's tl_bp.  Returns the set of (segment, terminal_role, path_orient, node_name, tl_bp)."""
+    segs, paths = parse_gfa(gfa_path)
+    rows = set()
+
+    def blocks_of(name):
+        seq = segs.get(name)
+        if seq is None:
+            return None, 0
+        res = backend.scan_segment(seq.upper().encode(), 0, True)          # unmaskSequence, then scanSegment(seq, 0, true)
+        return res["terminal_blocks"], len(seq)
+
+    if paths:
+        ends = set()
+        for _, comps in paths:
+            comps = [c for c in comps if c[0] in segs]
+            if comps:
+                ends.add((comps[0][0], comps[0][1], True))
+                ends.add((comps[-1][0], comps[-1][1], False))
+        for name, orient, is_first in sorted(ends):
+            blocks, n = blocks_of(name)
+            if blocks is None:
+                continue
+            scan_start = is_first == (orient == "+")
+            best = 0
+            for b in blocks:
+                at_start = int(b["start"]) <= n - (int(b["start"]) + int(b["block_len"]))
+                if at_start == scan_start:
+                    best = max(best, int(b["block_len"]))
+            if best:
+                role = "start" if is_first else "end"
+                rows.add((name, role, orient, "telomere_%s%s_%s" % (name, orient, role), best))
+    else:
+        for name in segs:
+            blocks, n = blocks_of(name)
+            if blocks is None:
+                continue
+            best = {}
+            for b in blocks:
+                at_start = int(b["start"]) <= n - (int(b["start"]) + int(b["block_len"]))
+                best[at_start] = max(best.get(at_start, 0), int(b["block_len"]))
+            for at_start, ln in best.items():
+                role = "start" if at_start else "end"
+                rows.add((name, role, ".", "telomere_%s+_%s" % (name, role), ln))
+    return rows
+
+
+def read_gfa_expectation(tsv_path):
+    rows = set()
+    with open(tsv_path) as fh:
+        header = fh.readline().rstrip("\n").split("\t")
+        for line in fh:
+            f = dict(zip(header, line.rstrip("\n").split("\t")))
+            rows.add((f["segment"], f["terminal_role"], f["path_orient"], f["node_name"], int(f["tl_bp"])))
+    return rows

@@ -83,6 +83,18 @@ def test_fastq_manifest_on_gpu(path):
                 assert sub == "FASTQ subset: kept %d of %d reads." % (kept, total)
 
 
+from tests.test_oracle_gfa_pins import GFA, gfa_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name,command,expect", GFA, ids=[g[0] for g in GFA])
+def test_gfa_telomere_lengths_on_gpu(name, command, expect):
+    """The reference's GFA manifests: per segment end the tips-only scan's terminal block length (tl_bp of
+    testFiles/expected/gfa/*.tsv), from the HIP path."""
+    opts = H.parse_cli(gfa_case(command))
+    got = H.gfa_annotations(ProductBackend(opts), opts, H.golden_path(opts.input))
+    assert got == H.read_gfa_expectation(H.golden_path(expect))
+
+
 @pytest.mark.parametrize("case", range(len(KATS)))
 def test_read_filter_kat_on_gpu(case):
     cli, seqs, expected = KATS[case]
@@ -135,8 +147,8 @@ def test_random_segments_match_oracle(cli):
     if orac.ambiguous:
         # a pattern that is its own reverse complement comes out of the expansion from both strands (TTAA and CTAG from
         # TTAG with one mismatch): which copy std::sort leaves first is unspecified in the reference; the
-        # oracle then takes the orientation flags the product's expansion chose
-        orac = OracleBackend(opts, patterns=prod.patterns)
+        # oracle takes the product's orientation flag for THOSE entries only, every other entry has to agree
+        orac = orac.with_ambiguous_orientation_from(prod.patterns)
     rng = np.random.default_rng(abs(hash(cli)) % (2 ** 32) if False else len(cli) * 7919 + 13)
     unit_f, unit_r = opts.canonical_fwd, opts.canonical_rev
     segs = []
@@ -497,7 +509,7 @@ def test_fuzz_parameters_and_degenerate_segments():
             # flag then depends on std::sort's order among equal keys; give the oracle
             # the pattern list the product built so that the scan itself is what is compared
             assert [p for p, _, _ in prod.patterns] == [p for p, _, _, _ in orac.patterns]
-            orac = OracleBackend(opts, patterns=prod.patterns)
+            orac = orac.with_ambiguous_orientation_from(prod.patterns)
         else:
             assert [(p, f) for p, f, _ in prod.patterns] == [(p, f) for p, f, _, _ in orac.patterns]
         segs = [(b"", 0), (c[:-1].encode(), 3), (b"N" * 500, 0), (b"A" * 3000, 9), (b"RYKMSWBDHV" * 40, 1),
