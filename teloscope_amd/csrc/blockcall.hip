@@ -380,28 +380,6 @@ __device__ char its_label(uint32_t fwd_count, uint32_t counts) {
     return 'b';
 }
 
-// One open chain of the interstitial search, wave-uniform (scalar registers): covered bases are counts x k.
-struct OpenChain {
-    bool open;
-    u64 start, prev;
-    uint32_t counts, fwd, canon;
-};
-
-// A closed chain -> a block, if it passes the reference's filters (src/teloscope.cpp:206-233): lane 0 writes it.
-__device__ __forceinline__ void its_close(const TsBlockCallParams &Q, const OpenChain &c, const TsShardSegIn &S, uint32_t lane) {
-    const uint32_t blen = (uint32_t)(c.prev + Q.k - c.start);
-    if (c.canon < 4u || blen < Q.its_min_len) return;
-    const char lab = its_label(c.fwd, c.counts);
-    if (lab == 'b' && c.fwd < 2u && (c.counts - c.fwd) < 2u) return;
-    if (lane != 0u) return;
-    TsDevBlock b;
-    b.start = c.start; b.block_len = blen; b.block_counts = c.counts;
-    b.forward_count = c.fwd; b.reverse_count = c.counts - c.fwd; b.canonical_count = c.canon;
-    b.non_canonical_count = c.counts - c.canon; b.total_covered = c.counts * Q.k; b.fwd_covered = c.fwd * Q.k;
-    b.can_covered = c.canon * Q.k; b.has_valid_or = 1; b.is_longest = 0; b.block_label = lab; b.reserved = 0;
-    emit_block(Q, b, S.seg, 2u, 0u, S.abs_pos);
-}
-
 // The value of the lane below (lane 0: 0) by DPP wave_shr:1.  The empty asm keeps it a v_mov_b32_dpp: folded into the
 // subtraction that follows (v_subrev_u32_dpp v, x, x wave_shr:1, what the DPP combiner makes of it) it came back wrong on gfx950.
 __device__ __forceinline__ uint32_t lane_below(uint32_t v) {
@@ -412,21 +390,74 @@ __device__ __forceinline__ uint32_t lane_below(uint32_t v) {
 
 __device__ __forceinline__ u64 low_bits(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
 
+// The chain that starts at record i0 of tile t0, walked record by record (64 per step) to its end — the first record more
+// than -k behind its predecessor, the first at or behind rb, or the end of the view — and, if it passes the reference's
+// filters (src/teloscope.cpp:206-233), its block.  Run by ts_interstitial_evaluate for the few chains the screening
+// kernel lists as holding four canonical matches; whole wave, lane 0 writes.  (Called from inside the screening kernel it
+// cost that kernel its registers: 99 VGPRs and a scratch frame for the call, 0.95 ms instead of 0.44.)
+__device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const TsShardSegIn &S, uint32_t t0, uint32_t i0, u64 rb) {
+    const uint32_t lane = threadIdx.x & 63u;
+    u64 start = 0, prev = 0;
+    uint32_t counts = 0, fwd = 0, canon = 0;
+    bool first = true, closed = false;
+    for (uint32_t t = t0; t < S.t1 && !closed; ++t) {
+        const uint32_t cnt = Q.tile_stats[4u * t];
+        if (cnt == 0u) continue;
+        const u64 rel = Q.tiles[t].in_off - S.in_off;
+        const uint32_t *src = Q.matches + Q.tile_off[t];
+        const uint32_t rb32 = rb <= rel ? 0u : (rb - rel > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(rb - rel));
+        for (uint32_t b0 = (t == t0 ? i0 : 0u); b0 < cnt && !closed; b0 += 64u) {
+            const uint32_t nvalid = cnt - b0 < 64u ? cnt - b0 : 64u;
+            const u64 VALID = low_bits(nvalid);
+            const uint32_t r = lane < nvalid ? src[b0 + lane] : 0u;
+            const uint32_t p32 = r >> 2;
+            const uint32_t below = lane_below(p32);
+            // records that end the chain: out of range, or too far behind their predecessor (lane 0: the last record of the
+            // step before; the chain's own first record never ends it)
+            u64 E = (__ballot(p32 >= rb32) | __ballot(p32 - below > Q.max_match_dist)) & VALID & ~1ull;
+            const u64 p0 = rel + (uint32_t)__builtin_amdgcn_readfirstlane((int)p32);
+            if (!first && ((uint32_t)__builtin_amdgcn_readfirstlane((int)p32) >= rb32 || p0 - prev > Q.max_match_dist)) E |= 1ull;
+            if (first && (uint32_t)__builtin_amdgcn_readfirstlane((int)p32) >= rb32) E |= 1ull;
+            const uint32_t stop = E ? (uint32_t)__builtin_ctzll(E) : nvalid;
+            const u64 take = low_bits(stop) & VALID;
+            if (take) {
+                if (first) { start = p0; first = false; }
+                counts += (uint32_t)__popcll(take);
+                fwd += (uint32_t)__popcll(__ballot((r & 2u) != 0u) & take);
+                canon += (uint32_t)__popcll(__ballot((r & 1u) != 0u) & take);
+                prev = rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(take));
+            }
+            if (E) closed = true;
+        }
+    }
+    if (first) return;
+    const uint32_t blen = (uint32_t)(prev + Q.k - start);
+    if (canon < 4u || blen < Q.its_min_len) return;
+    const char lab = its_label(fwd, counts);
+    if (lab == 'b' && fwd < 2u && (counts - fwd) < 2u) return;
+    if (lane != 0u) return;
+    TsDevBlock b;
+    b.start = start; b.block_len = blen; b.block_counts = counts;
+    b.forward_count = fwd; b.reverse_count = counts - fwd; b.canonical_count = canon;
+    b.non_canonical_count = counts - canon; b.total_covered = counts * Q.k; b.fwd_covered = fwd * Q.k;
+    b.can_covered = canon * Q.k; b.has_valid_or = 1; b.is_longest = 0; b.block_label = lab; b.reserved = 0;
+    emit_block(Q, b, S.seg, 2u, 0u, S.abs_pos);
+}
+
 // getInterstitialBlocks (src/teloscope.cpp:179-256) over the packed match stream, and — for a shard — the visible
 // match records of the tile on the way (the same records are in registers).
 //
-// One wave per tile, 64 records per step, no LDS, no per-record loop: a record opens a chain iff it is the first in
-// [fwdBoundary, revBoundary) or lies more than -k behind its predecessor; a ballot of those heads cuts the 64 records
-// into chains, and only when the step holds the four canonical matches a block needs does every head lane look at its
-// own chain (popcounts of the ballots under its lane range).  Everything else is scalar: the chain that is open at the
-// end of a step is carried on in wave-uniform registers.  A block belongs to the tile its chain STARTS in: records
-// ahead of a tile's first head belong to a chain of an earlier tile and are skipped; the chain that is open when the
-// tile's records end is followed through the tiles behind until a head closes it.
+// One wave per tile, 64 records per step, no LDS.  A record opens a chain iff it is the first in [fwdBoundary,
+// revBoundary) or lies more than -k behind its predecessor; a ballot of those heads cuts the 64 records into chains.
+// Almost no chain holds the four canonical matches a block needs, so the pass only SCREENS: all it keeps of the open
+// chain is where it starts and how many canonical matches the stream held before it (a running count); a chain that
+// closes with four or more is walked again, exactly, by its_evaluate — a few hundred times per genome.  The kernel is
+// bound by scalar issue (one scalar ALU per CU), and this is what a step costs least: one ballot of gap tests, one of
+// canonical flags, a dozen scalar bit operations.  A block belongs to the tile its chain STARTS in: records ahead of a
+// tile's first head belong to a chain of an earlier tile and are skipped; the chain that is open when the tile's
+// records end is followed (counting canonical matches) through the tiles behind until a head closes it.
 //
-// Measured on the 91.5 M records of configs[1] (profiles/r03/its_kernel_variants.txt): the LDS walker of rounds 1-2
-// 0.76 ms; this kernel 0.44 ms; a chunk of eight tiles per wave as one software-pipelined stream 0.70 ms (129 VGPRs);
-// one LANE per tile (a branch-free state machine per record, 128-byte bursts) 0.84 ms, 0.35 of it the loads alone:
-// sixty-four lanes reading sixty-four streams fetch every cache line many times over.
+// Measured on the 91.5 M records of configs[1]: profiles/r03/its_kernel_variants.txt.
 __global__ __launch_bounds__(256)
 void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base,
                             const u64 *bounds, uint32_t ntiles, TsShardSeg *seg_out, const TsVisibleOut W) {
@@ -436,7 +467,7 @@ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs,
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wave;
     if (tile >= ntiles) return;
     const uint32_t lane = threadIdx.x & 63u;
-    // A wave's time here is a chain of memory round trips: everything that does not depend on something else is
+    // A wave's time is also a chain of memory round trips: everything that does not depend on something else is
     // requested together — first the directory entries of the tile and its two neighbours, then the segment's entry, the
     // visible offsets, the record ahead of the tile, the tile's first eight batches and the first batch of the tile behind.
     const TsTile T = Q.tiles[tile];
@@ -464,7 +495,6 @@ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs,
         vis_on = W.off[i + 1] > vis_at && W.off[W.own1 - W.own0] <= W.capacity;
     }
     if ((!its_on && !vis_on) || cnt == 0u) return;
-    const SegView V = seg_view(Q, S);
     const u64 tile_rel = T.in_off - S.in_off;
     const uint32_t *src = Q.matches + off;
     const u64 z_lo = W.terminal_limit, z_hi = S.len > W.terminal_limit ? S.len - W.terminal_limit : 0ull;
@@ -474,18 +504,20 @@ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs,
     for (uint32_t q = 0; q < kGroup; ++q) recs[q] = 64u * q + lane < cnt ? src[64u * q + lane] : 0u;
     const uint32_t next_rec = (tn != tile && lane < next_cnt) ? Q.matches[next_off + lane] : 0u;
 
-    // the record ahead of the tile's first one (head test of that record)
+    // the record ahead of the tile's first one (head test of that record), as a position relative to the tile (negative)
     bool has_last = false;
-    u64 last_pos = 0;
+    int last_rel = 0;
     bool ooc = false;
+    const bool open_l = !(S.flags & TS_SEG_F_HAS_START), open_r = !(S.flags & TS_SEG_F_HAS_END);
     if (its_on) {
         bool found = false;
-        if (tile > V.t0 && prev_cnt) {                     // the usual case: the tile before holds it
+        u64 last_pos = 0;
+        if (tile > S.t0 && prev_cnt) {                     // the usual case: the tile before holds it
             const uint32_t r = Q.matches[prev_off + prev_cnt - 1u];
             last_pos = prev_in_off - S.in_off + (r >> 2);
             found = true;
         } else {
-            for (uint32_t t = tile; t > V.t0; --t) {
+            for (uint32_t t = tile; t > S.t0; --t) {
                 const uint32_t c = Q.tile_stats[4u * (t - 1u)];
                 if (c) {
                     const uint32_t r = Q.matches[Q.tile_off[t - 1u] + c - 1u];
@@ -496,15 +528,18 @@ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs,
             }
         }
         has_last = found && last_pos >= fb;                // (a record ahead of the search range does not chain)
-        if (!found && V.open_l && V.lo_rel > fb) {
+        // (farther than 2^30 ahead is as good as 2^30: -k is 16 bits)
+        last_rel = tile_rel - last_pos > 0x40000000ull ? -0x40000000 : -(int)(uint32_t)(tile_rel - last_pos);
+        if (!found && open_l && S.lo_rel > fb) {
             // nothing in the whole left context: a record further left is too far to chain if the context is wider than -k
             // (it is, shard.cpp sizes it so) — unless this tile's first record sits right at the view's edge
             const u64 p0 = tile_rel + ((uint32_t)__builtin_amdgcn_readfirstlane((int)recs[0]) >> 2);
-            if (p0 <= V.lo_rel + Q.max_match_dist) ooc = true;
+            if (p0 <= S.lo_rel + Q.max_match_dist) ooc = true;
         }
     }
-    OpenChain ch{false, 0, 0, 0, 0, 0};
-    bool finished = false;                                 // the search range ended inside this tile
+    // the open chain: the index of its first record in this tile, and the stream's canonical count ahead of it
+    bool open = false, finished = false;                   // finished: the search range ended inside this tile
+    uint32_t idx0 = 0, c0 = 0, ccum = 0;
     uint32_t vis_done = 0;
     // Everything a record is compared with, relative to the tile and in 32 bits (a tile's positions are < 2^16); and what
     // holds for the whole tile is decided once: nearly every tile lies wholly inside the search range and wholly outside
@@ -516,6 +551,15 @@ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs,
     const bool vis_all = tile_end - 1 <= z_lo || tile_rel >= z_hi, vis_canon = tile_rel > z_lo && tile_end <= z_hi;
     const uint32_t zlo32 = z_lo < tile_rel ? 0u : rel32(z_lo), zhi32 = rel32(z_hi);
     const bool zlo_none = z_lo < tile_rel;                 // no position of the tile is <= z_lo
+    const int kdist = (int)Q.max_match_dist;
+    // a chain with four canonical matches: listed for ts_interstitial_evaluate (past the list's capacity it is only counted:
+    // the evaluation kernel then reports an overflow, and the caller comes back with a longer list)
+    auto candidate = [&](uint32_t i0) {
+        if (lane == 0u) {
+            const uint32_t slot = atomicAdd(Q.n_cand, 1u);
+            if (slot < Q.cand_cap) { Q.cand[2u * slot] = tile; Q.cand[2u * slot + 1u] = i0; }
+        }
+    };
     auto batch = [&](uint32_t b0, uint32_t r) {
         const uint32_t nvalid = cnt - b0 < 64u ? cnt - b0 : 64u;
         const u64 VALID = low_bits(nvalid);
@@ -540,96 +584,148 @@ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs,
             // a record opens a chain iff its predecessor is out of range or more than -k ahead of it: the lane below, or for
             // lane 0 the last record of the batch / tile before
             const uint32_t below = lane_below(p32);
-            const u64 G = __ballot(p32 - below > Q.max_match_dist);
-            u64 H = R & (~(R << 1) | G);
-            if ((R & 1ull) && has_last && tile_rel + (uint32_t)__builtin_amdgcn_readfirstlane((int)p32) - last_pos <= Q.max_match_dist) H &= ~1ull;
-            const u64 Cn = CAN & R, F = __ballot((r & 2u) != 0u) & R;
-            const uint32_t first_head = H ? (uint32_t)__builtin_ctzll(H) : 64u;
-            // 1. the chain carried into this batch takes the records ahead of the first head
-            const u64 pre = R & low_bits(first_head);
-            if (ch.open && pre) {
-                ch.counts += (uint32_t)__popcll(pre); ch.fwd += (uint32_t)__popcll(pre & F); ch.canon += (uint32_t)__popcll(pre & Cn);
-                ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(pre));
-            }
-            if (ch.open && H != 0ull) { its_close(Q, ch, S, lane); ch.open = false; }
-            // 2. the chains that start in this batch
+            u64 H = R & (~(R << 1) | __ballot(p32 - below > Q.max_match_dist));
+            if ((R & 1ull) && has_last && (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)p32) - last_rel <= kdist) H &= ~1ull;
+            const u64 Cn = CAN & R;
             if (H != 0ull) {
-                const uint32_t top_head = 63u - (uint32_t)__builtin_clzll(H);
-                const u64 tail = R & ~low_bits(top_head);
-                // a block needs four canonical matches: only then does every head lane look at its own chain — its lane
-                // range runs to the next head — and the ones that are complete and qualify are written by their lanes
-                if (__popcll(Cn & ~(past ? 0ull : tail)) >= 4) {
+                const uint32_t first_head = (uint32_t)__builtin_ctzll(H), top_head = 63u - (uint32_t)__builtin_clzll(H);
+                const u64 ahead = low_bits(first_head), below_top = low_bits(top_head);
+                // the chain carried into this batch ends at the first head
+                if (open && ccum + (uint32_t)__popcll(Cn & ahead) - c0 >= 4u) candidate(idx0);
+                // the chains that start and end inside this batch: only when they hold four canonical matches between them
+                // does every head lane look at its own (its lane range runs to the next head)
+                const u64 inner = Cn & ~ahead & (past ? ~0ull : below_top);
+                if (__popcll(inner) >= 4) {
                     const u64 above = lane < 63u ? H >> (lane + 1u) : 0ull;
                     const uint32_t next = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 64u;   // the next head's lane
-                    const u64 mine = R & low_bits(next) & ~low_bits(lane);
-                    const uint32_t ncan = (uint32_t)__popcll(mine & Cn);
-                    const uint32_t last_lane = mine ? 63u - (uint32_t)__builtin_clzll(mine) : lane;
-                    const uint32_t p_last = (uint32_t)__shfl((int)p32, (int)last_lane);
-                    const bool complete = lane != top_head || past;      // the batch's last chain may go on in the next batch
-                    if (((H >> lane) & 1ull) && complete && ncan >= 4u) {
-                        OpenChain c{true, tile_rel + p32, tile_rel + p_last, (uint32_t)__popcll(mine), (uint32_t)__popcll(mine & F), ncan};
-                        its_close(Q, c, S, 0u);                           // (this lane writes it)
-                    }
+                    const bool mine4 = __popcll(Cn & low_bits(next) & ~low_bits(lane)) >= 4;
+                    u64 todo = __ballot(((H >> lane) & 1ull) && (lane != top_head || past) && mine4);
+                    for (; todo; todo &= todo - 1ull) candidate(b0 + (uint32_t)__builtin_ctzll(todo));
                 }
-                if (!past) {                                              // the last chain stays open
-                    ch.open = true;
-                    ch.start = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)top_head);
-                    ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(tail));
-                    ch.counts = (uint32_t)__popcll(tail); ch.fwd = (uint32_t)__popcll(tail & F); ch.canon = (uint32_t)__popcll(tail & Cn);
-                }
+                open = !past;                                             // the last head's chain stays open
+                idx0 = b0 + top_head;
+                c0 = ccum + (uint32_t)__popcll(Cn & below_top);
             }
+            ccum += (uint32_t)__popcll(Cn);
             has_last = true;
-            last_pos = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(R));
+            last_rel = (int)(uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(R));
         }
         if (past) {
-            if (ch.open) { its_close(Q, ch, S, lane); ch.open = false; }
+            if (open && ccum - c0 >= 4u) candidate(idx0);
+            open = false;
             finished = true;
         }
     };
-#pragma unroll
-    for (uint32_t q = 0; q < kGroup; ++q)
-        if (64u * q < cnt) batch(64u * q, recs[q]);
-    for (uint32_t b0 = 64u * kGroup; b0 < cnt; b0 += 64u)               // a dense tile: the rest, batch by batch
-        batch(b0, b0 + lane < cnt ? src[b0 + lane] : 0u);
-    // the chain that is still open belongs to this tile: follow it through the tiles behind until a head closes it
-    if (its_on && ch.open && !finished) {
-        bool closed = false;
-        auto follow = [&](u64 rel2, uint32_t c2, uint32_t b0, uint32_t r) {
-            const uint32_t nvalid = c2 - b0 < 64u ? c2 - b0 : 64u;
-            const u64 VALID = low_bits(nvalid);
-            const uint32_t p32 = r >> 2;
-            const uint32_t rb2 = rb <= rel2 ? 0u : (rb - rel2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(rb - rel2));
-            const u64 R = __ballot(p32 < rb2) & VALID;                   // (p >= fb: behind a record that was)
-            const bool past = R != VALID;
-            if (R != 0ull) {
-                const uint32_t below = lane_below(p32);
-                u64 H = R & (__ballot(p32 - below > Q.max_match_dist) | 1ull);
-                if ((R & 1ull) && rel2 + (uint32_t)__builtin_amdgcn_readfirstlane((int)p32) - last_pos <= Q.max_match_dist) H &= ~1ull;
-                const u64 pre = R & low_bits(H ? (uint32_t)__builtin_ctzll(H) : 64u);
-                if (pre) {
-                    const u64 Cn = __ballot((r & 1u) != 0u), F = __ballot((r & 2u) != 0u);
-                    ch.counts += (uint32_t)__popcll(pre); ch.fwd += (uint32_t)__popcll(pre & F); ch.canon += (uint32_t)__popcll(pre & Cn);
-                    ch.prev = rel2 + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(pre));
-                }
-                if (H != 0ull) closed = true;
-                last_pos = rel2 + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(R));
+    // The same step for the tiles that lie wholly inside the search range and wholly outside the terminal zone — all but a
+    // few per segment — where every valid record is in range and the visible ones are the canonical ones: straight-line
+    // scalar code (selects, no branch but the two rare ones), because scalar issue is what bounds this kernel.
+    auto fast_batch = [&](uint32_t b0, uint32_t r) {
+        const uint32_t nvalid = cnt - b0 < 64u ? cnt - b0 : 64u;
+        const u64 VALID = ~0ull >> (64u - nvalid);
+        const uint32_t p32 = r >> 2;
+        const u64 Cn = __ballot((r & 1u) != 0u) & VALID;
+        if (vis_on) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Cn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Cn, 0u));
+            if (r & 1u) {
+                if (W.rec_bytes == 2u) ((uint16_t *)W.dst)[vis_at + vis_done + rank] = (uint16_t)r;
+                else ((uint32_t *)W.dst)[vis_at + vis_done + rank] = r;
             }
-            if (past) closed = true;
-        };
-        for (uint32_t t = tile + 1u; t < V.t1 && !closed; ++t) {
+            vis_done += (uint32_t)__popcll(Cn);
+        }
+        if (!its_on) return;
+        const uint32_t below = lane_below(p32);
+        u64 H = VALID & (__ballot(p32 - below > Q.max_match_dist) | 1ull);
+        const int gap0 = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)p32) - last_rel;
+        H &= ~(u64)((has_last && gap0 <= kdist) ? 1u : 0u);
+        const bool any = H != 0ull;
+        const u64 ahead = (H - 1ull) & ~H;                                // the lanes ahead of the first head (all of them when there is none)
+        const uint32_t top_head = any ? 63u - (uint32_t)__builtin_clzll(H) : 0u;
+        const u64 below_top = (1ull << top_head) - 1ull;
+        const bool cand_carry = open && any && ccum + (uint32_t)__popcll(Cn & ahead) - c0 >= 4u;
+        const bool cand_inner = any && __popcll(Cn & ~ahead & below_top) >= 4;
+        if (cand_carry || cand_inner) {                                   // rare: a chain with four canonical matches ends in this batch
+            if (cand_carry) candidate(idx0);
+            if (cand_inner) {
+                const u64 above = lane < 63u ? H >> (lane + 1u) : 0ull;
+                const uint32_t next = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 64u;
+                const bool mine4 = __popcll(Cn & low_bits(next) & ~low_bits(lane)) >= 4;
+                u64 todo = __ballot(((H >> lane) & 1ull) && lane != top_head && mine4);
+                for (; todo; todo &= todo - 1ull) candidate(b0 + (uint32_t)__builtin_ctzll(todo));
+            }
+        }
+        open = any ? true : open;
+        idx0 = any ? b0 + top_head : idx0;
+        c0 = any ? ccum + (uint32_t)__popcll(Cn & below_top) : c0;
+        ccum += (uint32_t)__popcll(Cn);
+        has_last = true;
+        last_rel = (int)(uint32_t)__builtin_amdgcn_readlane((int)p32, (int)nvalid - 1);
+    };
+    if (all_in && (!vis_on || vis_canon)) {
+#pragma unroll
+        for (uint32_t q = 0; q < kGroup; ++q)
+            if (64u * q < cnt) fast_batch(64u * q, recs[q]);
+        for (uint32_t b0 = 64u * kGroup; b0 < cnt; b0 += 64u)           // a dense tile: the rest, batch by batch
+            fast_batch(b0, b0 + lane < cnt ? src[b0 + lane] : 0u);
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < kGroup; ++q)
+            if (64u * q < cnt) batch(64u * q, recs[q]);
+        for (uint32_t b0 = 64u * kGroup; b0 < cnt; b0 += 64u)
+            batch(b0, b0 + lane < cnt ? src[b0 + lane] : 0u);
+    }
+    // the chain that is still open belongs to this tile: follow it through the tiles behind until a head closes it
+    if (its_on && open && !finished) {
+        bool closed = false;
+        uint32_t canon = ccum - c0;
+        u64 last_abs = tile_rel + (uint32_t)last_rel;                      // (the open chain's last record lies in this tile)
+        for (uint32_t t = tile + 1u; t < S.t1 && !closed; ++t) {
             const bool pre_fetched = t == tn;
             const uint32_t c2 = pre_fetched ? next_cnt : Q.tile_stats[4u * t];
             if (c2 == 0u) continue;
             const u64 rel2 = (pre_fetched ? next_in_off : Q.tiles[t].in_off) - S.in_off;
             const uint32_t *src2 = Q.matches + (pre_fetched ? next_off : Q.tile_off[t]);
-            for (uint32_t b0 = 0; b0 < c2 && !closed; b0 += 64u)
-                follow(rel2, c2, b0, (pre_fetched && b0 == 0u) ? next_rec : (b0 + lane < c2 ? src2[b0 + lane] : 0u));
+            const uint32_t rb2 = rb <= rel2 ? 0u : (rb - rel2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(rb - rel2));
+            for (uint32_t b0 = 0; b0 < c2 && !closed; b0 += 64u) {
+                const uint32_t r = (pre_fetched && b0 == 0u) ? next_rec : (b0 + lane < c2 ? src2[b0 + lane] : 0u);
+                const uint32_t nvalid = c2 - b0 < 64u ? c2 - b0 : 64u;
+                const u64 VALID = low_bits(nvalid);
+                const uint32_t p32 = r >> 2;
+                const u64 R = __ballot(p32 < rb2) & VALID;               // (p >= fb: behind a record that was)
+                if (R != 0ull) {
+                    const uint32_t below = lane_below(p32);
+                    u64 H = R & (__ballot(p32 - below > Q.max_match_dist) | 1ull);
+                    if ((R & 1ull) && rel2 + (uint32_t)__builtin_amdgcn_readfirstlane((int)p32) - last_abs <= Q.max_match_dist) H &= ~1ull;
+                    const u64 pre = R & low_bits(H ? (uint32_t)__builtin_ctzll(H) : 64u);
+                    if (pre) {
+                        canon += (uint32_t)__popcll(__ballot((r & 1u) != 0u) & pre);
+                        last_abs = rel2 + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(pre));
+                    }
+                    if (H != 0ull) closed = true;
+                }
+                if (R != VALID) closed = true;                           // a record at or behind revBoundary
+            }
         }
         // the view ended first: the segment's end — or a neighbour's tiles, where the chain may go on
-        if (!closed && V.open_r && ch.prev + Q.max_match_dist >= V.hi_rel && V.hi_rel < rb) ooc = true;
-        else its_close(Q, ch, S, lane);
+        if (!closed && open_r && last_abs + Q.max_match_dist >= S.hi_rel && S.hi_rel < rb) ooc = true;
+        else if (canon >= 4u) candidate(idx0);
     }
     if (seg_out && ooc && lane == 0) atomicOr(&seg_out[si].flags, TS_SEG_F_CONTEXT);
+}
+
+// The listed chains, one wave each: walked exactly, filtered, written.  A list that overflowed is reported through the
+// block counter (more blocks than the buffer holds = "come back with more room": the callers' existing path).
+__global__ __launch_bounds__(256)
+void ts_interstitial_evaluate(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base, const u64 *bounds) {
+    const uint32_t n_all = *Q.n_cand;
+    const uint32_t n = n_all < Q.cand_cap ? n_all : Q.cand_cap;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_all > Q.cand_cap) atomicAdd(Q.n_blocks, Q.block_cap + 1u);
+    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave; i < n; i += gridDim.x * (blockDim.x >> 6)) {
+        const uint32_t tile = Q.cand[2u * i], i0 = Q.cand[2u * i + 1u];
+        const uint32_t si = Q.tiles[tile].seg - seg_base;
+        const TsShardSegIn S = segs[si];
+        its_evaluate(Q, S, tile, i0, bounds[2ull * si + 1]);
+    }
 }
 
 }  // namespace
@@ -641,8 +737,11 @@ int ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs,
     hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(256), 0, (hipStream_t)stream, *Q, segs, nseg, bounds, seg_out);
     TsVisibleOut W{};
     if (vis) W = *vis;
-    if ((with_its || W.off) && ntiles)
+    if ((with_its || W.off) && ntiles) {
         hipLaunchKernelGGL(ts_interstitial_blocks, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *Q,
                            segs, seg_base, (const u64 *)bounds, ntiles, seg_out, W);
+        hipLaunchKernelGGL(ts_interstitial_evaluate, dim3(256), dim3(256), 0, (hipStream_t)stream, *Q, segs, seg_base,
+                           (const u64 *)bounds);
+    }
     return (int)hipGetLastError();
 }

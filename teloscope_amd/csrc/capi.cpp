@@ -727,7 +727,7 @@ void ts_batch_destroy(ts_batch *b) {
         DeviceGuard g(c->device);
         for (DevBuf *d : {&b->d_in, &b->d_tiles, &b->d_windows, &b->d_matches, &b->d_tile_off, &b->d_stats, &b->d_fill, &b->d_tickets,
                           &b->d_segtab, &b->d_dense, &b->d_dense_base, &b->d_scan_tmp, &b->d_readtab, &b->d_shard_segs,
-                          &b->d_shard_bounds, &b->d_shard_tmp})
+                          &b->d_shard_bounds, &b->d_shard_tmp, &b->d_shard_cand})
             c->pool.give(std::move(*d));
         for (hipEvent_t e : b->evs)
             if (e) (void)hipEventDestroy(e);
@@ -1188,8 +1188,11 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
     char *const dt = (char *)d_tab.p;
     uint32_t cap = (uint32_t)std::min<uint64_t>(64ull * ns + 4096 + b->n_matches / 256, 1u << 26);
     bool done = false;
-    for (int attempt = 0; attempt < 2 && !done; ++attempt) {
-        HIP_TRY(c, c->pool.take((size_t)cap * sizeof(TsDevBlock), d_blocks));
+    for (int attempt = 0; attempt < 6 && !done; ++attempt) {
+        // (behind the blocks: the list of chains the interstitial screening hands to its evaluation kernel)
+        const uint32_t cand_cap = 2u * cap + 256u;
+        const size_t off_cand = (size_t)cap * sizeof(TsDevBlock);
+        HIP_TRY(c, c->pool.take(off_cand + (size_t)cand_cap * 8 + 16, d_blocks));
         HIP_TRY(c, hipMemcpyAsync(dt, tab.data(), off_bounds, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemsetAsync(dt + off_count, 0, 16, st));
         TsBlockCallParams Q{};
@@ -1200,6 +1203,9 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
         Q.blocks = (TsDevBlock *)d_blocks.p;
         Q.n_blocks = (uint32_t *)(dt + off_count);
         Q.block_cap = cap;
+        Q.cand = (uint32_t *)((char *)d_blocks.p + off_cand);
+        Q.n_cand = (uint32_t *)(dt + off_count) + 1;
+        Q.cand_cap = cand_cap;
         Q.terminal_limit = P.terminal_limit; Q.max_match_dist = P.max_match_dist;
         Q.min_block_len = P.min_block_len; Q.max_block_dist = P.max_block_dist;
         Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;
@@ -1217,8 +1223,8 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
         }
         done = true;
     }
-    // (block counts are deterministic: the second attempt is sized by the first one's count)
-    if (!done) return c->fail(TS_ERR_STATE, "device block calling overflowed its block buffer twice");
+    // (block counts are deterministic: an attempt is sized by the count of the one before)
+    if (!done) return c->fail(TS_ERR_STATE, "device block calling kept overflowing its block buffer");
     std::sort(blocks.begin(), blocks.end(), [](const TsDevBlock &x, const TsDevBlock &y) {
         if (x.seg != y.seg) return x.seg < y.seg;
         const uint32_t kx = x.kind == 2 ? 1 : 0, ky = y.kind == 2 ? 1 : 0;

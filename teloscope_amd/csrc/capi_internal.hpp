@@ -199,7 +199,7 @@ struct ts_batch {
     // a shard (ts_batch_restrict_shard): the range the batch executes is its OWNED tiles [own_lo, own_hi) plus context tiles
     uint32_t shard_parts = 0, shard_part = 0, shard_scale = 1;
     uint64_t own_lo = 0, own_hi = 0;
-    DevBuf d_shard_segs, d_shard_bounds, d_shard_tmp;
+    DevBuf d_shard_segs, d_shard_bounds, d_shard_tmp, d_shard_cand;
     ShardRange shard_r{};
     ShardLayout shard_L{};
     // caller-owned result buffers (ts_batch_bind_results / ts_batch_adopt); null = the batch's own

@@ -251,6 +251,13 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
         HIP_TRY(c, c->pool.take((size_t)std::max<uint32_t>(ns, 1) * 16, b->d_shard_bounds));
         HIP_TRY(c, c->pool.take((size_t)ts_k_shard_tmp_bytes(nown), b->d_shard_tmp));
     }
+    // the list of chains the interstitial screening hands to its evaluation kernel (+ its counter), sized with the blocks
+    const uint32_t cand_cap = 2u * L.block_capacity + 256u;
+    if (b->d_shard_cand.bytes < (size_t)cand_cap * 8 + 16) {
+        c->pool.give(std::move(b->d_shard_cand));
+        HIP_TRY(c, c->pool.take((size_t)cand_cap * 8 + 16, b->d_shard_cand));
+    }
+    HIP_TRY(c, hipMemsetAsync(b->d_shard_cand.p, 0, 16, (hipStream_t)stream));
     unsigned char *msg = (unsigned char *)d_msg;
     HIP_TRY(c, hipMemsetAsync(msg, 0, L.off_windows, st));               // header + per-segment entries
     const ts_params &P = c->params;
@@ -262,6 +269,9 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     Q.blocks = (TsDevBlock *)(msg + L.off_blocks);
     Q.n_blocks = &((TsShardHeader *)msg)->n_blocks;
     Q.block_cap = L.block_capacity;
+    Q.n_cand = (uint32_t *)b->d_shard_cand.p;
+    Q.cand = (uint32_t *)b->d_shard_cand.p + 4;
+    Q.cand_cap = cand_cap;
     Q.terminal_limit = P.terminal_limit; Q.max_match_dist = P.max_match_dist;
     Q.min_block_len = P.min_block_len; Q.max_block_dist = P.max_block_dist;
     Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;

@@ -98,6 +98,9 @@ struct TsBlockCallParams {
     TsDevBlock *blocks;
     uint32_t *n_blocks;                 // atomic counter; > block_cap means overflow
     uint32_t block_cap;
+    uint32_t *cand;                     // chains the interstitial screening lists for exact evaluation: {tile, record index} pairs
+    uint32_t *n_cand;                   // atomic counter (zero at launch); > cand_cap: reported as a block overflow
+    uint32_t cand_cap;
     uint32_t terminal_limit, max_match_dist, min_block_len, max_block_dist, min_block_counts;
     float    min_block_density;
     uint32_t k;                         // match length (uniform)
