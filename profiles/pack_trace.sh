@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/pack_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export TS_BENCH_FORCE_STRONG=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --no-cpu-baseline --no-e2e --steps 20 --warmup 5 > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --no-cpu-baseline --no-e2e --steps 20 --warmup 5 $BENCH_ARGS > $OUT/trace.log 2>&1
 f=$(find $OUT/trace -name '*kernel_stats.csv' | head -1)
 python3 - "$f" > $OUT/kernel_stats.txt <<'PY'
 import csv, sys

@@ -730,18 +730,31 @@ void ts_interstitial_evaluate(const TsBlockCallParams Q, const TsShardSegIn *seg
 
 }  // namespace
 
+// The two halves of block calling, for a caller that runs the terminal walks on a stream of their own (shard.cpp): the
+// walks are one latency-bound wave per segment end, and nothing but the interstitial search waits for them.
+int ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, unsigned long long *bounds,
+                         TsShardSeg *seg_out, void *stream) {
+    if (nseg == 0) return 0;
+    hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(256), 0, (hipStream_t)stream, *Q, segs, nseg, bounds, seg_out);
+    return (int)hipGetLastError();
+}
+
+int ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
+                             const unsigned long long *bounds, TsShardSeg *seg_out, const TsVisibleOut *vis, void *stream) {
+    if (nseg == 0 || ntiles == 0) return 0;
+    TsVisibleOut W{};
+    if (vis) W = *vis;
+    hipLaunchKernelGGL(ts_interstitial_blocks, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *Q,
+                       segs, seg_base, (const u64 *)bounds, ntiles, seg_out, W);
+    hipLaunchKernelGGL(ts_interstitial_evaluate, dim3(256), dim3(256), 0, (hipStream_t)stream, *Q, segs, seg_base,
+                       (const u64 *)bounds);
+    return (int)hipGetLastError();
+}
+
 int ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
                            uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its,
                            const TsVisibleOut *vis, void *stream) {
-    if (nseg == 0) return 0;
-    hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(256), 0, (hipStream_t)stream, *Q, segs, nseg, bounds, seg_out);
-    TsVisibleOut W{};
-    if (vis) W = *vis;
-    if ((with_its || W.off) && ntiles) {
-        hipLaunchKernelGGL(ts_interstitial_blocks, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *Q,
-                           segs, seg_base, (const u64 *)bounds, ntiles, seg_out, W);
-        hipLaunchKernelGGL(ts_interstitial_evaluate, dim3(256), dim3(256), 0, (hipStream_t)stream, *Q, segs, seg_base,
-                           (const u64 *)bounds);
-    }
-    return (int)hipGetLastError();
+    int e = ts_k_launch_terminal(Q, segs, nseg, bounds, seg_out, stream);
+    if (e == 0 && (with_its || (vis && vis->off))) e = ts_k_launch_interstitial(Q, segs, nseg, seg_base, ntiles, bounds, seg_out, vis, stream);
+    return e;
 }

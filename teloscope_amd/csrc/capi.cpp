@@ -731,6 +731,9 @@ void ts_batch_destroy(ts_batch *b) {
             c->pool.give(std::move(*d));
         for (hipEvent_t e : b->evs)
             if (e) (void)hipEventDestroy(e);
+        if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+        if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+        if (b->side_stream) (void)hipStreamDestroy(b->side_stream);
     }
     delete b;
 }

@@ -202,6 +202,8 @@ struct ts_batch {
     DevBuf d_shard_segs, d_shard_bounds, d_shard_tmp, d_shard_cand;
     ShardRange shard_r{};
     ShardLayout shard_L{};
+    hipStream_t side_stream = nullptr;          // ts_batch_pack_shard: the terminal walks run beside the counting / packing kernels
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // caller-owned result buffers (ts_batch_bind_results / ts_batch_adopt); null = the batch's own
     uint32_t *ext_windows = nullptr, *ext_stats = nullptr;
     const uint32_t *ext_dense = nullptr;

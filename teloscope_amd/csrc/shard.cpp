@@ -251,13 +251,18 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
         HIP_TRY(c, c->pool.take((size_t)std::max<uint32_t>(ns, 1) * 16, b->d_shard_bounds));
         HIP_TRY(c, c->pool.take((size_t)ts_k_shard_tmp_bytes(nown), b->d_shard_tmp));
     }
-    // the list of chains the interstitial screening hands to its evaluation kernel (+ its counter), sized with the blocks
+    // the list of chains the interstitial screening hands to its evaluation kernel, sized with the blocks (its counter lives in
+    // a reserved word of the header: cleared with it, overwritten by the header kernel at the end)
     const uint32_t cand_cap = 2u * L.block_capacity + 256u;
     if (b->d_shard_cand.bytes < (size_t)cand_cap * 8 + 16) {
         c->pool.give(std::move(b->d_shard_cand));
         HIP_TRY(c, c->pool.take((size_t)cand_cap * 8 + 16, b->d_shard_cand));
     }
-    HIP_TRY(c, hipMemsetAsync(b->d_shard_cand.p, 0, 16, (hipStream_t)stream));
+    if (!b->side_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    }
     unsigned char *msg = (unsigned char *)d_msg;
     HIP_TRY(c, hipMemsetAsync(msg, 0, L.off_windows, st));               // header + per-segment entries
     const ts_params &P = c->params;
@@ -269,8 +274,8 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     Q.blocks = (TsDevBlock *)(msg + L.off_blocks);
     Q.n_blocks = &((TsShardHeader *)msg)->n_blocks;
     Q.block_cap = L.block_capacity;
-    Q.n_cand = (uint32_t *)b->d_shard_cand.p;
-    Q.cand = (uint32_t *)b->d_shard_cand.p + 4;
+    Q.n_cand = (uint32_t *)&((TsShardHeader *)msg)->reserved[0];
+    Q.cand = (uint32_t *)b->d_shard_cand.p;
     Q.cand_cap = cand_cap;
     Q.terminal_limit = P.terminal_limit; Q.max_match_dist = P.max_match_dist;
     Q.min_block_len = P.min_block_len; Q.max_block_dist = P.max_block_dist;
@@ -303,12 +308,24 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     H.window_bytes = L.window_bytes; H.n_windows = L.n_windows; H.msg_bytes = L.bytes;
     // visible records per owned tile and their places; then the terminal walks and the interstitial pass, which also
     // writes the visible records (it reads the whole stream anyway); then the window records and the header
+    // The terminal walks (one latency-bound wave per segment end, ~60 us whatever the shard's size) run on a stream of their
+    // own beside the counting, the prefix sum and the window packing; the interstitial pass needs both (the bounds, and
+    // where every tile's visible records go) and joins them.
+    HIP_TRY(c, hipEventRecord(b->ev_fork, st));
+    HIP_TRY(c, hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
+    if (ts_k_launch_terminal(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (unsigned long long *)b->d_shard_bounds.p,
+                             (TsShardSeg *)(msg + L.off_segs), b->side_stream) != 0)
+        return c->fail(TS_ERR_HIP, "terminal block kernel launch failed");
+    HIP_TRY(c, hipEventRecord(b->ev_join, b->side_stream));
     TsVisibleOut vis{};
     if (ts_k_launch_shard_count(&K, &H, b->d_shard_tmp.p, b->tips ? 0 : 1, &vis, stream) != 0)
         return c->fail(TS_ERR_HIP, "shard count kernel launch failed");
-    if (ts_k_launch_block_call(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
-                               (unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs), b->tips ? 0 : 1, &vis, stream) != 0)
-        return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
+    if (ts_k_launch_shard_windows(&K, &H, stream) != 0)
+        return c->fail(TS_ERR_HIP, "window packing kernel launch failed");
+    HIP_TRY(c, hipStreamWaitEvent(st, b->ev_join, 0));
+    if (!b->tips && ts_k_launch_interstitial(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
+                                             (const unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs), &vis, stream) != 0)
+        return c->fail(TS_ERR_HIP, "interstitial block kernel launch failed");
     if (ts_k_launch_shard_pack(&K, &H, b->d_shard_tmp.p, b->tips ? 0 : 1, stream) != 0)
         return c->fail(TS_ERR_HIP, "shard pack kernel launch failed");
     return TS_OK;

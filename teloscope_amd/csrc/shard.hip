@@ -173,15 +173,18 @@ int ts_k_launch_shard_count(const TsShardPackParams *P, const TsShardHeader *H, 
     return (int)hipGetLastError();
 }
 
-// Phase 2 (after block calling, which counted the blocks in the zeroed header and wrote the visible records): the packed
-// window records and the header.
-int ts_k_launch_shard_pack(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
-    const uint32_t nown = P->own1 - P->own0;
-    u64 *vis_off = (u64 *)((char *)tmp + shard_tmp_off(nown, 1));
+// The packed window records (independent of block calling).
+int ts_k_launch_shard_windows(const TsShardPackParams *P, const TsShardHeader *H, void *stream) {
     const u64 nwin = P->own_win1 - P->own_win0;
     if (nwin)
-        hipLaunchKernelGGL(ts_shard_pack_windows, dim3((unsigned)((nwin + 255ull) / 256ull)), dim3(256), 0, st, *P, H->window_bytes);
-    hipLaunchKernelGGL(ts_shard_header, dim3(1), dim3(256), 0, st, *P, *H, (const u64 *)((with_visible && nown) ? vis_off : nullptr));
+        hipLaunchKernelGGL(ts_shard_pack_windows, dim3((unsigned)((nwin + 255ull) / 256ull)), dim3(256), 0, (hipStream_t)stream, *P, H->window_bytes);
+    return (int)hipGetLastError();
+}
+
+// Last (after block calling, which counted the blocks in the zeroed header and wrote the visible records): the header.
+int ts_k_launch_shard_pack(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, void *stream) {
+    const uint32_t nown = P->own1 - P->own0;
+    u64 *vis_off = (u64 *)((char *)tmp + shard_tmp_off(nown, 1));
+    hipLaunchKernelGGL(ts_shard_header, dim3(1), dim3(256), 0, (hipStream_t)stream, *P, *H, (const u64 *)((with_visible && nown) ? vis_off : nullptr));
     return (int)hipGetLastError();
 }

@@ -261,8 +261,13 @@ int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_o
 int  ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
                             uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its,
                             const TsVisibleOut *vis, void *stream);
+int  ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, unsigned long long *bounds,
+                          TsShardSeg *seg_out, void *stream);
+int  ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
+                              const unsigned long long *bounds, TsShardSeg *seg_out, const TsVisibleOut *vis, void *stream);
 // shard.hip: packed window records, visible records + per-tile counts, and the header of a shard's message
 int  ts_k_launch_shard_count(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, TsVisibleOut *vis, void *stream);
+int  ts_k_launch_shard_windows(const TsShardPackParams *P, const TsShardHeader *H, void *stream);
 int  ts_k_launch_shard_pack(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, void *stream);
 unsigned long long ts_k_shard_tmp_bytes(uint32_t own_tiles);
 // exchange.hip: tile directory of a dense tile-ordered stream, and the export of a scan's records into one
