@@ -457,6 +457,10 @@ def run_scan(args, rank, local_rank, world, dev, backend):
     plan = D.ShardPlan(tel, lens, world=world if strong else 1)
     offsets = plan.segment_offsets()
     info = plan.info
+    # The scans run on a stream of their own, not on the null stream: work on the null stream does not overlap with work on
+    # other streams the way two ordinary streams overlap (the sharded step at the size of one of 8 ranks: 0.349 -> 0.283 ms
+    # with block calling + packing of step i beside the scan of step i + 1).
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     stream = torch.cuda.current_stream()
     sptr = C.c_void_p(stream.cuda_stream)
     xdev = dev if backend == "nccl" else torch.device("cpu")

@@ -294,15 +294,45 @@ __device__ __forceinline__ SegView seg_view(const TsBlockCallParams &Q, const Ts
                    !(S.flags & TS_SEG_F_HAS_START), !(S.flags & TS_SEG_F_HAS_END), S.lo_rel, S.hi_rel};
 }
 
-__global__ void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t nseg, u64 *bounds,
-                                   TsShardSeg *seg_out) {
-    // one workgroup of four waves per segment: all threads add up the segment's tile counts (a 250 Mb
-    // contig has ~35 k tiles), then wave 0 walks the forward list from the start while wave 1 walks
-    // the reverse list from the end.  A shard (seg_out != nullptr) walks a direction only when it owns that end of
-    // the segment; the bounds of the other end are the widest possible, which the receiver checks against what
-    // the shard that did walk it reports (shard.cpp: finalize).
-    __shared__ u64 part[5][256];
-    __shared__ uint32_t walk_flags;
+// Per segment: match / forward counts over all its tiles the batch scanned, and match / canonical / forward counts over its
+// OWNED tiles — five u64 per segment in `sums` (zero at launch).  One thread per tile; a wave whose tiles all belong to one
+// segment (nearly every wave) adds up first and issues five atomics.  No LDS (see exchange.hip).
+__global__ __launch_bounds__(256)
+void ts_segment_sums(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base, uint32_t ntiles, u64 *sums) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t si = 0xFFFFFFFFu;
+    u64 v[5] = {0, 0, 0, 0, 0};
+    if (t < ntiles) {
+        si = Q.tiles[t].seg - seg_base;
+        const uint4 st = *(const uint4 *)&Q.tile_stats[4ull * t];
+        const TsShardSegIn S = segs[si];
+        if (t >= S.t0 && t < S.t1) { v[0] = st.x; v[1] = st.z; }
+        if (t >= S.o0 && t < S.o1) { v[2] = st.x; v[3] = st.y; v[4] = st.z; }
+    }
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)si);
+    if (__ballot(si != s0) == 0ull) {
+        if (s0 == 0xFFFFFFFFu) return;
+        for (int f = 0; f < 5; ++f) {
+            u64 x = v[f];
+            for (int o = 32; o >= 1; o >>= 1) {
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), o);
+                x += ((u64)hi << 32) | lo;
+            }
+            if ((threadIdx.x & 63u) == 0u && x) atomicAdd(&sums[5ull * s0 + f], x);
+        }
+    } else if (si != 0xFFFFFFFFu) {
+        for (int f = 0; f < 5; ++f)
+            if (v[f]) atomicAdd(&sums[5ull * si + f], v[f]);
+    }
+}
+
+__global__ __launch_bounds__(128)
+void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t nseg, u64 *bounds,
+                        TsShardSeg *seg_out, const u64 *sums) {
+    // two independent waves per segment: wave 0 walks the forward list from the start, wave 1 the reverse list from the end.
+    // A shard (seg_out != nullptr) walks a direction only when it owns that end of the segment; the bounds of the other end
+    // are the widest possible, which the receiver checks against what the shard that did walk it reports (shard.cpp:
+    // finalize).  No LDS, no barrier: the waves share nothing (see exchange.hip for why that matters).
     const uint32_t si = blockIdx.x;
     if (si >= nseg) return;
     // (readfirstlane: told that the wave index is the same in all lanes, the compiler keeps the walk's state machine — ballots,
@@ -311,33 +341,7 @@ __global__ void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn
     const TsShardSegIn S = segs[si];
     const SegView V = seg_view(Q, S);
     const u64 n = S.len;
-    u64 total = 0, nfwd = 0, own = 0, own_can = 0, own_fwd = 0;
-    // (eight directory entries per thread in flight: a 250 Mb contig has ~22 k tiles, and one load per trip of the loop
-    // made this sum the longest part of the kernel)
-    for (uint32_t t8 = V.t0 + threadIdx.x; t8 < V.t1; t8 += 8u * blockDim.x) {
-        uint4 st[8];
-#pragma unroll
-        for (uint32_t q = 0; q < 8u; ++q) {
-            const uint32_t t = t8 + q * blockDim.x;
-            st[q] = t < V.t1 ? *(const uint4 *)&V.tile_stats[4ull * t] : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < 8u; ++q) {
-            const uint32_t t = t8 + q * blockDim.x;
-            total += st[q].x; nfwd += st[q].z;
-            if (t >= S.o0 && t < S.o1) { own += st[q].x; own_can += st[q].y; own_fwd += st[q].z; }
-        }
-    }
-    part[0][threadIdx.x] = total; part[1][threadIdx.x] = nfwd;
-    part[2][threadIdx.x] = own; part[3][threadIdx.x] = own_can; part[4][threadIdx.x] = own_fwd;
-    if (threadIdx.x == 0) walk_flags = 0;
-    __syncthreads();
-    for (uint32_t o = 128; o >= 1; o >>= 1) {
-        if (threadIdx.x < o)
-            for (int f = 0; f < 5; ++f) part[f][threadIdx.x] += part[f][threadIdx.x + o];
-        __syncthreads();
-    }
-    total = part[0][0]; nfwd = part[1][0];
+    const u64 total = sums[5ull * si], nfwd = sums[5ull * si + 1];
     uint32_t seq = 0;                                      // blocks are ordered by (direction, seq)
     if (wave == 0) {
         u64 fb = 0;
@@ -346,29 +350,27 @@ __global__ void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn
         if (walk) fb = terminal_direction(Q, V, S.seg, n, S.abs_pos, true, seq, lane, ooc);
         if (lane == 0) {
             bounds[2ull * si] = fb;
-            atomicOr(&walk_flags, (walk ? TS_SEG_F_FWD_WALKED : 0u) | (ooc ? TS_SEG_F_CONTEXT : 0u));
+            if (seg_out) {
+                TsShardSeg &o = seg_out[si];
+                o.fwd_boundary = fb;
+                o.n_matches = sums[5ull * si + 2]; o.n_canonical = sums[5ull * si + 3]; o.n_forward = sums[5ull * si + 4];
+                o.seen_matches = total; o.seen_forward = nfwd;
+                atomicOr(&o.flags, (S.flags & (TS_SEG_F_HAS_START | TS_SEG_F_HAS_END)) | (walk ? TS_SEG_F_FWD_WALKED : 0u) | (ooc ? TS_SEG_F_CONTEXT : 0u));
+            }
         }
-    } else if (wave == 1) {
+    } else {
         u64 rb = n;
         bool ooc = false;
         const bool walk = (S.flags & TS_SEG_F_HAS_END) && total - nfwd >= 2;
         if (walk) rb = terminal_direction(Q, V, S.seg, n, S.abs_pos, false, seq, lane, ooc);
         if (lane == 0) {
-            bounds[2ull * si + 1] = total >= 2 ? rb : 0;       // 0 disables the interstitial search
-            atomicOr(&walk_flags, (walk ? TS_SEG_F_REV_WALKED : 0u) | (ooc ? TS_SEG_F_CONTEXT : 0u));
+            const u64 rb_out = total >= 2 ? rb : 0;        // 0 disables the interstitial search
+            bounds[2ull * si + 1] = rb_out;
+            if (seg_out) {
+                seg_out[si].rev_boundary = rb_out;
+                atomicOr(&seg_out[si].flags, (walk ? TS_SEG_F_REV_WALKED : 0u) | (ooc ? TS_SEG_F_CONTEXT : 0u));
+            }
         }
-    }
-    if (!seg_out) return;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        TsShardSeg o;
-        o.fwd_boundary = bounds[2ull * si];
-        o.rev_boundary = bounds[2ull * si + 1];
-        o.n_matches = part[2][0]; o.n_canonical = part[3][0]; o.n_forward = part[4][0];
-        o.seen_matches = total; o.seen_forward = nfwd;
-        o.flags = (S.flags & (TS_SEG_F_HAS_START | TS_SEG_F_HAS_END)) | walk_flags;
-        o.reserved = 0;
-        seg_out[si] = o;
     }
 }
 
@@ -732,10 +734,15 @@ void ts_interstitial_evaluate(const TsBlockCallParams Q, const TsShardSegIn *seg
 
 // The two halves of block calling, for a caller that runs the terminal walks on a stream of their own (shard.cpp): the
 // walks are one latency-bound wave per segment end, and nothing but the interstitial search waits for them.
-int ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, unsigned long long *bounds,
-                         TsShardSeg *seg_out, void *stream) {
+int ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
+                         unsigned long long *bounds, TsShardSeg *seg_out, unsigned long long *sums, void *stream) {
     if (nseg == 0) return 0;
-    hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(256), 0, (hipStream_t)stream, *Q, segs, nseg, bounds, seg_out);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)nseg * 40, st);
+    if (e != hipSuccess) return (int)e;
+    if (ntiles)
+        hipLaunchKernelGGL(ts_segment_sums, dim3((ntiles + 255u) / 256u), dim3(256), 0, st, *Q, segs, seg_base, ntiles, sums);
+    hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(128), 0, st, *Q, segs, nseg, bounds, seg_out, (const u64 *)sums);
     return (int)hipGetLastError();
 }
 
@@ -753,8 +760,8 @@ int ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *seg
 
 int ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
                            uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its,
-                           const TsVisibleOut *vis, void *stream) {
-    int e = ts_k_launch_terminal(Q, segs, nseg, bounds, seg_out, stream);
+                           const TsVisibleOut *vis, unsigned long long *sums, void *stream) {
+    int e = ts_k_launch_terminal(Q, segs, nseg, seg_base, ntiles, bounds, seg_out, sums, stream);
     if (e == 0 && (with_its || (vis && vis->off))) e = ts_k_launch_interstitial(Q, segs, nseg, seg_base, ntiles, bounds, seg_out, vis, stream);
     return e;
 }

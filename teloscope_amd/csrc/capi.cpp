@@ -1173,7 +1173,7 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
     blocks.clear();
     if (!ns) return TS_OK;
     // segment table of the kernels (a whole batch: every segment with all its tiles, both ends its own)
-    const size_t off_bounds = ns * sizeof(TsShardSegIn), off_count = off_bounds + ns * 16, tab_bytes = off_count + 16;
+    const size_t off_bounds = ns * sizeof(TsShardSegIn), off_count = off_bounds + ns * 16, off_sums = off_count + 16, tab_bytes = off_sums + ns * 40;
     std::vector<TsShardSegIn> tab(ns);
     for (size_t i = 0; i < ns; ++i) {
         TsShardSegIn &S = tab[i];
@@ -1214,7 +1214,7 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
         Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;
         Q.k = c->k; Q.its_min_len = (uint32_t)(uint16_t)(2 * c->bp.first_pattern_len);
         if (ts_k_launch_block_call(&Q, (const TsShardSegIn *)dt, (uint32_t)ns, 0u, (uint32_t)nt, (unsigned long long *)(dt + off_bounds),
-                                   nullptr, b->tips ? 0 : 1, nullptr, st) != 0) return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
+                                   nullptr, b->tips ? 0 : 1, nullptr, (unsigned long long *)(dt + off_sums), st) != 0) return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
         uint32_t nb = 0;
         HIP_TRY(c, hipMemcpyAsync(&nb, dt + off_count, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));

@@ -13,26 +13,22 @@ namespace {
 
 typedef unsigned long long u64;
 
-constexpr uint32_t kScanThreads = 256;
+// One wavefront per workgroup and no LDS: these kernels also run beside the persistent scan kernel of the next batch, whose
+// workgroups hold every CU's LDS (a kernel that asks for a single byte of it waits until they are gone).
+constexpr uint32_t kScanThreads = 64;
 constexpr uint32_t kScanPerThread = 8;
 constexpr uint32_t kScanBlock = kScanThreads * kScanPerThread;      // tiles per workgroup
 
-// block-wide exclusive prefix sum of one u64 per thread (256 threads); returns the thread's exclusive prefix,
-// *total = the block's sum
+// wave-wide exclusive prefix sum of one u64 per lane; returns the lane's exclusive prefix, *total = the wave's sum
 __device__ __forceinline__ u64 block_excl_scan(u64 v, u64 *total) {
-    __shared__ u64 part[kScanThreads];
-    const uint32_t t = threadIdx.x;
-    part[t] = v;
-    __syncthreads();
-    for (uint32_t o = 1; o < kScanThreads; o <<= 1) {
-        const u64 add = t >= o ? part[t - o] : 0ull;
-        __syncthreads();
-        part[t] += add;
-        __syncthreads();
+    u64 incl = v;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, (int)o), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), (int)o);
+        if (lane >= o) incl += ((u64)hi << 32) | lo;
     }
-    const u64 incl = part[t];
-    *total = part[kScanThreads - 1];
-    __syncthreads();
+    const uint32_t tlo = (uint32_t)__shfl((int)(uint32_t)incl, 63), thi = (uint32_t)__shfl((int)(uint32_t)(incl >> 32), 63);
+    *total = ((u64)thi << 32) | tlo;
     return incl - v;
 }
 
@@ -52,7 +48,7 @@ void ts_tile_count_blocks(const uint32_t *tile_stats, uint32_t ntiles, u64 *bloc
         bool over = false;
         for (uint32_t w = blockIdx.x * kScanThreads + threadIdx.x; w < nwaves; w += gridDim.x * kScanThreads)
             over |= wave_fill[w] > region_cap;
-        if (over) atomicOr(total_out + 1, 1ull);
+        if (__ballot(over) != 0ull && threadIdx.x == 0) atomicOr(total_out + 1, 1ull);
     }
 }
 

@@ -248,7 +248,7 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
         }
         HIP_TRY(c, c->pool.take(tab.size() * sizeof(TsShardSegIn), b->d_shard_segs));
         HIP_TRY(c, hipMemcpy(b->d_shard_segs.p, tab.data(), tab.size() * sizeof(TsShardSegIn), hipMemcpyHostToDevice));
-        HIP_TRY(c, c->pool.take((size_t)std::max<uint32_t>(ns, 1) * 16, b->d_shard_bounds));
+        HIP_TRY(c, c->pool.take((size_t)std::max<uint32_t>(ns, 1) * (16 + 40), b->d_shard_bounds));     // bounds, then the per-segment sums
         HIP_TRY(c, c->pool.take((size_t)ts_k_shard_tmp_bytes(nown), b->d_shard_tmp));
     }
     // the list of chains the interstitial screening hands to its evaluation kernel, sized with the blocks (its counter lives in
@@ -313,8 +313,9 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     // where every tile's visible records go) and joins them.
     HIP_TRY(c, hipEventRecord(b->ev_fork, st));
     HIP_TRY(c, hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
-    if (ts_k_launch_terminal(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (unsigned long long *)b->d_shard_bounds.p,
-                             (TsShardSeg *)(msg + L.off_segs), b->side_stream) != 0)
+    if (ts_k_launch_terminal(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
+                             (unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs),
+                             (unsigned long long *)b->d_shard_bounds.p + 2ull * std::max<uint32_t>(ns, 1), b->side_stream) != 0)
         return c->fail(TS_ERR_HIP, "terminal block kernel launch failed");
     HIP_TRY(c, hipEventRecord(b->ev_join, b->side_stream));
     TsVisibleOut vis{};

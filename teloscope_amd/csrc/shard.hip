@@ -114,21 +114,17 @@ void ts_shard_pack_windows(const TsShardPackParams P, uint32_t window_bytes) {
 
 // The header: what the host knows arrives by value, what the device found out is filled in here (n_blocks was
 // counted in place by the block-calling kernels).
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64)
 void ts_shard_header(const TsShardPackParams P, TsShardHeader H, const u64 *vis_off) {
-    __shared__ uint32_t over;
-    if (threadIdx.x == 0) over = 0;
-    __syncthreads();
     bool o = false;
-    for (uint32_t w = threadIdx.x; w < P.nwaves; w += 256u) o |= P.wave_fill[w] > P.region_cap;
+    for (uint32_t w = threadIdx.x; w < P.nwaves; w += 64u) o |= P.wave_fill[w] > P.region_cap;
     const TsShardSeg *segs = (const TsShardSeg *)(P.msg + P.off_segs);
     bool ctx = false;
-    for (uint32_t s = threadIdx.x; s < P.n_segs; s += 256u) ctx |= (segs[s].flags & TS_SEG_F_CONTEXT) != 0u;
-    if (o || ctx) atomicOr(&over, (o ? 1u : 0u) | (ctx ? 2u : 0u));
-    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < P.n_segs; s += 64u) ctx |= (segs[s].flags & TS_SEG_F_CONTEXT) != 0u;
+    const bool any_o = __ballot(o) != 0ull, any_ctx = __ballot(ctx) != 0ull;       // (one wavefront, no LDS: see exchange.hip)
     if (threadIdx.x != 0) return;
     TsShardHeader *dst = (TsShardHeader *)P.msg;
-    uint32_t flags = ((over & 1u) ? TS_SHARD_F_SCAN_OVERFLOW : 0u) | ((over & 2u) ? TS_SHARD_F_CONTEXT : 0u);
+    uint32_t flags = (any_o ? TS_SHARD_F_SCAN_OVERFLOW : 0u) | (any_ctx ? TS_SHARD_F_CONTEXT : 0u);
     H.n_blocks = dst->n_blocks;
     H.n_visible = vis_off ? vis_off[P.own1 - P.own0] : 0ull;
     if (H.n_visible > H.visible_capacity) flags |= TS_SHARD_F_VISIBLE_OVERFLOW;
@@ -185,6 +181,6 @@ int ts_k_launch_shard_windows(const TsShardPackParams *P, const TsShardHeader *H
 int ts_k_launch_shard_pack(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, void *stream) {
     const uint32_t nown = P->own1 - P->own0;
     u64 *vis_off = (u64 *)((char *)tmp + shard_tmp_off(nown, 1));
-    hipLaunchKernelGGL(ts_shard_header, dim3(1), dim3(256), 0, (hipStream_t)stream, *P, *H, (const u64 *)((with_visible && nown) ? vis_off : nullptr));
+    hipLaunchKernelGGL(ts_shard_header, dim3(1), dim3(64), 0, (hipStream_t)stream, *P, *H, (const u64 *)((with_visible && nown) ? vis_off : nullptr));
     return (int)hipGetLastError();
 }

@@ -258,11 +258,12 @@ int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_o
 // search over the batch's ntiles (range-local) tiles; seg_base = plan index of segs[0]'s segment; seg_out (nullable):
 // what a shard reports per segment
 // vis (nullable): where the interstitial pass leaves the visible records of the owned tiles (a shard's message)
+// sums: scratch of 5 x u64 per segment (per-segment counts the terminal walks are gated on and a shard reports)
 int  ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
                             uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its,
-                            const TsVisibleOut *vis, void *stream);
-int  ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, unsigned long long *bounds,
-                          TsShardSeg *seg_out, void *stream);
+                            const TsVisibleOut *vis, unsigned long long *sums, void *stream);
+int  ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
+                          unsigned long long *bounds, TsShardSeg *seg_out, unsigned long long *sums, void *stream);
 int  ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
                               const unsigned long long *bounds, TsShardSeg *seg_out, const TsVisibleOut *vis, void *stream);
 // shard.hip: packed window records, visible records + per-tile counts, and the header of a shard's message
