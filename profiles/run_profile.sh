@@ -9,7 +9,7 @@ make -s -C $REPO/teloscope_amd/csrc && make -s -C $REPO/oracle
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$REPO/bench.py --no-cpu-baseline --no-e2e"        # bench.py defaults: --steps 50 --warmup 5
+ARGS="$REPO/bench.py --no-cpu-baseline --no-e2e --no-reads"        # bench.py defaults: --steps 50 --warmup 5
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
     --output-format csv -d $OUT/pmc_sq1 -- python3 $ARGS > $OUT/pmc_sq1.log 2>&1

@@ -8,11 +8,9 @@ import sys
 
 root = sys.argv[1]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-try:
-    from bench import SETTLE_LAUNCHES
-except Exception:
-    SETTLE_LAUNCHES = 0
-DROP = SETTLE_LAUNCHES + 5          # launches of bench.py's default run before its timed region
+TIMED = 50                          # bench.py's default --steps: its timed region is the LAST 50 scans of the run (before them:
+                                    # the first / single-shot scans, W warm-ups + K steps of the unsettled protocol, the settling
+                                    # scans and W warm-ups; after them, with --no-reads --no-e2e, nothing)
 
 
 def find(pattern):
@@ -36,11 +34,10 @@ for f in find("*kernel_trace.csv"):
     for name, v in sorted(durs.items(), key=lambda kv: -sum(kv[1]))[:6]:
         print("   %-60s n=%d avg=%.1f us min=%.1f us max=%.1f us" % (name[:60], len(v), sum(v) / len(v) / 1e3,
                                                               min(v) / 1e3, max(v) / 1e3))
-        if "ts_scan_tiles" in name and len(v) > DROP:
-            # bench.py runs its settling scans and 5 untimed warm-up launches first; its roofline uses the timed ones
-            t = v[DROP:]
-            print("   %-60s      timed launches only (first %d dropped: %d settling + 5 warm-up): n=%d avg=%.1f us" % (
-                "", DROP, DROP - 5, len(t), sum(t) / len(t) / 1e3))
+        if "ts_scan_tiles" in name and len(v) > TIMED:
+            # bench.py's roofline uses the timed launches only: the last TIMED of the run
+            t = v[-TIMED:]
+            print("   %-60s      timed launches only (the last %d of %d): n=%d avg=%.1f us" % ("", TIMED, len(v), len(t), sum(t) / len(t) / 1e3))
             # what bench.py itself measured in this very run (its JSON line is in trace.log): the two must agree; between
             # runs the plateau moves by a few per cent
             log = os.path.join(root, "trace.log")
