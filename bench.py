@@ -484,6 +484,8 @@ def run_scan(args, rank, local_rank, world, dev, backend):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    enqueue_s = [0.0]
+
     def timed(step_fn, drain_fn, nsteps):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
@@ -491,6 +493,7 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         ev0.record(stream)
         for i in range(nsteps):
             step_fn(i)
+        enqueue_s[0] = time.perf_counter() - t0                 # host time to ENQUEUE the steps (nothing waited for)
         drain_fn()
         ev1.record(stream)
         barrier()
@@ -857,6 +860,7 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                                       args.flags, len(ui.patternInfo), len(ui.patternInfo[0][0])),
                        "bases": total, "windows": n_windows, "matches": n_matches, "tiles": n_tiles,
                        "device_ms_per_step_events": round(dev_ms, 4),
+                       "host_enqueue_ms_per_step": round(enqueue_s[0] / max(1, args.steps) * 1e3, 4),
                        "settle": "%d untimed scans before the %d warm-up steps: the device's launch time needs ~40 launches to reach "
                                  "its steady state (profiles/r02/launch_ramp.txt)" % (settle_info["launches"], args.warmup), **extra_cfg},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

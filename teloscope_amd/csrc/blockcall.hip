@@ -5,17 +5,21 @@
 // scanSegment (:642-657).  With it only blocks (a few per segment) have to leave the GPU instead
 // of the whole match stream.
 //
+//   ts_segment_sums         per segment: record totals over its scanned and over its owned tiles (atomics, no LDS)
 //   ts_terminal_blocks      one wave per segment and direction: the reference's two-phase walk (chain matches
 //                           <= -k apart inside the terminal zone, keep dense canonical sub-blocks,
 //                           merge sub-blocks <= -d apart, keep >= -l) over the forward list from
 //                           the start and the reverse list from the end, 64 records per step in parallel
-//                           (prefix maximum for the predecessor, ballot of chain heads, one scalar step per
-//                           chain); emits the blocks and the two boundaries that fence the interstitial search.
-//   ts_interstitial_blocks  one wave per tile, sparse: an interstitial block needs >= 4
-//                           canonical matches, and canonical matches are ~2 % of the stream, so the canonical
-//                           records of the tile are compacted first and only the FIRST canonical match of a
-//                           chain ("leader") walks its chain (matches <= -k apart inside [fwdBoundary,
-//                           revBoundary)) and evaluates the reference's filters.
+//                           (prefix maximum for the predecessor, ballot of chain heads, sub-blocks screened lane-parallel,
+//                           record rows prefetched eight ahead); emits the blocks and the two boundaries that fence the
+//                           interstitial search.
+//   ts_interstitial_blocks  one wave per tile, 64 records per step: a ballot of chain heads cuts the records into
+//                           chains, a running count of canonical matches SCREENS them (a block needs four), the
+//                           few chains that pass are listed; for a shard the tile's writer-visible records leave in
+//                           the same pass.
+//   ts_interstitial_evaluate one wave per listed chain: the exact walk and the reference's filters.
+//
+// None of these kernels uses LDS: they run beside the next scan, whose persistent workgroups hold every CU's LDS.
 //
 // Records are addressed through the tile directory {tile_off, tile_stats}; tiles of one segment
 // are consecutive and position-ordered, so prev/next step across tile boundaries.
