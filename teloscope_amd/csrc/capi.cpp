@@ -594,6 +594,7 @@ void ts_destroy(ts_ctx *ctx) {
             ctx->pin_up[i].release();
             if (ctx->pin_up_ev[i]) (void)hipEventDestroy(ctx->pin_up_ev[i]);
         }
+        for (hipEvent_t e : ctx->gen_ev) if (e) (void)hipEventDestroy(e);
         for (PinBuf &pb : ctx->pin_down) pb.release();
         for (hipStream_t st : {ctx->up_stream, ctx->scan_stream, ctx->down_stream})
             if (st) (void)hipStreamDestroy(st);

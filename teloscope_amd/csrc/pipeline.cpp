@@ -635,6 +635,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     const bool timing = getenv("TS_TIMING") != nullptr;
     const auto t_begin = Clock::now();
     double t_up = 0, t_dev = 0, t_host = 0;
+    float t_kern = 0;
+    if (timing && !c->gen_ev[0]) { HIP_TRY(c, hipEventCreate(&c->gen_ev[0])); HIP_TRY(c, hipEventCreate(&c->gen_ev[1])); }
 
     struct RegionL { uint64_t seg_start, len, layout_off; };                   // a scanned region and where it lies in the layout
     struct SegL { size_t idx; uint64_t len, abs_pos, layout_off; std::vector<RegionL> regions; uint64_t first_tile = 0, n_tiles = 0, win_base = 0, n_windows = 0; };
@@ -693,19 +695,22 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         const size_t ns = G.size(), nt = tiles.size();
         if (nt >= 0x7FFFFFFFull) return c->fail(TS_ERR_UNSUPPORTED, "too many tiles in one group");
         // ---- device buffers from the pool
-        DevBuf d_in, d_mask, d_tiles, d_tab, d_stats, d_off, d_tmp, d_rec, d_win;
+        DevBuf d_in, d_slots, d_tiles, d_tab, d_stats, d_off, d_tmp, d_rec, d_win;
         struct Return { ts_ctx *c; std::vector<DevBuf *> v; ~Return() { for (DevBuf *d : v) c->pool.give(std::move(*d)); } }
-            give_back{c, {&d_in, &d_mask, &d_tiles, &d_tab, &d_stats, &d_off, &d_tmp, &d_rec, &d_win}};
-        const size_t tab_len = 0, tab_in = ns * 8, tab_win = 2 * ns * 8, tab_bytes = 3 * ns * 8 + 8 + 16;
+            give_back{c, {&d_in, &d_slots, &d_tiles, &d_tab, &d_stats, &d_off, &d_tmp, &d_rec, &d_win}};
+        const size_t tab_len = 0, tab_win = 2 * ns * 8, tab_flag = 3 * ns * 8 + 8, tab_bytes = 3 * ns * 8 + 8 + 16;
+        // a tile's slot: one record per position — all a single-length set can produce; a mixed-length tile that holds
+        // more says so, and the group runs again with slots that cannot overflow
+        uint32_t slot_cap = TS_GENERAL_TILE;
         HIP_TRY(c, c->pool.take(span, d_in));
-        HIP_TRY(c, c->pool.take(span * 4, d_mask));
+        HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * (size_t)slot_cap * 4, d_slots));
         HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * sizeof(TsGeneralTile), d_tiles));
         HIP_TRY(c, c->pool.take(tab_bytes, d_tab));
         HIP_TRY(c, c->pool.take((nt + 1) * 16, d_stats));
         HIP_TRY(c, c->pool.take((nt + 1) * 8, d_off));
         HIP_TRY(c, c->pool.take((size_t)ts_k_scan_tmp_bytes((uint32_t)nt), d_tmp));
         if (nwin_total) HIP_TRY(c, c->pool.take(nwin_total * 32, d_win));
-        std::vector<unsigned long long> tab(3 * ns + 1);
+        std::vector<unsigned long long> tab(3 * ns + 3, 0ull);
         for (size_t i = 0; i < ns; ++i) { tab[i] = G[i].len; tab[ns + i] = G[i].layout_off; tab[2 * ns + i] = G[i].win_base; }
         tab[3 * ns] = nwin_total;
         const auto t0 = Clock::now();
@@ -714,41 +719,53 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         HIP_TRY(c, hipMemcpyAsync(d_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->up_stream));
         HIP_TRY(c, hipStreamSynchronize(c->up_stream));
         const auto t1 = Clock::now();
-        // ---- kernels
+        // ---- kernels: the fused pass, a prefix sum over the tile counts, the slots into one dense stream
         char *const dt = (char *)d_tab.p;
         std::vector<uint32_t> &wins = gh->wins, &recs = gh->recs;
         std::vector<unsigned long long> &tile_off = gh->tile_off;
         tile_off.assign(nt + 1, 0);
-        {
-            std::lock_guard<std::mutex> lk(c->mtx);
-            if (ts_k_launch_general_match((const unsigned char *)d_in.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt, &c->gpat,
-                                          P.fold_case, (uint32_t *)d_mask.p, st) != 0) return c->fail(TS_ERR_HIP, "general match kernel launch failed");
-            if (ts_k_launch_general_records((const uint32_t *)d_mask.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt,
-                                            (const unsigned long long *)(dt + tab_len), &c->gpat, &Q, tips ? 1 : 0, (uint32_t *)d_stats.p,
-                                            nullptr, nullptr, 0, st) != 0) return c->fail(TS_ERR_HIP, "general count kernel launch failed");
-            if (ts_k_launch_tile_offsets((const uint32_t *)d_stats.p, (uint32_t)nt, (unsigned long long *)d_off.p, d_tmp.p, st) != 0)
-                return c->fail(TS_ERR_HIP, "tile-offset kernel launch failed");
+        for (int attempt = 0;; ++attempt) {
+            uint32_t flag = 0;
+            {
+                std::lock_guard<std::mutex> lk(c->mtx);
+                if (timing) HIP_TRY(c, hipEventRecord(c->gen_ev[0], st));
+                HIP_TRY(c, hipMemsetAsync(dt + tab_flag, 0, 16, st));
+                if (nwin_total) HIP_TRY(c, hipMemsetAsync(d_win.p, 0, nwin_total * 32, st));
+                if (ts_k_launch_general_fused((const unsigned char *)d_in.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt,
+                                              (const unsigned long long *)(dt + tab_len), (const unsigned long long *)(dt + tab_win),
+                                              &c->gpat, &Q, tips ? 1 : 0, slot_cap, (uint32_t *)d_stats.p, (uint32_t *)d_slots.p,
+                                              (uint32_t *)d_win.p, (uint32_t *)(dt + tab_flag), st) != 0)
+                    return c->fail(TS_ERR_HIP, "general fused kernel launch failed");
+                if (ts_k_launch_tile_offsets((const uint32_t *)d_stats.p, (uint32_t)nt, (unsigned long long *)d_off.p, d_tmp.p, st) != 0)
+                    return c->fail(TS_ERR_HIP, "tile-offset kernel launch failed");
+                if (timing) HIP_TRY(c, hipEventRecord(c->gen_ev[1], st));
+            }
+            if (nt) HIP_TRY(c, hipMemcpyAsync(tile_off.data(), d_off.p, (nt + 1) * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipMemcpyAsync(&flag, dt + tab_flag, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            if (timing) { float ms = 0; if (hipEventElapsedTime(&ms, c->gen_ev[0], c->gen_ev[1]) == hipSuccess) t_kern += ms; }
+            if (!flag) break;
+            if (attempt > 0) return c->fail(TS_ERR_STATE, "general path: a tile overflowed a slot that holds every match it can have");
+            slot_cap = TS_GENERAL_TILE * std::max<uint32_t>(1u, c->gpat.nlen);
+            c->pool.give(std::move(d_slots));
+            HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * (size_t)slot_cap * 4, d_slots));
         }
-        if (nt) HIP_TRY(c, hipMemcpyAsync(tile_off.data(), d_off.p, (nt + 1) * 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
         const uint64_t nrec = tile_off[nt];
         HIP_TRY(c, c->pool.take(std::max<uint64_t>(nrec, 1) * 4, d_rec));
         {
             std::lock_guard<std::mutex> lk(c->mtx);
-            if (ts_k_launch_general_records((const uint32_t *)d_mask.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt,
-                                            (const unsigned long long *)(dt + tab_len), &c->gpat, &Q, tips ? 1 : 0, (uint32_t *)d_stats.p,
-                                            (const unsigned long long *)d_off.p, (uint32_t *)d_rec.p, 1, st) != 0)
-                return c->fail(TS_ERR_HIP, "general emit kernel launch failed");
-            if (!tips && ts_k_launch_general_windows((const unsigned char *)d_in.p, (const uint32_t *)d_mask.p, &c->gpat, &Q,
-                                                     (const unsigned long long *)(dt + tab_win), (const unsigned long long *)(dt + tab_in),
-                                                     (const unsigned long long *)(dt + tab_len), (uint32_t)ns, nwin_total, (uint32_t *)d_win.p, st) != 0)
-                return c->fail(TS_ERR_HIP, "general window kernel launch failed");
+            if (timing) HIP_TRY(c, hipEventRecord(c->gen_ev[0], st));
+            if (ts_k_launch_general_compact((const uint32_t *)d_stats.p, (const unsigned long long *)d_off.p, (const uint32_t *)d_slots.p,
+                                            slot_cap, (uint32_t)nt, (uint32_t *)d_rec.p, st) != 0)
+                return c->fail(TS_ERR_HIP, "general compact kernel launch failed");
+            if (timing) HIP_TRY(c, hipEventRecord(c->gen_ev[1], st));
         }
         recs.resize(nrec + 1);
         wins.resize(nwin_total * 8 + 1);
         if (nrec) HIP_TRY(c, hipMemcpyAsync(recs.data(), d_rec.p, nrec * 4, hipMemcpyDeviceToHost, st));
         if (nwin_total) HIP_TRY(c, hipMemcpyAsync(wins.data(), d_win.p, nwin_total * 32, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
+        if (timing) { float ms = 0; if (hipEventElapsedTime(&ms, c->gen_ev[0], c->gen_ev[1]) == hipSuccess) t_kern += ms; }
         const auto t2 = Clock::now();
         t_up += ms_between(t0, t1); t_dev += ms_between(t1, t2);
         // ---- host: records -> MatchInfo in the reference's push order, then block calling; one job per segment
@@ -824,8 +841,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     if (host_job.joinable()) host_job.join();
     if (host_err.load() != TS_OK) return host_err.load();
     if (timing)
-        fprintf(stderr, "general path: %zu segments, wall %.1f ms: upload %.1f ms, kernels + D2H %.1f ms, host ordering + block calling %.1f ms (on a thread of its own, one group behind)\n",
-                which.size(), ms_between(t_begin, Clock::now()), t_up, t_dev, t_host);
+        fprintf(stderr, "general path: %zu segments, wall %.1f ms: upload %.1f ms, kernels + D2H %.1f ms (kernels alone, HIP events: %.2f ms), host ordering + block calling %.1f ms (on a thread of its own, one group behind)\n",
+                which.size(), ms_between(t_begin, Clock::now()), t_up, t_dev, (double)t_kern, t_host);
     return TS_OK;
 }
 

@@ -234,16 +234,15 @@ int  ts_k_prepare(uint32_t lds_bytes);                       // raises the dynam
 int  ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, void *stream);
 int  ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_tile,
                          const uint64_t *seg_nwin, uint32_t nseg, unsigned long long *out, void *stream);
-int  ts_k_launch_general_match(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
-                               const TsGenericPatterns *G, uint32_t fold, uint32_t *mask, void *stream);
-int  ts_k_launch_general_records(const uint32_t *mask, const TsGeneralTile *tiles, uint32_t ntiles,
-                                 const unsigned long long *seg_len, const TsGenericPatterns *G, const TsGenericGeom *Q,
-                                 int tips, uint32_t *tile_stats, const unsigned long long *tile_off, uint32_t *records,
-                                 int emit, void *stream);
-int  ts_k_launch_general_windows(const unsigned char *in, const uint32_t *mask, const TsGenericPatterns *G,
-                                 const TsGenericGeom *Q, const unsigned long long *seg_win_base,
-                                 const unsigned long long *seg_in_off, const unsigned long long *seg_len, uint32_t nseg,
-                                 unsigned long long nwin, uint32_t *out, void *stream);
+unsigned long long ts_k_general_lds_bytes(const TsGenericPatterns *G, uint32_t *lds_patterns);
+int  ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
+                               const unsigned long long *seg_len, const unsigned long long *seg_win_base,
+                               const TsGenericPatterns *G, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
+                               uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, void *stream);
+                               // (records: ntiles x slot_cap entries; win_out zeroed by the caller; *overflow raised when a tile
+                               //  holds more than slot_cap records — its count is still written)
+int  ts_k_launch_general_compact(const uint32_t *tile_stats, const unsigned long long *tile_off, const uint32_t *records,
+                                 uint32_t slot_cap, uint32_t ntiles, uint32_t *dense, void *stream);
 int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,
                            const uint32_t *matches, unsigned long long nrec_limit, const uint32_t *seg_first_tile,
                            const unsigned long long *seg_in_off, const unsigned long long *seg_len,
