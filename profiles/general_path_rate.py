@@ -23,6 +23,8 @@ out = {}
 for name, flags in (("mixed_5_6", "-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i"),
                     ("k14", "-c TTTAGGGTTTAGGG -x 1 -w 1000 -s 500 -r -g -e -m -i"),
                     ("wrapped_start_index", "-w 1000 -s 997 -r -g -e -m -i")):
+    if os.environ.get("TS_GEN_ONLY") and os.environ["TS_GEN_ONLY"] != name:
+        continue
     opts = parse_cli("x.fa " + flags)
     tel = ta.Teloscope(user_input(opts, device=0))
     assert not tel.usesFastPath()

@@ -1082,11 +1082,28 @@ int ts_finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos
     if (!nm) std::free(matches);
     const uint64_t term_end = seg_len > P.terminal_limit ? seg_len - P.terminal_limit : 0;
     uint64_t nfwd = 0;
-    for (uint64_t i = 0; i < nm; ++i) {                             // isTerminal, src/teloscope.cpp:451-459
-        ts_match &m = o.matches[i];
-        const uint64_t rel = m.position - abs_pos;
-        if (rel <= P.terminal_limit || rel >= term_end) m.flags |= TS_MATCH_TERMINAL;
-        nfwd += (m.flags & TS_MATCH_FORWARD) ? 1u : 0u;
+    {
+        auto flag = [&](uint64_t i0, uint64_t i1, uint64_t *fwd_out) {
+            uint64_t f = 0;
+            for (uint64_t i = i0; i < i1; ++i) {                    // isTerminal, src/teloscope.cpp:451-459
+                ts_match &m = o.matches[i];
+                const uint64_t rel = m.position - abs_pos;
+                if (rel <= P.terminal_limit || rel >= term_end) m.flags |= TS_MATCH_TERMINAL;
+                f += (m.flags & TS_MATCH_FORWARD) ? 1u : 0u;
+            }
+            *fwd_out = f;
+        };
+        const unsigned nth = nm >= (1u << 20) ? std::max(1u, std::min<unsigned>(spare_threads, (unsigned)(nm >> 18))) : 1u;
+        std::vector<uint64_t> f(nth, 0);
+        if (nth <= 1u) flag(0, nm, &f[0]);
+        else {
+            std::vector<std::thread> pool;
+            const uint64_t share = (nm + nth - 1) / nth;
+            for (unsigned t = 0; t < nth; ++t)
+                pool.emplace_back(flag, std::min<uint64_t>(nm, t * share), std::min<uint64_t>(nm, (t + 1) * share), &f[t]);
+            for (std::thread &th : pool) th.join();
+        }
+        for (uint64_t v : f) nfwd += v;
     }
     // the two walks take their orientation's records out of the one position-ordered array (they leave the
     // terminal zone after a few thousand records: no per-orientation index lists of the whole segment)
@@ -1140,9 +1157,11 @@ struct HostLanding {
     }
 };
 
+}  // namespace
+
 // Result arrays of many megabytes are first touched by the threads that fill them; on 2 MB pages (when the
 // kernel grants them) that is 512 times fewer page faults.  free() releases them like any malloc'd block.
-void *alloc_large(size_t bytes) {
+void *ts_alloc_large(size_t bytes) {
     constexpr size_t kHuge = size_t(2) << 20;
     if (bytes < 4 * kHuge) return std::malloc(bytes);
     void *p = nullptr;
@@ -1150,6 +1169,8 @@ void *alloc_large(size_t bytes) {
     (void)madvise(p, (bytes + kHuge - 1) & ~(kHuge - 1), MADV_HUGEPAGE);
     return p;
 }
+
+namespace {
 
 // f(i) for i in [0, n) on up to max_threads host threads (dynamic: an atomic counter hands out the indices)
 template <typename F>
@@ -1350,7 +1371,7 @@ int batch_finalize(ts_batch *b, const Fetched &F, ts_segment_out *out) {
             out[si].n_windows = sp.n_windows;
         }
         if (rc == TS_OK && seg_nm[si]) {
-            out[si].matches = (ts_match *)alloc_large(seg_nm[si] * sizeof(ts_match));
+            out[si].matches = (ts_match *)ts_alloc_large(seg_nm[si] * sizeof(ts_match));
             if (!out[si].matches) rc = c->fail(TS_ERR_ALLOC, "out of host memory");
             out[si].n_matches = seg_nm[si];
         }

@@ -253,6 +253,7 @@ int  ts_pipeline_upload_batch(ts_batch *b, const ts_segment_in *segs, int *slot,
 
 // capi.cpp internals used by pipeline.cpp
 bool ts_full_scan_supported(const ts_ctx *c, std::string &why);
+void *ts_alloc_large(size_t bytes);     // malloc-compatible; many-MB arrays on 2 MB pages when the kernel grants them
 int  ts_finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos, const uint32_t *win_raw,
                          uint64_t n_windows, ts_match *matches, uint64_t nm, ts_segment_out &o, unsigned spare_threads);
 int  ts_batch_ensure_device(ts_batch *b);        // allocates the range's device state (idempotent)

@@ -30,31 +30,10 @@ constexpr uint32_t kTile = TS_GENERAL_TILE;           // positions per tile
 constexpr uint32_t kHalo = 32;                        // bases staged beyond it (longest pattern <= 32)
 constexpr uint32_t kMaxLdsPatterns = 2048;
 
-__device__ __forceinline__ uint32_t base_code_byte(uint32_t c, uint32_t fold) {
-    if (fold) c &= 0xDFu;
-    return c == 'A' ? 0u : c == 'C' ? 1u : c == 'T' ? 2u : c == 'G' ? 3u : 0xFFu;
-}
-
-// Is the match (segment-relative position p, length l) pushed to the reference's match vectors by a full scan of a
-// segment of n bases?  (src/teloscope.cpp:485: by the window whose own scan sees it with j >= overlap, or always in
-// window 0 / when windows do not overlap; restated from the window loop's index arithmetic, uint32 wrap included.)
-__device__ __forceinline__ bool full_scan_pushes(u64 p, uint32_t l, u64 n, const TsGenericGeom &Q) {
-    const uint32_t s = Q.s, w = Q.w, ov = w - s;
-    const u64 e = p + l - 1u;
-    if (ov == 0u) {
-        const u64 k = p / s;
-        const u64 left = n - k * s;
-        const u64 cws = left < w ? left : w;
-        return (p - k * s) + l <= cws;                  // may not cross its only window's end
-    }
-    if (e < (n < w ? n : (u64)w)) return true;          // window 0 scans everything it holds
-    const u64 k = (e - ov) / s;                         // the one window with j >= overlap
-    const uint32_t t1 = s - Q.longest, t2 = ov - Q.longest;
-    const uint32_t start_index = t1 < t2 ? t1 : t2;
-    return p >= k * s && (p - k * s) >= start_index;
-}
-
-struct Acc { uint32_t v[8]; };            // A C T G (code order), canonical, non-canonical, forward, reverse covered
+// nuc: the A C T G (code order) counts of a lane as four 8-bit fields (a lane visits at most 4096 / 64 positions of a tile:
+// no field overflows) — indexed by a shift, where an array indexed by the code went to scratch memory (6 GB of write
+// traffic per 3 Gb); then canonical, non-canonical, forward, reverse covered
+struct Acc { uint32_t nuc, can, non, fwd, rev; };
 
 __device__ __forceinline__ uint32_t wave_total(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
@@ -66,7 +45,6 @@ __device__ __forceinline__ uint32_t wave_total(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-
 // Inclusive prefix sum over the wave's lanes.
 __device__ __forceinline__ uint32_t wave_inclusive(uint32_t v, uint32_t lane) {
 #pragma unroll
@@ -77,13 +55,67 @@ __device__ __forceinline__ uint32_t wave_inclusive(uint32_t v, uint32_t lane) {
     return v;
 }
 
+// Per tile, what the push test needs of the segment's geometry — computed once (two 64-bit divisions), so that the
+// test itself is 32-bit arithmetic relative to the tile.
+struct PushGeom {
+    u64 P0, n;
+    uint32_t s, w, ov, start_index;
+    u64 N0;              // ov == 0: n - k0 s      (k0 = P0 / s)
+    uint32_t r0;         // ov == 0: P0 - k0 s
+    uint32_t r1;         // ov > 0:  Xb - k1 s     (Xb = max(P0, ov) - ov, k1 = Xb / s)
+    uint32_t D1;         // ov > 0:  P0 - k1 s     (< w + s)
+    uint32_t dsub;       // ov > 0:  what to take off (P0-relative end) to get x - Xb: 0 if P0 > ov else ov - P0
+};
+
+__device__ __forceinline__ PushGeom push_geom(u64 P0, u64 n, const TsGenericGeom &Q) {
+    PushGeom g{};
+    g.P0 = P0; g.n = n; g.s = Q.s; g.w = Q.w; g.ov = Q.w - Q.s;
+    const uint32_t t1 = Q.s - Q.longest, t2 = g.ov - Q.longest;       // uint32 on purpose (src/teloscope.cpp:413-415)
+    g.start_index = t1 < t2 ? t1 : t2;
+    if (g.ov == 0u) {
+        const u64 k0 = P0 / Q.s;
+        g.r0 = (uint32_t)(P0 - k0 * Q.s);
+        g.N0 = n - k0 * Q.s;
+    } else {
+        const u64 Xb = P0 > g.ov ? P0 - g.ov : 0ull;
+        const u64 k1 = Xb / Q.s;
+        g.r1 = (uint32_t)(Xb - k1 * Q.s);
+        g.D1 = (uint32_t)(P0 - k1 * Q.s);
+        g.dsub = P0 > g.ov ? 0u : (uint32_t)(g.ov - P0);
+    }
+    return g;
+}
+
+// Is the match (tile-relative position j, length l) pushed to the reference's match vectors by a full scan?
+// (src/teloscope.cpp:485: by the window whose own scan sees it with j >= overlap, or always in window 0 / when
+// windows do not overlap; restated from the window loop's index arithmetic, uint32 wrap included.)
+__device__ __forceinline__ bool full_scan_pushes(uint32_t j, uint32_t l, const PushGeom &g) {
+    if (g.ov == 0u) {
+        const uint32_t x = g.r0 + j;
+        const uint32_t dk = x / g.s;
+        const u64 left = g.N0 - (u64)dk * g.s;
+        const uint32_t cws = left < g.w ? (uint32_t)left : g.w;
+        return (x - dk * g.s) + l <= cws;                   // may not cross its only window's end
+    }
+    const u64 e = g.P0 + j + l - 1u;
+    if (e < (g.n < g.w ? g.n : (u64)g.w)) return true;      // window 0 scans everything it holds
+    const uint32_t xr = g.r1 + (j + l - 1u - g.dsub);       // (e - ov) relative to k1 s   [e >= w here]
+    const uint32_t dk = xr / g.s;                           // the one window with j >= overlap: k = k1 + dk
+    const long long diff = (long long)g.D1 + (long long)j - (long long)((u64)dk * g.s);
+    return diff >= 0 && (u64)diff >= g.start_index;
+}
+
+// code (0..3) and validity of tile position q from the packed planes
+__device__ __forceinline__ uint32_t plane_code(const uint32_t *codes2, uint32_t q) { return (codes2[q >> 4] >> (2u * (q & 15u))) & 3u; }
+__device__ __forceinline__ uint32_t plane_invalid(const uint32_t *inval, uint32_t q) { return (inval[q >> 5] >> (q & 31u)) & 1u; }
+
 // What one analyzeWindow() call over window `kw` adds either to its own record (carry == false: bases with
-// i >= mainlo, matches with j >= ov, or everything for window 0 / ov == 0) or to the NEXT window's record
-// (carry == true: i >= step) — restricted to the positions [P0, P0 + n) the tile holds in LDS; the wave's lanes
-// stride over i.  (src/teloscope.cpp:387-534, the index arithmetic in uint32 as there.)
-__device__ __forceinline__ void window_tile_part(const unsigned char *codes, const uint32_t *mask, const TsGenericPatterns &G,
-                                                 const TsGenericGeom &Q, u64 n, u64 kw, bool carry, u64 P0, uint32_t ntile,
-                                                 uint32_t lane, Acc &a) {
+// i >= overlap, matches with j >= overlap, or everything for window 0 / overlap == 0) or to the NEXT window's record
+// (carry == true: i >= step) — restricted to the positions [P0, P0 + ntile) the tile holds in LDS; the wave's lanes
+// stride over them.  (src/teloscope.cpp:387-534, the index arithmetic in uint32 as there.)
+__device__ __forceinline__ void window_tile_part(const uint32_t *codes2, const uint32_t *inval, const uint32_t *mask,
+                                                 const TsGenericPatterns &G, const TsGenericGeom &Q, u64 n, u64 kw, bool carry,
+                                                 u64 P0, uint32_t ntile, uint32_t lane, Acc &a) {
     const u64 wstart = kw * Q.s;
     const uint32_t cws = (uint32_t)((n - wstart) < Q.w ? (n - wstart) : Q.w);
     const uint32_t ov = Q.w - Q.s;
@@ -93,15 +125,16 @@ __device__ __forceinline__ void window_tile_part(const unsigned char *codes, con
     uint32_t start_index = always_main ? 0u : (t1 < t2 ? t1 : t2);
     if (carry && start_index < Q.s) start_index = Q.s;               // the carry only takes i >= step
     if (start_index >= cws) return;
-    u64 lo = wstart + start_index, hi = wstart + cws;                 // segment-relative positions the call visits
-    if (lo < P0) lo = P0;
-    if (hi > P0 + ntile) hi = P0 + ntile;
-    for (u64 p = lo + lane; p < hi; p += 64u) {
-        const uint32_t i = (uint32_t)(p - wstart), q = (uint32_t)(p - P0);
+    const u64 lo = wstart + start_index, hi = wstart + cws;           // segment-relative positions the call visits
+    const uint32_t qlo = lo > P0 ? (uint32_t)(lo - P0 < ntile ? lo - P0 : ntile) : 0u;
+    const uint32_t qhi = hi > P0 ? (uint32_t)(hi - P0 < ntile ? hi - P0 : ntile) : 0u;
+    const uint32_t ioff = (uint32_t)(P0 - wstart);                    // i = q + ioff (mod 2^32: i < cws fits)
+    const bool all_nuc = carry || always_main;
+    for (uint32_t q = qlo + lane; q < qhi; q += 64u) {
+        const uint32_t i = q + ioff;
         if (Q.nuc_on) {
-            const uint32_t c = codes[q];
-            if (c > 3u) continue;
-            if (carry || always_main || i >= ov) a.v[c]++;
+            if (plane_invalid(inval, q)) continue;
+            if (all_nuc || i >= ov) a.nuc += 1u << (8u * plane_code(codes2, q));
         }
         const uint32_t m = mask[q] & 0xFFFFFFu;
         if (!m) continue;
@@ -112,19 +145,23 @@ __device__ __forceinline__ void window_tile_part(const unsigned char *codes, con
             const uint32_t j = i + l - 1u;
             if (j >= cws) continue;                                 // scanLimit: may not cross the window end
             if (!carry && !(always_main || j >= ov)) continue;
-            if (b & 4u) a.v[4] += l; else a.v[5] += l;
-            if (b & 2u) a.v[6] += l; else a.v[7] += l;
+            if (b & 4u) a.can += l; else a.non += l;
+            if (b & 2u) a.fwd += l; else a.rev += l;
         }
     }
 }
 
+constexpr uint32_t kCodeWords = (kTile + kHalo) / 16u + 4u;          // 2-bit plane, dwords (+ slack: three are read per position)
+constexpr uint32_t kInvalWords = (kTile + kHalo) / 32u + 3u;         // validity plane
+
 // ONE pass per tile of 4096 positions of one scanned region (round 3; rounds 1-2 wrote a 4 B/base match mask to HBM
 // and read it back three times).  The workgroup
-//   1. stages the tile's bases into LDS as 2-bit codes (coalesced 16-byte loads; a non-ACGT byte becomes 0xFF) beside
-//      the pattern lists (per length: ascending 2-bit codes + {forward, canonical}) and one prefix bitmap per length
-//      (which min(l, 6)-mers start a pattern: most positions stop there);
-//   2. matches: every position extends its l-mer code length by length and looks it up (bitmap, then binary search
-//      in LDS); the result — 3 bits {match, forward, canonical} per length — stays in LDS;
+//   1. stages the tile's bases into LDS as a 2-bit plane + a validity plane (coalesced 16-byte loads, a thread packs
+//      its 16 bases into one dword) beside the pattern lists (per length: ascending 2-bit codes + {forward,
+//      canonical}) and one prefix bitmap per length (which min(l, 6)-mers start a pattern: most positions stop there);
+//   2. matches: a position takes its next 32 bases out of the plane with one funnel shift, and for every length looks
+//      the l-mer up (bitmap, then binary search in LDS); the result — 3 bits {match, forward, canonical} per length —
+//      stays in LDS;
 //   3. window records: a wave per (window, part) the tile's positions contribute to, lanes striding over the tile's
 //      share of the bases analyzeWindow visits for the window's own record and for the carry into the next one, the
 //      eight counters reduced by DPP and ADDED (atomics; the records are zeroed first) to the window's record — a window
@@ -140,13 +177,14 @@ void ts_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint3
                       const u64 *seg_win_base, const TsGenericPatterns G, const TsGenericGeom Q, int tips, uint32_t slot_cap,
                       uint32_t lds_patterns, uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
     extern __shared__ __align__(16) unsigned char lds[];
-    // layout: mask u32[kTile] | pcode u64[lds_patterns] | bitmap u32[8][128] | part u32[8] | pflag u8[lds_patterns] | codes u8[...]
+    // layout: mask u32[kTile] | pcode u64[lds_patterns] | bitmap u32[8][128] | part u32[8] | codes2 | inval | pflag u8[lds_patterns]
     uint32_t *mask = (uint32_t *)lds;
     u64 *pcode = (u64 *)(lds + kTile * 4u);
     uint32_t *bitmap = (uint32_t *)(lds + kTile * 4u + (size_t)lds_patterns * 8u);
     uint32_t *part = bitmap + 8u * 128u;
-    unsigned char *pflag = (unsigned char *)(part + 8);
-    unsigned char *codes = pflag + ((lds_patterns + 15u) & ~15u);
+    uint32_t *codes2 = part + 8;
+    uint32_t *inval = codes2 + kCodeWords;
+    unsigned char *pflag = (unsigned char *)(inval + kInvalWords);
     if (blockIdx.x >= ntiles) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t npat = G.first[G.nlen];
@@ -154,6 +192,40 @@ void ts_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint3
     for (uint32_t i = tid; i < 8u * 128u; i += 256u) bitmap[i] = 0u;
     if (lds_lists)
         for (uint32_t i = tid; i < npat; i += 256u) { pcode[i] = G.codes[i]; pflag[i] = G.flags[i]; }
+    const TsGeneralTile T = tiles[blockIdx.x];
+    if (Q.abl & 8u) { if (tid == 0u) *(uint4 *)&tile_stats[4ull * blockIdx.x] = make_uint4(0u, 0u, 0u, 0u); return; }
+    // 1. stage: bases [0, avail) of the tile (avail = what lies between its start and the region end, at most
+    // kTile + kHalo); layout offsets are 16-byte aligned per segment, tiles start at multiples of kTile inside it.
+    // Thread t packs bases [16 t, 16 t + 16) (and the halo's); positions beyond avail are invalid.
+    const uint32_t avail = T.avail;
+    const unsigned char *src = in + T.in_off;
+    for (uint32_t i = tid * 16u; i < kCodeWords * 16u; i += 256u * 16u) {
+        uint32_t cw = 0, iv = 0xFFFFu;
+        if (i < avail) {
+            uint32_t d[4];
+            if (((uintptr_t)(src + i) & 15u) == 0u && i + 16u <= avail) {
+                const uint4 v = *(const uint4 *)(src + i);
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            } else {
+                for (uint32_t q = 0; q < 4u; ++q) {
+                    uint32_t x = 0;
+                    for (uint32_t r = 0; r < 4u; ++r) x |= (i + 4u * q + r < avail ? (uint32_t)src[i + 4u * q + r] : 0u) << (8u * r);
+                    d[q] = x;
+                }
+            }
+            iv = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 16u; ++q) {
+                uint32_t c = (d[q >> 2] >> (8u * (q & 3u))) & 0xFFu;
+                if (Q.fold) c &= 0xDFu;
+                const uint32_t code = (c >> 1) & 3u;                               // A 0, C 1, T 2, G 3
+                cw |= code << (2u * q);
+                iv |= (c != ((0x47544341u >> (8u * code)) & 0xFFu) ? 1u : 0u) << q; // 'A' 'C' 'T' 'G' by code
+            }
+        }
+        codes2[i >> 4] = cw;
+        ((unsigned short *)inval)[i >> 4] = (unsigned short)iv;
+    }
     __syncthreads();
     for (uint32_t li = 0; li < G.nlen; ++li) {
         const uint32_t q = G.len[li] < 6u ? G.len[li] : 6u;
@@ -162,36 +234,22 @@ void ts_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint3
             atomicOr(&bitmap[li * 128u + (pre >> 5)], 1u << (pre & 31u));
         }
     }
-    const TsGeneralTile T = tiles[blockIdx.x];
-    // 1. stage: bases [0, avail) of the tile (avail = what lies between its start and the region end, at most
-    // kTile + kHalo); layout offsets are 16-byte aligned per segment, tiles start at multiples of kTile inside it
-    const uint32_t avail = T.avail;
-    const unsigned char *src = in + T.in_off;
-    for (uint32_t i = tid * 16u; i < avail; i += 256u * 16u) {
-        unsigned char b[16];
-        if (((uintptr_t)(src + i) & 15u) == 0u && i + 16u <= avail) {
-            *(uint4 *)b = *(const uint4 *)(src + i);
-        } else {
-            for (uint32_t q = 0; q < 16u; ++q) b[q] = i + q < avail ? src[i + q] : (unsigned char)0;
-        }
-        for (uint32_t q = 0; q < 16u; ++q) codes[i + q] = (unsigned char)base_code_byte(b[q], Q.fold);
-    }
     __syncthreads();
     // 2. matches
     for (uint32_t j = tid; j < T.n; j += 256u) {
-        uint32_t out = 0, have = 0;
-        u64 code = 0;
-        bool ok = true;
+        if (Q.abl & 1u) { mask[j] = 0; continue; }
+        // the next 32 bases of position j: three plane dwords funnelled by 2 (j mod 16) bits; their validity bits alike
+        const uint32_t wd = j >> 4, sh = 2u * (j & 15u);
+        const uint32_t c0 = codes2[wd], c1 = codes2[wd + 1u], c2 = codes2[wd + 2u];
+        const u64 code64 = (u64)__funnelshift_r(c0, c1, sh) | ((u64)__funnelshift_r(c1, c2, sh) << 32);
+        const uint32_t vd = j >> 5;
+        const uint32_t inv32 = __funnelshift_r(inval[vd], inval[vd + 1u], j & 31u);
+        uint32_t out = 0;
         for (uint32_t li = 0; li < G.nlen; ++li) {
             const uint32_t l = G.len[li];
             if (j + l > avail) break;                // lengths ascend; a match may not cross the region end
-            while (ok && have < l) {
-                const uint32_t c = codes[j + have];
-                if (c > 3u) { ok = false; break; }
-                code |= (u64)c << (2u * have);
-                ++have;
-            }
-            if (!ok) break;                          // a non-ACGT base kills this and every longer pattern
+            if (inv32 & (l >= 32u ? 0xFFFFFFFFu : ((1u << l) - 1u))) break;   // a non-ACGT base kills this and every longer pattern
+            const u64 code = l >= 32u ? code64 : (code64 & ((1ull << (2u * l)) - 1ull));
             const uint32_t q = l < 6u ? l : 6u;
             const uint32_t pre = (uint32_t)code & ((1u << (2u * q)) - 1u);
             if (!((bitmap[li * 128u + (pre >> 5)] >> (pre & 31u)) & 1u)) continue;
@@ -211,37 +269,52 @@ void ts_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint3
     const u64 n = seg_len[T.seg];
     const u64 P0 = T.seg_rel;
     // 3. window records (full scans)
-    if (!tips && T.n) {
+    if (!tips && T.n && !(Q.abl & 2u)) {
         const u64 nwin = (n + Q.s - 1u) / Q.s;
         const u64 kw_lo = P0 >= Q.w ? (P0 - Q.w) / Q.s + 1u : 0u;             // first call whose window reaches the tile
         u64 kw_hi = (P0 + T.n - 1u) / Q.s;                                    // last call that starts inside it
         if (kw_hi >= nwin) kw_hi = nwin - 1u;
         const bool carries = Q.w != Q.s;
-        const u64 items = (kw_hi - kw_lo + 1u) * (carries ? 2u : 1u);
+        // one item per window RECORD the tile's positions add to: the main part of its own call and the carry of the
+        // call before it.  Everything a record holds comes from the positions [R s, R s + w): a record whose span lies
+        // inside the tile is STORED (this workgroup is its only writer), one that spans two tiles is added to atomically
+        // (device-scope atomics are served at the memory side: eight of them per item were 6 GB of write traffic per 3 Gb)
+        u64 rec_hi = kw_hi + (carries ? 1u : 0u);
+        if (rec_hi >= nwin) rec_hi = nwin - 1u;
         uint32_t *const wrec = win_out + seg_win_base[T.seg] * 8ull;
-        for (u64 it = wave; it < items; it += 4u) {
-            const u64 kw = kw_lo + (carries ? it >> 1 : it);
-            const bool carry = carries && (it & 1u);
-            if (carry && kw + 1u >= nwin) continue;
-            Acc a = {{0, 0, 0, 0, 0, 0, 0, 0}};
-            window_tile_part(codes, mask, G, Q, n, kw, carry, P0, T.n, lane, a);
-            uint32_t t[8];
-            for (int i = 0; i < 8; ++i) t[i] = wave_total(a.v[i]);
-            // A C G T (codes A0 C1 T2 G3), then the four covered counters
-            const uint32_t mine = lane == 0u ? t[0] : lane == 1u ? t[1] : lane == 2u ? t[3] : lane == 3u ? t[2]
-                                : lane == 4u ? t[4] : lane == 5u ? t[5] : lane == 6u ? t[6] : t[7];
-            if (lane < 8u && mine) atomicAdd(&wrec[(kw + (carry ? 1u : 0u)) * 8ull + lane], mine);
+        for (u64 R = kw_lo + wave; R <= rec_hi; R += 4u) {
+            Acc a = {0, 0, 0, 0, 0};
+            window_tile_part(codes2, inval, mask, G, Q, n, R, false, P0, T.n, lane, a);
+            if (carries && R > 0u) window_tile_part(codes2, inval, mask, G, Q, n, R - 1u, true, P0, T.n, lane, a);
+            // two fields per reduction (a tile's share of a window is at most 4096 bases: 16 bits hold it)
+            const uint32_t tAT = wave_total((a.nuc & 0xFFu) | ((a.nuc >> 16) & 0xFFu) << 16);        // A | T << 16
+            const uint32_t tCG = wave_total(((a.nuc >> 8) & 0xFFu) | ((a.nuc >> 24) & 0xFFu) << 16);  // C | G << 16
+            const uint32_t tcan = wave_total(a.can), tnon = wave_total(a.non), tfwd = wave_total(a.fwd), trev = wave_total(a.rev);
+            // A C G T, then the four covered counters
+            const uint32_t mine = lane == 0u ? (tAT & 0xFFFFu) : lane == 1u ? (tCG & 0xFFFFu) : lane == 2u ? (tCG >> 16) : lane == 3u ? (tAT >> 16)
+                                : lane == 4u ? tcan : lane == 5u ? tnon : lane == 6u ? tfwd : trev;
+            const u64 span_lo = R * Q.s;
+            const u64 span_hi = span_lo + Q.w < n ? span_lo + Q.w : n;
+            const bool sole = span_lo >= P0 && span_hi <= P0 + T.n;
+            if (lane < 8u) {
+                if (sole) wrec[R * 8ull + lane] = mine;
+                else if (mine) atomicAdd(&wrec[R * 8ull + lane], mine);
+            }
         }
     }
     // 4. match records: wave v owns the 1024 consecutive positions [1024 v, 1024 v + 1024)
+    if (Q.abl & 4u) { if (tid == 0u) *(uint4 *)&tile_stats[4ull * blockIdx.x] = make_uint4(0u, 0u, 0u, 0u); return; }
+    const PushGeom pg = push_geom(P0, n, Q);
     uint32_t wave_cnt = 0;
     for (uint32_t r = 0; r < 16u; ++r) {
         const uint32_t j = wave * 1024u + r * 64u + lane;
-        uint32_t v = j < T.n ? (mask[j] & 0xFFFFFFu) : 0u;
+        const uint32_t v = j < T.n ? (mask[j] & 0xFFFFFFu) : 0u;
         uint32_t keep = 0;
-        for (uint32_t li = 0; v && li < G.nlen; ++li)
-            if (((v >> (3u * li)) & 1u) && (tips || full_scan_pushes(P0 + j, G.len[li], n, Q))) keep |= 1u << li;
-        if (j < T.n) mask[j] = v | (keep << 24);
+        if (v) {
+            for (uint32_t li = 0; li < G.nlen; ++li)
+                if (((v >> (3u * li)) & 1u) && (tips || full_scan_pushes(j, G.len[li], pg))) keep |= 1u << li;
+            mask[j] = v | (keep << 24);
+        }
         wave_cnt += (uint32_t)__popc(keep);
     }
     wave_cnt = wave_total(wave_cnt);
@@ -253,12 +326,13 @@ void ts_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint3
         *(uint4 *)&tile_stats[4ull * blockIdx.x] = make_uint4(total, 0u, 0u, 0u);
         if (total > slot_cap) atomicOr(overflow, 1u);
     }
-    if (total > slot_cap) return;
+    if (total > slot_cap || wave_cnt == 0u) return;
     uint32_t *dst = records + (u64)blockIdx.x * slot_cap;
     for (uint32_t r = 0; r < 16u; ++r) {
         const uint32_t j = wave * 1024u + r * 64u + lane;
         const uint32_t v = j < T.n ? mask[j] : 0u;
         const uint32_t keep = v >> 24;
+        if (__ballot(keep != 0u) == 0ull) continue;
         const uint32_t c = (uint32_t)__popc(keep);
         const uint32_t incl = wave_inclusive(c, lane);
         uint32_t at = base + incl - c;
@@ -287,7 +361,8 @@ unsigned long long ts_k_general_lds_bytes(const TsGenericPatterns *G, uint32_t *
     const uint32_t npat = G->first[G->nlen];
     const uint32_t lp = npat <= kMaxLdsPatterns ? (npat ? npat : 1u) : 0u;
     *lds_patterns = lp;
-    return (unsigned long long)kTile * 4u + (unsigned long long)lp * 8u + 8u * 128u * 4u + 32u + ((lp + 15u) & ~15u) + kTile + kHalo + 16u;
+    return (unsigned long long)kTile * 4u + (unsigned long long)lp * 8u + 8u * 128u * 4u + 32u + kCodeWords * 4u + kInvalWords * 4u +
+           ((lp + 15u) & ~15u);
 }
 
 int ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,

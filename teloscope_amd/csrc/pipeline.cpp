@@ -616,6 +616,8 @@ int submit_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &
 // kernels of generic.hip over groups of ~256 MB of regions at a time — match masks, the records the reference pushes
 // and the window records all come off the device; the host orders the records by the window that pushes them (only
 // mixed-length sets can be out of position order at all), expands them and calls blocks (ts_finalize_segment).
+std::atomic<uint64_t> ts_gen_ns[2];       // TS_TIMING: job time in record expansion / in ts_finalize_segment
+
 int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<size_t> &which,
                        bool tips, ts_segment_out *out) {
     if (which.empty()) return TS_OK;
@@ -632,6 +634,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     hipStream_t st = c->scan_stream;
     TsGenericGeom Q{};
     Q.s = s; Q.w = w; Q.longest = L; Q.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u; Q.fold = P.fold_case;
+    if (const char *e = getenv("TS_GEN_ABL")) Q.abl = (uint32_t)atoi(e);
     const bool timing = getenv("TS_TIMING") != nullptr;
     const auto t_begin = Clock::now();
     double t_up = 0, t_dev = 0, t_host = 0;
@@ -647,7 +650,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     // The host stage of group g (ordering + block calling on the host threads) runs on a background thread while the
     // device stage of group g + 1 (upload, kernels, D2H) runs here: what a group's host stage reads lives in a GroupHost.
     struct GroupHost { std::vector<SegL> G; std::vector<TsGeneralTile> tiles; std::vector<unsigned long long> tile_off;
-                       std::vector<uint32_t> recs, wins; };
+                       std::vector<uint32_t> recs_heap, wins_heap; const uint32_t *recs = nullptr, *wins = nullptr; };
+    size_t group_no = 0;
     std::thread host_job;
     std::atomic<int> host_err{TS_OK};
     struct JoinJob { std::thread &t; ~JoinJob() { if (t.joinable()) t.join(); } } join_job{host_job};
@@ -721,7 +725,6 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         const auto t1 = Clock::now();
         // ---- kernels: the fused pass, a prefix sum over the tile counts, the slots into one dense stream
         char *const dt = (char *)d_tab.p;
-        std::vector<uint32_t> &wins = gh->wins, &recs = gh->recs;
         std::vector<unsigned long long> &tile_off = gh->tile_off;
         tile_off.assign(nt + 1, 0);
         for (int attempt = 0;; ++attempt) {
@@ -760,10 +763,28 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 return c->fail(TS_ERR_HIP, "general compact kernel launch failed");
             if (timing) HIP_TRY(c, hipEventRecord(c->gen_ev[1], st));
         }
-        recs.resize(nrec + 1);
-        wins.resize(nwin_total * 8 + 1);
-        if (nrec) HIP_TRY(c, hipMemcpyAsync(recs.data(), d_rec.p, nrec * 4, hipMemcpyDeviceToHost, st));
-        if (nwin_total) HIP_TRY(c, hipMemcpyAsync(wins.data(), d_win.p, nwin_total * 32, hipMemcpyDeviceToHost, st));
+        // landing area: the context's pinned download buffers, alternating by group (the host stage of group g reads
+        // its buffer while group g + 1 lands in the other; it has been joined before group g + 2 arrives)
+        {
+            const size_t rec_bytes = ((size_t)nrec * 4 + 255) & ~(size_t)255, win_bytes = (size_t)nwin_total * 32;
+            PinBuf &pb = c->pin_down[group_no & 1];
+            ++group_no;
+            uint32_t *hrec, *hwin;
+            if (rec_bytes + win_bytes + 256 <= (768ull << 20) && pb.ensure(std::max<size_t>(rec_bytes + win_bytes + 256, 32u << 20)) == hipSuccess) {
+                hrec = (uint32_t *)pb.p;
+                hwin = (uint32_t *)((char *)pb.p + rec_bytes);
+            } else {
+                (void)hipGetLastError();
+                gh->recs_heap.resize(nrec + 1);
+                gh->wins_heap.resize(nwin_total * 8 + 1);
+                hrec = gh->recs_heap.data();
+                hwin = gh->wins_heap.data();
+            }
+            if (nrec) HIP_TRY(c, hipMemcpyAsync(hrec, d_rec.p, nrec * 4, hipMemcpyDeviceToHost, st));
+            if (nwin_total) HIP_TRY(c, hipMemcpyAsync(hwin, d_win.p, nwin_total * 32, hipMemcpyDeviceToHost, st));
+            gh->recs = hrec;
+            gh->wins = hwin;
+        }
         HIP_TRY(c, hipStreamSynchronize(st));
         if (timing) { float ms = 0; if (hipEventElapsedTime(&ms, c->gen_ev[0], c->gen_ev[1]) == hipSuccess) t_kern += ms; }
         const auto t2 = Clock::now();
@@ -771,12 +792,12 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         // ---- host: records -> MatchInfo in the reference's push order, then block calling; one job per segment
         if (host_job.joinable()) host_job.join();                     // (one host stage at a time: it takes all the host threads)
         if (host_err.load() != TS_OK) return host_err.load();
-        host_job = std::thread([c, gh, ns, tips, s, w, ov, out, &host_err, &t_host]() {
+        host_job = std::thread([c, gh, ns, tips, s, w, ov, out, timing, &host_err, &t_host]() {
         const auto th0 = Clock::now();
         const std::vector<SegL> &G = gh->G;
         const std::vector<TsGeneralTile> &tiles = gh->tiles;
         const std::vector<unsigned long long> &tile_off = gh->tile_off;
-        const std::vector<uint32_t> &recs = gh->recs, &wins = gh->wins;
+        const uint32_t *const recs = gh->recs, *const wins = gh->wins;
         std::atomic<size_t> next{0};
         std::atomic<int> first_err{TS_OK};
         const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
@@ -785,45 +806,86 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
             for (size_t gi; (gi = next.fetch_add(1)) < ns && first_err.load() == TS_OK;) {
                 const SegL &sl = G[gi];
                 const uint64_t r0 = tile_off[sl.first_tile], r1 = tile_off[sl.first_tile + sl.n_tiles], nm = r1 - r0;
-                ts_match *arr = nm ? (ts_match *)std::malloc(nm * sizeof(ts_match)) : nullptr;
+                ts_match *arr = nm ? (ts_match *)ts_alloc_large(nm * sizeof(ts_match)) : nullptr;
                 if (nm && !arr) { int e = TS_OK; first_err.compare_exchange_strong(e, c->fail(TS_ERR_ALLOC, "out of host memory")); return; }
-                std::vector<uint64_t> key;                                        // the window that pushes the match
-                if (!tips) key.resize(nm);
-                uint64_t at = 0;
-                bool sorted = true;
-                for (uint64_t t = 0; t < sl.n_tiles; ++t) {
-                    const TsGeneralTile &T = tiles[sl.first_tile + t];
-                    for (uint64_t ri = tile_off[sl.first_tile + t]; ri < tile_off[sl.first_tile + t + 1]; ++ri, ++at) {
-                        const uint32_t rec = recs[ri];
-                        const uint64_t p = T.seg_rel + (rec >> 5);
-                        const uint32_t len = c->gpat.len[(rec >> 2) & 7u];
-                        ts_match &m = arr[at];
-                        std::memset(&m, 0, sizeof m);
-                        m.position = sl.abs_pos + p;
-                        m.match_size = (uint16_t)len;
-                        m.flags = (uint8_t)(((rec & 1u) ? TS_MATCH_FORWARD : 0u) | ((rec & 2u) ? TS_MATCH_CANONICAL : 0u));   // (general records: forward is bit 0)
-                        if (!tips) {
-                            const uint64_t e = p + len - 1;
-                            const uint64_t k = ov == 0 ? p / s : (e < std::min<uint64_t>(w, sl.len) ? 0 : (e - ov) / s);
-                            key[at] = k;
-                            if (at && k < key[at - 1]) sorted = false;
+                // the window that pushes a match (src/teloscope.cpp:485): records must be in that order
+                auto push_window = [&](uint64_t p, uint32_t len) -> uint64_t {
+                    const uint64_t e = p + len - 1;
+                    return ov == 0 ? p / s : (e < std::min<uint64_t>(w, sl.len) ? 0 : (e - ov) / s);
+                };
+                // a segment's records are expanded by all the threads its job can spare (a group that holds ONE 250 Mb
+                // contig has one job): tile ranges of equal records, each thread checks the push order inside its range
+                const unsigned nth = nm >= (1u << 18) ? std::max(1u, std::min<unsigned>(spare, (unsigned)(nm >> 17))) : 1u;
+                std::vector<uint64_t> cut(nth + 1, sl.n_tiles);
+                cut[0] = 0;
+                for (unsigned q = 1; q < nth; ++q)
+                    cut[q] = (uint64_t)(std::lower_bound(tile_off.begin() + sl.first_tile, tile_off.begin() + sl.first_tile + sl.n_tiles,
+                                                         r0 + nm * q / nth) - (tile_off.begin() + sl.first_tile));
+                const auto tw0 = Clock::now();
+                std::vector<char> part_sorted(nth, 1);
+                std::vector<uint64_t> first_key(nth, 0), last_key(nth, 0);
+                auto expand = [&](unsigned q) {
+                    bool ok = true, any = false;
+                    uint64_t prev_k = 0;
+                    for (uint64_t t = cut[q]; t < cut[q + 1]; ++t) {
+                        const TsGeneralTile &T = tiles[sl.first_tile + t];
+                        uint64_t at = tile_off[sl.first_tile + t] - r0;
+                        for (uint64_t ri = tile_off[sl.first_tile + t]; ri < tile_off[sl.first_tile + t + 1]; ++ri, ++at) {
+                            const uint32_t rec = recs[ri];
+                            const uint64_t p = T.seg_rel + (rec >> 5);
+                            const uint32_t len = c->gpat.len[(rec >> 2) & 7u];
+                            ts_match &m = arr[at];
+                            std::memset(&m, 0, sizeof m);
+                            m.position = sl.abs_pos + p;
+                            m.match_size = (uint16_t)len;
+                            m.flags = (uint8_t)(((rec & 1u) ? TS_MATCH_FORWARD : 0u) | ((rec & 2u) ? TS_MATCH_CANONICAL : 0u));   // (general records: forward is bit 0)
+                            if (!tips) {
+                                const uint64_t k = push_window(p, len);
+                                if (!any) { first_key[q] = k; any = true; }
+                                else if (k < prev_k) ok = false;
+                                prev_k = k;
+                            }
                         }
+                    }
+                    part_sorted[q] = ok ? 1 : 0;
+                    last_key[q] = prev_k;
+                    if (!any) part_sorted[q] = 2;                                     // (an empty part)
+                };
+                if (nth <= 1) expand(0);
+                else {
+                    std::vector<std::thread> ex;
+                    for (unsigned q = 0; q < nth; ++q) ex.emplace_back(expand, q);
+                    for (std::thread &th : ex) th.join();
+                }
+                bool sorted = true;
+                {
+                    bool have_prev = false;
+                    uint64_t prev_last = 0;
+                    for (unsigned q = 0; q < nth; ++q) {                                 // (and the order across the parts' seams)
+                        if (part_sorted[q] == 2) continue;
+                        if (!part_sorted[q] || (have_prev && first_key[q] < prev_last)) sorted = false;
+                        prev_last = last_key[q];
+                        have_prev = true;
                     }
                 }
                 if (!tips && !sorted) {
                     // mixed-length sets: a long match near a window start is pushed by the NEXT window, after shorter
                     // matches that begin behind it — order by pushing window, position order within it
+                    std::vector<uint64_t> key(nm);
+                    for (uint64_t i = 0; i < nm; ++i) key[i] = push_window(arr[i].position - sl.abs_pos, arr[i].match_size);
                     std::vector<uint32_t> idx(nm);
                     for (uint64_t i = 0; i < nm; ++i) idx[i] = (uint32_t)i;
                     std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b2) { return key[a] < key[b2]; });
-                    ts_match *sorted_arr = (ts_match *)std::malloc(nm * sizeof(ts_match));
+                    ts_match *sorted_arr = (ts_match *)ts_alloc_large(nm * sizeof(ts_match));
                     if (!sorted_arr) { std::free(arr); int e = TS_OK; first_err.compare_exchange_strong(e, c->fail(TS_ERR_ALLOC, "out of host memory")); return; }
                     for (uint64_t i = 0; i < nm; ++i) sorted_arr[i] = arr[idx[i]];
                     std::free(arr);
                     arr = sorted_arr;
                 }
+                const auto tw1 = Clock::now();
                 const int rc = ts_finalize_segment(c, tips, sl.len, sl.abs_pos, sl.n_windows ? &wins[sl.win_base * 8] : nullptr,
                                                    tips ? 0 : sl.n_windows, arr, nm, out[sl.idx], spare);
+                if (timing) { ts_gen_ns[0] += (uint64_t)(ms_between(tw0, tw1) * 1e6); ts_gen_ns[1] += (uint64_t)(ms_between(tw1, Clock::now()) * 1e6); }
                 if (rc != TS_OK) { int e = TS_OK; first_err.compare_exchange_strong(e, rc); return; }
             }
         };
@@ -841,8 +903,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     if (host_job.joinable()) host_job.join();
     if (host_err.load() != TS_OK) return host_err.load();
     if (timing)
-        fprintf(stderr, "general path: %zu segments, wall %.1f ms: upload %.1f ms, kernels + D2H %.1f ms (kernels alone, HIP events: %.2f ms), host ordering + block calling %.1f ms (on a thread of its own, one group behind)\n",
-                which.size(), ms_between(t_begin, Clock::now()), t_up, t_dev, (double)t_kern, t_host);
+        fprintf(stderr, "general path: %zu segments, wall %.1f ms: upload %.1f ms, kernels + D2H %.1f ms (kernels alone, HIP events: %.2f ms), host ordering + block calling %.1f ms (on a thread of its own, one group behind; job time: expansion %.1f ms, windows + block calling %.1f ms)\n",
+                which.size(), ms_between(t_begin, Clock::now()), t_up, t_dev, (double)t_kern, t_host, ts_gen_ns[0].exchange(0) / 1e6, ts_gen_ns[1].exchange(0) / 1e6);
     return TS_OK;
 }
 

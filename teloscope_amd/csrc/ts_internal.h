@@ -209,6 +209,7 @@ struct TsGenericPatterns {
 struct TsGenericGeom {
     uint32_t s, w, longest;
     uint32_t nuc_on, fold;
+    uint32_t abl;                       // TS_GEN_ABL (profiling): 1 no matching, 2 no window records, 4 no match records, 8 nothing after the table load
 };
 
 #define TS_GENERAL_TILE 4096            // positions per tile of the general kernels (generic.hip)
