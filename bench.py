@@ -595,7 +595,7 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         # size both sides know from the plan; one grouped send / recv per step brings the messages to rank 0.  Nothing is
         # read back to the host inside a step; the messages' headers are checked (and the messages merged on the host,
         # ts_shards_finalize) before the timed steps and after them.
-        slots = 2
+        slots = max(2, int(os.environ.get("TS_BENCH_SLOTS", "3")))      # (profiles/r03/slots_sweep.txt)
         scale = 1
         exch = D.ShardExchange(plan, rank, dev, dst=0, slots=slots, scale=scale)
         shard = D.PackedShard(plan, rank, dev, slots=slots, scale=scale)
@@ -605,18 +605,20 @@ def run_scan(args, rank, local_rank, world, dev, backend):
             torch.cuda.empty_cache()
         in_ptr = buf.data_ptr()
         pending = [None] * slots
-        # Two streams: block calling + packing of step i (no LDS, few registers) run beside the scan of step i + 1 (a
-        # persistent kernel that holds every CU's LDS but leaves wave slots and issue cycles free), and the transfer of
-        # step i's message beside both.  A slot's scan waits for the pack that last read its records; a slot's pack
+        # Streams: block calling + packing of step i (no LDS, few registers) run beside the scans of the steps after it (a
+        # persistent kernel that holds every CU's LDS but leaves a SIMD room for one or two waves of anything else: the
+        # pack kernels are chains of latency, they make progress at that occupancy but take about two scans to finish —
+        # hence THREE buffer slots and TWO pack streams, so that two packs are in flight beside the scan), and the transfer
+        # of step i's message beside all of it.  A slot's scan waits for the pack that last read its records; a slot's pack
         # waits for the transfer that last read its message.
-        pack_stream = torch.cuda.Stream(device=dev)
-        pptr = C.c_void_p(pack_stream.cuda_stream)
+        pack_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(os.environ.get("TS_BENCH_PACK_STREAMS", "2"))))]
         scanned = [torch.cuda.Event() for _ in range(slots)]
         packed = [torch.cuda.Event() for _ in range(slots)]
         used = [False] * slots
 
         def step(i):
             j = i % slots
+            pack_stream = pack_streams[j % len(pack_streams)]
             if used[j]:
                 stream.wait_event(packed[j])
             shard.scan(in_ptr, sptr, j)
@@ -627,19 +629,20 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                     for w in pending[j]:
                         w.wait()
                     pending[j] = None
-                shard.pack(pptr, j)
+                shard.pack(C.c_void_p(pack_stream.cuda_stream), j)
                 packed[j].record(pack_stream)
                 pending[j] = exch.post(shard.msgs[j], j)
             used[j] = True
 
         def drain():
-            with torch.cuda.stream(pack_stream):
-                for j in range(slots):
+            for j in range(slots):
+                with torch.cuda.stream(pack_streams[j % len(pack_streams)]):
                     if pending[j] is not None:
                         for w in pending[j]:
                             w.wait()
                         pending[j] = None
-            stream.wait_stream(pack_stream)
+            for ps in pack_streams:
+                stream.wait_stream(ps)
 
         settle(step, drain)
         for i in range(max(args.warmup, slots)):
