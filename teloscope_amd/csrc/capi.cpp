@@ -593,6 +593,7 @@ void ts_destroy(ts_ctx *ctx) {
         for (int i = 0; i < ts_ctx::kUpSlots; ++i) {
             ctx->pin_up[i].release();
             if (ctx->pin_up_ev[i]) (void)hipEventDestroy(ctx->pin_up_ev[i]);
+            ctx->d_pack[i].release(); ctx->d_runs[i].release(); ctx->pin_runs[i].release();
         }
         for (hipEvent_t e : ctx->gen_ev) if (e) (void)hipEventDestroy(e);
         for (PinBuf &pb : ctx->pin_down) pb.release();

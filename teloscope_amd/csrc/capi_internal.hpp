@@ -130,6 +130,8 @@ struct ts_ctx {
     static constexpr int kUpSlots = 3;
     PinBuf pin_up[kUpSlots];
     hipEvent_t pin_up_ev[kUpSlots] = {nullptr, nullptr, nullptr};
+    DevBuf d_pack[kUpSlots], d_runs[kUpSlots];   // packed upload: a chunk's 2-bit codes and invalid runs on the device
+    PinBuf pin_runs[kUpSlots];
     hipEvent_t gen_ev[2] = {nullptr, nullptr};   // TS_TIMING: around the general path's kernels
     PinBuf pin_down[2];
     hipStream_t up_stream = nullptr, scan_stream = nullptr, down_stream = nullptr;

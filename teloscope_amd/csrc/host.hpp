@@ -44,6 +44,15 @@ void interstitial_blocks(const BlockParams &bp, const ts_match *m, size_t n, std
 int  label_terminal_blocks(ts_block *blocks, size_t n, uint16_t gaps, uint64_t path_size,
                            uint32_t terminal_limit, std::string &label);
 
+// pack.cpp — the packed upload's host half: bases -> 2-bit codes + invalid runs
+struct InvalidRun { uint32_t start, len; };          // positions relative to the staged chunk
+struct PackRuns {
+    std::vector<InvalidRun> runs;
+    uint32_t open_start = 0, open_len = 0;
+    void finish();
+};
+void pack_bases(const unsigned char *src, size_t n, unsigned char *dst, bool fold, uint32_t pos0, PackRuns &r);
+
 float gc_content(const uint32_t counts[4], uint32_t window_size);
 float shannon_entropy(const uint32_t counts[4], uint32_t window_size);
 

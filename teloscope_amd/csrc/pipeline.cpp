@@ -144,6 +144,34 @@ const char *text_locate(const char *text, uint64_t text_len, uint64_t skip) {
     return end;
 }
 
+// Up to n bases of FASTA body text from the cursor *pp on (line ends skipped), cursor advanced; returns the bases taken
+// (fewer than n only when the text ends).
+uint64_t strip_take(char *dst, uint64_t n, const char **pp, const char *end) {
+    const char *p = *pp;
+    uint64_t left = n;
+    while (left && p < end) {
+        const char *nl = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+        const char *stop = nl ? nl : end;
+        uint64_t line = (uint64_t)(stop - p);
+        const bool cr = line && stop[-1] == '\r';
+        if (cr) --line;
+        const uint64_t take = std::min(line, left);
+        std::memcpy(dst, p, take);
+        dst += take; left -= take;
+        if (take < line) { p += take; break; }             // stopped inside the line
+        p = nl ? nl + 1 : end;
+    }
+    *pp = p;
+    return n - left;
+}
+
+constexpr uint32_t kPackRunCap = 1u << 18;                 // invalid runs a packed chunk may carry (more: the chunk goes as ASCII)
+
+bool packed_upload_enabled() {
+    const char *e = getenv("TS_PACKED_UPLOAD");
+    return !(e && e[0] == '0');
+}
+
 // Uploads pieces of an input layout to the device buffer that holds its bytes from lo_all on (din = address of byte
 // lo_all).  Consecutive pieces that lie close together in the layout (full scans, reads: a few padding bytes apart) are
 // mirrored together in one of three pinned 32 MB buffers, filled by several host threads — plain bases by memcpy, FASTA
@@ -216,6 +244,16 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
     for (const UpPiece &pc : pieces) total_bytes += pc.len;
     StagePool stage_pool(total_bytes >= (8u << 20) ? nthr : 1u);
     std::atomic<int> bad_text{0};
+    const bool fold = c->params.fold_case != 0;
+    uint64_t packed_min = 1u << 20;                            // small calls are latency, not link time: they go plain
+    if (const char *e = getenv("TS_PACKED_MIN_BYTES")) packed_min = strtoull(e, nullptr, 10);
+    bool use_packed = packed_upload_enabled() && total_bytes >= packed_min;
+    if (use_packed && !c->d_pack[0].p) {                       // the device side of the ring, once per context
+        for (int q = 0; q < ts_ctx::kUpSlots && use_packed; ++q) {
+            if (c->d_pack[q].ensure((kChunk >> 2) + 4096) != hipSuccess || c->d_runs[q].ensure((size_t)kPackRunCap * 8) != hipSuccess ||
+                c->pin_runs[q].ensure((size_t)kPackRunCap * 8) != hipSuccess) { (void)hipGetLastError(); use_packed = false; }
+        }
+    }
     size_t i = 0;
     while (i < pieces.size()) {
         const uint64_t c0 = pieces[i].off;
@@ -226,6 +264,76 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
         if (used[slot]) HIP_TRY(c, hipEventSynchronize(c->pin_up_ev[slot]));
         char *dst = (char *)c->pin_up[slot].p;
         const unsigned nt = bytes >= (4u << 20) ? nthr : 1u;
+        const uint64_t hi_pos = pieces[j - 1].off + pieces[j - 1].len;
+        // ---- packed: the chunk leaves as 2-bit codes + invalid runs (pack.cpp), a quarter of the bytes; unpack.hip
+        // restores the byte layout on the device.  Worker t packs the layout range [t, t + 1) x share of the chunk
+        // (ranges end at multiples of 4096 positions: no two workers write the same byte), pulling its bases out of the
+        // pieces that overlap it — plain pieces in place, FASTA text through a small buffer that the line ends are
+        // stripped into — and 'A' into the padding between pieces, which nobody reads.
+        if (use_packed && bytes >= 4096) {
+            const uint64_t c0a = c0 & ~63ull;
+            const uint64_t P = hi_pos - c0a;                                  // chunk positions, incl. the lead before c0
+            const uint64_t share = ((P + nt - 1) / nt + 4095) & ~4095ull;
+            std::vector<ts::PackRuns> wr(nt);
+            std::atomic<int> short_text{0};
+            auto pack_range = [&](unsigned t) {
+                const uint64_t a0 = (uint64_t)t * share, z0 = std::min<uint64_t>(P, a0 + share);
+                if (a0 >= z0) return;
+                constexpr uint64_t BK = 16384;
+                alignas(64) unsigned char buf[BK];
+                ts::PackRuns &R = wr[t];
+                size_t k = i;
+                while (k < j && pieces[k].off + pieces[k].len <= c0a + a0) ++k;      // first piece that reaches into the range
+                const char *tcur = nullptr, *tend = nullptr;                         // text cursor inside pieces[tk]
+                size_t tk = (size_t)-1;
+                for (uint64_t a = a0; a < z0; a += BK) {
+                    const uint64_t z = std::min(z0, a + BK), la = c0a + a, lz = c0a + z;   // layout range of the block
+                    while (k < j && pieces[k].off + pieces[k].len <= la) ++k;
+                    // wholly inside one plain piece: packed from where it lies
+                    if (k < j && !pieces[k].text_len && pieces[k].off <= la && pieces[k].off + pieces[k].len >= lz) {
+                        ts::pack_bases((const unsigned char *)pieces[k].src + (la - pieces[k].off), z - a, (unsigned char *)dst + (a >> 2), fold, (uint32_t)a, R);
+                        continue;
+                    }
+                    std::memset(buf, 'A', z - a);
+                    for (size_t q = k; q < j && pieces[q].off < lz; ++q) {
+                        const UpPiece &pc = pieces[q];
+                        const uint64_t s0 = std::max(pc.off, la), s1 = std::min(pc.off + pc.len, lz);
+                        if (s1 <= s0) continue;
+                        if (!pc.text_len) { std::memcpy(buf + (s0 - la), pc.src + (s0 - pc.off), s1 - s0); continue; }
+                        if (tk != q) {                                               // enter this text piece (at base s0 - pc.off)
+                            tk = q;
+                            tend = pc.src + pc.text_len;
+                            tcur = s0 > pc.off ? text_locate(pc.src, pc.text_len, s0 - pc.off) : pc.src;
+                        }
+                        if (strip_take((char *)buf + (s0 - la), s1 - s0, &tcur, tend) != s1 - s0) short_text.store(1);
+                    }
+                    ts::pack_bases(buf, z - a, (unsigned char *)dst + (a >> 2), fold, (uint32_t)a, R);
+                }
+                R.finish();
+            };
+            if (nt == 1u) pack_range(0); else stage_pool.run(nt, pack_range);
+            if (short_text.load()) bad_text.store(1);
+            size_t nruns = 0;
+            for (const ts::PackRuns &R : wr) nruns += R.runs.size();
+            if (nruns <= kPackRunCap) {
+                ts::InvalidRun *hr = (ts::InvalidRun *)c->pin_runs[slot].p;
+                size_t at = 0;
+                for (const ts::PackRuns &R : wr) { if (!R.runs.empty()) std::memcpy(hr + at, R.runs.data(), R.runs.size() * sizeof(ts::InvalidRun)); at += R.runs.size(); }
+                const uint64_t pbytes = (((P + 3) >> 2) + 3) & ~3ull;
+                std::memset(dst + ((P + 3) >> 2), 0, pbytes - ((P + 3) >> 2) + 8);     // (the kernel reads one dword past the last code)
+                HIP_TRY(c, hipMemcpyAsync(c->d_pack[slot].p, dst, pbytes + 8, hipMemcpyHostToDevice, c->up_stream));
+                if (nruns) HIP_TRY(c, hipMemcpyAsync(c->d_runs[slot].p, hr, nruns * sizeof(ts::InvalidRun), hipMemcpyHostToDevice, c->up_stream));
+                if (ts_k_launch_unpack(c->d_pack[slot].p, (uint32_t)(c0 - c0a), (char *)din + (c0 - lo_all), hi_pos - c0, c->d_runs[slot].p, (uint32_t)nruns,
+                                       (char *)din + (c0 - lo_all) - (c0 - c0a), c->up_stream) != 0)
+                    return c->fail(TS_ERR_HIP, "unpack kernel launch failed");
+                HIP_TRY(c, hipEventRecord(c->pin_up_ev[slot], c->up_stream));
+                used[slot] = true;
+                slot = (slot + 1) % ts_ctx::kUpSlots;
+                i = j;
+                continue;
+            }
+            // (a chunk with more invalid runs than the list holds — not sequence data — goes the plain way below)
+        }
         auto copy_part = [&](size_t k) {
             const UpPiece &pc = pieces[k];
             if (pc.text_len) { if (!strip_copy(dst + (pc.off - c0), pc.src, pc.text_len, pc.len)) bad_text.store(1); }

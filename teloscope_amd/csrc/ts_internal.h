@@ -280,6 +280,11 @@ int  ts_k_launch_tile_order_export(const uint32_t *tile_stats, const unsigned lo
                                    uint32_t nwaves, uint32_t ntiles, unsigned long long *dense_off, void *tmp,
                                    uint32_t *dense, unsigned long long capacity, unsigned long long *total_out,
                                    void *stream);
+// unpack.hip: a staged chunk of 2-bit codes (pack.cpp) -> the byte layout: chunk positions [first, first + n) to dst, then
+// 'N' over the chunk's invalid runs ({start, len} pairs, device memory; run position x lies at runs_base + x).
+// packed: 4-byte aligned, 8 readable bytes behind the last code.
+int  ts_k_launch_unpack(const void *packed, uint32_t first, void *dst, unsigned long long n, const void *runs, uint32_t nruns,
+                        void *runs_base, void *stream);
 int  ts_k_launch_widen_u16(const uint16_t *src, uint32_t *dst, unsigned long long n, void *stream);
 int  ts_k_launch_compact(const uint32_t *regions, const uint32_t *wave_fill,
                          const unsigned long long *wave_dense_base, uint32_t region_cap,

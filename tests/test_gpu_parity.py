@@ -18,7 +18,7 @@ import pytest
 from tests import harness as H
 from tests import seqgen
 from tests.backends import (OracleBackend, OracleReadFilter, ProductBackend, ProductReadFilter,
-                            assert_segment_equal)
+                            assert_segment_equal, segment_as_dict)
 from tests.test_oracle_read_filter_kats import KATS, RANDOM_OPTION_SETS, random_read_set
 
 pytestmark = pytest.mark.gpu
@@ -163,6 +163,47 @@ def test_random_segments_match_oracle(cli):
     for (s, ap, tips), g in zip(segs, got):
         e = orac.scan_segment(s, ap, tips)
         assert_segment_equal(g, e, tips, ctx="cli=%r len=%d" % (cli, len(s)))
+
+
+PACKED_ROUTE_GRID = ["-w 1000 -s 500 -r -g -e -m -i", "-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i", "-w 777 -s 333 -r -g -e -m -i -t 700",
+                     "-t 300", "-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i", "-c TTAGG -w 100 -s 50 -g -e -i -l 50"]
+
+
+@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("cli", PACKED_ROUTE_GRID)
+def test_packed_upload_route_equals_plain_route_and_oracle(cli, fold, monkeypatch):
+    """The host entry points upload bases as 2-bit codes + invalid runs (pack.cpp / unpack.hip) when a call is large; here
+    the threshold is taken away so that the segments of the parity grid go that way: IUPAC codes, soft-masked stretches
+    (valid when the context folds case, invalid otherwise), N runs, runs that cross the 16 k blocks and 4 k ranges the
+    packing threads work in, every byte value once.  Route on == route off == oracle, record for record."""
+    import teloscope_amd as ta
+    from teloscope_amd.cli import user_input
+    opts = H.parse_cli("x.fa " + cli)
+    ui = user_input(opts)
+    ui.foldCase = fold
+    tel = ta.Teloscope(ui)
+    orac = OracleBackend(opts)
+    rng = np.random.default_rng(len(cli) * 3 + int(fold))
+    segs = []
+    for i, n in enumerate([1, 3, 4, 5, 63, 64, 65, 4095, 4096, 4097, 16383, 16385, 70001, 250003, 1_100_000]):
+        s = bytearray(seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, telo_repeats=min(150, max(1, n // 40)), tvr_rate=0.03,
+                                        n_its=3, iupac=(n // 3000), lower=0.1 if i % 3 == 0 else 0.0, n_runs=(n // 20000)))
+        if n > 70000:
+            s[4090:4100] = b"N" * 10                       # across a range boundary
+            s[16380:16390] = b"nnnnnRYKMS"                 # across a block boundary
+            s[30000:30256] = bytes(range(256))             # every byte value
+        segs.append((bytes(s), int(rng.integers(0, 10 ** 7)), opts.ultra_fast))
+    exp = None
+    for route in ("1", "0"):
+        monkeypatch.setenv("TS_PACKED_UPLOAD", route)
+        monkeypatch.setenv("TS_PACKED_MIN_BYTES", "0")
+        got = [segment_as_dict(s) for s in tel.scanSegments(segs)]
+        if exp is None:
+            # the oracle is strict scanSegment (lower case = non-ACGT): a context that folds case sees what the reference's
+            # callers hand over after unmaskSequence
+            exp = [orac.scan_segment(s.upper() if fold else s, ap, tips) for s, ap, tips in segs]
+        for (s, ap, tips), g, e in zip(segs, got, exp):
+            assert_segment_equal(g, e, tips, ctx="cli=%r fold=%r route=%s len=%d" % (cli, fold, route, len(s)))
 
 
 DENSE_GRID = [
