@@ -432,7 +432,7 @@ def pcie_inclusive(L, K, tel, buf, offsets, lens, total):
                                 "visible_matches": nvis, "n_ctx": n_ctx,
                                 "entry_point": "ts_scan_segments_multi (windows, blocks and the match records a writer reads; one shard per context)"}
     return {"entry_points": "ts_scan_segments_blocks / ts_scan_segments (pageable host buffers in, host results out; "
-                            "groups of ~256 MB pipelined through upload / scan / download stages; best of 3)", "n_ctx": 1, **e2e}
+                            "groups of ~512 MB pipelined through upload / scan / download stages; bases cross PCIe as 2-bit codes + invalid runs, packed by the staging threads and unpacked on the device; best of 3)", "n_ctx": 1, **e2e}
 
 
 # ------------------------------------------------------------------------------------------- the assembly scan

@@ -43,7 +43,10 @@ double ms_between(Clock::time_point a, Clock::time_point b) { return std::chrono
 uint64_t group_target_bytes() {
     static const uint64_t v = [] {
         if (const char *e = getenv("TS_GROUP_MB")) { const long mb = atol(e); if (mb > 0) return (uint64_t)mb << 20; }
-        return (uint64_t)256 << 20;
+        // (with the packed upload a group's bases are staged in 128 MB chunks: larger groups, fewer hand-overs between the
+        // stages — profiles/r03/packed_upload_rate.txt)
+        const char *pk = getenv("TS_PACKED_UPLOAD");
+        return (uint64_t)((pk && pk[0] == '0') ? 256 : 512) << 20;
     }();
     return v;
 }
@@ -182,6 +185,7 @@ bool packed_upload_enabled() {
 // Asynchronous: the DMAs are queued on up_stream.  `pieces` ascend by offset and do not overlap.
 int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, uint64_t lo_all, int &slot, bool used[]) {
     constexpr uint64_t kChunk = 32u << 20, kMaxGap = 64u << 10;
+    constexpr uint64_t kChunkPacked = 4 * kChunk;            // a packed chunk fills the same 32 MB pinned slot with 128 MB of layout
     std::vector<UpPiece> pieces;
     pieces.reserve(pieces_in.size());
     bool any_text = false;
@@ -250,7 +254,7 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
     bool use_packed = packed_upload_enabled() && total_bytes >= packed_min;
     if (use_packed && !c->d_pack[0].p) {                       // the device side of the ring, once per context
         for (int q = 0; q < ts_ctx::kUpSlots && use_packed; ++q) {
-            if (c->d_pack[q].ensure((kChunk >> 2) + 4096) != hipSuccess || c->d_runs[q].ensure((size_t)kPackRunCap * 8) != hipSuccess ||
+            if (c->d_pack[q].ensure((kChunkPacked >> 2) + 4096) != hipSuccess || c->d_runs[q].ensure((size_t)kPackRunCap * 8) != hipSuccess ||
                 c->pin_runs[q].ensure((size_t)kPackRunCap * 8) != hipSuccess) { (void)hipGetLastError(); use_packed = false; }
         }
     }
@@ -259,7 +263,8 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
         const uint64_t c0 = pieces[i].off;
         size_t j = i + 1;
         uint64_t bytes = pieces[i].len;
-        while (j < pieces.size() && pieces[j].off + pieces[j].len - c0 <= kChunk &&
+        const uint64_t chunk_limit = use_packed ? kChunkPacked : kChunk;
+        while (j < pieces.size() && pieces[j].off + pieces[j].len - c0 <= chunk_limit &&
                pieces[j].off - (pieces[j - 1].off + pieces[j - 1].len) <= kMaxGap) { bytes += pieces[j].len; ++j; }
         if (used[slot]) HIP_TRY(c, hipEventSynchronize(c->pin_up_ev[slot]));
         char *dst = (char *)c->pin_up[slot].p;
@@ -332,7 +337,9 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
                 i = j;
                 continue;
             }
-            // (a chunk with more invalid runs than the list holds — not sequence data — goes the plain way below)
+            // a chunk with more invalid runs than the list holds is not sequence data: the rest of the call goes the plain way
+            use_packed = false;
+            continue;
         }
         auto copy_part = [&](size_t k) {
             const UpPiece &pc = pieces[k];
