@@ -137,7 +137,7 @@ typedef struct ts_block {
  * file, line ends included; the pieces, in order, hold the segment's `len` bases.  The library skips the line ends while
  * it stages the bases for upload, so a front end never has to join the lines of a record into one buffer (what gfalibs
  * does before walkPath, and the largest host cost once the scan itself takes milliseconds).  The entry points read
- * pieces until `len` bases are covered; of the last piece only what is needed. */
+ * pieces until `len` bases are covered (at most `n_pieces` of them); of the last piece only what is needed. */
 #define TS_INPUT_BASES       0
 #define TS_INPUT_TEXT_PIECES 1
 typedef struct ts_text_piece {
@@ -152,7 +152,9 @@ typedef struct ts_segment_in {
     uint64_t    abs_pos;
     uint8_t     tips_only;
     uint8_t     input_format;   /* TS_INPUT_BASES / TS_INPUT_TEXT_PIECES (tiled kernel's parameter sets only) */
-    uint8_t     reserved[6];
+    uint8_t     reserved[2];
+    uint32_t    n_pieces;       /* TS_INPUT_TEXT_PIECES: entries of the ts_text_piece array (the walk never reads past it;
+                                   pieces that hold fewer than `len` bases are TS_ERR_INVALID_ARG) */
 } ts_segment_in;
 
 /* SegmentData, include/teloscope.h:139-148.  `matches` holds what the

@@ -279,13 +279,15 @@ public:
         mutable uint64_t cursorCum = 0;
         Segment(const char *d, size_t n, uint64_t a, bool t) : data(d), size(n), absPos(a), tipsOnly(t) {}
         Segment(const std::string *s, uint64_t a, bool t) : data(s->data()), size(s->size()), absPos(a), tipsOnly(t) {}
-        Segment(const ts_text_piece *p, size_t nBases, uint64_t a, bool t, const TextLines *l = nullptr)
-            : data(nullptr), size(nBases), absPos(a), tipsOnly(t), pieces(p), lines(l) {}
+        size_t nPieces = 0;                    // entries of `pieces`
+        Segment(const ts_text_piece *p, size_t np, size_t nBases, uint64_t a, bool t, const TextLines *l = nullptr)
+            : data(nullptr), size(nBases), absPos(a), tipsOnly(t), pieces(p), lines(l), nPieces(np) {}
         ts_segment_in in() const {
             ts_segment_in x{};
             x.seq = pieces ? reinterpret_cast<const char *>(pieces) : data;
             x.len = size; x.abs_pos = absPos; x.tips_only = static_cast<uint8_t>(tipsOnly);
             x.input_format = pieces ? TS_INPUT_TEXT_PIECES : TS_INPUT_BASES;
+            x.n_pieces = static_cast<uint32_t>(nPieces);
             return x;
         }
         // bases [pos, pos + n) of the segment, upper-cased (matchSeq, src/teloscope.cpp:466-468)

@@ -402,7 +402,7 @@ inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::ve
             continue;
         }
         if (oneSegment(pi)) {
-            batch.emplace_back(rv.pieces, rv.size, 0, ui.ultraFastMode, rv.lines);   // its pieces as they are
+            batch.emplace_back(rv.pieces, rv.nPieces, rv.size, 0, ui.ultraFastMode, rv.lines);   // its pieces as they are
             continue;
         }
         // a segment = bases [a, a + n) of the record: the text pieces that hold them, the first one entered at base a
@@ -435,7 +435,7 @@ inline std::vector<PathData> walkRecordViews(Teloscope &teloscope, const std::ve
                 sl.push_back(L);
                 at += n; left -= n; c2 += rv.pieces[q].n_bases;
             }
-            batch.emplace_back(sp.data(), static_cast<size_t>(sg.second), sg.first, ui.ultraFastMode, sl.data());
+            batch.emplace_back(sp.data(), sp.size(), static_cast<size_t>(sg.second), sg.first, ui.ultraFastMode, sl.data());
         }
     }
     // without -m nothing downstream reads a match record: blocks and counts come from the device

@@ -58,7 +58,10 @@ class Block(C.Structure):
 
 class SegmentIn(C.Structure):
     _fields_ = [("seq", C.c_char_p), ("len", C.c_uint64), ("abs_pos", C.c_uint64),
-                ("tips_only", C.c_uint8), ("input_format", C.c_uint8), ("reserved", C.c_uint8 * 6)]
+                ("tips_only", C.c_uint8), ("input_format", C.c_uint8), ("reserved", C.c_uint8 * 2), ("n_pieces", C.c_uint32)]
+
+
+TS_INPUT_BASES, TS_INPUT_TEXT_PIECES = 0, 1
 
 
 class TextPiece(C.Structure):

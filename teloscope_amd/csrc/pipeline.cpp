@@ -84,7 +84,7 @@ private:
 
 enum class Mode { Matches, Blocks, ReadPass };
 
-struct Item { const char *seq; uint64_t len, abs_pos; uint8_t format; };     // format: TS_INPUT_BASES / TS_INPUT_TEXT_PIECES (seq = ts_text_piece[])
+struct Item { const char *seq; uint64_t len, abs_pos; uint8_t format; uint32_t n_pieces; };     // format: TS_INPUT_BASES / TS_INPUT_TEXT_PIECES (seq = ts_text_piece[])
 
 struct Group {
     size_t first = 0, count = 0;                  // items [first, first + count) of the call's item list
@@ -392,7 +392,8 @@ int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
                 const ts_text_piece *tp = (const ts_text_piece *)items[i].seq;
                 uint64_t cum = 0, want = rg.start, left = rg.len, off = sp.in_off + rg.start;
                 for (size_t k = 0; left; ++k) {
-                    if (cum >= sp.len) return c->fail(TS_ERR_INVALID_ARG, "text pieces hold fewer bases than the segment's length");
+                    if (k >= items[i].n_pieces || cum >= sp.len)
+                        return c->fail(TS_ERR_INVALID_ARG, "text pieces hold fewer bases than the segment's length (or n_pieces is not set)");
                     const ts_text_piece &t = tp[k];
                     if (t.text_len > (16ull << 20) + 4096) return c->fail(TS_ERR_INVALID_ARG, "a text piece is larger than 16 MiB");
                     if (want >= cum + t.n_bases) { cum += t.n_bases; continue; }      // wholly before the region
@@ -1025,7 +1026,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
 
 std::vector<Item> items_of(const ts_segment_in *segs, const std::vector<size_t> &which) {
     std::vector<Item> v(which.size());
-    for (size_t i = 0; i < which.size(); ++i) v[i] = Item{segs[which[i]].seq, segs[which[i]].len, segs[which[i]].abs_pos, segs[which[i]].input_format};
+    for (size_t i = 0; i < which.size(); ++i) v[i] = Item{segs[which[i]].seq, segs[which[i]].len, segs[which[i]].abs_pos, segs[which[i]].input_format, segs[which[i]].n_pieces};
     return v;
 }
 
@@ -1082,7 +1083,7 @@ int ts_scan_segments_unlocked(ts_ctx *ctx, const ts_segment_in *segs, size_t n_s
 int ts_pipeline_ensure_streams(ts_ctx *c) { return ensure_streams(c); }
 int ts_pipeline_upload_batch(ts_batch *b, const ts_segment_in *segs, int *slot, bool used[]) {
     std::vector<Item> items(b->segs.size());
-    for (size_t i = 0; i < items.size(); ++i) items[i] = Item{segs[i].seq, segs[i].len, segs[i].abs_pos, segs[i].input_format};
+    for (size_t i = 0; i < items.size(); ++i) items[i] = Item{segs[i].seq, segs[i].len, segs[i].abs_pos, segs[i].input_format, segs[i].n_pieces};
     return upload_batch(b, items.data(), *slot, used);
 }
 
@@ -1144,7 +1145,7 @@ int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
         uint64_t n = lens[i];
         if (n && !seqs[i]) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
         if (n && seqs[i][n - 1] == '\r') --n;             // src/read-filter.cpp:38-40
-        items[i] = Item{seqs[i], n, 0, TS_INPUT_BASES};
+        items[i] = Item{seqs[i], n, 0, TS_INPUT_BASES, 0};
     }
     if (!ctx->fast_ok) {
         // pattern sets outside the tiled kernel (mixed lengths, k > 8): general kernels + host block calling

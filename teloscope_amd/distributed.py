@@ -383,6 +383,10 @@ class HipShard:
         (a wave's region or the export buffer was too small) the batch is synced — which grows the regions and
         rescans — the export buffer grown, and the export repeated."""
         import torch
+        # the read-back below is ordered on torch's CURRENT stream: it sees the export only if that is the stream the scan
+        # and the export were enqueued on
+        if int(getattr(stream_ptr, "value", stream_ptr) or 0) != int(torch.cuda.current_stream().cuda_stream):
+            raise ValueError("HipShard.finish: stream_ptr must be torch's current stream (enter `with torch.cuda.stream(s)` first)")
         for _ in range(4):
             n, bad = (int(x) for x in self.total[slot].tolist())         # D2H of 16 bytes: waits for the stream
             if not bad:

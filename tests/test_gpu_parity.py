@@ -206,6 +206,49 @@ def test_packed_upload_route_equals_plain_route_and_oracle(cli, fold, monkeypatc
             assert_segment_equal(g, e, tips, ctx="cli=%r fold=%r route=%s len=%d" % (cli, fold, route, len(s)))
 
 
+def test_text_pieces_are_bounded_by_their_count():
+    """TS_INPUT_TEXT_PIECES: the piece array carries its length (ts_segment_in.n_pieces); pieces that hold fewer bases
+    than the segment declares — or a count that is not set — are TS_ERR_INVALID_ARG, never a read past the array; the
+    same text through pieces and as joined bases gives the same segment."""
+    import ctypes as C
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import user_input
+    opts = H.parse_cli("x.fa -w 1000 -s 500 -r -g -e -m -i")
+    tel = ta.Teloscope(user_input(opts))
+    L = K.lib()
+    rng = np.random.default_rng(3)
+    seq = seqgen.chromosome(rng, 30_011, opts.canonical_fwd, opts.canonical_rev, n_its=2, iupac=3)
+    text = b"\n".join(seq[i:i + 70] for i in range(0, len(seq), 70)) + b"\n"
+    cuts = [0, 7100, 7171 * 2, len(text)]                                  # piece ends on line ends and inside lines
+    blobs = [text[a:b] for a, b in zip(cuts, cuts[1:])]
+    pieces = (K.TextPiece * len(blobs))()
+    for i, bl in enumerate(blobs):
+        pieces[i].text = bl
+        pieces[i].text_len = len(bl)
+        pieces[i].n_bases = len(bl.replace(b"\n", b""))
+    assert sum(p.n_bases for p in pieces) == len(seq)
+
+    def scan(n_pieces, length):
+        seg = (K.SegmentIn * 1)()
+        seg[0].seq = C.cast(pieces, C.c_char_p)
+        seg[0].len = length
+        seg[0].input_format = K.TS_INPUT_TEXT_PIECES
+        seg[0].n_pieces = n_pieces
+        out = (K.SegmentOut * 1)()
+        rc = L.ts_scan_segments(tel._ctx.ptr, seg, 1, out)
+        return rc, out
+
+    rc, out = scan(len(blobs), len(seq))
+    assert rc == 0, tel._ctx.error()
+    got = segment_as_dict(ta.SegmentData(out[0], False))
+    assert_segment_equal(got, OracleBackend(opts).scan_segment(seq, 0, False), False, ctx="text pieces")
+    L.ts_free_segments(out, 1)
+    for n_pieces, length in ((len(blobs) - 1, len(seq)), (0, len(seq)), (len(blobs), len(seq) + 5)):
+        rc, out = scan(n_pieces, length)
+        assert rc == K.TS_ERR_INVALID_ARG, (n_pieces, length, rc)
+
+
 DENSE_GRID = [
     # every position of a homopolymer run is a match: the per-chunk match list, the staging flushes and
     # the packed 16-bit window counters of the tiled kernel at their limits
