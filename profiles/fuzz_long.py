@@ -21,8 +21,13 @@ for it in range(iters):
     w = int(rng.choice([len(c), 17, 64, 100, 333, 500, 1000, 2000, 5000, 12000, 30000]))
     s = int(rng.integers(max(1, w // 40), w + 1)) if rng.random() < 0.5 else w
     tips = rng.random() < 0.2
-    cli = "-c %s -x %d -w %d -s %d -t %d -k %d -d %d -l %d -y %.2f" % (
-        c, int(rng.integers(0, 3)), w, s, int(rng.choice([50, 300, 5000, 50000])),
+    pat = ""
+    if rng.random() < 0.25:                      # a second motif of another length: the general path's mixed-length sets
+        c2 = motifs[int(rng.integers(0, len(motifs)))]
+        if len(c2) != len(c) and min(len(c), len(c2)) >= 4:
+            pat = " -p %s,%s" % (c, c2)
+    cli = "-c %s%s -x %d -w %d -s %d -t %d -k %d -d %d -l %d -y %.2f" % (
+        c, pat, int(rng.integers(0, 2 if pat else 3)), w, s, int(rng.choice([50, 300, 5000, 50000])),
         int(rng.choice([5, 20, 50])), int(rng.choice([10, 100, 500])), int(rng.choice([12, 60, 300])),
         float(rng.choice([0.3, 0.5, 0.9])))
     if not tips:
@@ -32,7 +37,7 @@ for it in range(iters):
         continue
     prod, orac = ProductBackend(opts), OracleBackend(opts)
     if orac.ambiguous:
-        orac = OracleBackend(opts, patterns=prod.patterns)
+        orac = orac.with_ambiguous_orientation_from(prod.patterns)
     dense = (c.encode() * 4000)[:int(rng.integers(2000, 24000))]
     mixed = bytearray(seqgen.chromosome(rng, int(rng.integers(30000, 200000)), opts.canonical_fwd, opts.canonical_rev,
                                         telo_repeats=int(rng.integers(10, 900)), n_its=6, iupac=int(rng.integers(0, 8)),
