@@ -207,3 +207,47 @@ def test_scan_segments_multi_equals_oracle():
             for i in range(n):
                 assert_visible_view_equal(ta.SegmentData(out[i], tipsv[i]), exp[i], tipsv[i], cnt[i], "%s nctx %d segment %d" % (cli, nctx, i))
             L.ts_free_segments(out, n)
+
+
+def test_eight_way_split_of_the_bench_assembly_merges_to_the_one_part_result():
+    """configs[2] at its real size, split as 8 GPUs would split it: the bench's own assembly (3.0 Gb, 200 contigs: 250 Mb
+    contigs spread over several parts, boundaries inside segments, context tiles) — every part scanned, block-called and
+    packed on its own restricted batch (one after the other on this GPU), the 8 messages merged.  The oracle needs
+    minutes for 3 Gb; the witness here is the ONE-part message of the same plan (no boundary, no context), whose kernels
+    the small-size tests pin to the oracle: windows, blocks, visible records and counts must be identical for every
+    segment, and the 8 messages together must stay under the 100 MB the design promises."""
+    import torch
+    import bench
+    import teloscope_amd as ta
+    from teloscope_amd.distributed import ShardPlan, finalize_shards, free_segments, shard_info
+    dev = torch.device("cuda", 0)
+    opts, tel = _teloscope(HEADLINE)
+    total = 3_000_000_000
+    lens = bench.contig_lengths(total, 200, 42)
+    plan1 = ShardPlan(tel, lens, world=1)
+    buf = torch.zeros(int(plan1.info.input_bytes), dtype=torch.uint8, device=dev)
+    bench.fill_synthetic(buf, plan1.segment_offsets(), lens, 42, dev)
+    results = {}
+    for world in (1, 8):
+        plan = plan1 if world == 1 else ShardPlan(tel, lens, world=world)
+        msgs, stats = _pack_all_parts(plan, buf, dev)
+        if world == 8:
+            assert sum(len(m) for m in msgs[1:]) < 100e6
+            inside = sum(int(shard_info(plan, p).ext_begin != shard_info(plan, p).own_begin) for p in range(world))
+            assert inside >= 4, "boundaries did not fall inside segments"
+        rc, out, cnt = finalize_shards(plan, msgs)
+        assert rc == 0, (world, rc, tel._ctx.error())
+        res = []
+        for i in range(len(lens)):
+            sd = ta.SegmentData(out[i], False)
+            res.append((sd.windows.tobytes(), sd.terminalBlocks.tobytes(), sd.interstitialBlocks.tobytes(), sd._m.tobytes(),
+                        (cnt[i].n_windows, cnt[i].n_matches, cnt[i].n_canonical, cnt[i].n_forward)))
+        results[world] = res
+        free_segments(plan, out)
+        if world != 1:
+            plan.close()
+    plan1.close()
+    assert sum(r[4][1] for r in results[1]) > 90_000_000
+    for i, (a, b) in enumerate(zip(results[1], results[8])):
+        for name, x, y in zip(("windows", "terminal blocks", "interstitial blocks", "visible records", "counts"), a, b):
+            assert x == y, "segment %d: %s differ between the 1-part and the 8-part merge" % (i, name)

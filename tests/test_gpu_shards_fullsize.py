@@ -152,6 +152,17 @@ def test_bench_read_shard_over_two_ranks_equals_one_rank_and_the_oracle():
         assert 0.02 < o["roofline"]["frac"] < 1.0 and o["roofline"]["algorithmic_bytes"] < 1.001 * o["config"]["bases"] / o["n_gpus"] + 1e6
 
 
+def test_bench_two_ranks_configs4_plant_equals_single_gpu():
+    """configs[4] (15 Gb plant assembly, k = 7, w = 2000 s = 1000) as two ranks (gloo, sharing this GPU): the merged writer
+    view of the two shards against a single-GPU scan of the whole assembly, at full size (--verify)."""
+    out = _bench("--gpus", "2", "--verify", "--gbases", "15", "--contigs", "521", "--flags", "-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i",
+                 "--steps", "2", "--warmup", "1", "--no-cpu-baseline", timeout=1500)
+    assert out["n_gpus"] == 2 and out["config"]["bases"] == 15_000_000_000
+    v = out["verify"]
+    assert v["contigs_checked"] == 521 and v["matches_checked"] == out["config"]["matches"]
+    assert v["sharded_equals_single_gpu"]["segments"] == 521 and v["sharded_equals_single_gpu"]["windows"] > 14_000_000
+
+
 def test_default_line_carries_the_read_filter_and_the_launch_protocol():
     """What the driver's plain `python bench.py` prints, minus the slow CPU leg: the `reads` sub-record (configs[3] at
     500 k reads, roofline over the whole step by 1 B/base + 1 bit/read, oracle-checked sample), the single-shot figures
