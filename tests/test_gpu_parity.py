@@ -206,6 +206,46 @@ def test_packed_upload_route_equals_plain_route_and_oracle(cli, fold, monkeypatc
             assert_segment_equal(g, e, tips, ctx="cli=%r fold=%r route=%s len=%d" % (cli, fold, route, len(s)))
 
 
+def test_packed_upload_falls_back_for_data_that_is_not_sequence(monkeypatch):
+    """A chunk with more invalid runs than the packed route's run list holds (2^18) goes as ASCII: 1.2 M isolated 'N's in a
+    2.4 Mb segment, next to an ordinary one; == oracle either way."""
+    import teloscope_amd as ta
+    from teloscope_amd.cli import user_input
+    opts = H.parse_cli("x.fa -w 1000 -s 500 -r -g -e -m -i")
+    tel = ta.Teloscope(user_input(opts))
+    orac = OracleBackend(opts)
+    rng = np.random.default_rng(12)
+    junk = bytearray(seqgen.chromosome(rng, 2_400_000, opts.canonical_fwd, opts.canonical_rev, n_its=4))
+    junk[0::2] = b"N" * len(junk[0::2])
+    good = seqgen.chromosome(rng, 300_000, opts.canonical_fwd, opts.canonical_rev, n_its=4, iupac=9)
+    segs = [(good, 7, False), (bytes(junk), 11, False), (good[::-1], 13, False)]
+    monkeypatch.setenv("TS_PACKED_MIN_BYTES", "0")
+    got = [segment_as_dict(s) for s in tel.scanSegments(segs)]
+    for (s, ap, tips), g in zip(segs, got):
+        assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="len=%d" % len(s))
+
+
+def test_general_path_dense_mixed_lengths_overflow_their_tile_slots():
+    """The fused general kernel gives a tile a slot of one record per position; a mixed-length set on a homopolymer puts
+    two records on every position: the group must run again with larger slots (and say nothing wrong in between)."""
+    opts = H.parse_cli("x.fa -p AAAAAA,AAAAA -x 0 -w 1000 -s 500 -r -g -e -m -i")
+    prod, orac = ProductBackend(opts), OracleBackend(opts)
+    assert not prod.teloscope.usesFastPath()
+    if orac.ambiguous:
+        orac = orac.with_ambiguous_orientation_from(prod.patterns)
+    rng = np.random.default_rng(4)
+    segs = []
+    for n, runs in [(20000, [(100, 19000)]), (9000, [(0, 9000)]), (70000, [(5000, 30000), (40000, 4097)])]:
+        s = bytearray(seqgen.random_dna(rng, n).tobytes())
+        for a, ln in runs:
+            s[a:a + ln] = b"A" * ln
+        segs.append((bytes(s), int(rng.integers(0, 10 ** 6)), False))
+    segs.append((seqgen.chromosome(rng, 50000, opts.canonical_fwd, opts.canonical_rev, n_its=2), 5, False))
+    got = prod.scan_segments(segs)
+    for (s, ap, tips), g in zip(segs, got):
+        assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="dense mixed len=%d" % len(s))
+
+
 def test_text_pieces_are_bounded_by_their_count():
     """TS_INPUT_TEXT_PIECES: the piece array carries its length (ts_segment_in.n_pieces); pieces that hold fewer bases
     than the segment declares — or a count that is not set — are TS_ERR_INVALID_ARG, never a read past the array; the
