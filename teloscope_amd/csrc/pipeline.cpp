@@ -527,28 +527,45 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
     Channel<Group *> to_scan, to_down;
     Semaphore inputs_in_flight(2);                               // device input buffers alive at a time
 
-    std::thread uploader([&] {
+    // planning (host only: tiles, windows, the input layout of a group) runs a group or more ahead of the upload on a thread
+    // of its own: for read batches — hundreds of thousands of segments — it takes as long as the upload itself
+    Channel<Group *> to_upload;
+    std::thread planner([&] {
         ctx->bind_this_thread();
         DeviceGuard g(ctx->device);
-        int slot = 0;
-        bool used[ts_ctx::kUpSlots] = {false, false, false};
         std::vector<uint64_t> lens, abs;
         for (Group &gr : groups) {
             if (first_err.load() != TS_OK) break;
             const auto t0 = Clock::now();
             lens.resize(gr.count); abs.resize(gr.count);
             for (size_t i = 0; i < gr.count; ++i) { lens[i] = items[gr.first + i].len; abs[i] = items[gr.first + i].abs_pos; }
-            inputs_in_flight.acquire();
             gr.b = ts_batch_create(ctx, lens.data(), abs.data(), gr.count, tips ? 1 : 0, 0);
-            if (!gr.b) { set_err(ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP); inputs_in_flight.release(); break; }
+            gr.t_plan = ms_between(t0, Clock::now());
+            if (!gr.b) { set_err(ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP); break; }
+            to_upload.push(&gr);
+        }
+        to_upload.close();
+    });
+
+    std::thread uploader([&] {
+        ctx->bind_this_thread();
+        DeviceGuard g(ctx->device);
+        int slot = 0;
+        bool used[ts_ctx::kUpSlots] = {false, false, false};
+        Group *grp;
+        while (to_upload.pop(grp)) {
+            Group &gr = *grp;
+            if (first_err.load() != TS_OK) { ts_batch_destroy(gr.b); gr.b = nullptr; continue; }
+            const auto t0 = Clock::now();
+            inputs_in_flight.acquire();
             int rc = ts_batch_ensure_device(gr.b);
             const auto t1 = Clock::now();
             if (rc == TS_OK) rc = upload_batch(gr.b, items.data() + gr.first, slot, used);
             if (rc == TS_OK && hipEventCreateWithFlags(&gr.uploaded, hipEventDisableTiming) != hipSuccess) rc = ctx->fail(TS_ERR_HIP, "hipEventCreate failed");
             if (rc == TS_OK && hipEventRecord(gr.uploaded, ctx->up_stream) != hipSuccess) rc = ctx->fail(TS_ERR_HIP, "hipEventRecord failed");
-            gr.t_plan = ms_between(t0, t1);
+            gr.t_plan += ms_between(t0, t1);
             gr.t_upload = ms_between(t1, Clock::now());
-            if (rc != TS_OK) { set_err(rc); ts_batch_destroy(gr.b); gr.b = nullptr; inputs_in_flight.release(); break; }
+            if (rc != TS_OK) { set_err(rc); ts_batch_destroy(gr.b); gr.b = nullptr; inputs_in_flight.release(); continue; }
             to_scan.push(&gr);
         }
         (void)hipStreamSynchronize(ctx->up_stream);              // the pinned ring is free again when the call returns
@@ -620,6 +637,7 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
         }
         if (post.joinable()) post.join();
     });
+    planner.join();
     uploader.join();
     scanner.join();
     downloader.join();
