@@ -152,6 +152,28 @@ def test_bench_read_shard_over_two_ranks_equals_one_rank_and_the_oracle():
         assert 0.02 < o["roofline"]["frac"] < 1.0 and o["roofline"]["algorithmic_bytes"] < 1.001 * o["config"]["bases"] / o["n_gpus"] + 1e6
 
 
+def test_bench_under_the_drivers_launcher():
+    """The driver's own launch form for N > 1 — python -m torch.distributed.run --nproc-per-node N bench.py --gpus N, ranks
+    from RANK / LOCAL_RANK / WORLD_SIZE in the environment — with two ranks on this one GPU (gloo): one JSON line from rank
+    0, the merged result equal to a single-GPU scan."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--gbases", "0.3", "--contigs", "14", "--verify", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3
+    assert out["verify"]["sharded_equals_single_gpu"]["segments"] == 14
+
+
 def test_bench_two_ranks_configs4_plant_equals_single_gpu():
     """configs[4] (15 Gb plant assembly, k = 7, w = 2000 s = 1000) as two ranks (gloo, sharing this GPU): the merged writer
     view of the two shards against a single-GPU scan of the whole assembly, at full size (--verify)."""
