@@ -214,6 +214,16 @@ int     ts_takes_text_input(const ts_ctx *ctx, int tips_only);
  * host a buffer or a staging thread on the other socket costs 15-20 % of the PCIe-inclusive rate. */
 int     ts_bind_thread_to_device(const ts_ctx *ctx);
 
+/* ---- The packed upload's host half, as a utility (host only, no device needed): `n` bases at `src` -> 2-bit codes at
+ *      `dst` ((n + 3) / 4 bytes; base i at bits 2 (i & 3) .. +1 of byte i >> 2; A 0, C 1, T 2, G 3 — the scan kernel's own
+ *      code — and 0 for every byte that is not one of the four letters), and the runs of such bytes {start, length} in
+ *      `runs` (up to run_cap; *n_runs = how many there are — more than run_cap: TS_ERR_INVALID_ARG, nothing usable).
+ *      fold_case as in ts_params.  This is what the host entry points do to every chunk they upload (unless
+ *      TS_PACKED_UPLOAD=0): a quarter of the bytes cross PCIe, and a kernel restores the byte layout in HBM. */
+typedef struct ts_invalid_run { uint32_t start, len; } ts_invalid_run;
+int     ts_pack_bases(const char *src, uint64_t n, int fold_case, uint8_t *dst, ts_invalid_run *runs, uint64_t run_cap,
+                      uint64_t *n_runs);
+
 /* ---- Teloscope::scanSegment, batched (src/teloscope.cpp:537-658).  out[i] receives the
  *      SegmentData of segs[i]; a one-element call equals one scanSegment() call.  Host
  *      buffers in, host results out (H2D, kernels, D2H and host block calling inside). */

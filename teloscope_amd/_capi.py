@@ -135,7 +135,7 @@ SYMBOLS = [
     "ts_batch_export", "ts_batch_adopt", "ts_batch_tile_stats_ptr", "ts_filter_reads_multi", "ts_batch_read_pass",
     "ts_batch_wire16_ok", "ts_wire_widen_u16", "ts_takes_text_input", "ts_bind_thread_to_device",
     "ts_batch_shard_info", "ts_batch_restrict_shard", "ts_batch_set_shard_scale", "ts_batch_pack_shard",
-    "ts_shard_peek", "ts_shards_finalize", "ts_scan_segments_multi", "ts_batch_read_pass_status",
+    "ts_shard_peek", "ts_shards_finalize", "ts_scan_segments_multi", "ts_batch_read_pass_status", "ts_pack_bases",
 ]
 
 
@@ -207,6 +207,8 @@ def lib():
     L.ts_uses_fast_path.argtypes = [C.c_void_p]
     L.ts_takes_text_input.argtypes = [C.c_void_p, C.c_int]
     L.ts_bind_thread_to_device.argtypes = [C.c_void_p]
+    L.ts_pack_bases.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.ts_pack_bases.restype = C.c_int
     L.ts_scan_segments.argtypes = [C.c_void_p, C.POINTER(SegmentIn), C.c_size_t, C.POINTER(SegmentOut)]
     L.ts_scan_segments_blocks.argtypes = [C.c_void_p, C.POINTER(SegmentIn), C.c_size_t, C.POINTER(SegmentOut),
                                           C.POINTER(SegmentCounts)]

@@ -631,6 +631,18 @@ int ts_uses_fast_path(const ts_ctx *ctx) {
     return ctx && ts_full_scan_supported(ctx, why) ? 1 : 0;
 }
 
+int ts_pack_bases(const char *src, uint64_t n, int fold_case, uint8_t *dst, ts_invalid_run *runs, uint64_t run_cap, uint64_t *n_runs) {
+    if ((!src || !dst) && n) return TS_ERR_INVALID_ARG;
+    if (n > 0xFFFFFFFFull) return TS_ERR_INVALID_ARG;            // (run positions are 32 bits: pack in pieces)
+    ts::PackRuns R;
+    ts::pack_bases((const unsigned char *)src, (size_t)n, dst, fold_case != 0, 0u, R);
+    R.finish();
+    if (n_runs) *n_runs = R.runs.size();
+    if (R.runs.size() > run_cap) return TS_ERR_INVALID_ARG;
+    for (size_t i = 0; i < R.runs.size(); ++i) { runs[i].start = R.runs[i].start; runs[i].len = R.runs[i].len; }
+    return TS_OK;
+}
+
 int ts_bind_thread_to_device(const ts_ctx *ctx) {
     if (!ctx || ctx->node_cpus.empty()) return 0;
     cpu_set_t before, after;

@@ -170,3 +170,43 @@ def test_planner_tiling_choices(ta, monkeypatch):
     assert windows_per_tile(headline) == 31
     monkeypatch.setenv("TS_GEOMETRY", "10,6")
     assert windows_per_tile("-c TTAGGG -r -g -e -m -i") == 12
+
+
+def test_pack_bases_against_a_numpy_statement_of_it():
+    """ts_pack_bases (the packed upload's host half; AVX2 with a scalar tail): 2-bit codes and invalid runs of random
+    buffers of every length around the vector widths, with and without case folding, against numpy."""
+    from teloscope_amd import _capi as K
+    L = K.lib()
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGTacgtNRYKMnX-*\x00\xff", dtype=np.uint8)
+    code_of = {ord("A"): 0, ord("C"): 1, ord("T"): 2, ord("G"): 3}
+    for n in list(range(0, 140)) + [255, 256, 257, 4095, 4096, 4097, 100_003]:
+        for fold in (0, 1):
+            for clean in (False, True):
+                s = (alpha[:4] if clean else alpha)[rng.integers(0, 4 if clean else len(alpha), size=n)].astype(np.uint8)
+                dst = np.full((n + 3) // 4 + 8, 0xEE, dtype=np.uint8)
+                runs = np.zeros((n + 1, 2), dtype=np.uint32)
+                nr = C.c_uint64(0)
+                rc = L.ts_pack_bases(s.tobytes(), n, fold, dst.ctypes.data, runs.ctypes.data, n + 1, C.byref(nr))
+                assert rc == 0
+                f = np.where(fold, s & 0xDF, s).astype(np.uint8) if n else s
+                valid = np.isin(f, np.frombuffer(b"ACGT", dtype=np.uint8))
+                codes = np.zeros(n, dtype=np.uint8)
+                for ch, cd in code_of.items():
+                    codes[f == ch] = cd
+                codes[~valid] = 0
+                pad = np.concatenate([codes, np.zeros((-n) % 4, dtype=np.uint8)]).reshape(-1, 4)
+                want = (pad[:, 0] | (pad[:, 1] << 2) | (pad[:, 2] << 4) | (pad[:, 3] << 6)).astype(np.uint8)
+                assert np.array_equal(dst[:len(want)], want), (n, fold, clean)
+                assert (dst[len(want):] == 0xEE).all(), "wrote past the packed bytes"
+                inv = np.zeros(n, dtype=bool)
+                last_end = -1
+                for a, ln in runs[:nr.value]:
+                    assert ln > 0 and int(a) > last_end, "runs must ascend, be maximal and not touch"
+                    inv[a:a + ln] = True
+                    last_end = int(a) + int(ln)
+                assert np.array_equal(inv, ~valid), (n, fold, clean)
+    # a run list that is too short is an error, and says how many runs there are
+    nr = C.c_uint64(0)
+    dst = np.zeros(8, dtype=np.uint8)
+    assert L.ts_pack_bases(b"ANANANAN", 8, 1, dst.ctypes.data, None, 0, C.byref(nr)) == K.TS_ERR_INVALID_ARG and nr.value == 4
