@@ -5,13 +5,13 @@
 // (src/teloscope.cpp:413-415) — is restated here LITERALLY (the main / carry attribution of analyzeWindow, not its
 // closed form), for a whole batch of segments at a time and with nothing but ordering work left to the host:
 //
-//   ts_general_fused    ONE pass, one workgroup per tile of 4096 positions of one scanned region: bases staged into
-//                       LDS as 2-bit codes, the pattern lists (per length: ascending 2-bit codes + {forward,
-//                       canonical}) and a prefix bitmap per length beside them; every position's matches (3 bits
-//                       {match, forward, canonical} per length) stay in LDS; from there the workgroup adds its share to
-//                       the window records (a wave per window part, literal main / carry attribution, DPP reduction,
-//                       atomics) and writes the match records the reference pushes, in position order, into the
-//                       tile's slot.
+//   ts_general_fused_list  ONE pass, one workgroup per tile of 4096 positions of one scanned region: bases staged into
+//                       LDS as 2-bit planes, the pattern lists (per length: ascending 2-bit codes + {forward, canonical})
+//                       and a prefix bitmap per length beside them; positions only ask the bitmaps, candidates go to
+//                       per-wave lists in LDS, and everything per match — search, push test, window shares, record —
+//                       runs a lane per candidate on full wavefronts.
+//   ts_general_fused    the position-strided form of the same pass (tiny steps, pattern lists too large for LDS, dense
+//                       tiles whose candidate lists spill).
 //   ts_general_compact  the tiles' slots into one dense tile-ordered stream (after a prefix sum over the counts).
 //
 // Traffic: 1 B/base in, 32 B/window and 2 x 4 B/match out.  (Rounds 1-2 ran three kernels around a 4 B/base match mask
@@ -65,6 +65,9 @@ struct PushGeom {
     uint32_t r1;         // ov > 0:  Xb - k1 s     (Xb = max(P0, ov) - ov, k1 = Xb / s)
     uint32_t D1;         // ov > 0:  P0 - k1 s     (< w + s)
     uint32_t dsub;       // ov > 0:  what to take off (P0-relative end) to get x - Xb: 0 if P0 > ov else ov - P0
+    u64 k0, k1;          // the quotients above
+    u64 kP0;             // P0 / s, and
+    uint32_t rP0;        // P0 - kP0 s   (both cases)
 };
 
 __device__ __forceinline__ PushGeom push_geom(u64 P0, u64 n, const TsGenericGeom &Q) {
@@ -76,12 +79,16 @@ __device__ __forceinline__ PushGeom push_geom(u64 P0, u64 n, const TsGenericGeom
         const u64 k0 = P0 / Q.s;
         g.r0 = (uint32_t)(P0 - k0 * Q.s);
         g.N0 = n - k0 * Q.s;
+        g.k0 = k0; g.kP0 = k0; g.rP0 = g.r0;
     } else {
         const u64 Xb = P0 > g.ov ? P0 - g.ov : 0ull;
         const u64 k1 = Xb / Q.s;
         g.r1 = (uint32_t)(Xb - k1 * Q.s);
         g.D1 = (uint32_t)(P0 - k1 * Q.s);
         g.dsub = P0 > g.ov ? 0u : (uint32_t)(g.ov - P0);
+        g.k1 = k1;
+        g.kP0 = P0 / Q.s;
+        g.rP0 = (uint32_t)(P0 - g.kP0 * Q.s);
     }
     return g;
 }
@@ -89,20 +96,47 @@ __device__ __forceinline__ PushGeom push_geom(u64 P0, u64 n, const TsGenericGeom
 // Is the match (tile-relative position j, length l) pushed to the reference's match vectors by a full scan?
 // (src/teloscope.cpp:485: by the window whose own scan sees it with j >= overlap, or always in window 0 / when
 // windows do not overlap; restated from the window loop's index arithmetic, uint32 wrap included.)
-__device__ __forceinline__ bool full_scan_pushes(uint32_t j, uint32_t l, const PushGeom &g) {
+// (*rec: the window whose own scan pushes it — the record its covered bases are added to as well)
+__device__ __forceinline__ bool full_scan_pushes(uint32_t j, uint32_t l, const PushGeom &g, u64 *rec) {
     if (g.ov == 0u) {
         const uint32_t x = g.r0 + j;
         const uint32_t dk = x / g.s;
         const u64 left = g.N0 - (u64)dk * g.s;
         const uint32_t cws = left < g.w ? (uint32_t)left : g.w;
+        *rec = g.k0 + dk;
         return (x - dk * g.s) + l <= cws;                   // may not cross its only window's end
     }
     const u64 e = g.P0 + j + l - 1u;
+    *rec = 0;
     if (e < (g.n < g.w ? g.n : (u64)g.w)) return true;      // window 0 scans everything it holds
     const uint32_t xr = g.r1 + (j + l - 1u - g.dsub);       // (e - ov) relative to k1 s   [e >= w here]
     const uint32_t dk = xr / g.s;                           // the one window with j >= overlap: k = k1 + dk
     const long long diff = (long long)g.D1 + (long long)j - (long long)((u64)dk * g.s);
+    *rec = g.k1 + dk;
     return diff >= 0 && (u64)diff >= g.start_index;
+}
+
+// A/C/T/G of the tile positions [qa, qb) from the packed planes, 16 positions per lane and step: valid2 holds 01 per valid
+// position, so the low code bits under it are the C and G, the high ones the T and G.
+__device__ __forceinline__ void count_range(const uint32_t *codes2, const uint32_t *valid2, uint32_t qa, uint32_t qb, uint32_t lane,
+                                            uint32_t &nV, uint32_t &nC, uint32_t &nT, uint32_t &nG) {
+    if (qa >= qb) return;
+    const uint32_t d0 = qa >> 4, d1 = (qb - 1u) >> 4;
+#pragma unroll 1
+    for (uint32_t d = d0 + lane; d <= d1; d += 64u) {
+        uint32_t v = valid2[d];
+        if (d == d0) v &= ~0u << (2u * (qa & 15u));
+        if (d == d1) v &= ~0u >> (2u * (15u - ((qb - 1u) & 15u)));
+        const uint32_t w = codes2[d], lo = w & v, hi = (w >> 1) & v;
+        const uint32_t g = (uint32_t)__popc(lo & hi);
+        nV += (uint32_t)__popc(v); nG += g; nC += (uint32_t)__popc(lo) - g; nT += (uint32_t)__popc(hi) - g;
+    }
+}
+
+// tile positions [P0, P0 + ntile) that are segment positions [lo, hi), as tile-relative [qa, qb)
+__device__ __forceinline__ void clip_to_tile(u64 lo, u64 hi, u64 P0, uint32_t ntile, uint32_t &qa, uint32_t &qb) {
+    qa = lo > P0 ? (uint32_t)(lo - P0 < ntile ? lo - P0 : ntile) : 0u;
+    qb = hi > P0 ? (uint32_t)(hi - P0 < ntile ? hi - P0 : ntile) : 0u;
 }
 
 // code (0..3) and validity of tile position q from the packed planes
@@ -311,8 +345,9 @@ void ts_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint3
         const uint32_t v = j < T.n ? (mask[j] & 0xFFFFFFu) : 0u;
         uint32_t keep = 0;
         if (v) {
+            u64 unused_rec;
             for (uint32_t li = 0; li < G.nlen; ++li)
-                if (((v >> (3u * li)) & 1u) && (tips || full_scan_pushes(j, G.len[li], pg))) keep |= 1u << li;
+                if (((v >> (3u * li)) & 1u) && (tips || full_scan_pushes(j, G.len[li], pg, &unused_rec))) keep |= 1u << li;
             mask[j] = v | (keep << 24);
         }
         wave_cnt += (uint32_t)__popc(keep);
@@ -342,6 +377,272 @@ void ts_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint3
     }
 }
 
+constexpr uint32_t kWaccMax = 256;          // window records a tile may add to on the list path
+constexpr uint32_t kListWave = 1024;        // candidate entries a wave's 1024 positions may produce on the list path
+
+// The same pass in its LIST form (round 3, second half): what the kernel above does per position — flag lookup, push
+// test, window shares — is done here per CANDIDATE, on full wavefronts.  Matches are a few per cent of the positions, so
+// a lane-per-position loop pays for the whole per-match path in nearly every round of 64 positions whatever the density
+// (what the tiled kernel's match queue is there for).  Here
+//   2'. every position only asks the prefix bitmaps (exact up to length 6, a 2 % filter for longer patterns) and a wave
+//       appends its candidates (position, length index), in order, to its own list in LDS;
+//   3'. a lane per candidate: the l-mer out of the planes again, the binary search (match? forward, canonical), the push
+//       test, and the covered bases of the match ADDED to the accumulators of the window records it belongs to — the
+//       pushing window's own record (analyzeWindow's main part) and the record after every call that carries it (i >= step,
+//       ends inside that call's window);
+//   4'. window records: a wave per record, nucleotides by popcounts over the packed planes (16 positions per lane and
+//       step) for the main part of the record's own call and the carry of the call before it, covered bases from the
+//       accumulators; stored or added as above;
+//   5'. match records: the pushed candidates, in list order (= position then length order), into the tile's slot.
+// Taken when a tile adds to at most kWaccMax window records (decided on the host from w and s) and the pattern lists fit
+// LDS; a wave whose list overflows (more than one candidate per position: dense repeats under a mixed-length set) raises
+// overflow bit 1 and the group runs again with the kernel above.
+__global__ __launch_bounds__(256)
+void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles, const u64 *seg_len,
+                           const u64 *seg_win_base, const TsGenericPatterns G, const TsGenericGeom Q, int tips, uint32_t slot_cap,
+                           uint32_t lds_patterns, uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    // layout: list u32[4][kListWave] | pcode u64[lds_patterns] | bitmap u32[8][128] | part u32[8] | codes2 | inval | valid2 | wacc | pflag
+    uint32_t *list_all = (uint32_t *)lds;
+    u64 *pcode = (u64 *)(lds + 4u * kListWave * 4u);
+    uint32_t *bitmap = (uint32_t *)(lds + 4u * kListWave * 4u + (size_t)lds_patterns * 8u);
+    uint32_t *part = bitmap + 8u * 128u;
+    uint32_t *codes2 = part + 8;
+    uint32_t *inval = codes2 + kCodeWords;
+    uint32_t *valid2 = inval + kInvalWords;
+    uint32_t *wacc = valid2 + kCodeWords;                                  // [kWaccMax][4]: canonical, non-canonical, forward, reverse covered
+    unsigned char *pflag = (unsigned char *)(wacc + kWaccMax * 4u);
+    if (blockIdx.x >= ntiles) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    uint32_t *const list = list_all + wave * kListWave;
+    const uint32_t npat = G.first[G.nlen];
+    for (uint32_t i = tid; i < 8u * 128u; i += 256u) bitmap[i] = 0u;
+    for (uint32_t i = tid; i < kWaccMax * 4u; i += 256u) wacc[i] = 0u;
+    for (uint32_t i = tid; i < npat; i += 256u) { pcode[i] = G.codes[i]; pflag[i] = G.flags[i]; }
+    const TsGeneralTile T = tiles[blockIdx.x];
+    // 1. stage (as above, plus the validity plane spread to 01 per valid position)
+    const uint32_t avail = T.avail;
+    const unsigned char *src = in + T.in_off;
+    for (uint32_t i = tid * 16u; i < kCodeWords * 16u; i += 256u * 16u) {
+        uint32_t cw = 0, iv = 0xFFFFu;
+        if (i < avail) {
+            uint32_t d[4];
+            if (((uintptr_t)(src + i) & 15u) == 0u && i + 16u <= avail) {
+                const uint4 v = *(const uint4 *)(src + i);
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            } else {
+                for (uint32_t q = 0; q < 4u; ++q) {
+                    uint32_t x = 0;
+                    for (uint32_t r = 0; r < 4u; ++r) x |= (i + 4u * q + r < avail ? (uint32_t)src[i + 4u * q + r] : 0u) << (8u * r);
+                    d[q] = x;
+                }
+            }
+            iv = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 16u; ++q) {
+                uint32_t c = (d[q >> 2] >> (8u * (q & 3u))) & 0xFFu;
+                if (Q.fold) c &= 0xDFu;
+                const uint32_t code = (c >> 1) & 3u;                               // A 0, C 1, T 2, G 3
+                cw |= code << (2u * q);
+                iv |= (c != ((0x47544341u >> (8u * code)) & 0xFFu) ? 1u : 0u) << q; // 'A' 'C' 'T' 'G' by code
+            }
+        }
+        codes2[i >> 4] = cw;
+        ((unsigned short *)inval)[i >> 4] = (unsigned short)iv;
+        uint32_t ok = ~iv & 0xFFFFu;
+        ok = (ok | (ok << 8)) & 0x00FF00FFu; ok = (ok | (ok << 4)) & 0x0F0F0F0Fu;
+        ok = (ok | (ok << 2)) & 0x33333333u; ok = (ok | (ok << 1)) & 0x55555555u;
+        valid2[i >> 4] = ok;
+    }
+    __syncthreads();
+    for (uint32_t li = 0; li < G.nlen; ++li) {
+        const uint32_t q = G.len[li] < 6u ? G.len[li] : 6u;
+        for (uint32_t i = G.first[li] + tid; i < G.first[li + 1]; i += 256u) {
+            const uint32_t pre = (uint32_t)pcode[i] & ((1u << (2u * q)) - 1u);
+            atomicOr(&bitmap[li * 128u + (pre >> 5)], 1u << (pre & 31u));
+        }
+    }
+    __syncthreads();
+    // the next 32 bases of tile position j and their validity bits
+    auto bases_at = [&](uint32_t j, u64 &code64, uint32_t &inv32) {
+        const uint32_t wd = j >> 4, sh = 2u * (j & 15u);
+        const uint32_t c0 = codes2[wd], c1 = codes2[wd + 1u], c2 = codes2[wd + 2u];
+        code64 = (u64)__funnelshift_r(c0, c1, sh) | ((u64)__funnelshift_r(c1, c2, sh) << 32);
+        const uint32_t vd = j >> 5;
+        inv32 = __funnelshift_r(inval[vd], inval[vd + 1u], j & 31u);
+    };
+    // 2'. candidates: wave v owns the 1024 consecutive positions [1024 v, 1024 v + 1024)
+    uint32_t ncand = 0;                                                    // (wave-uniform)
+    bool spilled = false;
+#pragma unroll 1
+    for (uint32_t r = 0; r < 16u; ++r) {
+        const uint32_t j = wave * 1024u + r * 64u + lane;
+        uint32_t bits = 0;
+        if (j < T.n) {
+            u64 code64; uint32_t inv32;
+            bases_at(j, code64, inv32);
+#pragma unroll 1
+            for (uint32_t li = 0; li < G.nlen; ++li) {
+                const uint32_t l = G.len[li];
+                if (j + l > avail) break;                // lengths ascend; a match may not cross the region end
+                if (inv32 & (l >= 32u ? 0xFFFFFFFFu : ((1u << l) - 1u))) break;   // a non-ACGT base kills this and every longer pattern
+                const uint32_t q = l < 6u ? l : 6u;
+                const uint32_t pre = (uint32_t)code64 & ((1u << (2u * q)) - 1u);
+                bits |= ((bitmap[li * 128u + (pre >> 5)] >> (pre & 31u)) & 1u) << li;
+            }
+        }
+        if (__ballot(bits != 0u) == 0ull) continue;
+        const uint32_t c = (uint32_t)__popc(bits);
+        const uint32_t incl = wave_inclusive(c, lane);
+        const uint32_t round_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (ncand + round_total > kListWave) { spilled = true; break; }
+        uint32_t at = ncand + incl - c;
+        for (uint32_t b = bits; b; b &= b - 1u) list[at++] = (j << 5) | ((uint32_t)__builtin_ctz(b) << 2);
+        ncand += round_total;
+    }
+    if (spilled && lane == 0u) atomicOr(overflow, 2u);
+    const u64 n = seg_len[T.seg];
+    const u64 P0 = T.seg_rel;
+    // window geometry of the tile: the calls whose windows reach it, the records it adds to
+    const bool win_on = !tips && T.n;
+    u64 nwin = 0, kw_lo = 0, kw_hi = 0, rec_hi = 0;
+    const bool carries = Q.w != Q.s;
+    if (win_on) {
+        nwin = (n + Q.s - 1u) / Q.s;
+        kw_lo = P0 >= Q.w ? (P0 - Q.w) / Q.s + 1u : 0u;                   // first call whose window reaches the tile
+        kw_hi = (P0 + T.n - 1u) / Q.s;                                    // last call that starts inside it
+        if (kw_hi >= nwin) kw_hi = nwin - 1u;
+        rec_hi = kw_hi + (carries ? 1u : 0u);
+        if (rec_hi >= nwin) rec_hi = nwin - 1u;
+        if (rec_hi - kw_lo >= kWaccMax) { if (tid == 0u) atomicOr(overflow, 2u); spilled = true; }     // (the host sizes this out: never)
+    }
+    const PushGeom pg = push_geom(P0, n, Q);
+    const u64 N1 = n - P0;                                                  // bases from the tile's first to the segment's end
+    // 3'. a lane per candidate
+    uint32_t npush = 0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (uint32_t e0 = 0; e0 < ncand && !spilled; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        bool pushed = false;
+        if (e < ncand) {
+            uint32_t ent = list[e];
+            const uint32_t j = ent >> 5, li = (ent >> 2) & 7u, l = G.len[li];
+            u64 code64; uint32_t inv32;
+            bases_at(j, code64, inv32);
+            const u64 code = l >= 32u ? code64 : (code64 & ((1ull << (2u * l)) - 1ull));
+            uint32_t lo = G.first[li], hi = G.first[li + 1];
+            const uint32_t end = hi;
+            while (lo < hi) {                        // binary search in the sorted code list of this length
+                const uint32_t mid = (lo + hi) >> 1;
+                if (pcode[mid] < code) lo = mid + 1; else hi = mid;
+            }
+            const bool found = lo < end && pcode[lo] == code;
+            if (found) {
+                const uint32_t fl = pflag[lo];                              // bit0 forward, bit1 canonical
+                u64 rec = 0;
+                pushed = tips || full_scan_pushes(j, l, pg, &rec);
+                if (win_on) {
+                    const uint32_t f_can = (fl & 2u) ? 0u : 1u, f_fwd = (fl & 1u) ? 2u : 3u;
+                    // the window that pushes a match counts it in its own record (analyzeWindow's main part) ...
+                    if (pushed) {
+                        uint32_t *a4 = wacc + (uint32_t)(rec - kw_lo) * 4u;
+                        atomicAdd(a4 + f_can, l);
+                        atomicAdd(a4 + f_fwd, l);
+                    }
+                    // ... and every call kw that meets it at i >= step (at or behind its own start index) carries it into
+                    // record kw + 1 as long as it ends inside that call's window: kw = p / s - 1 downwards, i grows by s
+                    if (carries) {
+                        const uint32_t x = pg.rP0 + j, dkp = x / Q.s;
+                        u64 kw = pg.kP0 + dkp;
+                        u64 i = x - dkp * Q.s;
+                        while (kw > 0u) {
+                            --kw; i += Q.s;
+                            if (i + l - 1u >= Q.w) break;                   // ends behind every further window too
+                            const uint32_t si = kw == 0u ? Q.s : (pg.start_index > Q.s ? pg.start_index : Q.s);
+                            if (i < si) continue;
+                            const u64 left = N1 - j + i;                    // n - kw s
+                            const u64 cws = left < Q.w ? left : Q.w;
+                            if (i + l - 1u < cws && kw + 1u <= rec_hi) {
+                                uint32_t *a4 = wacc + (uint32_t)(kw + 1u - kw_lo) * 4u;
+                                atomicAdd(a4 + f_can, l);
+                                atomicAdd(a4 + f_fwd, l);
+                            }
+                        }
+                    }
+                }
+                ent |= fl & 3u;
+            }
+            list[e] = pushed ? (ent | 0x80000000u) : 0u;                    // (tile positions are below 2^12: bit 31 is free)
+        }
+        npush += (uint32_t)__popcll(__ballot(pushed));
+    }
+    if (lane == 0u) { part[wave] = npush; part[4u + wave] = spilled ? 1u : 0u; }
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (uint32_t v = 0; v < 4u; ++v) { if (v < wave) base += part[v]; total += part[v]; }
+    // did any wave's list spill?  then nothing of this tile counts: the group runs again with the kernel above
+    const bool any_spill = (part[4] | part[5] | part[6] | part[7]) != 0u;
+    if (tid == 0u) {
+        *(uint4 *)&tile_stats[4ull * blockIdx.x] = make_uint4(total, 0u, 0u, 0u);
+        if (total > slot_cap) atomicOr(overflow, 1u);
+    }
+    if (any_spill) return;
+    // 4'. window records
+    if (win_on) {
+        uint32_t *const wrec = win_out + seg_win_base[T.seg] * 8ull;
+        const uint32_t ov = Q.w - Q.s;
+#pragma unroll 1
+        for (u64 R = kw_lo + wave; R <= rec_hi; R += 4u) {
+            uint32_t nV = 0, nC = 0, nT = 0, nG = 0;
+            if (Q.nuc_on) {
+                uint32_t qa, qb;
+                {                                                           // main part of call R
+                    const u64 ws = R * Q.s;
+                    const u64 left = n - ws;
+                    const uint32_t cws = left < Q.w ? (uint32_t)left : Q.w;
+                    const bool always_main = ov == 0u || R == 0u;
+                    const uint32_t from = always_main ? 0u : (pg.start_index > ov ? pg.start_index : ov);
+                    if (from < cws) { clip_to_tile(ws + from, ws + cws, P0, T.n, qa, qb); count_range(codes2, valid2, qa, qb, lane, nV, nC, nT, nG); }
+                }
+                if (carries && R > 0u) {                                    // carry of call R - 1: i >= max(its start index, step)
+                    const u64 ws = (R - 1u) * Q.s;
+                    const u64 left = n - ws;
+                    const uint32_t cws = left < Q.w ? (uint32_t)left : Q.w;
+                    const uint32_t si = R - 1u == 0u ? 0u : pg.start_index;
+                    const uint32_t from = si > Q.s ? si : Q.s;
+                    if (from < cws) { clip_to_tile(ws + from, ws + cws, P0, T.n, qa, qb); count_range(codes2, valid2, qa, qb, lane, nV, nC, nT, nG); }
+                }
+            }
+            const uint32_t tVG = wave_total(nV | (nG << 16)), tCT = wave_total(nC | (nT << 16));     // (each at most 8192)
+            const uint32_t tC = tCT & 0xFFFFu, tT = tCT >> 16, tG = tVG >> 16, tA = (tVG & 0xFFFFu) - tC - tT - tG;
+            const uint32_t mine = lane == 0u ? tA : lane == 1u ? tC : lane == 2u ? tG : lane == 3u ? tT
+                                : lane < 8u ? wacc[(uint32_t)(R - kw_lo) * 4u + (lane - 4u)] : 0u;
+            const u64 span_lo = R * Q.s;
+            const u64 span_hi = span_lo + Q.w < n ? span_lo + Q.w : n;
+            const bool sole = span_lo >= P0 && span_hi <= P0 + T.n;
+            if (lane < 8u) {
+                if (sole) wrec[R * 8ull + lane] = mine;
+                else if (mine) atomicAdd(&wrec[R * 8ull + lane], mine);
+            }
+        }
+    }
+    // 5'. match records
+    if (total > slot_cap || npush == 0u) return;
+    uint32_t *dst = records + (u64)blockIdx.x * slot_cap;
+#pragma unroll 1
+    for (uint32_t e0 = 0; e0 < ncand; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        const uint32_t ent = e < ncand ? list[e] : 0u;
+        const u64 m = __ballot(ent != 0u);
+        if (m == 0ull) continue;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (ent) dst[base + rank] = ent & 0x7FFFFFFFu;
+        base += (uint32_t)__popcll(m);
+    }
+}
+
 // One wave per tile: its records from its slot to their place in the dense, tile-ordered stream.
 __global__ __launch_bounds__(256)
 void ts_general_compact(const uint32_t *tile_stats, const u64 *tile_off, const uint32_t *records, uint32_t slot_cap,
@@ -365,13 +666,24 @@ unsigned long long ts_k_general_lds_bytes(const TsGenericPatterns *G, uint32_t *
            ((lp + 15u) & ~15u);
 }
 
+// list != 0: the list form of the pass (see ts_general_fused_list: the caller has checked that a tile adds to at most
+// ts_k_general_list_max_records() window records; *overflow bit 1 then means "run this group again with list = 0")
+uint32_t ts_k_general_list_max_records(void) { return kWaccMax; }
+
 int ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
                               const unsigned long long *seg_len, const unsigned long long *seg_win_base,
                               const TsGenericPatterns *G, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
-                              uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, void *stream) {
+                              uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, int list, void *stream) {
     if (ntiles == 0) return 0;
     uint32_t lp = 0;
     const unsigned long long lds = ts_k_general_lds_bytes(G, &lp);
+    if (list && lp) {
+        const unsigned long long lds2 = 4ull * kListWave * 4u + (unsigned long long)lp * 8u + 8u * 128u * 4u + 32u + kCodeWords * 4u + kInvalWords * 4u +
+                                        kCodeWords * 4u + kWaccMax * 16u + ((lp + 15u) & ~15u);
+        hipLaunchKernelGGL(ts_general_fused_list, dim3(ntiles), dim3(256), (size_t)lds2, (hipStream_t)stream, in, tiles, ntiles,
+                           (const u64 *)seg_len, (const u64 *)seg_win_base, *G, *Q, tips, slot_cap, lp, tile_stats, records, win_out, overflow);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(ts_general_fused, dim3(ntiles), dim3(256), (size_t)lds, (hipStream_t)stream, in, tiles, ntiles,
                        (const u64 *)seg_len, (const u64 *)seg_win_base, *G, *Q, tips, slot_cap, lp, tile_stats, records, win_out, overflow);
     return (int)hipGetLastError();

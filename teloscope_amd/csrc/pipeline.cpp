@@ -840,6 +840,11 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         // a tile's slot: one record per position — all a single-length set can produce; a mixed-length tile that holds
         // more says so, and the group runs again with slots that cannot overflow
         uint32_t slot_cap = TS_GENERAL_TILE;
+        // the list form of the fused pass (per-candidate work on full wavefronts) when a tile adds to few enough window
+        // records for the accumulators it keeps in LDS; a tile dense enough to overflow a wave's candidate list sends the
+        // group through the position-strided form instead
+        bool use_list = !(getenv("TS_GEN_LIST") && getenv("TS_GEN_LIST")[0] == '0') &&
+                        (tips || ((uint64_t)TS_GENERAL_TILE + w) / s + 3 <= ts_k_general_list_max_records());
         HIP_TRY(c, c->pool.take(span, d_in));
         HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * (size_t)slot_cap * 4, d_slots));
         HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * sizeof(TsGeneralTile), d_tiles));
@@ -871,7 +876,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 if (ts_k_launch_general_fused((const unsigned char *)d_in.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt,
                                               (const unsigned long long *)(dt + tab_len), (const unsigned long long *)(dt + tab_win),
                                               &c->gpat, &Q, tips ? 1 : 0, slot_cap, (uint32_t *)d_stats.p, (uint32_t *)d_slots.p,
-                                              (uint32_t *)d_win.p, (uint32_t *)(dt + tab_flag), st) != 0)
+                                              (uint32_t *)d_win.p, (uint32_t *)(dt + tab_flag), use_list ? 1 : 0, st) != 0)
                     return c->fail(TS_ERR_HIP, "general fused kernel launch failed");
                 if (ts_k_launch_tile_offsets((const uint32_t *)d_stats.p, (uint32_t)nt, (unsigned long long *)d_off.p, d_tmp.p, st) != 0)
                     return c->fail(TS_ERR_HIP, "tile-offset kernel launch failed");
@@ -882,7 +887,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
             HIP_TRY(c, hipStreamSynchronize(st));
             if (timing) { float ms = 0; if (hipEventElapsedTime(&ms, c->gen_ev[0], c->gen_ev[1]) == hipSuccess) t_kern += ms; }
             if (!flag) break;
-            if (attempt > 0) return c->fail(TS_ERR_STATE, "general path: a tile overflowed a slot that holds every match it can have");
+            if (attempt > 1) return c->fail(TS_ERR_STATE, "general path: a tile overflowed a slot that holds every match it can have");
+            if (flag & 2u) { use_list = false; continue; }            // a candidate list spilled: the strided form takes this group
             slot_cap = TS_GENERAL_TILE * std::max<uint32_t>(1u, c->gpat.nlen);
             c->pool.give(std::move(d_slots));
             HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * (size_t)slot_cap * 4, d_slots));

@@ -239,9 +239,12 @@ unsigned long long ts_k_general_lds_bytes(const TsGenericPatterns *G, uint32_t *
 int  ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
                                const unsigned long long *seg_len, const unsigned long long *seg_win_base,
                                const TsGenericPatterns *G, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
-                               uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, void *stream);
+                               uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, int list, void *stream);
+uint32_t ts_k_general_list_max_records(void);
                                // (records: ntiles x slot_cap entries; win_out zeroed by the caller; *overflow raised when a tile
-                               //  holds more than slot_cap records — its count is still written)
+                               //  holds more than slot_cap records — its count is still written; list != 0: the list form of
+                               //  the pass — for parameter sets whose tiles add to at most ts_k_general_list_max_records()
+                               //  window records and whose pattern lists fit LDS; *overflow bit 1: run again with list = 0)
 int  ts_k_launch_general_compact(const uint32_t *tile_stats, const unsigned long long *tile_off, const uint32_t *records,
                                  uint32_t slot_cap, uint32_t ntiles, uint32_t *dense, void *stream);
 int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,
