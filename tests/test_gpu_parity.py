@@ -381,6 +381,16 @@ def test_general_kernels_match_oracle(cli):
         assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="cli=%r len=%d" % (cli, len(s)))
 
 
+@pytest.mark.parametrize("cli", ["-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i", "-c TTTAGGGTTTAGGG -x 1 -w 1000 -s 500 -r -g -i",
+                                 "-w 1000 -s 997 -r -g -e -i", "-p TTAGGG,TTAGG,TTTAGGGTTTAGGG -x 1 -w 500 -s 500 -g -i"])
+def test_general_kernels_strided_form_matches_oracle(cli, monkeypatch):
+    """The fused general kernel has two forms (generic.hip): per-candidate work on compacted lists — the default where a
+    tile adds to few enough window records — and the position-strided form, which other parameter sets and dense groups
+    fall back to.  Here the strided form is pinned (TS_GEN_LIST=0) on parameter sets that normally take the list form."""
+    monkeypatch.setenv("TS_GEN_LIST", "0")
+    test_general_kernels_match_oracle(cli)
+
+
 def test_unsupported_parameter_sets_fail_loudly():
     """What even the general kernels do not take (a pattern longer than 32, more than 8 distinct
     lengths) returns TS_ERR_UNSUPPORTED; nothing is ever routed to a CPU path."""
