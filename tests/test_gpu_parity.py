@@ -361,6 +361,9 @@ GENERIC_GRID = [
     "-p TTAGGG,TTAGG -t 400",                             # mixed lengths, tips only
     "-c TTTAGGGTTTAGGG -x 1 -w 1000 -s 500 -r -g -i",     # k = 14 (no LDS table)
     "-c TTAGGGTTAGGG -x 0",                               # k = 12, tips only
+    "-c TTAGGGTTAGGGTTAGGGTTAGGGTTAGGGTT -x 0 -w 1000 -s 500 -r -g -e -i",     # k = 32, the longest pattern taken
+    "-c TTAGGGTTAGGGTTAGGGTTAGGGTTAGGGT -x 1 -t 2000",    # k = 31 with one mismatch (94 patterns), tips only
+    "-p TTAGGG,TTAGGGTTAGGGTTAGGGTTAGGGTTAGGGTT -x 0 -w 2000 -s 1000 -r -g -i",   # lengths 6 and 32 in one set
 ]
 
 
