@@ -3,6 +3,7 @@
 // post-processing.  There is no CPU scan path in this library: without a HIP device
 // ts_create() fails.
 #include <hip/hip_runtime.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1172,6 +1173,61 @@ struct HostLanding {
 
 }  // namespace
 
+// A tile's packed records -> ts_match: one 16-byte store per record {position; match_size | flags << 16}, past the caches
+// (the 1.5 GB of a 3 Gb scan's records are read by the caller much later; an ordinary store would first fetch every line
+// it fills).  m is 16-byte aligned.  rec = (tile-relative position << 2) | forward << 1 | canonical.
+static_assert(sizeof(ts_match) == 16 && TS_MATCH_FORWARD == 1 && TS_MATCH_CANONICAL == 2 && TS_MATCH_TERMINAL == 4, "record layout");
+
+__attribute__((target("avx2")))
+static void expand_records_avx2(const uint32_t *recs, uint32_t cnt, ts_match *m, uint64_t abs_pos, uint64_t rel0,
+                                uint64_t terminal_limit, uint64_t term_end, uint16_t klen) {
+    const __m256i vrel0 = _mm256_set1_epi64x((long long)rel0), vabs = _mm256_set1_epi64x((long long)abs_pos);
+    const __m256i vtl = _mm256_set1_epi64x((long long)terminal_limit), vte = _mm256_set1_epi64x((long long)term_end - 1);
+    const __m256i one = _mm256_set1_epi64x(1), vk = _mm256_set1_epi64x((long long)klen), four16 = _mm256_set1_epi64x(4ll << 16);
+    uint32_t i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+        const __m256i r = _mm256_cvtepu32_epi64(_mm_loadu_si128((const __m128i *)(recs + i)));
+        const __m256i rel = _mm256_add_epi64(vrel0, _mm256_srli_epi64(r, 2));
+        // terminal: rel <= limit or rel >= term_end  (positions are far below 2^63: signed compares)
+        const __m256i interior = _mm256_and_si256(_mm256_cmpgt_epi64(rel, vtl), _mm256_cmpgt_epi64(vte, _mm256_sub_epi64(rel, one)));
+        // flags: forward (record bit 1) -> bit 0, canonical (record bit 0) -> bit 1, terminal -> bit 2; all shifted to bit 16
+        const __m256i fwd = _mm256_slli_epi64(_mm256_and_si256(_mm256_srli_epi64(r, 1), one), 16);
+        const __m256i can = _mm256_slli_epi64(_mm256_and_si256(r, one), 17);
+        const __m256i ter = _mm256_andnot_si256(interior, four16);
+        const __m256i w1 = _mm256_or_si256(_mm256_or_si256(vk, fwd), _mm256_or_si256(can, ter));
+        const __m256i pos = _mm256_add_epi64(vabs, rel);
+        const __m256i lo = _mm256_unpacklo_epi64(pos, w1), hi = _mm256_unpackhi_epi64(pos, w1);   // {p0 w0 | p2 w2}, {p1 w1 | p3 w3}
+        _mm256_stream_si256((__m256i *)(m + i), _mm256_permute2x128_si256(lo, hi, 0x20));
+        _mm256_stream_si256((__m256i *)(m + i + 2), _mm256_permute2x128_si256(lo, hi, 0x31));
+    }
+    for (; i < cnt; ++i) {
+        const uint32_t rec = recs[i];
+        const uint64_t rel = rel0 + (rec >> 2);
+        const uint64_t fl = ((rec & 2u) ? TS_MATCH_FORWARD : 0u) | ((rec & 1u) ? TS_MATCH_CANONICAL : 0u) |
+                            ((rel <= terminal_limit || rel >= term_end) ? TS_MATCH_TERMINAL : 0u);
+        _mm_stream_si128((__m128i *)&m[i], _mm_set_epi64x((long long)((uint64_t)klen | (fl << 16)), (long long)(abs_pos + rel)));
+    }
+}
+
+static void expand_records(const uint32_t *recs, uint32_t cnt, ts_match *m, uint64_t abs_pos, uint64_t rel0,
+                           uint64_t terminal_limit, uint64_t term_end, uint16_t klen) {
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    auto one = [&](uint32_t i) {
+        const uint32_t rec = recs[i];
+        const uint64_t rel = rel0 + (rec >> 2);
+        const uint64_t fl = ((rec & 2u) ? TS_MATCH_FORWARD : 0u) | ((rec & 1u) ? TS_MATCH_CANONICAL : 0u) |
+                            ((rel <= terminal_limit || rel >= term_end) ? TS_MATCH_TERMINAL : 0u);
+        _mm_stream_si128((__m128i *)&m[i], _mm_set_epi64x((long long)((uint64_t)klen | (fl << 16)), (long long)(abs_pos + rel)));
+    };
+    uint32_t i = 0;
+    if (have_avx2 && term_end >= 1 && term_end < (1ull << 62) && terminal_limit < (1ull << 62)) {
+        if (cnt && (((uintptr_t)m) & 31u)) { one(0); i = 1; }              // (to the 32-byte boundary the 4-record rounds store at)
+        if (i < cnt) expand_records_avx2(recs + i, cnt - i, m + i, abs_pos, rel0, terminal_limit, term_end, klen);
+        return;
+    }
+    for (; i < cnt; ++i) one(i);
+}
+
 // Result arrays of many megabytes are first touched by the threads that fill them; on 2 MB pages (when the
 // kernel grants them) that is 512 times fewer page faults.  free() releases them like any malloc'd block.
 void *ts_alloc_large(size_t bytes) {
@@ -1433,17 +1489,9 @@ int batch_finalize(ts_batch *b, const Fetched &F, ts_segment_out *out) {
             const uint64_t r0 = F.tile_off[ti];
             if (r0 + cnt > F.nrecs) { bad.store(1); return; }
             const uint64_t rel0 = b->tiles[ti].in_off - sp.in_off;          // segment-relative position of the tile
-            ts_match *m = o.matches + tile_out[ti];
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const uint32_t rec = F.recs[r0 + i];
-                const uint64_t rel = rel0 + (rec >> 2);
-                std::memset(&m[i], 0, sizeof m[i]);
-                m[i].position = sp.abs_pos + rel;
-                m[i].match_size = klen;
-                m[i].flags = (uint8_t)(((rec & 2u) ? TS_MATCH_FORWARD : 0u) | ((rec & 1u) ? TS_MATCH_CANONICAL : 0u) |
-                                       ((rel <= P.terminal_limit || rel >= term_end) ? TS_MATCH_TERMINAL : 0u));
-            }
+            expand_records(F.recs + r0, cnt, o.matches + tile_out[ti], sp.abs_pos, rel0, P.terminal_limit, term_end, klen);
         }
+        _mm_sfence();
     });
     if (bad.load()) { ts_free_segments(out, ns); return c->fail(TS_ERR_STATE, "tile directory out of range"); }
     // blocks: the sorted list's slice of every segment
