@@ -246,4 +246,27 @@ float shannon_entropy(const uint32_t counts[4], uint32_t window_size) {
     return std::round(entropy * 1000.0f) / 1000.0f;
 }
 
+// The same with the four terms p log2 p looked up: a count c of a window of `w` bases always gives the same term, and a
+// scan converts millions of windows of one size (log2f four times per window was most of the host's share of a scan
+// without match vectors).  term[c] is computed by the expression above, so the sum is the same float.
+void entropy_terms(uint32_t w, std::vector<float> &term) {
+    term.assign((size_t)w + 1, 0.0f);
+    for (uint32_t c = 1; c <= w; ++c) {
+        const float p = static_cast<float>(c) / w;
+        term[c] = p * std::log2(p);
+    }
+}
+
+float shannon_entropy_memo(const uint32_t counts[4], uint32_t window_size, const std::vector<float> &term) {
+    if (term.size() != (size_t)window_size + 1) return shannon_entropy(counts, window_size);
+    float entropy = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        if (counts[i] > 0) {
+            if (counts[i] > window_size) return shannon_entropy(counts, window_size);
+            entropy -= term[counts[i]];
+        }
+    }
+    return std::round(entropy * 1000.0f) / 1000.0f;
+}
+
 }  // namespace ts

@@ -481,6 +481,7 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
         c->patterns.push_back(std::move(p));
     }
     c->longest = kmax;
+    if (c->params.out_entropy && c->params.window_size && c->params.window_size <= (1u << 22)) ts::entropy_terms(c->params.window_size, c->entropy_term);
     c->bp.terminal_limit = c->params.terminal_limit;
     c->bp.max_match_dist = c->params.max_match_dist;
     c->bp.min_block_len = c->params.min_block_len;
@@ -1072,7 +1073,7 @@ int ts_finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos
             w.current_window_size = (uint32_t)std::min<uint64_t>(P.window_size, seg_len - ws);
             if (nuc) for (int i = 0; i < 4; ++i) w.nucleotide_counts[i] = r[i];
             if (P.out_gc) w.gc_content = ts::gc_content(w.nucleotide_counts, w.current_window_size);
-            if (P.out_entropy) w.shannon_entropy = ts::shannon_entropy(w.nucleotide_counts, w.current_window_size);
+            if (P.out_entropy) w.shannon_entropy = ts::shannon_entropy_memo(w.nucleotide_counts, w.current_window_size, c->entropy_term);
             w.canonical_covered = r[4];
             w.non_canonical_covered = r[5];
             w.fwd_covered = r[6];
@@ -1473,7 +1474,7 @@ int batch_finalize(ts_batch *b, const Fetched &F, ts_segment_out *out) {
                 w.current_window_size = (uint32_t)std::min<uint64_t>(P.window_size, sp.len - ws);
                 if (nuc) for (int i = 0; i < 4; ++i) w.nucleotide_counts[i] = r[i];
                 if (P.out_gc) w.gc_content = ts::gc_content(w.nucleotide_counts, w.current_window_size);
-                if (P.out_entropy) w.shannon_entropy = ts::shannon_entropy(w.nucleotide_counts, w.current_window_size);
+                if (P.out_entropy) w.shannon_entropy = ts::shannon_entropy_memo(w.nucleotide_counts, w.current_window_size, c->entropy_term);
                 w.canonical_covered = r[4];
                 w.non_canonical_covered = r[5];
                 w.fwd_covered = r[6];

@@ -125,6 +125,7 @@ struct ts_ctx {
     // CPUs of the NUMA node the device is attached to (empty: unknown / TS_NO_NUMA_BIND): the pipeline's own threads run
     // there, and the pinned staging buffers are allocated there — a DMA out of the other socket's memory, or staging
     // threads on the other socket, cost 15-20 % of the PCIe-inclusive rate on a two-socket host
+    std::vector<float> entropy_term;      // ts::entropy_terms(window_size): windows of the full size look their terms up
     std::vector<int> node_cpus;
     void bind_this_thread() const;          // no-op when node_cpus is empty; never widens the thread's current mask
     static constexpr int kUpSlots = 3;

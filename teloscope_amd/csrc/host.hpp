@@ -55,6 +55,8 @@ void pack_bases(const unsigned char *src, size_t n, unsigned char *dst, bool fol
 
 float gc_content(const uint32_t counts[4], uint32_t window_size);
 float shannon_entropy(const uint32_t counts[4], uint32_t window_size);
+void  entropy_terms(uint32_t w, std::vector<float> &term);                       // term[c] = (c / w) log2 (c / w), as shannon_entropy computes it
+float shannon_entropy_memo(const uint32_t counts[4], uint32_t window_size, const std::vector<float> &term);   // == shannon_entropy
 
 }  // namespace ts
 

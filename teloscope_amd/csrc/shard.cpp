@@ -537,7 +537,7 @@ extern "C" int ts_shards_finalize(const ts_batch *b, const void *const *msgs, co
                 w.current_window_size = (uint32_t)std::min<uint64_t>(P.window_size, sp.len - ws);
                 if (nuc) for (int q = 0; q < 4; ++q) w.nucleotide_counts[q] = f[q];
                 if (P.out_gc) w.gc_content = ts::gc_content(w.nucleotide_counts, w.current_window_size);
-                if (P.out_entropy) w.shannon_entropy = ts::shannon_entropy(w.nucleotide_counts, w.current_window_size);
+                if (P.out_entropy) w.shannon_entropy = ts::shannon_entropy_memo(w.nucleotide_counts, w.current_window_size, c->entropy_term);
                 w.canonical_covered = f[4] * klen;
                 w.non_canonical_covered = f[5] * klen;
                 w.fwd_covered = f[6] * klen;

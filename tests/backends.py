@@ -138,6 +138,10 @@ def assert_segment_equal(got, exp, tips_only, float_fields=True, ctx=""):
         # north_star tolerance is 1e-6
         assert np.max(np.abs(gw["gc_content"].astype(np.float64) - ew["gc_content"])) <= 1e-6, ctx
         assert np.max(np.abs(gw["shannon_entropy"].astype(np.float64) - ew["shannon_entropy"])) <= 1e-6, ctx
+        # (the same float32 expressions on the same integers: in fact bit-equal — the product looks the entropy terms of
+        # full-size windows up in a table built by those expressions)
+        assert np.array_equal(gw["gc_content"].astype(np.float32), np.asarray(ew["gc_content"], dtype=np.float32)), ctx + " gc_content bits"
+        assert np.array_equal(gw["shannon_entropy"].astype(np.float32), np.asarray(ew["shannon_entropy"], dtype=np.float32)), ctx + " shannon_entropy bits"
     for name in ("terminal_blocks", "interstitial_blocks"):
         g, e = got[name], exp[name]
         assert len(g) == len(e), "%s %s: %d vs %d" % (ctx, name, len(g), len(e))
