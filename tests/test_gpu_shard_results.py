@@ -175,6 +175,65 @@ def test_block_at_a_shard_boundary_and_a_telomere_longer_than_the_context():
     plan.close()
 
 
+def test_message_overflow_is_reported_and_a_larger_scale_fixes_it():
+    """The variable sections of a message (visible records, blocks) are sized from the plan for ordinary sequence; an
+    input with far more canonical matches than that — 800 kb of TTAGGG in one part's tiles, and a hundred short
+    interstitial blocks — must come back with TS_SHARD_OVERFLOW_* set and the factor to grow by, merge as
+    TS_SHARD_RETRY_GROW, and after ts_batch_set_shard_scale on every part merge to the oracle's result."""
+    import torch
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.distributed import PackedShard, ShardPlan, finalize_shards, free_segments
+    dev = torch.device("cuda", 0)
+    opts, tel = _teloscope(HEADLINE + " -t 3000")
+    rng = np.random.default_rng(21)
+    n = 2_400_000
+    seq = bytearray(seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, n_its=2))
+    seq[100_000:900_000] = (b"TTAGGG" * 133_334)[:800_000]
+    for i in range(100):
+        a = 1_300_000 + 3_000 * i
+        seq[a:a + 120] = b"TTAGGG" * 20
+    seq = bytes(seq)
+    plan = ShardPlan(tel, [n], world=2)
+    buf = _fill(plan, [seq], dev)
+    sptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    shards = [PackedShard(plan, p, dev, slots=1) for p in range(2)]
+    locals_ = [buf[s.info.input_begin:max(s.info.input_end, s.info.input_begin + 64)].clone() for s in shards]
+
+    def pack_all():
+        msgs, sts = [], []
+        for s, loc in zip(shards, locals_):
+            for _ in range(4):
+                s.scan_pack(loc.data_ptr(), sptr, 0)
+                st = s.status(0)
+                if not (st.flags & K.SHARD_OVERFLOW_SCAN):
+                    break
+                s.sync(0)
+            msgs.append(s.msgs[0].cpu().numpy().copy())
+            sts.append(st)
+        return msgs, sts
+
+    msgs, sts = pack_all()
+    assert any(st.flags & (K.SHARD_OVERFLOW_VISIBLE | K.SHARD_OVERFLOW_BLOCKS) for st in sts), [hex(st.flags) for st in sts]
+    factor = max(int(st.scale_factor_needed) for st in sts)
+    assert factor >= 2
+    rc, out, cnt = finalize_shards(plan, msgs)
+    assert rc == K.SHARD_RETRY_GROW, rc
+    for s in shards:
+        s.set_scale(factor)
+    msgs, sts = pack_all()
+    assert not any(st.flags & (K.SHARD_OVERFLOW_VISIBLE | K.SHARD_OVERFLOW_BLOCKS) for st in sts), [hex(st.flags) for st in sts]
+    rc, out, cnt = finalize_shards(plan, msgs)
+    assert rc == 0, (rc, tel._ctx.error())
+    e = OracleBackend(opts).scan_segment(seq, 0, False)
+    assert len(e["interstitial_blocks"]) >= 100
+    assert_visible_view_equal(ta.SegmentData(out[0], False), e, False, cnt[0], "after growing the message")
+    free_segments(plan, out)
+    for s in shards:
+        s.close()
+    plan.close()
+
+
 def test_scan_segments_multi_equals_oracle():
     """ts_scan_segments_multi over 1, 2 and 3 contexts (sharing this GPU): per segment == oracle, full scans and
     tips-only segments mixed in one call; a parameter set outside the tiled kernel takes the single-context path."""
