@@ -310,3 +310,29 @@ def test_eight_way_split_of_the_bench_assembly_merges_to_the_one_part_result():
     for i, (a, b) in enumerate(zip(results[1], results[8])):
         for name, x, y in zip(("windows", "terminal blocks", "interstitial blocks", "visible records", "counts"), a, b):
             assert x == y, "segment %d: %s differ between the 1-part and the 8-part merge" % (i, name)
+
+
+def test_scan_segments_multi_takes_the_single_context_path_when_the_shards_cannot_agree():
+    """A 60 kb repeat array across the boundary between the two shards of a segment (longer than the context tiles): the
+    merge says NEED_FULL and ts_scan_segments_multi answers from one context instead — the same result as the oracle's,
+    never an error and never a wrong block."""
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import parse_cli, user_input
+    L = K.lib()
+    opts = parse_cli("x.fa " + HEADLINE + " -t 3000")
+    tels = [ta.Teloscope(user_input(opts, device=0)) for _ in range(2)]
+    rng = np.random.default_rng(31)
+    n = 1_200_000
+    seq = bytearray(seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, n_its=2))
+    seq[570_000:630_000] = (b"TTAGGG" * 10_000)[:60_000]
+    seq = bytes(seq)
+    segs = (K.SegmentIn * 1)()
+    segs[0].seq, segs[0].len, segs[0].abs_pos = seq, n, 0
+    out, cnt = (K.SegmentOut * 1)(), (K.SegmentCounts * 1)()
+    ctxs = (C.c_void_p * 2)(*[t._ctx.ptr for t in tels])
+    assert L.ts_scan_segments_multi(ctxs, 2, segs, 1, out, cnt) == 0, tels[0]._ctx.error()
+    e = OracleBackend(opts).scan_segment(seq, 0, False)
+    assert any(b["block_len"] >= 59_000 for b in e["interstitial_blocks"])
+    assert_visible_view_equal(ta.SegmentData(out[0], False), e, False, cnt[0], "fallback")
+    L.ts_free_segments(out, 1)
