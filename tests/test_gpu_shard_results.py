@@ -27,7 +27,7 @@ def _teloscope(cli, device=0):
     return opts, ta.Teloscope(user_input(opts, device=device))
 
 
-def _pack_all_parts(plan, buf, dev):
+def _pack_all_parts(plan, buf, dev, scale=1):
     """Every part scanned and packed on its own restricted batch, as a rank would; returns the host messages."""
     import torch
     from teloscope_amd import _capi as K
@@ -35,7 +35,7 @@ def _pack_all_parts(plan, buf, dev):
     sptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     msgs, stats = [], []
     for p in range(plan.world):
-        ps = PackedShard(plan, p, dev, slots=1)
+        ps = PackedShard(plan, p, dev, slots=1, scale=scale)
         local = buf[ps.info.input_begin:max(ps.info.input_end, ps.info.input_begin + 64)].clone()   # a rank holds only the bytes its range reads
         for _ in range(6):
             ps.scan_pack(local.data_ptr(), sptr, 0)
@@ -43,7 +43,7 @@ def _pack_all_parts(plan, buf, dev):
             if st.flags & K.SHARD_OVERFLOW_SCAN:
                 ps.sync(0)
             elif st.flags & (K.SHARD_OVERFLOW_VISIBLE | K.SHARD_OVERFLOW_BLOCKS):
-                raise AssertionError("message overflow at scale 1: visible %d / %d, blocks %d / %d"
+                raise AssertionError("message overflow at this scale: visible %d / %d, blocks %d / %d"
                                      % (st.n_visible, st.visible_capacity, st.n_blocks, st.block_capacity))
             else:
                 break
