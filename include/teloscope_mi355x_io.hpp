@@ -1836,6 +1836,7 @@ inline AssemblySummary scanFastaToFiles(Teloscope &teloscope, const std::string 
     detail::BoundedQueue<Scanned> toWrite(2);
     std::exception_ptr readError, scanError;
     ScanFastaTimes T;
+    const bool trace = std::getenv("TS_MIRROR_TRACE") != nullptr;      // per-group stage intervals on stderr (ms since the call began)
 
     std::thread reader([&] {
         try {
@@ -1865,6 +1866,7 @@ inline AssemblySummary scanFastaToFiles(Teloscope &teloscope, const std::string 
                 s.paths = walkRecordViews(teloscope, views, g.firstRecord, g.owned.empty() ? &g.comps : nullptr);
                 s.group = std::move(g);                           // (-m: matchSeq was copied out of the bases already)
                 T.scan_ms += ms(t0, Clock::now());
+                if (trace) std::fprintf(stderr, "trace scan  %7.1f .. %7.1f\n", ms(t_begin, t0), ms(t_begin, Clock::now()));
                 toWrite.push(std::move(s));
             }
         } catch (...) {
@@ -1885,8 +1887,11 @@ inline AssemblySummary scanFastaToFiles(Teloscope &teloscope, const std::string 
             for (const PathData &pd : s.paths) { T.bases += pd.pathSize; T.windows += pd.windows.size(); }
             ++T.groups;
             T.write_ms += ms(t0, Clock::now());
+            if (trace) std::fprintf(stderr, "trace write %7.1f .. %7.1f\n", ms(t_begin, t0), ms(t_begin, Clock::now()));
         }
+        const auto tf = Clock::now();
         sum = writer.finish();
+        if (trace) std::fprintf(stderr, "trace finish %7.1f .. %7.1f\n", ms(t_begin, tf), ms(t_begin, Clock::now()));
     } catch (...) {
         writeError = std::current_exception();
         Scanned drop;
