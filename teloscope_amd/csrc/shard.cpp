@@ -134,7 +134,7 @@ ShardLayout shard_layout(const ts_batch *b, const ShardRange &r, uint32_t scale)
     uint64_t ncanon = 0;
     for (const ts::Pattern &p : c->patterns) ncanon += p.is_canonical ? 1 : 0;
     const double d_canon = (double)std::max<uint64_t>(ncanon, 1) / (double)(1ull << (2 * std::min<uint32_t>(c->k, 16)));
-    uint64_t vis = b->tips ? 0 : (uint64_t)((double)own_bases * d_canon * 1.5) + zone_bases / 4 + 65536;
+    uint64_t vis = b->tips ? 0 : (uint64_t)((double)own_bases * d_canon * 1.5) + zone_bases / 8 + 65536;   // (every match of a terminal zone is visible: ~3 % of its bases, more inside a telomere)
     vis = std::min<uint64_t>(vis * scale, own_bases + 16);
     L.visible_capacity = (vis + 7ull) & ~7ull;
     L.block_capacity = (uint32_t)std::min<uint64_t>((16ull * r.n_segs + 256ull) * scale, 1u << 24);
