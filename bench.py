@@ -11,12 +11,15 @@ the contigs, 0.1 % soft-masked bases; flags -c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TT
 N = 1: one "step" = one full scan of the resident assembly: window records (8 x u32 per window) and the packed
 match stream are produced in HBM.
 N > 1 (strong scaling, configs[2]): the SAME assembly; every rank builds the same plan and scans the p-th of N
-consecutive tile ranges (teloscope_amd/distributed.py), then ONE exchange — an all-gather of record counts and a
-grouped send/recv of window records, tile directory and tile-ordered match records over RCCL — leaves on rank 0
-what the single-GPU scan leaves there.  A step = scan + exchange; the exchange of step i overlaps the scan of
-step i+1 (two buffer sets), and every exchange is complete before the clock stops.  Ranks are started by
-torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, when those are absent, by this
-script itself (`python bench.py --gpus N` spawns N rank processes before anything touches a GPU).
+consecutive tile ranges plus a few context tiles (teloscope_amd/distributed.py), calls its blocks on its own device
+and packs ONE message of a size both sides know from the plan — bit-packed window records, the match records a
+writer reads, its blocks — and ONE grouped send / recv per step over RCCL brings the messages to rank 0, whose host
+merge (ts_shards_finalize, untimed, before and after the timed steps) leaves what the reference's writers read of a
+single-GPU scan.  A step = scan + block calling + pack + exchange; nothing is read back to the host inside a step,
+the pack and the exchange of step i run beside the scans of the steps after it (buffer slots), and every exchange
+is complete before the clock stops.  `--full-exchange` is round 2's form (every record to rank 0).  Ranks are
+started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, when those are absent, by
+this script itself (`python bench.py --gpus N` spawns N rank processes before anything touches a GPU).
 
   python bench.py --reads [--gpus N]        the read filter (configs[3]) instead of the assembly scan
 """
@@ -31,6 +34,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP streams share the runtime's hardware queues round-robin (4 by default), and kernels of two streams that landed on one
+# queue run one after the other: a sharded step uses the scan stream, two pack streams and a side stream per buffer slot
+# (profiles/r04/hwq_sweep.txt: 8 queues 0.174 ms per step at the N = 8 size against 0.197 with 4; 16 are slower than 4).
+# Read when the runtime initialises: before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLAGS = "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -x 1 -w 1000 -s 500 -r -g -e -m -i"
@@ -536,6 +544,8 @@ def run_scan(args, rank, local_rank, world, dev, backend):
     if not strong:
         # ---------------------------------------------------------------- N = 1 (or weak scaling)
         batch = plan.batch
+        if os.environ.get("TS_BENCH_EMIT") == "1":          # A/B: the plain scan with the emitting build (ts_batch_set_emit)
+            L.ts_batch_set_emit(batch, 1)
         dptr = C.c_void_p(buf.data_ptr())
         summaries = [torch.zeros(n * 4, dtype=torch.int64, device=dev) for _ in range(2)]
         gathered = [[torch.zeros(n * 4, dtype=torch.int64, device=xdev) for _ in range(world)]
@@ -614,7 +624,7 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         # size both sides know from the plan; one grouped send / recv per step brings the messages to rank 0.  Nothing is
         # read back to the host inside a step; the messages' headers are checked (and the messages merged on the host,
         # ts_shards_finalize) before the timed steps and after them.
-        slots = max(2, int(os.environ.get("TS_BENCH_SLOTS", "3")))      # (profiles/r03/slots_sweep.txt)
+        slots = max(2, int(os.environ.get("TS_BENCH_SLOTS", "4")))      # (profiles/r04/hwq_sweep.txt, slots_sweep.txt)
         scale = 1
         exch = D.ShardExchange(plan, rank, dev, dst=0, slots=slots, scale=scale)
         shard = D.PackedShard(plan, rank, dev, slots=slots, scale=scale)

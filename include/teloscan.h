@@ -357,8 +357,19 @@ int ts_batch_partition(const ts_batch *b, uint32_t n_parts, uint32_t part, uint6
  * the range, ts_batch_scan expects d_input to point at byte input_begin of the input layout
  * (ts_batch_range_info), and ts_batch_upload copies only the part of a segment the range reads. */
 int ts_batch_restrict(ts_batch *b, uint64_t tile_begin, uint64_t tile_end);
+/* on != 0: the batch's scans (window scans only; a tips-only batch ignores it) also leave, in HBM, what the calls that
+ * follow a scan would otherwise re-read the whole match stream for: the records a writer reads — canonicalMatches and
+ * the terminal nonCanonicalMatches, /root/reference/src/teloscope.cpp:486-496 — as a second, sparse output, and per tile
+ * a summary of its chains of matches (getInterstitialBlocks' grouping, src/teloscope.cpp:235-253).  Device block
+ * calling (ts_batch_download*, the host entry points) then looks only at the tiles that can hold an interstitial block,
+ * and ts_batch_pack_shard copies the visible records instead of filtering 4 bytes per match.  It costs the scan kernel
+ * about a tenth of its time, so it is OFF for a batch that is only scanned (results left in HBM) and switched ON by
+ * ts_batch_restrict_shard and by the host entry points, whose downloads always call blocks; results are identical
+ * either way.  May be changed between scans; the fourth word of a tile's directory entry is its visible-record count
+ * while on. */
+int ts_batch_set_emit(ts_batch *b, int on);
 /* Caller-owned result buffers (device): the scan writes the range's window records (32 B each, from
- * window_begin) to d_windows and its tile directory entries {matches, canonical, forward, 0} x uint32 (16 B per
+ * window_begin) to d_windows and its tile directory entries {matches, canonical, forward, 0 or visible} x uint32 (16 B per
  * tile, from tile_begin) to d_tile_stats.  Either may be NULL = the batch's own buffer.  Before the first scan. */
 int ts_batch_bind_results(ts_batch *b, void *d_windows, void *d_tile_stats);
 /* After a scan (asynchronous on `stream`): packs the range's match records into ONE stream in tile order

@@ -136,6 +136,7 @@ SYMBOLS = [
     "ts_batch_wire16_ok", "ts_wire_widen_u16", "ts_takes_text_input", "ts_bind_thread_to_device",
     "ts_batch_shard_info", "ts_batch_restrict_shard", "ts_batch_set_shard_scale", "ts_batch_pack_shard",
     "ts_shard_peek", "ts_shards_finalize", "ts_scan_segments_multi", "ts_batch_read_pass_status", "ts_pack_bases",
+    "ts_batch_set_emit",
 ]
 
 
@@ -245,6 +246,8 @@ def lib():
     L.ts_batch_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.ts_batch_restrict.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
     L.ts_batch_bind_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if hasattr(L, "ts_batch_set_emit"):                # (absent from a round-3 build loaded through TELOSCAN_LIB for an A/B run)
+        L.ts_batch_set_emit.argtypes = [C.c_void_p, C.c_int]
     L.ts_batch_export.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.ts_batch_adopt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.ts_batch_tile_stats_ptr.restype = C.c_void_p

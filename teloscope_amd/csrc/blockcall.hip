@@ -28,6 +28,13 @@
 
 #include "ts_internal.h"
 
+// These kernels run beside the persistent scan kernel of the next batch, whose waves raise their priority for the phases that
+// are chains of latency (s_setprio 2 / 3, kernels.hip): at the default priority a wave of a small kernel that shares a SIMD with
+// them is served only when none of them is ready — a visible-record copy of 60 us took the whole 0.8 ms of the scan beside it, and
+// a pack, a chain of a dozen such kernels, about two scans.  At the top priority they are served first, and being a few
+// thousand instructions each they cost the scan nothing measurable.
+#define TS_SIDE_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
+
 namespace {
 
 typedef unsigned long long u64;
@@ -303,6 +310,7 @@ __device__ __forceinline__ SegView seg_view(const TsBlockCallParams &Q, const Ts
 // segment (nearly every wave) adds up first and issues five atomics.  No LDS (see exchange.hip).
 __global__ __launch_bounds__(256)
 void ts_segment_sums(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base, uint32_t ntiles, u64 *sums) {
+    TS_SIDE_KERNEL_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t si = 0xFFFFFFFFu;
     u64 v[5] = {0, 0, 0, 0, 0};
@@ -333,6 +341,7 @@ void ts_segment_sums(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32
 __global__ __launch_bounds__(128)
 void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t nseg, u64 *bounds,
                         TsShardSeg *seg_out, const u64 *sums) {
+    TS_SIDE_KERNEL_PRIO();
     // two independent waves per segment: wave 0 walks the forward list from the start, wave 1 the reverse list from the end.
     // A shard (seg_out != nullptr) walks a direction only when it owns that end of the segment; the bounds of the other end
     // are the widest possible, which the receiver checks against what the shard that did walk it reports (shard.cpp:
@@ -464,14 +473,9 @@ __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const T
 // records end is followed (counting canonical matches) through the tiles behind until a head closes it.
 //
 // Measured on the 91.5 M records of configs[1]: profiles/r03/its_kernel_variants.txt.
-__global__ __launch_bounds__(256)
-void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base,
-                            const u64 *bounds, uint32_t ntiles, TsShardSeg *seg_out, const TsVisibleOut W) {
-    // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all lanes of a wave; told so, it keeps the
-    // tile's directory entries, the bounds and every ballot in scalar registers and branches instead of predicating)
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (tile >= ntiles) return;
+__device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsShardSegIn *segs, uint32_t seg_base,
+                                         const u64 *bounds, uint32_t ntiles, TsShardSeg *seg_out, const TsVisibleOut &W,
+                                         const uint32_t tile) {
     const uint32_t lane = threadIdx.x & 63u;
     // A wave's time is also a chain of memory round trips: everything that does not depend on something else is
     // requested together — first the directory entries of the tile and its two neighbours, then the segment's entry, the
@@ -718,10 +722,123 @@ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs,
     if (seg_out && ooc && lane == 0) atomicOr(&seg_out[si].flags, TS_SEG_F_CONTEXT);
 }
 
+// every tile of the range: results that carry no chain summaries (adopted from elsewhere, TS_EMIT=0), and the shard pack
+// that takes the visible records from the match stream
+__global__ __launch_bounds__(256)
+void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base,
+                            const u64 *bounds, uint32_t ntiles, TsShardSeg *seg_out, const TsVisibleOut W) {
+    TS_SIDE_KERNEL_PRIO();
+    // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all lanes of a wave; told so, it keeps the
+    // tile's directory entries, the bounds and every ballot in scalar registers and branches instead of predicating)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (tile >= ntiles) return;
+    its_tile(Q, segs, seg_base, bounds, ntiles, seg_out, W, tile);
+}
+
+// ---- the interstitial search from the scan's own chain summaries (TsTileChain, written by ts_scan_tiles with P.emit)
+//
+// ts_chain_screen: ONE THREAD per tile decides, from 16 bytes per tile, whether a chain that STARTS in the tile can hold
+// the four canonical matches a block needs (getInterstitialBlocks, src/teloscope.cpp:206): a chain between two internal
+// heads (the scan flagged it), the chain of the tile's first record when that record opens one, or the chain open at the
+// tile's end followed through the summaries of the tiles behind.  The test errs on the side of listing — counts are upper
+// bounds where the search range ends inside a tile — because every listed tile is then walked by its_tile above, record by
+// record, exactly as before.  Tiles the two terminal boundaries cut, and tiles at the edge of a shard's view (where
+// its_tile decides whether a chain ran out of context), are always listed.  On random sequence about one tile in a
+// thousand is listed: the pass reads 3 MB instead of the 0.37 GB of records.
+__global__ __launch_bounds__(256)
+void ts_chain_screen(const TsBlockCallParams Q, const uint32_t *chain, const TsShardSegIn *segs, uint32_t seg_base,
+                     const u64 *bounds, uint32_t ntiles, uint32_t *work, uint32_t *n_work) {
+    TS_SIDE_KERNEL_PRIO();
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    bool list = false;
+    if (tile < ntiles) {
+        const uint32_t cnt = Q.tile_stats[4u * tile];
+        const TsTile T = Q.tiles[tile];
+        const uint32_t si = T.seg - seg_base;
+        const TsShardSegIn S = segs[si];
+        const u64 fb = bounds[2ull * si], rb = bounds[2ull * si + 1];
+        const bool its_on = !(rb == 0 || fb >= rb);
+        if (cnt != 0u && its_on && tile >= S.o0 && tile < S.o1) {
+            const u64 tile_rel = T.in_off - S.in_off, tile_end = tile_rel + T.own_len;
+            const uint2 c = *(const uint2 *)&chain[4ull * tile];
+            const uint32_t p_first = c.x & 0xFFFFu, p_last = c.x >> 16;
+            const uint32_t A = c.y & 0x7FFFu, Z = (c.y >> 16) & 0x7FFFu;
+            const bool heads = (c.y & TS_CHAIN_HEADS) != 0u, inner = (c.y & TS_CHAIN_INNER) != 0u;
+            const bool open_l = !(S.flags & TS_SEG_F_HAS_START), open_r = !(S.flags & TS_SEG_F_HAS_END);
+            if (!(fb <= tile_rel && rb >= tile_end)) {
+                // a boundary inside the tile: exact walk, unless no record of it can lie in [fb, rb)
+                list = tile_rel + p_last >= fb && tile_rel + p_first < rb;
+            } else if (inner) {
+                list = true;
+            } else {
+                // does the tile's first record open a chain?  (the record before it: in the nearest tile ahead that holds one; an
+                // empty tile wider than -k in between settles it)
+                bool first_head = true;
+                bool found = false;
+                for (uint32_t t = tile; t > S.t0; --t) {
+                    const uint32_t c2 = Q.tile_stats[4u * (t - 1u)];
+                    if (c2 == 0u) {
+                        if (Q.tiles[t - 1u].own_len > Q.max_match_dist) { found = true; break; }     // too far whatever lies ahead
+                        continue;
+                    }
+                    const u64 last_pos = Q.tiles[t - 1u].in_off - S.in_off + (chain[4ull * (t - 1u)] >> 16);
+                    found = true;
+                    if (last_pos >= fb && tile_rel + p_first - last_pos <= Q.max_match_dist) first_head = false;
+                    break;
+                }
+                // nothing in the whole left context of a clipped view: its_tile decides whether that is out of context
+                if (!found && open_l && S.lo_rel > fb) list = true;
+                if (first_head && heads && A >= 4u) list = true;
+                if (heads || first_head) {
+                    // the chain open at the tile's end — from its last internal head, or from its first record — through the tiles behind
+                    uint32_t canon = Z;
+                    u64 last_abs = tile_rel + p_last;
+                    bool closed = false;
+                    for (uint32_t t = tile + 1u; t < S.t1 && !closed; ++t) {
+                        const uint32_t c2 = Q.tile_stats[4u * t];
+                        if (c2 == 0u) {
+                            if (Q.tiles[t].own_len > Q.max_match_dist) closed = true;
+                            continue;
+                        }
+                        const uint2 d = *(const uint2 *)&chain[4ull * t];
+                        const u64 rel2 = Q.tiles[t].in_off - S.in_off;
+                        if (rel2 + (d.x & 0xFFFFu) - last_abs > Q.max_match_dist) { closed = true; break; }
+                        canon += d.y & 0x7FFFu;
+                        if (d.y & TS_CHAIN_HEADS) { closed = true; break; }
+                        last_abs = rel2 + (d.x >> 16);
+                    }
+                    if (canon >= 4u || (!closed && open_r)) list = true;
+                }
+            }
+        }
+    }
+    const u64 m = __ballot(list);
+    if (m == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0u) base = atomicAdd(n_work, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (list) work[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = tile;
+}
+
+// the listed tiles, one wave each (the list holds at most every tile of the range)
+__global__ __launch_bounds__(256)
+void ts_interstitial_listed(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base, const u64 *bounds,
+                            uint32_t ntiles, TsShardSeg *seg_out, const uint32_t *work, const uint32_t *n_work) {
+    TS_SIDE_KERNEL_PRIO();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n = *n_work;
+    const TsVisibleOut W{};
+    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave; i < n; i += gridDim.x * (blockDim.x >> 6))
+        its_tile(Q, segs, seg_base, bounds, ntiles, seg_out, W, (uint32_t)__builtin_amdgcn_readfirstlane((int)work[i]));
+}
+
 // The listed chains, one wave each: walked exactly, filtered, written.  A list that overflowed is reported through the
 // block counter (more blocks than the buffer holds = "come back with more room": the callers' existing path).
 __global__ __launch_bounds__(256)
 void ts_interstitial_evaluate(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base, const u64 *bounds) {
+    TS_SIDE_KERNEL_PRIO();
     const uint32_t n_all = *Q.n_cand;
     const uint32_t n = n_all < Q.cand_cap ? n_all : Q.cand_cap;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -736,14 +853,41 @@ void ts_interstitial_evaluate(const TsBlockCallParams Q, const TsShardSegIn *seg
 
 }  // namespace
 
+namespace {
+struct ZeroJobs { void *p[4]; unsigned long long n[4]; };     // byte counts, multiples of 4, pointers 4-byte aligned
+__global__ __launch_bounds__(256)
+void ts_zero_ranges(const ZeroJobs J) {
+    TS_SIDE_KERNEL_PRIO();
+    for (int q = 0; q < 4; ++q) {
+        uint32_t *dst = (uint32_t *)J.p[q];
+        const u64 n = J.n[q] >> 2;
+        for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u) dst[i] = 0u;
+    }
+}
+}  // namespace
+
+// Up to four ranges zeroed by ONE kernel (a pack accumulates into its header, the per-segment sums and two list counters: four
+// memsets were four launches on its chain of latencies).  n: bytes, multiples of 4; null pointers are skipped.
+int ts_k_launch_zero(void *p0, unsigned long long n0, void *p1, unsigned long long n1, void *p2, unsigned long long n2,
+                     void *p3, unsigned long long n3, void *stream) {
+    ZeroJobs J{{p0, p1, p2, p3}, {p0 ? n0 : 0, p1 ? n1 : 0, p2 ? n2 : 0, p3 ? n3 : 0}};
+    unsigned long long most = 0;
+    for (int q = 0; q < 4; ++q) most = J.n[q] > most ? J.n[q] : most;
+    const unsigned grid = (unsigned)((most / 4 + 255) / 256 < 1 ? 1 : ((most / 4 + 255) / 256 > 64 ? 64 : (most / 4 + 255) / 256));
+    hipLaunchKernelGGL(ts_zero_ranges, dim3(grid), dim3(256), 0, (hipStream_t)stream, J);
+    return (int)hipGetLastError();
+}
+
 // The two halves of block calling, for a caller that runs the terminal walks on a stream of their own (shard.cpp): the
 // walks are one latency-bound wave per segment end, and nothing but the interstitial search waits for them.
 int ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
-                         unsigned long long *bounds, TsShardSeg *seg_out, unsigned long long *sums, void *stream) {
+                         unsigned long long *bounds, TsShardSeg *seg_out, unsigned long long *sums, int prezeroed, void *stream) {
     if (nseg == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums, 0, (size_t)nseg * 40, st);
-    if (e != hipSuccess) return (int)e;
+    if (!prezeroed) {                                      // (a shard's pack zeroes everything it accumulates into with one kernel: ts_k_launch_zero)
+        hipError_t e = hipMemsetAsync(sums, 0, (size_t)nseg * 40, st);
+        if (e != hipSuccess) return (int)e;
+    }
     if (ntiles)
         hipLaunchKernelGGL(ts_segment_sums, dim3((ntiles + 255u) / 256u), dim3(256), 0, st, *Q, segs, seg_base, ntiles, sums);
     hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(128), 0, st, *Q, segs, nseg, bounds, seg_out, (const u64 *)sums);
@@ -751,12 +895,26 @@ int ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, u
 }
 
 int ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
-                             const unsigned long long *bounds, TsShardSeg *seg_out, const TsVisibleOut *vis, void *stream) {
+                             const unsigned long long *bounds, TsShardSeg *seg_out, const TsVisibleOut *vis,
+                             const uint32_t *chain, uint32_t *work, int prezeroed, void *stream) {
     if (nseg == 0 || ntiles == 0) return 0;
     TsVisibleOut W{};
     if (vis) W = *vis;
-    hipLaunchKernelGGL(ts_interstitial_blocks, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *Q,
-                       segs, seg_base, (const u64 *)bounds, ntiles, seg_out, W);
+    if (chain && work && !W.off) {
+        // from the scan's chain summaries: screen (a thread per tile), then the exact walk of the listed tiles only.
+        // work[0] = the list's counter (zeroed here unless the caller did), work[1 ..] = the list
+        if (!prezeroed) {
+            hipError_t e = hipMemsetAsync(work, 0, 4, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(ts_chain_screen, dim3((ntiles + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *Q, chain,
+                           segs, seg_base, (const u64 *)bounds, ntiles, work + 1, work);
+        hipLaunchKernelGGL(ts_interstitial_listed, dim3(128), dim3(256), 0, (hipStream_t)stream, *Q, segs, seg_base,
+                           (const u64 *)bounds, ntiles, seg_out, (const uint32_t *)(work + 1), (const uint32_t *)work);
+    } else {
+        hipLaunchKernelGGL(ts_interstitial_blocks, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *Q,
+                           segs, seg_base, (const u64 *)bounds, ntiles, seg_out, W);
+    }
     hipLaunchKernelGGL(ts_interstitial_evaluate, dim3(256), dim3(256), 0, (hipStream_t)stream, *Q, segs, seg_base,
                        (const u64 *)bounds);
     return (int)hipGetLastError();
@@ -764,8 +922,8 @@ int ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *seg
 
 int ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
                            uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its,
-                           const TsVisibleOut *vis, unsigned long long *sums, void *stream) {
-    int e = ts_k_launch_terminal(Q, segs, nseg, seg_base, ntiles, bounds, seg_out, sums, stream);
-    if (e == 0 && (with_its || (vis && vis->off))) e = ts_k_launch_interstitial(Q, segs, nseg, seg_base, ntiles, bounds, seg_out, vis, stream);
+                           const TsVisibleOut *vis, unsigned long long *sums, const uint32_t *chain, uint32_t *work, void *stream) {
+    int e = ts_k_launch_terminal(Q, segs, nseg, seg_base, ntiles, bounds, seg_out, sums, 0, stream);
+    if (e == 0 && (with_its || (vis && vis->off))) e = ts_k_launch_interstitial(Q, segs, nseg, seg_base, ntiles, bounds, seg_out, vis, chain, work, 0, stream);
     return e;
 }

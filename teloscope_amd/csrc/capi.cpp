@@ -135,6 +135,8 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     kp.fc_byte_table = c->fc_byte_table ? 1u : 0u;
     kp.pair_byte_table = c->pair_byte_table ? 1u : 0u;
     kp.fold_mask = P.fold_case ? 0xDFDFDFDFu : 0xFFFFFFFFu;
+    kp.emit = 0;                         // (ts_batch_set_emit)
+    kp.kdist = P.max_match_dist;
     if (tips) {
         kp.halo_blocks = 0;
         kp.straddle_fix = 0; kp.windows_on = 0; kp.nuc_on = 0; kp.block_sums = 0;
@@ -214,6 +216,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
                 while ((uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) cand.stage_cap -= 16;
             }
             // (the kernels for the 2-bit tables of k >= 7 need 97 VGPRs: built for 80 they spill)
+            if (wgs > 1 && !(kp.pair_byte_table && kp.fc_byte_table)) continue;      // not built: it would spill (kernels.hip: scan_variant)
             if (wgs > 1 && !pin_waves && (tips || sparse || !(kp.pair_byte_table && kp.fc_byte_table) || nch < 6 || cand.stage_cap < 256 || cand.acc_copies < 4)) continue;
             const double passes = tips ? 0.0 : (double)ceil_div((uint64_t)cwpt * 4, 64);
             // fewer accumulator copies serialise the window adds of a pass: 8 chunks with 2 copies measured 2.5 %
@@ -223,7 +226,11 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
             if (score > best) { best = score; best_kp = cand; best_wpt = cwpt; }
         }
     }
-    if (best > 0.0) { kp = best_kp; wpt = best_wpt; return true; }
+    if (best > 0.0) {
+        kp = best_kp; wpt = best_wpt;
+        kp.vis_wide = ((uint64_t)kp.nch * TS_CHUNK + 64u <= (1u << 14)) ? 0u : 1u;      // (position << 2 | flags) in 16 bits?
+        return true;
+    }
     why = "window/step geometry does not fit the 160 KB LDS of a CU";
     return false;
 }
@@ -294,6 +301,33 @@ void ts_ctx::bind_this_thread() const {
     if (n > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof want, &want);       // (threads started from here inherit it)
 }
 
+// The buffers of a batch that emits (ts_batch_set_emit): per-wave regions of visible records, the per-tile chain summaries
+// and, planned here, every tile's terminal-zone word.  Idempotent.
+static int ensure_emit_buffers(ts_batch *b) {
+    ts_ctx *c = b->ctx;
+    if (!b->kp.emit || b->d_chain.p) return TS_OK;
+    const size_t nt = (size_t)b->range_tiles();
+    {
+        HIP_TRY(c, c->pool.take(std::max<uint64_t>((uint64_t)b->vis_cap * b->total_waves, 4) * (b->kp.vis_wide ? 4 : 2) + 16, b->d_vis));
+        HIP_TRY(c, c->pool.take((nt + 1) * 16, b->d_chain));
+        HIP_TRY(c, c->pool.take((nt + 1) * 4, b->d_zone));
+        // terminal zone of a segment (isTerminal, src/teloscope.cpp:451-459): rel <= t || rel >= N - t, the whole of a
+        // segment no longer than t; per tile as two 16-bit thresholds on the tile-relative position
+        std::vector<uint32_t> zone(nt + 1, TS_ZONE_NONE);
+        const uint64_t tl = c->params.terminal_limit;
+        for (size_t i = 0; i < nt; ++i) {
+            const TsTile &T = b->tiles[b->tile_lo + i];
+            const SegPlan &sp = b->segs[T.seg];
+            const uint64_t rel0 = T.in_off - sp.in_off;
+            uint64_t zlo = rel0 <= tl ? tl + 1 - rel0 : 0, zhi = 0;
+            if (sp.len > tl) zhi = sp.len - tl > rel0 ? sp.len - tl - rel0 : 0;
+            zone[i] = (uint32_t)std::min<uint64_t>(zlo, 0xFFFF) | ((uint32_t)std::min<uint64_t>(zhi, 0xFFFF) << 16);
+        }
+        HIP_TRY(c, hipMemcpy(b->d_zone.p, zone.data(), (nt + 1) * 4, hipMemcpyHostToDevice));
+    }
+    return TS_OK;
+}
+
 // Allocates (from the context's pool) the device state of the batch's tile range; idempotent.
 int ts_batch_ensure_device(ts_batch *b) {
     ts_ctx *c = b->ctx;
@@ -309,7 +343,7 @@ int ts_batch_ensure_device(ts_batch *b) {
     HIP_TRY(c, c->pool.take(std::max<uint64_t>((uint64_t)b->region_cap * b->total_waves, 4) * 4 + 16, b->d_matches));   // + 16: the read predicate fetches whole aligned 16-byte blocks
     HIP_TRY(c, c->pool.take((nt + 1) * 8, b->d_tile_off));
     if (!b->ext_stats) HIP_TRY(c, c->pool.take((nt + 1) * 16, b->d_stats));
-    HIP_TRY(c, c->pool.take((size_t)b->total_waves * 4 + 16, b->d_fill));
+    HIP_TRY(c, c->pool.take((size_t)b->total_waves * 8 + 16, b->d_fill));       // records needed per wave, then visible records needed per wave
     HIP_TRY(c, c->pool.take(2 * TS_MAX_TICKET_GROUPS * TS_TICKET_STRIDE * 4, b->d_tickets));
     HIP_TRY(c, hipMemset(b->d_tickets.p, 0, 2 * TS_MAX_TICKET_GROUPS * TS_TICKET_STRIDE * 4));
     if (nt) HIP_TRY(c, hipMemcpy(b->d_tiles.p, b->tiles.data() + b->tile_lo, nt * sizeof(TsTile), hipMemcpyHostToDevice));
@@ -351,6 +385,32 @@ void size_launch(ts_batch *b) {
     cap = std::min<uint64_t>(std::max<uint64_t>(cap, 256), worst);
     b->region_cap = (uint32_t)((cap + 3) & ~3ull);
     b->match_cap = (uint64_t)b->region_cap * b->total_waves;
+    // visible records (kp.emit): canonical matches at their density on random sequence, every match of a terminal zone
+    // (a few per cent of its bases; every k-th base inside a telomere), twice the even share per wave, grown on overflow
+    b->vis_cap = 0;
+    if (!b->tips) {
+        const ts_ctx *c = b->ctx;
+        uint64_t zone_bases = 0;
+        const uint64_t tl = c->params.terminal_limit;
+        for (uint64_t t = 0; t < nt; ++t) {
+            const TsTile &T = b->tiles[b->tile_lo + t];
+            const SegPlan &sp = b->segs[T.seg];
+            const uint64_t rel0 = T.in_off - sp.in_off, rel1 = rel0 + T.own_len;
+            if (rel0 <= tl || sp.len <= tl || rel1 > sp.len - tl) zone_bases += T.own_len;
+        }
+        uint64_t ncanon = 0;
+        for (const ts::Pattern &p : c->patterns) ncanon += p.is_canonical ? 1 : 0;
+        const double d_canon = (double)std::max<uint64_t>(ncanon, 1) / (double)(1ull << (2 * std::min<uint32_t>(c->k, 16)));
+        const uint64_t vwant = (uint64_t)((double)b->range_bases * d_canon * 1.5) + zone_bases / 8;
+        // (which wave scans which tile is decided at run time: a wave may take several of the few tiles that lie in a telomere,
+        // where every k-th base is a visible record — room for a dozen of those per wave, so that an overflow, which costs a
+        // rescan with dealt tiles, stays an event for inputs that are telomere through and through)
+        const uint64_t tile_bases = (uint64_t)b->wpt * std::max<uint32_t>(b->kp.s, 1);
+        uint64_t vcap = 2 * ceil_div(vwant, b->total_waves) + 12 * ceil_div(tile_bases, std::max<uint32_t>(c->k, 1)) + 2048;
+        if (b->dealt_tiles && !b->match_cap_request) vcap = worst;          // small ranges: the worst case, like the record regions
+        vcap = std::min<uint64_t>(vcap, std::max<uint64_t>(worst, 256));
+        b->vis_cap = (uint32_t)((vcap + 7) & ~7ull);
+    }
 }
 
 void set_range(ts_batch *b, uint64_t lo, uint64_t hi) {
@@ -743,7 +803,7 @@ void ts_batch_destroy(ts_batch *b) {
         DeviceGuard g(c->device);
         for (DevBuf *d : {&b->d_in, &b->d_tiles, &b->d_windows, &b->d_matches, &b->d_tile_off, &b->d_stats, &b->d_fill, &b->d_tickets,
                           &b->d_segtab, &b->d_dense, &b->d_dense_base, &b->d_scan_tmp, &b->d_readtab, &b->d_shard_segs,
-                          &b->d_shard_bounds, &b->d_shard_tmp, &b->d_shard_cand})
+                          &b->d_shard_bounds, &b->d_shard_tmp, &b->d_shard_cand, &b->d_vis, &b->d_chain, &b->d_zone})
             c->pool.give(std::move(*d));
         for (hipEvent_t e : b->evs)
             if (e) (void)hipEventDestroy(e);
@@ -795,6 +855,17 @@ int ts_batch_restrict(ts_batch *b, uint64_t tile_begin, uint64_t tile_end) {
     return TS_OK;
 }
 
+// TS_EMIT=0 keeps every batch from emitting (A/B measurements: the interstitial search then reads every record again, as it
+// does for results adopted from elsewhere)
+static bool emit_allowed() { const char *e = getenv("TS_EMIT"); return !(e && e[0] == '0'); }
+
+int ts_batch_set_emit(ts_batch *b, int on) {
+    if (!b) return TS_ERR_INVALID_ARG;
+    if (b->dense) return b->ctx->fail(TS_ERR_STATE, "ts_batch_set_emit on a batch that adopted results");
+    b->kp.emit = (on && !b->tips && emit_allowed()) ? 1u : 0u;
+    return TS_OK;
+}
+
 int ts_batch_bind_results(ts_batch *b, void *d_windows, void *d_tile_stats) {
     if (!b) return TS_ERR_INVALID_ARG;
     if (b->allocated || b->scanned) return b->ctx->fail(TS_ERR_STATE, "ts_batch_bind_results after the batch was used on the device");
@@ -840,6 +911,8 @@ int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
     DEVICE_TRY(c);
     if (b->dense) return c->fail(TS_ERR_STATE, "ts_batch_scan on a batch that adopted results");
     { int rc = ts_batch_ensure_device(b); if (rc != TS_OK) return rc; }
+    { int rc = ensure_emit_buffers(b); if (rc != TS_OK) return rc; }
+    b->emitted = b->kp.emit != 0u;
     if (!d_input) d_input = ts_batch_input_ptr(b);
     if (!d_input) return c->fail(TS_ERR_ALLOC, "no device input buffer");
     hipStream_t st = (hipStream_t)stream;
@@ -869,6 +942,10 @@ int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
     kp.ticket_slot = (uint32_t)(b->ticket_seq & 1u);
     kp.region_cap = b->region_cap;
     kp.ntiles = (uint32_t)b->range_tiles();
+    kp.vis_out = b->d_vis.p;
+    kp.vis_cap = b->vis_cap;
+    kp.tile_zone = (const uint32_t *)b->d_zone.p;
+    kp.tile_chain = (uint32_t *)b->d_chain.p;
 
     const size_t slot = (size_t)(b->scan_seq % kEventRing);
     HIP_TRY(c, hipEventRecord(b->evs[2 * slot], st));
@@ -908,22 +985,34 @@ int ts_batch_sync(ts_batch *b) {
             }
             b->harvested = b->scan_seq;
         }
-        b->wave_fill.assign(b->total_waves, 0u);
-        HIP_TRY(c, hipMemcpyAsync(b->wave_fill.data(), b->d_fill.p, (size_t)b->total_waves * 4, hipMemcpyDeviceToHost, (hipStream_t)b->last_stream));
+        const uint32_t nfill = b->total_waves * (b->emitted ? 2u : 1u);          // with emit: the visible records needed follow
+        b->wave_fill.assign(nfill, 0u);
+        HIP_TRY(c, hipMemcpyAsync(b->wave_fill.data(), b->d_fill.p, (size_t)nfill * 4, hipMemcpyDeviceToHost, (hipStream_t)b->last_stream));
         HIP_TRY(c, hipStreamSynchronize((hipStream_t)b->last_stream));
         uint64_t total = 0;
-        uint32_t worst = 0;
-        for (uint32_t f : b->wave_fill) { total += f; worst = std::max(worst, f); }
+        uint32_t worst = 0, worst_vis = 0;
+        for (uint32_t w = 0; w < b->total_waves; ++w) { total += b->wave_fill[w]; worst = std::max(worst, b->wave_fill[w]); }
+        for (uint32_t w = b->total_waves; w < nfill; ++w) worst_vis = std::max(worst_vis, b->wave_fill[w]);
         b->n_matches = total;
-        if (worst <= b->region_cap) { b->synced = true; return TS_OK; }
+        if (worst <= b->region_cap && worst_vis <= b->vis_cap) { b->synced = true; return TS_OK; }
         // a wave's region overflowed: size the regions for the fullest wave and rescan, from now on with the tiles
         // dealt round-robin (the counts of one such scan are those of the next)
         b->dealt_tiles = true;
-        b->region_cap = (uint32_t)(((uint64_t)worst + worst / 8 + 64 + 3) & ~3ull);
-        b->match_cap = (uint64_t)b->region_cap * b->total_waves;
-        if (b->d_matches.bytes < b->match_cap * 4 + 16) {
-            c->pool.give(std::move(b->d_matches));
-            HIP_TRY(c, c->pool.take(b->match_cap * 4 + 16, b->d_matches));
+        if (worst > b->region_cap) {
+            b->region_cap = (uint32_t)(((uint64_t)worst + worst / 8 + 64 + 3) & ~3ull);
+            b->match_cap = (uint64_t)b->region_cap * b->total_waves;
+            if (b->d_matches.bytes < b->match_cap * 4 + 16) {
+                c->pool.give(std::move(b->d_matches));
+                HIP_TRY(c, c->pool.take(b->match_cap * 4 + 16, b->d_matches));
+            }
+        }
+        if (worst_vis > b->vis_cap) {
+            b->vis_cap = (uint32_t)(((uint64_t)worst_vis + worst_vis / 8 + 64 + 7) & ~7ull);
+            const size_t need = (size_t)b->vis_cap * b->total_waves * (b->kp.vis_wide ? 4 : 2) + 16;
+            if (b->d_vis.bytes < need) {
+                c->pool.give(std::move(b->d_vis));
+                HIP_TRY(c, c->pool.take(need, b->d_vis));
+            }
         }
         int rc = ts_batch_scan(b, b->last_input, b->last_stream);
         if (rc != TS_OK) return rc;
@@ -1305,8 +1394,16 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
         Q.min_block_len = P.min_block_len; Q.max_block_dist = P.max_block_dist;
         Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;
         Q.k = c->k; Q.its_min_len = (uint32_t)(uint16_t)(2 * c->bp.first_pattern_len);
+        // (with the scan's chain summaries the interstitial search screens the tiles and walks only the listed ones)
+        const bool from_scan = b->chain_valid() && !b->tips;
+        if (from_scan && b->d_scan_tmp.bytes < (nt + 2) * 4) {
+            c->pool.give(std::move(b->d_scan_tmp));
+            HIP_TRY(c, c->pool.take((nt + 2) * 4, b->d_scan_tmp));
+        }
         if (ts_k_launch_block_call(&Q, (const TsShardSegIn *)dt, (uint32_t)ns, 0u, (uint32_t)nt, (unsigned long long *)(dt + off_bounds),
-                                   nullptr, b->tips ? 0 : 1, nullptr, (unsigned long long *)(dt + off_sums), st) != 0) return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
+                                   nullptr, b->tips ? 0 : 1, nullptr, (unsigned long long *)(dt + off_sums),
+                                   from_scan ? (const uint32_t *)b->d_chain.p : nullptr, from_scan ? (uint32_t *)b->d_scan_tmp.p : nullptr, st) != 0)
+            return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
         uint32_t nb = 0;
         HIP_TRY(c, hipMemcpyAsync(&nb, dt + off_count, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));

@@ -200,6 +200,12 @@ struct ts_batch {
     const void *last_input = nullptr;
     void *last_stream = nullptr;
     DevBuf d_in, d_tiles, d_windows, d_matches, d_tile_off, d_stats, d_fill, d_tickets, d_segtab, d_dense, d_dense_base, d_scan_tmp, d_readtab;
+    // what the scan hands to block calling and to a shard's message (kp.emit): per-wave regions of visible records, the
+    // per-tile chain summaries (TsTileChain) and, planned on the host, the terminal-zone word of every tile
+    DevBuf d_vis, d_chain, d_zone;
+    uint32_t vis_cap = 0;           // visible records per wave region
+    bool emitted = false;           // the latest scan ran the emitting build: tile_stats word 3, d_chain and d_vis describe it
+    bool chain_valid() const { return emitted && !dense && d_chain.p != nullptr; }
     // a shard (ts_batch_restrict_shard): the range the batch executes is its OWNED tiles [own_lo, own_hi) plus context tiles
     uint32_t shard_parts = 0, shard_part = 0, shard_scale = 1;
     uint64_t own_lo = 0, own_hi = 0;

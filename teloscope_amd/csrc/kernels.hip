@@ -98,9 +98,36 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v), 63);
+// Wave-wide inclusive prefix maximum, same six DPP steps (lanes outside a shift read 0)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return v > o ? v : o;
 }
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+    v = dpp_max<0x111, 0xf>(v);
+    v = dpp_max<0x112, 0xf>(v);
+    v = dpp_max<0x114, 0xf>(v);
+    v = dpp_max<0x118, 0xf>(v);
+    v = dpp_max<0x142, 0xa>(v);
+    v = dpp_max<0x143, 0xc>(v);
+    return v;
+}
+
+// The value of the lane below (lane 0: 0) by DPP wave_shr:1; the empty asm keeps it a v_mov_b32_dpp (folded into the
+// subtraction that follows it came back wrong on gfx950: see blockcall.hip)
+__device__ __forceinline__ uint32_t lane_below(uint32_t v) {
+    uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long low_bits(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
+
+// the lanes for which `p` holds, as a mask: on a bool this is one scalar AND of the compare's result with exec (__ballot takes
+// an int: the bool is first materialised per lane and compared again, two vector instructions per ballot)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 
 // sixteen 2-bit codes, held doubled (2 * code = ASCII & 6) one per byte of t[0..3] -> one dword, base i at
 // bits 2i..2i+1; four independent v_dot4_u32_u8 (weights 1,4,16,64: twice the packed byte, 9 bits) and four
@@ -131,13 +158,22 @@ __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15
 //           address
 //   stage   packed match records waiting to leave in whole coalesced rows (and kept out of the
 //           chunk loads' counted vmcnt waits), + one spare slot per lane for predicated-off writes
+//   (rec, during phase 1, with P.emit)  the tile's VISIBLE records — canonical ones, and the others where the tile lies in
+//           its segment's terminal zone: what a writer reads (src/teloscope.cpp:486-496) — waiting to leave for vis_out
 struct SliceLayout { uint32_t codes, rec, wacc, stage, bytes; };
 
 __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     SliceLayout s;
     uint32_t o = 0;
     s.codes = o; o += align16((P.nch * 63u + 1u) * 8u);
-    s.rec = o; o += (P.windows_on && P.nuc_on) ? align16((P.max_windows + P.halo_blocks) * 16u) : 0u;
+    {
+        // (with emit the region also stages the tile's visible records during phase 1 — the nucleotide rows are only
+        // assembled in phase 2, after the last of them has left — and holds at least the TS_VSTAGE_BYTES / 4 of them that
+        // one pass can produce)
+        uint32_t rb = (P.windows_on && P.nuc_on) ? align16((P.max_windows + P.halo_blocks) * 16u) : 0u;
+        if (P.windows_on && rb < TS_VSTAGE_BYTES) rb = TS_VSTAGE_BYTES;      // (whether or not this batch emits: one geometry)
+        s.rec = o; o += rb;
+    }
     s.wacc = o; o += P.windows_on ? align16(P.max_windows * 8u * P.acc_copies) : 0u;
     s.stage = o; o += (P.stage_cap + 64u) * 4u;
     s.bytes = o;
@@ -160,7 +196,10 @@ __host__ __device__ inline uint32_t lds_total(const TsScanParams &P) {
 // WAVES_EU = 6: at most 80 VGPRs, so that TWO workgroups of 10 waves share a CU — a workgroup's waves go round the SIMDs
 // 3,3,2,2 and two of them put six on SIMD 0, which 81 registers (five waves per SIMD) do not allow: the second workgroup then
 // waits for the first (measured: 1.14 ms instead of 0.74).
-template <bool FC_BYTES, bool PAIR_BYTES, int WAVES_EU>
+// EMIT: the build that also leaves the visible records and the per-tile chain summaries (P.emit).  A build of its own, so that a
+// scan nobody calls blocks from afterwards (a resident scan whose results stay in HBM) runs the code it always ran: with the
+// emit state merely branched around, the register allocator spilled 60 more scalars in the chunk loop (+7 % on configs[1]).
+template <bool FC_BYTES, bool PAIR_BYTES, int WAVES_EU, bool EMIT>
 __global__ __launch_bounds__(TS_MAX_WG_THREADS, WAVES_EU)
 void ts_scan_tiles(const TsScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -214,6 +253,8 @@ void ts_scan_tiles(const TsScanParams P) {
         return q;
     };
     uint32_t cursor = 0;                          // records this wave has produced so far
+    uint32_t vcursor = 0;                         // visible records this wave has produced so far (P.emit)
+    constexpr uint32_t vcap = TS_VSTAGE_BYTES / 4u;               // the stage of visible records: the head of the rec region (slice_layout), u32 entries
     const uint32_t nwper = P.halo_blocks + 1u;             // windows a position can belong to: ceil(w / s)
 
     // The first chunk of a tile is fetched while the previous tile's window phase runs (its loads would
@@ -272,11 +313,22 @@ void ts_scan_tiles(const TsScanParams P) {
         nch = (uint32_t)__builtin_amdgcn_readfirstlane((int)nch);
         bool has_invalid = false;
         const uint32_t own_end = sh + T.own_len;                   // plane coord: positions [sh, own_end) are this tile's
-        uint32_t done = 0, ccan = 0, cfwd = 0;                     // records of this tile so far (uniform); per-lane flag counts
+        uint32_t done = 0, ccan = 0, cfwd = 0;                     // records of this tile so far, canonical / forward among them (uniform)
         uint32_t flushed = 0;                                      // how many of them have left the staging buffer
+        // ---- what the tile hands to block calling and to a shard's message (P.emit): its visible records, and the summary
+        // of its chains of matches (TsTileChain) that lets the interstitial search skip the tile without reading its records
+        uint32_t zone = TS_ZONE_NONE;                              // tile_zone word: first needed by the tile's first pass, a chunk pair away
+        if (EMIT) zone = tail_params()->tile_zone[tile];
+        uint32_t vfill = 0, vout = 0;                              // visible records of this tile on the stage / that have left it
+        // ch_last starts at 0: a first record more than -k behind the tile's first base is a head whatever lies ahead of the
+        // tile, and is treated as an internal one; a first record closer than that is not a head HERE — whether it opens a
+        // chain depends on the tile before, which the screening looks up (ts_chain_screen, blockcall.hip)
+        uint32_t ch_first = 0, ch_last = 0;                        // position of the tile's first (taken at its first flush) / latest record
+        uint32_t ch_cc = 0, ch_w1 = 0;                             // canonical records of the open chain; word 1 of the summary so far
         auto flush_stage = [&]() {                                 // stage[0 .. done - flushed) -> wave_out[cursor + flushed ..)
             __builtin_amdgcn_wave_barrier();
             const uint32_t n = done - flushed;
+            if (EMIT && flushed == 0u && n != 0u) ch_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)stage[0]) >> 2;   // the tile's first record
             KernArgs Q = tail_params();
             const uint32_t cap = Q->region_cap;
             uint32_t *const wave_out = Q->matches_out + (u64)gw * cap;
@@ -286,6 +338,22 @@ void ts_scan_tiles(const TsScanParams P) {
             }
             __builtin_amdgcn_wave_barrier();
             flushed = done;
+        };
+        auto flush_vis = [&]() {                                   // rec[0 .. vfill) -> the wave's region of vis_out
+            __builtin_amdgcn_wave_barrier();
+            KernArgs Q = tail_params();
+            const uint32_t cap = Q->vis_cap;
+            const uint32_t at = vcursor + vout;
+            const u64 base = (u64)gw * cap + at;
+            for (uint32_t i = lane; i < vfill; i += 64u) {
+                if (at + i < cap) {
+                    if (Q->vis_wide) ((uint32_t *)Q->vis_out)[base + i] = rec[i];
+                    else ((uint16_t *)Q->vis_out)[base + i] = (uint16_t)rec[i];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            vout += vfill;
+            vfill = 0;
         };
         if (P.windows_on)                                          // match fields accumulate from zero
             for (uint32_t it = lane; it < P.max_windows * 2u * P.acc_copies; it += 64u) ((lds_u32 *)wacc)[it] = 0u;
@@ -323,19 +391,112 @@ void ts_scan_tiles(const TsScanParams P) {
                 uint32_t q = __umul24(u, P.s_inv) >> 16, qs = __umul24(q, P.s);
                 if (qs > u) { --q; qs -= P.s; }
                 const uint32_t o = u - qs;
+                // Which lanes hold what is decided on MASKS — one vector compare each, the logic between them on the scalar unit —
+                // and a lane's own predicate is read back off the mask (inverse ballot: the mask itself becomes the lane predicate).
                 // w == s: a match that would straddle a window end is lost (the carry rule of
                 // src/teloscope.cpp:611-628; pinned by t2t.fa -i = 199)
-                const bool valid = live && xp >= sh && !(P.straddle_fix && o + k > P.s);
-                const bool owned = valid && xp < own_end;
+                u64 valid_m = low_bits(n) & ballot64(xp >= sh);
+                if (P.straddle_fix) valid_m &= ~ballot64(o + k > P.s);
+                const u64 bal = valid_m & ballot64(xp < own_end);          // the owned matches of this pass
+                const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m), owned = __builtin_amdgcn_inverse_ballot_w64(bal);
                 // record slot = rank among the owned matches of this pass
-                const u64 bal = __ballot(owned);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                 const uint32_t slot = owned ? (done - flushed) + rank : P.stage_cap + lane;
-                stage[slot] = (u << 2) | fc;
+                const uint32_t record = (u << 2) | fc;
+                stage[slot] = record;
                 done += (uint32_t)__popcll(bal);
-                const bool is_can = (fc & 1u) != 0u, is_fwd = (fc & 2u) != 0u;
-                ccan += owned ? (fc & 1u) : 0u;
-                cfwd += owned ? (fc >> 1) : 0u;
+                const u64 can_all = ballot64((fc & 1u) != 0u), fwd_all = ballot64((fc & 2u) != 0u);
+                const bool is_can = __builtin_amdgcn_inverse_ballot_w64(can_all), is_fwd = __builtin_amdgcn_inverse_ballot_w64(fwd_all);
+                const u64 canm = can_all & bal;
+                ccan += (uint32_t)__popcll(canm);              // (scalar counts: popcounts of masks)
+                cfwd += (uint32_t)__popcll(fwd_all & bal);
+                if (EMIT && bal != 0ull) {
+                    // ---- visible records: the canonical ones, and every record where the tile lies in the terminal zone
+                    {
+                        u64 vm = canm;
+                        if (zone != TS_ZONE_NONE) vm = bal & (can_all | ballot64(u < (zone & 0xFFFFu)) | ballot64(u >= (zone >> 16)));
+                        if (vm != 0ull) {
+                            const uint32_t nv = (uint32_t)__popcll(vm);
+                            if (vfill + nv > vcap) flush_vis();
+                            const uint32_t vr = vfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
+                            if (__builtin_amdgcn_inverse_ballot_w64(vm)) rec[vr] = record;
+                            vfill += nv;
+                        }
+                    }
+                    // ---- chains.  A record more than -k behind the owned record before it is a head; all a pass keeps is the
+                    // canonical count of the chain that is open at its end (ch_cc) and, until the tile's first head, the count
+                    // ahead of it.  A pass without a canonical record and with none carried in (a third of them) changes neither.
+                    const uint32_t ncan = (uint32_t)__popcll(canm);
+                    const uint32_t t = ch_cc + ncan;
+                    if ((t | (~ch_w1 & TS_CHAIN_HEADS)) != 0u) {            // (integer logic: a uniform bool costs three scalar instructions to combine)
+                        // The owned lanes are nearly always the pass's first lanes: the lane below holds the record before, lane 0
+                        // gets the last record of the pass before.  Otherwise (lanes ahead of the tile's first base, matches a
+                        // w == s tile loses to the straddle rule) a prefix maximum finds it.
+                        uint32_t below;
+                        if (__builtin_expect((bal & (bal + 1ull)) == 0ull, 1)) {
+                            below = (uint32_t)__builtin_amdgcn_update_dpp((int)ch_last, (int)u, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps ch_last
+                            asm volatile("" : "+v"(below));        // (kept a v_mov_b32_dpp: see lane_below)
+                        } else {
+                            const uint32_t before = lane_below(wave_scan_max(owned ? u + 1u : 0u));
+                            below = before ? before - 1u : ch_last;
+                        }
+                        const u64 H = bal & ballot64(u - below > P.kdist);
+                        if (__builtin_expect(t >= 4u, 0)) {
+                            // a chain that ends in this pass may hold the four canonical records a block needs: the exact look
+                            if (H != 0ull) {
+                                const u64 ahead = ~H & (H - 1ull);                      // the lanes below the first head
+                                const uint32_t top_head = 63u - (uint32_t)__builtin_clzll(H);
+                                const u64 below_top = low_bits(top_head);
+                                // the chain carried into the pass ends at the first head
+                                const uint32_t carry = ch_cc + (uint32_t)__popcll(canm & ahead);
+                                if (!(ch_w1 & TS_CHAIN_HEADS)) ch_w1 |= carry < 0x7FFFu ? carry : 0x7FFFu;
+                                else if (carry >= 4u) ch_w1 |= TS_CHAIN_INNER;
+                                // chains that start and end inside the pass: looked at only when they hold four canonical records between them
+                                if (__popcll(canm & ~ahead & below_top) >= 4) {
+                                    const u64 above = lane < 63u ? H >> (lane + 1u) : 0ull;
+                                    const uint32_t next = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 64u;   // the next head's lane
+                                    const bool mine4 = __popcll(canm & low_bits(next) & ~low_bits(lane)) >= 4;
+                                    if (ballot64(((H >> lane) & 1ull) && lane != top_head && mine4) != 0ull) ch_w1 |= TS_CHAIN_INNER;
+                                }
+                                ch_w1 |= TS_CHAIN_HEADS;
+                                ch_cc = (uint32_t)__popcll(canm & ~below_top);
+                            } else {
+                                ch_cc = t;
+                            }
+                        } else {
+                            // Fewer than four (nearly every pass): nothing to saturate, no chain to flag.  Until the tile's first
+                            // head: the canonical count ahead of it, ch_cc + popcount(canm below H's lowest bit), and the HEADS flag,
+                            // into ch_w1.  Always: ch_cc = canonical records from H's highest bit on, or t when the pass has no head.
+                            // Written out for the scalar unit (the compiler's version of these seven lines came to forty
+                            // instructions, every combination of two uniform conditions materialised as a 64-bit mask):
+                            uint32_t tmp;
+                            u64 m;
+                            asm volatile("s_bitcmp1_b32 %[w1], 15\n\t"
+                                         "s_cbranch_scc1 .Lts_cq%=\n\t"
+                                         "s_cmp_eq_u64 %[H], 0\n\t"
+                                         "s_cbranch_scc1 .Lts_cq%=\n\t"
+                                         "s_ff1_i32_b64 %[tmp], %[H]\n\t"
+                                         "s_lshl_b64 %[m], -1, %[tmp]\n\t"
+                                         "s_andn2_b64 %[m], %[canm], %[m]\n\t"
+                                         "s_bcnt1_i32_b64 %[tmp], %[m]\n\t"
+                                         "s_add_i32 %[tmp], %[tmp], %[cc]\n\t"
+                                         "s_or_b32 %[w1], %[w1], %[tmp]\n\t"
+                                         "s_bitset1_b32 %[w1], 15\n"
+                                         ".Lts_cq%=:\n\t"
+                                         "s_flbit_i32_b64 %[tmp], %[H]\n\t"          // (-1 without a head: the shift below is then 0 and t is taken anyway)
+                                         "s_xor_b32 %[tmp], %[tmp], 63\n\t"
+                                         "s_lshl_b64 %[m], -1, %[tmp]\n\t"
+                                         "s_and_b64 %[m], %[m], %[canm]\n\t"
+                                         "s_bcnt1_i32_b64 %[tmp], %[m]\n\t"
+                                         "s_cmp_lg_u64 %[H], 0\n\t"
+                                         "s_cselect_b32 %[cc], %[tmp], %[t]"
+                                         : [cc] "+s"(ch_cc), [w1] "+s"(ch_w1), [tmp] "=&s"(tmp), [m] "=&s"(m)
+                                         : [H] "s"(H), [canm] "s"(canm), [t] "s"(t)
+                                         : "scc");
+                        }
+                    }
+                    ch_last = (uint32_t)__builtin_amdgcn_readlane((int)u, 63 - (int)__builtin_clzll(bal));
+                }
                 // {canonical, non-canonical, forward, reverse} as one 4 x 16-bit increment
                 const u64 inc = (u64)(is_can ? 1u : 0x10000u) | ((u64)(is_fwd ? 1u : 0x10000u) << 32);
                 // windows q, q-1, ... contain the match as long as it ends inside them.  Window q always does:
@@ -577,6 +738,7 @@ void ts_scan_tiles(const TsScanParams P) {
         set_prio(kPrioWindows);
         // The match fields of the tile's window records are complete (accumulated above).
         flush_stage();
+        if (EMIT && vfill != 0u) flush_vis();   // (the nucleotide rows are assembled where the visible records were staged)
         if (P.windows_on) {
             // Nucleotides.  Counted here, from the tile's code plane, not per chunk: a row (a step block when w is a
             // multiple of s — a window is then the sum of w / s of them and overlapping windows share them — else a
@@ -675,18 +837,30 @@ void ts_scan_tiles(const TsScanParams P) {
 
         // ------------------------------------------------------- tile directory
         {
-            const uint32_t tcan = wave_sum(ccan), tfwd = wave_sum(cfwd);
+            const uint32_t tcan = ccan, tfwd = cfwd;
             if (lane == 0) {
                 KernArgs Q = tail_params();
                 Q->tile_off[tile] = (u64)gw * Q->region_cap + cursor;
-                *(uint4 *)&Q->tile_stats[4ull * tile] = make_uint4(done, tcan, tfwd, (TS_EXP & 8) ? (((uint32_t)wall_clock64() & 0xFFFFFu) | (gw << 20)) : 0u);
+                *(uint4 *)&Q->tile_stats[4ull * tile] = make_uint4(done, tcan, tfwd, (TS_EXP & 8) ? (((uint32_t)wall_clock64() & 0xFFFFFu) | (gw << 20)) : vout);
+                if (EMIT) {
+                    const uint32_t z15 = ch_cc < 0x7FFFu ? ch_cc : 0x7FFFu;
+                    if (!(ch_w1 & TS_CHAIN_HEADS)) ch_w1 |= z15;         // no head: every canonical record is ahead of the first
+                    const u64 voff = (u64)gw * Q->vis_cap + vcursor;
+                    *(uint4 *)&Q->tile_chain[4ull * tile] = make_uint4(ch_first | (ch_last << 16), ch_w1 | (z15 << 16),
+                                                                        (uint32_t)voff, (uint32_t)(voff >> 32));
+                }
             }
             cursor += done;
+            vcursor += vout;
         }
         set_prio(0);
         __builtin_amdgcn_wave_barrier();          // next tile overwrites the planes
     }
-    if (lane == 0) tail_params()->wave_fill[gw] = cursor;      // records needed by this wave (may exceed region_cap)
+    if (lane == 0) {
+        KernArgs Q = tail_params();
+        Q->wave_fill[gw] = cursor;                             // records needed by this wave (may exceed region_cap)
+        if (EMIT) Q->wave_fill[total_waves + gw] = vcursor;    // visible records needed (may exceed vis_cap)
+    }
 }
 
 // Per-segment hit summary {windows, matches, canonical, forward}: the buffer ranks gather.
@@ -736,18 +910,24 @@ __global__ void ts_compact_regions(const uint32_t *regions, const uint32_t *wave
 int ts_k_lds_bytes(const TsScanParams *p) { return (int)lds_total(*p); }
 
 namespace {
-template <int WAVES_EU>
-const void *scan_variant(const TsScanParams *p) {
-    if (p->pair_byte_table && p->fc_byte_table) return (const void *)ts_scan_tiles<true, true, WAVES_EU>;
-    if (p->fc_byte_table) return (const void *)ts_scan_tiles<true, false, WAVES_EU>;
-    return (const void *)ts_scan_tiles<false, false, WAVES_EU>;
+// The 80-VGPR build (two workgroups per CU) exists for the byte tables only: the probe path of the 2-bit tables (k >= 7)
+// needs 97 registers and would spill to scratch there, so it is not instantiated and plan_geometry never asks for it.
+template <bool EMIT>
+const void *scan_variant_e(const TsScanParams *p) {
+    const bool two = p->wgs_per_cu > 1u;
+    if (p->pair_byte_table && p->fc_byte_table) return two ? (const void *)ts_scan_tiles<true, true, 6, EMIT> : (const void *)ts_scan_tiles<true, true, 4, EMIT>;
+    if (two) return nullptr;
+    if (p->fc_byte_table) return (const void *)ts_scan_tiles<true, false, 4, EMIT>;
+    return (const void *)ts_scan_tiles<false, false, 4, EMIT>;
 }
+const void *scan_variant(const TsScanParams *p) { return p->emit ? scan_variant_e<true>(p) : scan_variant_e<false>(p); }
 }  // namespace
 
 int ts_k_prepare(uint32_t lds_bytes) {
-    const void *fns[] = {(const void *)ts_scan_tiles<true, true, 4>, (const void *)ts_scan_tiles<true, false, 4>,
-                         (const void *)ts_scan_tiles<false, false, 4>, (const void *)ts_scan_tiles<true, true, 6>,
-                         (const void *)ts_scan_tiles<true, false, 6>, (const void *)ts_scan_tiles<false, false, 6>};
+    const void *fns[] = {(const void *)ts_scan_tiles<true, true, 4, false>, (const void *)ts_scan_tiles<true, false, 4, false>,
+                         (const void *)ts_scan_tiles<false, false, 4, false>, (const void *)ts_scan_tiles<true, true, 6, false>,
+                         (const void *)ts_scan_tiles<true, true, 4, true>, (const void *)ts_scan_tiles<true, false, 4, true>,
+                         (const void *)ts_scan_tiles<false, false, 4, true>, (const void *)ts_scan_tiles<true, true, 6, true>};
     // the limit is a property of the function, not of a launch: batches of different geometries share it, so it is
     // raised to the CU's whole LDS rather than set to the size one batch asked for
     const int limit = (int)(lds_bytes > 160u * 1024u ? lds_bytes : 160u * 1024u);
@@ -760,7 +940,8 @@ int ts_k_prepare(uint32_t lds_bytes) {
 
 int ts_k_launch_scan(const TsScanParams *p, uint32_t grid, uint32_t lds_bytes, void *stream) {
     const dim3 block(p->waves_per_wg * 64u);
-    const void *fn = p->wgs_per_cu > 1u ? scan_variant<6>(p) : scan_variant<4>(p);
+    const void *fn = scan_variant(p);
+    if (!fn) return (int)hipErrorInvalidConfiguration;
     void *args[] = {(void *)p};
     return (int)hipLaunchKernel(fn, dim3(grid), block, args, lds_bytes, (hipStream_t)stream);
 }

@@ -104,7 +104,9 @@ int ensure_streams(ts_ctx *c) {
         c->bind_this_thread();
         DeviceGuard g(c->device);
         for (int i = 0; i < ts_ctx::kUpSlots && rc == TS_OK; ++i) {
-            if (c->pin_up[i].ensure(32u << 20) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "cannot allocate the pinned staging ring"); break; }
+            // (+ 4096: a packed chunk of exactly 128 Mi positions that starts off a 64-byte boundary packs to a few bytes more
+            // than 32 MiB, and its DMA reads 8 bytes past the last code)
+            if (c->pin_up[i].ensure((32u << 20) + 4096u) != hipSuccess) { rc = c->fail(TS_ERR_ALLOC, "cannot allocate the pinned staging ring"); break; }
             if (hipEventCreateWithFlags(&c->pin_up_ev[i], hipEventDisableTiming) != hipSuccess) rc = c->fail(TS_ERR_HIP, "hipEventCreate failed");
         }
     });
@@ -325,6 +327,8 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
                 size_t at = 0;
                 for (const ts::PackRuns &R : wr) { if (!R.runs.empty()) std::memcpy(hr + at, R.runs.data(), R.runs.size() * sizeof(ts::InvalidRun)); at += R.runs.size(); }
                 const uint64_t pbytes = (((P + 3) >> 2) + 3) & ~3ull;
+                if (pbytes + 8 > c->pin_up[slot].bytes || pbytes + 8 > c->d_pack[slot].bytes)
+                    return c->fail(TS_ERR_STATE, "packed upload: a chunk does not fit its staging slot");
                 std::memset(dst + ((P + 3) >> 2), 0, pbytes - ((P + 3) >> 2) + 8);     // (the kernel reads one dword past the last code)
                 HIP_TRY(c, hipMemcpyAsync(c->d_pack[slot].p, dst, pbytes + 8, hipMemcpyHostToDevice, c->up_stream));
                 if (nruns) HIP_TRY(c, hipMemcpyAsync(c->d_runs[slot].p, hr, nruns * sizeof(ts::InvalidRun), hipMemcpyHostToDevice, c->up_stream));
@@ -540,6 +544,7 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
             lens.resize(gr.count); abs.resize(gr.count);
             for (size_t i = 0; i < gr.count; ++i) { lens[i] = items[gr.first + i].len; abs[i] = items[gr.first + i].abs_pos; }
             gr.b = ts_batch_create(ctx, lens.data(), abs.data(), gr.count, tips ? 1 : 0, 0);
+            if (gr.b) (void)ts_batch_set_emit(gr.b, 1);      // every download calls blocks on the device
             gr.t_plan = ms_between(t0, Clock::now());
             if (!gr.b) { set_err(ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP); break; }
             to_upload.push(&gr);
@@ -732,7 +737,17 @@ int submit_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &
                 it = ctx->sq.erase(it);
             }
             lk.unlock();
-            run_group(ctx, group);
+            // (a throw in here — std::bad_alloc on a merged multi-GB batch — must not leave the context with a leader that
+            // no longer exists: every later caller would wait for it forever)
+            try {
+                run_group(ctx, group);
+            } catch (const std::exception &e) {
+                for (SubmitReq *r : group)
+                    if (!r->done) { r->rc = TS_ERR_ALLOC; r->error = std::string("batched call failed: ") + e.what(); }
+            } catch (...) {
+                for (SubmitReq *r : group)
+                    if (!r->done) { r->rc = TS_ERR_ALLOC; r->error = "batched call failed"; }
+            }
             lk.lock();
             for (SubmitReq *r : group) r->done = true;
             ctx->sq_cv.notify_all();

@@ -198,6 +198,7 @@ int ts_batch_restrict_shard(ts_batch *b, uint32_t n_parts, uint32_t part, uint32
     const ShardRange r = shard_range(b, n_parts, part);
     int rc = ts_batch_restrict(b, r.ext_lo, r.ext_hi);
     if (rc != TS_OK) return rc;
+    (void)ts_batch_set_emit(b, 1);                       // the pack takes the visible records and the chain summaries from the scan
     b->shard_parts = n_parts; b->shard_part = part; b->shard_scale = scale ? scale : 1;
     b->own_lo = r.own_lo; b->own_hi = r.own_hi;
     b->shard_r = r;
@@ -264,7 +265,18 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
         HIP_TRY(c, hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
     }
     unsigned char *msg = (unsigned char *)d_msg;
-    HIP_TRY(c, hipMemsetAsync(msg, 0, L.off_windows, st));               // header + per-segment entries
+    // everything the pack's kernels accumulate into, zeroed by ONE kernel: the message's header + per-segment entries, the
+    // per-segment sums, the counter of the screening's tile list and the counter of the visible-record copy's list
+    const uint32_t ns_z = std::max<uint32_t>((uint32_t)b->shard_r.n_segs, 1);
+    const bool from_scan_z = b->chain_valid() && !b->tips;
+    if (from_scan_z && b->d_scan_tmp.bytes < ((size_t)b->range_tiles() + 2) * 4) {
+        c->pool.give(std::move(b->d_scan_tmp));
+        HIP_TRY(c, c->pool.take(((size_t)b->range_tiles() + 2) * 4, b->d_scan_tmp));
+    }
+    if (ts_k_launch_zero(msg, L.off_windows & ~3ull, (unsigned long long *)b->d_shard_bounds.p + 2ull * ns_z, (unsigned long long)b->shard_r.n_segs * 40,
+                         from_scan_z ? b->d_scan_tmp.p : nullptr, 4,
+                         (from_scan_z && nown) ? ts_k_shard_big_counter(b->d_shard_tmp.p, nown) : nullptr, 4, st) != 0)
+        return c->fail(TS_ERR_HIP, "zeroing kernel launch failed");
     const ts_params &P = c->params;
     TsBlockCallParams Q{};
     Q.tiles = (const TsTile *)b->d_tiles.p;
@@ -299,6 +311,17 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     K.msg = msg;
     K.off_segs = L.off_segs; K.off_windows = L.off_windows; K.off_tilevis = L.off_tilevis; K.off_visible = L.off_visible;
     K.off_blocks = L.off_blocks;
+    // with the scan's own visible records and chain summaries (kp.emit) neither the counting pass nor the interstitial pass
+    // reads the match stream
+    const bool from_scan = b->chain_valid() && !b->tips;
+    if (from_scan) {
+        K.chain = (const uint32_t *)b->d_chain.p;
+        K.vis_src = b->d_vis.p; K.vis_src_wide = b->kp.vis_wide; K.vis_cap = b->vis_cap;
+        if (b->d_scan_tmp.bytes < ((size_t)b->range_tiles() + 2) * 4) {           // the screening's list of tiles
+            c->pool.give(std::move(b->d_scan_tmp));
+            HIP_TRY(c, c->pool.take(((size_t)b->range_tiles() + 2) * 4, b->d_scan_tmp));
+        }
+    }
     TsShardHeader H{};
     H.magic = TS_SHARD_MAGIC; H.version = TS_SHARD_VERSION;
     H.part = b->shard_part; H.n_parts = b->shard_parts;
@@ -306,6 +329,7 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     H.seg_begin = r.seg_begin; H.n_segs = ns;
     H.visible_bytes = L.visible_bytes; H.visible_capacity = L.visible_capacity; H.block_capacity = L.block_capacity;
     H.window_bytes = L.window_bytes; H.n_windows = L.n_windows; H.msg_bytes = L.bytes;
+    H.reserved[1] = b->shard_scale;                       // the capacity scale the sections were laid out with (any value >= 1)
     // visible records per owned tile and their places; then the terminal walks and the interstitial pass, which also
     // writes the visible records (it reads the whole stream anyway); then the window records and the header
     // The terminal walks (one latency-bound wave per segment end, ~60 us whatever the shard's size) run on a stream of their
@@ -315,17 +339,23 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     HIP_TRY(c, hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
     if (ts_k_launch_terminal(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
                              (unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs),
-                             (unsigned long long *)b->d_shard_bounds.p + 2ull * std::max<uint32_t>(ns, 1), b->side_stream) != 0)
+                             (unsigned long long *)b->d_shard_bounds.p + 2ull * std::max<uint32_t>(ns, 1), 1, b->side_stream) != 0)
         return c->fail(TS_ERR_HIP, "terminal block kernel launch failed");
     HIP_TRY(c, hipEventRecord(b->ev_join, b->side_stream));
     TsVisibleOut vis{};
-    if (ts_k_launch_shard_count(&K, &H, b->d_shard_tmp.p, b->tips ? 0 : 1, &vis, stream) != 0)
+    if (from_scan) {
+        if (ts_k_launch_shard_visible(&K, &H, b->d_shard_tmp.p, 1, stream) != 0)
+            return c->fail(TS_ERR_HIP, "visible-record kernel launch failed");
+    } else if (ts_k_launch_shard_count(&K, &H, b->d_shard_tmp.p, b->tips ? 0 : 1, &vis, stream) != 0)
         return c->fail(TS_ERR_HIP, "shard count kernel launch failed");
     if (ts_k_launch_shard_windows(&K, &H, stream) != 0)
         return c->fail(TS_ERR_HIP, "window packing kernel launch failed");
+    if (ts_k_launch_shard_overflow(&K, stream) != 0)
+        return c->fail(TS_ERR_HIP, "overflow check kernel launch failed");
     HIP_TRY(c, hipStreamWaitEvent(st, b->ev_join, 0));
     if (!b->tips && ts_k_launch_interstitial(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
-                                             (const unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs), &vis, stream) != 0)
+                                             (const unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs), &vis,
+                                             from_scan ? K.chain : nullptr, from_scan ? (uint32_t *)b->d_scan_tmp.p : nullptr, 1, stream) != 0)
         return c->fail(TS_ERR_HIP, "interstitial block kernel launch failed");
     if (ts_k_launch_shard_pack(&K, &H, b->d_shard_tmp.p, b->tips ? 0 : 1, stream) != 0)
         return c->fail(TS_ERR_HIP, "shard pack kernel launch failed");
@@ -391,18 +421,25 @@ extern "C" int ts_shards_finalize(const ts_batch *b, const void *const *msgs, co
         if (H.magic != TS_SHARD_MAGIC || H.version != TS_SHARD_VERSION || H.n_parts != n_parts || H.part != p)
             return c->fail(TS_ERR_INVALID_ARG, "ts_shards_finalize: message " + std::to_string(p) + " is not part " + std::to_string(p) + " of " + std::to_string(n_parts));
         pv.r = shard_range(b, n_parts, p);
-        uint32_t scale = 1;                                   // the capacities tell the scale the sender packed with
+        // the scale the sender laid its sections out with travels in the header (reserved[1]); what it implies is checked below
+        const uint32_t scale = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(H.reserved[1], 1), 1u << 24);
         pv.L = shard_layout(b, pv.r, scale);
-        while ((pv.L.visible_capacity != H.visible_capacity || pv.L.block_capacity != H.block_capacity) && scale < (1u << 20)) {
-            scale *= 2;
-            pv.L = shard_layout(b, pv.r, scale);
-        }
+        if (pv.L.visible_capacity != H.visible_capacity || pv.L.block_capacity != H.block_capacity)
+            return c->fail(TS_ERR_INVALID_ARG, "ts_shards_finalize: message " + std::to_string(p) + " was packed with capacities that do not match its scale");
         if (H.own_begin != pv.r.own_lo || H.own_end != pv.r.own_hi || H.ext_begin != pv.r.ext_lo || H.ext_end != pv.r.ext_hi ||
             H.n_segs != pv.r.n_segs || (H.n_segs && H.seg_begin != pv.r.seg_begin) || H.msg_bytes != pv.L.bytes || msg_bytes[p] < pv.L.bytes ||
             H.window_bytes != pv.L.window_bytes || H.visible_bytes != pv.L.visible_bytes || H.n_windows != pv.L.n_windows)
             return c->fail(TS_ERR_INVALID_ARG, "ts_shards_finalize: message " + std::to_string(p) + " was packed for a different plan or split");
         pv.segs = (const TsShardSeg *)(pv.msg + pv.L.off_segs);
         flags_any |= H.flags;
+        // counts a message reports beyond what its sections hold are only legitimate together with the overflow flag that
+        // asks for a larger message; anything else (a truncated or corrupt message, a header kernel that did not run) is refused
+        // here, before any count is used as a length
+        const bool vis_over = H.n_visible > H.visible_capacity, blk_over = H.n_blocks > H.block_capacity;
+        if ((vis_over && !(H.flags & TS_SHARD_F_VISIBLE_OVERFLOW)) || (blk_over && !(H.flags & TS_SHARD_F_BLOCK_OVERFLOW)) ||
+            (!blk_over && pv.L.off_blocks + (uint64_t)H.n_blocks * sizeof(TsDevBlock) > msg_bytes[p]) ||
+            (!vis_over && pv.L.off_visible + H.n_visible * H.visible_bytes > msg_bytes[p]))
+            return c->fail(TS_ERR_INVALID_ARG, "ts_shards_finalize: message " + std::to_string(p) + " reports more records or blocks than it holds");
     }
     if (flags_any & TS_SHARD_F_SCAN_OVERFLOW) { c->fail(TS_OK, "a shard's scan overflowed its record regions: ts_batch_sync, then pack again"); return TS_SHARD_RETRY_SYNC; }
     if (flags_any & (TS_SHARD_F_VISIBLE_OVERFLOW | TS_SHARD_F_BLOCK_OVERFLOW)) { c->fail(TS_OK, "a shard's message overflowed: pack again with a larger scale"); return TS_SHARD_RETRY_GROW; }
@@ -573,6 +610,11 @@ extern "C" int ts_shards_finalize(const ts_batch *b, const void *const *msgs, co
     std::vector<TsDevBlock> blocks;
     for (const PartView &pv : parts) {
         const TsDevBlock *src = (const TsDevBlock *)(pv.msg + pv.L.off_blocks);
+        for (uint32_t q = 0; q < pv.H->n_blocks; ++q)           // a block names a segment of its part's range, or the message is corrupt
+            if (src[q].seg < pv.r.seg_begin || src[q].seg >= pv.r.seg_begin + pv.r.n_segs) {
+                ts_free_segments(out, ns);
+                return c->fail(TS_ERR_INVALID_ARG, "ts_shards_finalize: a block names a segment outside its part's range");
+            }
         blocks.insert(blocks.end(), src, src + pv.H->n_blocks);
     }
     std::sort(blocks.begin(), blocks.end(), [](const TsDevBlock &x, const TsDevBlock &y) {

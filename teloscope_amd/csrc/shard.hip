@@ -18,6 +18,13 @@
 
 #include "ts_internal.h"
 
+// These kernels run beside the persistent scan kernel of the next batch, whose waves raise their priority for the phases that
+// are chains of latency (s_setprio 2 / 3, kernels.hip): at the default priority a wave of a small kernel that shares a SIMD with
+// them is served only when none of them is ready — a visible-record copy of 60 us took the whole 0.8 ms of the scan beside it, and
+// a pack, a chain of a dozen such kernels, about two scans.  At the top priority they are served first, and being a few
+// thousand instructions each they cost the scan nothing measurable.
+#define TS_SIDE_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
+
 namespace {
 
 typedef unsigned long long u64;
@@ -47,6 +54,7 @@ __device__ __forceinline__ uint32_t seg_of_tile(const TsShardPackParams &P, uint
 // whole stream anyway.)
 __global__ __launch_bounds__(256)
 void ts_shard_visible_count(const TsShardPackParams P, uint32_t *vis_stats) {
+    TS_SIDE_KERNEL_PRIO();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t nown = P.own1 - P.own0;
     const uint32_t lane = threadIdx.x & 63u;
@@ -88,10 +96,68 @@ void ts_shard_visible_count(const TsShardPackParams P, uint32_t *vis_stats) {
     }
 }
 
+// The visible records of the owned tiles as the scan left them (per-wave regions, TsTileChain words 2-3 say where) into the
+// message's section in tile order, and the u16 count per tile.  A thread per tile — its directory entries are read
+// coalesced, and a tile outside the terminal zones holds a dozen canonical records, which the thread copies itself, four
+// loads in flight.  The few tiles with more (a telomere: every k-th base; a terminal zone: every match) lie next to each
+// other — copied where they are found they were one wave's serial loop, 75 us whatever the batch size — and go onto a list
+// {tile, source, destination, count} that ts_shard_copy_visible_big spreads over whole workgroups.
+constexpr uint32_t kVisOwn = 32;                              // records a thread copies itself
+struct BigCopy { u64 src, dst; uint32_t n, pad; };            // 24 bytes
+
+__device__ __forceinline__ uint32_t vis_get(const TsShardPackParams &P, u64 at) {
+    return P.vis_src_wide ? ((const uint32_t *)P.vis_src)[at] : ((const uint16_t *)P.vis_src)[at];
+}
+__device__ __forceinline__ void vis_put(const TsShardPackParams &P, uint32_t dst_bytes, u64 at, uint32_t r) {
+    if (dst_bytes == 2u) ((uint16_t *)(P.msg + P.off_visible))[at] = (uint16_t)r;
+    else ((uint32_t *)(P.msg + P.off_visible))[at] = r;
+}
+
+__global__ __launch_bounds__(256)
+void ts_shard_copy_visible(const TsShardPackParams P, const u64 *vis_off, u64 capacity, uint32_t dst_bytes, BigCopy *big, uint32_t *n_big) {
+    TS_SIDE_KERNEL_PRIO();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t nown = P.own1 - P.own0;
+    uint32_t n = 0;
+    u64 src0 = 0, dst0 = 0;
+    if (i < nown) {
+        const uint32_t t = P.own0 + i;
+        n = P.tile_stats[4ull * t + 3u];
+        ((uint16_t *)(P.msg + P.off_tilevis))[i] = (uint16_t)n;
+        const uint2 where = *(const uint2 *)&P.chain[4ull * t + 2u];
+        src0 = ((u64)where.y << 32) | where.x;
+        dst0 = vis_off[i];
+    }
+    if (vis_off[nown] > capacity) return;                     // does not fit: nothing is written, the header reports it
+    if (n <= kVisOwn) {
+        uint32_t j = 0;
+        for (; j + 4u <= n; j += 4u) {
+            const uint32_t a = vis_get(P, src0 + j), b = vis_get(P, src0 + j + 1u), c = vis_get(P, src0 + j + 2u), d = vis_get(P, src0 + j + 3u);
+            vis_put(P, dst_bytes, dst0 + j, a); vis_put(P, dst_bytes, dst0 + j + 1u, b);
+            vis_put(P, dst_bytes, dst0 + j + 2u, c); vis_put(P, dst_bytes, dst0 + j + 3u, d);
+        }
+        for (; j < n; ++j) vis_put(P, dst_bytes, dst0 + j, vis_get(P, src0 + j));
+    } else {
+        const uint32_t slot = atomicAdd(n_big, 1u);           // (the list holds an entry per owned tile: it cannot overflow)
+        big[slot] = BigCopy{src0, dst0, n, 0u};
+    }
+}
+
+__global__ __launch_bounds__(256)
+void ts_shard_copy_visible_big(const TsShardPackParams P, uint32_t dst_bytes, const BigCopy *big, const uint32_t *n_big) {
+    TS_SIDE_KERNEL_PRIO();
+    const uint32_t n = *n_big;
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const BigCopy B = big[e];
+        for (uint32_t j = threadIdx.x; j < B.n; j += 256u) vis_put(P, dst_bytes, B.dst + j, vis_get(P, B.src + j));
+    }
+}
+
 // Window records of the owned windows, bit-packed: fields [A C G T] (when nucleotide counts are on), canonical,
 // non-canonical and forward match counts, field_bits each, least significant first, in window_bytes bytes.
 __global__ __launch_bounds__(256)
 void ts_shard_pack_windows(const TsShardPackParams P, uint32_t window_bytes) {
+    TS_SIDE_KERNEL_PRIO();
     const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
     const u64 n = P.own_win1 - P.own_win0;
     if (i >= n) return;
@@ -112,16 +178,32 @@ void ts_shard_pack_windows(const TsShardPackParams P, uint32_t window_bytes) {
         dst[b] = (unsigned char)(b < 8u ? lo >> (8u * b) : hi >> (8u * (b - 8u)));
 }
 
+// A scan that overflowed a wave's record region (or, when it emits, its visible-record region) promises records it never
+// stored: TS_SHARD_F_SCAN_OVERFLOW into the (zeroed) header's flags.  A thread per wave.
+__global__ __launch_bounds__(256)
+void ts_overflow_flag(const TsShardPackParams P) {
+    TS_SIDE_KERNEL_PRIO();
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    bool o = false;
+    if (w < P.nwaves) {
+        o = P.wave_fill[w] > P.region_cap;
+        if (P.chain) o |= P.wave_fill[P.nwaves + w] > P.vis_cap;
+    }
+    if (__ballot(o) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(&((TsShardHeader *)P.msg)->flags, TS_SHARD_F_SCAN_OVERFLOW);
+}
+
 // The header: what the host knows arrives by value, what the device found out is filled in here (n_blocks was
 // counted in place by the block-calling kernels).
 __global__ __launch_bounds__(64)
 void ts_shard_header(const TsShardPackParams P, TsShardHeader H, const u64 *vis_off) {
-    bool o = false;
-    for (uint32_t w = threadIdx.x; w < P.nwaves; w += 64u) o |= P.wave_fill[w] > P.region_cap;
+    TS_SIDE_KERNEL_PRIO();
+    // (whether the scan overflowed a wave's region: checked over the waves by ts_overflow_flag, launched with the terminal walks,
+    // which leaves TS_SHARD_F_SCAN_OVERFLOW in the zeroed header's flags — 5120 waves are an eighty-step loop for one wave here)
+    const bool o = (((const TsShardHeader *)P.msg)->flags & TS_SHARD_F_SCAN_OVERFLOW) != 0u;
     const TsShardSeg *segs = (const TsShardSeg *)(P.msg + P.off_segs);
     bool ctx = false;
     for (uint32_t s = threadIdx.x; s < P.n_segs; s += 64u) ctx |= (segs[s].flags & TS_SEG_F_CONTEXT) != 0u;
-    const bool any_o = __ballot(o) != 0ull, any_ctx = __ballot(ctx) != 0ull;       // (one wavefront, no LDS: see exchange.hip)
+    const bool any_o = o, any_ctx = __ballot(ctx) != 0ull;       // (one wavefront, no LDS: see exchange.hip)
     if (threadIdx.x != 0) return;
     TsShardHeader *dst = (TsShardHeader *)P.msg;
     uint32_t flags = (any_o ? TS_SHARD_F_SCAN_OVERFLOW : 0u) | (any_ctx ? TS_SHARD_F_CONTEXT : 0u);
@@ -145,7 +227,9 @@ static unsigned long long shard_tmp_off(uint32_t own_tiles, int which) {
     const unsigned long long b = a + ((unsigned long long)own_tiles + 2ull) * 8ull;
     return which == 0 ? 0ull : which == 1 ? a : ((b + 15ull) & ~15ull);
 }
-unsigned long long ts_k_shard_tmp_bytes(uint32_t own_tiles) { return shard_tmp_off(own_tiles, 2) + ts_k_scan_tmp_bytes(own_tiles) + 16ull; }
+// ... [the list of tiles whose visible records a whole workgroup copies: a counter, then 24 bytes per owned tile]
+static unsigned long long shard_big_off(uint32_t own_tiles) { return (shard_tmp_off(own_tiles, 2) + ts_k_scan_tmp_bytes(own_tiles) + 31ull) & ~15ull; }
+unsigned long long ts_k_shard_tmp_bytes(uint32_t own_tiles) { return shard_big_off(own_tiles) + 16ull + 24ull * ((unsigned long long)own_tiles + 1ull); }
 
 // Phase 1 (before block calling): visible records per owned tile and where each tile's go.  Fills `vis` for the
 // interstitial pass (off == nullptr when the shard has no owned tile or no visible records: a tips-only batch).
@@ -166,6 +250,36 @@ int ts_k_launch_shard_count(const TsShardPackParams *P, const TsShardHeader *H, 
     vis->own0 = P->own0; vis->own1 = P->own1;
     vis->rec_bytes = H->visible_bytes;
     vis->terminal_limit = P->terminal_limit;
+    return (int)hipGetLastError();
+}
+
+void *ts_k_shard_big_counter(void *tmp, uint32_t own_tiles) { return (char *)tmp + shard_big_off(own_tiles); }
+
+int ts_k_launch_shard_visible(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int prezeroed, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t nown = P->own1 - P->own0;
+    if (!nown || !P->chain) return 0;
+    u64 *vis_off = (u64 *)((char *)tmp + shard_tmp_off(nown, 1));
+    void *scan_tmp = (char *)tmp + shard_tmp_off(nown, 2);
+    // per-tile counts: word 3 of the owned tiles' tile_stats rows (the prefix sum reads every fourth dword)
+    int e = ts_k_launch_tile_offsets(P->tile_stats + 4ull * P->own0 + 3u, nown, vis_off, scan_tmp, stream);
+    if (e) return e;
+    uint32_t *n_big = (uint32_t *)((char *)tmp + shard_big_off(nown));
+    BigCopy *big = (BigCopy *)((char *)tmp + shard_big_off(nown) + 16);
+    if (!prezeroed) {
+        hipError_t he = hipMemsetAsync(n_big, 0, 4, st);
+        if (he != hipSuccess) return (int)he;
+    }
+    hipLaunchKernelGGL(ts_shard_copy_visible, dim3((nown + 255u) / 256u), dim3(256), 0, st, *P, (const u64 *)vis_off,
+                       (u64)H->visible_capacity, H->visible_bytes, big, n_big);
+    hipLaunchKernelGGL(ts_shard_copy_visible_big, dim3(256), dim3(256), 0, st, *P, H->visible_bytes, (const BigCopy *)big, (const uint32_t *)n_big);
+    return (int)hipGetLastError();
+}
+
+// After the header was zeroed, any time before ts_k_launch_shard_pack: the scan-overflow flag.
+int ts_k_launch_shard_overflow(const TsShardPackParams *P, void *stream) {
+    if (P->nwaves)
+        hipLaunchKernelGGL(ts_overflow_flag, dim3((P->nwaves + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *P);
     return (int)hipGetLastError();
 }
 

@@ -20,6 +20,7 @@
 #define TS_BLK_COUNTERS 10             // 4 NB dwords of window nucleotide counts, then per step block: match head[3] rest[3]
 #define TS_TICKET_STRIDE 64            // dwords between two ticket counters (each in its own 256 bytes)
 #define TS_MAX_TICKET_GROUPS 64
+#define TS_VSTAGE_BYTES 256            // least size of a wave's stage of visible records (the nucleotide rows' LDS during phase 1)
 #define TS_IN_PAD       4096           // bytes of zero padding after the last segment in the input buffer
 
 struct TsTile {                 // 32 bytes
@@ -38,8 +39,8 @@ struct TsScanParams {
     uint32_t       *windows_out;    // 8 x u32 per window
     uint32_t       *matches_out;    // packed records, one region of region_cap records per wave
     unsigned long long *tile_off;   // tile directory: first record of each tile (index into matches_out)
-    uint32_t       *tile_stats;     // tile directory: {matches, canonical, forward, 0} per tile
-    uint32_t       *wave_fill;      // per wave: records it needed (> region_cap means overflow)
+    uint32_t       *tile_stats;     // tile directory: {matches, canonical, forward, visible (with emit, else 0)} per tile
+    uint32_t       *wave_fill;      // per wave: records it needed (> region_cap means overflow); with emit, behind them per wave: visible records it needed (> vis_cap)
     uint32_t       *tile_tickets;   // 2 x ticket_groups ticket counters, TS_TICKET_STRIDE dwords apart; set [ticket_slot] is zero at launch
     uint32_t        region_cap;     // records per wave region
     uint32_t        ntiles;
@@ -65,7 +66,30 @@ struct TsScanParams {
     uint32_t        ticket_slot;    // which of the two counter sets this launch counts on (it zeroes the other)
     uint32_t        ticket_groups;  // groups of workgroups with a counter each (<= 64; group g owns the tiles t = g mod groups)
     uint32_t        wgs_per_cu;     // host side: workgroups that share a CU (1, or 2 of 10 waves: selects the 80-VGPR build)
+    // ---- what the scan hands to block calling and to a shard's message (window scans only; emit == 0: none of it)
+    uint32_t        emit;           // 1: visible records + per-tile chain summaries are produced
+    uint32_t        kdist;          // -k (maxMatchDistance): matches farther apart than this start a new chain
+    uint32_t        vis_wide;       // 0: visible records are u16 (tile positions < 2^14), 1: u32
+    uint32_t        vis_cap;        // visible records per wave region
+    void           *vis_out;        // visible records, one region of vis_cap records per wave (u16 or u32 each)
+    const uint32_t *tile_zone;      // per tile: {zlo, zhi} 16 bits each: a non-canonical record at tile position u is visible
+                                    // (lies in its segment's terminal zone) iff u < zlo || u >= zhi
+    uint32_t       *tile_chain;     // per tile: TsTileChain (4 dwords)
 };
+
+// What ts_scan_tiles leaves per tile beside {matches, canonical, forward, visible} in tile_stats: the summary the
+// interstitial screening needs instead of re-reading the tile's records, and where the tile's visible records are.
+// A chain (getInterstitialBlocks, src/teloscope.cpp:235-253) links consecutive matches of any kind at most -k apart; an
+// "internal head" is a record of the tile more than -k behind its predecessor IN the tile.
+//   word 0   position of the tile's first record | position of its last record << 16      (tile-relative, < 2^16)
+//   word 1   bits 0-14  canonical records ahead of the first internal head (all of them when there is none), saturating
+//            bit  15    the tile holds an internal head
+//            bits 16-30 canonical records from the last internal head on (all of them when there is none), saturating
+//            bit  31    a chain between two internal heads of the tile holds four or more canonical records
+//   word 2,3 index (u64) of the tile's first visible record in vis_out
+#define TS_CHAIN_HEADS 0x8000u
+#define TS_CHAIN_INNER 0x80000000u
+#define TS_ZONE_NONE   0xFFFF0000u      // tile_zone word of a tile no position of which is terminal
 
 // parameters of getTerminalBlocks for the device-side predicate (kernels.hip: ts_terminal_predicate)
 struct TsPredParams {
@@ -142,7 +166,7 @@ struct TsShardHeader {                  // 128 bytes
     uint32_t window_bytes;                      // bytes per packed window record
     unsigned long long n_windows;               // owned window records
     unsigned long long msg_bytes;
-    unsigned long long reserved[2];
+    unsigned long long reserved[2];             // [0]: scratch of the pack (candidate counter), 0 on the wire; [1]: the capacity scale
 };
 static_assert(sizeof(TsShardHeader) == 128, "TsShardHeader is 128 bytes on the wire");
 
@@ -195,6 +219,11 @@ struct TsShardPackParams {
     uint32_t terminal_limit, k, nuc_on, field_bits;
     unsigned char *msg;
     unsigned long long off_segs, off_windows, off_tilevis, off_visible, off_blocks;   // byte offsets of the sections
+    // what the scan left for the message (kp.emit; chain == nullptr: the visible records come out of the match stream)
+    const uint32_t *chain;              // TsTileChain per tile (words 2, 3: where the tile's visible records are in vis_src)
+    const void *vis_src;                // the scan's visible records, per-wave regions
+    uint32_t vis_src_wide;              // 1: u32 each, 0: u16
+    uint32_t vis_cap;                   // records per wave region (wave_fill[nwaves + w] > vis_cap: that wave's region overflowed)
 };
 
 // ---- general kernels (generic.hip) ----
@@ -262,16 +291,28 @@ int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_o
 // what a shard reports per segment
 // vis (nullable): where the interstitial pass leaves the visible records of the owned tiles (a shard's message)
 // sums: scratch of 5 x u64 per segment (per-segment counts the terminal walks are gated on and a shard reports)
+// chain + work (both or neither): the scan's per-tile chain summaries (TsTileChain) and scratch of (ntiles + 1) dwords — the
+// interstitial search then screens the tiles by their summaries and walks only the listed ones (ignored when vis asks for
+// the visible records out of the match stream)
 int  ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
                             uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its,
-                            const TsVisibleOut *vis, unsigned long long *sums, void *stream);
+                            const TsVisibleOut *vis, unsigned long long *sums, const uint32_t *chain, uint32_t *work, void *stream);
+// prezeroed != 0: the caller has zeroed what the launch accumulates into (sums: 40 bytes per segment; work[0]) — ts_k_launch_zero
 int  ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
-                          unsigned long long *bounds, TsShardSeg *seg_out, unsigned long long *sums, void *stream);
+                          unsigned long long *bounds, TsShardSeg *seg_out, unsigned long long *sums, int prezeroed, void *stream);
+int  ts_k_launch_zero(void *p0, unsigned long long n0, void *p1, unsigned long long n1, void *p2, unsigned long long n2,
+                      void *p3, unsigned long long n3, void *stream);
 int  ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
-                              const unsigned long long *bounds, TsShardSeg *seg_out, const TsVisibleOut *vis, void *stream);
+                              const unsigned long long *bounds, TsShardSeg *seg_out, const TsVisibleOut *vis,
+                              const uint32_t *chain, uint32_t *work, int prezeroed, void *stream);
 // shard.hip: packed window records, visible records + per-tile counts, and the header of a shard's message
 int  ts_k_launch_shard_count(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, TsVisibleOut *vis, void *stream);
+// the same from the scan's own visible records (P->chain != nullptr): per-tile counts out of tile_stats, prefix sum, then the
+// records copied into the message in tile order — nothing is left for the interstitial pass to write
+int  ts_k_launch_shard_visible(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int prezeroed, void *stream);
+void *ts_k_shard_big_counter(void *tmp, uint32_t own_tiles);      // the 4 bytes ts_k_launch_shard_visible wants zero
 int  ts_k_launch_shard_windows(const TsShardPackParams *P, const TsShardHeader *H, void *stream);
+int  ts_k_launch_shard_overflow(const TsShardPackParams *P, void *stream);     // after the header's memset, before ts_k_launch_shard_pack
 int  ts_k_launch_shard_pack(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, void *stream);
 unsigned long long ts_k_shard_tmp_bytes(uint32_t own_tiles);
 // exchange.hip: tile directory of a dense tile-ordered stream, and the export of a scan's records into one

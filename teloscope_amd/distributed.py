@@ -495,7 +495,9 @@ class PackedShard:
         self.scale = scale
         self.info = shard_info(self.plan, self.part, scale)
         for j, b in enumerate(self.batches):
-            self.L.ts_batch_set_shard_scale(b, scale)
+            rc = self.L.ts_batch_set_shard_scale(b, scale)
+            if rc != K.TS_OK:                                   # a silent failure would leave layout and buffer size disagreeing between ranks
+                raise K.TeloscanError(rc, "ts_batch_set_shard_scale(%d) failed" % scale)
             self.msgs[j] = torch.zeros(int(self.info.msg_bytes), dtype=torch.uint8, device=self.device)
 
     def kernel_ms(self, slot=0):
@@ -529,6 +531,7 @@ class ShardExchange:
         self.plan, self.rank, self.device, self.dst, self.group, self.slots = plan, rank, device, dst, group, slots
         self.world = plan.world
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self._keep = {}
         self.set_scale(scale)
 
     def set_scale(self, scale):
@@ -554,7 +557,7 @@ class ShardExchange:
         ops = []
         if self.rank != self.dst:
             t = msg if self.backend == "nccl" else msg.cpu()
-            self._keep = t
+            self._keep[slot] = t                                # a staged host copy lives until its slot is posted again (several slots are in flight)
             ops.append(dist.P2POp(dist.isend, t, self.dst, group=self.group))
         else:
             for p in range(self.world):

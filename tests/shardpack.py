@@ -195,7 +195,7 @@ def pack_shard(plan, opts, part, oracle_results, scale=1):
     hdr = np.zeros(1, dtype=HEADER_DT)
     hdr[0] = (MAGIC, VERSION, part, plan.world, int(info.own_begin), int(info.own_end), int(info.ext_begin), int(info.ext_end),
               int(info.seg_begin) if nown else 0, nseg, flags_any, len(visible), len(blocks), vb, int(info.visible_capacity),
-              int(info.block_capacity), int(info.window_bytes), nwin, int(info.msg_bytes), (0, 0))
+              int(info.block_capacity), int(info.window_bytes), nwin, int(info.msg_bytes), (0, scale))
     msg[:128] = hdr.view(np.uint8)
     return msg
 

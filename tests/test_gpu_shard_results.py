@@ -27,8 +27,10 @@ def _teloscope(cli, device=0):
     return opts, ta.Teloscope(user_input(opts, device=device))
 
 
-def _pack_all_parts(plan, buf, dev, scale=1):
-    """Every part scanned and packed on its own restricted batch, as a rank would; returns the host messages."""
+def _pack_all_parts(plan, buf, dev, scale=1, emit=True):
+    """Every part scanned and packed on its own restricted batch, as a rank would; returns the host messages.
+    emit=False: the scan leaves no visible records / chain summaries (ts_batch_set_emit off) — the pack then takes both out
+    of the match stream, as it does for results adopted from elsewhere."""
     import torch
     from teloscope_amd import _capi as K
     from teloscope_amd.distributed import PackedShard
@@ -36,6 +38,8 @@ def _pack_all_parts(plan, buf, dev, scale=1):
     msgs, stats = [], []
     for p in range(plan.world):
         ps = PackedShard(plan, p, dev, slots=1, scale=scale)
+        if not emit:
+            assert K.lib().ts_batch_set_emit(ps.batches[0], 0) == 0
         local = buf[ps.info.input_begin:max(ps.info.input_end, ps.info.input_begin + 64)].clone()   # a rank holds only the bytes its range reads
         for _ in range(6):
             ps.scan_pack(local.data_ptr(), sptr, 0)
@@ -134,6 +138,44 @@ def test_kernel_messages_equal_the_messages_packed_from_oracle_results():
                 key = ("seg", "kind", "seq", "start")            # (the kernels append blocks in completion order)
                 assert np.array_equal(np.sort(bg, order=key), np.sort(bw, order=key)), (cli, world, p)
             plan.close()
+
+
+@pytest.mark.parametrize("cli", [HEADLINE + " -t 3000", "-r -g -e -m -i", "-r -i -w 700 -s 700 -t 1000 -k 120"])
+def test_messages_do_not_depend_on_whether_the_scan_emits(cli):
+    """ts_batch_set_emit: with it the pack copies the visible records the scan left and the interstitial search walks only
+    the tiles the scan's chain summaries cannot rule out; without it both read the whole match stream.  The messages must be
+    the same bytes either way (blocks: the same set — the kernels append them in completion order)."""
+    import torch
+    from tests import shardpack
+    from teloscope_amd.distributed import ShardPlan, shard_info
+    dev = torch.device("cuda", 0)
+    opts, tel = _teloscope(cli)
+    rng = np.random.default_rng(41)
+    lens = [420_000, 12, 0, 90_001, 1_300_000, 33_000]
+    seqs = [seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, n_its=6, iupac=2) if n else b"" for n in lens]
+    # a telomere-like array inside the big contig, away from its ends: chains of canonical matches across many tiles
+    big = bytearray(seqs[4])
+    big[600_000:640_000] = (opts.canonical_fwd.encode() * 7000)[:40_000]
+    seqs[4] = bytes(big)
+    for world in (1, 3):
+        plan = ShardPlan(tel, lens, world=world)
+        buf = _fill(plan, seqs, dev)
+        with_emit, st1 = _pack_all_parts(plan, buf, dev, emit=True)
+        without, st0 = _pack_all_parts(plan, buf, dev, emit=False)
+        for p in range(world):
+            a, b = with_emit[p], without[p]
+            ha, hb = shardpack.read_header(a), shardpack.read_header(b)
+            assert ha == hb, (cli, world, p, ha, hb)
+            nb = int(ha["n_blocks"])
+            nseg, nown, nwin = int(ha["n_segs"]), int(ha["own_end"] - ha["own_begin"]), int(ha["n_windows"])
+            off = shardpack.sections(shard_info(plan, p), nseg, nown, nwin)
+            assert np.array_equal(a[128:off["blocks"]], b[128:off["blocks"]]), (cli, world, p)
+            key = ("seg", "kind", "seq", "start")
+            ba = np.frombuffer(a[off["blocks"]:off["blocks"] + nb * 64].tobytes(), dtype=shardpack.DEVBLOCK_DT)
+            bb = np.frombuffer(b[off["blocks"]:off["blocks"] + nb * 64].tobytes(), dtype=shardpack.DEVBLOCK_DT)
+            assert np.array_equal(np.sort(ba, order=key), np.sort(bb, order=key)), (cli, world, p)
+        assert sum(int(x.n_blocks) for x in st1) > 0
+        plan.close()
 
 
 def test_block_at_a_shard_boundary_and_a_telomere_longer_than_the_context():
