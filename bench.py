@@ -641,6 +641,11 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         # of step i's message beside all of it.  A slot's scan waits for the pack that last read its records; a slot's pack
         # waits for the transfer that last read its message.
         pack_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(os.environ.get("TS_BENCH_PACK_STREAMS", "2"))))]
+        # (TS_BENCH_SCAN_STREAMS=2 alternates the scans of consecutive steps between two streams, so that the workgroups of
+        # step i + 1 could take the CUs the tail of step i frees.  Measured, profiles/r04/two_scan_streams.txt: slower at every
+        # size — 1.15 against 0.93 ms at 3 Gb, 0.188 against 0.177 at the N = 8 size: two persistent kernels that each want
+        # every CU's whole LDS take turns badly.  One stream is the default.)
+        scan_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(max(1, int(os.environ.get("TS_BENCH_SCAN_STREAMS", "1"))) - 1)]
         scanned = [torch.cuda.Event() for _ in range(slots)]
         packed = [torch.cuda.Event() for _ in range(slots)]
         used = [False] * slots
@@ -648,10 +653,11 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         def step(i):
             j = i % slots
             pack_stream = pack_streams[j % len(pack_streams)]
+            scan_stream = scan_streams[i % len(scan_streams)]
             if used[j]:
-                stream.wait_event(packed[j])
-            shard.scan(in_ptr, sptr, j)
-            scanned[j].record(stream)
+                scan_stream.wait_event(packed[j])
+            shard.scan(in_ptr, C.c_void_p(scan_stream.cuda_stream), j)
+            scanned[j].record(scan_stream)
             with torch.cuda.stream(pack_stream):
                 pack_stream.wait_event(scanned[j])
                 if pending[j] is not None:
@@ -670,7 +676,7 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                         for w in pending[j]:
                             w.wait()
                         pending[j] = None
-            for ps in pack_streams:
+            for ps in pack_streams + scan_streams[1:]:
                 stream.wait_stream(ps)
 
         settle(step, drain)

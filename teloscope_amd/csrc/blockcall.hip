@@ -28,12 +28,13 @@
 
 #include "ts_internal.h"
 
-// These kernels run beside the persistent scan kernel of the next batch, whose waves raise their priority for the phases that
-// are chains of latency (s_setprio 2 / 3, kernels.hip): at the default priority a wave of a small kernel that shares a SIMD with
-// them is served only when none of them is ready — a visible-record copy of 60 us took the whole 0.8 ms of the scan beside it, and
-// a pack, a chain of a dozen such kernels, about two scans.  At the top priority they are served first, and being a few
-// thousand instructions each they cost the scan nothing measurable.
-#define TS_SIDE_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
+// ONE-WAVE WORKGROUPS.  These kernels run beside the persistent scan kernel of the next batch, whose two workgroups of ten
+// waves leave a CU's SIMDs with 6, 6, 4 and 4 waves of 80 registers: 32 free registers on two of the four SIMDs.  A
+// workgroup's waves go round the SIMDs, so a 256-thread workgroup of a kernel with more than 32 registers per thread cannot
+// be placed on ANY CU while the scan is resident — kernels launched with 256 threads ended the microsecond the scan beside
+// them did (profiles/r04/pack_beside_scan_trace.txt) — while a single wave goes where there is room.  None of these kernels
+// uses LDS or a barrier: the workgroup size is free.  (Raising their wave priority above the scan's changed nothing.)
+constexpr unsigned kSideWg = 64;
 
 namespace {
 
@@ -308,9 +309,8 @@ __device__ __forceinline__ SegView seg_view(const TsBlockCallParams &Q, const Ts
 // Per segment: match / forward counts over all its tiles the batch scanned, and match / canonical / forward counts over its
 // OWNED tiles — five u64 per segment in `sums` (zero at launch).  One thread per tile; a wave whose tiles all belong to one
 // segment (nearly every wave) adds up first and issues five atomics.  No LDS (see exchange.hip).
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kSideWg)
 void ts_segment_sums(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base, uint32_t ntiles, u64 *sums) {
-    TS_SIDE_KERNEL_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t si = 0xFFFFFFFFu;
     u64 v[5] = {0, 0, 0, 0, 0};
@@ -338,19 +338,18 @@ void ts_segment_sums(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32
     }
 }
 
-__global__ __launch_bounds__(128)
+__global__ __launch_bounds__(kSideWg)
 void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t nseg, u64 *bounds,
                         TsShardSeg *seg_out, const u64 *sums) {
-    TS_SIDE_KERNEL_PRIO();
     // two independent waves per segment: wave 0 walks the forward list from the start, wave 1 the reverse list from the end.
     // A shard (seg_out != nullptr) walks a direction only when it owns that end of the segment; the bounds of the other end
     // are the widest possible, which the receiver checks against what the shard that did walk it reports (shard.cpp:
     // finalize).  No LDS, no barrier: the waves share nothing (see exchange.hip for why that matters).
-    const uint32_t si = blockIdx.x;
+    // (one-wave workgroups, two per segment: see kSideWg; blockIdx is uniform, so the walk's state machine — ballots, chain
+    // state, the branch on the direction — stays in scalar registers)
+    const uint32_t si = blockIdx.x >> 1;
     if (si >= nseg) return;
-    // (readfirstlane: told that the wave index is the same in all lanes, the compiler keeps the walk's state machine — ballots,
-    // chain state, the branch on the wave — in scalar registers instead of predicated vector code)
-    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x & 1u;
     const TsShardSegIn S = segs[si];
     const SegView V = seg_view(Q, S);
     const u64 n = S.len;
@@ -724,10 +723,9 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
 
 // every tile of the range: results that carry no chain summaries (adopted from elsewhere, TS_EMIT=0), and the shard pack
 // that takes the visible records from the match stream
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kSideWg)
 void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base,
                             const u64 *bounds, uint32_t ntiles, TsShardSeg *seg_out, const TsVisibleOut W) {
-    TS_SIDE_KERNEL_PRIO();
     // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all lanes of a wave; told so, it keeps the
     // tile's directory entries, the bounds and every ballot in scalar registers and branches instead of predicating)
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -746,10 +744,9 @@ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs,
 // record, exactly as before.  Tiles the two terminal boundaries cut, and tiles at the edge of a shard's view (where
 // its_tile decides whether a chain ran out of context), are always listed.  On random sequence about one tile in a
 // thousand is listed: the pass reads 3 MB instead of the 0.37 GB of records.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kSideWg)
 void ts_chain_screen(const TsBlockCallParams Q, const uint32_t *chain, const TsShardSegIn *segs, uint32_t seg_base,
                      const u64 *bounds, uint32_t ntiles, uint32_t *work, uint32_t *n_work) {
-    TS_SIDE_KERNEL_PRIO();
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
     bool list = false;
     if (tile < ntiles) {
@@ -823,10 +820,9 @@ void ts_chain_screen(const TsBlockCallParams Q, const uint32_t *chain, const TsS
 }
 
 // the listed tiles, one wave each (the list holds at most every tile of the range)
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kSideWg)
 void ts_interstitial_listed(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base, const u64 *bounds,
                             uint32_t ntiles, TsShardSeg *seg_out, const uint32_t *work, const uint32_t *n_work) {
-    TS_SIDE_KERNEL_PRIO();
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n = *n_work;
     const TsVisibleOut W{};
@@ -836,9 +832,8 @@ void ts_interstitial_listed(const TsBlockCallParams Q, const TsShardSegIn *segs,
 
 // The listed chains, one wave each: walked exactly, filtered, written.  A list that overflowed is reported through the
 // block counter (more blocks than the buffer holds = "come back with more room": the callers' existing path).
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kSideWg)
 void ts_interstitial_evaluate(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base, const u64 *bounds) {
-    TS_SIDE_KERNEL_PRIO();
     const uint32_t n_all = *Q.n_cand;
     const uint32_t n = n_all < Q.cand_cap ? n_all : Q.cand_cap;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -855,13 +850,12 @@ void ts_interstitial_evaluate(const TsBlockCallParams Q, const TsShardSegIn *seg
 
 namespace {
 struct ZeroJobs { void *p[4]; unsigned long long n[4]; };     // byte counts, multiples of 4, pointers 4-byte aligned
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kSideWg)
 void ts_zero_ranges(const ZeroJobs J) {
-    TS_SIDE_KERNEL_PRIO();
     for (int q = 0; q < 4; ++q) {
         uint32_t *dst = (uint32_t *)J.p[q];
         const u64 n = J.n[q] >> 2;
-        for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u) dst[i] = 0u;
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[i] = 0u;
     }
 }
 }  // namespace
@@ -874,7 +868,7 @@ int ts_k_launch_zero(void *p0, unsigned long long n0, void *p1, unsigned long lo
     unsigned long long most = 0;
     for (int q = 0; q < 4; ++q) most = J.n[q] > most ? J.n[q] : most;
     const unsigned grid = (unsigned)((most / 4 + 255) / 256 < 1 ? 1 : ((most / 4 + 255) / 256 > 64 ? 64 : (most / 4 + 255) / 256));
-    hipLaunchKernelGGL(ts_zero_ranges, dim3(grid), dim3(256), 0, (hipStream_t)stream, J);
+    hipLaunchKernelGGL(ts_zero_ranges, dim3(grid * 4u), dim3(kSideWg), 0, (hipStream_t)stream, J);
     return (int)hipGetLastError();
 }
 
@@ -889,8 +883,8 @@ int ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, u
         if (e != hipSuccess) return (int)e;
     }
     if (ntiles)
-        hipLaunchKernelGGL(ts_segment_sums, dim3((ntiles + 255u) / 256u), dim3(256), 0, st, *Q, segs, seg_base, ntiles, sums);
-    hipLaunchKernelGGL(ts_terminal_blocks, dim3(nseg), dim3(128), 0, st, *Q, segs, nseg, bounds, seg_out, (const u64 *)sums);
+        hipLaunchKernelGGL(ts_segment_sums, dim3((ntiles + kSideWg - 1u) / kSideWg), dim3(kSideWg), 0, st, *Q, segs, seg_base, ntiles, sums);
+    hipLaunchKernelGGL(ts_terminal_blocks, dim3(2u * nseg), dim3(kSideWg), 0, st, *Q, segs, nseg, bounds, seg_out, (const u64 *)sums);
     return (int)hipGetLastError();
 }
 
@@ -907,15 +901,15 @@ int ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *seg
             hipError_t e = hipMemsetAsync(work, 0, 4, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(ts_chain_screen, dim3((ntiles + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *Q, chain,
+        hipLaunchKernelGGL(ts_chain_screen, dim3((ntiles + kSideWg - 1u) / kSideWg), dim3(kSideWg), 0, (hipStream_t)stream, *Q, chain,
                            segs, seg_base, (const u64 *)bounds, ntiles, work + 1, work);
-        hipLaunchKernelGGL(ts_interstitial_listed, dim3(128), dim3(256), 0, (hipStream_t)stream, *Q, segs, seg_base,
+        hipLaunchKernelGGL(ts_interstitial_listed, dim3(512), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, seg_base,
                            (const u64 *)bounds, ntiles, seg_out, (const uint32_t *)(work + 1), (const uint32_t *)work);
     } else {
-        hipLaunchKernelGGL(ts_interstitial_blocks, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *Q,
+        hipLaunchKernelGGL(ts_interstitial_blocks, dim3(ntiles), dim3(kSideWg), 0, (hipStream_t)stream, *Q,
                            segs, seg_base, (const u64 *)bounds, ntiles, seg_out, W);
     }
-    hipLaunchKernelGGL(ts_interstitial_evaluate, dim3(256), dim3(256), 0, (hipStream_t)stream, *Q, segs, seg_base,
+    hipLaunchKernelGGL(ts_interstitial_evaluate, dim3(1024), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, seg_base,
                        (const u64 *)bounds);
     return (int)hipGetLastError();
 }

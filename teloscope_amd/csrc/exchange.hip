@@ -9,12 +9,6 @@
 
 #include "ts_internal.h"
 
-// These kernels run beside the persistent scan kernel of the next batch, whose waves raise their priority for the phases that
-// are chains of latency (s_setprio 2 / 3, kernels.hip): at the default priority a wave of a small kernel that shares a SIMD with
-// them is served only when none of them is ready — a visible-record copy of 60 us took the whole 0.8 ms of the scan beside it, and
-// a pack, a chain of a dozen such kernels, about two scans.  At the top priority they are served first, and being a few
-// thousand instructions each they cost the scan nothing measurable.
-#define TS_SIDE_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
 
 namespace {
 
@@ -44,7 +38,6 @@ __device__ __forceinline__ u64 block_excl_scan(u64 v, u64 *total) {
 __global__ __launch_bounds__(kScanThreads)
 void ts_tile_count_blocks(const uint32_t *tile_stats, uint32_t ntiles, u64 *block_sums,
                           const uint32_t *wave_fill, uint32_t region_cap, uint32_t nwaves, u64 *total_out) {
-    TS_SIDE_KERNEL_PRIO();
     const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
     u64 v = 0;
     for (uint32_t i = 0; i < kScanPerThread; ++i)
@@ -63,7 +56,6 @@ void ts_tile_count_blocks(const uint32_t *tile_stats, uint32_t ntiles, u64 *bloc
 // pass 2 (one workgroup): exclusive scan of the block sums in place; the grand total goes to block_sums[nblocks]
 __global__ __launch_bounds__(kScanThreads)
 void ts_tile_scan_blocks(u64 *block_sums, uint32_t nblocks) {
-    TS_SIDE_KERNEL_PRIO();
     u64 carry = 0;
     for (uint32_t b0 = 0; b0 < nblocks; b0 += kScanThreads) {
         const uint32_t i = b0 + threadIdx.x;
@@ -81,7 +73,6 @@ void ts_tile_scan_blocks(u64 *block_sums, uint32_t nblocks) {
 __global__ __launch_bounds__(kScanThreads)
 void ts_tile_offsets(const uint32_t *tile_stats, uint32_t ntiles, const u64 *block_sums, uint32_t nblocks,
                      u64 *tile_off, u64 *total_out, u64 capacity) {
-    TS_SIDE_KERNEL_PRIO();
     const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
     uint32_t c[kScanPerThread];
     u64 v = 0;

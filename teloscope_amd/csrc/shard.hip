@@ -18,12 +18,7 @@
 
 #include "ts_internal.h"
 
-// These kernels run beside the persistent scan kernel of the next batch, whose waves raise their priority for the phases that
-// are chains of latency (s_setprio 2 / 3, kernels.hip): at the default priority a wave of a small kernel that shares a SIMD with
-// them is served only when none of them is ready — a visible-record copy of 60 us took the whole 0.8 ms of the scan beside it, and
-// a pack, a chain of a dozen such kernels, about two scans.  At the top priority they are served first, and being a few
-// thousand instructions each they cost the scan nothing measurable.
-#define TS_SIDE_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
+constexpr unsigned kSideWg = 64;        // one-wave workgroups: what can be placed beside the resident scan (see blockcall.hip)
 
 namespace {
 
@@ -52,10 +47,9 @@ __device__ __forceinline__ uint32_t seg_of_tile(const TsShardPackParams &P, uint
 // counted them: tile_stats[1]); one inside it holds all its records; only the few tiles the zone's edge cuts are read.
 // One thread per tile.  (The records themselves are written by the interstitial pass, blockcall.hip, which reads the
 // whole stream anyway.)
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kSideWg)
 void ts_shard_visible_count(const TsShardPackParams P, uint32_t *vis_stats) {
-    TS_SIDE_KERNEL_PRIO();
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = blockIdx.x * kSideWg + threadIdx.x;
     const uint32_t nown = P.own1 - P.own0;
     const uint32_t lane = threadIdx.x & 63u;
     bool edge = false;
@@ -113,10 +107,9 @@ __device__ __forceinline__ void vis_put(const TsShardPackParams &P, uint32_t dst
     else ((uint32_t *)(P.msg + P.off_visible))[at] = r;
 }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kSideWg)
 void ts_shard_copy_visible(const TsShardPackParams P, const u64 *vis_off, u64 capacity, uint32_t dst_bytes, BigCopy *big, uint32_t *n_big) {
-    TS_SIDE_KERNEL_PRIO();
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = blockIdx.x * kSideWg + threadIdx.x;
     const uint32_t nown = P.own1 - P.own0;
     uint32_t n = 0;
     u64 src0 = 0, dst0 = 0;
@@ -143,22 +136,20 @@ void ts_shard_copy_visible(const TsShardPackParams P, const u64 *vis_off, u64 ca
     }
 }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kSideWg)
 void ts_shard_copy_visible_big(const TsShardPackParams P, uint32_t dst_bytes, const BigCopy *big, const uint32_t *n_big) {
-    TS_SIDE_KERNEL_PRIO();
     const uint32_t n = *n_big;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
         const BigCopy B = big[e];
-        for (uint32_t j = threadIdx.x; j < B.n; j += 256u) vis_put(P, dst_bytes, B.dst + j, vis_get(P, B.src + j));
+        for (uint32_t j = threadIdx.x; j < B.n; j += kSideWg) vis_put(P, dst_bytes, B.dst + j, vis_get(P, B.src + j));
     }
 }
 
 // Window records of the owned windows, bit-packed: fields [A C G T] (when nucleotide counts are on), canonical,
 // non-canonical and forward match counts, field_bits each, least significant first, in window_bytes bytes.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kSideWg)
 void ts_shard_pack_windows(const TsShardPackParams P, uint32_t window_bytes) {
-    TS_SIDE_KERNEL_PRIO();
-    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 i = (u64)blockIdx.x * kSideWg + threadIdx.x;
     const u64 n = P.own_win1 - P.own_win0;
     if (i >= n) return;
     const uint32_t *r = P.windows + (P.own_win0 - P.win_lo + i) * 8ull;
@@ -180,10 +171,9 @@ void ts_shard_pack_windows(const TsShardPackParams P, uint32_t window_bytes) {
 
 // A scan that overflowed a wave's record region (or, when it emits, its visible-record region) promises records it never
 // stored: TS_SHARD_F_SCAN_OVERFLOW into the (zeroed) header's flags.  A thread per wave.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kSideWg)
 void ts_overflow_flag(const TsShardPackParams P) {
-    TS_SIDE_KERNEL_PRIO();
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t w = blockIdx.x * kSideWg + threadIdx.x;
     bool o = false;
     if (w < P.nwaves) {
         o = P.wave_fill[w] > P.region_cap;
@@ -196,7 +186,6 @@ void ts_overflow_flag(const TsShardPackParams P) {
 // counted in place by the block-calling kernels).
 __global__ __launch_bounds__(64)
 void ts_shard_header(const TsShardPackParams P, TsShardHeader H, const u64 *vis_off) {
-    TS_SIDE_KERNEL_PRIO();
     // (whether the scan overflowed a wave's region: checked over the waves by ts_overflow_flag, launched with the terminal walks,
     // which leaves TS_SHARD_F_SCAN_OVERFLOW in the zeroed header's flags — 5120 waves are an eighty-step loop for one wave here)
     const bool o = (((const TsShardHeader *)P.msg)->flags & TS_SHARD_F_SCAN_OVERFLOW) != 0u;
@@ -241,7 +230,7 @@ int ts_k_launch_shard_count(const TsShardPackParams *P, const TsShardHeader *H, 
     uint32_t *vis_stats = (uint32_t *)((char *)tmp + shard_tmp_off(nown, 0));
     u64 *vis_off = (u64 *)((char *)tmp + shard_tmp_off(nown, 1));
     void *scan_tmp = (char *)tmp + shard_tmp_off(nown, 2);
-    hipLaunchKernelGGL(ts_shard_visible_count, dim3((nown + 255u) / 256u), dim3(256), 0, st, *P, vis_stats);
+    hipLaunchKernelGGL(ts_shard_visible_count, dim3((nown + kSideWg - 1u) / kSideWg), dim3(kSideWg), 0, st, *P, vis_stats);
     int e = ts_k_launch_tile_offsets(vis_stats, nown, vis_off, scan_tmp, stream);
     if (e) return e;
     vis->off = vis_off;
@@ -270,16 +259,16 @@ int ts_k_launch_shard_visible(const TsShardPackParams *P, const TsShardHeader *H
         hipError_t he = hipMemsetAsync(n_big, 0, 4, st);
         if (he != hipSuccess) return (int)he;
     }
-    hipLaunchKernelGGL(ts_shard_copy_visible, dim3((nown + 255u) / 256u), dim3(256), 0, st, *P, (const u64 *)vis_off,
+    hipLaunchKernelGGL(ts_shard_copy_visible, dim3((nown + kSideWg - 1u) / kSideWg), dim3(kSideWg), 0, st, *P, (const u64 *)vis_off,
                        (u64)H->visible_capacity, H->visible_bytes, big, n_big);
-    hipLaunchKernelGGL(ts_shard_copy_visible_big, dim3(256), dim3(256), 0, st, *P, H->visible_bytes, (const BigCopy *)big, (const uint32_t *)n_big);
+    hipLaunchKernelGGL(ts_shard_copy_visible_big, dim3(1024), dim3(kSideWg), 0, st, *P, H->visible_bytes, (const BigCopy *)big, (const uint32_t *)n_big);
     return (int)hipGetLastError();
 }
 
 // After the header was zeroed, any time before ts_k_launch_shard_pack: the scan-overflow flag.
 int ts_k_launch_shard_overflow(const TsShardPackParams *P, void *stream) {
     if (P->nwaves)
-        hipLaunchKernelGGL(ts_overflow_flag, dim3((P->nwaves + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *P);
+        hipLaunchKernelGGL(ts_overflow_flag, dim3((P->nwaves + kSideWg - 1u) / kSideWg), dim3(kSideWg), 0, (hipStream_t)stream, *P);
     return (int)hipGetLastError();
 }
 
@@ -287,7 +276,7 @@ int ts_k_launch_shard_overflow(const TsShardPackParams *P, void *stream) {
 int ts_k_launch_shard_windows(const TsShardPackParams *P, const TsShardHeader *H, void *stream) {
     const u64 nwin = P->own_win1 - P->own_win0;
     if (nwin)
-        hipLaunchKernelGGL(ts_shard_pack_windows, dim3((unsigned)((nwin + 255ull) / 256ull)), dim3(256), 0, (hipStream_t)stream, *P, H->window_bytes);
+        hipLaunchKernelGGL(ts_shard_pack_windows, dim3((unsigned)((nwin + kSideWg - 1ull) / kSideWg)), dim3(kSideWg), 0, (hipStream_t)stream, *P, H->window_bytes);
     return (int)hipGetLastError();
 }
 
