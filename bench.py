@@ -34,11 +34,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# HIP streams share the runtime's hardware queues round-robin (4 by default), and kernels of two streams that landed on one
-# queue run one after the other: a sharded step uses the scan stream, two pack streams and a side stream per buffer slot
-# (profiles/r04/hwq_sweep.txt: 8 queues 0.174 ms per step at the N = 8 size against 0.197 with 4; 16 are slower than 4).
-# Read when the runtime initialises: before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (HIP streams share the runtime's hardware queues round-robin — 4 by default, GPU_MAX_HW_QUEUES — and kernels of two streams
+# that landed on one queue run one after the other.  With a side stream per batch a sharded step used seven streams and 8 queues
+# measured 0.174 against 0.197 ms at the N = 8 size (profiles/r04/hwq_sweep.txt); since the terminal walks of every batch share
+# the context's one side stream a step uses four, and 4 and 8 queues measure the same: the runtime's default is left alone.)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLAGS = "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -x 1 -w 1000 -s 500 -r -g -e -m -i"
@@ -263,9 +262,60 @@ def verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev):
         assert got_nuc.tolist() == nuc.tolist(), ("nucleotide totals differ on contig %d" % ci)
         cov = w[:, 4:8].sum(dim=0, dtype=torch.int64)                       # covered bases, each match in <= 2 windows
         assert int(cov[0] + cov[1]) == int(cov[2] + cov[3])
-    return {"contigs_checked": n, "matches_checked": int(summ[:, 1].sum()),
+    # ---- per WINDOW, on a seeded sample: every field of the record recomputed from the bases with the same torch k-mer
+    # lookup — A/C/G/T over the window, and k x the matches that lie fully inside it, by kind (the closed form of
+    # analyzeWindow's carry loop; with w == s this is also the straddle rule).  Nothing of the oracle or of the
+    # HIP kernels is involved: the per-contig sums above cannot see a count that moved from one window to its neighbour.
+    import numpy as np
+    n_sample = int(os.environ.get("TS_VERIFY_WINDOWS", "10000"))
+    rng = np.random.default_rng(1234)
+    nwins = np.array([-(-nb // step) for nb in lens], dtype=np.int64)
+    wstart = np.concatenate([[0], np.cumsum(nwins)])
+    total_w = int(wstart[-1])
+    pick = np.unique(rng.integers(0, total_w, size=min(n_sample, total_w)))
+    # every contig's last window (the short tail) and first window are always in
+    pick = np.unique(np.concatenate([pick, wstart[:-1][nwins > 0], (wstart[1:] - 1)[nwins > 0]]))
+    ci_of = np.searchsorted(wstart, pick, side="right") - 1
+    widx = pick - wstart[ci_of]
+    starts = widx * step
+    sizes = np.minimum(window, np.array(lens, dtype=np.int64)[ci_of] - starts)
+    base_off = np.array(offsets, dtype=np.int64)[ci_of] + starts
+    span = window + k - 1
+    checked = 0
+    for a in range(0, len(pick), 2048):
+        z = min(len(pick), a + 2048)
+        bo = torch.as_tensor(base_off[a:z], device=dev).view(-1, 1)
+        sz = torch.as_tensor(sizes[a:z], device=dev).view(-1, 1)
+        col = torch.arange(span, device=dev).view(1, -1)
+        idx = torch.minimum(bo + col, torch.tensor(buf.numel() - 1, device=dev))
+        c = lut[buf[idx].long()]                                 # [m, span] codes, 4 = not A/C/G/T
+        inside = col < sz
+        want = torch.zeros(z - a, 8, dtype=torch.int64, device=dev)
+        for code_v, field in ((0, 0), (1, 1), (3, 2), (2, 3)):   # records are A C G T; codes A0 C1 T2 G3
+            want[:, field] = ((c == code_v) & inside).sum(dim=1)
+        code = torch.zeros(z - a, window, dtype=torch.int64, device=dev)
+        bad = torch.zeros(z - a, window, dtype=torch.bool, device=dev)
+        for i in range(k):
+            ci_ = c[:, i:i + window]
+            code += (ci_ & 3).long() << (2 * i)
+            bad |= ci_ == 4
+        fully = (col[:, :window] + k) <= sz                      # the match ends inside the window
+        hit = tbl[0][code] & ~bad & fully
+        is_fwd, is_can = tbl[1][code] & hit, tbl[2][code] & hit
+        want[:, 4] = k * is_can.sum(dim=1)
+        want[:, 5] = k * (hit & ~is_can).sum(dim=1)
+        want[:, 6] = k * is_fwd.sum(dim=1)
+        want[:, 7] = k * (hit & ~is_fwd).sum(dim=1)
+        got = wins[torch.as_tensor(pick[a:z], device=dev)].long()
+        if not torch.equal(got, want):
+            bad_row = int((got != want).any(dim=1).nonzero()[0])
+            raise AssertionError("window record differs from the independent recomputation: contig %d window %d: got %s want %s"
+                                 % (int(ci_of[a + bad_row]), int(widx[a + bad_row]), got[bad_row].tolist(), want[bad_row].tolist()))
+        checked += z - a
+    return {"contigs_checked": n, "matches_checked": int(summ[:, 1].sum()), "windows_checked_field_by_field": checked,
             "properties": "per-contig match/canonical/forward counts vs independent torch k-mer lookup; "
-                          "A/C/G/T totals vs the sums of the windows that tile each contig"}
+                          "A/C/G/T totals vs the sums of the windows that tile each contig; all eight fields of %d sampled "
+                          "window records (every contig's first and last window among them) vs the same lookup" % checked}
 
 
 def compare_sharded_with_single_gpu(L, K, tel, batch, sharded, n, with_matches):
@@ -649,6 +699,34 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         scanned = [torch.cuda.Event() for _ in range(slots)]
         packed = [torch.cuda.Event() for _ in range(slots)]
         used = [False] * slots
+        # Rehearsal of the exchange's SHAPE on one GPU (TS_BENCH_REHEARSE_WORLD=8 with TS_BENCH_FORCE_STRONG=1): what rank 0 of
+        # an N-rank job posts per step — one grouped batch of N - 1 receives, one per sender, of the message sizes the N-way
+        # plan gives (ts_batch_shard_info) — and what the N - 1 senders post, all from this one rank on the real RCCL group
+        # with itself as the peer: 2 (N - 1) operations per step in one batch_isend_irecv, `slots` steps in flight, posted
+        # from the pack stream as in the real step.  What it cannot show is seven links; what it does show is the grouped
+        # P2P call pattern of rank 0 meeting the library.  The received bytes are compared with what was sent afterwards.
+        rehearse = None
+        rw = int(os.environ.get("TS_BENCH_REHEARSE_WORLD", "0"))
+        if world == 1 and rw > 1 and backend == "nccl":
+            plan_r = D.ShardPlan(tel, lens, world=rw)
+            sizes = [int(D.shard_info(plan_r, p).msg_bytes) for p in range(1, rw)]
+            plan_r.close()
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(7)
+            rehearse = {"world": rw, "sizes": sizes,
+                        "send": [[torch.randint(0, 256, (sz,), dtype=torch.uint8, device=dev, generator=gen) for sz in sizes] for _ in range(slots)],
+                        "recv": [[torch.zeros(sz, dtype=torch.uint8, device=dev) for sz in sizes] for _ in range(slots)],
+                        "posted": 0, "steps": 0}
+
+        def post_rehearsal(j):
+            ops = []
+            for q in range(len(rehearse["sizes"])):
+                ops.append(dist.P2POp(dist.irecv, rehearse["recv"][j][q], 0))
+            for q in range(len(rehearse["sizes"])):
+                ops.append(dist.P2POp(dist.isend, rehearse["send"][j][q], 0))
+            rehearse["posted"] += len(ops)
+            rehearse["steps"] += 1
+            return dist.batch_isend_irecv(ops)
 
         def step(i):
             j = i % slots
@@ -666,7 +744,7 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                     pending[j] = None
                 shard.pack(C.c_void_p(pack_stream.cuda_stream), j)
                 packed[j].record(pack_stream)
-                pending[j] = exch.post(shard.msgs[j], j)
+                pending[j] = exch.post(shard.msgs[j], j) if rehearse is None else post_rehearsal(j)
             used[j] = True
 
         def drain():
@@ -773,6 +851,18 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                                       "capacity_scale": scale, "context_tiles": int(exch.infos[0].context_tiles),
                                       "round2_full_exchange_bytes_over_links": None},
                          "step_split": split}
+            if rehearse is not None:
+                torch.cuda.synchronize()
+                same = all(torch.equal(rehearse["recv"][j][q], rehearse["send"][j][q])
+                           for j in range(min(slots, rehearse["steps"])) for q in range(len(rehearse["sizes"])))
+                if not same:
+                    raise RuntimeError("exchange rehearsal: received bytes differ from the bytes sent")
+                extra_cfg["exchange"]["rehearsal"] = {
+                    "of_world": rehearse["world"], "posted_ops_per_step": rehearse["posted"] // max(1, rehearse["steps"]),
+                    "steps_posted": rehearse["steps"], "bytes_per_step": int(sum(rehearse["sizes"])),
+                    "message_bytes": rehearse["sizes"], "received_equals_sent": True,
+                    "what": "rank 0's grouped batch of an %d-rank step (N - 1 receives) plus the N - 1 sends, from ONE rank on the RCCL "
+                            "group with itself as the peer, `slots` steps in flight" % rehearse["world"]}
         else:
             extra_cfg = {}
         bases_done = total
@@ -916,7 +1006,7 @@ def run_scan(args, rank, local_rank, world, dev, backend):
             if L.ts_batch_scan(one.batch, C.c_void_p(full.data_ptr()), sptr) != 0 or L.ts_batch_sync(one.batch) != 0:
                 raise RuntimeError(tel._ctx.error())
             out["verify"] = verify_full_size(L, one.batch, tel, full, offsets, lens, ui, dev)
-            out["verify"]["sharded_equals_single_gpu"] = compare_sharded_with_single_gpu(L, K, tel, one.batch, sharded, n, total <= 1_200_000_000)
+            out["verify"]["sharded_equals_single_gpu"] = compare_sharded_with_single_gpu(L, K, tel, one.batch, sharded, n, n_matches <= 600_000_000)   # (16 B per match record on the host: 1.5 GB at configs[1], 0.7 GB at configs[4])
             one.close()
         elif args.verify:
             out["verify"] = verify_full_size(L, result_batch, tel, full if strong else buf, offsets, lens, ui, dev)
@@ -944,6 +1034,8 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                 "terminal_blocks": int(sum(seg_out[i].n_terminal_blocks for i in range(n))),
                 "interstitial_blocks": int(sum(seg_out[i].n_interstitial_blocks for i in range(n)))}
             L.ts_free_segments(seg_out, n)
+        if world == 1 and not forced_strong and not os.environ.get("TS_BENCH_NO_BLOCKS_RECORD"):
+            out["scan_plus_block_calling"] = scan_plus_block_calling_record(args, tel, lens, buf, dev, out["ms_per_step"], stream)
         if world == 1 and not args.no_reads and not forced_strong:
             out["reads"] = reads_sub_record(args, dev)
         if world == 1 and not args.no_e2e:
@@ -1013,6 +1105,86 @@ def fill_read_range(buf, all_lens, g0, g1, dev):
         at += nbytes
         del tmp
     return np.asarray(carriers, dtype=np.int64)
+
+
+def scan_plus_block_calling_record(args, tel, lens, buf, dev, plain_ms, stream):
+    """What a rank of the sharded job does per step, on this one GPU with the whole assembly: the EMITTING scan
+    (ts_batch_set_emit: visible records + chain summaries) + block calling on the device + the packed message — the
+    reference's scanSegment contains block calling (src/teloscope.cpp:642-657), the plain scan that `value` times does not.
+    This is the like-for-like origin of a 1 -> N curve: the N > 1 lines time exactly this per rank, plus the exchange."""
+    import torch
+    import teloscope_amd.distributed as D
+    steps, slots = min(args.steps, 40), max(2, int(os.environ.get("TS_BENCH_SLOTS", "4")))
+    plan = D.ShardPlan(tel, lens, world=1)
+    shard = D.PackedShard(plan, 0, dev, slots=slots, scale=1)
+    sptr = C.c_void_p(stream.cuda_stream)                     # (the stream the plain scans ran on: streams share a few hardware queues)
+    pack_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    scanned = [torch.cuda.Event() for _ in range(slots)]
+    packed = [torch.cuda.Event() for _ in range(slots)]
+    used = [False] * slots
+    in_ptr = buf.data_ptr()
+
+    def step(i):
+        j = i % slots
+        ps = pack_streams[j % 2]
+        if used[j]:
+            stream.wait_event(packed[j])
+        shard.scan(in_ptr, sptr, j)
+        scanned[j].record(stream)
+        with torch.cuda.stream(ps):
+            ps.wait_event(scanned[j])
+            shard.pack(C.c_void_p(ps.cuda_stream), j)
+            packed[j].record(ps)
+        used[j] = True
+
+    def settle_regions():
+        for _ in range(6):
+            for i in range(slots):
+                step(i)
+            torch.cuda.synchronize()
+            st = [shard.status(j) for j in range(slots)]
+            if any(x.flags & K_SHARD_SCAN for x in st):
+                for j in range(slots):
+                    shard.sync(j)
+            elif any(x.flags & K_SHARD_GROW for x in st):
+                shard.set_scale(shard.scale * 2)
+            else:
+                return st[0]
+        raise RuntimeError("scan_plus_block_calling: the message kept overflowing")
+
+    from teloscope_amd import _capi as K
+    K_SHARD_SCAN, K_SHARD_GROW = K.SHARD_OVERFLOW_SCAN, K.SHARD_OVERFLOW_VISIBLE | K.SHARD_OVERFLOW_BLOCKS
+    with torch.cuda.stream(stream):
+        st0 = settle_regions()
+        for i in range(3 * slots):
+            step(i)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        overlapped = (time.perf_counter() - c0) / steps * 1e3
+        # serialised: scan, then block calling + pack, each waited for
+        t_scan = t_pack = 0.0
+        nb = min(10, steps)
+        for i in range(nb):
+            c0 = time.perf_counter()
+            shard.scan(in_ptr, sptr, 0)
+            torch.cuda.synchronize()
+            c1 = time.perf_counter()
+            shard.pack(sptr, 0)
+            torch.cuda.synchronize()
+            t_scan += c1 - c0
+            t_pack += time.perf_counter() - c1
+    rec = {"ms_per_step": round(overlapped, 4), "gbases_per_s": round(sum(lens) / overlapped / 1e6, 1), "steps": steps,
+           "emitting_scan_alone_ms": round(t_scan / nb * 1e3, 4), "block_calling_and_pack_alone_ms": round(t_pack / nb * 1e3, 4),
+           "plain_scan_ms_per_step": round(plain_ms, 4),
+           "blocks": int(st0.n_blocks), "visible_records": int(st0.n_visible), "message_bytes": int(shard.info.msg_bytes),
+           "what": "emitting scan + terminal / interstitial block calling on the device + packed message (bit-packed windows, visible "
+                   "records, blocks), %d buffer slots, pack beside the next scan; results stay in HBM" % slots}
+    shard.close()
+    plan.close()
+    return rec
 
 
 def reads_sub_record(args, dev):

@@ -659,7 +659,7 @@ void ts_destroy(ts_ctx *ctx) {
         }
         for (hipEvent_t e : ctx->gen_ev) if (e) (void)hipEventDestroy(e);
         for (PinBuf &pb : ctx->pin_down) pb.release();
-        for (hipStream_t st : {ctx->up_stream, ctx->scan_stream, ctx->down_stream})
+        for (hipStream_t st : {ctx->up_stream, ctx->scan_stream, ctx->down_stream, ctx->side_stream})
             if (st) (void)hipStreamDestroy(st);
         delete ctx;
         return;
@@ -809,7 +809,6 @@ void ts_batch_destroy(ts_batch *b) {
             if (e) (void)hipEventDestroy(e);
         if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
         if (b->ev_join) (void)hipEventDestroy(b->ev_join);
-        if (b->side_stream) (void)hipStreamDestroy(b->side_stream);
     }
     delete b;
 }

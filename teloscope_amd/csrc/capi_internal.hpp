@@ -129,6 +129,8 @@ struct ts_ctx {
     std::vector<int> node_cpus;
     void bind_this_thread() const;          // no-op when node_cpus is empty; never widens the thread's current mask
     static constexpr int kUpSlots = 3;
+    hipStream_t side_stream = nullptr;          // ts_batch_pack_shard: the terminal walks of every batch's pack (created on first use)
+    std::mutex side_mtx;
     PinBuf pin_up[kUpSlots];
     hipEvent_t pin_up_ev[kUpSlots] = {nullptr, nullptr, nullptr};
     DevBuf d_pack[kUpSlots], d_runs[kUpSlots];   // packed upload: a chunk's 2-bit codes and invalid runs on the device
@@ -212,7 +214,9 @@ struct ts_batch {
     DevBuf d_shard_segs, d_shard_bounds, d_shard_tmp, d_shard_cand;
     ShardRange shard_r{};
     ShardLayout shard_L{};
-    hipStream_t side_stream = nullptr;          // ts_batch_pack_shard: the terminal walks run beside the counting / packing kernels
+    // (ts_batch_pack_shard runs the terminal walks beside the counting / packing kernels on the CONTEXT's side stream: HIP
+    // streams share a handful of hardware queues, and kernels of two streams on one queue run one after the other — a side
+    // stream per batch, four buffer slots = four more streams, pushed the scan stream onto a shared queue)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // caller-owned result buffers (ts_batch_bind_results / ts_batch_adopt); null = the batch's own
     uint32_t *ext_windows = nullptr, *ext_stats = nullptr;

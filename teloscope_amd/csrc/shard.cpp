@@ -259,8 +259,11 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
         c->pool.give(std::move(b->d_shard_cand));
         HIP_TRY(c, c->pool.take((size_t)cand_cap * 8 + 16, b->d_shard_cand));
     }
-    if (!b->side_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
+    {
+        std::lock_guard<std::mutex> lk(c->side_mtx);
+        if (!c->side_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    }
+    if (!b->ev_fork) {
         HIP_TRY(c, hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
     }
@@ -336,12 +339,12 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     // own beside the counting, the prefix sum and the window packing; the interstitial pass needs both (the bounds, and
     // where every tile's visible records go) and joins them.
     HIP_TRY(c, hipEventRecord(b->ev_fork, st));
-    HIP_TRY(c, hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
+    HIP_TRY(c, hipStreamWaitEvent(c->side_stream, b->ev_fork, 0));
     if (ts_k_launch_terminal(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
                              (unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs),
-                             (unsigned long long *)b->d_shard_bounds.p + 2ull * std::max<uint32_t>(ns, 1), 1, b->side_stream) != 0)
+                             (unsigned long long *)b->d_shard_bounds.p + 2ull * std::max<uint32_t>(ns, 1), 1, c->side_stream) != 0)
         return c->fail(TS_ERR_HIP, "terminal block kernel launch failed");
-    HIP_TRY(c, hipEventRecord(b->ev_join, b->side_stream));
+    HIP_TRY(c, hipEventRecord(b->ev_join, c->side_stream));
     TsVisibleOut vis{};
     if (from_scan) {
         if (ts_k_launch_shard_visible(&K, &H, b->d_shard_tmp.p, 1, stream) != 0)

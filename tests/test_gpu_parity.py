@@ -57,6 +57,16 @@ def test_legacy_manifest_on_gpu(path):
     assert stdout.split("\n") == m["expected"].split("\n")
 
 
+from tests import val_answers as _V
+
+
+@pytest.mark.parametrize("args,must,sub", _V.cases(), ids=["%s | %s" % (a, s.replace("\t", " ")) for a, _, s in _V.cases()])
+def test_val_known_answer_on_gpu(args, must, sub):
+    """The known answers of the reference's CI script (val.sh:107-196, tests/golden/val_known_answers.tsv) through the HIP
+    path, every scanSegment result compared with the oracle's on the way."""
+    _V.check(BothBackends, args, must, sub)
+
+
 @pytest.mark.parametrize("path", FASTQ, ids=[os.path.basename(p) for p in FASTQ])
 def test_fastq_manifest_on_gpu(path):
     m = H.load_manifest(path)

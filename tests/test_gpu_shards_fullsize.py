@@ -128,6 +128,24 @@ def test_bench_two_ranks_on_one_gpu_equals_single_gpu():
     assert cfg["step_split"]["exchange_ms"] > 0
 
 
+def test_bench_rehearses_the_eight_rank_exchange_shape_on_rccl(monkeypatch):
+    """One rank on the real RCCL group, the sharded code path at full size (configs[1], 3 Gb) for 50 steps with --verify,
+    posting per step what the ranks of an 8-rank job post between them: rank 0's grouped batch of seven receives (message
+    sizes of the 8-way plan) and the seven sends, fourteen operations in one batch_isend_irecv, several steps in flight,
+    from the pack streams.  The received bytes must be the bytes sent, and the merged writer view must still equal the
+    single-GPU scan (windows, blocks, visible match records — compared at full size)."""
+    monkeypatch.setenv("TS_BENCH_FORCE_STRONG", "1")
+    monkeypatch.setenv("TS_BENCH_REHEARSE_WORLD", "8")
+    out = _bench("--steps", "50", "--warmup", "3", "--verify", "--no-cpu-baseline", "--no-e2e", "--no-reads")
+    cfg = out["config"]
+    r = cfg["exchange"]["rehearsal"]
+    assert r["of_world"] == 8 and r["posted_ops_per_step"] == 14 and r["received_equals_sent"] and len(r["message_bytes"]) == 7
+    assert r["steps_posted"] >= 50 and r["bytes_per_step"] < 100_000_000
+    v = out["verify"]
+    assert v["windows_checked_field_by_field"] >= 10_000
+    assert v["sharded_equals_single_gpu"]["visible_matches"] > 2_000_000       # compared, not skipped, at 3 Gb
+
+
 def test_bench_full_exchange_two_ranks_on_one_gpu_equals_single_gpu():
     """Round 2's exchange (every record assembled on rank 0) stays available behind --full-exchange: it is what a batch
     takes when the shards' assumptions do not hold for its input."""
