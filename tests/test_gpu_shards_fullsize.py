@@ -170,6 +170,17 @@ def test_bench_read_shard_over_two_ranks_equals_one_rank_and_the_oracle():
         assert 0.02 < o["roofline"]["frac"] < 1.0 and o["roofline"]["algorithmic_bytes"] < 1.001 * o["config"]["bases"] / o["n_gpus"] + 1e6
 
 
+def test_bench_reads_at_five_million_reads():
+    """configs[3] at a tenth of its size — 5 M reads, 75 Gbases resident in HBM (BASELINE: "may be scaled to 5 M reads for
+    CI") — through bench.py --reads on one GPU with --verify: every planted carrier kept, a sample from both ends of the read
+    set equal to the oracle's ReadTelomereFilter::matches, and the roofline figure over the whole step (scan + predicate)."""
+    out = _bench("--reads", "--n-reads", "5e6", "--steps", "2", "--warmup", "1", "--verify", "--no-cpu-baseline", timeout=1200)
+    assert out["n_gpus"] == 1 and out["config"]["reads"] == 5_000_000
+    assert out["config"]["bases"] > 70e9 and out["config"]["kept"] > 20_000
+    assert out["verify"]["reads_checked_against_oracle"] > 100
+    assert 0.3 < out["roofline"]["frac"] < 1.0
+
+
 def test_bench_under_the_drivers_launcher():
     """The driver's own launch form for N > 1 — python -m torch.distributed.run --nproc-per-node N bench.py --gpus N, ranks
     from RANK / LOCAL_RANK / WORLD_SIZE in the environment — with two ranks on this one GPU (gloo): one JSON line from rank
