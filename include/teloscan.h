@@ -140,18 +140,33 @@ typedef struct ts_block {
  * pieces until `len` bases are covered (at most `n_pieces` of them); of the last piece only what is needed. */
 #define TS_INPUT_BASES       0
 #define TS_INPUT_TEXT_PIECES 1
+#define TS_INPUT_PACKED2     2
 typedef struct ts_text_piece {
     const char *text;        /* text_len bytes: n_bases bases and the line ends between / behind them ('\n', and a '\r'
                                 right before one or at the very end of the piece) */
     uint64_t    text_len;    /* at most 16 MiB */
     uint64_t    n_bases;
 } ts_text_piece;
+/* input_format TS_INPUT_PACKED2: `seq` points to ONE ts_packed_seq — the segment's bases already as 2-bit codes (four per
+ * byte, base i at bits 2 (i & 3) of byte i >> 2; A 0, C 1, T 2, G 3: what ts_pack_bases writes) plus the runs of positions
+ * that are not A/C/G/T (after case folding, if the context folds case), ascending and non-overlapping, segment-relative.
+ * A front end that parses FASTA touches every base once anyway: packing there (ts_pack_bases, or its own loop) means the
+ * bases are read from host memory ONCE between the file and the PCIe link — the library's staging threads then copy a
+ * quarter of the bytes instead of reading the ASCII a second time, which is what bounds the host entry points once the
+ * link carries packed bases.  Results cannot depend on the input format: the device restores the same
+ * byte layout ('N' over the runs) that TS_INPUT_BASES uploads.  Tiled kernel's parameter sets only, like the text pieces. */
+typedef struct ts_packed_run { uint64_t start, len; } ts_packed_run;
+typedef struct ts_packed_seq {
+    const uint8_t       *codes;     /* (len + 3) / 4 bytes */
+    const ts_packed_run *runs;      /* may be NULL when n_runs == 0 */
+    uint64_t             n_runs;
+} ts_packed_seq;
 typedef struct ts_segment_in {
     const char *seq;        /* borrowed for the duration of the call; need not be NUL-terminated */
     uint64_t    len;
     uint64_t    abs_pos;
     uint8_t     tips_only;
-    uint8_t     input_format;   /* TS_INPUT_BASES / TS_INPUT_TEXT_PIECES (tiled kernel's parameter sets only) */
+    uint8_t     input_format;   /* TS_INPUT_BASES / TS_INPUT_TEXT_PIECES / TS_INPUT_PACKED2 (the latter two: tiled kernel's parameter sets only) */
     uint8_t     reserved[2];
     uint32_t    n_pieces;       /* TS_INPUT_TEXT_PIECES: entries of the ts_text_piece array (the walk never reads past it;
                                    pieces that hold fewer than `len` bases are TS_ERR_INVALID_ARG) */

@@ -61,7 +61,44 @@ class SegmentIn(C.Structure):
                 ("tips_only", C.c_uint8), ("input_format", C.c_uint8), ("reserved", C.c_uint8 * 2), ("n_pieces", C.c_uint32)]
 
 
-TS_INPUT_BASES, TS_INPUT_TEXT_PIECES = 0, 1
+TS_INPUT_BASES, TS_INPUT_TEXT_PIECES, TS_INPUT_PACKED2 = 0, 1, 2
+
+
+class PackedRun(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("len", C.c_uint64)]
+
+
+class PackedSeq(C.Structure):
+    _fields_ = [("codes", C.c_void_p), ("runs", C.c_void_p), ("n_runs", C.c_uint64)]
+
+
+def pack_sequence(seq, fold_case):
+    """bytes -> (PackedSeq, keep-alive objects): 2-bit codes + invalid runs through ts_pack_bases (pieces of < 2^32 bases,
+    the run positions made segment-relative), the TS_INPUT_PACKED2 form of a segment."""
+    n = len(seq)
+    codes = np.zeros((n + 3) // 4 + 64, dtype=np.uint8)
+    runs = []
+    piece = 1 << 28                                                  # a multiple of 4: pieces start on byte boundaries
+    buf = C.create_string_buffer(seq, n) if not isinstance(seq, (bytes, bytearray)) else seq
+    for a in range(0, n, piece):
+        m = min(piece, n - a)
+        cap = m + 1
+        rr = np.zeros((cap, 2), dtype=np.uint32)
+        nr = C.c_uint64(0)
+        rc = lib().ts_pack_bases(bytes(buf[a:a + m]), m, int(bool(fold_case)), C.c_void_p(codes.ctypes.data + a // 4),
+                                 C.c_void_p(rr.ctypes.data), cap, C.byref(nr))
+        if rc != TS_OK:
+            raise TeloscanError(rc, "ts_pack_bases failed")
+        for s0, ln in rr[:int(nr.value)]:
+            if runs and runs[-1][0] + runs[-1][1] == a + int(s0):
+                runs[-1][1] += int(ln)
+            else:
+                runs.append([a + int(s0), int(ln)])
+    arr = (PackedRun * max(1, len(runs)))()
+    for i, (s0, ln) in enumerate(runs):
+        arr[i].start, arr[i].len = s0, ln
+    ps = PackedSeq(C.c_void_p(codes.ctypes.data), C.cast(arr, C.c_void_p), len(runs))
+    return ps, (codes, arr)
 
 
 class TextPiece(C.Structure):

@@ -124,7 +124,7 @@ extern "C" int ts_scan_segments_multi(ts_ctx *const *ctxs, size_t n_ctx, const t
         std::memset(&out[i], 0, sizeof out[i]);
         if (counts) counts[i] = ts_segment_counts{0, 0, 0, 0};
         if (segs[i].len && !segs[i].seq) return c0->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
-        if (segs[i].input_format > TS_INPUT_TEXT_PIECES) return c0->fail(TS_ERR_INVALID_ARG, "unknown input_format");
+        if (segs[i].input_format > TS_INPUT_PACKED2) return c0->fail(TS_ERR_INVALID_ARG, "unknown input_format");
     }
     if (!n_segs) return TS_OK;
     for (size_t i = 0; i < n_ctx; ++i)

@@ -114,8 +114,9 @@ int ensure_streams(ts_ctx *c) {
     return rc;
 }
 
-struct UpPiece { uint64_t off; const char *src; uint64_t len; uint64_t text_len; };   // off: byte offset in the input layout; len: bases;
+struct UpPiece { uint64_t off; const char *src; uint64_t len; uint64_t text_len;     // off: byte offset in the input layout; len: bases;
                                                                                      // text_len != 0: src is FASTA text (line ends to skip)
+                 const ts_packed_seq *packed = nullptr; uint64_t packed_first = 0; };  // packed: the bases are codes [packed_first, + len) of *packed
 
 // the bases of a run of FASTA body text, without its line ends ('\n', and a '\r' right before one or at the very end)
 bool strip_copy(char *dst, const char *text, uint64_t text_len, uint64_t n_bases) {
@@ -190,12 +191,19 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
     constexpr uint64_t kChunkPacked = 4 * kChunk;            // a packed chunk fills the same 32 MB pinned slot with 128 MB of layout
     std::vector<UpPiece> pieces;
     pieces.reserve(pieces_in.size());
-    bool any_text = false;
+    bool any_text = false, any_packed = false;
     for (const UpPiece &pc : pieces_in) {
         if (pc.text_len) {
             if (pc.len > kChunk) return c->fail(TS_ERR_INVALID_ARG, "a text piece holds more than 32 MiB of bases");
             pieces.push_back(pc);
             any_text = true;
+        } else if (pc.packed) {
+            for (uint64_t a = 0; a < pc.len; a += kChunk) {
+                UpPiece q = pc;
+                q.off = pc.off + a; q.len = std::min<uint64_t>(kChunk, pc.len - a); q.packed_first = pc.packed_first + a;
+                pieces.push_back(q);
+            }
+            any_packed = true;
         } else {
             for (uint64_t a = 0; a < pc.len; a += kChunk) pieces.push_back({pc.off + a, pc.src + a, std::min<uint64_t>(kChunk, pc.len - a), 0});
         }
@@ -253,13 +261,14 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
     const bool fold = c->params.fold_case != 0;
     uint64_t packed_min = 1u << 20;                            // small calls are latency, not link time: they go plain
     if (const char *e = getenv("TS_PACKED_MIN_BYTES")) packed_min = strtoull(e, nullptr, 10);
-    bool use_packed = packed_upload_enabled() && total_bytes >= packed_min;
+    bool use_packed = (packed_upload_enabled() && total_bytes >= packed_min) || any_packed;      // (bases that arrive packed leave packed)
     if (use_packed && !c->d_pack[0].p) {                       // the device side of the ring, once per context
         for (int q = 0; q < ts_ctx::kUpSlots && use_packed; ++q) {
             if (c->d_pack[q].ensure((kChunkPacked >> 2) + 4096) != hipSuccess || c->d_runs[q].ensure((size_t)kPackRunCap * 8) != hipSuccess ||
                 c->pin_runs[q].ensure((size_t)kPackRunCap * 8) != hipSuccess) { (void)hipGetLastError(); use_packed = false; }
         }
     }
+    if (any_packed && !use_packed) return c->fail(TS_ERR_ALLOC, "packed input needs the packed upload's device buffers");
     size_t i = 0;
     while (i < pieces.size()) {
         const uint64_t c0 = pieces[i].off;
@@ -277,7 +286,7 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
         // (ranges end at multiples of 4096 positions: no two workers write the same byte), pulling its bases out of the
         // pieces that overlap it — plain pieces in place, FASTA text through a small buffer that the line ends are
         // stripped into — and 'A' into the padding between pieces, which nobody reads.
-        if (use_packed && bytes >= 4096) {
+        if (use_packed && (bytes >= 4096 || any_packed)) {
             const uint64_t c0a = c0 & ~63ull;
             const uint64_t P = hi_pos - c0a;                                  // chunk positions, incl. the lead before c0
             const uint64_t share = ((P + nt - 1) / nt + 4095) & ~4095ull;
@@ -297,15 +306,76 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
                     const uint64_t z = std::min(z0, a + BK), la = c0a + a, lz = c0a + z;   // layout range of the block
                     while (k < j && pieces[k].off + pieces[k].len <= la) ++k;
                     // wholly inside one plain piece: packed from where it lies
-                    if (k < j && !pieces[k].text_len && pieces[k].off <= la && pieces[k].off + pieces[k].len >= lz) {
+                    if (k < j && !pieces[k].text_len && !pieces[k].packed && pieces[k].off <= la && pieces[k].off + pieces[k].len >= lz) {
                         ts::pack_bases((const unsigned char *)pieces[k].src + (la - pieces[k].off), z - a, (unsigned char *)dst + (a >> 2), fold, (uint32_t)a, R);
                         continue;
+                    }
+                    // bases that arrive packed (TS_INPUT_PACKED2): when every piece the block touches is such, their codes are
+                    // copied — whole bytes where source and destination agree on the phase within a byte (full scans: segments
+                    // start on 16-byte boundaries of the layout), else shifted — and their invalid runs translated; a block
+                    // that mixes packed and ASCII pieces (the seam between two segments of different formats) takes the
+                    // ASCII path below with the codes spelled out as letters
+                    {
+                        bool all_packed = true, any_here = false;
+                        for (size_t q = k; q < j && pieces[q].off < lz; ++q) {
+                            if (pieces[q].off + pieces[q].len <= la) continue;
+                            any_here = true;
+                            if (!pieces[q].packed) all_packed = false;
+                        }
+                        if (any_here && all_packed) {
+                            unsigned char *out = (unsigned char *)dst + (a >> 2);              // a is a multiple of 4 (blocks of 16384 from a multiple of 4096)
+                            std::memset(out, 0, (z - a + 3) >> 2);
+                            for (size_t q = k; q < j && pieces[q].off < lz; ++q) {
+                                const UpPiece &pc = pieces[q];
+                                const uint64_t s0 = std::max(pc.off, la), s1 = std::min(pc.off + pc.len, lz);
+                                if (s1 <= s0) continue;
+                                const uint64_t d0 = s0 - la, n = s1 - s0, i0 = pc.packed_first + (s0 - pc.off);   // block position, bases, source base index
+                                const uint8_t *codes = pc.packed->codes;
+                                if (((d0 ^ i0) & 3u) == 0u) {
+                                    uint64_t x = 0;
+                                    for (; x < n && ((d0 + x) & 3u); ++x)                                        // up to the first whole byte
+                                        out[(d0 + x) >> 2] |= (unsigned char)(((codes[(i0 + x) >> 2] >> (2u * ((i0 + x) & 3u))) & 3u) << (2u * ((d0 + x) & 3u)));
+                                    const uint64_t whole = (n - x) >> 2;
+                                    std::memcpy(out + ((d0 + x) >> 2), codes + ((i0 + x) >> 2), whole);
+                                    for (x += whole * 4; x < n; ++x)
+                                        out[(d0 + x) >> 2] |= (unsigned char)(((codes[(i0 + x) >> 2] >> (2u * ((i0 + x) & 3u))) & 3u) << (2u * ((d0 + x) & 3u)));
+                                } else {
+                                    for (uint64_t x = 0; x < n; ++x)
+                                        out[(d0 + x) >> 2] |= (unsigned char)(((codes[(i0 + x) >> 2] >> (2u * ((i0 + x) & 3u))) & 3u) << (2u * ((d0 + x) & 3u)));
+                                }
+                                // the piece's invalid runs that reach into [i0, i0 + n): chunk positions; the codes under them are zeroed
+                                // (what pack_bases leaves there: the unpack kernel writes 'N' over them anyway)
+                                const ts_packed_run *pr = pc.packed->runs;
+                                const uint64_t nr = pr ? pc.packed->n_runs : 0;
+                                size_t r0 = (size_t)(std::upper_bound(pr, pr + nr, i0, [](uint64_t v, const ts_packed_run &r) { return v < r.start + r.len; }) - pr);
+                                for (; r0 < nr && pr[r0].start < i0 + n; ++r0) {
+                                    const uint64_t ra = std::max<uint64_t>(pr[r0].start, i0), rz = std::min<uint64_t>(pr[r0].start + pr[r0].len, i0 + n);
+                                    if (rz <= ra) continue;
+                                    R.finish();
+                                    const uint32_t cs = (uint32_t)(a + d0 + (ra - i0));
+                                    if (!R.runs.empty() && R.runs.back().start + R.runs.back().len == cs) R.runs.back().len += (uint32_t)(rz - ra);
+                                    else R.runs.push_back({cs, (uint32_t)(rz - ra)});
+                                }
+                            }
+                            continue;
+                        }
                     }
                     std::memset(buf, 'A', z - a);
                     for (size_t q = k; q < j && pieces[q].off < lz; ++q) {
                         const UpPiece &pc = pieces[q];
                         const uint64_t s0 = std::max(pc.off, la), s1 = std::min(pc.off + pc.len, lz);
                         if (s1 <= s0) continue;
+                        if (pc.packed) {                                                             // (a mixed block: letters, 'N' under the runs)
+                            const uint64_t i0 = pc.packed_first + (s0 - pc.off);
+                            for (uint64_t x = 0; x < s1 - s0; ++x)
+                                buf[s0 - la + x] = "ACTG"[(pc.packed->codes[(i0 + x) >> 2] >> (2u * ((i0 + x) & 3u))) & 3u];
+                            const ts_packed_run *pr = pc.packed->runs;
+                            for (uint64_t r = 0; pr && r < pc.packed->n_runs; ++r) {
+                                const uint64_t ra = std::max<uint64_t>(pr[r].start, i0), rz = std::min<uint64_t>(pr[r].start + pr[r].len, i0 + (s1 - s0));
+                                for (uint64_t y = ra; y < rz; ++y) buf[s0 - la + (y - i0)] = 'N';
+                            }
+                            continue;
+                        }
                         if (!pc.text_len) { std::memcpy(buf + (s0 - la), pc.src + (s0 - pc.off), s1 - s0); continue; }
                         if (tk != q) {                                               // enter this text piece (at base s0 - pc.off)
                             tk = q;
@@ -342,6 +412,7 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
                 continue;
             }
             // a chunk with more invalid runs than the list holds is not sequence data: the rest of the call goes the plain way
+            if (any_packed) return c->fail(TS_ERR_INVALID_ARG, "packed input with more invalid runs per 128 Mi bases than the upload carries (2^18)");
             use_packed = false;
             continue;
         }
@@ -411,6 +482,16 @@ int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
                         pieces.push_back({a, from, z - a, (uint64_t)(t.text + t.text_len - from)});
                     }
                     off += n; left -= n; want += n; cum += t.n_bases;
+                }
+            } else if (items[i].format == TS_INPUT_PACKED2) {
+                const ts_packed_seq *ps = (const ts_packed_seq *)items[i].seq;
+                if (!ps || (!ps->codes && sp.len) || (ps->n_runs && !ps->runs)) return c->fail(TS_ERR_INVALID_ARG, "packed input: null codes or runs");
+                const uint64_t s0 = std::max<uint64_t>(sp.in_off + rg.start, b->in_lo);
+                const uint64_t s1 = std::min<uint64_t>(sp.in_off + rg.start + rg.len, b->in_hi);
+                if (s1 > s0) {
+                    UpPiece pc{s0, nullptr, s1 - s0, 0};
+                    pc.packed = ps; pc.packed_first = s0 - sp.in_off;
+                    pieces.push_back(pc);
                 }
             } else {
                 const uint64_t s0 = std::max<uint64_t>(sp.in_off + rg.start, b->in_lo);
@@ -775,7 +856,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                                            "than 32 or a non-ACGT pattern");
     for (size_t i : which)
         if (segs[i].input_format != TS_INPUT_BASES)
-            return c->fail(TS_ERR_UNSUPPORTED, "text-piece input is taken by the tiled kernel's parameter sets only: join the lines for this one");
+            return c->fail(TS_ERR_UNSUPPORTED, "text-piece and packed input are taken by the tiled kernel's parameter sets only: hand this one its bases");
     DEVICE_TRY(c);
     { int rc = ensure_streams(c); if (rc != TS_OK) return rc; }
     const ts_params &P = c->params;
@@ -1099,7 +1180,7 @@ int scan_segments_impl(ts_ctx *ctx, const ts_segment_in *segs, size_t n_segs, ts
     for (size_t i = 0; i < n_segs; ++i) {
         std::memset(&out[i], 0, sizeof out[i]);
         if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
-        if (segs[i].input_format > TS_INPUT_TEXT_PIECES) return ctx->fail(TS_ERR_INVALID_ARG, "unknown input_format");
+        if (segs[i].input_format > TS_INPUT_PACKED2) return ctx->fail(TS_ERR_INVALID_ARG, "unknown input_format");
     }
     std::vector<size_t> full, tips;
     for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
@@ -1143,7 +1224,7 @@ int ts_scan_segments_blocks(ts_ctx *ctx, const ts_segment_in *segs, size_t n_seg
         std::memset(&out[i], 0, sizeof out[i]);
         if (counts) counts[i] = ts_segment_counts{0, 0, 0, 0};
         if (segs[i].len && !segs[i].seq) return ctx->fail(TS_ERR_INVALID_ARG, "null sequence pointer");
-        if (segs[i].input_format > TS_INPUT_TEXT_PIECES) return ctx->fail(TS_ERR_INVALID_ARG, "unknown input_format");
+        if (segs[i].input_format > TS_INPUT_PACKED2) return ctx->fail(TS_ERR_INVALID_ARG, "unknown input_format");
     }
     std::vector<size_t> full, tips;
     for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);

@@ -12,9 +12,11 @@ namespace {
 // first byte; lead = bytes between the two (0..15).  packed: chunk position x at bits 2 (x & 3) of byte x >> 2, 4-byte
 // aligned, padded by 8 readable bytes; the chunk's first byte is position `first` (< 64: chunks are packed from a
 // 64-position boundary of the layout).
-__global__ __launch_bounds__(256)
+// (64-thread workgroups: these kernels run beside the scan of the group before, where a 256-thread workgroup cannot be
+// placed — blockcall.hip, kSideWg)
+__global__ __launch_bounds__(64)
 void ts_unpack_bases(const uint32_t *packed, uint32_t first, unsigned char *dst_aligned, uint32_t lead, unsigned long long n) {
-    const unsigned long long g = (unsigned long long)blockIdx.x * 256u + threadIdx.x;        // 16-byte group of the destination
+    const unsigned long long g = (unsigned long long)blockIdx.x * 64u + threadIdx.x;        // 16-byte group of the destination
     const unsigned long long b0 = g * 16ull;                                                  // its first byte, relative to dst_aligned
     if (b0 >= lead + n) return;
     // chunk position of that byte (negative for the group that holds the lead: handled by the byte path)
@@ -43,9 +45,9 @@ void ts_unpack_bases(const uint32_t *packed, uint32_t first, unsigned char *dst_
 }
 
 // One wave per invalid run {start, len} (positions relative to the chunk): 'N'.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64)
 void ts_poke_invalid(const uint2 *runs, uint32_t nruns, unsigned char *dst) {
-    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t r = blockIdx.x;
     if (r >= nruns) return;
     const uint2 run = runs[r];
     for (uint32_t i = threadIdx.x & 63u; i < run.y; i += 64u) dst[(unsigned long long)run.x + i] = (unsigned char)'N';
@@ -59,10 +61,10 @@ int ts_k_launch_unpack(const void *packed, uint32_t first, void *dst, unsigned l
     const uintptr_t a = (uintptr_t)dst;
     const uint32_t lead = (uint32_t)(a & 15u);
     const unsigned long long groups = (lead + n + 15ull) / 16ull;
-    hipLaunchKernelGGL(ts_unpack_bases, dim3((unsigned)((groups + 255ull) / 256ull)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(ts_unpack_bases, dim3((unsigned)((groups + 63ull) / 64ull)), dim3(64), 0, (hipStream_t)stream,
                        (const uint32_t *)packed, first, (unsigned char *)(a - lead), lead, n);
     if (nruns)
-        hipLaunchKernelGGL(ts_poke_invalid, dim3((nruns + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, (const uint2 *)runs, nruns,
+        hipLaunchKernelGGL(ts_poke_invalid, dim3(nruns), dim3(64), 0, (hipStream_t)stream, (const uint2 *)runs, nruns,
                            (unsigned char *)runs_base);
     return (int)hipGetLastError();
 }

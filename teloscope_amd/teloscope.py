@@ -185,8 +185,10 @@ class Teloscope:
     def usesFastPath(self):
         return bool(K.lib().ts_uses_fast_path(self._ctx.ptr))
 
-    def scanSegments(self, segments):
-        """Batched scanSegment: segments = [(sequence, absPos, tipsOnly)] -> [SegmentData]."""
+    def scanSegments(self, segments, packed=False):
+        """Batched scanSegment: segments = [(sequence, absPos, tipsOnly)] -> [SegmentData].
+        packed=True hands the bases over as TS_INPUT_PACKED2 (2-bit codes + invalid runs, packed here with ts_pack_bases and
+        this context's case folding): what a front end that packs while it parses would pass."""
         n = len(segments)
         seg_in = (K.SegmentIn * max(1, n))()
         keep = []
@@ -194,7 +196,13 @@ class Teloscope:
             if isinstance(seq, str):
                 seq = seq.encode()
             keep.append(seq)
-            seg_in[i].seq = seq
+            if packed:
+                ps, alive = K.pack_sequence(seq, self.userInput.foldCase)
+                keep.append((ps, alive))
+                seg_in[i].seq = C.cast(C.pointer(ps), C.c_char_p)
+                seg_in[i].input_format = K.TS_INPUT_PACKED2
+            else:
+                seg_in[i].seq = seq
             seg_in[i].len = len(seq)
             seg_in[i].abs_pos = abs_pos
             seg_in[i].tips_only = int(bool(tips))

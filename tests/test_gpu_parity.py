@@ -204,10 +204,19 @@ def test_packed_upload_route_equals_plain_route_and_oracle(cli, fold, monkeypatc
             s[30000:30256] = bytes(range(256))             # every byte value
         segs.append((bytes(s), int(rng.integers(0, 10 ** 7)), opts.ultra_fast))
     exp = None
-    for route in ("1", "0"):
-        monkeypatch.setenv("TS_PACKED_UPLOAD", route)
+    # ... and a third way in: the caller hands the bases over ALREADY packed (TS_INPUT_PACKED2: codes + invalid runs, here
+    # made by ts_pack_bases with the context's case folding) — the staging threads then copy codes, whole bytes where the
+    # phases agree (full scans) and shifted where they do not (the second region of a tips-only scan starts anywhere)
+    from teloscope_amd import _capi as K
+    takes_packed = bool(K.lib().ts_takes_text_input(tel._ctx.ptr, int(opts.ultra_fast)))     # (the tiled kernel's parameter sets)
+    for route in ("1", "0", "packed-in"):
+        if route == "packed-in" and not takes_packed:
+            with pytest.raises(K.TeloscanError):
+                tel.scanSegments(segs, packed=True)
+            continue
+        monkeypatch.setenv("TS_PACKED_UPLOAD", "1" if route == "packed-in" else route)
         monkeypatch.setenv("TS_PACKED_MIN_BYTES", "0")
-        got = [segment_as_dict(s) for s in tel.scanSegments(segs)]
+        got = [segment_as_dict(s) for s in tel.scanSegments(segs, packed=(route == "packed-in"))]
         if exp is None:
             # the oracle is strict scanSegment (lower case = non-ACGT): a context that folds case sees what the reference's
             # callers hand over after unmaskSequence
