@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence for bench.py on the GPU box (run through gpurun).
 # usage: bash profiles/run_profile.sh <round-tag>      -> gpurun_out/prof_<tag>/...
 set -e
-TAG=${1:-r02}
+TAG=${1:-r04}
 REPO=$(pwd)
 # build first, outside the profiler: bench.py must never spawn make / hipcc from a profiled, GPU-initialised process
 make -s -C $REPO/teloscope_amd/csrc && make -s -C $REPO/oracle

@@ -34,7 +34,7 @@ for f in find("*kernel_trace.csv"):
     for name, v in sorted(durs.items(), key=lambda kv: -sum(kv[1]))[:6]:
         print("   %-60s n=%d avg=%.1f us min=%.1f us max=%.1f us" % (name[:60], len(v), sum(v) / len(v) / 1e3,
                                                               min(v) / 1e3, max(v) / 1e3))
-        if "ts_scan_tiles" in name and len(v) > TIMED:
+        if "ts_scan_tiles" in name and ", false>" in name and len(v) > TIMED:      # the plain build: what `value` and `roofline` time
             # bench.py's roofline uses the timed launches only: the last TIMED of the run
             t = v[-TIMED:]
             print("   %-60s      timed launches only (the last %d of %d): n=%d avg=%.1f us" % ("", TIMED, len(v), len(t), sum(t) / len(t) / 1e3))
@@ -46,16 +46,28 @@ for f in find("*kernel_trace.csv"):
                 m = re.search(r'"kernel_ms": ([0-9.]+)', open(log, errors="replace").read())
                 if m:
                     print("   %-60s      bench.py in the same process (HIP events, roofline.kernel_ms): %.1f us" % ("", float(m.group(1)) * 1e3))
+def variant(name):
+    """The two builds of the scan kernel (kernels.hip, template EMIT): 'plain' leaves window records + match stream, 'emit' also
+    the visible records and per-tile chain summaries (the scans of the line's scan_plus_block_calling sub-record)."""
+    if "ts_scan_tiles" not in name:
+        return None
+    return "emit" if ", true>" in name else "plain"
+
+
 for f in find("*counter_collection.csv"):
-    acc = {}
+    acc = {"plain": {}, "emit": {}}
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "ts_scan_tiles" not in row.get("Kernel_Name", ""):
-                continue
-            acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-    print("== counters (ts_scan_tiles, per dispatch avg):", os.path.relpath(f, root))
-    for k, v in sorted(acc.items()):
-        print("   %-28s n=%d avg=%.6g" % (k, len(v), sum(v) / len(v)))
+            k = variant(row.get("Kernel_Name", ""))
+            if k:
+                acc[k].setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    for kind in ("plain", "emit"):
+        if not acc[kind]:
+            continue
+        print("== counters (ts_scan_tiles, %s build, per dispatch avg over the full-size dispatches):" % kind, os.path.relpath(f, root))
+        for k, v in sorted(acc[kind].items()):
+            big = [x for x in v if x >= 0.5 * max(v)]                # (the sub-record's settling runs include small dispatches)
+            print("   %-28s n=%d avg=%.6g" % (k, len(big), sum(big) / len(big)))
 
 # HBM bytes per launch of ts_scan_tiles for bench.py's roofline.traffic: FETCH_SIZE and WRITE_SIZE (KB, separate --pmc
 # passes; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream -> x2, WRITE_SIZE is exact for 16-byte
@@ -65,18 +77,28 @@ import hashlib
 import json
 
 fetch = write = None
+emit_fetch = emit_write = None
 for f in find("*counter_collection.csv"):
-    acc = {}
+    acc = {"plain": {}, "emit": {}}
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "ts_scan_tiles" in row.get("Kernel_Name", ""):
-                acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-    if "FETCH_SIZE" in acc:
-        v = acc["FETCH_SIZE"][5:] or acc["FETCH_SIZE"]
+            k = variant(row.get("Kernel_Name", ""))
+            if k:
+                acc[k].setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    if "FETCH_SIZE" in acc["plain"]:
+        v = acc["plain"]["FETCH_SIZE"][5:] or acc["plain"]["FETCH_SIZE"]
         fetch = sum(v) / len(v)
-    if "WRITE_SIZE" in acc:
-        v = acc["WRITE_SIZE"][5:] or acc["WRITE_SIZE"]
+    if "WRITE_SIZE" in acc["plain"]:
+        v = acc["plain"]["WRITE_SIZE"][5:] or acc["plain"]["WRITE_SIZE"]
         write = sum(v) / len(v)
+    if "FETCH_SIZE" in acc["emit"]:
+        v = acc["emit"]["FETCH_SIZE"]
+        v = [x for x in v if x >= 0.5 * max(v)]
+        emit_fetch = sum(v) / len(v)
+    if "WRITE_SIZE" in acc["emit"]:
+        v = acc["emit"]["WRITE_SIZE"]
+        v = [x for x in v if x >= 0.5 * max(v)]
+        emit_write = sum(v) / len(v)
 if fetch is not None and write is not None:
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(repo, "teloscope_amd", "csrc", "kernels.hip")
@@ -84,6 +106,7 @@ if fetch is not None and write is not None:
            "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
            "correction": "gfx950: FETCH_SIZE reports half of a wide coalesced read stream -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
            "hbm_bytes_per_launch": int(round((2 * fetch + write) * 1024)),
+           "emit_build_hbm_bytes_per_launch": int(round((2 * emit_fetch + emit_write) * 1024)) if emit_fetch is not None and emit_write is not None else None,
            "kernels_hip_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(),
            "source": "separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python3 bench.py --no-cpu-baseline --no-e2e` (profiles/run_profile.sh)"}
     with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
