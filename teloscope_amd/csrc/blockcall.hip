@@ -40,7 +40,26 @@ namespace {
 
 typedef unsigned long long u64;
 
-struct Cursor { uint32_t t, i; };            // record i of tile t
+// Two record formats.  The tiled kernel's (uniform length Q.k): position << 2 | forward << 1 | canonical.  The general
+// kernels' (generic.hip; Q.gen_lens != 0: up to eight pattern lengths, six bits each): position << 5 | length index << 2 |
+// canonical << 1 | forward.  Every load goes through rec_norm, which hands the code below the first form, and rec_len.
+__device__ __forceinline__ uint32_t rec_norm(const TsBlockCallParams &Q, uint32_t raw) {
+    return Q.gen_lens ? ((raw >> 5) << 2) | ((raw & 1u) << 1) | ((raw >> 1) & 1u) : raw;
+}
+__device__ __forceinline__ uint32_t rec_len(const TsBlockCallParams &Q, uint32_t raw) {
+    return Q.gen_lens ? (uint32_t)(Q.gen_lens >> (6u * ((raw >> 2) & 7u))) & 63u : Q.k;
+}
+// sum of v over the lanes of `mask` (wave-uniform result)
+__device__ __forceinline__ uint32_t masked_sum(uint32_t v, u64 mask) {
+    uint32_t x = ((mask >> (threadIdx.x & 63u)) & 1ull) ? v : 0u;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
 
 struct SegView {
     const TsTile *tiles;
@@ -55,43 +74,11 @@ struct SegView {
     u64 lo_rel, hi_rel;
 
     __device__ uint32_t count(uint32_t t) const { return tile_stats[4u * t]; }
-    __device__ uint32_t rec(Cursor c) const { return matches[tile_off[c.t] + c.i]; }
-    __device__ u64 pos(Cursor c, uint32_t r) const { return tiles[c.t].in_off - base + (r >> 2); }
-    __device__ bool next(Cursor &c) const {
-        if (c.i + 1u < count(c.t)) { ++c.i; return true; }
-        for (uint32_t t = c.t + 1u; t < t1; ++t)
-            if (count(t)) { c.t = t; c.i = 0; return true; }
-        return false;
-    }
-    __device__ bool prev(Cursor &c) const {
-        if (c.i > 0u) { --c.i; return true; }
-        for (uint32_t t = c.t; t > t0; --t)
-            if (count(t - 1u)) { c.t = t - 1u; c.i = count(t - 1u) - 1u; return true; }
-        return false;
-    }
-    __device__ bool first(Cursor &c) const {
-        for (uint32_t t = t0; t < t1; ++t)
-            if (count(t)) { c.t = t; c.i = 0; return true; }
-        return false;
-    }
-    __device__ bool last(Cursor &c) const {
-        for (uint32_t t = t1; t > t0; --t)
-            if (count(t - 1u)) { c.t = t - 1u; c.i = count(t - 1u) - 1u; return true; }
-        return false;
-    }
 };
 
 struct Chain {                               // running chain of matches (startNewBlock / extend)
     u64 start, end, prev;
     uint32_t counts, fwd, canon, cov, fwd_cov, can_cov;
-    __device__ void begin(u64 p, uint32_t r, uint32_t k) {
-        start = p; end = p + k; prev = p; counts = 1;
-        fwd = (r >> 1) & 1u; canon = r & 1u; cov = k; fwd_cov = fwd * k; can_cov = canon * k;
-    }
-    __device__ void add(u64 p, uint32_t r, uint32_t k) {
-        ++counts; const uint32_t f = (r >> 1) & 1u, c = r & 1u;
-        fwd += f; canon += c; cov += k; fwd_cov += f * k; can_cov += c * k; prev = p;
-    }
     __device__ void to_block(TsDevBlock &b) const {
         b.start = start; b.block_len = (uint32_t)(end - start); b.block_counts = counts;
         b.forward_count = fwd; b.reverse_count = counts - fwd; b.canonical_count = canon;
@@ -203,14 +190,16 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
           for (uint32_t q = 0; q < 8u; ++q) {
               const uint32_t bq = b4 + 64u * q;
               const uint32_t idx = from_start ? bq + lane : cnt - 1u - bq - lane;      // walk order
-              recs[q] = bq + lane < cnt ? V.matches[off + idx] : 0u;
+              recs[q] = bq + lane < cnt ? V.matches[off + idx] : 0u;      // (raw: normalised where a row is taken up)
           }
 #pragma unroll
           for (uint32_t q = 0; q < 8u; ++q) {
             const uint32_t b0 = b4 + 64u * q;
             if (b0 >= cnt || stop) break;
             const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
-            const uint32_t rec = recs[q];
+            const uint32_t lenv = rec_len(Q, recs[q]);       // this lane's match length (Q.k for the tiled kernel's records)
+            const uint32_t rec = rec_norm(Q, recs[q]);
+            const bool uni = Q.gen_lens == 0ull;             // uniform length: covered bases = records x k
             const bool sel = lane < nb && (((rec >> 1) & 1u) != 0u) == from_start;      // forward list from the start, reverse from the end
             u64 rem = __ballot(sel);
             if (rem == 0ull) continue;
@@ -240,9 +229,11 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
                 const uint32_t nrun = (uint32_t)__popcll(pre), ncan = (uint32_t)__popcll(pre & canon);
                 const uint32_t nfwd = from_start ? nrun : 0u;                              // the list has one orientation
                 ch.counts += nrun; ch.fwd += nfwd; ch.canon += ncan;
-                ch.cov += nrun * Q.k; ch.fwd_cov += nfwd * Q.k; ch.can_cov += ncan * Q.k;
-                ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(pre));
-                if (from_start) ch.end = ch.prev + Q.k; else ch.start = ch.prev;
+                const uint32_t cov_pre = uni ? nrun * Q.k : masked_sum(lenv, pre), can_pre = uni ? ncan * Q.k : masked_sum(lenv, pre & canon);
+                ch.cov += cov_pre; ch.fwd_cov += from_start ? cov_pre : 0u; ch.can_cov += can_pre;
+                const int last_pre = 63 - (int)__builtin_clzll(pre);
+                ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, last_pre);
+                if (from_start) ch.end = ch.prev + (uint32_t)__builtin_amdgcn_readlane((int)lenv, last_pre); else ch.start = ch.prev;
             }
             if (open && h_all) close_sub();
             if (h_live) {
@@ -253,6 +244,7 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
                 const uint32_t nrun_l = (uint32_t)__popcll(mine), ncan_l = (uint32_t)__popcll(mine & canon);
                 const uint32_t last_l = mine ? 63u - (uint32_t)__builtin_clzll(mine) : lane;
                 const uint32_t p_last_l = (uint32_t)__shfl((int)p32, (int)last_l);
+                const uint32_t len_last_l = (uint32_t)__shfl((int)lenv, (int)last_l);           // length of the chain's last record in walk order
                 u64 sub = __ballot(((h_live >> lane) & 1ull) && next < 64u && nrun_l >= Q.min_block_counts && ncan_l > 0u);
                 while (sub) {                              // the complete chains that may be sub-blocks, in walk order
                     const int i = (int)__builtin_ctzll(sub);
@@ -263,9 +255,17 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
                     const uint32_t ncan = (uint32_t)__builtin_amdgcn_readlane((int)ncan_l, i);
                     const uint32_t nfwd = from_start ? nrun : 0u;
                     ch.prev = p_end;
-                    if (from_start) { ch.start = p_head; ch.end = p_end + Q.k; } else { ch.start = p_end; ch.end = p_head + Q.k; }
+                    // (a chain's end = its last record in POSITION order + that record's length: the walk's last record from the
+                    // start, its first from the end)
+                    if (from_start) { ch.start = p_head; ch.end = p_end + (uint32_t)__builtin_amdgcn_readlane((int)len_last_l, i); }
+                    else { ch.start = p_end; ch.end = p_head + (uint32_t)__builtin_amdgcn_readlane((int)lenv, i); }
                     ch.counts = nrun; ch.fwd = nfwd; ch.canon = ncan;
-                    ch.cov = nrun * Q.k; ch.fwd_cov = nfwd * Q.k; ch.can_cov = ncan * Q.k;
+                    if (uni) { ch.cov = nrun * Q.k; ch.can_cov = ncan * Q.k; }
+                    else {
+                        const u64 mine_i = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), i) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, i);
+                        ch.cov = masked_sum(lenv, mine_i); ch.can_cov = masked_sum(lenv, mine_i & canon);
+                    }
+                    ch.fwd_cov = from_start ? ch.cov : 0u;
                     open = true;
                     close_sub();
                 }
@@ -275,10 +275,13 @@ __device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, 
                     const uint32_t nrun = (uint32_t)__popcll(tail), ncan = (uint32_t)__popcll(tail & canon);
                     const uint32_t nfwd = from_start ? nrun : 0u;
                     const u64 p_head = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)top);
-                    ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(tail));
-                    if (from_start) { ch.start = p_head; ch.end = ch.prev + Q.k; } else { ch.start = ch.prev; ch.end = p_head + Q.k; }
+                    const int last_tail = 63 - (int)__builtin_clzll(tail);
+                    ch.prev = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, last_tail);
+                    if (from_start) { ch.start = p_head; ch.end = ch.prev + (uint32_t)__builtin_amdgcn_readlane((int)lenv, last_tail); }
+                    else { ch.start = ch.prev; ch.end = p_head + (uint32_t)__builtin_amdgcn_readlane((int)lenv, (int)top); }
                     ch.counts = nrun; ch.fwd = nfwd; ch.canon = ncan;
-                    ch.cov = nrun * Q.k; ch.fwd_cov = nfwd * Q.k; ch.can_cov = ncan * Q.k;
+                    ch.cov = uni ? nrun * Q.k : masked_sum(lenv, tail); ch.can_cov = uni ? ncan * Q.k : masked_sum(lenv, tail & canon);
+                    ch.fwd_cov = from_start ? ch.cov : 0u;
                     open = true;
                 }
             }
@@ -413,6 +416,7 @@ __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const T
     const uint32_t lane = threadIdx.x & 63u;
     u64 start = 0, prev = 0;
     uint32_t counts = 0, fwd = 0, canon = 0;
+    uint32_t last_len = Q.k, cov = 0, fwd_cov = 0, can_cov = 0;       // (general records: length of the chain's last record, covered bases)
     bool first = true, closed = false;
     for (uint32_t t = t0; t < S.t1 && !closed; ++t) {
         const uint32_t cnt = Q.tile_stats[4u * t];
@@ -423,7 +427,8 @@ __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const T
         for (uint32_t b0 = (t == t0 ? i0 : 0u); b0 < cnt && !closed; b0 += 64u) {
             const uint32_t nvalid = cnt - b0 < 64u ? cnt - b0 : 64u;
             const u64 VALID = low_bits(nvalid);
-            const uint32_t r = lane < nvalid ? src[b0 + lane] : 0u;
+            const uint32_t raw = lane < nvalid ? src[b0 + lane] : 0u;
+            const uint32_t r = rec_norm(Q, raw), lenv = rec_len(Q, raw);
             const uint32_t p32 = r >> 2;
             const uint32_t below = lane_below(p32);
             // records that end the chain: out of range, or too far behind their predecessor (lane 0: the last record of the
@@ -439,13 +444,20 @@ __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const T
                 counts += (uint32_t)__popcll(take);
                 fwd += (uint32_t)__popcll(__ballot((r & 2u) != 0u) & take);
                 canon += (uint32_t)__popcll(__ballot((r & 1u) != 0u) & take);
-                prev = rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, 63 - (int)__builtin_clzll(take));
+                const int last_take = 63 - (int)__builtin_clzll(take);
+                prev = rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, last_take);
+                last_len = (uint32_t)__builtin_amdgcn_readlane((int)lenv, last_take);
+                if (Q.gen_lens) {                           // covered bases: the records' own lengths
+                    cov += masked_sum(lenv, take);
+                    fwd_cov += masked_sum(lenv, __ballot((r & 2u) != 0u) & take);
+                    can_cov += masked_sum(lenv, __ballot((r & 1u) != 0u) & take);
+                }
             }
             if (E) closed = true;
         }
     }
     if (first) return;
-    const uint32_t blen = (uint32_t)(prev + Q.k - start);
+    const uint32_t blen = (uint32_t)(prev + last_len - start);
     if (canon < 4u || blen < Q.its_min_len) return;
     const char lab = its_label(fwd, counts);
     if (lab == 'b' && fwd < 2u && (counts - fwd) < 2u) return;
@@ -453,8 +465,9 @@ __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const T
     TsDevBlock b;
     b.start = start; b.block_len = blen; b.block_counts = counts;
     b.forward_count = fwd; b.reverse_count = counts - fwd; b.canonical_count = canon;
-    b.non_canonical_count = counts - canon; b.total_covered = counts * Q.k; b.fwd_covered = fwd * Q.k;
-    b.can_covered = canon * Q.k; b.has_valid_or = 1; b.is_longest = 0; b.block_label = lab; b.reserved = 0;
+    b.non_canonical_count = counts - canon;
+    b.total_covered = Q.gen_lens ? cov : counts * Q.k; b.fwd_covered = Q.gen_lens ? fwd_cov : fwd * Q.k;
+    b.can_covered = Q.gen_lens ? can_cov : canon * Q.k; b.has_valid_or = 1; b.is_longest = 0; b.block_label = lab; b.reserved = 0;
     emit_block(Q, b, S.seg, 2u, 0u, S.abs_pos);
 }
 
@@ -510,8 +523,8 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
     constexpr uint32_t kGroup = 8;                         // batches of 64 records requested together
     uint32_t recs[kGroup];
 #pragma unroll
-    for (uint32_t q = 0; q < kGroup; ++q) recs[q] = 64u * q + lane < cnt ? src[64u * q + lane] : 0u;
-    const uint32_t next_rec = (tn != tile && lane < next_cnt) ? Q.matches[next_off + lane] : 0u;
+    for (uint32_t q = 0; q < kGroup; ++q) recs[q] = 64u * q + lane < cnt ? rec_norm(Q, src[64u * q + lane]) : 0u;
+    const uint32_t next_rec = (tn != tile && lane < next_cnt) ? rec_norm(Q, Q.matches[next_off + lane]) : 0u;
 
     // the record ahead of the tile's first one (head test of that record), as a position relative to the tile (negative)
     bool has_last = false;
@@ -522,14 +535,14 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
         bool found = false;
         u64 last_pos = 0;
         if (tile > S.t0 && prev_cnt) {                     // the usual case: the tile before holds it
-            const uint32_t r = Q.matches[prev_off + prev_cnt - 1u];
+            const uint32_t r = rec_norm(Q, Q.matches[prev_off + prev_cnt - 1u]);
             last_pos = prev_in_off - S.in_off + (r >> 2);
             found = true;
         } else {
             for (uint32_t t = tile; t > S.t0; --t) {
                 const uint32_t c = Q.tile_stats[4u * (t - 1u)];
                 if (c) {
-                    const uint32_t r = Q.matches[Q.tile_off[t - 1u] + c - 1u];
+                    const uint32_t r = rec_norm(Q, Q.matches[Q.tile_off[t - 1u] + c - 1u]);
                     last_pos = Q.tiles[t - 1u].in_off - S.in_off + (r >> 2);
                     found = true;
                     break;
@@ -674,13 +687,13 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
         for (uint32_t q = 0; q < kGroup; ++q)
             if (64u * q < cnt) fast_batch(64u * q, recs[q]);
         for (uint32_t b0 = 64u * kGroup; b0 < cnt; b0 += 64u)           // a dense tile: the rest, batch by batch
-            fast_batch(b0, b0 + lane < cnt ? src[b0 + lane] : 0u);
+            fast_batch(b0, b0 + lane < cnt ? rec_norm(Q, src[b0 + lane]) : 0u);
     } else {
 #pragma unroll
         for (uint32_t q = 0; q < kGroup; ++q)
             if (64u * q < cnt) batch(64u * q, recs[q]);
         for (uint32_t b0 = 64u * kGroup; b0 < cnt; b0 += 64u)
-            batch(b0, b0 + lane < cnt ? src[b0 + lane] : 0u);
+            batch(b0, b0 + lane < cnt ? rec_norm(Q, src[b0 + lane]) : 0u);
     }
     // the chain that is still open belongs to this tile: follow it through the tiles behind until a head closes it
     if (its_on && open && !finished) {
@@ -695,7 +708,7 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
             const uint32_t *src2 = Q.matches + (pre_fetched ? next_off : Q.tile_off[t]);
             const uint32_t rb2 = rb <= rel2 ? 0u : (rb - rel2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(rb - rel2));
             for (uint32_t b0 = 0; b0 < c2 && !closed; b0 += 64u) {
-                const uint32_t r = (pre_fetched && b0 == 0u) ? next_rec : (b0 + lane < c2 ? src2[b0 + lane] : 0u);
+                const uint32_t r = (pre_fetched && b0 == 0u) ? next_rec : (b0 + lane < c2 ? rec_norm(Q, src2[b0 + lane]) : 0u);
                 const uint32_t nvalid = c2 - b0 < 64u ? c2 - b0 : 64u;
                 const u64 VALID = low_bits(nvalid);
                 const uint32_t p32 = r >> 2;

@@ -1141,7 +1141,7 @@ int ts_batch_segment_summary(ts_batch *b, void *d_out, void *stream) {
 // becomes the segment's match array.
 int ts_finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos,
                         const uint32_t *win_raw, uint64_t n_windows, ts_match *matches, uint64_t nm,
-                        ts_segment_out &o, unsigned spare_threads) {
+                        ts_segment_out &o, unsigned spare_threads, const TsDevBlock *pre_blocks, size_t n_pre, bool have_pre) {
     const ts_params &P = c->params;
     std::memset(&o, 0, sizeof o);
     if (!tips && n_windows) {
@@ -1211,12 +1211,21 @@ int ts_finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos
     // the two walks take their orientation's records out of the one position-ordered array (they leave the
     // terminal zone after a few thousand records: no per-orientation index lists of the whole segment)
     std::vector<ts_block> term, its;
+    if (have_pre) {
+        // the blocks were called on the device (sorted: terminal blocks in push order, then interstitial blocks by start)
+        for (size_t q = 0; q < n_pre; ++q) {
+            ts_block b;
+            std::memcpy(&b, &pre_blocks[q], sizeof b);
+            (pre_blocks[q].kind == 2 ? its : term).push_back(b);
+        }
+    }
     uint64_t fwd_boundary = abs_pos, rev_boundary = abs_pos + seg_len;
-    if (nfwd >= 2)
+    if (have_pre) {
+    } else if (nfwd >= 2)
         fwd_boundary = ts::terminal_blocks(c->bp, o.matches, nullptr, nm, term, seg_len, abs_pos, true, 1);
-    if (nm - nfwd >= 2)
+    if (!have_pre && nm - nfwd >= 2)
         rev_boundary = ts::terminal_blocks(c->bp, o.matches, nullptr, nm, term, seg_len, abs_pos, false, 0);
-    if (!tips && fwd_boundary < rev_boundary && nm >= 2)
+    if (!have_pre && !tips && fwd_boundary < rev_boundary && nm >= 2)
         ts::interstitial_blocks(c->bp, o.matches, nm, its, fwd_boundary, rev_boundary);
     auto copy_blocks = [&](const std::vector<ts_block> &v, ts_block *&dst, uint64_t &n) -> bool {
         n = v.size();
@@ -1346,30 +1355,26 @@ void parallel_for(size_t n, unsigned max_threads, F &&f) {
 // Block calling ON THE DEVICE (getTerminalBlocks / getInterstitialBlocks, src/teloscope.cpp:29-256) over the
 // batch's resident match stream: the blocks of all segments, sorted by (segment; terminal blocks in push order:
 // forward walk then reverse walk; interstitial blocks by start).
-int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &blocks) {
-    ts_ctx *c = b->ctx;
+}  // namespace
+
+// Block calling on the device over ANY resident match stream addressed by a tile directory: the tiled kernel's (a batch) or the
+// general kernels' dense stream (gen_lens != 0: their record format and pattern lengths, ts_internal.h).  tab: the kernels'
+// per-segment table; sums_out (nullable): the per-segment sums {matches, forward (seen), matches, canonical, forward (owned)}.
+int ts_device_block_call_raw(ts_ctx *c, const TsTile *d_tiles, const unsigned long long *d_tile_off, const uint32_t *d_stats,
+                             const uint32_t *d_matches, uint64_t n_matches_hint, const std::vector<TsShardSegIn> &tab, size_t nt,
+                             bool tips, unsigned long long gen_lens, const uint32_t *d_chain, uint32_t *d_work, hipStream_t st,
+                             std::vector<TsDevBlock> &blocks, std::vector<unsigned long long> *sums_out) {
     const ts_params &P = c->params;
-    const size_t ns = b->segs.size(), nt = b->tiles.size();
+    const size_t ns = tab.size();
     blocks.clear();
+    if (sums_out) sums_out->assign(ns * 5, 0ull);
     if (!ns) return TS_OK;
-    // segment table of the kernels (a whole batch: every segment with all its tiles, both ends its own)
     const size_t off_bounds = ns * sizeof(TsShardSegIn), off_count = off_bounds + ns * 16, off_sums = off_count + 16, tab_bytes = off_sums + ns * 40;
-    std::vector<TsShardSegIn> tab(ns);
-    for (size_t i = 0; i < ns; ++i) {
-        TsShardSegIn &S = tab[i];
-        S.in_off = b->segs[i].in_off; S.len = b->segs[i].len; S.abs_pos = b->segs[i].abs_pos;
-        S.t0 = S.o0 = b->segs[i].first_tile;
-        S.t1 = S.o1 = b->segs[i].first_tile + b->segs[i].n_tiles;
-        S.flags = TS_SEG_F_HAS_START | TS_SEG_F_HAS_END;
-        S.lo_rel = 0; S.hi_rel = b->segs[i].len;
-        S.seg = (uint32_t)i;
-    }
-    (void)nt;
     DevBuf d_tab, d_blocks;
     struct Return { ts_ctx *c; DevBuf &a, &b2; ~Return() { c->pool.give(std::move(a)); c->pool.give(std::move(b2)); } } give_back{c, d_tab, d_blocks};
     HIP_TRY(c, c->pool.take(tab_bytes, d_tab));
     char *const dt = (char *)d_tab.p;
-    uint32_t cap = (uint32_t)std::min<uint64_t>(64ull * ns + 4096 + b->n_matches / 256, 1u << 26);
+    uint32_t cap = (uint32_t)std::min<uint64_t>(64ull * ns + 4096 + n_matches_hint / 256, 1u << 26);
     bool done = false;
     for (int attempt = 0; attempt < 6 && !done; ++attempt) {
         // (behind the blocks: the list of chains the interstitial screening hands to its evaluation kernel)
@@ -1379,10 +1384,10 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
         HIP_TRY(c, hipMemcpyAsync(dt, tab.data(), off_bounds, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemsetAsync(dt + off_count, 0, 16, st));
         TsBlockCallParams Q{};
-        Q.tiles = (const TsTile *)b->d_tiles.p;
-        Q.tile_off = (const unsigned long long *)b->d_tile_off.p;
-        Q.tile_stats = b->stats_ptr();
-        Q.matches = b->records_ptr();
+        Q.tiles = d_tiles;
+        Q.tile_off = d_tile_off;
+        Q.tile_stats = d_stats;
+        Q.matches = d_matches;
         Q.blocks = (TsDevBlock *)d_blocks.p;
         Q.n_blocks = (uint32_t *)(dt + off_count);
         Q.block_cap = cap;
@@ -1393,18 +1398,13 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
         Q.min_block_len = P.min_block_len; Q.max_block_dist = P.max_block_dist;
         Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;
         Q.k = c->k; Q.its_min_len = (uint32_t)(uint16_t)(2 * c->bp.first_pattern_len);
-        // (with the scan's chain summaries the interstitial search screens the tiles and walks only the listed ones)
-        const bool from_scan = b->chain_valid() && !b->tips;
-        if (from_scan && b->d_scan_tmp.bytes < (nt + 2) * 4) {
-            c->pool.give(std::move(b->d_scan_tmp));
-            HIP_TRY(c, c->pool.take((nt + 2) * 4, b->d_scan_tmp));
-        }
+        Q.gen_lens = gen_lens;
         if (ts_k_launch_block_call(&Q, (const TsShardSegIn *)dt, (uint32_t)ns, 0u, (uint32_t)nt, (unsigned long long *)(dt + off_bounds),
-                                   nullptr, b->tips ? 0 : 1, nullptr, (unsigned long long *)(dt + off_sums),
-                                   from_scan ? (const uint32_t *)b->d_chain.p : nullptr, from_scan ? (uint32_t *)b->d_scan_tmp.p : nullptr, st) != 0)
+                                   nullptr, tips ? 0 : 1, nullptr, (unsigned long long *)(dt + off_sums), d_chain, d_work, st) != 0)
             return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
         uint32_t nb = 0;
         HIP_TRY(c, hipMemcpyAsync(&nb, dt + off_count, 4, hipMemcpyDeviceToHost, st));
+        if (sums_out) HIP_TRY(c, hipMemcpyAsync(sums_out->data(), dt + off_sums, ns * 40, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         if (nb > cap) { cap = nb + 1024; c->pool.give(std::move(d_blocks)); continue; }   // rare: more blocks than provisioned, rerun
         blocks.resize(nb);
@@ -1424,6 +1424,33 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
         return x.kind != y.kind ? x.kind < y.kind : x.seq < y.seq;
     });
     return TS_OK;
+}
+
+namespace {
+
+int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &blocks) {
+    ts_ctx *c = b->ctx;
+    const size_t ns = b->segs.size(), nt = b->tiles.size();
+    // segment table of the kernels (a whole batch: every segment with all its tiles, both ends its own)
+    std::vector<TsShardSegIn> tab(ns);
+    for (size_t i = 0; i < ns; ++i) {
+        TsShardSegIn &S = tab[i];
+        S.in_off = b->segs[i].in_off; S.len = b->segs[i].len; S.abs_pos = b->segs[i].abs_pos;
+        S.t0 = S.o0 = b->segs[i].first_tile;
+        S.t1 = S.o1 = b->segs[i].first_tile + b->segs[i].n_tiles;
+        S.flags = TS_SEG_F_HAS_START | TS_SEG_F_HAS_END;
+        S.lo_rel = 0; S.hi_rel = b->segs[i].len;
+        S.seg = (uint32_t)i;
+    }
+    // (with the scan's chain summaries the interstitial search screens the tiles and walks only the listed ones)
+    const bool from_scan = b->chain_valid() && !b->tips;
+    if (from_scan && b->d_scan_tmp.bytes < (nt + 2) * 4) {
+        c->pool.give(std::move(b->d_scan_tmp));
+        HIP_TRY(c, c->pool.take((nt + 2) * 4, b->d_scan_tmp));
+    }
+    return ts_device_block_call_raw(c, (const TsTile *)b->d_tiles.p, (const unsigned long long *)b->d_tile_off.p, b->stats_ptr(),
+                                    b->records_ptr(), b->n_matches, tab, nt, b->tips, 0ull,
+                                    from_scan ? (const uint32_t *)b->d_chain.p : nullptr, from_scan ? (uint32_t *)b->d_scan_tmp.p : nullptr, st, blocks, nullptr);
 }
 
 unsigned finalize_threads() {

@@ -268,8 +268,14 @@ int  ts_pipeline_upload_batch(ts_batch *b, const ts_segment_in *segs, int *slot,
 bool ts_full_scan_supported(const ts_ctx *c, std::string &why);
 void *ts_alloc_large(size_t bytes);     // malloc-compatible; many-MB arrays on 2 MB pages when the kernel grants them
 int  ts_finalize_segment(ts_ctx *c, bool tips, uint64_t seg_len, uint64_t abs_pos, const uint32_t *win_raw,
-                         uint64_t n_windows, ts_match *matches, uint64_t nm, ts_segment_out &o, unsigned spare_threads);
+                         uint64_t n_windows, ts_match *matches, uint64_t nm, ts_segment_out &o, unsigned spare_threads,
+                         const TsDevBlock *pre_blocks = nullptr, size_t n_pre = 0, bool have_pre = false);   // have_pre: blocks called on the device
 int  ts_batch_ensure_device(ts_batch *b);        // allocates the range's device state (idempotent)
+// block calling on the device over a resident match stream + tile directory (a batch's, or the general kernels' dense stream)
+int  ts_device_block_call_raw(ts_ctx *c, const TsTile *d_tiles, const unsigned long long *d_tile_off, const uint32_t *d_stats,
+                              const uint32_t *d_matches, uint64_t n_matches_hint, const std::vector<TsShardSegIn> &tab, size_t nt,
+                              bool tips, unsigned long long gen_lens, const uint32_t *d_chain, uint32_t *d_work, hipStream_t st,
+                              std::vector<TsDevBlock> &blocks, std::vector<unsigned long long> *sums_out);
 void ts_batch_release_input(ts_batch *b);        // returns the batch's input buffer to the context's pool
 void *ts_batch_input_ptr_nozero(ts_batch *b);
 struct ts_fetched;                               // what a download left in host memory, before post-processing

@@ -689,6 +689,44 @@ int ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tile
     return (int)hipGetLastError();
 }
 
+namespace {
+// What block calling on the device (blockcall.hip) needs of a group scanned by the kernels above: per tile a TsTile whose
+// in_off - (its segment's base) is the tile's segment-relative position, and the canonical / forward counts of its records in
+// the tile directory (words 1 and 2; the fused pass leaves only the count).  One wave per tile over the dense stream.
+__global__ __launch_bounds__(64)
+void ts_general_block_inputs(const TsGeneralTile *gtiles, const u64 *tile_off, const uint32_t *dense, const u64 *seg_base,
+                             uint32_t ntiles, TsTile *tiles, uint32_t *tile_stats) {
+    const uint32_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    const uint32_t lane = threadIdx.x;
+    const TsGeneralTile G = gtiles[t];
+    const uint32_t n = tile_stats[4ull * t];
+    const uint32_t *src = dense + tile_off[t];
+    uint32_t ncan = 0, nfwd = 0;
+    for (uint32_t i = lane; i < n; i += 64u) {
+        const uint32_t r = src[i];
+        nfwd += r & 1u; ncan += (r >> 1) & 1u;                 // (general records: forward is bit 0, canonical bit 1)
+    }
+    ncan = wave_total(ncan); nfwd = wave_total(nfwd);
+    if (lane == 0u) {
+        tile_stats[4ull * t + 1u] = ncan;
+        tile_stats[4ull * t + 2u] = nfwd;
+        TsTile T{};
+        T.in_off = seg_base[G.seg] + G.seg_rel;
+        T.own_len = G.n; T.nrel = G.n; T.nwin = 0; T.win_out = 0; T.seg = G.seg;
+        tiles[t] = T;
+    }
+}
+}  // namespace
+
+int ts_k_launch_general_block_inputs(const TsGeneralTile *gtiles, const unsigned long long *tile_off, const uint32_t *dense,
+                                     const unsigned long long *seg_base, uint32_t ntiles, TsTile *tiles, uint32_t *tile_stats, void *stream) {
+    if (ntiles == 0) return 0;
+    hipLaunchKernelGGL(ts_general_block_inputs, dim3(ntiles), dim3(64), 0, (hipStream_t)stream, gtiles, (const u64 *)tile_off, dense,
+                       (const u64 *)seg_base, ntiles, tiles, tile_stats);
+    return (int)hipGetLastError();
+}
+
 int ts_k_launch_general_compact(const uint32_t *tile_stats, const unsigned long long *tile_off, const uint32_t *records,
                                 uint32_t slot_cap, uint32_t ntiles, uint32_t *dense, void *stream) {
     if (ntiles == 0) return 0;

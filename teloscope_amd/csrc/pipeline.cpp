@@ -848,8 +848,10 @@ int submit_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &
 // mixed-length sets can be out of position order at all), expands them and calls blocks (ts_finalize_segment).
 std::atomic<uint64_t> ts_gen_ns[2];       // TS_TIMING: job time in record expansion / in ts_finalize_segment
 
+// blocks_only: the caller reads no match vectors (ts_scan_segments_blocks) — where the blocks can be called on the device
+// the match records then never leave it; counts (nullable): the sizes the vectors would have had.
 int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<size_t> &which,
-                       bool tips, ts_segment_out *out) {
+                       bool tips, ts_segment_out *out, bool blocks_only = false, ts_segment_counts *counts = nullptr) {
     if (which.empty()) return TS_OK;
     if (!c->generic_ok)
         return c->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: more than 8 pattern lengths, a pattern longer "
@@ -880,7 +882,20 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     // The host stage of group g (ordering + block calling on the host threads) runs on a background thread while the
     // device stage of group g + 1 (upload, kernels, D2H) runs here: what a group's host stage reads lives in a GroupHost.
     struct GroupHost { std::vector<SegL> G; std::vector<TsGeneralTile> tiles; std::vector<unsigned long long> tile_off;
-                       std::vector<uint32_t> recs_heap, wins_heap; const uint32_t *recs = nullptr, *wins = nullptr; };
+                       std::vector<uint32_t> recs_heap, wins_heap; const uint32_t *recs = nullptr, *wins = nullptr;
+                       bool dev_blocks = false; std::vector<TsDevBlock> blocks; std::vector<unsigned long long> sums; };
+    // Block calling on the device (blockcall.hip with the general record format) wherever the match stream is in the order
+    // the reference calls blocks over: tips-only scans and w == s always (position order), w > s when the pattern lengths
+    // differ by at most one (the record that ends later is never pushed earlier: end positions are monotone in stream
+    // order, hence so is the pushing window).  Sets with a length gap of two or more under w > s keep the host path: the
+    // reference's lower_bound runs over a stream that is not quite sorted there, and that is restated on the
+    // host only.  TS_GEN_HOST_BLOCKS=1 forces the host path (A/B, tests).
+    const bool dev_blocks_ok = !(getenv("TS_GEN_HOST_BLOCKS") && getenv("TS_GEN_HOST_BLOCKS")[0] == '1') && c->gpat.nlen >= 1 &&
+                               (tips || ov == 0 || c->gpat.len[c->gpat.nlen - 1] - c->gpat.len[0] <= 1u);
+    unsigned long long gen_lens = 0;
+    for (uint32_t li = 0; li < c->gpat.nlen && li < 8u; ++li) gen_lens |= (unsigned long long)(c->gpat.len[li] & 63u) << (6u * li);
+    if (c->gpat.nlen && c->gpat.len[c->gpat.nlen - 1] > 63u) gen_lens = 0;
+    const bool skip_records = blocks_only && dev_blocks_ok && gen_lens != 0;
     size_t group_no = 0;
     std::thread host_job;
     std::atomic<int> host_err{TS_OK};
@@ -999,10 +1014,39 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 return c->fail(TS_ERR_HIP, "general compact kernel launch failed");
             if (timing) HIP_TRY(c, hipEventRecord(c->gen_ev[1], st));
         }
+        if (dev_blocks_ok && gen_lens != 0) {
+            // ---- blocks on the device: the tiles as blockcall.hip addresses them, the canonical / forward counts, then the walks
+            DevBuf d_bct, d_sbase;
+            struct Ret2 { ts_ctx *c; DevBuf &a, &b2; ~Ret2() { c->pool.give(std::move(a)); c->pool.give(std::move(b2)); } } give2{c, d_bct, d_sbase};
+            HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * sizeof(TsTile), d_bct));
+            HIP_TRY(c, c->pool.take(std::max<size_t>(ns, 1) * 8, d_sbase));
+            std::vector<unsigned long long> sbase(std::max<size_t>(ns, 1), 0ull);
+            std::vector<TsShardSegIn> segtab(ns);
+            unsigned long long X = 0;
+            for (size_t i = 0; i < ns; ++i) {
+                sbase[i] = X;
+                TsShardSegIn &S = segtab[i];
+                S = TsShardSegIn{};
+                S.in_off = X; S.len = G[i].len; S.abs_pos = G[i].abs_pos;
+                S.t0 = S.o0 = (uint32_t)G[i].first_tile; S.t1 = S.o1 = (uint32_t)(G[i].first_tile + G[i].n_tiles);
+                S.flags = TS_SEG_F_HAS_START | TS_SEG_F_HAS_END;
+                S.lo_rel = 0; S.hi_rel = G[i].len; S.seg = (uint32_t)i;
+                X += G[i].len + 64;
+            }
+            HIP_TRY(c, hipMemcpyAsync(d_sbase.p, sbase.data(), sbase.size() * 8, hipMemcpyHostToDevice, st));
+            if (ts_k_launch_general_block_inputs((const TsGeneralTile *)d_tiles.p, (const unsigned long long *)d_off.p, (const uint32_t *)d_rec.p,
+                                                 (const unsigned long long *)d_sbase.p, (uint32_t)nt, (TsTile *)d_bct.p, (uint32_t *)d_stats.p, st) != 0)
+                return c->fail(TS_ERR_HIP, "general block-input kernel launch failed");
+            int rc = ts_device_block_call_raw(c, (const TsTile *)d_bct.p, (const unsigned long long *)d_off.p, (const uint32_t *)d_stats.p,
+                                              (const uint32_t *)d_rec.p, nrec, segtab, nt, tips, gen_lens, nullptr, nullptr, st, gh->blocks, &gh->sums);
+            if (rc != TS_OK) return rc;
+            gh->dev_blocks = true;
+        }
         // landing area: the context's pinned download buffers, alternating by group (the host stage of group g reads
         // its buffer while group g + 1 lands in the other; it has been joined before group g + 2 arrives)
         {
-            const size_t rec_bytes = ((size_t)nrec * 4 + 255) & ~(size_t)255, win_bytes = (size_t)nwin_total * 32;
+            const uint64_t nrec_dl = skip_records ? 0 : nrec;
+            const size_t rec_bytes = ((size_t)nrec_dl * 4 + 255) & ~(size_t)255, win_bytes = (size_t)nwin_total * 32;
             PinBuf &pb = c->pin_down[group_no & 1];
             ++group_no;
             uint32_t *hrec, *hwin;
@@ -1011,12 +1055,12 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 hwin = (uint32_t *)((char *)pb.p + rec_bytes);
             } else {
                 (void)hipGetLastError();
-                gh->recs_heap.resize(nrec + 1);
+                gh->recs_heap.resize(nrec_dl + 1);
                 gh->wins_heap.resize(nwin_total * 8 + 1);
                 hrec = gh->recs_heap.data();
                 hwin = gh->wins_heap.data();
             }
-            if (nrec) HIP_TRY(c, hipMemcpyAsync(hrec, d_rec.p, nrec * 4, hipMemcpyDeviceToHost, st));
+            if (nrec_dl) HIP_TRY(c, hipMemcpyAsync(hrec, d_rec.p, nrec_dl * 4, hipMemcpyDeviceToHost, st));
             if (nwin_total) HIP_TRY(c, hipMemcpyAsync(hwin, d_win.p, nwin_total * 32, hipMemcpyDeviceToHost, st));
             gh->recs = hrec;
             gh->wins = hwin;
@@ -1028,7 +1072,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         // ---- host: records -> MatchInfo in the reference's push order, then block calling; one job per segment
         if (host_job.joinable()) host_job.join();                     // (one host stage at a time: it takes all the host threads)
         if (host_err.load() != TS_OK) return host_err.load();
-        host_job = std::thread([c, gh, ns, tips, s, w, ov, out, timing, &host_err, &t_host]() {
+        host_job = std::thread([c, gh, ns, tips, s, w, ov, out, counts, skip_records, timing, &host_err, &t_host]() {
         const auto th0 = Clock::now();
         const std::vector<SegL> &G = gh->G;
         const std::vector<TsGeneralTile> &tiles = gh->tiles;
@@ -1038,9 +1082,30 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         std::atomic<int> first_err{TS_OK};
         const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
         const unsigned spare = std::max(1u, std::min(16u, hw_threads) / (unsigned)std::max<size_t>(1, std::min<size_t>(ns, 16)));
+        // the device-called blocks of the group, sorted by segment: where each segment's begin
+        std::vector<size_t> blk_at(ns + 1, 0);
+        if (gh->dev_blocks) {
+            size_t q = 0;
+            for (size_t gi = 0; gi < ns; ++gi) {
+                blk_at[gi] = q;
+                while (q < gh->blocks.size() && gh->blocks[q].seg == gi) ++q;
+            }
+            blk_at[ns] = q;
+        }
         auto worker = [&]() {
             for (size_t gi; (gi = next.fetch_add(1)) < ns && first_err.load() == TS_OK;) {
                 const SegL &sl = G[gi];
+                const TsDevBlock *pre = gh->dev_blocks ? gh->blocks.data() + blk_at[gi] : nullptr;
+                const size_t n_pre = gh->dev_blocks ? blk_at[gi + 1] - blk_at[gi] : 0;
+                if (counts && gh->dev_blocks)
+                    counts[sl.idx] = ts_segment_counts{tips ? 0 : sl.n_windows, gh->sums[5 * gi + 2], gh->sums[5 * gi + 3], gh->sums[5 * gi + 4]};
+                if (skip_records) {
+                    // windows + the device's blocks; the match records stayed on the device
+                    const int rc = ts_finalize_segment(c, tips, sl.len, sl.abs_pos, sl.n_windows ? &wins[sl.win_base * 8] : nullptr,
+                                                       tips ? 0 : sl.n_windows, nullptr, 0, out[sl.idx], spare, pre, n_pre, true);
+                    if (rc != TS_OK) { int e = TS_OK; first_err.compare_exchange_strong(e, rc); return; }
+                    continue;
+                }
                 const uint64_t r0 = tile_off[sl.first_tile], r1 = tile_off[sl.first_tile + sl.n_tiles], nm = r1 - r0;
                 ts_match *arr = nm ? (ts_match *)ts_alloc_large(nm * sizeof(ts_match)) : nullptr;
                 if (nm && !arr) { int e = TS_OK; first_err.compare_exchange_strong(e, c->fail(TS_ERR_ALLOC, "out of host memory")); return; }
@@ -1120,7 +1185,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 }
                 const auto tw1 = Clock::now();
                 const int rc = ts_finalize_segment(c, tips, sl.len, sl.abs_pos, sl.n_windows ? &wins[sl.win_base * 8] : nullptr,
-                                                   tips ? 0 : sl.n_windows, arr, nm, out[sl.idx], spare);
+                                                   tips ? 0 : sl.n_windows, arr, nm, out[sl.idx], spare, pre, n_pre, gh->dev_blocks);
                 if (timing) { ts_gen_ns[0] += (uint64_t)(ms_between(tw0, tw1) * 1e6); ts_gen_ns[1] += (uint64_t)(ms_between(tw1, Clock::now()) * 1e6); }
                 if (rc != TS_OK) { int e = TS_OK; first_err.compare_exchange_strong(e, rc); return; }
             }
@@ -1169,10 +1234,11 @@ int scan_subset(ts_ctx *ctx, Mode mode, const ts_segment_in *segs, const std::ve
 }
 
 // the general kernels run one call at a time (their groups are not merged across callers)
-int generic_locked(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<size_t> &which, bool tips, ts_segment_out *out, bool have_lock) {
-    if (have_lock) return scan_group_generic(ctx, segs, which, tips, out);
+int generic_locked(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<size_t> &which, bool tips, ts_segment_out *out, bool have_lock,
+                   bool blocks_only = false, ts_segment_counts *counts = nullptr) {
+    if (have_lock) return scan_group_generic(ctx, segs, which, tips, out, blocks_only, counts);
     std::lock_guard<std::mutex> api(ctx->api_mtx);
-    return scan_group_generic(ctx, segs, which, tips, out);
+    return scan_group_generic(ctx, segs, which, tips, out, blocks_only, counts);
 }
 
 // ts_scan_segments; have_lock: the caller holds the context's call lock (ts_filter_reads's general path, ts_scan_segments_multi)
@@ -1230,10 +1296,13 @@ int ts_scan_segments_blocks(ts_ctx *ctx, const ts_segment_in *segs, size_t n_seg
     for (size_t i = 0; i < n_segs; ++i) (segs[i].tips_only ? tips : full).push_back(i);
     // parameter sets outside the tiled kernel take the general path and drop the match vectors afterwards
     auto via_matches = [&](const std::vector<size_t> &which, bool tips_mode) -> int {
-        int rc = generic_locked(ctx, segs, which, tips_mode, out, false);
+        // (blocks on the device and no record download where the match stream is in calling order; else the host path, whose
+        // match vectors are counted and dropped here)
+        if (counts) for (size_t i : which) counts[i] = ts_segment_counts{~0ull, 0, 0, 0};
+        int rc = generic_locked(ctx, segs, which, tips_mode, out, false, true, counts);
         if (rc != TS_OK) return rc;
         for (size_t i : which) {
-            if (counts) {
+            if (counts && counts[i].n_windows == ~0ull) {
                 ts_segment_counts cnt{tips_mode ? 0 : out[i].n_windows, out[i].n_matches, 0, 0};
                 for (uint64_t m = 0; m < out[i].n_matches; ++m) {
                     cnt.n_canonical += (out[i].matches[m].flags & TS_MATCH_CANONICAL) ? 1 : 0;

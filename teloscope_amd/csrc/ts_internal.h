@@ -129,6 +129,9 @@ struct TsBlockCallParams {
     float    min_block_density;
     uint32_t k;                         // match length (uniform)
     uint32_t its_min_len;               // 2 * patterns.front().size()
+    unsigned long long gen_lens;        // 0: the tiled kernel's records (position << 2 | forward << 1 | canonical, length k);
+                                        // else the general kernels' (position << 5 | length index << 2 | canonical << 1 | forward)
+                                        // and the up to eight pattern lengths, six bits each, length index i at bits 6i..
 };
 
 // ---- shard results (shard.hip, shard.cpp): what one device contributes to a scan that several devices share ----
@@ -274,6 +277,10 @@ uint32_t ts_k_general_list_max_records(void);
                                //  holds more than slot_cap records — its count is still written; list != 0: the list form of
                                //  the pass — for parameter sets whose tiles add to at most ts_k_general_list_max_records()
                                //  window records and whose pattern lists fit LDS; *overflow bit 1: run again with list = 0)
+// after the compaction: what device block calling needs of the group (TsTile per tile with in_off = seg_base[seg] + the tile's
+// segment-relative position; canonical / forward counts into words 1, 2 of the tile directory)
+int  ts_k_launch_general_block_inputs(const TsGeneralTile *gtiles, const unsigned long long *tile_off, const uint32_t *dense,
+                                      const unsigned long long *seg_base, uint32_t ntiles, TsTile *tiles, uint32_t *tile_stats, void *stream);
 int  ts_k_launch_general_compact(const uint32_t *tile_stats, const unsigned long long *tile_off, const uint32_t *records,
                                  uint32_t slot_cap, uint32_t ntiles, uint32_t *dense, void *stream);
 int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,

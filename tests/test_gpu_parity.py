@@ -602,6 +602,24 @@ BLOCKCALL_GRID = ["-r -g -e -m -i", "-w 1000 -s 500 -r -g -e -m -i",
                   "-w 1000 -s 500 -i -t 700 -l 60 -k 10 -d 30 -y 0.8", "", "-t 300", "-t 1000 -l 60 -k 10 -d 30 -y 0.8"]
 
 
+# ... and through the general kernels (generic.hip): mixed pattern lengths — the match stream carries a length per record —
+# where the blocks are called on the device too (lengths at most one apart, w == s, tips-only), and a set with lengths 6 and
+# 14 under w > s, whose stream is not in the reference's calling order and keeps the host path
+GENERIC_BLOCKCALL_GRID = ["-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i", "-p TTAGGG,TTAGG,TTTAGGGTTTAGGG -x 1 -w 500 -s 500 -g -i",
+                          "-p TTAGGG,TTAGG -t 400", "-c TTTAGGGTTTAGGG -x 1 -w 1000 -s 500 -r -g -i -k 80",
+                          "-p TTAGGG,TTTAGGGTTTAGGG -x 0 -w 1000 -s 500 -r -g -i", "-w 1000 -s 997 -r -g -e -i"]
+
+
+@pytest.mark.parametrize("host_blocks", [False, True])
+@pytest.mark.parametrize("cli", GENERIC_BLOCKCALL_GRID)
+def test_general_path_block_calling_matches_oracle(cli, host_blocks, monkeypatch):
+    """The same through ts_scan_segments_blocks on parameter sets the general kernels take; host_blocks pins the host's block
+    calling (TS_GEN_HOST_BLOCKS=1) so that both ways are compared with the oracle on the same input."""
+    if host_blocks:
+        monkeypatch.setenv("TS_GEN_HOST_BLOCKS", "1")
+    test_device_block_calling_matches_oracle(cli)
+
+
 @pytest.mark.parametrize("cli", BLOCKCALL_GRID)
 def test_device_block_calling_matches_oracle(cli):
     """getTerminalBlocks / getInterstitialBlocks on the device (ts_batch_download_blocks): blocks
