@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TELOSCAN_ABI_VERSION 3
+#define TELOSCAN_ABI_VERSION 4
 
 /* ts_params.device value of a PLANNING-ONLY context: no HIP call is ever made behind it.  It plans batches
  * (ts_batch_create, ts_batch_get_info, ts_batch_get_tiles, ts_batch_partition, ts_batch_range_info) so that a
@@ -213,7 +213,11 @@ void ts_free_patterns(ts_pattern *p);
  *      calls that arrive while the device is busy are COALESCED — the next run takes every waiting call of one kind
  *      (ts_scan_segments, ts_scan_segments_blocks, ts_filter_reads; full scans and tips-only apart) as one batch and hands
  *      each caller its own results.  Sixty-four threads with one segment each cost about what one call with sixty-four
- *      segments costs; results never depend on who was merged with whom. */
+ *      segments costs; results never depend on who was merged with whom.
+ *      LIMITS of the pattern set (the reference's trie has none, include/teloscope.h:40-57): a pattern longer than 32 bases,
+ *      more than 8 distinct pattern lengths, or a non-ACGT pattern make every scan of the context fail with
+ *      TS_ERR_UNSUPPORTED (loudly: there is no CPU path to fall back to).  Uniform-length sets of 3..8 bases under
+ *      w == s or k <= min(s, w - s) take the tiled kernel; everything else inside the limits the general kernels. */
 ts_ctx *ts_create(const ts_params *params, const ts_pattern *patterns, size_t n_patterns);
 void    ts_destroy(ts_ctx *ctx);
 /* 1 if full scans with this (window, step, patterns) run on the tiled uniform-k kernel,

@@ -28,7 +28,7 @@ def test_header_symbols_exported(ta):
     lib = C.CDLL(_capi.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.ts_abi_version() == 3
+    assert lib.ts_abi_version() == 4
 
 
 def test_struct_sizes_match_header(ta, tmp_path):
