@@ -409,6 +409,7 @@ void size_launch(ts_batch *b) {
         uint64_t vcap = 2 * ceil_div(vwant, b->total_waves) + 12 * ceil_div(tile_bases, std::max<uint32_t>(c->k, 1)) + 2048;
         if (b->dealt_tiles && !b->match_cap_request) vcap = worst;          // small ranges: the worst case, like the record regions
         vcap = std::min<uint64_t>(vcap, std::max<uint64_t>(worst, 256));
+        if (const char *e = getenv("TS_VIS_CAP")) { const long v = atol(e); if (v > 0) vcap = (uint64_t)v; }   // (tests: force the overflow -> regrow -> rescan path)
         b->vis_cap = (uint32_t)((vcap + 7) & ~7ull);
     }
 }

@@ -103,6 +103,45 @@ def test_shard_messages_merge_to_the_oracle(cli):
         assert split_inside > 0, "no boundary fell inside a segment: the context tiles were never exercised"
 
 
+def test_visible_record_regions_that_overflow_are_regrown(monkeypatch):
+    """The emitting scan appends a wave's visible records to a region of its own; one that is too small (here: 64 records, by
+    TS_VIS_CAP) must be REPORTED — TS_SHARD_F_SCAN_OVERFLOW in the message's header, nothing trusted — and ts_batch_sync must
+    size the regions for the fullest wave and rescan, after which the merge equals the oracle."""
+    import torch
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.distributed import PackedShard, ShardPlan, finalize_shards, free_segments
+    monkeypatch.setenv("TS_VIS_CAP", "64")
+    dev = torch.device("cuda", 0)
+    opts, tel = _teloscope(HEADLINE + " -t 3000")
+    rng = np.random.default_rng(3)
+    lens = [900_000, 250_003]
+    seqs = [seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, telo_repeats=1500, n_its=5) for n in lens]
+    plan = ShardPlan(tel, lens, world=2)
+    buf = _fill(plan, seqs, dev)
+    sptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    msgs, syncs = [], 0
+    for p in range(2):
+        ps = PackedShard(plan, p, dev, slots=1)
+        local = buf[ps.info.input_begin:max(ps.info.input_end, ps.info.input_begin + 64)].clone()
+        for _ in range(4):
+            ps.scan_pack(local.data_ptr(), sptr, 0)
+            if not (ps.status(0).flags & K.SHARD_OVERFLOW_SCAN):
+                break
+            ps.sync(0)
+            syncs += 1
+        msgs.append(ps.msgs[0].cpu().numpy().copy())
+        ps.close()
+    assert syncs >= 1, "a 64-record region did not overflow on a telomere: the path under test did not run"
+    rc, out, cnt = finalize_shards(plan, msgs)
+    assert rc == 0, tel._ctx.error()
+    orac = OracleBackend(opts)
+    for i, sq in enumerate(seqs):
+        assert_visible_view_equal(ta.SegmentData(out[i], False), orac.scan_segment(sq, 0, False), False, cnt[i], "segment %d" % i)
+    free_segments(plan, out)
+    plan.close()
+
+
 def test_kernel_messages_equal_the_messages_packed_from_oracle_results():
     """Byte level: what the kernels pack (header, per-segment entries, bit-packed windows, per-tile counts, visible records,
     blocks) against tests/shardpack.py's rendering of the oracle's results in the same layout."""
