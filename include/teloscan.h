@@ -166,7 +166,7 @@ typedef struct ts_segment_in {
     uint64_t    len;
     uint64_t    abs_pos;
     uint8_t     tips_only;
-    uint8_t     input_format;   /* TS_INPUT_BASES / TS_INPUT_TEXT_PIECES / TS_INPUT_PACKED2 (the latter two: tiled kernel's parameter sets only) */
+    uint8_t     input_format;   /* TS_INPUT_BASES / TS_INPUT_TEXT_PIECES / TS_INPUT_PACKED2 (any parameter set the library scans) */
     uint8_t     reserved[2];
     uint32_t    n_pieces;       /* TS_INPUT_TEXT_PIECES: entries of the ts_text_piece array (the walk never reads past it;
                                    pieces that hold fewer than `len` bases are TS_ERR_INVALID_ARG) */
@@ -224,7 +224,8 @@ void    ts_destroy(ts_ctx *ctx);
  * 0 if on the general kernels (mixed-length sets, k > 9, or a longest pattern exceeding
  * min(step, window-step), where the reference's start-index arithmetic wraps). */
 int     ts_uses_fast_path(const ts_ctx *ctx);
-/* 1 if segments of this kind (full scan / tips-only) may come as TS_INPUT_TEXT_PIECES: those the tiled kernel scans. */
+/* 1 if segments of this kind (full scan / tips-only) may come as TS_INPUT_TEXT_PIECES or TS_INPUT_PACKED2: every parameter
+ * set the library scans (until ABI 4 the general kernels wanted the bases joined). */
 int     ts_takes_text_input(const ts_ctx *ctx, int tips_only);
 /* Restricts the CALLING thread (and the threads it starts from then on) to the CPUs of the NUMA node the context's
  * device is attached to; returns 1 if it did, 0 if the topology is unknown, the thread's mask holds none of those CPUs,

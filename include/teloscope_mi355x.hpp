@@ -259,8 +259,7 @@ public:
     size_t deviceCount() const { return all.size(); }
 
     const UserInputTeloscope &input() const { return userInput; }
-    // does the library take TS_INPUT_TEXT_PIECES segments for this parameter set (the tiled kernel's; the general path
-    // wants the bases joined)?
+    // does the library take TS_INPUT_TEXT_PIECES segments for this parameter set (every set it scans)?
     bool takesTextPieces() const { return ts_takes_text_input(ctx.get(), userInput.ultraFastMode ? 1 : 0) != 0; }
     // keeps the calling thread (and the threads it starts) on the CPUs of the device's NUMA node: ts_bind_thread_to_device
     bool bindThreadToDevice() const { return ts_bind_thread_to_device(ctx.get()) != 0; }

@@ -723,8 +723,9 @@ int ts_bind_thread_to_device(const ts_ctx *ctx) {
 }
 
 int ts_takes_text_input(const ts_ctx *ctx, int tips_only) {
+    // (round 4: the general path stages its groups through the same upload as the tiled path — every format, every set)
     std::string why;
-    return ctx && (tips_only ? ctx->fast_ok : ts_full_scan_supported(ctx, why)) ? 1 : 0;
+    return ctx && ((tips_only ? ctx->fast_ok : ts_full_scan_supported(ctx, why)) || ctx->generic_ok) ? 1 : 0;
 }
 
 // =========================================================================== batches

@@ -379,20 +379,68 @@ void ts_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint3
 
 constexpr uint32_t kWaccMax = 256;          // window records a tile may add to on the list path
 constexpr uint32_t kListWave = 1024;        // candidate entries a wave's 1024 positions may produce on the list path
+constexpr uint32_t kShortLen = 6;           // pattern lengths up to this have exact tables in LDS (their l-mers index them)
 
-// The same pass in its LIST form (round 3, second half): what the kernel above does per position — flag lookup, push
-// test, window shares — is done here per CANDIDATE, on full wavefronts.  Matches are a few per cent of the positions, so
-// a lane-per-position loop pays for the whole per-match path in nearly every round of 64 positions whatever the density
-// (what the tiled kernel's match queue is there for).  Here
-//   2'. every position only asks the prefix bitmaps (exact up to length 6, a 2 % filter for longer patterns) and a wave
-//       appends its candidates (position, length index), in order, to its own list in LDS;
-//   3'. a lane per candidate: the l-mer out of the planes again, the binary search (match? forward, canonical), the push
-//       test, and the covered bases of the match ADDED to the accumulators of the window records it belongs to — the
-//       pushing window's own record (analyzeWindow's main part) and the record after every call that carries it (i >= step,
-//       ends inside that call's window);
-//   4'. window records: a wave per record, nucleotides by popcounts over the packed planes (16 positions per lane and
-//       step) for the main part of the record's own call and the carry of the call before it, covered bases from the
-//       accumulators; stored or added as above;
+// Inclusive prefix sum over the wave's lanes by DPP (row shifts, then the two row broadcasts: lane 63 holds the total).
+__device__ __forceinline__ uint32_t wave_inclusive_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// sixteen doubled 2-bit codes (ASCII & 6), one per byte of t[0..3] -> one dword, base i at bits 2i..2i+1
+__device__ __forceinline__ uint32_t pack16(const uint32_t t[4]) {
+    const uint32_t b0 = __builtin_amdgcn_udot4(t[0], 0x40100401u, 0u, false);
+    const uint32_t b1 = __builtin_amdgcn_udot4(t[1], 0x40100401u, 0u, false);
+    const uint32_t b2 = __builtin_amdgcn_udot4(t[2], 0x40100401u, 0u, false);
+    const uint32_t b3 = __builtin_amdgcn_udot4(t[3], 0x40100401u, 0u, false);
+    return ((b0 | (b1 << 8)) >> 1) | ((b2 | (b3 << 8)) << 15);
+}
+
+// x / s for the x this kernel divides (x < s + 4200): one multiply by ceil-ish(2^32 / s) when s <= 8192 (exact for
+// x < 2^32 / s), a compare above that (x < 2 s).  s >= 2 wherever the list form runs.
+__device__ __forceinline__ uint32_t div_step(uint32_t x, uint32_t s, uint32_t magic) {
+    return s > 8192u ? (x >= s ? 1u : 0u) : __umulhi(x, magic);
+}
+
+// full_scan_pushes with the division above (same arithmetic otherwise)
+__device__ __forceinline__ bool full_scan_pushes_m(uint32_t j, uint32_t l, const PushGeom &g, uint32_t magic, u64 *rec) {
+    if (g.ov == 0u) {
+        const uint32_t x = g.r0 + j;
+        const uint32_t dk = div_step(x, g.s, magic), dks = dk * g.s;
+        const u64 left = g.N0 - dks;
+        const uint32_t cws = left < g.w ? (uint32_t)left : g.w;
+        *rec = g.k0 + dk;
+        return (x - dks) + l <= cws;                        // may not cross its only window's end
+    }
+    const u64 e = g.P0 + j + l - 1u;
+    *rec = 0;
+    if (e < (g.n < g.w ? g.n : (u64)g.w)) return true;      // window 0 scans everything it holds
+    const uint32_t xr = g.r1 + (j + l - 1u - g.dsub);       // (e - ov) relative to k1 s   [e >= w here]
+    const uint32_t dk = div_step(xr, g.s, magic);           // the one window with j >= overlap: k = k1 + dk
+    const long long diff = (long long)g.D1 + (long long)j - (long long)((u64)dk * g.s);
+    *rec = g.k1 + dk;
+    return diff >= 0 && (u64)diff >= g.start_index;
+}
+
+// The same pass in its LIST form (round 3; restructured in round 4): what the kernel above does per position — flag
+// lookup, push test, window shares — is done here per CANDIDATE, on full wavefronts, and a position costs ONE LDS probe.
+//   1'. stage as above (SWAR: v_perm / v_dot4, four bases per instruction), plus two tables built per workgroup:
+//       cand6   a byte per 6-mer: bit li set when its first min(l, 6) bases begin a pattern of length index li — exact for
+//               l <= 6 (a pattern shorter than six sets the bit under every extension), a filter for longer ones;
+//       sflag   per length <= 6: {forward, canonical} of the l-mer, 2 bits each — those lengths need no search at all;
+//   2'. candidates: a lane owns SIXTEEN CONSECUTIVE positions (one plane dword + the next), takes their 6-mers with one
+//       v_bfe / v_alignbit each and reads cand6 once per position; the wave appends its candidates (position, length
+//       index), in order, to its own list in LDS after ONE prefix sum over the lanes' counts.  Non-ACGT bases and the
+//       region's end are handled on a wave-uniform slow path (the bits of lengths that do not fit are dropped);
+//   3'. a lane per candidate: flags from sflag, or the binary search for l > 6; the push test (divisions by the step as
+//       one multiply); the covered bases of the match ADDED to the accumulators of the window records it belongs to — the
+//       pushing window's own record (analyzeWindow's main part) and the record after every call that carries it;
+//   4'. window records: a wave per record, nucleotides by popcounts over the packed planes; stored or added as above;
 //   5'. match records: the pushed candidates, in list order (= position then length order), into the tile's slot.
 // Taken when a tile adds to at most kWaccMax window records (decided on the host from w and s) and the pattern lists fit
 // LDS; a wave whose list overflows (more than one candidate per position: dense repeats under a mixed-length set) raises
@@ -400,14 +448,18 @@ constexpr uint32_t kListWave = 1024;        // candidate entries a wave's 1024 p
 __global__ __launch_bounds__(256)
 void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles, const u64 *seg_len,
                            const u64 *seg_win_base, const TsGenericPatterns G, const TsGenericGeom Q, int tips, uint32_t slot_cap,
-                           uint32_t lds_patterns, uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
+                           uint32_t lds_patterns, uint32_t nshort, uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
     extern __shared__ __align__(16) unsigned char lds[];
-    // layout: list u32[4][kListWave] | pcode u64[lds_patterns] | bitmap u32[8][128] | part u32[8] | codes2 | inval | valid2 | wacc | pflag
+    // layout: list u32[4][kListWave] | pcode u64[lds_patterns] | cand6 u8[4096] | sflag u8[nshort][1024] | part u32[8] | first u32[12] |
+    //         codes2 | inval | valid2 | wacc | pflag
     uint32_t *list_all = (uint32_t *)lds;
     u64 *pcode = (u64 *)(lds + 4u * kListWave * 4u);
-    uint32_t *bitmap = (uint32_t *)(lds + 4u * kListWave * 4u + (size_t)lds_patterns * 8u);
-    uint32_t *part = bitmap + 8u * 128u;
-    uint32_t *codes2 = part + 8;
+    uint32_t *cand6w = (uint32_t *)(lds + 4u * kListWave * 4u + (size_t)lds_patterns * 8u);
+    const unsigned char *cand6 = (const unsigned char *)cand6w;
+    uint32_t *sflagw = cand6w + 1024u;
+    uint32_t *part = sflagw + nshort * 256u;
+    uint32_t *firstl = part + 8;
+    uint32_t *codes2 = firstl + 12;
     uint32_t *inval = codes2 + kCodeWords;
     uint32_t *valid2 = inval + kInvalWords;
     uint32_t *wacc = valid2 + kCodeWords;                                  // [kWaccMax][4]: canonical, non-canonical, forward, reverse covered
@@ -417,18 +469,27 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     uint32_t *const list = list_all + wave * kListWave;
     const uint32_t npat = G.first[G.nlen];
-    for (uint32_t i = tid; i < 8u * 128u; i += 256u) bitmap[i] = 0u;
+    for (uint32_t i = tid; i < 1024u + nshort * 256u; i += 256u) cand6w[i] = 0u;       // (cand6 and sflag are adjacent)
     for (uint32_t i = tid; i < kWaccMax * 4u; i += 256u) wacc[i] = 0u;
     for (uint32_t i = tid; i < npat; i += 256u) { pcode[i] = G.codes[i]; pflag[i] = G.flags[i]; }
+    if (tid == 0u) {
+#pragma unroll
+        for (uint32_t q = 0; q < 9u; ++q) firstl[q] = G.first[q];
+    }
+    // the pattern lengths as six bits each (uniform), for the per-candidate pass
+    u64 lens64 = 0;
+#pragma unroll
+    for (uint32_t li = 0; li < 8u; ++li) lens64 |= (u64)(li < G.nlen ? G.len[li] : 0u) << (6u * li);
     const TsGeneralTile T = tiles[blockIdx.x];
-    // 1. stage (as above, plus the validity plane spread to 01 per valid position)
+    // 1'. stage
     const uint32_t avail = T.avail;
     const unsigned char *src = in + T.in_off;
+    const uint32_t fold_mask = Q.fold ? 0xDFDFDFDFu : 0xFFFFFFFFu;
     for (uint32_t i = tid * 16u; i < kCodeWords * 16u; i += 256u * 16u) {
         uint32_t cw = 0, iv = 0xFFFFu;
         if (i < avail) {
             uint32_t d[4];
-            if (((uintptr_t)(src + i) & 15u) == 0u && i + 16u <= avail) {
+            if (((uintptr_t)(src + i) & 15u) == 0u) {                      // (the layout keeps 64 readable bytes behind the last region)
                 const uint4 v = *(const uint4 *)(src + i);
                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             } else {
@@ -438,15 +499,20 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
                     d[q] = x;
                 }
             }
-            iv = 0;
+            // ASCII & 6 = twice the code (A 0, C 2, T 4, G 6) and the v_perm selector of the letter that code stands for; a byte
+            // that is not that letter (up to case folding) is invalid
+            uint32_t t[4], b4[4];
 #pragma unroll
-            for (uint32_t q = 0; q < 16u; ++q) {
-                uint32_t c = (d[q >> 2] >> (8u * (q & 3u))) & 0xFFu;
-                if (Q.fold) c &= 0xDFu;
-                const uint32_t code = (c >> 1) & 3u;                               // A 0, C 1, T 2, G 3
-                cw |= code << (2u * q);
-                iv |= (c != ((0x47544341u >> (8u * code)) & 0xFFu) ? 1u : 0u) << q; // 'A' 'C' 'T' 'G' by code
+            for (uint32_t q = 0; q < 4u; ++q) {
+                t[q] = d[q] & 0x06060606u;
+                const uint32_t e = __builtin_amdgcn_perm(0xFF47FF54u, 0xFF43FF41u, t[q]);
+                const uint32_t dd = (d[q] & fold_mask) ^ e;
+                const uint32_t nz = ((((dd & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | dd) & 0x80808080u) >> 7;
+                b4[q] = __builtin_amdgcn_udot4(nz, 0x08040201u, 0u, false);
             }
+            cw = pack16(t);
+            iv = b4[0] | (b4[1] << 4) | (b4[2] << 8) | (b4[3] << 12);
+            if (i + 16u > avail) iv = (iv | (~0u << (avail - i))) & 0xFFFFu;       // bases behind the region's end
         }
         codes2[i >> 4] = cw;
         ((unsigned short *)inval)[i >> 4] = (unsigned short)iv;
@@ -456,50 +522,75 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
         valid2[i >> 4] = ok;
     }
     __syncthreads();
+    // the tables: every pattern once (the first of equal codes, as the search finds it)
     for (uint32_t li = 0; li < G.nlen; ++li) {
-        const uint32_t q = G.len[li] < 6u ? G.len[li] : 6u;
-        for (uint32_t i = G.first[li] + tid; i < G.first[li + 1]; i += 256u) {
-            const uint32_t pre = (uint32_t)pcode[i] & ((1u << (2u * q)) - 1u);
-            atomicOr(&bitmap[li * 128u + (pre >> 5)], 1u << (pre & 31u));
+        const uint32_t l = G.len[li], q = l < kShortLen ? l : kShortLen, ext_bits = 2u * (kShortLen - q);
+        const uint32_t f0 = G.first[li], cnt = G.first[li + 1] - f0;
+        for (uint32_t x = tid; x < (cnt << ext_bits); x += 256u) {
+            const uint32_t i = f0 + (x >> ext_bits);
+            const u64 code = pcode[i];
+            if (i > f0 && pcode[i - 1u] == code) continue;
+            const uint32_t idx = ((uint32_t)code & ((1u << (2u * q)) - 1u)) | ((x & ((1u << ext_bits) - 1u)) << (2u * q));
+            atomicOr(&cand6w[idx >> 2], (1u << li) << (8u * (idx & 3u)));
+            if (l <= kShortLen && (x & ((1u << ext_bits) - 1u)) == 0u)
+                atomicOr(&sflagw[li * 256u + ((uint32_t)code >> 4)], (uint32_t)(pflag[i] & 3u) << (2u * ((uint32_t)code & 15u)));
         }
     }
     __syncthreads();
-    // the next 32 bases of tile position j and their validity bits
-    auto bases_at = [&](uint32_t j, u64 &code64, uint32_t &inv32) {
+    // the next 32 bases of tile position j
+    auto bases_at = [&](uint32_t j) -> u64 {
         const uint32_t wd = j >> 4, sh = 2u * (j & 15u);
         const uint32_t c0 = codes2[wd], c1 = codes2[wd + 1u], c2 = codes2[wd + 2u];
-        code64 = (u64)__funnelshift_r(c0, c1, sh) | ((u64)__funnelshift_r(c1, c2, sh) << 32);
-        const uint32_t vd = j >> 5;
-        inv32 = __funnelshift_r(inval[vd], inval[vd + 1u], j & 31u);
+        return (u64)__funnelshift_r(c0, c1, sh) | ((u64)__funnelshift_r(c1, c2, sh) << 32);
     };
-    // 2'. candidates: wave v owns the 1024 consecutive positions [1024 v, 1024 v + 1024)
+    // 2'. candidates: wave v owns the 1024 consecutive positions [1024 v, 1024 v + 1024), lane L the sixteen from 16 L on
     uint32_t ncand = 0;                                                    // (wave-uniform)
     bool spilled = false;
+    if (!(Q.abl & 16u)) {
+        const uint32_t wd0 = wave * 64u + lane, j0 = wd0 * 16u;
+        const uint32_t c0 = codes2[wd0], c1 = codes2[wd0 + 1u];
+        uint32_t acc[4] = {0u, 0u, 0u, 0u};                                // a byte of length bits per position
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) {
+            const uint32_t idx = (i <= 10u ? (c0 >> (2u * i)) : __builtin_amdgcn_alignbit(c1, c0, 2u * i)) & 0xFFFu;
+            acc[i >> 2] |= (uint32_t)cand6[idx] << (8u * (i & 3u));
+        }
+        // non-ACGT bases within reach of the wave's positions, or the region's end: lengths that do not fit are dropped
+        const unsigned short *inval16 = (const unsigned short *)inval;
+        const u64 iv48 = (u64)inval16[wd0] | ((u64)inval16[wd0 + 1u] << 16) | ((u64)inval16[wd0 + 2u] << 32);
+        const bool slow = wave * 1024u + 1024u + 32u > avail || __builtin_amdgcn_ballot_w64(iv48 != 0ull) != 0ull;
+        if (slow) {
 #pragma unroll 1
-    for (uint32_t r = 0; r < 16u; ++r) {
-        const uint32_t j = wave * 1024u + r * 64u + lane;
-        uint32_t bits = 0;
-        if (j < T.n) {
-            u64 code64; uint32_t inv32;
-            bases_at(j, code64, inv32);
-#pragma unroll 1
-            for (uint32_t li = 0; li < G.nlen; ++li) {
-                const uint32_t l = G.len[li];
-                if (j + l > avail) break;                // lengths ascend; a match may not cross the region end
-                if (inv32 & (l >= 32u ? 0xFFFFFFFFu : ((1u << l) - 1u))) break;   // a non-ACGT base kills this and every longer pattern
-                const uint32_t q = l < 6u ? l : 6u;
-                const uint32_t pre = (uint32_t)code64 & ((1u << (2u * q)) - 1u);
-                bits |= ((bitmap[li * 128u + (pre >> 5)] >> (pre & 31u)) & 1u) << li;
+            for (uint32_t i = 0; i < 16u; ++i) {
+                const uint32_t ivi = (uint32_t)(iv48 >> i), j = j0 + i;
+                const uint32_t nvalid = ivi ? (uint32_t)__builtin_ctz(ivi) : 32u;
+                const uint32_t rem = avail > j ? avail - j : 0u;
+                const uint32_t maxlen = nvalid < rem ? nvalid : rem;
+                uint32_t cnt = 0;
+#pragma unroll
+                for (uint32_t li = 0; li < 8u; ++li) cnt += ((uint32_t)(lens64 >> (6u * li)) & 63u) - 1u < maxlen ? 1u : 0u;   // 1 <= len <= maxlen (len 0: unused slot)
+                const uint32_t keep = ~(0xFFu << cnt) & 0xFFu;
+                const uint32_t r = i >> 2, sh = 8u * (i & 3u);
+                // (acc is indexed by constants only: no scratch)
+                if (r == 0u) acc[0] &= ~(0xFFu << sh) | (keep << sh);
+                else if (r == 1u) acc[1] &= ~(0xFFu << sh) | (keep << sh);
+                else if (r == 2u) acc[2] &= ~(0xFFu << sh) | (keep << sh);
+                else acc[3] &= ~(0xFFu << sh) | (keep << sh);
             }
         }
-        if (__ballot(bits != 0u) == 0ull) continue;
-        const uint32_t c = (uint32_t)__popc(bits);
-        const uint32_t incl = wave_inclusive(c, lane);
-        const uint32_t round_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (ncand + round_total > kListWave) { spilled = true; break; }
-        uint32_t at = ncand + incl - c;
-        for (uint32_t b = bits; b; b &= b - 1u) list[at++] = (j << 5) | ((uint32_t)__builtin_ctz(b) << 2);
-        ncand += round_total;
+        const uint32_t c = (uint32_t)(__popc(acc[0]) + __popc(acc[1]) + __popc(acc[2]) + __popc(acc[3]));
+        const uint32_t incl = wave_inclusive_dpp(c);
+        ncand = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (ncand > kListWave) { spilled = true; ncand = 0; }
+        else {
+            uint32_t at = incl - c;
+#pragma unroll
+            for (uint32_t r = 0; r < 4u; ++r)
+                for (uint32_t m = acc[r]; m; m &= m - 1u) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(m);
+                    list[at++] = ((j0 + 4u * r + (b >> 3)) << 5) | ((b & 7u) << 2);
+                }
+        }
     }
     if (spilled && lane == 0u) atomicOr(overflow, 2u);
     const u64 n = seg_len[T.seg];
@@ -518,31 +609,38 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
         if (rec_hi - kw_lo >= kWaccMax) { if (tid == 0u) atomicOr(overflow, 2u); spilled = true; }     // (the host sizes this out: never)
     }
     const PushGeom pg = push_geom(P0, n, Q);
+    const uint32_t magic = Q.s_magic;
     const u64 N1 = n - P0;                                                  // bases from the tile's first to the segment's end
     // 3'. a lane per candidate
     uint32_t npush = 0;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-    for (uint32_t e0 = 0; e0 < ncand && !spilled; e0 += 64u) {
+    for (uint32_t e0 = 0; e0 < ncand && !spilled && !(Q.abl & 32u); e0 += 64u) {
         const uint32_t e = e0 + lane;
         bool pushed = false;
         if (e < ncand) {
             uint32_t ent = list[e];
-            const uint32_t j = ent >> 5, li = (ent >> 2) & 7u, l = G.len[li];
-            u64 code64; uint32_t inv32;
-            bases_at(j, code64, inv32);
+            const uint32_t j = ent >> 5, li = (ent >> 2) & 7u, l = (uint32_t)(lens64 >> (6u * li)) & 63u;
+            const u64 code64 = bases_at(j);
             const u64 code = l >= 32u ? code64 : (code64 & ((1ull << (2u * l)) - 1ull));
-            uint32_t lo = G.first[li], hi = G.first[li + 1];
-            const uint32_t end = hi;
-            while (lo < hi) {                        // binary search in the sorted code list of this length
-                const uint32_t mid = (lo + hi) >> 1;
-                if (pcode[mid] < code) lo = mid + 1; else hi = mid;
+            bool found = true;
+            uint32_t fl;
+            if (l <= kShortLen) {                                           // exact tables: a candidate is a match
+                const uint32_t cidx = (uint32_t)code;
+                fl = (sflagw[li * 256u + (cidx >> 4)] >> (2u * (cidx & 15u))) & 3u;
+            } else {
+                uint32_t lo = firstl[li], hi = firstl[li + 1u];
+                const uint32_t end = hi;
+                while (lo < hi) {                    // binary search in the sorted code list of this length
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pcode[mid] < code) lo = mid + 1; else hi = mid;
+                }
+                found = lo < end && pcode[lo] == code;
+                fl = found ? pflag[lo] : 0u;                                // bit0 forward, bit1 canonical
             }
-            const bool found = lo < end && pcode[lo] == code;
             if (found) {
-                const uint32_t fl = pflag[lo];                              // bit0 forward, bit1 canonical
                 u64 rec = 0;
-                pushed = tips || full_scan_pushes(j, l, pg, &rec);
+                pushed = tips || full_scan_pushes_m(j, l, pg, magic, &rec);
                 if (win_on) {
                     const uint32_t f_can = (fl & 2u) ? 0u : 1u, f_fwd = (fl & 1u) ? 2u : 3u;
                     // the window that pushes a match counts it in its own record (analyzeWindow's main part) ...
@@ -554,9 +652,9 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
                     // ... and every call kw that meets it at i >= step (at or behind its own start index) carries it into
                     // record kw + 1 as long as it ends inside that call's window: kw = p / s - 1 downwards, i grows by s
                     if (carries) {
-                        const uint32_t x = pg.rP0 + j, dkp = x / Q.s;
+                        const uint32_t x = pg.rP0 + j, dkp = div_step(x, Q.s, magic);
                         u64 kw = pg.kP0 + dkp;
-                        u64 i = x - dkp * Q.s;
+                        uint32_t i = x - dkp * Q.s;                          // (< w + s while the loop runs)
                         while (kw > 0u) {
                             --kw; i += Q.s;
                             if (i + l - 1u >= Q.w) break;                   // ends behind every further window too
@@ -576,7 +674,7 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
             }
             list[e] = pushed ? (ent | 0x80000000u) : 0u;                    // (tile positions are below 2^12: bit 31 is free)
         }
-        npush += (uint32_t)__popcll(__ballot(pushed));
+        npush += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pushed));
     }
     if (lane == 0u) { part[wave] = npush; part[4u + wave] = spilled ? 1u : 0u; }
     __syncthreads();
@@ -590,7 +688,7 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
     }
     if (any_spill) return;
     // 4'. window records
-    if (win_on) {
+    if (win_on && !(Q.abl & 64u)) {
         uint32_t *const wrec = win_out + seg_win_base[T.seg] * 8ull;
         const uint32_t ov = Q.w - Q.s;
 #pragma unroll 1
@@ -635,7 +733,7 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
     for (uint32_t e0 = 0; e0 < ncand; e0 += 64u) {
         const uint32_t e = e0 + lane;
         const uint32_t ent = e < ncand ? list[e] : 0u;
-        const u64 m = __ballot(ent != 0u);
+        const u64 m = __builtin_amdgcn_ballot_w64(ent != 0u);
         if (m == 0ull) continue;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (ent) dst[base + rank] = ent & 0x7FFFFFFFu;
@@ -678,10 +776,12 @@ int ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tile
     uint32_t lp = 0;
     const unsigned long long lds = ts_k_general_lds_bytes(G, &lp);
     if (list && lp) {
-        const unsigned long long lds2 = 4ull * kListWave * 4u + (unsigned long long)lp * 8u + 8u * 128u * 4u + 32u + kCodeWords * 4u + kInvalWords * 4u +
-                                        kCodeWords * 4u + kWaccMax * 16u + ((lp + 15u) & ~15u);
+        uint32_t nshort = 0;
+        for (uint32_t li = 0; li < G->nlen; ++li) nshort += G->len[li] <= kShortLen ? 1u : 0u;
+        const unsigned long long lds2 = 4ull * kListWave * 4u + (unsigned long long)lp * 8u + 4096u + nshort * 1024u + 32u + 48u + kCodeWords * 4u +
+                                        kInvalWords * 4u + kCodeWords * 4u + kWaccMax * 16u + ((lp + 15u) & ~15u);
         hipLaunchKernelGGL(ts_general_fused_list, dim3(ntiles), dim3(256), (size_t)lds2, (hipStream_t)stream, in, tiles, ntiles,
-                           (const u64 *)seg_len, (const u64 *)seg_win_base, *G, *Q, tips, slot_cap, lp, tile_stats, records, win_out, overflow);
+                           (const u64 *)seg_len, (const u64 *)seg_win_base, *G, *Q, tips, slot_cap, lp, nshort, tile_stats, records, win_out, overflow);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(ts_general_fused, dim3(ntiles), dim3(256), (size_t)lds, (hipStream_t)stream, in, tiles, ntiles,

@@ -451,6 +451,49 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
     return TS_OK;
 }
 
+// The upload pieces of one scanned region of an item: its bases [rg_start, rg_start + rg_len), whose first lies at byte
+// layout_off of the input layout, clipped to the layout range [lo, hi) the caller uploads — from whichever of the three
+// input formats the item arrived in.
+int region_pieces(ts_ctx *c, const Item &it, uint64_t seg_len, uint64_t rg_start, uint64_t rg_len, uint64_t layout_off,
+                  uint64_t lo, uint64_t hi, std::vector<UpPiece> &pieces) {
+    if (it.format == TS_INPUT_TEXT_PIECES) {
+        // the region's bases out of the segment's text pieces
+        const ts_text_piece *tp = (const ts_text_piece *)it.seq;
+        uint64_t cum = 0, want = rg_start, left = rg_len, off = layout_off;
+        for (size_t k = 0; left; ++k) {
+            if (k >= it.n_pieces || cum >= seg_len)
+                return c->fail(TS_ERR_INVALID_ARG, "text pieces hold fewer bases than the segment's length (or n_pieces is not set)");
+            const ts_text_piece &t = tp[k];
+            if (t.text_len > (16ull << 20) + 4096) return c->fail(TS_ERR_INVALID_ARG, "a text piece is larger than 16 MiB");
+            if (want >= cum + t.n_bases) { cum += t.n_bases; continue; }      // wholly before the region
+            const uint64_t skip = want - cum;
+            const uint64_t n = std::min<uint64_t>(t.n_bases - skip, left);
+            // of these n bases, those the range reads (a shard uploads only its part of a segment)
+            const uint64_t a = std::max<uint64_t>(off, lo), z = std::min<uint64_t>(off + n, hi);
+            if (z > a) {
+                const uint64_t skip2 = skip + (a - off);
+                const char *from = skip2 ? text_locate(t.text, t.text_len, skip2) : t.text;
+                pieces.push_back({a, from, z - a, (uint64_t)(t.text + t.text_len - from)});
+            }
+            off += n; left -= n; want += n; cum += t.n_bases;
+        }
+        return TS_OK;
+    }
+    const uint64_t s0 = std::max<uint64_t>(layout_off, lo), s1 = std::min<uint64_t>(layout_off + rg_len, hi);
+    if (it.format == TS_INPUT_PACKED2) {
+        const ts_packed_seq *ps = (const ts_packed_seq *)it.seq;
+        if (!ps || (!ps->codes && seg_len) || (ps->n_runs && !ps->runs)) return c->fail(TS_ERR_INVALID_ARG, "packed input: null codes or runs");
+        if (s1 > s0) {
+            UpPiece pc{s0, nullptr, s1 - s0, 0};
+            pc.packed = ps; pc.packed_first = rg_start + (s0 - layout_off);
+            pieces.push_back(pc);
+        }
+        return TS_OK;
+    }
+    if (s1 > s0) pieces.push_back({s0, it.seq + rg_start + (s0 - layout_off), s1 - s0, 0});
+    return TS_OK;
+}
+
 // Uploads the bases a batch reads: whole segments of a full scan; only the two terminal regions of a long segment
 // in tips-only mode — the rest of the layout is never read.
 int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
@@ -462,42 +505,8 @@ int upload_batch(ts_batch *b, const Item *items, int &slot, bool used[]) {
         const SegPlan &sp = b->segs[i];
         for (const Region &rg : sp.regions) {
             // (consecutive regions of one segment never overlap: tips regions are [0,t) and [N-t,N) with N > 2t)
-            if (items[i].format == TS_INPUT_TEXT_PIECES) {
-                // the region's bases [rg.start, rg.start + rg.len) out of the segment's text pieces
-                const ts_text_piece *tp = (const ts_text_piece *)items[i].seq;
-                uint64_t cum = 0, want = rg.start, left = rg.len, off = sp.in_off + rg.start;
-                for (size_t k = 0; left; ++k) {
-                    if (k >= items[i].n_pieces || cum >= sp.len)
-                        return c->fail(TS_ERR_INVALID_ARG, "text pieces hold fewer bases than the segment's length (or n_pieces is not set)");
-                    const ts_text_piece &t = tp[k];
-                    if (t.text_len > (16ull << 20) + 4096) return c->fail(TS_ERR_INVALID_ARG, "a text piece is larger than 16 MiB");
-                    if (want >= cum + t.n_bases) { cum += t.n_bases; continue; }      // wholly before the region
-                    const uint64_t skip = want - cum;
-                    const uint64_t n = std::min<uint64_t>(t.n_bases - skip, left);
-                    // of these n bases, those the batch's range reads (a shard uploads only its part of a segment)
-                    const uint64_t a = std::max<uint64_t>(off, b->in_lo), z = std::min<uint64_t>(off + n, b->in_hi);
-                    if (z > a) {
-                        const uint64_t skip2 = skip + (a - off);
-                        const char *from = skip2 ? text_locate(t.text, t.text_len, skip2) : t.text;
-                        pieces.push_back({a, from, z - a, (uint64_t)(t.text + t.text_len - from)});
-                    }
-                    off += n; left -= n; want += n; cum += t.n_bases;
-                }
-            } else if (items[i].format == TS_INPUT_PACKED2) {
-                const ts_packed_seq *ps = (const ts_packed_seq *)items[i].seq;
-                if (!ps || (!ps->codes && sp.len) || (ps->n_runs && !ps->runs)) return c->fail(TS_ERR_INVALID_ARG, "packed input: null codes or runs");
-                const uint64_t s0 = std::max<uint64_t>(sp.in_off + rg.start, b->in_lo);
-                const uint64_t s1 = std::min<uint64_t>(sp.in_off + rg.start + rg.len, b->in_hi);
-                if (s1 > s0) {
-                    UpPiece pc{s0, nullptr, s1 - s0, 0};
-                    pc.packed = ps; pc.packed_first = s0 - sp.in_off;
-                    pieces.push_back(pc);
-                }
-            } else {
-                const uint64_t s0 = std::max<uint64_t>(sp.in_off + rg.start, b->in_lo);
-                const uint64_t s1 = std::min<uint64_t>(sp.in_off + rg.start + rg.len, b->in_hi);
-                if (s1 > s0) pieces.push_back({s0, items[i].seq + (s0 - sp.in_off), s1 - s0, 0});
-            }
+            const int rc = region_pieces(c, items[i], sp.len, rg.start, rg.len, sp.in_off + rg.start, b->in_lo, b->in_hi, pieces);
+            if (rc != TS_OK) return rc;
         }
     }
     return upload_pieces(c, pieces, din, b->in_lo, slot, used);
@@ -856,9 +865,6 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     if (!c->generic_ok)
         return c->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: more than 8 pattern lengths, a pattern longer "
                                            "than 32 or a non-ACGT pattern");
-    for (size_t i : which)
-        if (segs[i].input_format != TS_INPUT_BASES)
-            return c->fail(TS_ERR_UNSUPPORTED, "text-piece and packed input are taken by the tiled kernel's parameter sets only: hand this one its bases");
     DEVICE_TRY(c);
     { int rc = ensure_streams(c); if (rc != TS_OK) return rc; }
     const ts_params &P = c->params;
@@ -866,6 +872,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     hipStream_t st = c->scan_stream;
     TsGenericGeom Q{};
     Q.s = s; Q.w = w; Q.longest = L; Q.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u; Q.fold = P.fold_case;
+    Q.s_magic = s >= 2u ? (uint32_t)((1ull << 32) / s + 1ull) : 0u;
     if (const char *e = getenv("TS_GEN_ABL")) Q.abl = (uint32_t)atoi(e);
     const bool timing = getenv("TS_TIMING") != nullptr;
     const auto t_begin = Clock::now();
@@ -900,15 +907,27 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     std::thread host_job;
     std::atomic<int> host_err{TS_OK};
     struct JoinJob { std::thread &t; ~JoinJob() { if (t.joinable()) t.join(); } } join_job{host_job};
-    while (wi < which.size()) {
+    // What the upload stage hands the device stage: a group planned, its input buffer, tile list and segment table on the device.
+    // Group g + 1 is planned, staged and uploaded on a thread of its own while group g's kernels, block calling and
+    // download run here (round 4: the two used to run one after the other, 32 + 22 ms per 3 Gb).
+    struct Prepared {
+        std::shared_ptr<GroupHost> gh;
+        DevBuf d_in, d_tiles, d_tab;
+        uint64_t nwin_total = 0;
+        int rc = TS_OK;
+        double ms = 0;
+    };
+    const bool prefetch = !(getenv("TS_GEN_PREFETCH") && getenv("TS_GEN_PREFETCH")[0] == '0');
+    auto prepare = [&](Prepared &PR) -> int {
         // ---- a group of consecutive segments, ~256 MB of regions; layout = the regions back to back, 16-byte aligned
-        std::shared_ptr<GroupHost> gh = std::make_shared<GroupHost>();
-        std::vector<SegL> &G = gh->G;
-        std::vector<TsGeneralTile> &tiles = gh->tiles;
+        PR.gh = std::make_shared<GroupHost>();
+        std::vector<SegL> &G = PR.gh->G;
+        std::vector<TsGeneralTile> &tiles = PR.gh->tiles;
         std::vector<UpPiece> pieces;
         uint64_t off = 0, nwin_total = 0;
         while (wi < which.size() && (G.empty() || off < target)) {
             const ts_segment_in &sg = segs[which[wi]];
+            const Item it{sg.seq, sg.len, sg.abs_pos, sg.input_format, sg.n_pieces};
             SegL sl{which[wi], sg.len, sg.abs_pos, off, {}};
             // regions exactly as scanSegment picks them (src/teloscope.cpp:576-583; uint32 product)
             if (tips) {
@@ -922,7 +941,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
             sl.first_tile = tiles.size();
             for (RegionL &rg : sl.regions) {
                 rg.layout_off = off;
-                pieces.push_back({off, sg.seq + rg.seg_start, rg.len, 0});
+                const int rc = region_pieces(c, it, sg.len, rg.seg_start, rg.len, off, 0, ~0ull, pieces);
+                if (rc != TS_OK) return rc;
                 for (uint64_t a = 0; a < rg.len; a += TS_GENERAL_TILE) {
                     TsGeneralTile T{};
                     T.in_off = off + a;
@@ -940,39 +960,64 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
             G.push_back(std::move(sl));
             ++wi;
         }
+        PR.nwin_total = nwin_total;
         const uint64_t span = off + 64;
         const size_t ns = G.size(), nt = tiles.size();
         if (nt >= 0x7FFFFFFFull) return c->fail(TS_ERR_UNSUPPORTED, "too many tiles in one group");
+        const size_t tab_bytes = 3 * ns * 8 + 8 + 16;
+        HIP_TRY(c, c->pool.take(span, PR.d_in));
+        HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * sizeof(TsGeneralTile), PR.d_tiles));
+        HIP_TRY(c, c->pool.take(tab_bytes, PR.d_tab));
+        std::vector<unsigned long long> tab(3 * ns + 3, 0ull);
+        for (size_t i = 0; i < ns; ++i) { tab[i] = G[i].len; tab[ns + i] = G[i].layout_off; tab[2 * ns + i] = G[i].win_base; }
+        tab[3 * ns] = nwin_total;
+        const auto t0 = Clock::now();
+        { int rc = upload_pieces(c, pieces, PR.d_in.p, 0, slot, used); if (rc != TS_OK) return rc; }
+        HIP_TRY(c, hipMemcpyAsync(PR.d_tiles.p, tiles.data(), nt * sizeof(TsGeneralTile), hipMemcpyHostToDevice, c->up_stream));
+        HIP_TRY(c, hipMemcpyAsync(PR.d_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->up_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->up_stream));
+        PR.ms = ms_between(t0, Clock::now());
+        return TS_OK;
+    };
+    std::unique_ptr<Prepared> cur(new Prepared), nxt;
+    std::thread pf;
+    struct JoinJob join_pf{pf};
+    cur->rc = prepare(*cur);
+    while (cur) {
+        if (cur->rc != TS_OK) return cur->rc;
+        if (pf.joinable()) pf.join();
+        nxt.reset();
+        if (wi < which.size()) {
+            nxt.reset(new Prepared);
+            Prepared *np = nxt.get();
+            if (prefetch) pf = std::thread([&, np] { c->bind_this_thread(); DeviceGuard g2(c->device); np->rc = prepare(*np); });
+        }
+        std::shared_ptr<GroupHost> gh = cur->gh;
+        std::vector<SegL> &G = gh->G;
+        std::vector<TsGeneralTile> &tiles = gh->tiles;
+        const uint64_t nwin_total = cur->nwin_total;
+        const size_t ns = G.size(), nt = tiles.size();
         // ---- device buffers from the pool
-        DevBuf d_in, d_slots, d_tiles, d_tab, d_stats, d_off, d_tmp, d_rec, d_win;
+        DevBuf &d_in = cur->d_in, &d_tiles = cur->d_tiles, &d_tab = cur->d_tab;
+        DevBuf d_slots, d_stats, d_off, d_tmp, d_rec, d_win;
         struct Return { ts_ctx *c; std::vector<DevBuf *> v; ~Return() { for (DevBuf *d : v) c->pool.give(std::move(*d)); } }
             give_back{c, {&d_in, &d_slots, &d_tiles, &d_tab, &d_stats, &d_off, &d_tmp, &d_rec, &d_win}};
-        const size_t tab_len = 0, tab_win = 2 * ns * 8, tab_flag = 3 * ns * 8 + 8, tab_bytes = 3 * ns * 8 + 8 + 16;
+        const size_t tab_len = 0, tab_win = 2 * ns * 8, tab_flag = 3 * ns * 8 + 8;
         // a tile's slot: one record per position — all a single-length set can produce; a mixed-length tile that holds
         // more says so, and the group runs again with slots that cannot overflow
         uint32_t slot_cap = TS_GENERAL_TILE;
         // the list form of the fused pass (per-candidate work on full wavefronts) when a tile adds to few enough window
         // records for the accumulators it keeps in LDS; a tile dense enough to overflow a wave's candidate list sends the
         // group through the position-strided form instead
-        bool use_list = !(getenv("TS_GEN_LIST") && getenv("TS_GEN_LIST")[0] == '0') &&
+        bool use_list = !(getenv("TS_GEN_LIST") && getenv("TS_GEN_LIST")[0] == '0') && s >= 2u &&
                         (tips || ((uint64_t)TS_GENERAL_TILE + w) / s + 3 <= ts_k_general_list_max_records());
-        HIP_TRY(c, c->pool.take(span, d_in));
         HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * (size_t)slot_cap * 4, d_slots));
-        HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * sizeof(TsGeneralTile), d_tiles));
-        HIP_TRY(c, c->pool.take(tab_bytes, d_tab));
         HIP_TRY(c, c->pool.take((nt + 1) * 16, d_stats));
         HIP_TRY(c, c->pool.take((nt + 1) * 8, d_off));
         HIP_TRY(c, c->pool.take((size_t)ts_k_scan_tmp_bytes((uint32_t)nt), d_tmp));
         if (nwin_total) HIP_TRY(c, c->pool.take(nwin_total * 32, d_win));
-        std::vector<unsigned long long> tab(3 * ns + 3, 0ull);
-        for (size_t i = 0; i < ns; ++i) { tab[i] = G[i].len; tab[ns + i] = G[i].layout_off; tab[2 * ns + i] = G[i].win_base; }
-        tab[3 * ns] = nwin_total;
-        const auto t0 = Clock::now();
-        { int rc = upload_pieces(c, pieces, d_in.p, 0, slot, used); if (rc != TS_OK) return rc; }
-        HIP_TRY(c, hipMemcpyAsync(d_tiles.p, tiles.data(), nt * sizeof(TsGeneralTile), hipMemcpyHostToDevice, c->up_stream));
-        HIP_TRY(c, hipMemcpyAsync(d_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->up_stream));
-        HIP_TRY(c, hipStreamSynchronize(c->up_stream));
         const auto t1 = Clock::now();
+        t_up += cur->ms;
         // ---- kernels: the fused pass, a prefix sum over the tile counts, the slots into one dense stream
         char *const dt = (char *)d_tab.p;
         std::vector<unsigned long long> &tile_off = gh->tile_off;
@@ -1068,7 +1113,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         HIP_TRY(c, hipStreamSynchronize(st));
         if (timing) { float ms = 0; if (hipEventElapsedTime(&ms, c->gen_ev[0], c->gen_ev[1]) == hipSuccess) t_kern += ms; }
         const auto t2 = Clock::now();
-        t_up += ms_between(t0, t1); t_dev += ms_between(t1, t2);
+        t_dev += ms_between(t1, t2);
         // ---- host: records -> MatchInfo in the reference's push order, then block calling; one job per segment
         if (host_job.joinable()) host_job.join();                     // (one host stage at a time: it takes all the host threads)
         if (host_err.load() != TS_OK) return host_err.load();
@@ -1200,6 +1245,10 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         if (first_err.load() != TS_OK) { int e = TS_OK; host_err.compare_exchange_strong(e, first_err.load()); }
         t_host += ms_between(th0, Clock::now());
         });
+        // ---- next group: already uploaded by the prefetch thread (or planned and uploaded here)
+        if (pf.joinable()) pf.join();
+        if (nxt && !prefetch) nxt->rc = prepare(*nxt);
+        cur = std::move(nxt);
     }
     if (host_job.joinable()) host_job.join();
     if (host_err.load() != TS_OK) return host_err.load();

@@ -241,7 +241,9 @@ struct TsGenericPatterns {
 struct TsGenericGeom {
     uint32_t s, w, longest;
     uint32_t nuc_on, fold;
-    uint32_t abl;                       // TS_GEN_ABL (profiling): 1 no matching, 2 no window records, 4 no match records, 8 nothing after the table load
+    uint32_t abl;                       // TS_GEN_ABL (profiling): strided form: 1 no matching, 2 no window records, 4 no match records, 8 nothing
+                                        // after the table load; list form: 16 no candidates, 32 no per-candidate pass, 64 no window records
+    uint32_t s_magic;                   // floor(2^32 / s) + 1 (s >= 2): x / s == umulhi(x, s_magic) for x < 2^32 / s (the list form, s <= 8192)
 };
 
 #define TS_GENERAL_TILE 4096            // positions per tile of the general kernels (generic.hip)

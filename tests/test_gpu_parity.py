@@ -208,12 +208,8 @@ def test_packed_upload_route_equals_plain_route_and_oracle(cli, fold, monkeypatc
     # made by ts_pack_bases with the context's case folding) — the staging threads then copy codes, whole bytes where the
     # phases agree (full scans) and shifted where they do not (the second region of a tips-only scan starts anywhere)
     from teloscope_amd import _capi as K
-    takes_packed = bool(K.lib().ts_takes_text_input(tel._ctx.ptr, int(opts.ultra_fast)))     # (the tiled kernel's parameter sets)
+    assert K.lib().ts_takes_text_input(tel._ctx.ptr, int(opts.ultra_fast)) == 1       # (tiled and general parameter sets alike)
     for route in ("1", "0", "packed-in"):
-        if route == "packed-in" and not takes_packed:
-            with pytest.raises(K.TeloscanError):
-                tel.scanSegments(segs, packed=True)
-            continue
         monkeypatch.setenv("TS_PACKED_UPLOAD", "1" if route == "packed-in" else route)
         monkeypatch.setenv("TS_PACKED_MIN_BYTES", "0")
         got = [segment_as_dict(s) for s in tel.scanSegments(segs, packed=(route == "packed-in"))]
@@ -265,15 +261,17 @@ def test_general_path_dense_mixed_lengths_overflow_their_tile_slots():
         assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="dense mixed len=%d" % len(s))
 
 
-def test_text_pieces_are_bounded_by_their_count():
+@pytest.mark.parametrize("cli", ["-w 1000 -s 500 -r -g -e -m -i", "-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i",
+                                 "-c TTTAGGGTTTAGGG -x 1 -w 700 -s 700 -r -g -e -m -i"])
+def test_text_pieces_are_bounded_by_their_count(cli):
     """TS_INPUT_TEXT_PIECES: the piece array carries its length (ts_segment_in.n_pieces); pieces that hold fewer bases
     than the segment declares — or a count that is not set — are TS_ERR_INVALID_ARG, never a read past the array; the
-    same text through pieces and as joined bases gives the same segment."""
+    same text through pieces and as joined bases gives the same segment.  (Tiled and general parameter sets.)"""
     import ctypes as C
     import teloscope_amd as ta
     from teloscope_amd import _capi as K
     from teloscope_amd.cli import user_input
-    opts = H.parse_cli("x.fa -w 1000 -s 500 -r -g -e -m -i")
+    opts = H.parse_cli("x.fa " + cli)
     tel = ta.Teloscope(user_input(opts))
     L = K.lib()
     rng = np.random.default_rng(3)
