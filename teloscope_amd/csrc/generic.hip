@@ -20,6 +20,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "ts_internal.h"
 
 namespace {
@@ -114,29 +117,6 @@ __device__ __forceinline__ bool full_scan_pushes(uint32_t j, uint32_t l, const P
     const long long diff = (long long)g.D1 + (long long)j - (long long)((u64)dk * g.s);
     *rec = g.k1 + dk;
     return diff >= 0 && (u64)diff >= g.start_index;
-}
-
-// A/C/T/G of the tile positions [qa, qb) from the packed planes, 16 positions per lane and step: valid2 holds 01 per valid
-// position, so the low code bits under it are the C and G, the high ones the T and G.
-__device__ __forceinline__ void count_range(const uint32_t *codes2, const uint32_t *valid2, uint32_t qa, uint32_t qb, uint32_t lane,
-                                            uint32_t &nV, uint32_t &nC, uint32_t &nT, uint32_t &nG) {
-    if (qa >= qb) return;
-    const uint32_t d0 = qa >> 4, d1 = (qb - 1u) >> 4;
-#pragma unroll 1
-    for (uint32_t d = d0 + lane; d <= d1; d += 64u) {
-        uint32_t v = valid2[d];
-        if (d == d0) v &= ~0u << (2u * (qa & 15u));
-        if (d == d1) v &= ~0u >> (2u * (15u - ((qb - 1u) & 15u)));
-        const uint32_t w = codes2[d], lo = w & v, hi = (w >> 1) & v;
-        const uint32_t g = (uint32_t)__popc(lo & hi);
-        nV += (uint32_t)__popc(v); nG += g; nC += (uint32_t)__popc(lo) - g; nT += (uint32_t)__popc(hi) - g;
-    }
-}
-
-// tile positions [P0, P0 + ntile) that are segment positions [lo, hi), as tile-relative [qa, qb)
-__device__ __forceinline__ void clip_to_tile(u64 lo, u64 hi, u64 P0, uint32_t ntile, uint32_t &qa, uint32_t &qb) {
-    qa = lo > P0 ? (uint32_t)(lo - P0 < ntile ? lo - P0 : ntile) : 0u;
-    qb = hi > P0 ? (uint32_t)(hi - P0 < ntile ? hi - P0 : ntile) : 0u;
 }
 
 // code (0..3) and validity of tile position q from the packed planes
@@ -379,6 +359,7 @@ void ts_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint3
 
 constexpr uint32_t kWaccMax = 256;          // window records a tile may add to on the list path
 constexpr uint32_t kListWave = 1024;        // candidate entries a wave's 1024 positions may produce on the list path
+constexpr uint32_t kCumWords = 260;         // per-dword nucleotide prefix sums of a tile (256 + the end sentinel), list path
 constexpr uint32_t kShortLen = 6;           // pattern lengths up to this have exact tables in LDS (their l-mers index them)
 
 // Inclusive prefix sum over the wave's lanes by DPP (row shifts, then the two row broadcasts: lane 63 holds the total).
@@ -429,10 +410,13 @@ __device__ __forceinline__ bool full_scan_pushes_m(uint32_t j, uint32_t l, const
 
 // The same pass in its LIST form (round 3; restructured in round 4): what the kernel above does per position — flag
 // lookup, push test, window shares — is done here per CANDIDATE, on full wavefronts, and a position costs ONE LDS probe.
-//   1'. stage as above (SWAR: v_perm / v_dot4, four bases per instruction), plus two tables built per workgroup:
-//       cand6   a byte per 6-mer: bit li set when its first min(l, 6) bases begin a pattern of length index li — exact for
-//               l <= 6 (a pattern shorter than six sets the bit under every extension), a filter for longer ones;
-//       sflag   per length <= 6: {forward, canonical} of the l-mer, 2 bits each — those lengths need no search at all;
+// PERSISTENT workgroups (a few per CU) stride over the tiles: the pattern tables are built once per workgroup, not per tile.
+//   0.  once: cand6   a byte per 6-mer: bit li set when its first min(l, 6) bases begin a pattern of length index li — exact
+//               for l <= 6 (a pattern shorter than six sets the bit under every extension), a filter for longer ones;
+//             sflag   per length <= 6: {forward, canonical} of the l-mer, 2 bits each — those lengths need no search at all;
+//   per tile:
+//   1'. stage (SWAR: v_perm / v_dot4, four bases per instruction; the next tile's bases are requested before this one's
+//       are consumed), and per plane dword the nucleotide counts of its 16 positions, prefix-summed over the tile (DPP);
 //   2'. candidates: a lane owns SIXTEEN CONSECUTIVE positions (one plane dword + the next), takes their 6-mers with one
 //       v_bfe / v_alignbit each and reads cand6 once per position; the wave appends its candidates (position, length
 //       index), in order, to its own list in LDS after ONE prefix sum over the lanes' counts.  Non-ACGT bases and the
@@ -440,7 +424,9 @@ __device__ __forceinline__ bool full_scan_pushes_m(uint32_t j, uint32_t l, const
 //   3'. a lane per candidate: flags from sflag, or the binary search for l > 6; the push test (divisions by the step as
 //       one multiply); the covered bases of the match ADDED to the accumulators of the window records it belongs to — the
 //       pushing window's own record (analyzeWindow's main part) and the record after every call that carries it;
-//   4'. window records: a wave per record, nucleotides by popcounts over the packed planes; stored or added as above;
+//   4'. window records: a LANE per record — the nucleotides of the (up to two) position ranges a record collects are
+//       differences of the prefix sums at their ends; stored (two 16-byte stores) when the tile holds the whole record,
+//       added otherwise;
 //   5'. match records: the pushed candidates, in list order (= position then length order), into the tile's slot.
 // Taken when a tile adds to at most kWaccMax window records (decided on the host from w and s) and the pattern lists fit
 // LDS; a wave whose list overflows (more than one candidate per position: dense repeats under a mixed-length set) raises
@@ -450,55 +436,84 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
                            const u64 *seg_win_base, const TsGenericPatterns G, const TsGenericGeom Q, int tips, uint32_t slot_cap,
                            uint32_t lds_patterns, uint32_t nshort, uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
     extern __shared__ __align__(16) unsigned char lds[];
-    // layout: list u32[4][kListWave] | pcode u64[lds_patterns] | cand6 u8[4096] | sflag u8[nshort][1024] | part u32[8] | first u32[12] |
-    //         codes2 | inval | valid2 | wacc | pflag
+    // layout: list u32[4][kListWave] | pcode u64[lds_patterns] | cand6 u8[4096] | sflag u8[nshort][1024] | wacc u32[kWaccMax][4] |
+    //         part u32[8] | first u32[12] | wtot u32[2][4] | wbase u32[2][8] | codes2 | inval | valid2 | cum u32[2][kCumWords] | pflag
     uint32_t *list_all = (uint32_t *)lds;
     u64 *pcode = (u64 *)(lds + 4u * kListWave * 4u);
-    uint32_t *cand6w = (uint32_t *)(lds + 4u * kListWave * 4u + (size_t)lds_patterns * 8u);
+    uint32_t *cand6w = (uint32_t *)(lds + 4u * kListWave * 4u + (((size_t)lds_patterns * 8u + 15u) & ~(size_t)15u));   // (16-byte aligned: wacc is zeroed and read as uint4)
     const unsigned char *cand6 = (const unsigned char *)cand6w;
     uint32_t *sflagw = cand6w + 1024u;
-    uint32_t *part = sflagw + nshort * 256u;
+    uint32_t *wacc = sflagw + nshort * 256u;                               // [kWaccMax][4]: canonical, non-canonical, forward, reverse covered
+    uint32_t *part = wacc + kWaccMax * 4u;
     uint32_t *firstl = part + 8;
-    uint32_t *codes2 = firstl + 12;
+    uint32_t *wtot = firstl + 12;                                          // per wave: nucleotide totals of its 64 plane dwords {V | G << 16, C | T << 16}
+    uint32_t *wbase = wtot + 8;                                            // the same summed over the waves before (entries 0..4, twice)
+    uint32_t *codes2 = wbase + 16;
     uint32_t *inval = codes2 + kCodeWords;
     uint32_t *valid2 = inval + kInvalWords;
-    uint32_t *wacc = valid2 + kCodeWords;                                  // [kWaccMax][4]: canonical, non-canonical, forward, reverse covered
-    unsigned char *pflag = (unsigned char *)(wacc + kWaccMax * 4u);
-    if (blockIdx.x >= ntiles) return;
+    uint32_t *cumVG = valid2 + kCodeWords;                                 // per plane dword: counts of the dwords before it IN ITS WAVE
+    uint32_t *cumCT = cumVG + kCumWords;
+    unsigned char *pflag = (unsigned char *)(cumCT + kCumWords);
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     uint32_t *const list = list_all + wave * kListWave;
+    if (blockIdx.x >= ntiles) return;
     const uint32_t npat = G.first[G.nlen];
+    // 0. the tables, once per workgroup
     for (uint32_t i = tid; i < 1024u + nshort * 256u; i += 256u) cand6w[i] = 0u;       // (cand6 and sflag are adjacent)
-    for (uint32_t i = tid; i < kWaccMax * 4u; i += 256u) wacc[i] = 0u;
     for (uint32_t i = tid; i < npat; i += 256u) { pcode[i] = G.codes[i]; pflag[i] = G.flags[i]; }
     if (tid == 0u) {
 #pragma unroll
         for (uint32_t q = 0; q < 9u; ++q) firstl[q] = G.first[q];
+        cumVG[256] = 0u; cumCT[256] = 0u;
     }
     // the pattern lengths as six bits each (uniform), for the per-candidate pass
     u64 lens64 = 0;
 #pragma unroll
     for (uint32_t li = 0; li < 8u; ++li) lens64 |= (u64)(li < G.nlen ? G.len[li] : 0u) << (6u * li);
-    const TsGeneralTile T = tiles[blockIdx.x];
-    // 1'. stage
-    const uint32_t avail = T.avail;
-    const unsigned char *src = in + T.in_off;
+    __syncthreads();
+    // every pattern once (the first of equal codes, as the search finds it)
+    for (uint32_t li = 0; li < G.nlen; ++li) {
+        const uint32_t l = G.len[li], q = l < kShortLen ? l : kShortLen, ext_bits = 2u * (kShortLen - q);
+        const uint32_t f0 = G.first[li], cnt = G.first[li + 1] - f0;
+        for (uint32_t x = tid; x < (cnt << ext_bits); x += 256u) {
+            const uint32_t i = f0 + (x >> ext_bits);
+            const u64 code = pcode[i];
+            if (i > f0 && pcode[i - 1u] == code) continue;
+            const uint32_t idx = ((uint32_t)code & ((1u << (2u * q)) - 1u)) | ((x & ((1u << ext_bits) - 1u)) << (2u * q));
+            atomicOr(&cand6w[idx >> 2], (1u << li) << (8u * (idx & 3u)));
+            if (l <= kShortLen && (x & ((1u << ext_bits) - 1u)) == 0u)
+                atomicOr(&sflagw[li * 256u + ((uint32_t)code >> 4)], (uint32_t)(pflag[i] & 3u) << (2u * ((uint32_t)code & 15u)));
+        }
+    }
     const uint32_t fold_mask = Q.fold ? 0xDFDFDFDFu : 0xFFFFFFFFu;
-    for (uint32_t i = tid * 16u; i < kCodeWords * 16u; i += 256u * 16u) {
+    const uint32_t magic = Q.s_magic;
+    const bool carries = Q.w != Q.s;
+    const uint32_t ov = Q.w - Q.s;
+    // the next 32 bases of tile position j
+    auto bases_at = [&](uint32_t j) -> u64 {
+        const uint32_t wd = j >> 4, sh = 2u * (j & 15u);
+        const uint32_t c0 = codes2[wd], c1 = codes2[wd + 1u], c2 = codes2[wd + 2u];
+        return (u64)__funnelshift_r(c0, c1, sh) | ((u64)__funnelshift_r(c1, c2, sh) << 32);
+    };
+    // nucleotide counts of the tile positions [0, q), q <= 4096: {V | G << 16, C | T << 16} (V: valid bases)
+    auto prefix_counts = [&](uint32_t q, uint32_t &VG, uint32_t &CT) {
+        const uint32_t d = q >> 4, m = (1u << (2u * (q & 15u))) - 1u;
+        const uint32_t v = valid2[d] & m, w = codes2[d], lo = w & v, hi = (w >> 1) & v;
+        const uint32_t g = (uint32_t)__popc(lo & hi);
+        VG = cumVG[d] + wbase[d >> 6] + ((uint32_t)__popc(v) | (g << 16));
+        CT = cumCT[d] + wbase[8u + (d >> 6)] + (((uint32_t)__popc(lo) - g) | (((uint32_t)__popc(hi) - g) << 16));
+    };
+    // a thread stages the plane dword tid (bases [16 tid, 16 tid + 16)); threads 0..5 also the halo's dwords 256 + tid.  The
+    // layout's regions start on 16-byte boundaries and tiles at multiples of 4096 inside them (the host checks): aligned loads;
+    // the layout keeps 64 readable bytes behind the last region.
+    auto load16 = [&](const TsGeneralTile &T, uint32_t i) -> uint4 {
+        return i < T.avail ? *(const uint4 *)(in + T.in_off + i) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto stage16 = [&](const uint4 v, uint32_t i, uint32_t avail, uint32_t &vg, uint32_t &ct) {
         uint32_t cw = 0, iv = 0xFFFFu;
         if (i < avail) {
-            uint32_t d[4];
-            if (((uintptr_t)(src + i) & 15u) == 0u) {                      // (the layout keeps 64 readable bytes behind the last region)
-                const uint4 v = *(const uint4 *)(src + i);
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            } else {
-                for (uint32_t q = 0; q < 4u; ++q) {
-                    uint32_t x = 0;
-                    for (uint32_t r = 0; r < 4u; ++r) x |= (i + 4u * q + r < avail ? (uint32_t)src[i + 4u * q + r] : 0u) << (8u * r);
-                    d[q] = x;
-                }
-            }
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
             // ASCII & 6 = twice the code (A 0, C 2, T 4, G 6) and the v_perm selector of the letter that code stands for; a byte
             // that is not that letter (up to case folding) is invalid
             uint32_t t[4], b4[4];
@@ -520,224 +535,251 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
         ok = (ok | (ok << 8)) & 0x00FF00FFu; ok = (ok | (ok << 4)) & 0x0F0F0F0Fu;
         ok = (ok | (ok << 2)) & 0x33333333u; ok = (ok | (ok << 1)) & 0x55555555u;
         valid2[i >> 4] = ok;
-    }
-    __syncthreads();
-    // the tables: every pattern once (the first of equal codes, as the search finds it)
-    for (uint32_t li = 0; li < G.nlen; ++li) {
-        const uint32_t l = G.len[li], q = l < kShortLen ? l : kShortLen, ext_bits = 2u * (kShortLen - q);
-        const uint32_t f0 = G.first[li], cnt = G.first[li + 1] - f0;
-        for (uint32_t x = tid; x < (cnt << ext_bits); x += 256u) {
-            const uint32_t i = f0 + (x >> ext_bits);
-            const u64 code = pcode[i];
-            if (i > f0 && pcode[i - 1u] == code) continue;
-            const uint32_t idx = ((uint32_t)code & ((1u << (2u * q)) - 1u)) | ((x & ((1u << ext_bits) - 1u)) << (2u * q));
-            atomicOr(&cand6w[idx >> 2], (1u << li) << (8u * (idx & 3u)));
-            if (l <= kShortLen && (x & ((1u << ext_bits) - 1u)) == 0u)
-                atomicOr(&sflagw[li * 256u + ((uint32_t)code >> 4)], (uint32_t)(pflag[i] & 3u) << (2u * ((uint32_t)code & 15u)));
-        }
-    }
-    __syncthreads();
-    // the next 32 bases of tile position j
-    auto bases_at = [&](uint32_t j) -> u64 {
-        const uint32_t wd = j >> 4, sh = 2u * (j & 15u);
-        const uint32_t c0 = codes2[wd], c1 = codes2[wd + 1u], c2 = codes2[wd + 2u];
-        return (u64)__funnelshift_r(c0, c1, sh) | ((u64)__funnelshift_r(c1, c2, sh) << 32);
+        const uint32_t lo = cw & ok, hi = (cw >> 1) & ok, g = (uint32_t)__popc(lo & hi);
+        vg = (uint32_t)__popc(ok) | (g << 16);
+        ct = ((uint32_t)__popc(lo) - g) | (((uint32_t)__popc(hi) - g) << 16);
     };
-    // 2'. candidates: wave v owns the 1024 consecutive positions [1024 v, 1024 v + 1024), lane L the sixteen from 16 L on
-    uint32_t ncand = 0;                                                    // (wave-uniform)
-    bool spilled = false;
-    if (!(Q.abl & 16u)) {
-        const uint32_t wd0 = wave * 64u + lane, j0 = wd0 * 16u;
-        const uint32_t c0 = codes2[wd0], c1 = codes2[wd0 + 1u];
-        uint32_t acc[4] = {0u, 0u, 0u, 0u};                                // a byte of length bits per position
-#pragma unroll
-        for (uint32_t i = 0; i < 16u; ++i) {
-            const uint32_t idx = (i <= 10u ? (c0 >> (2u * i)) : __builtin_amdgcn_alignbit(c1, c0, 2u * i)) & 0xFFFu;
-            acc[i >> 2] |= (uint32_t)cand6[idx] << (8u * (i & 3u));
+    uint32_t tile = blockIdx.x;
+    TsGeneralTile T = tiles[tile];
+    uint4 v_main = load16(T, tid * 16u), v_halo = tid < kCodeWords - 256u ? load16(T, 4096u + tid * 16u) : make_uint4(0u, 0u, 0u, 0u);
+    for (;;) {
+        // 1'. stage
+        const uint32_t avail = T.avail;
+        {
+            uint32_t vg, ct, hv = 0, hc = 0;
+            for (uint32_t i = tid; i < kWaccMax; i += 256u) *(uint4 *)&wacc[4u * i] = make_uint4(0u, 0u, 0u, 0u);
+            stage16(v_main, tid * 16u, avail, vg, ct);
+            if (tid < kCodeWords - 256u) stage16(v_halo, 4096u + tid * 16u, avail, hv, hc);
+            (void)hv; (void)hc;
+            // the wave's prefix sums of the counts (each field <= 4096: the 16-bit halves do not carry into each other)
+            const uint32_t ivg = wave_inclusive_dpp(vg), ict = wave_inclusive_dpp(ct);
+            cumVG[tid] = ivg - vg; cumCT[tid] = ict - ct;
+            if (lane == 63u) { wtot[wave] = ivg; wtot[4u + wave] = ict; }
         }
-        // non-ACGT bases within reach of the wave's positions, or the region's end: lengths that do not fit are dropped
-        const unsigned short *inval16 = (const unsigned short *)inval;
-        const u64 iv48 = (u64)inval16[wd0] | ((u64)inval16[wd0 + 1u] << 16) | ((u64)inval16[wd0 + 2u] << 32);
-        const bool slow = wave * 1024u + 1024u + 32u > avail || __builtin_amdgcn_ballot_w64(iv48 != 0ull) != 0ull;
-        if (slow) {
-#pragma unroll 1
+        // the next tile's bases are on their way while this one is worked on
+        const uint32_t tile_next = tile + gridDim.x;
+        const bool more = tile_next < ntiles;
+        TsGeneralTile Tn = T;
+        if (more) {
+            Tn = tiles[tile_next];
+            v_main = load16(Tn, tid * 16u);
+            if (tid < kCodeWords - 256u) v_halo = load16(Tn, 4096u + tid * 16u);
+        }
+        __syncthreads();
+        if (tid < 5u) {                                                    // sums over the waves before (entry 4: the whole tile)
+            uint32_t a = 0, b = 0;
+            for (uint32_t v = 0; v < tid; ++v) { a += wtot[v]; b += wtot[4u + v]; }
+            wbase[tid] = a; wbase[8u + tid] = b;
+        }
+        // 2'. candidates: wave v owns the 1024 consecutive positions [1024 v, 1024 v + 1024), lane L the sixteen from 16 L on
+        uint32_t ncand = 0;                                                    // (wave-uniform)
+        bool spilled = false;
+        if (!(Q.abl & 16u)) {
+            const uint32_t wd0 = wave * 64u + lane, j0 = wd0 * 16u;
+            const uint32_t c0 = codes2[wd0], c1 = codes2[wd0 + 1u];
+            uint32_t acc[4] = {0u, 0u, 0u, 0u};                                // a byte of length bits per position
+#pragma unroll
             for (uint32_t i = 0; i < 16u; ++i) {
-                const uint32_t ivi = (uint32_t)(iv48 >> i), j = j0 + i;
-                const uint32_t nvalid = ivi ? (uint32_t)__builtin_ctz(ivi) : 32u;
-                const uint32_t rem = avail > j ? avail - j : 0u;
-                const uint32_t maxlen = nvalid < rem ? nvalid : rem;
-                uint32_t cnt = 0;
-#pragma unroll
-                for (uint32_t li = 0; li < 8u; ++li) cnt += ((uint32_t)(lens64 >> (6u * li)) & 63u) - 1u < maxlen ? 1u : 0u;   // 1 <= len <= maxlen (len 0: unused slot)
-                const uint32_t keep = ~(0xFFu << cnt) & 0xFFu;
-                const uint32_t r = i >> 2, sh = 8u * (i & 3u);
-                // (acc is indexed by constants only: no scratch)
-                if (r == 0u) acc[0] &= ~(0xFFu << sh) | (keep << sh);
-                else if (r == 1u) acc[1] &= ~(0xFFu << sh) | (keep << sh);
-                else if (r == 2u) acc[2] &= ~(0xFFu << sh) | (keep << sh);
-                else acc[3] &= ~(0xFFu << sh) | (keep << sh);
+                const uint32_t idx = (i <= 10u ? (c0 >> (2u * i)) : __builtin_amdgcn_alignbit(c1, c0, 2u * i)) & 0xFFFu;
+                acc[i >> 2] |= (uint32_t)cand6[idx] << (8u * (i & 3u));
             }
-        }
-        const uint32_t c = (uint32_t)(__popc(acc[0]) + __popc(acc[1]) + __popc(acc[2]) + __popc(acc[3]));
-        const uint32_t incl = wave_inclusive_dpp(c);
-        ncand = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (ncand > kListWave) { spilled = true; ncand = 0; }
-        else {
-            uint32_t at = incl - c;
-#pragma unroll
-            for (uint32_t r = 0; r < 4u; ++r)
-                for (uint32_t m = acc[r]; m; m &= m - 1u) {
-                    const uint32_t b = (uint32_t)__builtin_ctz(m);
-                    list[at++] = ((j0 + 4u * r + (b >> 3)) << 5) | ((b & 7u) << 2);
-                }
-        }
-    }
-    if (spilled && lane == 0u) atomicOr(overflow, 2u);
-    const u64 n = seg_len[T.seg];
-    const u64 P0 = T.seg_rel;
-    // window geometry of the tile: the calls whose windows reach it, the records it adds to
-    const bool win_on = !tips && T.n;
-    u64 nwin = 0, kw_lo = 0, kw_hi = 0, rec_hi = 0;
-    const bool carries = Q.w != Q.s;
-    if (win_on) {
-        nwin = (n + Q.s - 1u) / Q.s;
-        kw_lo = P0 >= Q.w ? (P0 - Q.w) / Q.s + 1u : 0u;                   // first call whose window reaches the tile
-        kw_hi = (P0 + T.n - 1u) / Q.s;                                    // last call that starts inside it
-        if (kw_hi >= nwin) kw_hi = nwin - 1u;
-        rec_hi = kw_hi + (carries ? 1u : 0u);
-        if (rec_hi >= nwin) rec_hi = nwin - 1u;
-        if (rec_hi - kw_lo >= kWaccMax) { if (tid == 0u) atomicOr(overflow, 2u); spilled = true; }     // (the host sizes this out: never)
-    }
-    const PushGeom pg = push_geom(P0, n, Q);
-    const uint32_t magic = Q.s_magic;
-    const u64 N1 = n - P0;                                                  // bases from the tile's first to the segment's end
-    // 3'. a lane per candidate
-    uint32_t npush = 0;
-    __builtin_amdgcn_wave_barrier();
+            // non-ACGT bases within reach of the wave's positions, or the region's end: lengths that do not fit are dropped
+            const unsigned short *inval16 = (const unsigned short *)inval;
+            const u64 iv48 = (u64)inval16[wd0] | ((u64)inval16[wd0 + 1u] << 16) | ((u64)inval16[wd0 + 2u] << 32);
+            const bool slow = wave * 1024u + 1024u + 32u > avail || __builtin_amdgcn_ballot_w64(iv48 != 0ull) != 0ull;
+            if (slow) {
 #pragma unroll 1
-    for (uint32_t e0 = 0; e0 < ncand && !spilled && !(Q.abl & 32u); e0 += 64u) {
-        const uint32_t e = e0 + lane;
-        bool pushed = false;
-        if (e < ncand) {
-            uint32_t ent = list[e];
-            const uint32_t j = ent >> 5, li = (ent >> 2) & 7u, l = (uint32_t)(lens64 >> (6u * li)) & 63u;
-            const u64 code64 = bases_at(j);
-            const u64 code = l >= 32u ? code64 : (code64 & ((1ull << (2u * l)) - 1ull));
-            bool found = true;
-            uint32_t fl;
-            if (l <= kShortLen) {                                           // exact tables: a candidate is a match
-                const uint32_t cidx = (uint32_t)code;
-                fl = (sflagw[li * 256u + (cidx >> 4)] >> (2u * (cidx & 15u))) & 3u;
-            } else {
-                uint32_t lo = firstl[li], hi = firstl[li + 1u];
-                const uint32_t end = hi;
-                while (lo < hi) {                    // binary search in the sorted code list of this length
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (pcode[mid] < code) lo = mid + 1; else hi = mid;
+                for (uint32_t i = 0; i < 16u; ++i) {
+                    const uint32_t ivi = (uint32_t)(iv48 >> i), j = j0 + i;
+                    const uint32_t nvalid = ivi ? (uint32_t)__builtin_ctz(ivi) : 32u;
+                    const uint32_t rem = avail > j ? avail - j : 0u;
+                    const uint32_t maxlen = nvalid < rem ? nvalid : rem;
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (uint32_t li = 0; li < 8u; ++li) cnt += ((uint32_t)(lens64 >> (6u * li)) & 63u) - 1u < maxlen ? 1u : 0u;   // 1 <= len <= maxlen (len 0: unused slot)
+                    const uint32_t keep = ~(0xFFu << cnt) & 0xFFu;
+                    const uint32_t r = i >> 2, sh = 8u * (i & 3u);
+                    // (acc is indexed by constants only: no scratch)
+                    if (r == 0u) acc[0] &= ~(0xFFu << sh) | (keep << sh);
+                    else if (r == 1u) acc[1] &= ~(0xFFu << sh) | (keep << sh);
+                    else if (r == 2u) acc[2] &= ~(0xFFu << sh) | (keep << sh);
+                    else acc[3] &= ~(0xFFu << sh) | (keep << sh);
                 }
-                found = lo < end && pcode[lo] == code;
-                fl = found ? pflag[lo] : 0u;                                // bit0 forward, bit1 canonical
             }
-            if (found) {
-                u64 rec = 0;
-                pushed = tips || full_scan_pushes_m(j, l, pg, magic, &rec);
-                if (win_on) {
-                    const uint32_t f_can = (fl & 2u) ? 0u : 1u, f_fwd = (fl & 1u) ? 2u : 3u;
-                    // the window that pushes a match counts it in its own record (analyzeWindow's main part) ...
-                    if (pushed) {
-                        uint32_t *a4 = wacc + (uint32_t)(rec - kw_lo) * 4u;
-                        atomicAdd(a4 + f_can, l);
-                        atomicAdd(a4 + f_fwd, l);
+            const uint32_t c = (uint32_t)(__popc(acc[0]) + __popc(acc[1]) + __popc(acc[2]) + __popc(acc[3]));
+            const uint32_t incl = wave_inclusive_dpp(c);
+            ncand = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (ncand > kListWave) { spilled = true; ncand = 0; }
+            else {
+                uint32_t at = incl - c;
+#pragma unroll
+                for (uint32_t r = 0; r < 4u; ++r)
+                    for (uint32_t m = acc[r]; m; m &= m - 1u) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(m);
+                        list[at++] = ((j0 + 4u * r + (b >> 3)) << 5) | ((b & 7u) << 2);
                     }
-                    // ... and every call kw that meets it at i >= step (at or behind its own start index) carries it into
-                    // record kw + 1 as long as it ends inside that call's window: kw = p / s - 1 downwards, i grows by s
-                    if (carries) {
-                        const uint32_t x = pg.rP0 + j, dkp = div_step(x, Q.s, magic);
-                        u64 kw = pg.kP0 + dkp;
-                        uint32_t i = x - dkp * Q.s;                          // (< w + s while the loop runs)
-                        while (kw > 0u) {
-                            --kw; i += Q.s;
-                            if (i + l - 1u >= Q.w) break;                   // ends behind every further window too
-                            const uint32_t si = kw == 0u ? Q.s : (pg.start_index > Q.s ? pg.start_index : Q.s);
-                            if (i < si) continue;
-                            const u64 left = N1 - j + i;                    // n - kw s
-                            const u64 cws = left < Q.w ? left : Q.w;
-                            if (i + l - 1u < cws && kw + 1u <= rec_hi) {
-                                uint32_t *a4 = wacc + (uint32_t)(kw + 1u - kw_lo) * 4u;
-                                atomicAdd(a4 + f_can, l);
-                                atomicAdd(a4 + f_fwd, l);
+            }
+        }
+        if (spilled && lane == 0u) atomicOr(overflow, 2u);
+        const u64 n = seg_len[T.seg];
+        const u64 P0 = T.seg_rel;
+        // window geometry of the tile: the calls whose windows reach it, the records it adds to
+        const bool win_on = !tips && T.n;
+        u64 nwin = 0, kw_lo = 0, kw_hi = 0, rec_hi = 0;
+        if (win_on) {
+            nwin = (n + Q.s - 1u) / Q.s;
+            kw_lo = P0 >= Q.w ? (P0 - Q.w) / Q.s + 1u : 0u;                   // first call whose window reaches the tile
+            kw_hi = (P0 + T.n - 1u) / Q.s;                                    // last call that starts inside it
+            if (kw_hi >= nwin) kw_hi = nwin - 1u;
+            rec_hi = kw_hi + (carries ? 1u : 0u);
+            if (rec_hi >= nwin) rec_hi = nwin - 1u;
+            if (rec_hi - kw_lo >= kWaccMax) { if (tid == 0u) atomicOr(overflow, 2u); spilled = true; }     // (the host sizes this out: never)
+        }
+        const PushGeom pg = push_geom(P0, n, Q);
+        const u64 N1 = n - P0;                                                  // bases from the tile's first to the segment's end
+        // 3'. a lane per candidate
+        uint32_t npush = 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (uint32_t e0 = 0; e0 < ncand && !spilled && !(Q.abl & 32u); e0 += 64u) {
+            const uint32_t e = e0 + lane;
+            bool pushed = false;
+            if (e < ncand) {
+                uint32_t ent = list[e];
+                const uint32_t j = ent >> 5, li = (ent >> 2) & 7u, l = (uint32_t)(lens64 >> (6u * li)) & 63u;
+                const u64 code64 = bases_at(j);
+                const u64 code = l >= 32u ? code64 : (code64 & ((1ull << (2u * l)) - 1ull));
+                bool found = true;
+                uint32_t fl;
+                if (l <= kShortLen) {                                           // exact tables: a candidate is a match
+                    const uint32_t cidx = (uint32_t)code;
+                    fl = (sflagw[li * 256u + (cidx >> 4)] >> (2u * (cidx & 15u))) & 3u;
+                } else {
+                    uint32_t lo = firstl[li], hi = firstl[li + 1u];
+                    const uint32_t end = hi;
+                    while (lo < hi) {                    // binary search in the sorted code list of this length
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (pcode[mid] < code) lo = mid + 1; else hi = mid;
+                    }
+                    found = lo < end && pcode[lo] == code;
+                    fl = found ? pflag[lo] : 0u;                                // bit0 forward, bit1 canonical
+                }
+                if (found) {
+                    u64 rec = 0;
+                    pushed = tips || full_scan_pushes_m(j, l, pg, magic, &rec);
+                    if (win_on) {
+                        const uint32_t f_can = (fl & 2u) ? 0u : 1u, f_fwd = (fl & 1u) ? 2u : 3u;
+                        // the window that pushes a match counts it in its own record (analyzeWindow's main part) ...
+                        if (pushed) {
+                            uint32_t *a4 = wacc + (uint32_t)(rec - kw_lo) * 4u;
+                            atomicAdd(a4 + f_can, l);
+                            atomicAdd(a4 + f_fwd, l);
+                        }
+                        // ... and every call kw that meets it at i >= step (at or behind its own start index) carries it into
+                        // record kw + 1 as long as it ends inside that call's window: kw = p / s - 1 downwards, i grows by s
+                        if (carries) {
+                            const uint32_t x = pg.rP0 + j, dkp = div_step(x, Q.s, magic);
+                            u64 kw = pg.kP0 + dkp;
+                            uint32_t i = x - dkp * Q.s;                          // (< w + s while the loop runs)
+                            while (kw > 0u) {
+                                --kw; i += Q.s;
+                                if (i + l - 1u >= Q.w) break;                   // ends behind every further window too
+                                const uint32_t si = kw == 0u ? Q.s : (pg.start_index > Q.s ? pg.start_index : Q.s);
+                                if (i < si) continue;
+                                const u64 left = N1 - j + i;                    // n - kw s
+                                const u64 cws = left < Q.w ? left : Q.w;
+                                if (i + l - 1u < cws && kw + 1u <= rec_hi) {
+                                    uint32_t *a4 = wacc + (uint32_t)(kw + 1u - kw_lo) * 4u;
+                                    atomicAdd(a4 + f_can, l);
+                                    atomicAdd(a4 + f_fwd, l);
+                                }
                             }
                         }
                     }
+                    ent |= fl & 3u;
                 }
-                ent |= fl & 3u;
+                list[e] = pushed ? (ent | 0x80000000u) : 0u;                    // (tile positions are below 2^12: bit 31 is free)
             }
-            list[e] = pushed ? (ent | 0x80000000u) : 0u;                    // (tile positions are below 2^12: bit 31 is free)
+            npush += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pushed));
         }
-        npush += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pushed));
-    }
-    if (lane == 0u) { part[wave] = npush; part[4u + wave] = spilled ? 1u : 0u; }
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-    for (uint32_t v = 0; v < 4u; ++v) { if (v < wave) base += part[v]; total += part[v]; }
-    // did any wave's list spill?  then nothing of this tile counts: the group runs again with the kernel above
-    const bool any_spill = (part[4] | part[5] | part[6] | part[7]) != 0u;
-    if (tid == 0u) {
-        *(uint4 *)&tile_stats[4ull * blockIdx.x] = make_uint4(total, 0u, 0u, 0u);
-        if (total > slot_cap) atomicOr(overflow, 1u);
-    }
-    if (any_spill) return;
-    // 4'. window records
-    if (win_on && !(Q.abl & 64u)) {
-        uint32_t *const wrec = win_out + seg_win_base[T.seg] * 8ull;
-        const uint32_t ov = Q.w - Q.s;
-#pragma unroll 1
-        for (u64 R = kw_lo + wave; R <= rec_hi; R += 4u) {
-            uint32_t nV = 0, nC = 0, nT = 0, nG = 0;
+        if (lane == 0u) { part[wave] = npush; part[4u + wave] = spilled ? 1u : 0u; }
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+        for (uint32_t v = 0; v < 4u; ++v) { if (v < wave) base += part[v]; total += part[v]; }
+        // did any wave's list spill?  then nothing of this tile counts: the group runs again with the kernel above
+        const bool any_spill = (part[4] | part[5] | part[6] | part[7]) != 0u;
+        if (tid == 0u) {
+            *(uint4 *)&tile_stats[4ull * tile] = make_uint4(total, 0u, 0u, 0u);
+            if (total > slot_cap) atomicOr(overflow, 1u);
+        }
+        // 4'. window records: thread r takes record kw_lo + r.  Positions relative to the tile's first base, 32-bit signed (the
+        // host keeps w below 2^28 on this path; a segment end farther away than that is as good as infinitely far)
+        if (win_on && !any_spill && !(Q.abl & 64u) && (u64)tid <= rec_hi - kw_lo) {
+            const u64 R = kw_lo + tid;
+            const int32_t rel = (int32_t)((long long)(kw_lo * Q.s) - (long long)P0) + (int32_t)(tid * Q.s);   // R s - P0
+            const int32_t N1c = N1 > 0x3FFF0000ull ? 0x3FFF0000 : (int32_t)N1;
+            const int32_t left = N1c - rel;                                  // n - R s (>= 1: R < nwin)
+            const int32_t tn = (int32_t)T.n;
+            uint32_t VG = 0, CT = 0;
+            auto add_range = [&](int32_t a, int32_t b) {                     // tile positions [a, b) clipped to the tile
+                const uint32_t qa = (uint32_t)(a < 0 ? 0 : (a > tn ? tn : a)), qb = (uint32_t)(b < 0 ? 0 : (b > tn ? tn : b));
+                if (qa >= qb) return;
+                uint32_t va, ca, vb, cb;
+                prefix_counts(qa, va, ca);
+                prefix_counts(qb, vb, cb);
+                VG += vb - va; CT += cb - ca;
+            };
             if (Q.nuc_on) {
-                uint32_t qa, qb;
                 {                                                           // main part of call R
-                    const u64 ws = R * Q.s;
-                    const u64 left = n - ws;
-                    const uint32_t cws = left < Q.w ? (uint32_t)left : Q.w;
+                    const uint32_t cws = left < (int32_t)Q.w ? (uint32_t)left : Q.w;
                     const bool always_main = ov == 0u || R == 0u;
                     const uint32_t from = always_main ? 0u : (pg.start_index > ov ? pg.start_index : ov);
-                    if (from < cws) { clip_to_tile(ws + from, ws + cws, P0, T.n, qa, qb); count_range(codes2, valid2, qa, qb, lane, nV, nC, nT, nG); }
+                    if (from < cws) add_range(rel + (int32_t)from, rel + (int32_t)cws);
                 }
                 if (carries && R > 0u) {                                    // carry of call R - 1: i >= max(its start index, step)
-                    const u64 ws = (R - 1u) * Q.s;
-                    const u64 left = n - ws;
-                    const uint32_t cws = left < Q.w ? (uint32_t)left : Q.w;
+                    const int32_t left1 = left + (int32_t)Q.s;
+                    const uint32_t cws = left1 < (int32_t)Q.w ? (uint32_t)left1 : Q.w;
                     const uint32_t si = R - 1u == 0u ? 0u : pg.start_index;
                     const uint32_t from = si > Q.s ? si : Q.s;
-                    if (from < cws) { clip_to_tile(ws + from, ws + cws, P0, T.n, qa, qb); count_range(codes2, valid2, qa, qb, lane, nV, nC, nT, nG); }
+                    if (from < cws) add_range(rel - (int32_t)Q.s + (int32_t)from, rel - (int32_t)Q.s + (int32_t)cws);
                 }
             }
-            const uint32_t tVG = wave_total(nV | (nG << 16)), tCT = wave_total(nC | (nT << 16));     // (each at most 8192)
-            const uint32_t tC = tCT & 0xFFFFu, tT = tCT >> 16, tG = tVG >> 16, tA = (tVG & 0xFFFFu) - tC - tT - tG;
-            const uint32_t mine = lane == 0u ? tA : lane == 1u ? tC : lane == 2u ? tG : lane == 3u ? tT
-                                : lane < 8u ? wacc[(uint32_t)(R - kw_lo) * 4u + (lane - 4u)] : 0u;
-            const u64 span_lo = R * Q.s;
-            const u64 span_hi = span_lo + Q.w < n ? span_lo + Q.w : n;
-            const bool sole = span_lo >= P0 && span_hi <= P0 + T.n;
-            if (lane < 8u) {
-                if (sole) wrec[R * 8ull + lane] = mine;
-                else if (mine) atomicAdd(&wrec[R * 8ull + lane], mine);
+            const uint32_t tC = CT & 0xFFFFu, tT = CT >> 16, tG = VG >> 16, tA = (VG & 0xFFFFu) - tC - tT - tG;
+            const uint4 cov = *(const uint4 *)&wacc[4u * tid];
+            uint32_t *const wr = win_out + (seg_win_base[T.seg] + R) * 8ull;
+            const int32_t span_hi = rel + (left < (int32_t)Q.w ? left : (int32_t)Q.w);
+            if (rel >= 0 && span_hi <= tn) {                                 // the tile holds the whole record: this thread is its only writer
+                *(uint4 *)wr = make_uint4(tA, tC, tG, tT);
+                *(uint4 *)(wr + 4) = cov;
+            } else {
+                if (tA) atomicAdd(wr + 0, tA);
+                if (tC) atomicAdd(wr + 1, tC);
+                if (tG) atomicAdd(wr + 2, tG);
+                if (tT) atomicAdd(wr + 3, tT);
+                if (cov.x) atomicAdd(wr + 4, cov.x);
+                if (cov.y) atomicAdd(wr + 5, cov.y);
+                if (cov.z) atomicAdd(wr + 6, cov.z);
+                if (cov.w) atomicAdd(wr + 7, cov.w);
             }
         }
-    }
-    // 5'. match records
-    if (total > slot_cap || npush == 0u) return;
-    uint32_t *dst = records + (u64)blockIdx.x * slot_cap;
+        // 5'. match records
+        if (!any_spill && total <= slot_cap && npush != 0u) {
+            uint32_t *dst = records + (u64)tile * slot_cap;
 #pragma unroll 1
-    for (uint32_t e0 = 0; e0 < ncand; e0 += 64u) {
-        const uint32_t e = e0 + lane;
-        const uint32_t ent = e < ncand ? list[e] : 0u;
-        const u64 m = __builtin_amdgcn_ballot_w64(ent != 0u);
-        if (m == 0ull) continue;
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (ent) dst[base + rank] = ent & 0x7FFFFFFFu;
-        base += (uint32_t)__popcll(m);
+            for (uint32_t e0 = 0; e0 < ncand; e0 += 64u) {
+                const uint32_t e = e0 + lane;
+                const uint32_t ent = e < ncand ? list[e] : 0u;
+                const u64 m = __builtin_amdgcn_ballot_w64(ent != 0u);
+                if (m == 0ull) continue;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (ent) dst[base + rank] = ent & 0x7FFFFFFFu;
+                base += (uint32_t)__popcll(m);
+            }
+        }
+        if (!more) break;
+        tile = tile_next;
+        T = Tn;
+        __syncthreads();                                                   // planes, lists and accumulators are rewritten next
     }
 }
 
@@ -771,16 +813,22 @@ uint32_t ts_k_general_list_max_records(void) { return kWaccMax; }
 int ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
                               const unsigned long long *seg_len, const unsigned long long *seg_win_base,
                               const TsGenericPatterns *G, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
-                              uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, int list, void *stream) {
+                              uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, int list, int num_cu, void *stream) {
     if (ntiles == 0) return 0;
     uint32_t lp = 0;
     const unsigned long long lds = ts_k_general_lds_bytes(G, &lp);
     if (list && lp) {
         uint32_t nshort = 0;
         for (uint32_t li = 0; li < G->nlen; ++li) nshort += G->len[li] <= kShortLen ? 1u : 0u;
-        const unsigned long long lds2 = 4ull * kListWave * 4u + (unsigned long long)lp * 8u + 4096u + nshort * 1024u + 32u + 48u + kCodeWords * 4u +
-                                        kInvalWords * 4u + kCodeWords * 4u + kWaccMax * 16u + ((lp + 15u) & ~15u);
-        hipLaunchKernelGGL(ts_general_fused_list, dim3(ntiles), dim3(256), (size_t)lds2, (hipStream_t)stream, in, tiles, ntiles,
+        const unsigned long long lds2 = 4ull * kListWave * 4u + (((unsigned long long)lp * 8u + 15u) & ~15ull) + 4096u + nshort * 1024u + kWaccMax * 16u + 32u + 48u + 32u + 64u +
+                                        kCodeWords * 4u + kInvalWords * 4u + kCodeWords * 4u + 2u * kCumWords * 4u + ((lp + 15u) & ~15u);
+        // persistent workgroups: as many as the device holds at once (LDS bound), each strides over the tiles
+        static const uint32_t wg_override = [] { const char *e = getenv("TS_GEN_WGS"); return e ? (uint32_t)atoi(e) : 0u; }();
+        const uint32_t per_cu = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(8ull, (160ull << 10) / lds2));
+        uint32_t grid = (uint32_t)(num_cu > 0 ? num_cu : 256) * per_cu;
+        if (wg_override) grid = wg_override;
+        if (grid > ntiles) grid = ntiles;
+        hipLaunchKernelGGL(ts_general_fused_list, dim3(grid), dim3(256), (size_t)lds2, (hipStream_t)stream, in, tiles, ntiles,
                            (const u64 *)seg_len, (const u64 *)seg_win_base, *G, *Q, tips, slot_cap, lp, nshort, tile_stats, records, win_out, overflow);
         return (int)hipGetLastError();
     }

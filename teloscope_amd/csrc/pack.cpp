@@ -10,6 +10,7 @@
 #include <immintrin.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -52,7 +53,11 @@ size_t pack_avx2(const unsigned char *src, size_t n, unsigned char *dst, bool fo
     // 128 bases per round: four independent chains, ONE 32-byte store (the four blocks' bytes, one per dword, narrowed by
     // two saturating packs and put back in order by a dword permute)
     const __m256i order = _mm256_setr_epi32(0, 4, 1, 5, 2, 6, 3, 7);
+    // TS_PACK_MODE (experiment knob): bit 0 = prefetch the source 1 KB ahead, bit 1 = non-temporal stores when dst is aligned
+    static const int mode = [] { const char *e = getenv("TS_PACK_MODE"); return e ? atoi(e) : 0; }();
+    const bool nt_store = (mode & 2) && (((uintptr_t)dst & 31u) == 0u);
     for (; i + 128 <= n; i += 128) {
+        if (mode & 1) { _mm_prefetch((const char *)src + i + 1024, _MM_HINT_NTA); _mm_prefetch((const char *)src + i + 1088, _MM_HINT_NTA); }
         __m256i t32[4];
         uint32_t bad[4];
 #pragma GCC unroll 4
@@ -66,7 +71,8 @@ size_t pack_avx2(const unsigned char *src, size_t n, unsigned char *dst, bool fo
         }
         const __m256i ab = _mm256_packus_epi32(t32[0], t32[1]), cd = _mm256_packus_epi32(t32[2], t32[3]);
         const __m256i out = _mm256_permutevar8x32_epi32(_mm256_packus_epi16(ab, cd), order);
-        _mm256_storeu_si256((__m256i *)(dst + (i >> 2)), out);
+        if (nt_store) _mm256_stream_si256((__m256i *)(dst + (i >> 2)), out);
+        else _mm256_storeu_si256((__m256i *)(dst + (i >> 2)), out);
         if (bad[0] | bad[1] | bad[2] | bad[3]) {
             for (int q = 0; q < 4; ++q) {
                 uint32_t b = bad[q];
@@ -74,6 +80,7 @@ size_t pack_avx2(const unsigned char *src, size_t n, unsigned char *dst, bool fo
             }
         }
     }
+    if (nt_store) _mm_sfence();
     for (; i + 32 <= n; i += 32) {
         const __m256i v = _mm256_and_si256(_mm256_loadu_si256((const __m256i *)(src + i)), fold_mask);
         __m256i code = _mm256_and_si256(_mm256_srli_epi16(v, 1), three);

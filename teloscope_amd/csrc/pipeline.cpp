@@ -269,6 +269,11 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
         }
     }
     if (any_packed && !use_packed) return c->fail(TS_ERR_ALLOC, "packed input needs the packed upload's device buffers");
+    static const bool stage_timing = getenv("TS_TIMING") != nullptr && getenv("TS_STAGE_TIMING") != nullptr;
+    double t_wait = 0, t_pack = 0, t_issue = 0;
+    size_t n_chunks = 0;
+    struct Report { const bool on; double &w, &p, &i; size_t &n; ~Report() { if (on && n) fprintf(stderr, "  upload_pieces: %zu chunks, waiting for a free slot %.2f ms, packing %.2f ms, runs + DMA + unpack enqueue %.2f ms\n", n, w, p, i); } }
+        report{stage_timing, t_wait, t_pack, t_issue, n_chunks};
     size_t i = 0;
     while (i < pieces.size()) {
         const uint64_t c0 = pieces[i].off;
@@ -277,7 +282,10 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
         const uint64_t chunk_limit = use_packed ? kChunkPacked : kChunk;
         while (j < pieces.size() && pieces[j].off + pieces[j].len - c0 <= chunk_limit &&
                pieces[j].off - (pieces[j - 1].off + pieces[j - 1].len) <= kMaxGap) { bytes += pieces[j].len; ++j; }
+        const auto tw0 = Clock::now();
         if (used[slot]) HIP_TRY(c, hipEventSynchronize(c->pin_up_ev[slot]));
+        if (stage_timing) t_wait += ms_between(tw0, Clock::now());
+        ++n_chunks;
         char *dst = (char *)c->pin_up[slot].p;
         const unsigned nt = bytes >= (4u << 20) ? nthr : 1u;
         const uint64_t hi_pos = pieces[j - 1].off + pieces[j - 1].len;
@@ -388,7 +396,10 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
                 }
                 R.finish();
             };
+            const auto tp0 = Clock::now();
             if (nt == 1u) pack_range(0); else stage_pool.run(nt, pack_range);
+            const auto tp1 = Clock::now();
+            if (stage_timing) t_pack += ms_between(tp0, tp1);
             if (short_text.load()) bad_text.store(1);
             size_t nruns = 0;
             for (const ts::PackRuns &R : wr) nruns += R.runs.size();
@@ -406,6 +417,7 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
                                        (char *)din + (c0 - lo_all) - (c0 - c0a), c->up_stream) != 0)
                     return c->fail(TS_ERR_HIP, "unpack kernel launch failed");
                 HIP_TRY(c, hipEventRecord(c->pin_up_ev[slot], c->up_stream));
+                if (stage_timing) t_issue += ms_between(tp1, Clock::now());
                 used[slot] = true;
                 slot = (slot + 1) % ts_ctx::kUpSlots;
                 i = j;
@@ -876,7 +888,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     if (const char *e = getenv("TS_GEN_ABL")) Q.abl = (uint32_t)atoi(e);
     const bool timing = getenv("TS_TIMING") != nullptr;
     const auto t_begin = Clock::now();
-    double t_up = 0, t_dev = 0, t_host = 0;
+    double t_up = 0, t_dev = 0, t_host = 0, t_take = 0, t_fused = 0, t_blk = 0, t_d2h = 0, t_wait_next = 0;
     float t_kern = 0;
     if (timing && !c->gen_ev[0]) { HIP_TRY(c, hipEventCreate(&c->gen_ev[0])); HIP_TRY(c, hipEventCreate(&c->gen_ev[1])); }
 
@@ -992,6 +1004,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
             Prepared *np = nxt.get();
             if (prefetch) pf = std::thread([&, np] { c->bind_this_thread(); DeviceGuard g2(c->device); np->rc = prepare(*np); });
         }
+        const auto t_iter0 = Clock::now();
         std::shared_ptr<GroupHost> gh = cur->gh;
         std::vector<SegL> &G = gh->G;
         std::vector<TsGeneralTile> &tiles = gh->tiles;
@@ -1009,7 +1022,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         // the list form of the fused pass (per-candidate work on full wavefronts) when a tile adds to few enough window
         // records for the accumulators it keeps in LDS; a tile dense enough to overflow a wave's candidate list sends the
         // group through the position-strided form instead
-        bool use_list = !(getenv("TS_GEN_LIST") && getenv("TS_GEN_LIST")[0] == '0') && s >= 2u &&
+        bool use_list = !(getenv("TS_GEN_LIST") && getenv("TS_GEN_LIST")[0] == '0') && s >= 2u && w < (1u << 28) &&
                         (tips || ((uint64_t)TS_GENERAL_TILE + w) / s + 3 <= ts_k_general_list_max_records());
         HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * (size_t)slot_cap * 4, d_slots));
         HIP_TRY(c, c->pool.take((nt + 1) * 16, d_stats));
@@ -1018,6 +1031,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         if (nwin_total) HIP_TRY(c, c->pool.take(nwin_total * 32, d_win));
         const auto t1 = Clock::now();
         t_up += cur->ms;
+        t_take += ms_between(t_iter0, t1);
         // ---- kernels: the fused pass, a prefix sum over the tile counts, the slots into one dense stream
         char *const dt = (char *)d_tab.p;
         std::vector<unsigned long long> &tile_off = gh->tile_off;
@@ -1032,7 +1046,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 if (ts_k_launch_general_fused((const unsigned char *)d_in.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt,
                                               (const unsigned long long *)(dt + tab_len), (const unsigned long long *)(dt + tab_win),
                                               &c->gpat, &Q, tips ? 1 : 0, slot_cap, (uint32_t *)d_stats.p, (uint32_t *)d_slots.p,
-                                              (uint32_t *)d_win.p, (uint32_t *)(dt + tab_flag), use_list ? 1 : 0, st) != 0)
+                                              (uint32_t *)d_win.p, (uint32_t *)(dt + tab_flag), use_list ? 1 : 0, c->num_cu, st) != 0)
                     return c->fail(TS_ERR_HIP, "general fused kernel launch failed");
                 if (ts_k_launch_tile_offsets((const uint32_t *)d_stats.p, (uint32_t)nt, (unsigned long long *)d_off.p, d_tmp.p, st) != 0)
                     return c->fail(TS_ERR_HIP, "tile-offset kernel launch failed");
@@ -1050,6 +1064,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
             HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * (size_t)slot_cap * 4, d_slots));
         }
         const uint64_t nrec = tile_off[nt];
+        const auto t_f = Clock::now();
+        t_fused += ms_between(t1, t_f);
         HIP_TRY(c, c->pool.take(std::max<uint64_t>(nrec, 1) * 4, d_rec));
         {
             std::lock_guard<std::mutex> lk(c->mtx);
@@ -1087,6 +1103,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
             if (rc != TS_OK) return rc;
             gh->dev_blocks = true;
         }
+        const auto t_b = Clock::now();
+        t_blk += ms_between(t_f, t_b);
         // landing area: the context's pinned download buffers, alternating by group (the host stage of group g reads
         // its buffer while group g + 1 lands in the other; it has been joined before group g + 2 arrives)
         {
@@ -1113,6 +1131,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         HIP_TRY(c, hipStreamSynchronize(st));
         if (timing) { float ms = 0; if (hipEventElapsedTime(&ms, c->gen_ev[0], c->gen_ev[1]) == hipSuccess) t_kern += ms; }
         const auto t2 = Clock::now();
+        t_d2h += ms_between(t_b, t2);
         t_dev += ms_between(t1, t2);
         // ---- host: records -> MatchInfo in the reference's push order, then block calling; one job per segment
         if (host_job.joinable()) host_job.join();                     // (one host stage at a time: it takes all the host threads)
@@ -1246,12 +1265,17 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         t_host += ms_between(th0, Clock::now());
         });
         // ---- next group: already uploaded by the prefetch thread (or planned and uploaded here)
+        const auto t_w = Clock::now();
         if (pf.joinable()) pf.join();
+        t_wait_next += ms_between(t_w, Clock::now());
         if (nxt && !prefetch) nxt->rc = prepare(*nxt);
         cur = std::move(nxt);
     }
     if (host_job.joinable()) host_job.join();
     if (host_err.load() != TS_OK) return host_err.load();
+    if (timing)
+        fprintf(stderr, "general path: device stage: buffers %.1f ms, fused pass + tile offsets (synced) %.1f ms, compaction + block calling %.1f ms, D2H %.1f ms, waiting for the next group's upload %.1f ms\n",
+                t_take, t_fused, t_blk, t_d2h, t_wait_next);
     if (timing)
         fprintf(stderr, "general path: %zu segments, wall %.1f ms: upload %.1f ms, kernels + D2H %.1f ms (kernels alone, HIP events: %.2f ms), host ordering + block calling %.1f ms (on a thread of its own, one group behind; job time: expansion %.1f ms, windows + block calling %.1f ms)\n",
                 which.size(), ms_between(t_begin, Clock::now()), t_up, t_dev, (double)t_kern, t_host, ts_gen_ns[0].exchange(0) / 1e6, ts_gen_ns[1].exchange(0) / 1e6);

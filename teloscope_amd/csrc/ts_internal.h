@@ -273,7 +273,7 @@ unsigned long long ts_k_general_lds_bytes(const TsGenericPatterns *G, uint32_t *
 int  ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
                                const unsigned long long *seg_len, const unsigned long long *seg_win_base,
                                const TsGenericPatterns *G, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
-                               uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, int list, void *stream);
+                               uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, int list, int num_cu, void *stream);
 uint32_t ts_k_general_list_max_records(void);
                                // (records: ntiles x slot_cap entries; win_out zeroed by the caller; *overflow raised when a tile
                                //  holds more than slot_cap records — its count is still written; list != 0: the list form of
