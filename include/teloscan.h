@@ -508,6 +508,29 @@ int ts_batch_read_pass_status(ts_batch *b, int *overflowed);
 int ts_filter_reads_multi(ts_ctx *const *ctxs, size_t n_ctx, const char *const *seqs, const uint64_t *lens,
                           size_t n_reads, uint8_t *pass);
 
+/* ---- the rank form's ONE exchange for a C++ host (one process per GPU): every rank's shard message
+ *      (ts_batch_pack_shard) to rank `dst` in one grouped send / recv over RCCL — xGMI between the GPUs of a node.  The
+ *      reference merges its per-path results in process, under a mutex (src/input.cpp:719-733, sortBySeqPos
+ *      include/teloscope.h:262-266); this is that merge's transport when the paths were scanned by other processes.
+ *      librccl is opened at run time: on a host without it these four calls fail with TS_ERR_UNSUPPORTED and nothing else
+ *      changes.  Message sizes come from ts_batch_shard_info on both sides, so a step needs no size exchange and no host
+ *      synchronisation.  (teloscope_amd/distributed.py's ShardExchange is the same exchange through torch.distributed.) */
+typedef struct ts_exchange ts_exchange;
+#define TS_EXCHANGE_ID_BYTES 128
+/* One rank makes the id (ncclGetUniqueId) and hands its 128 bytes to the others by whatever the host has: MPI_Bcast, a
+ * socket, a file.  On failure ts_exchange_last_error() says why. */
+int          ts_exchange_unique_id(void *id_out);
+const char  *ts_exchange_last_error(void);
+/* Collective over the n_ranks processes (ncclCommInitRank on the context's device); NULL on failure (ts_last_error(ctx)). */
+ts_exchange *ts_exchange_create(ts_ctx *ctx, const void *id, int rank, int n_ranks);
+void         ts_exchange_destroy(ts_exchange *x);
+/* Asynchronous on `stream` (the one the message was packed on, or one that waits for it).  A rank other than dst sends
+ * d_msg[0, my_bytes); dst receives rank p's message into d_recv[p] (device memory, msg_bytes[p] bytes) for every p != dst —
+ * its own message stays where it is (d_recv[dst] may be NULL; when it is given and differs from d_msg the message also goes
+ * through RCCL to itself: the loop-back a one-GPU box rehearses the pattern with).  d_recv / msg_bytes are read on dst only. */
+int          ts_exchange_gather(ts_exchange *x, int dst, const void *d_msg, uint64_t my_bytes, void *const *d_recv,
+                                const uint64_t *msg_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

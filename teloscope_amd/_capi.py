@@ -173,7 +173,8 @@ SYMBOLS = [
     "ts_batch_wire16_ok", "ts_wire_widen_u16", "ts_takes_text_input", "ts_bind_thread_to_device",
     "ts_batch_shard_info", "ts_batch_restrict_shard", "ts_batch_set_shard_scale", "ts_batch_pack_shard",
     "ts_shard_peek", "ts_shards_finalize", "ts_scan_segments_multi", "ts_batch_read_pass_status", "ts_pack_bases",
-    "ts_batch_set_emit",
+    "ts_batch_set_emit", "ts_exchange_unique_id", "ts_exchange_last_error", "ts_exchange_create", "ts_exchange_destroy",
+    "ts_exchange_gather",
 ]
 
 
@@ -304,6 +305,12 @@ def lib():
                                      C.POINTER(SegmentOut), C.POINTER(SegmentCounts)]
     L.ts_scan_segments_multi.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(SegmentIn), C.c_size_t,
                                          C.POINTER(SegmentOut), C.POINTER(SegmentCounts)]
+    L.ts_exchange_unique_id.argtypes = [C.c_void_p]
+    L.ts_exchange_last_error.restype = C.c_char_p
+    L.ts_exchange_create.restype = C.c_void_p
+    L.ts_exchange_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.ts_exchange_destroy.argtypes = [C.c_void_p]
+    L.ts_exchange_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]
     _lib = L
     return L
 

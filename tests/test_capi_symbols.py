@@ -143,6 +143,25 @@ def test_bind_thread_needs_a_device(ta):
     assert os.sched_getaffinity(0) == before
 
 
+def test_rank_exchange_needs_a_device_and_sane_arguments(ta):
+    """ts_exchange_*: no communicator on a planning-only context (TS_ERR_NO_DEVICE in ts_last_error, NULL returned), null
+    arguments are refused, destroying nothing is fine — none of which needs librccl or a GPU."""
+    import ctypes as C
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import parse_cli, user_input
+    L = K.lib()
+    tel = ta.Teloscope(user_input(parse_cli("x.fa -r"), device=K.DEVICE_NONE))
+    ident = (C.c_char * 128)()
+    assert not L.ts_exchange_create(tel._ctx.ptr, ident, 0, 1)
+    assert "planning-only" in tel._ctx.error()
+    assert not L.ts_exchange_create(tel._ctx.ptr, None, 0, 1)
+    assert not L.ts_exchange_create(tel._ctx.ptr, ident, 2, 2)
+    assert not L.ts_exchange_create(None, ident, 0, 1)
+    assert L.ts_exchange_unique_id(None) == K.TS_ERR_INVALID_ARG
+    assert L.ts_exchange_gather(None, 0, None, 0, None, None, None) == K.TS_ERR_INVALID_ARG
+    L.ts_exchange_destroy(None)
+
+
 def test_planner_tiling_choices(ta, monkeypatch):
     """plan_geometry's choice between one workgroup of 16 waves per CU and two of 10 (the 80-VGPR build of the scan kernel),
     read off the plan of a planning-only context (no GPU): windows per tile = what the chosen chunks per tile hold.  Two

@@ -417,3 +417,59 @@ def test_scan_segments_multi_takes_the_single_context_path_when_the_shards_canno
     assert any(b["block_len"] >= 59_000 for b in e["interstitial_blocks"])
     assert_visible_view_equal(ta.SegmentData(out[0], False), e, False, cnt[0], "fallback")
     L.ts_free_segments(out, 1)
+
+
+def test_rank_exchange_carries_every_part_s_message_through_rccl():
+    """The C-ABI's rank-form exchange (ts_exchange_*: one grouped ncclSend / ncclRecv round, librccl opened at run time) on
+    the one rank this box has: every part's message of a 3-way split goes through RCCL (the loop-back form of
+    ts_exchange_gather) into a receive buffer; the received bytes are the packed bytes, and merged they are the oracle's
+    segments.  Argument errors are refused without touching the communicator."""
+    import torch
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.distributed import PackedShard, ShardPlan, finalize_shards, free_segments
+    dev = torch.device("cuda", 0)
+    L = K.lib()
+    opts, tel = _teloscope(HEADLINE + " -t 3000")
+    rng = np.random.default_rng(77)
+    lens = [250003, 70001, 0, 1_000_000, 16500]
+    seqs = [seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, n_its=4, iupac=2) if n else b"" for n in lens]
+    orac = OracleBackend(opts)
+    exp = [orac.scan_segment(sq, 11 * i, False) for i, sq in enumerate(seqs)]
+    ident = (C.c_char * 128)()
+    assert L.ts_exchange_unique_id(ident) == 0, L.ts_exchange_last_error()
+    x = L.ts_exchange_create(tel._ctx.ptr, ident, 0, 1)
+    assert x, tel._ctx.error()
+    assert not L.ts_exchange_create(tel._ctx.ptr, ident, 1, 1)                 # rank outside the communicator
+    plan = ShardPlan(tel, lens, abs_pos=[11 * i for i in range(len(lens))], tips_only=False, world=3)
+    buf = _fill(plan, seqs, dev)
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    received = []
+    for p in range(3):
+        ps = PackedShard(plan, p, dev, slots=1)
+        local = buf[ps.info.input_begin:max(ps.info.input_end, ps.info.input_begin + 64)].clone()
+        ps.scan_pack(local.data_ptr(), sptr, 0)
+        assert ps.status(0).flags == 0
+        msg = ps.msgs[0]
+        n = int(ps.info.msg_bytes)
+        landing = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
+        recv = (C.c_void_p * 1)(landing.data_ptr())
+        sizes = (C.c_uint64 * 1)(n)
+        assert L.ts_exchange_gather(x, 0, C.c_void_p(msg.data_ptr()), n, recv, sizes, sptr) == 0, tel._ctx.error()
+        stream.synchronize()
+        assert torch.equal(landing, msg[:n]), "part %d: the message changed on its way through RCCL" % p
+        received.append(landing.cpu().numpy().copy())
+        # refused: a dst that is not a rank, the receiving rank without buffers, a size that disagrees with the message
+        assert L.ts_exchange_gather(x, 1, C.c_void_p(msg.data_ptr()), n, recv, sizes, sptr) == K.TS_ERR_INVALID_ARG
+        assert L.ts_exchange_gather(x, 0, C.c_void_p(msg.data_ptr()), n, None, None, sptr) == K.TS_ERR_INVALID_ARG
+        bad = (C.c_uint64 * 1)(n - 1)
+        assert L.ts_exchange_gather(x, 0, C.c_void_p(msg.data_ptr()), n, recv, bad, sptr) == K.TS_ERR_INVALID_ARG
+        ps.close()
+    rc, out, cnt = finalize_shards(plan, received)
+    assert rc == 0, tel._ctx.error()
+    for i in range(len(lens)):
+        assert_visible_view_equal(ta.SegmentData(out[i], False), exp[i], False, cnt[i], "through RCCL, segment %d" % i)
+    free_segments(plan, out)
+    plan.close()
+    L.ts_exchange_destroy(x)
