@@ -358,7 +358,8 @@ void ts_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint3
 }
 
 constexpr uint32_t kWaccMax = 256;          // window records a tile may add to on the list path
-constexpr uint32_t kListWave = 1024;        // candidate entries a wave's 1024 positions may produce on the list path
+constexpr uint32_t kListWave = 1024;        // candidate entries a wave's 1024 positions may produce on the list path (u16 each:
+                                            // position in the wave's range << 6 | length index << 3 | pushed << 2 | canonical << 1 | forward)
 constexpr uint32_t kCumWords = 260;         // per-dword nucleotide prefix sums of a tile (256 + the end sentinel), list path
 constexpr uint32_t kShortLen = 6;           // pattern lengths up to this have exact tables in LDS (their l-mers index them)
 
@@ -436,11 +437,11 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
                            const u64 *seg_win_base, const TsGenericPatterns G, const TsGenericGeom Q, int tips, uint32_t slot_cap,
                            uint32_t lds_patterns, uint32_t nshort, uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
     extern __shared__ __align__(16) unsigned char lds[];
-    // layout: list u32[4][kListWave] | pcode u64[lds_patterns] | cand6 u8[4096] | sflag u8[nshort][1024] | wacc u32[kWaccMax][4] |
+    // layout: list u16[4][kListWave] | pcode u64[lds_patterns] | cand6 u8[4096] | sflag u8[nshort][1024] | wacc u32[kWaccMax][4] |
     //         part u32[8] | first u32[12] | wtot u32[2][4] | wbase u32[2][8] | codes2 | inval | valid2 | cum u32[2][kCumWords] | pflag
-    uint32_t *list_all = (uint32_t *)lds;
-    u64 *pcode = (u64 *)(lds + 4u * kListWave * 4u);
-    uint32_t *cand6w = (uint32_t *)(lds + 4u * kListWave * 4u + (((size_t)lds_patterns * 8u + 15u) & ~(size_t)15u));   // (16-byte aligned: wacc is zeroed and read as uint4)
+    unsigned short *list_all = (unsigned short *)lds;
+    u64 *pcode = (u64 *)(lds + 4u * kListWave * 2u);
+    uint32_t *cand6w = (uint32_t *)(lds + 4u * kListWave * 2u + (((size_t)lds_patterns * 8u + 15u) & ~(size_t)15u));   // (16-byte aligned: wacc is zeroed and read as uint4)
     const unsigned char *cand6 = (const unsigned char *)cand6w;
     uint32_t *sflagw = cand6w + 1024u;
     uint32_t *wacc = sflagw + nshort * 256u;                               // [kWaccMax][4]: canonical, non-canonical, forward, reverse covered
@@ -456,7 +457,7 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
     unsigned char *pflag = (unsigned char *)(cumCT + kCumWords);
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    uint32_t *const list = list_all + wave * kListWave;
+    unsigned short *const list = list_all + wave * kListWave;
     if (blockIdx.x >= ntiles) return;
     const uint32_t npat = G.first[G.nlen];
     // 0. the tables, once per workgroup
@@ -616,7 +617,7 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
                 for (uint32_t r = 0; r < 4u; ++r)
                     for (uint32_t m = acc[r]; m; m &= m - 1u) {
                         const uint32_t b = (uint32_t)__builtin_ctz(m);
-                        list[at++] = ((j0 + 4u * r + (b >> 3)) << 5) | ((b & 7u) << 2);
+                        list[at++] = (unsigned short)(((lane * 16u + 4u * r + (b >> 3)) << 6) | ((b & 7u) << 3));
                     }
             }
         }
@@ -646,7 +647,7 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
             bool pushed = false;
             if (e < ncand) {
                 uint32_t ent = list[e];
-                const uint32_t j = ent >> 5, li = (ent >> 2) & 7u, l = (uint32_t)(lens64 >> (6u * li)) & 63u;
+                const uint32_t j = wave * 1024u + (ent >> 6), li = (ent >> 3) & 7u, l = (uint32_t)(lens64 >> (6u * li)) & 63u;
                 const u64 code64 = bases_at(j);
                 const u64 code = l >= 32u ? code64 : (code64 & ((1ull << (2u * l)) - 1ull));
                 bool found = true;
@@ -698,7 +699,7 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
                     }
                     ent |= fl & 3u;
                 }
-                list[e] = pushed ? (ent | 0x80000000u) : 0u;                    // (tile positions are below 2^12: bit 31 is free)
+                list[e] = (unsigned short)(pushed ? (ent | 4u) : 0u);
             }
             npush += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pushed));
         }
@@ -769,10 +770,11 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
             for (uint32_t e0 = 0; e0 < ncand; e0 += 64u) {
                 const uint32_t e = e0 + lane;
                 const uint32_t ent = e < ncand ? list[e] : 0u;
-                const u64 m = __builtin_amdgcn_ballot_w64(ent != 0u);
+                const u64 m = __builtin_amdgcn_ballot_w64((ent & 4u) != 0u);
                 if (m == 0ull) continue;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (ent) dst[base + rank] = ent & 0x7FFFFFFFu;
+                // the stream's record: tile position << 5 | length index << 2 | canonical << 1 | forward
+                if (ent & 4u) dst[base + rank] = ((wave * 1024u + (ent >> 6)) << 5) | (((ent >> 3) & 7u) << 2) | (ent & 3u);
                 base += (uint32_t)__popcll(m);
             }
         }
@@ -820,12 +822,18 @@ int ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tile
     if (list && lp) {
         uint32_t nshort = 0;
         for (uint32_t li = 0; li < G->nlen; ++li) nshort += G->len[li] <= kShortLen ? 1u : 0u;
-        const unsigned long long lds2 = 4ull * kListWave * 4u + (((unsigned long long)lp * 8u + 15u) & ~15ull) + 4096u + nshort * 1024u + kWaccMax * 16u + 32u + 48u + 32u + 64u +
+        const unsigned long long lds2 = 4ull * kListWave * 2u + (((unsigned long long)lp * 8u + 15u) & ~15ull) + 4096u + nshort * 1024u + kWaccMax * 16u + 32u + 48u + 32u + 64u +
                                         kCodeWords * 4u + kInvalWords * 4u + kCodeWords * 4u + 2u * kCumWords * 4u + ((lp + 15u) & ~15u);
         // persistent workgroups: as many as the device holds at once (LDS bound), each strides over the tiles
         static const uint32_t wg_override = [] { const char *e = getenv("TS_GEN_WGS"); return e ? (uint32_t)atoi(e) : 0u; }();
-        const uint32_t per_cu = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(8ull, (160ull << 10) / lds2));
-        uint32_t grid = (uint32_t)(num_cu > 0 ? num_cu : 256) * per_cu;
+        // (what the runtime says fits: a grid of more workgroups than are resident at once ends in a round of stragglers —
+        // 1280 workgroups where 1024 fit measured 7.0 ms against 6.0, profiles/r04/general_occupancy.txt)
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ts_general_fused_list, 256, (size_t)lds2) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = (int)std::max<unsigned long long>(1ull, std::min<unsigned long long>(8ull, (128ull << 10) / lds2));
+        }
+        uint32_t grid = (uint32_t)(num_cu > 0 ? num_cu : 256) * (uint32_t)per_cu;
         if (wg_override) grid = wg_override;
         if (grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL(ts_general_fused_list, dim3(grid), dim3(256), (size_t)lds2, (hipStream_t)stream, in, tiles, ntiles,
