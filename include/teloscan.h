@@ -225,7 +225,7 @@ void    ts_destroy(ts_ctx *ctx);
  * min(step, window-step), where the reference's start-index arithmetic wraps). */
 int     ts_uses_fast_path(const ts_ctx *ctx);
 /* 1 if segments of this kind (full scan / tips-only) may come as TS_INPUT_TEXT_PIECES or TS_INPUT_PACKED2: every parameter
- * set the library scans (until ABI 4 the general kernels wanted the bases joined). */
+ * set the library scans (until ABI 3 the general kernels wanted the bases joined). */
 int     ts_takes_text_input(const ts_ctx *ctx, int tips_only);
 /* Restricts the CALLING thread (and the threads it starts from then on) to the CPUs of the NUMA node the context's
  * device is attached to; returns 1 if it did, 0 if the topology is unknown, the thread's mask holds none of those CPUs,

@@ -1002,7 +1002,11 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         if (wi < which.size()) {
             nxt.reset(new Prepared);
             Prepared *np = nxt.get();
-            if (prefetch) pf = std::thread([&, np] { c->bind_this_thread(); DeviceGuard g2(c->device); np->rc = prepare(*np); });
+            // (an exception on the thread — std::bad_alloc while planning a group — must come back as an error code, not end the process)
+            if (prefetch) pf = std::thread([&, np] {
+                try { c->bind_this_thread(); DeviceGuard g2(c->device); np->rc = prepare(*np); }
+                catch (const std::exception &e) { np->rc = c->fail(TS_ERR_ALLOC, std::string("general path: planning / upload of a group failed: ") + e.what()); }
+            });
         }
         const auto t_iter0 = Clock::now();
         std::shared_ptr<GroupHost> gh = cur->gh;
