@@ -432,9 +432,12 @@ __device__ __forceinline__ bool full_scan_pushes_m(uint32_t j, uint32_t l, const
 // Taken when a tile adds to at most kWaccMax window records (decided on the host from w and s) and the pattern lists fit
 // LDS; a wave whose list overflows (more than one candidate per position: dense repeats under a mixed-length set) raises
 // overflow bit 1 and the group runs again with the kernel above.
-__global__ __launch_bounds__(256)
+#ifndef TS_GEN_WAVES
+#define TS_GEN_WAVES 5
+#endif
+__global__ __launch_bounds__(256, TS_GEN_WAVES)        // waves per SIMD = workgroups per CU (5: at most 96 VGPRs, two of them spilled; 6 — 80 VGPRs, nine spilled — measured the same, 4 — 99 VGPRs, none spilled — 8 % slower: profiles/r04/general_occupancy.txt)
 void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles, const u64 *seg_len,
-                           const u64 *seg_win_base, const TsGenericPatterns G, const TsGenericGeom Q, int tips, uint32_t slot_cap,
+                           const u64 *seg_win_base, const u64 *seg_nwin, const TsGenericPatterns G, const TsGenericGeom Q, int tips, uint32_t slot_cap,
                            uint32_t lds_patterns, uint32_t nshort, uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
     extern __shared__ __align__(16) unsigned char lds[];
     // layout: list u16[4][kListWave] | pcode u64[lds_patterns] | cand6 u8[4096] | sflag u8[nshort][1024] | wacc u32[kWaccMax][4] |
@@ -624,20 +627,40 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
         if (spilled && lane == 0u) atomicOr(overflow, 2u);
         const u64 n = seg_len[T.seg];
         const u64 P0 = T.seg_rel;
-        // window geometry of the tile: the calls whose windows reach it, the records it adds to
+        const u64 N1 = n - P0;                                                  // bases from the tile's first to the segment's end
+        // window geometry of the tile: the calls whose windows reach it, the records it adds to.  No 64-bit division: the
+        // host hands over P0 = k_p0 s + r_p0 per tile and w = cw s + rw per call, the rest are sums and compares
         const bool win_on = !tips && T.n;
         u64 nwin = 0, kw_lo = 0, kw_hi = 0, rec_hi = 0;
         if (win_on) {
-            nwin = (n + Q.s - 1u) / Q.s;
-            kw_lo = P0 >= Q.w ? (P0 - Q.w) / Q.s + 1u : 0u;                   // first call whose window reaches the tile
-            kw_hi = (P0 + T.n - 1u) / Q.s;                                    // last call that starts inside it
+            nwin = seg_nwin[T.seg];
+            kw_lo = P0 >= Q.w ? T.k_p0 + 1u - Q.cw - (Q.rw > T.r_p0 ? 1u : 0u) : 0u;     // first call whose window reaches the tile: (P0 - w) / s + 1
+            kw_hi = T.k_p0 + div_step(T.r_p0 + T.n - 1u, Q.s, magic);         // last call that starts inside it
             if (kw_hi >= nwin) kw_hi = nwin - 1u;
             rec_hi = kw_hi + (carries ? 1u : 0u);
             if (rec_hi >= nwin) rec_hi = nwin - 1u;
             if (rec_hi - kw_lo >= kWaccMax) { if (tid == 0u) atomicOr(overflow, 2u); spilled = true; }     // (the host sizes this out: never)
         }
-        const PushGeom pg = push_geom(P0, n, Q);
-        const u64 N1 = n - P0;                                                  // bases from the tile's first to the segment's end
+        PushGeom pg{};
+        {
+            pg.P0 = P0; pg.n = n; pg.s = Q.s; pg.w = Q.w; pg.ov = ov;
+            const uint32_t t1 = Q.s - Q.longest, t2 = ov - Q.longest;        // uint32 on purpose (src/teloscope.cpp:413-415)
+            pg.start_index = t1 < t2 ? t1 : t2;
+            pg.kP0 = T.k_p0; pg.rP0 = T.r_p0;
+            if (ov == 0u) {
+                pg.k0 = T.k_p0; pg.r0 = T.r_p0;
+                pg.N0 = N1 + T.r_p0;                                          // n - k0 s
+            } else if (P0 > ov) {
+                // P0 - ov = (k_p0 - cw + 1) s + (r_p0 - rw)
+                const bool borrow = T.r_p0 < Q.rw;
+                pg.k1 = T.k_p0 + 1u - Q.cw - (borrow ? 1u : 0u);
+                pg.r1 = T.r_p0 - Q.rw + (borrow ? Q.s : 0u);
+                pg.D1 = pg.r1 + ov;                                           // P0 - k1 s
+                pg.dsub = 0u;
+            } else {
+                pg.k1 = 0u; pg.r1 = 0u; pg.D1 = (uint32_t)P0; pg.dsub = (uint32_t)(ov - P0);
+            }
+        }
         // 3'. a lane per candidate
         uint32_t npush = 0;
         __builtin_amdgcn_wave_barrier();
@@ -813,7 +836,7 @@ unsigned long long ts_k_general_lds_bytes(const TsGenericPatterns *G, uint32_t *
 uint32_t ts_k_general_list_max_records(void) { return kWaccMax; }
 
 int ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
-                              const unsigned long long *seg_len, const unsigned long long *seg_win_base,
+                              const unsigned long long *seg_len, const unsigned long long *seg_win_base, const unsigned long long *seg_nwin,
                               const TsGenericPatterns *G, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
                               uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, int list, int num_cu, void *stream) {
     if (ntiles == 0) return 0;
@@ -837,7 +860,7 @@ int ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tile
         if (wg_override) grid = wg_override;
         if (grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL(ts_general_fused_list, dim3(grid), dim3(256), (size_t)lds2, (hipStream_t)stream, in, tiles, ntiles,
-                           (const u64 *)seg_len, (const u64 *)seg_win_base, *G, *Q, tips, slot_cap, lp, nshort, tile_stats, records, win_out, overflow);
+                           (const u64 *)seg_len, (const u64 *)seg_win_base, (const u64 *)seg_nwin, *G, *Q, tips, slot_cap, lp, nshort, tile_stats, records, win_out, overflow);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(ts_general_fused, dim3(ntiles), dim3(256), (size_t)lds, (hipStream_t)stream, in, tiles, ntiles,

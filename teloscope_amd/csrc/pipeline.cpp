@@ -885,6 +885,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     TsGenericGeom Q{};
     Q.s = s; Q.w = w; Q.longest = L; Q.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u; Q.fold = P.fold_case;
     Q.s_magic = s >= 2u ? (uint32_t)((1ull << 32) / s + 1ull) : 0u;
+    Q.cw = w / s; Q.rw = w - Q.cw * s;
     if (const char *e = getenv("TS_GEN_ABL")) Q.abl = (uint32_t)atoi(e);
     const bool timing = getenv("TS_TIMING") != nullptr;
     const auto t_begin = Clock::now();
@@ -955,14 +956,18 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 rg.layout_off = off;
                 const int rc = region_pieces(c, it, sg.len, rg.seg_start, rg.len, off, 0, ~0ull, pieces);
                 if (rc != TS_OK) return rc;
+                uint64_t kq = rg.seg_start / s, kr = rg.seg_start - kq * s;          // P0 = kq s + kr, walked from tile to tile
                 for (uint64_t a = 0; a < rg.len; a += TS_GENERAL_TILE) {
                     TsGeneralTile T{};
                     T.in_off = off + a;
                     T.seg_rel = rg.seg_start + a;
+                    T.k_p0 = kq; T.r_p0 = (uint32_t)kr;
                     T.n = (uint32_t)std::min<uint64_t>(TS_GENERAL_TILE, rg.len - a);
                     T.avail = (uint32_t)std::min<uint64_t>(rg.len - a, (uint64_t)T.n + 32u);
                     T.seg = (uint32_t)G.size();
                     tiles.push_back(T);
+                    kr += TS_GENERAL_TILE;
+                    if (kr >= s) { const uint64_t d = kr / s; kq += d; kr -= d * s; }
                 }
                 off += (rg.len + 15) & ~15ull;
             }
@@ -976,13 +981,13 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         const uint64_t span = off + 64;
         const size_t ns = G.size(), nt = tiles.size();
         if (nt >= 0x7FFFFFFFull) return c->fail(TS_ERR_UNSUPPORTED, "too many tiles in one group");
-        const size_t tab_bytes = 3 * ns * 8 + 8 + 16;
+        const size_t tab_bytes = 4 * ns * 8 + 8 + 16;
         HIP_TRY(c, c->pool.take(span, PR.d_in));
         HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * sizeof(TsGeneralTile), PR.d_tiles));
         HIP_TRY(c, c->pool.take(tab_bytes, PR.d_tab));
-        std::vector<unsigned long long> tab(3 * ns + 3, 0ull);
-        for (size_t i = 0; i < ns; ++i) { tab[i] = G[i].len; tab[ns + i] = G[i].layout_off; tab[2 * ns + i] = G[i].win_base; }
-        tab[3 * ns] = nwin_total;
+        std::vector<unsigned long long> tab(4 * ns + 3, 0ull);
+        for (size_t i = 0; i < ns; ++i) { tab[i] = G[i].len; tab[ns + i] = G[i].layout_off; tab[2 * ns + i] = G[i].win_base; tab[3 * ns + i] = G[i].n_windows; }
+        tab[4 * ns] = nwin_total;
         const auto t0 = Clock::now();
         { int rc = upload_pieces(c, pieces, PR.d_in.p, 0, slot, used); if (rc != TS_OK) return rc; }
         HIP_TRY(c, hipMemcpyAsync(PR.d_tiles.p, tiles.data(), nt * sizeof(TsGeneralTile), hipMemcpyHostToDevice, c->up_stream));
@@ -1019,7 +1024,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         DevBuf d_slots, d_stats, d_off, d_tmp, d_rec, d_win;
         struct Return { ts_ctx *c; std::vector<DevBuf *> v; ~Return() { for (DevBuf *d : v) c->pool.give(std::move(*d)); } }
             give_back{c, {&d_in, &d_slots, &d_tiles, &d_tab, &d_stats, &d_off, &d_tmp, &d_rec, &d_win}};
-        const size_t tab_len = 0, tab_win = 2 * ns * 8, tab_flag = 3 * ns * 8 + 8;
+        const size_t tab_len = 0, tab_win = 2 * ns * 8, tab_nwin = 3 * ns * 8, tab_flag = 4 * ns * 8 + 8;
         // a tile's slot: one record per position — all a single-length set can produce; a mixed-length tile that holds
         // more says so, and the group runs again with slots that cannot overflow
         uint32_t slot_cap = TS_GENERAL_TILE;
@@ -1049,7 +1054,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 if (nwin_total) HIP_TRY(c, hipMemsetAsync(d_win.p, 0, nwin_total * 32, st));
                 if (ts_k_launch_general_fused((const unsigned char *)d_in.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt,
                                               (const unsigned long long *)(dt + tab_len), (const unsigned long long *)(dt + tab_win),
-                                              &c->gpat, &Q, tips ? 1 : 0, slot_cap, (uint32_t *)d_stats.p, (uint32_t *)d_slots.p,
+                                              (const unsigned long long *)(dt + tab_nwin), &c->gpat, &Q, tips ? 1 : 0, slot_cap, (uint32_t *)d_stats.p, (uint32_t *)d_slots.p,
                                               (uint32_t *)d_win.p, (uint32_t *)(dt + tab_flag), use_list ? 1 : 0, c->num_cu, st) != 0)
                     return c->fail(TS_ERR_HIP, "general fused kernel launch failed");
                 if (ts_k_launch_tile_offsets((const uint32_t *)d_stats.p, (uint32_t)nt, (unsigned long long *)d_off.p, d_tmp.p, st) != 0)

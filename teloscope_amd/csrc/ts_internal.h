@@ -244,16 +244,20 @@ struct TsGenericGeom {
     uint32_t abl;                       // TS_GEN_ABL (profiling): strided form: 1 no matching, 2 no window records, 4 no match records, 8 nothing
                                         // after the table load; list form: 16 no candidates, 32 no per-candidate pass, 64 no window records
     uint32_t s_magic;                   // floor(2^32 / s) + 1 (s >= 2): x / s == umulhi(x, s_magic) for x < 2^32 / s (the list form, s <= 8192)
+    uint32_t cw, rw;                    // w / s and w - cw s
 };
 
 #define TS_GENERAL_TILE 4096            // positions per tile of the general kernels (generic.hip)
-struct TsGeneralTile {                  // 32 bytes
+struct TsGeneralTile {                  // 40 bytes
     unsigned long long in_off;          // byte offset (input layout) of the tile's first base; the match mask is indexed alike
-    unsigned long long seg_rel;         // segment-relative position of that base
+    unsigned long long seg_rel;         // segment-relative position of that base (P0)
+    unsigned long long k_p0;            // P0 / step and
     uint32_t n;                         // positions of the tile (<= TS_GENERAL_TILE)
     uint32_t avail;                     // bases from the tile's first base to the end of its region (clamped to n + 32)
     uint32_t seg;                       // segment index within the group
-    uint32_t pad;
+    uint32_t r_p0;                      // P0 - k_p0 step: the host walks them from tile to tile, so that the list kernel never
+                                        // divides 64-bit numbers (five such divisions per tile and wave were a third of its
+                                        // vector instructions)
 };
 
 struct TsLaunchInfo {
@@ -271,7 +275,7 @@ int  ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_t
                          const uint64_t *seg_nwin, uint32_t nseg, unsigned long long *out, void *stream);
 unsigned long long ts_k_general_lds_bytes(const TsGenericPatterns *G, uint32_t *lds_patterns);
 int  ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
-                               const unsigned long long *seg_len, const unsigned long long *seg_win_base,
+                               const unsigned long long *seg_len, const unsigned long long *seg_win_base, const unsigned long long *seg_nwin,
                                const TsGenericPatterns *G, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
                                uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, int list, int num_cu, void *stream);
 uint32_t ts_k_general_list_max_records(void);
