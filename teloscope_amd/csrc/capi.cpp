@@ -630,7 +630,11 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
                 delete c;
                 return nullptr;
             }
-            c->fast_ok = true;
+            // TS_FORCE_GENERAL=1 (read when the context is made): the general kernels take every scan of this context although the
+            // tiled kernel could — two independent device implementations of one parameter set, compared at full size by the tests
+            const char *fg = getenv("TS_FORCE_GENERAL");
+            if (fg && fg[0] == '1' && c->generic_ok) c->why_not = "TS_FORCE_GENERAL: the general kernels take every scan of this context";
+            else c->fast_ok = true;
         }
     }
     return c;

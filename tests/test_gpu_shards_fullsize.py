@@ -569,3 +569,86 @@ def test_read_pass_reports_a_scan_that_overflowed_its_record_regions():
     assert L.ts_batch_read_pass_status(b, C.byref(flag)) == 0 and flag.value == 0
     assert [bool(x) for x in d_pass[:n].cpu().numpy()] == OracleReadFilter(opts).filter(reads)
     L.ts_batch_destroy(b)
+
+
+@pytest.mark.parametrize("cli,gb", [(HEADLINE, 3.0), ("-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i", 1.0), ("-r -g -e -m -i", 1.0)])
+def test_tiled_and_general_kernels_agree_at_full_size(cli, gb, monkeypatch):
+    """Two independent device implementations of one parameter set at full size: the tiled kernel (closed form of the
+    reference's carry loop, pair-table probes, a wave per tile of 23 windows) and the general kernels (the literal main /
+    carry attribution of analyzeWindow, candidate lists, a workgroup per 4096 positions), forced onto the same set by
+    TS_FORCE_GENERAL=1 — every window record (all fields, GC and entropy bit for bit), every terminal and interstitial
+    block and the per-segment counts of bench.py's 3 Gb assembly must be equal.  Neither path shares a kernel with the
+    other (kernels.hip + blockcall.hip's tiled record format against generic.hip + the general format)."""
+    import torch
+    import bench
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import parse_cli, user_input
+    L = K.lib()
+    opts = parse_cli("x.fa " + cli)
+    tel_t = ta.Teloscope(user_input(opts, device=0))
+    assert tel_t.usesFastPath()
+    monkeypatch.setenv("TS_FORCE_GENERAL", "1")
+    tel_g = ta.Teloscope(user_input(opts, device=0))
+    monkeypatch.delenv("TS_FORCE_GENERAL")
+    assert not tel_g.usesFastPath()
+    total = int(gb * 1e9)
+    lens = bench.contig_lengths(total, 200, 42)
+    offs, off = [], 0
+    for n in lens:
+        offs.append(off)
+        off += (n + 15) & ~15
+    dev = torch.device("cuda", 0)
+    buf = torch.zeros(off + 4096, dtype=torch.uint8, device=dev)
+    bench.fill_synthetic(buf, offs, lens, 42, dev)
+    host = buf.cpu().numpy()
+    del buf
+    n = len(lens)
+    segs = (K.SegmentIn * n)()
+    for i in range(n):
+        segs[i].seq = C.cast(C.c_void_p(host.ctypes.data + offs[i]), C.c_char_p)
+        segs[i].len = lens[i]
+        segs[i].abs_pos = 1000 * i
+    res = {}
+    for name, tel in (("tiled", tel_t), ("general", tel_g)):
+        o = (K.SegmentOut * n)()
+        cnt = (K.SegmentCounts * n)()
+        assert L.ts_scan_segments_blocks(tel._ctx.ptr, segs, n, o, cnt) == 0, tel._ctx.error()
+        res[name] = (o, cnt)
+    (ot, ct), (og, cg) = res["tiled"], res["general"]
+    nwin = nblk = 0
+    for i in range(n):
+        assert (ct[i].n_windows, ct[i].n_matches, ct[i].n_canonical, ct[i].n_forward) == \
+               (cg[i].n_windows, cg[i].n_matches, cg[i].n_canonical, cg[i].n_forward), "counts of segment %d" % i
+        assert ot[i].n_windows == og[i].n_windows and ot[i].n_terminal_blocks == og[i].n_terminal_blocks and \
+               ot[i].n_interstitial_blocks == og[i].n_interstitial_blocks, "sizes of segment %d" % i
+        for field, k, size in (("windows", ot[i].n_windows, C.sizeof(K.Window)), ("terminal_blocks", ot[i].n_terminal_blocks, C.sizeof(K.Block)),
+                               ("interstitial_blocks", ot[i].n_interstitial_blocks, C.sizeof(K.Block))):
+            if k:
+                a = C.string_at(C.cast(getattr(ot[i], field), C.c_void_p), k * size)
+                b = C.string_at(C.cast(getattr(og[i], field), C.c_void_p), k * size)
+                assert a == b, "%s of segment %d differ between the tiled and the general kernels" % (field, i)
+        nwin += ot[i].n_windows
+        nblk += ot[i].n_terminal_blocks + ot[i].n_interstitial_blocks
+    assert nwin >= total // opts.step and nblk > 0
+    L.ts_free_segments(ot, n)
+    L.ts_free_segments(og, n)
+    # ... and the five match vectors' source — every record, in the reference's push order — of the first forty contigs
+    m = min(n, 40)
+    mo = {}
+    for name, tel in (("tiled", tel_t), ("general", tel_g)):
+        o = (K.SegmentOut * m)()
+        assert L.ts_scan_segments(tel._ctx.ptr, segs, m, o) == 0, tel._ctx.error()
+        mo[name] = o
+    nrec = 0
+    for i in range(m):
+        a, b = mo["tiled"][i], mo["general"][i]
+        assert a.n_matches == b.n_matches, "match count of segment %d" % i
+        if a.n_matches:
+            ka = C.string_at(C.cast(a.matches, C.c_void_p), a.n_matches * C.sizeof(K.Match))
+            kb = C.string_at(C.cast(b.matches, C.c_void_p), b.n_matches * C.sizeof(K.Match))
+            assert ka == kb, "match records of segment %d differ between the tiled and the general kernels" % i
+        nrec += a.n_matches
+    assert nrec > 1000
+    L.ts_free_segments(mo["tiled"], m)
+    L.ts_free_segments(mo["general"], m)
