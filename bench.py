@@ -568,6 +568,32 @@ def pcie_inclusive(L, K, tel, buf, offsets, lens, total):
     e2e["writer_view_multi"] = {"seconds": round(best, 4), "gbases_per_s": round(total / best / 1e9, 3), "matches": nm,
                                 "visible_matches": nvis, "n_ctx": n_ctx,
                                 "entry_point": "ts_scan_segments_multi (windows, blocks and the match records a writer reads; one shard per context)"}
+    # the GENERAL path (parameter sets the tiled kernel does not take: here a mixed-length set, -p TTAGGG,TTAGG) over the same
+    # host buffer and entry point — generic.hip's list kernel, block calling on the device, upload of group g + 1 beside group
+    # g's kernels.  Reported beside the figures above, never in `value`; TS_BENCH_NO_GENERAL=1 skips it.
+    if not os.environ.get("TS_BENCH_NO_GENERAL"):
+        from teloscope_amd.cli import parse_cli, user_input
+        gflags = "-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i"
+        gtel = ta.Teloscope(user_input(parse_cli("x.fa " + gflags), device=tel.userInput.device))
+        if not gtel.usesFastPath():
+            res = (K.SegmentOut * n)()
+            cnts = (K.SegmentCounts * n)()
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                rc = L.ts_scan_segments_blocks(gtel._ctx.ptr, segs, n, res, cnts)
+                dt = time.perf_counter() - t0
+                if rc != 0:
+                    raise RuntimeError(gtel._ctx.error())
+                nm = int(sum(c.n_matches for c in cnts))
+                nb = int(sum(res[i].n_terminal_blocks + res[i].n_interstitial_blocks for i in range(n)))
+                L.ts_free_segments(res, n)
+                best = dt if best is None else min(best, dt)
+            e2e["general_path_blocks_windows_counts"] = {
+                "flags": gflags, "patterns": len(gtel.userInput.patternInfo), "seconds": round(best, 4),
+                "gbases_per_s": round(total / best / 1e9, 3), "matches": nm, "blocks": nb,
+                "kernels": "generic.hip: ts_general_fused_list + compaction + blockcall.hip (general record format)"}
+        gtel.close()
     return {"entry_points": "ts_scan_segments_blocks / ts_scan_segments (pageable host buffers in, host results out; "
                             "groups of ~512 MB pipelined through upload / scan / download stages; bases cross PCIe as 2-bit codes + invalid runs, packed by the staging threads and unpacked on the device; best of 3)", "host_buffer": host_pages, "n_ctx": 1, **e2e}
 
