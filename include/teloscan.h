@@ -214,10 +214,12 @@ void ts_free_patterns(ts_pattern *p);
  *      (ts_scan_segments, ts_scan_segments_blocks, ts_filter_reads; full scans and tips-only apart) as one batch and hands
  *      each caller its own results.  Sixty-four threads with one segment each cost about what one call with sixty-four
  *      segments costs; results never depend on who was merged with whom.
- *      LIMITS of the pattern set (the reference's trie has none, include/teloscope.h:40-57): a pattern longer than 32 bases,
- *      more than 8 distinct pattern lengths, or a non-ACGT pattern make every scan of the context fail with
- *      TS_ERR_UNSUPPORTED (loudly: there is no CPU path to fall back to).  Uniform-length sets of 3..8 bases under
- *      w == s or k <= min(s, w - s) take the tiled kernel; everything else inside the limits the general kernels. */
+ *      LIMITS of the pattern set (the reference's trie has none, include/teloscope.h:40-57): what a ts_pattern[] can express — a
+ *      pattern of up to 63 bases, hence up to 63 distinct lengths — is scanned; a longer pattern is refused by ts_create and by
+ *      ts_expand_patterns (never truncated), a non-ACGT pattern makes every scan fail with TS_ERR_UNSUPPORTED (loudly: there
+ *      is no CPU path to fall back to).  Uniform-length sets of 3..8 bases under w == s or k <= min(s, w - s) take the tiled
+ *      kernel; sets of up to 8 distinct lengths of up to 32 bases the general kernels' table forms; everything else the
+ *      general kernels' wide form (128-bit codes; a correct path for rare sets, not a fast one). */
 ts_ctx *ts_create(const ts_params *params, const ts_pattern *patterns, size_t n_patterns);
 void    ts_destroy(ts_ctx *ctx);
 /* 1 if full scans with this (window, step, patterns) run on the tiled uniform-k kernel,

@@ -152,6 +152,7 @@ inline std::vector<ts_pattern> makePatterns(UserInputTeloscope &ui) {
     std::vector<ts_pattern> pats;
     for (const auto &pi : ui.patternInfo) {
         ui.patterns.push_back(pi.first);
+        if (pi.first.size() > 63) throw std::runtime_error("pattern longer than 63 bases: more than the library's ts_pattern holds");
         ts_pattern t{};
         std::strncpy(t.seq, pi.first.c_str(), 63);
         t.len = static_cast<uint8_t>(pi.first.size());

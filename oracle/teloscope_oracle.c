@@ -178,7 +178,7 @@ tso_pattern *tso_expand_patterns(const char *raw_csv, int edit_distance,
     while (*p) {
         const char *q = strchr(p, ',');
         size_t len = q ? (size_t)(q - p) : strlen(p);
-        if (len > 0 && len < 63) {
+        if (len > 0 && len < 64) {
             char seed[64], cur[64];
             memcpy(seed, p, len); seed[len] = '\0';
             memcpy(cur, seed, len + 1);

@@ -22,18 +22,24 @@ for it in range(iters):
     s = int(rng.integers(max(1, w // 40), w + 1)) if rng.random() < 0.5 else w
     tips = rng.random() < 0.2
     pat = ""
-    if rng.random() < 0.25:                      # a second motif of another length: the general path's mixed-length sets
+    wide = rng.random() < float(os.environ.get("TS_FUZZ_WIDE", "0.06"))
+    if wide:                                     # beyond 8 lengths or 32 bases: the general path's wide form
+        pool = [c, c[:4], c + c[:1], c + c[:2], c * 2, c * 2 + c[:3], c * 3, (c * 8)[:33], (c * 8)[:40], (c * 11)[:62], c[:3], c + "A", c * 4 + "T"]
+        k = int(rng.integers(1, len(pool)))
+        pick = sorted(set(pool[int(i)] for i in rng.choice(len(pool), size=k, replace=False)) | {(c * 8)[:int(rng.integers(33, 50))]}, key=len)
+        pat = " -p %s" % ",".join(pick)
+    elif rng.random() < 0.25:                    # a second motif of another length: the general path's mixed-length sets
         c2 = motifs[int(rng.integers(0, len(motifs)))]
         if len(c2) != len(c) and min(len(c), len(c2)) >= 4:
             pat = " -p %s,%s" % (c, c2)
     cli = "-c %s%s -x %d -w %d -s %d -t %d -k %d -d %d -l %d -y %.2f" % (
-        c, pat, int(rng.integers(0, 2 if pat else 3)), w, s, int(rng.choice([50, 300, 5000, 50000])),
+        c, pat, (0 if wide and rng.random() < 0.7 else int(rng.integers(0, 2 if pat else 3))), w, s, int(rng.choice([50, 300, 5000, 50000])),
         int(rng.choice([5, 20, 50])), int(rng.choice([10, 100, 500])), int(rng.choice([12, 60, 300])),
         float(rng.choice([0.3, 0.5, 0.9])))
     if not tips:
         cli += " " + " ".join(rng.choice(["-r", "-g", "-e", "-m", "-i"], size=3, replace=False)) + " -g"
     opts = H.parse_cli("x.fa " + cli)
-    if len(c) > w:
+    if len(c) > w or (wide and w < 64):
         continue
     prod, orac = ProductBackend(opts), OracleBackend(opts)
     if orac.ambiguous:

@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include <cctype>
@@ -446,7 +447,7 @@ int ts_device_count(void) {
 }
 
 int ts_canonical_orientation(const char *canonical_in, char *fwd_out, char *rev_out) {
-    if (!canonical_in || !fwd_out || !rev_out || std::strlen(canonical_in) > 62) return TS_ERR_INVALID_ARG;
+    if (!canonical_in || !fwd_out || !rev_out || std::strlen(canonical_in) > 63) return TS_ERR_INVALID_ARG;
     std::string f, r;
     ts::canonical_orientation(canonical_in, f, r);
     std::strcpy(fwd_out, f.c_str());
@@ -458,6 +459,12 @@ int ts_expand_patterns(const char *raw_csv, int edit_distance, const char *canon
                        ts_pattern **out, size_t *n_out) {
     if (!raw_csv || !canonical_fwd || !out || !n_out || edit_distance < 0 || edit_distance > 2)
         return TS_ERR_INVALID_ARG;
+    for (const char *p = raw_csv; *p;) {                        // a seed longer than a ts_pattern holds: refused, never dropped or truncated
+        const char *q = std::strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : std::strlen(p);
+        if (len > 63) return TS_ERR_UNSUPPORTED;
+        p += len + (q ? 1 : 0);
+    }
     std::vector<ts::Pattern> v = ts::expand_patterns(raw_csv, edit_distance, canonical_fwd);
     ts_pattern *arr = (ts_pattern *)std::calloc(v.size() ? v.size() : 1, sizeof(ts_pattern));
     if (!arr) return TS_ERR_ALLOC;
@@ -498,6 +505,11 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
         g_create_error = "ts_create: need 0 < step <= window_size";
         return nullptr;
     }
+    for (size_t i = 0; i < n_patterns; ++i)
+        if (patterns[i].len > 63) {
+            g_create_error = "ts_create: unsupported pattern: longer than the 63 bases a ts_pattern holds";
+            return nullptr;
+        }
     const bool plan_only = params->device == kNoDevice;
     int ndev = 0;
     if (!plan_only && (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)) {
@@ -581,6 +593,47 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
             }
             c->gpat.first[lens.size()] = (uint32_t)codes.size();
         }
+        // beyond 8 lengths or 32 bases: the wide form's tables (whatever a ts_pattern[] can hold: 63 lengths of up to 63 bases)
+        if (!ok && lens.size() <= 63 && lens.back() <= 63 && lens.front() >= 1) {
+            bool acgt = true;
+            std::vector<unsigned long long> lo, hi;
+            std::vector<uint8_t> wflags;
+            std::vector<uint32_t> first;
+            for (size_t li = 0; li < lens.size() && acgt; ++li) {
+                first.push_back((uint32_t)lo.size());
+                std::vector<std::tuple<unsigned long long, unsigned long long, uint8_t>> v;
+                for (const ts::Pattern &p : c->patterns) {
+                    if (p.seq.size() != lens[li]) continue;
+                    unsigned long long a = 0, b = 0;
+                    for (size_t i = 0; i < p.seq.size(); ++i) {
+                        const int code = ts::base_code(p.seq[i]);
+                        if (code < 0) { acgt = false; break; }
+                        if (i < 32) a |= (unsigned long long)code << (2 * i); else b |= (unsigned long long)code << (2 * (i - 32));
+                    }
+                    v.emplace_back(a, b, (uint8_t)((p.is_forward ? 1 : 0) | (p.is_canonical ? 2 : 0)));
+                }
+                std::sort(v.begin(), v.end());
+                for (const auto &e : v) { lo.push_back(std::get<0>(e)); hi.push_back(std::get<1>(e)); wflags.push_back(std::get<2>(e)); }
+            }
+            first.push_back((uint32_t)lo.size());
+            if (acgt && plan_only) {
+                c->generic_ok = true; c->gen_wide = true; c->wide_lens = lens;
+            } else if (acgt && c->d_wlo.ensure(lo.size() * 8 + 16) == hipSuccess && c->d_whi.ensure(hi.size() * 8 + 16) == hipSuccess &&
+                       c->d_wflags.ensure(wflags.size() + 16) == hipSuccess && c->d_wlen.ensure(lens.size() * 4 + 16) == hipSuccess &&
+                       c->d_wfirst.ensure(first.size() * 4 + 16) == hipSuccess &&
+                       hipMemcpy(c->d_wlo.p, lo.data(), lo.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+                       hipMemcpy(c->d_whi.p, hi.data(), hi.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+                       hipMemcpy(c->d_wflags.p, wflags.data(), wflags.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                       hipMemcpy(c->d_wlen.p, lens.data(), lens.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                       hipMemcpy(c->d_wfirst.p, first.data(), first.size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
+                c->wpat.lo = (const unsigned long long *)c->d_wlo.p; c->wpat.hi = (const unsigned long long *)c->d_whi.p;
+                c->wpat.flags = (const uint8_t *)c->d_wflags.p; c->wpat.len = (const uint32_t *)c->d_wlen.p;
+                c->wpat.first = (const uint32_t *)c->d_wfirst.p;
+                c->wpat.nlen = (uint32_t)lens.size(); c->wpat.npat = (uint32_t)lo.size();
+                c->wide_lens = lens;
+                c->generic_ok = true; c->gen_wide = true;
+            }
+        }
         if (ok && plan_only) {
             c->generic_ok = true;                        // (tables stay on the host: nothing is ever launched)
         } else if (ok && c->d_gcodes.ensure(codes.size() * 8) == hipSuccess && c->d_gflags.ensure(flags.size() + 16) == hipSuccess &&
@@ -656,6 +709,7 @@ void ts_destroy(ts_ctx *ctx) {
         ctx->d_table.release();
         ctx->d_gcodes.release();
         ctx->d_gflags.release();
+        ctx->d_wlo.release(); ctx->d_whi.release(); ctx->d_wflags.release(); ctx->d_wlen.release(); ctx->d_wfirst.release();
         ctx->pool.clear();
         for (int i = 0; i < ts_ctx::kUpSlots; ++i) {
             ctx->pin_up[i].release();

@@ -116,6 +116,11 @@ struct ts_ctx {
     bool generic_ok = false;
     TsGenericPatterns gpat{};
     DevBuf d_gcodes, d_gflags;
+    // ... or, for sets beyond 8 lengths / 32 bases, the wide form's tables (128-bit codes, up to 63 lengths of up to 63 bases)
+    bool gen_wide = false;
+    TsWidePatterns wpat{};
+    std::vector<uint32_t> wide_lens;        // host copy of wpat.len
+    DevBuf d_wlo, d_whi, d_wflags, d_wlen, d_wfirst;
     DevBuf d_table;
     mutable std::mutex mtx;         // guards batch planning / launches that read the context's tables
     mutable std::string error;

@@ -808,6 +808,231 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The WIDE form (round 4): pattern sets beyond the two forms above — more than 8 distinct lengths or a pattern longer than 32
+// bases, up to the 63 lengths of up to 63 bases a ts_pattern[] can hold (the reference's trie has no limit of its own,
+// include/teloscope.h:40-57).  The same pass as ts_general_fused, position-strided, with
+//   * 128-bit codes (lo: bases 0..31, hi: 32..62) searched in the sorted lists in device memory, behind a prefix table in LDS:
+//     pre6, a u64 per 6-mer whose bit li says "these bases begin a pattern of length index li";
+//   * per position three u64 masks in LDS — matched lengths, which of them are forward, which canonical — instead of three bits
+//     per length in one dword;
+//   * a halo of 64 bases, and records that carry six bits of length index: position << 8 | index << 2 | canonical << 1 | forward.
+// One workgroup per CU (130 KB of LDS): a correct path for rare parameter sets, not a fast one.
+constexpr uint32_t kWideCodeWords = (kTile + TS_WIDE_HALO) / 16u + 6u;     // 2-bit plane, dwords (five are read per position)
+constexpr uint32_t kWideInvalWords = (kTile + TS_WIDE_HALO) / 32u + 4u;    // validity plane (three are read per position)
+
+struct WideAcc { uint32_t nuc, can, non, fwd, rev; };
+
+// window_tile_part for the wide form's masks
+__device__ __forceinline__ void window_tile_part_wide(const uint32_t *codes2, const uint32_t *inval, const u64 *hit, const u64 *fwdm, const u64 *canm,
+                                                      const uint32_t *lens, const TsGenericGeom &Q, u64 n, u64 kw, bool carry,
+                                                      u64 P0, uint32_t ntile, uint32_t lane, WideAcc &a) {
+    const u64 wstart = kw * Q.s;
+    const uint32_t cws = (uint32_t)((n - wstart) < Q.w ? (n - wstart) : Q.w);
+    const uint32_t ov = Q.w - Q.s;
+    const bool always_main = (ov == 0 || wstart == 0);
+    const uint32_t t1 = Q.s - Q.longest, t2 = ov - Q.longest;           // uint32 on purpose (src/teloscope.cpp:413-415)
+    uint32_t start_index = always_main ? 0u : (t1 < t2 ? t1 : t2);
+    if (carry && start_index < Q.s) start_index = Q.s;               // the carry only takes i >= step
+    if (start_index >= cws) return;
+    const u64 lo = wstart + start_index, hi = wstart + cws;
+    const uint32_t qlo = lo > P0 ? (uint32_t)(lo - P0 < ntile ? lo - P0 : ntile) : 0u;
+    const uint32_t qhi = hi > P0 ? (uint32_t)(hi - P0 < ntile ? hi - P0 : ntile) : 0u;
+    const uint32_t ioff = (uint32_t)(P0 - wstart);
+    const bool all_nuc = carry || always_main;
+    for (uint32_t q = qlo + lane; q < qhi; q += 64u) {
+        const uint32_t i = q + ioff;
+        if (Q.nuc_on) {
+            if (plane_invalid(inval, q)) continue;
+            if (all_nuc || i >= ov) a.nuc += 1u << (8u * plane_code(codes2, q));
+        }
+        u64 m = hit[q];
+        if (!m) continue;
+        const u64 f = fwdm[q], c = canm[q];
+        for (; m; m &= m - 1ull) {
+            const uint32_t li = (uint32_t)__builtin_ctzll(m);
+            const uint32_t l = lens[li];
+            const uint32_t j = i + l - 1u;
+            if (j >= cws) continue;                                 // scanLimit: may not cross the window end
+            if (!carry && !(always_main || j >= ov)) continue;
+            if ((c >> li) & 1ull) a.can += l; else a.non += l;
+            if ((f >> li) & 1ull) a.fwd += l; else a.rev += l;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles, const u64 *seg_len,
+                     const u64 *seg_win_base, const TsWidePatterns W, const TsGenericGeom Q, int tips, uint32_t slot_cap,
+                     uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    // layout: hit u64[kTile] | fwd u64[kTile] | can u64[kTile] | pre6 u64[4096] | lens u32[64] | first u32[68] | part u32[8] | codes2 | inval
+    u64 *hit = (u64 *)lds;
+    u64 *fwdm = hit + kTile;
+    u64 *canm = fwdm + kTile;
+    u64 *pre6 = canm + kTile;
+    uint32_t *lens = (uint32_t *)(pre6 + 4096u);
+    uint32_t *first = lens + 64;
+    uint32_t *part = first + 68;
+    uint32_t *codes2 = part + 8;
+    uint32_t *inval = codes2 + kWideCodeWords;
+    if (blockIdx.x >= ntiles) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < 4096u; i += 256u) pre6[i] = 0ull;
+    if (tid < 64u) lens[tid] = tid < W.nlen ? W.len[tid] : 0xFFFFFFFFu;
+    if (tid <= W.nlen && tid < 68u) first[tid] = W.first[tid];
+    const TsGeneralTile T = tiles[blockIdx.x];
+    // 1. stage: bases [0, avail) of the tile, avail <= kTile + 64; positions beyond avail are invalid
+    const uint32_t avail = T.avail;
+    const unsigned char *src = in + T.in_off;
+    for (uint32_t i = tid * 16u; i < kWideCodeWords * 16u; i += 256u * 16u) {
+        uint32_t cw = 0, iv = 0xFFFFu;
+        if (i < avail) {
+            uint32_t d[4];
+            if (((uintptr_t)(src + i) & 15u) == 0u && i + 16u <= avail) {
+                const uint4 v = *(const uint4 *)(src + i);
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            } else {
+                for (uint32_t q = 0; q < 4u; ++q) {
+                    uint32_t x = 0;
+                    for (uint32_t r = 0; r < 4u; ++r) x |= (i + 4u * q + r < avail ? (uint32_t)src[i + 4u * q + r] : 0u) << (8u * r);
+                    d[q] = x;
+                }
+            }
+            iv = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 16u; ++q) {
+                uint32_t c = (d[q >> 2] >> (8u * (q & 3u))) & 0xFFu;
+                if (Q.fold) c &= 0xDFu;
+                const uint32_t code = (c >> 1) & 3u;                               // A 0, C 1, T 2, G 3
+                cw |= code << (2u * q);
+                iv |= (c != ((0x47544341u >> (8u * code)) & 0xFFu) ? 1u : 0u) << q; // 'A' 'C' 'T' 'G' by code
+            }
+        }
+        codes2[i >> 4] = cw;
+        ((unsigned short *)inval)[i >> 4] = (unsigned short)iv;
+    }
+    __syncthreads();
+    // the prefix table: every pattern's first min(l, 6) bases under every extension to six
+    for (uint32_t li = 0; li < W.nlen; ++li) {
+        const uint32_t l = lens[li], q = l < 6u ? l : 6u, ext_bits = 2u * (6u - q);
+        const uint32_t f0 = first[li], cnt = first[li + 1u] - f0;
+        for (uint32_t x = tid; x < (cnt << ext_bits); x += 256u) {
+            const uint32_t pre = (uint32_t)W.lo[f0 + (x >> ext_bits)] & ((1u << (2u * q)) - 1u);
+            const uint32_t idx = pre | ((x & ((1u << ext_bits) - 1u)) << (2u * q));
+            atomicOr((unsigned long long *)&pre6[idx], 1ull << li);
+        }
+    }
+    __syncthreads();
+    // 2. matches
+    for (uint32_t j = tid; j < kTile; j += 256u) {
+        u64 h = 0, f = 0, c = 0;
+        if (j < T.n) {
+            const uint32_t wd = j >> 4, sh = 2u * (j & 15u);
+            const uint32_t c0 = codes2[wd], c1 = codes2[wd + 1u], c2 = codes2[wd + 2u], c3 = codes2[wd + 3u], c4 = codes2[wd + 4u];
+            const u64 lo = (u64)__funnelshift_r(c0, c1, sh) | ((u64)__funnelshift_r(c1, c2, sh) << 32);
+            const u64 hi = (u64)__funnelshift_r(c2, c3, sh) | ((u64)__funnelshift_r(c3, c4, sh) << 32);
+            const uint32_t vd = j >> 5, vs = j & 31u;
+            const uint32_t ilo = __funnelshift_r(inval[vd], inval[vd + 1u], vs), ihi = __funnelshift_r(inval[vd + 1u], inval[vd + 2u], vs);
+            const uint32_t nvalid = ilo ? (uint32_t)__builtin_ctz(ilo) : (ihi ? 32u + (uint32_t)__builtin_ctz(ihi) : 64u);
+            const uint32_t rem = avail > j ? avail - j : 0u;
+            const uint32_t maxlen = nvalid < rem ? nvalid : rem;
+            for (u64 cand = pre6[(uint32_t)lo & 0xFFFu]; cand; cand &= cand - 1ull) {
+                const uint32_t li = (uint32_t)__builtin_ctzll(cand);
+                const uint32_t l = lens[li];
+                if (l > maxlen) break;                   // lengths ascend: a non-ACGT base or the region's end stops this and every longer pattern
+                const u64 klo = l >= 32u ? lo : (lo & ((1ull << (2u * l)) - 1ull));
+                const u64 khi = l <= 32u ? 0ull : (hi & ((1ull << (2u * (l - 32u))) - 1ull));      // (l <= 63: the shift is below 64)
+                uint32_t a = first[li], b = first[li + 1u];
+                const uint32_t end = b;
+                while (a < b) {                          // binary search in the (lo, hi)-sorted list of this length
+                    const uint32_t mid = (a + b) >> 1;
+                    const u64 mlo = W.lo[mid], mhi = W.hi[mid];
+                    if (mlo < klo || (mlo == klo && mhi < khi)) a = mid + 1u; else b = mid;
+                }
+                if (a < end && W.lo[a] == klo && W.hi[a] == khi) {
+                    const uint32_t fl = W.flags[a];
+                    h |= 1ull << li;
+                    if (fl & 1u) f |= 1ull << li;
+                    if (fl & 2u) c |= 1ull << li;
+                }
+            }
+        }
+        hit[j] = h; fwdm[j] = f; canm[j] = c;
+    }
+    __syncthreads();
+    const u64 n = seg_len[T.seg];
+    const u64 P0 = T.seg_rel;
+    // 3. window records (full scans): as in ts_general_fused
+    if (!tips && T.n) {
+        const u64 nwin = (n + Q.s - 1u) / Q.s;
+        const u64 kw_lo = P0 >= Q.w ? (P0 - Q.w) / Q.s + 1u : 0u;
+        u64 kw_hi = (P0 + T.n - 1u) / Q.s;
+        if (kw_hi >= nwin) kw_hi = nwin - 1u;
+        const bool carries = Q.w != Q.s;
+        u64 rec_hi = kw_hi + (carries ? 1u : 0u);
+        if (rec_hi >= nwin) rec_hi = nwin - 1u;
+        uint32_t *const wrec = win_out + seg_win_base[T.seg] * 8ull;
+        for (u64 R = kw_lo + wave; R <= rec_hi; R += 4u) {
+            WideAcc a = {0, 0, 0, 0, 0};
+            window_tile_part_wide(codes2, inval, hit, fwdm, canm, lens, Q, n, R, false, P0, T.n, lane, a);
+            if (carries && R > 0u) window_tile_part_wide(codes2, inval, hit, fwdm, canm, lens, Q, n, R - 1u, true, P0, T.n, lane, a);
+            const uint32_t tAT = wave_total((a.nuc & 0xFFu) | ((a.nuc >> 16) & 0xFFu) << 16);        // A | T << 16
+            const uint32_t tCG = wave_total(((a.nuc >> 8) & 0xFFu) | ((a.nuc >> 24) & 0xFFu) << 16);  // C | G << 16
+            const uint32_t tcan = wave_total(a.can), tnon = wave_total(a.non), tfwd = wave_total(a.fwd), trev = wave_total(a.rev);
+            const uint32_t mine = lane == 0u ? (tAT & 0xFFFFu) : lane == 1u ? (tCG & 0xFFFFu) : lane == 2u ? (tCG >> 16) : lane == 3u ? (tAT >> 16)
+                                : lane == 4u ? tcan : lane == 5u ? tnon : lane == 6u ? tfwd : trev;
+            const u64 span_lo = R * Q.s;
+            const u64 span_hi = span_lo + Q.w < n ? span_lo + Q.w : n;
+            const bool sole = span_lo >= P0 && span_hi <= P0 + T.n;
+            if (lane < 8u) {
+                if (sole) wrec[R * 8ull + lane] = mine;
+                else if (mine) atomicAdd(&wrec[R * 8ull + lane], mine);
+            }
+        }
+    }
+    __syncthreads();                                   // (the masks are rewritten below)
+    // 4. match records: the matches the reference pushes, position then length order; wave v owns positions [1024 v, 1024 v + 1024)
+    const PushGeom pg = push_geom(P0, n, Q);
+    uint32_t wave_cnt = 0;
+    for (uint32_t r = 0; r < 16u; ++r) {
+        const uint32_t j = wave * 1024u + r * 64u + lane;
+        u64 keep = 0;
+        for (u64 m = hit[j]; m; m &= m - 1ull) {
+            const uint32_t li = (uint32_t)__builtin_ctzll(m);
+            u64 unused_rec;
+            if (tips || full_scan_pushes(j, lens[li], pg, &unused_rec)) keep |= 1ull << li;
+        }
+        hit[j] = keep;
+        wave_cnt += (uint32_t)__popcll(keep);
+    }
+    wave_cnt = wave_total(wave_cnt);
+    if (lane == 0u) part[wave] = wave_cnt;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (uint32_t v = 0; v < 4u; ++v) { if (v < wave) base += part[v]; total += part[v]; }
+    if (tid == 0u) {
+        *(uint4 *)&tile_stats[4ull * blockIdx.x] = make_uint4(total, 0u, 0u, 0u);
+        if (total > slot_cap) atomicOr(overflow, 1u);
+    }
+    if (total > slot_cap || wave_cnt == 0u) return;
+    uint32_t *dst = records + (u64)blockIdx.x * slot_cap;
+    for (uint32_t r = 0; r < 16u; ++r) {
+        const uint32_t j = wave * 1024u + r * 64u + lane;
+        const u64 keep = hit[j];
+        if (__builtin_amdgcn_ballot_w64(keep != 0ull) == 0ull) continue;
+        const uint32_t c = (uint32_t)__popcll(keep);
+        const uint32_t incl = wave_inclusive(c, lane);
+        uint32_t at = base + incl - c;
+        const u64 f = fwdm[j], cm = canm[j];
+        for (u64 m = keep; m; m &= m - 1ull) {
+            const uint32_t li = (uint32_t)__builtin_ctzll(m);
+            dst[at++] = (j << 8) | (li << 2) | ((uint32_t)((cm >> li) & 1ull) << 1) | (uint32_t)((f >> li) & 1ull);
+        }
+        base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+}
+
 // One wave per tile: its records from its slot to their place in the dense, tile-ordered stream.
 __global__ __launch_bounds__(256)
 void ts_general_compact(const uint32_t *tile_stats, const u64 *tile_off, const uint32_t *records, uint32_t slot_cap,
@@ -911,5 +1136,18 @@ int ts_k_launch_general_compact(const uint32_t *tile_stats, const unsigned long 
     if (ntiles == 0) return 0;
     hipLaunchKernelGGL(ts_general_compact, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, tile_stats,
                        (const u64 *)tile_off, records, slot_cap, ntiles, dense);
+    return (int)hipGetLastError();
+}
+
+int ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
+                             const unsigned long long *seg_len, const unsigned long long *seg_win_base,
+                             const TsWidePatterns *W, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
+                             uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, void *stream) {
+    if (ntiles == 0) return 0;
+    const size_t lds = 4u * (size_t)kTile * 8u + 64u * 4u + 68u * 4u + 32u + kWideCodeWords * 4u + kWideInvalWords * 4u;
+    hipError_t e = hipFuncSetAttribute((const void *)ts_general_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (130 KB: above the default limit)
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(ts_general_wide, dim3(ntiles), dim3(256), lds, (hipStream_t)stream, in, tiles, ntiles,
+                       (const u64 *)seg_len, (const u64 *)seg_win_base, *W, *Q, tips, slot_cap, tile_stats, records, win_out, overflow);
     return (int)hipGetLastError();
 }

@@ -119,7 +119,7 @@ std::vector<Pattern> expand_patterns(const std::string &raw_csv, int edit_distan
         if (comma == std::string::npos) comma = raw_csv.size();
         std::string seed = raw_csv.substr(pos, comma - pos);
         pos = comma + 1;
-        if (seed.empty() || seed.size() > 62) continue;
+        if (seed.empty() || seed.size() > 63) continue;           // (ts_expand_patterns refuses such a list before it gets here)
         unmask(seed);
 
         std::vector<std::string> cs;

@@ -875,8 +875,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                        bool tips, ts_segment_out *out, bool blocks_only = false, ts_segment_counts *counts = nullptr) {
     if (which.empty()) return TS_OK;
     if (!c->generic_ok)
-        return c->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: more than 8 pattern lengths, a pattern longer "
-                                           "than 32 or a non-ACGT pattern");
+        return c->fail(TS_ERR_UNSUPPORTED, "unsupported parameter set: a non-ACGT pattern, or more than 63 pattern lengths / a pattern "
+                                           "longer than 63 bases (more than a ts_pattern holds)");
     DEVICE_TRY(c);
     { int rc = ensure_streams(c); if (rc != TS_OK) return rc; }
     const ts_params &P = c->params;
@@ -895,7 +895,11 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
 
     struct RegionL { uint64_t seg_start, len, layout_off; };                   // a scanned region and where it lies in the layout
     struct SegL { size_t idx; uint64_t len, abs_pos, layout_off; std::vector<RegionL> regions; uint64_t first_tile = 0, n_tiles = 0, win_base = 0, n_windows = 0; };
-    const uint64_t target = group_target_bytes();
+    // the wide form (sets beyond 8 lengths / 32 bases): its own kernel, a 64-base halo, records with six bits of length index, host
+    // block calling; smaller groups, because a tile's slot may have to grow to a record per position AND length
+    const bool wide = c->gen_wide;
+    const uint32_t rec_shift = wide ? 8u : 5u, rec_li_mask = wide ? 63u : 7u;
+    const uint64_t target = wide ? std::min<uint64_t>(group_target_bytes(), 64ull << 20) : group_target_bytes();
     int slot = 0;
     bool used[ts_ctx::kUpSlots] = {false, false, false};
     size_t wi = 0;
@@ -963,7 +967,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                     T.seg_rel = rg.seg_start + a;
                     T.k_p0 = kq; T.r_p0 = (uint32_t)kr;
                     T.n = (uint32_t)std::min<uint64_t>(TS_GENERAL_TILE, rg.len - a);
-                    T.avail = (uint32_t)std::min<uint64_t>(rg.len - a, (uint64_t)T.n + 32u);
+                    T.avail = (uint32_t)std::min<uint64_t>(rg.len - a, (uint64_t)T.n + (wide ? (uint32_t)TS_WIDE_HALO : 32u));
                     T.seg = (uint32_t)G.size();
                     tiles.push_back(T);
                     kr += TS_GENERAL_TILE;
@@ -1031,7 +1035,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         // the list form of the fused pass (per-candidate work on full wavefronts) when a tile adds to few enough window
         // records for the accumulators it keeps in LDS; a tile dense enough to overflow a wave's candidate list sends the
         // group through the position-strided form instead
-        bool use_list = !(getenv("TS_GEN_LIST") && getenv("TS_GEN_LIST")[0] == '0') && s >= 2u && w < (1u << 28) &&
+        bool use_list = !wide && !(getenv("TS_GEN_LIST") && getenv("TS_GEN_LIST")[0] == '0') && s >= 2u && w < (1u << 28) &&
                         (tips || ((uint64_t)TS_GENERAL_TILE + w) / s + 3 <= ts_k_general_list_max_records());
         HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * (size_t)slot_cap * 4, d_slots));
         HIP_TRY(c, c->pool.take((nt + 1) * 16, d_stats));
@@ -1052,6 +1056,13 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 if (timing) HIP_TRY(c, hipEventRecord(c->gen_ev[0], st));
                 HIP_TRY(c, hipMemsetAsync(dt + tab_flag, 0, 16, st));
                 if (nwin_total) HIP_TRY(c, hipMemsetAsync(d_win.p, 0, nwin_total * 32, st));
+                if (wide) {
+                    if (ts_k_launch_general_wide((const unsigned char *)d_in.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt,
+                                                 (const unsigned long long *)(dt + tab_len), (const unsigned long long *)(dt + tab_win), &c->wpat, &Q,
+                                                 tips ? 1 : 0, slot_cap, (uint32_t *)d_stats.p, (uint32_t *)d_slots.p, (uint32_t *)d_win.p,
+                                                 (uint32_t *)(dt + tab_flag), st) != 0)
+                        return c->fail(TS_ERR_HIP, "general wide kernel launch failed");
+                } else
                 if (ts_k_launch_general_fused((const unsigned char *)d_in.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt,
                                               (const unsigned long long *)(dt + tab_len), (const unsigned long long *)(dt + tab_win),
                                               (const unsigned long long *)(dt + tab_nwin), &c->gpat, &Q, tips ? 1 : 0, slot_cap, (uint32_t *)d_stats.p, (uint32_t *)d_slots.p,
@@ -1066,9 +1077,12 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
             HIP_TRY(c, hipStreamSynchronize(st));
             if (timing) { float ms = 0; if (hipEventElapsedTime(&ms, c->gen_ev[0], c->gen_ev[1]) == hipSuccess) t_kern += ms; }
             if (!flag) break;
-            if (attempt > 1) return c->fail(TS_ERR_STATE, "general path: a tile overflowed a slot that holds every match it can have");
+            const uint32_t slot_max = TS_GENERAL_TILE * std::max<uint32_t>(1u, wide ? c->wpat.nlen : c->gpat.nlen);
+            if (attempt > (wide ? 4 : 1) || (slot_cap >= slot_max && !(flag & 2u)))
+                return c->fail(TS_ERR_STATE, "general path: a tile overflowed a slot that holds every match it can have");
             if (flag & 2u) { use_list = false; continue; }            // a candidate list spilled: the strided form takes this group
-            slot_cap = TS_GENERAL_TILE * std::max<uint32_t>(1u, c->gpat.nlen);
+            // (the wide form grows by fours: a slot for every position AND length — 63 of them — is 1 MB per tile)
+            slot_cap = wide ? std::min<uint32_t>(slot_max, slot_cap * 4u) : slot_max;
             c->pool.give(std::move(d_slots));
             HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * (size_t)slot_cap * 4, d_slots));
         }
@@ -1145,7 +1159,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         // ---- host: records -> MatchInfo in the reference's push order, then block calling; one job per segment
         if (host_job.joinable()) host_job.join();                     // (one host stage at a time: it takes all the host threads)
         if (host_err.load() != TS_OK) return host_err.load();
-        host_job = std::thread([c, gh, ns, tips, s, w, ov, out, counts, skip_records, timing, &host_err, &t_host]() {
+        host_job = std::thread([c, gh, ns, tips, s, w, ov, out, counts, skip_records, timing, wide, rec_shift, rec_li_mask, &host_err, &t_host]() {
         const auto th0 = Clock::now();
         const std::vector<SegL> &G = gh->G;
         const std::vector<TsGeneralTile> &tiles = gh->tiles;
@@ -1206,8 +1220,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                         uint64_t at = tile_off[sl.first_tile + t] - r0;
                         for (uint64_t ri = tile_off[sl.first_tile + t]; ri < tile_off[sl.first_tile + t + 1]; ++ri, ++at) {
                             const uint32_t rec = recs[ri];
-                            const uint64_t p = T.seg_rel + (rec >> 5);
-                            const uint32_t len = c->gpat.len[(rec >> 2) & 7u];
+                            const uint64_t p = T.seg_rel + (rec >> rec_shift);
+                            const uint32_t len = wide ? c->wide_lens[(rec >> 2) & rec_li_mask] : c->gpat.len[(rec >> 2) & rec_li_mask];
                             ts_match &m = arr[at];
                             std::memset(&m, 0, sizeof m);
                             m.position = sl.abs_pos + p;

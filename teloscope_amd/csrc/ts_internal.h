@@ -238,6 +238,18 @@ struct TsGenericPatterns {
     uint32_t first[9];                  // codes[first[i] .. first[i+1]) have length len[i]
 };
 
+// The WIDE form's tables (generic.hip: ts_general_wide): pattern sets beyond the table forms above — up to 63 distinct lengths of
+// up to 63 bases, what a ts_pattern can hold.  Codes are 128 bits (lo: bases 0..31, hi: bases 32..62), per length ascending by
+// (lo, hi); everything lives in device memory.
+struct TsWidePatterns {
+    const unsigned long long *lo, *hi;
+    const uint8_t *flags;               // bit0 forward, bit1 canonical (parallel to lo / hi)
+    const uint32_t *len;                // nlen lengths, ascending
+    const uint32_t *first;              // nlen + 1: patterns [first[i], first[i + 1]) have length len[i]
+    uint32_t nlen, npat;
+};
+#define TS_WIDE_HALO 64                 // bases staged beyond a tile for the wide form (the other forms: 32)
+
 struct TsGenericGeom {
     uint32_t s, w, longest;
     uint32_t nuc_on, fold;
@@ -279,6 +291,12 @@ int  ts_k_launch_general_fused(const unsigned char *in, const TsGeneralTile *til
                                const TsGenericPatterns *G, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
                                uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, int list, int num_cu, void *stream);
 uint32_t ts_k_general_list_max_records(void);
+// the wide form of the same pass: any set a ts_pattern[] can express; records are (tile position << 8) | (length index << 2) |
+// canonical << 1 | forward; tiles' avail is clamped to n + TS_WIDE_HALO; *overflow bit 0 as above
+int  ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
+                              const unsigned long long *seg_len, const unsigned long long *seg_win_base,
+                              const TsWidePatterns *W, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
+                              uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, void *stream);
                                // (records: ntiles x slot_cap entries; win_out zeroed by the caller; *overflow raised when a tile
                                //  holds more than slot_cap records — its count is still written; list != 0: the list form of
                                //  the pass — for parameter sets whose tiles add to at most ts_k_general_list_max_records()

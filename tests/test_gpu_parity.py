@@ -411,18 +411,57 @@ def test_general_kernels_strided_form_matches_oracle(cli, monkeypatch):
     test_general_kernels_match_oracle(cli)
 
 
-def test_unsupported_parameter_sets_fail_loudly():
-    """What even the general kernels do not take (a pattern longer than 32, more than 8 distinct
-    lengths) returns TS_ERR_UNSUPPORTED; nothing is ever routed to a CPU path."""
-    import teloscope_amd as ta
+WIDE_GRID = [
+    # pattern sets beyond the table forms of the general kernels (more than 8 distinct lengths, or a pattern above 32 bases):
+    # the wide form (generic.hip: ts_general_wide — 128-bit codes, a u64 of matched lengths per position)
+    "-p " + "TTAGGG" * 6 + " -x 0 -w 1000 -s 500 -g -r -i",                          # one 36-base pattern (+ its reverse complement)
+    "-x 0 -p " + ",".join("TTAGGG"[:3] + "A" * i for i in range(9)) + " -w 1000 -s 500 -g -r -e -i",   # nine lengths 3..11
+    "-x 1 -p " + ",".join("TTAGGG"[:3] + "A" * i for i in range(9)) + " -t 600",     # the same with one mismatch, tips only
+    "-c TTAGGG -p TTAGGG,TTAGG,TTTAGGG,TTTTAGGG,TTAGGGG,TTAGGGTTAGGG,TTAGGGTTAGGGTTAGGG,TTAG,TTAGGGT," + "TTAGGG" * 7 + " -x 0 -w 500 -s 500 -g -i",
+    "-c TTAGGG -p TTAGGG," + ("TTAGGG" * 11)[:63] + " -x 0 -w 2000 -s 1000 -r -g -m -i",   # lengths 6 and 63: the longest a ts_pattern holds
+    "-p " + ("TTAGGG" * 7)[:40] + " -x 1 -w 1000 -s 990 -g -i",                      # 40 bases, one mismatch, L > overlap (wrapped start index)
+    "-x 0 -p A,AA,AAA,AAAA,AAAAA,AAAAAA,AAAAAAA,AAAAAAAA,AAAAAAAAA,AAAAAAAAAA -w 100 -s 50 -g -i -l 20",   # every length matches inside a run
+]
+
+
+@pytest.mark.parametrize("cli", WIDE_GRID)
+def test_wide_pattern_sets_match_oracle(cli):
+    opts = H.parse_cli("x.fa " + cli)
+    prod, orac = ProductBackend(opts), OracleBackend(opts)
+    if orac.ambiguous:
+        orac = orac.with_ambiguous_orientation_from(prod.patterns)
+    assert not prod.teloscope.usesFastPath() or opts.ultra_fast
+    rng = np.random.default_rng(len(cli) * 13 + 5)
+    segs = []
+    for i, n in enumerate([1, 5, 9, 36, 37, 63, 64, 65, 100, 997, 1000, 2001, 4095, 4096, 4097, 4160, 8200, 33333, 70001]):
+        s = bytearray(seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev,
+                                        telo_repeats=min(100, max(1, n // 40)), tvr_rate=0.03, n_its=3, iupac=(n // 3000) * (i % 2)))
+        if n > 8000:
+            s[4000:4300] = (b"TTAGGG" * 50)[:300]            # a repeat across a tile boundary
+            s[6000:6200] = b"A" * 200                         # a homopolymer run
+            s[4090] = ord("N")
+        segs.append((bytes(s), int(rng.integers(0, 10 ** 6)), opts.ultra_fast))
+    got = prod.scan_segments(segs)
+    for (s, ap, tips), g in zip(segs, got):
+        assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="cli=%r len=%d" % (cli, len(s)))
+
+
+def test_what_a_pattern_cannot_hold_is_refused_loudly():
+    """A pattern longer than the 63 bases a ts_pattern holds is refused when the context is made (never truncated, never routed
+    to a CPU path); everything a ts_pattern[] can express is scanned (test_wide_pattern_sets_match_oracle)."""
+    import ctypes as C
     from teloscope_amd import _capi as K
-    for cli in ("-p " + "TTAGGG" * 6 + " -x 0 -w 1000 -s 500 -g",
-                "-x 0 -p " + ",".join("TTAGGG"[:3] + "A" * i for i in range(9)) + " -w 1000 -s 500 -g"):
-        opts = H.parse_cli("x.fa " + cli)
-        be = ProductBackend(opts)
-        with pytest.raises(ta.TeloscanError) as ei:
-            be.scan_segment(b"ACGT" * 100, 0, False)
-        assert ei.value.code == K.TS_ERR_UNSUPPORTED
+    L = K.lib()
+    arr = (K.Pattern * 1)()
+    arr[0].seq = b"TTAGGG" * 10
+    arr[0].len = 64
+    prm = K.Params()
+    prm.struct_size = C.sizeof(K.Params)
+    prm.window_size, prm.step = 1000, 500
+    assert not L.ts_create(C.byref(prm), arr, 1)
+    assert b"longer than the 63 bases" in L.ts_last_error(None)
+    out, n = C.POINTER(K.Pattern)(), C.c_size_t(0)
+    assert L.ts_expand_patterns(("TTAGGG" * 11).encode(), 0, b"CCCTAA", C.byref(out), C.byref(n)) == K.TS_ERR_UNSUPPORTED
 
 
 def test_real_chromosome_matches_oracle():

@@ -368,7 +368,9 @@ def test_slice_around_position_4g_of_one_contig():
 
 
 @pytest.mark.parametrize("cli", ["--fastq-subset -p TTAGGG,TTAGG", "--fastq-subset -c TTAGGGTTA -x 0 -l 30",
-                                 "--fastq-subset -c AACCCTAACC -x 1"])
+                                 "--fastq-subset -c AACCCTAACC -x 1",
+                                 "--fastq-subset -x 0 -p TTAG,TTAGG,TTAGGG,TTTAGGG,TTTTAGGG,TTAGGGTTA,TTAGGGTTAG,TTAGGGTTAGG,TTAGGGTTAGGG",   # nine lengths: the wide form
+                                 "--fastq-subset -c TTAGGG -x 0 -p TTAGGG," + "TTAGGG" * 7])
 def test_read_filter_on_pattern_sets_outside_the_tiled_kernel(cli):
     """Mixed-length -p sets and 9-10 nt canonical motifs take the general kernels inside ts_filter_reads (the path
     that used to relock the context's call mutex and hang)."""
