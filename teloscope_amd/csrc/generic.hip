@@ -824,7 +824,8 @@ constexpr uint32_t kWideInvalWords = (kTile + TS_WIDE_HALO) / 32u + 4u;    // va
 struct WideAcc { uint32_t nuc, can, non, fwd, rev; };
 
 // window_tile_part for the wide form's masks
-__device__ __forceinline__ void window_tile_part_wide(const uint32_t *codes2, const uint32_t *inval, const u64 *hit, const u64 *fwdm, const u64 *canm,
+template <typename M>
+__device__ __forceinline__ void window_tile_part_wide(const uint32_t *codes2, const uint32_t *inval, const M *hit, const M *fwdm, const M *canm,
                                                       const uint32_t *lens, const TsGenericGeom &Q, u64 n, u64 kw, bool carry,
                                                       u64 P0, uint32_t ntile, uint32_t lane, WideAcc &a) {
     const u64 wstart = kw * Q.s;
@@ -861,16 +862,19 @@ __device__ __forceinline__ void window_tile_part_wide(const uint32_t *codes2, co
     }
 }
 
+// M: the per-position masks' type (uint16_t for up to 16 lengths, uint32_t for up to 32, u64 for up to 63: LDS per workgroup
+// 40 / 64 / 130 KB, i.e. three / two / one workgroup per CU); P: the prefix table's entry type (uint32_t or u64)
+template <typename M, typename P>
 __global__ __launch_bounds__(256)
 void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles, const u64 *seg_len,
                      const u64 *seg_win_base, const TsWidePatterns W, const TsGenericGeom Q, int tips, uint32_t slot_cap,
                      uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
     extern __shared__ __align__(16) unsigned char lds[];
-    // layout: hit u64[kTile] | fwd u64[kTile] | can u64[kTile] | pre6 u64[4096] | lens u32[64] | first u32[68] | part u32[8] | codes2 | inval
-    u64 *hit = (u64 *)lds;
-    u64 *fwdm = hit + kTile;
-    u64 *canm = fwdm + kTile;
-    u64 *pre6 = canm + kTile;
+    // layout: hit M[kTile] | fwd M[kTile] | can M[kTile] | pre6 P[4096] | lens u32[64] | first u32[68] | part u32[8] | codes2 | inval
+    M *hit = (M *)lds;
+    M *fwdm = hit + kTile;
+    M *canm = fwdm + kTile;
+    P *pre6 = (P *)(canm + kTile);
     uint32_t *lens = (uint32_t *)(pre6 + 4096u);
     uint32_t *first = lens + 64;
     uint32_t *part = first + 68;
@@ -878,7 +882,7 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
     uint32_t *inval = codes2 + kWideCodeWords;
     if (blockIdx.x >= ntiles) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t i = tid; i < 4096u; i += 256u) pre6[i] = 0ull;
+    for (uint32_t i = tid; i < 4096u; i += 256u) pre6[i] = (P)0;
     if (tid < 64u) lens[tid] = tid < W.nlen ? W.len[tid] : 0xFFFFFFFFu;
     if (tid <= W.nlen && tid < 68u) first[tid] = W.first[tid];
     const TsGeneralTile T = tiles[blockIdx.x];
@@ -920,7 +924,7 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
         for (uint32_t x = tid; x < (cnt << ext_bits); x += 256u) {
             const uint32_t pre = (uint32_t)W.lo[f0 + (x >> ext_bits)] & ((1u << (2u * q)) - 1u);
             const uint32_t idx = pre | ((x & ((1u << ext_bits) - 1u)) << (2u * q));
-            atomicOr((unsigned long long *)&pre6[idx], 1ull << li);
+            atomicOr(&pre6[idx], (P)((P)1 << li));
         }
     }
     __syncthreads();
@@ -937,7 +941,7 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
             const uint32_t nvalid = ilo ? (uint32_t)__builtin_ctz(ilo) : (ihi ? 32u + (uint32_t)__builtin_ctz(ihi) : 64u);
             const uint32_t rem = avail > j ? avail - j : 0u;
             const uint32_t maxlen = nvalid < rem ? nvalid : rem;
-            for (u64 cand = pre6[(uint32_t)lo & 0xFFFu]; cand; cand &= cand - 1ull) {
+            for (u64 cand = (u64)pre6[(uint32_t)lo & 0xFFFu]; cand; cand &= cand - 1ull) {
                 const uint32_t li = (uint32_t)__builtin_ctzll(cand);
                 const uint32_t l = lens[li];
                 if (l > maxlen) break;                   // lengths ascend: a non-ACGT base or the region's end stops this and every longer pattern
@@ -958,7 +962,7 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
                 }
             }
         }
-        hit[j] = h; fwdm[j] = f; canm[j] = c;
+        hit[j] = (M)h; fwdm[j] = (M)f; canm[j] = (M)c;
     }
     __syncthreads();
     const u64 n = seg_len[T.seg];
@@ -1003,7 +1007,7 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
             u64 unused_rec;
             if (tips || full_scan_pushes(j, lens[li], pg, &unused_rec)) keep |= 1ull << li;
         }
-        hit[j] = keep;
+        hit[j] = (M)keep;
         wave_cnt += (uint32_t)__popcll(keep);
     }
     wave_cnt = wave_total(wave_cnt);
@@ -1144,10 +1148,19 @@ int ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tiles
                              const TsWidePatterns *W, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
                              uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, void *stream) {
     if (ntiles == 0) return 0;
-    const size_t lds = 4u * (size_t)kTile * 8u + 64u * 4u + 68u * 4u + 32u + kWideCodeWords * 4u + kWideInvalWords * 4u;
-    hipError_t e = hipFuncSetAttribute((const void *)ts_general_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (130 KB: above the default limit)
+    const size_t rest = 64u * 4u + 68u * 4u + 32u + kWideCodeWords * 4u + kWideInvalWords * 4u;
+    auto launch = [&](auto kernel, size_t mask_bytes, size_t pre_bytes) -> hipError_t {
+        const size_t lds = 3u * (size_t)kTile * mask_bytes + 4096u * pre_bytes + rest;
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (up to 130 KB: above the default limit)
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(ntiles), dim3(256), lds, (hipStream_t)stream, in, tiles, ntiles,
+                           (const u64 *)seg_len, (const u64 *)seg_win_base, *W, *Q, tips, slot_cap, tile_stats, records, win_out, overflow);
+        return hipSuccess;
+    };
+    hipError_t e;
+    if (W->nlen <= 16u) e = launch(ts_general_wide<uint16_t, uint32_t>, 2, 4);
+    else if (W->nlen <= 32u) e = launch(ts_general_wide<uint32_t, uint32_t>, 4, 4);
+    else e = launch(ts_general_wide<u64, u64>, 8, 8);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(ts_general_wide, dim3(ntiles), dim3(256), lds, (hipStream_t)stream, in, tiles, ntiles,
-                       (const u64 *)seg_len, (const u64 *)seg_win_base, *W, *Q, tips, slot_cap, tile_stats, records, win_out, overflow);
     return (int)hipGetLastError();
 }

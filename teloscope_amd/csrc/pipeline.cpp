@@ -1259,16 +1259,20 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 if (!tips && !sorted) {
                     // mixed-length sets: a long match near a window start is pushed by the NEXT window, after shorter
                     // matches that begin behind it — order by pushing window, position order within it
+                    // The stream is in position order and a record's pushing window grows with its END position, so a record is
+                    // out of place by at most the few records that start within (longest - shortest) bases ahead of it: one
+                    // insertion pass, stable by construction (a record only moves behind records with a LARGER key), instead
+                    // of a stable_sort over an index array and a gather (0.7 s per 3 Gb on a nine-length set).
                     std::vector<uint64_t> key(nm);
                     for (uint64_t i = 0; i < nm; ++i) key[i] = push_window(arr[i].position - sl.abs_pos, arr[i].match_size);
-                    std::vector<uint32_t> idx(nm);
-                    for (uint64_t i = 0; i < nm; ++i) idx[i] = (uint32_t)i;
-                    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b2) { return key[a] < key[b2]; });
-                    ts_match *sorted_arr = (ts_match *)ts_alloc_large(nm * sizeof(ts_match));
-                    if (!sorted_arr) { std::free(arr); int e = TS_OK; first_err.compare_exchange_strong(e, c->fail(TS_ERR_ALLOC, "out of host memory")); return; }
-                    for (uint64_t i = 0; i < nm; ++i) sorted_arr[i] = arr[idx[i]];
-                    std::free(arr);
-                    arr = sorted_arr;
+                    for (uint64_t i = 1; i < nm; ++i) {
+                        if (key[i] >= key[i - 1]) continue;
+                        const ts_match t = arr[i];
+                        const uint64_t kk = key[i];
+                        uint64_t j = i;
+                        while (j > 0 && key[j - 1] > kk) { arr[j] = arr[j - 1]; key[j] = key[j - 1]; --j; }
+                        arr[j] = t; key[j] = kk;
+                    }
                 }
                 const auto tw1 = Clock::now();
                 const int rc = ts_finalize_segment(c, tips, sl.len, sl.abs_pos, sl.n_windows ? &wins[sl.win_base * 8] : nullptr,

@@ -421,6 +421,8 @@ WIDE_GRID = [
     "-c TTAGGG -p TTAGGG," + ("TTAGGG" * 11)[:63] + " -x 0 -w 2000 -s 1000 -r -g -m -i",   # lengths 6 and 63: the longest a ts_pattern holds
     "-p " + ("TTAGGG" * 7)[:40] + " -x 1 -w 1000 -s 990 -g -i",                      # 40 bases, one mismatch, L > overlap (wrapped start index)
     "-x 0 -p A,AA,AAA,AAAA,AAAAA,AAAAAA,AAAAAAA,AAAAAAAA,AAAAAAAAA,AAAAAAAAAA -w 100 -s 50 -g -i -l 20",   # every length matches inside a run
+    "-x 0 -p " + ",".join(("TTAGGG" * 7)[:k] for k in range(4, 21)) + " -w 1000 -s 500 -g -r -i",     # 17 lengths: the 32-bit masks
+    "-x 0 -p " + ",".join(("TTAGGG" * 7)[:k] for k in range(3, 36)) + " -w 600 -s 600 -g -i",          # 33 lengths: the 64-bit masks
 ]
 
 
