@@ -9,7 +9,7 @@ make -s -C $REPO/teloscope_amd/csrc && make -s -C $REPO/oracle
 OUT=$REPO/gpurun_out/genprof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export TS_GEN_ONLY=mixed_5_6 TS_TIMING=1
+export TS_GEN_ONLY=${GEN_ONLY:-mixed_5_6} TS_TIMING=1
 ARGS="$REPO/profiles/general_path_rate.py 3.0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1 || true

@@ -867,21 +867,28 @@ __device__ __forceinline__ void window_tile_part_wide(const uint32_t *codes2, co
 template <typename M, typename P>
 __global__ __launch_bounds__(256)
 void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles, const u64 *seg_len,
-                     const u64 *seg_win_base, const TsWidePatterns W, const TsGenericGeom Q, int tips, uint32_t slot_cap,
+                     const u64 *seg_win_base, const TsWidePatterns W, const TsGenericGeom Q, int tips, uint32_t slot_cap, uint32_t lds_pat,
                      uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
     extern __shared__ __align__(16) unsigned char lds[];
-    // layout: hit M[kTile] | fwd M[kTile] | can M[kTile] | pre6 P[4096] | lens u32[64] | first u32[68] | part u32[8] | codes2 | inval
+    // layout: hit M[kTile] | fwd M[kTile] | can M[kTile] | pre6 P[4096] | plo u64[lds_pat] | phi u64[lds_pat] | lens u32[64] | first u32[68] |
+    //         part u32[8] | codes2 | inval | pfl u8[lds_pat]      (lds_pat: the pattern lists in LDS when they fit — a search step is then an
+    //         LDS read; out of device memory the searches of the few lanes that hold a candidate were 80 % of the kernel's time)
     M *hit = (M *)lds;
     M *fwdm = hit + kTile;
     M *canm = fwdm + kTile;
     P *pre6 = (P *)(canm + kTile);
-    uint32_t *lens = (uint32_t *)(pre6 + 4096u);
+    u64 *plo = (u64 *)(pre6 + 4096u);
+    u64 *phi = plo + lds_pat;
+    uint32_t *lens = (uint32_t *)(phi + lds_pat);
     uint32_t *first = lens + 64;
     uint32_t *part = first + 68;
     uint32_t *codes2 = part + 8;
     uint32_t *inval = codes2 + kWideCodeWords;
+    unsigned char *pfl = (unsigned char *)(inval + kWideInvalWords);
     if (blockIdx.x >= ntiles) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool in_lds = lds_pat != 0u;
+    for (uint32_t i = tid; i < lds_pat; i += 256u) { plo[i] = W.lo[i]; phi[i] = W.hi[i]; pfl[i] = W.flags[i]; }
     for (uint32_t i = tid; i < 4096u; i += 256u) pre6[i] = (P)0;
     if (tid < 64u) lens[tid] = tid < W.nlen ? W.len[tid] : 0xFFFFFFFFu;
     if (tid <= W.nlen && tid < 68u) first[tid] = W.first[tid];
@@ -922,7 +929,7 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
         const uint32_t l = lens[li], q = l < 6u ? l : 6u, ext_bits = 2u * (6u - q);
         const uint32_t f0 = first[li], cnt = first[li + 1u] - f0;
         for (uint32_t x = tid; x < (cnt << ext_bits); x += 256u) {
-            const uint32_t pre = (uint32_t)W.lo[f0 + (x >> ext_bits)] & ((1u << (2u * q)) - 1u);
+            const uint32_t pre = (uint32_t)(in_lds ? plo[f0 + (x >> ext_bits)] : W.lo[f0 + (x >> ext_bits)]) & ((1u << (2u * q)) - 1u);
             const uint32_t idx = pre | ((x & ((1u << ext_bits) - 1u)) << (2u * q));
             atomicOr(&pre6[idx], (P)((P)1 << li));
         }
@@ -931,7 +938,7 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
     // 2. matches
     for (uint32_t j = tid; j < kTile; j += 256u) {
         u64 h = 0, f = 0, c = 0;
-        if (j < T.n) {
+        if (j < T.n && !(Q.abl & 128u)) {
             const uint32_t wd = j >> 4, sh = 2u * (j & 15u);
             const uint32_t c0 = codes2[wd], c1 = codes2[wd + 1u], c2 = codes2[wd + 2u], c3 = codes2[wd + 3u], c4 = codes2[wd + 4u];
             const u64 lo = (u64)__funnelshift_r(c0, c1, sh) | ((u64)__funnelshift_r(c1, c2, sh) << 32);
@@ -951,11 +958,11 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
                 const uint32_t end = b;
                 while (a < b) {                          // binary search in the (lo, hi)-sorted list of this length
                     const uint32_t mid = (a + b) >> 1;
-                    const u64 mlo = W.lo[mid], mhi = W.hi[mid];
+                    const u64 mlo = in_lds ? plo[mid] : W.lo[mid], mhi = in_lds ? phi[mid] : W.hi[mid];
                     if (mlo < klo || (mlo == klo && mhi < khi)) a = mid + 1u; else b = mid;
                 }
-                if (a < end && W.lo[a] == klo && W.hi[a] == khi) {
-                    const uint32_t fl = W.flags[a];
+                if (a < end && (in_lds ? plo[a] : W.lo[a]) == klo && (in_lds ? phi[a] : W.hi[a]) == khi) {
+                    const uint32_t fl = in_lds ? pfl[a] : W.flags[a];
                     h |= 1ull << li;
                     if (fl & 1u) f |= 1ull << li;
                     if (fl & 2u) c |= 1ull << li;
@@ -968,7 +975,7 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
     const u64 n = seg_len[T.seg];
     const u64 P0 = T.seg_rel;
     // 3. window records (full scans): as in ts_general_fused
-    if (!tips && T.n) {
+    if (!tips && T.n && !(Q.abl & 256u)) {
         const u64 nwin = (n + Q.s - 1u) / Q.s;
         const u64 kw_lo = P0 >= Q.w ? (P0 - Q.w) / Q.s + 1u : 0u;
         u64 kw_hi = (P0 + T.n - 1u) / Q.s;
@@ -1148,13 +1155,17 @@ int ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tiles
                              const TsWidePatterns *W, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
                              uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, void *stream) {
     if (ntiles == 0) return 0;
-    const size_t rest = 64u * 4u + 68u * 4u + 32u + kWideCodeWords * 4u + kWideInvalWords * 4u;
+    const size_t fixed = 64u * 4u + 68u * 4u + 32u + kWideCodeWords * 4u + kWideInvalWords * 4u;
     auto launch = [&](auto kernel, size_t mask_bytes, size_t pre_bytes) -> hipError_t {
-        const size_t lds = 3u * (size_t)kTile * mask_bytes + 4096u * pre_bytes + rest;
-        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (up to 130 KB: above the default limit)
+        const size_t tables = 3u * (size_t)kTile * mask_bytes + 4096u * pre_bytes + fixed;
+        // the pattern lists in LDS (17 bytes per pattern) when they fit beside the tables
+        uint32_t lds_pat = W->npat <= 2048u ? W->npat : 0u;
+        if (tables + (size_t)lds_pat * 16u + ((lds_pat + 15u) & ~15u) > (160u << 10)) lds_pat = 0u;
+        const size_t lds = tables + (size_t)lds_pat * 16u + ((lds_pat + 15u) & ~15u);
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (up to 160 KB: above the default limit)
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, dim3(ntiles), dim3(256), lds, (hipStream_t)stream, in, tiles, ntiles,
-                           (const u64 *)seg_len, (const u64 *)seg_win_base, *W, *Q, tips, slot_cap, tile_stats, records, win_out, overflow);
+                           (const u64 *)seg_len, (const u64 *)seg_win_base, *W, *Q, tips, slot_cap, lds_pat, tile_stats, records, win_out, overflow);
         return hipSuccess;
     };
     hipError_t e;

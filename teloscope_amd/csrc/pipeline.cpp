@@ -1000,6 +1000,9 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         PR.ms = ms_between(t0, Clock::now());
         return TS_OK;
     };
+    // a tile's slot at the start of a group: what the groups before needed (a telomeric tile under a many-length set holds more
+    // than a record per position; finding that out again for every group ran half the groups of a call twice)
+    uint32_t slot_cap_call = wide ? TS_GENERAL_TILE * std::min<uint32_t>(4u, std::max<uint32_t>(1u, c->wpat.nlen)) : TS_GENERAL_TILE;
     std::unique_ptr<Prepared> cur(new Prepared), nxt;
     std::thread pf;
     struct JoinJob join_pf{pf};
@@ -1031,7 +1034,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         const size_t tab_len = 0, tab_win = 2 * ns * 8, tab_nwin = 3 * ns * 8, tab_flag = 4 * ns * 8 + 8;
         // a tile's slot: one record per position — all a single-length set can produce; a mixed-length tile that holds
         // more says so, and the group runs again with slots that cannot overflow
-        uint32_t slot_cap = TS_GENERAL_TILE;
+        uint32_t slot_cap = slot_cap_call;
         // the list form of the fused pass (per-candidate work on full wavefronts) when a tile adds to few enough window
         // records for the accumulators it keeps in LDS; a tile dense enough to overflow a wave's candidate list sends the
         // group through the position-strided form instead
@@ -1083,6 +1086,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
             if (flag & 2u) { use_list = false; continue; }            // a candidate list spilled: the strided form takes this group
             // (the wide form grows by fours: a slot for every position AND length — 63 of them — is 1 MB per tile)
             slot_cap = wide ? std::min<uint32_t>(slot_max, slot_cap * 4u) : slot_max;
+            slot_cap_call = slot_cap;
             c->pool.give(std::move(d_slots));
             HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * (size_t)slot_cap * 4, d_slots));
         }
