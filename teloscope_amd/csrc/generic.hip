@@ -1,22 +1,24 @@
 // generic.hip — the GENERAL path of libteloscan (gfx950): every parameter set the tiled kernel in kernels.hip
 // does not take.  That kernel covers uniform-length pattern sets (3 <= k <= 8) under the geometry where the
 // reference's per-window carry loop has a closed form; what is left — mixed-length pattern sets (several matches per
-// position), pattern lengths up to 32, and window/step pairs where the reference's `uint32` start index wraps
+// position), long patterns (up to the 63 bases a ts_pattern holds), and window/step pairs where the reference's `uint32` start index wraps
 // (src/teloscope.cpp:413-415) — is restated here LITERALLY (the main / carry attribution of analyzeWindow, not its
 // closed form), for a whole batch of segments at a time and with nothing but ordering work left to the host:
 //
-//   ts_general_fused_list  ONE pass, one workgroup per tile of 4096 positions of one scanned region: bases staged into
-//                       LDS as 2-bit planes, the pattern lists (per length: ascending 2-bit codes + {forward, canonical})
-//                       and a prefix bitmap per length beside them; positions only ask the bitmaps, candidates go to
-//                       per-wave lists in LDS, and everything per match — search, push test, window shares, record —
-//                       runs a lane per candidate on full wavefronts.
+//   ts_general_fused_list  the LIST form (sets of up to 8 lengths of up to 32 bases whose lists fit LDS): persistent workgroups
+//                       stride over tiles of 4096 positions; bases staged into LDS as 2-bit planes; ONE LDS probe per position
+//                       from a 6-mer table that holds a bit per pattern length; candidates go to per-wave lists in LDS, and
+//                       everything per match — flags (exact tables for lengths <= 6, a binary search above), push test, window
+//                       shares, record — runs a lane per candidate on full wavefronts; window records a lane per record.
 //   ts_general_fused    the position-strided form of the same pass (tiny steps, pattern lists too large for LDS, dense
 //                       tiles whose candidate lists spill).
+//   ts_general_wide     the WIDE form: what the two above do not take — up to 63 lengths of up to 63 bases (128-bit codes, a
+//                       mask of matched lengths per position).
 //   ts_general_compact  the tiles' slots into one dense tile-ordered stream (after a prefix sum over the counts).
 //
 // Traffic: 1 B/base in, 32 B/window and 2 x 4 B/match out.  (Rounds 1-2 ran three kernels around a 4 B/base match mask
-// in HBM: ~13 B/base.)  The host orders mixed-length records by pushing window where they are out of that order,
-// expands them and calls blocks.
+// in HBM: ~13 B/base.)  Blocks are called on the device (blockcall.hip) wherever the stream is in the reference's calling
+// order; otherwise the host orders the records by pushing window, expands them and calls blocks.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
