@@ -30,7 +30,7 @@ for i in tel:
         pool[offs[i + 1] - len(t):offs[i + 1]] = t
 buf = pool.tobytes()
 reads = [buf[offs[i]:offs[i + 1]] for i in range(n_reads)]
-opts = H.parse_cli("--fastq-subset -l 42")
+opts = H.parse_cli(os.environ.get("TS_RF_FLAGS", "--fastq-subset -l 42"))
 rf = ProductReadFilter(opts)
 rf.filter(reads[:1000])                                   # warm-up
 t0 = time.perf_counter()

@@ -1441,12 +1441,16 @@ int ts_filter_reads(ts_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
         items[i] = Item{seqs[i], n, 0, TS_INPUT_BASES, 0};
     }
     if (!ctx->fast_ok) {
-        // pattern sets outside the tiled kernel (mixed lengths, k > 8): general kernels + host block calling
+        // pattern sets outside the tiled kernel (mixed lengths, k > 8): the general kernels in their blocks-only form — a
+        // tips-only scan's stream is in calling order, so the blocks are called on the device and no match record leaves it
+        // (the wide form alone keeps host block calling); all the filter reads is whether a read has a terminal block
         std::vector<ts_segment_in> in(n_reads);
-        for (size_t i = 0; i < n_reads; ++i) { in[i] = ts_segment_in{}; in[i].seq = items[i].seq; in[i].len = items[i].len; in[i].abs_pos = 0; in[i].tips_only = 1; }
+        std::vector<size_t> all(n_reads);
+        for (size_t i = 0; i < n_reads; ++i) { in[i] = ts_segment_in{}; in[i].seq = items[i].seq; in[i].len = items[i].len; in[i].abs_pos = 0; in[i].tips_only = 1; all[i] = i; }
         std::vector<ts_segment_out> out(n_reads);
-        int rc = scan_segments_impl(ctx, in.data(), n_reads, out.data(), false);
-        if (rc != TS_OK) return rc;
+        for (size_t i = 0; i < n_reads; ++i) std::memset(&out[i], 0, sizeof out[i]);
+        int rc = generic_locked(ctx, in.data(), all, true, out.data(), false, true, nullptr);
+        if (rc != TS_OK) { ts_free_segments(out.data(), n_reads); return rc; }
         for (size_t i = 0; i < n_reads; ++i) pass[i] = out[i].n_terminal_blocks != 0;
         ts_free_segments(out.data(), n_reads);
         return TS_OK;
