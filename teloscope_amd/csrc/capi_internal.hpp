@@ -142,6 +142,7 @@ struct ts_ctx {
     PinBuf pin_runs[kUpSlots];
     hipEvent_t gen_ev[2] = {nullptr, nullptr};   // TS_TIMING: around the general path's kernels
     PinBuf pin_down[2];
+    PinBuf pin_off;                              // general path: a group's tile directory lands here (a pageable landing cost 9 ms per MB-sized copy)
     hipStream_t up_stream = nullptr, scan_stream = nullptr, down_stream = nullptr;
 
     std::mutex down_mtx;            // one download (pinned landing area + its stream) at a time

@@ -889,6 +889,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     if (const char *e = getenv("TS_GEN_ABL")) Q.abl = (uint32_t)atoi(e);
     const bool timing = getenv("TS_TIMING") != nullptr;
     const auto t_begin = Clock::now();
+    double t_dbg[3] = {0, 0, 0};
     double t_up = 0, t_dev = 0, t_host = 0, t_take = 0, t_fused = 0, t_blk = 0, t_d2h = 0, t_wait_next = 0;
     float t_kern = 0;
     if (timing && !c->gen_ev[0]) { HIP_TRY(c, hipEventCreate(&c->gen_ev[0])); HIP_TRY(c, hipEventCreate(&c->gen_ev[1])); }
@@ -1075,9 +1076,18 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                     return c->fail(TS_ERR_HIP, "tile-offset kernel launch failed");
                 if (timing) HIP_TRY(c, hipEventRecord(c->gen_ev[1], st));
             }
-            if (nt) HIP_TRY(c, hipMemcpyAsync(tile_off.data(), d_off.p, (nt + 1) * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipMemcpyAsync(&flag, dt + tab_flag, 4, hipMemcpyDeviceToHost, st));
+            const auto te0 = Clock::now();
+            // (pinned landing: asynchronous for real, then one memcpy into the group's own vector)
+            unsigned long long *land = nullptr;
+            if (nt && c->pin_off.ensure(std::max<size_t>((nt + 1) * 8 + 64, 1u << 20)) == hipSuccess) land = (unsigned long long *)c->pin_off.p;
+            else (void)hipGetLastError();
+            uint32_t *flag_land = land ? (uint32_t *)(land + nt + 1) : &flag;
+            if (nt) HIP_TRY(c, hipMemcpyAsync(land ? land : tile_off.data(), d_off.p, (nt + 1) * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipMemcpyAsync(flag_land, dt + tab_flag, 4, hipMemcpyDeviceToHost, st));
+            const auto te1 = Clock::now();
             HIP_TRY(c, hipStreamSynchronize(st));
+            if (land) { std::memcpy(tile_off.data(), land, (nt + 1) * 8); flag = *flag_land; }
+            if (timing) { t_dbg[0] += ms_between(t1, te0); t_dbg[1] += ms_between(te0, te1); t_dbg[2] += ms_between(te1, Clock::now()); }
             if (timing) { float ms = 0; if (hipEventElapsedTime(&ms, c->gen_ev[0], c->gen_ev[1]) == hipSuccess) t_kern += ms; }
             if (!flag) break;
             const uint32_t slot_max = TS_GENERAL_TILE * std::max<uint32_t>(1u, wide ? c->wpat.nlen : c->gpat.nlen);
@@ -1305,8 +1315,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     if (host_job.joinable()) host_job.join();
     if (host_err.load() != TS_OK) return host_err.load();
     if (timing)
-        fprintf(stderr, "general path: device stage: buffers %.1f ms, fused pass + tile offsets (synced) %.1f ms, compaction + block calling %.1f ms, D2H %.1f ms, waiting for the next group's upload %.1f ms\n",
-                t_take, t_fused, t_blk, t_d2h, t_wait_next);
+        fprintf(stderr, "general path: device stage: buffers %.1f ms, fused pass + tile offsets (synced) %.1f ms, compaction + block calling %.1f ms, D2H %.1f ms, waiting for the next group's upload %.1f ms (fused stage: enqueue %.1f, copies enqueue %.1f, sync %.1f)\n",
+                t_take, t_fused, t_blk, t_d2h, t_wait_next, t_dbg[0], t_dbg[1], t_dbg[2]);
     if (timing)
         fprintf(stderr, "general path: %zu segments, wall %.1f ms: upload %.1f ms, kernels + D2H %.1f ms (kernels alone, HIP events: %.2f ms), host ordering + block calling %.1f ms (on a thread of its own, one group behind; job time: expansion %.1f ms, windows + block calling %.1f ms)\n",
                 which.size(), ms_between(t_begin, Clock::now()), t_up, t_dev, (double)t_kern, t_host, ts_gen_ns[0].exchange(0) / 1e6, ts_gen_ns[1].exchange(0) / 1e6);
