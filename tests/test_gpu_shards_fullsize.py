@@ -654,3 +654,86 @@ def test_tiled_and_general_kernels_agree_at_full_size(cli, gb, monkeypatch):
     assert nrec > 1000
     L.ts_free_segments(mo["tiled"], m)
     L.ts_free_segments(mo["general"], m)
+
+
+@pytest.mark.parametrize("cli,gb", [("-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i", 1.0),
+                                    ("-x 0 -p TTAG,TTAGG,TTAGGG,TTTAGGG,TTTTAGGG,TTAGGGTTA,TTAGGGTTAG,TTAGGGTTAGG,TTAGGGTTAGGG -w 1000 -s 500 -r -g -e -m -i", 0.5)])
+def test_general_path_counts_equal_an_independent_count_at_scale(cli, gb):
+    """The general kernels (list form: a mixed-length set; wide form: nine lengths) against a computation that shares nothing
+    with them — torch: a rolling 2-bit code and one lookup table PER PATTERN LENGTH — on bench.py's synthetic assembly: per
+    contig the number of matches, of canonical and of forward ones (for w > s every match that fits its segment is pushed
+    exactly once), and the A / C / G / T totals summed over the windows that tile the contig."""
+    import torch
+    import bench
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import parse_cli, user_input
+    L = K.lib()
+    opts = parse_cli("x.fa " + cli)
+    tel = ta.Teloscope(user_input(opts, device=0))
+    assert not tel.usesFastPath()
+    ui = tel.userInput
+    total = int(gb * 1e9)
+    lens = bench.contig_lengths(total, 200, 42)
+    offs, off = [], 0
+    for n_ in lens:
+        offs.append(off)
+        off += (n_ + 15) & ~15
+    dev = torch.device("cuda", 0)
+    buf = torch.zeros(off + 4096, dtype=torch.uint8, device=dev)
+    bench.fill_synthetic(buf, offs, lens, 42, dev)
+    host = buf.cpu().numpy()
+    n = len(lens)
+    segs = (K.SegmentIn * n)()
+    for i in range(n):
+        segs[i].seq = C.cast(C.c_void_p(host.ctypes.data + offs[i]), C.c_char_p)
+        segs[i].len = lens[i]
+    out = (K.SegmentOut * n)()
+    cnt = (K.SegmentCounts * n)()
+    assert L.ts_scan_segments_blocks(tel._ctx.ptr, segs, n, out, cnt) == 0, tel._ctx.error()
+    # the independent side: a table per pattern length
+    code_of = {"A": 0, "C": 1, "T": 2, "G": 3}
+    by_len = {}
+    for pat, fwd in ui.patternInfo:
+        by_len.setdefault(len(pat), []).append((sum(code_of[ch] << (2 * i) for i, ch in enumerate(pat)), bool(fwd), pat in (ui.canonicalFwd, ui.canonicalRev)))
+    tables = {}
+    for k, pats in by_len.items():
+        t = torch.zeros(3, 4 ** k, dtype=torch.bool)
+        for x, fwd, can in pats:
+            t[0, x], t[1, x], t[2, x] = True, fwd, can
+        tables[k] = t.to(dev)
+    lut = torch.full((256,), 4, dtype=torch.int64)
+    for ch, c in code_of.items():
+        lut[ord(ch)] = c
+        lut[ord(ch.lower())] = c
+    lut = lut.to(dev)
+    step, window = ui.step, ui.windowSize
+    assert window == 2 * step
+    kmax = max(tables)
+    for ci in range(n):
+        nb = lens[ci]
+        c = lut[buf[offs[ci]:offs[ci] + nb].long()]
+        nuc = torch.bincount(c, minlength=5)[:4]
+        tot = torch.zeros(3, dtype=torch.int64, device=dev)
+        for k, t in tables.items():
+            m = nb - k + 1
+            if m <= 0:
+                continue
+            code = torch.zeros(m, dtype=torch.int64, device=dev)
+            bad = torch.zeros(m, dtype=torch.bool, device=dev)
+            for i in range(k):
+                ci_ = c[i:i + m]
+                code += (ci_ & 3) << (2 * i)
+                bad |= ci_ == 4
+            for f in range(3):
+                tot[f] += (t[f][code] & ~bad).sum()
+        nwin = -(-nb // step)
+        assert (cnt[ci].n_windows, cnt[ci].n_matches, cnt[ci].n_forward, cnt[ci].n_canonical) == (nwin, int(tot[0]), int(tot[1]), int(tot[2])), \
+            "contig %d: counts %s against the independent %s" % (ci, (cnt[ci].n_windows, cnt[ci].n_matches, cnt[ci].n_forward, cnt[ci].n_canonical), (nwin, tot.tolist()))
+        w = np.ctypeslib.as_array(C.cast(out[ci].windows, C.POINTER(C.c_uint8)), shape=(nwin * C.sizeof(K.Window),)).view(
+            np.dtype({"names": ["nuc"], "formats": [(np.uint32, 4)], "offsets": [K.Window.nucleotide_counts.offset], "itemsize": C.sizeof(K.Window)}))["nuc"]
+        got = w[0::2].sum(axis=0, dtype=np.int64)                    # records are A C G T; codes A C T G
+        assert got[[0, 1, 3, 2]].tolist() == nuc.tolist(), "contig %d: nucleotide totals" % ci
+        del c
+    assert kmax >= 6
+    L.ts_free_segments(out, n)
