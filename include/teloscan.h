@@ -487,8 +487,9 @@ int ts_shards_finalize(const ts_batch *plan, const void *const *msgs, const uint
  *      shard's message over its OWN PCIe link; the host merges (ts_shards_finalize).  Replaces the reference's one job
  *      per path + merge under a mutex (src/input.cpp:719-733, :1036-1037).  out[i].matches holds the VISIBLE records
  *      only (see above); counts may be NULL.  Contexts must have been created with the same parameters and patterns and
- *      may share a device.  Parameter sets outside the tiled kernel, and inputs for which the shards' assumptions fail,
- *      run on ctxs[0] alone (same results). */
+ *      may share a device.  Parameter sets outside the tiled kernel have no shard results: their segments are dealt WHOLE to the
+ *      contexts, in consecutive runs of equal bases (the reference's one job per path); inputs for which the shards' assumptions
+ *      fail run on ctxs[0] alone (same results). */
 int ts_scan_segments_multi(ts_ctx *const *ctxs, size_t n_ctx, const ts_segment_in *segs, size_t n_segs,
                            ts_segment_out *out, ts_segment_counts *counts);
 

@@ -140,17 +140,45 @@ extern "C" int ts_scan_segments_multi(ts_ctx *const *ctxs, size_t n_ctx, const t
     std::vector<std::unique_lock<std::mutex>> locks;
     for (ts_ctx *c : order) locks.emplace_back(c->api_mtx);
 
-    // everything on the first context alone: the single-device pipeline, reduced to the same view
-    auto single = [&](const std::vector<size_t> &which) -> int {
-        if (which.empty()) return TS_OK;
-        std::vector<ts_segment_in> in(which.size());
-        std::vector<ts_segment_out> tmp(which.size());
-        std::vector<ts_segment_counts> cnt(which.size());
-        for (size_t i = 0; i < which.size(); ++i) in[i] = segs[which[i]];
-        int rc = ts_scan_segments_unlocked(c0, in.data(), in.size(), tmp.data());
+    // segments [a, z) of `which` on one context alone: the single-device pipeline, reduced to the same view
+    auto on_ctx = [&](ts_ctx *c, const std::vector<size_t> &which, size_t a, size_t z) -> int {
+        if (z <= a) return TS_OK;
+        std::vector<ts_segment_in> in(z - a);
+        std::vector<ts_segment_out> tmp(z - a);
+        std::vector<ts_segment_counts> cnt(z - a);
+        for (size_t i = a; i < z; ++i) in[i - a] = segs[which[i]];
+        int rc = ts_scan_segments_unlocked(c, in.data(), in.size(), tmp.data());
         if (rc != TS_OK) return rc;
         keep_visible(in.data(), in.size(), tmp.data(), cnt.data());
-        for (size_t i = 0; i < which.size(); ++i) { out[which[i]] = tmp[i]; if (counts) counts[which[i]] = cnt[i]; }
+        for (size_t i = a; i < z; ++i) { out[which[i]] = tmp[i - a]; if (counts) counts[which[i]] = cnt[i - a]; }
+        return TS_OK;
+    };
+    // everything on the first context alone
+    auto single = [&](const std::vector<size_t> &which) -> int { return on_ctx(c0, which, 0, which.size()); };
+    // Parameter sets outside the tiled kernel (the general kernels have no shard results): whole segments dealt to the contexts
+    // in consecutive runs of equal bases — the reference's own decomposition, one job per path (src/input.cpp:719-724) —
+    // one host thread per context, results in input order.
+    auto whole_segments = [&](const std::vector<size_t> &which) -> int {
+        if (n_ctx == 1 || which.size() < 2) return single(which);
+        uint64_t total = 0;
+        for (size_t i : which) total += segs[i].len;
+        std::vector<size_t> cut(n_ctx + 1, which.size());
+        cut[0] = 0;
+        {
+            uint64_t acc = 0;
+            size_t d = 1;
+            for (size_t i = 0; i < which.size() && d < n_ctx; ++i) {
+                acc += segs[which[i]].len;
+                while (d < n_ctx && (unsigned __int128)acc * n_ctx >= (unsigned __int128)total * d) cut[d++] = i + 1;
+            }
+        }
+        std::vector<int> rcs(n_ctx, TS_OK);
+        std::vector<std::thread> pool;
+        for (size_t d = 0; d < n_ctx; ++d)
+            pool.emplace_back([&, d] { rcs[d] = on_ctx(ctxs[d], which, cut[d], cut[d + 1]); });
+        for (std::thread &th : pool) th.join();
+        for (size_t d = 0; d < n_ctx; ++d)
+            if (rcs[d] != TS_OK) return d == 0 ? rcs[d] : c0->fail(rcs[d], "context " + std::to_string(d) + ": " + ts_last_error(ctxs[d]));
         return TS_OK;
     };
 
@@ -162,7 +190,7 @@ extern "C" int ts_scan_segments_multi(ts_ctx *const *ctxs, size_t n_ctx, const t
         if (which.empty()) continue;
         std::string why;
         const bool tiled = mode ? c0->fast_ok : ts_full_scan_supported(c0, why);
-        if (!tiled) { rc = single(which); continue; }
+        if (!tiled) { rc = whole_segments(which); continue; }
         std::vector<uint64_t> lens(which.size()), abs(which.size());
         std::vector<ts_segment_in> in(which.size());
         for (size_t i = 0; i < which.size(); ++i) { in[i] = segs[which[i]]; lens[i] = in[i].len; abs[i] = in[i].abs_pos; }

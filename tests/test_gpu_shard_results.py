@@ -317,13 +317,15 @@ def test_message_overflow_is_reported_and_a_larger_scale_fixes_it():
 
 def test_scan_segments_multi_equals_oracle():
     """ts_scan_segments_multi over 1, 2 and 3 contexts (sharing this GPU): per segment == oracle, full scans and
-    tips-only segments mixed in one call; a parameter set outside the tiled kernel takes the single-context path."""
+    tips-only segments mixed in one call; parameter sets outside the tiled kernel (a mixed-length set, a nine-length one) have their
+    segments dealt whole to the contexts."""
     import teloscope_amd as ta
     from teloscope_amd import _capi as K
     from teloscope_amd.cli import parse_cli, user_input
     L = K.lib()
     rng = np.random.default_rng(77)
-    for cli in (HEADLINE + " -t 3000", "-r -g -i", "-p TTAGGG,TTAGG -r -i -w 1000 -s 500"):
+    for cli in (HEADLINE + " -t 3000", "-r -g -i", "-p TTAGGG,TTAGG -r -i -w 1000 -s 500",
+                "-x 0 -p TTAG,TTAGG,TTAGGG,TTTAGGG,TTTTAGGG,TTAGGGTTA,TTAGGGTTAG,TTAGGGTTAGG,TTAGGGTTAGGG -g -i -w 1000 -s 500"):
         opts = parse_cli("x.fa " + cli)
         tels = [ta.Teloscope(user_input(opts, device=0)) for _ in range(3)]
         lens = [400_000, 0, 33, 150_000, 20_000, 600_001, 90_000]
