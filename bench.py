@@ -1083,6 +1083,15 @@ def run_scan(args, rank, local_rank, world, dev, backend):
                          "kernel": "ts_scan_tiles" + (" (rank 0's range)" if strong else ""), "kernel_ms": round(kern_ms, 4),
                          "launches_timed": launches, "algorithmic_bytes": alg_bytes},
         }
+        if world == 1 and not os.environ.get("TS_BENCH_NO_BOX_PROBE"):
+            # what THIS box issues and streams (ts_box_probe: hand-written independent integer instructions at four waves per SIMD;
+            # a 1 GiB copy), measured right after the timed steps: boxes of this pool differ by up to 7 % (profiles/r04/
+            # bench_default_slower_box.json against rocprof_summary_r04_scan_tiles.txt, same kernel hash), and the scan is bound by
+            # instruction issue — frac moves with the first figure, not with the kernel
+            vi, cb = C.c_double(0), C.c_double(0)
+            if L.ts_box_probe(tel._ctx.ptr, C.byref(vi), C.byref(cb)) == 0:
+                out["roofline"]["box"] = {"valu_wave_instr_per_ns": round(vi.value, 1), "copy_read_plus_write_gbs": round(cb.value, 1),
+                                          "note": "device-wide issue rate of independent v_and_b32 at 4 waves per SIMD; 16-byte grid-strided copy of 1 GiB"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, opts, buf, offsets, lens)
         if args.verify and sharded is not None:

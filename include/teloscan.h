@@ -226,6 +226,10 @@ void    ts_destroy(ts_ctx *ctx);
  * 0 if on the general kernels (mixed-length sets, k > 9, or a longest pattern exceeding
  * min(step, window-step), where the reference's start-index arithmetic wraps). */
 int     ts_uses_fast_path(const ts_ctx *ctx);
+/* Measurement aid (no counterpart in the reference): what THIS device issues — wave-instructions per ns of hand-written
+ * independent integer instructions at four waves per SIMD — and streams — read + write bytes per ns of a 1 GiB copy —, so that
+ * a benchmark line from a box that runs everything a few per cent slower can be told from a slower kernel (bench.py: roofline.box). */
+int     ts_box_probe(ts_ctx *ctx, double *valu_wave_instr_per_ns, double *copy_bytes_per_ns);
 /* 1 if segments of this kind (full scan / tips-only) may come as TS_INPUT_TEXT_PIECES or TS_INPUT_PACKED2: every parameter
  * set the library scans (until ABI 3 the general kernels wanted the bases joined). */
 int     ts_takes_text_input(const ts_ctx *ctx, int tips_only);

@@ -174,7 +174,7 @@ SYMBOLS = [
     "ts_batch_shard_info", "ts_batch_restrict_shard", "ts_batch_set_shard_scale", "ts_batch_pack_shard",
     "ts_shard_peek", "ts_shards_finalize", "ts_scan_segments_multi", "ts_batch_read_pass_status", "ts_pack_bases",
     "ts_batch_set_emit", "ts_exchange_unique_id", "ts_exchange_last_error", "ts_exchange_create", "ts_exchange_destroy",
-    "ts_exchange_gather",
+    "ts_exchange_gather", "ts_box_probe",
 ]
 
 
@@ -305,6 +305,7 @@ def lib():
                                      C.POINTER(SegmentOut), C.POINTER(SegmentCounts)]
     L.ts_scan_segments_multi.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(SegmentIn), C.c_size_t,
                                          C.POINTER(SegmentOut), C.POINTER(SegmentCounts)]
+    L.ts_box_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ts_exchange_unique_id.argtypes = [C.c_void_p]
     L.ts_exchange_last_error.restype = C.c_char_p
     L.ts_exchange_create.restype = C.c_void_p

@@ -780,6 +780,21 @@ int ts_bind_thread_to_device(const ts_ctx *ctx) {
     return 0;
 }
 
+// Box calibration for measurements (bench.py's roofline.box): what this device issues (wave-instructions per ns, hand-written
+// independent v_and_b32 at four waves per SIMD) and streams (read + write bytes per ns of a 16-byte grid-strided copy of 1 GiB).
+int ts_box_probe(ts_ctx *ctx, double *valu_wave_instr_per_ns, double *copy_bytes_per_ns) {
+    if (!ctx || !valu_wave_instr_per_ns || !copy_bytes_per_ns) return TS_ERR_INVALID_ARG;
+    DEVICE_TRY(ctx);
+    const unsigned long long bytes = 1ull << 30;
+    DevBuf scratch;
+    HIP_TRY(ctx, ctx->pool.take((size_t)(2 * bytes), scratch));
+    struct Return { ts_ctx *c; DevBuf &a; ~Return() { c->pool.give(std::move(a)); } } give_back{ctx, scratch};
+    HIP_TRY(ctx, hipMemset(scratch.p, 0x41, (size_t)bytes));
+    const int e = ts_k_box_probe(scratch.p, bytes, ctx->num_cu, valu_wave_instr_per_ns, copy_bytes_per_ns, nullptr);
+    if (e != 0) return ctx->fail(TS_ERR_HIP, "box probe failed");
+    return TS_OK;
+}
+
 int ts_takes_text_input(const ts_ctx *ctx, int tips_only) {
     // (round 4: the general path stages its groups through the same upload as the tiled path — every format, every set)
     std::string why;

@@ -170,3 +170,61 @@ int ts_k_launch_widen_u16(const uint16_t *src, uint32_t *dst, unsigned long long
     hipLaunchKernelGGL(ts_widen_u16, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     return (int)hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Box calibration (bench.py: roofline.box): what THIS device issues and streams, measured the same way on every box, so that a
+// bench line from a box that runs everything a few per cent slower (power cap, clocks) can be told from a slower kernel.
+//   issue probe  every SIMD holds four waves that each execute `iters` x 64 independent v_and_b32 (hand-written, nothing to
+//                fuse or reorder): wave-instructions per nanosecond over the whole device;
+//   copy probe   a grid-strided 16-byte copy of `bytes`: read + write bytes per nanosecond.
+namespace {
+#define TS_V8_AND "v_and_b32 %0, %8, %0\n v_and_b32 %1, %8, %1\n v_and_b32 %2, %8, %2\n v_and_b32 %3, %8, %3\n" \
+                  "v_and_b32 %4, %8, %4\n v_and_b32 %5, %8, %5\n v_and_b32 %6, %8, %6\n v_and_b32 %7, %8, %7\n"
+__global__ __launch_bounds__(256) void ts_issue_probe(uint32_t *out, int iters, uint32_t seed) {
+    uint32_t a0 = seed * threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const uint32_t s = seed | 0xFFFF0000u;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            asm volatile(TS_V8_AND : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(s));
+    }
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345u) out[0] = a0;        // (never true: keeps the chain alive)
+}
+__global__ __launch_bounds__(256) void ts_copy_probe(const uint4 *src, uint4 *dst, unsigned long long n16) {
+    for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256ull) dst[i] = src[i];
+}
+}  // namespace
+
+// issue_per_ns / copy_bytes_per_ns: best of five launches each.  scratch: device memory of 2 x bytes (bytes a multiple of 16).
+int ts_k_box_probe(void *scratch, unsigned long long bytes, int num_cu, double *issue_per_ns, double *copy_bytes_per_ns, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipGetLastError();
+    const int iters = 4000;
+    const unsigned grid = (unsigned)(num_cu > 0 ? num_cu : 256) * 4u;             // 4 workgroups of 4 waves per CU: four waves per SIMD
+    double best_issue = 0, best_copy = 0;
+    for (int r = 0; r < 6; ++r) {
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(ts_issue_probe, dim3(grid), dim3(256), 0, st, (uint32_t *)scratch, iters, 0x9E3779B9u);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) return (int)hipGetLastError();
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        const double instr = (double)grid * 4.0 * iters * 64.0;                   // waves x iterations x 64 instructions
+        if (r && ms > 0 && instr / (ms * 1e6) > best_issue) best_issue = instr / (ms * 1e6);
+    }
+    const unsigned long long n16 = bytes / 16u;
+    for (int r = 0; r < 6 && n16; ++r) {
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(ts_copy_probe, dim3(grid * 4u), dim3(256), 0, st, (const uint4 *)scratch, (uint4 *)((char *)scratch + bytes), n16);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) return (int)hipGetLastError();
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r && ms > 0 && 2.0 * (double)bytes / (ms * 1e6) > best_copy) best_copy = 2.0 * (double)bytes / (ms * 1e6);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *issue_per_ns = best_issue; *copy_bytes_per_ns = best_copy;
+    return (int)hipGetLastError();
+}
