@@ -1085,9 +1085,9 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         }
         if world == 1 and not os.environ.get("TS_BENCH_NO_BOX_PROBE"):
             # what THIS box issues and streams (ts_box_probe: hand-written independent integer instructions at four waves per SIMD;
-            # a 1 GiB copy), measured right after the timed steps: boxes of this pool differ by up to 7 % (profiles/r04/
-            # bench_default_slower_box.json against rocprof_summary_r04_scan_tiles.txt, same kernel hash), and the scan is bound by
-            # instruction issue — frac moves with the first figure, not with the kernel
+            # a 1 GiB copy), measured right after the timed steps, for context: the boxes of this pool differ by up to 7 % on one
+            # kernel hash (0.705 .. 0.758 ms per step).  The short probes do not explain that spread (0.720 / 0.727 / 0.739 / 0.758 ms
+            # at 580 / 567 / 585 / 583 wave-instructions per ns): they say what a plain copy moves on the box — 4.65-4.78 TB/s
             vi, cb = C.c_double(0), C.c_double(0)
             if L.ts_box_probe(tel._ctx.ptr, C.byref(vi), C.byref(cb)) == 0:
                 out["roofline"]["box"] = {"valu_wave_instr_per_ns": round(vi.value, 1), "copy_read_plus_write_gbs": round(cb.value, 1),
