@@ -423,6 +423,7 @@ WIDE_GRID = [
     "-x 0 -p A,AA,AAA,AAAA,AAAAA,AAAAAA,AAAAAAA,AAAAAAAA,AAAAAAAAA,AAAAAAAAAA -w 100 -s 50 -g -i -l 20",   # every length matches inside a run
     "-x 0 -p " + ",".join(("TTAGGG" * 7)[:k] for k in range(4, 21)) + " -w 1000 -s 500 -g -r -i",     # 17 lengths: the 32-bit masks
     "-x 0 -p " + ",".join(("TTAGGG" * 7)[:k] for k in range(3, 36)) + " -w 600 -s 600 -g -i",          # 33 lengths: the 64-bit masks
+    "-p " + ("TTAGGG" * 7)[:40] + " -x 2 -t 700",                                    # 14 k patterns of 40 bases: the lists stay in device memory
 ]
 
 
