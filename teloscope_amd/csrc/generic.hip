@@ -33,7 +33,7 @@ typedef unsigned long long u64;
 
 constexpr uint32_t kTile = TS_GENERAL_TILE;           // positions per tile
 constexpr uint32_t kHalo = 32;                        // bases staged beyond it (longest pattern <= 32)
-constexpr uint32_t kMaxLdsPatterns = 2048;
+constexpr uint32_t kMaxLdsPatterns = 4096;       // (9 bytes of LDS each: the list form then keeps three workgroups per CU)
 
 // nuc: the A C T G (code order) counts of a lane as four 8-bit fields (a lane visits at most 4096 / 64 positions of a tile:
 // no field overflows) — indexed by a shift, where an array indexed by the code went to scratch memory (6 GB of write

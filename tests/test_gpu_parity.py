@@ -381,7 +381,8 @@ GENERIC_GRID = [
     "-c TTAGGGTTAGGGTTAGGGTTAGGGTTAGGGTT -x 0 -w 1000 -s 500 -r -g -e -i",     # k = 32, the longest pattern taken
     "-c TTAGGGTTAGGGTTAGGGTTAGGGTTAGGGT -x 1 -t 2000",    # k = 31 with one mismatch (94 patterns), tips only
     "-p TTAGGG,TTAGGGTTAGGGTTAGGGTTAGGGTTAGGGTT -x 0 -w 2000 -s 1000 -r -g -i",   # lengths 6 and 32 in one set
-    "-c TTAGGGTTAGGGTTAGGGTT -x 2 -w 1000 -s 500 -g -i",  # k = 20 with two mismatches: 3 500 patterns, more than the lists' LDS holds (strided form, lists in device memory)
+    "-c TTAGGGTTAGGGTTAGGGTT -x 2 -w 1000 -s 500 -g -i",  # k = 20 with two mismatches: 3 500 patterns in LDS (list form)
+    "-c TTAGGGTTAGGGTTAGGGTTAGGG -x 2 -w 1000 -s 500 -g -i",   # k = 24: 5 100 patterns, more than the lists' LDS holds (strided form, lists in device memory)
 ]
 
 
