@@ -148,17 +148,31 @@ def test_output_files_do_not_depend_on_the_number_of_devices(cli, tmp_path, flag
             assert outs[devices][1][sfx] == ref[1][sfx], (devices, sfx)
 
 
-@pytest.mark.gpu
-def test_cpp_rank_program_scans_packs_and_gathers_over_rccl(tmp_path):
-    """tests/cpp/rank_scan.cpp: one rank of a sharded scan written against the C-ABI alone (plan, shard, scan, pack,
-    ts_exchange_gather over RCCL, ts_shards_finalize), run here as the only rank — its message loops back through RCCL — and
-    compared inside the program with the whole-batch result of ts_scan_segments_blocks."""
+def _build_rank_scan(tmp_path):
     import teloscope_amd  # noqa: F401
     exe = tmp_path / "rank_scan"
     libdir = os.path.join(ROOT, "teloscope_amd")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "rank_scan.cpp"), "-L", libdir, "-lteloscan",
                            "-Wl,-rpath," + libdir, "-pthread", "-o", str(exe)])
+    return exe
+
+
+def test_cpp_rank_program_builds_and_refuses_without_gpu(tmp_path):
+    from teloscope_amd import _capi as K
+    if K.lib().ts_device_count() > 0:
+        pytest.skip("a GPU is present")
+    exe = _build_rank_scan(tmp_path)
+    r = subprocess.run([str(exe), "--rank", "0", "--ranks", "1", "--id-file", str(tmp_path / "id")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr and r.stdout == ""
+
+
+@pytest.mark.gpu
+def test_cpp_rank_program_scans_packs_and_gathers_over_rccl(tmp_path):
+    """tests/cpp/rank_scan.cpp: one rank of a sharded scan written against the C-ABI alone (plan, shard, scan, pack,
+    ts_exchange_gather over RCCL, ts_shards_finalize), run here as the only rank — its message loops back through RCCL — and
+    compared inside the program with the whole-batch result of ts_scan_segments_blocks."""
+    exe = _build_rank_scan(tmp_path)
     r = subprocess.run([str(exe), "--rank", "0", "--ranks", "1", "--id-file", str(tmp_path / "id"), "--mbases", "60"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rank_scan ok: 1 rank(s)" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-600:])
