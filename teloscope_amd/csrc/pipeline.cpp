@@ -917,6 +917,10 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     // host only.  TS_GEN_HOST_BLOCKS=1 forces the host path (A/B, tests).
     const bool dev_blocks_ok = !(getenv("TS_GEN_HOST_BLOCKS") && getenv("TS_GEN_HOST_BLOCKS")[0] == '1') && c->gpat.nlen >= 1 &&
                                (tips || ov == 0 || c->gpat.len[c->gpat.nlen - 1] - c->gpat.len[0] <= 1u);
+    // is the stream in the reference's push order whatever the input?  (position order IS push order then)
+    const uint32_t len_spread = c->gen_wide ? (c->wide_lens.empty() ? 0u : c->wide_lens.back() - c->wide_lens.front())
+                                            : (c->gpat.nlen ? c->gpat.len[c->gpat.nlen - 1] - c->gpat.len[0] : 0u);
+    const bool known_order = tips || ov == 0 || len_spread <= 1u;
     unsigned long long gen_lens = 0;
     for (uint32_t li = 0; li < c->gpat.nlen && li < 8u; ++li) gen_lens |= (unsigned long long)(c->gpat.len[li] & 63u) << (6u * li);
     if (c->gpat.nlen && c->gpat.len[c->gpat.nlen - 1] > 63u) gen_lens = 0;
@@ -1173,7 +1177,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         // ---- host: records -> MatchInfo in the reference's push order, then block calling; one job per segment
         if (host_job.joinable()) host_job.join();                     // (one host stage at a time: it takes all the host threads)
         if (host_err.load() != TS_OK) return host_err.load();
-        host_job = std::thread([c, gh, ns, tips, s, w, ov, out, counts, skip_records, timing, wide, rec_shift, rec_li_mask, &host_err, &t_host]() {
+        host_job = std::thread([c, gh, ns, tips, s, w, ov, out, counts, skip_records, timing, wide, rec_shift, rec_li_mask, known_order, &host_err, &t_host]() {
         const auto th0 = Clock::now();
         const std::vector<SegL> &G = gh->G;
         const std::vector<TsGeneralTile> &tiles = gh->tiles;
@@ -1226,9 +1230,13 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 const auto tw0 = Clock::now();
                 std::vector<char> part_sorted(nth, 1);
                 std::vector<uint64_t> first_key(nth, 0), last_key(nth, 0);
+                // (a stream that is in the reference's push order by construction — tips-only scans, w == s, pattern lengths that
+                // differ by at most one: what device block calling relies on as well — is not checked at all)
+                const bool check_order = !tips && !known_order;
+                const uint64_t head_end = std::min<uint64_t>(w, sl.len);
                 auto expand = [&](unsigned q) {
-                    bool ok = true, any = false;
-                    uint64_t prev_k = 0;
+                    bool ok = true, any = false, have_base = false;
+                    uint64_t prev_k = 0, cur_k = 0, cur_base = 0;
                     for (uint64_t t = cut[q]; t < cut[q + 1]; ++t) {
                         const TsGeneralTile &T = tiles[sl.first_tile + t];
                         uint64_t at = tile_off[sl.first_tile + t] - r0;
@@ -1241,8 +1249,18 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                             m.position = sl.abs_pos + p;
                             m.match_size = (uint16_t)len;
                             m.flags = (uint8_t)(((rec & 1u) ? TS_MATCH_FORWARD : 0u) | ((rec & 2u) ? TS_MATCH_CANONICAL : 0u));   // (general records: forward is bit 0)
-                            if (!tips) {
-                                const uint64_t k = push_window(p, len);
+                            if (check_order) {
+                                // the pushing window without a division per record: the stream is in position order, so the quotient
+                                // of the record before is at most a step or two away
+                                uint64_t k = 0;
+                                const uint64_t e = p + len - 1;
+                                if (ov == 0 || e >= head_end) {
+                                    const uint64_t x = ov == 0 ? p : e - ov;
+                                    if (!have_base) { cur_k = x / s; cur_base = cur_k * s; have_base = true; }
+                                    while (x >= cur_base + s) { ++cur_k; cur_base += s; }
+                                    while (x < cur_base) { --cur_k; cur_base -= s; }
+                                    k = cur_k;
+                                }
                                 if (!any) { first_key[q] = k; any = true; }
                                 else if (k < prev_k) ok = false;
                                 prev_k = k;
