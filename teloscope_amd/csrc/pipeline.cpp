@@ -1368,9 +1368,14 @@ int scan_subset(ts_ctx *ctx, Mode mode, const ts_segment_in *segs, const std::ve
 // the general kernels run one call at a time (their groups are not merged across callers)
 int generic_locked(ts_ctx *ctx, const ts_segment_in *segs, const std::vector<size_t> &which, bool tips, ts_segment_out *out, bool have_lock,
                    bool blocks_only = false, ts_segment_counts *counts = nullptr) {
-    if (have_lock) return scan_group_generic(ctx, segs, which, tips, out, blocks_only, counts);
-    std::lock_guard<std::mutex> api(ctx->api_mtx);
-    return scan_group_generic(ctx, segs, which, tips, out, blocks_only, counts);
+    // (an exception — std::bad_alloc while a multi-GB group is planned — must leave as an error code: this is a C boundary)
+    try {
+        if (have_lock) return scan_group_generic(ctx, segs, which, tips, out, blocks_only, counts);
+        std::lock_guard<std::mutex> api(ctx->api_mtx);
+        return scan_group_generic(ctx, segs, which, tips, out, blocks_only, counts);
+    } catch (const std::exception &e) {
+        return ctx->fail(TS_ERR_ALLOC, std::string("general path: ") + e.what());
+    }
 }
 
 // ts_scan_segments; have_lock: the caller holds the context's call lock (ts_filter_reads's general path, ts_scan_segments_multi)
