@@ -1178,6 +1178,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         if (host_job.joinable()) host_job.join();                     // (one host stage at a time: it takes all the host threads)
         if (host_err.load() != TS_OK) return host_err.load();
         host_job = std::thread([c, gh, ns, tips, s, w, ov, out, counts, skip_records, timing, wide, rec_shift, rec_li_mask, known_order, &host_err, &t_host]() {
+        try {
         const auto th0 = Clock::now();
         const std::vector<SegL> &G = gh->G;
         const std::vector<TsGeneralTile> &tiles = gh->tiles;
@@ -1322,6 +1323,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         }
         if (first_err.load() != TS_OK) { int e = TS_OK; host_err.compare_exchange_strong(e, first_err.load()); }
         t_host += ms_between(th0, Clock::now());
+        } catch (...) { int e = TS_OK; host_err.compare_exchange_strong(e, c->fail(TS_ERR_ALLOC, "general path: the host stage ran out of memory")); }
         });
         // ---- next group: already uploaded by the prefetch thread (or planned and uploaded here)
         const auto t_w = Clock::now();
