@@ -80,15 +80,27 @@ def pack_sequence(seq, fold_case):
     runs = []
     piece = 1 << 28                                                  # a multiple of 4: pieces start on byte boundaries
     buf = C.create_string_buffer(seq, n) if not isinstance(seq, (bytes, bytearray)) else seq
+    # the bases are handed over where they lie (no copy per piece)
+    if isinstance(buf, bytearray):
+        view = (C.c_char * n).from_buffer(buf)
+        base = C.addressof(view)
+    elif isinstance(buf, bytes):
+        base = C.cast(C.c_char_p(buf), C.c_void_p).value or 0
+    else:
+        base = C.addressof(buf)
     for a in range(0, n, piece):
         m = min(piece, n - a)
-        cap = m + 1
-        rr = np.zeros((cap, 2), dtype=np.uint32)
-        nr = C.c_uint64(0)
-        rc = lib().ts_pack_bases(bytes(buf[a:a + m]), m, int(bool(fold_case)), C.c_void_p(codes.ctypes.data + a // 4),
-                                 C.c_void_p(rr.ctypes.data), cap, C.byref(nr))
-        if rc != TS_OK:
-            raise TeloscanError(rc, "ts_pack_bases failed")
+        cap = 1 << 16                                                # runs are rare: start small, grow to what the call reports
+        while True:
+            rr = np.empty((cap, 2), dtype=np.uint32)
+            nr = C.c_uint64(0)
+            rc = lib().ts_pack_bases(C.cast(C.c_void_p(base + a), C.c_char_p), m, int(bool(fold_case)),
+                                     C.c_void_p(codes.ctypes.data + a // 4), C.c_void_p(rr.ctypes.data), cap, C.byref(nr))
+            if rc == TS_OK:
+                break
+            if int(nr.value) <= cap:                                 # (more runs than `cap` is the one failure worth a retry)
+                raise TeloscanError(rc, "ts_pack_bases failed")
+            cap = int(nr.value) + 16
         for s0, ln in rr[:int(nr.value)]:
             if runs and runs[-1][0] + runs[-1][1] == a + int(s0):
                 runs[-1][1] += int(ln)

@@ -786,9 +786,9 @@ int ts_box_probe(ts_ctx *ctx, double *valu_wave_instr_per_ns, double *copy_bytes
     if (!ctx || !valu_wave_instr_per_ns || !copy_bytes_per_ns) return TS_ERR_INVALID_ARG;
     DEVICE_TRY(ctx);
     const unsigned long long bytes = 1ull << 30;
-    DevBuf scratch;
-    HIP_TRY(ctx, ctx->pool.take((size_t)(2 * bytes), scratch));
-    struct Return { ts_ctx *c; DevBuf &a; ~Return() { c->pool.give(std::move(a)); } } give_back{ctx, scratch};
+    // (its own allocation, freed on return: handed to the context's pool the 2 GiB would stay held for the rest of the process)
+    struct Scratch { void *p = nullptr; ~Scratch() { if (p) (void)hipFree(p); } } scratch;
+    HIP_TRY(ctx, hipMalloc(&scratch.p, (size_t)(2 * bytes)));
     HIP_TRY(ctx, hipMemset(scratch.p, 0x41, (size_t)bytes));
     const int e = ts_k_box_probe(scratch.p, bytes, ctx->num_cu, valu_wave_instr_per_ns, copy_bytes_per_ns, nullptr);
     if (e != 0) return ctx->fail(TS_ERR_HIP, "box probe failed");

@@ -196,11 +196,16 @@ __global__ __launch_bounds__(256) void ts_copy_probe(const uint4 *src, uint4 *ds
 }
 }  // namespace
 
-// issue_per_ns / copy_bytes_per_ns: best of five launches each.  scratch: device memory of 2 x bytes (bytes a multiple of 16).
+// issue_per_ns / copy_bytes_per_ns: best of five launches each (six run, the first — a cold start — is not counted).
+// scratch: device memory of 2 x bytes (bytes a multiple of 16).
 int ts_k_box_probe(void *scratch, unsigned long long bytes, int num_cu, double *issue_per_ns, double *copy_bytes_per_ns, void *stream) {
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipGetLastError();
+    struct Events {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }      // on every return path
+    } ev;
+    if (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess) return (int)hipGetLastError();
+    hipEvent_t e0 = ev.e0, e1 = ev.e1;
     const int iters = 4000;
     const unsigned grid = (unsigned)(num_cu > 0 ? num_cu : 256) * 4u;             // 4 workgroups of 4 waves per CU: four waves per SIMD
     double best_issue = 0, best_copy = 0;
@@ -224,7 +229,6 @@ int ts_k_box_probe(void *scratch, unsigned long long bytes, int num_cu, double *
         (void)hipEventElapsedTime(&ms, e0, e1);
         if (r && ms > 0 && 2.0 * (double)bytes / (ms * 1e6) > best_copy) best_copy = 2.0 * (double)bytes / (ms * 1e6);
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *issue_per_ns = best_issue; *copy_bytes_per_ns = best_copy;
     return (int)hipGetLastError();
 }

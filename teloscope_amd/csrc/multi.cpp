@@ -175,7 +175,12 @@ extern "C" int ts_scan_segments_multi(ts_ctx *const *ctxs, size_t n_ctx, const t
         std::vector<int> rcs(n_ctx, TS_OK);
         std::vector<std::thread> pool;
         for (size_t d = 0; d < n_ctx; ++d)
-            pool.emplace_back([&, d] { rcs[d] = on_ctx(ctxs[d], which, cut[d], cut[d + 1]); });
+            pool.emplace_back([&, d] {
+                // (on_ctx allocates: an exception must not leave the thread — std::terminate across the C boundary)
+                try { rcs[d] = on_ctx(ctxs[d], which, cut[d], cut[d + 1]); }
+                catch (const std::bad_alloc &) { rcs[d] = ctxs[d]->fail(TS_ERR_ALLOC, "out of host memory"); }
+                catch (...) { rcs[d] = ctxs[d]->fail(TS_ERR_ALLOC, "exception in a context's scan thread"); }
+            });
         for (std::thread &th : pool) th.join();
         for (size_t d = 0; d < n_ctx; ++d)
             if (rcs[d] != TS_OK) return d == 0 ? rcs[d] : c0->fail(rcs[d], "context " + std::to_string(d) + ": " + ts_last_error(ctxs[d]));

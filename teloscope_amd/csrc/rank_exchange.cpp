@@ -41,11 +41,18 @@ Rccl &rccl() {
     static Rccl R;
     static std::once_flag once;
     std::call_once(once, [] {
+        // TS_RCCL_LIB names the library instead of the usual places (a site's own build; the tests point it at a file that
+        // does not exist to reach the path below without uninstalling RCCL)
+        const char *forced = getenv("TS_RCCL_LIB");
+        std::string last;
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            R.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            R.lib = dlopen(forced && forced[0] ? forced : name, RTLD_NOW | RTLD_LOCAL);
             if (R.lib) break;
+            const char *e = dlerror();               // (read ONCE: the call clears the error, a second one returns NULL)
+            last = e ? e : "dlopen failed";
+            if (forced && forced[0]) break;
         }
-        if (!R.lib) { R.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
+        if (!R.lib) { R.why = "librccl not found: " + last; return; }
         auto sym = [&](const char *n) -> void * {
             void *p = dlsym(R.lib, n);
             if (!p && R.why.empty()) R.why = std::string("librccl lacks ") + n;

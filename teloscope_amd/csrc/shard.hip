@@ -120,6 +120,10 @@ void ts_shard_copy_visible(const TsShardPackParams P, const u64 *vis_off, u64 ca
         const uint2 where = *(const uint2 *)&P.chain[4ull * t + 2u];
         src0 = ((u64)where.y << 32) | where.x;
         dst0 = vis_off[i];
+        // A wave whose visible region overflowed in the scan (wave_fill[nwaves + w] > vis_cap; ts_overflow_flag reports it and the
+        // caller rescans) did not store the records it promises here: src0 = wave * vis_cap + the wave's cursor, and a cursor past
+        // the region's end would be read out of the next waves' regions — for the last waves, past the end of vis_src.
+        if (P.vis_cap == 0u || (src0 % P.vis_cap) + n > P.vis_cap) n = 0;
     }
     if (vis_off[nown] > capacity) return;                     // does not fit: nothing is written, the header reports it
     if (n <= kVisOwn) {

@@ -162,6 +162,28 @@ def test_rank_exchange_needs_a_device_and_sane_arguments(ta):
     L.ts_exchange_destroy(None)
 
 
+def test_rank_exchange_without_librccl_is_unsupported_not_a_crash():
+    """A host without librccl: ts_exchange_unique_id answers TS_ERR_UNSUPPORTED and ts_exchange_last_error says which
+    library was missing (include/teloscan.h promises exactly that).  TS_RCCL_LIB points the run-time loader at a file that
+    does not exist; the library is opened once per process, hence the child process."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "from teloscope_amd import _capi as K\n"
+            "L = K.lib()\n"
+            "ident = (C.c_char * 128)()\n"
+            "rc = L.ts_exchange_unique_id(ident)\n"
+            "msg = L.ts_exchange_last_error().decode()\n"
+            "assert rc == K.TS_ERR_UNSUPPORTED, rc\n"
+            "assert 'librccl not found' in msg and 'no_such_rccl' in msg, msg\n"
+            "assert L.ts_exchange_unique_id(ident) == K.TS_ERR_UNSUPPORTED\n"
+            "print('ok')\n") % ROOT
+    env = dict(os.environ, TS_RCCL_LIB="/nonexistent/libno_such_rccl.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
 def test_planner_tiling_choices(ta, monkeypatch):
     """plan_geometry's choice between one workgroup of 16 waves per CU and two of 10 (the 80-VGPR build of the scan kernel),
     read off the plan of a planning-only context (no GPU): windows per tile = what the chosen chunks per tile hold.  Two
