@@ -23,1711 +23,19 @@ this script itself (`python bench.py --gpus N` spawns N rank processes before an
 
   python bench.py --reads [--gpus N]        the read filter (configs[3]) instead of the assembly scan
 """
-import argparse
-import ctypes as C
-import json
 import os
-import socket
-import subprocess
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-# (HIP streams share the runtime's hardware queues round-robin — 4 by default, GPU_MAX_HW_QUEUES — and kernels of two streams
-# that landed on one queue run one after the other.  With a side stream per batch a sharded step used seven streams and 8 queues
-# measured 0.174 against 0.197 ms at the N = 8 size (profiles/r04/hwq_sweep.txt); since the terminal walks of every batch share
-# the context's one side stream a step uses four, and 4 and 8 queues measure the same: the runtime's default is left alone.)
-
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-FLAGS = "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -x 1 -w 1000 -s 500 -r -g -e -m -i"
-LIB = os.path.join(ROOT, "teloscope_amd", "libteloscan.so")
-ORACLE = os.path.join(ROOT, "oracle", "libteloscope_oracle.so")
-
-
-def parse_args():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--verify", action="store_true",
-                    help="untimed full-size parity properties (independent torch computation; at N > 1 also "
-                         "bit-equality of the assembled arrays with a single-GPU scan of the whole assembly on rank 0)")
-    ap.add_argument("--blocks", action="store_true", help="also time device block calling (untimed in value)")
-    ap.add_argument("--no-e2e", action="store_true",
-                    help="skip the PCIe-inclusive leg (host buffers through the C-ABI entry points; never in value)")
-    ap.add_argument("--e2e", action="store_true", help="(kept for compatibility: the PCIe-inclusive leg is on by default at N = 1)")
-    ap.add_argument("--flags", default=FLAGS, help="Teloscope flags of the workload (default: configs[1])")
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--gbases", type=float, default=3.0, help="bases of the assembly (Gb); 3.0 = BASELINE config")
-    ap.add_argument("--contigs", type=int, default=200)
-    ap.add_argument("--full-exchange", action="store_true",
-                    help="N > 1: round 2's exchange (every window, directory entry and match record assembled on rank 0) instead of "
-                         "the shard results (blocks called per rank; packed windows, writer-visible records and blocks travel)")
-    ap.add_argument("--weak", action="store_true", help="N > 1: every rank scans its own --gbases assembly (weak scaling; "
-                                                          "only per-segment hit summaries are gathered)")
-    ap.add_argument("--no-reads", action="store_true", help="skip the `reads` sub-record of the default line (configs[3] at 500 k reads)")
-    ap.add_argument("--cpu-sample-mb", type=float, default=384.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--reads", action="store_true", help="benchmark the read filter (configs[3]) instead of the assembly scan")
-    ap.add_argument("--n-reads", type=float, default=5e6, help="--reads: reads filtered per step across all GPUs")
-    return ap.parse_args()
-
-
-def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def ensure_built():
-    """A fresh checkout has no built artefacts: build them BEFORE any GPU or torch.distributed call (hipcc, gcc;
-    the first local rank builds, the others wait for the files).  Nothing here is a fallback — without the HIP
-    library the import of teloscope_amd raises."""
-    if os.path.exists(LIB) and os.path.exists(ORACLE):
-        return
-    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-        import __graft_entry__ as entry
-        entry.build()
-        return
-    t0 = time.time()
-    while not (os.path.exists(LIB) and os.path.exists(ORACLE)):
-        if time.time() - t0 > 900:
-            raise RuntimeError("libteloscan.so was not built by local rank 0")
-        time.sleep(1.0)
-    time.sleep(2.0)                                            # let the linker finish writing
-
-
-def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (the parent makes no
-    GPU call).  Rank 0 writes the JSON line to our stdout; every rank's stderr is ours.  The first rank that fails takes
-    the others down with it (they would wait in a collective for ever), and its exit code is ours."""
-    ensure_built()
-    env = dict(os.environ)
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
-    procs = []
-    for r in range(n):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    live = set(range(n))
-    while live:
-        for r in sorted(live):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            live.discard(r)
-            if code != 0 and rc == 0:
-                rc = abs(code) or 1
-                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
-                for q in sorted(live):
-                    procs[q].terminate()
-        if live:
-            time.sleep(0.05)
-    return rc
-
-
-# ------------------------------------------------------------------------------------------- synthetic data
-def contig_lengths(total, n, seed):
-    import numpy as np
-    rng = np.random.default_rng(seed)
-    raw = np.exp(rng.uniform(np.log(1e6), np.log(250e6), size=n))
-    lens = np.maximum((raw * (total / raw.sum())).astype(np.int64), 20000)
-    lens[-1] += total - lens.sum()
-    return [int(x) for x in lens]
-
-
-def fill_synthetic(buf, offsets, lens, seed, dev):
-    """Random ACGT + telomeres/TVRs at both ends of every contig + ITS blocks + N-runs + soft-masking,
-    generated on the device (model of src/get-mock-chr.cpp:96-136).  Deterministic in (seed, lens): every rank
-    of a sharded run generates the same assembly."""
-    import numpy as np
-    import torch
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    chunk = 1 << 28
-    for a in range(0, buf.numel(), chunk):
-        b = min(buf.numel(), a + chunk)
-        idx = torch.randint(0, 4, (b - a,), dtype=torch.uint8, device=dev, generator=g)
-        buf[a:b] = lut[idx.long()]
-        m = torch.rand(b - a, device=dev, generator=g) < 0.001          # 0.1 % lower case
-        buf[a:b] |= (m.to(torch.uint8) << 5)
-        del idx, m
-    rng = np.random.default_rng(seed + 1)
-
-    def tract(unit, reps, rate):
-        t = np.tile(np.frombuffer(unit, dtype=np.uint8), reps).copy()
-        k = rng.random(len(t)) < rate
-        t[k] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(k.sum()))]
-        return torch.from_numpy(t).to(dev)
-
-    for off, n in zip(offsets, lens):
-        p = torch.cat([tract(b"CCCTAA", 2000, 0.0), tract(b"CCCTAA", 100, 1.0 / 6)])
-        q = torch.cat([tract(b"TTAGGG", 100, 1.0 / 6), tract(b"TTAGGG", 2000, 0.0)])
-        if len(p) + len(q) < n:
-            buf[off:off + len(p)] = p
-            buf[off + n - len(q):off + n] = q
-    n_its = 50
-    for _ in range(n_its):
-        ci = int(rng.integers(0, len(lens)))
-        ln = int(rng.integers(200, 2000)) // 6
-        unit = b"TTAGGG" if rng.random() < 0.5 else b"CCCTAA"
-        at = int(rng.integers(20000, max(20001, lens[ci] - 20000 - 6 * ln)))
-        t = tract(unit, ln, 0.02)
-        buf[offsets[ci] + at:offsets[ci] + at + len(t)] = t
-    for ci in rng.choice(len(lens), size=max(1, len(lens) // 100), replace=False):    # 1 % of contigs: an N-run
-        ln = int(rng.integers(100, 10001))
-        at = int(rng.integers(20000, max(20001, lens[ci] - 20000 - ln)))
-        buf[offsets[ci] + at:offsets[ci] + at + ln] = ord("N")
-
-
-def verify_full_size(L, batch, tel, buf, offsets, lens, ui, dev):
-    """Size-independent parity properties at the full bench size, with an INDEPENDENT computation
-    in torch (rolling 2-bit k-mer code + table lookup, nothing shared with the HIP kernels):
-      * per contig: matches / canonical / forward counts == ts_batch_segment_summary;
-      * per contig: A,C,G,T totals == sum of the nucleotide counts of the windows that tile the contig
-        (w = 2s: the even-indexed ones; w = s: all of them);
-      * w = s: matches straddling a window end are excluded, as the reference loses them.
-    `batch` holds the results (a scanned batch, or one that adopted the ranks' shards).
-    Returns a dict for the bench line; raises on any mismatch."""
-    import torch
-    from teloscope_amd import _capi as K
-    n = len(lens)
-    k = len(ui.patternInfo[0][0])
-    code_of = {"A": 0, "C": 1, "T": 2, "G": 3}
-    tbl = torch.zeros(3, 4 ** k, dtype=torch.bool)
-    for pat, fwd in ui.patternInfo:
-        x = sum(code_of[ch] << (2 * i) for i, ch in enumerate(pat))
-        tbl[0, x] = True
-        tbl[1, x] = bool(fwd)
-        tbl[2, x] = pat in (ui.canonicalFwd, ui.canonicalRev)
-    tbl = tbl.to(dev)
-    lut = torch.full((256,), 4, dtype=torch.int32)
-    for ch, c in code_of.items():
-        lut[ord(ch)] = c
-        lut[ord(ch.lower())] = c
-    lut = lut.to(dev)
-    summ = torch.zeros(n * 4, dtype=torch.int64, device=dev)
-    if L.ts_batch_segment_summary(batch, C.c_void_p(summ.data_ptr()), None) != 0:
-        raise RuntimeError(tel._ctx.error())
-    torch.cuda.synchronize()
-    summ = summ.view(n, 4).cpu().numpy()
-    info = K.BatchInfo()
-    L.ts_batch_get_info(batch, C.byref(info))
-    wins = torch.empty(int(info.n_windows) * 8, dtype=torch.int32, device=dev)
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    wp = L.ts_batch_windows_ptr(batch)
-    assert hip.hipMemcpy(C.c_void_p(wins.data_ptr()), C.c_void_p(wp), C.c_size_t(wins.numel() * 4), 3) == 0
-    wins = wins.view(-1, 8)
-    step, window = ui.step, ui.windowSize
-    assert window in (step, 2 * step), "--verify knows the window tilings of w = s and w = 2s"
-    stride = window // step                                  # every stride-th window: together they tile a contig
-    wbase = 0
-    chunk = 1 << 27
-    for ci in range(n):
-        nb, off = lens[ci], offsets[ci]
-        cnt = torch.zeros(3, dtype=torch.int64, device=dev)
-        nuc = torch.zeros(4, dtype=torch.int64, device=dev)
-        for a in range(0, nb, chunk):
-            b = min(nb, a + chunk + k - 1)
-            c = lut[buf[off + a:off + b].long()]
-            own = min(nb, a + chunk) - a
-            nuc += torch.bincount(c[:own], minlength=5)[:4]
-            m = b - a - k + 1
-            if m > 0:
-                code = torch.zeros(m, dtype=torch.int32, device=dev)
-                bad = torch.zeros(m, dtype=torch.bool, device=dev)
-                for i in range(k):
-                    ci_ = c[i:i + m]
-                    code += (ci_ & 3) << (2 * i)
-                    bad |= ci_ == 4
-                take = min(m, own)
-                code, bad = code[:take].long(), bad[:take]
-                if window == step:                           # w == s: a match that straddles a window end is lost
-                    pos = torch.arange(a, a + take, device=dev)
-                    bad = bad | ((pos % step) + k > step)
-                for f in range(3):
-                    cnt[f] += (tbl[f][code] & ~bad).sum()
-            del c
-        nwin = -(-nb // step)
-        w = wins[wbase:wbase + nwin]
-        wbase += nwin
-        got_nuc = w[0::stride, [0, 1, 3, 2]].sum(dim=0, dtype=torch.int64)  # records are A C G T; codes A C T G
-        assert summ[ci].tolist() == [nwin, int(cnt[0]), int(cnt[2]), int(cnt[1])], \
-            ("match counts differ on contig %d" % ci, summ[ci].tolist(), cnt.tolist())
-        assert got_nuc.tolist() == nuc.tolist(), ("nucleotide totals differ on contig %d" % ci)
-        cov = w[:, 4:8].sum(dim=0, dtype=torch.int64)                       # covered bases, each match in <= 2 windows
-        assert int(cov[0] + cov[1]) == int(cov[2] + cov[3])
-    # ---- per WINDOW, on a seeded sample: every field of the record recomputed from the bases with the same torch k-mer
-    # lookup — A/C/G/T over the window, and k x the matches that lie fully inside it, by kind (the closed form of
-    # analyzeWindow's carry loop, SURVEY 3.5; with w == s this is also the straddle rule).  Nothing of the oracle or of the
-    # HIP kernels is involved: the per-contig sums above cannot see a count that moved from one window to its neighbour.
-    import numpy as np
-    n_sample = int(os.environ.get("TS_VERIFY_WINDOWS", "10000"))
-    rng = np.random.default_rng(1234)
-    nwins = np.array([-(-nb // step) for nb in lens], dtype=np.int64)
-    wstart = np.concatenate([[0], np.cumsum(nwins)])
-    total_w = int(wstart[-1])
-    pick = np.unique(rng.integers(0, total_w, size=min(n_sample, total_w)))
-    # every contig's last window (the short tail) and first window are always in
-    pick = np.unique(np.concatenate([pick, wstart[:-1][nwins > 0], (wstart[1:] - 1)[nwins > 0]]))
-    ci_of = np.searchsorted(wstart, pick, side="right") - 1
-    widx = pick - wstart[ci_of]
-    starts = widx * step
-    sizes = np.minimum(window, np.array(lens, dtype=np.int64)[ci_of] - starts)
-    base_off = np.array(offsets, dtype=np.int64)[ci_of] + starts
-    span = window + k - 1
-    checked = 0
-    for a in range(0, len(pick), 2048):
-        z = min(len(pick), a + 2048)
-        bo = torch.as_tensor(base_off[a:z], device=dev).view(-1, 1)
-        sz = torch.as_tensor(sizes[a:z], device=dev).view(-1, 1)
-        col = torch.arange(span, device=dev).view(1, -1)
-        idx = torch.minimum(bo + col, torch.tensor(buf.numel() - 1, device=dev))
-        c = lut[buf[idx].long()]                                 # [m, span] codes, 4 = not A/C/G/T
-        inside = col < sz
-        want = torch.zeros(z - a, 8, dtype=torch.int64, device=dev)
-        for code_v, field in ((0, 0), (1, 1), (3, 2), (2, 3)):   # records are A C G T; codes A0 C1 T2 G3
-            want[:, field] = ((c == code_v) & inside).sum(dim=1)
-        code = torch.zeros(z - a, window, dtype=torch.int64, device=dev)
-        bad = torch.zeros(z - a, window, dtype=torch.bool, device=dev)
-        for i in range(k):
-            ci_ = c[:, i:i + window]
-            code += (ci_ & 3).long() << (2 * i)
-            bad |= ci_ == 4
-        fully = (col[:, :window] + k) <= sz                      # the match ends inside the window
-        hit = tbl[0][code] & ~bad & fully
-        is_fwd, is_can = tbl[1][code] & hit, tbl[2][code] & hit
-        want[:, 4] = k * is_can.sum(dim=1)
-        want[:, 5] = k * (hit & ~is_can).sum(dim=1)
-        want[:, 6] = k * is_fwd.sum(dim=1)
-        want[:, 7] = k * (hit & ~is_fwd).sum(dim=1)
-        got = wins[torch.as_tensor(pick[a:z], device=dev)].long()
-        if not torch.equal(got, want):
-            bad_row = int((got != want).any(dim=1).nonzero()[0])
-            raise AssertionError("window record differs from the independent recomputation: contig %d window %d: got %s want %s"
-                                 % (int(ci_of[a + bad_row]), int(widx[a + bad_row]), got[bad_row].tolist(), want[bad_row].tolist()))
-        checked += z - a
-    return {"contigs_checked": n, "matches_checked": int(summ[:, 1].sum()), "windows_checked_field_by_field": checked,
-            "properties": "per-contig match/canonical/forward counts vs independent torch k-mer lookup; "
-                          "A/C/G/T totals vs the sums of the windows that tile each contig; all eight fields of %d sampled "
-                          "window records (every contig's first and last window among them) vs the same lookup" % checked}
-
-
-def compare_sharded_with_single_gpu(L, K, tel, batch, sharded, n, with_matches):
-    """The merged shard results (ts_shards_finalize on rank 0) against the downloads of a single-GPU scan of the whole
-    assembly: window records and blocks byte for byte, the per-segment counts, and — when the assembly is small enough
-    to bring every match record to the host — the visible match records.  Raises on any difference."""
-    import numpy as np
-    seg_out, seg_cnt = sharded["seg_out"], sharded["seg_cnt"]
-    ref = (K.SegmentOut * n)()
-    rc = L.ts_batch_download(batch, None, ref) if with_matches else L.ts_batch_download_blocks(batch, ref)
-    if rc != 0:
-        raise RuntimeError(tel._ctx.error())
-
-    def raw(ptr, count, dt):
-        return np.frombuffer(C.string_at(C.cast(ptr, C.c_void_p), int(count) * dt.itemsize), dtype=np.uint8) if count else np.zeros(0, np.uint8)
-
-    nwin = nblk = nvis = 0
-    for i in range(n):
-        g, e = seg_out[i], ref[i]
-        assert g.n_windows == e.n_windows and np.array_equal(raw(g.windows, g.n_windows, K.WINDOW_DT), raw(e.windows, e.n_windows, K.WINDOW_DT)), ("windows", i)
-        assert g.n_terminal_blocks == e.n_terminal_blocks and g.n_interstitial_blocks == e.n_interstitial_blocks, ("block counts", i)
-        assert np.array_equal(raw(g.terminal_blocks, g.n_terminal_blocks, K.BLOCK_DT), raw(e.terminal_blocks, e.n_terminal_blocks, K.BLOCK_DT)), ("terminal blocks", i)
-        assert np.array_equal(raw(g.interstitial_blocks, g.n_interstitial_blocks, K.BLOCK_DT), raw(e.interstitial_blocks, e.n_interstitial_blocks, K.BLOCK_DT)), ("interstitial blocks", i)
-        nwin += int(g.n_windows)
-        nblk += int(g.n_terminal_blocks + g.n_interstitial_blocks)
-        if with_matches:
-            em = np.frombuffer(raw(e.matches, e.n_matches, K.MATCH_DT), dtype=K.MATCH_DT) if e.n_matches else np.zeros(0, K.MATCH_DT)
-            vis = em[(em["flags"] & (K.MATCH_CANONICAL | K.MATCH_TERMINAL)) != 0]
-            gm = np.frombuffer(raw(g.matches, g.n_matches, K.MATCH_DT), dtype=K.MATCH_DT) if g.n_matches else np.zeros(0, K.MATCH_DT)
-            assert len(gm) == len(vis) and np.array_equal(gm["position"], vis["position"]) and np.array_equal(gm["flags"], vis["flags"]), ("visible matches", i)
-            assert int(seg_cnt[i].n_matches) == len(em) and int(seg_cnt[i].n_canonical) == int(((em["flags"] & K.MATCH_CANONICAL) != 0).sum()) \
-                and int(seg_cnt[i].n_forward) == int(((em["flags"] & K.MATCH_FORWARD) != 0).sum()), ("counts", i)
-            nvis += len(gm)
-    L.ts_free_segments(ref, n)
-    return {"segments": n, "windows": nwin, "blocks": nblk, "visible_matches": nvis if with_matches else None,
-            "compared": "window records and blocks byte for byte" + (", visible match records, per-segment counts" if with_matches else "")}
-
-
-def traffic_from_profile(args):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of the default command, with where it came
-    from; null when the kernel source is newer than the profile (a stale figure is worse than none)."""
-    if args.gbases != 3.0 or args.contigs != 200 or args.flags != FLAGS:
-        return None, None
-    best = None
-    pdir = os.path.join(ROOT, "profiles")
-    for rd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        cand = os.path.join(pdir, rd, "pmc_traffic.json")
-        if os.path.exists(cand):
-            best = cand
-    if best is None:
-        return None, None
-    d = json.load(open(best))
-    src = "static: %s" % os.path.relpath(best, ROOT)
-    want = d.get("kernels_hip_sha256")
-    if want:
-        import hashlib
-        have = hashlib.sha256(open(os.path.join(ROOT, "teloscope_amd", "csrc", "kernels.hip"), "rb").read()).hexdigest()
-        if have != want:
-            return None, src + " is stale (kernels.hip changed since it was measured)"
-        src += " @ kernels.hip sha256 %s" % want[:12]
-    else:
-        return None, src + " carries no kernel hash (measured for an earlier kernel)"
-    return d["hbm_bytes_per_launch"], src
-
-
-# ------------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(args, opts, buf, offsets, lens):
-    """Bounded sample of the same workload on the host cores through the oracle port, with the reference's own
-    parallel decomposition: one job per path (src/input.cpp:719-724), here one contig slice per thread (ctypes
-    releases the GIL inside the C call); at 1 thread and at as many threads as the process may use, best of 3 each
-    (BASELINE.md section 3).  The process was bound to the GPU's NUMA node for the PCIe legs: for this leg it gets back every
-    CPU it was started with.  The reference binary itself cannot be built (gfalibs is absent from the reference tree and
-    stand-in headers are not allowed), so this port is not calibrated against it."""
-    from concurrent.futures import ThreadPoolExecutor
-    from tests.backends import OracleBackend
-    bound = os.sched_getaffinity(0)
-    if ORIG_AFFINITY:
-        os.sched_setaffinity(0, ORIG_AFFINITY)
-    try:
-        n = len(lens)
-        ncpu = len(os.sched_getaffinity(0))
-        cores = max(1, min(ncpu, n))
-        # ~10-30 s of CPU work in all (three passes at N threads + three single-core passes), whatever the core count
-        total_sample = args.cpu_sample_mb * 1e6 * max(1.0, cores / 4.0) / 4.0
-        per_job = int(total_sample / cores)
-        order = sorted(range(n), key=lambda i: -lens[i])[:cores]
-        jobs = []
-        for ci in order:
-            nb = int(min(per_job, lens[ci]))
-            jobs.append(buf[offsets[ci]:offsets[ci] + nb].cpu().numpy().tobytes().upper())
-        backends = [OracleBackend(opts) for _ in jobs]
-
-        def run(i):
-            return backends[i].oracle.bench_scan(jobs[i])
-
-        t1 = tn = None
-        with ThreadPoolExecutor(max_workers=cores) as ex:
-            for _ in range(3):
-                c0 = time.perf_counter()
-                r1 = run(0)                                         # one core, one job
-                d = time.perf_counter() - c0
-                t1 = d if t1 is None else min(t1, d)
-                c0 = time.perf_counter()
-                res = list(ex.map(run, range(len(jobs))))
-                d = time.perf_counter() - c0
-                tn = d if tn is None else min(tn, d)
-        took = sum(len(j) for j in jobs)
-        assert r1[0] == res[0][0]
-        return {"value": round(took / tn / 1e9, 5), "unit": "Gbases/s", "cores": cores, "host_cpus": os.cpu_count(), "cpus_usable": ncpu,
-                "kind": "port", "single_core_value": round(len(jobs[0]) / t1 / 1e9, 5), "passes": "best of 3 at 1 thread and at %d threads" % cores,
-                "calibrated_against_reference": False,
-                "sample": "first %.0f Mb of each of the %d largest contigs of the same synthetic assembly "
-                          "(%.0f Mb), same flags, scan stage only incl. block calling "
-                          "(oracle/teloscope_oracle.c: trie walk + carry loop), one job per contig as the "
-                          "reference's -j N does, on every CPU the process was started with; %d windows, %d matches, best pass "
-                          "%.1f s wall (%.1f s for one job on one core); the reference binary cannot be built here (gfalibs "
-                          "absent), so the port is not calibrated against it" % (per_job / 1e6, len(jobs), took / 1e6, sum(r[1] for r in res),
-                                                                                  sum(r[2] for r in res), tn, t1)}
-    finally:
-        os.sched_setaffinity(0, bound)
-
-
-def pcie_inclusive(L, K, tel, buf, offsets, lens, total):
-    """ASCII in host memory in, results in host memory out, through the drop-in entry points (pipelined upload,
-    scan, block calling, D2H, host post-processing) — SURVEY 8d's second figure; reported beside `value`, never
-    in it."""
-    n = len(lens)
-    import mmap
-    import numpy as np
-    import torch
-    # the caller's buffer: ordinary pageable memory.  (TS_BENCH_HOST_HUGEPAGES=1 puts it on 2 MB pages when the kernel grants
-    # them on request — measured: no difference, 84 against 84 Gbases/s.)
-    nbytes = int(buf.numel())
-    host_pages = "4 KB pages"
-    if os.environ.get("TS_BENCH_HOST_HUGEPAGES", "0") == "1" and hasattr(mmap, "MADV_HUGEPAGE"):
-        mm = mmap.mmap(-1, nbytes + (4 << 20))
-        try:
-            mm.madvise(mmap.MADV_HUGEPAGE)
-            host_pages = "anonymous mapping with madvise(MADV_HUGEPAGE)"
-        except OSError:
-            pass
-        whole = np.frombuffer(mm, dtype=np.uint8)
-        skip = (-whole.ctypes.data) % (2 << 20)
-        host = whole[skip:skip + nbytes]
-        torch.from_numpy(host).copy_(buf)
-    else:
-        host = buf.cpu().numpy()
-    segs = (K.SegmentIn * n)()
-    base = host.ctypes.data
-    for i in range(n):
-        segs[i].seq = C.cast(C.c_void_p(base + offsets[i]), C.c_char_p)
-        segs[i].len = lens[i]
-        segs[i].abs_pos = 0
-        segs[i].tips_only = 0
-    e2e = {}
-    for name, with_matches in (("blocks_windows_counts", False), ("with_match_vectors", True)):
-        res = (K.SegmentOut * n)()
-        cnts = (K.SegmentCounts * n)()
-        best = None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            rc = (L.ts_scan_segments(tel._ctx.ptr, segs, n, res) if with_matches
-                  else L.ts_scan_segments_blocks(tel._ctx.ptr, segs, n, res, cnts))
-            dt = time.perf_counter() - t0
-            if rc != 0:
-                raise RuntimeError(tel._ctx.error())
-            nm = int(sum(res[i].n_matches for i in range(n))) if with_matches else int(sum(c.n_matches for c in cnts))
-            L.ts_free_segments(res, n)
-            best = dt if best is None else min(best, dt)
-        e2e[name] = {"seconds": round(best, 4), "gbases_per_s": round(total / best / 1e9, 3), "matches": nm}
-    # the same call with the bases handed over ALREADY packed (TS_INPUT_PACKED2: 2-bit codes + invalid runs): what a front end
-    # that packs while it parses passes (a FASTA reader touches every base once anyway) — the library's staging threads then
-    # copy a quarter of the bytes instead of reading 3 GB of ASCII, which is what bounds the legs above.  The packing itself
-    # (ts_pack_bases, here on a thread per contig, untimed) is the front end's pass over the text, not this entry point's.
-    if int(L.ts_takes_text_input(tel._ctx.ptr, 0)):
-        from concurrent.futures import ThreadPoolExecutor
-        packed, keep = [None] * n, [None] * n
-
-        def pack_one(i):
-            m = int(lens[i])
-            codes = np.zeros((m + 3) // 4 + 64, dtype=np.uint8)
-            runs = []
-            piece = 1 << 28
-            for a in range(0, m, piece):
-                mm_ = min(piece, m - a)
-                cap = 1 << 16
-                while True:
-                    rr = np.zeros((cap, 2), dtype=np.uint32)
-                    nr = C.c_uint64(0)
-                    rc = L.ts_pack_bases(C.cast(C.c_void_p(base + offsets[i] + a), C.c_char_p), mm_, int(bool(tel.userInput.foldCase)),
-                                         C.c_void_p(codes.ctypes.data + a // 4), C.c_void_p(rr.ctypes.data), cap, C.byref(nr))
-                    if rc == 0:
-                        break
-                    if int(nr.value) <= cap:
-                        raise RuntimeError("ts_pack_bases failed")
-                    cap = int(nr.value) + 16
-                for s0, ln in rr[:int(nr.value)]:
-                    runs.append((a + int(s0), int(ln)))
-            arr = (K.PackedRun * max(1, len(runs)))()
-            for q, (s0, ln) in enumerate(runs):
-                arr[q].start, arr[q].len = s0, ln
-            packed[i] = K.PackedSeq(C.c_void_p(codes.ctypes.data), C.cast(arr, C.c_void_p), len(runs))
-            keep[i] = (codes, arr)
-
-        with ThreadPoolExecutor(max_workers=8) as ex:
-            list(ex.map(pack_one, range(n)))
-        psegs = (K.SegmentIn * n)()
-        for i in range(n):
-            psegs[i].seq = C.cast(C.pointer(packed[i]), C.c_char_p)
-            psegs[i].len = lens[i]
-            psegs[i].input_format = K.TS_INPUT_PACKED2
-        res = (K.SegmentOut * n)()
-        cnts = (K.SegmentCounts * n)()
-        best = None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            rc = L.ts_scan_segments_blocks(tel._ctx.ptr, psegs, n, res, cnts)
-            dt = time.perf_counter() - t0
-            if rc != 0:
-                raise RuntimeError(tel._ctx.error())
-            nm = int(sum(c.n_matches for c in cnts))
-            L.ts_free_segments(res, n)
-            best = dt if best is None else min(best, dt)
-        if nm != e2e["blocks_windows_counts"]["matches"]:
-            raise RuntimeError("packed input and ASCII input gave different match counts")
-        e2e["blocks_windows_counts_packed_in"] = {
-            "seconds": round(best, 4), "gbases_per_s": round(total / best / 1e9, 3), "matches": nm,
-            "input": "TS_INPUT_PACKED2: 2-bit codes + invalid runs in host memory (%.2f GB instead of %.2f), packed before the clock "
-                     "starts as a FASTA front end would while parsing" % (total / 4e9, total / 1e9)}
-        del packed, keep, psegs
-    # the writers' view over ts_scan_segments_multi: one shard per context, each over its own PCIe link (here: the contexts
-    # this one GPU can give — the figure says what the entry point costs, not what more links would add)
-    import teloscope_amd as ta
-    n_ctx = max(1, min(int(os.environ.get("TS_BENCH_CTXS", "1")), 8))
-    tels = [tel] + [ta.Teloscope(tel.userInput) for _ in range(n_ctx - 1)]
-    ctxs = (C.c_void_p * n_ctx)(*[t._ctx.ptr for t in tels])
-    res = (K.SegmentOut * n)()
-    cnts = (K.SegmentCounts * n)()
-    best = None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        rc = L.ts_scan_segments_multi(ctxs, n_ctx, segs, n, res, cnts)
-        dt = time.perf_counter() - t0
-        if rc != 0:
-            raise RuntimeError(tel._ctx.error())
-        nvis = int(sum(res[i].n_matches for i in range(n)))
-        nm = int(sum(c.n_matches for c in cnts))
-        L.ts_free_segments(res, n)
-        best = dt if best is None else min(best, dt)
-    e2e["writer_view_multi"] = {"seconds": round(best, 4), "gbases_per_s": round(total / best / 1e9, 3), "matches": nm,
-                                "visible_matches": nvis, "n_ctx": n_ctx,
-                                "entry_point": "ts_scan_segments_multi (windows, blocks and the match records a writer reads; one shard per context)"}
-    # the GENERAL path (parameter sets the tiled kernel does not take: here a mixed-length set, -p TTAGGG,TTAGG) over the same
-    # host buffer and entry point — generic.hip's list kernel, block calling on the device, upload of group g + 1 beside group
-    # g's kernels.  Reported beside the figures above, never in `value`; TS_BENCH_NO_GENERAL=1 skips it.
-    if not os.environ.get("TS_BENCH_NO_GENERAL"):
-        from teloscope_amd.cli import parse_cli, user_input
-        gflags = "-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i"
-        gtel = ta.Teloscope(user_input(parse_cli("x.fa " + gflags), device=tel.userInput.device))
-        if not gtel.usesFastPath():
-            res = (K.SegmentOut * n)()
-            cnts = (K.SegmentCounts * n)()
-            best = None
-            for _ in range(3):
-                t0 = time.perf_counter()
-                rc = L.ts_scan_segments_blocks(gtel._ctx.ptr, segs, n, res, cnts)
-                dt = time.perf_counter() - t0
-                if rc != 0:
-                    raise RuntimeError(gtel._ctx.error())
-                nm = int(sum(c.n_matches for c in cnts))
-                nb = int(sum(res[i].n_terminal_blocks + res[i].n_interstitial_blocks for i in range(n)))
-                L.ts_free_segments(res, n)
-                best = dt if best is None else min(best, dt)
-            e2e["general_path_blocks_windows_counts"] = {
-                "flags": gflags, "patterns": len(gtel.userInput.patternInfo), "seconds": round(best, 4),
-                "gbases_per_s": round(total / best / 1e9, 3), "matches": nm, "blocks": nb,
-                "kernels": "generic.hip: ts_general_fused_list + compaction + blockcall.hip (general record format)"}
-        gtel.close()
-    return {"entry_points": "ts_scan_segments_blocks / ts_scan_segments (pageable host buffers in, host results out; "
-                            "groups of ~512 MB pipelined through upload / scan / download stages; bases cross PCIe as 2-bit codes + invalid runs, packed by the staging threads and unpacked on the device; best of 3)", "host_buffer": host_pages, "n_ctx": 1, **e2e}
-
-
-# ------------------------------------------------------------------------------------------- the assembly scan
-def run_scan(args, rank, local_rank, world, dev, backend):
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    import teloscope_amd as ta
-    from teloscope_amd import _capi as K
-    from teloscope_amd import distributed as D
-    from teloscope_amd.cli import parse_cli, user_input
-
-    opts = parse_cli("x.fa " + args.flags)
-    ui = user_input(opts, device=dev.index)
-    tel = ta.Teloscope(ui)
-    L = K.lib()
-    forced_strong = world == 1 and bool(os.environ.get("TS_BENCH_FORCE_STRONG"))
-    strong = (world > 1 or forced_strong) and not args.weak
-    total = int(args.gbases * 1e9)
-    lens = contig_lengths(total, args.contigs, 42 + (rank if args.weak else 0))
-    n = len(lens)
-    plan = D.ShardPlan(tel, lens, world=world if strong else 1)
-    offsets = plan.segment_offsets()
-    info = plan.info
-    # The scans run on a stream of their own, not on the null stream: work on the null stream does not overlap with work on
-    # other streams the way two ordinary streams overlap (the sharded step at the size of one of 8 ranks: 0.349 -> 0.283 ms
-    # with block calling + packing of step i beside the scan of step i + 1).
-    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
-    stream = torch.cuda.current_stream()
-    sptr = C.c_void_p(stream.cuda_stream)
-    xdev = dev if backend == "nccl" else torch.device("cpu")
-
-    # the assembly: generated whole on every rank (same seed -> same bytes); a strong-scaling rank keeps only
-    # the bytes its tile range reads
-    full = torch.zeros(int(info.input_bytes), dtype=torch.uint8, device=dev)
-    fill_synthetic(full, offsets, lens, 42 + (rank if args.weak else 0), dev)
-    keep_full = (not strong) or (rank == 0 and args.verify)
-    buf = full                                                  # (a strong-scaling rank cuts its own range out below)
-    sharded = None
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device=xdev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    enqueue_s = [0.0]
-
-    def timed(step_fn, drain_fn, nsteps):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier()
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        for i in range(nsteps):
-            step_fn(i)
-        enqueue_s[0] = time.perf_counter() - t0                 # host time to ENQUEUE the steps (nothing waited for)
-        drain_fn()
-        ev1.record(stream)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        return max_over_ranks(elapsed), ev0.elapsed_time(ev1) / max(1, nsteps)
-
-    # A device that has just been handed its first kernels is not in its steady state: the launch time of this kernel rises
-    # for five launches (0.81 -> 0.97 ms) and then falls for about forty (-> 0.765 ms; profiles/r02/launch_ramp.txt).  The W
-    # warm-up steps of the contract are taken from there: SETTLE_LAUNCHES untimed scans first (reported in config.settle).
-    def settle(step_fn, drain_fn):
-        for n in range(SETTLE_LAUNCHES):
-            step_fn(n)
-            if n % 8 == 7:
-                drain_fn()
-        drain_fn()
-        torch.cuda.synchronize()
-        settle_info["launches"] = SETTLE_LAUNCHES
-
-    settle_info = {"launches": 0}
-    out = None
-    if not strong:
-        # ---------------------------------------------------------------- N = 1 (or weak scaling)
-        batch = plan.batch
-        if os.environ.get("TS_BENCH_EMIT") == "1":          # A/B: the plain scan with the emitting build (ts_batch_set_emit)
-            L.ts_batch_set_emit(batch, 1)
-        dptr = C.c_void_p(buf.data_ptr())
-        summaries = [torch.zeros(n * 4, dtype=torch.int64, device=dev) for _ in range(2)]
-        gathered = [[torch.zeros(n * 4, dtype=torch.int64, device=xdev) for _ in range(world)]
-                    if (world > 1 and rank == 0) else None for _ in range(2)]
-        pending = [None, None]
-
-        def step(i):
-            if L.ts_batch_scan(batch, dptr, sptr) != 0:
-                raise RuntimeError(tel._ctx.error())
-            if world > 1:                                       # weak scaling: per-segment hit summaries to rank 0
-                j = i & 1
-                if pending[j] is not None:
-                    pending[j].wait()
-                if L.ts_batch_segment_summary(batch, C.c_void_p(summaries[j].data_ptr()), sptr) != 0:
-                    raise RuntimeError(tel._ctx.error())
-                src = summaries[j] if backend == "nccl" else summaries[j].cpu()
-                pending[j] = dist.gather(src, gathered[j], dst=0, async_op=True)
-
-        def drain():
-            for j in range(2):
-                if pending[j] is not None:
-                    pending[j].wait()
-                    pending[j] = None
-
-        # what a user sees: a genome is scanned ONCE.  The first scan of the process (device buffers allocated, code objects
-        # loaded), the second (a single shot on a warm library), and the contract's own protocol without the settling scans
-        # below (W warm-ups, then K steps) are measured before the steady state that `value` reports.
-        protocol = {}
-        if world == 1:
-            def one():
-                torch.cuda.synchronize()
-                c0 = time.perf_counter()
-                step(0)
-                drain()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - c0) * 1e3
-            protocol["first_scan_ms_incl_module_load_and_allocation"] = round(one(), 3)
-            if L.ts_batch_sync(batch) != 0:      # (grows the match buffer and rescans if the first scan overflowed)
-                raise RuntimeError(tel._ctx.error())
-            protocol["single_shot_ms"] = round(one(), 4)
-            for i in range(args.warmup):
-                step(i)
-            drain()
-            torch.cuda.synchronize()
-            c0 = time.perf_counter()
-            for i in range(args.steps):
-                step(i)
-            drain()
-            torch.cuda.synchronize()
-            protocol["after_%d_warmups_ms_per_step" % args.warmup] = round((time.perf_counter() - c0) / args.steps * 1e3, 4)
-        settle(step, drain)
-        for i in range(args.warmup):
-            step(i)
-        drain()
-        if L.ts_batch_sync(batch) != 0:          # also grows the match buffer if it overflowed
-            raise RuntimeError(tel._ctx.error())
-        tmax, dev_ms = timed(step, drain, args.steps)
-        if world == 1:
-            protocol["settled_ms_per_step"] = round(tmax / args.steps * 1e3, 4)
-            protocol["value_is"] = "settled_ms_per_step: the steady state after %d untimed scans; a genome scanned once costs single_shot_ms" % SETTLE_LAUNCHES
-        if L.ts_batch_sync(batch) != 0:
-            raise RuntimeError(tel._ctx.error())
-        L.ts_batch_get_info(batch, C.byref(info))
-        kern_ms, launches = float(info.avg_kernel_ms), int(info.kernel_launches)
-        alg_bytes, n_matches, n_windows, n_tiles = int(info.algorithmic_bytes), int(info.n_matches), int(info.n_windows), int(info.n_tiles)
-        result_batch = batch
-        extra_cfg = {"timed_region": "resident ASCII in HBM -> window records + packed match stream in HBM"
-                                     + (" + RCCL gather of per-segment hit summaries (weak scaling: every rank its own assembly)"
-                                        if world > 1 else "")}
-        if protocol:
-            extra_cfg["launch_protocol"] = protocol
-        bases_done = world * total
-    elif not args.full_exchange:
-        # ---------------------------------------------------------------- N > 1, strong scaling (configs[2]): shard results
-        # Every rank scans its tile range (+ context tiles), calls its blocks on its own device and packs ONE message of a
-        # size both sides know from the plan; one grouped send / recv per step brings the messages to rank 0.  Nothing is
-        # read back to the host inside a step; the messages' headers are checked (and the messages merged on the host,
-        # ts_shards_finalize) before the timed steps and after them.
-        slots = max(2, int(os.environ.get("TS_BENCH_SLOTS", "4")))      # (profiles/r04/hwq_sweep.txt, slots_sweep.txt)
-        scale = 1
-        exch = D.ShardExchange(plan, rank, dev, dst=0, slots=slots, scale=scale)
-        shard = D.PackedShard(plan, rank, dev, slots=slots, scale=scale)
-        buf = full[int(shard.info.input_begin):max(int(shard.info.input_end), int(shard.info.input_begin) + 64)].clone()
-        if not keep_full:
-            del full
-            torch.cuda.empty_cache()
-        in_ptr = buf.data_ptr()
-        pending = [None] * slots
-        # Streams: block calling + packing of step i (no LDS, few registers) run beside the scans of the steps after it (a
-        # persistent kernel that holds every CU's LDS but leaves a SIMD room for one or two waves of anything else: the
-        # pack kernels are chains of latency, they make progress at that occupancy but take about two scans to finish —
-        # hence THREE buffer slots and TWO pack streams, so that two packs are in flight beside the scan), and the transfer
-        # of step i's message beside all of it.  A slot's scan waits for the pack that last read its records; a slot's pack
-        # waits for the transfer that last read its message.
-        pack_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(os.environ.get("TS_BENCH_PACK_STREAMS", "2"))))]
-        # (TS_BENCH_SCAN_STREAMS=2 alternates the scans of consecutive steps between two streams, so that the workgroups of
-        # step i + 1 could take the CUs the tail of step i frees.  Measured, profiles/r04/two_scan_streams.txt: slower at every
-        # size — 1.15 against 0.93 ms at 3 Gb, 0.188 against 0.177 at the N = 8 size: two persistent kernels that each want
-        # every CU's whole LDS take turns badly.  One stream is the default.)
-        scan_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(max(1, int(os.environ.get("TS_BENCH_SCAN_STREAMS", "1"))) - 1)]
-        scanned = [torch.cuda.Event() for _ in range(slots)]
-        packed = [torch.cuda.Event() for _ in range(slots)]
-        used = [False] * slots
-        # Rehearsal of the exchange's SHAPE on one GPU (TS_BENCH_REHEARSE_WORLD=8 with TS_BENCH_FORCE_STRONG=1): what rank 0 of
-        # an N-rank job posts per step — one grouped batch of N - 1 receives, one per sender, of the message sizes the N-way
-        # plan gives (ts_batch_shard_info) — and what the N - 1 senders post, all from this one rank on the real RCCL group
-        # with itself as the peer: 2 (N - 1) operations per step in one batch_isend_irecv, `slots` steps in flight, posted
-        # from the pack stream as in the real step.  What it cannot show is seven links; what it does show is the grouped
-        # P2P call pattern of rank 0 meeting the library.  The received bytes are compared with what was sent afterwards.
-        rehearse = None
-        rw = int(os.environ.get("TS_BENCH_REHEARSE_WORLD", "0"))
-        if world == 1 and rw > 1 and backend == "nccl":
-            plan_r = D.ShardPlan(tel, lens, world=rw)
-            sizes = [int(D.shard_info(plan_r, p).msg_bytes) for p in range(1, rw)]
-            plan_r.close()
-            gen = torch.Generator(device=dev)
-            gen.manual_seed(7)
-            rehearse = {"world": rw, "sizes": sizes,
-                        "send": [[torch.randint(0, 256, (sz,), dtype=torch.uint8, device=dev, generator=gen) for sz in sizes] for _ in range(slots)],
-                        "recv": [[torch.zeros(sz, dtype=torch.uint8, device=dev) for sz in sizes] for _ in range(slots)],
-                        "posted": 0, "steps": 0}
-
-        def post_rehearsal(j):
-            ops = []
-            for q in range(len(rehearse["sizes"])):
-                ops.append(dist.P2POp(dist.irecv, rehearse["recv"][j][q], 0))
-            for q in range(len(rehearse["sizes"])):
-                ops.append(dist.P2POp(dist.isend, rehearse["send"][j][q], 0))
-            rehearse["posted"] += len(ops)
-            rehearse["steps"] += 1
-            return dist.batch_isend_irecv(ops)
-
-        def step(i):
-            j = i % slots
-            pack_stream = pack_streams[j % len(pack_streams)]
-            scan_stream = scan_streams[i % len(scan_streams)]
-            if used[j]:
-                scan_stream.wait_event(packed[j])
-            shard.scan(in_ptr, C.c_void_p(scan_stream.cuda_stream), j)
-            scanned[j].record(scan_stream)
-            with torch.cuda.stream(pack_stream):
-                pack_stream.wait_event(scanned[j])
-                if pending[j] is not None:
-                    for w in pending[j]:
-                        w.wait()
-                    pending[j] = None
-                shard.pack(C.c_void_p(pack_stream.cuda_stream), j)
-                packed[j].record(pack_stream)
-                pending[j] = exch.post(shard.msgs[j], j) if rehearse is None else post_rehearsal(j)
-            used[j] = True
-
-        def drain():
-            for j in range(slots):
-                with torch.cuda.stream(pack_streams[j % len(pack_streams)]):
-                    if pending[j] is not None:
-                        for w in pending[j]:
-                            w.wait()
-                        pending[j] = None
-            for ps in pack_streams + scan_streams[1:]:
-                stream.wait_stream(ps)
-
-        settle(step, drain)
-        for i in range(max(args.warmup, slots)):
-            step(i)
-        drain()
-        torch.cuda.synchronize()
-        # capacities and record regions settle here (untimed): a scan that overflowed its regions is regrown, a message that
-        # overflowed gets a larger scale on every rank; an input the shards' assumptions do not hold for takes the full exchange
-        ok = False
-        for attempt in range(8):
-            action, factor, merged = exch.check(shard.msgs[0], 0)
-            if merged is not None:
-                D.free_segments(plan, merged[1])
-            if action == exch.OK:
-                ok = True
-                break
-            if action == exch.FULL:
-                break
-            if action == exch.SYNC:
-                for j in range(slots):
-                    shard.sync(j)
-            elif action == exch.GROW:
-                scale *= factor
-                shard.set_scale(scale)
-                exch.set_scale(scale)
-            for i in range(slots):
-                step(i)
-            drain()
-            torch.cuda.synchronize()
-        if not ok:
-            raise RuntimeError("the shard results need the full exchange for this input: run with --full-exchange")
-        for j in range(slots):
-            shard.kernel_ms(j)                                   # (harvest the scans' event times so far)
-        tmax, dev_ms = timed(step, drain, args.steps)
-        last = (args.steps - 1) % slots
-        km = [shard.kernel_ms(j) for j in range(slots)]
-        launches = sum(k[1] for k in km)
-        kern_ms = sum(k[0] * k[1] for k in km) / max(1, launches)
-        rinfo = km[last][2]
-        alg_bytes = int(rinfo.algorithmic_bytes)
-        # where a step's time goes when nothing overlaps: scan + pack / exchange, each waited for
-        nb = min(10, args.steps)
-        t_scan = t_pack = t_x = 0.0
-        for i in range(nb):
-            barrier()
-            c0 = time.perf_counter()
-            if L.ts_batch_scan(shard.batches[0], C.c_void_p(in_ptr), sptr) != 0:
-                raise RuntimeError(tel._ctx.error())
-            torch.cuda.synchronize()
-            c1 = time.perf_counter()
-            if L.ts_batch_pack_shard(shard.batches[0], C.c_void_p(shard.msgs[0].data_ptr()), shard.msgs[0].numel(), sptr) != 0:
-                raise RuntimeError(tel._ctx.error())
-            torch.cuda.synchronize()
-            c2 = time.perf_counter()
-            for w in exch.post(shard.msgs[0], 0):
-                w.wait()
-            torch.cuda.synchronize()
-            c3 = time.perf_counter()
-            t_scan += c1 - c0; t_pack += c2 - c1; t_x += c3 - c2
-        split = {"scan_ms": round(max_over_ranks(t_scan / nb) * 1e3, 4), "block_calling_and_pack_ms": round(max_over_ranks(t_pack / nb) * 1e3, 4),
-                 "exchange_ms": round(max_over_ranks(t_x / nb) * 1e3, 4), "steps": nb,
-                 "note": "serialised (each phase waited for on the host); the timed region overlaps the exchange of step i "
-                         "with the scan of step i+1"}
-        # the last timed step's messages, checked and merged on rank 0 (untimed)
-        action, factor, merged = exch.check(shard.msgs[last], last)
-        if action != exch.OK:
-            raise RuntimeError("a timed step's messages came out incomplete (action %d)" % action)
-        result_batch = None
-        n_windows, n_tiles = plan.n_windows, plan.n_tiles
-        n_matches = 0
-        sharded = None
-        if rank == 0:
-            rc_m, seg_out, seg_cnt = merged
-            n_matches = int(sum(int(seg_cnt[i].n_matches) for i in range(n)))
-            statuses = []
-            for m in exch.messages(shard.msgs[last], last):
-                st = K.ShardStatus()
-                L.ts_shard_peek(m.ctypes.data, m.nbytes, C.byref(st))
-                statuses.append(st)
-            sharded = {"seg_out": seg_out, "seg_cnt": seg_cnt}
-            extra_cfg = {"timed_region": "resident ASCII in HBM on %d ranks (consecutive tile ranges of ONE plan, + context tiles) -> scan + block calling "
-                                         "on every rank's own device + ONE message per rank (bit-packed window records, the match records a writer "
-                                         "reads, blocks) -> all messages in rank 0's HBM; no host synchronisation inside a step; the exchange of "
-                                         "step i overlaps the scan of step i+1" % world,
-                         "backend": backend + ("" if backend == "nccl" else " (rehearsal: ranks share a GPU, messages staged through the host)"),
-                         "bases_per_rank": [int(x.bases) for x in exch.infos],
-                         "exchange": {"bytes_over_links_per_step": exch.bytes_over_links,
-                                      "message_bytes_per_rank": [int(x.msg_bytes) for x in exch.infos],
-                                      "window_bytes": int(exch.infos[0].window_bytes), "visible_record_bytes": int(exch.infos[0].visible_bytes),
-                                      "visible_records_per_rank": [int(st.n_visible) for st in statuses],
-                                      "visible_capacity_per_rank": [int(st.visible_capacity) for st in statuses],
-                                      "blocks_per_rank": [int(st.n_blocks) for st in statuses],
-                                      "capacity_scale": scale, "context_tiles": int(exch.infos[0].context_tiles),
-                                      "round2_full_exchange_bytes_over_links": None},
-                         "step_split": split}
-            if rehearse is not None:
-                torch.cuda.synchronize()
-                same = all(torch.equal(rehearse["recv"][j][q], rehearse["send"][j][q])
-                           for j in range(min(slots, rehearse["steps"])) for q in range(len(rehearse["sizes"])))
-                if not same:
-                    raise RuntimeError("exchange rehearsal: received bytes differ from the bytes sent")
-                extra_cfg["exchange"]["rehearsal"] = {
-                    "of_world": rehearse["world"], "posted_ops_per_step": rehearse["posted"] // max(1, rehearse["steps"]),
-                    "steps_posted": rehearse["steps"], "bytes_per_step": int(sum(rehearse["sizes"])),
-                    "message_bytes": rehearse["sizes"], "received_equals_sent": True,
-                    "what": "rank 0's grouped batch of an %d-rank step (N - 1 receives) plus the N - 1 sends, from ONE rank on the RCCL "
-                            "group with itself as the peer, `slots` steps in flight" % rehearse["world"]}
-        else:
-            extra_cfg = {}
-        bases_done = total
-    else:
-        # ---------------------------------------------------------------- N > 1, strong scaling, round 2's full exchange
-        r = plan.ranges[rank]
-        buf = full[r.input_begin:r.input_end].clone()
-        if not keep_full:
-            del full
-            torch.cuda.empty_cache()
-        sharded = None
-        slots = 2
-        cap0 = total // 4 + 4096
-        assembled = None
-        if rank == 0:
-            assembled = [D.Assembled(torch.empty(8 * plan.n_windows, dtype=torch.int32, device=dev),
-                                     torch.empty(4 * plan.n_tiles, dtype=torch.int32, device=dev),
-                                     torch.empty(cap0, dtype=torch.int32, device=dev), 0, [0] * world) for _ in range(slots)]
-        shard = D.HipShard(plan, rank, dev, slots=slots, assembled=assembled)
-        in_ptr = buf.data_ptr()
-        pending = [None] * slots
-        n_local = [0] * slots
-        dir_only = [False]
-
-        def step(i):
-            j = i % slots
-            if pending[j] is not None:
-                pending[j].wait()
-                pending[j] = None
-            shard.scan(in_ptr, sptr, j)
-            n_local[j] = shard.finish(in_ptr, sptr, j)
-            pending[j] = D.gather_shards(plan, rank, shard.windows[j], shard.stats[j], shard.dense[j], n_local[j], dst=0,
-                                         out=assembled[j] if rank == 0 else None, async_op=True, directory_only=dir_only[0])
-
-        def drain():
-            for j in range(slots):
-                if pending[j] is not None:
-                    pending[j].wait()
-                    pending[j] = None
-
-        settle(step, drain)
-        for i in range(max(args.warmup, slots)):
-            step(i)
-        drain()
-        for j in range(slots):                                   # (a sync also grows a shard's match regions if they overflowed)
-            shard.kernel_ms(j)
-        tmax, dev_ms = timed(step, drain, args.steps)
-        last = (args.steps - 1) % slots
-        km = [shard.kernel_ms(j) for j in range(slots)]
-        launches = sum(k[1] for k in km)
-        kern_ms = sum(k[0] * k[1] for k in km) / max(1, launches)
-        rinfo = km[last][2]
-        alg_bytes = int(rinfo.algorithmic_bytes)
-
-        # the summaries-only variant, measured not argued: only the tile directory (16 B per tile) travels
-        dir_only[0] = True
-        t_dir, _ = timed(step, drain, args.steps)
-        dir_only[0] = False
-        # where a step's time goes when nothing overlaps: scan + export / exchange / merge, each waited for
-        nb = min(10, args.steps)
-        t_scan = t_x = t_merge = 0.0
-        for i in range(nb):
-            barrier()
-            c0 = time.perf_counter()
-            shard.scan(in_ptr, sptr, 0)
-            nl = shard.finish(in_ptr, sptr, 0)
-            torch.cuda.synchronize()
-            c1 = time.perf_counter()
-            a = D.gather_shards(plan, rank, shard.windows[0], shard.stats[0], shard.dense[0], nl, dst=0,
-                                out=assembled[0] if rank == 0 else None)
-            torch.cuda.synchronize()
-            c2 = time.perf_counter()
-            if rank == 0:
-                hb = D.adopt(plan, a, sptr)
-                L.ts_batch_destroy(hb)
-            c3 = time.perf_counter()
-            t_scan += c1 - c0; t_x += c2 - c1; t_merge += c3 - c2
-        split = {"scan_export_ms": round(max_over_ranks(t_scan / nb) * 1e3, 4), "exchange_ms": round(max_over_ranks(t_x / nb) * 1e3, 4),
-                 "merge_ms_rank0": round(t_merge / nb * 1e3, 4), "steps": nb,
-                 "note": "serialised (each phase waited for on the host); the timed region overlaps the exchange of step i "
-                         "with the scan of step i+1"}
-        step(0)
-        drain()
-        a = assembled[0] if rank == 0 else None
-        result_batch = D.adopt(plan, a, sptr) if rank == 0 else None
-        n_matches = a.n_records if rank == 0 else 0
-        n_windows, n_tiles = plan.n_windows, plan.n_tiles
-        gather_bytes = (8 * 4 * plan.n_windows + 16 * plan.n_tiles + 4 * n_matches) if rank == 0 else 0
-        own = plan.ranges[0]
-        gather_bytes_rx = gather_bytes - (32 * (own.window_end - own.window_begin) + 16 * (own.tile_end - own.tile_begin)
-                                          + 4 * (a.counts[0] if rank == 0 else 0)) if rank == 0 else 0
-        if plan.wire16_ok:
-            gather_bytes_rx //= 2                               # every value travels as u16 and is widened on rank 0
-        extra_cfg = {"timed_region": "resident ASCII in HBM on %d ranks (consecutive tile ranges of ONE plan) -> scan + tile-ordered "
-                                     "export + ONE exchange (all-gather of record counts, grouped send/recv of window records, tile "
-                                     "directory, match records) -> the whole assembly's results in rank 0's HBM; exchange of step i "
-                                     "overlaps scan of step i+1" % world,
-                     "backend": backend + ("" if backend == "nccl" else " (rehearsal: ranks share a GPU, tensors staged through the host)"),
-                     "bases_per_rank": [int(x.bases) for x in plan.ranges],
-                     "records_per_rank": a.counts if rank == 0 else None,
-                     "gather_bytes_per_step": {"assembled_on_rank0": gather_bytes, "received_over_links": gather_bytes_rx,
-                                               "wire_format": "u16 per value (records, tile counts and window fields all fit), widened on rank 0"
-                                                              if plan.wire16_ok else "u32"},
-                     "step_split": split,
-                     "summaries_only_variant": {"ms_per_step": round(t_dir / args.steps * 1e3, 4),
-                                                "value": round(total / (t_dir / args.steps) / 1e9, 3),
-                                                "what_travels": "tile directory entries only (16 B per tile: %d B per step)" % (16 * plan.n_tiles)}}
-        bases_done = total
-
-    if rank == 0:
-        ms_per_step = tmax / args.steps * 1e3
-        value = bases_done / (tmax / args.steps) / 1e9
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_source = traffic_from_profile(args) if world == 1 else (None, None)
-        out = {
-            "metric": "Gbases/s scanned (whole node), 3 Gb FASTA TTAGGG w=1000 s=500",
-            "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak" if (world > 1 and args.weak) else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: synthetic %.2f Gb / %d contigs%s, %s, %d patterns k=%d"
-                                   % (("configs[1]" if world == 1 else "configs[2]") if args.flags == FLAGS and args.gbases == 3.0 else "custom",
-                                      args.gbases, n, " per GPU" if args.weak and world > 1 else (" sharded over %d GPUs" % world if world > 1 else ""),
-                                      args.flags, len(ui.patternInfo), len(ui.patternInfo[0][0])),
-                       "bases": total, "windows": n_windows, "matches": n_matches, "tiles": n_tiles,
-                       "device_ms_per_step_events": round(dev_ms, 4),
-                       "host_enqueue_ms_per_step": round(enqueue_s[0] / max(1, args.steps) * 1e3, 4),
-                       "settle": "%d untimed scans before the %d warm-up steps: the device's launch time needs ~40 launches to reach "
-                                 "its steady state (profiles/r02/launch_ramp.txt)" % (settle_info["launches"], args.warmup), **extra_cfg},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_source,
-                         "kernel": "ts_scan_tiles" + (" (rank 0's range)" if strong else ""), "kernel_ms": round(kern_ms, 4),
-                         "launches_timed": launches, "algorithmic_bytes": alg_bytes},
-        }
-        if world == 1 and not os.environ.get("TS_BENCH_NO_BOX_PROBE"):
-            # what THIS box issues and streams (ts_box_probe: hand-written independent integer instructions at four waves per SIMD;
-            # a 1 GiB copy), measured right after the timed steps, for context: the boxes of this pool differ by up to 7 % on one
-            # kernel hash (0.705 .. 0.758 ms per step).  The short probes do not explain that spread (0.720 / 0.727 / 0.739 / 0.758 ms
-            # at 580 / 567 / 585 / 583 wave-instructions per ns): they say what a plain copy moves on the box — 4.65-4.78 TB/s
-            vi, cb = C.c_double(0), C.c_double(0)
-            if L.ts_box_probe(tel._ctx.ptr, C.byref(vi), C.byref(cb)) == 0:
-                out["roofline"]["box"] = {"valu_wave_instr_per_ns": round(vi.value, 1), "copy_read_plus_write_gbs": round(cb.value, 1),
-                                          "note": "device-wide issue rate of independent v_and_b32 at 4 waves per SIMD; 16-byte grid-strided copy of 1 GiB"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, opts, buf, offsets, lens)
-        if args.verify and sharded is not None:
-            # shard results: a single-GPU scan of the whole assembly on rank 0 is (a) checked against the independent torch
-            # computation and (b) compared, segment by segment, with what the ranks' messages merged to
-            one = D.ShardPlan(tel, lens, world=1)
-            if L.ts_batch_scan(one.batch, C.c_void_p(full.data_ptr()), sptr) != 0 or L.ts_batch_sync(one.batch) != 0:
-                raise RuntimeError(tel._ctx.error())
-            out["verify"] = verify_full_size(L, one.batch, tel, full, offsets, lens, ui, dev)
-            out["verify"]["sharded_equals_single_gpu"] = compare_sharded_with_single_gpu(L, K, tel, one.batch, sharded, n, n_matches <= 600_000_000)   # (16 B per match record on the host: 1.5 GB at configs[1], 0.7 GB at configs[4])
-            one.close()
-        elif args.verify:
-            out["verify"] = verify_full_size(L, result_batch, tel, full if strong else buf, offsets, lens, ui, dev)
-            if strong:
-                # the assembled arrays against a single-GPU scan of the whole assembly, bit for bit
-                one = D.ShardPlan(tel, lens, world=1)
-                hs = D.HipShard(one, 0, dev, slots=1)
-                hs.scan(full.data_ptr(), sptr, 0)
-                n1 = hs.finish(full.data_ptr(), sptr, 0)
-                a = assembled[0]
-                assert n1 == a.n_records, (n1, a.n_records)
-                assert torch.equal(hs.windows[0], a.windows) and torch.equal(hs.stats[0], a.stats)
-                assert torch.equal(hs.dense[0][:n1], a.dense[:n1])
-                out["verify"]["sharded_equals_single_gpu"] = {"windows": int(plan.n_windows), "tiles": int(plan.n_tiles), "records": int(n1)}
-                hs.close()
-        if args.blocks:
-            seg_out = (K.SegmentOut * n)()
-            b0 = time.perf_counter()
-            rc = L.ts_batch_download_blocks(result_batch, seg_out)
-            bdt = time.perf_counter() - b0
-            if rc != 0:
-                raise RuntimeError(tel._ctx.error())
-            out["device_block_calling"] = {
-                "wall_ms_incl_alloc_d2h_windows": round(bdt * 1e3, 2),
-                "terminal_blocks": int(sum(seg_out[i].n_terminal_blocks for i in range(n))),
-                "interstitial_blocks": int(sum(seg_out[i].n_interstitial_blocks for i in range(n)))}
-            L.ts_free_segments(seg_out, n)
-        if world == 1 and not forced_strong and not os.environ.get("TS_BENCH_NO_BLOCKS_RECORD"):
-            out["scan_plus_block_calling"] = scan_plus_block_calling_record(args, tel, lens, buf, dev, out["ms_per_step"], stream)
-        if world == 1 and not args.no_reads and not forced_strong:
-            out["reads"] = reads_sub_record(args, dev)
-        if world == 1 and not args.no_e2e:
-            out["pcie_inclusive"] = pcie_inclusive(L, K, tel, buf, offsets, lens, total)
-            out["pcie_inclusive"]["host_placement"] = ("process and library threads on NUMA node %d, the GPU's" % HOST_NUMA_NODE
-                                                       if HOST_NUMA_NODE is not None else "not bound to a NUMA node")
-        print(json.dumps(out), flush=True)
-    if strong:
-        if result_batch:
-            L.ts_batch_destroy(result_batch)
-        if sharded is not None:
-            D.free_segments(plan, sharded["seg_out"])
-        shard.close()
-    barrier()
-
-
-# ------------------------------------------------------------------------------------------- the read filter
-READ_FLAGS = "--fastq-subset -l 42"
-
-
-def read_lengths(n, seed):
-    import numpy as np
-    rng = np.random.default_rng(seed)
-    return np.clip(rng.normal(15000, 3000, size=n), 1000, 40000).astype(np.int64)
-
-
-READ_CHUNK = 100_000            # reads per generation chunk: the read set does not depend on how it is dealt to ranks
-
-
-def fill_read_range(buf, all_lens, g0, g1, dev):
-    """configs[3]'s synthetic HiFi reads [g0, g1) of the global read set into `buf`, back to back in the batch layout
-    (every read at a 16-byte boundary): uniform ACGT, 0.5 % of the reads carry a 300-8000 b terminal TTAGGG / CCCTAA tract
-    with 1 % substitutions.  Generated per chunk of READ_CHUNK reads (seeded by the chunk's index), so that the same read
-    has the same bases whichever rank, sub-batch or read count it is generated for.  Returns the indices (relative to
-    g0) of the reads that carry a tract."""
-    import numpy as np
-    import torch
-    pad = (all_lens + 15) & ~15
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    carriers, at = [], 0
-    for c in range(g0 // READ_CHUNK, (g1 - 1) // READ_CHUNK + 1):
-        c0, c1 = c * READ_CHUNK, min((c + 1) * READ_CHUNK, len(all_lens))
-        cl = all_lens[c0:c1]
-        coffs = np.concatenate(([0], np.cumsum(pad[c0:c1])))
-        g = torch.Generator(device=dev)
-        g.manual_seed(43 + c)
-        tmp = torch.empty(int(coffs[-1]), dtype=torch.uint8, device=dev)
-        step = 1 << 28
-        for a in range(0, tmp.numel(), step):
-            b = min(tmp.numel(), a + step)
-            tmp[a:b] = lut[torch.randint(0, 4, (b - a,), dtype=torch.uint8, device=dev, generator=g).long()]
-        rng = np.random.default_rng(1043 + c)
-        a, z = max(g0, c0) - c0, min(g1, c1) - c0
-        for i in np.flatnonzero(rng.random(len(cl)) < 0.005):
-            ln = int(min(rng.integers(300, 8001), cl[i]))
-            unit = b"TTAGGG" if rng.random() < 0.5 else b"CCCTAA"
-            t = np.tile(np.frombuffer(unit, dtype=np.uint8), ln // 6 + 1)[:ln].copy()
-            k = rng.random(ln) < 0.01
-            t[k] = acgt[rng.integers(0, 4, size=int(k.sum()))]
-            if a <= i < z:
-                p = int(coffs[i]) if unit == b"CCCTAA" else int(coffs[i]) + int(cl[i]) - ln
-                tmp[p:p + ln] = torch.from_numpy(t).to(dev)
-                carriers.append(int(i) + c0 - g0)
-        nbytes = int(coffs[z] - coffs[a])
-        buf[at:at + nbytes] = tmp[int(coffs[a]):int(coffs[z])]
-        at += nbytes
-        del tmp
-    return np.asarray(carriers, dtype=np.int64)
-
-
-def scan_plus_block_calling_record(args, tel, lens, buf, dev, plain_ms, stream):
-    """What a rank of the sharded job does per step, on this one GPU with the whole assembly: the EMITTING scan
-    (ts_batch_set_emit: visible records + chain summaries) + block calling on the device + the packed message — the
-    reference's scanSegment contains block calling (src/teloscope.cpp:642-657), the plain scan that `value` times does not.
-    This is the like-for-like origin of a 1 -> N curve: the N > 1 lines time exactly this per rank, plus the exchange."""
-    import torch
-    import teloscope_amd.distributed as D
-    steps, slots = min(args.steps, 40), max(2, int(os.environ.get("TS_BENCH_SLOTS", "4")))
-    plan = D.ShardPlan(tel, lens, world=1)
-    shard = D.PackedShard(plan, 0, dev, slots=slots, scale=1)
-    sptr = C.c_void_p(stream.cuda_stream)                     # (the stream the plain scans ran on: streams share a few hardware queues)
-    pack_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-    scanned = [torch.cuda.Event() for _ in range(slots)]
-    packed = [torch.cuda.Event() for _ in range(slots)]
-    used = [False] * slots
-    in_ptr = buf.data_ptr()
-
-    def step(i):
-        j = i % slots
-        ps = pack_streams[j % 2]
-        if used[j]:
-            stream.wait_event(packed[j])
-        shard.scan(in_ptr, sptr, j)
-        scanned[j].record(stream)
-        with torch.cuda.stream(ps):
-            ps.wait_event(scanned[j])
-            shard.pack(C.c_void_p(ps.cuda_stream), j)
-            packed[j].record(ps)
-        used[j] = True
-
-    def settle_regions():
-        for _ in range(6):
-            for i in range(slots):
-                step(i)
-            torch.cuda.synchronize()
-            st = [shard.status(j) for j in range(slots)]
-            if any(x.flags & K_SHARD_SCAN for x in st):
-                for j in range(slots):
-                    shard.sync(j)
-            elif any(x.flags & K_SHARD_GROW for x in st):
-                shard.set_scale(shard.scale * 2)
-            else:
-                return st[0]
-        raise RuntimeError("scan_plus_block_calling: the message kept overflowing")
-
-    from teloscope_amd import _capi as K
-    K_SHARD_SCAN, K_SHARD_GROW = K.SHARD_OVERFLOW_SCAN, K.SHARD_OVERFLOW_VISIBLE | K.SHARD_OVERFLOW_BLOCKS
-    with torch.cuda.stream(stream):
-        st0 = settle_regions()
-        for i in range(3 * slots):
-            step(i)
-        torch.cuda.synchronize()
-        c0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        torch.cuda.synchronize()
-        overlapped = (time.perf_counter() - c0) / steps * 1e3
-        # serialised: scan, then block calling + pack, each waited for
-        t_scan = t_pack = 0.0
-        nb = min(10, steps)
-        for i in range(nb):
-            c0 = time.perf_counter()
-            shard.scan(in_ptr, sptr, 0)
-            torch.cuda.synchronize()
-            c1 = time.perf_counter()
-            shard.pack(sptr, 0)
-            torch.cuda.synchronize()
-            t_scan += c1 - c0
-            t_pack += time.perf_counter() - c1
-    rec = {"ms_per_step": round(overlapped, 4), "gbases_per_s": round(sum(lens) / overlapped / 1e6, 1), "steps": steps,
-           "emitting_scan_alone_ms": round(t_scan / nb * 1e3, 4), "block_calling_and_pack_alone_ms": round(t_pack / nb * 1e3, 4),
-           "plain_scan_ms_per_step": round(plain_ms, 4),
-           "blocks": int(st0.n_blocks), "visible_records": int(st0.n_visible), "message_bytes": int(shard.info.msg_bytes),
-           "what": "emitting scan + terminal / interstitial block calling on the device + packed message (bit-packed windows, visible "
-                   "records, blocks), %d buffer slots, pack beside the next scan; results stay in HBM" % slots}
-    shard.close()
-    plan.close()
-    return rec
-
-
-def reads_sub_record(args, dev):
-    """configs[3] in small inside the default line: 500 k synthetic HiFi reads (7.5 Gb) resident in HBM, whole-read tips
-    scan + terminal-block predicate on the device, one pass byte per read.  Roofline by SURVEY 8(d): 1 B per base + 1 bit
-    per read over the WHOLE step (scan and predicate; the match stream is an intermediate).  A sample is checked against
-    the oracle's ReadTelomereFilter::matches."""
-    import numpy as np
-    import torch
-    import teloscope_amd as ta
-    from teloscope_amd import _capi as K
-    from teloscope_amd.cli import parse_cli, user_input
-    from tests.backends import OracleReadFilter
-    opts = parse_cli(READ_FLAGS)
-    ui = user_input(opts, device=dev.index)
-    rf = ta.ReadTelomereFilter(ui)
-    L = K.lib()
-    n = 500_000
-    lens = read_lengths(n, 43)
-    bases = int(lens.sum())
-    arr = (C.c_uint64 * n)(*[int(x) for x in lens])
-    # two batch objects over the same reads: the predicate of step i (few registers, no LDS) runs on a stream of its own
-    # beside the scan of step i + 1, as bench.py --reads does with its sub-batches
-    nslots = 2
-    batches = []
-    for _ in range(nslots):
-        b = L.ts_batch_create(rf._ctx.ptr, arr, None, n, 1, bases // 8 + 4096)
-        if not b:
-            raise RuntimeError(rf._ctx.error())
-        batches.append(b)
-    info = K.BatchInfo()
-    L.ts_batch_get_info(batches[0], C.byref(info))
-    offs = np.concatenate(([0], np.cumsum((lens + 15) & ~15)))[:-1]
-    buf = torch.zeros(int(info.input_bytes), dtype=torch.uint8, device=dev)
-    carriers = fill_read_range(buf, lens, 0, n, dev)
-    d_passes = [torch.zeros(n + 16, dtype=torch.uint8, device=dev) for _ in range(nslots)]
-    stream = torch.cuda.current_stream()
-    sptr = C.c_void_p(stream.cuda_stream)
-    pred_stream = torch.cuda.Stream(device=dev)
-    pptr = C.c_void_p(pred_stream.cuda_stream)
-    scanned = [torch.cuda.Event() for _ in range(nslots)]
-    judged = [torch.cuda.Event() for _ in range(nslots)]
-    used = [False] * nslots
-
-    def step(i):
-        j = i % nslots
-        if used[j]:
-            stream.wait_event(judged[j])                           # the predicate that last read this slot's records
-        if L.ts_batch_scan(batches[j], C.c_void_p(buf.data_ptr()), sptr) != 0:
-            raise RuntimeError(rf._ctx.error())
-        scanned[j].record(stream)
-        pred_stream.wait_event(scanned[j])
-        if L.ts_batch_read_pass(batches[j], C.c_void_p(d_passes[j].data_ptr()), pptr) != 0:
-            raise RuntimeError(rf._ctx.error())
-        judged[j].record(pred_stream)
-        used[j] = True
-
-    def drain():
-        stream.wait_stream(pred_stream)
-        torch.cuda.synchronize()
-
-    def overflowed():
-        any_flag = False
-        for b in batches:
-            flag = C.c_int(0)
-            if L.ts_batch_read_pass_status(b, C.byref(flag)) != 0:
-                raise RuntimeError(rf._ctx.error())
-            any_flag = any_flag or bool(flag.value)
-        return any_flag
-
-    steps = 6
-    sec = None
-    for attempt in range(3):
-        for i in range(nslots):
-            step(i)
-        drain()
-        for b in batches:
-            if L.ts_batch_sync(b) != 0:                            # (grows the record regions and rescans if the scan overflowed)
-                raise RuntimeError(rf._ctx.error())
-        overflowed()
-        for i in range(nslots):
-            step(i)
-        drain()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        drain()
-        sec = (time.perf_counter() - t0) / steps
-        if not overflowed():
-            break
-    else:
-        raise RuntimeError("the read batch kept overflowing its record regions")
-    for b in batches:
-        if L.ts_batch_sync(b) != 0:
-            raise RuntimeError(rf._ctx.error())
-    L.ts_batch_get_info(batches[0], C.byref(info))
-    d_pass = d_passes[(steps - 1) % nslots]
-    assert all(bool(torch.equal(d_passes[0][:n], x[:n])) for x in d_passes[1:]), "the slots' pass bytes differ"
-    got = d_pass[:n].cpu().numpy()
-    assert got[carriers].all(), "a read with a planted terminal telomere tract was not kept"
-    sample = sorted(set(range(150)) | set(int(i) for i in carriers[:100]))
-    host = {i: bytes(buf[int(offs[i]):int(offs[i]) + int(lens[i])].cpu().numpy()) for i in sample}
-    want = OracleReadFilter(opts).filter([host[i] for i in sample])
-    assert [bool(got[i]) for i in sample] == want, "oracle and HIP read filter disagree on the sample"
-    alg = bases + (n + 7) // 8
-    out = {"workload": "configs[3] at %d reads (%s; lengths N(15000, 3000^2) clipped to [1000, 40000], 0.5 %% with a terminal tract), "
-                       "resident in HBM -> one pass byte per read in HBM" % (n, READ_FLAGS),
-           "reads": n, "bases": bases, "steps": steps, "ms_per_step": round(sec * 1e3, 4), "gbases_per_s": round(bases / sec / 1e9, 3),
-           "reads_per_s": round(n / sec, 1), "kept": int(got.sum()), "planted_carriers": int(len(carriers)),
-           "oracle_checked_reads": len(sample),
-           "roofline": {"bound": "hbm", "achieved": round(alg / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg,
-                        "over": "the whole step: tips scan (%.3f ms alone, HIP events) + predicate; the predicate of step i runs on a "
-                                "second stream beside the scan of step i + 1 (two batch objects)" % float(info.avg_kernel_ms)}}
-    for b in batches:
-        L.ts_batch_destroy(b)
-    del buf
-    torch.cuda.empty_cache()
-    return out
-
-
-def run_reads(args, rank, local_rank, world, dev, backend):
-    """configs[3]: --fastq-subset -l 42 on synthetic HiFi reads (~15 kb), the reads dealt to the ranks in consecutive
-    shards of equal count (the reference deals a batch's records to its workers in chunks and writes the chunk
-    outputs in chunk order, src/input.cpp:753-812); the only exchange is one gather of the pass bytes, in input
-    order, to rank 0.  `value` = resident rate (reads in HBM -> pass bytes in HBM [-> rank 0]); the streaming
-    PCIe-inclusive rate through ts_filter_reads is reported beside it."""
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    import teloscope_amd as ta
-    from teloscope_amd import _capi as K
-    from teloscope_amd.cli import parse_cli, user_input
-
-    opts = parse_cli(READ_FLAGS)
-    ui = user_input(opts, device=dev.index)
-    rf = ta.ReadTelomereFilter(ui)
-    L = K.lib()
-    n_total = int(args.n_reads)
-    lo, hi = rank * n_total // world, (rank + 1) * n_total // world       # this rank's shard of the reads
-    all_lens = read_lengths(n_total, 43)
-    lens = all_lens[lo:hi]
-    stream = torch.cuda.current_stream()
-    sptr = C.c_void_p(stream.cuda_stream)
-    xdev = dev if backend == "nccl" else torch.device("cpu")
-
-    # resident sub-batches of <= 500 k reads (~7.5 Gb each): input, match stream and pass bytes stay in HBM
-    sub = 500_000
-    batches = []
-    for a in range(0, len(lens), sub):
-        sl = lens[a:a + sub]
-        n = len(sl)
-        arr = (C.c_uint64 * n)(*[int(x) for x in sl])
-        b = L.ts_batch_create(rf._ctx.ptr, arr, None, n, 1, int(sl.sum()) // 8 + 4096)
-        if not b:
-            raise RuntimeError(rf._ctx.error())
-        info = K.BatchInfo()
-        L.ts_batch_get_info(b, C.byref(info))
-        offs = np.concatenate(([0], np.cumsum((sl + 15) & ~15)))[:-1]
-        buf = torch.zeros(int(info.input_bytes), dtype=torch.uint8, device=dev)
-        carriers = fill_read_range(buf, all_lens, lo + a, lo + a + n, dev)
-        batches.append(dict(b=b, n=n, buf=buf, lens=sl, offs=offs, carriers=carriers,
-                            d_pass=torch.zeros(n + 16, dtype=torch.uint8, device=dev)))
-    my_bases = int(lens.sum())
-    total_bases = int(all_lens.sum())
-    max_n = max((rank_hi - rank_lo) for rank_lo, rank_hi in ((r * n_total // world, (r + 1) * n_total // world) for r in range(world)))
-    pass_local = torch.zeros(max_n, dtype=torch.uint8, device=dev)
-    gathered = [torch.zeros(max_n, dtype=torch.uint8, device=xdev) for _ in range(world)] if (world > 1 and rank == 0) else None
-
-    # Two streams: the predicate of sub-batch i (no LDS, 64 VGPRs) runs beside the tips scan of sub-batch i + 1 (a persistent
-    # kernel that leaves wave slots and a fifth of the issue cycles free), as it does between the stages of ts_filter_reads.
-    pred_stream = torch.cuda.Stream(device=dev)
-    pptr = C.c_void_p(pred_stream.cuda_stream)
-    for e in batches:
-        e["scanned"] = torch.cuda.Event()
-        e["judged"] = torch.cuda.Event()
-    overlap = [True]
-
-    def step(_i=0):
-        at = 0
-        for e in batches:
-            if overlap[0]:
-                stream.wait_event(e["judged"])                   # the last predicate over this sub-batch's records is done
-            if L.ts_batch_scan(e["b"], C.c_void_p(e["buf"].data_ptr()), sptr) != 0:
-                raise RuntimeError(rf._ctx.error())
-            if overlap[0]:
-                e["scanned"].record(stream)
-                pred_stream.wait_event(e["scanned"])
-            if L.ts_batch_read_pass(e["b"], C.c_void_p(e["d_pass"].data_ptr()), pptr if overlap[0] else sptr) != 0:
-                raise RuntimeError(rf._ctx.error())
-            with torch.cuda.stream(pred_stream if overlap[0] else stream):
-                pass_local[at:at + e["n"]] = e["d_pass"][:e["n"]]
-            if overlap[0]:
-                e["judged"].record(pred_stream)
-            at += e["n"]
-        # No join of the two streams at the end of a pass: the next pass's first scans run beside this pass's last predicates,
-        # as the groups of ts_filter_reads do (a sub-batch's scan only waits for the predicate over its own records: "judged").
-        if world > 1:                                            # the 1-byte-per-read gather, in input order, behind the predicates
-            with torch.cuda.stream(pred_stream if overlap[0] else stream):
-                dist.gather(pass_local if backend == "nccl" else pass_local.cpu(), gathered, dst=0)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def any_overflow():
-        """Did a predicate since the last call find its scan overflowed (ts_batch_read_pass_status)?  Agreed over the ranks."""
-        over = 0
-        for e in batches:
-            flag = C.c_int(0)
-            if L.ts_batch_read_pass_status(e["b"], C.byref(flag)) != 0:
-                raise RuntimeError(rf._ctx.error())
-            over |= flag.value
-        t = torch.tensor([over], dtype=torch.int32, device=xdev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return bool(int(t.item()))
-
-    tmax = None
-    for attempt in range(3):
-        for _ in range(max(1, args.warmup)):
-            step()
-        for e in batches:                                        # (a sync grows a match buffer that overflowed, and rescans)
-            if L.ts_batch_sync(e["b"]) != 0:
-                raise RuntimeError(rf._ctx.error())
-        step()
-        barrier()
-        any_overflow()                                           # (what the warm-up raised is dealt with: the syncs regrew)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        tmax = float(t.item())
-        # tiles are taken on demand, so a wave's record count differs from pass to pass: a timed pass whose scan overflowed a
-        # region judged nothing — the measurement is repeated after the regions have been regrown
-        if not any_overflow():
-            break
-    else:
-        raise RuntimeError("the read batches kept overflowing their record regions")
-
-    # the tips kernel's own time, for the roofline: one more pass with nothing beside it (the syncs harvest the event times
-    # of the scans since the sync before: first those of the timed, overlapped loop, then this pass's)
-    for e in batches:
-        if L.ts_batch_sync(e["b"]) != 0:
-            raise RuntimeError(rf._ctx.error())
-    overlap[0] = False
-    torch.cuda.synchronize()
-    step()
-    torch.cuda.synchronize()
-    overlap[0] = True
-    kern_ms = alg = nm = launches = 0
-    for e in batches:
-        if L.ts_batch_sync(e["b"]) != 0:
-            raise RuntimeError(rf._ctx.error())
-        info = K.BatchInfo()
-        L.ts_batch_get_info(e["b"], C.byref(info))
-        kern_ms += float(info.avg_kernel_ms)
-        launches += int(info.kernel_launches)
-        alg += int(info.algorithmic_bytes)
-        nm += int(info.n_matches)
-    kept_local = int(pass_local[:len(lens)].sum().item())
-    n_carriers = int(sum(len(e["carriers"]) for e in batches))
-    # every read that carries a planted terminal tract of >= 300 b must pass; (a random 15 kb read passes with negligible probability)
-    at = 0
-    for e in batches:
-        got = e["d_pass"][:e["n"]].cpu().numpy()
-        assert got[e["carriers"]].all(), "a read with a planted terminal telomere tract was not kept"
-        at += e["n"]
-
-    assert not any_overflow(), "the verification pass overflowed its record regions"
-    if rank == 0:
-        shard_sizes = [(r + 1) * n_total // world - r * n_total // world for r in range(world)]
-        all_pass = pass_local[:len(lens)].cpu().numpy() if world == 1 else \
-            np.concatenate([gathered[r][:shard_sizes[r]].cpu().numpy() for r in range(world)])
-        kept = int(all_pass.sum())
-        sec = tmax / args.steps
-        achieved = alg / (kern_ms * 1e-3) / 1e9
-        out = {
-            "metric": "Gbases/s filtered (whole node), --fastq-subset -l 42 on synthetic ~15 kb HiFi reads",
-            "value": round(total_bases / sec / 1e9, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(sec * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[3] at %d reads: %s, lengths N(15000, 3000^2) clipped to [1000, 40000], seed 43, 0.5 %% of the reads with a "
-                                   "300-8000 b terminal tract; %d patterns k=%d" % (n_total, READ_FLAGS, len(ui.patternInfo), len(ui.patternInfo[0][0])),
-                       "reads": n_total, "reads_per_s": round(n_total / sec, 1), "bases": total_bases, "kept": kept,
-                       "planted_carriers_rank0": n_carriers, "matches_rank0": nm,
-                       "timed_region": "reads resident in HBM -> whole-read tips scan + terminal-block predicate on the device -> one pass byte "
-                                       "per read in HBM" + (" -> one gather of the pass bytes to rank 0" if world > 1 else "")
-                                       + "; the predicate of sub-batch i runs beside the scan of sub-batch i + 1 (two streams); roofline.kernel_ms is "
-                                         "the tips kernel alone, from a pass without that overlap"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "ts_scan_tiles (tips mode, rank 0's reads)", "kernel_ms": round(kern_ms, 4), "launches_timed": launches,
-                         "algorithmic_bytes": alg},
-        }
-        import hashlib
-        out["config"]["pass_bytes_sha1"] = hashlib.sha1(all_pass.tobytes()).hexdigest()     # (the same for any number of ranks)
-        if args.verify:
-            # a sample over the WHOLE read set — the first reads and the last ones, wherever they were filtered — against
-            # the oracle's ReadTelomereFilter::matches (the last chunk is generated again here)
-            from tests.backends import OracleReadFilter
-            orf = OracleReadFilter(opts)
-            checked = 0
-            for g0, g1 in ((0, min(n_total, 3000)), (max(0, n_total - 3000), n_total)):
-                pad = (all_lens[g0:g1] + 15) & ~15
-                o = np.concatenate(([0], np.cumsum(pad)))
-                tmpb = torch.zeros(int(o[-1]) + 64, dtype=torch.uint8, device=dev)
-                car = fill_read_range(tmpb, all_lens, g0, g1, dev)
-                pick = sorted(set(range(0, g1 - g0, 40)) | set(int(i) for i in car))
-                hostb = tmpb.cpu().numpy()
-                seqs = [bytes(hostb[int(o[i]):int(o[i]) + int(all_lens[g0 + i])]) for i in pick]
-                assert [bool(all_pass[g0 + i]) for i in pick] == orf.filter(seqs), "oracle and the gathered pass bytes disagree"
-                checked += len(pick)
-            out["verify"] = {"reads_checked_against_oracle": checked, "where": "the first and the last 3000 reads of the set (every 40th + every carrier)"}
-        # streaming, PCIe-inclusive: host reads through ts_filter_reads (groups pipelined through upload / scan / predicate);
-        # a pool of 200 k host reads is cycled, so that any read count streams through bounded host memory
-        e = batches[0]
-        npool = min(200_000, e["n"])
-        host = e["buf"][:int(e["offs"][npool - 1] + e["lens"][npool - 1])].cpu().numpy()
-        ptrs = (C.c_char_p * npool)()
-        base = host.ctypes.data
-        for i in range(npool):
-            ptrs[i] = C.cast(C.c_void_p(base + int(e["offs"][i])), C.c_char_p)
-        hl = (C.c_uint64 * npool)(*[int(x) for x in e["lens"][:npool]])
-        hp = (C.c_uint8 * npool)()
-        pool_bases = int(e["lens"][:npool].sum())
-        rounds = max(1, min(25, int(round(n_total / world / npool))))
-        assert L.ts_filter_reads(rf._ctx.ptr, ptrs, hl, npool, hp) == 0, rf._ctx.error()        # warm: pool, pinned rings
-        assert bytes(hp) == bytes(e["d_pass"][:npool].cpu().numpy().tobytes()), "streaming and resident filters disagree"
-        c0 = time.perf_counter()
-        for _ in range(rounds):
-            if L.ts_filter_reads(rf._ctx.ptr, ptrs, hl, npool, hp) != 0:
-                raise RuntimeError(rf._ctx.error())
-        dt = time.perf_counter() - c0
-        out["pcie_inclusive"] = {"host_placement": ("process and library threads on NUMA node %d, the GPU's" % HOST_NUMA_NODE
-                                                    if HOST_NUMA_NODE is not None else "not bound to a NUMA node"),
-                                 "entry_point": "ts_filter_reads (pageable host reads in, pass bytes out; groups of ~256 MB pipelined)",
-                                 "reads": rounds * npool, "seconds": round(dt, 4), "reads_per_s": round(rounds * npool / dt, 1),
-                                 "gbases_per_s": round(rounds * pool_bases / dt / 1e9, 3),
-                                 "note": "a pool of %d host reads filtered %d times on one GPU" % (npool, rounds)}
-        if world == 1 and not args.no_cpu_baseline:
-            from concurrent.futures import ThreadPoolExecutor
-            from tests.backends import OracleReadFilter
-            cores = max(1, os.cpu_count() or 1)
-            per = 600                                             # reads per core: ~9 Mb each, ~10-30 s of CPU work in all
-            take = min(npool, per * cores)
-            seqs = [bytes(host[int(e["offs"][i]):int(e["offs"][i]) + int(e["lens"][i])]) for i in range(take)]
-            filt = [OracleReadFilter(opts) for _ in range(cores)]
-            share = -(-take // cores)
-
-            def job(ci):
-                return filt[ci].filter(seqs[ci * share:(ci + 1) * share])
-            c0 = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=cores) as ex:
-                res = [x for part in ex.map(job, range(cores)) for x in part]
-            tn = time.perf_counter() - c0
-            assert res == [bool(x) for x in hp[:take]], "oracle and HIP read filter disagree on the sample"
-            sb = sum(len(x) for x in seqs)
-            out["cpu_baseline"] = {"value": round(sb / tn / 1e9, 5), "unit": "Gbases/s", "cores": cores, "kind": "port",
-                                   "calibrated_against_reference": False,
-                                   "sample": "%d of the same reads (%.0f Mb), ReadTelomereFilter::matches through the oracle port, one chunk of "
-                                             "reads per thread as the reference's -j N does; %.1f s wall; identical pass bits"
-                                             % (take, sb / 1e6, tn)}
-        print(json.dumps(out), flush=True)
-    for e in batches:
-        L.ts_batch_destroy(e["b"])
-    barrier()
-
-
-def bind_to_gpu_node(dev_index):
-    """One process per GPU, on the CPUs of the NUMA node the GPU hangs off (what `numactl --cpunodebind` does for a rank):
-    on a two-socket host a pageable buffer or a staging thread on the other socket costs 15-20 % of the PCIe-inclusive
-    rate.  Returns the node, or None when the topology cannot be read (then nothing is bound)."""
-    try:
-        import torch
-        p = torch.cuda.get_device_properties(dev_index)
-        bus = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
-        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
-        if node < 0 or os.environ.get("TS_NO_NUMA_BIND"):
-            return None
-        cpus = set()
-        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
-            a, _, b = part.partition("-")
-            cpus.update(range(int(a), int(b or a) + 1))
-        want = os.sched_getaffinity(0) & cpus
-        if not want:
-            return None
-        os.sched_setaffinity(0, want)
-        return node
-    except Exception:
-        return None
-
-
-HOST_NUMA_NODE = None
-ORIG_AFFINITY = None            # the CPUs the process was started with (before it bound itself to the GPU's NUMA node)
-SETTLE_LAUNCHES = 96            # untimed scans before the warm-up steps, see run_scan (profiles/summarize.py drops them too)
-
-
-def main():
-    global HOST_NUMA_NODE, ORIG_AFFINITY
-    args = parse_args()
-    ORIG_AFFINITY = os.sched_getaffinity(0)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))
-    ensure_built()                                              # before any GPU / torch.distributed call
-
-    import torch  # noqa: E402  (imported before libteloscan so both share one HIP runtime)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    ndev = max(1, torch.cuda.device_count())
-    dev_index = local_rank % ndev
-    # one rank per GPU over RCCL; "gloo" only to rehearse N > 1 where ranks have to share a GPU
-    backend = os.environ.get("TS_BENCH_BACKEND") or ("nccl" if ndev >= int(os.environ.get("LOCAL_WORLD_SIZE", world)) else "gloo")
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    HOST_NUMA_NODE = bind_to_gpu_node(dev_index)
-    # TS_BENCH_FORCE_STRONG=1: the N > 1 code path (shard object, export, exchange, adopt) with ONE rank on the RCCL group — as
-    # far as the sharded path can be taken on real RCCL where two ranks cannot share a GPU (rehearsal hook, not a bench mode)
-    forced = world == 1 and bool(os.environ.get("TS_BENCH_FORCE_STRONG"))
-    if forced:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(free_port()))
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-    if world > 1 or forced:
-        import torch.distributed as dist
-        import datetime
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
-        else:
-            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=600))
-    try:
-        if args.reads:
-            run_reads(args, rank, local_rank, world, dev, backend)
-        else:
-            run_scan(args, rank, local_rank, world, dev, backend)
-    finally:
-        if world > 1 or forced:
-            import torch.distributed as dist
-            dist.destroy_process_group()
-
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# The pieces live in benchlib/ (common, contigs, reads, verify, launcher); the names below are what tests and profile scripts take
+# from `import bench`.
+from benchlib.common import FLAGS, HBM_PEAK_GBS, READ_FLAGS, SETTLE_LAUNCHES  # noqa: E402,F401
+from benchlib.contigs import contig_lengths, fill_synthetic  # noqa: E402,F401
+from benchlib.reads import fill_read_range, read_lengths  # noqa: E402,F401
+from benchlib.launcher import main  # noqa: E402
 
 if __name__ == "__main__":
     main()

@@ -233,6 +233,11 @@ int     ts_box_probe(ts_ctx *ctx, double *valu_wave_instr_per_ns, double *copy_b
 /* 1 if segments of this kind (full scan / tips-only) may come as TS_INPUT_TEXT_PIECES or TS_INPUT_PACKED2: every parameter
  * set the library scans (until ABI 3 the general kernels wanted the bases joined). */
 int     ts_takes_text_input(const ts_ctx *ctx, int tips_only);
+/* The host entry points read a handful of measurement / test knobs from the environment (TS_TIMING, TS_PACKED_UPLOAD,
+ * TS_PACKED_MIN_BYTES, TS_STAGE_THREADS, TS_GEN_HOST_BLOCKS, TS_GEN_PREFETCH, TS_GEN_LIST, TS_GEN_ABL) ONCE, when the context
+ * is made — never per call.  This reads them again (tests and A/B scripts that flip one between two calls on one context).
+ * No counterpart in the reference (its options are fixed by main, /root/reference/src/main.cpp:149-184). */
+int     ts_refresh_env(ts_ctx *ctx);
 /* Restricts the CALLING thread (and the threads it starts from then on) to the CPUs of the NUMA node the context's
  * device is attached to; returns 1 if it did, 0 if the topology is unknown, the thread's mask holds none of those CPUs,
  * or TS_NO_NUMA_BIND is set.  The library's own pipeline threads do this by themselves; a front end calls it on the threads
@@ -462,6 +467,15 @@ int ts_batch_set_shard_scale(ts_batch *b, uint32_t scale);
 /* After ts_batch_scan, asynchronous on `stream`, no host synchronisation: block calling on the device and the packed
  * message at d_msg (device memory, msg_bytes >= ts_shard_info.msg_bytes). */
 int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stream);
+/* Optional, after ts_batch_restrict_shard: the message buffer (device memory, msg_bytes >= ts_shard_info.msg_bytes) the
+ * shard's scans will be packed into.  Knowing it, an emitting scan writes the records of the windows it owns straight into the
+ * message's window section in their bit-packed form (7 fields x bit_width(window) bits: what a writer reads of a WindowData,
+ * /root/reference/src/teloscope.cpp:785-812, /root/reference/include/teloscope.h:119-137) instead of 8 x uint32 per window
+ * that ts_batch_pack_shard then packs in a pass of its own: the pack has one kernel fewer and the scan stores a quarter of
+ * the bytes.  The 8 x uint32 records of such a scan are NOT produced (ts_batch_windows_ptr / ts_batch_download see none), and
+ * ts_batch_pack_shard must be given the same buffer (TS_ERR_STATE otherwise).  The message's bytes do not depend on it.
+ * d_msg == NULL unbinds; ts_batch_set_shard_scale unbinds (the message's size changes with the scale). */
+int ts_batch_bind_shard_message(ts_batch *b, void *d_msg, uint64_t msg_bytes);
 #define TS_SHARD_OVERFLOW_VISIBLE 0x1u   /* ts_shard_status.flags */
 #define TS_SHARD_OVERFLOW_BLOCKS  0x2u
 #define TS_SHARD_OVERFLOW_SCAN    0x4u   /* a wave's record region overflowed in the scan: ts_batch_sync, then pack again */

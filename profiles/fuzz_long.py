@@ -15,7 +15,7 @@ from tests.backends import BLOCK_FIELDS, OracleBackend, ProductBackend, assert_s
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 motifs = ["TTAGGG", "TTAGG", "CCCTAAA", "TTTTAGGG", "TTAGGGG", "TCAGG", "AAAAAA", "ACACAC", "TTAGGC", "TTAG", "TTA", "CCTA"]
-done = 0
+done = n_wide = 0
 for it in range(iters):
     c = motifs[int(rng.integers(0, len(motifs)))]
     w = int(rng.choice([len(c), 17, 64, 100, 333, 500, 1000, 2000, 5000, 12000, 30000]))
@@ -68,6 +68,7 @@ for it in range(iters):
                     assert np.array_equal(blk[f], e[name][f]), (cli, name, f, len(q))
             assert cnt[1] == len(e["fwd_matches"]) + len(e["rev_matches"]) and cnt[3] == len(e["fwd_matches"]), (cli, cnt)
     done += 1
+    n_wide += int(wide)
     if done % 20 == 0:
         print("fuzz: %d parameter sets ok" % done, flush=True)
-print("fuzz: all %d parameter sets equal the oracle" % done)
+print("fuzz: all %d parameter sets equal the oracle (%d wide: beyond 8 lengths / 32 bases)" % (done, n_wide))

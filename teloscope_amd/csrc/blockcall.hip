@@ -310,11 +310,11 @@ __device__ __forceinline__ SegView seg_view(const TsBlockCallParams &Q, const Ts
 }
 
 // Per segment: match / forward counts over all its tiles the batch scanned, and match / canonical / forward counts over its
-// OWNED tiles — five u64 per segment in `sums` (zero at launch).  One thread per tile; a wave whose tiles all belong to one
-// segment (nearly every wave) adds up first and issues five atomics.  No LDS (see exchange.hip).
-__global__ __launch_bounds__(kSideWg)
-void ts_segment_sums(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base, uint32_t ntiles, u64 *sums) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+// OWNED tiles — five u64 per segment: in `sums` (zero at launch), or, for a shard, straight in the segment's entry of the message
+// (seg_out, zeroed with the header).  One thread per tile; a wave whose tiles all belong to one segment (nearly every wave) adds
+// up first and issues five atomics.  No LDS (see exchange.hip).  Called by every thread of the wave (t >= ntiles: nothing to add).
+__device__ __forceinline__ void add_segment_sums(const TsBlockCallParams &Q, const TsShardSegIn *segs, uint32_t seg_base, uint32_t t,
+                                                 uint32_t ntiles, u64 *sums, TsShardSeg *seg_out) {
     uint32_t si = 0xFFFFFFFFu;
     u64 v[5] = {0, 0, 0, 0, 0};
     if (t < ntiles) {
@@ -324,62 +324,92 @@ void ts_segment_sums(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32
         if (t >= S.t0 && t < S.t1) { v[0] = st.x; v[1] = st.z; }
         if (t >= S.o0 && t < S.o1) { v[2] = st.x; v[3] = st.y; v[4] = st.z; }
     }
+    // where field f of segment s goes: sums[5 s + f], or the u64 of the segment's TsShardSeg that holds it ({fwd_boundary, rev_boundary,
+    // n_matches, n_canonical, n_forward, seen_matches, seen_forward}: f = 0, 1 are the seen counts, 2 .. 4 the owned ones)
+    u64 *const base = seg_out ? (u64 *)seg_out : sums;
+    const uint32_t stride = seg_out ? (uint32_t)(sizeof(TsShardSeg) / 8u) : 5u;
+    auto slot = [&](int f) -> uint32_t { return seg_out ? (f < 2 ? 5u + (uint32_t)f : (uint32_t)f) : (uint32_t)f; };
     const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)si);
     if (__ballot(si != s0) == 0ull) {
-        if (s0 == 0xFFFFFFFFu) return;
-        for (int f = 0; f < 5; ++f) {
-            u64 x = v[f];
-            for (int o = 32; o >= 1; o >>= 1) {
-                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), o);
-                x += ((u64)hi << 32) | lo;
+        if (s0 != 0xFFFFFFFFu) {
+            for (int f = 0; f < 5; ++f) {
+                u64 x = v[f];
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), o);
+                    x += ((u64)hi << 32) | lo;
+                }
+                if ((threadIdx.x & 63u) == 0u && x) atomicAdd(base + (u64)s0 * stride + slot(f), x);
             }
-            if ((threadIdx.x & 63u) == 0u && x) atomicAdd(&sums[5ull * s0 + f], x);
         }
     } else if (si != 0xFFFFFFFFu) {
         for (int f = 0; f < 5; ++f)
-            if (v[f]) atomicAdd(&sums[5ull * si + f], v[f]);
+            if (v[f]) atomicAdd(base + (u64)si * stride + slot(f), v[f]);
     }
 }
 
 __global__ __launch_bounds__(kSideWg)
-void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t nseg, u64 *bounds,
-                        TsShardSeg *seg_out, const u64 *sums) {
+void ts_segment_sums(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base, uint32_t ntiles, u64 *sums, TsShardSeg *seg_out) {
+    add_segment_sums(Q, segs, seg_base, blockIdx.x * blockDim.x + threadIdx.x, ntiles, sums, seg_out);
+}
+
+// Does the segment's view hold at least two records of a kind (which: 0 any, 1 forward, 2 reverse)?  The gates of
+// scanSegment's block calling (src/teloscope.cpp:646-653: fwdMatches.size() >= 2, revMatches.size() >= 2, allMatches.size()
+// >= 2), answered by the wave that needs it from the tile directory — 64 tiles per step, from the end the walk starts at,
+// until it knows: one step on any sequence with matches in it.  (Round 4 had a kernel add up every segment's totals first:
+// 28 us on the walks' critical path.)
+__device__ __forceinline__ bool view_has_two(const TsBlockCallParams &Q, const SegView &V, int which, bool from_end, uint32_t lane) {
+    const uint32_t nt = V.t1 - V.t0;
+    uint32_t acc = 0;
+    for (uint32_t b0 = 0; b0 < nt && acc < 2u; b0 += 64u) {
+        uint32_t v = 0;
+        if (b0 + lane < nt) {
+            const uint32_t t = from_end ? V.t1 - 1u - (b0 + lane) : V.t0 + b0 + lane;
+            const uint4 st = *(const uint4 *)&Q.tile_stats[4ull * t];
+            v = which == 0 ? st.x : which == 1 ? st.z : st.x - st.z;
+        }
+        const u64 two = __ballot(v >= 2u), one = __ballot(v == 1u);
+        acc = two ? 2u : acc + (uint32_t)__popcll(one);
+    }
+    return acc >= 2u;
+}
+
+__global__ __launch_bounds__(kSideWg)
+void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t nseg, u64 *bounds, TsShardSeg *seg_out) {
     // two independent waves per segment: wave 0 walks the forward list from the start, wave 1 the reverse list from the end.
     // A shard (seg_out != nullptr) walks a direction only when it owns that end of the segment; the bounds of the other end
     // are the widest possible, which the receiver checks against what the shard that did walk it reports (shard.cpp:
     // finalize).  No LDS, no barrier: the waves share nothing (see exchange.hip for why that matters).
     // (one-wave workgroups, two per segment: see kSideWg; blockIdx is uniform, so the walk's state machine — ballots, chain
     // state, the branch on the direction — stays in scalar registers)
+    // (the per-segment counts of a shard's message are added up elsewhere: ts_chain_screen / ts_segment_sums)
     const uint32_t si = blockIdx.x >> 1;
     if (si >= nseg) return;
     const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x & 1u;
     const TsShardSegIn S = segs[si];
     const SegView V = seg_view(Q, S);
     const u64 n = S.len;
-    const u64 total = sums[5ull * si], nfwd = sums[5ull * si + 1];
     uint32_t seq = 0;                                      // blocks are ordered by (direction, seq)
     if (wave == 0) {
         u64 fb = 0;
         bool ooc = false;
-        const bool walk = (S.flags & TS_SEG_F_HAS_START) && nfwd >= 2;
+        const bool walk = (S.flags & TS_SEG_F_HAS_START) && view_has_two(Q, V, 1, false, lane);
         if (walk) fb = terminal_direction(Q, V, S.seg, n, S.abs_pos, true, seq, lane, ooc);
         if (lane == 0) {
             bounds[2ull * si] = fb;
             if (seg_out) {
-                TsShardSeg &o = seg_out[si];
-                o.fwd_boundary = fb;
-                o.n_matches = sums[5ull * si + 2]; o.n_canonical = sums[5ull * si + 3]; o.n_forward = sums[5ull * si + 4];
-                o.seen_matches = total; o.seen_forward = nfwd;
-                atomicOr(&o.flags, (S.flags & (TS_SEG_F_HAS_START | TS_SEG_F_HAS_END)) | (walk ? TS_SEG_F_FWD_WALKED : 0u) | (ooc ? TS_SEG_F_CONTEXT : 0u));
+                seg_out[si].fwd_boundary = fb;
+                atomicOr(&seg_out[si].flags, (S.flags & (TS_SEG_F_HAS_START | TS_SEG_F_HAS_END)) | (walk ? TS_SEG_F_FWD_WALKED : 0u) | (ooc ? TS_SEG_F_CONTEXT : 0u));
             }
         }
     } else {
         u64 rb = n;
         bool ooc = false;
-        const bool walk = (S.flags & TS_SEG_F_HAS_END) && total - nfwd >= 2;
+        const bool two_rev = view_has_two(Q, V, 2, true, lane);
+        const bool walk = (S.flags & TS_SEG_F_HAS_END) && two_rev;
         if (walk) rb = terminal_direction(Q, V, S.seg, n, S.abs_pos, false, seq, lane, ooc);
+        const bool two_any = two_rev || view_has_two(Q, V, 0, true, lane);
         if (lane == 0) {
-            const u64 rb_out = total >= 2 ? rb : 0;        // 0 disables the interstitial search
+            const u64 rb_out = two_any ? rb : 0;           // 0 disables the interstitial search
             bounds[2ull * si + 1] = rb_out;
             if (seg_out) {
                 seg_out[si].rev_boundary = rb_out;
@@ -759,8 +789,10 @@ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs,
 // thousand is listed: the pass reads 3 MB instead of the 0.37 GB of records.
 __global__ __launch_bounds__(kSideWg)
 void ts_chain_screen(const TsBlockCallParams Q, const uint32_t *chain, const TsShardSegIn *segs, uint32_t seg_base,
-                     const u64 *bounds, uint32_t ntiles, uint32_t *work, uint32_t *n_work) {
+                     const u64 *bounds, uint32_t ntiles, uint32_t *work, uint32_t *n_work, TsShardSeg *seg_out) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    // (a shard: the per-segment counts of its message, from the same directory rows this thread reads anyway)
+    if (seg_out) add_segment_sums(Q, segs, seg_base, tile, ntiles, nullptr, seg_out);
     bool list = false;
     if (tile < ntiles) {
         const uint32_t cnt = Q.tile_stats[4u * tile];
@@ -888,16 +920,26 @@ int ts_k_launch_zero(void *p0, unsigned long long n0, void *p1, unsigned long lo
 // The two halves of block calling, for a caller that runs the terminal walks on a stream of their own (shard.cpp): the
 // walks are one latency-bound wave per segment end, and nothing but the interstitial search waits for them.
 int ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
-                         unsigned long long *bounds, TsShardSeg *seg_out, unsigned long long *sums, int prezeroed, void *stream) {
+                         unsigned long long *bounds, TsShardSeg *seg_out, void *stream) {
+    (void)seg_base; (void)ntiles;
+    if (nseg == 0) return 0;
+    hipLaunchKernelGGL(ts_terminal_blocks, dim3(2u * nseg), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, nseg, bounds, seg_out);
+    return (int)hipGetLastError();
+}
+
+// Per-segment totals {seen matches, seen forward, owned matches, owned canonical, owned forward}: into sums (5 x u64 per
+// segment, zeroed here unless prezeroed) or, seg_out != nullptr, into the segments' entries of a shard's message (zeroed by
+// the caller).  (A pack that screens by the scan's chain summaries does not need this: ts_chain_screen adds them up.)
+int ts_k_launch_segment_sums(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
+                             unsigned long long *sums, TsShardSeg *seg_out, int prezeroed, void *stream) {
     if (nseg == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (!prezeroed) {                                      // (a shard's pack zeroes everything it accumulates into with one kernel: ts_k_launch_zero)
+    if (!seg_out && !prezeroed) {
         hipError_t e = hipMemsetAsync(sums, 0, (size_t)nseg * 40, st);
         if (e != hipSuccess) return (int)e;
     }
     if (ntiles)
-        hipLaunchKernelGGL(ts_segment_sums, dim3((ntiles + kSideWg - 1u) / kSideWg), dim3(kSideWg), 0, st, *Q, segs, seg_base, ntiles, sums);
-    hipLaunchKernelGGL(ts_terminal_blocks, dim3(2u * nseg), dim3(kSideWg), 0, st, *Q, segs, nseg, bounds, seg_out, (const u64 *)sums);
+        hipLaunchKernelGGL(ts_segment_sums, dim3((ntiles + kSideWg - 1u) / kSideWg), dim3(kSideWg), 0, st, *Q, segs, seg_base, ntiles, sums, seg_out);
     return (int)hipGetLastError();
 }
 
@@ -915,7 +957,7 @@ int ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *seg
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL(ts_chain_screen, dim3((ntiles + kSideWg - 1u) / kSideWg), dim3(kSideWg), 0, (hipStream_t)stream, *Q, chain,
-                           segs, seg_base, (const u64 *)bounds, ntiles, work + 1, work);
+                           segs, seg_base, (const u64 *)bounds, ntiles, work + 1, work, seg_out);
         hipLaunchKernelGGL(ts_interstitial_listed, dim3(512), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, seg_base,
                            (const u64 *)bounds, ntiles, seg_out, (const uint32_t *)(work + 1), (const uint32_t *)work);
     } else {
@@ -930,7 +972,8 @@ int ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *seg
 int ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
                            uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its,
                            const TsVisibleOut *vis, unsigned long long *sums, const uint32_t *chain, uint32_t *work, void *stream) {
-    int e = ts_k_launch_terminal(Q, segs, nseg, seg_base, ntiles, bounds, seg_out, sums, 0, stream);
+    int e = ts_k_launch_terminal(Q, segs, nseg, seg_base, ntiles, bounds, seg_out, stream);
+    if (e == 0 && sums) e = ts_k_launch_segment_sums(Q, segs, nseg, seg_base, ntiles, sums, nullptr, 0, stream);
     if (e == 0 && (with_its || (vis && vis->off))) e = ts_k_launch_interstitial(Q, segs, nseg, seg_base, ntiles, bounds, seg_out, vis, chain, work, 0, stream);
     return e;
 }

@@ -80,6 +80,22 @@ constexpr uint32_t kMaxBlocksPerTile = 448;
 constexpr uint32_t kMaxChunks = 8;             // tiles up to ~16 k positions per wave
 constexpr uint32_t kTipsChunks = 6;            // tips-only / read batches: ~12 k positions per tile (measured on 15 kb reads: 2..8 chunks, TS_GEOMETRY)
 
+// The measurement / test knobs of the host entry points (ts_ctx::Knobs), from the environment: at ts_create and ts_refresh_env,
+// never per call.
+void read_env_knobs(ts_ctx *c) {
+    auto is = [](const char *name, char v) { const char *e = getenv(name); return e && e[0] == v; };
+    ts_ctx::Knobs k;
+    k.timing = getenv("TS_TIMING") != nullptr;
+    k.gen_host_blocks = is("TS_GEN_HOST_BLOCKS", '1');
+    k.gen_prefetch = !is("TS_GEN_PREFETCH", '0');
+    k.gen_list = !is("TS_GEN_LIST", '0');
+    if (const char *e = getenv("TS_GEN_ABL")) k.gen_abl = (uint32_t)atoi(e);
+    k.packed_upload = !is("TS_PACKED_UPLOAD", '0');
+    if (const char *e = getenv("TS_PACKED_MIN_BYTES")) k.packed_min_bytes = strtoull(e, nullptr, 10);
+    if (const char *e = getenv("TS_STAGE_THREADS")) { const int n = atoi(e); if (n > 0) k.stage_threads = (uint32_t)std::min(n, 64); }
+    c->knobs = k;
+}
+
 // diagnostics: TS_DEALT_TILES=1 keeps every scan on the round-robin tile assignment (A/B against on-demand tiles)
 bool ts_env_flag(const char *name) {
     const char *v = getenv(name);
@@ -140,7 +156,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     kp.kdist = P.max_match_dist;
     if (tips) {
         kp.halo_blocks = 0;
-        kp.straddle_fix = 0; kp.windows_on = 0; kp.nuc_on = 0; kp.block_sums = 0;
+        kp.straddle_fix = 0; kp.windows_on = 0; kp.nuc_on = 0; kp.block_sums = 0; kp.acc_blocks = 0;
     } else {
         const uint32_t s = P.step, w = P.window_size;
         kp.s = s; kp.w = w;
@@ -150,6 +166,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
         kp.windows_on = 1;
         kp.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u;
         kp.block_sums = (w % s == 0) ? 1u : 0u;
+        kp.acc_blocks = (kp.block_sums && !ts_env_flag("TS_ACC_PER_WINDOW")) ? 1u : 0u;      // (TS_ACC_PER_WINDOW=1: A/B)
     }
     // Search (waves per workgroup, chunks per tile) for the best modelled throughput:
     //   owned bases per tile x occupancy factor / instructions per tile.
@@ -193,6 +210,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
             cand.waves_per_wg = occ.waves;
             cand.wgs_per_cu = wgs;
             cand.nch = nch;
+            cand.stage_u16 = ((uint64_t)nch * TS_CHUNK + 64u <= (1u << 14) && !ts_env_flag("TS_STAGE_U32")) ? 1u : 0u;      // (position << 2 | flags) in 16 bits: the stage's entries (TS_STAGE_U32=1: A/B)
             const uint32_t span_max = nch * TS_CHUNK - 63u;
             uint32_t cwpt;
             if (tips) {
@@ -212,7 +230,7 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
             while (cand.acc_copies > 1 && (uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) cand.acc_copies >>= 1;
             if (cwpt < 1 || (uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) continue;
             {
-                const uint32_t spare = (kMaxLds - (uint32_t)ts_k_lds_bytes(&cand)) / occ.waves / 4u;
+                const uint32_t spare = (kMaxLds - (uint32_t)ts_k_lds_bytes(&cand)) / occ.waves / (cand.stage_u16 ? 2u : 4u);
                 cand.stage_cap = std::min<uint32_t>(pin_stage ? pin_stage : 1024u, 128u + (spare & ~15u));
                 while ((uint32_t)ts_k_lds_bytes(&cand) > kMaxLds) cand.stage_cap -= 16;
             }
@@ -223,7 +241,12 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
             // fewer accumulator copies serialise the window adds of a pass: 8 chunks with 2 copies measured 2.5 %
             // slower than 7 chunks with 4 on the headline configuration, where the model alone says 1 % faster
             const double copies = cand.acc_copies >= 4 ? 1.0 : cand.acc_copies == 2 ? 0.96 : 0.92;
-            const double score = (double)cwpt * cand.s * occ.factor * copies / (470.0 * nch + 170.0 * passes + 100.0);
+            // a stage that holds a tile of random sequence whole (its matches at the pattern set's density, + 15 % + most of a pass) lets
+            // the records leave once, at the tile's end; a smaller one flushes from inside the chunk loop, where a store sits in
+            // the memory queue ahead of the chunk loads that are waited for next
+            const double tile_records = (double)c->patterns.size() / (double)(1ull << (2 * std::min<uint32_t>(k, 16))) * (double)cwpt * cand.s;
+            const double whole = (double)cand.stage_cap >= 1.15 * tile_records + 48.0 ? 1.0 : 0.93;
+            const double score = (double)cwpt * cand.s * occ.factor * copies * whole / (470.0 * nch + 170.0 * passes + 100.0);
             if (score > best) { best = score; best_kp = cand; best_wpt = cwpt; }
         }
     }
@@ -519,6 +542,7 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
     ts_ctx *c = new ts_ctx();
     c->params = *params;
     c->read_filter = read_filter;
+    read_env_knobs(c);
     if (read_filter) {                                   // makeReadFilterInput, src/read-filter.cpp:10-30
         if (!min_block_len_set) c->params.min_block_len = 42;
         c->params.terminal_limit = std::numeric_limits<uint32_t>::max() / 2;
@@ -795,6 +819,13 @@ int ts_box_probe(ts_ctx *ctx, double *valu_wave_instr_per_ns, double *copy_bytes
     return TS_OK;
 }
 
+int ts_refresh_env(ts_ctx *ctx) {
+    if (!ctx) return TS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->api_mtx);          // (not under a running call)
+    read_env_knobs(ctx);
+    return TS_OK;
+}
+
 int ts_takes_text_input(const ts_ctx *ctx, int tips_only) {
     // (round 4: the general path stages its groups through the same upload as the tiled path — every format, every set)
     std::string why;
@@ -1020,6 +1051,20 @@ int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
     kp.vis_cap = b->vis_cap;
     kp.tile_zone = (const uint32_t *)b->d_zone.p;
     kp.tile_chain = (uint32_t *)b->d_chain.p;
+    // a shard whose message buffer is known (ts_batch_bind_shard_message): the emitting scan packs the owned windows' records
+    // into the message itself (the base is shifted back by what precedes the owned windows, never dereferenced there)
+    kp.win_packed = nullptr;
+    b->msg_windows = nullptr;
+    if (kp.emit && b->bound_msg && b->shard_parts && !b->tips && b->shard_r.own_hi > b->shard_r.own_lo && b->shard_L.window_bytes) {
+        const uint64_t w0 = b->tiles[b->shard_r.own_lo].win_out;
+        const TsTile &lastT = b->tiles[b->shard_r.own_hi - 1];
+        kp.win_pack_lo = w0;
+        kp.win_pack_hi = lastT.win_out + lastT.nwin;
+        kp.win_pack_bytes = b->shard_L.window_bytes;
+        kp.win_field_bits = b->shard_L.field_bits;
+        kp.win_packed = (uint8_t *)b->bound_msg + b->shard_L.off_windows - w0 * (uint64_t)b->shard_L.window_bytes;
+        b->msg_windows = b->bound_msg;
+    }
 
     const size_t slot = (size_t)(b->scan_seq % kEventRing);
     HIP_TRY(c, hipEventRecord(b->evs[2 * slot], st));
@@ -1552,6 +1597,7 @@ int batch_fetch(ts_batch *b, bool with_matches, PinBuf &pin, Fetched &F) {
     const size_t nt = b->tiles.size();
     hipStream_t st = (hipStream_t)b->last_stream;
     F.with_matches = with_matches;
+    if (b->msg_windows) return c->fail(TS_ERR_STATE, "the batch's scan packed its window records into a shard message (ts_batch_bind_shard_message): there are no 32-byte records to download");
     { int rc = device_block_call(b, st, F.blocks); if (rc != TS_OK) return rc; }
     const uint64_t nwin_dl = b->tips ? 0 : b->n_windows;
     const uint64_t nrecs = with_matches ? b->n_matches : 0;

@@ -125,6 +125,15 @@ struct ts_ctx {
     mutable std::mutex mtx;         // guards batch planning / launches that read the context's tables
     mutable std::string error;
     bool read_filter = false;
+    // measurement / test knobs of the host entry points, read from the environment ONCE, when the context is made (never per call):
+    // TS_TIMING (stage times to stderr), TS_GEN_HOST_BLOCKS=1 (general path: block calling on the host), TS_GEN_PREFETCH=0,
+    // TS_GEN_LIST=0 (general path: the strided form), TS_GEN_ABL (profiling mask of the general kernels)
+    // TS_PACKED_UPLOAD=0 (bases cross PCIe as ASCII), TS_PACKED_MIN_BYTES (calls below it go plain), TS_STAGE_THREADS
+    struct Knobs {
+        bool timing = false, gen_host_blocks = false, gen_prefetch = true, gen_list = true, packed_upload = true;
+        uint32_t gen_abl = 0, stage_threads = 0;
+        uint64_t packed_min_bytes = 1u << 20;                 // small calls are latency, not link time: they go plain
+    } knobs;
     BufferPool pool;
     // host-buffer entry points (pipeline.cpp): pinned staging rings and their streams
     // CPUs of the NUMA node the device is attached to (empty: unknown / TS_NO_NUMA_BIND): the pipeline's own threads run
@@ -220,6 +229,10 @@ struct ts_batch {
     DevBuf d_shard_segs, d_shard_bounds, d_shard_tmp, d_shard_cand;
     ShardRange shard_r{};
     ShardLayout shard_L{};
+    // ts_batch_bind_shard_message: the message buffer the shard's (emitting) scans pack their window records into themselves;
+    // msg_windows: the buffer the LATEST scan did so for (null: it wrote 8 x u32 per window, the pack's own kernel packs them)
+    void *bound_msg = nullptr;
+    const void *msg_windows = nullptr;
     // (ts_batch_pack_shard runs the terminal walks beside the counting / packing kernels on the CONTEXT's side stream: HIP
     // streams share a handful of hardware queues, and kernels of two streams on one queue run one after the other — a side
     // stream per batch, four buffer slots = four more streams, pushed the scan stream onto a shared queue)

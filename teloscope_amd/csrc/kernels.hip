@@ -48,6 +48,14 @@
 #ifndef TS_EXP
 #define TS_EXP 0
 #endif
+// (measurement) 1: the emitting build requests its next tile behind finish_records instead of ahead of the tile's last passes
+#ifndef TS_EMIT_LATE_REQUEST
+#define TS_EMIT_LATE_REQUEST 0
+#endif
+// (measurement: results are then wrong) 1: the rows are not looked at, 2: no visible records, 4: no chain summary
+#ifndef TS_EMIT_ABL
+#define TS_EMIT_ABL 0
+#endif
 
 // Wave priorities (s_setprio; the SIMD's arbiter picks the ready wave of the highest priority, the oldest among equals).
 // The dense per-chunk work (decode, probes: long runs of independent vector instructions) stays at 0; the phases that are
@@ -73,6 +81,7 @@ typedef unsigned long long u64;
 // LDS pointers are declared in their own address space so that indexing stays 32-bit arithmetic
 #define LDS __attribute__((address_space(3)))
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef LDS unsigned char lds_u8;
 typedef LDS uint16_t lds_u16;
 typedef LDS uint32_t lds_u32;
@@ -151,31 +160,30 @@ __host__ __device__ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15
 //           on full wavefronts
 //   rec     nucleotide counts {A, C, G, T}, 4 x u32 per step block of the tile (windows + halo) when w is a
 //           multiple of s (a window is the sum of w / s rows), else per window
-//   wacc    the match fields of the tile's window records while they accumulate: one u64 per window
+//   wacc    the match fields of the tile's window records while they accumulate: one u64 per step block (w a multiple of s:
+//           a window's fields are then the sum of its blocks' minus the matches that run over the end of its last block,
+//           which have a row of their own — ONE add per match instead of one per window that contains it) or per window
 //           = four 16-bit counters {canonical, non-canonical, forward, reverse}, bumped by ONE
 //           ds_add_u64 per (match, window); kept in acc_copies lane-interleaved copies so that the
 //           matches of a pass, which mostly fall into the same few windows, do not serialise on one
 //           address
-//   stage   packed match records waiting to leave in whole coalesced rows (and kept out of the
-//           chunk loads' counted vmcnt waits), + one spare slot per lane for predicated-off writes
-//   (rec, during phase 1, with P.emit)  the tile's VISIBLE records — canonical ones, and the others where the tile lies in
-//           its segment's terminal zone: what a writer reads (src/teloscope.cpp:486-496) — waiting to leave for vis_out
-struct SliceLayout { uint32_t codes, rec, wacc, stage, bytes; };
+//   stage   packed match records waiting to leave in whole coalesced rows at the tile's end (kept out of the
+//           chunk loads' counted vmcnt waits), 16 bits each when tile positions allow (P.stage_u16), + one spare slot per lane
+//           for predicated-off writes
+//   park    eight dwords of per-wave state of the emitting build that only the end of a tile touches (finish_records): kept here,
+//           not in scalar registers, so that the chunk loop of the emitting build is the plain build's
+struct SliceLayout { uint32_t codes, rec, wacc, stage, park, bytes; };
 
 __host__ __device__ inline SliceLayout slice_layout(const TsScanParams &P) {
     SliceLayout s;
     uint32_t o = 0;
     s.codes = o; o += align16((P.nch * 63u + 1u) * 8u);
-    {
-        // (with emit the region also stages the tile's visible records during phase 1 — the nucleotide rows are only
-        // assembled in phase 2, after the last of them has left — and holds at least the TS_VSTAGE_BYTES / 4 of them that
-        // one pass can produce)
-        uint32_t rb = (P.windows_on && P.nuc_on) ? align16((P.max_windows + P.halo_blocks) * 16u) : 0u;
-        if (P.windows_on && rb < TS_VSTAGE_BYTES) rb = TS_VSTAGE_BYTES;      // (whether or not this batch emits: one geometry)
-        s.rec = o; o += rb;
-    }
-    s.wacc = o; o += P.windows_on ? align16(P.max_windows * 8u * P.acc_copies) : 0u;
-    s.stage = o; o += (P.stage_cap + 64u) * 4u;
+    s.rec = o; o += (P.windows_on && P.nuc_on) ? align16((P.max_windows + P.halo_blocks) * 16u) : 0u;
+    // (per step block when w is a multiple of s: rows for the tile's windows + halo in every copy, then one row per block for
+    //  the matches that run over their block's end; else per window)
+    s.wacc = o; o += P.windows_on ? align16((P.max_windows + (P.acc_blocks ? P.halo_blocks : 0u)) * 8u * (P.acc_copies + (P.acc_blocks ? 1u : 0u))) : 0u;
+    s.stage = o; o += (P.stage_cap + 64u) * (P.stage_u16 ? 2u : 4u);
+    s.park = o; o += 32u;                                     // (whether or not this batch emits: one geometry)
     s.bytes = o;
     return s;
 }
@@ -228,7 +236,9 @@ void ts_scan_tiles(const TsScanParams P) {
     lds_u32 *rec = (lds_u32 *)(slice + SL.rec);
     lds_u32 *stage = (lds_u32 *)(slice + SL.stage);
     LDS u64 *wacc = (LDS u64 *)(slice + SL.wacc);
-    const uint32_t acc_off = (lane & (P.acc_copies - 1u)) * P.max_windows;     // this lane's copy of wacc
+    lds_u32 *park = (lds_u32 *)(slice + SL.park);          // EMIT: [4] the wave's visible cursor, [5] "this tile flushed from inside a pass" (finish_records)
+    const uint32_t acc_rows = P.max_windows + (P.acc_blocks ? P.halo_blocks : 0u);   // rows of one copy of wacc
+    const uint32_t acc_off = (lane & (P.acc_copies - 1u)) * acc_rows;          // this lane's copy of wacc
 
     const uint32_t k = P.k;
     const uint32_t rowbits = 2u * (k + 1u) - 4u;      // pair table: 4^(k+1) entries, 16 per dword
@@ -253,8 +263,7 @@ void ts_scan_tiles(const TsScanParams P) {
         return q;
     };
     uint32_t cursor = 0;                          // records this wave has produced so far
-    uint32_t vcursor = 0;                         // visible records this wave has produced so far (P.emit)
-    constexpr uint32_t vcap = TS_VSTAGE_BYTES / 4u;               // the stage of visible records: the head of the rec region (slice_layout), u32 entries
+    if (EMIT) { park[4] = 0u; park[5] = 0u; }     // [4] visible records this wave has produced so far, [5] tile mark (every lane writes the same words)
     const uint32_t nwper = P.halo_blocks + 1u;             // windows a position can belong to: ceil(w / s)
 
     // The first chunk of a tile is fetched while the previous tile's window phase runs (its loads would
@@ -315,48 +324,202 @@ void ts_scan_tiles(const TsScanParams P) {
         const uint32_t own_end = sh + T.own_len;                   // plane coord: positions [sh, own_end) are this tile's
         uint32_t done = 0, ccan = 0, cfwd = 0;                     // records of this tile so far, canonical / forward among them (uniform)
         uint32_t flushed = 0;                                      // how many of them have left the staging buffer
-        // ---- what the tile hands to block calling and to a shard's message (P.emit): its visible records, and the summary
-        // of its chains of matches (TsTileChain) that lets the interstitial search skip the tile without reading its records
-        uint32_t zone = TS_ZONE_NONE;                              // tile_zone word: first needed by the tile's first pass, a chunk pair away
-        if (EMIT) zone = tail_params()->tile_zone[tile];
-        uint32_t vfill = 0, vout = 0;                              // visible records of this tile on the stage / that have left it
-        // ch_last starts at 0: a first record more than -k behind the tile's first base is a head whatever lies ahead of the
-        // tile, and is treated as an internal one; a first record closer than that is not a head HERE — whether it opens a
-        // chain depends on the tile before, which the screening looks up (ts_chain_screen, blockcall.hip)
-        uint32_t ch_first = 0, ch_last = 0;                        // position of the tile's first (taken at its first flush) / latest record
-        uint32_t ch_cc = 0, ch_w1 = 0;                             // canonical records of the open chain; word 1 of the summary so far
-        auto flush_stage = [&]() {                                 // stage[0 .. done - flushed) -> wave_out[cursor + flushed ..)
+        // ---- The records of a tile wait in the stage — 16 bits each (position << 2 | flags < 2^16: P.stage_u16, every tiling of
+        // up to eight chunks) — and leave ONCE, at the tile's end: a store in the chunk loop sits in the memory queue ahead of the
+        // chunk loads that are waited for next (vmcnt counts in order), so a mid-tile flush is a stall; with 16-bit entries the stage
+        // holds a tile of random sequence whole (592 records at configs[1]'s geometry; a tile has 350 +- 19).  A tile with more
+        // (a telomere: a record every k bases) flushes from inside a pass when the stage is full, as before.
+        //
+        // What the tile hands to block calling and to a shard's message (EMIT): its VISIBLE records — the canonical ones, and
+        // every record where the tile lies in its segment's terminal zone: what a writer reads (src/teloscope.cpp:486-496) — and
+        // the summary of its chains of matches (TsTileChain) that lets the interstitial search skip the tile without reading its
+        // records.  Both are taken from the records AS THEY LEAVE at the tile's end (whole rows of 64 owned records in tile order, a
+        // record per lane), not in the per-match pass: the pass and the chunk loop are then the plain build's — with the emit
+        // state live through them the register allocator spilled 43 more scalars there (round 4: +17 % on configs[1]) — and all the
+        // state this needs lives for those few rows only.  A tile that flushed from inside a pass (marked: park[5]) is looked at
+        // from the wave's region of the output, which holds all its records by then.
+        // A record more than -k behind the record before it is a head (a first record more than -k behind the tile's first base
+        // is one whatever lies ahead of the tile: the latest position starts at 0; a closer one is not a head HERE — whether it
+        // opens a chain depends on the tile before, which the screening looks up: ts_chain_screen, blockcall.hip).
+        auto stage_at = [&](uint32_t i) -> uint32_t { return P.stage_u16 ? (uint32_t)((lds_u16 *)stage)[i] : stage[i]; };
+        auto flush_stage = [&]() {                                 // stage[0 .. done - flushed) -> wave_out[cursor + flushed ..), from inside a pass
             __builtin_amdgcn_wave_barrier();
             const uint32_t n = done - flushed;
-            if (EMIT && flushed == 0u && n != 0u) ch_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)stage[0]) >> 2;   // the tile's first record
             KernArgs Q = tail_params();
             const uint32_t cap = Q->region_cap;
             uint32_t *const wave_out = Q->matches_out + (u64)gw * cap;
             for (uint32_t i = lane; i < n; i += 64u) {
                 const uint32_t o = cursor + flushed + i;
-                if (o < cap && !(TS_ABL & 1)) wave_out[o] = stage[i];
+                if (o < cap && !(TS_ABL & 1)) wave_out[o] = stage_at(i);
             }
+            if (EMIT) park[5] = 1u;                                // (every lane writes the same word)
+            // (the stores are waited for here, where a dense tile pays for it, so that the compiler knows of no pending store whose
+            // registers the code after the chunk loop reuses: it protected those with a vmcnt(0) at the start of finish_records, which
+            // was also a wait for the next tile's first chunk and the ticket's atomic — a memory round trip per tile, dense or not)
+            __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
             __builtin_amdgcn_wave_barrier();
             flushed = done;
         };
-        auto flush_vis = [&]() {                                   // rec[0 .. vfill) -> the wave's region of vis_out
+        // the tile's end: what is left in the stage leaves, and (EMIT) every record of the tile is looked at on its way
+        uint32_t tile_vis = 0;                                     // EMIT: visible records of the tile (set by finish_records)
+        auto finish_records = [&]() {
             __builtin_amdgcn_wave_barrier();
             KernArgs Q = tail_params();
-            const uint32_t cap = Q->vis_cap;
-            const uint32_t at = vcursor + vout;
-            const u64 base = (u64)gw * cap + at;
-            for (uint32_t i = lane; i < vfill; i += 64u) {
-                if (at + i < cap) {
-                    if (Q->vis_wide) ((uint32_t *)Q->vis_out)[base + i] = rec[i];
-                    else ((uint16_t *)Q->vis_out)[base + i] = (uint16_t)rec[i];
+            const uint32_t cap = Q->region_cap;
+            uint32_t *const wave_out = Q->matches_out + (u64)gw * cap;
+            // (a lane id the compiler cannot see through: what the rows derive from it — LDS and output addresses, masks — is
+            // then computed here, per tile, instead of being kept in registers through the chunk loop, which has none to spare)
+            uint32_t ln = lane;
+            asm volatile("" : "+v"(ln));
+            uint32_t n = done - flushed;
+            bool redo = false;
+            if (EMIT) redo = __builtin_amdgcn_readfirstlane((int)park[5]) != 0;
+            if (!EMIT || redo) {
+                for (uint32_t i = ln; i < n; i += 64u) {
+                    const uint32_t o = cursor + flushed + i;
+                    if (o < cap && !(TS_ABL & 1)) wave_out[o] = stage_at(i);
+                }
+                flushed = done;
+                if (!EMIT) return;
+                // the whole tile again, from the region.  The loads below must find the stores above: same wave, same L2 — the
+                // stores have been acknowledged (vmcnt) before the loads are issued, and the loads bypass the CU's non-coherent L1
+                // (agent-scope atomic loads).
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                park[5] = 0u;
+                n = done;
+            }
+            const uint32_t base = redo ? 0u : flushed;             // index (in the tile) of row 0's first record
+            uint32_t ch_first = 0, ch_last = 0, ch_cc = 0, ch_w1 = 0, vout = 0;
+            const uint32_t vbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)park[4]);   // the wave's visible cursor
+            // (a scalar load — the table is written by the host only — not a vector one, whose wait (vmcnt) is also a wait for the next
+            // tile's first chunk, in flight since the end of phase 1, and for every store ahead of it)
+            typedef const uint32_t __attribute__((address_space(4))) *ConstU32;
+            const uint32_t zone = ((ConstU32)(uintptr_t)Q->tile_zone)[tile];
+            const uint32_t vis_cap = Q->vis_cap;
+            const bool wide = Q->vis_wide != 0u;
+            void *const vis_out = Q->vis_out;
+            const u64 vwave = (u64)gw * vis_cap;
+            const uint32_t kdist = P.kdist;
+            // what a row of up to 64 records (a record per lane, r = 0 in the lanes behind it) adds to the tile's visible records and
+            // to its chain summary
+            auto look = [&](const uint32_t r, const uint32_t nrow, const uint32_t i0) {
+                const uint32_t u = r >> 2;                                 // position in the tile
+                const u64 live_m = low_bits(nrow);
+                const u64 canm = ballot64((r & 1u) != 0u);                  // (the lanes behind the row hold 0)
+                if (i0 == 0u) ch_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);   // the tile's first record
+                // ---- visible records: the canonical ones, and every record where the tile lies in the terminal zone
+                {
+                    u64 vm = canm;
+                    if (zone != TS_ZONE_NONE) vm = live_m & (canm | ballot64(u < (zone & 0xFFFFu)) | ballot64(u >= (zone >> 16)));
+                    if (vm != 0ull && !(TS_EMIT_ABL & 2)) {
+                        const uint32_t at = vbase + vout + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
+                        if (__builtin_amdgcn_inverse_ballot_w64(vm) && at < vis_cap) {
+                            if (wide) ((uint32_t *)vis_out)[vwave + at] = r;
+                            else ((uint16_t *)vis_out)[vwave + at] = (uint16_t)r;
+                        }
+                        vout += (uint32_t)__popcll(vm);
+                    }
+                }
+                // ---- chains.  All a row keeps is the canonical count of the chain that is open at its end (ch_cc) and, until
+                // the tile's first head, the count ahead of it.  A row without a canonical record and with none carried in (a
+                // third of them) changes neither.
+                const uint32_t ncan = (uint32_t)__popcll(canm);
+                const uint32_t t = ch_cc + ncan;
+                if ((t | (~ch_w1 & TS_CHAIN_HEADS)) != 0u && !(TS_EMIT_ABL & 4)) {            // (integer logic: a uniform bool costs three scalar instructions to combine)
+                    // the lane below holds the record before, lane 0 gets the last record of the row before
+                    uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp((int)ch_last, (int)u, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps ch_last
+                    asm volatile("" : "+v"(below));            // (kept a v_mov_b32_dpp: see lane_below)
+                    const u64 H = live_m & ballot64(u - below > kdist);
+                    if (__builtin_expect(t >= 4u, 0)) {
+                        // a chain that ends in this row may hold the four canonical records a block needs: the exact look
+                        if (H != 0ull) {
+                            const u64 ahead = ~H & (H - 1ull);                      // the lanes below the first head
+                            const uint32_t top_head = 63u - (uint32_t)__builtin_clzll(H);
+                            const u64 below_top = low_bits(top_head);
+                            // the chain carried into the row ends at the first head
+                            const uint32_t carry = ch_cc + (uint32_t)__popcll(canm & ahead);
+                            if (!(ch_w1 & TS_CHAIN_HEADS)) ch_w1 |= carry < 0x7FFFu ? carry : 0x7FFFu;
+                            else if (carry >= 4u) ch_w1 |= TS_CHAIN_INNER;
+                            // chains that start and end inside the row: looked at only when they hold four canonical records between them
+                            if (__popcll(canm & ~ahead & below_top) >= 4) {
+                                const u64 above = ln < 63u ? H >> (ln + 1u) : 0ull;
+                                const uint32_t next = above ? ln + 1u + (uint32_t)__builtin_ctzll(above) : 64u;   // the next head's lane
+                                const bool mine4 = __popcll(canm & low_bits(next) & ~low_bits(ln)) >= 4;
+                                if (ballot64(((H >> ln) & 1ull) && ln != top_head && mine4) != 0ull) ch_w1 |= TS_CHAIN_INNER;
+                            }
+                            ch_w1 |= TS_CHAIN_HEADS;
+                            ch_cc = (uint32_t)__popcll(canm & ~below_top);
+                        } else {
+                            ch_cc = t;
+                        }
+                    } else {
+                        // Fewer than four (nearly every row): nothing to saturate, no chain to flag.  Until the tile's first
+                        // head: the canonical count ahead of it, ch_cc + popcount(canm below H's lowest bit), and the HEADS flag,
+                        // into ch_w1.  Always: ch_cc = canonical records from H's highest bit on, or t when the row has no head.
+                        // Written out for the scalar unit (the compiler's version of these seven lines came to forty
+                        // instructions, every combination of two uniform conditions materialised as a 64-bit mask):
+                        uint32_t tmp;
+                        u64 m;
+                        asm volatile("s_bitcmp1_b32 %[w1], 15\n\t"
+                                     "s_cbranch_scc1 .Lts_cq%=\n\t"
+                                     "s_cmp_eq_u64 %[H], 0\n\t"
+                                     "s_cbranch_scc1 .Lts_cq%=\n\t"
+                                     "s_ff1_i32_b64 %[tmp], %[H]\n\t"
+                                     "s_lshl_b64 %[m], -1, %[tmp]\n\t"
+                                     "s_andn2_b64 %[m], %[canm], %[m]\n\t"
+                                     "s_bcnt1_i32_b64 %[tmp], %[m]\n\t"
+                                     "s_add_i32 %[tmp], %[tmp], %[cc]\n\t"
+                                     "s_or_b32 %[w1], %[w1], %[tmp]\n\t"
+                                     "s_bitset1_b32 %[w1], 15\n"
+                                     ".Lts_cq%=:\n\t"
+                                     "s_flbit_i32_b64 %[tmp], %[H]\n\t"          // (-1 without a head: the shift below is then 0 and t is taken anyway)
+                                     "s_xor_b32 %[tmp], %[tmp], 63\n\t"
+                                     "s_lshl_b64 %[m], -1, %[tmp]\n\t"
+                                     "s_and_b64 %[m], %[m], %[canm]\n\t"
+                                     "s_bcnt1_i32_b64 %[tmp], %[m]\n\t"
+                                     "s_cmp_lg_u64 %[H], 0\n\t"
+                                     "s_cselect_b32 %[cc], %[tmp], %[t]"
+                                     : [cc] "+s"(ch_cc), [w1] "+s"(ch_w1), [tmp] "=&s"(tmp), [m] "=&s"(m)
+                                     : [H] "s"(H), [canm] "s"(canm), [t] "s"(t)
+                                     : "scc");
+                    }
+                }
+                ch_last = (uint32_t)__builtin_amdgcn_readlane((int)u, (int)nrow - 1);
+            };
+            // Two loops, not one with the source of a row picked inside it: a loop that may load from global memory waits for its
+            // loads with vmcnt(0), which also waits for the row stores before them and for the next tile's first chunk (in flight
+            // since the end of phase 1) — six memory round trips per tile in the first version of this code.
+            if (!redo) {
+                for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+                    const uint32_t nrow = n - i0 < 64u ? n - i0 : 64u;
+                    const uint32_t o = cursor + base + i0 + ln;
+                    uint32_t r = 0u;
+                    if (ln < nrow) {
+                        r = stage_at(i0 + ln);
+                        if (o < cap && !(TS_ABL & 1)) wave_out[o] = r;
+                    }
+                    if (!(TS_EMIT_ABL & 1)) look(r, nrow, i0);
+                }
+            } else {
+                for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+                    const uint32_t nrow = n - i0 < 64u ? n - i0 : 64u;
+                    const uint32_t o = cursor + base + i0 + ln;
+                    uint32_t r = 0u;
+                    if (ln < nrow && o < cap) r = __hip_atomic_load(wave_out + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (past the non-coherent L1)
+                    look(r, nrow, i0);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            vout += vfill;
-            vfill = 0;
+            flushed = done;
+            // the tile's summary and where its visible records are
+            const uint32_t z15 = ch_cc < 0x7FFFu ? ch_cc : 0x7FFFu;
+            if (!(ch_w1 & TS_CHAIN_HEADS)) ch_w1 |= z15;               // no head: every canonical record is ahead of the first
+            const u64 voff = vwave + vbase;
+            if (ln == 0u) *(uint4 *)&Q->tile_chain[4ull * tile] = make_uint4((ch_first & 0xFFFFu) | (ch_last << 16), ch_w1 | (z15 << 16), (uint32_t)voff, (uint32_t)(voff >> 32));
+            tile_vis = vout;
+            park[4] = vbase + vout;                                // (every lane writes the same word)
         };
         if (P.windows_on)                                          // match fields accumulate from zero
-            for (uint32_t it = lane; it < P.max_windows * 2u * P.acc_copies; it += 64u) ((lds_u32 *)wacc)[it] = 0u;
+            for (uint32_t it = lane; it < acc_rows * 2u * (P.acc_copies + (P.acc_blocks ? 1u : 0u)); it += 64u) ((lds_u32 *)wacc)[it] = 0u;
 
         // ------------------------------------------------------------------ phase 1
         // Chunk c+1's 16 B/lane load is in flight while chunk c is resolved; the loop is unrolled
@@ -403,105 +566,26 @@ void ts_scan_tiles(const TsScanParams P) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                 const uint32_t slot = owned ? (done - flushed) + rank : P.stage_cap + lane;
                 const uint32_t record = (u << 2) | fc;
-                stage[slot] = record;
+                if (P.stage_u16) ((lds_u16 *)stage)[slot] = (uint16_t)record; else stage[slot] = record;
                 done += (uint32_t)__popcll(bal);
                 const u64 can_all = ballot64((fc & 1u) != 0u), fwd_all = ballot64((fc & 2u) != 0u);
                 const bool is_can = __builtin_amdgcn_inverse_ballot_w64(can_all), is_fwd = __builtin_amdgcn_inverse_ballot_w64(fwd_all);
                 const u64 canm = can_all & bal;
                 ccan += (uint32_t)__popcll(canm);              // (scalar counts: popcounts of masks)
                 cfwd += (uint32_t)__popcll(fwd_all & bal);
-                if (EMIT && bal != 0ull) {
-                    // ---- visible records: the canonical ones, and every record where the tile lies in the terminal zone
-                    {
-                        u64 vm = canm;
-                        if (zone != TS_ZONE_NONE) vm = bal & (can_all | ballot64(u < (zone & 0xFFFFu)) | ballot64(u >= (zone >> 16)));
-                        if (vm != 0ull) {
-                            const uint32_t nv = (uint32_t)__popcll(vm);
-                            if (vfill + nv > vcap) flush_vis();
-                            const uint32_t vr = vfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
-                            if (__builtin_amdgcn_inverse_ballot_w64(vm)) rec[vr] = record;
-                            vfill += nv;
-                        }
-                    }
-                    // ---- chains.  A record more than -k behind the owned record before it is a head; all a pass keeps is the
-                    // canonical count of the chain that is open at its end (ch_cc) and, until the tile's first head, the count
-                    // ahead of it.  A pass without a canonical record and with none carried in (a third of them) changes neither.
-                    const uint32_t ncan = (uint32_t)__popcll(canm);
-                    const uint32_t t = ch_cc + ncan;
-                    if ((t | (~ch_w1 & TS_CHAIN_HEADS)) != 0u) {            // (integer logic: a uniform bool costs three scalar instructions to combine)
-                        // The owned lanes are nearly always the pass's first lanes: the lane below holds the record before, lane 0
-                        // gets the last record of the pass before.  Otherwise (lanes ahead of the tile's first base, matches a
-                        // w == s tile loses to the straddle rule) a prefix maximum finds it.
-                        uint32_t below;
-                        if (__builtin_expect((bal & (bal + 1ull)) == 0ull, 1)) {
-                            below = (uint32_t)__builtin_amdgcn_update_dpp((int)ch_last, (int)u, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps ch_last
-                            asm volatile("" : "+v"(below));        // (kept a v_mov_b32_dpp: see lane_below)
-                        } else {
-                            const uint32_t before = lane_below(wave_scan_max(owned ? u + 1u : 0u));
-                            below = before ? before - 1u : ch_last;
-                        }
-                        const u64 H = bal & ballot64(u - below > P.kdist);
-                        if (__builtin_expect(t >= 4u, 0)) {
-                            // a chain that ends in this pass may hold the four canonical records a block needs: the exact look
-                            if (H != 0ull) {
-                                const u64 ahead = ~H & (H - 1ull);                      // the lanes below the first head
-                                const uint32_t top_head = 63u - (uint32_t)__builtin_clzll(H);
-                                const u64 below_top = low_bits(top_head);
-                                // the chain carried into the pass ends at the first head
-                                const uint32_t carry = ch_cc + (uint32_t)__popcll(canm & ahead);
-                                if (!(ch_w1 & TS_CHAIN_HEADS)) ch_w1 |= carry < 0x7FFFu ? carry : 0x7FFFu;
-                                else if (carry >= 4u) ch_w1 |= TS_CHAIN_INNER;
-                                // chains that start and end inside the pass: looked at only when they hold four canonical records between them
-                                if (__popcll(canm & ~ahead & below_top) >= 4) {
-                                    const u64 above = lane < 63u ? H >> (lane + 1u) : 0ull;
-                                    const uint32_t next = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 64u;   // the next head's lane
-                                    const bool mine4 = __popcll(canm & low_bits(next) & ~low_bits(lane)) >= 4;
-                                    if (ballot64(((H >> lane) & 1ull) && lane != top_head && mine4) != 0ull) ch_w1 |= TS_CHAIN_INNER;
-                                }
-                                ch_w1 |= TS_CHAIN_HEADS;
-                                ch_cc = (uint32_t)__popcll(canm & ~below_top);
-                            } else {
-                                ch_cc = t;
-                            }
-                        } else {
-                            // Fewer than four (nearly every pass): nothing to saturate, no chain to flag.  Until the tile's first
-                            // head: the canonical count ahead of it, ch_cc + popcount(canm below H's lowest bit), and the HEADS flag,
-                            // into ch_w1.  Always: ch_cc = canonical records from H's highest bit on, or t when the pass has no head.
-                            // Written out for the scalar unit (the compiler's version of these seven lines came to forty
-                            // instructions, every combination of two uniform conditions materialised as a 64-bit mask):
-                            uint32_t tmp;
-                            u64 m;
-                            asm volatile("s_bitcmp1_b32 %[w1], 15\n\t"
-                                         "s_cbranch_scc1 .Lts_cq%=\n\t"
-                                         "s_cmp_eq_u64 %[H], 0\n\t"
-                                         "s_cbranch_scc1 .Lts_cq%=\n\t"
-                                         "s_ff1_i32_b64 %[tmp], %[H]\n\t"
-                                         "s_lshl_b64 %[m], -1, %[tmp]\n\t"
-                                         "s_andn2_b64 %[m], %[canm], %[m]\n\t"
-                                         "s_bcnt1_i32_b64 %[tmp], %[m]\n\t"
-                                         "s_add_i32 %[tmp], %[tmp], %[cc]\n\t"
-                                         "s_or_b32 %[w1], %[w1], %[tmp]\n\t"
-                                         "s_bitset1_b32 %[w1], 15\n"
-                                         ".Lts_cq%=:\n\t"
-                                         "s_flbit_i32_b64 %[tmp], %[H]\n\t"          // (-1 without a head: the shift below is then 0 and t is taken anyway)
-                                         "s_xor_b32 %[tmp], %[tmp], 63\n\t"
-                                         "s_lshl_b64 %[m], -1, %[tmp]\n\t"
-                                         "s_and_b64 %[m], %[m], %[canm]\n\t"
-                                         "s_bcnt1_i32_b64 %[tmp], %[m]\n\t"
-                                         "s_cmp_lg_u64 %[H], 0\n\t"
-                                         "s_cselect_b32 %[cc], %[tmp], %[t]"
-                                         : [cc] "+s"(ch_cc), [w1] "+s"(ch_w1), [tmp] "=&s"(tmp), [m] "=&s"(m)
-                                         : [H] "s"(H), [canm] "s"(canm), [t] "s"(t)
-                                         : "scc");
-                        }
-                    }
-                    ch_last = (uint32_t)__builtin_amdgcn_readlane((int)u, 63 - (int)__builtin_clzll(bal));
-                }
                 // {canonical, non-canonical, forward, reverse} as one 4 x 16-bit increment
                 const u64 inc = (u64)(is_can ? 1u : 0x10000u) | ((u64)(is_fwd ? 1u : 0x10000u) << 32);
                 // windows q, q-1, ... contain the match as long as it ends inside them.  Window q always does:
                 // o + k <= w holds for every valid match (w == s: the straddle rule above; w > s: k <= w - s)
-                if (P.windows_on && !(TS_ABL & 4)) {
+                if (P.windows_on && P.acc_blocks && !(TS_ABL & 4)) {
+                    // per step block: block q takes the match, and the row of run-overs takes it too when it ends behind the block's
+                    // end (o + k > s: k - 1 offsets of s) — a window is the sum of its blocks minus the run-overs of its last one
+                    if (valid && q < nblk) atomicAdd((unsigned long long *)(wacc + acc_off + q), inc);
+                    const u64 over = valid_m & ballot64(o + k > P.s);
+                    if (over != 0ull) {
+                        if (__builtin_amdgcn_inverse_ballot_w64(over) && q < nblk) atomicAdd((unsigned long long *)(wacc + P.acc_copies * acc_rows + q), inc);
+                    }
+                } else if (P.windows_on && !(TS_ABL & 4)) {
                     for (uint32_t j = 0; j < nwper; ++j) {
                         const uint32_t wi = q - j;            // wraps past window 0
                         const bool in = valid && wi < T.nwin && o + k + j * P.s <= P.w;
@@ -719,26 +803,28 @@ void ts_scan_tiles(const TsScanParams P) {
                 cpos += 2u * TS_CHUNK; ch += 126u;
             }
         }
-        {
-            KernArgs Q = tail_params();
-            const bool dyn = Q->dynamic_tiles != 0u;
-            tile_next = dyn ? group + Q->ticket_groups * (group_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket))
-                            : tile + total_waves;
-            if (tile_next < P.ntiles) {           // next tile: descriptor + first chunk, in flight during phase 2
-                Tn = P.tiles[tile_next];
-                const unsigned char *ls = P.in + (Tn.in_off & ~15ull) + lane * 32u;
-                n0 = *(const uint4 *)ls; n1 = *(const uint4 *)(ls + 16);
-                if (dyn && lane == 0) ticket = take_ticket(Q);      // and the ticket for the tile after it
-            }
+#define TS_REQUEST_NEXT_TILE()                                                                                                   \
+        {                                                                                                                        \
+            KernArgs Q = tail_params();                                                                                          \
+            const bool dyn = Q->dynamic_tiles != 0u;                                                                             \
+            tile_next = dyn ? group + Q->ticket_groups * (group_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket))   \
+                            : tile + total_waves;                                                                                \
+            if (tile_next < P.ntiles) {           /* next tile: descriptor + first chunk, in flight during phase 2 */            \
+                Tn = P.tiles[tile_next];                                                                                         \
+                const unsigned char *ls = P.in + (Tn.in_off & ~15ull) + lane * 32u;                                              \
+                n0 = *(const uint4 *)ls; n1 = *(const uint4 *)(ls + 16);                                                         \
+                if (dyn && lane == 0) ticket = take_ticket(Q);      /* and the ticket for the tile after it */                   \
+            }                                                                                                                    \
         }
+        if (!(EMIT && TS_EMIT_LATE_REQUEST)) TS_REQUEST_NEXT_TILE()
         drain_queue(1u);                          // the matches still queued when the tile ends
         __builtin_amdgcn_wave_barrier();          // planes written above are read by other lanes below
 
         // ------------------------------------------------------------------ phase 2: windows
         set_prio(kPrioWindows);
         // The match fields of the tile's window records are complete (accumulated above).
-        flush_stage();
-        if (EMIT && vfill != 0u) flush_vis();   // (the nucleotide rows are assembled where the visible records were staged)
+        finish_records();
+        if (EMIT && TS_EMIT_LATE_REQUEST) TS_REQUEST_NEXT_TILE()
         if (P.windows_on) {
             // Nucleotides.  Counted here, from the tile's code plane, not per chunk: a row (a step block when w is a
             // multiple of s — a window is then the sum of w / s of them and overlapping windows share them — else a
@@ -807,9 +893,62 @@ void ts_scan_tiles(const TsScanParams P) {
             }
             __builtin_amdgcn_wave_barrier();
 
+            // the four packed 16-bit match counters of window i {canonical, non-canonical, forward, reverse}.  The counters of the
+            // copies (and of a window's blocks) add without carries between fields: a field's total is at most the matches of one
+            // window (<= 32768); the run-overs of the window's last block are among what was added, so the subtraction borrows nothing
+            auto window_fields = [&](uint32_t i) -> u64 {
+                u64 a = 0;
+                if (P.acc_blocks) {
+                    for (uint32_t c = 0; c < P.acc_copies; ++c)
+                        for (uint32_t j = 0; j < nwper; ++j) a += wacc[c * acc_rows + i + j];
+                    a -= wacc[P.acc_copies * acc_rows + i + nwper - 1u];
+                } else {
+                    for (uint32_t c = 0; c < P.acc_copies; ++c) a += wacc[c * acc_rows + i];
+                }
+                return a;
+            };
             // records leave as whole 16-byte halves in order: {A, C, G, T} and {canonical, non-canonical, forward,
             // reverse} covered bases (= k x matches) per window, coalesced
-            if (!(TS_ABL & 8)) {
+            if (EMIT && tail_params()->win_packed != nullptr) {
+                // A shard's scan (ts_batch_bind_shard_message): the records of the OWNED windows go straight into the message's
+                // window section in its bit-packed form — fields [A C G T] (when nucleotide counts are on), canonical,
+                // non-canonical and forward match COUNTS, win_field_bits each, least significant first, in win_pack_bytes bytes
+                // (9 instead of 32 at w = 1000: what ts_shard_pack_windows, shard.hip, made of the 32-byte records in a pass of
+                // its own) — and nothing is written for the context tiles' windows, which nobody reads.  A lane per window.
+                KernArgs Q = tail_params();
+                if (T.win_out >= Q->win_pack_lo && T.win_out < Q->win_pack_hi && !(TS_ABL & 8)) {
+                    const uint32_t wb = Q->win_pack_bytes, B = Q->win_field_bits;
+                    unsigned char *const dst0 = Q->win_packed + T.win_out * (u64)wb;
+                    uint32_t ln = lane;
+                    asm volatile("" : "+v"(ln));              // (nothing derived from the lane id here is worth a register through the chunk loop)
+                    for (uint32_t i = ln; i < T.nwin; i += 64u) {
+                        u64 lo = 0, hi = 0;
+                        uint32_t at = 0;
+                        auto put = [&](uint32_t v) {
+                            lo |= at < 64u ? (u64)v << at : 0ull;
+                            if (at + B > 64u) hi |= at >= 64u ? (u64)v << (at - 64u) : (u64)v >> (64u - at);
+                            at += B;
+                        };
+                        if (P.nuc_on) {
+                            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                            const uint32_t nrow = by_blocks ? P.halo_blocks + 1u : 1u;
+                            for (uint32_t j = 0; j < nrow; ++j) {
+                                const LDS uint32_t *r4 = rec + (i + j) * 4u;
+                                v.x += r4[0]; v.y += r4[1]; v.z += r4[2]; v.w += r4[3];
+                            }
+                            put(v.x); put(v.y); put(v.z); put(v.w);
+                        }
+                        const u64 a = window_fields(i);
+                        put((uint32_t)a & 0xFFFFu); put((uint32_t)a >> 16); put((uint32_t)(a >> 32) & 0xFFFFu);
+                        // (unaligned 8- and 4-byte stores: two store instructions for the 9 bytes of w = 1000, not nine)
+                        unsigned char *d = dst0 + (u64)i * wb;
+                        uint32_t b = 0;
+                        if (wb >= 8u) { __builtin_memcpy(d, &lo, 8); b = 8u; }
+                        if (wb - b >= 4u) { const uint32_t x = b ? (uint32_t)hi : (uint32_t)lo; __builtin_memcpy(d + b, &x, 4); b += 4u; }
+                        for (; b < wb; ++b) d[b] = (unsigned char)(b < 8u ? lo >> (8u * b) : hi >> (8u * (b - 8u)));
+                    }
+                }
+            } else if (!(TS_ABL & 8)) {
                 uint4 *wout = (uint4 *)(tail_params()->windows_out + T.win_out * 8ull);
                 for (uint32_t it = lane; it < T.nwin * 2u; it += 64u) {
                     const uint32_t i = it >> 1;
@@ -823,10 +962,7 @@ void ts_scan_tiles(const TsScanParams P) {
                             }
                         }
                     } else {
-                        // the packed 4 x 16-bit counters of the copies add without carries between fields: a
-                        // field's total is at most the matches of one window (<= 32768)
-                        u64 a = 0;
-                        for (uint32_t c = 0; c < P.acc_copies; ++c) a += wacc[c * P.max_windows + i];
+                        const u64 a = window_fields(i);
                         v.x = ((uint32_t)a & 0xFFFFu) * k; v.y = ((uint32_t)a >> 16) * k;
                         v.z = ((uint32_t)(a >> 32) & 0xFFFFu) * k; v.w = (uint32_t)(a >> 48) * k;
                     }
@@ -841,17 +977,10 @@ void ts_scan_tiles(const TsScanParams P) {
             if (lane == 0) {
                 KernArgs Q = tail_params();
                 Q->tile_off[tile] = (u64)gw * Q->region_cap + cursor;
+                const uint32_t vout = EMIT ? tile_vis : 0u;       // (the tile's chain summary left with its records: finish_records)
                 *(uint4 *)&Q->tile_stats[4ull * tile] = make_uint4(done, tcan, tfwd, (TS_EXP & 8) ? (((uint32_t)wall_clock64() & 0xFFFFFu) | (gw << 20)) : vout);
-                if (EMIT) {
-                    const uint32_t z15 = ch_cc < 0x7FFFu ? ch_cc : 0x7FFFu;
-                    if (!(ch_w1 & TS_CHAIN_HEADS)) ch_w1 |= z15;         // no head: every canonical record is ahead of the first
-                    const u64 voff = (u64)gw * Q->vis_cap + vcursor;
-                    *(uint4 *)&Q->tile_chain[4ull * tile] = make_uint4(ch_first | (ch_last << 16), ch_w1 | (z15 << 16),
-                                                                        (uint32_t)voff, (uint32_t)(voff >> 32));
-                }
             }
             cursor += done;
-            vcursor += vout;
         }
         set_prio(0);
         __builtin_amdgcn_wave_barrier();          // next tile overwrites the planes
@@ -859,7 +988,7 @@ void ts_scan_tiles(const TsScanParams P) {
     if (lane == 0) {
         KernArgs Q = tail_params();
         Q->wave_fill[gw] = cursor;                             // records needed by this wave (may exceed region_cap)
-        if (EMIT) Q->wave_fill[total_waves + gw] = vcursor;    // visible records needed (may exceed vis_cap)
+        if (EMIT) Q->wave_fill[total_waves + gw] = park[4];    // visible records needed (may exceed vis_cap)
     }
 }
 

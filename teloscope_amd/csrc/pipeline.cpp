@@ -173,10 +173,6 @@ uint64_t strip_take(char *dst, uint64_t n, const char **pp, const char *end) {
 
 constexpr uint32_t kPackRunCap = 1u << 18;                 // invalid runs a packed chunk may carry (more: the chunk goes as ASCII)
 
-bool packed_upload_enabled() {
-    const char *e = getenv("TS_PACKED_UPLOAD");
-    return !(e && e[0] == '0');
-}
 
 // Uploads pieces of an input layout to the device buffer that holds its bytes from lo_all on (din = address of byte
 // lo_all).  Consecutive pieces that lie close together in the layout (full scans, reads: a few padding bytes apart) are
@@ -210,7 +206,7 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
     }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned nthr = std::min(8u, std::max(1u, hw / 2u));
-    if (const char *e = getenv("TS_STAGE_THREADS")) { const int n = atoi(e); if (n > 0) nthr = (unsigned)std::min(n, 64); }
+    if (c->knobs.stage_threads) nthr = c->knobs.stage_threads;
     // The staging threads live for the whole call, not for one 32 MB chunk (a chunk is staged in ~0.6 ms: spawning and
     // joining eight threads for each cost a tenth of the upload): job(t) runs on worker t, the caller is worker 0.
     struct StagePool {
@@ -259,9 +255,8 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
     StagePool stage_pool(total_bytes >= (8u << 20) ? nthr : 1u);
     std::atomic<int> bad_text{0};
     const bool fold = c->params.fold_case != 0;
-    uint64_t packed_min = 1u << 20;                            // small calls are latency, not link time: they go plain
-    if (const char *e = getenv("TS_PACKED_MIN_BYTES")) packed_min = strtoull(e, nullptr, 10);
-    bool use_packed = (packed_upload_enabled() && total_bytes >= packed_min) || any_packed;      // (bases that arrive packed leave packed)
+    const uint64_t packed_min = c->knobs.packed_min_bytes;
+    bool use_packed = (c->knobs.packed_upload && total_bytes >= packed_min) || any_packed;      // (bases that arrive packed leave packed)
     if (use_packed && !c->d_pack[0].p) {                       // the device side of the ring, once per context
         for (int q = 0; q < ts_ctx::kUpSlots && use_packed; ++q) {
             if (c->d_pack[q].ensure((kChunkPacked >> 2) + 4096) != hipSuccess || c->d_runs[q].ensure((size_t)kPackRunCap * 8) != hipSuccess ||
@@ -607,7 +602,7 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
     if (items.empty()) return TS_OK;
     if (ctx->device == kNoDevice) return ctx->fail(TS_ERR_NO_DEVICE, "planning-only context: no HIP device behind it");
     const auto t_begin = Clock::now();
-    const bool timing = getenv("TS_TIMING") != nullptr;          // stage times to stderr
+    const bool timing = ctx->knobs.timing;                       // stage times to stderr
     {
         DeviceGuard g(ctx->device);
         if (g.error() != hipSuccess) return ctx->fail(TS_ERR_HIP, "hipSetDevice failed");
@@ -886,8 +881,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     Q.s = s; Q.w = w; Q.longest = L; Q.nuc_on = (P.out_gc || P.out_entropy) ? 1u : 0u; Q.fold = P.fold_case;
     Q.s_magic = s >= 2u ? (uint32_t)((1ull << 32) / s + 1ull) : 0u;
     Q.cw = w / s; Q.rw = w - Q.cw * s;
-    if (const char *e = getenv("TS_GEN_ABL")) Q.abl = (uint32_t)atoi(e);
-    const bool timing = getenv("TS_TIMING") != nullptr;
+    Q.abl = c->knobs.gen_abl;
+    const bool timing = c->knobs.timing;
     const auto t_begin = Clock::now();
     double t_dbg[3] = {0, 0, 0};
     double t_up = 0, t_dev = 0, t_host = 0, t_take = 0, t_fused = 0, t_blk = 0, t_d2h = 0, t_wait_next = 0;
@@ -915,7 +910,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     // order, hence so is the pushing window).  Sets with a length gap of two or more under w > s keep the host path: the
     // reference's lower_bound runs over a stream that is not quite sorted there, and that is restated on the
     // host only.  TS_GEN_HOST_BLOCKS=1 forces the host path (A/B, tests).
-    const bool dev_blocks_ok = !(getenv("TS_GEN_HOST_BLOCKS") && getenv("TS_GEN_HOST_BLOCKS")[0] == '1') && c->gpat.nlen >= 1 &&
+    const bool dev_blocks_ok = !c->knobs.gen_host_blocks && c->gpat.nlen >= 1 &&
                                (tips || ov == 0 || c->gpat.len[c->gpat.nlen - 1] - c->gpat.len[0] <= 1u);
     // is the stream in the reference's push order whatever the input?  (position order IS push order then)
     const uint32_t len_spread = c->gen_wide ? (c->wide_lens.empty() ? 0u : c->wide_lens.back() - c->wide_lens.front())
@@ -939,7 +934,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         int rc = TS_OK;
         double ms = 0;
     };
-    const bool prefetch = !(getenv("TS_GEN_PREFETCH") && getenv("TS_GEN_PREFETCH")[0] == '0');
+    const bool prefetch = c->knobs.gen_prefetch;
     auto prepare = [&](Prepared &PR) -> int {
         // ---- a group of consecutive segments, ~256 MB of regions; layout = the regions back to back, 16-byte aligned
         PR.gh = std::make_shared<GroupHost>();
@@ -1043,7 +1038,7 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         // the list form of the fused pass (per-candidate work on full wavefronts) when a tile adds to few enough window
         // records for the accumulators it keeps in LDS; a tile dense enough to overflow a wave's candidate list sends the
         // group through the position-strided form instead
-        bool use_list = !wide && !(getenv("TS_GEN_LIST") && getenv("TS_GEN_LIST")[0] == '0') && s >= 2u && w < (1u << 28) &&
+        bool use_list = !wide && c->knobs.gen_list && s >= 2u && w < (1u << 28) &&
                         (tips || ((uint64_t)TS_GENERAL_TILE + w) / s + 3 <= ts_k_general_list_max_records());
         HIP_TRY(c, c->pool.take(std::max<size_t>(nt, 1) * (size_t)slot_cap * 4, d_slots));
         HIP_TRY(c, c->pool.take((nt + 1) * 16, d_stats));

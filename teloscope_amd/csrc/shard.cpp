@@ -210,6 +210,16 @@ int ts_batch_set_shard_scale(ts_batch *b, uint32_t scale) {
     if (!b || !b->shard_parts || !scale) return TS_ERR_INVALID_ARG;
     b->shard_scale = scale;
     b->shard_L = shard_layout(b, b->shard_r, scale);
+    b->bound_msg = nullptr;                               // (a message of the new size is bound anew)
+    return TS_OK;
+}
+
+int ts_batch_bind_shard_message(ts_batch *b, void *d_msg, uint64_t msg_bytes) {
+    if (!b) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    if (!b->shard_parts) return c->fail(TS_ERR_STATE, "ts_batch_bind_shard_message needs ts_batch_restrict_shard first");
+    if (d_msg && msg_bytes < b->shard_L.bytes) return c->fail(TS_ERR_INVALID_ARG, "ts_batch_bind_shard_message: message buffer smaller than ts_batch_shard_info says");
+    b->bound_msg = d_msg;
     return TS_OK;
 }
 
@@ -222,6 +232,9 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     const ShardRange &r = b->shard_r;
     const ShardLayout &L = b->shard_L;
     if (msg_bytes < L.bytes) return c->fail(TS_ERR_INVALID_ARG, "ts_batch_pack_shard: message buffer smaller than ts_batch_shard_info says");
+    // (a scan that packed its window records into a bound message left no 8 x u32 records for the pack's own kernel)
+    if (b->msg_windows && b->msg_windows != d_msg)
+        return c->fail(TS_ERR_STATE, "ts_batch_pack_shard: the scan packed its window records into the message bound by ts_batch_bind_shard_message; pack into that buffer");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t ns = (uint32_t)r.n_segs;
     const uint32_t nown = (uint32_t)(r.own_hi - r.own_lo);
@@ -276,7 +289,8 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
         c->pool.give(std::move(b->d_scan_tmp));
         HIP_TRY(c, c->pool.take(((size_t)b->range_tiles() + 2) * 4, b->d_scan_tmp));
     }
-    if (ts_k_launch_zero(msg, L.off_windows & ~3ull, (unsigned long long *)b->d_shard_bounds.p + 2ull * ns_z, (unsigned long long)b->shard_r.n_segs * 40,
+    (void)ns_z;                                          // (the per-segment counts accumulate in the message's own entries, zeroed with the header)
+    if (ts_k_launch_zero(msg, L.off_windows & ~3ull, nullptr, 0,
                          from_scan_z ? b->d_scan_tmp.p : nullptr, 4,
                          (from_scan_z && nown) ? ts_k_shard_big_counter(b->d_shard_tmp.p, nown) : nullptr, 4, st) != 0)
         return c->fail(TS_ERR_HIP, "zeroing kernel launch failed");
@@ -341,8 +355,7 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     HIP_TRY(c, hipEventRecord(b->ev_fork, st));
     HIP_TRY(c, hipStreamWaitEvent(c->side_stream, b->ev_fork, 0));
     if (ts_k_launch_terminal(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
-                             (unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs),
-                             (unsigned long long *)b->d_shard_bounds.p + 2ull * std::max<uint32_t>(ns, 1), 1, c->side_stream) != 0)
+                             (unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs), c->side_stream) != 0)
         return c->fail(TS_ERR_HIP, "terminal block kernel launch failed");
     HIP_TRY(c, hipEventRecord(b->ev_join, c->side_stream));
     TsVisibleOut vis{};
@@ -351,10 +364,15 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
             return c->fail(TS_ERR_HIP, "visible-record kernel launch failed");
     } else if (ts_k_launch_shard_count(&K, &H, b->d_shard_tmp.p, b->tips ? 0 : 1, &vis, stream) != 0)
         return c->fail(TS_ERR_HIP, "shard count kernel launch failed");
-    if (ts_k_launch_shard_windows(&K, &H, stream) != 0)
+    if (!b->msg_windows && ts_k_launch_shard_windows(&K, &H, stream) != 0)        // (unless the scan packed them: ts_batch_bind_shard_message)
         return c->fail(TS_ERR_HIP, "window packing kernel launch failed");
     if (ts_k_launch_shard_overflow(&K, stream) != 0)
         return c->fail(TS_ERR_HIP, "overflow check kernel launch failed");
+    // the per-segment counts of the message: added up by the screening kernel of the interstitial search when that runs from
+    // the scan's chain summaries, by a kernel of their own otherwise (a tips-only shard; results without summaries)
+    if (!from_scan && ts_k_launch_segment_sums(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
+                                               nullptr, (TsShardSeg *)(msg + L.off_segs), 1, stream) != 0)
+        return c->fail(TS_ERR_HIP, "segment sums kernel launch failed");
     HIP_TRY(c, hipStreamWaitEvent(st, b->ev_join, 0));
     if (!b->tips && ts_k_launch_interstitial(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
                                              (const unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs), &vis,

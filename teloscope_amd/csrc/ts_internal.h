@@ -20,7 +20,6 @@
 #define TS_BLK_COUNTERS 10             // 4 NB dwords of window nucleotide counts, then per step block: match head[3] rest[3]
 #define TS_TICKET_STRIDE 64            // dwords between two ticket counters (each in its own 256 bytes)
 #define TS_MAX_TICKET_GROUPS 64
-#define TS_VSTAGE_BYTES 256            // least size of a wave's stage of visible records (the nucleotide rows' LDS during phase 1)
 #define TS_IN_PAD       4096           // bytes of zero padding after the last segment in the input buffer
 
 struct TsTile {                 // 32 bytes
@@ -57,11 +56,13 @@ struct TsScanParams {
     uint32_t        max_windows;    // windows per tile (rows of the LDS record buffer)
     uint32_t        acc_copies;     // lane-interleaved copies of the window match accumulators (power of two)
     uint32_t        stage_cap;      // match records a wave can stage in LDS before it flushes them
+    uint32_t        stage_u16;      // 1: the stage holds 16-bit entries (position << 2 | flags < 2^16: tiles of at most 16 k positions)
     uint32_t        fold_mask;      // 0xDFDFDFDF (fold case) or 0xFFFFFFFF
     uint32_t        straddle_fix;   // 1: w == s, drop matches that straddle a window end
     uint32_t        windows_on;     // 0 in tips-only mode
     uint32_t        nuc_on;         // nucleotide counts wanted (-g / -e)
     uint32_t        block_sums;     // 1: w is a multiple of s, nucleotide counts are summed per step block
+    uint32_t        acc_blocks;     // 1: (w a multiple of s) the match fields of the window records accumulate per step block too
     uint32_t        dynamic_tiles;  // 1: a wave takes the next free tile (ticket counter); 0: tiles dealt round-robin
     uint32_t        ticket_slot;    // which of the two counter sets this launch counts on (it zeroes the other)
     uint32_t        ticket_groups;  // groups of workgroups with a counter each (<= 64; group g owns the tiles t = g mod groups)
@@ -75,6 +76,13 @@ struct TsScanParams {
     const uint32_t *tile_zone;      // per tile: {zlo, zhi} 16 bits each: a non-canonical record at tile position u is visible
                                     // (lies in its segment's terminal zone) iff u < zlo || u >= zhi
     uint32_t       *tile_chain;     // per tile: TsTileChain (4 dwords)
+    // ---- a shard's scan that packs its window records itself (ts_batch_bind_shard_message; emit only).  nullptr: 8 x u32 per
+    // window to windows_out.  Else the record of plan window i, win_pack_lo <= i < win_pack_hi (the owned windows), goes to
+    // win_packed + i * win_pack_bytes in the message's bit-packed form (shard.hip: ts_shard_pack_windows) and windows_out is
+    // not written at all.
+    uint8_t        *win_packed;
+    unsigned long long win_pack_lo, win_pack_hi;
+    uint32_t        win_pack_bytes, win_field_bits;
 };
 
 // What ts_scan_tiles leaves per tile beside {matches, canonical, forward, visible} in tile_stats: the summary the
@@ -321,16 +329,19 @@ int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_o
 // search over the batch's ntiles (range-local) tiles; seg_base = plan index of segs[0]'s segment; seg_out (nullable):
 // what a shard reports per segment
 // vis (nullable): where the interstitial pass leaves the visible records of the owned tiles (a shard's message)
-// sums: scratch of 5 x u64 per segment (per-segment counts the terminal walks are gated on and a shard reports)
+// sums (nullable): 5 x u64 per segment, the per-segment totals for a caller that wants them
 // chain + work (both or neither): the scan's per-tile chain summaries (TsTileChain) and scratch of (ntiles + 1) dwords — the
 // interstitial search then screens the tiles by their summaries and walks only the listed ones (ignored when vis asks for
 // the visible records out of the match stream)
 int  ts_k_launch_block_call(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base,
                             uint32_t ntiles, unsigned long long *bounds, TsShardSeg *seg_out, int with_its,
                             const TsVisibleOut *vis, unsigned long long *sums, const uint32_t *chain, uint32_t *work, void *stream);
-// prezeroed != 0: the caller has zeroed what the launch accumulates into (sums: 40 bytes per segment; work[0]) — ts_k_launch_zero
+// the terminal walks alone (they answer scanSegment's ">= 2 matches" gates from the tile directory themselves)
 int  ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
-                          unsigned long long *bounds, TsShardSeg *seg_out, unsigned long long *sums, int prezeroed, void *stream);
+                          unsigned long long *bounds, TsShardSeg *seg_out, void *stream);
+// per-segment totals into sums (5 x u64 per segment) or into the segments' entries of a shard's message (seg_out)
+int  ts_k_launch_segment_sums(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,
+                              unsigned long long *sums, TsShardSeg *seg_out, int prezeroed, void *stream);
 int  ts_k_launch_zero(void *p0, unsigned long long n0, void *p1, unsigned long long n1, void *p2, unsigned long long n2,
                       void *p3, unsigned long long n3, void *stream);
 int  ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *segs, uint32_t nseg, uint32_t seg_base, uint32_t ntiles,

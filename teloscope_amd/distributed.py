@@ -22,6 +22,7 @@ in seqPos order (sortBySeqPos, include/teloscope.h:262-266).  Here the unit is a
 the same function on two gloo ranks (no GPU: the tile results there are computed by the test itself).
 """
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -455,6 +456,16 @@ class PackedShard:
                 raise K.TeloscanError(rc, plan.teloscope._ctx.error())
             self.batches.append(b)
             self.msgs.append(torch.zeros(int(self.info.msg_bytes), dtype=torch.uint8, device=device))
+            self._bind(len(self.batches) - 1)
+
+    def _bind(self, slot):
+        """The slot's scans pack their window records into the slot's message themselves (ts_batch_bind_shard_message;
+        TS_SHARD_BIND=0 leaves that to the pack's own kernel: A/B measurements, and the tests compare the two)."""
+        if os.environ.get("TS_SHARD_BIND", "1") == "0":
+            return
+        rc = self.L.ts_batch_bind_shard_message(self.batches[slot], C.c_void_p(self.msgs[slot].data_ptr()), self.msgs[slot].numel())
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, self.plan.teloscope._ctx.error())
 
     def scan(self, d_input, stream_ptr, slot=0):
         """Enqueue the scan of the shard's tiles.  d_input: device address of byte `info.input_begin` of the input layout."""
@@ -499,6 +510,7 @@ class PackedShard:
             if rc != K.TS_OK:                                   # a silent failure would leave layout and buffer size disagreeing between ranks
                 raise K.TeloscanError(rc, "ts_batch_set_shard_scale(%d) failed" % scale)
             self.msgs[j] = torch.zeros(int(self.info.msg_bytes), dtype=torch.uint8, device=self.device)
+            self._bind(j)
 
     def kernel_ms(self, slot=0):
         b = self.batches[slot]

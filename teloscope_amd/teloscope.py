@@ -166,6 +166,13 @@ class _Ctx:
     def error(self):
         return (K.lib().ts_last_error(self.ptr) or b"").decode()
 
+    def refresh_env(self):
+        """ts_refresh_env: the context reads its measurement / test knobs (TS_TIMING, TS_PACKED_UPLOAD, ...) from the
+        environment when it is made; this reads them again."""
+        rc = K.lib().ts_refresh_env(self.ptr)
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, "ts_refresh_env failed")
+
 
 class Teloscope:
     """include/teloscope.h:166-300: ctor builds the match structure from userInput.patternInfo."""

@@ -212,6 +212,7 @@ def test_packed_upload_route_equals_plain_route_and_oracle(cli, fold, monkeypatc
     for route in ("1", "0", "packed-in"):
         monkeypatch.setenv("TS_PACKED_UPLOAD", "1" if route == "packed-in" else route)
         monkeypatch.setenv("TS_PACKED_MIN_BYTES", "0")
+        tel._ctx.refresh_env()                              # (the context read its knobs when it was made)
         got = [segment_as_dict(s) for s in tel.scanSegments(segs, packed=(route == "packed-in"))]
         if exp is None:
             # the oracle is strict scanSegment (lower case = non-ACGT): a context that folds case sees what the reference's
@@ -235,6 +236,7 @@ def test_packed_upload_falls_back_for_data_that_is_not_sequence(monkeypatch):
     good = seqgen.chromosome(rng, 300_000, opts.canonical_fwd, opts.canonical_rev, n_its=4, iupac=9)
     segs = [(good, 7, False), (bytes(junk), 11, False), (good[::-1], 13, False)]
     monkeypatch.setenv("TS_PACKED_MIN_BYTES", "0")
+    tel._ctx.refresh_env()
     got = [segment_as_dict(s) for s in tel.scanSegments(segs)]
     for (s, ap, tips), g in zip(segs, got):
         assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="len=%d" % len(s))
