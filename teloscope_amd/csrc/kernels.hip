@@ -56,6 +56,9 @@
 #ifndef TS_EMIT_ABL
 #define TS_EMIT_ABL 0
 #endif
+#ifndef TS_EMIT_FINISH_LAST
+#define TS_EMIT_FINISH_LAST 1
+#endif
 
 // Wave priorities (s_setprio; the SIMD's arbiter picks the ready wave of the highest priority, the oldest among equals).
 // The dense per-chunk work (decode, probes: long runs of independent vector instructions) stays at 0; the phases that are
@@ -207,9 +210,14 @@ __host__ __device__ inline uint32_t lds_total(const TsScanParams &P) {
 // EMIT: the build that also leaves the visible records and the per-tile chain summaries (P.emit).  A build of its own, so that a
 // scan nobody calls blocks from afterwards (a resident scan whose results stay in HBM) runs the code it always ran: with the
 // emit state merely branched around, the register allocator spilled 60 more scalars in the chunk loop (+7 % on configs[1]).
-template <bool FC_BYTES, bool PAIR_BYTES, int WAVES_EU, bool EMIT>
+// FAST: the build for what nearly every scan is — 16-bit stage entries (tiles of at most eight chunks) and, in a window scan, match
+// fields accumulated per step block (w a multiple of s) — with both decided at compile time: the other forms' code and the
+// registers it keeps alive through the chunk loop are then not there (byte tables only: the configurations that are timed).
+template <bool FC_BYTES, bool PAIR_BYTES, int WAVES_EU, bool EMIT, bool FAST>
 __global__ __launch_bounds__(TS_MAX_WG_THREADS, WAVES_EU)
 void ts_scan_tiles(const TsScanParams P) {
+    const bool st16 = FAST ? true : P.stage_u16 != 0u;
+    const bool accb = FAST ? true : P.acc_blocks != 0u;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -237,7 +245,7 @@ void ts_scan_tiles(const TsScanParams P) {
     lds_u32 *stage = (lds_u32 *)(slice + SL.stage);
     LDS u64 *wacc = (LDS u64 *)(slice + SL.wacc);
     lds_u32 *park = (lds_u32 *)(slice + SL.park);          // EMIT: [4] the wave's visible cursor, [5] "this tile flushed from inside a pass" (finish_records)
-    const uint32_t acc_rows = P.max_windows + (P.acc_blocks ? P.halo_blocks : 0u);   // rows of one copy of wacc
+    const uint32_t acc_rows = P.max_windows + (accb ? P.halo_blocks : 0u);   // rows of one copy of wacc
     const uint32_t acc_off = (lane & (P.acc_copies - 1u)) * acc_rows;          // this lane's copy of wacc
 
     const uint32_t k = P.k;
@@ -283,7 +291,10 @@ void ts_scan_tiles(const TsScanParams P) {
     // so no wait is spent on it.  Without P.dynamic_tiles the per-wave record counts are reproducible, which the sizing
     // of small batches and the rescan after an overflow rely on.  The counters of the NEXT launch are zeroed here (two
     // sets used alternately: launches of one batch are ordered on its stream).
-    TsTile Tn = {};
+    // (tile descriptors are written by the host only: read through the constant address space they come by scalar loads — as
+    // plain global loads they came into vector registers, seven v_readfirstlane per tile, behind a vmcnt wait)
+    typedef const TsTile __attribute__((address_space(4))) *ConstTiles;
+    const ConstTiles const_tiles = (ConstTiles)(uintptr_t)P.tiles;
     uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
     uint32_t ticket = 0;                          // lane 0: tickets taken in the group before this one
     const uint32_t ngroups = P.dynamic_tiles ? P.ticket_groups : 1u;
@@ -305,12 +316,21 @@ void ts_scan_tiles(const TsScanParams P) {
     const uint32_t first_tile = P.dynamic_tiles ? group + ngroups * ((blockIdx.x / ngroups) * P.waves_per_wg + wave) : gw;
     if (first_tile < P.ntiles) {
         if (P.dynamic_tiles && lane == 0) ticket = take_ticket(tail_params());
-        Tn = P.tiles[first_tile];
-        const unsigned char *ls = P.in + (Tn.in_off & ~15ull) + lane * 32u;
+        const unsigned char *ls = P.in + (const_tiles[first_tile].in_off & ~15ull) + lane * 32u;
         n0 = *(const uint4 *)ls; n1 = *(const uint4 *)(ls + 16);
     }
     for (uint32_t tile = first_tile, tile_next = 0; tile < P.ntiles; tile = tile_next) {
-        const TsTile T = Tn;                      // wave-uniform: came by scalar loads
+        // wave-uniform, by scalar loads (the request for the tile's first chunk read its in_off a phase ago: not kept)
+        // Only what phase 1 needs is kept, each field a scalar of its own (as one eight-register tuple the descriptor was
+        // spilled and reloaded whole — eight moves — wherever one field of it was wanted); the index of the tile's first window
+        // record is read again where phase 2 needs it.
+        struct { u64 in_off; uint32_t nrel, nwin, own_len; } T;
+        {
+            const ConstTiles q = const_tiles + tile;
+            uint32_t lo = (uint32_t)q->in_off, hi = (uint32_t)(q->in_off >> 32), a = q->nrel, b = q->nwin, c = q->own_len;
+            asm volatile("" : "+s"(lo), "+s"(hi), "+s"(a), "+s"(b), "+s"(c));
+            T.in_off = ((u64)hi << 32) | lo; T.nrel = a; T.nwin = b; T.own_len = c;
+        }
         const uint32_t sh = (uint32_t)(T.in_off & 15ull);
         const unsigned char *src = P.in + (T.in_off - sh);
         const uint32_t nblk = T.nwin + P.halo_blocks;             // step blocks the tile's windows reach into
@@ -341,7 +361,7 @@ void ts_scan_tiles(const TsScanParams P) {
         // A record more than -k behind the record before it is a head (a first record more than -k behind the tile's first base
         // is one whatever lies ahead of the tile: the latest position starts at 0; a closer one is not a head HERE — whether it
         // opens a chain depends on the tile before, which the screening looks up: ts_chain_screen, blockcall.hip).
-        auto stage_at = [&](uint32_t i) -> uint32_t { return P.stage_u16 ? (uint32_t)((lds_u16 *)stage)[i] : stage[i]; };
+        auto stage_at = [&](uint32_t i) -> uint32_t { return st16 ? (uint32_t)((lds_u16 *)stage)[i] : stage[i]; };
         auto flush_stage = [&]() {                                 // stage[0 .. done - flushed) -> wave_out[cursor + flushed ..), from inside a pass
             __builtin_amdgcn_wave_barrier();
             const uint32_t n = done - flushed;
@@ -396,7 +416,7 @@ void ts_scan_tiles(const TsScanParams P) {
             typedef const uint32_t __attribute__((address_space(4))) *ConstU32;
             const uint32_t zone = ((ConstU32)(uintptr_t)Q->tile_zone)[tile];
             const uint32_t vis_cap = Q->vis_cap;
-            const bool wide = Q->vis_wide != 0u;
+            const bool wide = FAST ? false : Q->vis_wide != 0u;        // (16-bit stage entries = tile positions below 2^14 = 16-bit visible records)
             void *const vis_out = Q->vis_out;
             const u64 vwave = (u64)gw * vis_cap;
             const uint32_t kdist = P.kdist;
@@ -519,7 +539,7 @@ void ts_scan_tiles(const TsScanParams P) {
             park[4] = vbase + vout;                                // (every lane writes the same word)
         };
         if (P.windows_on)                                          // match fields accumulate from zero
-            for (uint32_t it = lane; it < acc_rows * 2u * (P.acc_copies + (P.acc_blocks ? 1u : 0u)); it += 64u) ((lds_u32 *)wacc)[it] = 0u;
+            for (uint32_t it = lane; it < acc_rows * 2u * (P.acc_copies + (accb ? 1u : 0u)); it += 64u) ((lds_u32 *)wacc)[it] = 0u;
 
         // ------------------------------------------------------------------ phase 1
         // Chunk c+1's 16 B/lane load is in flight while chunk c is resolved; the loop is unrolled
@@ -566,7 +586,7 @@ void ts_scan_tiles(const TsScanParams P) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                 const uint32_t slot = owned ? (done - flushed) + rank : P.stage_cap + lane;
                 const uint32_t record = (u << 2) | fc;
-                if (P.stage_u16) ((lds_u16 *)stage)[slot] = (uint16_t)record; else stage[slot] = record;
+                if (st16) ((lds_u16 *)stage)[slot] = (uint16_t)record; else stage[slot] = record;
                 done += (uint32_t)__popcll(bal);
                 const u64 can_all = ballot64((fc & 1u) != 0u), fwd_all = ballot64((fc & 2u) != 0u);
                 const bool is_can = __builtin_amdgcn_inverse_ballot_w64(can_all), is_fwd = __builtin_amdgcn_inverse_ballot_w64(fwd_all);
@@ -577,7 +597,7 @@ void ts_scan_tiles(const TsScanParams P) {
                 const u64 inc = (u64)(is_can ? 1u : 0x10000u) | ((u64)(is_fwd ? 1u : 0x10000u) << 32);
                 // windows q, q-1, ... contain the match as long as it ends inside them.  Window q always does:
                 // o + k <= w holds for every valid match (w == s: the straddle rule above; w > s: k <= w - s)
-                if (P.windows_on && P.acc_blocks && !(TS_ABL & 4)) {
+                if (P.windows_on && accb && !(TS_ABL & 4)) {
                     // per step block: block q takes the match, and the row of run-overs takes it too when it ends behind the block's
                     // end (o + k > s: k - 1 offsets of s) — a window is the sum of its blocks minus the run-overs of its last one
                     if (valid && q < nblk) atomicAdd((unsigned long long *)(wacc + acc_off + q), inc);
@@ -810,8 +830,7 @@ void ts_scan_tiles(const TsScanParams P) {
             tile_next = dyn ? group + Q->ticket_groups * (group_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket))   \
                             : tile + total_waves;                                                                                \
             if (tile_next < P.ntiles) {           /* next tile: descriptor + first chunk, in flight during phase 2 */            \
-                Tn = P.tiles[tile_next];                                                                                         \
-                const unsigned char *ls = P.in + (Tn.in_off & ~15ull) + lane * 32u;                                              \
+                const unsigned char *ls = P.in + (const_tiles[tile_next].in_off & ~15ull) + lane * 32u;                          \
                 n0 = *(const uint4 *)ls; n1 = *(const uint4 *)(ls + 16);                                                         \
                 if (dyn && lane == 0) ticket = take_ticket(Q);      /* and the ticket for the tile after it */                   \
             }                                                                                                                    \
@@ -823,7 +842,9 @@ void ts_scan_tiles(const TsScanParams P) {
         // ------------------------------------------------------------------ phase 2: windows
         set_prio(kPrioWindows);
         // The match fields of the tile's window records are complete (accumulated above).
-        finish_records();
+        // (the emitting build flushes — and looks at — the records BEHIND the window phase: its rows want thirty scalars of their own,
+        // and between the chunk loop and the window phase they competed with both for registers: 110 more spill moves per tile)
+        if (!EMIT || !TS_EMIT_FINISH_LAST) finish_records();
         if (EMIT && TS_EMIT_LATE_REQUEST) TS_REQUEST_NEXT_TILE()
         if (P.windows_on) {
             // Nucleotides.  Counted here, from the tile's code plane, not per chunk: a row (a step block when w is a
@@ -898,7 +919,7 @@ void ts_scan_tiles(const TsScanParams P) {
             // window (<= 32768); the run-overs of the window's last block are among what was added, so the subtraction borrows nothing
             auto window_fields = [&](uint32_t i) -> u64 {
                 u64 a = 0;
-                if (P.acc_blocks) {
+                if (accb) {
                     for (uint32_t c = 0; c < P.acc_copies; ++c)
                         for (uint32_t j = 0; j < nwper; ++j) a += wacc[c * acc_rows + i + j];
                     a -= wacc[P.acc_copies * acc_rows + i + nwper - 1u];
@@ -916,9 +937,10 @@ void ts_scan_tiles(const TsScanParams P) {
                 // (9 instead of 32 at w = 1000: what ts_shard_pack_windows, shard.hip, made of the 32-byte records in a pass of
                 // its own) — and nothing is written for the context tiles' windows, which nobody reads.  A lane per window.
                 KernArgs Q = tail_params();
-                if (T.win_out >= Q->win_pack_lo && T.win_out < Q->win_pack_hi && !(TS_ABL & 8)) {
+                const u64 T_win_out = const_tiles[tile].win_out;
+                if (T_win_out >= Q->win_pack_lo && T_win_out < Q->win_pack_hi && !(TS_ABL & 8)) {
                     const uint32_t wb = Q->win_pack_bytes, B = Q->win_field_bits;
-                    unsigned char *const dst0 = Q->win_packed + T.win_out * (u64)wb;
+                    unsigned char *const dst0 = Q->win_packed + T_win_out * (u64)wb;
                     uint32_t ln = lane;
                     asm volatile("" : "+v"(ln));              // (nothing derived from the lane id here is worth a register through the chunk loop)
                     for (uint32_t i = ln; i < T.nwin; i += 64u) {
@@ -949,7 +971,7 @@ void ts_scan_tiles(const TsScanParams P) {
                     }
                 }
             } else if (!(TS_ABL & 8)) {
-                uint4 *wout = (uint4 *)(tail_params()->windows_out + T.win_out * 8ull);
+                uint4 *wout = (uint4 *)(tail_params()->windows_out + const_tiles[tile].win_out * 8ull);
                 for (uint32_t it = lane; it < T.nwin * 2u; it += 64u) {
                     const uint32_t i = it >> 1;
                     uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -971,6 +993,7 @@ void ts_scan_tiles(const TsScanParams P) {
             }
         }
 
+        if (EMIT && TS_EMIT_FINISH_LAST) finish_records();
         // ------------------------------------------------------- tile directory
         {
             const uint32_t tcan = ccan, tfwd = cfwd;
@@ -1044,19 +1067,25 @@ namespace {
 template <bool EMIT>
 const void *scan_variant_e(const TsScanParams *p) {
     const bool two = p->wgs_per_cu > 1u;
-    if (p->pair_byte_table && p->fc_byte_table) return two ? (const void *)ts_scan_tiles<true, true, 6, EMIT> : (const void *)ts_scan_tiles<true, true, 4, EMIT>;
+    if (p->pair_byte_table && p->fc_byte_table) {
+        const bool fast = p->stage_u16 && (!p->windows_on || p->acc_blocks);
+        if (fast) return two ? (const void *)ts_scan_tiles<true, true, 6, EMIT, true> : (const void *)ts_scan_tiles<true, true, 4, EMIT, true>;
+        return two ? (const void *)ts_scan_tiles<true, true, 6, EMIT, false> : (const void *)ts_scan_tiles<true, true, 4, EMIT, false>;
+    }
     if (two) return nullptr;
-    if (p->fc_byte_table) return (const void *)ts_scan_tiles<true, false, 4, EMIT>;
-    return (const void *)ts_scan_tiles<false, false, 4, EMIT>;
+    if (p->fc_byte_table) return (const void *)ts_scan_tiles<true, false, 4, EMIT, false>;
+    return (const void *)ts_scan_tiles<false, false, 4, EMIT, false>;
 }
 const void *scan_variant(const TsScanParams *p) { return p->emit ? scan_variant_e<true>(p) : scan_variant_e<false>(p); }
 }  // namespace
 
 int ts_k_prepare(uint32_t lds_bytes) {
-    const void *fns[] = {(const void *)ts_scan_tiles<true, true, 4, false>, (const void *)ts_scan_tiles<true, false, 4, false>,
-                         (const void *)ts_scan_tiles<false, false, 4, false>, (const void *)ts_scan_tiles<true, true, 6, false>,
-                         (const void *)ts_scan_tiles<true, true, 4, true>, (const void *)ts_scan_tiles<true, false, 4, true>,
-                         (const void *)ts_scan_tiles<false, false, 4, true>, (const void *)ts_scan_tiles<true, true, 6, true>};
+    const void *fns[] = {(const void *)ts_scan_tiles<true, true, 4, false, false>, (const void *)ts_scan_tiles<true, false, 4, false, false>,
+                         (const void *)ts_scan_tiles<false, false, 4, false, false>, (const void *)ts_scan_tiles<true, true, 6, false, false>,
+                         (const void *)ts_scan_tiles<true, true, 4, true, false>, (const void *)ts_scan_tiles<true, false, 4, true, false>,
+                         (const void *)ts_scan_tiles<false, false, 4, true, false>, (const void *)ts_scan_tiles<true, true, 6, true, false>,
+                         (const void *)ts_scan_tiles<true, true, 4, false, true>, (const void *)ts_scan_tiles<true, true, 6, false, true>,
+                         (const void *)ts_scan_tiles<true, true, 4, true, true>, (const void *)ts_scan_tiles<true, true, 6, true, true>};
     // the limit is a property of the function, not of a launch: batches of different geometries share it, so it is
     // raised to the CU's whole LDS rather than set to the size one batch asked for
     const int limit = (int)(lds_bytes > 160u * 1024u ? lds_bytes : 160u * 1024u);

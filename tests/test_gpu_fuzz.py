@@ -31,7 +31,7 @@ def _run(script, args, env=None, timeout=400):
 
 
 def test_fuzz_scan_parameters_300_sets_a_tenth_of_them_wide():
-    out = _run("fuzz_long.py", [340, 20261005], env={"TS_FUZZ_WIDE": "0.12"})
+    out = _run("fuzz_long.py", [340, 20261005], env={"TS_FUZZ_WIDE": "0.16"})
     m = re.search(r"fuzz: all (\d+) parameter sets equal the oracle", out)
     assert m and int(m.group(1)) >= 300, out[-1500:]
     w = re.search(r"(\d+) wide", out)
