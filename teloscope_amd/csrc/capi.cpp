@@ -78,7 +78,8 @@ constexpr uint32_t kMaxLds = 160u * 1024u;
 constexpr uint64_t kEventRing = 64;            // scans whose HIP-event times a batch remembers
 constexpr uint32_t kMaxBlocksPerTile = 448;
 constexpr uint32_t kMaxChunks = 8;             // tiles up to ~16 k positions per wave
-constexpr uint32_t kTipsChunks = 6;            // tips-only / read batches: ~12 k positions per tile (measured on 15 kb reads: 2..8 chunks, TS_GEOMETRY)
+constexpr uint32_t kTipsChunks = 8;            // tips-only / read batches: ~16 k positions per tile (15 kb reads, TS_GEOMETRY sweeps: six chunks until round 4;
+                                               // eight since the stage's entries are 16 bits — profiles/r05/reads_tilings.txt)
 
 // The measurement / test knobs of the host entry points (ts_ctx::Knobs), from the environment: at ts_create and ts_refresh_env,
 // never per call.
@@ -334,6 +335,7 @@ static int ensure_emit_buffers(ts_batch *b) {
     {
         HIP_TRY(c, c->pool.take(std::max<uint64_t>((uint64_t)b->vis_cap * b->total_waves, 4) * (b->kp.vis_wide ? 4 : 2) + 16, b->d_vis));
         HIP_TRY(c, c->pool.take((nt + 1) * 16, b->d_chain));
+        if (b->kp.emit == 2u) return TS_OK;                 // (a read batch: no terminal-zone words, every record is in the zone)
         HIP_TRY(c, c->pool.take((nt + 1) * 4, b->d_zone));
         // terminal zone of a segment (isTerminal, src/teloscope.cpp:451-459): rel <= t || rel >= N - t, the whole of a
         // segment no longer than t; per tile as two 16-bit thresholds on the tile-relative position
@@ -412,7 +414,20 @@ void size_launch(ts_batch *b) {
     // visible records (kp.emit): canonical matches at their density on random sequence, every match of a terminal zone
     // (a few per cent of its bases; every k-th base inside a telomere), twice the even share per wave, grown on overflow
     b->vis_cap = 0;
-    if (!b->tips) {
+    if (b->tips && b->kp.emit == 2u) {
+        // a read batch: the canonical records' indices — their density on random sequence, twice the even share per wave, and
+        // room for a few telomeric reads (a canonical record every k bases over thousands of bases); grown on overflow
+        const ts_ctx *c = b->ctx;
+        uint64_t ncanon = 0;
+        for (const ts::Pattern &p : c->patterns) ncanon += p.is_canonical ? 1 : 0;
+        const double d_canon = (double)std::max<uint64_t>(ncanon, 1) / (double)(1ull << (2 * std::min<uint32_t>(c->k, 16)));
+        const uint64_t vwant = (uint64_t)((double)b->range_bases * d_canon * 1.5);
+        uint64_t vcap = 2 * ceil_div(vwant, b->total_waves) + 8192;
+        if (b->dealt_tiles && !b->match_cap_request) vcap = worst;
+        vcap = std::min<uint64_t>(vcap, std::max<uint64_t>(worst, 256));
+        if (const char *e = getenv("TS_VIS_CAP")) { const long v = atol(e); if (v > 0) vcap = (uint64_t)v; }
+        b->vis_cap = (uint32_t)((vcap + 7) & ~7ull);
+    } else if (!b->tips) {
         const ts_ctx *c = b->ctx;
         uint64_t zone_bases = 0;
         const uint64_t tl = c->params.terminal_limit;
@@ -898,6 +913,16 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
         return nullptr;
     }
     b->lds_bytes = (uint32_t)ts_k_lds_bytes(&b->kp);
+    // TS_READ_EMIT=1 (an experiment of round 5, off by default): a read filter's batches (ReadTelomereFilter::matches,
+    // /root/reference/src/read-filter.cpp:10-45: tips-only, every read terminal zone as a whole) have their scans leave the indices of
+    // the canonical records (kp.emit = 2), and the predicate visits only the chains that hold one (predicate.hip:
+    // ts_read_predicate_canon) — a twentieth of the records, but each visit is a scattered 32-byte look at the match stream, a
+    // 128-byte line of HBM traffic: 0.35 ms per 5e5 reads against the streaming walk's 0.31, and the scan pays 5 % for the indices
+    // (profiles/r05/reads_canonical_index_experiment.txt).  The same pass bytes on the read-filter fuzz either way.
+    if (b->tips && ctx->read_filter && b->kp.stage_u16) {
+        const char *e = getenv("TS_READ_EMIT");
+        if (e && e[0] == '1') b->kp.emit = 2u;
+    }
     set_range(b, 0, b->tiles.size());
     return b;
 }
@@ -967,7 +992,8 @@ static bool emit_allowed() { const char *e = getenv("TS_EMIT"); return !(e && e[
 int ts_batch_set_emit(ts_batch *b, int on) {
     if (!b) return TS_ERR_INVALID_ARG;
     if (b->dense) return b->ctx->fail(TS_ERR_STATE, "ts_batch_set_emit on a batch that adopted results");
-    b->kp.emit = (on && !b->tips && emit_allowed()) ? 1u : 0u;
+    if (b->tips) return TS_OK;                           // (a tips-only batch ignores it: a read batch keeps its own form, see ts_batch_create)
+    b->kp.emit = (on && emit_allowed()) ? 1u : 0u;
     return TS_OK;
 }
 

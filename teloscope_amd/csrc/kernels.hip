@@ -413,8 +413,12 @@ void ts_scan_tiles(const TsScanParams P) {
             const uint32_t vbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)park[4]);   // the wave's visible cursor
             // (a scalar load — the table is written by the host only — not a vector one, whose wait (vmcnt) is also a wait for the next
             // tile's first chunk, in flight since the end of phase 1, and for every store ahead of it)
+            // P.emit == 2 (a read batch: tips-only, every segment terminal zone as a whole): what leaves is the INDEX, among the
+            // tile's records, of every canonical record — the read predicate (predicate.hip: ts_read_predicate_canon) then looks
+            // only at the chains that hold one, a twentieth of the records — and no chain summary.
+            const bool idx_mode = Q->emit == 2u;
             typedef const uint32_t __attribute__((address_space(4))) *ConstU32;
-            const uint32_t zone = ((ConstU32)(uintptr_t)Q->tile_zone)[tile];
+            const uint32_t zone = idx_mode ? TS_ZONE_NONE : ((ConstU32)(uintptr_t)Q->tile_zone)[tile];
             const uint32_t vis_cap = Q->vis_cap;
             const bool wide = FAST ? false : Q->vis_wide != 0u;        // (16-bit stage entries = tile positions below 2^14 = 16-bit visible records)
             void *const vis_out = Q->vis_out;
@@ -434,8 +438,9 @@ void ts_scan_tiles(const TsScanParams P) {
                     if (vm != 0ull && !(TS_EMIT_ABL & 2)) {
                         const uint32_t at = vbase + vout + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
                         if (__builtin_amdgcn_inverse_ballot_w64(vm) && at < vis_cap) {
-                            if (wide) ((uint32_t *)vis_out)[vwave + at] = r;
-                            else ((uint16_t *)vis_out)[vwave + at] = (uint16_t)r;
+                            const uint32_t what = idx_mode ? base + i0 + ln : r;
+                            if (wide) ((uint32_t *)vis_out)[vwave + at] = what;
+                            else ((uint16_t *)vis_out)[vwave + at] = (uint16_t)what;
                         }
                         vout += (uint32_t)__popcll(vm);
                     }
@@ -445,7 +450,7 @@ void ts_scan_tiles(const TsScanParams P) {
                 // third of them) changes neither.
                 const uint32_t ncan = (uint32_t)__popcll(canm);
                 const uint32_t t = ch_cc + ncan;
-                if ((t | (~ch_w1 & TS_CHAIN_HEADS)) != 0u && !(TS_EMIT_ABL & 4)) {            // (integer logic: a uniform bool costs three scalar instructions to combine)
+                if ((t | (~ch_w1 & TS_CHAIN_HEADS)) != 0u && !idx_mode && !(TS_EMIT_ABL & 4)) {            // (integer logic: a uniform bool costs three scalar instructions to combine)
                     // the lane below holds the record before, lane 0 gets the last record of the row before
                     uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp((int)ch_last, (int)u, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps ch_last
                     asm volatile("" : "+v"(below));            // (kept a v_mov_b32_dpp: see lane_below)

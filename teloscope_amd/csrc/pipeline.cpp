@@ -552,6 +552,7 @@ int batch_read_pass_device(ts_batch *b, unsigned char *d_pass, hipStream_t st) {
     Q.min_block_density = c->params.min_block_density;
     Q.k = c->k;
     Q.long_list = 128;                                        // floor of the per-wave threshold, see ts_terminal_predicate
+    const bool canon = b->emitted && b->kp.emit == 2u && !b->dense && b->all_terminal && b->d_chain.p && b->d_vis.p && !b->kp.vis_wide;
     int e = ts_k_launch_predicate((const TsTile *)b->d_tiles.p, (const unsigned long long *)b->d_tile_off.p,
                                   b->stats_ptr(), b->records_ptr(), b->records_limit(), (const uint32_t *)dt,
                                   (const unsigned long long *)(dt + off_in), (const unsigned long long *)(dt + off_len),
@@ -560,7 +561,9 @@ int batch_read_pass_device(ts_batch *b, unsigned char *d_pass, hipStream_t st) {
                                   // regions (16-byte aligned, 16 bytes of slack behind them: whole aligned blocks can be fetched)
                                   (b->all_terminal && !b->dense && ((uintptr_t)b->records_ptr() & 15u) == 0) ? 1 : 0,
                                   (const uint32_t *)b->d_fill.p, b->dense ? 0xFFFFFFFFu : b->region_cap, b->dense ? 0u : b->total_waves,
-                                  (uint32_t *)(dt + off_flag), st);
+                                  (uint32_t *)(dt + off_flag),
+                                  // (the scan left the canonical records' indices: the predicate visits only the chains that hold one)
+                                  canon ? (const uint32_t *)b->d_chain.p : nullptr, canon ? b->d_vis.p : nullptr, canon ? b->vis_cap : 0u, st);
     if (e != 0) return c->fail(TS_ERR_HIP, "predicate kernel launch failed");
     return TS_OK;
 }

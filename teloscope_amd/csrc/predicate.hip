@@ -377,6 +377,157 @@ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint3
     pass[si] = ok ? 1 : 0;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// ts_read_predicate_canon: the same answer from a twentieth of the records.  A chain of matches can only become a sub-block
+// if it holds a canonical match (finalizeSubBlock, src/teloscope.cpp:75-92: canonicalCount > 0), and a chain that does not
+// become one leaves no trace in what follows (phase 2 merges the KEPT sub-blocks, :129-174).  A read batch's scan leaves the
+// index of every canonical record among its tile's records (kernels.hip, P.emit == 2): a thread per read visits those —
+// seven per 15 kb read of random sequence under the default 38 patterns, of 140 records — and builds, around each one that
+// no earlier chain of its list has covered, the chain it belongs to: back and forth over the neighbouring records of the
+// same orientation while they are at most -k apart (a record of either orientation more than -k away ends the search:
+// positions ascend).  A kept chain is merged into its list's running block exactly as the walk above does it
+// (read_chain_kept, read_block_merge: the same u32 / float expressions), in the same order — chains of one list are
+// disjoint and are met in position order.  Long lists go to ts_terminal_predicate_long, as before.
+struct ReadCursor { uint32_t t, i; };          // a record of the read: tile, index among the tile's records
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // four records behind a dword-aligned address
+
+__global__ __launch_bounds__(64, TS_PRED_WAVES)
+void ts_read_predicate_canon(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats, const uint32_t *matches,
+                             const u64 nrec_limit, const uint32_t *chain, const uint16_t *vis, const uint32_t *seg_first_tile,
+                             const u64 *seg_in_off, uint32_t nseg, const TsPredParams Q, unsigned char *pass, uint32_t *long_list,
+                             uint32_t *long_count, const uint32_t *overflow) {
+    if (*overflow) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t si = blockIdx.x * 64u + lane;
+    const bool live = si < nseg;
+    const uint32_t t0 = live ? seg_first_tile[si] : 0u, t1 = live ? seg_first_tile[si + 1] : 0u;
+    const u64 base = live ? seg_in_off[si] : 0ull;
+    u64 total = 0, nfwd = 0;
+    for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
+    uint32_t sum = (uint32_t)(total < 0xFFFFFu ? total : 0xFFFFFu);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);
+    if (!live) return;
+    const uint32_t long_from = Q.long_list > sum / 32u ? Q.long_list : sum / 32u;       // twice the wave's mean (see ts_terminal_predicate)
+    if (total > long_from) {
+        long_list[atomicAdd(long_count, 1u)] = si;
+        return;
+    }
+    const bool walk_list[2] = {total - nfwd >= 2, nfwd >= 2};           // [reverse, forward]: a list of fewer than two matches is not walked
+    ReadBlock blk[2] = {};
+    ReadCursor covered[2] = {{t0, 0u}, {t0, 0u}};                         // per list: the first record no evaluated chain has reached
+    auto rec_at = [&](ReadCursor c) -> uint32_t { return matches[tile_off[c.t] + c.i]; };
+    auto pos_of = [&](ReadCursor c, uint32_t r) -> uint32_t { return (uint32_t)(tiles[c.t].in_off - base) + (r >> 2); };
+    auto step_back = [&](ReadCursor &c) -> bool {                        // to the record before; false at the read's first record
+        if (c.i) { --c.i; return true; }
+        for (uint32_t t = c.t; t > t0; --t) {
+            const uint32_t n = tile_stats[4u * (t - 1u)];
+            if (n) { c.t = t - 1u; c.i = n - 1u; return true; }
+        }
+        return false;
+    };
+    auto step_on = [&](ReadCursor &c) -> bool {                          // to the record behind; past the read's last record: {t1, 0}, false
+        if (c.i + 1u < tile_stats[4u * c.t]) { ++c.i; return true; }
+        for (uint32_t t = c.t + 1u; t < t1; ++t)
+            if (tile_stats[4u * t]) { c.t = t; c.i = 0u; return true; }
+        c.t = t1; c.i = 0u;
+        return false;
+    };
+    auto before = [](ReadCursor a, ReadCursor b) { return a.t < b.t || (a.t == b.t && a.i < b.i); };
+    bool ok = false;
+    for (uint32_t t = t0; t < t1 && !ok; ++t) {
+        const uint32_t nv = tile_stats[4u * t + 3u];
+        if (nv == 0u) continue;
+        const u64 voff = ((u64)chain[4u * t + 3u] << 32) | chain[4u * t + 2u];
+        const uint32_t cnt = tile_stats[4u * t];
+        const u64 off = tile_off[t];
+        const uint32_t rel0 = (uint32_t)(tiles[t].in_off - base);
+        uint32_t idx_next = vis[voff];                                     // (the next index is asked for a record ahead of its use)
+        for (uint32_t j = 0; j < nv && !ok; ++j) {
+            const uint32_t i = idx_next;
+            if (j + 1u < nv) idx_next = vis[voff + j + 1u];
+            const ReadCursor c = {t, i};
+            // The record and its neighbourhood — four records either side, two 16-byte loads in one round trip: on random sequence
+            // a record's neighbours of either orientation are 100 bases apart and -k is 50, so the search for the chain's ends
+            // nearly always stops inside it.  Entries outside the tile's records are masked (their tile's neighbour is looked at
+            // record by record below, like a chain that runs out of the neighbourhood).
+            const u64 g = off + i;
+            uint32_t e[8];
+            if (g >= 4u && g + 4u <= nrec_limit) {
+                const u32x4_a4 wa = *(const u32x4_a4 *)(matches + g - 4u), wb = *(const u32x4_a4 *)(matches + g);
+                e[0] = wa.x; e[1] = wa.y; e[2] = wa.z; e[3] = wa.w; e[4] = wb.x; e[5] = wb.y; e[6] = wb.z; e[7] = wb.w;
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) e[q] = (i + q >= 4u && i + q - 4u < cnt) ? matches[off + i + q - 4u] : 0u;
+            }
+            const uint32_t r = e[4];
+            const uint32_t o = (r >> 1) & 1u;                              // the record's list
+            if (!walk_list[o] || before(c, covered[o])) continue;          // inside a chain that was evaluated already
+            ReadChain ch = {rel0 + (r >> 2), rel0 + (r >> 2), 1u, 1u};
+            // back through the neighbourhood, nearest first; nb: records looked at, far_b: the search met a record too far ahead
+            uint32_t nb = 0;
+            bool far_b = false, go = true;
+#pragma unroll
+            for (uint32_t d = 1; d <= 4u; ++d) {
+                const uint32_t x = e[4u - d], px = rel0 + (x >> 2);
+                const bool in = go & (i >= d);                             // (the tile holds a record there)
+                const bool far = in & (ch.first - px > Q.max_match_dist);
+                const bool take = in & !far & (((x >> 1) & 1u) == o);
+                ch.first = take ? px : ch.first; ch.counts += take ? 1u : 0u; ch.canon += take ? (x & 1u) : 0u;
+                nb += in ? 1u : 0u;
+                far_b |= far;
+                go = in & !far;
+            }
+            if (!far_b) {                                                  // the neighbourhood (or the tile) ended first: record by record from there
+                ReadCursor b = {t, i - nb};
+                while (step_back(b)) {
+                    const uint32_t rb = rec_at(b), pb = pos_of(b, rb);
+                    if (ch.first - pb > Q.max_match_dist) break;          // (any orientation: whatever lies further ahead is further away)
+                    if (((rb >> 1) & 1u) != o) continue;
+                    ch.first = pb; ++ch.counts; ch.canon += rb & 1u;
+                }
+            }
+            // forth; e_after: the record behind the chain's last one ({t1, 0} when that is the read's last record)
+            uint32_t nf = 0, last_at = 0;                                  // records looked at; the neighbourhood offset (1..3) of the chain's last record so far
+            bool far_f = false;
+            go = true;
+#pragma unroll
+            for (uint32_t d = 1; d <= 3u; ++d) {
+                const uint32_t x = e[4u + d], px = rel0 + (x >> 2);
+                const bool in = go & (i + d < cnt);
+                const bool far = in & (px - ch.last > Q.max_match_dist);
+                const bool take = in & !far & (((x >> 1) & 1u) == o);
+                ch.last = take ? px : ch.last; ch.counts += take ? 1u : 0u; ch.canon += take ? (x & 1u) : 0u;
+                last_at = take ? d : last_at;
+                nf += in ? 1u : 0u;
+                far_f |= far;
+                go = in & !far;
+            }
+            ReadCursor e_after = {t, i + last_at};
+            if (e_after.i + 1u < cnt) ++e_after.i; else (void)step_on(e_after);   // (the tile's own count is at hand: no load on the usual path)
+            if (!far_f) {
+                ReadCursor f = {t, i + nf};
+                while (step_on(f)) {
+                    const uint32_t rf = rec_at(f), pf = pos_of(f, rf);
+                    if (pf - ch.last > Q.max_match_dist) break;
+                    if (((rf >> 1) & 1u) != o) continue;
+                    ch.last = pf; ++ch.counts; ch.canon += rf & 1u;
+                    e_after = f;
+                    (void)step_on(e_after);
+                }
+            }
+            covered[o] = e_after;
+            if (read_chain_kept(ch, Q)) {
+                read_block_merge(blk[o], Q, ch.first, ch.last + Q.k - ch.first);
+                ok = blk[o].pass;
+            }
+        }
+    }
+    for (int o = 0; o < 2; ++o) if (blk[o].have_cur && blk[o].clen >= Q.min_block_len) ok = true;
+    pass[si] = ok ? 1 : 0;
+}
+
 // One wave per listed read (grid-stride over the list), 64 records per step in parallel (pred_scan_wave).
 __global__ __launch_bounds__(64)
 void ts_terminal_predicate_long(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
@@ -402,9 +553,11 @@ void ts_terminal_predicate_long(const TsTile *tiles, const u64 *tile_off, const 
 
 // Raises *flag (sticky) when a wave needed more records than its region holds: with tiles taken on demand the per-wave
 // fill differs from launch to launch, so a launch that fitted says nothing about the next.
-__global__ void ts_pred_guard(const uint32_t *wave_fill, uint32_t region_cap, uint32_t nwaves, uint32_t *flag) {
+// (vis_cap != 0: the scan also left the canonical records' indices, a region per wave — wave_fill[nwaves + w] of them)
+__global__ void ts_pred_guard(const uint32_t *wave_fill, uint32_t region_cap, uint32_t nwaves, uint32_t *flag, uint32_t vis_cap) {
     bool over = false;
-    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nwaves; w += gridDim.x * blockDim.x) over |= wave_fill[w] > region_cap;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nwaves; w += gridDim.x * blockDim.x)
+        over |= wave_fill[w] > region_cap || (vis_cap != 0u && wave_fill[nwaves + w] > vis_cap);
     if (over) atomicOr(flag, 1u);
 }
 
@@ -414,13 +567,17 @@ int ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_of
                           const uint32_t *matches, unsigned long long nrec_limit, const uint32_t *seg_first_tile,
                           const unsigned long long *seg_in_off, const unsigned long long *seg_len, uint32_t nseg,
                           const TsPredParams *Q, unsigned char *pass, uint32_t *long_list, uint32_t *long_count, int all_terminal,
-                          const uint32_t *wave_fill, uint32_t region_cap, uint32_t nwaves, uint32_t *overflow, void *stream) {
+                          const uint32_t *wave_fill, uint32_t region_cap, uint32_t nwaves, uint32_t *overflow,
+                          const uint32_t *chain, const void *canon_idx, uint32_t vis_cap, void *stream) {
     if (nseg == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(long_count, 0, 4, st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(ts_pred_guard, dim3(8), dim3(256), 0, st, wave_fill, region_cap, nwaves, overflow);
-    if (all_terminal)
+    hipLaunchKernelGGL(ts_pred_guard, dim3(8), dim3(256), 0, st, wave_fill, region_cap, nwaves, overflow, chain ? vis_cap : 0u);
+    if (all_terminal && chain && canon_idx)
+        hipLaunchKernelGGL(ts_read_predicate_canon, dim3((nseg + 63u) / 64u), dim3(64), 0, st, tiles, tile_off, tile_stats, matches, (u64)nrec_limit, chain,
+                           (const uint16_t *)canon_idx, seg_first_tile, seg_in_off, nseg, *Q, pass, long_list, long_count, (const uint32_t *)overflow);
+    else if (all_terminal)
         hipLaunchKernelGGL((ts_terminal_predicate<true>), dim3((nseg + 63u) / 64u), dim3(64), 0, st,
                            tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
                            long_list, long_count, (const uint32_t *)overflow);

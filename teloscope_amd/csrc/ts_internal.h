@@ -68,7 +68,8 @@ struct TsScanParams {
     uint32_t        ticket_groups;  // groups of workgroups with a counter each (<= 64; group g owns the tiles t = g mod groups)
     uint32_t        wgs_per_cu;     // host side: workgroups that share a CU (1, or 2 of 10 waves: selects the 80-VGPR build)
     // ---- what the scan hands to block calling and to a shard's message (window scans only; emit == 0: none of it)
-    uint32_t        emit;           // 1: visible records + per-tile chain summaries are produced
+    uint32_t        emit;           // 1: visible records + per-tile chain summaries are produced; 2 (tips-only read batches): the indices of the
+                                    // canonical records among every tile's records instead, no summaries (vis_out, tile_chain words 2-3, tile_stats word 3 as for 1)
     uint32_t        kdist;          // -k (maxMatchDistance): matches farther apart than this start a new chain
     uint32_t        vis_wide;       // 0: visible records are u16 (tile positions < 2^14), 1: u32
     uint32_t        vis_cap;        // visible records per wave region
@@ -320,7 +321,10 @@ int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_o
                            const unsigned long long *seg_in_off, const unsigned long long *seg_len,
                            uint32_t nseg, const TsPredParams *Q, unsigned char *pass, uint32_t *long_list,
                            uint32_t *long_count, int all_terminal, const uint32_t *wave_fill, uint32_t region_cap,
-                           uint32_t nwaves, uint32_t *overflow, void *stream);
+                           uint32_t nwaves, uint32_t *overflow, const uint32_t *chain, const void *canon_idx, uint32_t vis_cap, void *stream);
+                           // (chain + canon_idx, both or neither: a read batch's scan left the indices of the canonical records — u16 each,
+                           //  per-wave regions of vis_cap, TsTileChain words 2-3 say where a tile's are, tile_stats word 3 how many — and
+                           //  the predicate visits only the chains that hold one)
                            // (nrec_limit: records that may be READ behind `matches` — the predicate fetches aligned 16-byte blocks;
                            //  long_list: nseg entries of scratch + long_count: one counter, for the reads a whole wave walks;
                            //  all_terminal: no segment is longer than the terminal limit — every read batch — the lean kernel;
