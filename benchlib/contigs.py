@@ -492,7 +492,9 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         # hence THREE buffer slots and TWO pack streams, so that two packs are in flight beside the scan), and the transfer
         # of step i's message beside all of it.  A slot's scan waits for the pack that last read its records; a slot's pack
         # waits for the transfer that last read its message.
-        pack_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(os.environ.get("TS_BENCH_PACK_STREAMS", "2"))))]
+        # (HIP maps streams onto four hardware queues and two streams on one queue take turns: the pack streams are chosen so that
+        # they do not share the scan stream's — distributed.concurrent_streams)
+        pack_streams = D.concurrent_streams(tel, dev, 1 + max(1, int(os.environ.get("TS_BENCH_PACK_STREAMS", "2"))), first=stream)[1:]
         # (TS_BENCH_SCAN_STREAMS=2 alternates the scans of consecutive steps between two streams, so that the workgroups of
         # step i + 1 could take the CUs the tail of step i frees.  Measured, profiles/r04/two_scan_streams.txt: slower at every
         # size — 1.15 against 0.93 ms at 3 Gb, 0.188 against 0.177 at the N = 8 size: two persistent kernels that each want
@@ -946,7 +948,7 @@ def scan_plus_block_calling_record(args, tel, lens, buf, dev, plain_ms, stream):
     plan = D.ShardPlan(tel, lens, world=1)
     shard = D.PackedShard(plan, 0, dev, slots=slots, scale=1)
     sptr = C.c_void_p(stream.cuda_stream)                     # (the stream the plain scans ran on: streams share a few hardware queues)
-    pack_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    pack_streams = D.concurrent_streams(tel, dev, 3, first=stream)[1:]      # (not on the scan stream's hardware queue)
     scanned = [torch.cuda.Event() for _ in range(slots)]
     packed = [torch.cuda.Event() for _ in range(slots)]
     used = [False] * slots

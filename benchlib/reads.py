@@ -85,7 +85,8 @@ def reads_sub_record(args, dev):
     d_passes = [torch.zeros(n + 16, dtype=torch.uint8, device=dev) for _ in range(nslots)]
     stream = torch.cuda.current_stream()
     sptr = C.c_void_p(stream.cuda_stream)
-    pred_stream = torch.cuda.Stream(device=dev)
+    import teloscope_amd.distributed as D
+    pred_stream = D.concurrent_streams(rf, dev, 2, first=stream)[1]     # (not on the scan stream's hardware queue)
     pptr = C.c_void_p(pred_stream.cuda_stream)
     scanned = [torch.cuda.Event() for _ in range(nslots)]
     judged = [torch.cuda.Event() for _ in range(nslots)]
@@ -218,7 +219,8 @@ def run_reads(args, rank, local_rank, world, dev, backend):
 
     # Two streams: the predicate of sub-batch i (no LDS, 64 VGPRs) runs beside the tips scan of sub-batch i + 1 (a persistent
     # kernel that leaves wave slots and a fifth of the issue cycles free), as it does between the stages of ts_filter_reads.
-    pred_stream = torch.cuda.Stream(device=dev)
+    import teloscope_amd.distributed as D
+    pred_stream = D.concurrent_streams(rf, dev, 2, first=stream)[1]     # (not on the scan stream's hardware queue)
     pptr = C.c_void_p(pred_stream.cuda_stream)
     for e in batches:
         e["scanned"] = torch.cuda.Event()

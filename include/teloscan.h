@@ -238,6 +238,14 @@ int     ts_takes_text_input(const ts_ctx *ctx, int tips_only);
  * is made — never per call.  This reads them again (tests and A/B scripts that flip one between two calls on one context).
  * No counterpart in the reference (its options are fixed by main, /root/reference/src/main.cpp:149-184). */
 int     ts_refresh_env(ts_ctx *ctx);
+/* HIP puts the streams of a process on a few hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise) and does not say which;
+ * kernels of two streams that share a queue run one after the other, whatever events allow.  Returns 1 when a kernel on stream_b
+ * runs while one on stream_a is still running, 0 when the two streams share a queue (a caller that wants a pack beside the next
+ * scan — ts_batch_pack_shard — makes streams until it holds a scan stream and pack streams that do not), negative on error.
+ * Waits for the work both streams hold, then takes ~1 ms.  The library tries its own side stream (the terminal walks of
+ * ts_batch_pack_shard) against every scan / pack stream it meets in the same way.  No counterpart in the reference (one thread
+ * per path, /root/reference/src/input.cpp:719-733). */
+int     ts_streams_concurrent(ts_ctx *ctx, void *stream_a, void *stream_b);
 /* Restricts the CALLING thread (and the threads it starts from then on) to the CPUs of the NUMA node the context's
  * device is attached to; returns 1 if it did, 0 if the topology is unknown, the thread's mask holds none of those CPUs,
  * or TS_NO_NUMA_BIND is set.  The library's own pipeline threads do this by themselves; a front end calls it on the threads

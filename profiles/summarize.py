@@ -17,6 +17,18 @@ def find(pattern):
     return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
 
 
+def variant(name):
+    """The two builds of the scan kernel (kernels.hip, template EMIT): 'plain' leaves window records + match stream, 'emit' also
+    the visible records and per-tile chain summaries (the scans of the line's scan_plus_block_calling sub-record)."""
+    if "ts_scan_tiles" not in name:
+        return None
+    import re
+    m = re.search(r"ts_scan_tiles<([^>]*)>", name)          # <FC_BYTES, PAIR_BYTES, WAVES_EU, EMIT[, FAST]>
+    args = [a.strip() for a in m.group(1).split(",")] if m else []
+    emit = args[3] if len(args) > 3 else ("true" if ", true>" in name else "false")
+    return "emit" if emit in ("true", "1") else "plain"
+
+
 for f in find("*kernel_stats.csv"):
     print("== kernel stats:", os.path.relpath(f, root))
     with open(f) as fh:
@@ -34,7 +46,7 @@ for f in find("*kernel_trace.csv"):
     for name, v in sorted(durs.items(), key=lambda kv: -sum(kv[1]))[:6]:
         print("   %-60s n=%d avg=%.1f us min=%.1f us max=%.1f us" % (name[:60], len(v), sum(v) / len(v) / 1e3,
                                                               min(v) / 1e3, max(v) / 1e3))
-        if "ts_scan_tiles" in name and ", false>" in name and len(v) > TIMED:      # the plain build: what `value` and `roofline` time
+        if variant(name) == "plain" and len(v) > TIMED:      # the plain build: what `value` and `roofline` time
             # bench.py's roofline uses the timed launches only: the last TIMED of the run
             t = v[-TIMED:]
             print("   %-60s      timed launches only (the last %d of %d): n=%d avg=%.1f us" % ("", TIMED, len(v), len(t), sum(t) / len(t) / 1e3))
@@ -46,14 +58,6 @@ for f in find("*kernel_trace.csv"):
                 m = re.search(r'"kernel_ms": ([0-9.]+)', open(log, errors="replace").read())
                 if m:
                     print("   %-60s      bench.py in the same process (HIP events, roofline.kernel_ms): %.1f us" % ("", float(m.group(1)) * 1e3))
-def variant(name):
-    """The two builds of the scan kernel (kernels.hip, template EMIT): 'plain' leaves window records + match stream, 'emit' also
-    the visible records and per-tile chain summaries (the scans of the line's scan_plus_block_calling sub-record)."""
-    if "ts_scan_tiles" not in name:
-        return None
-    return "emit" if ", true>" in name else "plain"
-
-
 for f in find("*counter_collection.csv"):
     acc = {"plain": {}, "emit": {}}
     with open(f) as fh:

@@ -373,6 +373,9 @@ __device__ __forceinline__ bool view_has_two(const TsBlockCallParams &Q, const S
     return acc >= 2u;
 }
 
+#ifndef TS_TERMINAL_PRIO
+#define TS_TERMINAL_PRIO 0
+#endif
 __global__ __launch_bounds__(kSideWg)
 void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t nseg, u64 *bounds, TsShardSeg *seg_out) {
     // two independent waves per segment: wave 0 walks the forward list from the start, wave 1 the reverse list from the end.
@@ -384,6 +387,9 @@ void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uin
     // (the per-segment counts of a shard's message are added up elsewhere: ts_chain_screen / ts_segment_sums)
     const uint32_t si = blockIdx.x >> 1;
     if (si >= nseg) return;
+#if TS_TERMINAL_PRIO
+    __builtin_amdgcn_s_setprio(TS_TERMINAL_PRIO);
+#endif
     const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x & 1u;
     const TsShardSegIn S = segs[si];
     const SegView V = seg_view(Q, S);

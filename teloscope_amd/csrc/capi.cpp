@@ -94,6 +94,8 @@ void read_env_knobs(ts_ctx *c) {
     k.packed_upload = !is("TS_PACKED_UPLOAD", '0');
     if (const char *e = getenv("TS_PACKED_MIN_BYTES")) k.packed_min_bytes = strtoull(e, nullptr, 10);
     if (const char *e = getenv("TS_STAGE_THREADS")) { const int n = atoi(e); if (n > 0) k.stage_threads = (uint32_t)std::min(n, 64); }
+    if (const char *e = getenv("TS_SIDE_PRIORITY")) k.side_priority = atoi(e);
+    k.side_probe = !is("TS_SIDE_PROBE", '0');
     c->knobs = k;
 }
 
@@ -253,6 +255,12 @@ bool plan_geometry(const ts_ctx *c, bool tips, TsScanParams &kp, uint32_t &wpt, 
     }
     if (best > 0.0) {
         kp = best_kp; wpt = best_wpt;
+        {   // the exact 22-bit magic of the step, where it exists for every position of a tile (see kernels.hip: the per-match pass)
+            const uint64_t s64 = std::max<uint32_t>(kp.s, 1), magic = ((1ull << 22) + s64 - 1) / s64, err = magic * s64 - (1ull << 22);
+            const uint64_t max_u = (uint64_t)kp.nch * TS_CHUNK + 64u;
+            kp.s_magic22 = (uint32_t)magic;
+            kp.div_exact = (!tips && magic < (1u << 24) && max_u < (1u << 24) && max_u * magic < (1ull << 32) && max_u * err < (1ull << 22)) ? 1u : 0u;
+        }
         kp.vis_wide = ((uint64_t)kp.nch * TS_CHUNK + 64u <= (1u << 14)) ? 0u : 1u;      // (position << 2 | flags) in 16 bits?
         return true;
     }
@@ -832,6 +840,14 @@ int ts_box_probe(ts_ctx *ctx, double *valu_wave_instr_per_ns, double *copy_bytes
     const int e = ts_k_box_probe(scratch.p, bytes, ctx->num_cu, valu_wave_instr_per_ns, copy_bytes_per_ns, nullptr);
     if (e != 0) return ctx->fail(TS_ERR_HIP, "box probe failed");
     return TS_OK;
+}
+
+int ts_streams_concurrent(ts_ctx *ctx, void *stream_a, void *stream_b) {
+    if (!ctx) return TS_ERR_INVALID_ARG;
+    DEVICE_TRY(ctx);
+    int ok = 0;
+    if (ts_k_streams_concurrent(stream_a, stream_b, &ok) != 0) return ctx->fail(TS_ERR_HIP, "stream probe failed");
+    return ok;
 }
 
 int ts_refresh_env(ts_ctx *ctx) {

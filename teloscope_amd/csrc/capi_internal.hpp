@@ -132,6 +132,8 @@ struct ts_ctx {
     struct Knobs {
         bool timing = false, gen_host_blocks = false, gen_prefetch = true, gen_list = true, packed_upload = true;
         uint32_t gen_abl = 0, stage_threads = 0;
+        int side_priority = 0;                                // stream priority of the pack's side stream (0: the default priority)
+        bool side_probe = true;                               // try the side stream against the scan / pack streams it meets (shard.cpp)
         uint64_t packed_min_bytes = 1u << 20;                 // small calls are latency, not link time: they go plain
     } knobs;
     BufferPool pool;
@@ -145,6 +147,10 @@ struct ts_ctx {
     static constexpr int kUpSlots = 3;
     hipStream_t side_stream = nullptr;          // ts_batch_pack_shard: the terminal walks of every batch's pack (created on first use)
     std::mutex side_mtx;
+    // the streams (scan, pack) the side stream has been tried against: HIP puts a process's streams on a few hardware queues, and a
+    // side stream that shares the scan stream's queue puts the terminal walks of step i in front of the scan of step i + 1
+    // (shard.cpp: side_stream_for)
+    std::vector<void *> side_tried;
     PinBuf pin_up[kUpSlots];
     hipEvent_t pin_up_ev[kUpSlots] = {nullptr, nullptr, nullptr};
     DevBuf d_pack[kUpSlots], d_runs[kUpSlots];   // packed upload: a chunk's 2-bit codes and invalid runs on the device

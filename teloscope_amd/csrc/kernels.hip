@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "ts_internal.h"
 
 // Profiling only: -DTS_ABL=<mask> builds a kernel with one stage removed (results are then wrong)
@@ -48,9 +50,13 @@
 #ifndef TS_EXP
 #define TS_EXP 0
 #endif
-// (measurement) 1: the emitting build requests its next tile behind finish_records instead of ahead of the tile's last passes
+// 1: the emitting build requests its next tile at the start of phase 2 instead of ahead of the tile's last passes (-0.4 % on configs[1]: profiles/r05/emit_ab_plain_emit_r04_r05_late_ffirst.txt; 0 for A/B)
+// whole rows of 64 records take a copy of the row code without the mask of live lanes (0: one copy for every row)
+#ifndef TS_EMIT_FULL_ROWS
+#define TS_EMIT_FULL_ROWS 1
+#endif
 #ifndef TS_EMIT_LATE_REQUEST
-#define TS_EMIT_LATE_REQUEST 0
+#define TS_EMIT_LATE_REQUEST 1
 #endif
 // (measurement: results are then wrong) 1: the rows are not looked at, 2: no visible records, 4: no chain summary
 #ifndef TS_EMIT_ABL
@@ -426,9 +432,10 @@ void ts_scan_tiles(const TsScanParams P) {
             const uint32_t kdist = P.kdist;
             // what a row of up to 64 records (a record per lane, r = 0 in the lanes behind it) adds to the tile's visible records and
             // to its chain summary
-            auto look = [&](const uint32_t r, const uint32_t nrow, const uint32_t i0) {
+            auto look = [&](const uint32_t r, const uint32_t nrow, const uint32_t i0, auto full_row) {
+                constexpr bool FULL = decltype(full_row)::value;           // a row of 64 records: no mask of live lanes to make or to apply
                 const uint32_t u = r >> 2;                                 // position in the tile
-                const u64 live_m = low_bits(nrow);
+                const u64 live_m = FULL ? ~0ull : low_bits(nrow);
                 const u64 canm = ballot64((r & 1u) != 0u);                  // (the lanes behind the row hold 0)
                 if (i0 == 0u) ch_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);   // the tile's first record
                 // ---- visible records: the canonical ones, and every record where the tile lies in the terminal zone
@@ -454,7 +461,7 @@ void ts_scan_tiles(const TsScanParams P) {
                     // the lane below holds the record before, lane 0 gets the last record of the row before
                     uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp((int)ch_last, (int)u, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps ch_last
                     asm volatile("" : "+v"(below));            // (kept a v_mov_b32_dpp: see lane_below)
-                    const u64 H = live_m & ballot64(u - below > kdist);
+                    const u64 H = FULL ? ballot64(u - below > kdist) : live_m & ballot64(u - below > kdist);
                     if (__builtin_expect(t >= 4u, 0)) {
                         // a chain that ends in this row may hold the four canonical records a block needs: the exact look
                         if (H != 0ull) {
@@ -509,13 +516,20 @@ void ts_scan_tiles(const TsScanParams P) {
                                      : "scc");
                     }
                 }
-                ch_last = (uint32_t)__builtin_amdgcn_readlane((int)u, (int)nrow - 1);
+                ch_last = (uint32_t)__builtin_amdgcn_readlane((int)u, FULL ? 63 : (int)nrow - 1);
             };
             // Two loops, not one with the source of a row picked inside it: a loop that may load from global memory waits for its
             // loads with vmcnt(0), which also waits for the row stores before them and for the next tile's first chunk (in flight
             // since the end of phase 1) — six memory round trips per tile in the first version of this code.
             if (!redo) {
-                for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+                const uint32_t nfull = TS_EMIT_FULL_ROWS ? n & ~63u : 0u;
+                for (uint32_t i0 = 0; i0 < nfull; i0 += 64u) {             // whole rows
+                    const uint32_t o = cursor + base + i0 + ln;
+                    const uint32_t r = stage_at(i0 + ln);
+                    if (o < cap && !(TS_ABL & 1)) wave_out[o] = r;
+                    if (!(TS_EMIT_ABL & 1)) look(r, 64u, i0, std::true_type{});
+                }
+                for (uint32_t i0 = nfull; i0 < n; i0 += 64u) {              // the tile's last, partial row
                     const uint32_t nrow = n - i0 < 64u ? n - i0 : 64u;
                     const uint32_t o = cursor + base + i0 + ln;
                     uint32_t r = 0u;
@@ -523,7 +537,7 @@ void ts_scan_tiles(const TsScanParams P) {
                         r = stage_at(i0 + ln);
                         if (o < cap && !(TS_ABL & 1)) wave_out[o] = r;
                     }
-                    if (!(TS_EMIT_ABL & 1)) look(r, nrow, i0);
+                    if (!(TS_EMIT_ABL & 1)) look(r, nrow, i0, std::false_type{});
                 }
             } else {
                 for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
@@ -531,7 +545,7 @@ void ts_scan_tiles(const TsScanParams P) {
                     const uint32_t o = cursor + base + i0 + ln;
                     uint32_t r = 0u;
                     if (ln < nrow && o < cap) r = __hip_atomic_load(wave_out + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (past the non-coherent L1)
-                    look(r, nrow, i0);
+                    look(r, nrow, i0, std::false_type{});
                 }
             }
             flushed = done;
@@ -573,12 +587,22 @@ void ts_scan_tiles(const TsScanParams P) {
                 if (PAIR_BYTES) fc = __builtin_amdgcn_ubfe((uint32_t)*lds_at8(kw & pmask), 2, 2);   // bits 2..3 of the pair-table byte (table at LDS address 0)
                 else if (FC_BYTES) fc = fc_bytes[idx];
                 else fc = (fc_table[idx >> 4] >> ((idx & 15u) << 1)) & 3u;
-                // position in the tile, step block and offset inside it: u < 2^16, so the quotient is one 24-bit
-                // multiply by ceil(2^16 / s) (full rate; exact or one too large, corrected below)
+                // position in the tile, step block and offset inside it (a tips-only tile is one block: nothing to divide).  u < 2^16,
+                // so the quotient is one 24-bit multiply (full rate): by ceil(2^22 / s) where that is exact for every position of a
+                // tile (P.div_exact: the host checked (nch x 2016 + 64) x (ceil(2^22 / s) s - 2^22) < 2^22 — s = 500, 1000, ...), else
+                // by ceil(2^16 / s), exact or one too large and corrected
                 const uint32_t u = xp - sh;                   // wraps for the few bases before the tile
-                uint32_t q = __umul24(u, P.s_inv) >> 16, qs = __umul24(q, P.s);
-                if (qs > u) { --q; qs -= P.s; }
-                const uint32_t o = u - qs;
+                uint32_t q = 0u, o = u;
+                if (P.windows_on) {
+                    uint32_t qs;
+                    if (P.div_exact) {
+                        q = __umul24(u, P.s_magic22) >> 22; qs = __umul24(q, P.s);
+                    } else {
+                        q = __umul24(u, P.s_inv) >> 16; qs = __umul24(q, P.s);
+                        if (qs > u) { --q; qs -= P.s; }
+                    }
+                    o = u - qs;
+                }
                 // Which lanes hold what is decided on MASKS — one vector compare each, the logic between them on the scalar unit —
                 // and a lane's own predicate is read back off the mask (inverse ballot: the mask itself becomes the lane predicate).
                 // w == s: a match that would straddle a window end is lost (the carry rule of

@@ -30,6 +30,12 @@
 
 #include "capi_internal.hpp"
 
+// Measurement only (-DTS_PACK_ABL=bits: results are wrong): 1 no terminal walks, 2 no visible-record copy, 8 no interstitial search,
+// 32 no header kernel — which of the pack's kernels costs the scan beside it what (profiles/r05_pack_abl.sh).
+#ifndef TS_PACK_ABL
+#define TS_PACK_ABL 0
+#endif
+
 namespace {
 
 uint32_t bit_width_u32(uint32_t v) { uint32_t b = 0; while (v) { ++b; v >>= 1; } return b ? b : 1u; }
@@ -97,6 +103,47 @@ ShardRange shard_range(const ts_batch *b, uint32_t n_parts, uint32_t part) {
         r.n_segs = b->tiles[r.own_hi - 1].seg - r.seg_begin + 1;
     }
     return r;
+}
+
+// The context's side stream, on a hardware queue of its own where that can be had.  HIP maps the streams of a process onto a few
+// hardware queues (four by default) and does not say which; kernels of two streams on one queue run one after the other.  A side
+// stream on the SCAN stream's queue puts the terminal walks of step i (a latency chain: ~60-90 us) in front of the scan of step
+// i + 1 — 0.95 ms per 3 Gb step instead of 0.85 (profiles/r05/shard_step_queues.txt); on a pack stream's queue it costs less.
+// So every stream a pack meets (the batch's scan stream, the pack's own) is tried once against the side stream
+// (ts_k_streams_concurrent: ~1 ms, and it waits for the work those streams hold); when they share a queue, up to eight fresh
+// streams are tried for one that runs beside every stream seen so far.  TS_SIDE_PROBE=0 keeps the first stream.
+int side_stream_for(ts_ctx *c, void *scan_stream, void *pack_stream) {
+    std::lock_guard<std::mutex> lk(c->side_mtx);
+    if (!c->side_stream) HIP_TRY(c, hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, c->knobs.side_priority));
+    if (!c->knobs.side_probe) return TS_OK;
+    for (void *s : {scan_stream, pack_stream}) {
+        if (!s || std::find(c->side_tried.begin(), c->side_tried.end(), s) != c->side_tried.end()) continue;
+        c->side_tried.push_back(s);                          // (tried once, whatever comes of it)
+        int ok = 0;
+        if (ts_k_streams_concurrent(s, c->side_stream, &ok) != 0) return c->fail(TS_ERR_HIP, "stream probe failed");
+        if (ok) continue;
+        std::vector<hipStream_t> fresh;
+        hipStream_t found = nullptr;
+        for (int i = 0; i < 8 && !found; ++i) {
+            hipStream_t cand = nullptr;
+            if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, c->knobs.side_priority) != hipSuccess) break;
+            fresh.push_back(cand);
+            bool all = true;
+            for (void *t : c->side_tried) {
+                int k = 0;
+                if (ts_k_streams_concurrent(t, cand, &k) != 0) { all = false; break; }
+                if (!k) { all = false; break; }
+            }
+            if (all) found = cand;
+        }
+        for (hipStream_t f : fresh) if (f != found) (void)hipStreamDestroy(f);
+        if (found) {
+            (void)hipStreamSynchronize(c->side_stream);
+            (void)hipStreamDestroy(c->side_stream);
+            c->side_stream = found;
+        }
+    }
+    return TS_OK;
 }
 
 uint64_t align16u(uint64_t v) { return (v + 15ull) & ~15ull; }
@@ -272,10 +319,7 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
         c->pool.give(std::move(b->d_shard_cand));
         HIP_TRY(c, c->pool.take((size_t)cand_cap * 8 + 16, b->d_shard_cand));
     }
-    {
-        std::lock_guard<std::mutex> lk(c->side_mtx);
-        if (!c->side_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-    }
+    { const int rc = side_stream_for(c, b->last_stream, stream); if (rc != TS_OK) return rc; }
     if (!b->ev_fork) {
         HIP_TRY(c, hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
@@ -354,13 +398,13 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     // where every tile's visible records go) and joins them.
     HIP_TRY(c, hipEventRecord(b->ev_fork, st));
     HIP_TRY(c, hipStreamWaitEvent(c->side_stream, b->ev_fork, 0));
-    if (ts_k_launch_terminal(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
+    if (!(TS_PACK_ABL & 1) && ts_k_launch_terminal(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
                              (unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs), c->side_stream) != 0)
         return c->fail(TS_ERR_HIP, "terminal block kernel launch failed");
     HIP_TRY(c, hipEventRecord(b->ev_join, c->side_stream));
     TsVisibleOut vis{};
     if (from_scan) {
-        if (ts_k_launch_shard_visible(&K, &H, b->d_shard_tmp.p, 1, stream) != 0)
+        if (!(TS_PACK_ABL & 2) && ts_k_launch_shard_visible(&K, &H, b->d_shard_tmp.p, 1, stream) != 0)
             return c->fail(TS_ERR_HIP, "visible-record kernel launch failed");
     } else if (ts_k_launch_shard_count(&K, &H, b->d_shard_tmp.p, b->tips ? 0 : 1, &vis, stream) != 0)
         return c->fail(TS_ERR_HIP, "shard count kernel launch failed");
@@ -374,11 +418,11 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
                                                nullptr, (TsShardSeg *)(msg + L.off_segs), 1, stream) != 0)
         return c->fail(TS_ERR_HIP, "segment sums kernel launch failed");
     HIP_TRY(c, hipStreamWaitEvent(st, b->ev_join, 0));
-    if (!b->tips && ts_k_launch_interstitial(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
+    if (!(TS_PACK_ABL & 8) && !b->tips && ts_k_launch_interstitial(&Q, (const TsShardSegIn *)b->d_shard_segs.p, ns, (uint32_t)r.seg_begin, (uint32_t)b->range_tiles(),
                                              (const unsigned long long *)b->d_shard_bounds.p, (TsShardSeg *)(msg + L.off_segs), &vis,
                                              from_scan ? K.chain : nullptr, from_scan ? (uint32_t *)b->d_scan_tmp.p : nullptr, 1, stream) != 0)
         return c->fail(TS_ERR_HIP, "interstitial block kernel launch failed");
-    if (ts_k_launch_shard_pack(&K, &H, b->d_shard_tmp.p, b->tips ? 0 : 1, stream) != 0)
+    if (!(TS_PACK_ABL & 32) && ts_k_launch_shard_pack(&K, &H, b->d_shard_tmp.p, b->tips ? 0 : 1, stream) != 0)
         return c->fail(TS_ERR_HIP, "shard pack kernel launch failed");
     return TS_OK;
 }

@@ -269,6 +269,49 @@ int ts_k_launch_shard_visible(const TsShardPackParams *P, const TsShardHeader *H
     return (int)hipGetLastError();
 }
 
+// ---- do two streams run kernels at the same time?  HIP maps a process's streams onto a few hardware queues (four by default), and
+// kernels of two streams that share one run one after the other whatever their events say.  A wave that waits ~1 ms on the constant
+// 100 MHz clock goes to stream a, an empty kernel behind it to stream b: b's kernel is done while a's still waits exactly when the
+// two streams sit on different queues.
+__global__ __launch_bounds__(64)
+void ts_probe_wait(unsigned long long ticks, unsigned long long *sink) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long t = t0;
+    while (t - t0 < ticks) { __builtin_amdgcn_s_sleep(64); t = wall_clock64(); }
+    if (sink && threadIdx.x == 0) *sink = t - t0;
+}
+__global__ __launch_bounds__(64)
+void ts_probe_empty() {}
+
+int ts_k_streams_concurrent(void *a, void *b, int *concurrent) {
+    hipEvent_t ea = nullptr, eb = nullptr;
+    int rc = 0;
+    *concurrent = 0;
+    if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess) return 1;
+    if (hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(ea); return 1; }
+    if (hipStreamSynchronize((hipStream_t)a) != hipSuccess || hipStreamSynchronize((hipStream_t)b) != hipSuccess) rc = 1;
+    if (!rc) {
+        hipLaunchKernelGGL(ts_probe_wait, dim3(1), dim3(64), 0, (hipStream_t)a, 100000ull, (unsigned long long *)nullptr);   // 1 ms
+        if (hipEventRecord(ea, (hipStream_t)a) != hipSuccess) rc = 1;
+        hipLaunchKernelGGL(ts_probe_empty, dim3(1), dim3(64), 0, (hipStream_t)b);
+        if (hipEventRecord(eb, (hipStream_t)b) != hipSuccess) rc = 1;
+        if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+    if (!rc) {
+        if (hipEventSynchronize(eb) != hipSuccess) rc = 1;
+        else {
+            const hipError_t q = hipEventQuery(ea);
+            if (q == hipErrorNotReady) *concurrent = 1;
+            else if (q != hipSuccess) rc = 1;
+        }
+        if (hipEventSynchronize(ea) != hipSuccess) rc = 1;
+    }
+    (void)hipGetLastError();
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    return rc;
+}
+
 // After the header was zeroed, any time before ts_k_launch_shard_pack: the scan-overflow flag.
 int ts_k_launch_shard_overflow(const TsShardPackParams *P, void *stream) {
     if (P->nwaves)

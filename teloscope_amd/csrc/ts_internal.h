@@ -51,6 +51,8 @@ struct TsScanParams {
     uint32_t        k;              // pattern length
     uint32_t        s, w;           // step and window (tips mode: s = w = tile size)
     uint32_t        s_inv;          // ceil(2^16 / s): 24-bit multiply division by s (tile-relative positions < 2^16)
+    uint32_t        s_magic22;      // ceil(2^22 / s) and
+    uint32_t        div_exact;      // 1: u x s_magic22 >> 22 == u / s for every tile position u (no correction step)
     uint32_t        halo_blocks;    // step blocks read beyond the owned ones: ceil(w / s) - 1
     uint32_t        nch;            // chunks of TS_CHUNK positions per tile
     uint32_t        max_windows;    // windows per tile (rows of the LDS record buffer)
@@ -358,6 +360,9 @@ int  ts_k_launch_shard_count(const TsShardPackParams *P, const TsShardHeader *H,
 int  ts_k_launch_shard_visible(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int prezeroed, void *stream);
 void *ts_k_shard_big_counter(void *tmp, uint32_t own_tiles);      // the 4 bytes ts_k_launch_shard_visible wants zero
 int  ts_k_launch_shard_windows(const TsShardPackParams *P, const TsShardHeader *H, void *stream);
+// 1 in *concurrent when a kernel on stream b runs while one on stream a is still running (the streams sit on different hardware
+// queues); both streams are synchronised first; ~1 ms.
+int  ts_k_streams_concurrent(void *a, void *b, int *concurrent);
 int  ts_k_launch_shard_overflow(const TsShardPackParams *P, void *stream);     // after the header's memset, before ts_k_launch_shard_pack
 int  ts_k_launch_shard_pack(const TsShardPackParams *P, const TsShardHeader *H, void *tmp, int with_visible, void *stream);
 unsigned long long ts_k_shard_tmp_bytes(uint32_t own_tiles);

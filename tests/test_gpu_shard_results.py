@@ -475,3 +475,54 @@ def test_rank_exchange_carries_every_part_s_message_through_rccl():
     free_segments(plan, out)
     plan.close()
     L.ts_exchange_destroy(x)
+
+
+def test_streams_on_one_queue_are_told_from_streams_that_run_side_by_side():
+    """ts_streams_concurrent (include/teloscan.h): a stream shares its hardware queue with itself; distributed.concurrent_streams
+    hands out streams that pairwise do not; and a pack on a stream of its own, with the library's side stream chosen against the
+    scan and pack streams (shard.cpp: side_stream_for), leaves the same message as one on the scan stream."""
+    import torch
+    from teloscope_amd import _capi as K
+    from teloscope_amd.distributed import PackedShard, ShardPlan, concurrent_streams
+    dev = torch.device("cuda", 0)
+    opts, tel = _teloscope(HEADLINE)
+    L, ctx = K.lib(), tel._ctx.ptr
+    s0 = torch.cuda.Stream(device=dev)
+    assert L.ts_streams_concurrent(ctx, C.c_void_p(s0.cuda_stream), C.c_void_p(s0.cuda_stream)) == 0
+    streams = concurrent_streams(tel, dev, 3, first=s0)
+    assert len(streams) == 3 and streams[0] is s0 and len({s.cuda_stream for s in streams}) == 3
+    for i in range(3):
+        for j in range(3):
+            if i != j:
+                assert L.ts_streams_concurrent(ctx, C.c_void_p(streams[i].cuda_stream), C.c_void_p(streams[j].cuda_stream)) == 1
+    rng = np.random.default_rng(77)
+    lens = [60_000, 9_000, 150_000]
+    seqs = [seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, n_its=3, iupac=1) for n in lens]
+    plan = ShardPlan(tel, lens, world=1)
+    buf = _fill(plan, seqs, dev)
+    msgs = []
+    for pack_stream in (streams[0], streams[1], streams[2]):
+        ps = PackedShard(plan, 0, dev, slots=1)
+        done = torch.cuda.Event()
+        with torch.cuda.stream(streams[0]):
+            ps.scan(buf.data_ptr(), C.c_void_p(streams[0].cuda_stream), 0)
+            done.record(streams[0])
+        pack_stream.wait_event(done)
+        ps.pack(C.c_void_p(pack_stream.cuda_stream), 0)
+        torch.cuda.synchronize()
+        assert not ps.status(0).flags
+        msgs.append(ps.msgs[0].cpu().numpy().copy())
+        ps.close()
+    from tests import shardpack
+    from teloscope_amd.distributed import shard_info
+    h = shardpack.read_header(msgs[0])
+    nb = int(h["n_blocks"])
+    assert nb > 0
+    off = shardpack.sections(shard_info(plan, 0), int(h["n_segs"]), int(h["own_end"] - h["own_begin"]), int(h["n_windows"]))
+    plan.close()
+    blocks = lambda m: np.sort(np.frombuffer(m[off["blocks"]:off["blocks"] + nb * 64].tobytes(), dtype=shardpack.DEVBLOCK_DT),
+                               order=("seg", "kind", "seq", "start"))           # (appended in completion order)
+    for m in msgs[1:]:
+        assert shardpack.read_header(m) == h
+        assert np.array_equal(msgs[0][128:off["blocks"]], m[128:off["blocks"]])
+        assert np.array_equal(blocks(msgs[0]), blocks(m))
