@@ -54,12 +54,14 @@ for do_pack in ([1, 0, 1, 0] if os.environ.get("PACK", "both") == "both" else [i
     buf = torch.zeros(int(plan.info.input_bytes), dtype=torch.uint8, device=dev)
     bench.fill_synthetic(buf, plan.segment_offsets(), lens, 42, dev)
     shard = D.PackedShard(plan, 0, dev, slots=slots, scale=1)
-    if os.environ.get("STREAMS") == "probe":               # scan + two pack streams on hardware queues of their own
-        stream, *pack_streams = D.concurrent_streams(tel, dev, 3)
+    NSCAN, NPACK = int(os.environ.get("SCAN_STREAMS", "1")), int(os.environ.get("PACK_STREAMS", "2"))
+    if os.environ.get("STREAMS") == "probe":               # scan + pack streams on hardware queues of their own
+        got = D.concurrent_streams(tel, dev, NSCAN + NPACK)
+        scan_streams, pack_streams = got[:NSCAN], got[NSCAN:]
     else:
-        stream = torch.cuda.Stream(device=dev)
-        pack_streams = [torch.cuda.Stream(device=dev, priority=-1 if PRIO else 0) for _ in range(2)]
-    sptr = C.c_void_p(stream.cuda_stream)
+        scan_streams = [torch.cuda.Stream(device=dev) for _ in range(NSCAN)]
+        pack_streams = [torch.cuda.Stream(device=dev, priority=-1 if PRIO else 0) for _ in range(NPACK)]
+    main = scan_streams[0]
     mk = HipEvent if EV == "hip" else torch.cuda.Event
     scanned = [mk() for _ in range(slots)]
     packed = [mk() for _ in range(slots)]
@@ -68,7 +70,9 @@ for do_pack in ([1, 0, 1, 0] if os.environ.get("PACK", "both") == "both" else [i
 
     def step(i):
         j = i % slots
-        ps = pack_streams[j % 2]
+        ps = pack_streams[j % len(pack_streams)]
+        stream = scan_streams[i % len(scan_streams)]
+        sptr = C.c_void_p(stream.cuda_stream)
         if EV == "none":
             shard.scan(in_ptr, sptr, j)
             return
@@ -77,7 +81,7 @@ for do_pack in ([1, 0, 1, 0] if os.environ.get("PACK", "both") == "both" else [i
         shard.scan(in_ptr, sptr, j)
         if EV == "wait-only":
             used[j] = True
-            packed[j].record(pack_streams[j % 2])
+            packed[j].record(ps)
             return
         scanned[j].record(stream)
         with torch.cuda.stream(ps):
@@ -87,7 +91,7 @@ for do_pack in ([1, 0, 1, 0] if os.environ.get("PACK", "both") == "both" else [i
             packed[j].record(ps)
         used[j] = True
 
-    with torch.cuda.stream(stream):
+    with torch.cuda.stream(main):
         for _ in range(2):
             for i in range(slots):
                 step(i)

@@ -18,7 +18,7 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
 rows.sort()
-scans = [i for i, r in enumerate(rows) if "ts_scan_tiles" in r[2] and r[1] - r[0] > 400000]
+scans = [i for i, r in enumerate(rows) if "ts_scan_tiles" in r[2] and r[1] - r[0] > float(os.environ.get("MIN_SCAN_US", "400")) * 1e3]
 # passes: separated by gaps of more than 50 ms between scans
 passes, cur = [], [scans[0]]
 for a, b in zip(scans, scans[1:]):

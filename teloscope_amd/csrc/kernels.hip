@@ -65,6 +65,9 @@
 #ifndef TS_EMIT_FINISH_LAST
 #define TS_EMIT_FINISH_LAST 1
 #endif
+#ifndef TS_PLAIN_FINISH_LAST
+#define TS_PLAIN_FINISH_LAST 0
+#endif
 
 // Wave priorities (s_setprio; the SIMD's arbiter picks the ready wave of the highest priority, the oldest among equals).
 // The dense per-chunk work (decode, probes: long runs of independent vector instructions) stays at 0; the phases that are
@@ -98,6 +101,70 @@ typedef LDS uint32_t lds_u32;
 // an LDS byte address (the dynamic-LDS base is 0) as a pointer
 __device__ __forceinline__ lds_u16 *lds_at16(uint32_t addr) { return (lds_u16 *)(uintptr_t)addr; }
 __device__ __forceinline__ lds_u8 *lds_at8(uint32_t addr) { return (lds_u8 *)(uintptr_t)addr; }
+
+// Global stores the compiler does not see (TS_ASM_STORES, default on).  On gfx9 loads and stores share one counter (vmcnt) and may
+// retire out of order with respect to each other, so once a store is pending the compiler can only wait for a LOAD with vmcnt(0) —
+// and it does so early: in front of every loop that holds a store and no load it empties the counter ("flush in the preheader").
+// In this kernel that meant an s_waitcnt vmcnt(0) right behind the request of the next tile's first chunk (the last drain of the
+// match queue is such a loop: its overflow path stores), i.e. the prefetch was waited for on the spot, and two more in phase 2.
+// The stores never feed a load of this kernel (the one place that reads records back waits for vmcnt(0) itself), so they are issued
+// by inline asm: the compiler counts only its loads, whose waits stay counted, and a pending store can only make such a wait longer,
+// never too short (loads retire in order among themselves).  Measurements: profiles/r05/asm_stores.txt.
+#ifndef TS_ASM_STORES
+#define TS_ASM_STORES 1
+#endif
+__device__ __forceinline__ void gstore(uint32_t *p, uint32_t v) {
+#if TS_ASM_STORES
+    asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void gstore(uint16_t *p, uint16_t v) {
+#if TS_ASM_STORES
+    asm volatile("global_store_short %0, %1, off" :: "v"(p), "v"((uint32_t)v));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void gstore(unsigned char *p, unsigned char v) {
+#if TS_ASM_STORES
+    asm volatile("global_store_byte %0, %1, off" :: "v"(p), "v"((uint32_t)v));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void gstore(u64 *p, u64 v) {
+#if TS_ASM_STORES
+    asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void gstore(uint4 *p, uint4 v) {
+#if TS_ASM_STORES
+    const u32x4 d = {v.x, v.y, v.z, v.w};
+    // (s_nop: a store of more than 8 bytes reads its data a cycle late, and the hazard recogniser does not look into asm)
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" :: "v"(p), "v"(d));
+#else
+    *p = v;
+#endif
+}
+// (possibly unaligned: the bit-packed window records)
+__device__ __forceinline__ void gstore_unaligned(unsigned char *p, u64 v) {
+#if TS_ASM_STORES
+    asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v));
+#else
+    __builtin_memcpy(p, &v, 8);
+#endif
+}
+__device__ __forceinline__ void gstore_unaligned(unsigned char *p, uint32_t v) {
+#if TS_ASM_STORES
+    asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v));
+#else
+    __builtin_memcpy(p, &v, 4);
+#endif
+}
 
 // Wave-wide inclusive prefix sum in 6 DPP adds (row_shr 1/2/4/8 inside each row of 16,
 // then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3); no LDS traffic.
@@ -376,7 +443,7 @@ void ts_scan_tiles(const TsScanParams P) {
             uint32_t *const wave_out = Q->matches_out + (u64)gw * cap;
             for (uint32_t i = lane; i < n; i += 64u) {
                 const uint32_t o = cursor + flushed + i;
-                if (o < cap && !(TS_ABL & 1)) wave_out[o] = stage_at(i);
+                if (o < cap && !(TS_ABL & 1)) gstore(wave_out + o, stage_at(i));
             }
             if (EMIT) park[5] = 1u;                                // (every lane writes the same word)
             // (the stores are waited for here, where a dense tile pays for it, so that the compiler knows of no pending store whose
@@ -403,7 +470,7 @@ void ts_scan_tiles(const TsScanParams P) {
             if (!EMIT || redo) {
                 for (uint32_t i = ln; i < n; i += 64u) {
                     const uint32_t o = cursor + flushed + i;
-                    if (o < cap && !(TS_ABL & 1)) wave_out[o] = stage_at(i);
+                    if (o < cap && !(TS_ABL & 1)) gstore(wave_out + o, stage_at(i));
                 }
                 flushed = done;
                 if (!EMIT) return;
@@ -446,8 +513,8 @@ void ts_scan_tiles(const TsScanParams P) {
                         const uint32_t at = vbase + vout + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
                         if (__builtin_amdgcn_inverse_ballot_w64(vm) && at < vis_cap) {
                             const uint32_t what = idx_mode ? base + i0 + ln : r;
-                            if (wide) ((uint32_t *)vis_out)[vwave + at] = what;
-                            else ((uint16_t *)vis_out)[vwave + at] = (uint16_t)what;
+                            if (wide) gstore((uint32_t *)vis_out + (vwave + at), what);
+                            else gstore((uint16_t *)vis_out + (vwave + at), (uint16_t)what);
                         }
                         vout += (uint32_t)__popcll(vm);
                     }
@@ -526,7 +593,7 @@ void ts_scan_tiles(const TsScanParams P) {
                 for (uint32_t i0 = 0; i0 < nfull; i0 += 64u) {             // whole rows
                     const uint32_t o = cursor + base + i0 + ln;
                     const uint32_t r = stage_at(i0 + ln);
-                    if (o < cap && !(TS_ABL & 1)) wave_out[o] = r;
+                    if (o < cap && !(TS_ABL & 1)) gstore(wave_out + o, r);
                     if (!(TS_EMIT_ABL & 1)) look(r, 64u, i0, std::true_type{});
                 }
                 for (uint32_t i0 = nfull; i0 < n; i0 += 64u) {              // the tile's last, partial row
@@ -535,7 +602,7 @@ void ts_scan_tiles(const TsScanParams P) {
                     uint32_t r = 0u;
                     if (ln < nrow) {
                         r = stage_at(i0 + ln);
-                        if (o < cap && !(TS_ABL & 1)) wave_out[o] = r;
+                        if (o < cap && !(TS_ABL & 1)) gstore(wave_out + o, r);
                     }
                     if (!(TS_EMIT_ABL & 1)) look(r, nrow, i0, std::false_type{});
                 }
@@ -553,7 +620,7 @@ void ts_scan_tiles(const TsScanParams P) {
             const uint32_t z15 = ch_cc < 0x7FFFu ? ch_cc : 0x7FFFu;
             if (!(ch_w1 & TS_CHAIN_HEADS)) ch_w1 |= z15;               // no head: every canonical record is ahead of the first
             const u64 voff = vwave + vbase;
-            if (ln == 0u) *(uint4 *)&Q->tile_chain[4ull * tile] = make_uint4((ch_first & 0xFFFFu) | (ch_last << 16), ch_w1 | (z15 << 16), (uint32_t)voff, (uint32_t)(voff >> 32));
+            if (ln == 0u) gstore((uint4 *)&Q->tile_chain[4ull * tile], make_uint4((ch_first & 0xFFFFu) | (ch_last << 16), ch_w1 | (z15 << 16), (uint32_t)voff, (uint32_t)(voff >> 32)));
             tile_vis = vout;
             park[4] = vbase + vout;                                // (every lane writes the same word)
         };
@@ -854,6 +921,9 @@ void ts_scan_tiles(const TsScanParams P) {
         }
 #define TS_REQUEST_NEXT_TILE()                                                                                                   \
         {                                                                                                                        \
+            /* the chunk loop's last loads re-read the final chunk and are never used: told complete here (they are a chunk old),  \
+               or every register of theirs that is written below waits for them AND for the loads requested here */               \
+            if (TS_ASM_STORES) __builtin_amdgcn_s_waitcnt(0x0F70);                                                                \
             KernArgs Q = tail_params();                                                                                          \
             const bool dyn = Q->dynamic_tiles != 0u;                                                                             \
             tile_next = dyn ? group + Q->ticket_groups * (group_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket))   \
@@ -873,7 +943,7 @@ void ts_scan_tiles(const TsScanParams P) {
         // The match fields of the tile's window records are complete (accumulated above).
         // (the emitting build flushes — and looks at — the records BEHIND the window phase: its rows want thirty scalars of their own,
         // and between the chunk loop and the window phase they competed with both for registers: 110 more spill moves per tile)
-        if (!EMIT || !TS_EMIT_FINISH_LAST) finish_records();
+        if (EMIT ? !TS_EMIT_FINISH_LAST : !TS_PLAIN_FINISH_LAST) finish_records();
         if (EMIT && TS_EMIT_LATE_REQUEST) TS_REQUEST_NEXT_TILE()
         if (P.windows_on) {
             // Nucleotides.  Counted here, from the tile's code plane, not per chunk: a row (a step block when w is a
@@ -994,9 +1064,9 @@ void ts_scan_tiles(const TsScanParams P) {
                         // (unaligned 8- and 4-byte stores: two store instructions for the 9 bytes of w = 1000, not nine)
                         unsigned char *d = dst0 + (u64)i * wb;
                         uint32_t b = 0;
-                        if (wb >= 8u) { __builtin_memcpy(d, &lo, 8); b = 8u; }
-                        if (wb - b >= 4u) { const uint32_t x = b ? (uint32_t)hi : (uint32_t)lo; __builtin_memcpy(d + b, &x, 4); b += 4u; }
-                        for (; b < wb; ++b) d[b] = (unsigned char)(b < 8u ? lo >> (8u * b) : hi >> (8u * (b - 8u)));
+                        if (wb >= 8u) { gstore_unaligned(d, lo); b = 8u; }
+                        if (wb - b >= 4u) { const uint32_t x = b ? (uint32_t)hi : (uint32_t)lo; gstore_unaligned(d + b, x); b += 4u; }
+                        for (; b < wb; ++b) gstore(d + b, (unsigned char)(b < 8u ? lo >> (8u * b) : hi >> (8u * (b - 8u))));
                     }
                 }
             } else if (!(TS_ABL & 8)) {
@@ -1017,20 +1087,20 @@ void ts_scan_tiles(const TsScanParams P) {
                         v.x = ((uint32_t)a & 0xFFFFu) * k; v.y = ((uint32_t)a >> 16) * k;
                         v.z = ((uint32_t)(a >> 32) & 0xFFFFu) * k; v.w = (uint32_t)(a >> 48) * k;
                     }
-                    wout[it] = v;
+                    gstore(wout + it, v);
                 }
             }
         }
 
-        if (EMIT && TS_EMIT_FINISH_LAST) finish_records();
+        if (EMIT ? TS_EMIT_FINISH_LAST : TS_PLAIN_FINISH_LAST) finish_records();
         // ------------------------------------------------------- tile directory
         {
             const uint32_t tcan = ccan, tfwd = cfwd;
             if (lane == 0) {
                 KernArgs Q = tail_params();
-                Q->tile_off[tile] = (u64)gw * Q->region_cap + cursor;
+                gstore((u64 *)&Q->tile_off[tile], (u64)gw * Q->region_cap + cursor);
                 const uint32_t vout = EMIT ? tile_vis : 0u;       // (the tile's chain summary left with its records: finish_records)
-                *(uint4 *)&Q->tile_stats[4ull * tile] = make_uint4(done, tcan, tfwd, (TS_EXP & 8) ? (((uint32_t)wall_clock64() & 0xFFFFFu) | (gw << 20)) : vout);
+                gstore((uint4 *)&Q->tile_stats[4ull * tile], make_uint4(done, tcan, tfwd, (TS_EXP & 8) ? (((uint32_t)wall_clock64() & 0xFFFFFu) | (gw << 20)) : vout));
             }
             cursor += done;
         }
