@@ -1,8 +1,8 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 set -o pipefail
-timeout -k 10 500 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_shard_results.py -x -q 2>&1 | tail -2 || exit 1
+LABEL=warm python3 profiles/emit_time.py 2>/dev/null
 for i in 1 2 3; do
-  LABEL=asm-stores python3 profiles/emit_time.py 2>/dev/null
-  LABEL=compiler-stores TELOSCAN_LIB=$PWD/teloscope_amd/libteloscan_noasm.so python3 profiles/emit_time.py 2>/dev/null
+  LABEL=base python3 profiles/emit_time.py 2>/dev/null
+  for d in 1 2 3; do LABEL=l2-prefetch-$d TELOSCAN_LIB=$PWD/teloscope_amd/libteloscan_pf$d.so python3 profiles/emit_time.py 2>/dev/null; done
 done
