@@ -937,7 +937,7 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
     // (profiles/r05/reads_canonical_index_experiment.txt).  The same pass bytes on the read-filter fuzz either way.
     if (b->tips && ctx->read_filter && b->kp.stage_u16) {
         const char *e = getenv("TS_READ_EMIT");
-        if (e && e[0] == '1') b->kp.emit = 2u;
+        if (e && e[0] == '1' && ts_k_read_index_built()) b->kp.emit = 2u;     // (only a library built with -DTS_READ_INDEX_BUILD=1 has it)
     }
     set_range(b, 0, b->tiles.size());
     return b;

@@ -110,6 +110,12 @@ __device__ __forceinline__ lds_u8 *lds_at8(uint32_t addr) { return (lds_u8 *)(ui
 // The stores never feed a load of this kernel (the one place that reads records back waits for vmcnt(0) itself), so they are issued
 // by inline asm: the compiler counts only its loads, whose waits stay counted, and a pending store can only make such a wait longer,
 // never too short (loads retire in order among themselves).  Measurements: profiles/r05/asm_stores.txt.
+// -DTS_READ_INDEX_BUILD=1: the emitting build also knows kp.emit == 2 (canonical-record indices for ts_read_predicate_canon, the read
+// filter experiment of profiles/r05/reads_canonical_index_experiment.txt); without it ts_k_read_index_built() says no and
+// TS_READ_EMIT=1 is ignored.
+#ifndef TS_READ_INDEX_BUILD
+#define TS_READ_INDEX_BUILD 0
+#endif
 #ifndef TS_ASM_STORES
 #define TS_ASM_STORES 1
 #endif
@@ -183,30 +189,8 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
     return v;
 }
 
-// Wave-wide inclusive prefix maximum, same six DPP steps (lanes outside a shift read 0)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_max(uint32_t v) {
-    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-    return v > o ? v : o;
-}
-__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
-    v = dpp_max<0x111, 0xf>(v);
-    v = dpp_max<0x112, 0xf>(v);
-    v = dpp_max<0x114, 0xf>(v);
-    v = dpp_max<0x118, 0xf>(v);
-    v = dpp_max<0x142, 0xa>(v);
-    v = dpp_max<0x143, 0xc>(v);
-    return v;
-}
-
-// The value of the lane below (lane 0: 0) by DPP wave_shr:1; the empty asm keeps it a v_mov_b32_dpp (folded into the
-// subtraction that follows it came back wrong on gfx950: see blockcall.hip)
-__device__ __forceinline__ uint32_t lane_below(uint32_t v) {
-    uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
-    asm volatile("" : "+v"(r));
-    return r;
-}
-
+// (a DPP move folded into the subtraction that follows it came back wrong on gfx950 — see blockcall.hip — so the places that take the
+// lane below's value keep it a v_mov_b32_dpp behind an empty asm)
 __device__ __forceinline__ unsigned long long low_bits(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
 
 // the lanes for which `p` holds, as a mask: on a bool this is one scalar AND of the compare's result with exec (__ballot takes
@@ -489,7 +473,7 @@ void ts_scan_tiles(const TsScanParams P) {
             // P.emit == 2 (a read batch: tips-only, every segment terminal zone as a whole): what leaves is the INDEX, among the
             // tile's records, of every canonical record — the read predicate (predicate.hip: ts_read_predicate_canon) then looks
             // only at the chains that hold one, a twentieth of the records — and no chain summary.
-            const bool idx_mode = Q->emit == 2u;
+            const bool idx_mode = TS_READ_INDEX_BUILD ? Q->emit == 2u : false;     // (a build flag: two vector instructions per row otherwise)
             typedef const uint32_t __attribute__((address_space(4))) *ConstU32;
             const uint32_t zone = idx_mode ? TS_ZONE_NONE : ((ConstU32)(uintptr_t)Q->tile_zone)[tile];
             const uint32_t vis_cap = Q->vis_cap;
@@ -499,6 +483,8 @@ void ts_scan_tiles(const TsScanParams P) {
             const uint32_t kdist = P.kdist;
             // what a row of up to 64 records (a record per lane, r = 0 in the lanes behind it) adds to the tile's visible records and
             // to its chain summary
+            // (whole-tile bounds, checked once on the scalar unit: the per-lane checks are for the tile that does not fit)
+            const bool rec_fit = cursor + base + n <= cap, vis_fit = vbase + n <= vis_cap;
             auto look = [&](const uint32_t r, const uint32_t nrow, const uint32_t i0, auto full_row) {
                 constexpr bool FULL = decltype(full_row)::value;           // a row of 64 records: no mask of live lanes to make or to apply
                 const uint32_t u = r >> 2;                                 // position in the tile
@@ -511,7 +497,7 @@ void ts_scan_tiles(const TsScanParams P) {
                     if (zone != TS_ZONE_NONE) vm = live_m & (canm | ballot64(u < (zone & 0xFFFFu)) | ballot64(u >= (zone >> 16)));
                     if (vm != 0ull && !(TS_EMIT_ABL & 2)) {
                         const uint32_t at = vbase + vout + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
-                        if (__builtin_amdgcn_inverse_ballot_w64(vm) && at < vis_cap) {
+                        if (__builtin_amdgcn_inverse_ballot_w64(vm) && (vis_fit || at < vis_cap)) {
                             const uint32_t what = idx_mode ? base + i0 + ln : r;
                             if (wide) gstore((uint32_t *)vis_out + (vwave + at), what);
                             else gstore((uint16_t *)vis_out + (vwave + at), (uint16_t)what);
@@ -593,7 +579,10 @@ void ts_scan_tiles(const TsScanParams P) {
                 for (uint32_t i0 = 0; i0 < nfull; i0 += 64u) {             // whole rows
                     const uint32_t o = cursor + base + i0 + ln;
                     const uint32_t r = stage_at(i0 + ln);
-                    if (o < cap && !(TS_ABL & 1)) gstore(wave_out + o, r);
+                    if (!(TS_ABL & 1)) {
+                        if (rec_fit) gstore(wave_out + o, r);
+                        else if (o < cap) gstore(wave_out + o, r);
+                    }
                     if (!(TS_EMIT_ABL & 1)) look(r, 64u, i0, std::true_type{});
                 }
                 for (uint32_t i0 = nfull; i0 < n; i0 += 64u) {              // the tile's last, partial row
@@ -1177,6 +1166,9 @@ const void *scan_variant_e(const TsScanParams *p) {
 }
 const void *scan_variant(const TsScanParams *p) { return p->emit ? scan_variant_e<true>(p) : scan_variant_e<false>(p); }
 }  // namespace
+
+// 1 when the emitting build knows kp.emit == 2 (see TS_READ_INDEX_BUILD)
+int ts_k_read_index_built(void) { return TS_READ_INDEX_BUILD; }
 
 int ts_k_prepare(uint32_t lds_bytes) {
     const void *fns[] = {(const void *)ts_scan_tiles<true, true, 4, false, false>, (const void *)ts_scan_tiles<true, false, 4, false, false>,

@@ -381,6 +381,7 @@ int  ts_k_launch_tile_order_export(const uint32_t *tile_stats, const unsigned lo
 int  ts_k_launch_unpack(const void *packed, uint32_t first, void *dst, unsigned long long n, const void *runs, uint32_t nruns,
                         void *runs_base, void *stream);
 // exchange.hip: box calibration (see there)
+int  ts_k_read_index_built(void);      // kernels.hip: built with -DTS_READ_INDEX_BUILD=1 (the read filter's canonical-index experiment)
 int  ts_k_box_probe(void *scratch, unsigned long long bytes, int num_cu, double *issue_per_ns, double *copy_bytes_per_ns, void *stream);
 int  ts_k_launch_widen_u16(const uint16_t *src, uint32_t *dst, unsigned long long n, void *stream);
 int  ts_k_launch_compact(const uint32_t *regions, const uint32_t *wave_fill,
