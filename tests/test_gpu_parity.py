@@ -882,6 +882,16 @@ def test_output_independent_of_tiling(cli, monkeypatch):
         for (s, ap, tips), g, e in zip(segs, got, want):
             assert_segment_equal(g, e, tips, ctx="tiling=%s cli=%r len=%d" % (tiling, cli, len(s)))
     assert ran >= 4, "too few tilings ran for %r" % cli
+    # round 5's forms of the per-match pass against round 4's, which the planner keeps for geometries that need them: 32-bit
+    # stage entries (TS_STAGE_U32=1: tiles above 2^14 positions take them anyway) and one accumulator row per window
+    # (TS_ACC_PER_WINDOW=1: what a window that is not a multiple of the step takes) — the same bits either way
+    monkeypatch.delenv("TS_GEOMETRY", raising=False)
+    for env in ("TS_STAGE_U32", "TS_ACC_PER_WINDOW"):
+        monkeypatch.setenv(env, "1")
+        got = ProductBackend(opts).scan_segments(segs)
+        monkeypatch.delenv(env)
+        for (s, ap, tips), g, e in zip(segs, got, want):
+            assert_segment_equal(g, e, tips, ctx="%s=1 cli=%r len=%d" % (env, cli, len(s)))
 
 
 @pytest.mark.parametrize("cli", ["-l 42", "-l 300 -k 30 -d 200 -y 0.7", "-x 0 -l 100 -k 12 -d 2000 -y 0.3",
