@@ -480,6 +480,9 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         scale = 1
         exch = D.ShardExchange(plan, rank, dev, dst=0, slots=slots, scale=scale)
         shard = D.PackedShard(plan, rank, dev, slots=slots, scale=scale)
+        # one scan in four of a slot is timed (roofline.kernel_ms is their mean): the start event of a timed scan is a packet on
+        # the scan's queue, 0.005 ms per scan at the N = 8 size (profiles/r05/shard_step_queues.txt)
+        shard.set_timing(max(0, int(os.environ.get("TS_BENCH_TIME_EVERY", "4"))))
         buf = full[int(shard.info.input_begin):max(int(shard.info.input_end), int(shard.info.input_begin) + 64)].clone()
         if not keep_full:
             del full
@@ -500,7 +503,6 @@ def run_scan(args, rank, local_rank, world, dev, backend):
         # size — 1.15 against 0.93 ms at 3 Gb, 0.188 against 0.177 at the N = 8 size: two persistent kernels that each want
         # every CU's whole LDS take turns badly.  One stream is the default.)
         scan_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(max(1, int(os.environ.get("TS_BENCH_SCAN_STREAMS", "1"))) - 1)]
-        scanned = [torch.cuda.Event() for _ in range(slots)]
         packed = [torch.cuda.Event() for _ in range(slots)]
         used = [False] * slots
         # Rehearsal of the exchange's SHAPE on one GPU (TS_BENCH_REHEARSE_WORLD=8 with TS_BENCH_FORCE_STRONG=1): what rank 0 of
@@ -539,9 +541,8 @@ def run_scan(args, rank, local_rank, world, dev, backend):
             if used[j]:
                 scan_stream.wait_event(packed[j])
             shard.scan(in_ptr, C.c_void_p(scan_stream.cuda_stream), j)
-            scanned[j].record(scan_stream)
             with torch.cuda.stream(pack_stream):
-                pack_stream.wait_event(scanned[j])
+                shard.wait_scan(C.c_void_p(pack_stream.cuda_stream), j)       # (the library's own event behind the scan)
                 if pending[j] is not None:
                     for w in pending[j]:
                         w.wait()
@@ -947,9 +948,9 @@ def scan_plus_block_calling_record(args, tel, lens, buf, dev, plain_ms, stream):
     steps, slots = min(args.steps, 40), max(2, int(os.environ.get("TS_BENCH_SLOTS", "4")))
     plan = D.ShardPlan(tel, lens, world=1)
     shard = D.PackedShard(plan, 0, dev, slots=slots, scale=1)
+    shard.set_timing(0)                                       # (no kernel times are read from these steps)
     sptr = C.c_void_p(stream.cuda_stream)                     # (the stream the plain scans ran on: streams share a few hardware queues)
     pack_streams = D.concurrent_streams(tel, dev, 3, first=stream)[1:]      # (not on the scan stream's hardware queue)
-    scanned = [torch.cuda.Event() for _ in range(slots)]
     packed = [torch.cuda.Event() for _ in range(slots)]
     used = [False] * slots
     in_ptr = buf.data_ptr()
@@ -960,9 +961,8 @@ def scan_plus_block_calling_record(args, tel, lens, buf, dev, plain_ms, stream):
         if used[j]:
             stream.wait_event(packed[j])
         shard.scan(in_ptr, sptr, j)
-        scanned[j].record(stream)
         with torch.cuda.stream(ps):
-            ps.wait_event(scanned[j])
+            shard.wait_scan(C.c_void_p(ps.cuda_stream), j)       # (the library's own event behind the scan)
             shard.pack(C.c_void_p(ps.cuda_stream), j)
             packed[j].record(ps)
         used[j] = True

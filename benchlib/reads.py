@@ -88,7 +88,6 @@ def reads_sub_record(args, dev):
     import teloscope_amd.distributed as D
     pred_stream = D.concurrent_streams(rf, dev, 2, first=stream)[1]     # (not on the scan stream's hardware queue)
     pptr = C.c_void_p(pred_stream.cuda_stream)
-    scanned = [torch.cuda.Event() for _ in range(nslots)]
     judged = [torch.cuda.Event() for _ in range(nslots)]
     used = [False] * nslots
 
@@ -98,8 +97,8 @@ def reads_sub_record(args, dev):
             stream.wait_event(judged[j])                           # the predicate that last read this slot's records
         if L.ts_batch_scan(batches[j], C.c_void_p(buf.data_ptr()), sptr) != 0:
             raise RuntimeError(rf._ctx.error())
-        scanned[j].record(stream)
-        pred_stream.wait_event(scanned[j])
+        if L.ts_batch_wait_scan(batches[j], pptr) != 0:            # (the library's own event behind the scan)
+            raise RuntimeError(rf._ctx.error())
         if L.ts_batch_read_pass(batches[j], C.c_void_p(d_passes[j].data_ptr()), pptr) != 0:
             raise RuntimeError(rf._ctx.error())
         judged[j].record(pred_stream)
@@ -223,7 +222,6 @@ def run_reads(args, rank, local_rank, world, dev, backend):
     pred_stream = D.concurrent_streams(rf, dev, 2, first=stream)[1]     # (not on the scan stream's hardware queue)
     pptr = C.c_void_p(pred_stream.cuda_stream)
     for e in batches:
-        e["scanned"] = torch.cuda.Event()
         e["judged"] = torch.cuda.Event()
     overlap = [True]
 
@@ -234,9 +232,8 @@ def run_reads(args, rank, local_rank, world, dev, backend):
                 stream.wait_event(e["judged"])                   # the last predicate over this sub-batch's records is done
             if L.ts_batch_scan(e["b"], C.c_void_p(e["buf"].data_ptr()), sptr) != 0:
                 raise RuntimeError(rf._ctx.error())
-            if overlap[0]:
-                e["scanned"].record(stream)
-                pred_stream.wait_event(e["scanned"])
+            if overlap[0] and L.ts_batch_wait_scan(e["b"], pptr) != 0:          # (the library's own event behind the scan)
+                raise RuntimeError(rf._ctx.error())
             if L.ts_batch_read_pass(e["b"], C.c_void_p(e["d_pass"].data_ptr()), pptr if overlap[0] else sptr) != 0:
                 raise RuntimeError(rf._ctx.error())
             with torch.cuda.stream(pred_stream if overlap[0] else stream):

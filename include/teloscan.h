@@ -336,6 +336,17 @@ int       ts_batch_upload(ts_batch *b, size_t i, const char *seq);
 /* Enqueues the scan on `stream` (a hipStream_t, NULL = default stream), reading bases from
  * d_input (NULL = the batch's own input buffer). Asynchronous. */
 int       ts_batch_scan(ts_batch *b, const void *d_input, void *stream);
+/* Makes `stream` wait for the batch's last scan (no-op when it is the scan's own stream): a stream wait on the event the library
+ * records behind every scan anyway — a caller that records an event of its own behind the scan puts a second packet on the scan's
+ * queue, 0.011-0.013 ms per scan that the next scan starts later (profiles/r05/shard_step_queues.txt).  What runs beside the next
+ * scan (ts_batch_pack_shard, ts_batch_read_pass on a stream of their own) is ordered this way.  The reference orders the same two
+ * steps by program order inside one job (scanSegment: scan, then block calling, /root/reference/src/teloscope.cpp:600-657). */
+int       ts_batch_wait_scan(ts_batch *b, void *stream);
+/* Which of the batch's scans are timed: every `every`-th (1, the default: all; 0: none).  A timed scan has an event recorded in
+ * front of it as well as the one behind every scan; ts_batch_info's kernel times are means over the timed scans since the last
+ * ts_batch_sync.  An event is a packet on the scan's queue: a caller that enqueues scans back to back and does not need every
+ * one's time (a rank's steps) saves 0.005 ms per untimed scan. */
+int       ts_batch_set_timing(ts_batch *b, uint32_t every);
 /* Waits for the last scan, reads back counters; grows the match buffer and rescans if it
  * overflowed. */
 int       ts_batch_sync(ts_batch *b);

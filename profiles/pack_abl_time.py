@@ -54,6 +54,8 @@ for do_pack in ([1, 0, 1, 0] if os.environ.get("PACK", "both") == "both" else [i
     buf = torch.zeros(int(plan.info.input_bytes), dtype=torch.uint8, device=dev)
     bench.fill_synthetic(buf, plan.segment_offsets(), lens, 42, dev)
     shard = D.PackedShard(plan, 0, dev, slots=slots, scale=1)
+    if "TIME_EVERY" in os.environ:
+        shard.set_timing(int(os.environ["TIME_EVERY"]))
     NSCAN, NPACK = int(os.environ.get("SCAN_STREAMS", "1")), int(os.environ.get("PACK_STREAMS", "2"))
     if os.environ.get("STREAMS") == "probe":               # scan + pack streams on hardware queues of their own
         got = D.concurrent_streams(tel, dev, NSCAN + NPACK)
@@ -83,9 +85,13 @@ for do_pack in ([1, 0, 1, 0] if os.environ.get("PACK", "both") == "both" else [i
             used[j] = True
             packed[j].record(ps)
             return
-        scanned[j].record(stream)
+        if EV != "lib":
+            scanned[j].record(stream)
         with torch.cuda.stream(ps):
-            wait(ps, scanned[j])
+            if EV == "lib":                         # ts_batch_wait_scan: the library's own event behind the scan
+                shard.wait_scan(C.c_void_p(ps.cuda_stream), j)
+            else:
+                wait(ps, scanned[j])
             if do_pack:
                 shard.pack(C.c_void_p(ps.cuda_stream), j)
             packed[j].record(ps)

@@ -96,6 +96,7 @@ void read_env_knobs(ts_ctx *c) {
     if (const char *e = getenv("TS_STAGE_THREADS")) { const int n = atoi(e); if (n > 0) k.stage_threads = (uint32_t)std::min(n, 64); }
     if (const char *e = getenv("TS_SIDE_PRIORITY")) k.side_priority = atoi(e);
     k.side_probe = !is("TS_SIDE_PROBE", '0');
+    if (const char *e = getenv("TS_SCAN_EVENTS")) k.scan_events = atoi(e);
     c->knobs = k;
 }
 
@@ -1109,15 +1110,36 @@ int ts_batch_scan(ts_batch *b, const void *d_input, void *stream) {
     }
 
     const size_t slot = (size_t)(b->scan_seq % kEventRing);
-    HIP_TRY(c, hipEventRecord(b->evs[2 * slot], st));
+    static_assert(kEventRing == 64, "timed_mask holds one bit per ring slot");
+    const bool timed = c->knobs.scan_events >= 2 && b->time_every && (b->scan_seq % b->time_every) == 0;
+    if (timed) { HIP_TRY(c, hipEventRecord(b->evs[2 * slot], st)); b->timed_mask |= 1ull << slot; }
+    else b->timed_mask &= ~(1ull << slot);
     {
         std::lock_guard<std::mutex> lk(c->mtx);
         int e = ts_k_launch_scan(&kp, b->grid, b->lds_bytes, stream);
         if (e != 0) return c->fail(TS_ERR_HIP, std::string("scan kernel launch: ") + hipGetErrorString((hipError_t)e));
     }
     if (kp.dynamic_tiles) ++b->ticket_seq;        // the launch is enqueued: it zeroes the other counter for the next one
-    HIP_TRY(c, hipEventRecord(b->evs[2 * slot + 1], st));
+    if (c->knobs.scan_events >= 1) HIP_TRY(c, hipEventRecord(b->evs[2 * slot + 1], st));
     ++b->scan_seq;
+    return TS_OK;
+}
+
+int ts_batch_set_timing(ts_batch *b, uint32_t every) {
+    if (!b) return TS_ERR_INVALID_ARG;
+    b->time_every = every;
+    return TS_OK;
+}
+
+int ts_batch_wait_scan(ts_batch *b, void *stream) {
+    if (!b) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    if (!b->scanned || b->dense || b->scan_seq == 0) return c->fail(TS_ERR_STATE, "ts_batch_wait_scan needs a scanned batch");
+    if (stream == b->last_stream) return TS_OK;                 // (the same stream: in order already)
+    if (c->knobs.scan_events < 1) return c->fail(TS_ERR_STATE, "ts_batch_wait_scan: the scan's events are switched off (TS_SCAN_EVENTS=0)");
+    DEVICE_TRY(c);
+    const size_t last = (size_t)((b->scan_seq - 1) % kEventRing);
+    HIP_TRY(c, hipStreamWaitEvent((hipStream_t)stream, b->evs[2 * last + 1], 0));
     return TS_OK;
 }
 
@@ -1130,18 +1152,21 @@ int ts_batch_sync(ts_batch *b) {
     for (int attempt = 0; attempt < 4; ++attempt) {
         {   // kernel times of the scans since the previous sync (the ring keeps the latest kEventRing)
             const size_t last = (size_t)((b->scan_seq - 1) % kEventRing);
-            HIP_TRY(c, hipEventSynchronize(b->evs[2 * last + 1]));
+            if (c->knobs.scan_events >= 1) HIP_TRY(c, hipEventSynchronize(b->evs[2 * last + 1]));
             const uint64_t from = std::max(b->harvested, b->scan_seq > kEventRing ? b->scan_seq - kEventRing : 0);
             double sum = 0.0;
             float ms = 0.f;
+            uint64_t ntimed = 0;
             for (uint64_t q = from; q < b->scan_seq; ++q) {
                 const size_t s2 = (size_t)(q % kEventRing);
+                if (!((b->timed_mask >> s2) & 1ull)) continue;              // (ts_batch_set_timing: not every scan has a start event)
                 HIP_TRY(c, hipEventElapsedTime(&ms, b->evs[2 * s2], b->evs[2 * s2 + 1]));
                 sum += ms;
+                ++ntimed;
             }
-            if (b->scan_seq > from) {
-                b->avg_n = b->scan_seq - from;
-                b->avg_ms = sum / (double)b->avg_n;
+            if (ntimed) {
+                b->avg_n = ntimed;
+                b->avg_ms = sum / (double)ntimed;
                 b->last_ms = ms;
             }
             b->harvested = b->scan_seq;

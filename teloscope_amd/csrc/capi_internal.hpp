@@ -133,6 +133,7 @@ struct ts_ctx {
         bool timing = false, gen_host_blocks = false, gen_prefetch = true, gen_list = true, packed_upload = true;
         uint32_t gen_abl = 0, stage_threads = 0;
         int side_priority = 0;                                // stream priority of the pack's side stream (0: the default priority)
+        int scan_events = 2;                                  // events ts_batch_scan records around a scan: 2 both (kernel times), 1 the one behind it, 0 none (measurements)
         bool side_probe = true;                               // try the side stream against the scan / pack streams it meets (shard.cpp)
         uint64_t packed_min_bytes = 1u << 20;                 // small calls are latency, not link time: they go plain
     } knobs;
@@ -253,6 +254,8 @@ struct ts_batch {
     std::vector<uint32_t> wave_fill;
     std::vector<hipEvent_t> evs;                 // ring of {start, stop} pairs, one per enqueued scan
     uint64_t scan_seq = 0, harvested = 0;        // scans enqueued / scans whose time has been read
+    uint32_t time_every = 1;                     // ts_batch_set_timing: every n-th scan has a start event too (0: none)
+    uint64_t timed_mask = 0;                     // ring slots whose scan was timed (kEventRing = 64 bits)
     double avg_ms = 0.0;
     uint64_t avg_n = 0;
 

@@ -505,6 +505,19 @@ class PackedShard:
         if rc != K.TS_OK:
             raise K.TeloscanError(rc, self.plan.teloscope._ctx.error())
 
+    def set_timing(self, every):
+        """ts_batch_set_timing on every slot: every n-th scan of a slot is timed (0: none).  A rank's steps time one scan in a few —
+        the start event of a timed scan is a packet on the scan's queue."""
+        for b in self.batches:
+            self.L.ts_batch_set_timing(b, every)
+
+    def wait_scan(self, stream_ptr, slot=0):
+        """`stream_ptr` waits for the slot's last scan (ts_batch_wait_scan: the library's own event behind the scan — an event of the
+        caller's would be a second packet on the scan's queue)."""
+        rc = self.L.ts_batch_wait_scan(self.batches[slot], stream_ptr)
+        if rc != K.TS_OK:
+            raise K.TeloscanError(rc, self.plan.teloscope._ctx.error())
+
     def pack(self, stream_ptr, slot=0):
         """Enqueue block calling + the packed message of the slot's last scan (the stream must be ordered behind that
         scan: the same stream, or one that waits for an event recorded after it — the kernels use no LDS and few

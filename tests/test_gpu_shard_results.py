@@ -503,11 +503,9 @@ def test_streams_on_one_queue_are_told_from_streams_that_run_side_by_side():
     msgs = []
     for pack_stream in (streams[0], streams[1], streams[2]):
         ps = PackedShard(plan, 0, dev, slots=1)
-        done = torch.cuda.Event()
         with torch.cuda.stream(streams[0]):
             ps.scan(buf.data_ptr(), C.c_void_p(streams[0].cuda_stream), 0)
-            done.record(streams[0])
-        pack_stream.wait_event(done)
+        ps.wait_scan(C.c_void_p(pack_stream.cuda_stream), 0)          # ts_batch_wait_scan: the pack stream behind the slot's scan
         ps.pack(C.c_void_p(pack_stream.cuda_stream), 0)
         torch.cuda.synchronize()
         assert not ps.status(0).flags
