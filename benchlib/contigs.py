@@ -86,6 +86,19 @@ def traffic_from_profile(args):
     return d["hbm_bytes_per_launch"], src
 
 
+def fastest_box_seen(args):
+    """Kernel time (ms) of the default workload on the fastest box the current kernels.hip has been measured on, from the committed
+    profile that carries its hash; None for another workload or a newer kernel."""
+    nbytes, src = traffic_from_profile(args)
+    if nbytes is None or not src:
+        return None
+    path = os.path.join(ROOT, src.split("static: ", 1)[1].split(" @", 1)[0])
+    try:
+        return float(json.load(open(path)).get("fastest_box_seen", {}).get("kernel_ms")) or None
+    except (OSError, TypeError, ValueError):
+        return None
+
+
 # ------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(args, opts, buf, offsets, lens):
     """Bounded sample of the same workload on the host cores through the oracle port, with the reference's own
@@ -882,6 +895,12 @@ def run_scan(args, rank, local_rank, world, dev, backend):
             if L.ts_box_probe(tel._ctx.ptr, C.byref(vi), C.byref(cb)) == 0:
                 out["roofline"]["box"] = {"valu_wave_instr_per_ns": round(vi.value, 1), "copy_read_plus_write_gbs": round(cb.value, 1),
                                           "note": "device-wide issue rate of independent v_and_b32 at 4 waves per SIMD; 16-byte grid-strided copy of 1 GiB"}
+                # spread or regression?  this box's kernel time over the fastest box the SAME kernel source has met (kept beside
+                # the PMC traffic, under the same hash): 1.00-1.10 is the pool's spread, more than that is not
+                fast = fastest_box_seen(args)
+                if fast:
+                    out["roofline"]["box"]["kernel_ms_over_fastest_box_seen"] = round(kern_ms / fast, 3)
+                    out["roofline"]["box"]["fastest_box_seen_kernel_ms"] = fast
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, opts, buf, offsets, lens)
         if args.verify and sharded is not None:

@@ -524,3 +524,38 @@ def test_streams_on_one_queue_are_told_from_streams_that_run_side_by_side():
         assert shardpack.read_header(m) == h
         assert np.array_equal(msgs[0][128:off["blocks"]], m[128:off["blocks"]])
         assert np.array_equal(blocks(msgs[0]), blocks(m))
+
+
+def test_one_scan_in_n_is_timed():
+    """ts_batch_set_timing: with n = 3 the scans 0, 3, 6 of seven have a start event; ts_batch_info's kernel time is their mean, and
+    the results do not depend on it."""
+    import torch
+    from teloscope_amd import _capi as K
+    from teloscope_amd.distributed import ShardPlan
+    dev = torch.device("cuda", 0)
+    opts, tel = _teloscope(HEADLINE)
+    L = K.lib()
+    rng = np.random.default_rng(5)
+    lens = [300_000, 41_000]
+    seqs = [seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev, n_its=2, iupac=1) for n in lens]
+    plan = ShardPlan(tel, lens, world=1)
+    buf = _fill(plan, seqs, dev)
+    sptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    info = K.BatchInfo()
+
+    def scans(n):
+        for _ in range(n):
+            assert L.ts_batch_scan(plan.batch, C.c_void_p(buf.data_ptr()), sptr) == 0
+        assert L.ts_batch_sync(plan.batch) == 0
+        assert L.ts_batch_get_info(plan.batch, C.byref(info)) == 0
+        return int(info.kernel_launches), float(info.avg_kernel_ms), int(info.n_matches)
+
+    n_all, ms_all, matches = scans(4)
+    assert n_all == 4 and ms_all > 0
+    assert L.ts_batch_set_timing(plan.batch, 3) == 0
+    n3, ms3, m3 = scans(7)                      # scans 4 .. 10 of the batch: 6 and 9 are multiples of 3
+    assert n3 == 2 and ms3 > 0 and m3 == matches
+    assert L.ts_batch_set_timing(plan.batch, 0) == 0
+    n0, ms0, m0 = scans(3)
+    assert (n0, ms0) == (n3, ms3) and m0 == matches          # nothing timed: the figures stay what they were
+    plan.close()
