@@ -1,10 +1,8 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 set -o pipefail
+timeout -k 10 500 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_shard_results.py -x -q 2>&1 | tail -2 || exit 1
 for i in 1 2 3; do
-LABEL=script STREAMS=probe EV=lib TIME_EVERY=0 python3 profiles/pack_abl_time.py 60 2>/dev/null
-timeout -k 10 400 python3 bench.py --no-cpu-baseline --no-e2e --no-reads 2>/dev/null | python3 -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['scan_plus_block_calling']
-print('bench: plain', d['ms_per_step'], d['roofline']['kernel_ms'], 'sharded', s['ms_per_step'], round(s['ms_per_step']/d['ms_per_step'],3), 'emit alone', s['emitting_scan_alone_ms'], 'pack alone', s['block_calling_and_pack_alone_ms'])"
+  LABEL=row-trim2 python3 profiles/emit_time.py 2>/dev/null
+  LABEL=before TELOSCAN_LIB=$PWD/teloscope_amd/libteloscan_pretrim.so python3 profiles/emit_time.py 2>/dev/null
 done
