@@ -25,6 +25,8 @@ for emit in (0, 1, 0, 1):
     buf = torch.zeros(int(plan.info.input_bytes), dtype=torch.uint8, device=dev)
     bench.fill_synthetic(buf, plan.segment_offsets(), lens, 42, dev)
     L.ts_batch_set_emit(plan.batch, emit)
+    if "TIME_EVERY" in os.environ:                         # ts_batch_set_timing: one scan in n has a start event
+        L.ts_batch_set_timing(plan.batch, int(os.environ["TIME_EVERY"]))
     st = torch.cuda.Stream(device=dev)
     sp = C.c_void_p(st.cuda_stream)
     dp = C.c_void_p(buf.data_ptr())
