@@ -411,6 +411,19 @@ __device__ __forceinline__ bool full_scan_pushes_m(uint32_t j, uint32_t l, const
     return diff >= 0 && (u64)diff >= g.start_index;
 }
 
+// Global stores and return-less atomics the compiler does not see (round 5; kernels.hip has the same helpers and the full story):
+// on gfx9 loads and stores share vmcnt, so with a store pending the compiler waits for the NEXT TILE'S PREFETCH with vmcnt(0) at the
+// first register it reuses — in the list kernel a few instructions behind the prefetch's issue.  Nothing in the kernel loads what it
+// stored.
+__device__ __forceinline__ void gen_store(uint32_t *p, uint32_t v) { asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v)); }
+__device__ __forceinline__ void gen_store(uint4 *p, uint4 v) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" :: "v"(p), "v"(d));       // (s_nop: the data of a store of more than 8 bytes is read a cycle late)
+}
+__device__ __forceinline__ void gen_add(uint32_t *p, uint32_t v) { asm volatile("global_atomic_add %0, %1, off" :: "v"(p), "v"(v)); }
+__device__ __forceinline__ void gen_or(uint32_t *p, uint32_t v) { asm volatile("global_atomic_or %0, %1, off" :: "v"(p), "v"(v)); }
+
 // The same pass in its LIST form (round 3; restructured in round 4): what the kernel above does per position — flag
 // lookup, push test, window shares — is done here per CANDIDATE, on full wavefronts, and a position costs ONE LDS probe.
 // PERSISTENT workgroups (a few per CU) stride over the tiles: the pattern tables are built once per workgroup, not per tile.
@@ -545,8 +558,20 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
         vg = (uint32_t)__popc(ok) | (g << 16);
         ct = ((uint32_t)__popc(lo) - g) | (((uint32_t)__popc(hi) - g) << 16);
     };
+    // tile descriptors by scalar loads (the table is written by the host only): as vector loads they sat behind a vmcnt wait in
+    // front of the very prefetch they address
+    typedef const TsGeneralTile __attribute__((address_space(4))) *ConstTile;
+    const ConstTile ctiles = (ConstTile)(uintptr_t)tiles;
+    auto tile_at = [&](uint32_t t) {
+        TsGeneralTile X;
+        X.in_off = ctiles[t].in_off; X.seg_rel = ctiles[t].seg_rel; X.k_p0 = ctiles[t].k_p0;
+        X.n = ctiles[t].n; X.avail = ctiles[t].avail; X.seg = ctiles[t].seg; X.r_p0 = ctiles[t].r_p0;
+        return X;
+    };
+    typedef const u64 __attribute__((address_space(4))) *ConstU64;        // (the per-segment tables too: host-written, uniform reads)
+    const ConstU64 c_seg_len = (ConstU64)(uintptr_t)seg_len, c_seg_win_base = (ConstU64)(uintptr_t)seg_win_base, c_seg_nwin = (ConstU64)(uintptr_t)seg_nwin;
     uint32_t tile = blockIdx.x;
-    TsGeneralTile T = tiles[tile];
+    TsGeneralTile T = tile_at(tile);
     uint4 v_main = load16(T, tid * 16u), v_halo = tid < kCodeWords - 256u ? load16(T, 4096u + tid * 16u) : make_uint4(0u, 0u, 0u, 0u);
     for (;;) {
         // 1'. stage
@@ -567,7 +592,7 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
         const bool more = tile_next < ntiles;
         TsGeneralTile Tn = T;
         if (more) {
-            Tn = tiles[tile_next];
+            Tn = tile_at(tile_next);
             v_main = load16(Tn, tid * 16u);
             if (tid < kCodeWords - 256u) v_halo = load16(Tn, 4096u + tid * 16u);
         }
@@ -626,8 +651,8 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
                     }
             }
         }
-        if (spilled && lane == 0u) atomicOr(overflow, 2u);
-        const u64 n = seg_len[T.seg];
+        if (spilled && lane == 0u) gen_or(overflow, 2u);
+        const u64 n = c_seg_len[T.seg];
         const u64 P0 = T.seg_rel;
         const u64 N1 = n - P0;                                                  // bases from the tile's first to the segment's end
         // window geometry of the tile: the calls whose windows reach it, the records it adds to.  No 64-bit division: the
@@ -635,13 +660,13 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
         const bool win_on = !tips && T.n;
         u64 nwin = 0, kw_lo = 0, kw_hi = 0, rec_hi = 0;
         if (win_on) {
-            nwin = seg_nwin[T.seg];
+            nwin = c_seg_nwin[T.seg];
             kw_lo = P0 >= Q.w ? T.k_p0 + 1u - Q.cw - (Q.rw > T.r_p0 ? 1u : 0u) : 0u;     // first call whose window reaches the tile: (P0 - w) / s + 1
             kw_hi = T.k_p0 + div_step(T.r_p0 + T.n - 1u, Q.s, magic);         // last call that starts inside it
             if (kw_hi >= nwin) kw_hi = nwin - 1u;
             rec_hi = kw_hi + (carries ? 1u : 0u);
             if (rec_hi >= nwin) rec_hi = nwin - 1u;
-            if (rec_hi - kw_lo >= kWaccMax) { if (tid == 0u) atomicOr(overflow, 2u); spilled = true; }     // (the host sizes this out: never)
+            if (rec_hi - kw_lo >= kWaccMax) { if (tid == 0u) gen_or(overflow, 2u); spilled = true; }     // (the host sizes this out: never)
         }
         PushGeom pg{};
         {
@@ -735,8 +760,8 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
         // did any wave's list spill?  then nothing of this tile counts: the group runs again with the kernel above
         const bool any_spill = (part[4] | part[5] | part[6] | part[7]) != 0u;
         if (tid == 0u) {
-            *(uint4 *)&tile_stats[4ull * tile] = make_uint4(total, 0u, 0u, 0u);
-            if (total > slot_cap) atomicOr(overflow, 1u);
+            gen_store((uint4 *)&tile_stats[4ull * tile], make_uint4(total, 0u, 0u, 0u));
+            if (total > slot_cap) gen_or(overflow, 1u);
         }
         // 4'. window records: thread r takes record kw_lo + r.  Positions relative to the tile's first base, 32-bit signed (the
         // host keeps w below 2^28 on this path; a segment end farther away than that is as good as infinitely far)
@@ -772,20 +797,20 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
             }
             const uint32_t tC = CT & 0xFFFFu, tT = CT >> 16, tG = VG >> 16, tA = (VG & 0xFFFFu) - tC - tT - tG;
             const uint4 cov = *(const uint4 *)&wacc[4u * tid];
-            uint32_t *const wr = win_out + (seg_win_base[T.seg] + R) * 8ull;
+            uint32_t *const wr = win_out + (c_seg_win_base[T.seg] + R) * 8ull;
             const int32_t span_hi = rel + (left < (int32_t)Q.w ? left : (int32_t)Q.w);
             if (rel >= 0 && span_hi <= tn) {                                 // the tile holds the whole record: this thread is its only writer
-                *(uint4 *)wr = make_uint4(tA, tC, tG, tT);
-                *(uint4 *)(wr + 4) = cov;
+                gen_store((uint4 *)wr, make_uint4(tA, tC, tG, tT));
+                gen_store((uint4 *)(wr + 4), cov);
             } else {
-                if (tA) atomicAdd(wr + 0, tA);
-                if (tC) atomicAdd(wr + 1, tC);
-                if (tG) atomicAdd(wr + 2, tG);
-                if (tT) atomicAdd(wr + 3, tT);
-                if (cov.x) atomicAdd(wr + 4, cov.x);
-                if (cov.y) atomicAdd(wr + 5, cov.y);
-                if (cov.z) atomicAdd(wr + 6, cov.z);
-                if (cov.w) atomicAdd(wr + 7, cov.w);
+                if (tA) gen_add(wr + 0, tA);
+                if (tC) gen_add(wr + 1, tC);
+                if (tG) gen_add(wr + 2, tG);
+                if (tT) gen_add(wr + 3, tT);
+                if (cov.x) gen_add(wr + 4, cov.x);
+                if (cov.y) gen_add(wr + 5, cov.y);
+                if (cov.z) gen_add(wr + 6, cov.z);
+                if (cov.w) gen_add(wr + 7, cov.w);
             }
         }
         // 5'. match records
@@ -799,7 +824,7 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
                 if (m == 0ull) continue;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 // the stream's record: tile position << 5 | length index << 2 | canonical << 1 | forward
-                if (ent & 4u) dst[base + rank] = ((wave * 1024u + (ent >> 6)) << 5) | (((ent >> 3) & 7u) << 2) | (ent & 3u);
+                if (ent & 4u) gen_store(dst + (base + rank), ((wave * 1024u + (ent >> 6)) << 5) | (((ent >> 3) & 7u) << 2) | (ent & 3u));
                 base += (uint32_t)__popcll(m);
             }
         }
