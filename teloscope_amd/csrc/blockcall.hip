@@ -87,7 +87,7 @@ struct Chain {                               // running chain of matches (startN
     }
 };
 
-__device__ void emit_block(const TsBlockCallParams &Q, TsDevBlock &b, uint32_t seg, uint32_t kind, uint32_t seq,
+__device__ __forceinline__ void emit_block(const TsBlockCallParams &Q, TsDevBlock &b, uint32_t seg, uint32_t kind, uint32_t seq,
                            u64 abs_pos) {
     const uint32_t slot = atomicAdd(Q.n_blocks, 1u);
     if (slot >= Q.block_cap) return;                       // overflow: the host sees n_blocks > cap
@@ -119,7 +119,9 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 // wanted orientation its predecessor in the walk, a ballot marks those that open a new chain (gap > -k), and the
 // state machine — wave-uniform, scalar — steps once per CHAIN (counts are popcounts of ballots), not once per
 // record: a telomere is one chain of thousands of matches.  Lane 0 writes the blocks.
-__device__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, uint32_t seg, u64 n, u64 abs_pos,
+// (forced inline: as a function of its own it took the kernel's parameters by reference — the whole parameter block went to scratch,
+// every pointer out of it became a flat address, and the eight rows it fetches ahead were waited for behind the first scratch reload)
+__device__ __forceinline__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, uint32_t seg, u64 n, u64 abs_pos,
                                   bool from_start, uint32_t &seq, uint32_t lane, bool &out_of_context) {
     u64 boundary = from_start ? 0 : n;                     // segment-relative
     Chain ch; bool open = false;
