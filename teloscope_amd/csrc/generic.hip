@@ -450,7 +450,7 @@ __device__ __forceinline__ void gen_or(uint32_t *p, uint32_t v) { asm volatile("
 #ifndef TS_GEN_WAVES
 #define TS_GEN_WAVES 5
 #endif
-__global__ __launch_bounds__(256, TS_GEN_WAVES)        // waves per SIMD = workgroups per CU (5: at most 96 VGPRs, two of them spilled; 6 — 80 VGPRs, nine spilled — measured the same, 4 — 99 VGPRs, none spilled — 8 % slower: profiles/r04/general_occupancy.txt)
+__global__ __launch_bounds__(256, TS_GEN_WAVES)        // waves per SIMD = workgroups per CU.  74 VGPRs and nothing spilled since round 5 (scalar descriptor loads); five per CU still measure best: six +1.5 %, seven +8 % (profiles/r05/general_list_waits.txt; round 4, at 96 VGPRs with two spilled: profiles/r04/general_occupancy.txt)
 void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles, const u64 *seg_len,
                            const u64 *seg_win_base, const u64 *seg_nwin, const TsGenericPatterns G, const TsGenericGeom Q, int tips, uint32_t slot_cap,
                            uint32_t lds_patterns, uint32_t nshort, uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
