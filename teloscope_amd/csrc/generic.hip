@@ -956,7 +956,9 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
         const uint32_t l = lens[li], q = l < 6u ? l : 6u, ext_bits = 2u * (6u - q);
         const uint32_t f0 = first[li], cnt = first[li + 1u] - f0;
         for (uint32_t x = tid; x < (cnt << ext_bits); x += 256u) {
-            const uint32_t pre = (uint32_t)(in_lds ? plo[f0 + (x >> ext_bits)] : W.lo[f0 + (x >> ext_bits)]) & ((1u << (2u * q)) - 1u);
+            u64 code_lo;
+            if (in_lds) code_lo = plo[f0 + (x >> ext_bits)]; else code_lo = W.lo[f0 + (x >> ext_bits)];        // (not a ternary: that is a flat read)
+            const uint32_t pre = (uint32_t)code_lo & ((1u << (2u * q)) - 1u);
             const uint32_t idx = pre | ((x & ((1u << ext_bits) - 1u)) << (2u * q));
             atomicOr(&pre6[idx], (P)((P)1 << li));
         }
@@ -975,26 +977,31 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
             const uint32_t nvalid = ilo ? (uint32_t)__builtin_ctz(ilo) : (ihi ? 32u + (uint32_t)__builtin_ctz(ihi) : 64u);
             const uint32_t rem = avail > j ? avail - j : 0u;
             const uint32_t maxlen = nvalid < rem ? nvalid : rem;
-            for (u64 cand = (u64)pre6[(uint32_t)lo & 0xFFFu]; cand; cand &= cand - 1ull) {
-                const uint32_t li = (uint32_t)__builtin_ctzll(cand);
-                const uint32_t l = lens[li];
-                if (l > maxlen) break;                   // lengths ascend: a non-ACGT base or the region's end stops this and every longer pattern
-                const u64 klo = l >= 32u ? lo : (lo & ((1ull << (2u * l)) - 1ull));
-                const u64 khi = l <= 32u ? 0ull : (hi & ((1ull << (2u * (l - 32u))) - 1ull));      // (l <= 63: the shift is below 64)
-                uint32_t a = first[li], b = first[li + 1u];
-                const uint32_t end = b;
-                while (a < b) {                          // binary search in the (lo, hi)-sorted list of this length
-                    const uint32_t mid = (a + b) >> 1;
-                    const u64 mlo = in_lds ? plo[mid] : W.lo[mid], mhi = in_lds ? phi[mid] : W.hi[mid];
-                    if (mlo < klo || (mlo == klo && mhi < khi)) a = mid + 1u; else b = mid;
+            // (the same search twice, over the lists in LDS or in device memory: one loop with `in_lds ? lds : global` reads made
+            // every read a FLAT access, which for LDS is far slower than a ds_read)
+            auto search = [&](const auto *list_lo, const auto *list_hi, const auto *list_fl) {
+                for (u64 cand = (u64)pre6[(uint32_t)lo & 0xFFFu]; cand; cand &= cand - 1ull) {
+                    const uint32_t li = (uint32_t)__builtin_ctzll(cand);
+                    const uint32_t l = lens[li];
+                    if (l > maxlen) break;               // lengths ascend: a non-ACGT base or the region's end stops this and every longer pattern
+                    const u64 klo = l >= 32u ? lo : (lo & ((1ull << (2u * l)) - 1ull));
+                    const u64 khi = l <= 32u ? 0ull : (hi & ((1ull << (2u * (l - 32u))) - 1ull));  // (l <= 63: the shift is below 64)
+                    uint32_t a = first[li], b = first[li + 1u];
+                    const uint32_t end = b;
+                    while (a < b) {                      // binary search in the (lo, hi)-sorted list of this length
+                        const uint32_t mid = (a + b) >> 1;
+                        const u64 mlo = list_lo[mid], mhi = list_hi[mid];
+                        if (mlo < klo || (mlo == klo && mhi < khi)) a = mid + 1u; else b = mid;
+                    }
+                    if (a < end && list_lo[a] == klo && list_hi[a] == khi) {
+                        const uint32_t fl = list_fl[a];
+                        h |= 1ull << li;
+                        if (fl & 1u) f |= 1ull << li;
+                        if (fl & 2u) c |= 1ull << li;
+                    }
                 }
-                if (a < end && (in_lds ? plo[a] : W.lo[a]) == klo && (in_lds ? phi[a] : W.hi[a]) == khi) {
-                    const uint32_t fl = in_lds ? pfl[a] : W.flags[a];
-                    h |= 1ull << li;
-                    if (fl & 1u) f |= 1ull << li;
-                    if (fl & 2u) c |= 1ull << li;
-                }
-            }
+            };
+            if (in_lds) search(plo, phi, pfl); else search(W.lo, W.hi, W.flags);
         }
         hit[j] = (M)h; fwdm[j] = (M)f; canm[j] = (M)c;
     }
