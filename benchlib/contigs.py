@@ -264,6 +264,57 @@ def pcie_inclusive(L, K, tel, buf, offsets, lens, total):
             "input": "TS_INPUT_PACKED2: 2-bit codes + invalid runs in host memory (%.2f GB instead of %.2f), packed before the clock "
                      "starts as a FASTA front end would while parsing" % (total / 4e9, total / 1e9)}
         del packed, keep, psegs
+    # FASTA TEXT in (TS_INPUT_TEXT_PIECES): the assembly as 80-column FASTA lines in host memory — what a front end that maps a file
+    # holds — handed over as text pieces; the library's staging threads skip the line ends and pack INSIDE the clock.  This is the
+    # honest "file bytes in host memory -> results" figure (round 4's verdict, item 4); the packed-in leg above leaves the packing out.
+    if int(L.ts_takes_text_input(tel._ctx.ptr, 0)) and not os.environ.get("TS_BENCH_NO_TEXT_IN"):
+        width, lines_per_piece = 80, 200_000                              # 16.2 MB of text per piece (the format's limit: 16 MiB)
+        texts, piece_arrays, tsegs = [], [], (K.SegmentIn * n)()
+        for i in range(n):
+            m = int(lens[i])
+            bases = host[offsets[i]:offsets[i] + m]
+            rows = m // width
+            txt = np.empty(m + rows + (1 if m % width else 0), dtype=np.uint8)
+            if rows:
+                body = txt[:rows * (width + 1)].reshape(rows, width + 1)
+                body[:, :width] = bases[:rows * width].reshape(rows, width)
+                body[:, width] = 10
+            if m % width:
+                txt[rows * (width + 1):-1] = bases[rows * width:]
+                txt[-1] = 10
+            texts.append(txt)
+            step_t, step_b = lines_per_piece * (width + 1), lines_per_piece * width
+            npieces = max(1, -(-len(txt) // step_t))
+            arr = (K.TextPiece * npieces)()
+            for q in range(npieces):
+                t0_, t1_ = q * step_t, min(len(txt), (q + 1) * step_t)
+                arr[q].text = C.cast(C.c_void_p(txt.ctypes.data + t0_), C.c_char_p)
+                arr[q].text_len = t1_ - t0_
+                arr[q].n_bases = min(m, (q + 1) * step_b) - q * step_b
+            piece_arrays.append(arr)
+            tsegs[i].seq = C.cast(arr, C.c_char_p)
+            tsegs[i].len = m
+            tsegs[i].input_format = K.TS_INPUT_TEXT_PIECES
+            tsegs[i].n_pieces = npieces
+        res = (K.SegmentOut * n)()
+        cnts = (K.SegmentCounts * n)()
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = L.ts_scan_segments_blocks(tel._ctx.ptr, tsegs, n, res, cnts)
+            dt = time.perf_counter() - t0
+            if rc != 0:
+                raise RuntimeError(tel._ctx.error())
+            nm = int(sum(c.n_matches for c in cnts))
+            L.ts_free_segments(res, n)
+            best = dt if best is None else min(best, dt)
+        if nm != e2e["blocks_windows_counts"]["matches"]:
+            raise RuntimeError("FASTA text input and joined bases gave different match counts")
+        e2e["fasta_text_in"] = {
+            "seconds": round(best, 4), "gbases_per_s": round(total / best / 1e9, 3), "matches": nm,
+            "input": "TS_INPUT_TEXT_PIECES: %d-column FASTA lines in host memory (%.2f GB of text), pieces of %d lines; line ends skipped and "
+                     "bases packed by the library's staging threads inside the clock" % (width, sum(len(t) for t in texts) / 1e9, lines_per_piece)}
+        del texts, piece_arrays, tsegs
     # the writers' view over ts_scan_segments_multi: one shard per context, each over its own PCIe link (here: the contexts
     # this one GPU can give — the figure says what the entry point costs, not what more links would add)
     import teloscope_amd as ta

@@ -52,6 +52,11 @@ struct PackRuns {
     void finish();
 };
 void pack_bases(const unsigned char *src, size_t n, unsigned char *dst, bool fold, uint32_t pos0, PackRuns &r);
+// The same from FASTA body text: up to n bases from *cursor on (line ends skipped: '\n', and a '\r' right before one or at the very end
+// of the text), packed straight from the text — no stripped copy in between.  dst gets (taken + 3) / 4 bytes (the last one padded with
+// code 0) and may be written up to 8 bytes beyond that; returns the bases taken (fewer than n only when the text ends) and leaves the
+// cursor behind the last byte it consumed (never between a carriage return and its line feed).
+size_t pack_text(const char **cursor, const char *end, size_t n, unsigned char *dst, bool fold, uint32_t pos0, PackRuns &r);
 
 float gc_content(const uint32_t counts[4], uint32_t window_size);
 float shannon_entropy(const uint32_t counts[4], uint32_t window_size);

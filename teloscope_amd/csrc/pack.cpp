@@ -112,6 +112,99 @@ void pack_bases(const unsigned char *src, size_t n, unsigned char *dst, bool fol
     for (; i < n; i += 4) dst[i >> 2] = pack4_scalar(src + i, n - i < 4 ? n - i : 4, fold_and, pos0 + (uint32_t)i, r);
 }
 
+namespace {
+
+// appends `nbits` (<= 64) low bits of `bits` to a little-endian bit stream: acc holds `fill` (< 64) pending bits
+struct BitOut {
+    unsigned char *dst;
+    uint64_t acc = 0;
+    uint32_t fill = 0;
+    inline void put(uint64_t bits, uint32_t nbits) {
+        if (!nbits) return;
+        acc |= bits << fill;
+        if (fill + nbits >= 64u) {
+            std::memcpy(dst, &acc, 8);
+            dst += 8;
+            acc = fill ? bits >> (64u - fill) : 0ull;
+            fill = fill + nbits - 64u;
+        } else fill += nbits;
+    }
+    inline void flush() {                                             // the pending bits, whole bytes, zero padded
+        for (uint32_t b = 0; b < fill; b += 8) *dst++ = (unsigned char)(acc >> b);
+        acc = 0; fill = 0;
+    }
+};
+
+__attribute__((target("avx2,bmi2")))
+size_t pack_text_avx2(const char **cursor, const char *end, size_t n, BitOut &out, bool fold, uint32_t pos0, PackRuns &r) {
+    const __m256i fold_mask = _mm256_set1_epi8(fold ? (char)0xDF : (char)0xFF);
+    const __m256i three = _mm256_set1_epi8(3);
+    const __m256i lut = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                         'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i w14 = _mm256_set1_epi16(0x0401), w116 = _mm256_set1_epi32(0x00100001);
+    const __m256i gather = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                            0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const __m256i lf = _mm256_set1_epi8('\n'), crv = _mm256_set1_epi8('\r');
+    const char *p = *cursor;
+    size_t done = 0;
+    // 32 text bytes per round while 32 more bases are wanted and byte p[32] is readable (it decides whether a carriage return in
+    // the chunk's last byte belongs to a line end)
+    while (n - done >= 32 && end - p >= 33) {
+        const __m256i raw = _mm256_loadu_si256((const __m256i *)p);
+        const uint32_t mlf = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(raw, lf));
+        const uint32_t mcr = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(raw, crv));
+        const uint32_t ends = mlf | (mcr & ((mlf >> 1) | (p[32] == '\n' ? 0x80000000u : 0u)));      // bytes that are (part of) a line end
+        const __m256i v = _mm256_and_si256(raw, fold_mask);
+        __m256i code = _mm256_and_si256(_mm256_srli_epi16(v, 1), three);
+        const __m256i ok = _mm256_cmpeq_epi8(v, _mm256_shuffle_epi8(lut, code));
+        uint32_t bad = ~(uint32_t)_mm256_movemask_epi8(ok);
+        code = _mm256_and_si256(code, ok);
+        const __m256i t32 = _mm256_madd_epi16(_mm256_maddubs_epi16(code, w14), w116);
+        const __m256i q = _mm256_shuffle_epi8(t32, gather);
+        uint64_t bits = (uint64_t)(uint32_t)_mm_cvtsi128_si32(_mm256_castsi256_si128(q)) |
+                        ((uint64_t)(uint32_t)_mm_cvtsi128_si32(_mm256_extracti128_si256(q, 1)) << 32);
+        uint32_t nb = 32u;
+        if (ends) {                                                  // take the line ends' slots out of the codes and of the invalid mask
+            const uint32_t keep = ~ends;
+            const uint64_t keep2 = _pdep_u64((uint64_t)keep, 0x5555555555555555ull) * 3ull;
+            bits = _pext_u64(bits, keep2);
+            bad = (uint32_t)_pext_u32(bad, keep);
+            nb = (uint32_t)__builtin_popcount(keep);
+        }
+        out.put(bits, 2u * nb);
+        while (bad) { push_invalid(r, pos0 + (uint32_t)done + (uint32_t)__builtin_ctz(bad)); bad &= bad - 1u; }
+        done += nb;
+        p += 32;
+    }
+    *cursor = p;
+    return done;
+}
+
+}  // namespace
+
+size_t pack_text(const char **cursor, const char *end, size_t n, unsigned char *dst, bool fold, uint32_t pos0, PackRuns &r) {
+    static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+    BitOut out;
+    out.dst = dst;
+    size_t done = fast ? pack_text_avx2(cursor, end, n, out, fold, pos0, r) : 0;
+    // the last bytes (and everything, without AVX2 / BMI2): a byte at a time
+    const uint32_t fold_and = fold ? 0xDFu : 0xFFu;
+    const char *p = *cursor;
+    while (done < n && p < end) {
+        const unsigned char raw = (unsigned char)*p;
+        if (raw == '\n') { ++p; continue; }
+        if (raw == '\r' && (p + 1 == end || p[1] == '\n')) { ++p; continue; }
+        const uint32_t c = raw & fold_and, code = (c >> 1) & 3u;
+        if (c != ((0x47544341u >> (8u * code)) & 0xFFu)) { push_invalid(r, pos0 + (uint32_t)done); out.put(0ull, 2u); }
+        else out.put((uint64_t)code, 2u);
+        ++done; ++p;
+    }
+    // (line ends right behind the last base stay for the next call: it skips them)
+    out.flush();
+    *cursor = p;
+    return done;
+}
+
 void PackRuns::finish() {
     if (open_len) runs.push_back({open_start, open_len});
     open_len = 0;

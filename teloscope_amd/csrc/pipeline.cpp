@@ -17,6 +17,7 @@
 // and one job per chunk of a 2048-record FASTQ batch (src/input.cpp:753-812); a group is the GPU-sized
 // equivalent of such a job, and results come back in input order whatever the grouping.
 #include <hip/hip_runtime.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -135,9 +136,57 @@ bool strip_copy(char *dst, const char *text, uint64_t text_len, uint64_t n_bases
     return left == 0;
 }
 
+// The two walks over FASTA body text below — find the text position of a base, copy bases without their line ends — took a
+// memchr and a memcpy per 81-byte LINE (37 M lines per 3 Gb: FASTA text in ran at half the rate of joined bases).  With AVX2 they
+// go 32 bytes at a time.  A byte is a base unless it is a line feed, or a carriage return right before one (the byte behind the
+// chunk is looked at for the chunk's last byte, so a chunk's count is exact by itself).  The scalar loops finish the last bytes of
+// a piece and are the whole path without AVX2.
+__attribute__((target("avx2")))
+inline uint32_t line_end_mask32(const char *p) {               // bit i: byte i of the chunk is (part of) a line end; p[32] is readable
+    const __m256i v = _mm256_loadu_si256((const __m256i *)p);
+    const uint32_t lf = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('\n')));
+    const uint32_t cr = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('\r')));
+    const uint32_t lf_next = (lf >> 1) | (p[32] == '\n' ? 0x80000000u : 0u);     // bit i: byte i + 1 is a line feed
+    return lf | (cr & lf_next);
+}
+
+// skips whole 32-byte chunks of [p, end) while base `*skip` lies behind them; returns the chunk it lies in (or the last bytes)
+__attribute__((target("avx2")))
+const char *text_locate_avx2(const char *p, const char *end, uint64_t *skip) {
+    while (end - p >= 33) {
+        const uint32_t bases = 32u - (uint32_t)__builtin_popcount(line_end_mask32(p));
+        if (*skip < bases) break;
+        *skip -= bases;
+        p += 32;
+    }
+    return p;
+}
+
+// copies bases of [*pp, end) to dst, 32 text bytes at a time, while at least 32 more are wanted; the cursor stays at a place the
+// scalar walk can go on from (never between a carriage return and its line feed).  dst must have 32 bytes of slack.
+__attribute__((target("avx2")))
+uint64_t strip_take_avx2(char *dst, uint64_t n, const char **pp, const char *end) {
+    const char *p = *pp;
+    uint64_t left = n;
+    while (left >= 32 && end - p >= 33) {
+        const uint32_t m = line_end_mask32(p);
+        _mm256_storeu_si256((__m256i *)dst, _mm256_loadu_si256((const __m256i *)p));
+        if (m == 0u) { dst += 32; p += 32; left -= 32; continue; }
+        const uint32_t pos = (uint32_t)__builtin_ctz(m);             // the bases before the chunk's first line end are in place
+        dst += pos; left -= pos;
+        p += pos;
+        if (*p == '\r') ++p;                                        // (followed by a line feed: that is what the mask says)
+        ++p;                                                        // the line feed
+    }
+    *pp = p;
+    return n - left;
+}
+
 // text position of base `skip` of a text piece (skip < its n_bases)
 const char *text_locate(const char *text, uint64_t text_len, uint64_t skip) {
     const char *p = text, *end = text + text_len;
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2) p = text_locate_avx2(p, end, &skip);          // (chunks begin anywhere in a line: the walk below counts from any byte)
     while (p < end) {
         const char *nl = (const char *)std::memchr(p, '\n', (size_t)(end - p));
         const char *stop = nl ? nl : end;
@@ -153,8 +202,10 @@ const char *text_locate(const char *text, uint64_t text_len, uint64_t skip) {
 // Up to n bases of FASTA body text from the cursor *pp on (line ends skipped), cursor advanced; returns the bases taken
 // (fewer than n only when the text ends).
 uint64_t strip_take(char *dst, uint64_t n, const char **pp, const char *end) {
-    const char *p = *pp;
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
     uint64_t left = n;
+    if (have_avx2) { const uint64_t got = strip_take_avx2(dst, n, pp, end); dst += got; left -= got; }
+    const char *p = *pp;
     while (left && p < end) {
         const char *nl = (const char *)std::memchr(p, '\n', (size_t)(end - p));
         const char *stop = nl ? nl : end;
@@ -295,8 +346,31 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
             const uint64_t share = ((P + nt - 1) / nt + 4095) & ~4095ull;
             std::vector<ts::PackRuns> wr(nt);
             std::atomic<int> short_text{0};
+            // the workers' ranges: equal shares — but where FASTA text pieces lie in the chunk, a range begins where a piece begins
+            // (rounded up to a whole byte of codes) when one does within half a share of the even cut: a worker that enters a text
+            // piece in its middle has to find the text position of its first base, i.e. read the piece's text up to there, and the
+            // same text is read again when it is packed (text in ran memory-bound at 1.5 x the traffic of joined bases)
+            std::vector<uint64_t> cut(nt + 1);
+            for (unsigned t = 0; t <= nt; ++t) cut[t] = std::min<uint64_t>(P, (uint64_t)t * share);
+            {
+                size_t q = i;
+                for (unsigned t = 1; t < nt; ++t) {
+                    const uint64_t ideal = (uint64_t)t * share;
+                    if (ideal >= P) break;
+                    while (q < j && pieces[q].off < c0a + ideal) ++q;                  // first piece that begins at or behind the even cut
+                    uint64_t best = ideal, dist = share / 2;
+                    for (size_t c = (q > i ? q - 1 : q); c < j && c <= q; ++c) {       // the piece starts either side of it
+                        if (!pieces[c].text_len || pieces[c].off < c0a) continue;
+                        const uint64_t at = (pieces[c].off - c0a + 3) & ~3ull;
+                        const uint64_t d = at > ideal ? at - ideal : ideal - at;
+                        if (d < dist && at > cut[t - 1] && at < P) { best = at; dist = d; }
+                    }
+                    cut[t] = best;
+                }
+                for (unsigned t = 1; t <= nt; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+            }
             auto pack_range = [&](unsigned t) {
-                const uint64_t a0 = (uint64_t)t * share, z0 = std::min<uint64_t>(P, a0 + share);
+                const uint64_t a0 = cut[t], z0 = cut[t + 1];
                 if (a0 >= z0) return;
                 constexpr uint64_t BK = 16384;
                 alignas(64) unsigned char buf[BK];
@@ -311,6 +385,18 @@ int upload_pieces(ts_ctx *c, const std::vector<UpPiece> &pieces_in, void *din, u
                     // wholly inside one plain piece: packed from where it lies
                     if (k < j && !pieces[k].text_len && !pieces[k].packed && pieces[k].off <= la && pieces[k].off + pieces[k].len >= lz) {
                         ts::pack_bases((const unsigned char *)pieces[k].src + (la - pieces[k].off), z - a, (unsigned char *)dst + (a >> 2), fold, (uint32_t)a, R);
+                        continue;
+                    }
+                    // wholly inside one FASTA text piece: packed straight from the text (ts::pack_text: 32 text bytes at a time, the line
+                    // ends' slots taken out of the codes) — the stripped copy in between made text in half as fast as joined bases
+                    if (k < j && pieces[k].text_len && !pieces[k].packed && pieces[k].off <= la && pieces[k].off + pieces[k].len >= lz) {
+                        const UpPiece &pc = pieces[k];
+                        if (tk != k) {                                               // enter this text piece (at base la - pc.off)
+                            tk = k;
+                            tend = pc.src + pc.text_len;
+                            tcur = la > pc.off ? text_locate(pc.src, pc.text_len, la - pc.off) : pc.src;
+                        }
+                        if (ts::pack_text(&tcur, tend, z - a, (unsigned char *)dst + (a >> 2), fold, (uint32_t)a, R) != z - a) short_text.store(1);
                         continue;
                     }
                     // bases that arrive packed (TS_INPUT_PACKED2): when every piece the block touches is such, their codes are

@@ -852,6 +852,72 @@ def test_sixty_four_concurrent_callers_cost_about_one_batched_call():
 TILINGS = ["16,1", "16,3", "12,5", "10,6", "10,3", "8,2", "4,7", "2,4", "1,1", "1,8"]      # 10 waves = two workgroups per CU
 
 
+def test_ragged_fasta_text_equals_joined_bases():
+    """TS_INPUT_TEXT_PIECES through the staging threads' 32-byte walks (pipeline.cpp: text_locate / strip_take): lines of every
+    width from 1 to 130, LF and CRLF mixed, blank lines, a stray carriage return inside a line (a byte that is not a base), pieces
+    cut anywhere — between a carriage return and its line feed too — and a segment long enough that every staging thread enters
+    its pieces in the middle.  The same bases joined give the same segment, which is the oracle's."""
+    import ctypes as C
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import user_input
+    cli = "-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -m -i"
+    opts = H.parse_cli("x.fa " + cli)
+    tel = ta.Teloscope(user_input(opts))
+    L = K.lib()
+    rng = np.random.default_rng(20261005)
+    seq = bytearray(seqgen.chromosome(rng, 3_300_017, opts.canonical_fwd, opts.canonical_rev, n_its=6, iupac=4, lower=0.02))
+    for at in rng.integers(1000, len(seq) - 1000, 40):                 # stray carriage returns: bytes like any other non-base
+        seq[int(at)] = 13
+    seq = bytes(seq)
+    out, at, lines = [], 0, 0
+    while at < len(seq):
+        w = int(rng.integers(1, 131)) if lines % 7 else 80
+        line = seq[at:at + w]
+        if line.endswith(b"\r") and at + w < len(seq):                 # (a line's own last byte is never a bare carriage return)
+            line = line[:-1] if len(line) > 1 else seq[at:at + 2]
+        at += len(line)
+        out.append(line + (b"\r\n" if rng.random() < 0.3 else b"\n"))
+        if rng.random() < 0.01:
+            out.append(b"\n")
+        lines += 1
+    text = b"".join(out)
+    cuts = sorted(set([0, len(text)] + [int(x) for x in rng.integers(1, len(text) - 1, 9)]))
+    blobs = [text[a:b] for a, b in zip(cuts, cuts[1:])]
+
+    def bases_of(blob, last):
+        b = blob.replace(b"\r\n", b"\n").replace(b"\n", b"")
+        return len(b) - (1 if b.endswith(b"\r") and not last else 0)     # a '\r' at the very end of a piece belongs to a line end
+    # (a stray '\r' must not end a piece: move such cuts one byte on)
+    fixed = [0]
+    for c in cuts[1:-1]:
+        while text[c - 1:c] == b"\r" and text[c:c + 1] != b"\n":
+            c += 1
+        fixed.append(c)
+    cuts = sorted(set(fixed + [len(text)]))
+    blobs = [text[a:b] for a, b in zip(cuts, cuts[1:])]
+    pieces = (K.TextPiece * len(blobs))()
+    keep = []
+    for i, bl in enumerate(blobs):
+        buf = C.create_string_buffer(bl, len(bl))
+        keep.append(buf)
+        pieces[i].text = C.cast(buf, C.c_char_p)
+        pieces[i].text_len = len(bl)
+        pieces[i].n_bases = bases_of(bl, i == len(blobs) - 1)
+    assert sum(p.n_bases for p in pieces) == len(seq)
+    seg = (K.SegmentIn * 1)()
+    seg[0].seq = C.cast(pieces, C.c_char_p)
+    seg[0].len = len(seq)
+    seg[0].input_format = K.TS_INPUT_TEXT_PIECES
+    seg[0].n_pieces = len(blobs)
+    res = (K.SegmentOut * 1)()
+    assert L.ts_scan_segments(tel._ctx.ptr, seg, 1, res) == 0, tel._ctx.error()
+    got = segment_as_dict(ta.SegmentData(res[0], False))
+    L.ts_free_segments(res, 1)
+    want = OracleBackend(opts).scan_segment(seq.upper(), 0, False)
+    assert_segment_equal(got, want, False, ctx="ragged FASTA text")
+
+
 @pytest.mark.parametrize("cli", ["-c TTAGGG -p TTAGGG,TCAGGG,TGAGGG,TTGGGG -w 1000 -s 500 -r -g -e -m -i",
                                  "-r -g -e -m -i", "-c CCCTAAA -w 2000 -s 1000 -r -g -e -m -i",
                                  "-w 300 -s 100 -g -e -m -i", "-t 3000"])
