@@ -76,6 +76,8 @@ def reads_sub_record(args, dev):
         b = L.ts_batch_create(rf._ctx.ptr, arr, None, n, 1, bases // 8 + 4096)
         if not b:
             raise RuntimeError(rf._ctx.error())
+        if os.environ.get("TS_REC32") != "1":
+            L.ts_batch_set_record_bits(b, 16)                          # (the predicate is the records' only reader: ts_filter_reads does the same)
         batches.append(b)
     info = K.BatchInfo()
     L.ts_batch_get_info(batches[0], C.byref(info))
@@ -203,6 +205,8 @@ def run_reads(args, rank, local_rank, world, dev, backend):
         b = L.ts_batch_create(rf._ctx.ptr, arr, None, n, 1, int(sl.sum()) // 8 + 4096)
         if not b:
             raise RuntimeError(rf._ctx.error())
+        if os.environ.get("TS_REC32") != "1":
+            L.ts_batch_set_record_bits(b, 16)                          # (the predicate is the records' only reader: ts_filter_reads does the same)
         info = K.BatchInfo()
         L.ts_batch_get_info(b, C.byref(info))
         offs = np.concatenate(([0], np.cumsum((sl + 15) & ~15)))[:-1]

@@ -341,6 +341,14 @@ int       ts_batch_scan(ts_batch *b, const void *d_input, void *stream);
  * queue, 0.011-0.013 ms per scan that the next scan starts later (profiles/r05/shard_step_queues.txt).  What runs beside the next
  * scan (ts_batch_pack_shard, ts_batch_read_pass on a stream of their own) is ordered this way.  The reference orders the same two
  * steps by program order inside one job (scanSegment: scan, then block calling, /root/reference/src/teloscope.cpp:600-657). */
+/* Width of the match records the batch's scans leave: 32 bits (the default: ts_batch_matches_ptr's format), or 16 — position << 2 |
+ * forward << 1 | canonical with a 14-bit tile position — for a batch whose ONLY reader is ts_batch_read_pass: an unrestricted
+ * tips-only batch of segments that are terminal zone as a whole (reads) on tile geometries below 2^14 positions; anything else is
+ * TS_ERR_UNSUPPORTED and the batch stays at 32.  The records are a tenth of the bytes a read step moves through HBM, and the step
+ * runs at what HBM gives; ts_filter_reads asks for 16 itself.  With 16-bit records every other reader of the batch's records
+ * (downloads, export, pack, ts_batch_matches_ptr) refuses.  Before the first scan.  The reference has no such stream at all
+ * (ReadTelomereFilter::matches walks SegmentData in place, /root/reference/src/read-filter.cpp:10-45). */
+int       ts_batch_set_record_bits(ts_batch *b, int bits);
 int       ts_batch_wait_scan(ts_batch *b, void *stream);
 /* Which of the batch's scans are timed: every `every`-th (1, the default: all; 0: none).  A timed scan has an event recorded in
  * front of it as well as the one behind every scan; ts_batch_info's kernel times are means over the timed scans since the last

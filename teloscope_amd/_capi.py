@@ -186,7 +186,7 @@ SYMBOLS = [
     "ts_batch_shard_info", "ts_batch_restrict_shard", "ts_batch_set_shard_scale", "ts_batch_pack_shard",
     "ts_shard_peek", "ts_shards_finalize", "ts_scan_segments_multi", "ts_batch_read_pass_status", "ts_pack_bases",
     "ts_batch_set_emit", "ts_exchange_unique_id", "ts_exchange_last_error", "ts_exchange_create", "ts_exchange_destroy",
-    "ts_exchange_gather", "ts_box_probe", "ts_batch_bind_shard_message", "ts_refresh_env", "ts_streams_concurrent", "ts_batch_wait_scan", "ts_batch_set_timing",
+    "ts_exchange_gather", "ts_box_probe", "ts_batch_bind_shard_message", "ts_refresh_env", "ts_streams_concurrent", "ts_batch_wait_scan", "ts_batch_set_timing", "ts_batch_set_record_bits",
 ]
 
 
@@ -317,6 +317,7 @@ def lib():
     L.ts_streams_concurrent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ts_batch_wait_scan.argtypes = [C.c_void_p, C.c_void_p]
     L.ts_batch_set_timing.argtypes = [C.c_void_p, C.c_uint32]
+    L.ts_batch_set_record_bits.argtypes = [C.c_void_p, C.c_int]
     L.ts_shard_peek.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(ShardStatus)]
     L.ts_shards_finalize.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32,
                                      C.POINTER(SegmentOut), C.POINTER(SegmentCounts)]

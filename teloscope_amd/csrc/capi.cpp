@@ -96,6 +96,7 @@ void read_env_knobs(ts_ctx *c) {
     if (const char *e = getenv("TS_STAGE_THREADS")) { const int n = atoi(e); if (n > 0) k.stage_threads = (uint32_t)std::min(n, 64); }
     if (const char *e = getenv("TS_SIDE_PRIORITY")) k.side_priority = atoi(e);
     k.side_probe = !is("TS_SIDE_PROBE", '0');
+    k.rec16 = !is("TS_REC32", '1');
     if (const char *e = getenv("TS_SCAN_EVENTS")) k.scan_events = atoi(e);
     c->knobs = k;
 }
@@ -1131,6 +1132,20 @@ int ts_batch_set_timing(ts_batch *b, uint32_t every) {
     return TS_OK;
 }
 
+int ts_batch_set_record_bits(ts_batch *b, int bits) {
+    if (!b || (bits != 16 && bits != 32)) return TS_ERR_INVALID_ARG;
+    ts_ctx *c = b->ctx;
+    if (bits == 32) { b->kp.rec16 = 0u; return TS_OK; }
+    // 16-bit records are the stage's own entries: a tips-only batch whose tile positions fit 14 bits, every segment terminal zone
+    // as a whole (the lean predicate kernel is the only reader that knows the format), nothing emitted, nothing restricted
+    if (!b->tips || !b->kp.stage_u16 || b->kp.emit || !b->whole() || b->dense)
+        return c->fail(TS_ERR_UNSUPPORTED, "16-bit records need an unrestricted tips-only batch with 16-bit stage entries and no emit");
+    for (const SegPlan &sp : b->segs)
+        if (sp.len > c->params.terminal_limit) return c->fail(TS_ERR_UNSUPPORTED, "16-bit records need every segment to be terminal zone as a whole");
+    b->kp.rec16 = 1u;
+    return TS_OK;
+}
+
 int ts_batch_wait_scan(ts_batch *b, void *stream) {
     if (!b) return TS_ERR_INVALID_ARG;
     ts_ctx *c = b->ctx;
@@ -1227,7 +1242,7 @@ int ts_batch_get_info(const ts_batch *b, ts_batch_info *info) {
 }
 
 const void *ts_batch_windows_ptr(const ts_batch *b) { return b ? b->windows_ptr() : nullptr; }
-const void *ts_batch_matches_ptr(const ts_batch *b) { return b ? b->records_ptr() : nullptr; }
+const void *ts_batch_matches_ptr(const ts_batch *b) { return b && !b->kp.rec16 ? b->records_ptr() : nullptr; }   // (16-bit records: no raw view)
 const void *ts_batch_tile_stats_ptr(const ts_batch *b) { return b ? b->stats_ptr() : nullptr; }
 
 int ts_batch_export(ts_batch *b, void *d_dense, uint64_t dense_capacity, void *d_total, void *stream) {
@@ -1235,6 +1250,7 @@ int ts_batch_export(ts_batch *b, void *d_dense, uint64_t dense_capacity, void *d
     ts_ctx *c = b->ctx;
     DEVICE_TRY(c);
     if (!b->scanned || b->dense) return c->fail(TS_ERR_STATE, "ts_batch_export needs a scanned batch");
+    if (b->kp.rec16) return c->fail(TS_ERR_STATE, "ts_batch_export: the batch keeps 16-bit records (ts_batch_set_record_bits): only ts_batch_read_pass reads them");
     const uint32_t nt = (uint32_t)b->range_tiles();
     HIP_TRY(c, b->d_dense_base.p && b->d_dense_base.bytes >= ((size_t)nt + 1) * 8 ? hipSuccess : c->pool.take(((size_t)nt + 1) * 8, b->d_dense_base));
     const size_t tmp_bytes = (size_t)ts_k_scan_tmp_bytes(nt);
@@ -1661,6 +1677,7 @@ struct Fetched {
 // Device work + D2H of a synced whole batch (on its stream), into pinned landing area `pin`.
 int batch_fetch(ts_batch *b, bool with_matches, PinBuf &pin, Fetched &F) {
     ts_ctx *c = b->ctx;
+    if (b->kp.rec16) return c->fail(TS_ERR_STATE, "the batch keeps 16-bit records (ts_batch_set_record_bits): only ts_batch_read_pass reads them");
     const size_t nt = b->tiles.size();
     hipStream_t st = (hipStream_t)b->last_stream;
     F.with_matches = with_matches;

@@ -134,6 +134,7 @@ struct ts_ctx {
         uint32_t gen_abl = 0, stage_threads = 0;
         int side_priority = 0;                                // stream priority of the pack's side stream (0: the default priority)
         int scan_events = 2;                                  // events ts_batch_scan records around a scan: 2 both (kernel times), 1 the one behind it, 0 none (measurements)
+        bool rec16 = true;                                    // read-filter batches keep 16-bit records where they can (TS_REC32=1: 32-bit, for A/B)
         bool side_probe = true;                               // try the side stream against the scan / pack streams it meets (shard.cpp)
         uint64_t packed_min_bytes = 1u << 20;                 // small calls are latency, not link time: they go plain
     } knobs;

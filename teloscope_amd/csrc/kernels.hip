@@ -133,6 +133,14 @@ __device__ __forceinline__ void gstore(uint16_t *p, uint16_t v) {
     *p = v;
 #endif
 }
+// (the low 16 bits of v: the store takes them itself)
+__device__ __forceinline__ void gstore_lo16(uint16_t *p, uint32_t v) {
+#if TS_ASM_STORES
+    asm volatile("global_store_short %0, %1, off" :: "v"(p), "v"(v));
+#else
+    *p = (uint16_t)v;
+#endif
+}
 __device__ __forceinline__ void gstore(unsigned char *p, unsigned char v) {
 #if TS_ASM_STORES
     asm volatile("global_store_byte %0, %1, off" :: "v"(p), "v"((uint32_t)v));
@@ -425,9 +433,13 @@ void ts_scan_tiles(const TsScanParams P) {
             KernArgs Q = tail_params();
             const uint32_t cap = Q->region_cap;
             uint32_t *const wave_out = Q->matches_out + (u64)gw * cap;
+            const bool rec16 = !EMIT && Q->rec16 != 0u;             // (a read filter's batch: 16-bit records, see TsScanParams)
             for (uint32_t i = lane; i < n; i += 64u) {
                 const uint32_t o = cursor + flushed + i;
-                if (o < cap && !(TS_ABL & 1)) gstore(wave_out + o, stage_at(i));
+                if (o < cap && !(TS_ABL & 1)) {
+                    if (rec16) gstore_lo16((uint16_t *)Q->matches_out + (u64)gw * cap + o, stage_at(i));
+                    else gstore(wave_out + o, stage_at(i));
+                }
             }
             if (EMIT) park[5] = 1u;                                // (every lane writes the same word)
             // (the stores are waited for here, where a dense tile pays for it, so that the compiler knows of no pending store whose
@@ -452,9 +464,13 @@ void ts_scan_tiles(const TsScanParams P) {
             bool redo = false;
             if (EMIT) redo = __builtin_amdgcn_readfirstlane((int)park[5]) != 0;
             if (!EMIT || redo) {
+                const bool rec16 = !EMIT && Q->rec16 != 0u;
                 for (uint32_t i = ln; i < n; i += 64u) {
                     const uint32_t o = cursor + flushed + i;
-                    if (o < cap && !(TS_ABL & 1)) gstore(wave_out + o, stage_at(i));
+                    if (o < cap && !(TS_ABL & 1)) {
+                        if (rec16) gstore_lo16((uint16_t *)Q->matches_out + (u64)gw * cap + o, stage_at(i));
+                        else gstore(wave_out + o, stage_at(i));
+                    }
                 }
                 flushed = done;
                 if (!EMIT) return;

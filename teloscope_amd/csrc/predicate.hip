@@ -183,11 +183,14 @@ __device__ __forceinline__ void read_feed(ReadChain &cf, ReadChain &cr, ReadBloc
     cr.first = wr ? c.first : cr.first; cr.last = wr ? pos : cr.last; cr.counts = wr ? c.counts : cr.counts; cr.canon = wr ? c.canon : cr.canon;
 }
 
-template <uint32_t NB, bool PADDED>              // NB: 16-byte blocks a thread requests at a time (and as many again in flight);
-                                                // PADDED: the records lie in a 16-byte aligned buffer with 16 bytes of slack
+template <uint32_t NB, bool PADDED, typename REC = uint32_t>   // NB: 16-byte blocks a thread requests at a time (and as many again in flight);
+                                                // PADDED: the records lie in a 16-byte aligned buffer with 16 bytes of slack;
+                                                // REC: uint16_t for a read batch whose scan left 16-bit records (TsScanParams.rec16):
+                                                // a block then holds eight records — half the load instructions, half the bytes
 __device__ __forceinline__ bool pred_walk_read(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
                                                const uint32_t *matches, u64 nrec_limit, uint32_t t0, uint32_t t1, u64 base,
                                                const TsPredParams &Q, bool walk_fwd, bool walk_rev) {
+    constexpr uint32_t RPB = 16u / (uint32_t)sizeof(REC);     // records per 16-byte block
     ReadChain cf = {}, cr = {};                 // (a list of fewer than two matches is not walked: walk_fwd / walk_rev)
     ReadBlock bf = {}, br = {};
     for (uint32_t t = t0; t < t1 && !bf.pass && !br.pass; ++t) {
@@ -195,29 +198,31 @@ __device__ __forceinline__ bool pred_walk_read(const TsTile *tiles, const u64 *t
         if (cnt == 0u) continue;
         const uint32_t rel0 = (uint32_t)(tiles[t].in_off - base);
         const u64 off = tile_off[t];
-        const uint32_t *r = matches + off;
-        const uint32_t m = (uint32_t)(((uintptr_t)r >> 2) & 3u);      // see pred_walk: aligned 16-byte blocks, record i = dword m + i
-        const uint32_t nb = (m + cnt + 3u) >> 2;
+        const REC *r = (const REC *)matches + off;
+        const uint32_t m = (uint32_t)(((uintptr_t)r / sizeof(REC)) & (RPB - 1u));   // see pred_walk: aligned 16-byte blocks, record i = entry m + i
+        const uint32_t nb = (m + cnt + RPB - 1u) / RPB;
         const uint4 *ra = (const uint4 *)(r - m);
-        const bool inside = PADDED || (off >= m && off - m + 4ull * nb <= nrec_limit);
+        const bool inside = PADDED || (off >= m && off - m + (u64)RPB * nb <= nrec_limit);
         auto blk = [&](uint32_t bi) -> uint4 {
             const uint32_t q = bi < nb ? bi : nb - 1u;
             if (PADDED || inside) return ra[q];
-            uint32_t e[4];
+            uint32_t e[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) {
-                const uint32_t i = 4u * q + j - m;
-                e[j] = i < cnt ? r[i] : 0u;
+            for (uint32_t j = 0; j < RPB; ++j) {
+                const uint32_t i = RPB * q + j - m;
+                const uint32_t x = i < cnt ? (uint32_t)r[i] : 0u;
+                if (sizeof(REC) == 4) e[j & 3u] = x; else e[j >> 1] |= x << (16u * (j & 1u));
             }
             return make_uint4(e[0], e[1], e[2], e[3]);
         };
         auto feed_block = [&](uint32_t bi, const uint4 &v) {
-            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) {
-                const uint32_t i = 4u * bi + j - m;          // wraps below the first record, runs past the last one
-                const bool valid = i < cnt, fwd = (e[j] & 2u) != 0u;
-                const uint32_t pos = rel0 + (e[j] >> 2), can = e[j] & 1u;
+            for (uint32_t j = 0; j < RPB; ++j) {
+                const uint32_t ej = sizeof(REC) == 4 ? w[j & 3u] : (w[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu;
+                const uint32_t i = RPB * bi + j - m;         // wraps below the first record, runs past the last one
+                const bool valid = i < cnt, fwd = (ej & 2u) != 0u;
+                const uint32_t pos = rel0 + (ej >> 2), can = ej & 1u;
                 read_feed(cf, cr, bf, br, Q, valid & (fwd ? walk_fwd : walk_rev), fwd, pos, can);
             }
         };
@@ -264,8 +269,8 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 // predecessor, a ballot marks the records that start a new sub-block (gap > -k), and the scalar state machine
 // then steps once per SUB-BLOCK (counts by popcount of ballots) instead of once per record — a telomeric read
 // is one sub-block of thousands of matches.
-template <bool FWD_LIST>
-__device__ bool pred_scan_wave(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
+template <bool FWD_LIST, typename REC = uint32_t>
+__device__ __forceinline__ bool pred_scan_wave(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
                                const uint32_t *matches, uint32_t t0, uint32_t t1, u64 base,
                                const TsPredParams &Q, uint32_t lane) {
     PredState st = {};
@@ -275,10 +280,10 @@ __device__ bool pred_scan_wave(const TsTile *tiles, const u64 *tile_off, const u
         const uint32_t cnt = tile_stats[4u * t];
         if (cnt == 0u) continue;
         const u64 rel0 = tiles[t].in_off - base;
-        const uint32_t *r = matches + tile_off[t];
+        const REC *r = (const REC *)matches + tile_off[t];
         for (uint32_t b0 = 0; b0 < cnt; b0 += 64u) {
             const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
-            const uint32_t rec = lane < nb ? r[b0 + lane] : 0u;
+            const uint32_t rec = lane < nb ? (uint32_t)r[b0 + lane] : 0u;
             const bool sel = lane < nb && (((rec & 2u) != 0u) == FWD_LIST);
             u64 rem = __ballot(sel);
             if (rem == 0ull) continue;
@@ -336,7 +341,7 @@ __device__ bool pred_scan_wave(const TsTile *tiles, const u64 *tile_off, const u
 #ifndef TS_PRED_NB
 #define TS_PRED_NB 4u
 #endif
-template <bool READS>
+template <bool READS, typename REC = uint32_t>
 __global__ __launch_bounds__(64, TS_PRED_WAVES)
 void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
                            const uint32_t *matches, const u64 nrec_limit, const uint32_t *seg_first_tile,
@@ -367,7 +372,7 @@ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint3
     bool ok = false;
     if (READS || n <= Q.terminal_limit) {
         if (nfwd >= 2 || total - nfwd >= 2)
-            ok = pred_walk_read<READS ? TS_PRED_NB : 2u, READS>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, Q, nfwd >= 2, total - nfwd >= 2);
+            ok = pred_walk_read<READS ? TS_PRED_NB : 2u, READS, REC>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, Q, nfwd >= 2, total - nfwd >= 2);
     } else if (!READS) {
         if (nfwd >= 2)                                      // forward list, from the segment start
             ok = pred_walk<true>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
@@ -529,6 +534,7 @@ void ts_read_predicate_canon(const TsTile *tiles, const u64 *tile_off, const uin
 }
 
 // One wave per listed read (grid-stride over the list), 64 records per step in parallel (pred_scan_wave).
+template <typename REC>
 __global__ __launch_bounds__(64)
 void ts_terminal_predicate_long(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
                                 const uint32_t *matches, const uint32_t *seg_first_tile, const u64 *seg_in_off,
@@ -543,9 +549,9 @@ void ts_terminal_predicate_long(const TsTile *tiles, const u64 *tile_off, const 
         for (uint32_t t = t0; t < t1; ++t) { total += tile_stats[4u * t]; nfwd += tile_stats[4u * t + 2u]; }
         bool ok = false;
         if (nfwd >= 2)
-            ok = pred_scan_wave<true>(tiles, tile_off, tile_stats, matches, t0, t1, base, Q, lane);
+            ok = pred_scan_wave<true, REC>(tiles, tile_off, tile_stats, matches, t0, t1, base, Q, lane);
         if (!ok && total - nfwd >= 2)
-            ok = pred_scan_wave<false>(tiles, tile_off, tile_stats, matches, t0, t1, base, Q, lane);
+            ok = pred_scan_wave<false, REC>(tiles, tile_off, tile_stats, matches, t0, t1, base, Q, lane);
         if (lane == 0) pass[si] = ok ? 1 : 0;
     }
 }
@@ -568,7 +574,7 @@ int ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_of
                           const unsigned long long *seg_in_off, const unsigned long long *seg_len, uint32_t nseg,
                           const TsPredParams *Q, unsigned char *pass, uint32_t *long_list, uint32_t *long_count, int all_terminal,
                           const uint32_t *wave_fill, uint32_t region_cap, uint32_t nwaves, uint32_t *overflow,
-                          const uint32_t *chain, const void *canon_idx, uint32_t vis_cap, void *stream) {
+                          const uint32_t *chain, const void *canon_idx, uint32_t vis_cap, int rec16, void *stream) {
     if (nseg == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(long_count, 0, 4, st);
@@ -577,6 +583,10 @@ int ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_of
     if (all_terminal && chain && canon_idx)
         hipLaunchKernelGGL(ts_read_predicate_canon, dim3((nseg + 63u) / 64u), dim3(64), 0, st, tiles, tile_off, tile_stats, matches, (u64)nrec_limit, chain,
                            (const uint16_t *)canon_idx, seg_first_tile, seg_in_off, nseg, *Q, pass, long_list, long_count, (const uint32_t *)overflow);
+    else if (all_terminal && rec16)                           // (16-bit records: only a batch the lean kernel takes has them)
+        hipLaunchKernelGGL((ts_terminal_predicate<true, uint16_t>), dim3((nseg + 63u) / 64u), dim3(64), 0, st,
+                           tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
+                           long_list, long_count, (const uint32_t *)overflow);
     else if (all_terminal)
         hipLaunchKernelGGL((ts_terminal_predicate<true>), dim3((nseg + 63u) / 64u), dim3(64), 0, st,
                            tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
@@ -586,9 +596,14 @@ int ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_of
                            tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
                            long_list, long_count, (const uint32_t *)overflow);
     const uint32_t grid = nseg < 8192u ? nseg : 8192u;      // waves of the second kernel: it strides over the list
-    hipLaunchKernelGGL(ts_terminal_predicate_long, dim3(grid), dim3(64), 0, st,
-                       tiles, tile_off, tile_stats, matches, seg_first_tile, seg_in_off, *Q, pass,
-                       (const uint32_t *)long_list, (const uint32_t *)long_count);
+    if (all_terminal && rec16)
+        hipLaunchKernelGGL(ts_terminal_predicate_long<uint16_t>, dim3(grid), dim3(64), 0, st,
+                           tiles, tile_off, tile_stats, matches, seg_first_tile, seg_in_off, *Q, pass,
+                           (const uint32_t *)long_list, (const uint32_t *)long_count);
+    else
+        hipLaunchKernelGGL(ts_terminal_predicate_long<uint32_t>, dim3(grid), dim3(64), 0, st,
+                           tiles, tile_off, tile_stats, matches, seg_first_tile, seg_in_off, *Q, pass,
+                           (const uint32_t *)long_list, (const uint32_t *)long_count);
     return (int)hipGetLastError();
 }
 

@@ -276,6 +276,7 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     DEVICE_TRY(c);
     if (!b->shard_parts) return c->fail(TS_ERR_STATE, "ts_batch_pack_shard needs ts_batch_restrict_shard first");
     if (!b->scanned || b->dense) return c->fail(TS_ERR_STATE, "ts_batch_pack_shard needs a scanned batch");
+    if (b->kp.rec16) return c->fail(TS_ERR_STATE, "ts_batch_pack_shard: the batch keeps 16-bit records (ts_batch_set_record_bits)");
     const ShardRange &r = b->shard_r;
     const ShardLayout &L = b->shard_L;
     if (msg_bytes < L.bytes) return c->fail(TS_ERR_INVALID_ARG, "ts_batch_pack_shard: message buffer smaller than ts_batch_shard_info says");

@@ -86,6 +86,11 @@ struct TsScanParams {
     uint8_t        *win_packed;
     unsigned long long win_pack_lo, win_pack_hi;
     uint32_t        win_pack_bytes, win_field_bits;
+    // ---- a read filter's batch (tips-only, 16-bit stage entries, every read terminal zone as a whole, no emit): the records leave as
+    // 16 bits each — the stage's own entries: position (14 bits) << 2 | forward << 1 | canonical — into matches_out read as uint16_t
+    // (regions of region_cap records as before).  Their only reader is the read predicate (predicate.hip), and the records are a
+    // tenth of what the read step moves through HBM, a step that runs at what HBM gives (profiles/r05/reads_u16_records.txt).
+    uint32_t        rec16;
 };
 
 // What ts_scan_tiles leaves per tile beside {matches, canonical, forward, visible} in tile_stats: the summary the
@@ -323,7 +328,7 @@ int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_o
                            const unsigned long long *seg_in_off, const unsigned long long *seg_len,
                            uint32_t nseg, const TsPredParams *Q, unsigned char *pass, uint32_t *long_list,
                            uint32_t *long_count, int all_terminal, const uint32_t *wave_fill, uint32_t region_cap,
-                           uint32_t nwaves, uint32_t *overflow, const uint32_t *chain, const void *canon_idx, uint32_t vis_cap, void *stream);
+                           uint32_t nwaves, uint32_t *overflow, const uint32_t *chain, const void *canon_idx, uint32_t vis_cap, int rec16, void *stream);
                            // (chain + canon_idx, both or neither: a read batch's scan left the indices of the canonical records — u16 each,
                            //  per-wave regions of vis_cap, TsTileChain words 2-3 say where a tile's are, tile_stats word 3 how many — and
                            //  the predicate visits only the chains that hold one)

@@ -991,3 +991,44 @@ def test_read_filter_long_match_lists(cli):
     exp = OracleReadFilter(opts).filter(reads)
     assert got == exp
     assert 0 < sum(got) < len(got)
+
+
+def test_read_records_of_16_and_of_32_bits_give_the_same_pass_bytes(monkeypatch):
+    """ts_batch_set_record_bits: ts_filter_reads keeps its batches' records at 16 bits (the predicate is their only reader);
+    TS_REC32=1 (read when the context is made) keeps 32.  Same pass bytes, the oracle's; a batch that cannot have 16-bit records
+    says so and stays at 32, and a batch that has them gives no raw view of them."""
+    import ctypes as C
+    import teloscope_amd as ta
+    from teloscope_amd import _capi as K
+    from teloscope_amd.cli import user_input
+    opts = H.parse_cli("--fastq-subset -l 42")
+    rng = np.random.default_rng(77)
+    reads = []
+    for i in range(700):
+        n = int(rng.integers(200, 40000))
+        s = bytearray(seqgen.random_dna(rng, n).tobytes())
+        if i % 5 == 0:
+            unit = opts.canonical_fwd if i % 2 else opts.canonical_rev
+            t = seqgen.mutate(rng, seqgen.repeat_array(unit, int(rng.integers(3, 400))), 0.02).tobytes()
+            at = 0 if i % 3 else max(0, n - len(t))
+            s[at:at + len(t)] = t[:n - at]
+        reads.append(bytes(s))
+    exp = OracleReadFilter(opts).filter(reads)
+    got16 = ProductReadFilter(opts).filter(reads)
+    monkeypatch.setenv("TS_REC32", "1")
+    got32 = ProductReadFilter(opts).filter(reads)
+    monkeypatch.delenv("TS_REC32")
+    assert got16 == exp and got32 == exp and 0 < sum(exp) < len(exp)
+    # the batch interface
+    L = K.lib()
+    rf = ta.ReadTelomereFilter(user_input(opts))
+    lens = (C.c_uint64 * 3)(5000, 17000, 900)
+    b = L.ts_batch_create(rf._ctx.ptr, lens, None, 3, 1, 0)
+    assert b and L.ts_batch_set_record_bits(b, 16) == 0
+    assert not L.ts_batch_matches_ptr(b)                                         # no raw view of 16-bit records
+    assert L.ts_batch_set_record_bits(b, 32) == 0 and L.ts_batch_set_record_bits(b, 24) == K.TS_ERR_INVALID_ARG
+    L.ts_batch_destroy(b)
+    tel = ta.Teloscope(user_input(H.parse_cli("x.fa -r")))
+    full = L.ts_batch_create(tel._ctx.ptr, lens, None, 3, 0, 0)
+    assert full and L.ts_batch_set_record_bits(full, 16) == K.TS_ERR_UNSUPPORTED  # a window scan's records have other readers
+    L.ts_batch_destroy(full)
