@@ -341,15 +341,17 @@ int       ts_batch_scan(ts_batch *b, const void *d_input, void *stream);
  * queue, 0.011-0.013 ms per scan that the next scan starts later (profiles/r05/shard_step_queues.txt).  What runs beside the next
  * scan (ts_batch_pack_shard, ts_batch_read_pass on a stream of their own) is ordered this way.  The reference orders the same two
  * steps by program order inside one job (scanSegment: scan, then block calling, /root/reference/src/teloscope.cpp:600-657). */
-/* Width of the match records the batch's scans leave: 32 bits (the default: ts_batch_matches_ptr's format), or 16 — position << 2 |
- * forward << 1 | canonical with a 14-bit tile position — for a batch whose ONLY reader is ts_batch_read_pass: an unrestricted
- * tips-only batch of segments that are terminal zone as a whole (reads) on tile geometries below 2^14 positions; anything else is
- * TS_ERR_UNSUPPORTED and the batch stays at 32.  The records are a tenth of the bytes a read step moves through HBM, and the step
- * runs at what HBM gives; ts_filter_reads asks for 16 itself.  With 16-bit records every other reader of the batch's records
- * (downloads, export, pack, ts_batch_matches_ptr) refuses.  Before the first scan.  The reference has no such stream at all
- * (ReadTelomereFilter::matches walks SegmentData in place, /root/reference/src/read-filter.cpp:10-45). */
-int       ts_batch_set_record_bits(ts_batch *b, int bits);
 int       ts_batch_wait_scan(ts_batch *b, void *stream);
+/* Width of the match records the batch's scans leave in their per-wave regions: 16 bits each — the kernel's own staged entries,
+ * (tile-relative position << 2) | forward << 1 | canonical with positions below 2^14 — wherever the batch's tiles are that short
+ * (every geometry the planner picks for windows up to 8 192 bases, and read batches), else 32.  Every reader inside the library
+ * knows both (block calling, the read predicate, pack; export, downloads and the dense stream widen to 32 bits, so nothing that
+ * leaves the device changes); the records are a tenth of the bytes a scan moves through HBM.  ts_batch_set_record_bits(b, 32)
+ * before the first scan keeps 32-bit regions — what a caller that reads them raw through ts_batch_matches_ptr needs (that
+ * pointer is NULL for 16-bit regions); 16 asks for 16 (TS_ERR_UNSUPPORTED when the tiles are too long).  TS_REC32=1 (read when the
+ * context is made) makes 32 the default.  The reference has no such stream at all (it walks SegmentData in place,
+ * /root/reference/src/teloscope.cpp:600-657, src/read-filter.cpp:10-45). */
+int       ts_batch_set_record_bits(ts_batch *b, int bits);
 /* Which of the batch's scans are timed: every `every`-th (1, the default: all; 0: none).  A timed scan has an event recorded in
  * front of it as well as the one behind every scan; ts_batch_info's kernel times are means over the timed scans since the last
  * ts_batch_sync.  An event is a packet on the scan's queue: a caller that enqueues scans back to back and does not need every
@@ -360,10 +362,11 @@ int       ts_batch_set_timing(ts_batch *b, uint32_t every);
 int       ts_batch_sync(ts_batch *b);
 int       ts_batch_get_info(const ts_batch *b, ts_batch_info *info);
 /* Device pointers to the raw result buffers (valid after sync): window records
- * (8 x uint32 each: A,C,G,T, canonical/nonCanonical/fwd/rev covered) and the dense stream of
+ * (8 x uint32 each: A,C,G,T, canonical/nonCanonical/fwd/rev covered) and the stream of
  * packed 32-bit match records ((tile-relative position << 2) | fwd << 1 | canonical).  Records
  * of one tile are contiguous and position-ordered; tiles are placed in completion order and
- * located through the batch's tile directory (ts_batch_download does that). */
+ * located through the batch's tile directory (ts_batch_download does that).  ts_batch_matches_ptr is NULL
+ * while the regions hold 16-bit records (ts_batch_set_record_bits). */
 const void *ts_batch_windows_ptr(const ts_batch *b);
 const void *ts_batch_matches_ptr(const ts_batch *b);
 /* D2H + host post-processing (absolute positions, terminal flags, block calling):

@@ -43,6 +43,10 @@ typedef unsigned long long u64;
 // Two record formats.  The tiled kernel's (uniform length Q.k): position << 2 | forward << 1 | canonical.  The general
 // kernels' (generic.hip; Q.gen_lens != 0: up to eight pattern lengths, six bits each): position << 5 | length index << 2 |
 // canonical << 1 | forward.  Every load goes through rec_norm, which hands the code below the first form, and rec_len.
+// record i of the stream `matches` (the tiled kernel's may be 16 bits each: Q.rec16 — uniform, so the branch is scalar)
+__device__ __forceinline__ uint32_t rec_at(const TsBlockCallParams &Q, const uint32_t *matches, u64 i) {
+    return Q.rec16 ? (uint32_t)((const uint16_t *)matches)[i] : matches[i];
+}
 __device__ __forceinline__ uint32_t rec_norm(const TsBlockCallParams &Q, uint32_t raw) {
     return Q.gen_lens ? ((raw >> 5) << 2) | ((raw & 1u) << 1) | ((raw >> 1) & 1u) : raw;
 }
@@ -192,7 +196,7 @@ __device__ __forceinline__ u64 terminal_direction(const TsBlockCallParams &Q, co
           for (uint32_t q = 0; q < 8u; ++q) {
               const uint32_t bq = b4 + 64u * q;
               const uint32_t idx = from_start ? bq + lane : cnt - 1u - bq - lane;      // walk order
-              recs[q] = bq + lane < cnt ? V.matches[off + idx] : 0u;      // (raw: normalised where a row is taken up)
+              recs[q] = bq + lane < cnt ? rec_at(Q, V.matches, off + idx) : 0u;      // (raw: normalised where a row is taken up)
           }
 #pragma unroll
           for (uint32_t q = 0; q < 8u; ++q) {
@@ -460,12 +464,12 @@ __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const T
         const uint32_t cnt = Q.tile_stats[4u * t];
         if (cnt == 0u) continue;
         const u64 rel = Q.tiles[t].in_off - S.in_off;
-        const uint32_t *src = Q.matches + Q.tile_off[t];
+        const u64 src = Q.tile_off[t];                     // (index of the tile's first record: rec_at reads either width)
         const uint32_t rb32 = rb <= rel ? 0u : (rb - rel > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(rb - rel));
         for (uint32_t b0 = (t == t0 ? i0 : 0u); b0 < cnt && !closed; b0 += 64u) {
             const uint32_t nvalid = cnt - b0 < 64u ? cnt - b0 : 64u;
             const u64 VALID = low_bits(nvalid);
-            const uint32_t raw = lane < nvalid ? src[b0 + lane] : 0u;
+            const uint32_t raw = lane < nvalid ? rec_at(Q, Q.matches, src + b0 + lane) : 0u;
             const uint32_t r = rec_norm(Q, raw), lenv = rec_len(Q, raw);
             const uint32_t p32 = r >> 2;
             const uint32_t below = lane_below(p32);
@@ -556,13 +560,13 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
     }
     if ((!its_on && !vis_on) || cnt == 0u) return;
     const u64 tile_rel = T.in_off - S.in_off;
-    const uint32_t *src = Q.matches + off;
+    const u64 src = off;                                   // (index of the tile's first record)
     const u64 z_lo = W.terminal_limit, z_hi = S.len > W.terminal_limit ? S.len - W.terminal_limit : 0ull;
     constexpr uint32_t kGroup = 8;                         // batches of 64 records requested together
     uint32_t recs[kGroup];
 #pragma unroll
-    for (uint32_t q = 0; q < kGroup; ++q) recs[q] = 64u * q + lane < cnt ? rec_norm(Q, src[64u * q + lane]) : 0u;
-    const uint32_t next_rec = (tn != tile && lane < next_cnt) ? rec_norm(Q, Q.matches[next_off + lane]) : 0u;
+    for (uint32_t q = 0; q < kGroup; ++q) recs[q] = 64u * q + lane < cnt ? rec_norm(Q, rec_at(Q, Q.matches, src + 64u * q + lane)) : 0u;
+    const uint32_t next_rec = (tn != tile && lane < next_cnt) ? rec_norm(Q, rec_at(Q, Q.matches, next_off + lane)) : 0u;
 
     // the record ahead of the tile's first one (head test of that record), as a position relative to the tile (negative)
     bool has_last = false;
@@ -573,14 +577,14 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
         bool found = false;
         u64 last_pos = 0;
         if (tile > S.t0 && prev_cnt) {                     // the usual case: the tile before holds it
-            const uint32_t r = rec_norm(Q, Q.matches[prev_off + prev_cnt - 1u]);
+            const uint32_t r = rec_norm(Q, rec_at(Q, Q.matches, prev_off + prev_cnt - 1u));
             last_pos = prev_in_off - S.in_off + (r >> 2);
             found = true;
         } else {
             for (uint32_t t = tile; t > S.t0; --t) {
                 const uint32_t c = Q.tile_stats[4u * (t - 1u)];
                 if (c) {
-                    const uint32_t r = rec_norm(Q, Q.matches[Q.tile_off[t - 1u] + c - 1u]);
+                    const uint32_t r = rec_norm(Q, rec_at(Q, Q.matches, Q.tile_off[t - 1u] + c - 1u));
                     last_pos = Q.tiles[t - 1u].in_off - S.in_off + (r >> 2);
                     found = true;
                     break;
@@ -725,13 +729,13 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
         for (uint32_t q = 0; q < kGroup; ++q)
             if (64u * q < cnt) fast_batch(64u * q, recs[q]);
         for (uint32_t b0 = 64u * kGroup; b0 < cnt; b0 += 64u)           // a dense tile: the rest, batch by batch
-            fast_batch(b0, b0 + lane < cnt ? rec_norm(Q, src[b0 + lane]) : 0u);
+            fast_batch(b0, b0 + lane < cnt ? rec_norm(Q, rec_at(Q, Q.matches, src + b0 + lane)) : 0u);
     } else {
 #pragma unroll
         for (uint32_t q = 0; q < kGroup; ++q)
             if (64u * q < cnt) batch(64u * q, recs[q]);
         for (uint32_t b0 = 64u * kGroup; b0 < cnt; b0 += 64u)
-            batch(b0, b0 + lane < cnt ? rec_norm(Q, src[b0 + lane]) : 0u);
+            batch(b0, b0 + lane < cnt ? rec_norm(Q, rec_at(Q, Q.matches, src + b0 + lane)) : 0u);
     }
     // the chain that is still open belongs to this tile: follow it through the tiles behind until a head closes it
     if (its_on && open && !finished) {
@@ -743,10 +747,10 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
             const uint32_t c2 = pre_fetched ? next_cnt : Q.tile_stats[4u * t];
             if (c2 == 0u) continue;
             const u64 rel2 = (pre_fetched ? next_in_off : Q.tiles[t].in_off) - S.in_off;
-            const uint32_t *src2 = Q.matches + (pre_fetched ? next_off : Q.tile_off[t]);
+            const u64 src2 = pre_fetched ? next_off : Q.tile_off[t];
             const uint32_t rb2 = rb <= rel2 ? 0u : (rb - rel2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(rb - rel2));
             for (uint32_t b0 = 0; b0 < c2 && !closed; b0 += 64u) {
-                const uint32_t r = (pre_fetched && b0 == 0u) ? next_rec : (b0 + lane < c2 ? rec_norm(Q, src2[b0 + lane]) : 0u);
+                const uint32_t r = (pre_fetched && b0 == 0u) ? next_rec : (b0 + lane < c2 ? rec_norm(Q, rec_at(Q, Q.matches, src2 + b0 + lane)) : 0u);
                 const uint32_t nvalid = c2 - b0 < 64u ? c2 - b0 : 64u;
                 const u64 VALID = low_bits(nvalid);
                 const uint32_t p32 = r >> 2;

@@ -941,6 +941,8 @@ ts_batch *ts_batch_create(ts_ctx *ctx, const uint64_t *seg_lens, const uint64_t 
         const char *e = getenv("TS_READ_EMIT");
         if (e && e[0] == '1' && ts_k_read_index_built()) b->kp.emit = 2u;     // (only a library built with -DTS_READ_INDEX_BUILD=1 has it)
     }
+    // records leave as the stage holds them: 16 bits each where tile positions fit 14 bits (TS_REC32=1 / ts_batch_set_record_bits: 32)
+    b->kp.rec16 = (b->kp.stage_u16 && ctx->knobs.rec16 && b->kp.emit != 2u) ? 1u : 0u;
     set_range(b, 0, b->tiles.size());
     return b;
 }
@@ -1135,13 +1137,11 @@ int ts_batch_set_timing(ts_batch *b, uint32_t every) {
 int ts_batch_set_record_bits(ts_batch *b, int bits) {
     if (!b || (bits != 16 && bits != 32)) return TS_ERR_INVALID_ARG;
     ts_ctx *c = b->ctx;
+    if (b->scanned) return c->fail(TS_ERR_STATE, "ts_batch_set_record_bits: before the first scan");
     if (bits == 32) { b->kp.rec16 = 0u; return TS_OK; }
-    // 16-bit records are the stage's own entries: a tips-only batch whose tile positions fit 14 bits, every segment terminal zone
-    // as a whole (the lean predicate kernel is the only reader that knows the format), nothing emitted, nothing restricted
-    if (!b->tips || !b->kp.stage_u16 || b->kp.emit || !b->whole() || b->dense)
-        return c->fail(TS_ERR_UNSUPPORTED, "16-bit records need an unrestricted tips-only batch with 16-bit stage entries and no emit");
-    for (const SegPlan &sp : b->segs)
-        if (sp.len > c->params.terminal_limit) return c->fail(TS_ERR_UNSUPPORTED, "16-bit records need every segment to be terminal zone as a whole");
+    // 16-bit records are the stage's own entries: tile positions below 2^14 (every geometry the planner picks for w <= 8192)
+    if (!b->kp.stage_u16 || b->kp.emit == 2u || b->dense)
+        return c->fail(TS_ERR_UNSUPPORTED, "16-bit records need 16-bit stage entries (tile positions below 2^14)");
     b->kp.rec16 = 1u;
     return TS_OK;
 }
@@ -1250,7 +1250,6 @@ int ts_batch_export(ts_batch *b, void *d_dense, uint64_t dense_capacity, void *d
     ts_ctx *c = b->ctx;
     DEVICE_TRY(c);
     if (!b->scanned || b->dense) return c->fail(TS_ERR_STATE, "ts_batch_export needs a scanned batch");
-    if (b->kp.rec16) return c->fail(TS_ERR_STATE, "ts_batch_export: the batch keeps 16-bit records (ts_batch_set_record_bits): only ts_batch_read_pass reads them");
     const uint32_t nt = (uint32_t)b->range_tiles();
     HIP_TRY(c, b->d_dense_base.p && b->d_dense_base.bytes >= ((size_t)nt + 1) * 8 ? hipSuccess : c->pool.take(((size_t)nt + 1) * 8, b->d_dense_base));
     const size_t tmp_bytes = (size_t)ts_k_scan_tmp_bytes(nt);
@@ -1258,7 +1257,7 @@ int ts_batch_export(ts_batch *b, void *d_dense, uint64_t dense_capacity, void *d
     int e = ts_k_launch_tile_order_export(b->stats_ptr(), (const unsigned long long *)b->d_tile_off.p, (const uint32_t *)b->d_matches.p,
                                           (const uint32_t *)b->d_fill.p, b->region_cap, b->total_waves, nt,
                                           (unsigned long long *)b->d_dense_base.p, b->d_scan_tmp.p, (uint32_t *)d_dense,
-                                          dense_capacity, (unsigned long long *)d_total, stream);
+                                          dense_capacity, (unsigned long long *)d_total, b->records16() ? 1 : 0, stream);
     if (e != 0) return c->fail(TS_ERR_HIP, std::string("export kernel launch: ") + hipGetErrorString((hipError_t)e));
     return TS_OK;
 }
@@ -1566,7 +1565,7 @@ void parallel_for(size_t n, unsigned max_threads, F &&f) {
 int ts_device_block_call_raw(ts_ctx *c, const TsTile *d_tiles, const unsigned long long *d_tile_off, const uint32_t *d_stats,
                              const uint32_t *d_matches, uint64_t n_matches_hint, const std::vector<TsShardSegIn> &tab, size_t nt,
                              bool tips, unsigned long long gen_lens, const uint32_t *d_chain, uint32_t *d_work, hipStream_t st,
-                             std::vector<TsDevBlock> &blocks, std::vector<unsigned long long> *sums_out) {
+                             std::vector<TsDevBlock> &blocks, std::vector<unsigned long long> *sums_out, int rec16) {
     const ts_params &P = c->params;
     const size_t ns = tab.size();
     blocks.clear();
@@ -1602,6 +1601,7 @@ int ts_device_block_call_raw(ts_ctx *c, const TsTile *d_tiles, const unsigned lo
         Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;
         Q.k = c->k; Q.its_min_len = (uint32_t)(uint16_t)(2 * c->bp.first_pattern_len);
         Q.gen_lens = gen_lens;
+        Q.rec16 = rec16 ? 1u : 0u;
         if (ts_k_launch_block_call(&Q, (const TsShardSegIn *)dt, (uint32_t)ns, 0u, (uint32_t)nt, (unsigned long long *)(dt + off_bounds),
                                    nullptr, tips ? 0 : 1, nullptr, (unsigned long long *)(dt + off_sums), d_chain, d_work, st) != 0)
             return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
@@ -1653,7 +1653,8 @@ int device_block_call(ts_batch *b, hipStream_t st, std::vector<TsDevBlock> &bloc
     }
     return ts_device_block_call_raw(c, (const TsTile *)b->d_tiles.p, (const unsigned long long *)b->d_tile_off.p, b->stats_ptr(),
                                     b->records_ptr(), b->n_matches, tab, nt, b->tips, 0ull,
-                                    from_scan ? (const uint32_t *)b->d_chain.p : nullptr, from_scan ? (uint32_t *)b->d_scan_tmp.p : nullptr, st, blocks, nullptr);
+                                    from_scan ? (const uint32_t *)b->d_chain.p : nullptr, from_scan ? (uint32_t *)b->d_scan_tmp.p : nullptr, st, blocks, nullptr,
+                                    b->records16() ? 1 : 0);
 }
 
 unsigned finalize_threads() {
@@ -1677,7 +1678,6 @@ struct Fetched {
 // Device work + D2H of a synced whole batch (on its stream), into pinned landing area `pin`.
 int batch_fetch(ts_batch *b, bool with_matches, PinBuf &pin, Fetched &F) {
     ts_ctx *c = b->ctx;
-    if (b->kp.rec16) return c->fail(TS_ERR_STATE, "the batch keeps 16-bit records (ts_batch_set_record_bits): only ts_batch_read_pass reads them");
     const size_t nt = b->tiles.size();
     hipStream_t st = (hipStream_t)b->last_stream;
     F.with_matches = with_matches;
@@ -1714,7 +1714,7 @@ int batch_fetch(ts_batch *b, bool with_matches, PinBuf &pin, Fetched &F) {
             HIP_TRY(c, hipMemcpyAsync(b->d_dense_base.p, dense_base.data(), (size_t)(b->total_waves + 1) * 8, hipMemcpyHostToDevice, st));
             int e = ts_k_launch_compact((const uint32_t *)b->d_matches.p, (const uint32_t *)b->d_fill.p,
                                         (const unsigned long long *)b->d_dense_base.p, b->region_cap,
-                                        b->total_waves, (uint32_t *)b->d_dense.p, st);
+                                        b->total_waves, (uint32_t *)b->d_dense.p, b->records16() ? 1 : 0, st);
             if (e != 0) return c->fail(TS_ERR_HIP, "compaction kernel launch failed");
             HIP_TRY(c, hipMemcpyAsync(recs, b->d_dense.p, nrecs * 4, hipMemcpyDeviceToHost, st));
         }

@@ -262,6 +262,7 @@ struct ts_batch {
 
     uint32_t *windows_ptr() const { return ext_windows ? ext_windows : (uint32_t *)d_windows.p; }
     uint32_t *stats_ptr() const { return ext_stats ? ext_stats : (uint32_t *)d_stats.p; }
+    bool records16() const { return kp.rec16 != 0u && !dense; }    // the scan's own regions hold 16-bit records (the dense / adopted stream never does)
     const uint32_t *records_ptr() const { return dense ? (ext_dense ? ext_dense : (const uint32_t *)d_dense.p) : (const uint32_t *)d_matches.p; }
     // records that may be read behind records_ptr(): the per-wave regions, or the dense stream
     unsigned long long records_limit() const { return dense ? n_matches : (unsigned long long)region_cap * total_waves; }
@@ -304,7 +305,7 @@ int  ts_batch_ensure_device(ts_batch *b);        // allocates the range's device
 int  ts_device_block_call_raw(ts_ctx *c, const TsTile *d_tiles, const unsigned long long *d_tile_off, const uint32_t *d_stats,
                               const uint32_t *d_matches, uint64_t n_matches_hint, const std::vector<TsShardSegIn> &tab, size_t nt,
                               bool tips, unsigned long long gen_lens, const uint32_t *d_chain, uint32_t *d_work, hipStream_t st,
-                              std::vector<TsDevBlock> &blocks, std::vector<unsigned long long> *sums_out);
+                              std::vector<TsDevBlock> &blocks, std::vector<unsigned long long> *sums_out, int rec16 = 0);
 void ts_batch_release_input(ts_batch *b);        // returns the batch's input buffer to the context's pool
 void *ts_batch_input_ptr_nozero(ts_batch *b);
 struct ts_fetched;                               // what a download left in host memory, before post-processing

@@ -99,15 +99,16 @@ void ts_tile_offsets(const uint32_t *tile_stats, uint32_t ntiles, const u64 *blo
 // One wave per tile: its records, wherever the scan's wave put them, to their place in the tile-ordered stream.
 __global__ __launch_bounds__(256)
 void ts_tile_order_copy(const uint32_t *tile_stats, const u64 *region_off, const uint32_t *regions,
-                        const u64 *dense_off, uint32_t ntiles, uint32_t *dense, const u64 *total_out) {
+                        const u64 *dense_off, uint32_t ntiles, uint32_t *dense, const u64 *total_out, int rec16) {
     if (total_out[1] != 0ull) return;                        // incomplete: the caller rescans (ts_batch_sync) and exports again
     const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (t >= ntiles) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = tile_stats[4ull * t];
-    const uint32_t *src = regions + region_off[t];
     uint32_t *dst = dense + dense_off[t];
-    for (uint32_t i = lane; i < n; i += 64u) dst[i] = src[i];
+    // (the tile-ordered stream is 32 bits per record whatever the regions hold)
+    if (rec16) { const uint16_t *src = (const uint16_t *)regions + region_off[t]; for (uint32_t i = lane; i < n; i += 64u) dst[i] = src[i]; }
+    else { const uint32_t *src = regions + region_off[t]; for (uint32_t i = lane; i < n; i += 64u) dst[i] = src[i]; }
 }
 
 // The exchange's wire format: every u32 of a rank's three arrays fits 16 bits (a packed match record is a
@@ -148,7 +149,7 @@ int ts_k_launch_tile_offsets(const uint32_t *tile_stats, uint32_t ntiles, unsign
 int ts_k_launch_tile_order_export(const uint32_t *tile_stats, const unsigned long long *region_off, const uint32_t *regions,
                                   const uint32_t *wave_fill, uint32_t region_cap, uint32_t nwaves, uint32_t ntiles,
                                   unsigned long long *dense_off, void *tmp, uint32_t *dense, unsigned long long capacity,
-                                  unsigned long long *total_out, void *stream) {
+                                  unsigned long long *total_out, int rec16, void *stream) {
     const uint32_t nb = scan_blocks(ntiles);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(total_out, 0, 16, st);
@@ -160,7 +161,7 @@ int ts_k_launch_tile_order_export(const uint32_t *tile_stats, const unsigned lon
                        dense_off, total_out, capacity);
     if (ntiles)
         hipLaunchKernelGGL(ts_tile_order_copy, dim3((ntiles + 3u) / 4u), dim3(256), 0, st, tile_stats, region_off, regions,
-                           (const u64 *)dense_off, ntiles, dense, (const u64 *)total_out);
+                           (const u64 *)dense_off, ntiles, dense, (const u64 *)total_out, rec16);
     return (int)hipGetLastError();
 }
 

@@ -433,7 +433,7 @@ void ts_scan_tiles(const TsScanParams P) {
             KernArgs Q = tail_params();
             const uint32_t cap = Q->region_cap;
             uint32_t *const wave_out = Q->matches_out + (u64)gw * cap;
-            const bool rec16 = !EMIT && Q->rec16 != 0u;             // (a read filter's batch: 16-bit records, see TsScanParams)
+            const bool rec16 = Q->rec16 != 0u;                       // (16-bit records: the stage's entries as they are, see TsScanParams)
             for (uint32_t i = lane; i < n; i += 64u) {
                 const uint32_t o = cursor + flushed + i;
                 if (o < cap && !(TS_ABL & 1)) {
@@ -463,12 +463,13 @@ void ts_scan_tiles(const TsScanParams P) {
             uint32_t n = done - flushed;
             bool redo = false;
             if (EMIT) redo = __builtin_amdgcn_readfirstlane((int)park[5]) != 0;
+            const bool rec16 = Q->rec16 != 0u;
+            uint16_t *const wave_out16 = (uint16_t *)Q->matches_out + (u64)gw * cap;
             if (!EMIT || redo) {
-                const bool rec16 = !EMIT && Q->rec16 != 0u;
                 for (uint32_t i = ln; i < n; i += 64u) {
                     const uint32_t o = cursor + flushed + i;
                     if (o < cap && !(TS_ABL & 1)) {
-                        if (rec16) gstore_lo16((uint16_t *)Q->matches_out + (u64)gw * cap + o, stage_at(i));
+                        if (rec16) gstore_lo16(wave_out16 + o, stage_at(i));
                         else gstore(wave_out + o, stage_at(i));
                     }
                 }
@@ -596,8 +597,9 @@ void ts_scan_tiles(const TsScanParams P) {
                     const uint32_t o = cursor + base + i0 + ln;
                     const uint32_t r = stage_at(i0 + ln);
                     if (!(TS_ABL & 1)) {
-                        if (rec_fit) gstore(wave_out + o, r);
-                        else if (o < cap) gstore(wave_out + o, r);
+                        auto put = [&]() { if (rec16) gstore_lo16(wave_out16 + o, r); else gstore(wave_out + o, r); };
+                        if (rec_fit) put();                                // (whole-tile bound, scalar)
+                        else if (o < cap) put();
                     }
                     if (!(TS_EMIT_ABL & 1)) look(r, 64u, i0, std::true_type{});
                 }
@@ -607,7 +609,10 @@ void ts_scan_tiles(const TsScanParams P) {
                     uint32_t r = 0u;
                     if (ln < nrow) {
                         r = stage_at(i0 + ln);
-                        if (o < cap && !(TS_ABL & 1)) gstore(wave_out + o, r);
+                        if (o < cap && !(TS_ABL & 1)) {
+                            if (rec16) gstore_lo16(wave_out16 + o, r);
+                            else gstore(wave_out + o, r);
+                        }
                     }
                     if (!(TS_EMIT_ABL & 1)) look(r, nrow, i0, std::false_type{});
                 }
@@ -616,7 +621,9 @@ void ts_scan_tiles(const TsScanParams P) {
                     const uint32_t nrow = n - i0 < 64u ? n - i0 : 64u;
                     const uint32_t o = cursor + base + i0 + ln;
                     uint32_t r = 0u;
-                    if (ln < nrow && o < cap) r = __hip_atomic_load(wave_out + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (past the non-coherent L1)
+                    if (ln < nrow && o < cap)                             // (past the non-coherent L1)
+                        r = rec16 ? (uint32_t)__hip_atomic_load(wave_out16 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                  : __hip_atomic_load(wave_out + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     look(r, nrow, i0, std::false_type{});
                 }
             }
@@ -1152,13 +1159,14 @@ __global__ void ts_segment_summary(const uint32_t *tile_stats, const uint32_t *s
 
 // Packs the per-wave record regions into one dense stream (used before a D2H copy).
 __global__ void ts_compact_regions(const uint32_t *regions, const uint32_t *wave_fill, const u64 *wave_dense_base,
-                                   uint32_t region_cap, uint32_t nwaves, uint32_t *dense) {
+                                   uint32_t region_cap, uint32_t nwaves, uint32_t *dense, int rec16) {
     const uint32_t w = blockIdx.x;
     if (w >= nwaves) return;
     const uint32_t n = wave_fill[w] < region_cap ? wave_fill[w] : region_cap;
-    const uint32_t *src = regions + (u64)w * region_cap;
     uint32_t *dst = dense + wave_dense_base[w];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    // (the dense stream is 32 bits per record whatever the regions hold: what leaves the device keeps its format)
+    if (rec16) { const uint16_t *src = (const uint16_t *)regions + (u64)w * region_cap; for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i]; }
+    else { const uint32_t *src = regions + (u64)w * region_cap; for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i]; }
 }
 
 }  // namespace
@@ -1220,9 +1228,9 @@ int ts_k_launch_summary(const uint32_t *tile_stats, const uint32_t *seg_first_ti
 }
 
 int ts_k_launch_compact(const uint32_t *regions, const uint32_t *wave_fill, const unsigned long long *wave_dense_base,
-                        uint32_t region_cap, uint32_t nwaves, uint32_t *dense, void *stream) {
+                        uint32_t region_cap, uint32_t nwaves, uint32_t *dense, int rec16, void *stream) {
     if (nwaves == 0) return 0;
     hipLaunchKernelGGL(ts_compact_regions, dim3(nwaves), dim3(256), 0, (hipStream_t)stream,
-                       regions, wave_fill, wave_dense_base, region_cap, nwaves, dense);
+                       regions, wave_fill, wave_dense_base, region_cap, nwaves, dense, rec16);
     return (int)hipGetLastError();
 }

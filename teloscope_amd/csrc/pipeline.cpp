@@ -650,7 +650,7 @@ int batch_read_pass_device(ts_batch *b, unsigned char *d_pass, hipStream_t st) {
                                   (uint32_t *)(dt + off_flag),
                                   // (the scan left the canonical records' indices: the predicate visits only the chains that hold one)
                                   canon ? (const uint32_t *)b->d_chain.p : nullptr, canon ? b->d_vis.p : nullptr, canon ? b->vis_cap : 0u,
-                                  b->kp.rec16 ? 1 : 0, st);
+                                  b->records16() ? 1 : 0, st);
     if (e != 0) return c->fail(TS_ERR_HIP, "predicate kernel launch failed");
     return TS_OK;
 }
@@ -731,8 +731,6 @@ int run_pipeline(ts_ctx *ctx, Mode mode, bool tips, const std::vector<Item> &ite
             lens.resize(gr.count); abs.resize(gr.count);
             for (size_t i = 0; i < gr.count; ++i) { lens[i] = items[gr.first + i].len; abs[i] = items[gr.first + i].abs_pos; }
             gr.b = ts_batch_create(ctx, lens.data(), abs.data(), gr.count, tips ? 1 : 0, 0);
-            // a read filter's group: its records are read by the predicate only — 16 bits each where the batch allows (refused: 32)
-            if (gr.b && mode == Mode::ReadPass && ctx->knobs.rec16) (void)ts_batch_set_record_bits(gr.b, 16);
             if (gr.b) (void)ts_batch_set_emit(gr.b, 1);      // every download calls blocks on the device
             gr.t_plan = ms_between(t0, Clock::now());
             if (!gr.b) { set_err(ctx->error.rfind("unsupported", 0) == 0 ? TS_ERR_UNSUPPORTED : TS_ERR_HIP); break; }

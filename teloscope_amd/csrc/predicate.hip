@@ -75,10 +75,11 @@ __device__ __forceinline__ bool pred_feed(PredState &st, const TsPredParams &Q, 
 // masked — two blocks at a time with the next two already requested (round 2; dword loads before: 4x the instructions).
 // A block that would reach outside [matches, matches + nrec_limit) is read record by record.
 constexpr uint32_t kPredBlocks = 2;      // 16-byte blocks a thread requests at a time (and as many again in flight; four measured the same)
-template <bool FROM_START>
+template <bool FROM_START, typename REC = uint32_t>
 __device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_off, const uint32_t *tile_stats,
                                           const uint32_t *matches, u64 nrec_limit, uint32_t t0, uint32_t t1, u64 base, u64 n,
                                           const TsPredParams &Q) {
+    constexpr uint32_t RPB = 16u / (uint32_t)sizeof(REC);     // records per 16-byte block (REC: see pred_walk_read)
     PredState st = {};
     bool go = true;
     for (uint32_t tt = 0; tt < t1 - t0 && go && !st.pass; ++tt) {
@@ -87,33 +88,35 @@ __device__ __forceinline__ bool pred_walk(const TsTile *tiles, const u64 *tile_o
         if (cnt == 0u) continue;
         const u64 rel0 = tiles[t].in_off - base;
         const u64 off = tile_off[t];
-        const uint32_t *r = matches + off;
-        const uint32_t m = (uint32_t)(((uintptr_t)r >> 2) & 3u);      // records of the first block that are not ours
-        const uint32_t nb = (m + cnt + 3u) >> 2;                         // blocks covering records 0 .. cnt-1: record i = dword m + i
+        const REC *r = (const REC *)matches + off;
+        const uint32_t m = (uint32_t)(((uintptr_t)r / sizeof(REC)) & (RPB - 1u));   // records of the first block that are not ours
+        const uint32_t nb = (m + cnt + RPB - 1u) / RPB;                  // blocks covering records 0 .. cnt-1: record i = entry m + i
         const uint4 *ra = (const uint4 *)(r - m);
-        const bool inside = off >= m && off - m + 4ull * nb <= nrec_limit;
+        const bool inside = off >= m && off - m + (u64)RPB * nb <= nrec_limit;
         auto blk = [&](uint32_t bi) -> uint4 {             // bi-th block in walk order (clamped: loads are unconditional)
             const uint32_t qi = bi < nb ? bi : nb - 1u;
             const uint32_t q = FROM_START ? qi : nb - 1u - qi;
             if (inside) return ra[q];
-            uint32_t e[4];
+            uint32_t e[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) {
-                const uint32_t i = 4u * q + j - m;         // wraps below the first record
-                e[j] = i < cnt ? r[i] : 0u;
+            for (uint32_t j = 0; j < RPB; ++j) {
+                const uint32_t i = RPB * q + j - m;        // wraps below the first record
+                const uint32_t x = i < cnt ? (uint32_t)r[i] : 0u;
+                if (sizeof(REC) == 4) e[j & 3u] = x; else e[j >> 1] |= x << (16u * (j & 1u));
             }
             return make_uint4(e[0], e[1], e[2], e[3]);
         };
         auto feed_block = [&](uint32_t bi, const uint4 &v) {
             if (bi >= nb) return;
             const uint32_t q = FROM_START ? bi : nb - 1u - bi;
-            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (uint32_t jj = 0; jj < 4u; ++jj) {
-                const uint32_t j = FROM_START ? jj : 3u - jj;
-                const uint32_t i = 4u * q + j - m;
-                if (i < cnt && go && ((e[j] & 2u) != 0u) == FROM_START)
-                    go = pred_feed(st, Q, FROM_START, rel0 + (e[j] >> 2), e[j] & 1u, n);
+            for (uint32_t jj = 0; jj < RPB; ++jj) {
+                const uint32_t j = FROM_START ? jj : RPB - 1u - jj;
+                const uint32_t ej = sizeof(REC) == 4 ? w[j & 3u] : (w[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu;
+                const uint32_t i = RPB * q + j - m;
+                if (i < cnt && go && ((ej & 2u) != 0u) == FROM_START)
+                    go = pred_feed(st, Q, FROM_START, rel0 + (ej >> 2), ej & 1u, n);
             }
         };
         uint4 v[kPredBlocks], w[kPredBlocks];
@@ -375,9 +378,9 @@ void ts_terminal_predicate(const TsTile *tiles, const u64 *tile_off, const uint3
             ok = pred_walk_read<READS ? TS_PRED_NB : 2u, READS, REC>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, Q, nfwd >= 2, total - nfwd >= 2);
     } else if (!READS) {
         if (nfwd >= 2)                                      // forward list, from the segment start
-            ok = pred_walk<true>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
+            ok = pred_walk<true, REC>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
         if (!ok && total - nfwd >= 2)                       // reverse list, from the segment end
-            ok = pred_walk<false>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
+            ok = pred_walk<false, REC>(tiles, tile_off, tile_stats, matches, nrec_limit, t0, t1, base, n, Q);
     }
     pass[si] = ok ? 1 : 0;
 }
@@ -583,8 +586,12 @@ int ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_of
     if (all_terminal && chain && canon_idx)
         hipLaunchKernelGGL(ts_read_predicate_canon, dim3((nseg + 63u) / 64u), dim3(64), 0, st, tiles, tile_off, tile_stats, matches, (u64)nrec_limit, chain,
                            (const uint16_t *)canon_idx, seg_first_tile, seg_in_off, nseg, *Q, pass, long_list, long_count, (const uint32_t *)overflow);
-    else if (all_terminal && rec16)                           // (16-bit records: only a batch the lean kernel takes has them)
+    else if (all_terminal && rec16)                           // (16-bit records: TsScanParams.rec16)
         hipLaunchKernelGGL((ts_terminal_predicate<true, uint16_t>), dim3((nseg + 63u) / 64u), dim3(64), 0, st,
+                           tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
+                           long_list, long_count, (const uint32_t *)overflow);
+    else if (rec16)
+        hipLaunchKernelGGL((ts_terminal_predicate<false, uint16_t>), dim3((nseg + 63u) / 64u), dim3(64), 0, st,
                            tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
                            long_list, long_count, (const uint32_t *)overflow);
     else if (all_terminal)
@@ -596,7 +603,7 @@ int ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_of
                            tiles, tile_off, tile_stats, matches, (u64)nrec_limit, seg_first_tile, seg_in_off, seg_len, nseg, *Q, pass,
                            long_list, long_count, (const uint32_t *)overflow);
     const uint32_t grid = nseg < 8192u ? nseg : 8192u;      // waves of the second kernel: it strides over the list
-    if (all_terminal && rec16)
+    if (rec16)
         hipLaunchKernelGGL(ts_terminal_predicate_long<uint16_t>, dim3(grid), dim3(64), 0, st,
                            tiles, tile_off, tile_stats, matches, seg_first_tile, seg_in_off, *Q, pass,
                            (const uint32_t *)long_list, (const uint32_t *)long_count);

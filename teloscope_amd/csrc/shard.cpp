@@ -276,7 +276,6 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     DEVICE_TRY(c);
     if (!b->shard_parts) return c->fail(TS_ERR_STATE, "ts_batch_pack_shard needs ts_batch_restrict_shard first");
     if (!b->scanned || b->dense) return c->fail(TS_ERR_STATE, "ts_batch_pack_shard needs a scanned batch");
-    if (b->kp.rec16) return c->fail(TS_ERR_STATE, "ts_batch_pack_shard: the batch keeps 16-bit records (ts_batch_set_record_bits)");
     const ShardRange &r = b->shard_r;
     const ShardLayout &L = b->shard_L;
     if (msg_bytes < L.bytes) return c->fail(TS_ERR_INVALID_ARG, "ts_batch_pack_shard: message buffer smaller than ts_batch_shard_info says");
@@ -345,6 +344,7 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     Q.tile_off = (const unsigned long long *)b->d_tile_off.p;
     Q.tile_stats = b->stats_ptr();
     Q.matches = b->records_ptr();
+    Q.rec16 = b->records16() ? 1u : 0u;
     Q.blocks = (TsDevBlock *)(msg + L.off_blocks);
     Q.n_blocks = &((TsShardHeader *)msg)->n_blocks;
     Q.block_cap = L.block_capacity;
@@ -356,7 +356,7 @@ int ts_batch_pack_shard(ts_batch *b, void *d_msg, uint64_t msg_bytes, void *stre
     Q.min_block_counts = P.min_block_counts; Q.min_block_density = P.min_block_density;
     Q.k = c->k; Q.its_min_len = (uint32_t)(uint16_t)(2 * c->bp.first_pattern_len);
     TsShardPackParams K{};
-    K.tiles = Q.tiles; K.tile_off = Q.tile_off; K.tile_stats = Q.tile_stats; K.matches = Q.matches;
+    K.tiles = Q.tiles; K.tile_off = Q.tile_off; K.tile_stats = Q.tile_stats; K.matches = Q.matches; K.rec16 = Q.rec16;
     K.windows = b->windows_ptr();
     K.wave_fill = (const uint32_t *)b->d_fill.p;
     K.region_cap = b->region_cap; K.nwaves = b->total_waves;

@@ -74,10 +74,10 @@ void ts_shard_visible_count(const TsShardPackParams P, uint32_t *vis_stats) {
         const Zone z = zone_of(S.len, P.terminal_limit);
         const u64 rel0 = T.in_off - S.in_off;
         const uint32_t cnt = P.tile_stats[4ull * t];
-        const uint32_t *src = P.matches + P.tile_off[t];
+        const u64 src = P.tile_off[t];
         uint32_t n = 0;
         for (uint32_t j = lane; j < cnt; j += 64u) {
-            const uint32_t r = src[j];
+            const uint32_t r = P.rec16 ? (uint32_t)((const uint16_t *)P.matches)[src + j] : P.matches[src + j];
             const u64 rel = rel0 + (r >> 2);
             n += ((r & 1u) || rel <= z.lo_end || rel >= z.hi_begin) ? 1u : 0u;
         }

@@ -145,6 +145,7 @@ struct TsBlockCallParams {
     float    min_block_density;
     uint32_t k;                         // match length (uniform)
     uint32_t its_min_len;               // 2 * patterns.front().size()
+    uint32_t rec16;                     // the tiled kernel's records at 16 bits each (TsScanParams.rec16): `matches` is then read as uint16_t
     unsigned long long gen_lens;        // 0: the tiled kernel's records (position << 2 | forward << 1 | canonical, length k);
                                         // else the general kernels' (position << 5 | length index << 2 | canonical << 1 | forward)
                                         // and the up to eight pattern lengths, six bits each, length index i at bits 6i..
@@ -226,7 +227,7 @@ struct TsShardPackParams {
     const TsTile *tiles;                // range-local arrays of the batch (the range = owned + context tiles)
     const unsigned long long *tile_off;
     const uint32_t *tile_stats;
-    const uint32_t *matches;
+    const uint32_t *matches;      uint32_t rec16;      // (read as uint16_t when rec16: TsScanParams.rec16)
     const uint32_t *windows;            // 8 x u32 per window of the range, from win_lo
     const uint32_t *wave_fill;
     uint32_t region_cap, nwaves;
@@ -379,7 +380,7 @@ int  ts_k_launch_tile_order_export(const uint32_t *tile_stats, const unsigned lo
                                    const uint32_t *regions, const uint32_t *wave_fill, uint32_t region_cap,
                                    uint32_t nwaves, uint32_t ntiles, unsigned long long *dense_off, void *tmp,
                                    uint32_t *dense, unsigned long long capacity, unsigned long long *total_out,
-                                   void *stream);
+                                   int rec16, void *stream);
 // unpack.hip: a staged chunk of 2-bit codes (pack.cpp) -> the byte layout: chunk positions [first, first + n) to dst, then
 // 'N' over the chunk's invalid runs ({start, len} pairs, device memory; run position x lies at runs_base + x).
 // packed: 4-byte aligned, 8 readable bytes behind the last code.
@@ -391,7 +392,7 @@ int  ts_k_box_probe(void *scratch, unsigned long long bytes, int num_cu, double 
 int  ts_k_launch_widen_u16(const uint16_t *src, uint32_t *dst, unsigned long long n, void *stream);
 int  ts_k_launch_compact(const uint32_t *regions, const uint32_t *wave_fill,
                          const unsigned long long *wave_dense_base, uint32_t region_cap,
-                         uint32_t nwaves, uint32_t *dense, void *stream);
+                         uint32_t nwaves, uint32_t *dense, int rec16, void *stream);
 }
 #endif
 

@@ -952,7 +952,7 @@ def test_output_independent_of_tiling(cli, monkeypatch):
     # stage entries (TS_STAGE_U32=1: tiles above 2^14 positions take them anyway) and one accumulator row per window
     # (TS_ACC_PER_WINDOW=1: what a window that is not a multiple of the step takes) — the same bits either way
     monkeypatch.delenv("TS_GEOMETRY", raising=False)
-    for env in ("TS_STAGE_U32", "TS_ACC_PER_WINDOW"):
+    for env in ("TS_STAGE_U32", "TS_ACC_PER_WINDOW", "TS_REC32"):             # (TS_REC32: 32-bit records in the regions; the default is 16)
         monkeypatch.setenv(env, "1")
         got = ProductBackend(opts).scan_segments(segs)
         monkeypatch.delenv(env)
@@ -996,7 +996,8 @@ def test_read_filter_long_match_lists(cli):
 def test_read_records_of_16_and_of_32_bits_give_the_same_pass_bytes(monkeypatch):
     """ts_batch_set_record_bits: ts_filter_reads keeps its batches' records at 16 bits (the predicate is their only reader);
     TS_REC32=1 (read when the context is made) keeps 32.  Same pass bytes, the oracle's; a batch that cannot have 16-bit records
-    says so and stays at 32, and a batch that has them gives no raw view of them."""
+    says so and stays at 32, and a batch that has them gives no raw view of them (every reader inside the library knows both
+    widths: test_output_independent_of_tiling runs the window scan's readers with TS_REC32=1 as well)."""
     import ctypes as C
     import teloscope_amd as ta
     from teloscope_amd import _capi as K
@@ -1030,5 +1031,6 @@ def test_read_records_of_16_and_of_32_bits_give_the_same_pass_bytes(monkeypatch)
     L.ts_batch_destroy(b)
     tel = ta.Teloscope(user_input(H.parse_cli("x.fa -r")))
     full = L.ts_batch_create(tel._ctx.ptr, lens, None, 3, 0, 0)
-    assert full and L.ts_batch_set_record_bits(full, 16) == K.TS_ERR_UNSUPPORTED  # a window scan's records have other readers
+    assert full and not L.ts_batch_matches_ptr(full)                              # a window scan's records are 16 bits by default as well
+    assert L.ts_batch_set_record_bits(full, 32) == 0                              # ... unless the caller wants the raw 32-bit view
     L.ts_batch_destroy(full)
