@@ -1054,6 +1054,7 @@ void ts_scan_tiles(const TsScanParams P) {
                     unsigned char *const dst0 = Q->win_packed + T_win_out * (u64)wb;
                     uint32_t ln = lane;
                     asm volatile("" : "+v"(ln));              // (nothing derived from the lane id here is worth a register through the chunk loop)
+                    const bool ten = B == 10u && P.nuc_on != 0u;   // seven 10-bit fields (512 <= w < 1024): the layout by constants
                     for (uint32_t i = ln; i < T.nwin; i += 64u) {
                         u64 lo = 0, hi = 0;
                         uint32_t at = 0;
@@ -1062,17 +1063,27 @@ void ts_scan_tiles(const TsScanParams P) {
                             if (at + B > 64u) hi |= at >= 64u ? (u64)v << (at - 64u) : (u64)v >> (64u - at);
                             at += B;
                         };
+                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
                         if (P.nuc_on) {
-                            uint4 v = make_uint4(0u, 0u, 0u, 0u);
                             const uint32_t nrow = by_blocks ? P.halo_blocks + 1u : 1u;
                             for (uint32_t j = 0; j < nrow; ++j) {
                                 const LDS uint32_t *r4 = rec + (i + j) * 4u;
                                 v.x += r4[0]; v.y += r4[1]; v.z += r4[2]; v.w += r4[3];
                             }
-                            put(v.x); put(v.y); put(v.z); put(v.w);
                         }
                         const u64 a = window_fields(i);
-                        put((uint32_t)a & 0xFFFFu); put((uint32_t)a >> 16); put((uint32_t)(a >> 32) & 0xFFFFu);
+                        const uint32_t f4 = (uint32_t)a & 0xFFFFu, f5 = (uint32_t)a >> 16, f6 = (uint32_t)(a >> 32) & 0xFFFFu;
+                        if (ten) {
+                            // fields at bits 0, 10, .. 60 of a 70-bit record (every field < 1024): ten 32-bit instructions where the
+                            // generic shifts by a run-time amount below came to eighty
+                            const uint32_t w0 = v.x | (v.y << 10) | (v.z << 20) | (v.w << 30);
+                            const uint32_t w1 = (v.w >> 2) | (f4 << 8) | (f5 << 18) | (f6 << 28);
+                            lo = (u64)w0 | ((u64)w1 << 32);
+                            hi = (u64)(f6 >> 4);
+                        } else {
+                            if (P.nuc_on) { put(v.x); put(v.y); put(v.z); put(v.w); }
+                            put(f4); put(f5); put(f6);
+                        }
                         // (unaligned 8- and 4-byte stores: two store instructions for the 9 bytes of w = 1000, not nine)
                         unsigned char *d = dst0 + (u64)i * wb;
                         uint32_t b = 0;
