@@ -466,6 +466,17 @@ void ts_scan_tiles(const TsScanParams P) {
             const bool rec16 = Q->rec16 != 0u;
             uint16_t *const wave_out16 = (uint16_t *)Q->matches_out + (u64)gw * cap;
             if (!EMIT || redo) {
+                if (!EMIT && st16 && rec16 && cursor + flushed + n <= cap) {
+                    // the staged entries ARE the records: copied four to a lane (an 8-byte LDS read, an 8-byte store — unaligned where
+                    // the region's cursor is) instead of one; the last one to three go singly
+                    const uint32_t n4 = n & ~3u;
+                    uint16_t *const dst = wave_out16 + cursor + flushed;
+                    for (uint32_t i = 4u * ln; i < n4; i += 256u) {
+                        const u32x2 q = *(const LDS u32x2 *)((lds_u16 *)stage + i);
+                        if (!(TS_ABL & 1)) gstore_unaligned((unsigned char *)(dst + i), (u64)q.x | ((u64)q.y << 32));
+                    }
+                    if (ln < n - n4 && !(TS_ABL & 1)) gstore_lo16(dst + n4 + ln, stage_at(n4 + ln));
+                } else
                 for (uint32_t i = ln; i < n; i += 64u) {
                     const uint32_t o = cursor + flushed + i;
                     if (o < cap && !(TS_ABL & 1)) {
