@@ -47,10 +47,17 @@ typedef unsigned long long u64;
 __device__ __forceinline__ uint32_t rec_at(const TsBlockCallParams &Q, const uint32_t *matches, u64 i) {
     return Q.rec16 ? (uint32_t)((const uint16_t *)matches)[i] : matches[i];
 }
+// MODE 1 (the instantiations the general path launches for what MODE 0 does not take): additionally the WIDE form's records
+// (position << 8 | length index << 2 | canonical << 1 | forward, lengths in Q.wide_len) and streams in the reference's push order
+// (Q.unordered: generic.hip, ts_general_compact_push).  MODE 0 is the code the tiled kernel's batches and shards run.
+template <int MODE>
 __device__ __forceinline__ uint32_t rec_norm(const TsBlockCallParams &Q, uint32_t raw) {
+    if (MODE == 1 && Q.wide) return ((raw >> 8) << 2) | ((raw & 1u) << 1) | ((raw >> 1) & 1u);
     return Q.gen_lens ? ((raw >> 5) << 2) | ((raw & 1u) << 1) | ((raw >> 1) & 1u) : raw;
 }
+template <int MODE>
 __device__ __forceinline__ uint32_t rec_len(const TsBlockCallParams &Q, uint32_t raw) {
+    if (MODE == 1 && Q.wide) return Q.wide_len[(raw >> 2) & 63u];
     return Q.gen_lens ? (uint32_t)(Q.gen_lens >> (6u * ((raw >> 2) & 7u))) & 63u : Q.k;
 }
 // sum of v over the lanes of `mask` (wave-uniform result)
@@ -92,11 +99,11 @@ struct Chain {                               // running chain of matches (startN
 };
 
 __device__ __forceinline__ void emit_block(const TsBlockCallParams &Q, TsDevBlock &b, uint32_t seg, uint32_t kind, uint32_t seq,
-                           u64 abs_pos) {
+                           u64 abs_pos, uint32_t seq_hi = 0u) {
     const uint32_t slot = atomicAdd(Q.n_blocks, 1u);
     if (slot >= Q.block_cap) return;                       // overflow: the host sees n_blocks > cap
     b.start += abs_pos;
-    b.seg = seg; b.kind = kind; b.seq = seq; b.pad = 0;
+    b.seg = seg; b.kind = kind; b.seq = seq; b.pad = seq_hi;
     Q.blocks[slot] = b;
 }
 
@@ -125,6 +132,7 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 // record: a telomere is one chain of thousands of matches.  Lane 0 writes the blocks.
 // (forced inline: as a function of its own it took the kernel's parameters by reference — the whole parameter block went to scratch,
 // every pointer out of it became a flat address, and the eight rows it fetches ahead were waited for behind the first scratch reload)
+template <int MODE>
 __device__ __forceinline__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, uint32_t seg, u64 n, u64 abs_pos,
                                   bool from_start, uint32_t &seq, uint32_t lane, bool &out_of_context) {
     u64 boundary = from_start ? 0 : n;                     // segment-relative
@@ -203,8 +211,8 @@ __device__ __forceinline__ u64 terminal_direction(const TsBlockCallParams &Q, co
             const uint32_t b0 = b4 + 64u * q;
             if (b0 >= cnt || stop) break;
             const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
-            const uint32_t lenv = rec_len(Q, recs[q]);       // this lane's match length (Q.k for the tiled kernel's records)
-            const uint32_t rec = rec_norm(Q, recs[q]);
+            const uint32_t lenv = rec_len<MODE>(Q, recs[q]);       // this lane's match length (Q.k for the tiled kernel's records)
+            const uint32_t rec = rec_norm<MODE>(Q, recs[q]);
             const bool uni = Q.gen_lens == 0ull;             // uniform length: covered bases = records x k
             const bool sel = lane < nb && (((rec >> 1) & 1u) != 0u) == from_start;      // forward list from the start, reverse from the end
             u64 rem = __ballot(sel);
@@ -212,8 +220,19 @@ __device__ __forceinline__ u64 terminal_direction(const TsBlockCallParams &Q, co
             const uint32_t p32 = rec >> 2;                 // tile-relative (a batch lies in one tile), < 2^30
             // predecessor in the walk among the wanted records of this batch: prefix maximum of position + 1
             // (ascending walk) or of ~position (descending walk: the maximum of ~p is the minimum of p), one lane down
-            const uint32_t incl = wave_scan_max(sel ? (from_start ? p32 + 1u : ~p32) : 0u);
-            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xf, 0xf, false);   // wave_shr:1
+            uint32_t before;
+            if (MODE == 1 && Q.unordered) {
+                // a stream in push order: the predecessor is the wanted record before this one AS THE STREAM LIES (the nearest
+                // wanted lane below), whatever its position — one that lies behind this record's makes the gap wrap, and the
+                // chain breaks there, as the reference's unsigned subtraction does (src/teloscope.cpp:60-75)
+                const u64 below_me = rem & (lane ? (1ull << lane) - 1ull : 0ull);
+                const int pl = below_me ? 63 - (int)__builtin_clzll(below_me) : 0;
+                const uint32_t v = (uint32_t)__shfl((int)(from_start ? p32 + 1u : ~p32), pl);
+                before = below_me ? v : 0u;
+            } else {
+                const uint32_t incl = wave_scan_max(sel ? (from_start ? p32 + 1u : ~p32) : 0u);
+                before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xf, 0xf, false);   // wave_shr:1
+            }
             const uint32_t gap_in = from_start ? p32 - (before - 1u) : ~before - p32;
             const uint32_t first_lane = (uint32_t)__builtin_ctzll(rem);
             const u64 first_pos = tile_rel + (uint32_t)__builtin_amdgcn_readlane((int)p32, (int)first_lane);
@@ -382,6 +401,7 @@ __device__ __forceinline__ bool view_has_two(const TsBlockCallParams &Q, const S
 #ifndef TS_TERMINAL_PRIO
 #define TS_TERMINAL_PRIO 0
 #endif
+template <int MODE>
 __global__ __launch_bounds__(kSideWg)
 void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t nseg, u64 *bounds, TsShardSeg *seg_out) {
     // two independent waves per segment: wave 0 walks the forward list from the start, wave 1 the reverse list from the end.
@@ -405,7 +425,7 @@ void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uin
         u64 fb = 0;
         bool ooc = false;
         const bool walk = (S.flags & TS_SEG_F_HAS_START) && view_has_two(Q, V, 1, false, lane);
-        if (walk) fb = terminal_direction(Q, V, S.seg, n, S.abs_pos, true, seq, lane, ooc);
+        if (walk) fb = terminal_direction<MODE>(Q, V, S.seg, n, S.abs_pos, true, seq, lane, ooc);
         if (lane == 0) {
             bounds[2ull * si] = fb;
             if (seg_out) {
@@ -418,7 +438,7 @@ void ts_terminal_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uin
         bool ooc = false;
         const bool two_rev = view_has_two(Q, V, 2, true, lane);
         const bool walk = (S.flags & TS_SEG_F_HAS_END) && two_rev;
-        if (walk) rb = terminal_direction(Q, V, S.seg, n, S.abs_pos, false, seq, lane, ooc);
+        if (walk) rb = terminal_direction<MODE>(Q, V, S.seg, n, S.abs_pos, false, seq, lane, ooc);
         const bool two_any = two_rev || view_has_two(Q, V, 0, true, lane);
         if (lane == 0) {
             const u64 rb_out = two_any ? rb : 0;           // 0 disables the interstitial search
@@ -454,6 +474,7 @@ __device__ __forceinline__ u64 low_bits(uint32_t n) { return n >= 64u ? ~0ull : 
 // filters (src/teloscope.cpp:206-233), its block.  Run by ts_interstitial_evaluate for the few chains the screening
 // kernel lists as holding four canonical matches; whole wave, lane 0 writes.  (Called from inside the screening kernel it
 // cost that kernel its registers: 99 VGPRs and a scratch frame for the call, 0.95 ms instead of 0.44.)
+template <int MODE>
 __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const TsShardSegIn &S, uint32_t t0, uint32_t i0, u64 rb) {
     const uint32_t lane = threadIdx.x & 63u;
     u64 start = 0, prev = 0;
@@ -470,7 +491,7 @@ __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const T
             const uint32_t nvalid = cnt - b0 < 64u ? cnt - b0 : 64u;
             const u64 VALID = low_bits(nvalid);
             const uint32_t raw = lane < nvalid ? rec_at(Q, Q.matches, src + b0 + lane) : 0u;
-            const uint32_t r = rec_norm(Q, raw), lenv = rec_len(Q, raw);
+            const uint32_t r = rec_norm<MODE>(Q, raw), lenv = rec_len<MODE>(Q, raw);
             const uint32_t p32 = r >> 2;
             const uint32_t below = lane_below(p32);
             // records that end the chain: out of range, or too far behind their predecessor (lane 0: the last record of the
@@ -510,7 +531,10 @@ __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const T
     b.non_canonical_count = counts - canon;
     b.total_covered = Q.gen_lens ? cov : counts * Q.k; b.fwd_covered = Q.gen_lens ? fwd_cov : fwd * Q.k;
     b.can_covered = Q.gen_lens ? can_cov : canon * Q.k; b.has_valid_or = 1; b.is_longest = 0; b.block_label = lab; b.reserved = 0;
-    emit_block(Q, b, S.seg, 2u, 0u, S.abs_pos);
+    // (MODE 1: the stream index of the chain's first record orders the blocks as the reference's walk emits them — over a stream in
+    // push order a later chain may start ahead of an earlier one, or at the same position)
+    const u64 order = MODE == 1 ? Q.tile_off[t0] + i0 : 0ull;
+    emit_block(Q, b, S.seg, 2u, (uint32_t)order, S.abs_pos, (uint32_t)(order >> 32));
 }
 
 // getInterstitialBlocks (src/teloscope.cpp:179-256) over the packed match stream, and — for a shard — the visible
@@ -527,6 +551,7 @@ __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const T
 // records end is followed (counting canonical matches) through the tiles behind until a head closes it.
 //
 // Measured on the 91.5 M records of configs[1]: profiles/r03/its_kernel_variants.txt.
+template <int MODE>
 __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsShardSegIn *segs, uint32_t seg_base,
                                          const u64 *bounds, uint32_t ntiles, TsShardSeg *seg_out, const TsVisibleOut &W,
                                          const uint32_t tile) {
@@ -549,7 +574,11 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
     const TsShardSegIn S = segs[si];
     if (tile < S.o0 || tile >= S.o1) return;              // a context tile: its chains and its records are its owner's
     const u64 fb = bounds[2ull * si], rb = bounds[2ull * si + 1];
-    const bool its_on = !(rb == 0 || fb >= rb);
+    // A stream in push order (MODE 1, Q.unordered): the search range is a range of stream INDICES — from where the reference's
+    // lower_bound lands to the first record at or behind revBoundary as the stream lies (ts_its_range) — not of positions.
+    const bool unord = MODE == 1 && Q.unordered != 0u;
+    const u64 it_idx = unord ? Q.its_range[2ull * si] : 0ull, end_idx = unord ? Q.its_range[2ull * si + 1] : 0ull;
+    const bool its_on = unord ? it_idx < end_idx : !(rb == 0 || fb >= rb);
     // visible records of this tile (a shard's message): where they go, and whether there are any
     u64 vis_at = 0;
     bool vis_on = false;
@@ -565,8 +594,8 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
     constexpr uint32_t kGroup = 8;                         // batches of 64 records requested together
     uint32_t recs[kGroup];
 #pragma unroll
-    for (uint32_t q = 0; q < kGroup; ++q) recs[q] = 64u * q + lane < cnt ? rec_norm(Q, rec_at(Q, Q.matches, src + 64u * q + lane)) : 0u;
-    const uint32_t next_rec = (tn != tile && lane < next_cnt) ? rec_norm(Q, rec_at(Q, Q.matches, next_off + lane)) : 0u;
+    for (uint32_t q = 0; q < kGroup; ++q) recs[q] = 64u * q + lane < cnt ? rec_norm<MODE>(Q, rec_at(Q, Q.matches, src + 64u * q + lane)) : 0u;
+    const uint32_t next_rec = (tn != tile && lane < next_cnt) ? rec_norm<MODE>(Q, rec_at(Q, Q.matches, next_off + lane)) : 0u;
 
     // the record ahead of the tile's first one (head test of that record), as a position relative to the tile (negative)
     bool has_last = false;
@@ -577,14 +606,14 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
         bool found = false;
         u64 last_pos = 0;
         if (tile > S.t0 && prev_cnt) {                     // the usual case: the tile before holds it
-            const uint32_t r = rec_norm(Q, rec_at(Q, Q.matches, prev_off + prev_cnt - 1u));
+            const uint32_t r = rec_norm<MODE>(Q, rec_at(Q, Q.matches, prev_off + prev_cnt - 1u));
             last_pos = prev_in_off - S.in_off + (r >> 2);
             found = true;
         } else {
             for (uint32_t t = tile; t > S.t0; --t) {
                 const uint32_t c = Q.tile_stats[4u * (t - 1u)];
                 if (c) {
-                    const uint32_t r = rec_norm(Q, rec_at(Q, Q.matches, Q.tile_off[t - 1u] + c - 1u));
+                    const uint32_t r = rec_norm<MODE>(Q, rec_at(Q, Q.matches, Q.tile_off[t - 1u] + c - 1u));
                     last_pos = Q.tiles[t - 1u].in_off - S.in_off + (r >> 2);
                     found = true;
                     break;
@@ -594,6 +623,13 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
         has_last = found && last_pos >= fb;                // (a record ahead of the search range does not chain)
         // (farther than 2^30 ahead is as good as 2^30: -k is 16 bits)
         last_rel = tile_rel - last_pos > 0x40000000ull ? -0x40000000 : -(int)(uint32_t)(tile_rel - last_pos);
+        if (unord) {
+            // the record ahead is the stream's record off - 1, in range iff that index is; it may lie BEHIND this tile's first
+            // base (a record that moved into the tile before): the gap to it is then negative — wraps, in the reference — and
+            // the first record opens a chain whatever the distance
+            has_last = found && off > it_idx;
+            if (last_pos >= tile_rel) last_rel = last_pos - tile_rel > 0x3FFFFFFFull ? 0x3FFFFFFF : (int)(uint32_t)(last_pos - tile_rel);
+        }
         if (!found && open_l && S.lo_rel > fb) {
             // nothing in the whole left context: a record further left is too far to chain if the context is wider than -k
             // (it is, shard.cpp sizes it so) — unless this tile's first record sits right at the view's edge
@@ -611,7 +647,7 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
     const u64 tile_end = tile_rel + T.own_len;
     auto rel32 = [&](u64 x) -> uint32_t { return x <= tile_rel ? 0u : (x - tile_rel > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(x - tile_rel)); };
     const uint32_t fb32 = rel32(fb), rb32 = rel32(rb);
-    const bool all_in = fb <= tile_rel && rb >= tile_end;
+    const bool all_in = unord ? (off >= it_idx && off + cnt <= end_idx) : (fb <= tile_rel && rb >= tile_end);
     const bool vis_all = tile_end - 1 <= z_lo || tile_rel >= z_hi, vis_canon = tile_rel > z_lo && tile_end <= z_hi;
     const uint32_t zlo32 = z_lo < tile_rel ? 0u : rel32(z_lo), zhi32 = rel32(z_hi);
     const bool zlo_none = z_lo < tile_rel;                 // no position of the tile is <= z_lo
@@ -642,14 +678,27 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
             vis_done += (uint32_t)__popcll(m);
         }
         if (!its_on || finished) return;
-        const u64 R = all_in ? VALID : __ballot(p32 >= fb32 && p32 < rb32) & VALID;
-        const bool past = all_in ? false : (__ballot(p32 >= rb32) & VALID) != 0ull;   // records at or behind revBoundary: the search ends here
+        u64 R;
+        bool past;
+        if (unord && !all_in) {
+            const u64 g0 = off + b0;                        // stream index of lane 0's record
+            const uint32_t lo = it_idx > g0 ? (it_idx - g0 > 64ull ? 64u : (uint32_t)(it_idx - g0)) : 0u;
+            const uint32_t hi = end_idx > g0 ? (end_idx - g0 > 64ull ? 64u : (uint32_t)(end_idx - g0)) : 0u;
+            R = low_bits(hi) & ~low_bits(lo) & VALID;
+            past = end_idx < g0 + nvalid;
+        } else {
+            R = all_in ? VALID : __ballot(p32 >= fb32 && p32 < rb32) & VALID;
+            past = all_in ? false : (__ballot(p32 >= rb32) & VALID) != 0ull;   // records at or behind revBoundary: the search ends here
+        }
         if (R != 0ull) {
             // a record opens a chain iff its predecessor is out of range or more than -k ahead of it: the lane below, or for
             // lane 0 the last record of the batch / tile before
             const uint32_t below = lane_below(p32);
             u64 H = R & (~(R << 1) | __ballot(p32 - below > Q.max_match_dist));
-            if ((R & 1ull) && has_last && (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)p32) - last_rel <= kdist) H &= ~1ull;
+            // (unsigned: a predecessor that lies behind the record — a stream in push order — is farther than any -k, as the reference's
+            // wrapped gap is; in position order the difference is never negative)
+            const int gap0 = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)p32) - last_rel;
+            if ((R & 1ull) && has_last && (MODE == 1 ? (uint32_t)gap0 <= (uint32_t)kdist : gap0 <= kdist)) H &= ~1ull;
             const u64 Cn = CAN & R;
             if (H != 0ull) {
                 const uint32_t first_head = (uint32_t)__builtin_ctzll(H), top_head = 63u - (uint32_t)__builtin_clzll(H);
@@ -700,7 +749,7 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
         const uint32_t below = lane_below(p32);
         u64 H = VALID & (__ballot(p32 - below > Q.max_match_dist) | 1ull);
         const int gap0 = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)p32) - last_rel;
-        H &= ~(u64)((has_last && gap0 <= kdist) ? 1u : 0u);
+        H &= ~(u64)((has_last && (MODE == 1 ? (uint32_t)gap0 <= (uint32_t)kdist : gap0 <= kdist)) ? 1u : 0u);
         const bool any = H != 0ull;
         const u64 ahead = (H - 1ull) & ~H;                                // the lanes ahead of the first head (all of them when there is none)
         const uint32_t top_head = any ? 63u - (uint32_t)__builtin_clzll(H) : 0u;
@@ -729,13 +778,13 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
         for (uint32_t q = 0; q < kGroup; ++q)
             if (64u * q < cnt) fast_batch(64u * q, recs[q]);
         for (uint32_t b0 = 64u * kGroup; b0 < cnt; b0 += 64u)           // a dense tile: the rest, batch by batch
-            fast_batch(b0, b0 + lane < cnt ? rec_norm(Q, rec_at(Q, Q.matches, src + b0 + lane)) : 0u);
+            fast_batch(b0, b0 + lane < cnt ? rec_norm<MODE>(Q, rec_at(Q, Q.matches, src + b0 + lane)) : 0u);
     } else {
 #pragma unroll
         for (uint32_t q = 0; q < kGroup; ++q)
             if (64u * q < cnt) batch(64u * q, recs[q]);
         for (uint32_t b0 = 64u * kGroup; b0 < cnt; b0 += 64u)
-            batch(b0, b0 + lane < cnt ? rec_norm(Q, rec_at(Q, Q.matches, src + b0 + lane)) : 0u);
+            batch(b0, b0 + lane < cnt ? rec_norm<MODE>(Q, rec_at(Q, Q.matches, src + b0 + lane)) : 0u);
     }
     // the chain that is still open belongs to this tile: follow it through the tiles behind until a head closes it
     if (its_on && open && !finished) {
@@ -750,11 +799,15 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
             const u64 src2 = pre_fetched ? next_off : Q.tile_off[t];
             const uint32_t rb2 = rb <= rel2 ? 0u : (rb - rel2 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)(rb - rel2));
             for (uint32_t b0 = 0; b0 < c2 && !closed; b0 += 64u) {
-                const uint32_t r = (pre_fetched && b0 == 0u) ? next_rec : (b0 + lane < c2 ? rec_norm(Q, rec_at(Q, Q.matches, src2 + b0 + lane)) : 0u);
+                const uint32_t r = (pre_fetched && b0 == 0u) ? next_rec : (b0 + lane < c2 ? rec_norm<MODE>(Q, rec_at(Q, Q.matches, src2 + b0 + lane)) : 0u);
                 const uint32_t nvalid = c2 - b0 < 64u ? c2 - b0 : 64u;
                 const u64 VALID = low_bits(nvalid);
                 const uint32_t p32 = r >> 2;
-                const u64 R = __ballot(p32 < rb2) & VALID;               // (p >= fb: behind a record that was)
+                u64 R = __ballot(p32 < rb2) & VALID;                     // (p >= fb: behind a record that was)
+                if (unord) {                                             // by stream index: up to the range's end
+                    const u64 g0 = src2 + b0;
+                    R = low_bits(end_idx > g0 ? (end_idx - g0 > 64ull ? 64u : (uint32_t)(end_idx - g0)) : 0u) & VALID;
+                }
                 if (R != 0ull) {
                     const uint32_t below = lane_below(p32);
                     u64 H = R & (__ballot(p32 - below > Q.max_match_dist) | 1ull);
@@ -778,6 +831,7 @@ __device__ __forceinline__ void its_tile(const TsBlockCallParams &Q, const TsSha
 
 // every tile of the range: results that carry no chain summaries (adopted from elsewhere, TS_EMIT=0), and the shard pack
 // that takes the visible records from the match stream
+template <int MODE>
 __global__ __launch_bounds__(kSideWg)
 void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base,
                             const u64 *bounds, uint32_t ntiles, TsShardSeg *seg_out, const TsVisibleOut W) {
@@ -786,7 +840,7 @@ void ts_interstitial_blocks(const TsBlockCallParams Q, const TsShardSegIn *segs,
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wave;
     if (tile >= ntiles) return;
-    its_tile(Q, segs, seg_base, bounds, ntiles, seg_out, W, tile);
+    its_tile<MODE>(Q, segs, seg_base, bounds, ntiles, seg_out, W, tile);
 }
 
 // ---- the interstitial search from the scan's own chain summaries (TsTileChain, written by ts_scan_tiles with P.emit)
@@ -884,11 +938,12 @@ void ts_interstitial_listed(const TsBlockCallParams Q, const TsShardSegIn *segs,
     const uint32_t n = *n_work;
     const TsVisibleOut W{};
     for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave; i < n; i += gridDim.x * (blockDim.x >> 6))
-        its_tile(Q, segs, seg_base, bounds, ntiles, seg_out, W, (uint32_t)__builtin_amdgcn_readfirstlane((int)work[i]));
+        its_tile<0>(Q, segs, seg_base, bounds, ntiles, seg_out, W, (uint32_t)__builtin_amdgcn_readfirstlane((int)work[i]));
 }
 
 // The listed chains, one wave each: walked exactly, filtered, written.  A list that overflowed is reported through the
 // block counter (more blocks than the buffer holds = "come back with more room": the callers' existing path).
+template <int MODE>
 __global__ __launch_bounds__(kSideWg)
 void ts_interstitial_evaluate(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t seg_base, const u64 *bounds) {
     const uint32_t n_all = *Q.n_cand;
@@ -899,8 +954,71 @@ void ts_interstitial_evaluate(const TsBlockCallParams Q, const TsShardSegIn *seg
         const uint32_t tile = Q.cand[2u * i], i0 = Q.cand[2u * i + 1u];
         const uint32_t si = Q.tiles[tile].seg - seg_base;
         const TsShardSegIn S = segs[si];
-        its_evaluate(Q, S, tile, i0, bounds[2ull * si + 1]);
+        its_evaluate<MODE>(Q, S, tile, i0, bounds[2ull * si + 1]);
     }
+}
+
+// The interstitial search range of a stream in push order, per segment, as stream indices {first, end}: `first` is where
+// std::lower_bound(allMatches, fwdBoundary) lands — the bisection restated probe by probe, because on a stream that is not quite
+// sorted its result depends on which records it looks at (src/teloscope.cpp:188-191; libstdc++: half = len >> 1, mid = first +
+// half) — and `end` the first record from there on that lies at or behind revBoundary (:235 ends the loop at it).  {0, 0}: no
+// search (the gates of scanSegment, :646-653, or an empty range).  One wave per segment; a probe finds its record's tile by a
+// 64-way search of the tile offsets.
+__global__ __launch_bounds__(kSideWg)
+void ts_its_range(const TsBlockCallParams Q, const TsShardSegIn *segs, uint32_t nseg, const u64 *bounds, u64 *range) {
+    const uint32_t si = blockIdx.x;
+    if (si >= nseg) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const TsShardSegIn S = segs[si];
+    const u64 fb = bounds[2ull * si], rb = bounds[2ull * si + 1];
+    const u64 g_lo = Q.tile_off[S.t0], g_hi = Q.tile_off[S.t1], n = g_hi - g_lo;
+    u64 it = 0, end = 0;
+    // the last tile of [t0, t1) whose `what` (non-decreasing over the tiles) is <= v; t0 if none
+    auto last_tile_le = [&](auto what, u64 v) -> uint32_t {
+        uint32_t lo = S.t0, hi = S.t1;
+        while (hi - lo > 1u) {
+            const uint32_t step = (hi - lo + 63u) / 64u;
+            const uint32_t t = lo + lane * step;
+            const u64 m = __ballot(t < hi && (lane == 0u || what(t) <= v));
+            const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
+            lo += top * step;
+            hi = lo + step < hi ? lo + step : hi;
+        }
+        return lo;
+    };
+    auto pos_at = [&](u64 g) -> u64 {                      // segment-relative position of stream record g (wave-uniform)
+        const uint32_t t = last_tile_le([&](uint32_t x) { return Q.tile_off[x]; }, g);
+        return Q.tiles[t].in_off - S.in_off + (rec_norm<1>(Q, rec_at(Q, Q.matches, g)) >> 2);
+    };
+    if (rb != 0ull && n != 0ull && S.t1 > S.t0) {
+        u64 first = 0, len = n;
+        while (len > 0ull) {
+            const u64 half = len >> 1, mid = first + half;
+            if (pos_at(g_lo + mid) < fb) { first = mid + 1ull; len = len - half - 1ull; }
+            else len = half;
+        }
+        if (first < n && pos_at(g_lo + first) < rb) {
+            it = g_lo + first;
+            end = g_hi;
+            // records of the tiles ahead of the one that holds position rb - 64 all lie ahead of rb (a tile's records start
+            // before the next tile's 63rd base): the scan for the first record at or behind rb begins there
+            const u64 from = rb >= 64ull ? rb - 64ull : 0ull;
+            const uint32_t tq = last_tile_le([&](uint32_t x) { return Q.tiles[x].in_off - S.in_off; }, from);
+            bool found = false;
+            for (uint32_t t = tq; t < S.t1 && !found; ++t) {
+                const u64 o = Q.tile_off[t], o1 = Q.tile_off[t + 1u];
+                if (o1 <= it) continue;
+                const u64 rel = Q.tiles[t].in_off - S.in_off;
+                for (u64 g = o; g < o1 && !found; g += 64ull) {
+                    const bool valid = g + lane < o1 && g + lane >= it;
+                    const u64 p = valid ? rel + (rec_norm<1>(Q, rec_at(Q, Q.matches, g + lane)) >> 2) : 0ull;
+                    const u64 m = __ballot(valid && p >= rb);
+                    if (m) { end = g + (uint32_t)__builtin_ctzll(m); found = true; }
+                }
+            }
+        }
+    }
+    if (lane == 0u) { range[2ull * si] = it; range[2ull * si + 1] = end; }
 }
 
 }  // namespace
@@ -935,7 +1053,10 @@ int ts_k_launch_terminal(const TsBlockCallParams *Q, const TsShardSegIn *segs, u
                          unsigned long long *bounds, TsShardSeg *seg_out, void *stream) {
     (void)seg_base; (void)ntiles;
     if (nseg == 0) return 0;
-    hipLaunchKernelGGL(ts_terminal_blocks, dim3(2u * nseg), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, nseg, bounds, seg_out);
+    if (Q->unordered || Q->wide)
+        hipLaunchKernelGGL(ts_terminal_blocks<1>, dim3(2u * nseg), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, nseg, bounds, seg_out);
+    else
+        hipLaunchKernelGGL(ts_terminal_blocks<0>, dim3(2u * nseg), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, nseg, bounds, seg_out);
     return (int)hipGetLastError();
 }
 
@@ -972,11 +1093,23 @@ int ts_k_launch_interstitial(const TsBlockCallParams *Q, const TsShardSegIn *seg
                            segs, seg_base, (const u64 *)bounds, ntiles, work + 1, work, seg_out);
         hipLaunchKernelGGL(ts_interstitial_listed, dim3(512), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, seg_base,
                            (const u64 *)bounds, ntiles, seg_out, (const uint32_t *)(work + 1), (const uint32_t *)work);
+    } else if (Q->unordered || Q->wide) {
+        // the general path's wide records and push-ordered streams (MODE 1); the search range by stream index first
+        if (Q->unordered) {
+            if (!Q->its_range || seg_base != 0u) return (int)hipErrorInvalidValue;
+            hipLaunchKernelGGL(ts_its_range, dim3(nseg), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, nseg, (const u64 *)bounds,
+                               (u64 *)Q->its_range);
+        }
+        hipLaunchKernelGGL(ts_interstitial_blocks<1>, dim3(ntiles), dim3(kSideWg), 0, (hipStream_t)stream, *Q,
+                           segs, seg_base, (const u64 *)bounds, ntiles, seg_out, W);
+        hipLaunchKernelGGL(ts_interstitial_evaluate<1>, dim3(1024), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, seg_base,
+                           (const u64 *)bounds);
+        return (int)hipGetLastError();
     } else {
-        hipLaunchKernelGGL(ts_interstitial_blocks, dim3(ntiles), dim3(kSideWg), 0, (hipStream_t)stream, *Q,
+        hipLaunchKernelGGL(ts_interstitial_blocks<0>, dim3(ntiles), dim3(kSideWg), 0, (hipStream_t)stream, *Q,
                            segs, seg_base, (const u64 *)bounds, ntiles, seg_out, W);
     }
-    hipLaunchKernelGGL(ts_interstitial_evaluate, dim3(1024), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, seg_base,
+    hipLaunchKernelGGL(ts_interstitial_evaluate<0>, dim3(1024), dim3(kSideWg), 0, (hipStream_t)stream, *Q, segs, seg_base,
                        (const u64 *)bounds);
     return (int)hipGetLastError();
 }

@@ -1565,13 +1565,14 @@ void parallel_for(size_t n, unsigned max_threads, F &&f) {
 int ts_device_block_call_raw(ts_ctx *c, const TsTile *d_tiles, const unsigned long long *d_tile_off, const uint32_t *d_stats,
                              const uint32_t *d_matches, uint64_t n_matches_hint, const std::vector<TsShardSegIn> &tab, size_t nt,
                              bool tips, unsigned long long gen_lens, const uint32_t *d_chain, uint32_t *d_work, hipStream_t st,
-                             std::vector<TsDevBlock> &blocks, std::vector<unsigned long long> *sums_out, int rec16) {
+                             std::vector<TsDevBlock> &blocks, std::vector<unsigned long long> *sums_out, int rec16,
+                             const uint32_t *d_wide_len, bool unordered) {
     const ts_params &P = c->params;
     const size_t ns = tab.size();
     blocks.clear();
     if (sums_out) sums_out->assign(ns * 5, 0ull);
     if (!ns) return TS_OK;
-    const size_t off_bounds = ns * sizeof(TsShardSegIn), off_count = off_bounds + ns * 16, off_sums = off_count + 16, tab_bytes = off_sums + ns * 40;
+    const size_t off_bounds = ns * sizeof(TsShardSegIn), off_count = off_bounds + ns * 16, off_sums = off_count + 16, off_range = off_sums + ns * 40, tab_bytes = off_range + ns * 16;
     DevBuf d_tab, d_blocks;
     struct Return { ts_ctx *c; DevBuf &a, &b2; ~Return() { c->pool.give(std::move(a)); c->pool.give(std::move(b2)); } } give_back{c, d_tab, d_blocks};
     HIP_TRY(c, c->pool.take(tab_bytes, d_tab));
@@ -1602,6 +1603,9 @@ int ts_device_block_call_raw(ts_ctx *c, const TsTile *d_tiles, const unsigned lo
         Q.k = c->k; Q.its_min_len = (uint32_t)(uint16_t)(2 * c->bp.first_pattern_len);
         Q.gen_lens = gen_lens;
         Q.rec16 = rec16 ? 1u : 0u;
+        // (the general path's wide records and push-ordered streams: blockcall.hip, MODE 1)
+        Q.wide = d_wide_len ? 1u : 0u; Q.wide_len = d_wide_len;
+        Q.unordered = unordered ? 1u : 0u; Q.its_range = (unsigned long long *)(dt + off_range);
         if (ts_k_launch_block_call(&Q, (const TsShardSegIn *)dt, (uint32_t)ns, 0u, (uint32_t)nt, (unsigned long long *)(dt + off_bounds),
                                    nullptr, tips ? 0 : 1, nullptr, (unsigned long long *)(dt + off_sums), d_chain, d_work, st) != 0)
             return c->fail(TS_ERR_HIP, "block-calling kernel launch failed");
@@ -1623,7 +1627,13 @@ int ts_device_block_call_raw(ts_ctx *c, const TsTile *d_tiles, const unsigned lo
         if (x.seg != y.seg) return x.seg < y.seg;
         const uint32_t kx = x.kind == 2 ? 1 : 0, ky = y.kind == 2 ? 1 : 0;
         if (kx != ky) return kx < ky;
-        if (kx) return x.start < y.start;
+        if (kx) {
+            // interstitial blocks: in the order the reference's walk emits them — ascending start over a stream in position order; the
+            // general path's other streams carry the stream index of the chain's first record (blockcall.hip, MODE 1)
+            const unsigned long long ox = ((unsigned long long)x.pad << 32) | x.seq, oy = ((unsigned long long)y.pad << 32) | y.seq;
+            if (ox != oy) return ox < oy;
+            return x.start < y.start;
+        }
         return x.kind != y.kind ? x.kind < y.kind : x.seq < y.seq;
     });
     return TS_OK;

@@ -305,7 +305,8 @@ int  ts_batch_ensure_device(ts_batch *b);        // allocates the range's device
 int  ts_device_block_call_raw(ts_ctx *c, const TsTile *d_tiles, const unsigned long long *d_tile_off, const uint32_t *d_stats,
                               const uint32_t *d_matches, uint64_t n_matches_hint, const std::vector<TsShardSegIn> &tab, size_t nt,
                               bool tips, unsigned long long gen_lens, const uint32_t *d_chain, uint32_t *d_work, hipStream_t st,
-                              std::vector<TsDevBlock> &blocks, std::vector<unsigned long long> *sums_out, int rec16 = 0);
+                              std::vector<TsDevBlock> &blocks, std::vector<unsigned long long> *sums_out, int rec16 = 0,
+                              const uint32_t *d_wide_len = nullptr, bool unordered = false);
 void ts_batch_release_input(ts_batch *b);        // returns the batch's input buffer to the context's pool
 void *ts_batch_input_ptr_nozero(ts_batch *b);
 struct ts_fetched;                               // what a download left in host memory, before post-processing

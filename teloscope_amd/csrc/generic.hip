@@ -1091,6 +1091,131 @@ void ts_general_compact(const uint32_t *tile_stats, const u64 *tile_off, const u
     for (uint32_t i = lane; i < n; i += 64u) dst[i] = src[i];
 }
 
+
+// ---- the dense stream in the reference's PUSH order (mixed-length sets under w > s)
+//
+// scanSegment pushes a match from the first window that holds its END (src/teloscope.cpp:485-509: ascending window, then
+// ascending position, then ascending length), so with patterns of different lengths and overlapping windows allMatches is
+// not quite in position order: a long match that straddles a window's end is pushed by the NEXT window, behind shorter
+// matches that begin after it — and getTerminalBlocks / getInterstitialBlocks walk the stream as it lies
+// (:29-256; a position that steps back breaks the chain: the unsigned gap wraps).  The pushing window of a match that ends
+// at e is key(e) = e < w - s ? 0 : (e - (w - s)) / s for a segment of at least w bases (one window, key 0, otherwise): monotone in e.
+// Push order = the position-ordered stream stably sorted by key, and two records can only be out of order when they start
+// fewer than (longest - shortest) bases apart.  So every record finds its place by itself: its index in position order, plus
+// the records behind it with a smaller key, minus the records ahead of it with a larger one — a look at the few neighbours
+// that start within `spread` bases, and only for records that end within `spread` bases of a window's end.  Neighbours may lie
+// in the tile before or behind (the slots are read, nothing of this kernel's output).
+//
+// The stream stays tile-structured: a record of tile t that has to come before a record of tile t - 1 (its key is smaller
+// than the largest key of tile t - 1) MOVES into tile t - 1 — the tile's offset grows by the number that moved, the record's
+// tile-relative position by the positions of tile t - 1 — so that every reader of {tile_off, records} (blockcall.hip, the
+// host's expansion) walks the reference's sequence by walking the tiles.  The per-tile counts are recomputed from the offsets
+// (ts_general_block_inputs).
+struct PushOrder {
+    uint32_t w, s, spread, shift, li_mask;
+    u64 gen_lens;                        // up to eight lengths, six bits each (the list / strided forms' records); 0: wide_len
+    const uint32_t *wide_len;            // the wide form's lengths (device)
+};
+
+__device__ __forceinline__ uint32_t push_len(const PushOrder &O, uint32_t rec) {
+    const uint32_t li = (rec >> 2) & O.li_mask;
+    return O.gen_lens ? (uint32_t)(O.gen_lens >> (6u * li)) & 63u : O.wide_len[li];
+}
+
+__global__ __launch_bounds__(256)
+void ts_general_compact_push(const TsGeneralTile *gtiles, const uint32_t *tile_stats, u64 *tile_off, const uint32_t *records,
+                             uint32_t slot_cap, uint32_t ntiles, const u64 *seg_len, const PushOrder O, uint32_t *dense) {
+    const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (t >= ntiles) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const TsGeneralTile G = gtiles[t];
+    const uint32_t n = tile_stats[4ull * t];
+    const u64 off = tile_off[t];
+    const uint32_t *const src = records + (u64)t * slot_cap;
+    const bool has_prev = t > 0u && gtiles[t - 1u].seg == G.seg, has_next = t + 1u < ntiles && gtiles[t + 1u].seg == G.seg;
+    const uint32_t n_prev = has_prev ? tile_stats[4ull * (t - 1u)] : 0u, n_next = has_next ? tile_stats[4ull * (t + 1u)] : 0u;
+    const u64 prev_rel = has_prev ? gtiles[t - 1u].seg_rel : G.seg_rel, next_rel = has_next ? gtiles[t + 1u].seg_rel : 0ull;
+    const uint32_t prev_positions = (uint32_t)(G.seg_rel - prev_rel);
+    const uint32_t *const srcp = src - slot_cap, *const srcn = src + slot_cap;
+    const u64 ov = O.w - O.s;
+    const bool one_window = seg_len[G.seg] < O.w;              // every key is 0: position order is push order
+    // keys without a 64-bit division per record: everything this wave looks at ends at or behind X0
+    const u64 X0 = prev_rel;
+    const bool fast = X0 >= ov && O.s <= 0x7FFFFFFFu;
+    const u64 q0 = fast ? (X0 - ov) / O.s : 0ull;
+    const uint32_t r0 = fast ? (uint32_t)((X0 - ov) - q0 * O.s) : 0u;
+    auto key = [&](u64 e) -> u64 {
+        if (one_window) return 0ull;
+        if (fast) return q0 + (r0 + (uint32_t)(e - X0)) / O.s;     // (e - X0 < 3 tiles: no overflow beside r0 < s < 2^31)
+        return e < ov ? 0ull : (e - ov) / O.s;
+    };
+    // the largest key of the tile before: that of the record that ends last, one of those that start within `spread`
+    // bases of its last record
+    u64 kmax_prev = 0;
+    if (n_prev && !one_window) {
+        const u64 p_last = prev_rel + (srcp[n_prev - 1u] >> O.shift);
+        bool more = true;
+        for (uint32_t b0 = 0; b0 < n_prev && more; b0 += 64u) {
+            u64 k = 0;
+            bool in = false;
+            if (b0 + lane < n_prev) {
+                const uint32_t r = srcp[n_prev - 1u - b0 - lane];
+                const u64 p = prev_rel + (r >> O.shift);
+                in = p + O.spread >= p_last;
+                if (in) k = key(p + push_len(O, r) - 1u);
+            }
+            for (int sh = 1; sh < 64; sh <<= 1) {                  // wave maximum (rare path: a plain shuffle tree)
+                const u64 o = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), sh) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)k, sh);
+                k = o > k ? o : k;
+            }
+            kmax_prev = k > kmax_prev ? k : kmax_prev;
+            more = __ballot(b0 + lane < n_prev && !in) == 0ull;    // all 64 were in reach: the batch before them may be too
+        }
+    }
+    uint32_t moved_total = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < n;
+        uint32_t rec = valid ? src[i] : 0u;
+        const u64 p = G.seg_rel + (rec >> O.shift);
+        const u64 e = p + push_len(O, rec) - 1u;
+        const u64 k0 = key(e);
+        int disp = 0;
+        if (valid && !one_window) {
+            // records behind this one with a smaller key: only if a window ends in (e - spread, e]
+            if (e >= O.spread && key(e - O.spread) != k0) {
+                for (uint32_t d = 1;; ++d) {
+                    const uint32_t j = i + d;
+                    uint32_t rj; u64 base;
+                    if (j < n) { rj = src[j]; base = G.seg_rel; }
+                    else if (j - n < n_next) { rj = srcn[j - n]; base = next_rel; }
+                    else break;
+                    const u64 pj = base + (rj >> O.shift);
+                    if (pj - p >= O.spread) break;
+                    if (key(pj + push_len(O, rj) - 1u) < k0) ++disp;
+                }
+            }
+            // records ahead of it with a larger key: only if a window ends in (e, e + spread]
+            if (key(e + O.spread) != k0) {
+                for (uint32_t d = 1;; ++d) {
+                    uint32_t rj; u64 base;
+                    if (d <= i) { rj = src[i - d]; base = G.seg_rel; }
+                    else if (d - i <= n_prev) { rj = srcp[n_prev - (d - i)]; base = prev_rel; }
+                    else break;
+                    const u64 pj = base + (rj >> O.shift);
+                    if (p - pj >= O.spread) break;
+                    if (key(pj + push_len(O, rj) - 1u) > k0) --disp;
+                }
+            }
+        }
+        const bool moved = valid && has_prev && k0 < kmax_prev;
+        if (moved) rec += prev_positions << O.shift;
+        if (valid) dense[off + i + (long long)disp] = rec;
+        moved_total += (uint32_t)__popcll(__ballot(moved));
+    }
+    if (lane == 0u) tile_off[t] = off + moved_total;
+}
+
 }  // namespace
 
 unsigned long long ts_k_general_lds_bytes(const TsGenericPatterns *G, uint32_t *lds_patterns) {
@@ -1149,8 +1274,10 @@ void ts_general_block_inputs(const TsGeneralTile *gtiles, const u64 *tile_off, c
     if (t >= ntiles) return;
     const uint32_t lane = threadIdx.x;
     const TsGeneralTile G = gtiles[t];
-    const uint32_t n = tile_stats[4ull * t];
-    const uint32_t *src = dense + tile_off[t];
+    // (the count from the offsets: the push-ordered stream moved a few records across tile borders; tile_off has ntiles + 1 entries)
+    const u64 o0 = tile_off[t];
+    const uint32_t n = (uint32_t)(tile_off[t + 1u] - o0);
+    const uint32_t *src = dense + o0;
     uint32_t ncan = 0, nfwd = 0;
     for (uint32_t i = lane; i < n; i += 64u) {
         const uint32_t r = src[i];
@@ -1158,6 +1285,7 @@ void ts_general_block_inputs(const TsGeneralTile *gtiles, const u64 *tile_off, c
     }
     ncan = wave_total(ncan); nfwd = wave_total(nfwd);
     if (lane == 0u) {
+        tile_stats[4ull * t] = n;
         tile_stats[4ull * t + 1u] = ncan;
         tile_stats[4ull * t + 2u] = nfwd;
         TsTile T{};
@@ -1181,6 +1309,17 @@ int ts_k_launch_general_compact(const uint32_t *tile_stats, const unsigned long 
     if (ntiles == 0) return 0;
     hipLaunchKernelGGL(ts_general_compact, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, tile_stats,
                        (const u64 *)tile_off, records, slot_cap, ntiles, dense);
+    return (int)hipGetLastError();
+}
+
+int ts_k_launch_general_compact_push(const TsGeneralTile *gtiles, const uint32_t *tile_stats, unsigned long long *tile_off,
+                                     const uint32_t *records, uint32_t slot_cap, uint32_t ntiles, const unsigned long long *seg_len,
+                                     uint32_t w, uint32_t s, uint32_t spread, int wide, unsigned long long gen_lens,
+                                     const uint32_t *wide_len, uint32_t *dense, void *stream) {
+    if (ntiles == 0) return 0;
+    PushOrder O{w, s, spread, wide ? 8u : 5u, wide ? 63u : 7u, wide ? 0ull : gen_lens, wide_len};
+    hipLaunchKernelGGL(ts_general_compact_push, dim3((ntiles + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, gtiles, tile_stats,
+                       (u64 *)tile_off, records, slot_cap, ntiles, (const u64 *)seg_len, O, dense);
     return (int)hipGetLastError();
 }
 

@@ -994,22 +994,26 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     struct GroupHost { std::vector<SegL> G; std::vector<TsGeneralTile> tiles; std::vector<unsigned long long> tile_off;
                        std::vector<uint32_t> recs_heap, wins_heap; const uint32_t *recs = nullptr, *wins = nullptr;
                        bool dev_blocks = false; std::vector<TsDevBlock> blocks; std::vector<unsigned long long> sums; };
-    // Block calling on the device (blockcall.hip with the general record format) wherever the match stream is in the order
-    // the reference calls blocks over: tips-only scans and w == s always (position order), w > s when the pattern lengths
-    // differ by at most one (the record that ends later is never pushed earlier: end positions are monotone in stream
-    // order, hence so is the pushing window).  Sets with a length gap of two or more under w > s keep the host path: the
-    // reference's lower_bound runs over a stream that is not quite sorted there, and that is restated on the
-    // host only.  TS_GEN_HOST_BLOCKS=1 forces the host path (A/B, tests).
-    const bool dev_blocks_ok = !c->knobs.gen_host_blocks && c->gpat.nlen >= 1 &&
-                               (tips || ov == 0 || c->gpat.len[c->gpat.nlen - 1] - c->gpat.len[0] <= 1u);
-    // is the stream in the reference's push order whatever the input?  (position order IS push order then)
+    // Block calling on the device (blockcall.hip with the general record formats).  The reference calls blocks over allMatches
+    // as pushed (src/teloscope.cpp:485-509, :642-657): position order for tips-only scans, for w == s, and under w > s when the
+    // pattern lengths differ by at most one (the record that ends later is never pushed earlier: end positions are monotone
+    // in stream order, hence so is the pushing window).  Sets with a length gap of two or more under w > s are pushed not
+    // quite in position order: for those the compaction writes the dense stream IN PUSH ORDER
+    // (ts_general_compact_push) and block calling walks it as the reference does (blockcall.hip, MODE 1: the predecessor as
+    // the stream lies, the search range by stream index from a bisection restated probe by probe).  The host's expansion
+    // of such a stream needs no ordering pass either.  TS_GEN_HOST_BLOCKS=1 forces the round-4 route — position-ordered
+    // stream, ordering and block calling on the host — for A/B and tests.
     const uint32_t len_spread = c->gen_wide ? (c->wide_lens.empty() ? 0u : c->wide_lens.back() - c->wide_lens.front())
                                             : (c->gpat.nlen ? c->gpat.len[c->gpat.nlen - 1] - c->gpat.len[0] : 0u);
-    const bool known_order = tips || ov == 0 || len_spread <= 1u;
+    const bool position_order = tips || ov == 0 || len_spread <= 1u;      // position order IS push order
     unsigned long long gen_lens = 0;
     for (uint32_t li = 0; li < c->gpat.nlen && li < 8u; ++li) gen_lens |= (unsigned long long)(c->gpat.len[li] & 63u) << (6u * li);
     if (c->gpat.nlen && c->gpat.len[c->gpat.nlen - 1] > 63u) gen_lens = 0;
-    const bool skip_records = blocks_only && dev_blocks_ok && gen_lens != 0;
+    if (c->gen_wide) gen_lens = 1ull;                                      // (wide records: the lengths come from wpat.len; non-zero = "general format")
+    const bool dev_blocks_ok = !c->knobs.gen_host_blocks && gen_lens != 0 && (c->gen_wide ? c->wpat.nlen >= 1 : c->gpat.nlen >= 1);
+    const bool push_compact = dev_blocks_ok && !position_order;           // the device orders the stream
+    const bool known_order = position_order || push_compact;               // what the host stage receives is in push order
+    const bool skip_records = blocks_only && dev_blocks_ok;
     size_t group_no = 0;
     std::thread host_job;
     std::atomic<int> host_err{TS_OK};
@@ -1196,12 +1200,20 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         {
             std::lock_guard<std::mutex> lk(c->mtx);
             if (timing) HIP_TRY(c, hipEventRecord(c->gen_ev[0], st));
+            if (push_compact) {
+                if (ts_k_launch_general_compact_push((const TsGeneralTile *)d_tiles.p, (const uint32_t *)d_stats.p, (unsigned long long *)d_off.p,
+                                                     (const uint32_t *)d_slots.p, slot_cap, (uint32_t)nt, (const unsigned long long *)(dt + tab_len),
+                                                     w, s, len_spread, wide ? 1 : 0, gen_lens, wide ? c->wpat.len : nullptr, (uint32_t *)d_rec.p, st) != 0)
+                    return c->fail(TS_ERR_HIP, "general push-order compact kernel launch failed");
+                // (records moved across tile borders: the host stage reads the offsets as they are now)
+                if (!skip_records) HIP_TRY(c, hipMemcpyAsync(tile_off.data(), d_off.p, (nt + 1) * 8, hipMemcpyDeviceToHost, st));
+            } else
             if (ts_k_launch_general_compact((const uint32_t *)d_stats.p, (const unsigned long long *)d_off.p, (const uint32_t *)d_slots.p,
                                             slot_cap, (uint32_t)nt, (uint32_t *)d_rec.p, st) != 0)
                 return c->fail(TS_ERR_HIP, "general compact kernel launch failed");
             if (timing) HIP_TRY(c, hipEventRecord(c->gen_ev[1], st));
         }
-        if (dev_blocks_ok && gen_lens != 0) {
+        if (dev_blocks_ok) {
             // ---- blocks on the device: the tiles as blockcall.hip addresses them, the canonical / forward counts, then the walks
             DevBuf d_bct, d_sbase;
             struct Ret2 { ts_ctx *c; DevBuf &a, &b2; ~Ret2() { c->pool.give(std::move(a)); c->pool.give(std::move(b2)); } } give2{c, d_bct, d_sbase};
@@ -1225,7 +1237,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                                                  (const unsigned long long *)d_sbase.p, (uint32_t)nt, (TsTile *)d_bct.p, (uint32_t *)d_stats.p, st) != 0)
                 return c->fail(TS_ERR_HIP, "general block-input kernel launch failed");
             int rc = ts_device_block_call_raw(c, (const TsTile *)d_bct.p, (const unsigned long long *)d_off.p, (const uint32_t *)d_stats.p,
-                                              (const uint32_t *)d_rec.p, nrec, segtab, nt, tips, gen_lens, nullptr, nullptr, st, gh->blocks, &gh->sums);
+                                              (const uint32_t *)d_rec.p, nrec, segtab, nt, tips, gen_lens, nullptr, nullptr, st, gh->blocks, &gh->sums, 0,
+                                              wide ? c->wpat.len : nullptr, push_compact);
             if (rc != TS_OK) return rc;
             gh->dev_blocks = true;
         }
@@ -1422,6 +1435,9 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     if (timing)
         fprintf(stderr, "general path: device stage: buffers %.1f ms, fused pass + tile offsets (synced) %.1f ms, compaction + block calling %.1f ms, D2H %.1f ms, waiting for the next group's upload %.1f ms (fused stage: enqueue %.1f, copies enqueue %.1f, sync %.1f)\n",
                 t_take, t_fused, t_blk, t_d2h, t_wait_next, t_dbg[0], t_dbg[1], t_dbg[2]);
+    if (timing)
+        fprintf(stderr, "general path: route: %s form, blocks called on the %s, stream %s\n", wide ? "wide" : "table",
+                dev_blocks_ok ? "device" : "host", position_order ? "in position order" : push_compact ? "written in push order by the device" : "ordered on the host");
     if (timing)
         fprintf(stderr, "general path: %zu segments, wall %.1f ms: upload %.1f ms, kernels + D2H %.1f ms (kernels alone, HIP events: %.2f ms), host ordering + block calling %.1f ms (on a thread of its own, one group behind; job time: expansion %.1f ms, windows + block calling %.1f ms)\n",
                 which.size(), ms_between(t_begin, Clock::now()), t_up, t_dev, (double)t_kern, t_host, ts_gen_ns[0].exchange(0) / 1e6, ts_gen_ns[1].exchange(0) / 1e6);

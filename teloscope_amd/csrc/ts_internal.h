@@ -149,6 +149,11 @@ struct TsBlockCallParams {
     unsigned long long gen_lens;        // 0: the tiled kernel's records (position << 2 | forward << 1 | canonical, length k);
                                         // else the general kernels' (position << 5 | length index << 2 | canonical << 1 | forward)
                                         // and the up to eight pattern lengths, six bits each, length index i at bits 6i..
+    // the general path's other cases (blockcall.hip, MODE 1)
+    uint32_t wide;                      // records of the wide form: position << 8 | length index (six bits) << 2 | canonical << 1 | forward
+    uint32_t unordered;                 // the stream lies in the reference's PUSH order (generic.hip: ts_general_compact_push), not in position order
+    const uint32_t *wide_len;           // wide: the lengths by index (device)
+    unsigned long long *its_range;      // unordered: per segment {first, end} stream indices of the interstitial search (ts_its_range writes, the search reads)
 };
 
 // ---- shard results (shard.hip, shard.cpp): what one device contributes to a scan that several devices share ----
@@ -322,6 +327,10 @@ int  ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tile
 // segment-relative position; canonical / forward counts into words 1, 2 of the tile directory)
 int  ts_k_launch_general_block_inputs(const TsGeneralTile *gtiles, const unsigned long long *tile_off, const uint32_t *dense,
                                       const unsigned long long *seg_base, uint32_t ntiles, TsTile *tiles, uint32_t *tile_stats, void *stream);
+int  ts_k_launch_general_compact_push(const TsGeneralTile *gtiles, const uint32_t *tile_stats, unsigned long long *tile_off,
+                                      const uint32_t *records, uint32_t slot_cap, uint32_t ntiles, const unsigned long long *seg_len,
+                                      uint32_t w, uint32_t s, uint32_t spread, int wide, unsigned long long gen_lens,
+                                      const uint32_t *wide_len, uint32_t *dense, void *stream);
 int  ts_k_launch_general_compact(const uint32_t *tile_stats, const unsigned long long *tile_off, const uint32_t *records,
                                  uint32_t slot_cap, uint32_t ntiles, uint32_t *dense, void *stream);
 int  ts_k_launch_predicate(const TsTile *tiles, const unsigned long long *tile_off, const uint32_t *tile_stats,

@@ -664,6 +664,72 @@ def test_general_path_block_calling_matches_oracle(cli, host_blocks, monkeypatch
     test_device_block_calling_matches_oracle(cli)
 
 
+# Streams that are NOT in position order: pattern lengths two or more apart under w > s — a long match across a window's end
+# is pushed by the next window, behind shorter matches that begin after it (src/teloscope.cpp:485-509) — and the reference
+# walks the stream as it lies.  The device writes the dense stream in push order (generic.hip: ts_general_compact_push) and
+# calls blocks over it (blockcall.hip, MODE 1).  Nested telomeric patterns make every array a run of inversions at every
+# window end; small steps (below the length spread) put several window ends into one inversion zone; wide sets take the
+# wide form's records.
+PUSH_ORDER_GRID = [
+    "-p TTAGGG,TTAGGGTTAGGG,TTAGGGTTAGGGTTAGGG -x 0 -w 1000 -s 500 -r -g -i",
+    "-p TTAGGG,TTAGGGTTAGGG,TTAGGGTTAGGGTTAGGG -x 0 -w 100 -s 7 -r -g -i -k 12",
+    "-p TTAGGG,TTAGGGTT,TTAGGGTTAGGGT -x 0 -w 200 -s 100 -g -i -k 5 -d 40 -l 30",
+    "-p TTAGGG,TTAGGGTTAGGGTTAGGGTTAGGGTTAGGG -x 0 -w 64 -s 3 -g -i",
+    "-c TTAGGG -p TTAGGG,TTAGGGTTAGGGTTA -x 1 -w 512 -s 256 -r -g -e -i -t 3000",
+    "-x 0 -p " + ",".join(("TTAGGG" * 7)[:k] for k in range(4, 21)) + " -w 1000 -s 500 -g -r -i",     # wide: 17 lengths
+    "-x 0 -p " + ",".join(("TTAGGG" * 11)[:k] for k in (6, 9, 12, 15, 18, 24, 30, 36, 48, 63)) + " -w 300 -s 20 -g -i",   # wide, step < spread
+]
+
+
+@pytest.mark.parametrize("host_blocks", [False, True])
+@pytest.mark.parametrize("cli", PUSH_ORDER_GRID)
+def test_push_ordered_streams_blocks_match_oracle(cli, host_blocks, monkeypatch):
+    if host_blocks:
+        monkeypatch.setenv("TS_GEN_HOST_BLOCKS", "1")
+    test_device_block_calling_matches_oracle(cli)
+
+
+def test_push_ordered_sets_take_the_device_route(monkeypatch, capfd):
+    """No parameter set is sent to the host's block calling any more unless TS_GEN_HOST_BLOCKS=1 asks for it (the library says
+    which route a general-path call took under TS_TIMING=1)."""
+    monkeypatch.setenv("TS_TIMING", "1")
+    for cli, host in ((PUSH_ORDER_GRID[0], False), (PUSH_ORDER_GRID[5], False), (WIDE_GRID[3], False), (PUSH_ORDER_GRID[0], True)):
+        if host:
+            monkeypatch.setenv("TS_GEN_HOST_BLOCKS", "1")
+        opts = H.parse_cli("x.fa " + cli)
+        prod = ProductBackend(opts)
+        rng = np.random.default_rng(3)
+        s = seqgen.chromosome(rng, 30000, opts.canonical_fwd, opts.canonical_rev, telo_repeats=200, n_its=2)
+        capfd.readouterr()
+        prod.teloscope.scanSegmentsBlocksOnly([(s, 0)], tipsOnly=False, with_counts=True)
+        err = capfd.readouterr().err
+        assert ("blocks called on the host" in err) == host and ("blocks called on the device" in err) != host, err
+        if not host and cli in PUSH_ORDER_GRID:
+            assert "written in push order by the device" in err, err
+
+
+@pytest.mark.parametrize("cli", PUSH_ORDER_GRID)
+def test_push_ordered_streams_match_vectors_match_oracle(cli):
+    """The same sets with the match vectors downloaded: allMatches, fwdMatches, ... in the reference's push order, straight
+    from the device's stream (the host no longer orders anything), on segments whose arrays cross window ends and tile borders."""
+    opts = H.parse_cli("x.fa " + cli)
+    prod, orac = ProductBackend(opts), OracleBackend(opts)
+    if orac.ambiguous:
+        orac = orac.with_ambiguous_orientation_from(prod.patterns)
+    rng = np.random.default_rng(len(cli) * 7 + 1)
+    segs = []
+    for i, n in enumerate([5, 70, 999, 4095, 4096, 4097, 4200, 8192, 12290, 40000, 131072 + 17]):
+        s = bytearray(seqgen.chromosome(rng, n, opts.canonical_fwd, opts.canonical_rev,
+                                        telo_repeats=min(300, max(1, n // 30)), tvr_rate=0.02, n_its=4, iupac=0))
+        for at in (4096, 8192, 12288, 36864):                 # arrays across tile borders (4096 positions per tile)
+            if n > at + 200:
+                s[at - 150:at + 150] = (b"TTAGGG" * 50)[:300]
+        segs.append((bytes(s), int(rng.integers(0, 10 ** 6)), False))
+    got = prod.scan_segments(segs)
+    for (s, ap, tips), g in zip(segs, got):
+        assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="cli=%r len=%d" % (cli, len(s)))
+
+
 @pytest.mark.parametrize("cli", BLOCKCALL_GRID)
 def test_device_block_calling_matches_oracle(cli):
     """getTerminalBlocks / getInterstitialBlocks on the device (ts_batch_download_blocks): blocks
