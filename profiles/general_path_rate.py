@@ -23,6 +23,8 @@ out = {}
 for name, flags in (("mixed_5_6", "-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i"),
                     ("k14", "-c TTTAGGGTTTAGGG -x 1 -w 1000 -s 500 -r -g -e -m -i"),
                     ("wrapped_start_index", "-w 1000 -s 997 -r -g -e -m -i"),
+                    # lengths 6 and 14 under w > s: a stream that is not in position order (written in push order by the device)
+                    ("mixed_6_14", "-p TTAGGG,TTTAGGGTTTAGGG -x 0 -w 1000 -s 500 -r -g -e -m -i"),
                     # nine distinct lengths: beyond the table forms, the wide form (ts_general_wide)
                     ("wide_9_lengths", "-x 0 -p TTAG,TTAGG,TTAGGG,TTTAGGG,TTTTAGGG,TTAGGGTTA,TTAGGGTTAG,TTAGGGTTAGG,TTAGGGTTAGGG -w 1000 -s 500 -r -g -e -m -i")):
     if os.environ.get("TS_GEN_ONLY") and os.environ["TS_GEN_ONLY"] != name:

@@ -844,17 +844,24 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
 //   * per position three u64 masks in LDS — matched lengths, which of them are forward, which canonical — instead of three bits
 //     per length in one dword;
 //   * a halo of 64 bases, and records that carry six bits of length index: position << 8 | index << 2 | canonical << 1 | forward.
-// One workgroup per CU (130 KB of LDS): a correct path for rare parameter sets, not a fast one.
+// Persistent workgroups (round 5: the tables are built once per workgroup, not once per tile): three / two / one per CU by the
+// width of the masks (42 / 66 / 132 KB of LDS).
 constexpr uint32_t kWideCodeWords = (kTile + TS_WIDE_HALO) / 16u + 6u;     // 2-bit plane, dwords (five are read per position)
 constexpr uint32_t kWideInvalWords = (kTile + TS_WIDE_HALO) / 32u + 4u;    // validity plane (three are read per position)
+constexpr uint32_t kWideCumWords = 260;                                     // per-dword nucleotide prefix sums (256 + the end sentinel)
 
 struct WideAcc { uint32_t nuc, can, non, fwd, rev; };
 
-// window_tile_part for the wide form's masks
-template <typename M>
-__device__ __forceinline__ void window_tile_part_wide(const uint32_t *codes2, const uint32_t *inval, const M *hit, const M *fwdm, const M *canm,
+// The part of window call kw that lies in a tile, for the wide form: covered bases of its matches into `a` (per lane, summed by
+// the caller), the nucleotide counts of the part as a wave-uniform pair {A | T << 16, C | G << 16} added to nAT / nCG.
+// Round 5: the positions that hold a match come from a bitmap of the tile (a lane takes 32 positions and visits the set bits:
+// one position in eighty holds a match on random sequence), and the nucleotide counts are two lookups in per-dword prefix sums —
+// the round-4 loop visited every position of every window part, three to four times per base, and was half the kernel.
+template <typename M, typename PC>
+__device__ __forceinline__ void window_tile_part_wide(const uint32_t *hitmap, const M *hit, const M *fwdm, const M *canm,
                                                       const uint32_t *lens, const TsGenericGeom &Q, u64 n, u64 kw, bool carry,
-                                                      u64 P0, uint32_t ntile, uint32_t lane, WideAcc &a) {
+                                                      u64 P0, uint32_t ntile, uint32_t lane, WideAcc &a, PC prefix_counts,
+                                                      uint32_t &nAT, uint32_t &nCG) {
     const u64 wstart = kw * Q.s;
     const uint32_t cws = (uint32_t)((n - wstart) < Q.w ? (n - wstart) : Q.w);
     const uint32_t ov = Q.w - Q.s;
@@ -866,25 +873,45 @@ __device__ __forceinline__ void window_tile_part_wide(const uint32_t *codes2, co
     const u64 lo = wstart + start_index, hi = wstart + cws;
     const uint32_t qlo = lo > P0 ? (uint32_t)(lo - P0 < ntile ? lo - P0 : ntile) : 0u;
     const uint32_t qhi = hi > P0 ? (uint32_t)(hi - P0 < ntile ? hi - P0 : ntile) : 0u;
+    if (qlo >= qhi) return;
     const uint32_t ioff = (uint32_t)(P0 - wstart);
     const bool all_nuc = carry || always_main;
-    for (uint32_t q = qlo + lane; q < qhi; q += 64u) {
-        const uint32_t i = q + ioff;
-        if (Q.nuc_on) {
-            if (plane_invalid(inval, q)) continue;
-            if (all_nuc || i >= ov) a.nuc += 1u << (8u * plane_code(codes2, q));
+    if (Q.nuc_on) {
+        // valid bases at window indices i >= ov (all of the part for a carry or a first window): tile positions [nlo, qhi)
+        uint32_t nlo = qlo;
+        if (!all_nuc) {
+            const long long b = (long long)ov + (long long)wstart - (long long)P0;      // i >= ov  <=>  q >= b
+            if (b > (long long)qlo) nlo = b >= (long long)qhi ? qhi : (uint32_t)b;
         }
-        u64 m = hit[q];
-        if (!m) continue;
-        const u64 f = fwdm[q], c = canm[q];
-        for (; m; m &= m - 1ull) {
-            const uint32_t li = (uint32_t)__builtin_ctzll(m);
-            const uint32_t l = lens[li];
-            const uint32_t j = i + l - 1u;
-            if (j >= cws) continue;                                 // scanLimit: may not cross the window end
-            if (!carry && !(always_main || j >= ov)) continue;
-            if ((c >> li) & 1ull) a.can += l; else a.non += l;
-            if ((f >> li) & 1ull) a.fwd += l; else a.rev += l;
+        if (nlo < qhi) {
+            uint32_t vg1, ct1, vg0, ct0;
+            prefix_counts(qhi, vg1, ct1);
+            prefix_counts(nlo, vg0, ct0);
+            const uint32_t vg = vg1 - vg0, ct = ct1 - ct0;               // {valid | G << 16}, {C | T << 16}: fields never borrow
+            const uint32_t G_ = vg >> 16, C_ = ct & 0xFFFFu, T_ = ct >> 16, A_ = (vg & 0xFFFFu) - G_ - C_ - T_;
+            nAT += A_ | (T_ << 16);
+            nCG += C_ | (G_ << 16);
+        }
+    }
+    for (uint32_t wd = (qlo >> 5) + lane; wd <= ((qhi - 1u) >> 5); wd += 64u) {
+        uint32_t bits = hitmap[wd];
+        const uint32_t q0 = wd << 5;
+        if (q0 < qlo) bits &= ~0u << (qlo - q0);
+        if (q0 + 32u > qhi) bits &= ~0u >> (q0 + 32u - qhi);
+        for (; bits; bits &= bits - 1u) {
+            const uint32_t q = q0 + (uint32_t)__builtin_ctz(bits);
+            const uint32_t i = q + ioff;
+            u64 m = hit[q];
+            const u64 f = fwdm[q], c = canm[q];
+            for (; m; m &= m - 1ull) {
+                const uint32_t li = (uint32_t)__builtin_ctzll(m);
+                const uint32_t l = lens[li];
+                const uint32_t j = i + l - 1u;
+                if (j >= cws) continue;                                 // scanLimit: may not cross the window end
+                if (!carry && !(always_main || j >= ov)) continue;
+                if ((c >> li) & 1ull) a.can += l; else a.non += l;
+                if ((f >> li) & 1ull) a.fwd += l; else a.rev += l;
+            }
         }
     }
 }
@@ -898,8 +925,9 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
                      uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
     extern __shared__ __align__(16) unsigned char lds[];
     // layout: hit M[kTile] | fwd M[kTile] | can M[kTile] | pre6 P[4096] | plo u64[lds_pat] | phi u64[lds_pat] | lens u32[64] | first u32[68] |
-    //         part u32[8] | codes2 | inval | pfl u8[lds_pat]      (lds_pat: the pattern lists in LDS when they fit — a search step is then an
-    //         LDS read; out of device memory the searches of the few lanes that hold a candidate were 80 % of the kernel's time)
+    //         part u32[8] | wtot u32[8] | wbase u32[16] | hitmap u32[128] | cumVG u32[260] | cumCT u32[260] | codes2 | inval | valid2 | lists u16[4][1024] | pfl u8[lds_pat]
+    //         (lds_pat: the pattern lists in LDS when they fit — a search step is then an LDS read; out of device memory the searches of the
+    //         few lanes that hold a candidate were 80 % of the kernel's time)
     M *hit = (M *)lds;
     M *fwdm = hit + kTile;
     M *canm = fwdm + kTile;
@@ -909,9 +937,16 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
     uint32_t *lens = (uint32_t *)(phi + lds_pat);
     uint32_t *first = lens + 64;
     uint32_t *part = first + 68;
-    uint32_t *codes2 = part + 8;
+    uint32_t *wtot = part + 8;                       // per wave: nucleotide totals of its 64 plane dwords {valid | G << 16, C | T << 16}
+    uint32_t *wbase = wtot + 8;                      // the same summed over the waves before (entries 0..4, twice)
+    uint32_t *hitmap = wbase + 16;                   // a bit per tile position that holds a match
+    uint32_t *cumVG = hitmap + 128;                  // per plane dword: counts of the dwords before it in its wave
+    uint32_t *cumCT = cumVG + kWideCumWords;
+    uint32_t *codes2 = cumCT + kWideCumWords;
     uint32_t *inval = codes2 + kWideCodeWords;
-    unsigned char *pfl = (unsigned char *)(inval + kWideInvalWords);
+    uint32_t *valid2 = inval + kWideInvalWords;      // the low bit of each base's pair set: valid (the 2-bit plane's layout)
+    unsigned short *lists = (unsigned short *)(valid2 + kWideCodeWords);   // per wave: its candidate positions (of 1024), ascending
+    unsigned char *pfl = (unsigned char *)(lists + 4u * 1024u);
     if (blockIdx.x >= ntiles) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool in_lds = lds_pat != 0u;
@@ -919,39 +954,88 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
     for (uint32_t i = tid; i < 4096u; i += 256u) pre6[i] = (P)0;
     if (tid < 64u) lens[tid] = tid < W.nlen ? W.len[tid] : 0xFFFFFFFFu;
     if (tid <= W.nlen && tid < 68u) first[tid] = W.first[tid];
-    const TsGeneralTile T = tiles[blockIdx.x];
-    // 1. stage: bases [0, avail) of the tile, avail <= kTile + 64; positions beyond avail are invalid
-    const uint32_t avail = T.avail;
-    const unsigned char *src = in + T.in_off;
-    for (uint32_t i = tid * 16u; i < kWideCodeWords * 16u; i += 256u * 16u) {
+    if (tid == 0u) { cumVG[256] = 0u; cumCT[256] = 0u; }
+    // nucleotide counts of the tile positions [0, q), q <= 4096: {valid | G << 16, C | T << 16}
+    auto prefix_counts = [&](uint32_t q, uint32_t &VG, uint32_t &CT) {
+        const uint32_t d = q >> 4, m = (1u << (2u * (q & 15u))) - 1u;
+        const uint32_t v = valid2[d] & m & 0x55555555u, w = codes2[d], lo = w & v, hi = (w >> 1) & v;
+        const uint32_t g = (uint32_t)__popc(lo & hi);
+        VG = cumVG[d] + wbase[d >> 6] + ((uint32_t)__popc(v) | (g << 16));
+        CT = cumCT[d] + wbase[8u + (d >> 6)] + (((uint32_t)__popc(lo) - g) | (((uint32_t)__popc(hi) - g) << 16));
+    };
+    bool tables_built = false;
+    const uint32_t fold_mask = Q.fold ? 0xDFDFDFDFu : 0xFFFFFFFFu;
+    // sixteen bases of a tile (the layout keeps 64 readable bytes behind the last region; regions start on 16-byte boundaries and
+    // tiles at multiples of 4096 inside them — a misaligned tile is read byte by byte)
+    auto load16 = [&](const TsGeneralTile &X, uint32_t i) -> uint4 {
+        if (i >= X.avail) return make_uint4(0u, 0u, 0u, 0u);
+        const unsigned char *p = in + X.in_off + i;
+        if (((uintptr_t)p & 15u) == 0u) return *(const uint4 *)p;
+        uint32_t d[4];
+        for (uint32_t q = 0; q < 4u; ++q) {
+            uint32_t x = 0;
+            for (uint32_t r = 0; r < 4u; ++r) x |= (i + 4u * q + r < X.avail ? (uint32_t)p[4u * q + r] : 0u) << (8u * r);
+            d[q] = x;
+        }
+        return make_uint4(d[0], d[1], d[2], d[3]);
+    };
+    // plane dword i / 16 from sixteen bases (ASCII & 6 = twice the code: A 0, C 2, T 4, G 6, and the v_perm selector of the letter
+    // that code stands for; a byte that is not that letter, up to case folding, is invalid)
+    auto stage16 = [&](const uint4 v, uint32_t i, uint32_t avail, bool counts) {
         uint32_t cw = 0, iv = 0xFFFFu;
         if (i < avail) {
-            uint32_t d[4];
-            if (((uintptr_t)(src + i) & 15u) == 0u && i + 16u <= avail) {
-                const uint4 v = *(const uint4 *)(src + i);
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            } else {
-                for (uint32_t q = 0; q < 4u; ++q) {
-                    uint32_t x = 0;
-                    for (uint32_t r = 0; r < 4u; ++r) x |= (i + 4u * q + r < avail ? (uint32_t)src[i + 4u * q + r] : 0u) << (8u * r);
-                    d[q] = x;
-                }
-            }
-            iv = 0;
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            uint32_t t[4], b4[4];
 #pragma unroll
-            for (uint32_t q = 0; q < 16u; ++q) {
-                uint32_t c = (d[q >> 2] >> (8u * (q & 3u))) & 0xFFu;
-                if (Q.fold) c &= 0xDFu;
-                const uint32_t code = (c >> 1) & 3u;                               // A 0, C 1, T 2, G 3
-                cw |= code << (2u * q);
-                iv |= (c != ((0x47544341u >> (8u * code)) & 0xFFu) ? 1u : 0u) << q; // 'A' 'C' 'T' 'G' by code
+            for (uint32_t q = 0; q < 4u; ++q) {
+                t[q] = d[q] & 0x06060606u;
+                const uint32_t e = __builtin_amdgcn_perm(0xFF47FF54u, 0xFF43FF41u, t[q]);
+                const uint32_t dd = (d[q] & fold_mask) ^ e;
+                const uint32_t nz = ((((dd & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | dd) & 0x80808080u) >> 7;
+                b4[q] = __builtin_amdgcn_udot4(nz, 0x08040201u, 0u, false);
             }
+            cw = pack16(t);
+            iv = b4[0] | (b4[1] << 4) | (b4[2] << 8) | (b4[3] << 12);
+            if (i + 16u > avail) iv = (iv | (~0u << (avail - i))) & 0xFFFFu;       // bases behind the region's end
         }
         codes2[i >> 4] = cw;
         ((unsigned short *)inval)[i >> 4] = (unsigned short)iv;
+        uint32_t ok = ~iv & 0xFFFFu;
+        ok = (ok | (ok << 8)) & 0x00FF00FFu; ok = (ok | (ok << 4)) & 0x0F0F0F0Fu;
+        ok = (ok | (ok << 2)) & 0x33333333u; ok = (ok | (ok << 1)) & 0x55555555u;
+        valid2[i >> 4] = ok;                            // (the low bit of each base's pair)
+        if (counts) {                                   // (plane dword tid; every thread is here)
+            const uint32_t lo1 = cw & ok, hi1 = (cw >> 1) & ok, g = (uint32_t)__popc(lo1 & hi1);
+            const uint32_t vg = (uint32_t)__popc(ok) | (g << 16);
+            const uint32_t ct = ((uint32_t)__popc(lo1) - g) | (((uint32_t)__popc(hi1) - g) << 16);
+            const uint32_t ivg = wave_inclusive_dpp(vg), ict = wave_inclusive_dpp(ct);
+            cumVG[tid] = ivg - vg; cumCT[tid] = ict - ct;
+            if (lane == 63u) { wtot[wave] = ivg; wtot[4u + wave] = ict; }
+        }
+    };
+    TsGeneralTile T = tiles[blockIdx.x];
+    uint4 v_main = load16(T, tid * 16u), v_halo = tid < kWideCodeWords - 256u ? load16(T, 4096u + tid * 16u) : make_uint4(0u, 0u, 0u, 0u);
+  TsGeneralTile Tn = T;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, T = Tn) {
+    if (tables_built) __syncthreads();               // (the tile before is done with the planes and the masks)
+    // 1. stage: bases [0, avail) of the tile, avail <= kTile + 64; positions beyond avail are invalid
+    const uint32_t avail = T.avail;
+    stage16(v_main, tid * 16u, avail, true);
+    if (tid < kWideCodeWords - 256u) stage16(v_halo, 4096u + tid * 16u, avail, false);
+    // the next tile's bases are on their way while this one is worked on
+    if (tile + gridDim.x < ntiles) {
+        Tn = tiles[tile + gridDim.x];
+        v_main = load16(Tn, tid * 16u);
+        if (tid < kWideCodeWords - 256u) v_halo = load16(Tn, 4096u + tid * 16u);
     }
     __syncthreads();
-    // the prefix table: every pattern's first min(l, 6) bases under every extension to six
+    if (tid < 5u) {                                  // sums over the waves before (entry 4: the whole tile)
+        uint32_t a = 0, b = 0;
+        for (uint32_t v = 0; v < tid; ++v) { a += wtot[v]; b += wtot[4u + v]; }
+        wbase[tid] = a; wbase[8u + tid] = b;
+    }
+    // the prefix table: every pattern's first min(l, 6) bases under every extension to six (once per workgroup)
+    if (!tables_built)
     for (uint32_t li = 0; li < W.nlen; ++li) {
         const uint32_t l = lens[li], q = l < 6u ? l : 6u, ext_bits = 2u * (6u - q);
         const uint32_t f0 = first[li], cnt = first[li + 1u] - f0;
@@ -960,14 +1044,42 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
             if (in_lds) code_lo = plo[f0 + (x >> ext_bits)]; else code_lo = W.lo[f0 + (x >> ext_bits)];        // (not a ternary: that is a flat read)
             const uint32_t pre = (uint32_t)code_lo & ((1u << (2u * q)) - 1u);
             const uint32_t idx = pre | ((x & ((1u << ext_bits) - 1u)) << (2u * q));
-            atomicOr(&pre6[idx], (P)((P)1 << li));
+            if constexpr (sizeof(P) == 2) atomicOr((uint32_t *)pre6 + (idx >> 1), (1u << li) << (16u * (idx & 1u)));   // (LDS atomics are 32 bits wide)
+            else atomicOr(&pre6[idx], (P)((P)1 << li));
         }
     }
+    tables_built = true;
     __syncthreads();
-    // 2. matches
-    for (uint32_t j = tid; j < kTile; j += 256u) {
-        u64 h = 0, f = 0, c = 0;
-        if (j < T.n && !(Q.abl & 128u)) {
+    // 2. matches.  Round 5: candidates first — a position whose next six bases begin no pattern (pre6: ninety-nine in a hundred on
+    // random sequence) is settled by one table lookup; a lane looks up its sixteen consecutive positions and the wave lists the
+    // few that remain, in position order.  The 128-bit codes, the reach to the next non-ACGT base and the searches are then done
+    // with a LANE PER LISTED POSITION (round 4 did all of it for every position, a lane in sixty-four doing useful work).
+    unsigned short *const list = lists + wave * 1024u;
+    uint32_t ncand = 0;
+    for (uint32_t i = tid; i < kTile * (uint32_t)sizeof(M) / 16u; i += 256u) ((uint4 *)hit)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 128u) hitmap[tid] = 0u;
+    if (!(Q.abl & 128u)) {
+        const uint32_t wd0 = wave * 64u + lane, j0 = wd0 * 16u;
+        const uint32_t c0 = codes2[wd0], c1 = codes2[wd0 + 1u];
+        uint32_t mask16 = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) {
+            const uint32_t idx = (i <= 10u ? (c0 >> (2u * i)) : __builtin_amdgcn_alignbit(c1, c0, 2u * i)) & 0xFFFu;
+            mask16 |= (pre6[idx] != (P)0 ? 1u : 0u) << i;
+        }
+        if (j0 + 16u > T.n) mask16 &= j0 < T.n ? (1u << (T.n - j0)) - 1u : 0u;     // positions behind the tile's last
+        const uint32_t cnt = (uint32_t)__popc(mask16);
+        const uint32_t incl = wave_inclusive_dpp(cnt);
+        ncand = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t at = incl - cnt;
+        for (uint32_t m = mask16; m; m &= m - 1u) list[at++] = (unsigned short)(lane * 16u + (uint32_t)__builtin_ctz(m));
+    }
+    __syncthreads();                                   // (the masks are zero; a wave reads its own list only)
+    for (uint32_t e0 = 0; e0 < ncand; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        if (e < ncand) {
+            const uint32_t j = wave * 1024u + list[e];
+            u64 h = 0, f = 0, c = 0;
             const uint32_t wd = j >> 4, sh = 2u * (j & 15u);
             const uint32_t c0 = codes2[wd], c1 = codes2[wd + 1u], c2 = codes2[wd + 2u], c3 = codes2[wd + 3u], c4 = codes2[wd + 4u];
             const u64 lo = (u64)__funnelshift_r(c0, c1, sh) | ((u64)__funnelshift_r(c1, c2, sh) << 32);
@@ -1002,8 +1114,11 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
                 }
             };
             if (in_lds) search(plo, phi, pfl); else search(W.lo, W.hi, W.flags);
+            if (h) {
+                hit[j] = (M)h; fwdm[j] = (M)f; canm[j] = (M)c;
+                atomicOr(&hitmap[j >> 5], 1u << (j & 31u));
+            }
         }
-        hit[j] = (M)h; fwdm[j] = (M)f; canm[j] = (M)c;
     }
     __syncthreads();
     const u64 n = seg_len[T.seg];
@@ -1020,10 +1135,9 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
         uint32_t *const wrec = win_out + seg_win_base[T.seg] * 8ull;
         for (u64 R = kw_lo + wave; R <= rec_hi; R += 4u) {
             WideAcc a = {0, 0, 0, 0, 0};
-            window_tile_part_wide(codes2, inval, hit, fwdm, canm, lens, Q, n, R, false, P0, T.n, lane, a);
-            if (carries && R > 0u) window_tile_part_wide(codes2, inval, hit, fwdm, canm, lens, Q, n, R - 1u, true, P0, T.n, lane, a);
-            const uint32_t tAT = wave_total((a.nuc & 0xFFu) | ((a.nuc >> 16) & 0xFFu) << 16);        // A | T << 16
-            const uint32_t tCG = wave_total(((a.nuc >> 8) & 0xFFu) | ((a.nuc >> 24) & 0xFFu) << 16);  // C | G << 16
+            uint32_t tAT = 0, tCG = 0;                                       // A | T << 16, C | G << 16 (wave-uniform)
+            window_tile_part_wide(hitmap, hit, fwdm, canm, lens, Q, n, R, false, P0, T.n, lane, a, prefix_counts, tAT, tCG);
+            if (carries && R > 0u) window_tile_part_wide(hitmap, hit, fwdm, canm, lens, Q, n, R - 1u, true, P0, T.n, lane, a, prefix_counts, tAT, tCG);
             const uint32_t tcan = wave_total(a.can), tnon = wave_total(a.non), tfwd = wave_total(a.fwd), trev = wave_total(a.rev);
             const uint32_t mine = lane == 0u ? (tAT & 0xFFFFu) : lane == 1u ? (tCG & 0xFFFFu) : lane == 2u ? (tCG >> 16) : lane == 3u ? (tAT >> 16)
                                 : lane == 4u ? tcan : lane == 5u ? tnon : lane == 6u ? tfwd : trev;
@@ -1037,18 +1151,23 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
         }
     }
     __syncthreads();                                   // (the masks are rewritten below)
-    // 4. match records: the matches the reference pushes, position then length order; wave v owns positions [1024 v, 1024 v + 1024)
+    // 4. match records: the matches the reference pushes, position then length order; wave v owns positions [1024 v, 1024 v + 1024).
+    // A lane per LISTED position (the list is in position order): round 4 walked all 4096 positions twice, and the push test — 64-bit
+    // divisions — ran under divergence for every group of 64 positions that held a match.
     const PushGeom pg = push_geom(P0, n, Q);
     uint32_t wave_cnt = 0;
-    for (uint32_t r = 0; r < 16u; ++r) {
-        const uint32_t j = wave * 1024u + r * 64u + lane;
+    for (uint32_t e0 = 0; e0 < ncand; e0 += 64u) {
+        const uint32_t e = e0 + lane;
         u64 keep = 0;
-        for (u64 m = hit[j]; m; m &= m - 1ull) {
-            const uint32_t li = (uint32_t)__builtin_ctzll(m);
-            u64 unused_rec;
-            if (tips || full_scan_pushes(j, lens[li], pg, &unused_rec)) keep |= 1ull << li;
+        if (e < ncand) {
+            const uint32_t j = wave * 1024u + list[e];
+            for (u64 m = hit[j]; m; m &= m - 1ull) {
+                const uint32_t li = (uint32_t)__builtin_ctzll(m);
+                u64 unused_rec;
+                if (tips || full_scan_pushes(j, lens[li], pg, &unused_rec)) keep |= 1ull << li;
+            }
+            hit[j] = (M)keep;
         }
-        hit[j] = (M)keep;
         wave_cnt += (uint32_t)__popcll(keep);
     }
     wave_cnt = wave_total(wave_cnt);
@@ -1057,14 +1176,15 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
     uint32_t base = 0, total = 0;
     for (uint32_t v = 0; v < 4u; ++v) { if (v < wave) base += part[v]; total += part[v]; }
     if (tid == 0u) {
-        *(uint4 *)&tile_stats[4ull * blockIdx.x] = make_uint4(total, 0u, 0u, 0u);
+        *(uint4 *)&tile_stats[4ull * tile] = make_uint4(total, 0u, 0u, 0u);
         if (total > slot_cap) atomicOr(overflow, 1u);
     }
-    if (total > slot_cap || wave_cnt == 0u) return;
-    uint32_t *dst = records + (u64)blockIdx.x * slot_cap;
-    for (uint32_t r = 0; r < 16u; ++r) {
-        const uint32_t j = wave * 1024u + r * 64u + lane;
-        const u64 keep = hit[j];
+    if (total > slot_cap || wave_cnt == 0u) continue;
+    uint32_t *dst = records + (u64)tile * slot_cap;
+    for (uint32_t e0 = 0; e0 < ncand; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        const uint32_t j = e < ncand ? wave * 1024u + list[e] : 0u;
+        const u64 keep = e < ncand ? (u64)hit[j] : 0ull;
         if (__builtin_amdgcn_ballot_w64(keep != 0ull) == 0ull) continue;
         const uint32_t c = (uint32_t)__popcll(keep);
         const uint32_t incl = wave_inclusive(c, lane);
@@ -1076,6 +1196,7 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
         }
         base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
+  }
 }
 
 // One wave per tile: its records from its slot to their place in the dense, tile-ordered stream.
@@ -1328,7 +1449,8 @@ int ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tiles
                              const TsWidePatterns *W, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
                              uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, void *stream) {
     if (ntiles == 0) return 0;
-    const size_t fixed = 64u * 4u + 68u * 4u + 32u + kWideCodeWords * 4u + kWideInvalWords * 4u;
+    const size_t fixed = 64u * 4u + 68u * 4u + 32u + 32u + 64u + 128u * 4u + 2u * kWideCumWords * 4u + 2u * kWideCodeWords * 4u + kWideInvalWords * 4u + 4u * 1024u * 2u;
+    static const int cus = [] { int v = 0, dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
     auto launch = [&](auto kernel, size_t mask_bytes, size_t pre_bytes) -> hipError_t {
         const size_t tables = 3u * (size_t)kTile * mask_bytes + 4096u * pre_bytes + fixed;
         // the pattern lists in LDS (17 bytes per pattern) when they fit beside the tables
@@ -1337,12 +1459,15 @@ int ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tiles
         const size_t lds = tables + (size_t)lds_pat * 16u + ((lds_pat + 15u) & ~15u);
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (up to 160 KB: above the default limit)
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(ntiles), dim3(256), lds, (hipStream_t)stream, in, tiles, ntiles,
+        // persistent workgroups: as many as fit beside each other (LDS), each takes the tiles blockIdx.x, + gridDim.x, ...
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / std::max<size_t>(lds, 1)));
+        const uint32_t grid = (uint32_t)std::min<size_t>(ntiles, (size_t)cus * per_cu);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, in, tiles, ntiles,
                            (const u64 *)seg_len, (const u64 *)seg_win_base, *W, *Q, tips, slot_cap, lds_pat, tile_stats, records, win_out, overflow);
         return hipSuccess;
     };
     hipError_t e;
-    if (W->nlen <= 16u) e = launch(ts_general_wide<uint16_t, uint32_t>, 2, 4);
+    if (W->nlen <= 16u) e = launch(ts_general_wide<uint16_t, uint16_t>, 2, 2);
     else if (W->nlen <= 32u) e = launch(ts_general_wide<uint32_t, uint32_t>, 4, 4);
     else e = launch(ts_general_wide<u64, u64>, 8, 8);
     if (e != hipSuccess) return (int)e;
