@@ -985,7 +985,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
     // block calling; smaller groups, because a tile's slot may have to grow to a record per position AND length
     const bool wide = c->gen_wide;
     const uint32_t rec_shift = wide ? 8u : 5u, rec_li_mask = wide ? 63u : 7u;
-    const uint64_t target = wide ? std::min<uint64_t>(group_target_bytes(), 256ull << 20) : group_target_bytes();   // (16 - 64 KB of slot per tile: 4 - 17 GB per group)
+    static const uint64_t wide_cap = []() -> uint64_t { if (const char *e = getenv("TS_WIDE_GROUP_MB")) { const long mb = atol(e); if (mb > 0) return (uint64_t)mb << 20; } return 256ull << 20; }();
+    const uint64_t target = wide ? std::min<uint64_t>(group_target_bytes(), wide_cap) : group_target_bytes();   // (16 - 64 KB of slot per tile: 4 - 17 GB per group)
     int slot = 0;
     bool used[ts_ctx::kUpSlots] = {false, false, false};
     size_t wi = 0;
