@@ -55,9 +55,11 @@ __device__ __forceinline__ uint32_t rec_norm(const TsBlockCallParams &Q, uint32_
     if (MODE == 1 && Q.wide) return ((raw >> 8) << 2) | ((raw & 1u) << 1) | ((raw >> 1) & 1u);
     return Q.gen_lens ? ((raw >> 5) << 2) | ((raw & 1u) << 1) | ((raw >> 1) & 1u) : raw;
 }
+// (wide: lane i of the wave holds the length of index i — wlen_lane, loaded once per wave — and a record's length is a shuffle,
+// not a load behind the load of the record: the walks are chains of latencies; call it from uniform control flow)
 template <int MODE>
-__device__ __forceinline__ uint32_t rec_len(const TsBlockCallParams &Q, uint32_t raw) {
-    if (MODE == 1 && Q.wide) return Q.wide_len[(raw >> 2) & 63u];
+__device__ __forceinline__ uint32_t rec_len(const TsBlockCallParams &Q, uint32_t raw, uint32_t wlen_lane) {
+    if (MODE == 1 && Q.wide) return (uint32_t)__shfl((int)wlen_lane, (int)((raw >> 2) & 63u));
     return Q.gen_lens ? (uint32_t)(Q.gen_lens >> (6u * ((raw >> 2) & 7u))) & 63u : Q.k;
 }
 // sum of v over the lanes of `mask` (wave-uniform result)
@@ -136,6 +138,7 @@ template <int MODE>
 __device__ __forceinline__ u64 terminal_direction(const TsBlockCallParams &Q, const SegView &V, uint32_t seg, u64 n, u64 abs_pos,
                                   bool from_start, uint32_t &seq, uint32_t lane, bool &out_of_context) {
     u64 boundary = from_start ? 0 : n;                     // segment-relative
+    const uint32_t wlen_lane = (MODE == 1 && Q.wide) ? Q.wide_len[lane] : 0u;     // (the table holds 64 entries)
     Chain ch; bool open = false;
     ch.start = ch.end = ch.prev = 0; ch.counts = ch.fwd = ch.canon = ch.cov = ch.fwd_cov = ch.can_cov = 0;
     TsDevBlock cur; bool have_cur = false;
@@ -211,7 +214,7 @@ __device__ __forceinline__ u64 terminal_direction(const TsBlockCallParams &Q, co
             const uint32_t b0 = b4 + 64u * q;
             if (b0 >= cnt || stop) break;
             const uint32_t nb = cnt - b0 < 64u ? cnt - b0 : 64u;
-            const uint32_t lenv = rec_len<MODE>(Q, recs[q]);       // this lane's match length (Q.k for the tiled kernel's records)
+            const uint32_t lenv = rec_len<MODE>(Q, recs[q], wlen_lane);       // this lane's match length (Q.k for the tiled kernel's records)
             const uint32_t rec = rec_norm<MODE>(Q, recs[q]);
             const bool uni = Q.gen_lens == 0ull;             // uniform length: covered bases = records x k
             const bool sel = lane < nb && (((rec >> 1) & 1u) != 0u) == from_start;      // forward list from the start, reverse from the end
@@ -477,6 +480,7 @@ __device__ __forceinline__ u64 low_bits(uint32_t n) { return n >= 64u ? ~0ull : 
 template <int MODE>
 __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const TsShardSegIn &S, uint32_t t0, uint32_t i0, u64 rb) {
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wlen_lane = (MODE == 1 && Q.wide) ? Q.wide_len[lane] : 0u;
     u64 start = 0, prev = 0;
     uint32_t counts = 0, fwd = 0, canon = 0;
     uint32_t last_len = Q.k, cov = 0, fwd_cov = 0, can_cov = 0;       // (general records: length of the chain's last record, covered bases)
@@ -491,7 +495,7 @@ __device__ __forceinline__ void its_evaluate(const TsBlockCallParams &Q, const T
             const uint32_t nvalid = cnt - b0 < 64u ? cnt - b0 : 64u;
             const u64 VALID = low_bits(nvalid);
             const uint32_t raw = lane < nvalid ? rec_at(Q, Q.matches, src + b0 + lane) : 0u;
-            const uint32_t r = rec_norm<MODE>(Q, raw), lenv = rec_len<MODE>(Q, raw);
+            const uint32_t r = rec_norm<MODE>(Q, raw), lenv = rec_len<MODE>(Q, raw, wlen_lane);
             const uint32_t p32 = r >> 2;
             const uint32_t below = lane_below(p32);
             // records that end the chain: out of range, or too far behind their predecessor (lane 0: the last record of the

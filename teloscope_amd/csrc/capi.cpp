@@ -668,7 +668,8 @@ static ts_ctx *create_impl(const ts_params *params, const ts_pattern *patterns, 
             if (acgt && plan_only) {
                 c->generic_ok = true; c->gen_wide = true; c->wide_lens = lens;
             } else if (acgt && c->d_wlo.ensure(lo.size() * 8 + 16) == hipSuccess && c->d_whi.ensure(hi.size() * 8 + 16) == hipSuccess &&
-                       c->d_wflags.ensure(wflags.size() + 16) == hipSuccess && c->d_wlen.ensure(lens.size() * 4 + 16) == hipSuccess &&
+                       c->d_wflags.ensure(wflags.size() + 16) == hipSuccess && c->d_wlen.ensure(std::max<size_t>(lens.size(), 64) * 4 + 16) == hipSuccess &&       // (read as a table of 64: blockcall.hip)
+                       hipMemset(c->d_wlen.p, 0, std::max<size_t>(lens.size(), 64) * 4) == hipSuccess &&
                        c->d_wfirst.ensure(first.size() * 4 + 16) == hipSuccess &&
                        hipMemcpy(c->d_wlo.p, lo.data(), lo.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
                        hipMemcpy(c->d_whi.p, hi.data(), hi.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&

@@ -14,11 +14,12 @@
 //                       tiles whose candidate lists spill).
 //   ts_general_wide     the WIDE form: what the two above do not take — up to 63 lengths of up to 63 bases (128-bit codes, a
 //                       mask of matched lengths per position).
-//   ts_general_compact  the tiles' slots into one dense tile-ordered stream (after a prefix sum over the counts).
+//   ts_general_compact  the tiles' slots into one dense tile-ordered stream (after a prefix sum over the counts);
+//   ts_general_compact_push  the same with the records in the reference's push order (mixed lengths under w > s).
 //
 // Traffic: 1 B/base in, 32 B/window and 2 x 4 B/match out.  (Rounds 1-2 ran three kernels around a 4 B/base match mask
-// in HBM: ~13 B/base.)  Blocks are called on the device (blockcall.hip) wherever the stream is in the reference's calling
-// order; otherwise the host orders the records by pushing window, expands them and calls blocks.
+// in HBM: ~13 B/base.)  Blocks are called on the device (blockcall.hip) for every set: where the reference's calling
+// order is not position order, ts_general_compact_push writes the dense stream in that order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -1253,7 +1254,9 @@ void ts_general_compact_push(const TsGeneralTile *gtiles, const uint32_t *tile_s
     const uint32_t n = tile_stats[4ull * t];
     const u64 off = tile_off[t];
     const uint32_t *const src = records + (u64)t * slot_cap;
-    const bool has_prev = t > 0u && gtiles[t - 1u].seg == G.seg, has_next = t + 1u < ntiles && gtiles[t + 1u].seg == G.seg;
+    // (neighbours: the tiles before and behind when they continue this one — same segment, adjoining positions)
+    const bool has_prev = t > 0u && gtiles[t - 1u].seg == G.seg && gtiles[t - 1u].seg_rel + gtiles[t - 1u].n == G.seg_rel;
+    const bool has_next = t + 1u < ntiles && gtiles[t + 1u].seg == G.seg && G.seg_rel + G.n == gtiles[t + 1u].seg_rel;
     const uint32_t n_prev = has_prev ? tile_stats[4ull * (t - 1u)] : 0u, n_next = has_next ? tile_stats[4ull * (t + 1u)] : 0u;
     const u64 prev_rel = has_prev ? gtiles[t - 1u].seg_rel : G.seg_rel, next_rel = has_next ? gtiles[t + 1u].seg_rel : 0ull;
     const uint32_t prev_positions = (uint32_t)(G.seg_rel - prev_rel);

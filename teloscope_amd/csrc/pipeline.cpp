@@ -981,8 +981,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
 
     struct RegionL { uint64_t seg_start, len, layout_off; };                   // a scanned region and where it lies in the layout
     struct SegL { size_t idx; uint64_t len, abs_pos, layout_off; std::vector<RegionL> regions; uint64_t first_tile = 0, n_tiles = 0, win_base = 0, n_windows = 0; };
-    // the wide form (sets beyond 8 lengths / 32 bases): its own kernel, a 64-base halo, records with six bits of length index, host
-    // block calling; smaller groups, because a tile's slot may have to grow to a record per position AND length
+    // the wide form (sets beyond 8 lengths / 32 bases): its own kernel, a 64-base halo, records with six bits of length index;
+    // smaller groups, because a tile's slot may have to grow to a record per position AND length
     const bool wide = c->gen_wide;
     const uint32_t rec_shift = wide ? 8u : 5u, rec_li_mask = wide ? 63u : 7u;
     static const uint64_t wide_cap = []() -> uint64_t { if (const char *e = getenv("TS_WIDE_GROUP_MB")) { const long mb = atol(e); if (mb > 0) return (uint64_t)mb << 20; } return 256ull << 20; }();
