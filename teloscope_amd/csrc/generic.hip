@@ -850,6 +850,7 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
 constexpr uint32_t kWideCodeWords = (kTile + TS_WIDE_HALO) / 16u + 6u;     // 2-bit plane, dwords (five are read per position)
 constexpr uint32_t kWideInvalWords = (kTile + TS_WIDE_HALO) / 32u + 4u;    // validity plane (three are read per position)
 constexpr uint32_t kWideCumWords = 260;                                     // per-dword nucleotide prefix sums (256 + the end sentinel)
+constexpr uint32_t kWideWacc = 64;                                          // window records a tile may add to with a lane per record (more: a wave per record part)
 
 struct WideAcc { uint32_t nuc, can, non, fwd, rev; };
 
@@ -858,7 +859,7 @@ struct WideAcc { uint32_t nuc, can, non, fwd, rev; };
 // Round 5: the positions that hold a match come from a bitmap of the tile (a lane takes 32 positions and visits the set bits:
 // one position in eighty holds a match on random sequence), and the nucleotide counts are two lookups in per-dword prefix sums —
 // the round-4 loop visited every position of every window part, three to four times per base, and was half the kernel.
-template <typename M, typename PC>
+template <typename M, typename PC, bool NUC_ONLY = false>
 __device__ __forceinline__ void window_tile_part_wide(const uint32_t *hitmap, const M *hit, const M *fwdm, const M *canm,
                                                       const uint32_t *lens, const TsGenericGeom &Q, u64 n, u64 kw, bool carry,
                                                       u64 P0, uint32_t ntile, uint32_t lane, WideAcc &a, PC prefix_counts,
@@ -894,6 +895,7 @@ __device__ __forceinline__ void window_tile_part_wide(const uint32_t *hitmap, co
             nCG += C_ | (G_ << 16);
         }
     }
+    if (NUC_ONLY) return;                            // (a lane per record: the matches' share is added up per match)
     for (uint32_t wd = (qlo >> 5) + lane; wd <= ((qhi - 1u) >> 5); wd += 64u) {
         uint32_t bits = hitmap[wd];
         const uint32_t q0 = wd << 5;
@@ -926,7 +928,7 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
                      uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
     extern __shared__ __align__(16) unsigned char lds[];
     // layout: hit M[kTile] | fwd M[kTile] | can M[kTile] | pre6 P[4096] | plo u64[lds_pat] | phi u64[lds_pat] | lens u32[64] | first u32[68] |
-    //         part u32[8] | wtot u32[8] | wbase u32[16] | hitmap u32[128] | cumVG u32[260] | cumCT u32[260] | codes2 | inval | valid2 | lists u16[4][1024] | pfl u8[lds_pat]
+    //         part u32[8] | wtot u32[8] | wbase u32[16] | hitmap u32[128] | cumVG u32[260] | cumCT u32[260] | codes2 | inval | valid2 | lists u16[4][1024] | wacc u32[64][4] | pfl u8[lds_pat]
     //         (lds_pat: the pattern lists in LDS when they fit — a search step is then an LDS read; out of device memory the searches of the
     //         few lanes that hold a candidate were 80 % of the kernel's time)
     M *hit = (M *)lds;
@@ -947,7 +949,8 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
     uint32_t *inval = codes2 + kWideCodeWords;
     uint32_t *valid2 = inval + kWideInvalWords;      // the low bit of each base's pair set: valid (the 2-bit plane's layout)
     unsigned short *lists = (unsigned short *)(valid2 + kWideCodeWords);   // per wave: its candidate positions (of 1024), ascending
-    unsigned char *pfl = (unsigned char *)(lists + 4u * 1024u);
+    uint32_t *wacc = (uint32_t *)(lists + 4u * 1024u);                     // [kWideWacc][4]: canonical, non-canonical, forward, reverse covered, per window record of the tile
+    unsigned char *pfl = (unsigned char *)(wacc + kWideWacc * 4u);
     if (blockIdx.x >= ntiles) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool in_lds = lds_pat != 0u;
@@ -1134,6 +1137,72 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
         u64 rec_hi = kw_hi + (carries ? 1u : 0u);
         if (rec_hi >= nwin) rec_hi = nwin - 1u;
         uint32_t *const wrec = win_out + seg_win_base[T.seg] * 8ull;
+        if (rec_hi - kw_lo < kWideWacc) {
+            // Round 5: a LANE PER MATCH POSITION adds the covered bases to the accumulators of the records the match belongs to
+            // (the windows that hold the position: main part of record kw, carry of record kw + 1 — the conditions are
+            // window_tile_part_wide's, turned round), and a LANE PER RECORD adds the nucleotide counts of its two parts from the
+            // prefix sums and writes it.  (Before: a wave per record part, twenty of them per tile, each with its own geometry.)
+            const uint32_t nrec = (uint32_t)(rec_hi - kw_lo) + 1u;
+            if (tid < kWideWacc) *(uint4 *)&wacc[4u * tid] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+            const uint32_t ov = Q.w - Q.s;
+            const uint32_t t1 = Q.s - Q.longest, t2 = ov - Q.longest;        // uint32 on purpose (src/teloscope.cpp:413-415)
+            const uint32_t si_inner = t1 < t2 ? t1 : t2;
+            for (uint32_t e0 = 0; e0 < ncand; e0 += 64u) {
+                const uint32_t e = e0 + lane;
+                if (e >= ncand) continue;
+                const uint32_t j = wave * 1024u + list[e];
+                const u64 m = hit[j];
+                if (!m) continue;
+                const u64 f = fwdm[j], c = canm[j];
+                const u64 p = P0 + j;
+                const u64 rj = (u64)T.r_p0 + j;                               // p / s with P0 = k_p0 s + r_p0: a 32-bit division
+                const u64 kmax = T.k_p0 + (rj <= 0xFFFFFFFFull ? (u64)((uint32_t)rj / Q.s) : rj / Q.s);
+                const u64 kmin = p >= Q.w ? (p - Q.w) / Q.s + 1u : 0u;        // the first window that holds p
+                for (u64 kw = kmin; kw <= kmax && kw < nwin; ++kw) {
+                    const u64 wstart = kw * Q.s;
+                    const uint32_t i = (uint32_t)(p - wstart);
+                    const uint32_t cws = (uint32_t)((n - wstart) < Q.w ? (n - wstart) : Q.w);
+                    const bool always_main = (ov == 0u || kw == 0u);
+                    const uint32_t start_index = always_main ? 0u : si_inner;
+                    const bool main_i = i >= start_index && i < cws;
+                    const bool carry_i = carries && kw + 1u <= rec_hi && i >= (start_index < Q.s ? Q.s : start_index) && i < cws;
+                    if (!main_i && !carry_i) continue;
+                    uint32_t mc = 0, mn = 0, mf = 0, mr = 0, cc = 0, cn = 0, cf = 0, cr = 0;
+                    for (u64 mm = m; mm; mm &= mm - 1ull) {
+                        const uint32_t li = (uint32_t)__builtin_ctzll(mm);
+                        const uint32_t l = lens[li];
+                        const uint32_t jend = i + l - 1u;
+                        if (jend >= cws) continue;                              // scanLimit: may not cross the window end
+                        const bool isc = (c >> li) & 1ull, isf = (f >> li) & 1ull;
+                        if (main_i && (always_main || jend >= ov)) { if (isc) mc += l; else mn += l; if (isf) mf += l; else mr += l; }
+                        if (carry_i) { if (isc) cc += l; else cn += l; if (isf) cf += l; else cr += l; }
+                    }
+                    uint32_t *const am = &wacc[4u * (uint32_t)(kw - kw_lo)];
+                    if (mc) atomicAdd(am + 0, mc); if (mn) atomicAdd(am + 1, mn); if (mf) atomicAdd(am + 2, mf); if (mr) atomicAdd(am + 3, mr);
+                    if (cc) atomicAdd(am + 4, cc); if (cn) atomicAdd(am + 5, cn); if (cf) atomicAdd(am + 6, cf); if (cr) atomicAdd(am + 7, cr);
+                }
+            }
+            __syncthreads();
+            if (tid < nrec) {
+                const u64 R = kw_lo + tid;
+                WideAcc unused = {0, 0, 0, 0, 0};
+                uint32_t tAT = 0, tCG = 0;                                       // A | T << 16, C | G << 16
+                window_tile_part_wide<M, decltype(prefix_counts), true>(hitmap, hit, fwdm, canm, lens, Q, n, R, false, P0, T.n, lane, unused, prefix_counts, tAT, tCG);
+                if (carries && R > 0u) window_tile_part_wide<M, decltype(prefix_counts), true>(hitmap, hit, fwdm, canm, lens, Q, n, R - 1u, true, P0, T.n, lane, unused, prefix_counts, tAT, tCG);
+                const uint4 acc = *(const uint4 *)&wacc[4u * tid];
+                const uint4 lo4 = make_uint4(tAT & 0xFFFFu, tCG & 0xFFFFu, tCG >> 16, tAT >> 16);      // A, C, G, T
+                const u64 span_lo = R * Q.s;
+                const u64 span_hi = span_lo + Q.w < n ? span_lo + Q.w : n;
+                const bool sole = span_lo >= P0 && span_hi <= P0 + T.n;
+                uint32_t *const out = wrec + R * 8ull;
+                if (sole) { *(uint4 *)out = lo4; *(uint4 *)(out + 4) = acc; }
+                else {
+                    if (lo4.x) atomicAdd(out + 0, lo4.x); if (lo4.y) atomicAdd(out + 1, lo4.y); if (lo4.z) atomicAdd(out + 2, lo4.z); if (lo4.w) atomicAdd(out + 3, lo4.w);
+                    if (acc.x) atomicAdd(out + 4, acc.x); if (acc.y) atomicAdd(out + 5, acc.y); if (acc.z) atomicAdd(out + 6, acc.z); if (acc.w) atomicAdd(out + 7, acc.w);
+                }
+            }
+        } else
         for (u64 R = kw_lo + wave; R <= rec_hi; R += 4u) {
             WideAcc a = {0, 0, 0, 0, 0};
             uint32_t tAT = 0, tCG = 0;                                       // A | T << 16, C | G << 16 (wave-uniform)
@@ -1452,7 +1521,7 @@ int ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tiles
                              const TsWidePatterns *W, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
                              uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, void *stream) {
     if (ntiles == 0) return 0;
-    const size_t fixed = 64u * 4u + 68u * 4u + 32u + 32u + 64u + 128u * 4u + 2u * kWideCumWords * 4u + 2u * kWideCodeWords * 4u + kWideInvalWords * 4u + 4u * 1024u * 2u;
+    const size_t fixed = 64u * 4u + 68u * 4u + 32u + 32u + 64u + 128u * 4u + 2u * kWideCumWords * 4u + 2u * kWideCodeWords * 4u + kWideInvalWords * 4u + 4u * 1024u * 2u + (kWideWacc + 1u) * 16u;
     static const int cus = [] { int v = 0, dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
     auto launch = [&](auto kernel, size_t mask_bytes, size_t pre_bytes) -> hipError_t {
         const size_t tables = 3u * (size_t)kTile * mask_bytes + 4096u * pre_bytes + fixed;
