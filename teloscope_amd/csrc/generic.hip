@@ -924,7 +924,7 @@ __device__ __forceinline__ void window_tile_part_wide(const uint32_t *hitmap, co
 template <typename M, typename P>
 __global__ __launch_bounds__(256)
 void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles, const u64 *seg_len,
-                     const u64 *seg_win_base, const TsWidePatterns W, const TsGenericGeom Q, int tips, uint32_t slot_cap, uint32_t lds_pat,
+                     const u64 *seg_win_base, const u64 *seg_nwin, const TsWidePatterns W, const TsGenericGeom Q, int tips, uint32_t slot_cap, uint32_t lds_pat,
                      uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow) {
     extern __shared__ __align__(16) unsigned char lds[];
     // layout: hit M[kTile] | fwd M[kTile] | can M[kTile] | pre6 P[4096] | plo u64[lds_pat] | phi u64[lds_pat] | lens u32[64] | first u32[68] |
@@ -1129,9 +1129,11 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
     const u64 P0 = T.seg_rel;
     // 3. window records (full scans): as in ts_general_fused
     if (!tips && T.n && !(Q.abl & 256u)) {
-        const u64 nwin = (n + Q.s - 1u) / Q.s;
-        const u64 kw_lo = P0 >= Q.w ? (P0 - Q.w) / Q.s + 1u : 0u;
-        u64 kw_hi = (P0 + T.n - 1u) / Q.s;
+        // (no 64-bit division: the host hands over P0 = k_p0 s + r_p0 per tile, w = cw s + rw per call and the segments' window counts)
+        const u64 nwin = seg_nwin[T.seg];
+        const u64 kw_lo = P0 >= Q.w ? T.k_p0 + 1u - Q.cw - (Q.rw > T.r_p0 ? 1u : 0u) : 0u;     // first call whose window reaches the tile: (P0 - w) / s + 1
+        u64 kw_hi = T.k_p0 + (T.r_p0 + T.n - 1u) / Q.s;                                     // last call that starts inside it (r_p0 < s, n <= 4096: 32 bits unless s is huge)
+        if ((u64)T.r_p0 + T.n - 1u > 0xFFFFFFFFull) kw_hi = T.k_p0 + ((u64)T.r_p0 + T.n - 1u) / Q.s;
         if (kw_hi >= nwin) kw_hi = nwin - 1u;
         const bool carries = Q.w != Q.s;
         u64 rec_hi = kw_hi + (carries ? 1u : 0u);
@@ -1158,7 +1160,9 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
                 const u64 p = P0 + j;
                 const u64 rj = (u64)T.r_p0 + j;                               // p / s with P0 = k_p0 s + r_p0: a 32-bit division
                 const u64 kmax = T.k_p0 + (rj <= 0xFFFFFFFFull ? (u64)((uint32_t)rj / Q.s) : rj / Q.s);
-                const u64 kmin = p >= Q.w ? (p - Q.w) / Q.s + 1u : 0u;        // the first window that holds p
+                // the first window that holds p: (p - w) / s + 1 = k_p0 - cw + floor((r_p0 + j - rw) / s) + 1
+                const long long num = (long long)rj - (long long)Q.rw;
+                const u64 kmin = p >= Q.w ? T.k_p0 - Q.cw + (num < 0 ? 0ull : 1ull + (num <= 0xFFFFFFFFll ? (u64)((uint32_t)num / Q.s) : (u64)num / Q.s)) : 0ull;
                 for (u64 kw = kmin; kw <= kmax && kw < nwin; ++kw) {
                     const u64 wstart = kw * Q.s;
                     const uint32_t i = (uint32_t)(p - wstart);
@@ -1224,7 +1228,27 @@ void ts_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32
     // 4. match records: the matches the reference pushes, position then length order; wave v owns positions [1024 v, 1024 v + 1024).
     // A lane per LISTED position (the list is in position order): round 4 walked all 4096 positions twice, and the push test — 64-bit
     // divisions — ran under divergence for every group of 64 positions that held a match.
-    const PushGeom pg = push_geom(P0, n, Q);
+    PushGeom pg{};                                     // (as the list form derives it: sums and compares of the host's quotients)
+    {
+        const uint32_t ov = Q.w - Q.s;
+        pg.P0 = P0; pg.n = n; pg.s = Q.s; pg.w = Q.w; pg.ov = ov;
+        const uint32_t t1 = Q.s - Q.longest, t2 = ov - Q.longest;        // uint32 on purpose (src/teloscope.cpp:413-415)
+        pg.start_index = t1 < t2 ? t1 : t2;
+        pg.kP0 = T.k_p0; pg.rP0 = T.r_p0;
+        if (ov == 0u) {
+            pg.k0 = T.k_p0; pg.r0 = T.r_p0;
+            pg.N0 = (n - P0) + T.r_p0;                                    // n - k0 s
+        } else if (P0 > ov) {
+            // P0 - ov = (k_p0 - cw + 1) s + (r_p0 - rw)
+            const bool borrow = T.r_p0 < Q.rw;
+            pg.k1 = T.k_p0 + 1u - Q.cw - (borrow ? 1u : 0u);
+            pg.r1 = T.r_p0 - Q.rw + (borrow ? Q.s : 0u);
+            pg.D1 = pg.r1 + ov;                                           // P0 - k1 s
+            pg.dsub = 0u;
+        } else {
+            pg.k1 = 0u; pg.r1 = 0u; pg.D1 = (uint32_t)P0; pg.dsub = (uint32_t)(ov - P0);
+        }
+    }
     uint32_t wave_cnt = 0;
     for (uint32_t e0 = 0; e0 < ncand; e0 += 64u) {
         const uint32_t e = e0 + lane;
@@ -1517,7 +1541,7 @@ int ts_k_launch_general_compact_push(const TsGeneralTile *gtiles, const uint32_t
 }
 
 int ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
-                             const unsigned long long *seg_len, const unsigned long long *seg_win_base,
+                             const unsigned long long *seg_len, const unsigned long long *seg_win_base, const unsigned long long *seg_nwin,
                              const TsWidePatterns *W, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
                              uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, void *stream) {
     if (ntiles == 0) return 0;
@@ -1535,7 +1559,7 @@ int ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tiles
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / std::max<size_t>(lds, 1)));
         const uint32_t grid = (uint32_t)std::min<size_t>(ntiles, (size_t)cus * per_cu);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, in, tiles, ntiles,
-                           (const u64 *)seg_len, (const u64 *)seg_win_base, *W, *Q, tips, slot_cap, lds_pat, tile_stats, records, win_out, overflow);
+                           (const u64 *)seg_len, (const u64 *)seg_win_base, (const u64 *)seg_nwin, *W, *Q, tips, slot_cap, lds_pat, tile_stats, records, win_out, overflow);
         return hipSuccess;
     };
     hipError_t e;

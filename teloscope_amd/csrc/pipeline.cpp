@@ -1156,7 +1156,8 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 if (nwin_total) HIP_TRY(c, hipMemsetAsync(d_win.p, 0, nwin_total * 32, st));
                 if (wide) {
                     if (ts_k_launch_general_wide((const unsigned char *)d_in.p, (const TsGeneralTile *)d_tiles.p, (uint32_t)nt,
-                                                 (const unsigned long long *)(dt + tab_len), (const unsigned long long *)(dt + tab_win), &c->wpat, &Q,
+                                                 (const unsigned long long *)(dt + tab_len), (const unsigned long long *)(dt + tab_win),
+                                                 (const unsigned long long *)(dt + tab_nwin), &c->wpat, &Q,
                                                  tips ? 1 : 0, slot_cap, (uint32_t *)d_stats.p, (uint32_t *)d_slots.p, (uint32_t *)d_win.p,
                                                  (uint32_t *)(dt + tab_flag), st) != 0)
                         return c->fail(TS_ERR_HIP, "general wide kernel launch failed");

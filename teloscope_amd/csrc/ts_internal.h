@@ -316,7 +316,7 @@ uint32_t ts_k_general_list_max_records(void);
 // the wide form of the same pass: any set a ts_pattern[] can express; records are (tile position << 8) | (length index << 2) |
 // canonical << 1 | forward; tiles' avail is clamped to n + TS_WIDE_HALO; *overflow bit 0 as above
 int  ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tiles, uint32_t ntiles,
-                              const unsigned long long *seg_len, const unsigned long long *seg_win_base,
+                              const unsigned long long *seg_len, const unsigned long long *seg_win_base, const unsigned long long *seg_nwin,
                               const TsWidePatterns *W, const TsGenericGeom *Q, int tips, uint32_t slot_cap,
                               uint32_t *tile_stats, uint32_t *records, uint32_t *win_out, uint32_t *overflow, void *stream);
                                // (records: ntiles x slot_cap entries; win_out zeroed by the caller; *overflow raised when a tile
