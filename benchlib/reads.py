@@ -196,7 +196,7 @@ def run_reads(args, rank, local_rank, world, dev, backend):
     xdev = dev if backend == "nccl" else torch.device("cpu")
 
     # resident sub-batches of <= 500 k reads (~7.5 Gb each): input, match stream and pass bytes stay in HBM
-    sub = 500_000
+    sub = int(os.environ.get("TS_BENCH_READ_SUB", "500000"))     # (reads per resident sub-batch)
     batches = []
     for a in range(0, len(lens), sub):
         sl = lens[a:a + sub]
