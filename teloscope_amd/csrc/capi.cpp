@@ -88,6 +88,7 @@ void read_env_knobs(ts_ctx *c) {
     ts_ctx::Knobs k;
     k.timing = getenv("TS_TIMING") != nullptr;
     k.gen_host_blocks = is("TS_GEN_HOST_BLOCKS", '1');
+    k.gen_compact_always = is("TS_GEN_COMPACT", '1');     // (A/B: the dense stream made even where nothing reads it)
     k.gen_prefetch = !is("TS_GEN_PREFETCH", '0');
     k.gen_list = !is("TS_GEN_LIST", '0');
     if (const char *e = getenv("TS_GEN_ABL")) k.gen_abl = (uint32_t)atoi(e);

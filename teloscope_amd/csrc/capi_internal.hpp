@@ -130,7 +130,7 @@ struct ts_ctx {
     // TS_GEN_LIST=0 (general path: the strided form), TS_GEN_ABL (profiling mask of the general kernels)
     // TS_PACKED_UPLOAD=0 (bases cross PCIe as ASCII), TS_PACKED_MIN_BYTES (calls below it go plain), TS_STAGE_THREADS
     struct Knobs {
-        bool timing = false, gen_host_blocks = false, gen_prefetch = true, gen_list = true, packed_upload = true;
+        bool timing = false, gen_host_blocks = false, gen_prefetch = true, gen_list = true, packed_upload = true, gen_compact_always = false;
         uint32_t gen_abl = 0, stage_threads = 0;
         int side_priority = 0;                                // stream priority of the pack's side stream (0: the default priority)
         int scan_events = 2;                                  // events ts_batch_scan records around a scan: 2 both (kernel times), 1 the one behind it, 0 none (measurements)

@@ -1486,14 +1486,15 @@ namespace {
 // the tile directory (words 1 and 2; the fused pass leaves only the count).  One wave per tile over the dense stream.
 __global__ __launch_bounds__(64)
 void ts_general_block_inputs(const TsGeneralTile *gtiles, const u64 *tile_off, const uint32_t *dense, const u64 *seg_base,
-                             uint32_t ntiles, TsTile *tiles, uint32_t *tile_stats) {
+                             uint32_t ntiles, TsTile *tiles, uint32_t *tile_stats, int count_from_offsets) {
     const uint32_t t = blockIdx.x;
     if (t >= ntiles) return;
     const uint32_t lane = threadIdx.x;
     const TsGeneralTile G = gtiles[t];
-    // (the count from the offsets: the push-ordered stream moved a few records across tile borders; tile_off has ntiles + 1 entries)
+    // (count_from_offsets: the push-ordered stream moved a few records across tile borders; tile_off has ntiles + 1 entries.
+    // Otherwise the fused pass's count: the records may lie in the tiles' slots, which are not adjacent)
     const u64 o0 = tile_off[t];
-    const uint32_t n = (uint32_t)(tile_off[t + 1u] - o0);
+    const uint32_t n = count_from_offsets ? (uint32_t)(tile_off[t + 1u] - o0) : tile_stats[4ull * t];
     const uint32_t *src = dense + o0;
     uint32_t ncan = 0, nfwd = 0;
     for (uint32_t i = lane; i < n; i += 64u) {
@@ -1502,7 +1503,7 @@ void ts_general_block_inputs(const TsGeneralTile *gtiles, const u64 *tile_off, c
     }
     ncan = wave_total(ncan); nfwd = wave_total(nfwd);
     if (lane == 0u) {
-        tile_stats[4ull * t] = n;
+        if (count_from_offsets) tile_stats[4ull * t] = n;
         tile_stats[4ull * t + 1u] = ncan;
         tile_stats[4ull * t + 2u] = nfwd;
         TsTile T{};
@@ -1514,10 +1515,28 @@ void ts_general_block_inputs(const TsGeneralTile *gtiles, const u64 *tile_off, c
 }  // namespace
 
 int ts_k_launch_general_block_inputs(const TsGeneralTile *gtiles, const unsigned long long *tile_off, const uint32_t *dense,
-                                     const unsigned long long *seg_base, uint32_t ntiles, TsTile *tiles, uint32_t *tile_stats, void *stream) {
+                                     const unsigned long long *seg_base, uint32_t ntiles, TsTile *tiles, uint32_t *tile_stats,
+                                     int count_from_offsets, void *stream) {
     if (ntiles == 0) return 0;
     hipLaunchKernelGGL(ts_general_block_inputs, dim3(ntiles), dim3(64), 0, (hipStream_t)stream, gtiles, (const u64 *)tile_off, dense,
-                       (const u64 *)seg_base, ntiles, tiles, tile_stats);
+                       (const u64 *)seg_base, ntiles, tiles, tile_stats, count_from_offsets);
+    return (int)hipGetLastError();
+}
+
+namespace {
+// The tile directory of records that stay where the fused pass wrote them: tile t's begin at t * slot_cap.
+__global__ __launch_bounds__(256)
+void ts_general_slot_offsets(u64 *tile_off, uint32_t ntiles, uint32_t slot_cap) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t <= ntiles) tile_off[t] = (u64)t * slot_cap;
+}
+}  // namespace
+
+// Blocks-only calls over a stream in position order need no dense stream: block calling (blockcall.hip) addresses records
+// through the tile directory, so the directory is pointed at the slots and the compaction — every record read and written
+// once more — is not run.
+int ts_k_launch_general_slot_offsets(unsigned long long *tile_off, uint32_t ntiles, uint32_t slot_cap, void *stream) {
+    hipLaunchKernelGGL(ts_general_slot_offsets, dim3(ntiles / 256u + 1u), dim3(256), 0, (hipStream_t)stream, (u64 *)tile_off, ntiles, slot_cap);
     return (int)hipGetLastError();
 }
 

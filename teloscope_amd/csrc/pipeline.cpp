@@ -1198,10 +1198,19 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
         const uint64_t nrec = tile_off[nt];
         const auto t_f = Clock::now();
         t_fused += ms_between(t1, t_f);
-        HIP_TRY(c, c->pool.take(std::max<uint64_t>(nrec, 1) * 4, d_rec));
+        // blocks only, over a stream in position order: block calling reads the records where the fused pass wrote them (it
+        // addresses them through the tile directory), so there is no dense stream to make — every record used to be read and
+        // written once more for nothing
+        const bool in_place = skip_records && !push_compact && !c->knobs.gen_compact_always;
+        if (!in_place) HIP_TRY(c, c->pool.take(std::max<uint64_t>(nrec, 1) * 4, d_rec));
+        const uint32_t *const d_records = in_place ? (const uint32_t *)d_slots.p : (const uint32_t *)d_rec.p;
         {
             std::lock_guard<std::mutex> lk(c->mtx);
             if (timing) HIP_TRY(c, hipEventRecord(c->gen_ev[0], st));
+            if (in_place) {
+                if (ts_k_launch_general_slot_offsets((unsigned long long *)d_off.p, (uint32_t)nt, slot_cap, st) != 0)
+                    return c->fail(TS_ERR_HIP, "slot-offset kernel launch failed");
+            } else
             if (push_compact) {
                 if (ts_k_launch_general_compact_push((const TsGeneralTile *)d_tiles.p, (const uint32_t *)d_stats.p, (unsigned long long *)d_off.p,
                                                      (const uint32_t *)d_slots.p, slot_cap, (uint32_t)nt, (const unsigned long long *)(dt + tab_len),
@@ -1235,11 +1244,12 @@ int scan_group_generic(ts_ctx *c, const ts_segment_in *segs, const std::vector<s
                 X += G[i].len + 64;
             }
             HIP_TRY(c, hipMemcpyAsync(d_sbase.p, sbase.data(), sbase.size() * 8, hipMemcpyHostToDevice, st));
-            if (ts_k_launch_general_block_inputs((const TsGeneralTile *)d_tiles.p, (const unsigned long long *)d_off.p, (const uint32_t *)d_rec.p,
-                                                 (const unsigned long long *)d_sbase.p, (uint32_t)nt, (TsTile *)d_bct.p, (uint32_t *)d_stats.p, st) != 0)
+            if (ts_k_launch_general_block_inputs((const TsGeneralTile *)d_tiles.p, (const unsigned long long *)d_off.p, d_records,
+                                                 (const unsigned long long *)d_sbase.p, (uint32_t)nt, (TsTile *)d_bct.p, (uint32_t *)d_stats.p,
+                                                 push_compact ? 1 : 0, st) != 0)
                 return c->fail(TS_ERR_HIP, "general block-input kernel launch failed");
             int rc = ts_device_block_call_raw(c, (const TsTile *)d_bct.p, (const unsigned long long *)d_off.p, (const uint32_t *)d_stats.p,
-                                              (const uint32_t *)d_rec.p, nrec, segtab, nt, tips, gen_lens, nullptr, nullptr, st, gh->blocks, &gh->sums, 0,
+                                              d_records, nrec, segtab, nt, tips, gen_lens, nullptr, nullptr, st, gh->blocks, &gh->sums, 0,
                                               wide ? c->wpat.len : nullptr, push_compact);
             if (rc != TS_OK) return rc;
             gh->dev_blocks = true;

@@ -326,7 +326,9 @@ int  ts_k_launch_general_wide(const unsigned char *in, const TsGeneralTile *tile
 // after the compaction: what device block calling needs of the group (TsTile per tile with in_off = seg_base[seg] + the tile's
 // segment-relative position; canonical / forward counts into words 1, 2 of the tile directory)
 int  ts_k_launch_general_block_inputs(const TsGeneralTile *gtiles, const unsigned long long *tile_off, const uint32_t *dense,
-                                      const unsigned long long *seg_base, uint32_t ntiles, TsTile *tiles, uint32_t *tile_stats, void *stream);
+                                      const unsigned long long *seg_base, uint32_t ntiles, TsTile *tiles, uint32_t *tile_stats,
+                                      int count_from_offsets, void *stream);
+int  ts_k_launch_general_slot_offsets(unsigned long long *tile_off, uint32_t ntiles, uint32_t slot_cap, void *stream);
 int  ts_k_launch_general_compact_push(const TsGeneralTile *gtiles, const uint32_t *tile_stats, unsigned long long *tile_off,
                                       const uint32_t *records, uint32_t slot_cap, uint32_t ntiles, const unsigned long long *seg_len,
                                       uint32_t w, uint32_t s, uint32_t spread, int wide, unsigned long long gen_lens,
