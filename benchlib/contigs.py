@@ -342,27 +342,34 @@ def pcie_inclusive(L, K, tel, buf, offsets, lens, total):
     # g's kernels.  Reported beside the figures above, never in `value`; TS_BENCH_NO_GENERAL=1 skips it.
     if not os.environ.get("TS_BENCH_NO_GENERAL"):
         from teloscope_amd.cli import parse_cli, user_input
-        gflags = "-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i"
-        gtel = ta.Teloscope(user_input(parse_cli("x.fa " + gflags), device=tel.userInput.device))
-        if not gtel.usesFastPath():
-            res = (K.SegmentOut * n)()
-            cnts = (K.SegmentCounts * n)()
-            best = None
-            for _ in range(3):
-                t0 = time.perf_counter()
-                rc = L.ts_scan_segments_blocks(gtel._ctx.ptr, segs, n, res, cnts)
-                dt = time.perf_counter() - t0
-                if rc != 0:
-                    raise RuntimeError(gtel._ctx.error())
-                nm = int(sum(c.n_matches for c in cnts))
-                nb = int(sum(res[i].n_terminal_blocks + res[i].n_interstitial_blocks for i in range(n)))
-                L.ts_free_segments(res, n)
-                best = dt if best is None else min(best, dt)
-            e2e["general_path_blocks_windows_counts"] = {
-                "flags": gflags, "patterns": len(gtel.userInput.patternInfo), "seconds": round(best, 4),
-                "gbases_per_s": round(total / best / 1e9, 3), "matches": nm, "blocks": nb,
-                "kernels": "generic.hip: ts_general_fused_list + compaction + blockcall.hip (general record format)"}
-        gtel.close()
+        # (the second and third: what round 4 sent to the host's block calling — a stream that is not in position order (lengths 6 and
+        # 14 under w > s), and the wide form (nine lengths: beyond the table forms); the device writes such a stream in the
+        # reference's push order and calls the blocks over it)
+        for key, gflags, what in (
+                ("general_path_blocks_windows_counts", "-p TTAGGG,TTAGG -w 1000 -s 500 -r -g -e -m -i",
+                 "generic.hip: ts_general_fused_list, blockcall.hip over the records in the tiles' slots (stream in position order)"),
+                ("general_path_push_order_blocks_windows_counts", "-p TTAGGG,TTTAGGGTTTAGGG -x 0 -w 1000 -s 500 -r -g -e -m -i",
+                 "generic.hip: ts_general_fused_list + ts_general_compact_push (stream in the reference's push order), blockcall.hip MODE 1"),
+                ("general_path_wide_blocks_windows_counts", "-x 0 -p TTAG,TTAGG,TTAGGG,TTTAGGG,TTTTAGGG,TTAGGGTTA,TTAGGGTTAG,TTAGGGTTAGG,TTAGGGTTAGGG -w 1000 -s 500 -r -g -e -m -i",
+                 "generic.hip: ts_general_wide + ts_general_compact_push, blockcall.hip MODE 1 (wide records)")):
+            gtel = ta.Teloscope(user_input(parse_cli("x.fa " + gflags), device=tel.userInput.device))
+            if not gtel.usesFastPath():
+                res = (K.SegmentOut * n)()
+                cnts = (K.SegmentCounts * n)()
+                best = None
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    rc = L.ts_scan_segments_blocks(gtel._ctx.ptr, segs, n, res, cnts)
+                    dt = time.perf_counter() - t0
+                    if rc != 0:
+                        raise RuntimeError(gtel._ctx.error())
+                    nm = int(sum(c.n_matches for c in cnts))
+                    nb = int(sum(res[i].n_terminal_blocks + res[i].n_interstitial_blocks for i in range(n)))
+                    L.ts_free_segments(res, n)
+                    best = dt if best is None else min(best, dt)
+                e2e[key] = {"flags": gflags, "patterns": len(gtel.userInput.patternInfo), "seconds": round(best, 4),
+                            "gbases_per_s": round(total / best / 1e9, 3), "matches": nm, "blocks": nb, "kernels": what}
+            gtel.close()
     return {"entry_points": "ts_scan_segments_blocks / ts_scan_segments (pageable host buffers in, host results out; "
                             "groups of ~512 MB pipelined through upload / scan / download stages; bases cross PCIe as 2-bit codes + invalid runs, packed by the staging threads and unpacked on the device; best of 3)", "host_buffer": host_pages, "n_ctx": 1, **e2e}
 
