@@ -837,16 +837,25 @@ void ts_general_fused_list(const unsigned char *in, const TsGeneralTile *tiles, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The WIDE form (round 4): pattern sets beyond the two forms above — more than 8 distinct lengths or a pattern longer than 32
-// bases, up to the 63 lengths of up to 63 bases a ts_pattern[] can hold (the reference's trie has no limit of its own,
-// include/teloscope.h:40-57).  The same pass as ts_general_fused, position-strided, with
-//   * 128-bit codes (lo: bases 0..31, hi: 32..62) searched in the sorted lists in device memory, behind a prefix table in LDS:
-//     pre6, a u64 per 6-mer whose bit li says "these bases begin a pattern of length index li";
-//   * per position three u64 masks in LDS — matched lengths, which of them are forward, which canonical — instead of three bits
-//     per length in one dword;
+// The WIDE form (round 4; rebuilt in round 5): pattern sets beyond the two forms above — more than 8 distinct lengths or a pattern
+// longer than 32 bases, up to the 63 lengths of up to 63 bases a ts_pattern[] can hold (the reference's trie has no limit of its
+// own, include/teloscope.h:40-57).
+//   * 128-bit codes (lo: bases 0..31, hi: 32..62) searched in (lo, hi)-sorted lists (in LDS when they fit), behind a prefix table
+//     in LDS: pre6, an entry per 6-mer whose bit li says "these bases begin a pattern of length index li" (16, 32 or 64 bits wide);
+//   * per position three masks in LDS — matched lengths, which of them are forward, which canonical (16, 32 or 64 bits);
 //   * a halo of 64 bases, and records that carry six bits of length index: position << 8 | index << 2 | canonical << 1 | forward.
-// Persistent workgroups (round 5: the tables are built once per workgroup, not once per tile): three / two / one per CU by the
-// width of the masks (42 / 66 / 132 KB of LDS).
+// Persistent workgroups (three / two / one per CU by the width of the masks: 47 / 66 / 132 KB of LDS), the tables built once.  Per tile:
+//   1. stage: plane dwords by v_perm / v_dot4 and per-dword nucleotide prefix sums, as the list form; the next tile's bases are
+//      requested before this one is worked on;
+//   2. candidates: a lane looks pre6 up for its sixteen consecutive positions and the wave lists, in position order, the few
+//      positions whose next six bases begin a pattern; then a LANE PER LISTED POSITION builds the 128-bit code, finds the reach to
+//      the next non-ACGT base and searches the lengths pre6 named (round 4 did all of that for every position);
+//   3. window records: a lane per listed position adds the covered bases of its matches to LDS accumulators of the records they
+//      belong to (main part of record kw, carry of record kw + 1 — analyzeWindow's index arithmetic turned round), then a lane per
+//      record adds the nucleotide counts of its two parts from the prefix sums and writes it; a tile that adds to more than 64
+//      records (tiny steps) keeps round 4's wave per record part, over a bitmap of the match positions;
+//   4. match records: the push test and the record per listed position, in list order (= position, then length).
+// profiles/r05/general_unordered_device_blocks.txt has every step with its time: 41.75 -> 12.78 ms per 3 Gb on a nine-length set.
 constexpr uint32_t kWideCodeWords = (kTile + TS_WIDE_HALO) / 16u + 6u;     // 2-bit plane, dwords (five are read per position)
 constexpr uint32_t kWideInvalWords = (kTile + TS_WIDE_HALO) / 32u + 4u;    // validity plane (three are read per position)
 constexpr uint32_t kWideCumWords = 260;                                     // per-dword nucleotide prefix sums (256 + the end sentinel)
