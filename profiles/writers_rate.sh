@@ -50,4 +50,4 @@ echo "# the reference's default mode (no -r: tips-only scan of the contig ends, 
 for run in 1 2; do
 TS_TIMING=1 /tmp/manifest_cli -f /tmp/writers_rate.fa --out-base /tmp/writers_rate_t -c TTAGGG 2>&1 >/dev/null | grep -E "manifest_cli"
 done
-rm -f /tmp/writers_rate*
+[ -n "$KEEP" ] || rm -f /tmp/writers_rate*
