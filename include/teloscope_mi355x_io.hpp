@@ -1877,6 +1877,16 @@ inline AssemblySummary scanFastaToFiles(Teloscope &teloscope, const std::string 
     std::thread scanner([&] {
         try {
             detail::FastaGroup g;
+            // The library's first call in a process pays for its streams, its kernels' code, the device pool and the pinned staging
+            // (81-115 ms against 12-15 ms for a later group of 256 MB): made here, on a dummy record, while the reader is still
+            // parsing its first group.  TS_MIRROR_WARMUP=0 leaves it out (A/B).
+            if (const char *wu = std::getenv("TS_MIRROR_WARMUP"); !(wu && wu[0] == '0')) {
+                const auto tw = Clock::now();
+                const std::string hdr = "warm-up", seq(size_t(1) << 20, 'A');
+                std::vector<RecordView> one{RecordView{&hdr, seq.data(), seq.size(), nullptr, 0, nullptr}};
+                try { (void)walkRecordViews(teloscope, one, 0, nullptr); } catch (...) {}
+                if (trace) std::fprintf(stderr, "trace warm  %7.1f .. %7.1f\n", ms(t_begin, tw), ms(t_begin, Clock::now()));
+            }
             while (toScan.pop(g)) {
                 const auto t0 = Clock::now();
                 std::vector<RecordView> views;
