@@ -593,8 +593,36 @@ inline bool splitFastqRecords(const char *data, size_t size, std::vector<FastqRe
 }
 }  // namespace detail
 
+namespace detail {
+// The library's first call in a process pays for its streams, its kernels' code, the device pool and the pinned staging (about
+// 75 ms, whatever the size of the call).  The subset tools make it here, on one dummy read and a thread of its own, while their
+// first block of input is still being read and parsed; joined before the first real batch.  TS_MIRROR_WARMUP=0 leaves it out.
+class FilterWarmUp {
+    std::thread th;
+public:
+    explicit FilterWarmUp(ReadTelomereFilter &filter) {
+        const char *wu = std::getenv("TS_MIRROR_WARMUP");
+        if (wu && wu[0] == '0') return;
+        th = std::thread([&filter] {
+            try {
+                const std::string seq(4096, 'A');
+                const char *p = seq.data();
+                uint64_t l = seq.size();
+                uint8_t pass = 0;
+                filter.matchesPointers(&p, &l, 1, &pass);
+            } catch (...) {}
+        });
+    }
+    void join() { if (th.joinable()) th.join(); }
+    ~FilterWarmUp() { join(); }
+    FilterWarmUp(const FilterWarmUp &) = delete;
+    FilterWarmUp &operator=(const FilterWarmUp &) = delete;
+};
+}  // namespace detail
+
 inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &out, ReadTelomereFilter &filter,
                                      size_t readsPerBatch = 1u << 20, size_t bytesPerBatch = 512u << 20) {
+    detail::FilterWarmUp warmUp(filter);
     // The input is read in large blocks into one arena and parsed in place: a batch's sequences are
     // handed to the filter as pointers into the arena and a kept record is echoed as the byte range of
     // its four lines — no per-line copies.
@@ -693,6 +721,7 @@ inline FastqSubsetResult fastqSubset(const std::string &inFile, std::ostream &ou
         if (batch.empty()) return;
         ptr.resize(batch.size()); len.resize(batch.size()); pass.resize(batch.size());
         for (size_t i = 0; i < batch.size(); ++i) { ptr[i] = batch[i].seq; len[i] = batch[i].seqLen; }
+        warmUp.join();
         filter.matchesPointers(ptr.data(), len.data(), batch.size(), pass.data());
         text.clear();
         for (size_t i = 0; i < batch.size(); ++i) {
@@ -1080,6 +1109,7 @@ public:
 inline BamSubsetStats bamSubset(const std::string &inFile, std::ostream &out, ReadTelomereFilter &filter,
                                 size_t readsPerBatch = 1u << 20, size_t bytesPerBatch = 256u << 20) {
     BamSubsetStats stats;
+    detail::FilterWarmUp warmUp(filter);
     int fd = 0;
     if (inFile != "-") {
         fd = ::open(inFile.c_str(), O_RDONLY);
@@ -1205,6 +1235,7 @@ inline BamSubsetStats bamSubset(const std::string &inFile, std::ostream &out, Re
                 if (recs[i].seqLen) { ptr.push_back(seqs.get() + recs[i].seqOff); len.push_back(recs[i].seqLen); }
             pass.assign(ptr.size(), 0);
             const Clock::time_point tf = Clock::now();
+            warmUp.join();
             if (!ptr.empty()) filter.matchesPointers(ptr.data(), len.data(), ptr.size(), pass.data());
             msFilter += std::chrono::duration<double, std::milli>(Clock::now() - tf).count();
             size_t k = 0;
