@@ -724,7 +724,9 @@ def test_push_ordered_streams_match_vectors_match_oracle(cli):
         for at in (4096, 8192, 12288, 36864):                 # arrays across tile borders (4096 positions per tile)
             if n > at + 200:
                 s[at - 150:at + 150] = (b"TTAGGG" * 50)[:300]
-        segs.append((bytes(s), int(rng.integers(0, 10 ** 6)), False))
+        # (absolute positions: the last two segments lie beyond 2^32 — block starts and match positions are 64-bit sums)
+        ap = int(rng.integers(0, 10 ** 6)) + (5_000_000_000 if n >= 40000 else 0)
+        segs.append((bytes(s), ap, False))
     got = prod.scan_segments(segs)
     for (s, ap, tips), g in zip(segs, got):
         assert_segment_equal(g, orac.scan_segment(s, ap, tips), tips, ctx="cli=%r len=%d" % (cli, len(s)))
